@@ -1,0 +1,509 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+CPU fp32 restatement (plain PyTorch, own formulation) of the NUWA video-decoder
+training hot path of lucidrains/nuwa-pytorch.  Only `tests/`, `__graft_entry__.smoke()`
+and `bench.py`'s `cpu_baseline` leg may import this file; `nuwa_pytorch_amd/` never does.
+
+Every function cites the reference file:line it restates (paths relative to the
+reference checkout; np.py = nuwa_pytorch/nuwa_pytorch.py, vq.py = nuwa_pytorch/vqgan_vae.py,
+rev.py = nuwa_pytorch/reversible.py).
+
+Pinning: the reference ships no tests / golden vectors.  The
+restatement is pinned against the reference ITSELF, imported read-only in the build
+container (tests/test_oracle_vs_reference.py; only runs where /root/reference exists) and
+through fixtures generated from that import (tests/golden/*.npz, made by
+tests/golden/make_golden.py).  The one boundary that cannot be pinned is the third-party
+`vector_quantize_pytorch.VectorQuantize` (not vendored, not installed): `vq_eval_lookup`
+below restates its documented eval-path algorithm -- "parity unpinned" at that boundary.
+
+Parameters are passed as a flat dict using the reference's state_dict key names, so a
+reference module's `state_dict()` feeds these functions directly.
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+FP32_NEG_MAX = -torch.finfo(torch.float32).max
+
+
+# --------------------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------------------
+
+def _tup3(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+def sub(P, prefix):
+    """select the sub-dict of P under `prefix.` (prefix stripped)"""
+    pl = prefix + '.'
+    return {k[len(pl):]: v for k, v in P.items() if k.startswith(pl)}
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    """nn.LayerNorm over the last dim (np.py:120-121 prenorm / postnorm)."""
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def stable_layer_norm(x, w, b):
+    """StableLayerNorm np.py:88-95: divide by (detached) row amax, no abs, then LN."""
+    x = x / x.amax(dim=-1, keepdim=True).detach()
+    return layer_norm(x, w, b)
+
+
+# --------------------------------------------------------------------------------------
+# a5  ShiftVideoTokens (np.py:185-253), shift_space=True / shift_time=False only
+# --------------------------------------------------------------------------------------
+
+def shift_video_tokens(x, fmap):
+    """x (b, n, D): row 0 = bos (untouched); row 1+p = token at raster position p of a
+    (f, fmap, fmap) grid.  Channel chunks follow torch.chunk(4) (ceil-sized chunks):
+    chunk0 takes its value from (f, y-1, w) (0 at y==0), chunk1 from (f, y, w-1) (0 at
+    w==0), the rest unchanged.  np.py:227, 234-235."""
+    b, n, D = x.shape
+    if n == 1:
+        return x
+    c = -(-D // 4)  # chunk(4) -> ceil-sized chunks
+    p = torch.arange(n - 1)
+    y = (p // fmap) % fmap
+    w = p % fmap
+    xv = x[:, 1:]
+    out = xv.clone()
+    # chunk 0: from row p - fmap if y > 0 else 0
+    src_h = (p - fmap).clamp(min=0)
+    val_h = xv[:, src_h, 0:c] * (y > 0).to(x.dtype)[None, :, None]
+    out[:, :, 0:c] = val_h
+    # chunk 1: from row p - 1 if w > 0 else 0
+    c1 = min(2 * c, D)
+    if c1 > c:
+        src_w = (p - 1).clamp(min=0)
+        val_w = xv[:, src_w, c:c1] * (w > 0).to(x.dtype)[None, :, None]
+        out[:, :, c:c1] = val_w
+    return torch.cat((x[:, :1], out), dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# a7  neighbour table == what unfoldNd + causal padding computes (np.py:420-457, 507-528)
+# --------------------------------------------------------------------------------------
+
+def neighbor_table(video_shape, kernel_size, dilation, causal=True):
+    """idx (N, K) int64: for query raster position p, tap slot t=(a*kh+b)*kw+c ->
+    key raster position, or -1 when the tap falls in the zero padding (masked).
+    causal: taps reach backwards only (padding all on the low side, np.py:427)
+    non-causal: symmetric 'same' padding (np.py:429)."""
+    Fr, H, W = video_shape
+    kf, kh, kw = _tup3(kernel_size)
+    df, dh, dw = _tup3(dilation)
+    f = torch.arange(Fr)[:, None, None]
+    y = torch.arange(H)[None, :, None]
+    w = torch.arange(W)[None, None, :]
+    cols = []
+    for a in range(kf):
+        for b_ in range(kh):
+            for c in range(kw):
+                if causal:
+                    ff = f - (kf - 1 - a) * df
+                    yy = y - (kh - 1 - b_) * dh
+                    ww = w - (kw - 1 - c) * dw
+                else:
+                    ff = f + (a - (kf - 1) // 2) * df
+                    yy = y + (b_ - (kh - 1) // 2) * dh
+                    ww = w + (c - (kw - 1) // 2) * dw
+                ok = (ff >= 0) & (ff < Fr) & (yy >= 0) & (yy < H) & (ww >= 0) & (ww < W)
+                pos = (ff * H + yy) * W + ww
+                pos = torch.where(ok, pos, torch.full_like(pos, -1))
+                cols.append(pos.reshape(-1))
+    return torch.stack(cols, dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# a6  Sparse3DNA (np.py:381-613), causal
+# --------------------------------------------------------------------------------------
+
+def sparse3dna_core(q, k, v, w_th, idx, scale, rel_pos_bias=None):
+    """The attention core between the projections (np.py:488-608).
+    q, k, v: (b, n, h, d) fp32, unscaled q.  w_th: (h, h) talking-heads weight.
+    idx: (N, K) neighbour table.  Returns o (b, n, h, d).
+    Row 0 is <bos>: its output is v[:,0] (np.py:499, 608)."""
+    b, n, h, d = q.shape
+    if n == 1:
+        return v.clone()
+    nq = n - 1
+    K = idx.shape[1]
+    tab = idx[:nq]                               # (nq, K)
+    valid = tab >= 0
+    gidx = tab.clamp(min=0) + 1                  # row index into k / v (row 0 is bos)
+    qs = q[:, 1:] * scale                        # np.py:494-498
+    kg = k[:, gidx.reshape(-1)].reshape(b, nq, K, h, d)
+    vg = v[:, gidx.reshape(-1)].reshape(b, nq, K, h, d)
+    vmask = valid[None, :, :, None, None].to(q.dtype)
+    kg = kg * vmask                              # padded taps hold zero k / v (np.py:508)
+    vg = vg * vmask
+    kb = k[:, :1, None].expand(b, nq, 1, h, d)   # bos key/value first (np.py:532-534)
+    vb = v[:, :1, None].expand(b, nq, 1, h, d)
+    kk = torch.cat((kb, kg), dim=2)              # (b, nq, J, h, d)
+    vv = torch.cat((vb, vg), dim=2)
+    sim = torch.einsum('bihd,bijhd->bhij', qs, kk)            # np.py:538
+    if rel_pos_bias is not None:                 # (h, K) ; intended per-head broadcast (quirk Q4)
+        sim = sim + F.pad(rel_pos_bias, (1, 0))[None, :, None, :]
+    mask = F.pad(~valid, (1, 0), value=False)    # bos never masked (np.py:456)
+    sim = sim.masked_fill(mask[None, None], FP32_NEG_MAX)     # np.py:548-550
+    attn = sim.softmax(dim=-1, dtype=torch.float32)           # np.py:554
+    attn = torch.einsum('gh,bhij->bgij', w_th, attn)          # talking heads np.py:556-558
+    out = torch.einsum('bgij,bijgd->bigd', attn, vv)          # np.py:564
+    return torch.cat((v[:, :1], out), dim=1)                  # np.py:608
+
+
+def sparse3dna(x, P, video_shape, kernel_size, dilation, heads, idx=None):
+    """Sparse3DNA.forward np.py:459-613.  P keys: to_q.weight, to_kv.weight,
+    talking_heads.weight (h,h,1,1), to_out.weight, to_out.bias [, rel_pos_bias.axial{1,2,3}]."""
+    b, n, D = x.shape
+    inner = P['to_q.weight'].shape[0]
+    d = inner // heads
+    if idx is None:
+        idx = neighbor_table(video_shape, kernel_size, dilation, causal=True)
+    q = x @ P['to_q.weight'].t()
+    kv = x @ P['to_kv.weight'].t()               # zero pad rows give k=v=0 and are never attended
+    k, v = kv[..., :inner], kv[..., inner:]
+    if n == 1:                                   # np.py:485-486
+        return v @ P['to_out.weight'].t() + P['to_out.bias']
+    rpb = None
+    if 'rel_pos_bias.axial1' in P:
+        kf, kh, kw = _tup3(kernel_size)
+        pos = None
+        for i, klen in enumerate((kf, kh, kw)):
+            if klen <= 1:
+                continue
+        # AxialPositionalEmbedding(heads, shape=kernel_size) np.py:416, 1693-1709
+        axes = [P[f'rel_pos_bias.axial{i + 1}'] for i in range(sum(1 for t in (kf, kh, kw) if t > 1))]
+        pos = axes[0]
+        for ax in axes[1:]:
+            pos = pos.unsqueeze(-2) + ax
+        rpb = pos.reshape(-1, heads).t()         # (h, K)
+    sh = lambda t: t.reshape(b, n, heads, d)
+    o = sparse3dna_core(sh(q), sh(k), sh(v), P['talking_heads.weight'].reshape(heads, heads),
+                        idx, d ** -0.5, rpb)
+    return o.reshape(b, n, inner) @ P['to_out.weight'].t() + P['to_out.bias']
+
+
+# --------------------------------------------------------------------------------------
+# a8  Attention as cross-attention (np.py:290-379)
+# --------------------------------------------------------------------------------------
+
+def attention_core(q, k, v, null_k, null_v, w_th, key_mask, scale, causal=False):
+    """q (b,n,h,d); k,v (b,m,h,d); null_k/null_v (h,d); key_mask (b,m) bool or None.
+    np.py:339-378."""
+    b, n, h, d = q.shape
+    nk = null_k[None, None].expand(b, 1, h, d)
+    nv = null_v[None, None].expand(b, 1, h, d)
+    kk = torch.cat((nk, k), dim=1)
+    vv = torch.cat((nv, v), dim=1)
+    sim = torch.einsum('bihd,bjhd->bhij', q * scale, kk)
+    if key_mask is not None:
+        km = F.pad(key_mask, (1, 0), value=True)
+        sim = sim.masked_fill(~km[:, None, None, :], FP32_NEG_MAX)
+    if causal:
+        i, j = sim.shape[-2:]
+        cm = torch.ones(i, j, dtype=torch.bool).triu_(j - i + 1)
+        sim = sim.masked_fill(cm, FP32_NEG_MAX)
+    attn = sim.softmax(dim=-1, dtype=torch.float32)
+    attn = torch.einsum('gh,bhij->bgij', w_th, attn)
+    return torch.einsum('bgij,bjgd->bigd', attn, vv)
+
+
+def rotate_half(x):                               # np.py:144-147
+    x1, x2 = x.chunk(2, dim=-1)
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def apply_rotary(freqs, t):                       # np.py:149-153
+    rot = freqs.shape[-1]
+    t, tp = t[..., :rot], t[..., rot:]
+    t = t * freqs.cos() + rotate_half(t) * freqs.sin()
+    return torch.cat((t, tp), dim=-1)
+
+
+def attention(x, P, heads, context=None, context_mask=None, mask=None, rotary=None, causal=False):
+    """Attention.forward np.py:315-379 (to_out has no bias)."""
+    b, n, D = x.shape
+    inner = P['to_q.weight'].shape[0]
+    d = inner // heads
+    src = context if context is not None else x
+    q = (x @ P['to_q.weight'].t()).reshape(b, n, heads, d)
+    kv = src @ P['to_kv.weight'].t()
+    m = src.shape[1]
+    k = kv[..., :inner].reshape(b, m, heads, d)
+    v = kv[..., inner:].reshape(b, m, heads, d)
+    if context is None and rotary is not None:   # rotary on q, k AND v (quirk Q11) np.py:333-335
+        fr = rotary[None, :, None, :]
+        q, k, v = (apply_rotary(fr, t) for t in (q, k, v))
+    km = context_mask if context is not None else mask
+    o = attention_core(q, k, v, P['null_k'].reshape(heads, d), P['null_v'].reshape(heads, d),
+                       P['talking_heads.weight'].reshape(heads, heads), km, d ** -0.5, causal)
+    return o.reshape(b, n, inner) @ P['to_out.weight'].t()
+
+
+# --------------------------------------------------------------------------------------
+# a9  FeedForward + GEGLU (np.py:255-286)
+# --------------------------------------------------------------------------------------
+
+def feedforward(x, P):
+    u = x @ P['net.0.weight'].t()
+    a, g = u.chunk(2, dim=-1)
+    return (a * F.gelu(g)) @ P['net.3.weight'].t()
+
+
+# --------------------------------------------------------------------------------------
+# a3/a4  decoder layer and stack (Transformer np.py:1071-1182)
+# --------------------------------------------------------------------------------------
+
+def sandwich(x, P, fn):
+    """SandwichNorm np.py:112-128."""
+    h = layer_norm(x, P['prenorm.weight'], P['prenorm.bias'])
+    h = fn(h)
+    return layer_norm(h, P['postnorm.weight'], P['postnorm.bias'])
+
+
+def decoder_layer(x, P, cfg, layer_idx, context, context_mask):
+    """one iteration of Transformer.forward np.py:1174-1180.
+    cfg: dict(video_shape, kernel_size, dilations, heads, shift)"""
+    fmap = cfg['video_shape'][1]
+    dil = cfg['dilations'][layer_idx % len(cfg['dilations'])]
+    shift = cfg.get('shift', True)
+    key3 = '0.fn.fn' if shift else '0.fn'
+    keyf = '2.fn.fn' if shift else '2.fn'
+    sh = (lambda t: shift_video_tokens(t, fmap)) if shift else (lambda t: t)
+    x = sandwich(x, sub(P, '0'), lambda h: sparse3dna(sh(h), sub(P, key3), cfg['video_shape'],
+                                                      cfg['kernel_size'], dil, cfg['heads'])) + x
+    x = sandwich(x, sub(P, '1'), lambda h: attention(h, sub(P, '1.fn'), cfg['heads'],
+                                                     context=context, context_mask=context_mask)) + x
+    x = sandwich(x, sub(P, '2'), lambda h: feedforward(sh(h), sub(P, keyf))) + x
+    return x
+
+
+def decoder_stack(x, P, cfg, context, context_mask):
+    """Transformer.forward np.py:1167-1182; P = state dict of `video_transformer`."""
+    depth = cfg['depth']
+    for l in range(depth):
+        x = decoder_layer(x, sub(P, f'layers.{l}'), cfg, l, context, context_mask)
+    return stable_layer_norm(x, P['norm.norm.weight'], P['norm.norm.bias'])
+
+
+def reversible_decoder_stack(x, P, cfg, context, context_mask):
+    """ReversibleTransformer np.py:1184-1295 + rev.py:54-142, evaluated in plain (non-memory-
+    saving) form: y1 = x1 + f(x2); y2 = x2 + g(y1); out = y1 + y2 halves summed.
+    `layers` has 2 entries per depth: [3dna, ff], [cross, ff] (np.py:1246-1277)."""
+    fmap = cfg['video_shape'][1]
+    shift = cfg.get('shift', True)
+    sh = (lambda t: shift_video_tokens(t, fmap)) if shift else (lambda t: t)
+    x1, x2 = x, x                                           # rev.py:133
+    for l in range(cfg['depth']):
+        dil = cfg['dilations'][l % len(cfg['dilations'])]
+        A = sub(P, f'layers.{2 * l}')
+        # ShiftVideoTokens wrapper is always present in the reversible stack (np.py:1244);
+        # with shift_space False it is an identity but still adds a `.fn` level.
+        f = lambda h, A=A, dil=dil: sandwich(h, sub(A, '0'), lambda t: sparse3dna(
+            sh(t), sub(A, '0.fn.fn'), cfg['video_shape'], cfg['kernel_size'], dil, cfg['heads']))
+        g = lambda h, A=A: sandwich(h, sub(A, '1'), lambda t: feedforward(sh(t), sub(A, '1.fn.fn')))
+        y1 = x1 + f(x2)
+        y2 = x2 + g(y1)
+        x1, x2 = y1, y2
+        B = sub(P, f'layers.{2 * l + 1}')
+        f = lambda h, B=B: sandwich(h, sub(B, '0'), lambda t: attention(
+            t, sub(B, '0.fn'), cfg['heads'], context=context, context_mask=context_mask))
+        g = lambda h, B=B: sandwich(h, sub(B, '1'), lambda t: feedforward(sh(t), sub(B, '1.fn.fn')))
+        y1 = x1 + f(x2)
+        y2 = x2 + g(y1)
+        x1, x2 = y1, y2
+    return stable_layer_norm(x1 + x2, P['norm.norm.weight'], P['norm.norm.bias'])   # rev.py:142
+
+
+# --------------------------------------------------------------------------------------
+# a2  embedding assemble ; a11 logits + CE ; a1 NUWA.forward glue (decoder side)
+# --------------------------------------------------------------------------------------
+
+def axial_pos(P, prefix='video_pos_emb'):
+    """AxialPositionalEmbedding.forward np.py:1693-1709 (flattened)."""
+    pos = None
+    i = 1
+    while f'{prefix}.axial{i}' in P:
+        ax = P[f'{prefix}.axial{i}']
+        pos = ax if pos is None else pos.unsqueeze(-2) + ax
+        i += 1
+    return pos.reshape(-1, pos.shape[-1])
+
+
+def embed_assemble(ids_in, P, training=True, frac=0.2):
+    """np.py:1940-1944 + Embedding np.py:1665-1669 + frac_gradient np.py:83-84.
+    ids_in (b, n-1) -> x (b, n, D) with the <bos> row first."""
+    emb = P['image_embedding.embed.weight'][ids_in]
+    if training and frac < 1:
+        emb = emb * frac + emb.detach() * (1 - frac)
+    pos = axial_pos(P)
+    n1 = ids_in.shape[1]
+    x = pos[:n1] + emb
+    bos = P['video_bos'][None, None].expand(x.shape[0], 1, -1)
+    return torch.cat((bos, x), dim=1)
+
+
+def decoder_loss(P, cfg, ids, context, context_mask, training=True, return_logits=False):
+    """The metric path of NUWA.forward(return_loss=True), decoder side (np.py:1937-1963):
+    embed -> video_transformer -> to_logits -> cross entropy.  ids (b, N) int64."""
+    x = embed_assemble(ids[:, :-1], P, training=training, frac=cfg.get('embed_frac', 0.2))
+    vt = sub(P, 'video_transformer')
+    stack = reversible_decoder_stack if cfg.get('reversible', False) else decoder_stack
+    h = stack(x, vt, cfg, context, context_mask)
+    logits = h @ P['to_logits.weight'].t()
+    loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), ids.reshape(-1))
+    return (loss, logits) if return_logits else loss
+
+
+# --------------------------------------------------------------------------------------
+# f1  text encoder (embed_text np.py:1821-1839; always a ReversibleTransformer in practice, Q1)
+# --------------------------------------------------------------------------------------
+
+def rotary_freqs(inv_freq, seq_len):              # np.py:138-142
+    t = torch.arange(seq_len).type_as(inv_freq)
+    fr = torch.einsum('i,j->ij', t, inv_freq)
+    return torch.cat((fr, fr), dim=-1)
+
+
+def text_encoder(text, P, cfg, training=True):
+    """embed_text with enc_reversible=True: blocks (Attention, FeedForward) per depth,
+    no ShiftVideoTokens shifting (shift_space False -> identity wrapper level `.fn`)."""
+    mask = text != 0
+    emb = P['text_embedding.embed.weight'][text]
+    if training and cfg.get('embed_frac', 0.2) < 1:
+        fr = cfg.get('embed_frac', 0.2)
+        emb = emb * fr + emb.detach() * (1 - fr)
+    rot = rotary_freqs(P['text_rotary_pos_emb.inv_freq'], text.shape[1])
+    T = sub(P, 'text_transformer')
+    x1, x2 = emb, emb
+    for l in range(cfg['text_depth']):
+        A = sub(T, f'layers.{l}')
+        f = lambda h, A=A: sandwich(h, sub(A, '0'), lambda t: attention(
+            t, sub(A, '0.fn.fn'), cfg['text_heads'], mask=mask, rotary=rot))
+        g = lambda h, A=A: sandwich(h, sub(A, '1'), lambda t: feedforward(t, sub(A, '1.fn.fn')))
+        y1 = x1 + f(x2)
+        y2 = x2 + g(y1)
+        x1, x2 = y1, y2
+    return stable_layer_norm(x1 + x2, T['norm.norm.weight'], T['norm.norm.bias']), mask
+
+
+# --------------------------------------------------------------------------------------
+# a13  VQGanVAE encode path (vq.py:431-435) -- frozen tokenizer, eval mode
+# --------------------------------------------------------------------------------------
+
+def leaky(x):
+    return F.leaky_relu(x, 0.1)                   # vq.py:94-95 (slope always 0.1, quirk Q10)
+
+
+def resblock(x, P, groups=16):
+    """ResBlock vq.py:228-242."""
+    h = F.conv2d(x, P['net.0.weight'], P['net.0.bias'], padding=1)
+    h = leaky(F.group_norm(h, groups, P['net.1.weight'], P['net.1.bias']))
+    h = F.conv2d(h, P['net.3.weight'], P['net.3.bias'], padding=1)
+    h = leaky(F.group_norm(h, groups, P['net.4.weight'], P['net.4.bias']))
+    h = F.conv2d(h, P['net.6.weight'], P['net.6.bias'])
+    return h + x
+
+
+def glu_resblock(x, P, groups=16):
+    """GLUResBlock vq.py:212-226."""
+    h = F.glu(F.conv2d(x, P['net.0.weight'], P['net.0.bias'], padding=1), dim=1)
+    h = F.group_norm(h, groups, P['net.2.weight'], P['net.2.bias'])
+    h = F.glu(F.conv2d(h, P['net.3.weight'], P['net.3.bias'], padding=1), dim=1)
+    h = F.group_norm(h, groups, P['net.5.weight'], P['net.5.bias'])
+    h = F.conv2d(h, P['net.6.weight'], P['net.6.bias'])
+    return h + x
+
+
+def layernorm_chan(x, g, b, eps=1e-5):
+    """LayerNormChan vq.py:129-143."""
+    var = x.var(dim=1, unbiased=False, keepdim=True)
+    mean = x.mean(dim=1, keepdim=True)
+    return (x - mean) / (var + eps).sqrt() * g + b
+
+
+def cpb_bias(P, fmap):
+    """ContinuousPositionBias vq.py:178-210 -> (heads, n, n) bias."""
+    pos = torch.arange(fmap)
+    grid = torch.stack(torch.meshgrid(pos, pos, indexing='ij')).reshape(2, -1).t()
+    rel = grid[:, None, :] - grid[None, :, :]
+    rel = torch.sign(rel) * torch.log(rel.abs() + 1)
+    h = rel.float()
+    i = 0
+    while f'net.{i}.0.weight' in P:
+        h = leaky(h @ P[f'net.{i}.0.weight'].t() + P[f'net.{i}.0.bias'])
+        i += 1
+    h = h @ P[f'net.{i}.weight'].t() + P[f'net.{i}.bias']
+    return h.permute(2, 0, 1)
+
+
+def vqgan_attention(x, P, heads=8):
+    """VQGanAttention vq.py:244-286 incl. quirk Q9 (l2norm over the SPATIAL axis)."""
+    B, C, Hh, Ww = x.shape
+    qkv = F.conv2d(x, P['to_qkv.weight'])
+    q, k, v = qkv.chunk(3, dim=1)
+    rs = lambda t: t.reshape(B, heads, -1, Hh * Ww)          # b h c (x y)
+    q, k, v = rs(q), rs(k), rs(v)
+    q, k = F.normalize(q, dim=-1), F.normalize(k, dim=-1)
+    sim = torch.einsum('bhci,bhcj->bhij', q, k) * P['scale'].exp()
+    sim = sim + cpb_bias(sub(P, 'cpb'), Hh)
+    alpha = 32 ** 2                                          # stable_softmax vq.py:97-100
+    t = sim / alpha
+    t = t - t.amax(dim=-1, keepdim=True)
+    attn = (t * alpha).softmax(dim=-1)
+    out = torch.einsum('bhij,bhcj->bhci', attn, v).reshape(B, -1, Hh, Ww)
+    out = F.conv2d(out, P['to_out.weight'], P['to_out.bias'])
+    return layernorm_chan(out, P['post_norm.g'], P['post_norm.b']) + x
+
+
+def vae_encode_fmap(img, P, num_layers, num_resnet_blocks=1, use_attn=True, groups=16, heads=8):
+    """the `encoders` ModuleList of VQGanVAE (built vq.py:351-365, run vq.py:432-433):
+    encoders.0 = Conv(c->dim, 5, pad 2); then per layer Sequential(Conv 4 s2 p1, LeakyReLU);
+    last layer followed by ResBlock x n and VQGanAttention."""
+    E = sub(P, 'encoders')
+    h = F.conv2d(img, E['0.weight'], E['0.bias'], padding=E['0.weight'].shape[-1] // 2)
+    i = 1
+    for layer in range(num_layers):
+        h = leaky(F.conv2d(h, E[f'{i}.0.weight'], E[f'{i}.0.bias'], stride=2, padding=1))
+        i += 1
+        if layer == num_layers - 1:
+            for _ in range(num_resnet_blocks):
+                h = resblock(h, sub(E, str(i)), groups)
+                i += 1
+            if use_attn:
+                h = vqgan_attention(h, sub(E, str(i)), heads)
+                i += 1
+    return h
+
+
+def vq_eval_lookup(fmap, codebook, project_in_w=None, project_in_b=None):
+    """PARITY UNPINNED (third-party vector_quantize_pytorch, not available here; call sites
+    vq.py:368-378, 435).  Eval path, use_cosine_sim=True: x = project_in(b (h w) c);
+    idx = argmax_c( l2norm(x) . l2norm(codebook)^T ), lowest index on ties.
+    Returns (indices (B,h,w) int64, sim top-2 gap (B,h,w))."""
+    B, C, Hh, Ww = fmap.shape
+    x = fmap.permute(0, 2, 3, 1).reshape(B, Hh * Ww, C)
+    if project_in_w is not None:
+        x = x @ project_in_w.t() + (project_in_b if project_in_b is not None else 0)
+    xn = F.normalize(x, dim=-1)
+    cn = F.normalize(codebook, dim=-1)
+    sim = xn @ cn.t()
+    top2 = sim.topk(2, dim=-1).values
+    idx = sim.argmax(dim=-1)
+    return idx.reshape(B, Hh, Ww), (top2[..., 0] - top2[..., 1]).reshape(B, Hh, Ww)
+
+
+def get_video_indices(video, P, num_layers, **kw):
+    """VQGanVAE.get_video_indices vq.py:452-458. P = state dict of the VAE; expects the VQ
+    parameters under the names used by nuwa_pytorch_amd's VectorQuantize restatement:
+    vq.project_in.{weight,bias}, vq.codebook (C, codebook_dim)."""
+    b, f = video.shape[:2]
+    fm = vae_encode_fmap(video.reshape(b * f, *video.shape[2:]), P, num_layers, **kw)
+    idx, gap = vq_eval_lookup(fm, P['vq.codebook'], P.get('vq.project_in.weight'), P.get('vq.project_in.bias'))
+    return idx.reshape(b, f, *idx.shape[1:]), gap.reshape(b, f, *gap.shape[1:])

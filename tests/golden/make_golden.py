@@ -1,0 +1,190 @@
+"""Generates tests/golden/*.npz by importing the READ-ONLY reference checkout (through
+oracle/ref_shims.py) in the build container and recording seeded inputs, the parameters
+(state_dict, reference key names) and the reference's outputs / gradients.
+
+    python tests/golden/make_golden.py
+
+The fixtures are DATA (inputs + expected outputs).  They let the GPU box -- where
+/root/reference does not exist -- check both the oracle and the HIP path against the
+reference's own numbers.  fp32 CPU, dropout 0, cond_dropout_prob 0.
+Seeds: torch.manual_seed(0) for parameters, torch.manual_seed(1) for data.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shims  # noqa: E402
+
+ref_shims.install()
+from nuwa_pytorch import NUWA, VQGanVAE  # noqa: E402
+from nuwa_pytorch.nuwa_pytorch import (Sparse3DNA, Attention, FeedForward, SandwichNorm,  # noqa: E402
+                                       ShiftVideoTokens, StableLayerNorm, Transformer)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: (np_(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def params(mod, prefix='p.'):
+    return {prefix + k: v for k, v in mod.state_dict().items()}
+
+
+def grads(mod, prefix='g.'):
+    return {prefix + k: p.grad for k, p in mod.named_parameters() if p.grad is not None}
+
+
+def g1_sparse3dna():
+    cases = [((3, 4, 4), 3, 1, None), ((3, 4, 4), 3, 2, None), ((4, 8, 8), (5, 3, 3), 1, None),
+             ((4, 8, 8), (5, 3, 3), 2, None), ((4, 8, 8), (5, 3, 3), 4, None),
+             ((3, 4, 4), 3, 1, 1), ((3, 4, 4), 3, 1, 2), ((3, 4, 4), 3, 1, 16), ((3, 4, 4), 3, 1, 17),
+             ((3, 4, 4), 3, 2, 23)]
+    for ci, (shape, kernel, dil, n) in enumerate(cases):
+        torch.manual_seed(0)
+        m = Sparse3DNA(dim=32, video_shape=shape, kernel_size=kernel, dilation=dil, heads=2, dim_head=16, causal=True)
+        N = shape[0] * shape[1] * shape[2]
+        n = N if n is None else n
+        torch.manual_seed(1)
+        x = torch.randn(2, n, 32, requires_grad=True)
+        y = m(x)
+        g = torch.randn_like(y)
+        y.backward(g)
+        ks = kernel if isinstance(kernel, tuple) else (kernel,) * 3
+        save(f'g1_sparse3dna_{ci}', x=x, y=y, dy=g, dx=x.grad, video_shape=shape, kernel_size=ks, dilation=dil,
+             heads=2, **params(m), **grads(m))
+
+
+def g2_cross_attention():
+    torch.manual_seed(0)
+    m = Attention(dim=32, heads=2, dim_head=16)
+    torch.manual_seed(1)
+    x = torch.randn(3, 20, 32, requires_grad=True)
+    ctx = torch.randn(3, 7, 32, requires_grad=True)
+    mask = torch.ones(3, 7, dtype=torch.bool)
+    mask[1] = False
+    mask[2, 4:] = False
+    y = m(x, context=ctx, context_mask=mask)
+    g = torch.randn_like(y)
+    y.backward(g)
+    save('g2_cross_attention', x=x, ctx=ctx, mask=mask, y=y, dy=g, dx=x.grad, dctx=ctx.grad, heads=2,
+         **params(m), **grads(m))
+
+
+def g3_feedforward():
+    for dim in (32, 48):
+        torch.manual_seed(0)
+        m = FeedForward(dim=dim)
+        torch.manual_seed(1)
+        x = torch.randn(2, 9, dim, requires_grad=True)
+        y = m(x)
+        g = torch.randn_like(y)
+        y.backward(g)
+        save(f'g3_feedforward_{dim}', x=x, y=y, dy=g, dx=x.grad, **params(m), **grads(m))
+
+
+def g4_norms_and_shift():
+    torch.manual_seed(0)
+    sn = SandwichNorm(dim=32, fn=ShiftVideoTokens(torch.nn.Identity(), image_size=4))
+    sl = StableLayerNorm(32)
+    with torch.no_grad():
+        for p in list(sn.parameters()) + list(sl.parameters()):
+            p.normal_()
+    torch.manual_seed(1)
+    x = torch.randn(2, 23, 32, requires_grad=True)
+    y = sn(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    x2 = torch.randn(2, 9, 32, requires_grad=True)
+    y2 = sl(x2)
+    g2 = torch.randn_like(y2)
+    y2.backward(g2)
+    save('g4_norms_shift', x=x, y=y, dy=g, dx=x.grad, fmap=4, x2=x2, y2=y2, dy2=g2, dx2=x2.grad,
+         **params(sn, 'sn.'), **grads(sn, 'gsn.'), **params(sl, 'sl.'), **grads(sl, 'gsl.'))
+
+
+def tiny_nuwa(reversible):
+    torch.manual_seed(0)
+    vae = VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32,
+                   use_vgg_and_gan=False)
+    return NUWA(vae=vae, dim=32, text_num_tokens=50, text_max_seq_len=8, max_video_frames=3, text_enc_depth=2,
+                dec_depth=3, enc_reversible=True, dec_reversible=reversible, dec_heads=2, dec_dim_head=16,
+                text_enc_heads=2, text_enc_dim_head=16, sparse_3dna_kernel_size=3, sparse_3dna_dilation=(1, 2))
+
+
+def g5_g6_nuwa():
+    for name, rev in (('g5_nuwa_tiny', False), ('g6_nuwa_tiny_reversible', True)):
+        nuwa = tiny_nuwa(rev)
+        torch.manual_seed(1)
+        text = torch.randint(1, 50, (2, 8))
+        text[1, 5:] = 0
+        vid = torch.randint(0, 64, (2, 3, 4, 4))
+        cap = {}
+        hk = nuwa.to_logits.register_forward_hook(lambda m, i, o: cap.__setitem__('logits', o.detach()))
+        hk2 = nuwa.text_transformer.register_forward_hook(lambda m, i, o: cap.__setitem__('ctx', o.detach()))
+        loss = nuwa(text=text, video=vid, return_loss=True, cond_dropout_prob=0.)
+        hk.remove(); hk2.remove()
+        loss.backward()
+        P = {k: v for k, v in params(nuwa).items() if not k.startswith('p.vae.') and '.net.blocks.' not in k}
+        G = {k: v for k, v in grads(nuwa).items() if '.net.blocks.' not in k}
+        save(name, text=text, video_ids=vid, loss=loss, logits=cap['logits'], text_embeds=cap['ctx'],
+             reversible=rev, **P, **G)
+
+
+def g7_vae():
+    torch.manual_seed(0)
+    vae = VQGanVAE(dim=32, image_size=32, num_layers=2, vq_codebook_size=64, vq_codebook_dim=16,
+                   use_vgg_and_gan=False, attn_dim_head=16, attn_heads=4).eval()
+    torch.manual_seed(1)
+    img = torch.rand(3, 3, 32, 32)
+    fm = img
+    stages = {}
+    with torch.no_grad():
+        for i, enc in enumerate(vae.encoders):
+            fm = enc(fm)
+            stages[f'stage{i}'] = fm
+        quant, ind, _ = vae.vq(fm)          # VQ = shimmed restatement: PARITY UNPINNED
+        xn = torch.nn.functional.normalize(vae.vq.project_in(fm.permute(0, 2, 3, 1)), dim=-1)
+        sim = xn @ torch.nn.functional.normalize(vae.vq.embed, dim=-1).t()
+        top2 = sim.topk(2, dim=-1).values
+        recon = vae.decode(quant)
+        loss = vae(img, return_loss=True)
+    save('g7_vae', img=img, fmap=fm, indices=ind, top2_gap=top2[..., 0] - top2[..., 1], recon=recon,
+         recon_loss=loss, num_layers=2, heads=4, **stages, **params(vae))
+
+
+def g8_decoder_layer():
+    torch.manual_seed(0)
+    tr = Transformer(dim=32, depth=3, causal=True, heads=2, dim_head=16, cross_attend=True,
+                     sparse_3dna_attn=True, sparse_3dna_kernel_size=(3, 3, 3), sparse_3dna_video_shape=(3, 4, 4),
+                     sparse_3dna_dilations=(1, 2), shift_video_tokens=True)
+    torch.manual_seed(1)
+    x = torch.randn(2, 48, 32, requires_grad=True)
+    ctx = torch.randn(2, 6, 32, requires_grad=True)
+    mask = torch.ones(2, 6, dtype=torch.bool)
+    mask[1, 3:] = False
+    y = tr(x, context=ctx, context_mask=mask)
+    g = torch.randn_like(y)
+    y.backward(g)
+    save('g8_decoder_stack', x=x, ctx=ctx, mask=mask, y=y, dy=g, dx=x.grad, dctx=ctx.grad,
+         **params(tr), **grads(tr))
+
+
+if __name__ == '__main__':
+    g1_sparse3dna()
+    g2_cross_attention()
+    g3_feedforward()
+    g4_norms_and_shift()
+    g5_g6_nuwa()
+    g7_vae()
+    g8_decoder_layer()

@@ -1,0 +1,111 @@
+"""Oracle (oracle/nuwa_oracle.py) against the committed golden fixtures that were captured from
+the reference itself (tests/golden/make_golden.py).  Runs anywhere, CPU only."""
+import pytest
+import torch
+
+from oracle import nuwa_oracle as O
+from golden_util import load, load_raw, tup
+
+TOL = dict(rtol=1e-4, atol=2e-5)
+
+
+def req(P):
+    return {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in P.items()}
+
+
+@pytest.mark.parametrize('ci', range(10))
+def test_g1_sparse3dna(ci):
+    A, P, G = load(f'g1_sparse3dna_{ci}')
+    P = req(P)
+    x = A['x'].clone().requires_grad_(True)
+    dil = tup(A['dilation']) if A['dilation'].numel() > 1 else int(A['dilation'])
+    y = O.sparse3dna(x, P, tup(A['video_shape']), tup(A['kernel_size']), dil, int(A['heads']))
+    torch.testing.assert_close(y, A['y'], **TOL)
+    y.backward(A['dy'])
+    torch.testing.assert_close(x.grad, A['dx'], **TOL)
+    for k, g in G.items():
+        torch.testing.assert_close(P[k].grad, g, **TOL)
+
+
+def test_g2_cross_attention():
+    A, P, G = load('g2_cross_attention')
+    P = req(P)
+    x, ctx = A['x'].clone().requires_grad_(True), A['ctx'].clone().requires_grad_(True)
+    y = O.attention(x, P, int(A['heads']), context=ctx, context_mask=A['mask'])
+    torch.testing.assert_close(y, A['y'], **TOL)
+    y.backward(A['dy'])
+    torch.testing.assert_close(x.grad, A['dx'], **TOL)
+    torch.testing.assert_close(ctx.grad, A['dctx'], **TOL)
+    for k, g in G.items():
+        torch.testing.assert_close(P[k].grad, g, **TOL)
+
+
+@pytest.mark.parametrize('dim', [32, 48])
+def test_g3_feedforward(dim):
+    A, P, G = load(f'g3_feedforward_{dim}')
+    P = req(P)
+    x = A['x'].clone().requires_grad_(True)
+    y = O.feedforward(x, P)
+    torch.testing.assert_close(y, A['y'], **TOL)
+    y.backward(A['dy'])
+    torch.testing.assert_close(x.grad, A['dx'], **TOL)
+    for k, g in G.items():
+        torch.testing.assert_close(P[k].grad, g, **TOL)
+
+
+def test_g4_norms_shift():
+    R = load_raw('g4_norms_shift')
+    x = R['x'].clone().requires_grad_(True)
+    P = {k[3:]: v for k, v in R.items() if k.startswith('sn.')}
+    y = O.sandwich(x, P, lambda h: O.shift_video_tokens(h, int(R['fmap'])))
+    torch.testing.assert_close(y, R['y'], **TOL)
+    y.backward(R['dy'])
+    torch.testing.assert_close(x.grad, R['dx'], **TOL)
+    x2 = R['x2'].clone().requires_grad_(True)
+    y2 = O.stable_layer_norm(x2, R['sl.norm.weight'], R['sl.norm.bias'])
+    torch.testing.assert_close(y2, R['y2'], **TOL)
+    y2.backward(R['dy2'])
+    torch.testing.assert_close(x2.grad, R['dx2'], **TOL)
+
+
+@pytest.mark.parametrize('name', ['g5_nuwa_tiny', 'g6_nuwa_tiny_reversible'])
+def test_g5_g6_nuwa(name):
+    A, P, G = load(name)
+    P = req(P)
+    cfg = dict(video_shape=(3, 4, 4), kernel_size=3, dilations=(1, 2), heads=2, depth=3, shift=True,
+               reversible=bool(A['reversible']), text_depth=2, text_heads=2)
+    ctx, mask = O.text_encoder(A['text'], P, cfg)
+    torch.testing.assert_close(ctx, A['text_embeds'], **TOL)
+    loss, logits = O.decoder_loss(P, cfg, A['video_ids'].reshape(2, -1), ctx, mask, return_logits=True)
+    torch.testing.assert_close(logits, A['logits'], **TOL)
+    torch.testing.assert_close(loss, A['loss'], **TOL)
+    loss.backward()
+    n = 0
+    for k, g in G.items():
+        torch.testing.assert_close(P[k].grad, g, rtol=1e-3, atol=2e-5, msg=lambda m, k=k: f'{k}: {m}')
+        n += 1
+    assert n > 40
+
+
+def test_g7_vae_encode():
+    A, P, _ = load('g7_vae')
+    fm = O.vae_encode_fmap(A['img'], P, num_layers=int(A['num_layers']), heads=int(A['heads']))
+    torch.testing.assert_close(fm, A['fmap'], **TOL)
+    idx, gap = O.vq_eval_lookup(fm, P['vq.embed'], P['vq.project_in.weight'], P['vq.project_in.bias'])
+    sure = A['top2_gap'] > 1e-5
+    assert torch.equal(idx[sure], A['indices'][sure])   # bit-exact wherever the top-2 gap is not a near-tie
+    assert sure.float().mean() > 0.95
+
+
+def test_g8_decoder_stack():
+    A, P, G = load('g8_decoder_stack')
+    P = req(P)
+    x, ctx = A['x'].clone().requires_grad_(True), A['ctx'].clone().requires_grad_(True)
+    cfg = dict(video_shape=(3, 4, 4), kernel_size=3, dilations=(1, 2), heads=2, depth=3, shift=True)
+    y = O.decoder_stack(x, P, cfg, ctx, A['mask'])
+    torch.testing.assert_close(y, A['y'], **TOL)
+    y.backward(A['dy'])
+    torch.testing.assert_close(x.grad, A['dx'], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(ctx.grad, A['dctx'], rtol=1e-3, atol=2e-5)
+    for k, g in G.items():
+        torch.testing.assert_close(P[k].grad, g, rtol=1e-3, atol=2e-5, msg=lambda m, k=k: f'{k}: {m}')
