@@ -1,0 +1,177 @@
+/*
+ * libamdnuwa -- C-ABI of the MI355X (gfx950) NUWA video-decoder training hot path.
+ *
+ * The reference (lucidrains/nuwa-pytorch) has no FFI / operator registry: its boundary for this
+ * path is the set of nn.Module classes in nuwa_pytorch/nuwa_pytorch.py (np.py) and
+ * nuwa_pytorch/vqgan_vae.py (vq.py).  Each entry point below replaces the *body* of one of
+ * those modules' forward (or its autograd backward) and cites the lines it replaces.  The
+ * Python package `nuwa_pytorch_amd` keeps the module classes / signatures / state-dict keys
+ * and calls these functions through ctypes (see INTEGRATION.md for the reference-side stub).
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory + sizes + an explicit hipStream_t; nothing allocates,
+ *     nothing synchronises, nothing throws; return 0 on success, <0 = AMDNUWA_ERR_*, >0 = hipError_t.
+ *   - bf16 tensors are passed as uint16_t*; "hi/lo" pairs are the bf16 split of an fp32 value
+ *     (value ~= hi + lo).  A NULL lo pointer selects the plain-bf16 operand path; non-NULL lo
+ *     on both operands selects the 3-MFMA parity path (hi*hi + hi*lo + lo*hi).
+ *   - activations are row-major [rows, features] with an explicit leading dimension in elements.
+ *   - token rows of the video decoder: row = sample * ntok + i, i = 0 is <bos>, i = 1 + p is the
+ *     token at raster position p = (f*H + y)*W + w.
+ */
+#ifndef AMDNUWA_H
+#define AMDNUWA_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* amdnuwa_stream;   /* == hipStream_t */
+
+int amdnuwa_abi_version(void);                 /* bumps when any signature below changes */
+const char* amdnuwa_error_string(int code);
+
+/* opt-in HIP-event launch timer: while armed, _begin/_end bracket one launch on `stream` with an
+ * event pair; _collect synchronises and returns the summed kernel time and the launch count. */
+void amdnuwa_timer_arm(int on);
+int amdnuwa_timer_begin(amdnuwa_stream stream);
+int amdnuwa_timer_end(amdnuwa_stream stream);
+int amdnuwa_timer_collect(double* total_ms, long long* launches);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM (replaces every nn.Linear on the path: np.py:274-277 FeedForward, np.py:311-313 Attention,
+ * np.py:401-405 Sparse3DNA, np.py:1819 to_logits; and their autograd backward)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const uint16_t* A; const uint16_t* Alo; long long strideA; int lda;
+    const uint16_t* B; const uint16_t* Blo; long long strideB; int ldb;
+    void* C; uint16_t* Clo; long long strideC; int ldc;
+    int c_is_bf16;          /* 0: C is float*, 1: C (and optional Clo) are bf16 */
+    const float* bias;      /* NT only, fp32 output only; may be NULL */
+    float alpha, beta;      /* beta: TN only (C = beta*C + alpha*A^T B) */
+    int M, N, K;
+    int batch;              /* >=1; operand/result strides are per batch element */
+    int shift_ntok;         /* >0: fold ShiftVideoTokens (np.py:185-253) into the loader of the */
+    int shift_fmap;         /*     activation operand (A for NT, B for TN); ntok = rows per sample */
+    int batch_inner;        /* >0: two-level batch: element z lives at (z / batch_inner) * stride +   */
+    long long strideA_inner, strideB_inner, strideC_inner;   /*  (z % batch_inner) * stride_inner      */
+} amdnuwa_gemm_desc;
+
+/* C[M,N] = alpha * A[M,K] . B[N,K]^T (+ bias).  K, lda, ldb multiples of 8. */
+int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, amdnuwa_stream stream);
+/* C[M,N] (fp32) = beta*C + alpha * A[K,M]^T . B[K,N]   (reduction over the K token rows, split-K
+ * through `workspace`, fixed summation order => deterministic).  M, N, lda, ldb multiples of 8. */
+size_t amdnuwa_gemm_tn_workspace_bytes(const amdnuwa_gemm_desc* d);
+int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row kernels: LayerNorm of SandwichNorm (np.py:112-128) fused with the residual add of
+ * Transformer.forward (np.py:1175-1180); StableLayerNorm (np.py:88-95); GEGLU (np.py:255-258);
+ * Embedding/AxialPositionalEmbedding/<bos> assemble (np.py:1659-1709, 1940-1944);
+ * F.cross_entropy (np.py:1963).  fp32 statistics, bf16 hi[/lo] outputs where a GEMM consumes them.
+ * ---------------------------------------------------------------------------------------- */
+/* mode 0: out_hi[/lo] = LN(x)*w+b (bf16).  mode 1: out_f32 = resid + LN(x)*w+b.
+ * stable != 0 (mode 0 only): x is first divided by its row amax (saved as 1/amax). */
+int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const float* b, uint16_t* out_hi,
+                   uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R, int D,
+                   int mode, int stable, float eps, amdnuwa_stream stream);
+size_t amdnuwa_ln_bwd_workspace_bytes(long long R, int D);
+/* dy fp32; shift_ntok > 0 reads dy through the inverse token shift.  Exactly one of dx_hi (bf16
+ * hi[/lo] output) / dx_acc (fp32, accumulated into) is non-NULL.  dw, db, dsum (= column sums of
+ * dx) may be NULL; accumulate != 0 adds into them. */
+int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* inv_amax,
+                   const float* w, uint16_t* dx_hi, uint16_t* dx_lo, float* dx_acc, float* dw, float* db, float* dsum,
+                   long long R, int D, int shift_ntok, int shift_fmap, int stable, int accumulate, void* workspace,
+                   size_t workspace_bytes, amdnuwa_stream stream);
+/* u = [a | g], each FP columns wide: o = a * gelu_erf(g) */
+int amdnuwa_geglu_fwd(const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* o_hi, uint16_t* o_lo, long long R, int FP,
+                      amdnuwa_stream stream);
+int amdnuwa_geglu_bwd(const uint16_t* u_hi, const uint16_t* u_lo, const uint16_t* d_hi, const uint16_t* d_lo,
+                      uint16_t* du_hi, uint16_t* du_lo, long long R, int FP, amdnuwa_stream stream);
+/* dst[r][c<C] = bf16(src[r][c]), zero for C <= c < Cp */
+int amdnuwa_cast_pad(const float* src, int ld_src, uint16_t* hi, uint16_t* lo, int ld_dst, long long R, int C, int Cp,
+                     amdnuwa_stream stream);
+/* dst[c][r] = bf16(src[r][c]) */
+int amdnuwa_transpose_cast(const float* src, int ld_src, uint16_t* hi, uint16_t* lo, int ld_dst, int R, int C,
+                           amdnuwa_stream stream);
+int amdnuwa_embed_fwd(const long long* ids, const float* W, const float* ax1, const float* ax2, const float* ax3,
+                      const float* bos, float* x, int B, int ntok, int D, int H, int Wd, float frac,
+                      amdnuwa_stream stream);
+size_t amdnuwa_embed_bwd_workspace_bytes(int ntok, int D);
+int amdnuwa_embed_bwd(const long long* ids, const float* dx, float* dW, float* dax1, float* dax2, float* dax3,
+                      float* dbos, int B, int ntok, int D, int F, int H, int Wd, float frac, void* workspace,
+                      size_t workspace_bytes, amdnuwa_stream stream);
+/* row_loss[r] = lse(logits[r]) - logits[r][t]; *loss = mean(row_loss);
+ * dl (optional, bf16 hi[/lo], ld = ld_dl) = (softmax - onehot) * grad_scale */
+int amdnuwa_ce_fwd(const float* logits, const long long* targets, float* row_loss, float* loss, uint16_t* dl_hi,
+                   uint16_t* dl_lo, long long R, int C, int ld_dl, float grad_scale, amdnuwa_stream stream);
+int amdnuwa_scale_by_device_scalar(float* x, size_t n, const float* scalar, amdnuwa_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse3DNA core (np.py:488-608, incl. the unfoldNd gather np.py:526-534): causal 3-D nearby
+ * attention with <bos> key/value, fp32 softmax and talking heads.  q/k/v/o are token-row major
+ * [B*ntok, ld] with head h in columns [h*dim_head, (h+1)*dim_head); q is UNSCALED.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int B, ntok;            /* ntok = 1 (<bos>) + number of video tokens present (<= F*H*W) */
+    int F, H, W;            /* token grid (max_frames, fmap, fmap) */
+    int kf, kh, kw;         /* kernel size */
+    int df, dh, dw;         /* dilation */
+    int heads, dim_head;    /* heads <= 8; dim_head in {32, 64}; W*heads*4 <= 512 */
+    float scale;            /* dim_head ** -0.5 */
+} amdnuwa_s3_geom;
+
+int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* k, const uint16_t* v,
+                           const uint16_t* q_lo, const uint16_t* k_lo, const uint16_t* v_lo, int ld,
+                           const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, amdnuwa_stream stream);
+size_t amdnuwa_sparse3dna_bwd_workspace_bytes(const amdnuwa_s3_geom* g);
+int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* k, const uint16_t* v,
+                           const uint16_t* q_lo, const uint16_t* k_lo, const uint16_t* v_lo, int ld,
+                           const float* w_th, const uint16_t* dO, const uint16_t* dO_lo, int lddo, uint16_t* dq,
+                           uint16_t* dk, uint16_t* dv, uint16_t* dq_lo, uint16_t* dk_lo, uint16_t* dv_lo, int ldd,
+                           float* dw_th, int accumulate, void* workspace, size_t workspace_bytes,
+                           amdnuwa_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Text cross-attention core (Attention.forward with context, np.py:339-378): learned null key/value
+ * at key slot 0, context key mask, fp32 softmax, talking heads, attn @ v.  q/o are token-row major
+ * [B*n, ld]; keys/values are packed per (sample, head) by amdnuwa_xattn_pack.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int B, n, T;            /* queries per sample, context length */
+    int JP;                 /* amdnuwa_xattn_jp(T): T+1 rounded up to a multiple of 32 (<= 288) */
+    int heads, dim_head;    /* heads <= 8, dim_head in {32, 64} */
+    float scale;
+} amdnuwa_xattn_geom;
+
+typedef struct {            /* all [B][heads][JP][dim_head] (Kp, Vp) or [B][heads][dim_head][JP] (Kt, Vt), bf16 */
+    uint16_t *Kp, *Kp_lo, *Kt, *Kt_lo, *Vp, *Vp_lo, *Vt, *Vt_lo;
+    uint8_t* valid;         /* [B][JP] */
+} amdnuwa_xattn_kv;
+
+int amdnuwa_xattn_jp(int T);
+/* kv: [B*T, ldkv] bf16, keys in columns [0, inner), values in [inner, 2*inner) (= to_kv(context)) */
+int amdnuwa_xattn_pack(const amdnuwa_xattn_geom* g, const uint16_t* kv, const uint16_t* kv_lo, int ldkv,
+                       const float* null_k, const float* null_v, const uint8_t* context_mask,
+                       const amdnuwa_xattn_kv* packed, amdnuwa_stream stream);
+/* P / Pm (optional): softmax probabilities before / after talking heads, [B][heads][n][JP] bf16 hi[/lo],
+ * saved for the backward */
+int amdnuwa_xattn_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq,
+                      const amdnuwa_xattn_kv* packed, const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo,
+                      uint16_t* P, uint16_t* P_lo, uint16_t* Pm, uint16_t* Pm_lo, amdnuwa_stream stream);
+size_t amdnuwa_xattn_bwd_workspace_bytes(const amdnuwa_xattn_geom* g);
+/* query side of the backward: dq and ds = dL/dsim [B][heads][n][JP]; dK/dV follow as batched
+ * amdnuwa_gemm_tn over ds / Pm, then amdnuwa_xattn_unpack */
+int amdnuwa_xattn_bwd(const amdnuwa_xattn_geom* g, const uint16_t* dO, const uint16_t* dO_lo, int lddo,
+                      const amdnuwa_xattn_kv* packed, const float* w_th, const uint16_t* P, const uint16_t* P_lo,
+                      uint16_t* dS, uint16_t* dS_lo, uint16_t* dq, uint16_t* dq_lo, int lddq, float* dw_th,
+                      int accumulate, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
+int amdnuwa_xattn_unpack(const amdnuwa_xattn_geom* g, const float* dKp, const float* dVp, uint16_t* dkv,
+                         uint16_t* dkv_lo, int ldkv, float* dnull_k, float* dnull_v, int accumulate,
+                         amdnuwa_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,62 @@
+"""Builds libamdnuwa.so (gfx950) in-tree with hipcc.  No torch involvement: the library is a plain
+C-ABI shared object (include/amdnuwa.h) loaded through ctypes by nuwa_pytorch_amd._lib.
+
+    python -m nuwa_pytorch_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libamdnuwa.so')
+HEADER = os.path.join(os.path.dirname(HERE), 'include', 'amdnuwa.h')
+SOURCES = ['api.hip', 'gemm.hip', 'elementwise.hip', 'sparse3dna.hip', 'xattn.hip', 'vae.hip']
+ARCH = 'gfx950'
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    common = [os.path.join(CSRC, 'common.h'), HEADER]
+    objs, jobs = [], []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(LIBDIR, s.replace('.hip', '.o'))
+        objs.append(obj)
+        if force or _stale(obj, [src] + common):
+            jobs.append([_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed:\n{" ".join(cmd)}\n{r.stdout}\n{r.stderr}')
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,70 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of libamdnuwa.
+// Wave = 64 lanes everywhere.  bf16 values travel as raw uint16_t.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+#define AMDNUWA_OK 0
+#define AMDNUWA_ERR_ARG -1
+#define AMDNUWA_ERR_UNSUPPORTED -2
+#define AMDNUWA_ERR_WORKSPACE -3
+
+#define LAUNCH_CHECK()                                \
+    do {                                              \
+        hipError_t e__ = hipGetLastError();           \
+        if (e__ != hipSuccess) return (int)e__;       \
+    } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 (inputs are finite on this path)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+// split fp32 into a bf16 hi part and a bf16 residual (hi + lo carries ~16 mantissa bits)
+__device__ __forceinline__ void f2bf_hilo(float f, bf16_t& hi, bf16_t& lo) {
+    hi = f2bf(f);
+    lo = f2bf(f - bf2f(hi));
+}
+
+__device__ __forceinline__ uint32_t pack2(bf16_t a, bf16_t b) { return (uint32_t)a | ((uint32_t)b << 16); }
+__device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact-erf GELU (F.gelu default) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// XCD-aware bijective block remap (8 XCDs, block b runs on XCD b % 8): gives each XCD a
+// contiguous slab of logical tile ids so neighbouring tiles share operand panels in that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + loc;
+}

@@ -1,0 +1,568 @@
+// HBM-bound row kernels of the decoder path (gfx950).  One 64-lane wave per token row, 16-byte
+// accesses, fp32 statistics.  Replaces: nn.LayerNorm inside SandwichNorm (np.py:112-128),
+// StableLayerNorm (np.py:88-95), the residual adds of Transformer.forward (np.py:1175-1180),
+// GEGLU (np.py:255-258), Embedding + AxialPositionalEmbedding + <bos> concat (np.py:1659-1709,
+// 1940-1944), F.cross_entropy (np.py:1963), and their autograd backward.
+#include "common.h"
+#include "../../include/amdnuwa.h"
+
+namespace {
+
+constexpr int MAXV = 4;        // float4 slots per lane: supports D <= 1024
+constexpr int ROWS_PER_BLOCK = 4;
+
+struct RowVals { float4 v[MAXV]; };
+
+__device__ __forceinline__ void row_load(const float* __restrict__ p, int D, int lane, RowVals& r, float fill = 0.f) {
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+        const int e = (lane + it * 64) * 4;
+        r.v[it] = (e < D) ? *reinterpret_cast<const float4*>(p + e) : make_float4(fill, fill, fill, fill);
+    }
+}
+__device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, float a, float b, float c, float d) {
+    bf16_t h[4], l[4];
+    f2bf_hilo(a, h[0], l[0]); f2bf_hilo(b, h[1], l[1]); f2bf_hilo(c, h[2], l[2]); f2bf_hilo(d, h[3], l[3]);
+    *reinterpret_cast<uint2*>(hi + e) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+    if (lo) *reinterpret_cast<uint2*>(lo + e) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm forward.
+//   MODE 0 (pre-norm)        : out_bf16[hi,lo] = LN(x) * w + b
+//   MODE 1 (post-norm + res) : out_f32 = resid + LN(x) * w + b
+//   STABLE                   : x <- x / amax(x) first (StableLayerNorm np.py:93-95), saves 1/amax
+// saves mean / rstd per row for the backward.
+// ---------------------------------------------------------------------------------------------
+template <int MODE, bool STABLE>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ resid,
+                                                     const float* __restrict__ w, const float* __restrict__ b,
+                                                     bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
+                                                     float* __restrict__ out_f32, float* __restrict__ mean_o,
+                                                     float* __restrict__ rstd_o, float* __restrict__ inv_amax_o,
+                                                     long long R, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= R) return;
+    RowVals xv;
+    row_load(x + row * D, D, lane, xv, STABLE ? -3.0e38f : 0.f);
+    float inv_amax = 1.f;
+    if (STABLE) {
+        float m = -3.0e38f;
+#pragma unroll
+        for (int it = 0; it < MAXV; ++it) m = fmaxf(m, fmaxf(fmaxf(xv.v[it].x, xv.v[it].y), fmaxf(xv.v[it].z, xv.v[it].w)));
+        m = wave_max(m);
+        inv_amax = 1.f / m;
+#pragma unroll
+        for (int it = 0; it < MAXV; ++it) {
+            const int e = (lane + it * 64) * 4;
+            if (e < D) { xv.v[it].x = xv.v[it].x / m; xv.v[it].y = xv.v[it].y / m; xv.v[it].z = xv.v[it].z / m; xv.v[it].w = xv.v[it].w / m; }
+            else xv.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) s += (xv.v[it].x + xv.v[it].y) + (xv.v[it].z + xv.v[it].w);
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+        const int e = (lane + it * 64) * 4;
+        if (e < D) {
+            const float a = xv.v[it].x - mean, b_ = xv.v[it].y - mean, c = xv.v[it].z - mean, d = xv.v[it].w - mean;
+            q += (a * a + b_ * b_) + (c * c + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) {
+        mean_o[row] = mean; rstd_o[row] = rstd;
+        if (STABLE) inv_amax_o[row] = inv_amax;
+    }
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+        const int e = (lane + it * 64) * 4;
+        if (e >= D) continue;
+        const float4 wv = *reinterpret_cast<const float4*>(w + e);
+        const float4 bv = *reinterpret_cast<const float4*>(b + e);
+        const float y0 = (xv.v[it].x - mean) * rstd * wv.x + bv.x;
+        const float y1 = (xv.v[it].y - mean) * rstd * wv.y + bv.y;
+        const float y2 = (xv.v[it].z - mean) * rstd * wv.z + bv.z;
+        const float y3 = (xv.v[it].w - mean) * rstd * wv.w + bv.w;
+        if (MODE == 0) {
+            store_bf16x4(out_hi + row * D, out_lo ? out_lo + row * D : nullptr, e, y0, y1, y2, y3);
+        } else {
+            const float4 rv = *reinterpret_cast<const float4*>(resid + row * D + e);
+            *reinterpret_cast<float4*>(out_f32 + row * D + e) = make_float4(rv.x + y0, rv.y + y1, rv.z + y2, rv.w + y3);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward.  dy fp32 (optionally read through the INVERSE token shift), x = LN input.
+//   OUT 0: dx -> bf16 hi/lo (post-norm backward; feeds the dgrad / wgrad GEMMs)
+//   OUT 1: dx_acc (fp32) += dx (pre-norm backward; accumulates into the residual-stream gradient)
+// Writes per-block partial sums [nblk][3][D]: dw, db, and sum(dx) (= bias grad of the Linear that
+// produced x, when there is one).  Grid-stride over rows, fixed order => deterministic.
+// ---------------------------------------------------------------------------------------------
+template <int OUT, bool STABLE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                     const float* __restrict__ inv_amax_i, const float* __restrict__ w,
+                                                     bf16_t* __restrict__ dx_hi, bf16_t* __restrict__ dx_lo,
+                                                     float* __restrict__ dx_acc, float* __restrict__ partial,
+                                                     long long R, int D, int shift_ntok, int shift_fmap) {
+    __shared__ float red[ROWS_PER_BLOCK][3][MAXV * 256];
+    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+    float4 pw[MAXV], pb[MAXV], ps[MAXV];
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) pw[it] = pb[it] = ps[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int quarter = D >> 2;
+    for (long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + wv_; row < R; row += (long long)gridDim.x * ROWS_PER_BLOCK) {
+        RowVals xv, gv;
+        row_load(x + row * D, D, lane, xv);
+        if (shift_ntok > 0) {
+            // d(unshifted)[i][c] = d(shifted)[i + fmap][c] (quarter 0, when that row took its value from i),
+            //                      d(shifted)[i + 1][c]    (quarter 1), d(shifted)[i][c] otherwise
+            const int i = (int)(row % shift_ntok);
+            long long src_h = -1, src_w = -1;
+            if (i > 0) {
+                const int p = i - 1, wq = p % shift_fmap, yq = (p / shift_fmap) % shift_fmap;
+                if (yq < shift_fmap - 1 && i + shift_fmap < shift_ntok) src_h = row + shift_fmap;
+                if (wq < shift_fmap - 1 && i + 1 < shift_ntok) src_w = row + 1;
+            }
+#pragma unroll
+            for (int it = 0; it < MAXV; ++it) {
+                const int e = (lane + it * 64) * 4;
+                if (e >= D) { gv.v[it] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+                long long src = row;
+                if (i > 0) { const int qd = e / quarter; if (qd == 0) src = src_h; else if (qd == 1) src = src_w; }
+                gv.v[it] = src >= 0 ? *reinterpret_cast<const float4*>(dy + src * D + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            row_load(dy + row * D, D, lane, gv);
+        }
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        const float ia = STABLE ? inv_amax_i[row] : 1.f;
+        float s1 = 0.f, s2 = 0.f;
+        float4 xh[MAXV], g[MAXV];
+#pragma unroll
+        for (int it = 0; it < MAXV; ++it) {
+            const int e = (lane + it * 64) * 4;
+            if (e >= D) { xh[it] = g[it] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            const float4 wv = *reinterpret_cast<const float4*>(w + e);
+            float4 xx = xv.v[it];
+            if (STABLE) { xx.x *= ia; xx.y *= ia; xx.z *= ia; xx.w *= ia; }
+            xh[it] = make_float4((xx.x - mean) * rstd, (xx.y - mean) * rstd, (xx.z - mean) * rstd, (xx.w - mean) * rstd);
+            g[it] = make_float4(gv.v[it].x * wv.x, gv.v[it].y * wv.y, gv.v[it].z * wv.z, gv.v[it].w * wv.w);
+            s1 += (g[it].x + g[it].y) + (g[it].z + g[it].w);
+            s2 += (g[it].x * xh[it].x + g[it].y * xh[it].y) + (g[it].z * xh[it].z + g[it].w * xh[it].w);
+            pw[it].x += gv.v[it].x * xh[it].x; pw[it].y += gv.v[it].y * xh[it].y; pw[it].z += gv.v[it].z * xh[it].z; pw[it].w += gv.v[it].w * xh[it].w;
+            pb[it].x += gv.v[it].x; pb[it].y += gv.v[it].y; pb[it].z += gv.v[it].z; pb[it].w += gv.v[it].w;
+        }
+        const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
+        const float sc = STABLE ? rstd * ia : rstd;
+#pragma unroll
+        for (int it = 0; it < MAXV; ++it) {
+            const int e = (lane + it * 64) * 4;
+            if (e >= D) continue;
+            const float d0 = sc * (g[it].x - m1 - xh[it].x * m2), d1 = sc * (g[it].y - m1 - xh[it].y * m2);
+            const float d2 = sc * (g[it].z - m1 - xh[it].z * m2), d3 = sc * (g[it].w - m1 - xh[it].w * m2);
+            ps[it].x += d0; ps[it].y += d1; ps[it].z += d2; ps[it].w += d3;
+            if (OUT == 0) {
+                store_bf16x4(dx_hi + row * D, dx_lo ? dx_lo + row * D : nullptr, e, d0, d1, d2, d3);
+            } else {
+                float4* a = reinterpret_cast<float4*>(dx_acc + row * D + e);
+                float4 o = *a;
+                o.x += d0; o.y += d1; o.z += d2; o.w += d3;
+                *a = o;
+            }
+        }
+    }
+    // block reduce the 4 waves' partials in fixed order
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+        const int e = (lane + it * 64) * 4;
+        *reinterpret_cast<float4*>(&red[wv_][0][e]) = pw[it];
+        *reinterpret_cast<float4*>(&red[wv_][1][e]) = pb[it];
+        *reinterpret_cast<float4*>(&red[wv_][2][e]) = ps[it];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 3 * D; idx += 256) {
+        const int k = idx / D, c = idx % D;
+        partial[((size_t)blockIdx.x * 3 + k) * D + c] = ((red[0][k][c] + red[1][k][c]) + red[2][k][c]) + red[3][k][c];
+    }
+}
+
+// out[k][c] (+)= sum over blocks of partial[blk][k][c]  for the selected k rows -> destination pointers
+__global__ void partial_reduce_kernel(const float* __restrict__ partial, int nblk, int nk, int D,
+                                      float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nk * D) return;
+    const int k = idx / D, c = idx % D;
+    float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
+    if (!o) return;
+    float s = 0.f;
+    for (int bidx = 0; bidx < nblk; ++bidx) s += partial[((size_t)bidx * nk + k) * D + c];
+    o[c] = accumulate ? o[c] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEGLU (np.py:255-258): u = [a | g] (each FP wide, bf16 hi[/lo]) -> gg = a * gelu(g)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float hl(const bf16_t* hi, const bf16_t* lo, size_t i) { return bf2f(hi[i]) + (lo ? bf2f(lo[i]) : 0.f); }
+
+__global__ void geglu_fwd_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* __restrict__ u_lo,
+                                 bf16_t* __restrict__ o_hi, bf16_t* __restrict__ o_lo, long long R, int FP) {
+    const size_t total = (size_t)R * FP / 4;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = (t * 4) / FP;
+        const int c = (int)((t * 4) % FP);
+        const size_t ia = row * 2 * FP + c, ig = ia + FP;
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = hl(u_hi, u_lo, ia + k) * gelu_f(hl(u_hi, u_lo, ig + k));
+        store_bf16x4(o_hi + row * FP, o_lo ? o_lo + row * FP : nullptr, c, o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ void geglu_bwd_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* __restrict__ u_lo,
+                                 const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
+                                 bf16_t* __restrict__ du_hi, bf16_t* __restrict__ du_lo, long long R, int FP) {
+    const size_t total = (size_t)R * FP / 4;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = (t * 4) / FP;
+        const int c = (int)((t * 4) % FP);
+        const size_t ia = row * 2 * FP + c, ig = ia + FP, id = row * FP + c;
+        float da[4], dg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = hl(u_hi, u_lo, ia + k), g = hl(u_hi, u_lo, ig + k), d = hl(d_hi, d_lo, id + k);
+            da[k] = d * gelu_f(g);
+            dg[k] = d * a * gelu_grad_f(g);
+        }
+        store_bf16x4(du_hi + row * 2 * FP, du_lo ? du_lo + row * 2 * FP : nullptr, c, da[0], da[1], da[2], da[3]);
+        store_bf16x4(du_hi + row * 2 * FP, du_lo ? du_lo + row * 2 * FP : nullptr, c + FP, dg[0], dg[1], dg[2], dg[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// casts / transposes (weight preparation, once per optimiser step; small activations)
+// ---------------------------------------------------------------------------------------------
+// dst[r][c] (bf16 hi/lo, ld = ldd) = src[r][c] for c < C, 0 for C <= c < Cp
+__global__ void cast_pad_kernel(const float* __restrict__ src, int lds_, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                int ldd, long long R, int C, int Cp) {
+    const size_t total = (size_t)R * Cp;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = t / Cp;
+        const int c = (int)(t % Cp);
+        const float v = c < C ? src[r * lds_ + c] : 0.f;
+        bf16_t h, l;
+        f2bf_hilo(v, h, l);
+        hi[r * ldd + c] = h;
+        if (lo) lo[r * ldd + c] = l;
+    }
+}
+
+// dst[c][r] (bf16 hi/lo, ld = ldd) = src[r][c]; 32x32 LDS tile transpose
+__global__ void transpose_cast_kernel(const float* __restrict__ src, int lds_, bf16_t* __restrict__ hi,
+                                      bf16_t* __restrict__ lo, int ldd, int R, int C) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < C) ? src[(size_t)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < C && r < R) {
+            bf16_t h, l;
+            f2bf_hilo(tile[tx][k], h, l);
+            hi[(size_t)c * ldd + r] = h;
+            if (lo) lo[(size_t)c * ldd + r] = l;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding assemble (np.py:1940-1944): x[b, 0] = bos; x[b, 1+p] = ((ax1[f] + ax2[y]) + ax3[w]) + frac_grad(W[id])
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ ids, const float* __restrict__ W,
+                                                        const float* __restrict__ ax1, const float* __restrict__ ax2,
+                                                        const float* __restrict__ ax3, const float* __restrict__ bos,
+                                                        float* __restrict__ x, int B, int ntok, int D, int H, int Wd, float frac) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= (long long)B * ntok) return;
+    const int b = (int)(row / ntok), i = (int)(row % ntok);
+    float* o = x + row * D;
+    if (i == 0) {
+        for (int e = lane * 4; e < D; e += 256) *reinterpret_cast<float4*>(o + e) = *reinterpret_cast<const float4*>(bos + e);
+        return;
+    }
+    const int p = i - 1;
+    const int w = p % Wd, y = (p / Wd) % H, f = p / (Wd * H);
+    const long long id = ids[(long long)b * (ntok - 1) + p];
+    const float* wr = W + id * D;
+    for (int e = lane * 4; e < D; e += 256) {
+        const float4 t = *reinterpret_cast<const float4*>(wr + e);
+        const float4 a1 = *reinterpret_cast<const float4*>(ax1 + (size_t)f * D + e);
+        const float4 a2 = *reinterpret_cast<const float4*>(ax2 + (size_t)y * D + e);
+        const float4 a3 = *reinterpret_cast<const float4*>(ax3 + (size_t)w * D + e);
+        float4 em = t;
+        if (frac < 1.f) {   // frac_gradient np.py:83-84: t*frac + t.detach()*(1-frac)
+            const float omf = 1.f - frac;
+            em = make_float4(t.x * frac + t.x * omf, t.y * frac + t.y * omf, t.z * frac + t.z * omf, t.w * frac + t.w * omf);
+        }
+        *reinterpret_cast<float4*>(o + e) = make_float4(((a1.x + a2.x) + a3.x) + em.x, ((a1.y + a2.y) + a3.y) + em.y,
+                                                        ((a1.z + a2.z) + a3.z) + em.z, ((a1.w + a2.w) + a3.w) + em.w);
+    }
+}
+
+// token-embedding gradient: dW[id] += frac * dx  (fp32 atomics: summation order is not fixed)
+__global__ __launch_bounds__(256) void embed_bwd_tok_kernel(const long long* __restrict__ ids, const float* __restrict__ dx,
+                                                            float* __restrict__ dW, int B, int ntok, int D, float frac) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= (long long)B * ntok) return;
+    const int b = (int)(row / ntok), i = (int)(row % ntok);
+    if (i == 0) return;
+    const long long id = ids[(long long)b * (ntok - 1) + (i - 1)];
+    for (int e = lane; e < D; e += 64) atomicAdd(dW + id * D + e, frac * dx[row * D + e]);
+}
+
+// axial / bos gradients, two deterministic stages:
+//  A: T[p][c] = sum_b dx[b][1+p][c]  (p < ntok-1);  T[ntok-1][c] = sum_b dx[b][0][c]  (bos)
+//  B: ax1[f] = sum_{y,w} T, ax2[y] = sum_{f,w} T, ax3[w] = sum_{f,y} T   (one block per axis entry)
+__global__ __launch_bounds__(256) void embed_bwd_possum_kernel(const float* __restrict__ dx, float* __restrict__ T,
+                                                               float* __restrict__ dbos, int B, int ntok, int D) {
+    const int i = blockIdx.x;            // token row inside the sample, 0 = bos
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dx[((size_t)b * ntok + i) * D + c];
+        if (i == 0) dbos[c] += s; else T[(size_t)(i - 1) * D + c] = s;
+    }
+}
+__global__ __launch_bounds__(256) void embed_bwd_axial_kernel(const float* __restrict__ T, float* __restrict__ d1,
+                                                              float* __restrict__ d2, float* __restrict__ d3,
+                                                              int ntok, int D, int F, int H, int Wd) {
+    const int k = blockIdx.x;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < ntok - 1; ++p) {
+            const int w = p % Wd, y = (p / Wd) % H, f = p / (Wd * H);
+            const bool hit = k < F ? (f == k) : (k < F + H ? (y == k - F) : (w == k - F - H));
+            if (hit) s += T[(size_t)p * D + c];
+        }
+        if (k < F) d1[(size_t)k * D + c] += s;
+        else if (k < F + H) d2[(size_t)(k - F) * D + c] += s;
+        else d3[(size_t)(k - F - H) * D + c] += s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cross entropy over fp32 logits [R, C] (np.py:1963): row loss = lse - logit[target];
+// dlogits (bf16 hi/lo) = (softmax - onehot) * grad_scale   (grad_scale = 1/R for the mean)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ tgt,
+                                                     float* __restrict__ row_loss, bf16_t* __restrict__ dl_hi,
+                                                     bf16_t* __restrict__ dl_lo, int C, int ldd, float grad_scale) {
+    __shared__ float sred[4];
+    const long long row = blockIdx.x;
+    const float* lr = logits + row * C;
+    const int tid = threadIdx.x, lane = tid & 63, wv_ = tid >> 6;
+    float m = -3.0e38f;
+    for (int c = tid * 4; c < C; c += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(lr + c);
+        m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    m = wave_max(m);
+    if (lane == 0) sred[wv_] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = tid * 4; c < C; c += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(lr + c);
+        s += (expf(v.x - m) + expf(v.y - m)) + (expf(v.z - m) + expf(v.w - m));
+    }
+    s = wave_sum(s);
+    if (lane == 0) sred[wv_] = s;
+    __syncthreads();
+    s = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    const float lse = m + logf(s);
+    const long long t = tgt[row];
+    if (tid == 0) row_loss[row] = lse - lr[t];
+    if (dl_hi) {
+        const float inv = 1.f / s;
+        for (int c = tid * 4; c < C; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(lr + c);
+            float pz[4] = {expf(v.x - m) * inv, expf(v.y - m) * inv, expf(v.z - m) * inv, expf(v.w - m) * inv};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pz[k] = (pz[k] - ((long long)(c + k) == t ? 1.f : 0.f)) * grad_scale;
+            store_bf16x4(dl_hi + row * ldd, dl_lo ? dl_lo + row * ldd : nullptr, c, pz[0], pz[1], pz[2], pz[3]);
+        }
+    }
+}
+
+// loss = mean(row_loss) in a fixed order (single block)
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, long long n, float* __restrict__ out) {
+    __shared__ float sred[256];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) s += v[i];
+    sred[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sred[threadIdx.x] += sred[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sred[0] / (float)n;
+}
+
+// x[i] *= *scalar  (device scalar: upstream gradient of the loss)
+__global__ void scale_by_dev_scalar_kernel(float* __restrict__ x, size_t n, const float* __restrict__ s) {
+    const float sc = *s;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= sc;
+}
+
+inline int grid_for(size_t work, int per_block = 256, int cap = 4096) {
+    size_t g = (work + per_block - 1) / per_block;
+    if (g > (size_t)cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const float* b, uint16_t* out_hi,
+                              uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R,
+                              int D, int mode, int stable, float eps, hipStream_t stream) {
+    if (!x || !w || !b || !mean || !rstd || D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
+    if (mode == 0 && !out_hi) return AMDNUWA_ERR_ARG;
+    if (mode == 1 && (!out_f32 || !resid || stable)) return AMDNUWA_ERR_ARG;
+    if (stable && !inv_amax) return AMDNUWA_ERR_ARG;
+    if (R <= 0) return AMDNUWA_OK;
+    dim3 grid((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+    if (mode == 0 && !stable) hipLaunchKernelGGL((ln_fwd_kernel<0, false>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps);
+    else if (mode == 0) hipLaunchKernelGGL((ln_fwd_kernel<0, true>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps);
+    else hipLaunchKernelGGL((ln_fwd_kernel<1, false>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+static int ln_bwd_blocks(long long R) {
+    long long nb = (R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    if (nb > 1024) nb = 1024;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+extern "C" size_t amdnuwa_ln_bwd_workspace_bytes(long long R, int D) { return (size_t)ln_bwd_blocks(R) * 3 * D * sizeof(float); }
+
+extern "C" int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* inv_amax,
+                              const float* w, uint16_t* dx_hi, uint16_t* dx_lo, float* dx_acc, float* dw, float* db,
+                              float* dsum, long long R, int D, int shift_ntok, int shift_fmap, int stable, int accumulate,
+                              void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!dy || !x || !mean || !rstd || !w || D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
+    if ((dx_hi == nullptr) == (dx_acc == nullptr)) return AMDNUWA_ERR_ARG;   // exactly one output form
+    if (shift_ntok > 0 && (shift_fmap <= 0 || D % 16)) return AMDNUWA_ERR_ARG;
+    if (stable && !inv_amax) return AMDNUWA_ERR_ARG;
+    if (!workspace || workspace_bytes < amdnuwa_ln_bwd_workspace_bytes(R, D)) return AMDNUWA_ERR_WORKSPACE;
+    if (R <= 0) return AMDNUWA_OK;
+    const int nb = ln_bwd_blocks(R);
+    float* part = (float*)workspace;
+    dim3 grid(nb), block(256);
+    if (dx_hi) {
+        if (stable) hipLaunchKernelGGL((ln_bwd_kernel<0, true>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, part, R, D, shift_ntok, shift_fmap);
+        else hipLaunchKernelGGL((ln_bwd_kernel<0, false>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, part, R, D, shift_ntok, shift_fmap);
+    } else {
+        if (stable) hipLaunchKernelGGL((ln_bwd_kernel<1, true>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, part, R, D, shift_ntok, shift_fmap);
+        else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, part, R, D, shift_ntok, shift_fmap);
+    }
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((3 * D + 255) / 256), dim3(256), 0, stream, part, nb, 3, D, dw, db, dsum, accumulate);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_geglu_fwd(const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* o_hi, uint16_t* o_lo, long long R, int FP, hipStream_t stream) {
+    if (!u_hi || !o_hi || FP % 4) return AMDNUWA_ERR_ARG;
+    if (R <= 0) return AMDNUWA_OK;
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for((size_t)R * FP / 4)), dim3(256), 0, stream, u_hi, u_lo, o_hi, o_lo, R, FP);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_geglu_bwd(const uint16_t* u_hi, const uint16_t* u_lo, const uint16_t* d_hi, const uint16_t* d_lo,
+                                 uint16_t* du_hi, uint16_t* du_lo, long long R, int FP, hipStream_t stream) {
+    if (!u_hi || !d_hi || !du_hi || FP % 4) return AMDNUWA_ERR_ARG;
+    if (R <= 0) return AMDNUWA_OK;
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for((size_t)R * FP / 4)), dim3(256), 0, stream, u_hi, u_lo, d_hi, d_lo, du_hi, du_lo, R, FP);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_cast_pad(const float* src, int ld_src, uint16_t* hi, uint16_t* lo, int ld_dst, long long R, int C, int Cp, hipStream_t stream) {
+    if (!src || !hi || Cp < C || ld_dst < Cp) return AMDNUWA_ERR_ARG;
+    if (R <= 0) return AMDNUWA_OK;
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_for((size_t)R * Cp)), dim3(256), 0, stream, src, ld_src, hi, lo, ld_dst, R, C, Cp);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_transpose_cast(const float* src, int ld_src, uint16_t* hi, uint16_t* lo, int ld_dst, int R, int C, hipStream_t stream) {
+    if (!src || !hi || ld_dst < R) return AMDNUWA_ERR_ARG;
+    if (R <= 0 || C <= 0) return AMDNUWA_OK;
+    hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, stream, src, ld_src, hi, lo, ld_dst, R, C);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_embed_fwd(const long long* ids, const float* W, const float* ax1, const float* ax2, const float* ax3,
+                                 const float* bos, float* x, int B, int ntok, int D, int H, int Wd, float frac, hipStream_t stream) {
+    if (!ids || !W || !ax1 || !ax2 || !ax3 || !bos || !x || D % 4) return AMDNUWA_ERR_ARG;
+    const long long R = (long long)B * ntok;
+    if (R <= 0) return AMDNUWA_OK;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, stream, ids, W, ax1, ax2, ax3, bos, x, B, ntok, D, H, Wd, frac);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" size_t amdnuwa_embed_bwd_workspace_bytes(int ntok, int D) { return (size_t)ntok * D * sizeof(float); }
+
+// all gradient outputs are ACCUMULATED into (caller zero-fills fresh buffers)
+extern "C" int amdnuwa_embed_bwd(const long long* ids, const float* dx, float* dW, float* dax1, float* dax2, float* dax3,
+                                 float* dbos, int B, int ntok, int D, int F, int H, int Wd, float frac, void* workspace,
+                                 size_t workspace_bytes, hipStream_t stream) {
+    if (!ids || !dx || !dW || !dax1 || !dax2 || !dax3 || !dbos) return AMDNUWA_ERR_ARG;
+    if (!workspace || workspace_bytes < amdnuwa_embed_bwd_workspace_bytes(ntok, D)) return AMDNUWA_ERR_WORKSPACE;
+    const long long R = (long long)B * ntok;
+    if (R <= 0) return AMDNUWA_OK;
+    hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, stream, ids, dx, dW, B, ntok, D, frac);
+    LAUNCH_CHECK();
+    float* T = (float*)workspace;
+    hipLaunchKernelGGL(embed_bwd_possum_kernel, dim3(ntok), dim3(256), 0, stream, dx, T, dbos, B, ntok, D);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(embed_bwd_axial_kernel, dim3(F + H + Wd), dim3(256), 0, stream, T, dax1, dax2, dax3, ntok, D, F, H, Wd);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_ce_fwd(const float* logits, const long long* targets, float* row_loss, float* loss, uint16_t* dl_hi,
+                              uint16_t* dl_lo, long long R, int C, int ld_dl, float grad_scale, hipStream_t stream) {
+    if (!logits || !targets || !row_loss || !loss || C % 4) return AMDNUWA_ERR_ARG;
+    if (R <= 0) return AMDNUWA_OK;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, targets, row_loss, dl_hi, dl_lo, C, ld_dl, grad_scale);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, stream, row_loss, R, loss);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_scale_by_device_scalar(float* x, size_t n, const float* scalar, hipStream_t stream) {
+    if (!x || !scalar) return AMDNUWA_ERR_ARG;
+    if (n == 0) return AMDNUWA_OK;
+    hipLaunchKernelGGL(scale_by_dev_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, n, scalar);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}

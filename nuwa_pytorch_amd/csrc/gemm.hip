@@ -1,0 +1,456 @@
+// bf16 MFMA GEMM family for gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+//   gemm_nt : C[M,N]  = alpha * A[M,K] . B[N,K]^T (+ bias[N])      every nn.Linear forward
+//                                                                   (np.py:274-277, 311-313, 401-405, 1819)
+//                                                                   and, with pre-transposed weights, every dgrad
+//   gemm_tn : C[N1,N2] = beta*C + alpha * A[M,N1]^T . B[M,N2]        every weight gradient (reduction over tokens)
+//
+// Both take an optional bf16 "lo" residual per operand (hi+lo split of an fp32 value): with lo
+// operands present the kernel issues 3 MFMAs per product (hi*hi + hi*lo + lo*hi) = parity mode.
+//
+// Token shift (ShiftVideoTokens, np.py:185-253) is folded into the operand LOADER: when
+// shift_ntok > 0, logical row g / feature k of the shifted operand is fetched from row g-fmap
+// (first quarter of the features, zero at y==0), row g-1 (second quarter, zero at w==0) or row g.
+//
+// Tile: 128x128 output per 256-thread workgroup (2x2 waves of 64x64 = 4x4 MFMA fragments),
+// K-step 64 (NT) / 32 token rows (TN), LDS double-buffered with the next tile's global loads
+// in flight during the MFMAs; 16-byte chunks XOR-swizzled so ds_read_b128 / ds_read_b64_tr_b16
+// fragment reads are bank-conflict free.
+#include "common.h"
+#include "../../include/amdnuwa.h"
+
+namespace {
+
+struct GemmArgs {
+    const bf16_t* A; const bf16_t* Alo; long long sA; int lda;
+    const bf16_t* B; const bf16_t* Blo; long long sB; int ldb;
+    void* C; bf16_t* Clo; long long sC; int ldc;
+    const float* bias;
+    float alpha, beta;
+    int M, N, K;            // NT: C[M,N], reduce over K.  TN: C[N1=M... see kernel]
+    int shift_ntok, shift_fmap, shift_dim;
+    int tiles_m, tiles_n;
+    int ksplit_len;         // TN: token rows per split
+    int batch_inner;        // >0: batch index z -> (z / batch_inner) * stride + (z % batch_inner) * stride_in
+    long long sA_in, sB_in, sC_in;
+};
+
+__device__ __forceinline__ long long boff(const GemmArgs& p, long long z, long long s, long long s_in) {
+    return p.batch_inner > 0 ? (z / p.batch_inner) * s + (z % p.batch_inner) * s_in : z * s;
+}
+
+__device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// source-row offset for the token shift. returns 0 (no shift), a negative offset, or INT_MIN (zero fill)
+struct ShiftRow { int off_h, off_w; };
+__device__ __forceinline__ ShiftRow shift_row(long long g, int ntok, int fmap) {
+    ShiftRow s; s.off_h = 0; s.off_w = 0;
+    const int i = (int)(g % ntok);
+    if (i == 0) return s;                     // <bos> row is never shifted
+    const int p = i - 1;
+    const int w = p % fmap, y = (p / fmap) % fmap;
+    s.off_h = (y > 0) ? -fmap : INT_MIN;
+    s.off_w = (w > 0) ? -1 : INT_MIN;
+    return s;
+}
+__device__ __forceinline__ int shift_pick(const ShiftRow& s, int feat, int quarter) {
+    const int q = feat / quarter;
+    return q == 0 ? s.off_h : (q == 1 ? s.off_w : 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT
+// ---------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;       // 16 KiB per operand tile
+
+// byte offset of 16-byte chunk `cc` (0..7) of row `row` inside a [128][64] bf16 tile
+__device__ __forceinline__ int nt_lds_off(int row, int cc) { return row * 128 + ((cc ^ ((row >> 1) & 7)) << 4); }
+
+template <bool X3, bool SHIFT, int EPI>   // EPI 0: fp32 out (+bias), 1: bf16 out (hi [+lo])
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // layout: [buf][A_hi, B_hi, (A_lo, B_lo)]
+    constexpr int NT_ = X3 ? 4 : 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int lid = xcd_remap(blockIdx.x, nwg);
+    const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const long long bz = blockIdx.y;
+    const long long oA = boff(p, bz, p.sA, p.sA_in), oB = boff(p, bz, p.sB, p.sB_in), oC = boff(p, bz, p.sC, p.sC_in);
+    const bf16_t* A = p.A + oA;
+    const bf16_t* B = p.B + oB;
+    const bf16_t* Alo = X3 ? p.Alo + oA : nullptr;
+    const bf16_t* Blo = X3 ? p.Blo + oB : nullptr;
+
+    // loader geometry: 4 chunks per thread per operand; rows (tid>>3) + 32*i, chunk tid&7
+    const int lrow = tid >> 3, lcc = tid & 7;
+    ShiftRow srow[4];
+    if (SHIFT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) srow[i] = shift_row((long long)m0 + lrow + 32 * i, p.shift_ntok, p.shift_fmap);
+    }
+    const int quarter = SHIFT ? (p.shift_dim >> 2) : 1;
+
+    uint4 ra[4], rb[4], ral[4], rbl[4];
+    auto load_tile = [&](int k0) {
+        const int k = k0 + lcc * 8;
+        const bool kin = k < p.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lrow + 32 * i;
+            long long ga = (long long)m0 + r;
+            bool oka = kin && ga < p.M;
+            if (SHIFT && oka) {
+                const int off = shift_pick(srow[i], k, quarter);
+                if (off == INT_MIN) oka = false; else ga += off;
+            }
+            ra[i] = oka ? ldg16(A + ga * p.lda + k) : make_uint4(0, 0, 0, 0);
+            if (X3) ral[i] = oka ? ldg16(Alo + ga * p.lda + k) : make_uint4(0, 0, 0, 0);
+            const long long gb = (long long)n0 + r;
+            const bool okb = kin && gb < p.N;
+            rb[i] = okb ? ldg16(B + gb * p.ldb + k) : make_uint4(0, 0, 0, 0);
+            if (X3) rbl[i] = okb ? ldg16(Blo + gb * p.ldb + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* base = smem + buf * NT_ * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = nt_lds_off(lrow + 32 * i, lcc);
+            *reinterpret_cast<uint4*>(base + off) = ra[i];
+            *reinterpret_cast<uint4*>(base + TILE_BYTES + off) = rb[i];
+            if (X3) {
+                *reinterpret_cast<uint4*>(base + 2 * TILE_BYTES + off) = ral[i];
+                *reinterpret_cast<uint4*>(base + 3 * TILE_BYTES + off) = rbl[i];
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        const char* base = smem + cur * NT_ * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4], afl[4], bfl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra_ = wm * 64 + i * 16 + fr;
+                const int rb_ = wn * 64 + i * 16 + fr;
+                af[i] = *reinterpret_cast<const bf16x8*>(base + nt_lds_off(ra_, ks * 4 + fg));
+                bfr[i] = *reinterpret_cast<const bf16x8*>(base + TILE_BYTES + nt_lds_off(rb_, ks * 4 + fg));
+                if (X3) {
+                    afl[i] = *reinterpret_cast<const bf16x8*>(base + 2 * TILE_BYTES + nt_lds_off(ra_, ks * 4 + fg));
+                    bfl[i] = *reinterpret_cast<const bf16x8*>(base + 3 * TILE_BYTES + nt_lds_off(rb_, ks * 4 + fg));
+                }
+            }
+            // operands swapped (B as the MFMA "A"): D[row = n][col = m] so each lane ends up with
+            // 4 consecutive n of one output row m -> one vector store per fragment.
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (X3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfl[j], af[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], afl[i], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue
+    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long m = (long long)m0 + wm * 64 + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fg * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r] * p.alpha;
+                if (EPI == 0 && p.bias && n + r < p.N) v[r] += p.bias[n + r];
+            }
+            if (EPI == 0) {
+                float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
+                if (vec_ok) *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
+            } else {
+                bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + n;
+                bf16_t h[4], l[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f2bf_hilo(v[r], h[r], l[r]);
+                if (vec_ok) {
+                    *reinterpret_cast<uint2*>(C) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+                    if (p.Clo) *reinterpret_cast<uint2*>(p.Clo + oC + m * p.ldc + n) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                        C[r] = h[r];
+                        if (p.Clo) p.Clo[oC + m * p.ldc + n + r] = l[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN :  P[z][n1][n2] = sum over token rows m of split z of A[m][n1] * B[m][n2]   (fp32 partials)
+// ---------------------------------------------------------------------------------------------
+constexpr int TK = 32;                       // token rows per step
+constexpr int TN_TILE_BYTES = TK * 128 * 2;  // 8 KiB
+
+__device__ __forceinline__ int tn_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+// byte offset of 16-byte chunk cc (0..15) of token row `row` in a [32][128] bf16 tile (32-byte swizzle)
+__device__ __forceinline__ int tn_lds_off(int row, int cc) { return row * 256 + ((((cc >> 1) ^ tn_f(row)) << 5) | ((cc & 1) << 4)); }
+// byte offset of element column `col` (multiple of 4) of row `row`
+__device__ __forceinline__ int tn_lds_elem(int row, int col) { return row * 256 + ((((col >> 4) ^ tn_f(row)) << 5) | ((col & 15) << 1)); }
+
+__device__ __forceinline__ bf16x8 tn_frag(const char* tile, int colbase, int lane) {
+    // MFMA operand with the reduction (token) index along the per-lane vector: lane (c = lane&15,
+    // g = lane>>4) needs tile[8g + j][colbase + c], j = 0..7 -> two transposing LDS reads
+    // (ds_read_b64_tr_b16: within a 16-lane group, lane i receives element (i&3) of the 8-byte
+    // chunks addressed by lanes 4j + (i>>2), j = 0..3).
+    const int t = lane & 15, g = lane >> 4;
+    const int row = 8 * g + (t >> 2), col = colbase + ((t & 3) << 2);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + tn_lds_elem(row, col)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + tn_lds_elem(row + 4, col)));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool X3, bool SHIFT>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT_ = X3 ? 4 : 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int N1 = p.M, N2 = p.N;            // output dims; reduction length = p.K token rows
+    const int tmi = blockIdx.x / p.tiles_n, tni = blockIdx.x % p.tiles_n;
+    const int a0 = tmi * 128, b0 = tni * 128;
+    const long long bz = blockIdx.y;
+    const int z = blockIdx.z;
+    const long long oA = boff(p, bz, p.sA, p.sA_in), oB = boff(p, bz, p.sB, p.sB_in);
+    const bf16_t* A = p.A + oA;
+    const bf16_t* B = p.B + oB;
+    const bf16_t* Alo = X3 ? p.Alo + oA : nullptr;
+    const bf16_t* Blo = X3 ? p.Blo + oB : nullptr;
+    const long long mbeg = (long long)z * p.ksplit_len;
+    const long long mend = min((long long)p.K, mbeg + p.ksplit_len);
+
+    const int lrow = tid >> 4, lcc = tid & 15;   // 2 chunks per thread per operand: rows lrow, lrow+16
+    const int quarter = SHIFT ? (p.shift_dim >> 2) : 1;
+    uint4 ra[2], rb[2], ral[2], rbl[2];
+    auto load_tile = [&](long long mk0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long g = mk0 + lrow + 16 * i;
+            const bool rin = g < mend;
+            const int ca = a0 + lcc * 8, cb = b0 + lcc * 8;
+            const bool oka = rin && ca < N1;
+            ra[i] = oka ? ldg16(A + g * p.lda + ca) : make_uint4(0, 0, 0, 0);
+            if (X3) ral[i] = oka ? ldg16(Alo + g * p.lda + ca) : make_uint4(0, 0, 0, 0);
+            bool okb = rin && cb < N2;
+            long long gb = g;
+            if (SHIFT && okb) {
+                const ShiftRow s = shift_row(g, p.shift_ntok, p.shift_fmap);
+                const int off = shift_pick(s, cb, quarter);
+                if (off == INT_MIN) okb = false; else gb += off;
+            }
+            rb[i] = okb ? ldg16(B + gb * p.ldb + cb) : make_uint4(0, 0, 0, 0);
+            if (X3) rbl[i] = okb ? ldg16(Blo + gb * p.ldb + cb) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* base = smem + buf * NT_ * TN_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int off = tn_lds_off(lrow + 16 * i, lcc);
+            *reinterpret_cast<uint4*>(base + off) = ra[i];
+            *reinterpret_cast<uint4*>(base + TN_TILE_BYTES + off) = rb[i];
+            if (X3) {
+                *reinterpret_cast<uint4*>(base + 2 * TN_TILE_BYTES + off) = ral[i];
+                *reinterpret_cast<uint4*>(base + 3 * TN_TILE_BYTES + off) = rbl[i];
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)((mend - mbeg + TK - 1) / TK);
+    if (nk > 0) {
+        load_tile(mbeg);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(mbeg + (long long)(kt + 1) * TK);
+        const char* base = smem + cur * NT_ * TN_TILE_BYTES;
+        bf16x8 af[4], bfr[4], afl[4], bfl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = tn_frag(base, wm * 64 + i * 16, lane);
+            bfr[i] = tn_frag(base + TN_TILE_BYTES, wn * 64 + i * 16, lane);
+            if (X3) {
+                afl[i] = tn_frag(base + 2 * TN_TILE_BYTES, wm * 64 + i * 16, lane);
+                bfl[i] = tn_frag(base + 3 * TN_TILE_BYTES, wn * 64 + i * 16, lane);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (X3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfl[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], afl[i], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    // partial[bz][z][n1][n2] (dense ld = N2)
+    const int fr = lane & 15, fg = lane >> 4;
+    float* P = partial + ((size_t)bz * gridDim.z + z) * (size_t)N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n1 = a0 + wm * 64 + i * 16 + fr;
+        if (n1 >= N1) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n2 = b0 + wn * 64 + j * 16 + fg * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n2 + r < N2) P[(size_t)n1 * N2 + n2 + r] = acc[i][j][r];
+        }
+    }
+}
+
+// C[bz][n1][n2] = beta*C + alpha * sum_z partial[bz][z][n1][n2]   (fixed order -> deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, long long sC, long long sC_in,
+                                     int batch_inner, int ldc, int N1, int N2, int splits, float alpha, float beta) {
+    const size_t per = (size_t)N1 * N2;
+    const int bz = blockIdx.y;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        const float* P = partial + (size_t)bz * splits * per + e;
+        for (int z = 0; z < splits; ++z) s += P[(size_t)z * per];
+        const int n1 = (int)(e / N2), n2 = (int)(e % N2);
+        const long long oC = batch_inner > 0 ? (long long)(bz / batch_inner) * sC + (long long)(bz % batch_inner) * sC_in : (long long)bz * sC;
+        float* c = C + oC + (size_t)n1 * ldc + n2;
+        *c = (beta != 0.f ? beta * *c : 0.f) + alpha * s;
+    }
+}
+
+}  // namespace
+
+extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
+    if (!d || !d->A || !d->B || !d->C) return AMDNUWA_ERR_ARG;
+    if (d->M <= 0 || d->N <= 0) return AMDNUWA_OK;
+    if (d->K % 8 || d->lda % 8 || d->ldb % 8) return AMDNUWA_ERR_ARG;
+    if ((d->Alo == nullptr) != (d->Blo == nullptr)) return AMDNUWA_ERR_ARG;
+    if (d->shift_ntok > 0 && (d->shift_fmap <= 0 || d->K % 32)) return AMDNUWA_ERR_ARG;
+    GemmArgs p;
+    p.A = (const bf16_t*)d->A; p.Alo = (const bf16_t*)d->Alo; p.sA = d->strideA; p.lda = d->lda;
+    p.B = (const bf16_t*)d->B; p.Blo = (const bf16_t*)d->Blo; p.sB = d->strideB; p.ldb = d->ldb;
+    p.C = d->C; p.Clo = (bf16_t*)d->Clo; p.sC = d->strideC; p.ldc = d->ldc;
+    p.bias = d->bias; p.alpha = d->alpha; p.beta = 0.f;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.shift_ntok = d->shift_ntok; p.shift_fmap = d->shift_fmap; p.shift_dim = d->K;
+    p.tiles_m = (d->M + BM - 1) / BM; p.tiles_n = (d->N + BN - 1) / BN;
+    p.ksplit_len = 0;
+    p.batch_inner = d->batch_inner; p.sA_in = d->strideA_inner; p.sB_in = d->strideB_inner; p.sC_in = d->strideC_inner;
+    const bool x3 = d->Alo != nullptr, sh = d->shift_ntok > 0, ob = d->c_is_bf16 != 0;
+    dim3 grid(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), block(256);
+    const size_t lds = (size_t)2 * (x3 ? 4 : 2) * TILE_BYTES;
+#define NT_LAUNCH(X3, SH, EP)                                                                                        \
+    do {                                                                                                             \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<X3, SH, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((gemm_nt_kernel<X3, SH, EP>), grid, block, lds, stream, p);                               \
+    } while (0)
+    if (x3) { if (sh) { if (ob) NT_LAUNCH(true, true, 1); else NT_LAUNCH(true, true, 0); } else { if (ob) NT_LAUNCH(true, false, 1); else NT_LAUNCH(true, false, 0); } }
+    else    { if (sh) { if (ob) NT_LAUNCH(false, true, 1); else NT_LAUNCH(false, true, 0); } else { if (ob) NT_LAUNCH(false, false, 1); else NT_LAUNCH(false, false, 0); } }
+#undef NT_LAUNCH
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+static int tn_splits(const amdnuwa_gemm_desc* d) {
+    const int tiles = ((d->M + 127) / 128) * ((d->N + 127) / 128) * (d->batch > 0 ? d->batch : 1);
+    int splits = (1024 + tiles - 1) / tiles;             // aim for >= ~4 workgroups per CU
+    const int maxs = (d->K + 255) / 256;                 // at least 256 token rows per split
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+extern "C" size_t amdnuwa_gemm_tn_workspace_bytes(const amdnuwa_gemm_desc* d) {
+    if (!d) return 0;
+    return (size_t)tn_splits(d) * (d->batch > 0 ? d->batch : 1) * (size_t)d->M * d->N * sizeof(float);
+}
+
+// C[N1=M, N2=N] (fp32) = beta*C + alpha * A[K rows, M]^T . B[K rows, N]; shift (if any) applies to B.
+extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!d || !d->A || !d->B || !d->C || d->c_is_bf16) return AMDNUWA_ERR_ARG;
+    if (d->M <= 0 || d->N <= 0) return AMDNUWA_OK;
+    if (d->lda % 8 || d->ldb % 8 || d->M % 8 || d->N % 8) return AMDNUWA_ERR_ARG;
+    if ((d->Alo == nullptr) != (d->Blo == nullptr)) return AMDNUWA_ERR_ARG;
+    if (d->shift_ntok > 0 && (d->shift_fmap <= 0 || d->N % 32)) return AMDNUWA_ERR_ARG;
+    if (workspace_bytes < amdnuwa_gemm_tn_workspace_bytes(d) || !workspace) return AMDNUWA_ERR_WORKSPACE;
+    GemmArgs p;
+    p.A = (const bf16_t*)d->A; p.Alo = (const bf16_t*)d->Alo; p.sA = d->strideA; p.lda = d->lda;
+    p.B = (const bf16_t*)d->B; p.Blo = (const bf16_t*)d->Blo; p.sB = d->strideB; p.ldb = d->ldb;
+    p.C = d->C; p.Clo = nullptr; p.sC = d->strideC; p.ldc = d->ldc;
+    p.bias = nullptr; p.alpha = d->alpha; p.beta = d->beta;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.shift_ntok = d->shift_ntok; p.shift_fmap = d->shift_fmap; p.shift_dim = d->N;
+    p.tiles_m = (d->M + 127) / 128; p.tiles_n = (d->N + 127) / 128;
+    const int splits = tn_splits(d);
+    int len = (d->K + splits - 1) / splits;
+    len = (len + TK - 1) / TK * TK;
+    p.ksplit_len = len;
+    p.batch_inner = d->batch_inner; p.sA_in = d->strideA_inner; p.sB_in = d->strideB_inner; p.sC_in = d->strideC_inner;
+    const int batch = d->batch > 0 ? d->batch : 1;
+    const bool x3 = d->Alo != nullptr, sh = d->shift_ntok > 0;
+    dim3 grid(p.tiles_m * p.tiles_n, batch, splits), block(256);
+    const size_t lds = (size_t)2 * (x3 ? 4 : 2) * TN_TILE_BYTES;
+    float* part = (float*)workspace;
+    if (x3) { if (sh) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, block, lds, stream, p, part);
+              else    hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, block, lds, stream, p, part); }
+    else    { if (sh) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, block, lds, stream, p, part);
+              else    hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, block, lds, stream, p, part); }
+    LAUNCH_CHECK();
+    const size_t per = (size_t)d->M * d->N;
+    int rb = (int)((per + 255) / 256); if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb, batch), dim3(256), 0, stream, part, (float*)d->C, (long long)d->strideC,
+                       (long long)d->strideC_inner, d->batch_inner, d->ldc, d->M, d->N, splits, d->alpha, d->beta);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}

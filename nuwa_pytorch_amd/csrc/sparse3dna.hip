@@ -1,0 +1,665 @@
+// Fused causal 3-D nearby attention core (Sparse3DNA.forward np.py:488-608) for gfx950.
+//
+// The reference materialises unfolded K and V of shape (b*h, n, K+1, d) with unfoldNd
+// (np.py:526-534); here nothing of size n*J*d exists.  One workgroup owns one query ROW of the
+// token grid (all W queries (f, y, 0..W-1), all heads): for every causal tap plane (a, b) it
+// stages the key row (f - (kf-1-a)df, y - (kh-1-b)dh, 0..W-1) of all heads in LDS once, and the
+// kw taps along w of all W queries read it from there.  Scores for all (query, tap, head) of the
+// row live in LDS (W*J*h fp32 <= 23.5 KiB), so the fp32 softmax and the talking-heads 8x8 mix
+// (np.py:554-558) happen in-workgroup before the P.V pass.
+//
+// Thread map: t = ((w*NH + h)*4 + c): 4 lanes share one (query, head) and split the head dim in
+// chunks of DH/4 (a key/value row of one query position is read as one contiguous 2*NH*DH bytes).
+//
+// Backward is split so that it needs no atomics and is bit-reproducible:
+//   bwd_q  (query-centric, per query row): recompute P, dP' = dO.V, dP = W^T dP', ds, dq; writes
+//          ds and P' (fp32, [B][nq][J][NH]) + per-workgroup partials for dW_th and the <bos> k/v.
+//   bwd_kv (key-centric,  per key row): each key position PULLS from the <= K future queries that
+//          attend to it (the transposed gather):  dk = scale * sum ds*q,  dv = sum P'*dO.
+//   bwd_fin: fixed-order reduction of the partials (dW_th, dk[bos], dv[bos] + dO[bos]).
+//
+// hi/lo: every bf16 input may come with a bf16 residual (value = hi + lo); arithmetic is fp32 FMA.
+#include "common.h"
+#include "../../include/amdnuwa.h"
+
+namespace {
+
+struct S3Args {
+    const bf16_t *q, *k, *v, *ql, *kl, *vl; int ld;       // q/k/v rows: [B*ntok, ld]
+    bf16_t *o, *ol; int ldo;                              // fwd out
+    const bf16_t *dO, *dOl; int lddo;                     // bwd in
+    bf16_t *dq, *dk, *dv, *dql, *dkl, *dvl; int ldd;      // bwd out
+    const float* wth;                                     // [NH][NH] talking heads (g, h)
+    float *ds, *pm;                                       // [B][nq][J][NH]
+    float *part_th, *part_k0, *part_v0;                   // [B*F*H][NH*NH], [B*F*H][NH*DH] x2
+    float* dwth;                                          // [NH*NH] accumulated
+    int B, ntok, F, H, W, kf, kh, kw, df, dh, dw, NH;
+    float scale;
+    int accumulate;
+};
+
+constexpr float NEG_MAX = -3.4028234663852886e38f;
+
+template <int CH>
+__device__ __forceinline__ void load_chunk(const bf16_t* hi, const bf16_t* lo, float* f) {
+#pragma unroll
+    for (int v8 = 0; v8 < CH / 8; ++v8) {
+        const uint4 u = *reinterpret_cast<const uint4*>(hi + v8 * 8);
+        f[v8 * 8 + 0] = lo_f(u.x); f[v8 * 8 + 1] = hi_f(u.x); f[v8 * 8 + 2] = lo_f(u.y); f[v8 * 8 + 3] = hi_f(u.y);
+        f[v8 * 8 + 4] = lo_f(u.z); f[v8 * 8 + 5] = hi_f(u.z); f[v8 * 8 + 6] = lo_f(u.w); f[v8 * 8 + 7] = hi_f(u.w);
+        if (lo) {
+            const uint4 l = *reinterpret_cast<const uint4*>(lo + v8 * 8);
+            f[v8 * 8 + 0] += lo_f(l.x); f[v8 * 8 + 1] += hi_f(l.x); f[v8 * 8 + 2] += lo_f(l.y); f[v8 * 8 + 3] += hi_f(l.y);
+            f[v8 * 8 + 4] += lo_f(l.z); f[v8 * 8 + 5] += hi_f(l.z); f[v8 * 8 + 6] += lo_f(l.w); f[v8 * 8 + 7] += hi_f(l.w);
+        }
+    }
+}
+template <int CH>
+__device__ __forceinline__ void store_chunk(bf16_t* hi, bf16_t* lo, const float* f) {
+#pragma unroll
+    for (int v8 = 0; v8 < CH / 8; ++v8) {
+        bf16_t h[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f2bf_hilo(f[v8 * 8 + e], h[e], l[e]);
+        *reinterpret_cast<uint4*>(hi + v8 * 8) = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
+        if (lo) *reinterpret_cast<uint4*>(lo + v8 * 8) = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
+    }
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    return v;
+}
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    v = fmaxf(v, __shfl_xor(v, 2, 64));
+    return v;
+}
+
+// stage one grid row (fr, yr, 0..W-1) of `src` (all heads) into LDS as fp32-ready bf16 hi[/lo] chunks.
+// each active thread moves the chunk of its own (w, h, c); rows beyond the sequence are zero.
+template <int CH>
+__device__ __forceinline__ void stage_row(const S3Args& a, const bf16_t* src, const bf16_t* srcl, int coloff, int b, int fr,
+                                          int yr, int w, int h, int c, bool act, bf16_t* lds_hi, bf16_t* lds_lo) {
+    if (!act) return;
+    const int p = (fr * a.H + yr) * a.W + w;
+    const bool ok = (1 + p) < a.ntok;
+    const size_t g = ((size_t)b * a.ntok + 1 + p) * a.ld + coloff + h * (CH * 4) + c * CH;
+    const int slot = ((w * a.NH + h) * 4 + c) * CH;
+#pragma unroll
+    for (int v8 = 0; v8 < CH / 8; ++v8) {
+        *reinterpret_cast<uint4*>(lds_hi + slot + v8 * 8) = ok ? *reinterpret_cast<const uint4*>(src + g + v8 * 8) : make_uint4(0, 0, 0, 0);
+        if (srcl) *reinterpret_cast<uint4*>(lds_lo + slot + v8 * 8) = ok ? *reinterpret_cast<const uint4*>(srcl + g + v8 * 8) : make_uint4(0, 0, 0, 0);
+    }
+}
+
+// scores + softmax for one query row: fills SP[(w*J + j)*NH + h] with P (fp32).  Shared by fwd and bwd_q.
+template <int DH>
+__device__ __forceinline__ void scores_softmax(const S3Args& a, int b, int f, int y, int w, int h, int c, bool act, bool qvalid,
+                                               const float* qf, float* SP, bf16_t* st_hi, bf16_t* st_lo, int J) {
+    constexpr int CH = DH / 4;
+    const int t = threadIdx.x, nt = blockDim.x;
+    for (int e = t; e < a.W * J * a.NH; e += nt) SP[e] = NEG_MAX;
+    __syncthreads();
+    // <bos> key: slot j = 0
+    if (qvalid) {
+        float kf_[CH];
+        const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
+        load_chunk<CH>(a.k + g, a.kl ? a.kl + g : nullptr, kf_);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) s += qf[e] * kf_[e];
+        s = quad_sum(s);
+        if (c == 0) SP[(w * J + 0) * a.NH + h] = s * a.scale;
+    }
+    for (int ta = 0; ta < a.kf; ++ta) {
+        const int fr = f - (a.kf - 1 - ta) * a.df;
+        if (fr < 0) continue;
+        for (int tb = 0; tb < a.kh; ++tb) {
+            const int yr = y - (a.kh - 1 - tb) * a.dh;
+            if (yr < 0) continue;
+            __syncthreads();
+            stage_row<CH>(a, a.k, a.kl, 0, b, fr, yr, w, h, c, act, st_hi, st_lo);
+            __syncthreads();
+            if (qvalid) {
+                for (int tc = 0; tc < a.kw; ++tc) {
+                    const int wr = w - (a.kw - 1 - tc) * a.dw;
+                    if (wr < 0) continue;
+                    float kf_[CH];
+                    const int slot = ((wr * a.NH + h) * 4 + c) * CH;
+                    load_chunk<CH>(st_hi + slot, a.kl ? st_lo + slot : nullptr, kf_);
+                    float s = 0.f;
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) s += qf[e] * kf_[e];
+                    s = quad_sum(s);
+                    const int j = 1 + (ta * a.kh + tb) * a.kw + tc;
+                    if (c == 0) SP[(w * J + j) * a.NH + h] = s * a.scale;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // fp32 softmax over the J slots of each (w, h): the 4 lanes of the group split j
+    if (act) {
+        float m = NEG_MAX;
+        for (int j = c; j < J; j += 4) m = fmaxf(m, SP[(w * J + j) * a.NH + h]);
+        m = quad_max(m);
+        float s = 0.f;
+        for (int j = c; j < J; j += 4) s += expf(SP[(w * J + j) * a.NH + h] - m);
+        s = quad_sum(s);
+        const float inv = 1.f / s;
+        for (int j = c; j < J; j += 4) {
+            const int idx = (w * J + j) * a.NH + h;
+            SP[idx] = expf(SP[idx] - m) * inv;
+        }
+    }
+    __syncthreads();
+}
+
+template <int DH>
+__global__ __launch_bounds__(512) void s3_fwd_kernel(S3Args a) {
+    constexpr int CH = DH / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int J = a.kf * a.kh * a.kw + 1;
+    const int stage_elems = a.W * a.NH * DH;
+    bf16_t* st_hi = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* st_lo = st_hi + stage_elems;
+    float* SP = reinterpret_cast<float*>(smem + (size_t)stage_elems * (a.kl ? 4 : 2));
+    __shared__ float wsh[64];
+    const int t = threadIdx.x, c = t & 3, wh = t >> 2, h = wh % a.NH, w = wh / a.NH;
+    const bool act = w < a.W;
+    const int rows = a.F * a.H;
+    const int b = blockIdx.x / rows, ry = blockIdx.x % rows, f = ry / a.H, y = ry % a.H;
+    const int i = 1 + ry * a.W + w;
+    const bool qvalid = act && i < a.ntok;
+    if (t < a.NH * a.NH) wsh[t] = a.wth[t];
+    // <bos> output row = its own value (np.py:499, 608)
+    if (ry == 0) {
+        const int inner = a.NH * DH;
+        for (int e = t; e < inner; e += blockDim.x) {
+            const size_t gi = ((size_t)b * a.ntok) * a.ld + e, go = ((size_t)b * a.ntok) * a.ldo + e;
+            a.o[go] = a.v[gi];
+            if (a.ol) a.ol[go] = a.vl ? a.vl[gi] : (bf16_t)0;
+        }
+    }
+    if (ry * a.W + 1 >= a.ntok) return;   // whole row beyond the sequence (uniform)
+    float qf[CH];
+    if (qvalid) {
+        const size_t g = ((size_t)b * a.ntok + i) * a.ld + h * DH + c * CH;
+        load_chunk<CH>(a.q + g, a.ql ? a.ql + g : nullptr, qf);
+    }
+    scores_softmax<DH>(a, b, f, y, w, h, c, act, qvalid, qf, SP, st_hi, st_lo, J);
+    // talking heads: P'[g] = sum_h Wth[g][h] P[h] per (w, j), in place
+    for (int item = t; item < a.W * J; item += blockDim.x) {
+        float pv[8], out[8];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) pv[hh] = hh < a.NH ? SP[item * a.NH + hh] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < 8; ++hh) s += (g < a.NH && hh < a.NH ? wsh[g * a.NH + hh] : 0.f) * pv[hh];
+            out[g] = s;
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) if (g < a.NH) SP[item * a.NH + g] = out[g];
+    }
+    __syncthreads();
+    // P'.V
+    float of[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) of[e] = 0.f;
+    if (qvalid) {
+        float vf[CH];
+        const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
+        load_chunk<CH>(a.v + g, a.vl ? a.vl + g : nullptr, vf);
+        const float pj = SP[(w * J + 0) * a.NH + h];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) of[e] += pj * vf[e];
+    }
+    for (int ta = 0; ta < a.kf; ++ta) {
+        const int fr = f - (a.kf - 1 - ta) * a.df;
+        if (fr < 0) continue;
+        for (int tb = 0; tb < a.kh; ++tb) {
+            const int yr = y - (a.kh - 1 - tb) * a.dh;
+            if (yr < 0) continue;
+            __syncthreads();
+            stage_row<CH>(a, a.v, a.vl, 0, b, fr, yr, w, h, c, act, st_hi, st_lo);
+            __syncthreads();
+            if (qvalid) {
+                for (int tc = 0; tc < a.kw; ++tc) {
+                    const int wr = w - (a.kw - 1 - tc) * a.dw;
+                    if (wr < 0) continue;
+                    float vf[CH];
+                    const int slot = ((wr * a.NH + h) * 4 + c) * CH;
+                    load_chunk<CH>(st_hi + slot, a.vl ? st_lo + slot : nullptr, vf);
+                    const float pj = SP[(w * J + 1 + (ta * a.kh + tb) * a.kw + tc) * a.NH + h];
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) of[e] += pj * vf[e];
+                }
+            }
+        }
+    }
+    if (qvalid) {
+        const size_t g = ((size_t)b * a.ntok + i) * a.ldo + h * DH + c * CH;
+        store_chunk<CH>(a.o + g, a.ol ? a.ol + g : nullptr, of);
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
+    constexpr int CH = DH / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int J = a.kf * a.kh * a.kw + 1;
+    const int stage_elems = a.W * a.NH * DH;
+    const int nsp = a.W * J * a.NH;
+    bf16_t* st_hi = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* st_lo = st_hi + stage_elems;
+    float* SP = reinterpret_cast<float*>(smem + (size_t)stage_elems * (a.kl ? 4 : 2));   // P, later unchanged
+    float* DP = SP + nsp;                                                   // dP' -> dP -> ds
+    float* RED = DP + nsp;                                                  // [8][64] dW_th partials / [W][inner] bos partials
+    __shared__ float wsh[64];
+    const int t = threadIdx.x, c = t & 3, wh = t >> 2, h = wh % a.NH, w = wh / a.NH;
+    const bool act = w < a.W;
+    const int rows = a.F * a.H, inner = a.NH * DH;
+    const int b = blockIdx.x / rows, ry = blockIdx.x % rows, f = ry / a.H, y = ry % a.H;
+    const int i = 1 + ry * a.W + w;
+    const bool qvalid = act && i < a.ntok;
+    const int nq = a.ntok - 1;
+    if (t < a.NH * a.NH) wsh[t] = a.wth[t];
+    float* pth = a.part_th + (size_t)blockIdx.x * a.NH * a.NH;
+    float* pk0 = a.part_k0 + (size_t)blockIdx.x * inner;
+    float* pv0 = a.part_v0 + (size_t)blockIdx.x * inner;
+    if (ry == 0) {   // dq of the <bos> row is zero (its query is never used)
+        for (int e = t; e < inner; e += blockDim.x) {
+            const size_t go = ((size_t)b * a.ntok) * a.ldd + e;
+            a.dq[go] = 0;
+            if (a.dql) a.dql[go] = 0;
+        }
+    }
+    if (ry * a.W + 1 >= a.ntok) {   // row beyond the sequence: contributes nothing
+        for (int e = t; e < a.NH * a.NH; e += blockDim.x) pth[e] = 0.f;
+        for (int e = t; e < inner; e += blockDim.x) { pk0[e] = 0.f; pv0[e] = 0.f; }
+        return;
+    }
+    float qf[CH], dof[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { qf[e] = 0.f; dof[e] = 0.f; }
+    if (qvalid) {
+        const size_t g = ((size_t)b * a.ntok + i) * a.ld + h * DH + c * CH;
+        load_chunk<CH>(a.q + g, a.ql ? a.ql + g : nullptr, qf);
+        const size_t gd = ((size_t)b * a.ntok + i) * a.lddo + h * DH + c * CH;
+        load_chunk<CH>(a.dO + gd, a.dOl ? a.dOl + gd : nullptr, dof);
+    }
+    scores_softmax<DH>(a, b, f, y, w, h, c, act, qvalid, qf, SP, st_hi, st_lo, J);
+    // P' = mix(P) -> global (needed by bwd_kv); P stays in SP
+    for (int item = t; item < a.W * J; item += blockDim.x) {
+        const int wq = item / J, j = item % J;
+        const int iq = 1 + ry * a.W + wq;
+        float pv[8];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) pv[hh] = hh < a.NH ? SP[item * a.NH + hh] : 0.f;
+        if (iq < a.ntok) {
+            float* dst = a.pm + (((size_t)b * nq + (iq - 1)) * J + j) * a.NH;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                float s = 0.f;
+#pragma unroll
+                for (int hh = 0; hh < 8; ++hh) s += (g < a.NH && hh < a.NH ? wsh[g * a.NH + hh] : 0.f) * pv[hh];
+                if (g < a.NH) dst[g] = s;
+            }
+        }
+    }
+    for (int e = t; e < nsp; e += blockDim.x) DP[e] = 0.f;
+    __syncthreads();
+    // dP'[w][j][g] = dO[w][g] . v_j[g]
+    if (qvalid) {
+        float vf[CH];
+        const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
+        load_chunk<CH>(a.v + g, a.vl ? a.vl + g : nullptr, vf);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) s += dof[e] * vf[e];
+        s = quad_sum(s);
+        if (c == 0) DP[(w * J + 0) * a.NH + h] = s;
+    }
+    for (int ta = 0; ta < a.kf; ++ta) {
+        const int fr = f - (a.kf - 1 - ta) * a.df;
+        if (fr < 0) continue;
+        for (int tb = 0; tb < a.kh; ++tb) {
+            const int yr = y - (a.kh - 1 - tb) * a.dh;
+            if (yr < 0) continue;
+            __syncthreads();
+            stage_row<CH>(a, a.v, a.vl, 0, b, fr, yr, w, h, c, act, st_hi, st_lo);
+            __syncthreads();
+            if (qvalid) {
+                for (int tc = 0; tc < a.kw; ++tc) {
+                    const int wr = w - (a.kw - 1 - tc) * a.dw;
+                    if (wr < 0) continue;
+                    float vf[CH];
+                    const int slot = ((wr * a.NH + h) * 4 + c) * CH;
+                    load_chunk<CH>(st_hi + slot, a.vl ? st_lo + slot : nullptr, vf);
+                    float s = 0.f;
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) s += dof[e] * vf[e];
+                    s = quad_sum(s);
+                    if (c == 0) DP[(w * J + 1 + (ta * a.kh + tb) * a.kw + tc) * a.NH + h] = s;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // dW_th[g][h] partial = sum_{w,j} dP'[g] * P[h]   (thread = (g,h) pair x 8 item groups)
+    {
+        const int pair = t & 63, grp = t >> 6, ng = blockDim.x >> 6;
+        const int g = pair / a.NH, hh = pair % a.NH;
+        float acc = 0.f;
+        if (pair < a.NH * a.NH)
+            for (int item = grp; item < a.W * J; item += ng) acc += DP[item * a.NH + g] * SP[item * a.NH + hh];
+        RED[grp * 64 + pair] = acc;
+        __syncthreads();
+        if (t < a.NH * a.NH) {
+            float s = 0.f;
+            for (int k = 0; k < ng; ++k) s += RED[k * 64 + t];
+            pth[t] = s;
+        }
+        __syncthreads();
+    }
+    // dP[h] = sum_g Wth[g][h] dP'[g]   (in place, item-local)
+    for (int item = t; item < a.W * J; item += blockDim.x) {
+        float dv_[8], out[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) dv_[g] = g < a.NH ? DP[item * a.NH + g] : 0.f;
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += (g < a.NH && hh < a.NH ? wsh[g * a.NH + hh] : 0.f) * dv_[g];
+            out[hh] = s;
+        }
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) if (hh < a.NH) DP[item * a.NH + hh] = out[hh];
+    }
+    __syncthreads();
+    // ds = P * (dP - sum_j P dP)
+    if (act) {
+        float d = 0.f;
+        for (int j = c; j < J; j += 4) d += SP[(w * J + j) * a.NH + h] * DP[(w * J + j) * a.NH + h];
+        d = quad_sum(d);
+        for (int j = c; j < J; j += 4) {
+            const int idx = (w * J + j) * a.NH + h;
+            const float dsv = SP[idx] * (DP[idx] - d);
+            DP[idx] = dsv;
+            if (qvalid) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * a.NH + h] = dsv;
+        }
+    }
+    __syncthreads();
+    // dq = scale * sum_j ds_j k_j ;  <bos> partials: dk0 += scale*ds_0*q, dv0 += P'_0*dO
+    float dqf[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) dqf[e] = 0.f;
+    float k0c[CH], v0c[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { k0c[e] = 0.f; v0c[e] = 0.f; }
+    if (qvalid) {
+        float kf_[CH];
+        const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
+        load_chunk<CH>(a.k + g, a.kl ? a.kl + g : nullptr, kf_);
+        const float d0 = DP[(w * J + 0) * a.NH + h];
+        float pm0 = 0.f;                                        // P'[w][0][g = h] = sum_hh Wth[h][hh] P[w][0][hh]
+        for (int hh = 0; hh < a.NH; ++hh) pm0 += wsh[h * a.NH + hh] * SP[(w * J + 0) * a.NH + hh];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            dqf[e] += d0 * kf_[e];
+            k0c[e] = a.scale * d0 * qf[e];
+            v0c[e] = pm0 * dof[e];
+        }
+    }
+    for (int ta = 0; ta < a.kf; ++ta) {
+        const int fr = f - (a.kf - 1 - ta) * a.df;
+        if (fr < 0) continue;
+        for (int tb = 0; tb < a.kh; ++tb) {
+            const int yr = y - (a.kh - 1 - tb) * a.dh;
+            if (yr < 0) continue;
+            __syncthreads();
+            stage_row<CH>(a, a.k, a.kl, 0, b, fr, yr, w, h, c, act, st_hi, st_lo);
+            __syncthreads();
+            if (qvalid) {
+                for (int tc = 0; tc < a.kw; ++tc) {
+                    const int wr = w - (a.kw - 1 - tc) * a.dw;
+                    if (wr < 0) continue;
+                    float kf_[CH];
+                    const int slot = ((wr * a.NH + h) * 4 + c) * CH;
+                    load_chunk<CH>(st_hi + slot, a.kl ? st_lo + slot : nullptr, kf_);
+                    const float dj = DP[(w * J + 1 + (ta * a.kh + tb) * a.kw + tc) * a.NH + h];
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) dqf[e] += dj * kf_[e];
+                }
+            }
+        }
+    }
+    if (qvalid) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) dqf[e] *= a.scale;
+        const size_t g = ((size_t)b * a.ntok + i) * a.ldd + h * DH + c * CH;
+        store_chunk<CH>(a.dq + g, a.dql ? a.dql + g : nullptr, dqf);
+    }
+    // reduce the <bos> partials over the W queries of the row (fixed order), via LDS (reuses SP/DP space),
+    // one of the two at a time: needs W*inner floats <= 2*nsp (checked on the host)
+    float* RK = SP;                       // [W][inner]
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) RK[w * inner + h * DH + c * CH + e] = which ? v0c[e] : k0c[e];
+        }
+        __syncthreads();
+        for (int e = t; e < inner; e += blockDim.x) {
+            float sk = 0.f;
+            for (int ww = 0; ww < a.W; ++ww) sk += RK[ww * inner + e];
+            (which ? pv0 : pk0)[e] = sk;
+        }
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(512) void s3_bwd_kv_kernel(S3Args a) {
+    constexpr int CH = DH / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int J = a.kf * a.kh * a.kw + 1;
+    const int stage_elems = a.W * a.NH * DH;
+    bf16_t* sq_hi = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* sq_lo = sq_hi + stage_elems;
+    bf16_t* sd_hi = sq_lo + stage_elems;
+    bf16_t* sd_lo = sd_hi + stage_elems;
+    const int t = threadIdx.x, c = t & 3, wh = t >> 2, h = wh % a.NH, w = wh / a.NH;
+    const bool act = w < a.W;
+    const int rows = a.F * a.H;
+    const int b = blockIdx.x / rows, ry = blockIdx.x % rows, f = ry / a.H, y = ry % a.H;
+    const int ik = 1 + ry * a.W + w;                 // key row index inside the sample
+    const bool kvalid = act && ik < a.ntok;
+    const int nq = a.ntok - 1;
+    if (ry * a.W + 1 >= a.ntok) return;
+    float dkf[CH], dvf[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { dkf[e] = 0.f; dvf[e] = 0.f; }
+    for (int ta = 0; ta < a.kf; ++ta) {
+        const int fq = f + (a.kf - 1 - ta) * a.df;
+        if (fq >= a.F) continue;
+        for (int tb = 0; tb < a.kh; ++tb) {
+            const int yq = y + (a.kh - 1 - tb) * a.dh;
+            if (yq >= a.H) continue;
+            if ((fq * a.H + yq) * a.W + 1 >= a.ntok) continue;     // query row beyond the sequence (uniform)
+            __syncthreads();
+            // stage the q row and the dO row of the attending query row
+            if (act) {
+                const int pq = (fq * a.H + yq) * a.W + w;
+                const bool ok = (1 + pq) < a.ntok;
+                const size_t gq = ((size_t)b * a.ntok + 1 + pq) * a.ld + h * DH + c * CH;
+                const size_t gd = ((size_t)b * a.ntok + 1 + pq) * a.lddo + h * DH + c * CH;
+                const int slot = ((w * a.NH + h) * 4 + c) * CH;
+#pragma unroll
+                for (int v8 = 0; v8 < CH / 8; ++v8) {
+                    *reinterpret_cast<uint4*>(sq_hi + slot + v8 * 8) = ok ? *reinterpret_cast<const uint4*>(a.q + gq + v8 * 8) : make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(sd_hi + slot + v8 * 8) = ok ? *reinterpret_cast<const uint4*>(a.dO + gd + v8 * 8) : make_uint4(0, 0, 0, 0);
+                    if (a.ql) *reinterpret_cast<uint4*>(sq_lo + slot + v8 * 8) = ok ? *reinterpret_cast<const uint4*>(a.ql + gq + v8 * 8) : make_uint4(0, 0, 0, 0);
+                    if (a.dOl) *reinterpret_cast<uint4*>(sd_lo + slot + v8 * 8) = ok ? *reinterpret_cast<const uint4*>(a.dOl + gd + v8 * 8) : make_uint4(0, 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (kvalid) {
+                for (int tc = 0; tc < a.kw; ++tc) {
+                    const int wq = w + (a.kw - 1 - tc) * a.dw;
+                    if (wq >= a.W) continue;
+                    const int pq = (fq * a.H + yq) * a.W + wq;
+                    if (1 + pq >= a.ntok) continue;
+                    const int j = 1 + (ta * a.kh + tb) * a.kw + tc;
+                    const size_t ci = (((size_t)b * nq + pq) * J + j) * a.NH + h;
+                    const float dsv = a.ds[ci], pmv = a.pm[ci];
+                    float qq[CH], dd[CH];
+                    const int slot = ((wq * a.NH + h) * 4 + c) * CH;
+                    load_chunk<CH>(sq_hi + slot, a.ql ? sq_lo + slot : nullptr, qq);
+                    load_chunk<CH>(sd_hi + slot, a.dOl ? sd_lo + slot : nullptr, dd);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) { dkf[e] += dsv * qq[e]; dvf[e] += pmv * dd[e]; }
+                }
+            }
+        }
+    }
+    if (kvalid) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) dkf[e] *= a.scale;
+        const size_t g = ((size_t)b * a.ntok + ik) * a.ldd + h * DH + c * CH;
+        store_chunk<CH>(a.dk + g, a.dkl ? a.dkl + g : nullptr, dkf);
+        store_chunk<CH>(a.dv + g, a.dvl ? a.dvl + g : nullptr, dvf);
+    }
+}
+
+// fixed-order reductions: dW_th (+= over all workgroups); per sample dk[bos], dv[bos] (+ dO[bos])
+__global__ __launch_bounds__(256) void s3_bwd_fin_kernel(S3Args a, int DH) {
+    const int rows = a.F * a.H, inner = a.NH * DH;
+    if ((int)blockIdx.x == a.B) {
+        for (int e = threadIdx.x; e < a.NH * a.NH; e += blockDim.x) {
+            float s = 0.f;
+            for (int k = 0; k < a.B * rows; ++k) s += a.part_th[(size_t)k * a.NH * a.NH + e];
+            a.dwth[e] = a.accumulate ? a.dwth[e] + s : s;
+        }
+        return;
+    }
+    const int b = blockIdx.x;
+    for (int e = threadIdx.x; e < inner; e += blockDim.x) {
+        float sk = 0.f, sv = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            sk += a.part_k0[((size_t)b * rows + r) * inner + e];
+            sv += a.part_v0[((size_t)b * rows + r) * inner + e];
+        }
+        const size_t gi = ((size_t)b * a.ntok) * a.lddo + e, go = ((size_t)b * a.ntok) * a.ldd + e;
+        sv += bf2f(a.dO[gi]) + (a.dOl ? bf2f(a.dOl[gi]) : 0.f);
+        bf16_t hh, ll;
+        f2bf_hilo(sk, hh, ll); a.dk[go] = hh; if (a.dkl) a.dkl[go] = ll;
+        f2bf_hilo(sv, hh, ll); a.dv[go] = hh; if (a.dvl) a.dvl[go] = ll;
+    }
+}
+
+int check_geom(const amdnuwa_s3_geom* g) {
+    if (!g) return AMDNUWA_ERR_ARG;
+    if (g->dim_head != 32 && g->dim_head != 64) return AMDNUWA_ERR_UNSUPPORTED;
+    if (g->heads < 1 || g->heads > 8 || g->W < 1 || g->W * g->heads * 4 > 512) return AMDNUWA_ERR_UNSUPPORTED;
+    if (g->kf < 1 || g->kh < 1 || g->kw < 1 || g->df < 1 || g->dh < 1 || g->dw < 1) return AMDNUWA_ERR_ARG;
+    if (g->ntok < 1 || g->ntok - 1 > g->F * g->H * g->W) return AMDNUWA_ERR_ARG;
+    return AMDNUWA_OK;
+}
+void fill_geom(S3Args& a, const amdnuwa_s3_geom* g) {
+    a.B = g->B; a.ntok = g->ntok; a.F = g->F; a.H = g->H; a.W = g->W; a.kf = g->kf; a.kh = g->kh; a.kw = g->kw;
+    a.df = g->df; a.dh = g->dh; a.dw = g->dw; a.NH = g->heads; a.scale = g->scale;
+}
+int block_threads(const amdnuwa_s3_geom* g) { return ((g->W * g->heads * 4 + 63) / 64) * 64; }
+
+}  // namespace
+
+extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* k, const uint16_t* v,
+                                      const uint16_t* q_lo, const uint16_t* k_lo, const uint16_t* v_lo, int ld,
+                                      const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, hipStream_t stream) {
+    int rc = check_geom(g);
+    if (rc) return rc;
+    if (!q || !k || !v || !w_th || !o || ld % 8 || ldo % 8) return AMDNUWA_ERR_ARG;
+    if (g->B <= 0) return AMDNUWA_OK;
+    S3Args a{};
+    fill_geom(a, g);
+    a.q = q; a.k = k; a.v = v; a.ql = q_lo; a.kl = k_lo; a.vl = v_lo; a.ld = ld;
+    a.o = o; a.ol = o_lo; a.ldo = ldo; a.wth = w_th;
+    const int J = g->kf * g->kh * g->kw + 1;
+    if ((k_lo != nullptr) && (!q_lo || !v_lo)) return AMDNUWA_ERR_ARG;
+    const size_t lds = (size_t)g->W * g->heads * g->dim_head * (k_lo ? 4 : 2) + (size_t)g->W * J * g->heads * 4;
+    dim3 grid(g->B * g->F * g->H), block(block_threads(g));
+    if (g->dim_head == 64) {
+        (void)hipFuncSetAttribute((const void*)s3_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(s3_fwd_kernel<64>, grid, block, lds, stream, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)s3_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(s3_fwd_kernel<32>, grid, block, lds, stream, a);
+    }
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" size_t amdnuwa_sparse3dna_bwd_workspace_bytes(const amdnuwa_s3_geom* g) {
+    if (check_geom(g)) return 0;
+    const size_t J = (size_t)g->kf * g->kh * g->kw + 1, nq = g->ntok - 1, rows = (size_t)g->B * g->F * g->H;
+    const size_t inner = (size_t)g->heads * g->dim_head;
+    return (2 * (size_t)g->B * nq * J * g->heads + rows * g->heads * g->heads + 2 * rows * inner) * sizeof(float) + 256;
+}
+
+extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* k, const uint16_t* v,
+                                      const uint16_t* q_lo, const uint16_t* k_lo, const uint16_t* v_lo, int ld,
+                                      const float* w_th, const uint16_t* dO, const uint16_t* dO_lo, int lddo,
+                                      uint16_t* dq, uint16_t* dk, uint16_t* dv, uint16_t* dq_lo, uint16_t* dk_lo,
+                                      uint16_t* dv_lo, int ldd, float* dw_th, int accumulate, void* workspace,
+                                      size_t workspace_bytes, hipStream_t stream) {
+    int rc = check_geom(g);
+    if (rc) return rc;
+    if (!q || !k || !v || !w_th || !dO || !dq || !dk || !dv || !dw_th || ld % 8 || lddo % 8 || ldd % 8) return AMDNUWA_ERR_ARG;
+    if (!workspace || workspace_bytes < amdnuwa_sparse3dna_bwd_workspace_bytes(g)) return AMDNUWA_ERR_WORKSPACE;
+    if (g->B <= 0) return AMDNUWA_OK;
+    S3Args a{};
+    fill_geom(a, g);
+    a.q = q; a.k = k; a.v = v; a.ql = q_lo; a.kl = k_lo; a.vl = v_lo; a.ld = ld; a.wth = w_th;
+    a.dO = dO; a.dOl = dO_lo; a.lddo = lddo;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.dql = dq_lo; a.dkl = dk_lo; a.dvl = dv_lo; a.ldd = ldd;
+    a.dwth = dw_th; a.accumulate = accumulate;
+    const size_t J = (size_t)g->kf * g->kh * g->kw + 1, nq = g->ntok - 1, rows = (size_t)g->B * g->F * g->H;
+    const size_t inner = (size_t)g->heads * g->dim_head;
+    float* ws = (float*)workspace;
+    a.ds = ws; ws += (size_t)g->B * nq * J * g->heads;
+    a.pm = ws; ws += (size_t)g->B * nq * J * g->heads;
+    a.part_th = ws; ws += rows * g->heads * g->heads;
+    a.part_k0 = ws; ws += rows * inner;
+    a.part_v0 = ws;
+    const size_t nsp = (size_t)g->W * J * g->heads;
+    // bwd_q LDS: stage (hi+lo) + SP + DP + RED(8*64); the <bos> partial reduction reuses SP+DP: needs 2*W*inner <= 2*nsp
+    size_t spdp = 2 * nsp;
+    if (spdp < (size_t)g->W * inner) spdp = (size_t)g->W * inner;
+    const bool has_lo = k_lo != nullptr;
+    if (has_lo && (!q_lo || !v_lo)) return AMDNUWA_ERR_ARG;
+    const size_t lds_q = (size_t)g->W * g->heads * g->dim_head * (has_lo ? 4 : 2) + (spdp + 8 * 64) * 4;
+    const size_t lds_kv = (size_t)g->W * g->heads * g->dim_head * 8;
+    dim3 grid((unsigned)rows), block(block_threads(g));
+    if (g->dim_head == 64) {
+        (void)hipFuncSetAttribute((const void*)s3_bwd_q_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        hipLaunchKernelGGL(s3_bwd_q_kernel<64>, grid, block, lds_q, stream, a);
+        LAUNCH_CHECK();
+        (void)hipFuncSetAttribute((const void*)s3_bwd_kv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        hipLaunchKernelGGL(s3_bwd_kv_kernel<64>, grid, block, lds_kv, stream, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)s3_bwd_q_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        hipLaunchKernelGGL(s3_bwd_q_kernel<32>, grid, block, lds_q, stream, a);
+        LAUNCH_CHECK();
+        (void)hipFuncSetAttribute((const void*)s3_bwd_kv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        hipLaunchKernelGGL(s3_bwd_kv_kernel<32>, grid, block, lds_kv, stream, a);
+    }
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(s3_bwd_fin_kernel, dim3(g->B + 1), dim3(256), 0, stream, a, g->dim_head);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
