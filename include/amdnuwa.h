@@ -61,7 +61,8 @@ typedef struct {
 /* C[M,N] = alpha * A[M,K] . B[N,K]^T (+ bias).  K, lda, ldb multiples of 8. */
 int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, amdnuwa_stream stream);
 /* C[M,N] (fp32) = beta*C + alpha * A[K,M]^T . B[K,N]   (reduction over the K token rows, split-K
- * through `workspace`, fixed summation order => deterministic).  M, N, lda, ldb multiples of 8. */
+ * through `workspace`, fixed summation order => deterministic).  lda, ldb multiples of 8; operand rows
+ * must be readable up to the next multiple of 8 columns (padding content is irrelevant). */
 size_t amdnuwa_gemm_tn_workspace_bytes(const amdnuwa_gemm_desc* d);
 int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
 
@@ -78,11 +79,14 @@ int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const flo
                    int mode, int stable, float eps, amdnuwa_stream stream);
 size_t amdnuwa_ln_bwd_workspace_bytes(long long R, int D);
 /* dy fp32; shift_ntok > 0 reads dy through the inverse token shift.  Exactly one of dx_hi (bf16
- * hi[/lo] output) / dx_acc (fp32, accumulated into) is non-NULL.  dw, db, dsum (= column sums of
- * dx) may be NULL; accumulate != 0 adds into them. */
+ * hi[/lo] output) / dx_acc (fp32) is non-NULL; dx_acc = (dres ? dres : dx_acc) + dx.  dw, db, dsum
+ * (= column sums of dx) may be NULL; accumulate != 0 adds into them. */
 int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* inv_amax,
-                   const float* w, uint16_t* dx_hi, uint16_t* dx_lo, float* dx_acc, float* dw, float* db, float* dsum,
-                   long long R, int D, int shift_ntok, int shift_fmap, int stable, int accumulate, void* workspace,
+                   const float* w, uint16_t* dx_hi, uint16_t* dx_lo, float* dx_acc, const float* dres, float* dw,
+                   float* db, float* dsum, long long R, int D, int shift_ntok, int shift_fmap, int stable, int accumulate, void* workspace,
+                   size_t workspace_bytes, amdnuwa_stream stream);
+size_t amdnuwa_colsum_workspace_bytes(long long R, int D);
+int amdnuwa_colsum(const float* x, float* out, long long R, int D, int accumulate, void* workspace,
                    size_t workspace_bytes, amdnuwa_stream stream);
 /* u = [a | g], each FP columns wide: o = a * gelu_erf(g) */
 int amdnuwa_geglu_fwd(const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* o_hi, uint16_t* o_lo, long long R, int FP,

@@ -1,0 +1,117 @@
+"""ctypes binding of libamdnuwa.so (include/amdnuwa.h).  There is NO fallback: if the library is
+missing or a call fails, a RuntimeError is raised -- the product path never silently degrades to
+PyTorch eager or to the oracle."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libamdnuwa.so')
+ABI_VERSION = 3
+
+P = C.c_void_p
+I = C.c_int
+LL = C.c_longlong
+F = C.c_float
+SZ = C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [('A', P), ('Alo', P), ('strideA', LL), ('lda', I),
+                ('B', P), ('Blo', P), ('strideB', LL), ('ldb', I),
+                ('C', P), ('Clo', P), ('strideC', LL), ('ldc', I),
+                ('c_is_bf16', I), ('bias', P), ('alpha', F), ('beta', F),
+                ('M', I), ('N', I), ('K', I), ('batch', I), ('shift_ntok', I), ('shift_fmap', I),
+                ('batch_inner', I), ('strideA_inner', LL), ('strideB_inner', LL), ('strideC_inner', LL)]
+
+
+class S3Geom(C.Structure):
+    _fields_ = [('B', I), ('ntok', I), ('F', I), ('H', I), ('W', I), ('kf', I), ('kh', I), ('kw', I),
+                ('df', I), ('dh', I), ('dw', I), ('heads', I), ('dim_head', I), ('scale', F)]
+
+
+class XGeom(C.Structure):
+    _fields_ = [('B', I), ('n', I), ('T', I), ('JP', I), ('heads', I), ('dim_head', I), ('scale', F)]
+
+
+class XKV(C.Structure):
+    _fields_ = [('Kp', P), ('Kp_lo', P), ('Kt', P), ('Kt_lo', P), ('Vp', P), ('Vp_lo', P), ('Vt', P), ('Vt_lo', P),
+                ('valid', P)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('N', I), ('Cin', I), ('H', I), ('W', I), ('Cout', I), ('KH', I), ('KW', I), ('stride', I), ('pad', I),
+                ('Ho', I), ('Wo', I), ('leaky', I)]
+
+
+GD, SG, XG, XK, CD = (C.POINTER(t) for t in (GemmDesc, S3Geom, XGeom, XKV, ConvDesc))
+
+# name -> (restype, argtypes).  Mirrors include/amdnuwa.h declaration by declaration.
+SIGNATURES = {
+    'amdnuwa_abi_version': (I, []),
+    'amdnuwa_error_string': (C.c_char_p, [I]),
+    'amdnuwa_timer_arm': (None, [I]),
+    'amdnuwa_timer_begin': (I, [P]),
+    'amdnuwa_timer_end': (I, [P]),
+    'amdnuwa_timer_collect': (I, [C.POINTER(C.c_double), C.POINTER(LL)]),
+    'amdnuwa_gemm_nt': (I, [GD, P]),
+    'amdnuwa_gemm_tn_workspace_bytes': (SZ, [GD]),
+    'amdnuwa_gemm_tn': (I, [GD, P, SZ, P]),
+    'amdnuwa_ln_fwd': (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, P]),
+    'amdnuwa_ln_bwd_workspace_bytes': (SZ, [LL, I]),
+    'amdnuwa_ln_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, I, I, P, SZ, P]),
+    'amdnuwa_colsum_workspace_bytes': (SZ, [LL, I]),
+    'amdnuwa_colsum': (I, [P, P, LL, I, I, P, SZ, P]),
+    'amdnuwa_geglu_fwd': (I, [P, P, P, P, LL, I, P]),
+    'amdnuwa_geglu_bwd': (I, [P, P, P, P, P, P, LL, I, P]),
+    'amdnuwa_cast_pad': (I, [P, I, P, P, I, LL, I, I, P]),
+    'amdnuwa_transpose_cast': (I, [P, I, P, P, I, I, I, P]),
+    'amdnuwa_embed_fwd': (I, [P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    'amdnuwa_embed_bwd_workspace_bytes': (SZ, [I, I]),
+    'amdnuwa_embed_bwd': (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
+    'amdnuwa_ce_fwd': (I, [P, P, P, P, P, P, LL, I, I, F, P]),
+    'amdnuwa_scale_by_device_scalar': (I, [P, SZ, P, P]),
+    'amdnuwa_sparse3dna_fwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P]),
+    'amdnuwa_sparse3dna_bwd_workspace_bytes': (SZ, [SG]),
+    'amdnuwa_sparse3dna_bwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P, P, P, P, P, P, I, P, I, P, SZ, P]),
+    'amdnuwa_xattn_jp': (I, [I]),
+    'amdnuwa_xattn_pack': (I, [XG, P, P, I, P, P, P, XK, P]),
+    'amdnuwa_xattn_fwd': (I, [XG, P, P, I, XK, P, P, P, I, P, P, P, P, P]),
+    'amdnuwa_xattn_bwd_workspace_bytes': (SZ, [XG]),
+    'amdnuwa_xattn_bwd': (I, [XG, P, P, I, XK, P, P, P, P, P, P, P, I, P, I, P, SZ, P]),
+    'amdnuwa_xattn_unpack': (I, [XG, P, P, P, P, I, P, P, I, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """the loaded library; raises RuntimeError (loudly) when it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'libamdnuwa.so not found at {LIB_PATH}. Build it with `python -m nuwa_pytorch_amd.build` '
+            '(hipcc --offload-arch=gfx950). nuwa_pytorch_amd has no PyTorch/CPU fallback for the hot path.')
+    try:
+        l = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError(f'failed to load {LIB_PATH}: {e}') from e
+    missing = [n for n in SIGNATURES if not hasattr(l, n)]
+    if missing:
+        raise RuntimeError(f'{LIB_PATH} lacks symbols declared in include/amdnuwa.h: {missing}')
+    for n, (res, args) in SIGNATURES.items():
+        fn = getattr(l, n)
+        fn.restype = res
+        fn.argtypes = args
+    v = l.amdnuwa_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f'libamdnuwa ABI version {v} != expected {ABI_VERSION}: rebuild the library')
+    _lib = l
+    return l
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().amdnuwa_error_string(int(rc))
+        raise RuntimeError(f'{what} failed with code {rc}: {msg.decode() if msg else "?"}')

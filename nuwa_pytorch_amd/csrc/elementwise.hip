@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ inv_amax_i, const float* __restrict__ w,
                                                      bf16_t* __restrict__ dx_hi, bf16_t* __restrict__ dx_lo,
-                                                     float* __restrict__ dx_acc, float* __restrict__ partial,
+                                                     float* dx_acc, const float* dres, float* __restrict__ partial,
                                                      long long R, int D, int shift_ntok, int shift_fmap) {
     __shared__ float red[ROWS_PER_BLOCK][3][MAXV * 256];
     const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 store_bf16x4(dx_hi + row * D, dx_lo ? dx_lo + row * D : nullptr, e, d0, d1, d2, d3);
             } else {
                 float4* a = reinterpret_cast<float4*>(dx_acc + row * D + e);
-                float4 o = *a;
+                float4 o = dres ? *reinterpret_cast<const float4*>(dres + row * D + e) : *a;
                 o.x += d0; o.y += d1; o.z += d2; o.w += d3;
                 *a = o;
             }
@@ -190,6 +190,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int idx = threadIdx.x; idx < 3 * D; idx += 256) {
         const int k = idx / D, c = idx % D;
         partial[((size_t)blockIdx.x * 3 + k) * D + c] = ((red[0][k][c] + red[1][k][c]) + red[2][k][c]) + red[3][k][c];
+    }
+}
+
+// column sums of an fp32 [R, D] matrix -> partial[blk][D] (slot k = 0 of a 1-row partial layout)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ partial, long long R, int D) {
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float s = 0.f;
+        for (long long r = blockIdx.x; r < R; r += gridDim.x) s += x[r * D + c];
+        partial[(size_t)blockIdx.x * D + c] = s;
     }
 }
 
@@ -460,7 +469,7 @@ static int ln_bwd_blocks(long long R) {
 extern "C" size_t amdnuwa_ln_bwd_workspace_bytes(long long R, int D) { return (size_t)ln_bwd_blocks(R) * 3 * D * sizeof(float); }
 
 extern "C" int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* inv_amax,
-                              const float* w, uint16_t* dx_hi, uint16_t* dx_lo, float* dx_acc, float* dw, float* db,
+                              const float* w, uint16_t* dx_hi, uint16_t* dx_lo, float* dx_acc, const float* dres, float* dw, float* db,
                               float* dsum, long long R, int D, int shift_ntok, int shift_fmap, int stable, int accumulate,
                               void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!dy || !x || !mean || !rstd || !w || D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
@@ -473,14 +482,29 @@ extern "C" int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean
     float* part = (float*)workspace;
     dim3 grid(nb), block(256);
     if (dx_hi) {
-        if (stable) hipLaunchKernelGGL((ln_bwd_kernel<0, true>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, part, R, D, shift_ntok, shift_fmap);
-        else hipLaunchKernelGGL((ln_bwd_kernel<0, false>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, part, R, D, shift_ntok, shift_fmap);
+        if (stable) hipLaunchKernelGGL((ln_bwd_kernel<0, true>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap);
+        else hipLaunchKernelGGL((ln_bwd_kernel<0, false>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap);
     } else {
-        if (stable) hipLaunchKernelGGL((ln_bwd_kernel<1, true>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, part, R, D, shift_ntok, shift_fmap);
-        else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, part, R, D, shift_ntok, shift_fmap);
+        if (stable) hipLaunchKernelGGL((ln_bwd_kernel<1, true>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap);
+        else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap);
     }
     LAUNCH_CHECK();
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((3 * D + 255) / 256), dim3(256), 0, stream, part, nb, 3, D, dw, db, dsum, accumulate);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" size_t amdnuwa_colsum_workspace_bytes(long long R, int D) { return (size_t)(R < 256 ? (R < 1 ? 1 : R) : 256) * D * sizeof(float); }
+
+// out[c] (+)= sum_r x[r][c]   (fixed order => deterministic)
+extern "C" int amdnuwa_colsum(const float* x, float* out, long long R, int D, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!x || !out || D <= 0) return AMDNUWA_ERR_ARG;
+    if (!workspace || workspace_bytes < amdnuwa_colsum_workspace_bytes(R, D)) return AMDNUWA_ERR_WORKSPACE;
+    if (R <= 0) return AMDNUWA_OK;
+    const int nb = (int)(R < 256 ? R : 256);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, stream, x, (float*)workspace, R, D);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nb, 1, D, out, (float*)nullptr, (float*)nullptr, accumulate);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

@@ -420,7 +420,7 @@ extern "C" size_t amdnuwa_gemm_tn_workspace_bytes(const amdnuwa_gemm_desc* d) {
 extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!d || !d->A || !d->B || !d->C || d->c_is_bf16) return AMDNUWA_ERR_ARG;
     if (d->M <= 0 || d->N <= 0) return AMDNUWA_OK;
-    if (d->lda % 8 || d->ldb % 8 || d->M % 8 || d->N % 8) return AMDNUWA_ERR_ARG;
+    if (d->lda % 8 || d->ldb % 8) return AMDNUWA_ERR_ARG;   // operand rows must be readable up to the next multiple of 8 columns
     if ((d->Alo == nullptr) != (d->Blo == nullptr)) return AMDNUWA_ERR_ARG;
     if (d->shift_ntok > 0 && (d->shift_fmap <= 0 || d->N % 32)) return AMDNUWA_ERR_ARG;
     if (workspace_bytes < amdnuwa_gemm_tn_workspace_bytes(d) || !workspace) return AMDNUWA_ERR_WORKSPACE;

@@ -1,0 +1,434 @@
+"""Thin torch-tensor wrappers over the C-ABI (one function per entry point of include/amdnuwa.h).
+Tensors only provide device memory (torch caching allocator) and the current HIP stream; all
+arithmetic happens inside libamdnuwa."""
+import ctypes as C
+from collections import namedtuple
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, S3Geom, XGeom, XKV, check
+
+BF = namedtuple('BF', ['hi', 'lo'])     # bf16 hi part + optional bf16 residual (parity mode)
+
+_PRECISION = 'bf16'
+_TIMER = {'on': False, 'flops': 0.0}
+
+
+def set_precision(mode):
+    """'bf16'  : bf16 MFMA operands, fp32 accumulate / softmax / LayerNorm / residual stream (fast path)
+    'bf16x3': every MFMA operand carried as a bf16 hi+lo pair, 3 MFMAs per product (~fp32 accuracy;
+              the parity mode that meets the 1e-3 logits tolerance against the fp32 reference)."""
+    global _PRECISION
+    if mode not in ('bf16', 'bf16x3'):
+        raise ValueError(mode)
+    _PRECISION = mode
+
+
+def get_precision():
+    return _PRECISION
+
+
+def want_lo():
+    return _PRECISION == 'bf16x3'
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('nuwa_pytorch_amd kernels need CUDA(HIP) device tensors; there is no CPU fallback')
+
+
+def empty_bf(shape, device, lo=None):
+    lo = want_lo() if lo is None else lo
+    return BF(torch.empty(shape, dtype=torch.bfloat16, device=device),
+              torch.empty(shape, dtype=torch.bfloat16, device=device) if lo else None)
+
+
+def zeros_bf(shape, device, lo=None):
+    lo = want_lo() if lo is None else lo
+    return BF(torch.zeros(shape, dtype=torch.bfloat16, device=device),
+              torch.zeros(shape, dtype=torch.bfloat16, device=device) if lo else None)
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def view(b, rows=None, cols=None):
+    """2-D sub-view of a BF pair"""
+    r = rows if rows is not None else slice(None)
+    c = cols if cols is not None else slice(None)
+    return BF(b.hi[r, c], None if b.lo is None else b.lo[r, c])
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, 'GEMM operands must be 2-D with unit inner stride'
+    return t.stride(0)
+
+
+def timer_arm(on):
+    _TIMER['on'] = bool(on)
+    _TIMER['flops'] = 0.0
+    _lib.lib().amdnuwa_timer_arm(1 if on else 0)
+
+
+def timer_collect():
+    ms, n = C.c_double(0), C.c_longlong(0)
+    check(_lib.lib().amdnuwa_timer_collect(C.byref(ms), C.byref(n)), 'timer_collect')
+    return ms.value, n.value, _TIMER['flops']
+
+
+def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None, N=None, K=None):
+    """C[M,N] = alpha * A[M,K] @ B[N,K]^T (+ bias).  A, B: BF pairs of 2-D views.
+    out: fp32 tensor view or BF pair view (allocated when None).  shift = (ntok, fmap) folds the
+    token shift into A's loader."""
+    L = _lib.lib()
+    M = A.hi.shape[0]
+    K = A.hi.shape[1] if K is None else K
+    N = B.hi.shape[0] if N is None else N
+    dev = A.hi.device
+    _chk_dev(A.hi, B.hi)
+    x3 = A.lo is not None and B.lo is not None
+    if out is None:
+        out = empty_bf((M, N), dev) if out_bf16 else torch.empty((M, N), dtype=torch.float32, device=dev)
+    d = GemmDesc()
+    d.A, d.Alo, d.lda = _p(A.hi), _p(A.lo) if x3 else None, _ld(A.hi)
+    d.B, d.Blo, d.ldb = _p(B.hi), _p(B.lo) if x3 else None, _ld(B.hi)
+    if out_bf16:
+        d.C, d.Clo, d.ldc, d.c_is_bf16 = _p(out.hi), _p(out.lo), _ld(out.hi), 1
+    else:
+        d.C, d.Clo, d.ldc, d.c_is_bf16 = _p(out), None, _ld(out), 0
+    d.bias = _p(bias)
+    d.alpha, d.beta = float(alpha), 0.0
+    d.M, d.N, d.K, d.batch = M, N, K, 1
+    if shift is not None:
+        d.shift_ntok, d.shift_fmap = int(shift[0]), int(shift[1])
+    st = _stream()
+    if _TIMER['on']:
+        _TIMER['flops'] += 2.0 * M * N * K * (3 if x3 else 1)
+        L.amdnuwa_timer_begin(st)
+    check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt')
+    if _TIMER['on']:
+        L.amdnuwa_timer_end(st)
+    return out
+
+
+def gemm_tn(A, B, out, *, alpha=1.0, beta=0.0, shift=None, N1=None, N2=None):
+    """out[N1,N2] (fp32 view) = beta*out + alpha * A[R,N1]^T @ B[R,N2]; shift applies to B's loader."""
+    L = _lib.lib()
+    R = A.hi.shape[0]
+    N1 = A.hi.shape[1] if N1 is None else N1
+    N2 = B.hi.shape[1] if N2 is None else N2
+    x3 = A.lo is not None and B.lo is not None
+    d = GemmDesc()
+    d.A, d.Alo, d.lda = _p(A.hi), _p(A.lo) if x3 else None, _ld(A.hi)
+    d.B, d.Blo, d.ldb = _p(B.hi), _p(B.lo) if x3 else None, _ld(B.hi)
+    d.C, d.ldc, d.c_is_bf16 = _p(out), _ld(out), 0
+    d.alpha, d.beta = float(alpha), float(beta)
+    d.M, d.N, d.K, d.batch = N1, N2, R, 1
+    if shift is not None:
+        d.shift_ntok, d.shift_fmap = int(shift[0]), int(shift[1])
+    nb = L.amdnuwa_gemm_tn_workspace_bytes(C.byref(d))
+    ws = workspace(nb, A.hi.device)
+    check(L.amdnuwa_gemm_tn(C.byref(d), _p(ws), nb, _stream()), 'amdnuwa_gemm_tn')
+    return out
+
+
+def gemm_tn_batched(desc, device):
+    L = _lib.lib()
+    nb = L.amdnuwa_gemm_tn_workspace_bytes(C.byref(desc))
+    ws = workspace(nb, device)
+    check(L.amdnuwa_gemm_tn(C.byref(desc), _p(ws), nb, _stream()), 'amdnuwa_gemm_tn(batched)')
+
+
+# ------------------------------------------------------------------------------------------------
+# row kernels
+# ------------------------------------------------------------------------------------------------
+
+def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5):
+    """x fp32 [R, D] contiguous.  resid None -> (BF out, mean, rstd, inv_amax); else (fp32 out = resid + LN(x), mean, rstd)"""
+    L = _lib.lib()
+    R, D = x.shape
+    dev = x.device
+    _chk_dev(x)
+    mean = torch.empty(R, dtype=torch.float32, device=dev)
+    rstd = torch.empty(R, dtype=torch.float32, device=dev)
+    if resid is None:
+        out = empty_bf((R, D), dev)
+        ia = torch.empty(R, dtype=torch.float32, device=dev) if stable else None
+        check(L.amdnuwa_ln_fwd(_p(x), None, _p(w), _p(b), _p(out.hi), _p(out.lo), None, _p(mean), _p(rstd), _p(ia),
+                               R, D, 0, 1 if stable else 0, eps, _stream()), 'amdnuwa_ln_fwd')
+        return out, mean, rstd, ia
+    out = torch.empty_like(x)
+    check(L.amdnuwa_ln_fwd(_p(x), _p(resid), _p(w), _p(b), None, None, _p(out), _p(mean), _p(rstd), None,
+                           R, D, 1, 0, eps, _stream()), 'amdnuwa_ln_fwd')
+    return out, mean, rstd
+
+
+def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift=None, want_dsum=False):
+    """returns (dx, dw, db, dsum).  to_bf: dx as BF pair; else dx fp32 = dres + dx_ln (dres may be None -> zeros)."""
+    L = _lib.lib()
+    R, D = x.shape
+    dev = x.device
+    dw = torch.empty(D, dtype=torch.float32, device=dev)
+    db = torch.empty(D, dtype=torch.float32, device=dev)
+    ds = torch.empty(D, dtype=torch.float32, device=dev) if want_dsum else None
+    nb = L.amdnuwa_ln_bwd_workspace_bytes(R, D)
+    ws = workspace(nb, dev)
+    sn, sf = (int(shift[0]), int(shift[1])) if shift is not None else (0, 0)
+    if to_bf:
+        dx = empty_bf((R, D), dev)
+        check(L.amdnuwa_ln_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(inv_amax), _p(w), _p(dx.hi), _p(dx.lo), None, None,
+                               _p(dw), _p(db), _p(ds), R, D, sn, sf, 1 if inv_amax is not None else 0, 0, _p(ws), nb,
+                               _stream()), 'amdnuwa_ln_bwd')
+    else:
+        if dres is None:
+            dx = torch.zeros((R, D), dtype=torch.float32, device=dev)
+            dr = None
+        else:
+            dx = torch.empty((R, D), dtype=torch.float32, device=dev)
+            dr = dres
+        check(L.amdnuwa_ln_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(inv_amax), _p(w), None, None, _p(dx), _p(dr),
+                               _p(dw), _p(db), _p(ds), R, D, sn, sf, 1 if inv_amax is not None else 0, 0, _p(ws), nb,
+                               _stream()), 'amdnuwa_ln_bwd')
+    return dx, dw, db, ds
+
+
+def colsum(x):
+    L = _lib.lib()
+    R, D = x.shape
+    out = torch.empty(D, dtype=torch.float32, device=x.device)
+    nb = L.amdnuwa_colsum_workspace_bytes(R, D)
+    ws = workspace(nb, x.device)
+    check(L.amdnuwa_colsum(_p(x), _p(out), R, D, 0, _p(ws), nb, _stream()), 'amdnuwa_colsum')
+    return out
+
+
+def geglu_fwd(u, FP):
+    L = _lib.lib()
+    R = u.hi.shape[0]
+    out = empty_bf((R, FP), u.hi.device, lo=u.lo is not None)
+    check(L.amdnuwa_geglu_fwd(_p(u.hi), _p(u.lo), _p(out.hi), _p(out.lo), R, FP, _stream()), 'amdnuwa_geglu_fwd')
+    return out
+
+
+def geglu_bwd(u, dgg, FP):
+    L = _lib.lib()
+    R = u.hi.shape[0]
+    du = empty_bf((R, 2 * FP), u.hi.device, lo=u.lo is not None)
+    check(L.amdnuwa_geglu_bwd(_p(u.hi), _p(u.lo), _p(dgg.hi), _p(dgg.lo), _p(du.hi), _p(du.lo), R, FP, _stream()),
+          'amdnuwa_geglu_bwd')
+    return du
+
+
+def cast_pad(src, out, row0=0, Cp=None):
+    """out[row0 + r, :Cp] = bf16(src[r, :]) (zero padded); src fp32 2-D view, out BF pair (2-D)"""
+    L = _lib.lib()
+    R, Cc = src.shape
+    Cp = out.hi.shape[1] if Cp is None else Cp
+    hi = out.hi[row0:row0 + R]
+    lo = None if out.lo is None else out.lo[row0:row0 + R]
+    check(L.amdnuwa_cast_pad(_p(src), src.stride(0), _p(hi), _p(lo), out.hi.stride(0), R, Cc, Cp, _stream()), 'amdnuwa_cast_pad')
+
+
+def transpose_cast(src, out, col0=0):
+    """out[c, col0 + r] = bf16(src[r, c])"""
+    L = _lib.lib()
+    R, Cc = src.shape
+    hi = out.hi[:, col0:]
+    lo = None if out.lo is None else out.lo[:, col0:]
+    check(L.amdnuwa_transpose_cast(_p(src), src.stride(0), _p(hi), _p(lo), out.hi.stride(0), R, Cc, _stream()),
+          'amdnuwa_transpose_cast')
+
+
+def embed_fwd(ids, W, ax1, ax2, ax3, bos, B, ntok, H, Wd, frac):
+    L = _lib.lib()
+    D = W.shape[1]
+    x = torch.empty((B * ntok, D), dtype=torch.float32, device=W.device)
+    check(L.amdnuwa_embed_fwd(_p(ids), _p(W), _p(ax1), _p(ax2), _p(ax3), _p(bos), _p(x), B, ntok, D, H, Wd, float(frac),
+                              _stream()), 'amdnuwa_embed_fwd')
+    return x
+
+
+def embed_bwd(ids, dx, dW, dax1, dax2, dax3, dbos, B, ntok, F, H, Wd, frac):
+    L = _lib.lib()
+    D = dW.shape[1]
+    nb = L.amdnuwa_embed_bwd_workspace_bytes(ntok, D)
+    ws = workspace(nb, dx.device)
+    check(L.amdnuwa_embed_bwd(_p(ids), _p(dx), _p(dW), _p(dax1), _p(dax2), _p(dax3), _p(dbos), B, ntok, D, F, H, Wd,
+                              float(frac), _p(ws), nb, _stream()), 'amdnuwa_embed_bwd')
+
+
+def ce_fwd(logits, targets, grad_scale, want_grad=True):
+    L = _lib.lib()
+    R, Cc = logits.shape
+    dev = logits.device
+    row_loss = torch.empty(R, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dl = empty_bf((R, Cc), dev) if want_grad else BF(None, None)
+    check(L.amdnuwa_ce_fwd(_p(logits), _p(targets), _p(row_loss), _p(loss), _p(dl.hi), _p(dl.lo), R, Cc, Cc,
+                           float(grad_scale), _stream()), 'amdnuwa_ce_fwd')
+    return loss, dl
+
+
+def scale_by_device_scalar(x, scalar):
+    check(_lib.lib().amdnuwa_scale_by_device_scalar(_p(x), x.numel(), _p(scalar), _stream()), 'amdnuwa_scale_by_device_scalar')
+
+
+# ------------------------------------------------------------------------------------------------
+# attention cores
+# ------------------------------------------------------------------------------------------------
+
+def s3_geom(B, ntok, video_shape, kernel, dilation, heads, dim_head):
+    g = S3Geom()
+    g.B, g.ntok = B, ntok
+    g.F, g.H, g.W = video_shape
+    g.kf, g.kh, g.kw = kernel
+    g.df, g.dh, g.dw = dilation
+    g.heads, g.dim_head, g.scale = heads, dim_head, dim_head ** -0.5
+    return g
+
+
+def sparse3dna_fwd(g, qkv, wth):
+    """qkv: BF [B*ntok, 3*inner] (q | k | v);  returns o BF [B*ntok, inner]"""
+    L = _lib.lib()
+    inner = g.heads * g.dim_head
+    R = g.B * g.ntok
+    o = empty_bf((R, inner), qkv.hi.device, lo=qkv.lo is not None)
+    q, k, v = (view(qkv, cols=slice(i * inner, (i + 1) * inner)) for i in range(3))
+    check(L.amdnuwa_sparse3dna_fwd(C.byref(g), _p(q.hi), _p(k.hi), _p(v.hi), _p(q.lo), _p(k.lo), _p(v.lo), qkv.hi.stride(0),
+                                   _p(wth), _p(o.hi), _p(o.lo), inner, _stream()), 'amdnuwa_sparse3dna_fwd')
+    return o
+
+
+def sparse3dna_bwd(g, qkv, wth, dO):
+    """returns (dqkv BF [R, 3*inner], dw_th fp32 [h, h])"""
+    L = _lib.lib()
+    inner = g.heads * g.dim_head
+    R = g.B * g.ntok
+    dev = qkv.hi.device
+    dqkv = empty_bf((R, 3 * inner), dev, lo=qkv.lo is not None)
+    dwth = torch.empty((g.heads, g.heads), dtype=torch.float32, device=dev)
+    q, k, v = (view(qkv, cols=slice(i * inner, (i + 1) * inner)) for i in range(3))
+    dq, dk, dv = (view(dqkv, cols=slice(i * inner, (i + 1) * inner)) for i in range(3))
+    nb = L.amdnuwa_sparse3dna_bwd_workspace_bytes(C.byref(g))
+    ws = workspace(nb, dev)
+    check(L.amdnuwa_sparse3dna_bwd(C.byref(g), _p(q.hi), _p(k.hi), _p(v.hi), _p(q.lo), _p(k.lo), _p(v.lo), qkv.hi.stride(0),
+                                   _p(wth), _p(dO.hi), _p(dO.lo), dO.hi.stride(0), _p(dq.hi), _p(dk.hi), _p(dv.hi),
+                                   _p(dq.lo), _p(dk.lo), _p(dv.lo), dqkv.hi.stride(0), _p(dwth), 0, _p(ws), nb, _stream()),
+          'amdnuwa_sparse3dna_bwd')
+    return dqkv, dwth
+
+
+def x_geom(B, n, T, heads, dim_head):
+    g = XGeom()
+    g.B, g.n, g.T = B, n, T
+    g.JP = _lib.lib().amdnuwa_xattn_jp(T)
+    g.heads, g.dim_head, g.scale = heads, dim_head, dim_head ** -0.5
+    return g
+
+
+class PackedKV:
+    """per-(sample, head) key/value images for the cross-attention kernels"""
+
+    def __init__(self, g, device, lo):
+        sh1 = (g.B, g.heads, g.JP, g.dim_head)
+        sh2 = (g.B, g.heads, g.dim_head, g.JP)
+        mk = lambda s: empty_bf(s, device, lo=lo)
+        self.Kp, self.Vp, self.Kt, self.Vt = mk(sh1), mk(sh1), mk(sh2), mk(sh2)
+        self.valid = torch.empty((g.B, g.JP), dtype=torch.uint8, device=device)
+        s = XKV()
+        s.Kp, s.Kp_lo, s.Kt, s.Kt_lo = _p(self.Kp.hi), _p(self.Kp.lo), _p(self.Kt.hi), _p(self.Kt.lo)
+        s.Vp, s.Vp_lo, s.Vt, s.Vt_lo = _p(self.Vp.hi), _p(self.Vp.lo), _p(self.Vt.hi), _p(self.Vt.lo)
+        s.valid = _p(self.valid)
+        self.struct = s
+
+
+def xattn_pack(g, kv, null_k, null_v, mask_u8):
+    L = _lib.lib()
+    pk = PackedKV(g, kv.hi.device, kv.lo is not None)
+    check(L.amdnuwa_xattn_pack(C.byref(g), _p(kv.hi), _p(kv.lo), kv.hi.stride(0), _p(null_k), _p(null_v), _p(mask_u8),
+                               C.byref(pk.struct), _stream()), 'amdnuwa_xattn_pack')
+    return pk
+
+
+def xattn_fwd(g, q, pk, wth, save=True):
+    L = _lib.lib()
+    inner = g.heads * g.dim_head
+    dev = q.hi.device
+    lo = q.lo is not None
+    o = empty_bf((g.B * g.n, inner), dev, lo=lo)
+    if save:
+        P = empty_bf((g.B, g.heads, g.n, g.JP), dev, lo=lo)
+        Pm = empty_bf((g.B, g.heads, g.n, g.JP), dev, lo=lo)
+    else:
+        P = Pm = BF(None, None)
+    check(L.amdnuwa_xattn_fwd(C.byref(g), _p(q.hi), _p(q.lo), q.hi.stride(0), C.byref(pk.struct), _p(wth), _p(o.hi), _p(o.lo),
+                              inner, _p(P.hi), _p(P.lo), _p(Pm.hi), _p(Pm.lo), _stream()), 'amdnuwa_xattn_fwd')
+    return o, P, Pm
+
+
+def xattn_bwd(g, dO, pk, wth, P):
+    """returns dq BF [B*n, inner], dS BF [B,h,n,JP], dw_th"""
+    L = _lib.lib()
+    inner = g.heads * g.dim_head
+    dev = dO.hi.device
+    lo = dO.lo is not None
+    dq = empty_bf((g.B * g.n, inner), dev, lo=lo)
+    dS = empty_bf((g.B, g.heads, g.n, g.JP), dev, lo=lo)
+    dwth = torch.empty((g.heads, g.heads), dtype=torch.float32, device=dev)
+    nb = L.amdnuwa_xattn_bwd_workspace_bytes(C.byref(g))
+    ws = workspace(nb, dev)
+    check(L.amdnuwa_xattn_bwd(C.byref(g), _p(dO.hi), _p(dO.lo), dO.hi.stride(0), C.byref(pk.struct), _p(wth), _p(P.hi), _p(P.lo),
+                              _p(dS.hi), _p(dS.lo), _p(dq.hi), _p(dq.lo), inner, _p(dwth), 0, _p(ws), nb, _stream()),
+          'amdnuwa_xattn_bwd')
+    return dq, dS, dwth
+
+
+def xattn_kv_grads(g, dS, Pm, q, dO):
+    """dKp = scale * dS^T q, dVp = Pm^T dO per (sample, head): two batched TN GEMMs (reduction over queries).
+    returns fp32 [B, h, JP, dh] x 2"""
+    dev = q.hi.device
+    dKp = torch.empty((g.B, g.heads, g.JP, g.dim_head), dtype=torch.float32, device=dev)
+    dVp = torch.empty_like(dKp)
+    for (A, Bm, out, alpha) in ((dS, q, dKp, g.scale), (Pm, dO, dVp, 1.0)):
+        x3 = A.lo is not None and Bm.lo is not None
+        d = GemmDesc()
+        d.A, d.Alo, d.lda, d.strideA = _p(A.hi), _p(A.lo) if x3 else None, g.JP, g.n * g.JP
+        d.B, d.Blo, d.ldb = _p(Bm.hi), _p(Bm.lo) if x3 else None, Bm.hi.stride(0)
+        d.strideB, d.strideB_inner = g.n * Bm.hi.stride(0), g.dim_head
+        d.C, d.ldc, d.strideC, d.c_is_bf16 = _p(out), g.dim_head, g.JP * g.dim_head, 0
+        d.alpha, d.beta = float(alpha), 0.0
+        d.M, d.N, d.K = g.JP, g.dim_head, g.n
+        d.batch, d.batch_inner = g.B * g.heads, g.heads
+        d.strideA_inner = g.n * g.JP            # A / C are dense over (b, h): inner stride = one head
+        d.strideA = g.heads * g.n * g.JP
+        d.strideC_inner = g.JP * g.dim_head
+        d.strideC = g.heads * g.JP * g.dim_head
+        gemm_tn_batched(d, dev)
+    return dKp, dVp
+
+
+def xattn_unpack(g, dKp, dVp, lo):
+    L = _lib.lib()
+    inner = g.heads * g.dim_head
+    dev = dKp.device
+    dkv = empty_bf((g.B * g.T, 2 * inner), dev, lo=lo)
+    dnk = torch.empty((g.heads, g.dim_head), dtype=torch.float32, device=dev)
+    dnv = torch.empty_like(dnk)
+    check(L.amdnuwa_xattn_unpack(C.byref(g), _p(dKp), _p(dVp), _p(dkv.hi), _p(dkv.lo), 2 * inner, _p(dnk), _p(dnv), 0, _stream()),
+          'amdnuwa_xattn_unpack')
+    return dkv, dnk, dnv

@@ -1,0 +1,806 @@
+"""Host-side mirror of the reference's nuwa_pytorch/nuwa_pytorch.py (np.py) for the video-decoder
+training path: same class names, constructor kwargs, forward()/generate() signatures and
+state_dict keys, with every hot forward/backward routed to libamdnuwa (gfx950 HIP kernels) through
+`ops.py`.  nn.Linear / nn.Conv2d / nn.LayerNorm / nn.Embedding sub-modules are kept purely as
+PARAMETER CONTAINERS (identical keys, shapes and default initialisation as the reference); their
+own forward() is never called on the decoder path.
+
+Scope: decoder stack, embeddings, logits/loss = HIP.  The text encoder (row f1,
+256 tokens once per step) currently runs as PyTorch-ROCm ops on the GPU; NUWASketch / NUWAVideoAudio
+are not part of this round and raise NotImplementedError.
+"""
+import functools
+from functools import partial
+
+import torch
+import torch.nn.functional as F
+from torch import nn, einsum
+
+from . import kernels as K
+from . import ops
+
+MList = nn.ModuleList
+
+
+def exists(val):
+    return val is not None
+
+
+def default(val, d):
+    return val if exists(val) else d
+
+
+def cast_tuple(val, size=1):
+    return val if isinstance(val, tuple) else (val,) * size
+
+
+def calc_same_padding(kernel_size, dilation=1):
+    return dilation * (kernel_size - 1) // 2
+
+
+def mult_reduce(arr):
+    return functools.reduce(lambda x, y: x * y, arr, 1)
+
+
+def eval_decorator(fn):
+    def inner(model, *args, **kwargs):
+        was_training = model.training
+        model.eval()
+        out = fn(model, *args, **kwargs)
+        model.train(was_training)
+        return out
+    return inner
+
+
+def log(t, eps=1e-20):
+    return torch.log(t.clamp(min=eps))
+
+
+def gumbel_noise(t):
+    noise = torch.zeros_like(t).uniform_(0, 1)
+    return -log(-log(noise))
+
+
+def gumbel_sample(t, temperature=1., dim=-1):
+    return ((t / temperature) + gumbel_noise(t)).argmax(dim=dim)
+
+
+def prob_mask_like(shape, prob, device):
+    return torch.zeros(shape, device=device).float().uniform_(0, 1) < prob
+
+
+def batch_process(t, fn, chunks=10, dim=0):
+    chunks = [fn(t_chunk) for t_chunk in t.chunk(chunks, dim=dim)]
+    return torch.cat(chunks, dim=dim)
+
+
+def top_k(logits, thres=0.5):
+    num_logits = logits.shape[-1]
+    k = max(int((1 - thres) * num_logits), 1)
+    val, ind = torch.topk(logits, k)
+    probs = torch.full_like(logits, float('-inf'))
+    probs.scatter_(1, ind, val)
+    return probs
+
+
+def causal_neighbor_mask(video_shape, kernel_size, dilation):
+    """(N, K+1) bool, True = tap falls in the causal zero padding; column 0 (<bos>) never masked.
+    Same content as the reference's `mask` buffer (np.py:442-457), computed by index arithmetic."""
+    Fr, H, W = video_shape
+    kf, kh, kw = kernel_size
+    df, dh, dw = dilation
+    f = torch.arange(Fr)[:, None, None]
+    y = torch.arange(H)[None, :, None]
+    w = torch.arange(W)[None, None, :]
+    cols = [torch.zeros(Fr * H * W, dtype=torch.bool)]
+    for a in range(kf):
+        for b in range(kh):
+            for c in range(kw):
+                bad = ((f - (kf - 1 - a) * df) < 0) | ((y - (kh - 1 - b) * dh) < 0) | ((w - (kw - 1 - c) * dw) < 0)
+                cols.append(bad.expand(Fr, H, W).reshape(-1))
+    return torch.stack(cols, dim=1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# normalisations
+# ---------------------------------------------------------------------------------------------------
+
+class StableLayerNorm(nn.Module):
+    """np.py:88-95"""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+
+    def forward(self, x):
+        return ops.StableLNFn.apply(x, self.norm.weight, self.norm.bias)
+
+
+class SandwichNorm(nn.Module):
+    """np.py:112-128.  Standalone call = three nodes (LN, fn, LN); inside Transformer the whole
+    `SandwichNorm(fn)(x) + x` is one fused node (see Transformer.forward)."""
+
+    def __init__(self, *, dim, fn):
+        super().__init__()
+        self.prenorm = nn.LayerNorm(dim)
+        self.postnorm = nn.LayerNorm(dim)
+        self.fn = fn
+
+    def forward(self, x, **kwargs):
+        x = ops.LayerNormFn.apply(x, self.prenorm.weight, self.prenorm.bias, False)
+        x = self.fn(x, **kwargs)
+        return ops.LayerNormFn.apply(x, self.postnorm.weight, self.postnorm.bias, False)
+
+    # -- fused path -------------------------------------------------------------------------------
+    def _inner(self, context=None):
+        """(inner module, shift or None) when fn is one of the fusable hot modules, else None.
+        An Attention is fusable only as cross-attention (context given)."""
+        fn, shift = self.fn, None
+        if isinstance(fn, ShiftVideoTokens):
+            if fn.shift_time:
+                return None
+            if fn.shift_space:
+                shift = fn.image_size
+            fn = fn.fn
+        if isinstance(fn, (Sparse3DNA, FeedForward)):
+            return fn, shift
+        if isinstance(fn, Attention) and not fn.causal and context is not None:
+            return fn, shift
+        return None
+
+    def fused_residual(self, x, resid=None, context=None, context_mask=None):
+        """x_out = (resid if given else x) + postnorm(fn(prenorm(x)))  as one autograd node"""
+        inner, fmap = self._inner(context)
+        B, n, D = x.shape
+        meta = inner._meta(B, n, x.device, context=context, context_mask=context_mask)
+        if fmap is not None:
+            if D % 32:
+                raise RuntimeError('fused token shift needs dim % 32 == 0')
+            meta['shift'] = (n, fmap)
+        return ops.SandwichBlockFn.apply(x, resid, context if isinstance(inner, Attention) else None, meta,
+                                         self.prenorm.weight, self.prenorm.bias, self.postnorm.weight,
+                                         self.postnorm.bias, *inner._params())
+
+
+# ---------------------------------------------------------------------------------------------------
+# rotary (text encoder only)
+# ---------------------------------------------------------------------------------------------------
+
+class RotaryEmbedding(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        inv_freq = 1. / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+        self.register_buffer('inv_freq', inv_freq)
+
+    def forward(self, seq_len, device):
+        t = torch.arange(seq_len, device=device).type_as(self.inv_freq)
+        freqs = torch.einsum('i , j -> i j', t, self.inv_freq)
+        return torch.cat((freqs, freqs), dim=-1)
+
+
+def rotate_half(x):
+    x1, x2 = x.chunk(2, dim=-1)
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def apply_rotary_pos_emb(freqs, t):
+    rot_dim = freqs.shape[-1]
+    t, t_pass = t[..., :rot_dim], t[..., rot_dim:]
+    t = (t * freqs.cos()) + (rotate_half(t) * freqs.sin())
+    return torch.cat((t, t_pass), dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# token shift
+# ---------------------------------------------------------------------------------------------------
+
+class ShiftVideoTokens(nn.Module):
+    """np.py:185-253.  Inside the fused decoder block the shift costs nothing (it is an address
+    offset in the consumer GEMM's loader, see csrc/gemm.hip); this standalone forward materialises
+    it with index ops for arbitrary wrapped `fn`."""
+
+    def __init__(self, fn, image_size, shift_space=True, shift_time=False):
+        super().__init__()
+        self.fn = fn
+        self.image_size = image_size
+        self.shift_time = shift_time
+        self.shift_space = shift_space
+
+    def forward(self, x, **kwargs):
+        if not self.shift_time and not self.shift_space:
+            return self.fn(x, **kwargs)
+        fmap = self.image_size
+        b, n, D = x.shape
+        if n == 1:
+            return self.fn(x, **kwargs)
+        nchunk = 5 if (self.shift_space and self.shift_time) else (4 if self.shift_space else 3)
+        cs = -(-D // nchunk)
+        p = torch.arange(n - 1, device=x.device)
+        yy, ww, ff = (p // fmap) % fmap, p % fmap, p // (fmap * fmap)
+        xv = x[:, 1:]
+        parts, c0 = [], 0
+        plan = ([('f', fmap * fmap, ff)] if self.shift_time else []) + \
+               ([('h', fmap, yy), ('w', 1, ww)] if self.shift_space else [])
+        for _, off, coord in plan:
+            c1 = min(c0 + cs, D)
+            src = (p - off).clamp(min=0)
+            parts.append(xv[:, src, c0:c1] * (coord > 0).to(x.dtype)[None, :, None])
+            c0 = c1
+        parts.append(xv[:, :, c0:])
+        x = torch.cat((x[:, :1], torch.cat(parts, dim=-1)), dim=1)
+        return self.fn(x, **kwargs)
+
+
+class ShiftAudioTokens(nn.Module):
+    def __init__(self, fn, audio_tokens_per_timestep=1):
+        super().__init__()
+        raise NotImplementedError('NUWAVideoAudio (BASELINE cfg 5) is not built yet in nuwa_pytorch_amd')
+
+
+# ---------------------------------------------------------------------------------------------------
+# feed forward
+# ---------------------------------------------------------------------------------------------------
+
+class GEGLU(nn.Module):
+    def forward(self, x):
+        x, gate = x.chunk(2, dim=-1)
+        return x * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    """np.py:260-286; forward = GEMM -> fused GEGLU kernel -> GEMM (chunk_size only limits memory in the
+    reference and is numerically a no-op: kept in the signature, ignored)."""
+
+    def __init__(self, *, dim, mult=4, dropout=0., chunk_size=None):
+        super().__init__()
+        inner_dim = (dim * mult * 2) // 3
+        self.chunk_size = chunk_size
+        self.net = nn.Sequential(
+            nn.Linear(dim, inner_dim * 2, bias=False),
+            GEGLU(),
+            nn.Dropout(dropout),
+            nn.Linear(inner_dim, dim, bias=False)
+        )
+        self._cache = ops.WeightCache()
+
+    def _params(self):
+        return (self.net[0].weight, self.net[3].weight)
+
+    def _meta(self, B, n, device, **_):
+        if self.training and self.net[2].p > 0:
+            raise NotImplementedError('ff_dropout > 0 is not supported by the HIP path (all BASELINE configs use 0)')
+        return dict(kind='ff', cache=self._cache)
+
+    def forward(self, x):
+        B, n, D = x.shape
+        return ops.InnerFn.apply(x, None, self._meta(B, n, x.device), *self._params())
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------
+
+class Attention(nn.Module):
+    """np.py:290-379.  With `context` (the decoder's text cross-attention) the core runs on the MFMA
+    cross-attention kernels; the self-attention use (text encoder, row f1) is PyTorch-ROCm ops for now."""
+
+    def __init__(self, *, dim, heads=8, dim_head=64, causal=False, dropout=0.):
+        super().__init__()
+        inner_dim = heads * dim_head
+        self.heads = heads
+        self.dim_head = dim_head
+        self.causal = causal
+        self.scale = dim_head ** -0.5
+        self.null_k = nn.Parameter(torch.randn(heads, 1, dim_head))
+        self.null_v = nn.Parameter(torch.randn(heads, 1, dim_head))
+        self.talking_heads = nn.Conv2d(heads, heads, 1, bias=False)
+        self.dropout = nn.Dropout(dropout)
+        self.to_q = nn.Linear(dim, inner_dim, bias=False)
+        self.to_kv = nn.Linear(dim, inner_dim * 2, bias=False)
+        self.to_out = nn.Linear(inner_dim, dim, bias=False)
+        self._cache = ops.WeightCache()
+
+    def _params(self):
+        return (self.null_k, self.null_v, self.talking_heads.weight, self.to_q.weight, self.to_kv.weight, self.to_out.weight)
+
+    def _meta(self, B, n, device, context=None, context_mask=None, **_):
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError('attn_dropout > 0 is not supported by the HIP path (all BASELINE configs use 0)')
+        T = context.shape[1]
+        g = K.x_geom(B, n, T, self.heads, self.dim_head)
+        mask_u8 = context_mask.to(torch.uint8).contiguous() if exists(context_mask) else None
+        return dict(kind='xattn', cache=self._cache, xgeom=g, mask_u8=mask_u8, save=torch.is_grad_enabled())
+
+    def forward(self, x, mask=None, context=None, context_mask=None, rotary_pos_emb=None):
+        if exists(context) and not self.causal and x.is_cuda:
+            B, n, _ = x.shape
+            return ops.InnerFn.apply(x, context, self._meta(B, n, x.device, context, context_mask), *self._params())
+        return self._forward_selfattn(x, mask=mask, context=context, context_mask=context_mask,
+                                      rotary_pos_emb=rotary_pos_emb)
+
+    def _forward_selfattn(self, x, mask=None, context=None, context_mask=None, rotary_pos_emb=None):
+        # text-encoder path (row f1), PyTorch-ROCm ops
+        b, h = x.shape[0], self.heads
+        has_context = exists(context)
+        kv_input = context if has_context else x
+        q = self.to_q(x)
+        k, v = self.to_kv(kv_input).chunk(2, dim=-1)
+        sp = lambda t: t.reshape(t.shape[0], t.shape[1], h, -1).transpose(1, 2)
+        q, k, v = sp(q), sp(k), sp(v)
+        if not has_context and exists(rotary_pos_emb):
+            q, k, v = (apply_rotary_pos_emb(rotary_pos_emb, t) for t in (q, k, v))   # v too (quirk Q11)
+        k = torch.cat((self.null_k[None].expand(b, -1, -1, -1), k), dim=-2)
+        v = torch.cat((self.null_v[None].expand(b, -1, -1, -1), v), dim=-2)
+        sim = einsum('b h i d, b h j d -> b h i j', q * self.scale, k)
+        mask_value = -torch.finfo(x.dtype).max
+        key_mask = mask if not has_context else context_mask
+        if exists(key_mask):
+            key_mask = F.pad(key_mask, (1, 0), value=True)
+            sim = sim.masked_fill(~key_mask[:, None, None, :], mask_value)
+        if self.causal:
+            i, j = sim.shape[-2:]
+            cm = torch.ones(i, j, device=x.device, dtype=torch.bool).triu_(j - i + 1)
+            sim = sim.masked_fill(cm, mask_value)
+        attn = sim.softmax(dim=-1, dtype=torch.float32)
+        attn = self.dropout(self.talking_heads(attn))
+        out = einsum('b h i j, b h j d -> b h i d', attn, v)
+        out = out.transpose(1, 2).reshape(b, out.shape[2], -1)
+        return self.to_out(out)
+
+
+class Sparse3DNA(nn.Module):
+    """np.py:381-613, causal.  forward = qkv GEMM -> fused gfx950 3DNA kernel (no unfold
+    materialisation) -> to_out GEMM.  `query_num_frames_chunk` only bounds the reference's unfolded
+    tensors; it is accepted and ignored (chunked == unchunked bit for bit in the reference)."""
+
+    def __init__(self, dim, video_shape, kernel_size=3, dilation=1, heads=8, dim_head=64, dropout=0., causal=False,
+                 query_num_frames_chunk=None, rel_pos_bias=False):
+        super().__init__()
+        inner_dim = dim_head * heads
+        self.heads = heads
+        self.dim_head = dim_head
+        self.scale = dim_head ** -0.5
+        self.causal = causal
+        self.dropout = nn.Dropout(dropout)
+        self.to_q = nn.Linear(dim, inner_dim, bias=False)
+        self.to_kv = nn.Linear(dim, inner_dim * 2, bias=False)
+        self.talking_heads = nn.Conv2d(heads, heads, 1, bias=False)
+        self.to_out = nn.Linear(inner_dim, dim)
+        self.dilation = cast_tuple(dilation, size=3)
+        self.kernel_size = cast_tuple(kernel_size, size=3)
+        assert all(map(lambda n: n % 2 == 1, self.kernel_size)), 'kernel size must be odd'
+        self.kernel_numel = mult_reduce(self.kernel_size)
+        if rel_pos_bias:
+            raise NotImplementedError('Sparse3DNA(rel_pos_bias=True) is not supported by the HIP path yet')
+        if not causal:
+            raise NotImplementedError('non-causal Sparse3DNA (NUWASketch encoder) is not supported by the HIP path yet')
+        self.rel_pos_bias = None
+        self.video_shape = video_shape
+        max_frames, fmap_size, _ = video_shape
+        self.max_num_tokens = max_frames * fmap_size * fmap_size
+        self.query_num_frames_chunk = default(query_num_frames_chunk, max_frames)
+        self.register_buffer('mask', causal_neighbor_mask(video_shape, self.kernel_size, self.dilation))
+        self._cache = ops.WeightCache()
+
+    def _params(self):
+        return (self.to_q.weight, self.to_kv.weight, self.talking_heads.weight, self.to_out.weight, self.to_out.bias)
+
+    def _meta(self, B, n, device, **_):
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError('dropout inside Sparse3DNA is not supported (never enabled by Transformer, quirk Q14)')
+        assert n - 1 <= self.max_num_tokens, 'sequence longer than the video shape allows'
+        g = K.s3_geom(B, n, self.video_shape, self.kernel_size, self.dilation, self.heads, self.dim_head)
+        return dict(kind='s3', cache=self._cache, geom=g)
+
+    def forward(self, x, **kwargs):
+        B, n, _ = x.shape
+        return ops.InnerFn.apply(x, None, self._meta(B, n, x.device), *self._params())
+
+
+class SparseCausal2DNA(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError('NUWAVideoAudio (BASELINE cfg 5) is not built yet in nuwa_pytorch_amd')
+
+
+class SparseCross2DNA(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError('NUWASketch is outside this round (SURVEY.md section 8 row f4)')
+
+
+class CrossModalityCrossAttention(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError('NUWAVideoAudio (BASELINE cfg 5) is not built yet in nuwa_pytorch_amd')
+
+
+# ---------------------------------------------------------------------------------------------------
+# transformer stacks
+# ---------------------------------------------------------------------------------------------------
+
+class Transformer(nn.Module):
+    """np.py:1071-1182.  forward accepts (and ignores) rotary_pos_emb for the sparse-3DNA decoder;
+    for a plain-attention encoder it is routed to the self-attention (superset of the reference,
+    whose non-reversible encoder raises TypeError -- quirk Q1)."""
+
+    def __init__(self, *, dim, depth, causal=False, heads=8, dim_head=64, ff_mult=4, cross_attend=False,
+                 attn_dropout=0., ff_dropout=0., ff_chunk_size=None, cross_2dna_attn=False, cross_2dna_image_size=None,
+                 cross_2dna_kernel_size=3, cross_2dna_dilations=(1,), sparse_3dna_attn=False, sparse_3dna_kernel_size=3,
+                 sparse_3dna_video_shape=None, sparse_3dna_query_num_frames_chunk=None, sparse_3dna_dilations=(1,),
+                 sparse_3dna_rel_pos_bias=False, shift_video_tokens=False, rotary_pos_emb=False):
+        super().__init__()
+        assert not (sparse_3dna_attn and not exists(sparse_3dna_video_shape)), 'sparse_3dna_video_shape must be defined if turned on'
+        assert not (cross_2dna_attn and not exists(cross_2dna_image_size)), 'cross_2dna_image_size must be defined'
+        self.layers = MList([])
+        for ind in range(depth):
+            if sparse_3dna_attn:
+                dilation = sparse_3dna_dilations[ind % len(sparse_3dna_dilations)]
+                self_attn = Sparse3DNA(dim=dim, heads=heads, dim_head=dim_head, causal=causal,
+                                       kernel_size=sparse_3dna_kernel_size, dilation=dilation,
+                                       video_shape=sparse_3dna_video_shape,
+                                       query_num_frames_chunk=sparse_3dna_query_num_frames_chunk,
+                                       rel_pos_bias=sparse_3dna_rel_pos_bias)
+            else:
+                self_attn = Attention(dim=dim, heads=heads, dim_head=dim_head, causal=causal, dropout=attn_dropout)
+            cross_attn = None
+            if cross_attend:
+                if cross_2dna_attn:
+                    cross_attn = SparseCross2DNA()
+                else:
+                    cross_attn = Attention(dim=dim, heads=heads, dim_head=dim_head, dropout=attn_dropout)
+            ff = FeedForward(dim=dim, mult=ff_mult, dropout=ff_dropout, chunk_size=ff_chunk_size)
+            if sparse_3dna_attn and shift_video_tokens:
+                fmap_size = sparse_3dna_video_shape[-1]
+                self_attn = ShiftVideoTokens(self_attn, image_size=fmap_size)
+                ff = ShiftVideoTokens(ff, image_size=fmap_size)
+            self.layers.append(MList([
+                SandwichNorm(dim=dim, fn=self_attn),
+                SandwichNorm(dim=dim, fn=cross_attn) if cross_attend else None,
+                SandwichNorm(dim=dim, fn=ff)
+            ]))
+        self.norm = StableLayerNorm(dim)
+
+    def forward_layers(self, x, mask=None, context=None, context_mask=None, rotary_pos_emb=None):
+        for attn, cross_attn, ff in self.layers:
+            if attn._inner() is not None and x.is_cuda:
+                x = attn.fused_residual(x)
+            else:
+                x = attn(x, mask=mask, rotary_pos_emb=rotary_pos_emb) + x
+            if exists(cross_attn):
+                if cross_attn._inner(context) is not None and x.is_cuda:
+                    x = cross_attn.fused_residual(x, context=context, context_mask=context_mask)
+                else:
+                    x = cross_attn(x, context=context, mask=mask, context_mask=context_mask) + x
+            if ff._inner() is not None and x.is_cuda:
+                x = ff.fused_residual(x)
+            else:
+                x = ff(x) + x
+        return x
+
+    def forward(self, x, mask=None, context=None, context_mask=None, rotary_pos_emb=None):
+        x = self.forward_layers(x, mask=mask, context=context, context_mask=context_mask, rotary_pos_emb=rotary_pos_emb)
+        return self.norm(x)
+
+
+# reversible plumbing (rev.py) ------------------------------------------------------------------------
+
+def route_args(router, args, depth):
+    routed_args = [(dict(), dict()) for _ in range(depth)]
+    matched_keys = [key for key in args.keys() if key in router]
+    for key in matched_keys:
+        val = args[key]
+        for d, ((f_args, g_args), routes) in enumerate(zip(routed_args, router[key])):
+            new_f_args, new_g_args = map(lambda route: ({key: val} if route else {}), routes)
+            routed_args[d] = ({**f_args, **new_f_args}, {**g_args, **new_g_args})
+    return routed_args
+
+
+class Deterministic(nn.Module):
+    """rev.py:20-50: keeps the `.net` level of the state-dict key hierarchy.  No dropout on this path,
+    so there is no RNG to record/replay."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, *args, **kwargs):
+        return self.net(*args, **kwargs)
+
+
+class ReversibleBlock(nn.Module):
+    """rev.py:54-106: y1 = x1 + f(x2); y2 = x2 + g(y1)."""
+
+    def __init__(self, f, g):
+        super().__init__()
+        self.f = Deterministic(f)
+        self.g = Deterministic(g)
+
+    def forward(self, x1, x2, f_args={}, g_args={}):
+        f, g = self.f.net, self.g.net
+        if isinstance(f, SandwichNorm) and f._inner(f_args.get('context')) is not None and x1.is_cuda:
+            y1 = f.fused_residual(x2, resid=x1, context=f_args.get('context'), context_mask=f_args.get('context_mask'))
+        else:
+            y1 = x1 + f(x2, **f_args)
+        if isinstance(g, SandwichNorm) and g._inner() is not None and x1.is_cuda:
+            y2 = g.fused_residual(y1, resid=x2)
+        else:
+            y2 = x2 + g(y1, **g_args)
+        return y1, y2
+
+
+class ReversibleSequence(nn.Module):
+    """rev.py:126-142.  Same arithmetic as the reference (x -> (x, x); blocks; sum of the halves).
+    Activations are kept by autograd (the reference's O(1)-memory recomputation is a memory
+    optimisation, not a numerical one; on a 288 GB MI355X the decoder's activations fit)."""
+
+    def __init__(self, blocks, args_route={}):
+        super().__init__()
+        self.args_route = args_route
+        self.blocks = nn.ModuleList([ReversibleBlock(f=f, g=g) for f, g in blocks])
+
+    def forward(self, x, **kwargs):
+        args = route_args(self.args_route, kwargs, len(self.blocks))
+        x1, x2 = x, x
+        for block, (f_args, g_args) in zip(self.blocks, args):
+            x1, x2 = block(x1, x2, f_args=f_args, g_args=g_args)
+        return x1 + x2
+
+
+class ReversibleTransformer(nn.Module):
+    """np.py:1184-1295 (every parameter appears twice in the state dict: layers.* and net.blocks.*)."""
+
+    def __init__(self, *, dim, depth, causal=False, heads=8, dim_head=64, ff_mult=4, cross_attend=False,
+                 attn_dropout=0., ff_dropout=0., ff_chunk_size=None, cross_2dna_attn=False, cross_2dna_image_size=None,
+                 cross_2dna_kernel_size=3, cross_2dna_dilations=(1,), sparse_3dna_attn=False, sparse_3dna_kernel_size=3,
+                 sparse_3dna_video_shape=None, sparse_3dna_query_num_frames_chunk=None, sparse_3dna_dilations=(1,),
+                 sparse_3dna_rel_pos_bias=False, shift_video_tokens=False, rotary_pos_emb=False):
+        super().__init__()
+        assert not (sparse_3dna_attn and not exists(sparse_3dna_video_shape)), 'sparse_3dna_video_shape must be defined if turned on'
+        self.layers = MList([])
+        for ind in range(depth):
+            if sparse_3dna_attn:
+                dilation = sparse_3dna_dilations[ind % len(sparse_3dna_dilations)]
+                image_size = sparse_3dna_video_shape[-1]
+                self_attn = Sparse3DNA(dim=dim, heads=heads, dim_head=dim_head, causal=causal,
+                                       kernel_size=sparse_3dna_kernel_size, dilation=dilation,
+                                       video_shape=sparse_3dna_video_shape,
+                                       query_num_frames_chunk=sparse_3dna_query_num_frames_chunk,
+                                       rel_pos_bias=sparse_3dna_rel_pos_bias)
+            else:
+                image_size = None
+                self_attn = Attention(dim=dim, heads=heads, dim_head=dim_head, causal=causal, dropout=attn_dropout)
+            wrapper_fn = partial(ShiftVideoTokens, image_size=image_size, shift_space=sparse_3dna_attn and shift_video_tokens)
+            self.layers.append(MList([
+                SandwichNorm(dim=dim, fn=wrapper_fn(self_attn)),
+                SandwichNorm(dim=dim, fn=wrapper_fn(FeedForward(dim=dim, mult=ff_mult, dropout=ff_dropout, chunk_size=ff_chunk_size)))
+            ]))
+            if not cross_attend:
+                continue
+            if cross_2dna_attn:
+                cross_attn = SparseCross2DNA()
+            else:
+                cross_attn = Attention(dim=dim, heads=heads, dim_head=dim_head, dropout=attn_dropout)
+            self.layers.append(MList([
+                SandwichNorm(dim=dim, fn=cross_attn),
+                SandwichNorm(dim=dim, fn=wrapper_fn(FeedForward(dim=dim, mult=ff_mult, dropout=ff_dropout, chunk_size=ff_chunk_size)))
+            ]))
+        attn_context_layer = ((True, False),) if cross_attend else tuple()
+        route_attn = ((True, False), *attn_context_layer) * depth
+        route_context = ((False, False), *attn_context_layer) * depth
+        context_route_map = {'context': route_context, 'context_mask': route_context} if cross_attend else {}
+        attn_route_map = {'mask': route_attn, 'rotary_pos_emb': route_attn}
+        self.net = ReversibleSequence(self.layers, args_route={**context_route_map, **attn_route_map})
+        self.norm = StableLayerNorm(dim)
+
+    def forward_layers(self, x, **kwargs):
+        return self.net(x, **kwargs)
+
+    def forward(self, x, **kwargs):
+        return self.norm(self.net(x, **kwargs))
+
+
+# ---------------------------------------------------------------------------------------------------
+# embeddings
+# ---------------------------------------------------------------------------------------------------
+
+def frac_gradient(t, frac):
+    return t * frac + t.detach() * (1 - frac)
+
+
+class Embedding(nn.Module):
+    """np.py:1659-1671"""
+
+    def __init__(self, *shape, frac_gradient=1.):
+        super().__init__()
+        self.frac_gradient = frac_gradient
+        self.embed = nn.Embedding(*shape)
+
+    def forward(self, x):
+        x = self.embed(x)
+        if self.training and self.frac_gradient < 1:
+            x = frac_gradient(x, self.frac_gradient)
+        return x
+
+
+class AxialPositionalEmbedding(nn.Module):
+    """np.py:1675-1709"""
+
+    def __init__(self, dim, *, shape):
+        super().__init__()
+        shape = tuple(filter(lambda t: t > 1, shape))
+        self.dim = dim
+        self.shape = shape
+        self.num_axials = len(shape)
+        for axial_ind, axial_len in enumerate(shape):
+            setattr(self, f'axial{axial_ind + 1}', nn.Parameter(torch.randn(axial_len, dim)))
+
+    def forward(self, *, flatten=True):
+        positions = None
+        for axial_ind in range(self.num_axials):
+            axial_pos = getattr(self, f'axial{axial_ind + 1}')
+            if not exists(positions):
+                positions = axial_pos
+                continue
+            positions = positions.unsqueeze(-2) + axial_pos
+        if flatten:
+            positions = positions.reshape(-1, positions.shape[-1])
+        return positions
+
+
+# ---------------------------------------------------------------------------------------------------
+# main class
+# ---------------------------------------------------------------------------------------------------
+
+class NUWA(nn.Module):
+    """np.py:1723-1964: identical constructor kwargs, forward() and generate() signatures."""
+
+    def __init__(self, *, dim, vae=None, image_size=None, max_video_frames=5, text_num_tokens=49408,
+                 text_max_seq_len=256, text_enc_depth=6, text_enc_dim_head=64, text_enc_heads=8, text_rotary_pos_emb=True,
+                 enc_reversible=False, dec_depth=6, dec_dim_head=64, dec_heads=8, dec_reversible=False, attn_dropout=0.,
+                 ff_dropout=0., ff_chunk_size=None, embed_gradient_frac=0.2, shift_video_tokens=True,
+                 sparse_3dna_kernel_size=3, sparse_3dna_query_num_frames_chunk=None, sparse_3dna_dilation=1,
+                 sparse_3dna_rel_pos_bias=False):
+        super().__init__()
+        assert exists(vae) ^ exists(image_size), 'either VAE or image size must be specified'
+        assert exists(vae), 'a VAE must be passed (the reference dereferences vae.num_layers unconditionally, quirk Q3)'
+        self.vae = vae.copy_for_eval()
+        image_size = vae.image_size
+        vae_num_layers = vae.num_layers
+        num_image_tokens = vae.codebook_size
+        self.text_max_seq_len = text_max_seq_len
+        self.text_embedding = Embedding(text_num_tokens, dim, frac_gradient=embed_gradient_frac)
+        self.text_abs_pos_emb = Embedding(text_max_seq_len, dim) if not text_rotary_pos_emb else None
+        self.text_rotary_pos_emb = RotaryEmbedding(dim=min(32, text_enc_dim_head)) if text_rotary_pos_emb else None
+        enc_transformer_klass = Transformer if not enc_reversible else ReversibleTransformer
+        self.text_transformer = enc_transformer_klass(dim=dim, depth=text_enc_depth, heads=text_enc_heads,
+                                                      dim_head=text_enc_dim_head, attn_dropout=attn_dropout,
+                                                      ff_dropout=ff_dropout, rotary_pos_emb=text_rotary_pos_emb)
+        self.video_bos = nn.Parameter(torch.randn(dim))
+        self.image_embedding = Embedding(num_image_tokens, dim, frac_gradient=embed_gradient_frac)
+        fmap_size = image_size // (2 ** vae_num_layers)
+        self.video_fmap_size = fmap_size
+        self.max_video_frames = max_video_frames
+        video_shape = (max_video_frames, fmap_size, fmap_size)
+        self.video_shape = video_shape
+        self.video_pos_emb = AxialPositionalEmbedding(dim, shape=video_shape)
+        sparse_3dna_dilations = tuple(range(1, sparse_3dna_dilation + 1)) if not isinstance(sparse_3dna_dilation, (list, tuple)) else sparse_3dna_dilation
+        dec_transformer_klass = Transformer if not dec_reversible else ReversibleTransformer
+        self.video_transformer = dec_transformer_klass(
+            dim=dim, depth=dec_depth, heads=dec_heads, dim_head=dec_dim_head, causal=True, cross_attend=True,
+            attn_dropout=attn_dropout, ff_dropout=ff_dropout, ff_chunk_size=ff_chunk_size,
+            shift_video_tokens=shift_video_tokens, sparse_3dna_video_shape=video_shape, sparse_3dna_attn=True,
+            sparse_3dna_kernel_size=sparse_3dna_kernel_size, sparse_3dna_dilations=sparse_3dna_dilations,
+            sparse_3dna_query_num_frames_chunk=sparse_3dna_query_num_frames_chunk,
+            sparse_3dna_rel_pos_bias=sparse_3dna_rel_pos_bias)
+        self.to_logits = nn.Linear(dim, num_image_tokens, bias=False)
+        self._cache = ops.WeightCache()
+
+    # -- text side (adjacent, row f1) ------------------------------------------------------------
+    def embed_text(self, text, mask=None):
+        batch, seq_len, device = *text.shape, text.device
+        assert seq_len <= self.text_max_seq_len, 'your input text has a greater length than what was designated on initialization'
+        tokens = self.text_embedding(text)
+        if exists(self.text_abs_pos_emb):
+            pos_emb = self.text_abs_pos_emb(torch.arange(seq_len, device=device))
+            tokens = tokens + pos_emb[None]
+        rotary_pos_emb = None
+        if exists(self.text_rotary_pos_emb):
+            rotary_pos_emb = self.text_rotary_pos_emb(seq_len, device=device)
+        return self.text_transformer(tokens, mask=mask, rotary_pos_emb=rotary_pos_emb)
+
+    # -- decoder side (the hot path) ----------------------------------------------------------------
+    def embed_video(self, ids_in):
+        """ids_in (b, m) -> (b, m+1, dim): <bos> + positional + token embedding (np.py:1940-1944)"""
+        pe = self.video_pos_emb
+        if ids_in.is_cuda and pe.num_axials == 3:
+            frac = self.image_embedding.frac_gradient if self.training else 1.
+            return ops.EmbedAssembleFn.apply(ids_in, self.image_embedding.embed.weight, pe.axial1, pe.axial2, pe.axial3,
+                                             self.video_bos, self.video_shape, float(frac))
+        emb = self.image_embedding(ids_in)
+        emb = pe()[:ids_in.shape[1]] + emb
+        bos = self.video_bos[None, None].expand(ids_in.shape[0], 1, -1)
+        return torch.cat((bos, emb), dim=1)
+
+    def decode_hidden(self, frame_embeddings, text_embeds, text_mask):
+        """decoder layers WITHOUT the final StableLayerNorm (fused into the logits/loss node)"""
+        return self.video_transformer.forward_layers(frame_embeddings, context=text_embeds, context_mask=text_mask)
+
+    def _final(self, hidden, targets=None):
+        nrm = self.video_transformer.norm.norm
+        if hidden.is_cuda:
+            if exists(targets):
+                return ops.LogitsLossFn.apply(hidden, targets, nrm.weight, nrm.bias, self.to_logits.weight, self._cache)
+            return ops.LogitsFn.apply(hidden, nrm.weight, nrm.bias, self.to_logits.weight, self._cache)
+        raise RuntimeError('nuwa_pytorch_amd: the decoder path needs a HIP device; there is no CPU fallback')
+
+    @torch.no_grad()
+    @eval_decorator
+    def generate(self, *, text, filter_thres=0.9, temperature=1., decode_max_batchsize=10, cond_scale=2., num_frames=None):
+        """np.py:1841-1915 (token-by-token, whole prefix recomputed as in the reference; KV caching is row f3)."""
+        batch, seq_len, device = *text.shape, text.device
+        text_mask = text != 0
+        text_embeds = self.embed_text(text, mask=text_mask)
+        video_indices = torch.empty((batch, 0), device=device, dtype=torch.long)
+        num_tokens_per_frame = self.video_fmap_size ** 2
+        num_frames = default(num_frames, self.max_video_frames)
+        total_video_tokens = num_tokens_per_frame * num_frames
+        max_video_tokens = num_tokens_per_frame * self.max_video_frames
+        for ind in range(total_video_tokens):
+            video_indices_input = video_indices
+            num_video_tokens = video_indices.shape[1]
+            if num_video_tokens > max_video_tokens:
+                curr_frame_tokens = num_video_tokens % num_tokens_per_frame
+                lookback_tokens = (self.max_video_frames - (0 if curr_frame_tokens == 0 else 1)) * num_tokens_per_frame + curr_frame_tokens
+                video_indices_input = video_indices[:, -lookback_tokens:]
+            frame_embeddings = self.embed_video(video_indices_input)
+            hidden = self.decode_hidden(frame_embeddings, text_embeds, text_mask)
+            logits = self._final(hidden)
+            if cond_scale != 1:
+                # the reference feeds the conditioned decoder OUTPUT back in as the unconditional input (np.py:1894-1898)
+                cond_out = self.video_transformer.norm(hidden)
+                uncond_hidden = self.decode_hidden(cond_out, text_embeds, torch.zeros_like(text_mask).bool())
+                uncond_logits = self._final(uncond_hidden)
+                logits = uncond_logits + (logits - uncond_logits) * cond_scale
+            logits = logits[:, -1, :]
+            filtered_logits = top_k(logits, thres=filter_thres)
+            sample = gumbel_sample(filtered_logits, temperature=temperature, dim=-1)
+            video_indices = torch.cat((video_indices, sample[:, None]), dim=1)
+        codes = self.vae.codebook[video_indices]
+        fs = self.video_fmap_size
+        codes = codes.reshape(batch, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
+        image_reconstructions = batch_process(codes, self.vae.decode, chunks=decode_max_batchsize)
+        return image_reconstructions.reshape(batch, -1, *image_reconstructions.shape[1:])
+
+    def forward(self, *, text, video=None, return_loss=False, cond_dropout_prob=0.2):
+        batch, seq_len, frames, device = *text.shape, video.shape[1], text.device
+        text_mask = text != 0
+        text_embeds = self.embed_text(text, mask=text_mask)
+        if video.dtype == torch.long:
+            frame_indices = video
+        else:
+            assert frames == self.max_video_frames, f'you must give the full video frames ({self.max_video_frames}) during training'
+            assert exists(self.vae), 'VAE must be passed in if you wish for video to be encoded to ids automatically'
+            frame_indices = self.vae.get_video_indices(video)
+        frame_indices = frame_indices.reshape(batch, -1)
+        frame_indices_input = frame_indices[:, :-1] if return_loss else frame_indices
+        frame_embeddings = self.embed_video(frame_indices_input)
+        if self.training and cond_dropout_prob > 0:
+            uncond_mask = prob_mask_like((batch,), cond_dropout_prob, device=device)
+            text_mask = text_mask * (~uncond_mask)[:, None]
+        hidden = self.decode_hidden(frame_embeddings, text_embeds, text_mask)
+        if not return_loss:
+            return self._final(hidden)
+        return self._final(hidden, frame_indices)
+
+
+class NUWASketch(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError('NUWASketch is outside this round (SURVEY.md section 8 row f4)')
+
+
+class NUWAVideoAudio(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError('NUWAVideoAudio (BASELINE cfg 5) is not built yet in nuwa_pytorch_amd')

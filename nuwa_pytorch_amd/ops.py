@@ -1,0 +1,449 @@
+"""autograd.Function wrappers that sequence the libamdnuwa kernels for the decoder sub-blocks.
+
+Each decoder sub-block of the reference (Transformer.forward np.py:1174-1180)
+
+        x = SandwichNorm(fn)(x, ...) + x          fn in {Shift(Sparse3DNA), Attention(context), Shift(FeedForward)}
+
+is ONE autograd node here (`SandwichBlockFn`): pre-LN -> GEMM(s) [token shift folded into the GEMM
+loader] -> attention core / GEGLU -> GEMM -> post-LN + residual, with a hand-written backward that
+calls the backward kernels.  The residual stream, LayerNorm statistics, softmax and all accumulators
+are fp32; GEMM / attention operands are bf16 (plus a bf16 residual in 'bf16x3' parity mode).
+
+The same inner stages also back the standalone modules (Sparse3DNA, Attention, FeedForward,
+LayerNorm wrappers) through `InnerFn`, so `Sparse3DNA(...)(x)` alone works as in the reference.
+"""
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+from .kernels import BF
+
+
+def _ru(v, m):
+    return (v + m - 1) // m * m
+
+
+class WeightCache:
+    """bf16 (hi[/lo]) operand copies of fp32 master weights; rebuilt when a parameter changes
+    (optimizer step bumps `_version`) or the precision mode changes."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, params, builder):
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (K.get_precision(),)
+        ent = self._store.get(key)
+        if ent is None or ent[0] != ver:
+            with torch.no_grad():
+                ent = (ver, builder())
+            self._store[key] = ent
+        return ent[1]
+
+    def clear(self):
+        self._store.clear()
+
+
+def _cast(w):
+    out = K.empty_bf(tuple(w.shape), w.device)
+    K.cast_pad(w.detach(), out)
+    return out
+
+
+def _cast_t(w):
+    out = K.empty_bf((w.shape[1], w.shape[0]), w.device)
+    K.transpose_cast(w.detach(), out)
+    return out
+
+
+# =================================================================================================
+# inner stages.  fwd(h: BF [R, D], ...) -> (y fp32 [R, D], saved) ; bwd(saved, dy: BF) -> (dh fp32, grads)
+# =================================================================================================
+
+class S3Inner:
+    """to_q/to_kv -> Sparse3DNA core -> to_out (np.py:481-613).  params: to_q.w, to_kv.w, talking_heads.w,
+    to_out.w, to_out.b"""
+    nparams = 5
+
+    @staticmethod
+    def weights(cache, p):
+        wq, wkv, wth, wo, bo = p
+
+        def build():
+            inner, D = wq.shape
+            qkv = K.empty_bf((3 * inner, D), wq.device)
+            K.cast_pad(wq.detach(), qkv, row0=0)
+            K.cast_pad(wkv.detach(), qkv, row0=inner)
+            qkvT = K.empty_bf((D, 3 * inner), wq.device)
+            K.transpose_cast(wq.detach(), qkvT, col0=0)
+            K.transpose_cast(wkv.detach(), qkvT, col0=inner)
+            return dict(qkv=qkv, qkvT=qkvT, out=_cast(wo), outT=_cast_t(wo))
+        return cache.get('s3', (wq, wkv, wo), build)
+
+    @staticmethod
+    def fwd(h, p, meta):
+        W = S3Inner.weights(meta['cache'], p)
+        wth, bo = p[2], p[4]
+        g = meta['geom']
+        qkv = K.gemm_nt(h, W['qkv'], out_bf16=True, shift=meta.get('shift'))
+        o = K.sparse3dna_fwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous())
+        y = K.gemm_nt(o, W['out'], bias=bo.detach())
+        return y, (h, qkv, o)
+
+    @staticmethod
+    def bwd(saved, dy, p, meta, need_dbias=True, dy_f32=None):
+        h, qkv, o = saved
+        W = S3Inner.weights(meta['cache'], p)
+        wq, wkv, wth, wo, bo = p
+        g = meta['geom']
+        inner = g.heads * g.dim_head
+        d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
+        dwo = torch.empty_like(wo)
+        K.gemm_tn(dy, o, dwo)
+        dqkv, dwth = K.sparse3dna_bwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), d_o)
+        dh = K.gemm_nt(dqkv, W['qkvT'])
+        dwq, dwkv = torch.empty_like(wq), torch.empty_like(wkv)
+        sh = meta.get('shift')
+        K.gemm_tn(K.view(dqkv, cols=slice(0, inner)), h, dwq, shift=sh)
+        K.gemm_tn(K.view(dqkv, cols=slice(inner, 3 * inner)), h, dwkv, shift=sh)
+        dbo = K.colsum(dy_f32) if (need_dbias and dy_f32 is not None) else None
+        return dh, None, [dwq, dwkv, dwth.reshape(wth.shape), dwo, dbo]
+
+
+class XInner:
+    """to_q(x), to_kv(context) -> cross-attention core -> to_out (np.py:315-379, context given).
+    params: null_k, null_v, talking_heads.w, to_q.w, to_kv.w, to_out.w"""
+    nparams = 6
+
+    @staticmethod
+    def weights(cache, p):
+        nk, nv, wth, wq, wkv, wo = p
+        return cache.get('x', (wq, wkv, wo), lambda: dict(q=_cast(wq), qT=_cast_t(wq), kv=_cast(wkv), kvT=_cast_t(wkv),
+                                                        out=_cast(wo), outT=_cast_t(wo)))
+
+    @staticmethod
+    def fwd(h, p, meta):
+        W = XInner.weights(meta['cache'], p)
+        nk, nv, wth = p[0], p[1], p[2]
+        g = meta['xgeom']
+        ctx = meta['ctx_bf']
+        q = K.gemm_nt(h, W['q'], out_bf16=True)
+        kv = K.gemm_nt(ctx, W['kv'], out_bf16=True)
+        pk = K.xattn_pack(g, kv, nk.detach().reshape(g.heads, g.dim_head).contiguous(),
+                          nv.detach().reshape(g.heads, g.dim_head).contiguous(), meta['mask_u8'])
+        wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
+        o, P, Pm = K.xattn_fwd(g, q, pk, wth2, save=meta.get('save', True))
+        y = K.gemm_nt(o, W['out'])
+        return y, (h, ctx, q, pk, P, Pm, o)
+
+    @staticmethod
+    def bwd(saved, dy, p, meta, need_dbias=False, dy_f32=None):
+        h, ctx, q, pk, P, Pm, o = saved
+        W = XInner.weights(meta['cache'], p)
+        nk, nv, wth, wq, wkv, wo = p
+        g = meta['xgeom']
+        wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
+        d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
+        dwo = torch.empty_like(wo)
+        K.gemm_tn(dy, o, dwo)
+        dq, dS, dwth = K.xattn_bwd(g, d_o, pk, wth2, P)
+        dKp, dVp = K.xattn_kv_grads(g, dS, Pm, q, d_o)
+        dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=dy.lo is not None)
+        dh = K.gemm_nt(dq, W['qT'])
+        dwq, dwkv = torch.empty_like(wq), torch.empty_like(wkv)
+        K.gemm_tn(dq, h, dwq)
+        K.gemm_tn(dkv, ctx, dwkv)
+        dctx = K.gemm_nt(dkv, W['kvT'])
+        return dh, dctx, [dnk.reshape(nk.shape), dnv.reshape(nv.shape), dwth.reshape(wth.shape), dwq, dwkv, dwo]
+
+
+class FFInner:
+    """Linear -> GEGLU -> Linear (np.py:255-286).  params: net.0.w (2*FFI, D), net.3.w (D, FFI).
+    The inner width is zero-padded to FP = roundup(FFI, 32) inside the bf16 copies."""
+    nparams = 2
+
+    @staticmethod
+    def weights(cache, p):
+        w1, w2 = p
+
+        def build():
+            D, FFI = w2.shape
+            FP = _ru(FFI, 32)
+            dev = w1.device
+            w1p = K.zeros_bf((2 * FP, D), dev)
+            K.cast_pad(w1.detach()[:FFI], w1p, row0=0)
+            K.cast_pad(w1.detach()[FFI:], w1p, row0=FP)
+            w1T = K.zeros_bf((D, 2 * FP), dev)
+            K.transpose_cast(w1.detach()[:FFI], w1T, col0=0)
+            K.transpose_cast(w1.detach()[FFI:], w1T, col0=FP)
+            w2p = K.zeros_bf((D, FP), dev)
+            K.cast_pad(w2.detach(), w2p, Cp=FP)
+            w2T = K.zeros_bf((FP, D), dev)
+            K.transpose_cast(w2.detach(), w2T)
+            return dict(w1=w1p, w1T=w1T, w2=w2p, w2T=w2T, FP=FP, FFI=FFI)
+        return cache.get('ff', (w1, w2), build)
+
+    @staticmethod
+    def fwd(h, p, meta):
+        W = FFInner.weights(meta['cache'], p)
+        u = K.gemm_nt(h, W['w1'], out_bf16=True, shift=meta.get('shift'))
+        gg = K.geglu_fwd(u, W['FP'])
+        y = K.gemm_nt(gg, W['w2'])
+        return y, (h, u, gg)
+
+    @staticmethod
+    def bwd(saved, dy, p, meta, need_dbias=False, dy_f32=None):
+        h, u, gg = saved
+        W = FFInner.weights(meta['cache'], p)
+        w1, w2 = p
+        FP, FFI = W['FP'], W['FFI']
+        dgg = K.gemm_nt(dy, W['w2T'], out_bf16=True)
+        dw2 = torch.empty_like(w2)
+        K.gemm_tn(dy, gg, dw2, N2=FFI)
+        du = K.geglu_bwd(u, dgg, FP)
+        dh = K.gemm_nt(du, W['w1T'])
+        dw1 = torch.empty_like(w1)
+        sh = meta.get('shift')
+        K.gemm_tn(K.view(du, cols=slice(0, FP)), h, dw1[:FFI], shift=sh, N1=FFI)
+        K.gemm_tn(K.view(du, cols=slice(FP, 2 * FP)), h, dw1[FFI:], shift=sh, N1=FFI)
+        return dh, None, [dw1, dw2]
+
+
+INNERS = {'s3': S3Inner, 'xattn': XInner, 'ff': FFInner}
+
+
+def _ctx_to_bf(context):
+    """context fp32 [B, T, D] -> BF [B*T, D]"""
+    B, T, D = context.shape
+    out = K.empty_bf((B * T, D), context.device)
+    K.cast_pad(context.detach().reshape(B * T, D), out)
+    return out
+
+
+# =================================================================================================
+# fused decoder sub-block:  x_out = x + postLN(inner(shift(preLN(x))))
+# =================================================================================================
+
+class SandwichBlockFn(Function):
+    """x_out = (resid if given else x) + postLN(inner(shift(preLN(x)))).
+    args: x [B, n, D] fp32, resid (or None), context (or None), meta dict, pre_w, pre_b, post_w, post_b, *inner params"""
+
+    @staticmethod
+    def forward(ctx, x, resid, context, meta, pre_w, pre_b, post_w, post_b, *p):
+        inner = INNERS[meta['kind']]
+        B, n, D = x.shape
+        x2 = x.detach().contiguous().reshape(B * n, D)
+        r2_ = x2 if resid is None else resid.detach().contiguous().reshape(B * n, D)
+        meta = dict(meta)
+        if meta['kind'] == 'xattn':
+            meta['ctx_bf'] = _ctx_to_bf(context)
+        h, m1, r1, _ = K.ln_fwd(x2, pre_w.detach(), pre_b.detach())
+        y, saved = inner.fwd(h, p, meta)
+        xo, m2, r2 = K.ln_fwd(y, post_w.detach(), post_b.detach(), resid=r2_)
+        ctx.meta, ctx.inner_saved, ctx.p = meta, saved, p
+        ctx.has_ctx = context is not None
+        ctx.has_resid = resid is not None
+        ctx.save_for_backward(x2, y, m1, r1, m2, r2, pre_w, post_w)
+        ctx.shape = (B, n, D)
+        return xo.reshape(B, n, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, y, m1, r1, m2, r2, pre_w, post_w = ctx.saved_tensors
+        B, n, D = ctx.shape
+        meta, p = ctx.meta, ctx.p
+        inner = INNERS[meta['kind']]
+        g2 = g.contiguous().reshape(B * n, D)
+        want_bias = meta['kind'] == 's3'
+        dy, dpost_w, dpost_b, dsum = K.ln_bwd(g2, y, m2, r2, post_w.detach(), to_bf=True, want_dsum=want_bias)
+        dh, dctx, grads = inner.bwd(ctx.inner_saved, dy, p, meta, need_dbias=False)
+        if want_bias:
+            grads[4] = dsum                      # to_out.bias grad = column sums of d(to_out output)
+        dx, dpre_w, dpre_b, _ = K.ln_bwd(dh, x2, m1, r1, pre_w.detach(), dres=None if ctx.has_resid else g2,
+                                         shift=meta.get('shift'))
+        dcontext = None
+        if ctx.has_ctx:
+            T = meta['xgeom'].T
+            dcontext = dctx.reshape(B, T, D)
+        ctx.inner_saved = None
+        dresid = g if ctx.has_resid else None
+        return (dx.reshape(B, n, D), dresid, dcontext, None, dpre_w, dpre_b, dpost_w, dpost_b, *grads)
+
+
+# =================================================================================================
+# standalone inner module call:  y = inner(x)  (fp32 in / fp32 out), e.g. Sparse3DNA(x) on its own
+# =================================================================================================
+
+class InnerFn(Function):
+    @staticmethod
+    def forward(ctx, x, context, meta, *p):
+        inner = INNERS[meta['kind']]
+        B, n, D = x.shape
+        x2 = x.detach().contiguous().reshape(B * n, D)
+        meta = dict(meta)
+        if meta['kind'] == 'xattn':
+            meta['ctx_bf'] = _ctx_to_bf(context)
+        h = K.empty_bf((B * n, D), x.device)
+        K.cast_pad(x2, h)
+        y, saved = inner.fwd(h, p, meta)
+        ctx.meta, ctx.inner_saved, ctx.p = meta, saved, p
+        ctx.has_ctx = context is not None
+        ctx.shape = (B, n, D)
+        return y.reshape(B, n, y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        B, n, D = ctx.shape
+        meta, p = ctx.meta, ctx.p
+        inner = INNERS[meta['kind']]
+        g2 = g.contiguous().reshape(B * n, -1)
+        dy = K.empty_bf(tuple(g2.shape), g.device)
+        K.cast_pad(g2, dy)
+        dh, dctx, grads = inner.bwd(ctx.inner_saved, dy, p, meta, need_dbias=True, dy_f32=g2)
+        dcontext = dctx.reshape(B, meta['xgeom'].T, D) if ctx.has_ctx else None
+        ctx.inner_saved = None
+        return (dh.reshape(B, n, D), dcontext, None, *grads)
+
+
+# =================================================================================================
+# LayerNorm / StableLayerNorm as standalone nodes (fp32 in -> fp32 out)
+# =================================================================================================
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stable):
+        shp = x.shape
+        x2 = x.detach().contiguous().reshape(-1, shp[-1])
+        zero = torch.zeros_like(x2)
+        if stable:
+            raise RuntimeError('use StableLNLogitsFn / stable_ln_bf')
+        out, m, r = K.ln_fwd(x2, w.detach(), b.detach(), resid=zero)
+        ctx.save_for_backward(x2, m, r, w)
+        ctx.shp = shp
+        return out.reshape(shp)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, m, r, w = ctx.saved_tensors
+        g2 = g.contiguous().reshape(x2.shape)
+        dx, dw, db, _ = K.ln_bwd(g2, x2, m, r, w.detach())
+        return dx.reshape(ctx.shp), dw, db, None
+
+
+class StableLNFn(Function):
+    """StableLayerNorm (np.py:88-95) -> fp32 output (value of the bf16 hi[/lo] pair the logits GEMM consumes is
+    produced separately in LogitsFn; standalone use returns fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        shp = x.shape
+        x2 = x.detach().contiguous().reshape(-1, shp[-1])
+        out, m, r, ia = K.ln_fwd(x2, w.detach(), b.detach(), stable=True)
+        ctx.save_for_backward(x2, m, r, ia, w)
+        ctx.shp = shp
+        y = out.hi.float()
+        if out.lo is not None:
+            y = y + out.lo.float()
+        return y.reshape(shp)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, m, r, ia, w = ctx.saved_tensors
+        g2 = g.contiguous().reshape(x2.shape)
+        dx, dw, db, _ = K.ln_bwd(g2, x2, m, r, w.detach(), inv_amax=ia)
+        return dx.reshape(ctx.shp), dw, db
+
+
+# =================================================================================================
+# final StableLayerNorm + to_logits (+ cross entropy)   np.py:1182, 1958-1963
+# =================================================================================================
+
+class LogitsFn(Function):
+    """x [B, n, D] -> logits [B, n, C] fp32 (StableLayerNorm then Linear without bias)"""
+
+    @staticmethod
+    def forward(ctx, x, nw, nb, wl, cache):
+        B, n, D = x.shape
+        x2 = x.detach().contiguous().reshape(B * n, D)
+        W = cache.get('logits', (wl,), lambda: dict(w=_cast(wl), wT=_cast_t(wl)))
+        hn, m, r, ia = K.ln_fwd(x2, nw.detach(), nb.detach(), stable=True)
+        logits = K.gemm_nt(hn, W['w'])
+        ctx.save_for_backward(x2, m, r, ia, nw, wl)
+        ctx.hn, ctx.W, ctx.shape = hn, W, (B, n, D)
+        return logits.reshape(B, n, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, m, r, ia, nw, wl = ctx.saved_tensors
+        B, n, D = ctx.shape
+        g2 = g.contiguous().reshape(B * n, -1)
+        dl = K.empty_bf(tuple(g2.shape), g.device)
+        K.cast_pad(g2, dl)
+        dhn = K.gemm_nt(dl, ctx.W['wT'])
+        dwl = torch.empty_like(wl)
+        K.gemm_tn(dl, ctx.hn, dwl)
+        dx, dnw, dnb, _ = K.ln_bwd(dhn, x2, m, r, nw.detach(), inv_amax=ia)
+        ctx.hn = None
+        return dx.reshape(B, n, D), dnw, dnb, dwl, None
+
+
+class LogitsLossFn(Function):
+    """x [B, n, D], targets [B, n] -> scalar mean cross-entropy.  dlogits is produced in the forward
+    (bf16 hi[/lo], already divided by the number of targets) so the fp32 logits are read only once."""
+
+    @staticmethod
+    def forward(ctx, x, targets, nw, nb, wl, cache):
+        B, n, D = x.shape
+        x2 = x.detach().contiguous().reshape(B * n, D)
+        W = cache.get('logits', (wl,), lambda: dict(w=_cast(wl), wT=_cast_t(wl)))
+        hn, m, r, ia = K.ln_fwd(x2, nw.detach(), nb.detach(), stable=True)
+        logits = K.gemm_nt(hn, W['w'])
+        t = targets.contiguous().reshape(-1)
+        loss, dl = K.ce_fwd(logits, t, 1.0 / (B * n))
+        ctx.save_for_backward(x2, m, r, ia, nw, wl)
+        ctx.hn, ctx.dl, ctx.W, ctx.shape = hn, dl, W, (B, n, D)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, m, r, ia, nw, wl = ctx.saved_tensors
+        B, n, D = ctx.shape
+        dhn = K.gemm_nt(ctx.dl, ctx.W['wT'])
+        dwl = torch.empty_like(wl)
+        K.gemm_tn(ctx.dl, ctx.hn, dwl)
+        gs = g.detach().reshape(1).float().contiguous()
+        K.scale_by_device_scalar(dhn, gs)
+        K.scale_by_device_scalar(dwl, gs)
+        dx, dnw, dnb, _ = K.ln_bwd(dhn, x2, m, r, nw.detach(), inv_amax=ia)
+        ctx.hn = ctx.dl = None
+        return dx.reshape(B, n, D), None, dnw, dnb, dwl, None
+
+
+# =================================================================================================
+# embedding assemble  (np.py:1940-1944)
+# =================================================================================================
+
+class EmbedAssembleFn(Function):
+    """ids [B, n-1] int64 -> x [B, n, D] fp32 = cat(bos, pos[:n-1] + frac_gradient(emb(ids)))"""
+
+    @staticmethod
+    def forward(ctx, ids, W, ax1, ax2, ax3, bos, video_shape, frac):
+        B, n1 = ids.shape
+        ntok = n1 + 1
+        F, H, Wd = video_shape
+        ids_c = ids.contiguous()
+        x = K.embed_fwd(ids_c, W.detach(), ax1.detach(), ax2.detach(), ax3.detach(), bos.detach(), B, ntok, H, Wd, frac)
+        ctx.save_for_backward(ids_c)
+        ctx.meta = (B, ntok, F, H, Wd, frac, W.shape, ax1.shape, ax2.shape, ax3.shape, bos.shape)
+        return x.reshape(B, ntok, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        B, ntok, F, H, Wd, frac, ws, s1, s2, s3, sb = ctx.meta
+        dev = g.device
+        g2 = g.contiguous().reshape(B * ntok, -1)
+        dW = torch.zeros(ws, dtype=torch.float32, device=dev)
+        d1, d2, d3 = (torch.zeros(s, dtype=torch.float32, device=dev) for s in (s1, s2, s3))
+        db = torch.zeros(sb, dtype=torch.float32, device=dev)
+        K.embed_bwd(ids, g2, dW, d1, d2, d3, db, B, ntok, F, H, Wd, frac)
+        return None, dW, d1, d2, d3, db, None, None

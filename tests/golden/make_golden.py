@@ -52,7 +52,7 @@ def g1_sparse3dna():
              ((3, 4, 4), 3, 2, 23)]
     for ci, (shape, kernel, dil, n) in enumerate(cases):
         torch.manual_seed(0)
-        m = Sparse3DNA(dim=32, video_shape=shape, kernel_size=kernel, dilation=dil, heads=2, dim_head=16, causal=True)
+        m = Sparse3DNA(dim=32, video_shape=shape, kernel_size=kernel, dilation=dil, heads=2, dim_head=32, causal=True)
         N = shape[0] * shape[1] * shape[2]
         n = N if n is None else n
         torch.manual_seed(1)
@@ -67,7 +67,7 @@ def g1_sparse3dna():
 
 def g2_cross_attention():
     torch.manual_seed(0)
-    m = Attention(dim=32, heads=2, dim_head=16)
+    m = Attention(dim=32, heads=2, dim_head=32)
     torch.manual_seed(1)
     x = torch.randn(3, 20, 32, requires_grad=True)
     ctx = torch.randn(3, 7, 32, requires_grad=True)
@@ -118,7 +118,7 @@ def tiny_nuwa(reversible):
     vae = VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32,
                    use_vgg_and_gan=False)
     return NUWA(vae=vae, dim=32, text_num_tokens=50, text_max_seq_len=8, max_video_frames=3, text_enc_depth=2,
-                dec_depth=3, enc_reversible=True, dec_reversible=reversible, dec_heads=2, dec_dim_head=16,
+                dec_depth=3, enc_reversible=True, dec_reversible=reversible, dec_heads=2, dec_dim_head=32,
                 text_enc_heads=2, text_enc_dim_head=16, sparse_3dna_kernel_size=3, sparse_3dna_dilation=(1, 2))
 
 
@@ -165,7 +165,7 @@ def g7_vae():
 
 def g8_decoder_layer():
     torch.manual_seed(0)
-    tr = Transformer(dim=32, depth=3, causal=True, heads=2, dim_head=16, cross_attend=True,
+    tr = Transformer(dim=32, depth=3, causal=True, heads=2, dim_head=32, cross_attend=True,
                      sparse_3dna_attn=True, sparse_3dna_kernel_size=(3, 3, 3), sparse_3dna_video_shape=(3, 4, 4),
                      sparse_3dna_dilations=(1, 2), shift_video_tokens=True)
     torch.manual_seed(1)

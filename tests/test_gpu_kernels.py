@@ -1,0 +1,373 @@
+"""Kernel-level parity on the MI355X: every C-ABI entry point against a plain fp32 restatement
+(torch fp32 for the floating-point kernels, oracle/nuwa_oracle.py for the attention cores) on the
+same seeded inputs.  Tolerances are max-abs error / max-abs reference and are written next to each
+check: operands that are exactly representable in bf16 leave only fp32 accumulation-order noise."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import report, bf_round, to_bf_pair, bf_value  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from nuwa_pytorch_amd import kernels
+    return kernels
+
+
+@pytest.fixture(scope='module')
+def O():
+    from oracle import nuwa_oracle
+    return nuwa_oracle
+
+
+DEV = 'cuda'
+
+
+def shift_ref(x, ntok, fmap):
+    from oracle import nuwa_oracle as Or
+    B = x.shape[0] // ntok
+    return Or.shift_video_tokens(x.reshape(B, ntok, -1).cpu(), fmap).reshape(x.shape)
+
+
+# ---------------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('M,N,K_', [(128, 128, 64), (200, 72, 96), (1, 8, 8), (257, 513, 40), (2560, 1536, 512),
+                                    (96, 8192, 512), (300, 100, 1376)])
+@pytest.mark.parametrize('x3', [False, True])
+def test_gemm_nt(K, M, N, K_, x3):
+    torch.manual_seed(0)
+    a = torch.randn(M, K_) * (1 + torch.arange(K_) % 3)       # asymmetric data: catches transposed fragments
+    b = torch.randn(N, K_) + 0.25
+    if not x3:
+        a, b = bf_round(a), bf_round(b)
+    A, Bm = to_bf_pair(a.to(DEV), x3), to_bf_pair(b.to(DEV), x3)
+    bias = torch.randn(N, device=DEV)
+    ref = a.double() @ b.double().t()
+    tol = 2e-5 if x3 else 2e-6
+    out = K.gemm_nt(A, Bm, bias=bias, alpha=0.5)
+    report(f'gemm_nt_f32[{M},{N},{K_},x3={x3}]', out, (0.5 * ref + bias.cpu().double()).float(), tol)
+    outb = K.gemm_nt(A, Bm, out_bf16=True)
+    report(f'gemm_nt_bf16[{M},{N},{K_},x3={x3}]', outb.hi.float(), ref.float(), 2 ** -8)
+    if x3:
+        report(f'gemm_nt_bf16hilo[{M},{N},{K_}]', bf_value(outb), ref.float(), 3e-5)
+
+
+@pytest.mark.parametrize('B,ntok,fmap,D,N', [(2, 17, 4, 32, 24), (3, 48, 4, 64, 130), (2, 129, 8, 128, 64), (1, 2561, 16, 512, 256)])
+def test_gemm_nt_shift_loader(K, B, ntok, fmap, D, N):
+    torch.manual_seed(1)
+    a = bf_round(torch.randn(B * ntok, D))
+    w = bf_round(torch.randn(N, D))
+    ref = shift_ref(a, ntok, fmap).double() @ w.double().t()
+    out = K.gemm_nt(to_bf_pair(a.to(DEV), False), to_bf_pair(w.to(DEV), False), shift=(ntok, fmap))
+    report(f'gemm_nt_shift[{B},{ntok},{fmap},{D}]', out, ref.float(), 2e-6)
+
+
+@pytest.mark.parametrize('R,N1,N2', [(64, 128, 128), (300, 72, 40), (2560, 1536, 512), (5000, 85, 32), (33, 8, 8), (4096, 1365, 512)])
+@pytest.mark.parametrize('x3', [False, True])
+def test_gemm_tn(K, R, N1, N2, x3):
+    torch.manual_seed(2)
+    ld1, ld2 = (N1 + 7) // 8 * 8, (N2 + 7) // 8 * 8
+    a = torch.randn(R, ld1) * (1 + torch.arange(ld1) % 5)
+    b = torch.randn(R, ld2) - 0.3
+    if not x3:
+        a, b = bf_round(a), bf_round(b)
+    A, Bm = to_bf_pair(a.to(DEV), x3), to_bf_pair(b.to(DEV), x3)
+    from nuwa_pytorch_amd.kernels import BF, view
+    out = torch.full((N1, N2), 7.0, device=DEV)
+    K.gemm_tn(view(A, cols=slice(0, N1)), view(Bm, cols=slice(0, N2)), out, alpha=2.0, beta=0.0, N1=N1, N2=N2)
+    ref = 2.0 * (a[:, :N1].double().t() @ b[:, :N2].double())
+    report(f'gemm_tn[{R},{N1},{N2},x3={x3}]', out, ref.float(), 3e-5 if x3 else 3e-6)
+    out2 = torch.ones((N1, N2), device=DEV)
+    K.gemm_tn(view(A, cols=slice(0, N1)), view(Bm, cols=slice(0, N2)), out2, alpha=1.0, beta=1.0, N1=N1, N2=N2)
+    report(f'gemm_tn_beta[{R},{N1},{N2},x3={x3}]', out2, (ref / 2 + 1).float(), 3e-5 if x3 else 3e-6)
+
+
+@pytest.mark.parametrize('B,ntok,fmap,D,N1', [(2, 17, 4, 32, 24), (2, 129, 8, 128, 200), (1, 2561, 16, 512, 64)])
+def test_gemm_tn_shift_loader(K, B, ntok, fmap, D, N1):
+    torch.manual_seed(3)
+    dy = bf_round(torch.randn(B * ntok, (N1 + 7) // 8 * 8))
+    h = bf_round(torch.randn(B * ntok, D))
+    from nuwa_pytorch_amd.kernels import view
+    out = torch.empty((N1, D), device=DEV)
+    K.gemm_tn(view(to_bf_pair(dy.to(DEV), False), cols=slice(0, N1)), to_bf_pair(h.to(DEV), False), out, shift=(ntok, fmap), N1=N1)
+    ref = dy[:, :N1].double().t() @ shift_ref(h, ntok, fmap).double()
+    report(f'gemm_tn_shift[{B},{ntok},{fmap},{D}]', out, ref.float(), 3e-6)
+
+
+# ---------------------------------------------------------------------------------------------------
+# row kernels
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('R,D', [(7, 32), (130, 512), (64, 1024), (33, 48)])
+def test_layernorm_fwd_bwd(K, R, D):
+    torch.manual_seed(4)
+    x = (torch.randn(R, D) * 2 + 0.5).requires_grad_(True)
+    res = torch.randn(R, D, requires_grad=True)
+    w, b = torch.randn(D, requires_grad=True), torch.randn(D, requires_grad=True)
+    y_ref = F.layer_norm(x, (D,), w, b)
+    g = torch.randn(R, D)
+    (y_ref + res).backward(g)
+    xd, rd, wd, bd = (t.detach().to(DEV) for t in (x, res, w, b))
+    K.set_precision('bf16x3')
+    try:
+        out, m, r, _ = K.ln_fwd(xd, wd, bd)
+        report(f'ln_fwd_pre[{R},{D}]', bf_value(out), y_ref.detach(), 2e-5)
+        yo, m2, r2 = K.ln_fwd(xd, wd, bd, resid=rd)
+        report(f'ln_fwd_post[{R},{D}]', yo, (y_ref + res).detach(), 2e-6)
+        dx, dw, db, ds = K.ln_bwd(g.to(DEV), xd, m2, r2, wd, to_bf=True, want_dsum=True)
+        report(f'ln_bwd_dx_bf[{R},{D}]', bf_value(dx), x.grad, 3e-5)
+        report(f'ln_bwd_dw[{R},{D}]', dw, w.grad, 1e-5)
+        report(f'ln_bwd_db[{R},{D}]', db, b.grad, 1e-5)
+        report(f'ln_bwd_dsum[{R},{D}]', ds, x.grad.sum(0), 1e-4)
+        dres = torch.randn(R, D, device=DEV)
+        dx2, _, _, _ = K.ln_bwd(g.to(DEV), xd, m2, r2, wd, dres=dres)
+        report(f'ln_bwd_dx_acc[{R},{D}]', dx2, x.grad + dres.cpu(), 1e-5)
+    finally:
+        K.set_precision('bf16')
+
+
+def test_layernorm_bwd_inverse_shift(K, O):
+    torch.manual_seed(5)
+    B, ntok, fmap, D = 2, 23, 4, 32
+    x = torch.randn(B, ntok, D, requires_grad=True)
+    w, b = torch.randn(D), torch.randn(D)
+    hs = O.shift_video_tokens(O.layer_norm(x, w, b), fmap)
+    g = torch.randn(B, ntok, D)
+    hs.backward(g)
+    xd = x.detach().reshape(B * ntok, D).to(DEV)
+    _, m, r, _ = K.ln_fwd(xd, w.to(DEV), b.to(DEV))
+    dx, dw, db, _ = K.ln_bwd(g.reshape(B * ntok, D).to(DEV), xd, m, r, w.to(DEV), shift=(ntok, fmap))
+    report('ln_bwd_inverse_shift', dx, x.grad.reshape(B * ntok, D), 1e-5)
+
+
+def test_stable_layernorm(K, O):
+    torch.manual_seed(6)
+    R, D = 50, 64
+    x = torch.randn(R, D, requires_grad=True)
+    w, b = torch.randn(D, requires_grad=True), torch.randn(D, requires_grad=True)
+    y = O.stable_layer_norm(x, w, b)
+    g = torch.randn(R, D)
+    y.backward(g)
+    K.set_precision('bf16x3')
+    try:
+        xd = x.detach().to(DEV)
+        out, m, r, ia = K.ln_fwd(xd, w.detach().to(DEV), b.detach().to(DEV), stable=True)
+        report('stable_ln_fwd', bf_value(out), y.detach(), 2e-5)
+        dx, dw, db, _ = K.ln_bwd(g.to(DEV), xd, m, r, w.detach().to(DEV), inv_amax=ia)
+        report('stable_ln_dx', dx, x.grad, 2e-5)
+        report('stable_ln_dw', dw, w.grad, 1e-5)
+    finally:
+        K.set_precision('bf16')
+
+
+def test_geglu(K):
+    torch.manual_seed(7)
+    R, FP = 37, 96
+    u = bf_round(torch.randn(R, 2 * FP)).requires_grad_(True)
+    a, g_ = u[:, :FP], u[:, FP:]
+    y = a * F.gelu(g_)
+    d = bf_round(torch.randn(R, FP))
+    y.backward(d)
+    ub = to_bf_pair(u.detach().to(DEV), False)
+    K.set_precision('bf16x3')
+    try:
+        from nuwa_pytorch_amd.kernels import BF
+        ub = BF(ub.hi, torch.zeros_like(ub.hi))
+        o = K.geglu_fwd(ub, FP)
+        report('geglu_fwd', bf_value(o), y.detach(), 2e-5)
+        db = to_bf_pair(d.to(DEV), True)
+        du = K.geglu_bwd(ub, db, FP)
+        report('geglu_bwd', bf_value(du), u.grad, 3e-5)
+    finally:
+        K.set_precision('bf16')
+
+
+def test_casts(K):
+    torch.manual_seed(8)
+    w = torch.randn(70, 52, device=DEV)
+    K.set_precision('bf16x3')
+    try:
+        out = K.zeros_bf((80, 64), DEV)
+        K.cast_pad(w, out, row0=5, Cp=64)
+        v = bf_value(out)
+        report('cast_pad', v[5:75, :52], w.cpu(), 2e-5)
+        assert float(v[:5].abs().max()) == 0 and float(v[5:75, 52:].abs().max()) == 0
+        outT = K.zeros_bf((52, 90), DEV)
+        K.transpose_cast(w, outT, col0=10)
+        report('transpose_cast', bf_value(outT)[:, 10:80], w.t().cpu(), 2e-5)
+    finally:
+        K.set_precision('bf16')
+
+
+def test_embed_fwd_bwd(K, O):
+    torch.manual_seed(9)
+    B, Fr, H, W, D, C = 2, 3, 4, 4, 32, 20
+    N = Fr * H * W
+    P = {'image_embedding.embed.weight': torch.randn(C, D, requires_grad=True), 'video_bos': torch.randn(D, requires_grad=True),
+         'video_pos_emb.axial1': torch.randn(Fr, D, requires_grad=True), 'video_pos_emb.axial2': torch.randn(H, D, requires_grad=True),
+         'video_pos_emb.axial3': torch.randn(W, D, requires_grad=True)}
+    for n1 in (N - 1, 21, 1):
+        ids = torch.randint(0, C, (B, n1))
+        for p in P.values():
+            p.grad = None
+        x = O.embed_assemble(ids, P, training=True, frac=0.2)
+        g = torch.randn_like(x)
+        x.backward(g)
+        d = {k: v.detach().to(DEV) for k, v in P.items()}
+        xk = K.embed_fwd(ids.to(DEV), d['image_embedding.embed.weight'], d['video_pos_emb.axial1'], d['video_pos_emb.axial2'],
+                         d['video_pos_emb.axial3'], d['video_bos'], B, n1 + 1, H, W, 0.2)
+        report(f'embed_fwd[n1={n1}]', xk.reshape(B, n1 + 1, D), x.detach(), 1e-6)
+        dW = torch.zeros(C, D, device=DEV)
+        d1, d2, d3, db = (torch.zeros(s, D, device=DEV) for s in (Fr, H, W)) + (torch.zeros(D, device=DEV),)
+        K.embed_bwd(ids.to(DEV), g.reshape(B * (n1 + 1), D).to(DEV), dW, d1, d2, d3, db, B, n1 + 1, Fr, H, W, 0.2)
+        report(f'embed_bwd_dW[n1={n1}]', dW, P['image_embedding.embed.weight'].grad, 1e-5)
+        report(f'embed_bwd_ax1[n1={n1}]', d1, P['video_pos_emb.axial1'].grad, 1e-5)
+        report(f'embed_bwd_ax2[n1={n1}]', d2, P['video_pos_emb.axial2'].grad, 1e-5)
+        report(f'embed_bwd_ax3[n1={n1}]', d3, P['video_pos_emb.axial3'].grad, 1e-5)
+        report(f'embed_bwd_bos[n1={n1}]', db, P['video_bos'].grad, 1e-5)
+
+
+@pytest.mark.parametrize('R,C', [(5, 64), (300, 8192), (17, 1000)])
+def test_cross_entropy(K, R, C):
+    torch.manual_seed(10)
+    logits = (torch.randn(R, C) * 3).requires_grad_(True)
+    t = torch.randint(0, C, (R,))
+    loss = F.cross_entropy(logits, t)
+    loss.backward()
+    K.set_precision('bf16x3')
+    try:
+        lk, dl = K.ce_fwd(logits.detach().to(DEV), t.to(DEV), 1.0 / R)
+        report(f'ce_loss[{R},{C}]', lk.reshape(1), loss.detach().reshape(1), 1e-6)
+        report(f'ce_dlogits[{R},{C}]', bf_value(dl), logits.grad, 3e-5)
+    finally:
+        K.set_precision('bf16')
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention cores vs the oracle
+# ---------------------------------------------------------------------------------------------------
+
+S3_CASES = [((3, 4, 4), (3, 3, 3), (1, 1, 1), 2, 32, None), ((3, 4, 4), (3, 3, 3), (2, 2, 2), 2, 32, None),
+            ((4, 8, 8), (5, 3, 3), (1, 1, 1), 4, 64, None), ((4, 8, 8), (5, 3, 3), (2, 2, 2), 8, 64, None),
+            ((4, 8, 8), (5, 3, 3), (4, 4, 4), 8, 32, None), ((3, 4, 4), (3, 3, 3), (1, 1, 1), 2, 32, 2),
+            ((3, 4, 4), (3, 3, 3), (1, 1, 1), 2, 32, 17), ((3, 4, 4), (3, 3, 3), (1, 2, 1), 3, 64, 23),
+            ((2, 16, 16), (5, 3, 3), (1, 1, 1), 8, 64, None), ((3, 16, 16), (3, 3, 3), (4, 4, 4), 8, 64, 300)]
+
+
+@pytest.mark.parametrize('case', range(len(S3_CASES)))
+@pytest.mark.parametrize('x3', [False, True])
+def test_sparse3dna_core(K, O, case, x3):
+    shape, kern, dil, heads, dh, n = S3_CASES[case]
+    N = shape[0] * shape[1] * shape[2]
+    n = N if n is None else n
+    B = 2
+    inner = heads * dh
+    torch.manual_seed(11 + case)
+    qkv = torch.randn(B, n, 3, heads, dh)
+    if not x3:
+        qkv = bf_round(qkv)
+    qkv.requires_grad_(True)
+    wth = torch.randn(heads, heads) * 0.5 + torch.eye(heads)
+    wth.requires_grad_(True)
+    idx = O.neighbor_table(shape, kern, dil, causal=True)
+    o_ref = O.sparse3dna_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], wth, idx, dh ** -0.5)
+    do = torch.randn_like(o_ref)
+    if not x3:
+        do = bf_round(do)
+    o_ref.backward(do)
+    g = K.s3_geom(B, n, shape, kern, dil, heads, dh)
+    qkvp = to_bf_pair(qkv.detach().reshape(B * n, 3 * inner).to(DEV), x3)
+    o = K.sparse3dna_fwd(g, qkvp, wth.detach().to(DEV))
+    tol_o = 3e-5 if x3 else 2 ** -8
+    tag = f'[{case},x3={x3}]'
+    report('s3_fwd' + tag, (bf_value(o) if x3 else o.hi.float()).reshape(B, n, heads, dh), o_ref.detach(), tol_o)
+    dqkv, dwth = K.sparse3dna_bwd(g, qkvp, wth.detach().to(DEV), to_bf_pair(do.reshape(B * n, inner).to(DEV), x3))
+    gq = qkv.grad.reshape(B * n, 3 * inner)
+    got = bf_value(dqkv) if x3 else dqkv.hi.float()
+    tol_g = 5e-5 if x3 else 2 ** -7
+    for nm, sl in (('dq', slice(0, inner)), ('dk', slice(inner, 2 * inner)), ('dv', slice(2 * inner, 3 * inner))):
+        if n > 1 or nm == 'dv':
+            report(f's3_bwd_{nm}' + tag, got[:, sl], gq[:, sl], tol_g)
+    if n > 1:
+        report('s3_bwd_dwth' + tag, dwth, wth.grad, 1e-4)
+
+
+X_CASES = [(3, 20, 7, 2, 32), (2, 100, 33, 8, 64), (1, 64, 256, 8, 64), (2, 33, 31, 4, 32), (2, 70, 64, 3, 64)]
+
+
+@pytest.mark.parametrize('case', range(len(X_CASES)))
+@pytest.mark.parametrize('x3', [False, True])
+def test_cross_attention_core(K, O, case, x3):
+    B, n, T, heads, dh = X_CASES[case]
+    inner = heads * dh
+    torch.manual_seed(31 + case)
+    rnd = (lambda *s: torch.randn(*s)) if x3 else (lambda *s: bf_round(torch.randn(*s)))
+    q = rnd(B, n, heads, dh).requires_grad_(True)
+    kv = rnd(B, T, 2, heads, dh).requires_grad_(True)
+    nk, nv = rnd(heads, dh).requires_grad_(True), rnd(heads, dh).requires_grad_(True)
+    wth = (torch.randn(heads, heads) * 0.5 + torch.eye(heads)).requires_grad_(True)
+    mask = torch.rand(B, T) > 0.3
+    mask[0] = False                     # a fully masked sample attends only the null key
+    if B > 1:
+        mask[1, T // 2:] = False
+    o_ref = O.attention_core(q, kv[:, :, 0], kv[:, :, 1], nk, nv, wth, mask, dh ** -0.5)
+    do = rnd(B, n, heads, dh)
+    o_ref.backward(do)
+    g = K.x_geom(B, n, T, heads, dh)
+    qp = to_bf_pair(q.detach().reshape(B * n, inner).to(DEV), x3)
+    kvp = to_bf_pair(kv.detach().reshape(B * T, 2 * inner).to(DEV), x3)
+    pk = K.xattn_pack(g, kvp, nk.detach().to(DEV), nv.detach().to(DEV), mask.to(torch.uint8).to(DEV))
+    o, P, Pm = K.xattn_fwd(g, qp, pk, wth.detach().to(DEV))
+    tag = f'[{case},x3={x3}]'
+    val = (lambda p: bf_value(p)) if x3 else (lambda p: p.hi.float())
+    report('xattn_fwd' + tag, val(o).reshape(B, n, heads, dh), o_ref.detach(), 5e-5 if x3 else 2 ** -7)
+    dop = to_bf_pair(do.reshape(B * n, inner).to(DEV), x3)
+    dq, dS, dwth = K.xattn_bwd(g, dop, pk, wth.detach().to(DEV), P)
+    report('xattn_dq' + tag, val(dq).reshape(B, n, heads, dh), q.grad, 1e-4 if x3 else 2 ** -6)
+    report('xattn_dwth' + tag, dwth, wth.grad, 2e-4 if x3 else 2 ** -6)
+    dKp, dVp = K.xattn_kv_grads(g, dS, Pm, qp, dop)
+    dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=x3)
+    report('xattn_dkv' + tag, val(dkv).reshape(B, T, 2, heads, dh), kv.grad, 1e-4 if x3 else 2 ** -6)
+    report('xattn_dnull_k' + tag, dnk, nk.grad, 1e-4 if x3 else 2 ** -6)
+    report('xattn_dnull_v' + tag, dnv, nv.grad, 1e-4 if x3 else 2 ** -6)
+
+
+# ---------------------------------------------------------------------------------------------------
+# full-size (BASELINE cfg 3 geometry) size-independent properties
+# ---------------------------------------------------------------------------------------------------
+
+def test_sparse3dna_fullsize_causality_and_determinism(K):
+    """cfg 3 geometry (10x16x16 tokens, kernel (5,3,3), dilation 2, 8 heads x 64): (i) bit-reproducible
+    fwd/bwd across two runs (no atomics on the path), (ii) causal: changing token p leaves every
+    output row <= p untouched, bit for bit."""
+    shape, kern, dil, heads, dh = (10, 16, 16), (5, 3, 3), (2, 2, 2), 8, 64
+    B, n = 1, 2560
+    inner = heads * dh
+    torch.manual_seed(77)
+    qkv = torch.randn(B * n, 3 * inner, device=DEV)
+    wth = (torch.randn(heads, heads) * 0.3 + torch.eye(heads)).to(DEV)
+    g = K.s3_geom(B, n, shape, kern, dil, heads, dh)
+    p1 = to_bf_pair(qkv, False)
+    o1 = K.sparse3dna_fwd(g, p1, wth).hi.clone()
+    o2 = K.sparse3dna_fwd(g, p1, wth).hi
+    assert torch.equal(o1, o2)
+    do = to_bf_pair(torch.randn(B * n, inner, device=DEV), False)
+    d1, w1 = K.sparse3dna_bwd(g, p1, wth, do)
+    d2, w2 = K.sparse3dna_bwd(g, p1, wth, do)
+    assert torch.equal(d1.hi, d2.hi) and torch.equal(w1, w2)
+    cut = 1500
+    qkv2 = qkv.clone()
+    qkv2[cut:] += 1.0
+    o3 = K.sparse3dna_fwd(g, to_bf_pair(qkv2, False), wth).hi
+    assert torch.equal(o1[:cut], o3[:cut])
+    assert not torch.equal(o1[cut:], o3[cut:])
+    assert bool(torch.isfinite(o1.float()).all()) and bool(torch.isfinite(d1.hi.float()).all())
