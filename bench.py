@@ -86,7 +86,7 @@ def cpu_baseline(c, budget_layers=3):
     geometry; times `budget_layers` decoder layers (one per dilation) + embed/final-norm/logits/CE
     forward+backward and scales the layer time to the full depth."""
     from oracle import nuwa_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))     # beyond ~32 threads the fp32 oracle gets slower, not faster
     cores = torch.get_num_threads()
     D, h, d, T, C = c['dim'], c['heads'], c['dim_head'], c['text_len'], c['codebook']
     N = c['frames'] * c['fmap'] ** 2
@@ -224,7 +224,7 @@ def main():
                                    f'{c["frames"]}x{c["fmap"]}x{c["fmap"]} video tokens, 3DNA kernel {c["kernel"]} dilation {c["dilation"]}, '
                                    f'{c["text_len"]} text tokens, codebook {c["codebook"]}',
                        'per_gpu_batch': b, 'global_batch': b * world, 'tokens_per_sample': N, 'parallelism': f'dp{world}',
-                       'loss': float(loss)},
+                       'loss': float(loss.detach())},
             'per_gpu_value': value / world,
             'step_tflops_per_gpu': step_flops / (dt / args.steps) / 1e12,
             'step_mfma_frac': step_flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,

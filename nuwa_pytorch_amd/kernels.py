@@ -103,7 +103,7 @@ def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None,
     _chk_dev(A.hi, B.hi)
     x3 = A.lo is not None and B.lo is not None
     if out is None:
-        out = empty_bf((M, N), dev) if out_bf16 else torch.empty((M, N), dtype=torch.float32, device=dev)
+        out = empty_bf((M, N), dev, lo=x3 or want_lo()) if out_bf16 else torch.empty((M, N), dtype=torch.float32, device=dev)
     d = GemmDesc()
     d.A, d.Alo, d.lda = _p(A.hi), _p(A.lo) if x3 else None, _ld(A.hi)
     d.B, d.Blo, d.ldb = _p(B.hi), _p(B.lo) if x3 else None, _ld(B.hi)

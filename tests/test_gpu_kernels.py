@@ -227,7 +227,8 @@ def test_embed_fwd_bwd(K, O):
                          d['video_pos_emb.axial3'], d['video_bos'], B, n1 + 1, H, W, 0.2)
         report(f'embed_fwd[n1={n1}]', xk.reshape(B, n1 + 1, D), x.detach(), 1e-6)
         dW = torch.zeros(C, D, device=DEV)
-        d1, d2, d3, db = (torch.zeros(s, D, device=DEV) for s in (Fr, H, W)) + (torch.zeros(D, device=DEV),)
+        d1, d2, d3 = (torch.zeros(s, D, device=DEV) for s in (Fr, H, W))
+        db = torch.zeros(D, device=DEV)
         K.embed_bwd(ids.to(DEV), g.reshape(B * (n1 + 1), D).to(DEV), dW, d1, d2, d3, db, B, n1 + 1, Fr, H, W, 0.2)
         report(f'embed_bwd_dW[n1={n1}]', dW, P['image_embedding.embed.weight'].grad, 1e-5)
         report(f'embed_bwd_ax1[n1={n1}]', d1, P['video_pos_emb.axial1'].grad, 1e-5)
