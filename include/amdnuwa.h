@@ -31,6 +31,10 @@ typedef struct ihipStream_t* amdnuwa_stream;   /* == hipStream_t */
 
 int amdnuwa_abi_version(void);                 /* bumps when any signature below changes */
 const char* amdnuwa_error_string(int code);
+/* runtime tuning knobs (benchmarking): key 0 = NT GEMM variant (0 register-staged, 1 direct-to-LDS BK 64,
+ * 2 direct-to-LDS BK 32), key 1 = TN split-K target workgroup count, key 2 = TN minimum rows per split */
+int amdnuwa_set_tuning(int key, int value);
+int amdnuwa_get_tuning(int key);
 
 /* opt-in HIP-event launch timer: while armed, _begin/_end bracket one launch on `stream` with an
  * event pair; _collect synchronises and returns the summed kernel time and the launch count. */

@@ -49,6 +49,8 @@ GD, SG, XG, XK, CD = (C.POINTER(t) for t in (GemmDesc, S3Geom, XGeom, XKV, ConvD
 SIGNATURES = {
     'amdnuwa_abi_version': (I, []),
     'amdnuwa_error_string': (C.c_char_p, [I]),
+    'amdnuwa_set_tuning': (I, [I, I]),
+    'amdnuwa_get_tuning': (I, [I]),
     'amdnuwa_timer_arm': (None, [I]),
     'amdnuwa_timer_begin': (I, [P]),
     'amdnuwa_timer_end': (I, [P]),

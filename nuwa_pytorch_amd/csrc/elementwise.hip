@@ -203,16 +203,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 }
 
 // out[k][c] (+)= sum over blocks of partial[blk][k][c]  for the selected k rows -> destination pointers
-__global__ void partial_reduce_kernel(const float* __restrict__ partial, int nblk, int nk, int D,
-                                      float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nk * D) return;
-    const int k = idx / D, c = idx % D;
-    float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
-    if (!o) return;
+// 1024 threads = 64 consecutive (k, c) columns x 16 row groups: coalesced 256-byte reads, 16-way
+// row parallelism, fixed combine order (deterministic).  grid = ceil(nk*D / 64).
+__global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __restrict__ partial, int nblk, int nk, int D,
+                                                              float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2, int accumulate) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int bidx = 0; bidx < nblk; ++bidx) s += partial[((size_t)bidx * nk + k) * D + c];
-    o[c] = accumulate ? o[c] + s : s;
+    if (idx < nk * D)
+        for (int bidx = rg; bidx < nblk; bidx += 16) s += partial[(size_t)bidx * nk * D + idx];
+    red[rg][lane] = s;
+    __syncthreads();
+    if (rg == 0 && idx < nk * D) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][lane];
+        const int k = idx / D, c = idx % D;
+        float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
+        if (o) o[c] = accumulate ? o[c] + t : t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -356,17 +366,24 @@ __global__ __launch_bounds__(256) void embed_bwd_possum_kernel(const float* __re
 __global__ __launch_bounds__(256) void embed_bwd_axial_kernel(const float* __restrict__ T, float* __restrict__ d1,
                                                               float* __restrict__ d2, float* __restrict__ d3,
                                                               int ntok, int D, int F, int H, int Wd) {
-    const int k = blockIdx.x;
-    for (int c = threadIdx.x; c < D; c += blockDim.x) {
-        float s = 0.f;
-        for (int p = 0; p < ntok - 1; ++p) {
+    // grid (axis entry k, 64-column chunk); 256 threads = 64 columns x 4 position groups; fixed combine order
+    __shared__ float red[4][64];
+    const int k = blockIdx.x, lane = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    float s = 0.f;
+    if (c < D)
+        for (int p = pg; p < ntok - 1; p += 4) {
             const int w = p % Wd, y = (p / Wd) % H, f = p / (Wd * H);
             const bool hit = k < F ? (f == k) : (k < F + H ? (y == k - F) : (w == k - F - H));
             if (hit) s += T[(size_t)p * D + c];
         }
-        if (k < F) d1[(size_t)k * D + c] += s;
-        else if (k < F + H) d2[(size_t)(k - F) * D + c] += s;
-        else d3[(size_t)(k - F - H) * D + c] += s;
+    red[pg][lane] = s;
+    __syncthreads();
+    if (pg == 0 && c < D) {
+        const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        if (k < F) d1[(size_t)k * D + c] += t;
+        else if (k < F + H) d2[(size_t)(k - F) * D + c] += t;
+        else d3[(size_t)(k - F - H) * D + c] += t;
     }
 }
 
@@ -489,7 +506,7 @@ extern "C" int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean
         else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap);
     }
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((3 * D + 255) / 256), dim3(256), 0, stream, part, nb, 3, D, dw, db, dsum, accumulate);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((3 * D + 63) / 64), dim3(1024), 0, stream, part, nb, 3, D, dw, db, dsum, accumulate);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
@@ -504,7 +521,7 @@ extern "C" int amdnuwa_colsum(const float* x, float* out, long long R, int D, in
     const int nb = (int)(R < 256 ? R : 256);
     hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, stream, x, (float*)workspace, R, D);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nb, 1, D, out, (float*)nullptr, (float*)nullptr, accumulate);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, nb, 1, D, out, (float*)nullptr, (float*)nullptr, accumulate);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
@@ -567,7 +584,7 @@ extern "C" int amdnuwa_embed_bwd(const long long* ids, const float* dx, float* d
     float* T = (float*)workspace;
     hipLaunchKernelGGL(embed_bwd_possum_kernel, dim3(ntok), dim3(256), 0, stream, dx, T, dbos, B, ntok, D);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(embed_bwd_axial_kernel, dim3(F + H + Wd), dim3(256), 0, stream, T, dax1, dax2, dax3, ntok, D, F, H, Wd);
+    hipLaunchKernelGGL(embed_bwd_axial_kernel, dim3(F + H + Wd, (D + 63) / 64), dim3(256), 0, stream, T, dax1, dax2, dax3, ntok, D, F, H, Wd);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

@@ -216,6 +216,154 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// NT, direct-to-LDS variant: operand tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (16 B per
+// lane, no VGPR staging, no ds_write pass).  The DMA writes LDS lane-linearly (wave-uniform base +
+// lane*16), so the bank-conflict swizzle is applied on the per-lane SOURCE address and again on the
+// fragment read (same involution).  Zero fill (rows past M/N, shifted rows at y==0 / w==0) comes from
+// a 16-byte zero page in global memory.  Smaller LDS footprint (BK=32: 32 KiB) -> 4-5 resident
+// workgroups per CU to hide the LDS->MFMA latency.  Requires K % BK == 0; bf16 operands only.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) const uint4 g_zero_page[4] = {};
+
+template <int BK_>
+__device__ __forceinline__ int glds_swz(int row) {
+    if (BK_ == 64) return (row >> 1) & 7;
+    // BK 32: 64-byte rows, 4 chunks; row groups of 4 share a bank phase -> permute per group
+    const int gsel = (row >> 2) & 3;
+    return (0x1320 >> (gsel * 4)) & 3;                     // {0, 2, 3, 1}
+}
+template <int BK_>
+__device__ __forceinline__ int glds_off(int row, int cc) { return row * (BK_ * 2) + ((cc ^ glds_swz<BK_>(row)) << 4); }
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef __attribute__((address_space(1))) const void* glb_cvptr;
+
+template <int BK_, bool SHIFT, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 128 * BK_ * 2;            // bytes per operand tile
+    constexpr int NJ = TB / 4096;                // wave-instructions per operand tile per wave (4 waves x 1 KiB)
+    constexpr int RPK = 1024 / (BK_ * 2);        // tile rows per KiB
+    constexpr int CPR = BK_ / 8;                 // 16-byte chunks per row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int lid = xcd_remap(blockIdx.x, nwg);
+    const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const long long bz = blockIdx.y;
+    const long long oA = boff(p, bz, p.sA, p.sA_in), oB = boff(p, bz, p.sB, p.sB_in), oC = boff(p, bz, p.sC, p.sC_in);
+    const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+    // per-lane source pointers (k = 0) for each of this wave's NJ DMA pieces of A and B
+    const bf16_t* pa[NJ]; const bf16_t* pah[NJ]; const bf16_t* paw[NJ]; const bf16_t* pb[NJ];
+    int cca[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int row = (j * 4 + wave) * RPK + lane / CPR;
+        const int cc = (lane % CPR) ^ glds_swz<BK_>(row);
+        cca[j] = cc;
+        const long long ga = (long long)m0 + row, gb = (long long)n0 + row;
+        pa[j] = ga < p.M ? p.A + oA + ga * p.lda + cc * 8 : nullptr;
+        pb[j] = gb < p.N ? p.B + oB + gb * p.ldb + cc * 8 : nullptr;
+        pah[j] = paw[j] = pa[j];
+        if (SHIFT && pa[j]) {
+            const ShiftRow s = shift_row(ga, p.shift_ntok, p.shift_fmap);
+            pah[j] = s.off_h == INT_MIN ? nullptr : pa[j] + (long long)s.off_h * p.lda;
+            paw[j] = s.off_w == INT_MIN ? nullptr : pa[j] + (long long)s.off_w * p.lda;
+        }
+    }
+    const int quarter = SHIFT ? (p.shift_dim >> 2) : 1;
+
+    auto issue = [&](int buf, int k0) {
+        char* base = smem + buf * 2 * TB;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bf16_t* sa = pa[j];
+            if (SHIFT) {
+                const int q = (k0 + cca[j] * 8) / quarter;
+                sa = q == 0 ? pah[j] : (q == 1 ? paw[j] : pa[j]);
+            }
+            const bf16_t* srca = sa ? sa + k0 : zp;
+            const bf16_t* srcb = pb[j] ? pb[j] + k0 : zp;
+            const int off = (j * 4 + wave) * 1024;
+            __builtin_amdgcn_global_load_lds((glb_cvptr)srca, (lds_vptr)(base + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_cvptr)srcb, (lds_vptr)(base + TB + off), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK_;
+    issue(0, 0);
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(cur ^ 1, (kt + 1) * BK_);
+        const char* base = smem + cur * 2 * TB;
+#pragma unroll
+        for (int ks = 0; ks < BK_ / 32; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(base + glds_off<BK_>(wm * 64 + i * 16 + fr, ks * 4 + fg));
+                bfr[i] = *reinterpret_cast<const bf16x8*>(base + TB + glds_off<BK_>(wn * 64 + i * 16 + fr, ks * 4 + fg));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long m = (long long)m0 + wm * 64 + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fg * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r] * p.alpha;
+                if (EPI == 0 && p.bias && n + r < p.N) v[r] += p.bias[n + r];
+            }
+            if (EPI == 0) {
+                float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
+                if (vec_ok) *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
+            } else {
+                bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + n;
+                bf16_t h[4], l[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f2bf_hilo(v[r], h[r], l[r]);
+                if (vec_ok) {
+                    *reinterpret_cast<uint2*>(C) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+                    if (p.Clo) *reinterpret_cast<uint2*>(p.Clo + oC + m * p.ldc + n) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                        C[r] = h[r];
+                        if (p.Clo) p.Clo[oC + m * p.ldc + n + r] = l[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // TN :  P[z][n1][n2] = sum over token rows m of split z of A[m][n1] * B[m][n2]   (fp32 partials)
 // ---------------------------------------------------------------------------------------------
 constexpr int TK = 32;                       // token rows per step
@@ -389,8 +537,20 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     p.batch_inner = d->batch_inner; p.sA_in = d->strideA_inner; p.sB_in = d->strideB_inner; p.sC_in = d->strideC_inner;
     const bool x3 = d->Alo != nullptr, sh = d->shift_ntok > 0, ob = d->c_is_bf16 != 0;
     dim3 grid(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), block(256);
+    // direct-to-LDS variants (tuning key 0: 0 = register-staged, 1 = glds BK 64, 2 = glds BK 32)
+    const int variant = g_amdnuwa_tuning[0];
+    const int gbk = variant == 1 ? 64 : (variant == 2 ? 32 : 0);
+    if (!x3 && gbk && d->K % gbk == 0) {
+        const size_t gl = (size_t)2 * 2 * 128 * gbk * 2;
+#define GL_LAUNCH(BK__, SH, EP) hipLaunchKernelGGL((gemm_nt_glds_kernel<BK__, SH, EP>), grid, block, gl, stream, p)
+        if (gbk == 64) { if (sh) { if (ob) GL_LAUNCH(64, true, 1); else GL_LAUNCH(64, true, 0); } else { if (ob) GL_LAUNCH(64, false, 1); else GL_LAUNCH(64, false, 0); } }
+        else           { if (sh) { if (ob) GL_LAUNCH(32, true, 1); else GL_LAUNCH(32, true, 0); } else { if (ob) GL_LAUNCH(32, false, 1); else GL_LAUNCH(32, false, 0); } }
+#undef GL_LAUNCH
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
+    }
     const size_t lds = (size_t)2 * (x3 ? 4 : 2) * TILE_BYTES;
-#define NT_LAUNCH(X3, SH, EP)                                                                                        \
+#define NT_LAUNCH(X3, SH, EP)                                                                                      \
     do {                                                                                                             \
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<X3, SH, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((gemm_nt_kernel<X3, SH, EP>), grid, block, lds, stream, p);                               \
@@ -404,8 +564,10 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
 
 static int tn_splits(const amdnuwa_gemm_desc* d) {
     const int tiles = ((d->M + 127) / 128) * ((d->N + 127) / 128) * (d->batch > 0 ? d->batch : 1);
-    int splits = (1024 + tiles - 1) / tiles;             // aim for >= ~4 workgroups per CU
-    const int maxs = (d->K + 255) / 256;                 // at least 256 token rows per split
+    const int target = g_amdnuwa_tuning[1] > 0 ? g_amdnuwa_tuning[1] : 1024;   // aim for ~4 workgroups per CU
+    const int minrows = g_amdnuwa_tuning[2] > 0 ? g_amdnuwa_tuning[2] : 256;   // token rows per split, at least
+    int splits = (target + tiles - 1) / tiles;
+    const int maxs = (d->K + minrows - 1) / minrows;
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
     return splits;

@@ -537,28 +537,47 @@ __global__ __launch_bounds__(512) void s3_bwd_kv_kernel(S3Args a) {
 }
 
 // fixed-order reductions: dW_th (+= over all workgroups); per sample dk[bos], dv[bos] (+ dO[bos])
-__global__ __launch_bounds__(256) void s3_bwd_fin_kernel(S3Args a, int DH) {
+// 1024 threads = 64 columns x 16 row groups (coalesced reads, fixed combine order).
+// grid = B * ceil(inner/64) blocks for the <bos> k/v rows + 1 block for dW_th.
+__global__ __launch_bounds__(1024) void s3_bwd_fin_kernel(S3Args a, int DH) {
+    __shared__ float red[2][16][64];
     const int rows = a.F * a.H, inner = a.NH * DH;
-    if ((int)blockIdx.x == a.B) {
-        for (int e = threadIdx.x; e < a.NH * a.NH; e += blockDim.x) {
-            float s = 0.f;
-            for (int k = 0; k < a.B * rows; ++k) s += a.part_th[(size_t)k * a.NH * a.NH + e];
-            a.dwth[e] = a.accumulate ? a.dwth[e] + s : s;
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int nchunk = (inner + 63) / 64;
+    if ((int)blockIdx.x == a.B * nchunk) {
+        const int nn = a.NH * a.NH;
+        float s = 0.f;
+        if (lane < nn)
+            for (int k = rg; k < a.B * rows; k += 16) s += a.part_th[(size_t)k * nn + lane];
+        red[0][rg][lane] = s;
+        __syncthreads();
+        if (rg == 0 && lane < nn) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[0][r][lane];
+            a.dwth[lane] = a.accumulate ? a.dwth[lane] + t : t;
         }
         return;
     }
-    const int b = blockIdx.x;
-    for (int e = threadIdx.x; e < inner; e += blockDim.x) {
-        float sk = 0.f, sv = 0.f;
-        for (int r = 0; r < rows; ++r) {
+    const int b = blockIdx.x / nchunk, e = (blockIdx.x % nchunk) * 64 + lane;
+    float sk = 0.f, sv = 0.f;
+    if (e < inner)
+        for (int r = rg; r < rows; r += 16) {
             sk += a.part_k0[((size_t)b * rows + r) * inner + e];
             sv += a.part_v0[((size_t)b * rows + r) * inner + e];
         }
+    red[0][rg][lane] = sk;
+    red[1][rg][lane] = sv;
+    __syncthreads();
+    if (rg == 0 && e < inner) {
+        float tk = 0.f, tv = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { tk += red[0][r][lane]; tv += red[1][r][lane]; }
         const size_t gi = ((size_t)b * a.ntok) * a.lddo + e, go = ((size_t)b * a.ntok) * a.ldd + e;
-        sv += bf2f(a.dO[gi]) + (a.dOl ? bf2f(a.dOl[gi]) : 0.f);
+        tv += bf2f(a.dO[gi]) + (a.dOl ? bf2f(a.dOl[gi]) : 0.f);
         bf16_t hh, ll;
-        f2bf_hilo(sk, hh, ll); a.dk[go] = hh; if (a.dkl) a.dkl[go] = ll;
-        f2bf_hilo(sv, hh, ll); a.dv[go] = hh; if (a.dvl) a.dvl[go] = ll;
+        f2bf_hilo(tk, hh, ll); a.dk[go] = hh; if (a.dkl) a.dkl[go] = ll;
+        f2bf_hilo(tv, hh, ll); a.dv[go] = hh; if (a.dvl) a.dvl[go] = ll;
     }
 }
 
@@ -659,7 +678,7 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
         hipLaunchKernelGGL(s3_bwd_kv_kernel<32>, grid, block, lds_kv, stream, a);
     }
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(s3_bwd_fin_kernel, dim3(g->B + 1), dim3(256), 0, stream, a, g->dim_head);
+    hipLaunchKernelGGL(s3_bwd_fin_kernel, dim3(g->B * (((int)inner + 63) / 64) + 1), dim3(1024), 0, stream, a, g->dim_head);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

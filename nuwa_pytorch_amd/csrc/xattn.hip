@@ -480,12 +480,20 @@ __global__ __launch_bounds__(256) void xattn_unpack_kernel(const float* __restri
 }
 
 // dW_th (+)= sum over workgroups of the partials (fixed order)
-__global__ void xattn_wth_reduce_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ out, int accumulate) {
-    const int e = threadIdx.x;
-    if (e >= n) return;
+__global__ __launch_bounds__(1024) void xattn_wth_reduce_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ out, int accumulate) {
+    __shared__ float red[16][64];     // 64 entries (n <= 64) x 16 row groups, fixed combine order
+    const int e = threadIdx.x & 63, rg = threadIdx.x >> 6;
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * n + e];
-    out[e] = accumulate ? out[e] + s : s;
+    if (e < n)
+        for (int k = rg; k < nblk; k += 16) s += part[(size_t)k * n + e];
+    red[rg][e] = s;
+    __syncthreads();
+    if (rg == 0 && e < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][e];
+        out[e] = accumulate ? out[e] + t : t;
+    }
 }
 
 int check(const amdnuwa_xattn_geom* g) {
@@ -584,7 +592,7 @@ extern "C" int amdnuwa_xattn_bwd(const amdnuwa_xattn_geom* g, const uint16_t* dO
     else { if (x3) XB(32, true); else XB(32, false); }
 #undef XB
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(xattn_wth_reduce_kernel, dim3(1), dim3(64), 0, stream, a.part_th, g->B * tiles, g->heads * g->heads, dw_th, accumulate);
+    hipLaunchKernelGGL(xattn_wth_reduce_kernel, dim3(1), dim3(1024), 0, stream, a.part_th, g->B * tiles, g->heads * g->heads, dw_th, accumulate);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
