@@ -109,6 +109,10 @@ def lib():
     v = l.amdnuwa_abi_version()
     if v != ABI_VERSION:
         raise RuntimeError(f'libamdnuwa ABI version {v} != expected {ABI_VERSION}: rebuild the library')
+    # optional runtime tuning overrides, e.g. AMDNUWA_TUNING="0=2,6=1" (see amdnuwa_set_tuning in the header)
+    for kv in filter(None, os.environ.get('AMDNUWA_TUNING', '').split(',')):
+        k, v = kv.split('=')
+        l.amdnuwa_set_tuning(int(k), int(v))
     _lib = l
     return l
 

@@ -501,6 +501,113 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, float* __restr
     }
 }
 
+// TN, direct-to-LDS variant (bf16 operands only): same [32 token rows][128 columns] tiles and the same
+// 32-byte XOR swizzle as gemm_tn_kernel, but filled by global_load_lds_dwordx4 with the swizzle applied to
+// the per-lane source column.  One 1-KiB DMA piece = 4 token rows of a tile.
+template <bool SHIFT>
+__global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmArgs p, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int N1 = p.M, N2 = p.N;
+    const int tmi = blockIdx.x / p.tiles_n, tni = blockIdx.x % p.tiles_n;
+    const int a0 = tmi * 128, b0 = tni * 128;
+    const long long bz = blockIdx.y;
+    const int z = blockIdx.z;
+    const bf16_t* A = p.A + boff(p, bz, p.sA, p.sA_in);
+    const bf16_t* B = p.B + boff(p, bz, p.sB, p.sB_in);
+    const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
+    const long long mbeg = (long long)z * p.ksplit_len;
+    const long long mend = min((long long)p.K, mbeg + p.ksplit_len);
+    const int quarter = SHIFT ? (p.shift_dim >> 2) : 1;
+    const bool pow2 = SHIFT && (p.shift_fmap & (p.shift_fmap - 1)) == 0;
+    const int fsh = pow2 ? __ffs(p.shift_fmap) - 1 : 0;
+
+    // this lane's (row-in-tile, source column) for its two DMA pieces per operand
+    int prow[2], cola[2], colb[2];
+    bool oka[2], okb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (j * 4 + wave) * 4 + (lane >> 4);
+        const int ps = lane & 15;
+        const int cc16 = ((((ps >> 1) ^ tn_f(row)) << 1) | (ps & 1));
+        prow[j] = row;
+        cola[j] = a0 + cc16 * 8; colb[j] = b0 + cc16 * 8;
+        oka[j] = cola[j] < N1; okb[j] = colb[j] < N2;
+    }
+    auto issue = [&](int buf, long long mk0) {
+        char* base = smem + buf * 2 * TN_TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long g = mk0 + prow[j];
+            const bool rin = g < mend;
+            const bf16_t* sa = (rin && oka[j]) ? A + g * p.lda + cola[j] : zp;
+            const bf16_t* sb = zp;
+            if (rin && okb[j]) {
+                long long gb = g;
+                bool zero = false;
+                if (SHIFT) {
+                    const int i = (int)((unsigned)g % (unsigned)p.shift_ntok);
+                    if (i > 0) {
+                        const int pp = i - 1;
+                        const int w = pow2 ? (pp & (p.shift_fmap - 1)) : pp % p.shift_fmap;
+                        const int y = pow2 ? ((pp >> fsh) & (p.shift_fmap - 1)) : (pp / p.shift_fmap) % p.shift_fmap;
+                        const int q = colb[j] / quarter;
+                        if (q == 0) { if (y > 0) gb -= p.shift_fmap; else zero = true; }
+                        else if (q == 1) { if (w > 0) gb -= 1; else zero = true; }
+                    }
+                }
+                if (!zero) sb = B + gb * p.ldb + colb[j];
+            }
+            const int off = (j * 4 + wave) * 1024;
+            __builtin_amdgcn_global_load_lds((glb_cvptr)sa, (lds_vptr)(base + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_cvptr)sb, (lds_vptr)(base + TN_TILE_BYTES + off), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)((mend - mbeg + TK - 1) / TK);
+    if (nk > 0) issue(0, mbeg);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(cur ^ 1, mbeg + (long long)(kt + 1) * TK);
+        const char* base = smem + cur * 2 * TN_TILE_BYTES;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = tn_frag(base, wm * 64 + i * 16, lane);
+            bfr[i] = tn_frag(base + TN_TILE_BYTES, wn * 64 + i * 16, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+    float* P = partial + ((size_t)bz * gridDim.z + z) * (size_t)N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n1 = a0 + wm * 64 + i * 16 + fr;
+        if (n1 >= N1) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n2 = b0 + wn * 64 + j * 16 + fg * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n2 + r < N2) P[(size_t)n1 * N2 + n2 + r] = acc[i][j][r];
+        }
+    }
+}
+
 // C[bz][n1][n2] = beta*C + alpha * sum_z partial[bz][z][n1][n2]   (fixed order -> deterministic)
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, long long sC, long long sC_in,
                                      int batch_inner, int ldc, int N1, int N2, int splits, float alpha, float beta) {
@@ -604,6 +711,11 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
     dim3 grid(p.tiles_m * p.tiles_n, batch, splits), block(256);
     const size_t lds = (size_t)2 * (x3 ? 4 : 2) * TN_TILE_BYTES;
     float* part = (float*)workspace;
+    if (!x3 && g_amdnuwa_tuning[6] == 1 && (long long)d->K < (1LL << 31)) {     // tuning key 6: direct-to-LDS TN
+        const size_t gl = (size_t)2 * 2 * TN_TILE_BYTES;
+        if (sh) hipLaunchKernelGGL((gemm_tn_glds_kernel<true>), grid, block, gl, stream, p, part);
+        else    hipLaunchKernelGGL((gemm_tn_glds_kernel<false>), grid, block, gl, stream, p, part);
+    } else
     if (x3) { if (sh) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, block, lds, stream, p, part);
               else    hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, block, lds, stream, p, part); }
     else    { if (sh) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, block, lds, stream, p, part);

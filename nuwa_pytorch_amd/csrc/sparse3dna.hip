@@ -76,27 +76,95 @@ __device__ __forceinline__ float quad_max(float v) {
     return v;
 }
 
-// stage one grid row (fr, yr, 0..W-1) of `src` (all heads) into LDS as fp32-ready bf16 hi[/lo] chunks.
-// each active thread moves the chunk of its own (w, h, c); rows beyond the sequence are zero.
-template <int CH>
-__device__ __forceinline__ void stage_row(const S3Args& a, const bf16_t* src, const bf16_t* srcl, int coloff, int b, int fr,
-                                          int yr, int w, int h, int c, bool act, bf16_t* lds_hi, bf16_t* lds_lo) {
-    if (!act) return;
-    const int p = (fr * a.H + yr) * a.W + w;
-    const bool ok = (1 + p) < a.ntok;
-    const size_t g = ((size_t)b * a.ntok + 1 + p) * a.ld + coloff + h * (CH * 4) + c * CH;
-    const int slot = ((w * a.NH + h) * 4 + c) * CH;
+// Sweep over all causal taps of one query row.  Key/value rows are staged in LDS `GMAX` tap planes at a
+// time (GMAX == KHMAX: the kh rows of one tap FRAME = a "slab"; GMAX == 1: one row), and the NEXT group is
+// fetched into registers while the current one is consumed, so the global-load latency overlaps the FMAs.
+// fn(j, chunk) is called for every valid tap slot j >= 1 of this thread's (query, head) with the staged
+// fp32 chunk of that tap's key/value.  Each active thread moves the chunk of its own (w, h, c).
+constexpr int KHMAX = 3;
+
+template <int CH, int GMAX, typename Fn>
+__device__ __forceinline__ void sweep_taps(const S3Args& a, const bf16_t* src, const bf16_t* srcl, int b, int f, int y, int w,
+                                           int h, int c, bool act, bool qvalid, bf16_t* st_hi, Fn&& fn) {
+    const int G = GMAX == 1 ? 1 : a.kh;                  // planes staged per round
+    const int ngroups = (a.kf * a.kh) / G;
+    const int slab = a.W * a.NH * CH * 4;                // elements per staged row
+    bf16_t* st_lo = st_hi + G * slab;
+    const int myslot = ((w * a.NH + h) * 4 + c) * CH;
+    uint4 rh[GMAX][CH / 8], rl[GMAX][CH / 8];
+    auto plane = [&](int t, int& fr, int& yr) {
+        const int ta = t / a.kh, tb = t - ta * a.kh;
+        fr = f - (a.kf - 1 - ta) * a.df;
+        yr = y - (a.kh - 1 - tb) * a.dh;
+        return fr >= 0 && yr >= 0;
+    };
+    auto next_group = [&](int g) {
+        for (; g < ngroups; ++g) {
+            bool ok = false;
+            for (int k = 0; k < G; ++k) { int fr, yr; ok |= plane(g * G + k, fr, yr); }
+            if (ok) break;
+        }
+        return g;
+    };
+    auto fetch = [&](int g) {
 #pragma unroll
-    for (int v8 = 0; v8 < CH / 8; ++v8) {
-        *reinterpret_cast<uint4*>(lds_hi + slot + v8 * 8) = ok ? *reinterpret_cast<const uint4*>(src + g + v8 * 8) : make_uint4(0, 0, 0, 0);
-        if (srcl) *reinterpret_cast<uint4*>(lds_lo + slot + v8 * 8) = ok ? *reinterpret_cast<const uint4*>(srcl + g + v8 * 8) : make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < GMAX; ++k) {
+            int fr = 0, yr = 0;
+            bool ok = act && k < G && plane(g * G + k, fr, yr);
+            size_t gi = 0;
+            if (ok) {
+                const int p = (fr * a.H + yr) * a.W + w;
+                ok = (1 + p) < a.ntok;
+                gi = ((size_t)b * a.ntok + 1 + p) * a.ld + h * (CH * 4) + c * CH;
+            }
+#pragma unroll
+            for (int v8 = 0; v8 < CH / 8; ++v8) {
+                rh[k][v8] = ok ? *reinterpret_cast<const uint4*>(src + gi + v8 * 8) : make_uint4(0, 0, 0, 0);
+                if (srcl) rl[k][v8] = ok ? *reinterpret_cast<const uint4*>(srcl + gi + v8 * 8) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    int g = next_group(0);
+    if (g < ngroups) fetch(g);
+    while (g < ngroups) {
+        __syncthreads();                                 // previous group fully consumed
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < GMAX; ++k)
+                if (k < G) {
+#pragma unroll
+                    for (int v8 = 0; v8 < CH / 8; ++v8) {
+                        *reinterpret_cast<uint4*>(st_hi + k * slab + myslot + v8 * 8) = rh[k][v8];
+                        if (srcl) *reinterpret_cast<uint4*>(st_lo + k * slab + myslot + v8 * 8) = rl[k][v8];
+                    }
+                }
+        }
+        __syncthreads();
+        const int gn = next_group(g + 1);
+        if (gn < ngroups) fetch(gn);                     // in flight during the compute below
+        if (qvalid) {
+            for (int k = 0; k < G; ++k) {
+                int fr, yr;
+                const int t = g * G + k;
+                if (!plane(t, fr, yr)) continue;
+                for (int tc = 0; tc < a.kw; ++tc) {
+                    const int wr = w - (a.kw - 1 - tc) * a.dw;
+                    if (wr < 0) continue;
+                    float ch[CH];
+                    const int slot = k * slab + ((wr * a.NH + h) * 4 + c) * CH;
+                    load_chunk<CH>(st_hi + slot, srcl ? st_lo + slot : nullptr, ch);
+                    fn(1 + t * a.kw + tc, ch);
+                }
+            }
+        }
+        g = gn;
     }
 }
 
 // scores + softmax for one query row: fills SP[(w*J + j)*NH + h] with P (fp32).  Shared by fwd and bwd_q.
-template <int DH>
+template <int DH, int GMAX>
 __device__ __forceinline__ void scores_softmax(const S3Args& a, int b, int f, int y, int w, int h, int c, bool act, bool qvalid,
-                                               const float* qf, float* SP, bf16_t* st_hi, bf16_t* st_lo, int J) {
+                                               const float* qf, float* SP, bf16_t* st_hi, int J) {
     constexpr int CH = DH / 4;
     const int t = threadIdx.x, nt = blockDim.x;
     for (int e = t; e < a.W * J * a.NH; e += nt) SP[e] = NEG_MAX;
@@ -112,32 +180,13 @@ __device__ __forceinline__ void scores_softmax(const S3Args& a, int b, int f, in
         s = quad_sum(s);
         if (c == 0) SP[(w * J + 0) * a.NH + h] = s * a.scale;
     }
-    for (int ta = 0; ta < a.kf; ++ta) {
-        const int fr = f - (a.kf - 1 - ta) * a.df;
-        if (fr < 0) continue;
-        for (int tb = 0; tb < a.kh; ++tb) {
-            const int yr = y - (a.kh - 1 - tb) * a.dh;
-            if (yr < 0) continue;
-            __syncthreads();
-            stage_row<CH>(a, a.k, a.kl, 0, b, fr, yr, w, h, c, act, st_hi, st_lo);
-            __syncthreads();
-            if (qvalid) {
-                for (int tc = 0; tc < a.kw; ++tc) {
-                    const int wr = w - (a.kw - 1 - tc) * a.dw;
-                    if (wr < 0) continue;
-                    float kf_[CH];
-                    const int slot = ((wr * a.NH + h) * 4 + c) * CH;
-                    load_chunk<CH>(st_hi + slot, a.kl ? st_lo + slot : nullptr, kf_);
-                    float s = 0.f;
+    sweep_taps<CH, GMAX>(a, a.k, a.kl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const float* kf_) {
+        float s = 0.f;
 #pragma unroll
-                    for (int e = 0; e < CH; ++e) s += qf[e] * kf_[e];
-                    s = quad_sum(s);
-                    const int j = 1 + (ta * a.kh + tb) * a.kw + tc;
-                    if (c == 0) SP[(w * J + j) * a.NH + h] = s * a.scale;
-                }
-            }
-        }
-    }
+        for (int e = 0; e < CH; ++e) s += qf[e] * kf_[e];
+        s = quad_sum(s);
+        if (c == 0) SP[(w * J + j) * a.NH + h] = s * a.scale;
+    });
     __syncthreads();
     // fp32 softmax over the J slots of each (w, h): the 4 lanes of the group split j
     if (act) {
@@ -156,14 +205,13 @@ __device__ __forceinline__ void scores_softmax(const S3Args& a, int b, int f, in
     __syncthreads();
 }
 
-template <int DH>
+template <int DH, int GMAX>
 __global__ __launch_bounds__(512) void s3_fwd_kernel(S3Args a) {
     constexpr int CH = DH / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int J = a.kf * a.kh * a.kw + 1;
-    const int stage_elems = a.W * a.NH * DH;
+    const int stage_elems = a.W * a.NH * DH * (GMAX == 1 ? 1 : a.kh);
     bf16_t* st_hi = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* st_lo = st_hi + stage_elems;
     float* SP = reinterpret_cast<float*>(smem + (size_t)stage_elems * (a.kl ? 4 : 2));
     __shared__ float wsh[64];
     const int t = threadIdx.x, c = t & 3, wh = t >> 2, h = wh % a.NH, w = wh / a.NH;
@@ -188,7 +236,7 @@ __global__ __launch_bounds__(512) void s3_fwd_kernel(S3Args a) {
         const size_t g = ((size_t)b * a.ntok + i) * a.ld + h * DH + c * CH;
         load_chunk<CH>(a.q + g, a.ql ? a.ql + g : nullptr, qf);
     }
-    scores_softmax<DH>(a, b, f, y, w, h, c, act, qvalid, qf, SP, st_hi, st_lo, J);
+    scores_softmax<DH, GMAX>(a, b, f, y, w, h, c, act, qvalid, qf, SP, st_hi, J);
     // talking heads: P'[g] = sum_h Wth[g][h] P[h] per (w, j), in place
     for (int item = t; item < a.W * J; item += blockDim.x) {
         float pv[8], out[8];
@@ -217,44 +265,25 @@ __global__ __launch_bounds__(512) void s3_fwd_kernel(S3Args a) {
 #pragma unroll
         for (int e = 0; e < CH; ++e) of[e] += pj * vf[e];
     }
-    for (int ta = 0; ta < a.kf; ++ta) {
-        const int fr = f - (a.kf - 1 - ta) * a.df;
-        if (fr < 0) continue;
-        for (int tb = 0; tb < a.kh; ++tb) {
-            const int yr = y - (a.kh - 1 - tb) * a.dh;
-            if (yr < 0) continue;
-            __syncthreads();
-            stage_row<CH>(a, a.v, a.vl, 0, b, fr, yr, w, h, c, act, st_hi, st_lo);
-            __syncthreads();
-            if (qvalid) {
-                for (int tc = 0; tc < a.kw; ++tc) {
-                    const int wr = w - (a.kw - 1 - tc) * a.dw;
-                    if (wr < 0) continue;
-                    float vf[CH];
-                    const int slot = ((wr * a.NH + h) * 4 + c) * CH;
-                    load_chunk<CH>(st_hi + slot, a.vl ? st_lo + slot : nullptr, vf);
-                    const float pj = SP[(w * J + 1 + (ta * a.kh + tb) * a.kw + tc) * a.NH + h];
+    sweep_taps<CH, GMAX>(a, a.v, a.vl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const float* vf) {
+        const float pj = SP[(w * J + j) * a.NH + h];
 #pragma unroll
-                    for (int e = 0; e < CH; ++e) of[e] += pj * vf[e];
-                }
-            }
-        }
-    }
+        for (int e = 0; e < CH; ++e) of[e] += pj * vf[e];
+    });
     if (qvalid) {
         const size_t g = ((size_t)b * a.ntok + i) * a.ldo + h * DH + c * CH;
         store_chunk<CH>(a.o + g, a.ol ? a.ol + g : nullptr, of);
     }
 }
 
-template <int DH>
+template <int DH, int GMAX>
 __global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
     constexpr int CH = DH / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int J = a.kf * a.kh * a.kw + 1;
-    const int stage_elems = a.W * a.NH * DH;
+    const int stage_elems = a.W * a.NH * DH * (GMAX == 1 ? 1 : a.kh);
     const int nsp = a.W * J * a.NH;
     bf16_t* st_hi = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* st_lo = st_hi + stage_elems;
     float* SP = reinterpret_cast<float*>(smem + (size_t)stage_elems * (a.kl ? 4 : 2));   // P, later unchanged
     float* DP = SP + nsp;                                                   // dP' -> dP -> ds
     float* RED = DP + nsp;                                                  // [8][64] dW_th partials / [W][inner] bos partials
@@ -291,7 +320,7 @@ __global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
         const size_t gd = ((size_t)b * a.ntok + i) * a.lddo + h * DH + c * CH;
         load_chunk<CH>(a.dO + gd, a.dOl ? a.dOl + gd : nullptr, dof);
     }
-    scores_softmax<DH>(a, b, f, y, w, h, c, act, qvalid, qf, SP, st_hi, st_lo, J);
+    scores_softmax<DH, GMAX>(a, b, f, y, w, h, c, act, qvalid, qf, SP, st_hi, J);
     // P' = mix(P) -> global (needed by bwd_kv); P stays in SP
     for (int item = t; item < a.W * J; item += blockDim.x) {
         const int wq = item / J, j = item % J;
@@ -323,31 +352,13 @@ __global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
         s = quad_sum(s);
         if (c == 0) DP[(w * J + 0) * a.NH + h] = s;
     }
-    for (int ta = 0; ta < a.kf; ++ta) {
-        const int fr = f - (a.kf - 1 - ta) * a.df;
-        if (fr < 0) continue;
-        for (int tb = 0; tb < a.kh; ++tb) {
-            const int yr = y - (a.kh - 1 - tb) * a.dh;
-            if (yr < 0) continue;
-            __syncthreads();
-            stage_row<CH>(a, a.v, a.vl, 0, b, fr, yr, w, h, c, act, st_hi, st_lo);
-            __syncthreads();
-            if (qvalid) {
-                for (int tc = 0; tc < a.kw; ++tc) {
-                    const int wr = w - (a.kw - 1 - tc) * a.dw;
-                    if (wr < 0) continue;
-                    float vf[CH];
-                    const int slot = ((wr * a.NH + h) * 4 + c) * CH;
-                    load_chunk<CH>(st_hi + slot, a.vl ? st_lo + slot : nullptr, vf);
-                    float s = 0.f;
+    sweep_taps<CH, GMAX>(a, a.v, a.vl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const float* vf) {
+        float s = 0.f;
 #pragma unroll
-                    for (int e = 0; e < CH; ++e) s += dof[e] * vf[e];
-                    s = quad_sum(s);
-                    if (c == 0) DP[(w * J + 1 + (ta * a.kh + tb) * a.kw + tc) * a.NH + h] = s;
-                }
-            }
-        }
-    }
+        for (int e = 0; e < CH; ++e) s += dof[e] * vf[e];
+        s = quad_sum(s);
+        if (c == 0) DP[(w * J + j) * a.NH + h] = s;
+    });
     __syncthreads();
     // dW_th[g][h] partial = sum_{w,j} dP'[g] * P[h]   (thread = (g,h) pair x 8 item groups)
     {
@@ -415,29 +426,11 @@ __global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
             v0c[e] = pm0 * dof[e];
         }
     }
-    for (int ta = 0; ta < a.kf; ++ta) {
-        const int fr = f - (a.kf - 1 - ta) * a.df;
-        if (fr < 0) continue;
-        for (int tb = 0; tb < a.kh; ++tb) {
-            const int yr = y - (a.kh - 1 - tb) * a.dh;
-            if (yr < 0) continue;
-            __syncthreads();
-            stage_row<CH>(a, a.k, a.kl, 0, b, fr, yr, w, h, c, act, st_hi, st_lo);
-            __syncthreads();
-            if (qvalid) {
-                for (int tc = 0; tc < a.kw; ++tc) {
-                    const int wr = w - (a.kw - 1 - tc) * a.dw;
-                    if (wr < 0) continue;
-                    float kf_[CH];
-                    const int slot = ((wr * a.NH + h) * 4 + c) * CH;
-                    load_chunk<CH>(st_hi + slot, a.kl ? st_lo + slot : nullptr, kf_);
-                    const float dj = DP[(w * J + 1 + (ta * a.kh + tb) * a.kw + tc) * a.NH + h];
+    sweep_taps<CH, GMAX>(a, a.k, a.kl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const float* kf_) {
+        const float dj = DP[(w * J + j) * a.NH + h];
 #pragma unroll
-                    for (int e = 0; e < CH; ++e) dqf[e] += dj * kf_[e];
-                }
-            }
-        }
-    }
+        for (int e = 0; e < CH; ++e) dqf[e] += dj * kf_[e];
+    });
     if (qvalid) {
 #pragma unroll
         for (int e = 0; e < CH; ++e) dqf[e] *= a.scale;
@@ -484,48 +477,68 @@ __global__ __launch_bounds__(512) void s3_bwd_kv_kernel(S3Args a) {
     float dkf[CH], dvf[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) { dkf[e] = 0.f; dvf[e] = 0.f; }
-    for (int ta = 0; ta < a.kf; ++ta) {
-        const int fq = f + (a.kf - 1 - ta) * a.df;
-        if (fq >= a.F) continue;
-        for (int tb = 0; tb < a.kh; ++tb) {
-            const int yq = y + (a.kh - 1 - tb) * a.dh;
-            if (yq >= a.H) continue;
-            if ((fq * a.H + yq) * a.W + 1 >= a.ntok) continue;     // query row beyond the sequence (uniform)
-            __syncthreads();
-            // stage the q row and the dO row of the attending query row
-            if (act) {
-                const int pq = (fq * a.H + yq) * a.W + w;
-                const bool ok = (1 + pq) < a.ntok;
-                const size_t gq = ((size_t)b * a.ntok + 1 + pq) * a.ld + h * DH + c * CH;
-                const size_t gd = ((size_t)b * a.ntok + 1 + pq) * a.lddo + h * DH + c * CH;
-                const int slot = ((w * a.NH + h) * 4 + c) * CH;
+    // planes t = ta*kh + tb; the attending query row of plane t is (f + (kf-1-ta)df, y + (kh-1-tb)dh)
+    const int nplanes = a.kf * a.kh;
+    auto plane = [&](int t, int& fq, int& yq) {
+        const int ta = t / a.kh, tb = t - ta * a.kh;
+        fq = f + (a.kf - 1 - ta) * a.df;
+        yq = y + (a.kh - 1 - tb) * a.dh;
+        return fq < a.F && yq < a.H && (fq * a.H + yq) * a.W + 1 < a.ntok;
+    };
+    auto next_plane = [&](int t) { int fq, yq; while (t < nplanes && !plane(t, fq, yq)) ++t; return t; };
+    uint4 rq[CH / 8], rd[CH / 8], rql[CH / 8], rdl[CH / 8];
+    auto fetch = [&](int t) {                       // q row and dO row of the attending query row -> registers
+        int fq, yq;
+        plane(t, fq, yq);
+        const int pq = (fq * a.H + yq) * a.W + w;
+        const bool ok = act && (1 + pq) < a.ntok;
+        const size_t gq = ((size_t)b * a.ntok + 1 + pq) * a.ld + h * DH + c * CH;
+        const size_t gd = ((size_t)b * a.ntok + 1 + pq) * a.lddo + h * DH + c * CH;
 #pragma unroll
-                for (int v8 = 0; v8 < CH / 8; ++v8) {
-                    *reinterpret_cast<uint4*>(sq_hi + slot + v8 * 8) = ok ? *reinterpret_cast<const uint4*>(a.q + gq + v8 * 8) : make_uint4(0, 0, 0, 0);
-                    *reinterpret_cast<uint4*>(sd_hi + slot + v8 * 8) = ok ? *reinterpret_cast<const uint4*>(a.dO + gd + v8 * 8) : make_uint4(0, 0, 0, 0);
-                    if (a.ql) *reinterpret_cast<uint4*>(sq_lo + slot + v8 * 8) = ok ? *reinterpret_cast<const uint4*>(a.ql + gq + v8 * 8) : make_uint4(0, 0, 0, 0);
-                    if (a.dOl) *reinterpret_cast<uint4*>(sd_lo + slot + v8 * 8) = ok ? *reinterpret_cast<const uint4*>(a.dOl + gd + v8 * 8) : make_uint4(0, 0, 0, 0);
-                }
-            }
-            __syncthreads();
-            if (kvalid) {
-                for (int tc = 0; tc < a.kw; ++tc) {
-                    const int wq = w + (a.kw - 1 - tc) * a.dw;
-                    if (wq >= a.W) continue;
-                    const int pq = (fq * a.H + yq) * a.W + wq;
-                    if (1 + pq >= a.ntok) continue;
-                    const int j = 1 + (ta * a.kh + tb) * a.kw + tc;
-                    const size_t ci = (((size_t)b * nq + pq) * J + j) * a.NH + h;
-                    const float dsv = a.ds[ci], pmv = a.pm[ci];
-                    float qq[CH], dd[CH];
-                    const int slot = ((wq * a.NH + h) * 4 + c) * CH;
-                    load_chunk<CH>(sq_hi + slot, a.ql ? sq_lo + slot : nullptr, qq);
-                    load_chunk<CH>(sd_hi + slot, a.dOl ? sd_lo + slot : nullptr, dd);
+        for (int v8 = 0; v8 < CH / 8; ++v8) {
+            rq[v8] = ok ? *reinterpret_cast<const uint4*>(a.q + gq + v8 * 8) : make_uint4(0, 0, 0, 0);
+            rd[v8] = ok ? *reinterpret_cast<const uint4*>(a.dO + gd + v8 * 8) : make_uint4(0, 0, 0, 0);
+            if (a.ql) rql[v8] = ok ? *reinterpret_cast<const uint4*>(a.ql + gq + v8 * 8) : make_uint4(0, 0, 0, 0);
+            if (a.dOl) rdl[v8] = ok ? *reinterpret_cast<const uint4*>(a.dOl + gd + v8 * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    const int myslot = ((w * a.NH + h) * 4 + c) * CH;
+    int tp = next_plane(0);
+    if (tp < nplanes) fetch(tp);
+    while (tp < nplanes) {
+        __syncthreads();
+        if (act) {
 #pragma unroll
-                    for (int e = 0; e < CH; ++e) { dkf[e] += dsv * qq[e]; dvf[e] += pmv * dd[e]; }
-                }
+            for (int v8 = 0; v8 < CH / 8; ++v8) {
+                *reinterpret_cast<uint4*>(sq_hi + myslot + v8 * 8) = rq[v8];
+                *reinterpret_cast<uint4*>(sd_hi + myslot + v8 * 8) = rd[v8];
+                if (a.ql) *reinterpret_cast<uint4*>(sq_lo + myslot + v8 * 8) = rql[v8];
+                if (a.dOl) *reinterpret_cast<uint4*>(sd_lo + myslot + v8 * 8) = rdl[v8];
             }
         }
+        __syncthreads();
+        const int tn = next_plane(tp + 1);
+        if (tn < nplanes) fetch(tn);                // in flight during the FMAs below
+        if (kvalid) {
+            int fq, yq;
+            plane(tp, fq, yq);
+            for (int tc = 0; tc < a.kw; ++tc) {
+                const int wq = w + (a.kw - 1 - tc) * a.dw;
+                if (wq >= a.W) continue;
+                const int pq = (fq * a.H + yq) * a.W + wq;
+                if (1 + pq >= a.ntok) continue;
+                const int j = 1 + tp * a.kw + tc;
+                const size_t ci = (((size_t)b * nq + pq) * J + j) * a.NH + h;
+                const float dsv = a.ds[ci], pmv = a.pm[ci];
+                float qq[CH], dd[CH];
+                const int slot = ((wq * a.NH + h) * 4 + c) * CH;
+                load_chunk<CH>(sq_hi + slot, a.ql ? sq_lo + slot : nullptr, qq);
+                load_chunk<CH>(sd_hi + slot, a.dOl ? sd_lo + slot : nullptr, dd);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) { dkf[e] += dsv * qq[e]; dvf[e] += pmv * dd[e]; }
+            }
+        }
+        tp = tn;
     }
     if (kvalid) {
 #pragma unroll
@@ -610,15 +623,18 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
     a.o = o; a.ol = o_lo; a.ldo = ldo; a.wth = w_th;
     const int J = g->kf * g->kh * g->kw + 1;
     if ((k_lo != nullptr) && (!q_lo || !v_lo)) return AMDNUWA_ERR_ARG;
-    const size_t lds = (size_t)g->W * g->heads * g->dim_head * (k_lo ? 4 : 2) + (size_t)g->W * J * g->heads * 4;
+    // tuning key 3: 0 = stage the kh rows of a tap frame at once (needs kh <= KHMAX), 1 = one row per round
+    const bool slab = g->kh <= KHMAX && g_amdnuwa_tuning[3] == 0;
+    const size_t lds = (size_t)g->W * g->heads * g->dim_head * (k_lo ? 4 : 2) * (slab ? g->kh : 1) + (size_t)g->W * J * g->heads * 4;
     dim3 grid(g->B * g->F * g->H), block(block_threads(g));
-    if (g->dim_head == 64) {
-        (void)hipFuncSetAttribute((const void*)s3_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(s3_fwd_kernel<64>, grid, block, lds, stream, a);
-    } else {
-        (void)hipFuncSetAttribute((const void*)s3_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(s3_fwd_kernel<32>, grid, block, lds, stream, a);
-    }
+#define S3F(DH_, GM_)                                                                                             \
+    do {                                                                                                          \
+        (void)hipFuncSetAttribute((const void*)s3_fwd_kernel<DH_, GM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((s3_fwd_kernel<DH_, GM_>), grid, block, lds, stream, a);                               \
+    } while (0)
+    if (g->dim_head == 64) { if (slab) S3F(64, KHMAX); else S3F(64, 1); }
+    else { if (slab) S3F(32, KHMAX); else S3F(32, 1); }
+#undef S3F
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
@@ -661,19 +677,24 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     if (spdp < (size_t)g->W * inner) spdp = (size_t)g->W * inner;
     const bool has_lo = k_lo != nullptr;
     if (has_lo && (!q_lo || !v_lo)) return AMDNUWA_ERR_ARG;
-    const size_t lds_q = (size_t)g->W * g->heads * g->dim_head * (has_lo ? 4 : 2) + (spdp + 8 * 64) * 4;
+    // tuning key 4: 1 = slab staging in bwd_q too (more LDS -> one workgroup per CU), 0 = one row per round
+    const bool slab = g->kh <= KHMAX && g_amdnuwa_tuning[4] == 1;
+    const size_t lds_q = (size_t)g->W * g->heads * g->dim_head * (has_lo ? 4 : 2) * (slab ? g->kh : 1) + (spdp + 8 * 64) * 4;
     const size_t lds_kv = (size_t)g->W * g->heads * g->dim_head * 8;
     dim3 grid((unsigned)rows), block(block_threads(g));
+#define S3B(DH_, GM_)                                                                                             \
+    do {                                                                                                          \
+        (void)hipFuncSetAttribute((const void*)s3_bwd_q_kernel<DH_, GM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
+        hipLaunchKernelGGL((s3_bwd_q_kernel<DH_, GM_>), grid, block, lds_q, stream, a);                           \
+    } while (0)
+    if (g->dim_head == 64) { if (slab) S3B(64, KHMAX); else S3B(64, 1); }
+    else { if (slab) S3B(32, KHMAX); else S3B(32, 1); }
+#undef S3B
+    LAUNCH_CHECK();
     if (g->dim_head == 64) {
-        (void)hipFuncSetAttribute((const void*)s3_bwd_q_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-        hipLaunchKernelGGL(s3_bwd_q_kernel<64>, grid, block, lds_q, stream, a);
-        LAUNCH_CHECK();
         (void)hipFuncSetAttribute((const void*)s3_bwd_kv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
         hipLaunchKernelGGL(s3_bwd_kv_kernel<64>, grid, block, lds_kv, stream, a);
     } else {
-        (void)hipFuncSetAttribute((const void*)s3_bwd_q_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-        hipLaunchKernelGGL(s3_bwd_q_kernel<32>, grid, block, lds_q, stream, a);
-        LAUNCH_CHECK();
         (void)hipFuncSetAttribute((const void*)s3_bwd_kv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
         hipLaunchKernelGGL(s3_bwd_kv_kernel<32>, grid, block, lds_kv, stream, a);
     }

@@ -78,9 +78,10 @@ __device__ __forceinline__ f32x4 load4(const bf16_t* hi, const bf16_t* lo) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int DH, bool X3>
+template <int DH, bool X3, int NKB>      // NKB > 0: compile-time number of 16-key blocks (branch-free unrolled loops)
 __global__ __launch_bounds__(512) void xattn_fwd_kernel(XArgs a) {
     constexpr int KS = DH / 32, DB = DH / 16;
+    constexpr int NK = NKB > 0 ? NKB : MAXKB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* E = reinterpret_cast<float*>(smem);                 // [2][NH][4][64][4] fp32
     __shared__ float wsh[64];
@@ -108,33 +109,46 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(XArgs a) {
         }
     }
     // S^T = K Q^T
-    f32x4 S[MAXKB][2];
+    f32x4 S[NK][2];
+    // K fragments are software-pipelined PF key blocks ahead so their L2 latency overlaps the MFMAs
+    constexpr int PF = 3;
+    bf16x8 kq[PF][KS], kql[PF][KS];
+    auto ldk = [&](int kb, int slot) {
 #pragma unroll
-    for (int kb = 0; kb < MAXKB; ++kb) {
+        for (int ks = 0; ks < KS; ++ks) {
+            const size_t go = (size_t)(kb * 16 + c) * DH + ks * 32 + g4 * 8;
+            kq[slot][ks] = ldfrag16(Kp + go, true);
+            if (X3) kql[slot][ks] = ldfrag16(Kpl + go, true);
+        }
+    };
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf)
+        if (pf < NK && (NKB > 0 || pf < a.nkb)) ldk(pf, pf);
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) {
         S[kb][0] = S[kb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (kb < a.nkb) {
+        if (NKB > 0 || kb < a.nkb) {
+            bf16x8 kf[KS], kfl[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const size_t go = (size_t)(kb * 16 + c) * DH + ks * 32 + g4 * 8;
-                const bf16x8 kf = ldfrag16(Kp + go, true);
-                bf16x8 kfl;
-                if (X3) kfl = ldfrag16(Kpl + go, true);
+            for (int ks = 0; ks < KS; ++ks) { kf[ks] = kq[kb % PF][ks]; if (X3) kfl[ks] = kql[kb % PF][ks]; }
+            if (kb + PF < NK && (NKB > 0 || kb + PF < a.nkb)) ldk(kb + PF, kb % PF);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     if (X3) {
-                        S[kb][qb] = MFMA(kfl, qf[ks][qb], S[kb][qb]);
-                        S[kb][qb] = MFMA(kf, qfl[ks][qb], S[kb][qb]);
+                        S[kb][qb] = MFMA(kfl[ks], qf[ks][qb], S[kb][qb]);
+                        S[kb][qb] = MFMA(kf[ks], qfl[ks][qb], S[kb][qb]);
                     }
-                    S[kb][qb] = MFMA(kf, qf[ks][qb], S[kb][qb]);
+                    S[kb][qb] = MFMA(kf[ks], qf[ks][qb], S[kb][qb]);
                 }
-            }
         }
     }
     // scale, mask, fp32 softmax over keys (per query column)
     float mx[2] = {NEG_MAX, NEG_MAX};
 #pragma unroll
-    for (int kb = 0; kb < MAXKB; ++kb) {
-        if (kb < a.nkb) {
+    for (int kb = 0; kb < NK; ++kb) {
+        if (NKB > 0 || kb < a.nkb) {
             const uint32_t vm = *reinterpret_cast<const uint32_t*>(a.valid + (size_t)b * a.JP + kb * 16 + g4 * 4);
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
@@ -153,8 +167,8 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(XArgs a) {
         mx[qb] = fmaxf(mx[qb], __shfl_xor(mx[qb], 32, 64));
     }
 #pragma unroll
-    for (int kb = 0; kb < MAXKB; ++kb)
-        if (kb < a.nkb)
+    for (int kb = 0; kb < NK; ++kb)
+        if (NKB > 0 || kb < a.nkb)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -171,8 +185,8 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(XArgs a) {
     }
     // normalise + save P
 #pragma unroll
-    for (int kb = 0; kb < MAXKB; ++kb)
-        if (kb < a.nkb)
+    for (int kb = 0; kb < NK; ++kb)
+        if (NKB > 0 || kb < a.nkb)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 S[kb][qb] = S[kb][qb] * sm[qb];
@@ -193,9 +207,17 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(XArgs a) {
     for (int db = 0; db < DB; ++db) O[db][0] = O[db][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nch = a.nkb / 2;
 #pragma unroll
-    for (int ch = 0; ch < MAXKB / 2; ++ch) {
-        if (ch < nch) {
+    for (int ch = 0; ch < NK / 2; ++ch) {
+        if (NKB > 0 || ch < nch) {
             float* Eb = E + (size_t)(ch & 1) * a.NH * 4 * 64 * 4;
+            // V^T fragments of this chunk: issued before the exchange barrier so they arrive during the mix
+            bf16x8 vfr[DB], vfrl[DB];
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const size_t go = (size_t)(db * 16 + c) * a.JP + ch * 32 + g4 * 4;
+                vfr[db] = ldfrag8x2(Vt + go, Vt + go + 16);
+                if (X3) vfrl[db] = ldfrag8x2(Vtl + go, Vtl + go + 16);
+            }
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
@@ -228,17 +250,13 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(XArgs a) {
             }
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const size_t go = (size_t)(db * 16 + c) * a.JP + ch * 32 + g4 * 4;
-                const bf16x8 vf = ldfrag8x2(Vt + go, Vt + go + 16);
-                bf16x8 vfl;
-                if (X3) vfl = ldfrag8x2(Vtl + go, Vtl + go + 16);
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     if (X3) {
-                        O[db][qb] = MFMA(vfl, pf[qb], O[db][qb]);
-                        O[db][qb] = MFMA(vf, pfl[qb], O[db][qb]);
+                        O[db][qb] = MFMA(vfrl[db], pf[qb], O[db][qb]);
+                        O[db][qb] = MFMA(vfr[db], pfl[qb], O[db][qb]);
                     }
-                    O[db][qb] = MFMA(vf, pf[qb], O[db][qb]);
+                    O[db][qb] = MFMA(vfr[db], pf[qb], O[db][qb]);
                 }
             }
         }
@@ -259,9 +277,10 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(XArgs a) {
 // ------------------------------------------------------------------------------------------------
 // backward, query-centric part
 // ------------------------------------------------------------------------------------------------
-template <int DH, bool X3>
+template <int DH, bool X3, int NKB>      // NKB > 0: compile-time number of 16-key blocks (branch-free unrolled loops)
 __global__ __launch_bounds__(512) void xattn_bwd_kernel(XArgs a) {
     constexpr int KS = DH / 32, DB = DH / 16;
+    constexpr int NK = NKB > 0 ? NKB : MAXKB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* E = reinterpret_cast<float*>(smem);                 // [2][NH][4][64][4]
     __shared__ float wsh[64];
@@ -293,51 +312,69 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(XArgs a) {
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg) wcol[gg] = gg < a.NH ? wsh[gg * a.NH + h] : 0.f;
 
-    f32x4 dP[MAXKB][2];
+    f32x4 dP[NK][2];
     float dth[8];
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg) dth[gg] = 0.f;
     float delta[2] = {0.f, 0.f};
     const int nch = a.nkb / 2;
 #pragma unroll
-    for (int ch = 0; ch < MAXKB / 2; ++ch) {
+    for (int ch = 0; ch < NK / 2; ++ch) {
         dP[2 * ch][0] = dP[2 * ch][1] = dP[2 * ch + 1][0] = dP[2 * ch + 1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ch < nch) {
+        if (NKB > 0 || ch < nch) {
             float* Eb = E + (size_t)(ch & 1) * a.NH * 4 * 64 * 4;
+            // all global loads of this chunk (V fragments, saved P) are issued up front, ahead of the MFMAs
+            // and of the exchange barrier
+            bf16x8 vfr[2][KS], vfrl[2][KS];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const size_t go = (size_t)((2 * ch + k2) * 16 + c) * DH + ks * 32 + g4 * 8;
+                    vfr[k2][ks] = ldfrag16(Vp + go, true);
+                    if (X3) vfrl[k2][ks] = ldfrag16(Vpl + go, true);
+                }
+            }
             // dP'^T[key][query] = sum_d V[key][d] dO[query][d]   (head = this wave)
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
                 f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const size_t go = (size_t)((2 * ch + k2) * 16 + c) * DH + ks * 32 + g4 * 8;
-                    const bf16x8 vf = ldfrag16(Vp + go, true);
-                    bf16x8 vfl;
-                    if (X3) vfl = ldfrag16(Vpl + go, true);
 #pragma unroll
                     for (int qb = 0; qb < 2; ++qb) {
                         if (X3) {
-                            acc[qb] = MFMA(vfl, df[ks][qb], acc[qb]);
-                            acc[qb] = MFMA(vf, dfl[ks][qb], acc[qb]);
+                            acc[qb] = MFMA(vfrl[k2][ks], df[ks][qb], acc[qb]);
+                            acc[qb] = MFMA(vfr[k2][ks], dfl[ks][qb], acc[qb]);
                         }
-                        acc[qb] = MFMA(vf, df[ks][qb], acc[qb]);
+                        acc[qb] = MFMA(vfr[k2][ks], df[ks][qb], acc[qb]);
                     }
                 }
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb)
                     *reinterpret_cast<f32x4*>(Eb + ((size_t)(h * 4 + k2 * 2 + qb) * 64 + lane) * 4) = acc[qb];
             }
-            __syncthreads();
+            // saved P of this chunk: issued before the barrier wait, consumed right after
+            uint2 praw[2][2], prawl[2][2];
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     const int qi = q0 + qb * 16 + c;
-                    f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+                    praw[k2][qb] = prawl[k2][qb] = make_uint2(0, 0);
                     if (qi < a.n) {
                         const size_t go = (bh * a.n + qi) * a.JP + (2 * ch + k2) * 16 + g4 * 4;
-                        pv = load4(a.P + go, a.Pl ? a.Pl + go : nullptr);
+                        praw[k2][qb] = *reinterpret_cast<const uint2*>(a.P + go);
+                        if (a.Pl) prawl[k2][qb] = *reinterpret_cast<const uint2*>(a.Pl + go);
                     }
+                }
+            __syncthreads();
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const uint2 u = praw[k2][qb], ul = prawl[k2][qb];
+                    const f32x4 pv = {lo_f(u.x) + lo_f(ul.x), hi_f(u.x) + hi_f(ul.x), lo_f(u.y) + lo_f(ul.y), hi_f(u.y) + hi_f(ul.y)};
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int gg = 0; gg < 8; ++gg)
@@ -366,9 +403,39 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(XArgs a) {
     f32x4 dQ[DB][2];
 #pragma unroll
     for (int db = 0; db < DB; ++db) dQ[db][0] = dQ[db][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // explicit 2-deep software pipeline over the 32-key chunks: chunk ch+1's saved P and K^T fragments are
+    // requested before chunk ch is processed; a sched_barrier per chunk stops further compiler hoisting
+    // (dP is live: register pressure).
+    uint2 pr[2][2][2], prl[2][2][2];
+    auto ld2 = [&](int ch, int s) {
 #pragma unroll
-    for (int ch = 0; ch < MAXKB / 2; ++ch) {
-        if (ch < nch) {
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qi = q0 + qb * 16 + c;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const size_t go = (bh * a.n + qi) * a.JP + (2 * ch + k2) * 16 + g4 * 4;
+                pr[s][qb][k2] = make_uint2(0, 0);
+                if (X3) prl[s][qb][k2] = make_uint2(0, 0);
+                if (qi < a.n) {
+                    pr[s][qb][k2] = *reinterpret_cast<const uint2*>(a.P + go);
+                    if (X3 && a.Pl) prl[s][qb][k2] = *reinterpret_cast<const uint2*>(a.Pl + go);
+                }
+            }
+        }
+    };
+    if (NKB > 0 || 0 < nch) ld2(0, 0);
+#pragma unroll
+    for (int ch = 0; ch < NK / 2; ++ch) {
+        if (NKB > 0 || ch < nch) {
+            const int s = ch & 1;
+            if (ch + 1 < NK / 2 && (NKB > 0 || ch + 1 < nch)) ld2(ch + 1, s ^ 1);
+            bf16x8 kt[DB], ktl[DB];          // K^T fragments of this chunk (L2-resident): issued now, used after ds
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const size_t go = (size_t)(db * 16 + c) * a.JP + ch * 32 + g4 * 4;
+                kt[db] = ldfrag8x2(Kt + go, Kt + go + 16);
+                if (X3) ktl[db] = ldfrag8x2(Ktl + go, Ktl + go + 16);
+            }
             bf16x8 sf[2], sfl[2];
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
@@ -376,9 +443,10 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(XArgs a) {
                 float v8[8];
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
-                    f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+                    const uint2 u = pr[s][qb][k2];
+                    f32x4 pv = {lo_f(u.x), hi_f(u.x), lo_f(u.y), hi_f(u.y)};
+                    if (X3) { const uint2 ul = prl[s][qb][k2]; pv[0] += lo_f(ul.x); pv[1] += hi_f(ul.x); pv[2] += lo_f(ul.y); pv[3] += hi_f(ul.y); }
                     const size_t go = (bh * a.n + qi) * a.JP + (2 * ch + k2) * 16 + g4 * 4;
-                    if (qi < a.n) pv = load4(a.P + go, a.Pl ? a.Pl + go : nullptr);
                     f32x4 dsv;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -391,19 +459,16 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(XArgs a) {
             }
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const size_t go = (size_t)(db * 16 + c) * a.JP + ch * 32 + g4 * 4;
-                const bf16x8 kf = ldfrag8x2(Kt + go, Kt + go + 16);
-                bf16x8 kfl;
-                if (X3) kfl = ldfrag8x2(Ktl + go, Ktl + go + 16);
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     if (X3) {
-                        dQ[db][qb] = MFMA(kfl, sf[qb], dQ[db][qb]);
-                        dQ[db][qb] = MFMA(kf, sfl[qb], dQ[db][qb]);
+                        dQ[db][qb] = MFMA(ktl[db], sf[qb], dQ[db][qb]);
+                        dQ[db][qb] = MFMA(kt[db], sfl[qb], dQ[db][qb]);
                     }
-                    dQ[db][qb] = MFMA(kf, sf[qb], dQ[db][qb]);
+                    dQ[db][qb] = MFMA(kt[db], sf[qb], dQ[db][qb]);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
@@ -429,10 +494,11 @@ __global__ __launch_bounds__(256) void xattn_pack_kernel(const bf16_t* __restric
                                                          bf16_t* Ktl, bf16_t* Vp, bf16_t* Vpl, bf16_t* Vt, bf16_t* Vtl,
                                                          uint8_t* valid, int B, int T, int NH, int DH, int JP) {
     const int bh = blockIdx.x, b = bh / NH, h = bh % NH, inner = NH * DH;
-    if (h == 0)
+    if (h == 0 && blockIdx.y == 0)
         for (int j = threadIdx.x; j < JP; j += blockDim.x)
             valid[(size_t)b * JP + j] = j == 0 ? 1 : (j <= T ? (mask ? mask[(size_t)b * T + j - 1] : 1) : 0);
-    for (int e = threadIdx.x; e < JP * DH; e += blockDim.x) {
+    // grid.y slices the JP keys in blocks of 16
+    for (int e = blockIdx.y * 16 * DH + threadIdx.x; e < (blockIdx.y + 1) * 16 * DH; e += blockDim.x) {
         const int j = e / DH, d = e % DH;
         bf16_t kh = 0, kl = 0, vh = 0, vl = 0;
         if (j == 0) {
@@ -517,7 +583,7 @@ extern "C" int amdnuwa_xattn_pack(const amdnuwa_xattn_geom* g, const uint16_t* k
     if (!kv || !null_k || !null_v || !p || !p->Kp || !p->Kt || !p->Vp || !p->Vt || !p->valid) return AMDNUWA_ERR_ARG;
     if (kv_lo && (!p->Kp_lo || !p->Kt_lo || !p->Vp_lo || !p->Vt_lo)) return AMDNUWA_ERR_ARG;
     if (g->B <= 0) return AMDNUWA_OK;
-    hipLaunchKernelGGL(xattn_pack_kernel, dim3(g->B * g->heads), dim3(256), 0, stream, kv, kv_lo, ldkv, null_k, null_v, context_mask,
+    hipLaunchKernelGGL(xattn_pack_kernel, dim3(g->B * g->heads, g->JP / 16), dim3(256), 0, stream, kv, kv_lo, ldkv, null_k, null_v, context_mask,
                        p->Kp, kv_lo ? p->Kp_lo : nullptr, p->Kt, kv_lo ? p->Kt_lo : nullptr, p->Vp, kv_lo ? p->Vp_lo : nullptr,
                        p->Vt, kv_lo ? p->Vt_lo : nullptr, p->valid, g->B, g->T, g->heads, g->dim_head, g->JP);
     LAUNCH_CHECK();
@@ -547,13 +613,15 @@ extern "C" int amdnuwa_xattn_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q,
     const int tiles = (g->n + 31) / 32;
     dim3 grid(g->B * tiles), block(g->heads * 64);
     const size_t lds = (size_t)2 * g->heads * 4 * 64 * 4 * sizeof(float);
-#define XF(DH_, X3_)                                                                                              \
+#define XF(DH_, X3_, NKB_)                                                                                        \
     do {                                                                                                          \
-        (void)hipFuncSetAttribute((const void*)xattn_fwd_kernel<DH_, X3_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((xattn_fwd_kernel<DH_, X3_>), grid, block, lds, stream, a);                            \
+        (void)hipFuncSetAttribute((const void*)xattn_fwd_kernel<DH_, X3_, NKB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((xattn_fwd_kernel<DH_, X3_, NKB_>), grid, block, lds, stream, a);                      \
     } while (0)
-    if (g->dim_head == 64) { if (x3) XF(64, true); else XF(64, false); }
-    else { if (x3) XF(32, true); else XF(32, false); }
+    // production shape (dim_head 64, 256 text tokens -> 18 key blocks, bf16): branch-free instantiation
+    if (g->dim_head == 64 && !x3 && a.nkb == 18 && g_amdnuwa_tuning[5] == 0) XF(64, false, 18);
+    else if (g->dim_head == 64) { if (x3) XF(64, true, 0); else XF(64, false, 0); }
+    else { if (x3) XF(32, true, 0); else XF(32, false, 0); }
 #undef XF
     LAUNCH_CHECK();
     return AMDNUWA_OK;
@@ -583,13 +651,15 @@ extern "C" int amdnuwa_xattn_bwd(const amdnuwa_xattn_geom* g, const uint16_t* dO
     const int tiles = (g->n + 31) / 32;
     dim3 grid(g->B * tiles), block(g->heads * 64);
     const size_t lds = (size_t)2 * g->heads * 4 * 64 * 4 * sizeof(float);
-#define XB(DH_, X3_)                                                                                              \
+#define XB(DH_, X3_, NKB_)                                                                                        \
     do {                                                                                                          \
-        (void)hipFuncSetAttribute((const void*)xattn_bwd_kernel<DH_, X3_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((xattn_bwd_kernel<DH_, X3_>), grid, block, lds, stream, a);                            \
+        (void)hipFuncSetAttribute((const void*)xattn_bwd_kernel<DH_, X3_, NKB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((xattn_bwd_kernel<DH_, X3_, NKB_>), grid, block, lds, stream, a);                      \
     } while (0)
-    if (g->dim_head == 64) { if (x3) XB(64, true); else XB(64, false); }
-    else { if (x3) XB(32, true); else XB(32, false); }
+    // (a branch-free NKB = 18 instantiation of the backward spills registers -- dP is live throughout -- so the
+    //  backward always uses the guarded form with explicit prefetch)
+    if (g->dim_head == 64) { if (x3) XB(64, true, 0); else XB(64, false, 0); }
+    else { if (x3) XB(32, true, 0); else XB(32, false, 0); }
 #undef XB
     LAUNCH_CHECK();
     hipLaunchKernelGGL(xattn_wth_reduce_kernel, dim3(1), dim3(1024), 0, stream, a.part_th, g->B * tiles, g->heads * g->heads, dw_th, accumulate);

@@ -69,7 +69,8 @@ def main():
         out = torch.empty(n1, n2, device=dev)
         row = []
         ref = None
-        for target, minrows in ((1024, 256), (512, 512), (256, 1024), (2048, 256), (512, 2048)):
+        for variant, target, minrows in ((0, 512, 512), (1, 1024, 256), (1, 512, 512), (1, 256, 1024), (1, 512, 2048), (1, 1024, 1024)):
+            L.amdnuwa_set_tuning(6, variant)
             L.amdnuwa_set_tuning(1, target)
             L.amdnuwa_set_tuning(2, minrows)
             f = lambda: K.gemm_tn(K.view(A, cols=slice(0, n1)), K.view(Bm, cols=slice(0, n2)), out, shift=(n, 16) if sh else None, N1=n1, N2=n2)
@@ -78,10 +79,11 @@ def main():
                 ref = out.clone()
             err = float((out - ref).abs().max() / ref.abs().max())
             t = bench(f, args.iters)
-            row.append(f'wg{target}/r{minrows}: {2.0 * M * n1 * n2 / t / 1e12:6.1f} TF/s ({t * 1e6:6.1f} us){"" if err < 1e-4 else " MISMATCH"}')
+            row.append(f'v{variant}/wg{target}/r{minrows}: {2.0 * M * n1 * n2 / t / 1e12:6.1f} TF/s ({t * 1e6:6.1f} us){"" if err < 1e-4 else " MISMATCH"}')
         print(f'{name:22s} [{n1}x{n2}]  ' + ' | '.join(row))
     L.amdnuwa_set_tuning(1, 0)
     L.amdnuwa_set_tuning(2, 0)
+    L.amdnuwa_set_tuning(6, 0)
 
 
 if __name__ == '__main__':
