@@ -364,6 +364,138 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// NT, 256x256 tile, 8 waves (2 x 4, 128x64 each), K-step 32, NS-stage direct-to-LDS ring.
+// Twice the arithmetic intensity of the 128x128 tile per byte pulled through L2/MALL (128 flop/B), and
+// NS-1 K-tiles of DMA in flight: the ring is synchronised with a COUNTED s_waitcnt vmcnt(N) + a raw
+// s_barrier per K-tile (a __syncthreads() would drain every outstanding DMA).  Per K-tile per wave:
+// 4 global_load_lds, 12 ds_read_b128, 32 MFMAs.  One workgroup per CU (128 KiB LDS, 128 accumulators).
+// ---------------------------------------------------------------------------------------------
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <bool SHIFT, int EPI, int NS>
+__global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 256 * 32 * 2;             // 16 KiB per operand per stage
+    constexpr int STG = 2 * TB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int lid = xcd_remap(blockIdx.x, nwg);
+    const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const long long bz = blockIdx.y;
+    const long long oA = boff(p, bz, p.sA, p.sA_in), oB = boff(p, bz, p.sB, p.sB_in), oC = boff(p, bz, p.sC, p.sC_in);
+    const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+    const bf16_t* pa[2]; const bf16_t* pah[2]; const bf16_t* paw[2]; const bf16_t* pb[2];
+    int cca[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (j * 8 + wave) * 16 + (lane >> 2);
+        const int cc = (lane & 3) ^ glds_swz<32>(row);
+        cca[j] = cc;
+        const long long ga = (long long)m0 + row, gb = (long long)n0 + row;
+        pa[j] = ga < p.M ? p.A + oA + ga * p.lda + cc * 8 : nullptr;
+        pb[j] = gb < p.N ? p.B + oB + gb * p.ldb + cc * 8 : nullptr;
+        pah[j] = paw[j] = pa[j];
+        if (SHIFT && pa[j]) {
+            const ShiftRow s = shift_row(ga, p.shift_ntok, p.shift_fmap);
+            pah[j] = s.off_h == INT_MIN ? nullptr : pa[j] + (long long)s.off_h * p.lda;
+            paw[j] = s.off_w == INT_MIN ? nullptr : pa[j] + (long long)s.off_w * p.lda;
+        }
+    }
+    const int quarter = SHIFT ? (p.shift_dim >> 2) : 1;
+    auto issue = [&](int slot, int k0) {
+        char* base = smem + slot * STG;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16_t* sa = pa[j];
+            if (SHIFT) {
+                const int q = (k0 + cca[j] * 8) / quarter;
+                sa = q == 0 ? pah[j] : (q == 1 ? paw[j] : pa[j]);
+            }
+            const bf16_t* srca = sa ? sa + k0 : zp;
+            const bf16_t* srcb = pb[j] ? pb[j] + k0 : zp;
+            const int off = (j * 8 + wave) * 1024;
+            __builtin_amdgcn_global_load_lds((glb_cvptr)srca, (lds_vptr)(base + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_cvptr)srcb, (lds_vptr)(base + TB + off), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 32;
+    // prologue: NS-1 tiles in flight
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s, s * 32);
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed for THIS wave once at most (tiles after kt still in flight) x 4 DMAs remain
+        const int rem = nk - 1 - kt;
+        if (NS >= 4 && rem >= 2) VMCNT(8);
+        else if (rem >= 1) VMCNT(4);
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();            // ... and for every wave; also: everyone finished reading slot (kt-1)%NS
+        if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * 32);
+        const char* base = smem + (kt % NS) * STG;
+        bf16x8 af[8], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + glds_off<32>(wm * 128 + i * 16 + fr, fg));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(base + TB + glds_off<32>(wn * 64 + j * 16 + fr, fg));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+
+    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fg * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r] * p.alpha;
+                if (EPI == 0 && p.bias && n + r < p.N) v[r] += p.bias[n + r];
+            }
+            if (EPI == 0) {
+                float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
+                if (vec_ok) *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
+            } else {
+                bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + n;
+                bf16_t h[4], l[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f2bf_hilo(v[r], h[r], l[r]);
+                if (vec_ok) {
+                    *reinterpret_cast<uint2*>(C) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+                    if (p.Clo) *reinterpret_cast<uint2*>(p.Clo + oC + m * p.ldc + n) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                        C[r] = h[r];
+                        if (p.Clo) p.Clo[oC + m * p.ldc + n + r] = l[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // TN :  P[z][n1][n2] = sum over token rows m of split z of A[m][n1] * B[m][n2]   (fp32 partials)
 // ---------------------------------------------------------------------------------------------
 constexpr int TK = 32;                       // token rows per step
@@ -608,6 +740,131 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmArgs p, float* __
     }
 }
 
+// TN, 256x256 output tile, 8 waves (2 x 4, 128 x 64 each), 32 token rows per K-step, NS-stage DMA ring with
+// counted vmcnt + raw barrier (see gemm_nt_256_kernel).  Operand tiles are [32 rows][256 columns] (512-byte
+// rows, 32-byte XOR swizzle on the source column), fragments come from ds_read_b64_tr_b16.
+__device__ __forceinline__ int tn256_elem(int row, int col) { return row * 512 + ((((col >> 4) ^ tn_f(row)) << 5) | ((col & 15) << 1)); }
+__device__ __forceinline__ bf16x8 tn256_frag(const char* tile, int colbase, int lane) {
+    const int t = lane & 15, g = lane >> 4;
+    const int row = 8 * g + (t >> 2), col = colbase + ((t & 3) << 2);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + tn256_elem(row, col)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + tn256_elem(row + 4, col)));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool SHIFT, int NS>
+__global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmArgs p, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 32 * 256 * 2;             // 16 KiB per operand per stage
+    constexpr int STG = 2 * TB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int N1 = p.M, N2 = p.N;
+    const int tmi = blockIdx.x / p.tiles_n, tni = blockIdx.x % p.tiles_n;
+    const int a0 = tmi * 256, b0 = tni * 256;
+    const long long bz = blockIdx.y;
+    const int z = blockIdx.z;
+    const bf16_t* A = p.A + boff(p, bz, p.sA, p.sA_in);
+    const bf16_t* B = p.B + boff(p, bz, p.sB, p.sB_in);
+    const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
+    const long long mbeg = (long long)z * p.ksplit_len;
+    const long long mend = min((long long)p.K, mbeg + p.ksplit_len);
+    const int quarter = SHIFT ? (p.shift_dim >> 2) : 1;
+    const bool pow2 = SHIFT && (p.shift_fmap & (p.shift_fmap - 1)) == 0;
+    const int fsh = pow2 ? __ffs(p.shift_fmap) - 1 : 0;
+
+    // 16 DMA pieces (1 KiB = 2 token rows) per operand tile; each wave moves pieces wave and wave + 8
+    int prow[2], cola[2], colb[2];
+    bool oka[2], okb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (j * 8 + wave) * 2 + (lane >> 5);
+        const int ps = lane & 31;                               // 16-byte chunk position inside the 512-byte row
+        const int cc16 = ((((ps >> 1) ^ tn_f(row)) << 1) | (ps & 1));
+        prow[j] = row;
+        cola[j] = a0 + cc16 * 8; colb[j] = b0 + cc16 * 8;
+        oka[j] = cola[j] < N1; okb[j] = colb[j] < N2;
+    }
+    auto issue = [&](int slot, long long mk0) {
+        char* base = smem + slot * STG;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long g = mk0 + prow[j];
+            const bool rin = g < mend;
+            const bf16_t* sa = (rin && oka[j]) ? A + g * p.lda + cola[j] : zp;
+            const bf16_t* sb = zp;
+            if (rin && okb[j]) {
+                long long gb = g;
+                bool zero = false;
+                if (SHIFT) {
+                    const int i = (int)((unsigned)g % (unsigned)p.shift_ntok);
+                    if (i > 0) {
+                        const int pp = i - 1;
+                        const int w = pow2 ? (pp & (p.shift_fmap - 1)) : pp % p.shift_fmap;
+                        const int y = pow2 ? ((pp >> fsh) & (p.shift_fmap - 1)) : (pp / p.shift_fmap) % p.shift_fmap;
+                        const int q = colb[j] / quarter;
+                        if (q == 0) { if (y > 0) gb -= p.shift_fmap; else zero = true; }
+                        else if (q == 1) { if (w > 0) gb -= 1; else zero = true; }
+                    }
+                }
+                if (!zero) sb = B + gb * p.ldb + colb[j];
+            }
+            const int off = (j * 8 + wave) * 1024;
+            __builtin_amdgcn_global_load_lds((glb_cvptr)sa, (lds_vptr)(base + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_cvptr)sb, (lds_vptr)(base + TB + off), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)((mend - mbeg + TK - 1) / TK);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s, mbeg + (long long)s * TK);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = nk - 1 - kt;
+        if (NS >= 4 && rem >= 2) VMCNT(8);
+        else if (rem >= 1) VMCNT(4);
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, mbeg + (long long)(kt + NS - 1) * TK);
+        const char* base = smem + (kt % NS) * STG;
+        bf16x8 af[8], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = tn256_frag(base, wm * 128 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = tn256_frag(base + TB, wn * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+    float* P = partial + ((size_t)bz * gridDim.z + z) * (size_t)N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n1 = a0 + wm * 128 + i * 16 + fr;
+        if (n1 >= N1) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n2 = b0 + wn * 64 + j * 16 + fg * 4;
+            if (n2 + 3 < N2 && (N2 & 3) == 0) *reinterpret_cast<float4*>(P + (size_t)n1 * N2 + n2) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n2 + r < N2) P[(size_t)n1 * N2 + n2 + r] = acc[i][j][r];
+        }
+    }
+}
+
 // C[bz][n1][n2] = beta*C + alpha * sum_z partial[bz][z][n1][n2]   (fixed order -> deterministic)
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, long long sC, long long sC_in,
                                      int batch_inner, int ldc, int N1, int N2, int splits, float alpha, float beta) {
@@ -646,6 +903,21 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     dim3 grid(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), block(256);
     // direct-to-LDS variants (tuning key 0: 0 = register-staged, 1 = glds BK 64, 2 = glds BK 32)
     const int variant = g_amdnuwa_tuning[0];
+    if (!x3 && (variant == 3 || variant == 4) && d->K % 32 == 0) {        // 256x256 tile, 4- / 3-stage DMA ring
+        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
+        dim3 g256(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b256(512);
+#define G256(SH, EP, NS_)                                                                                             \
+    do {                                                                                                              \
+        const size_t l256 = (size_t)NS_ * 2 * 256 * 32 * 2;                                                           \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<SH, EP, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l256); \
+        hipLaunchKernelGGL((gemm_nt_256_kernel<SH, EP, NS_>), g256, b256, l256, stream, p);                            \
+    } while (0)
+        if (variant == 3) { if (sh) { if (ob) G256(true, 1, 4); else G256(true, 0, 4); } else { if (ob) G256(false, 1, 4); else G256(false, 0, 4); } }
+        else              { if (sh) { if (ob) G256(true, 1, 3); else G256(true, 0, 3); } else { if (ob) G256(false, 1, 3); else G256(false, 0, 3); } }
+#undef G256
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
+    }
     const int gbk = variant == 1 ? 64 : (variant == 2 ? 32 : 0);
     if (!x3 && gbk && d->K % gbk == 0) {
         const size_t gl = (size_t)2 * 2 * 128 * gbk * 2;
@@ -669,9 +941,14 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     return AMDNUWA_OK;
 }
 
+// tuning key 6: 0 register-staged 128x128, 1 direct-to-LDS 128x128, 2 direct-to-LDS 256x256 (4-stage ring)
+static bool tn_use256(const amdnuwa_gemm_desc* d) {
+    return g_amdnuwa_tuning[6] == 2 && d->Alo == nullptr && (long long)d->K < (1LL << 31) && d->M >= 256 && d->N >= 256;
+}
 static int tn_splits(const amdnuwa_gemm_desc* d) {
-    const int tiles = ((d->M + 127) / 128) * ((d->N + 127) / 128) * (d->batch > 0 ? d->batch : 1);
-    const int target = g_amdnuwa_tuning[1] > 0 ? g_amdnuwa_tuning[1] : 1024;   // aim for ~4 workgroups per CU
+    const int tl = tn_use256(d) ? 256 : 128;
+    const int tiles = ((d->M + tl - 1) / tl) * ((d->N + tl - 1) / tl) * (d->batch > 0 ? d->batch : 1);
+    const int target = g_amdnuwa_tuning[1] > 0 ? g_amdnuwa_tuning[1] : (tl == 256 ? 256 : 1024);   // workgroups to aim for
     const int minrows = g_amdnuwa_tuning[2] > 0 ? g_amdnuwa_tuning[2] : 256;   // token rows per split, at least
     int splits = (target + tiles - 1) / tiles;
     const int maxs = (d->K + minrows - 1) / minrows;
@@ -711,6 +988,18 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
     dim3 grid(p.tiles_m * p.tiles_n, batch, splits), block(256);
     const size_t lds = (size_t)2 * (x3 ? 4 : 2) * TN_TILE_BYTES;
     float* part = (float*)workspace;
+    if (tn_use256(d)) {
+        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
+        dim3 g256(p.tiles_m * p.tiles_n, batch, splits), b256(512);
+        const size_t l256 = (size_t)4 * 2 * 32 * 256 * 2;
+        if (sh) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_256_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l256);
+            hipLaunchKernelGGL((gemm_tn_256_kernel<true, 4>), g256, b256, l256, stream, p, part);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_256_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l256);
+            hipLaunchKernelGGL((gemm_tn_256_kernel<false, 4>), g256, b256, l256, stream, p, part);
+        }
+    } else
     if (!x3 && g_amdnuwa_tuning[6] == 1 && (long long)d->K < (1LL << 31)) {     // tuning key 6: direct-to-LDS TN
         const size_t gl = (size_t)2 * 2 * TN_TILE_BYTES;
         if (sh) hipLaunchKernelGGL((gemm_tn_glds_kernel<true>), grid, block, gl, stream, p, part);

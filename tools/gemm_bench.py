@@ -47,7 +47,7 @@ def main():
         A, Bm = mk(m, kk), mk(nn, kk)
         ref = None
         row = []
-        for var in (0, 1, 2):
+        for var in (0, 2, 3, 4):
             L.amdnuwa_set_tuning(0, var)
             out = K.gemm_nt(A, Bm, out_bf16=obf, shift=(n, 16) if sh else None)
             o = out.hi.float() if obf else out
@@ -69,7 +69,7 @@ def main():
         out = torch.empty(n1, n2, device=dev)
         row = []
         ref = None
-        for variant, target, minrows in ((0, 512, 512), (1, 1024, 256), (1, 512, 512), (1, 256, 1024), (1, 512, 2048), (1, 1024, 1024)):
+        for variant, target, minrows in ((0, 512, 512), (1, 1024, 1024), (2, 256, 512), (2, 512, 512), (2, 256, 2048), (2, 128, 1024)):
             L.amdnuwa_set_tuning(6, variant)
             L.amdnuwa_set_tuning(1, target)
             L.amdnuwa_set_tuning(2, minrows)
