@@ -902,7 +902,13 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     const bool x3 = d->Alo != nullptr, sh = d->shift_ntok > 0, ob = d->c_is_bf16 != 0;
     dim3 grid(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), block(256);
     // direct-to-LDS variants (tuning key 0: 0 = register-staged, 1 = glds BK 64, 2 = glds BK 32)
-    const int variant = g_amdnuwa_tuning[0];
+    // tuning key 0: 0 = auto, 1 = direct-to-LDS BK 64, 2 = direct-to-LDS BK 32, 3 / 4 = 256x256 tile with a 4- / 3-stage
+    // DMA ring, 5 = register-staged.  auto: 256x256 ring when it yields >= 2 full rounds of tiles on 256 CUs, else BK 32.
+    int variant = g_amdnuwa_tuning[0];
+    if (variant == 0) {
+        const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * (d->batch > 0 ? d->batch : 1);
+        variant = (d->K % 32 == 0) ? (t256 >= 512 ? 4 : 2) : 5;
+    }
     if (!x3 && (variant == 3 || variant == 4) && d->K % 32 == 0) {        // 256x256 tile, 4- / 3-stage DMA ring
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         dim3 g256(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b256(512);
@@ -941,16 +947,25 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     return AMDNUWA_OK;
 }
 
-// tuning key 6: 0 register-staged 128x128, 1 direct-to-LDS 128x128, 2 direct-to-LDS 256x256 (4-stage ring)
-static bool tn_use256(const amdnuwa_gemm_desc* d) {
-    return g_amdnuwa_tuning[6] == 2 && d->Alo == nullptr && (long long)d->K < (1LL << 31) && d->M >= 256 && d->N >= 256;
+// tuning key 6: 0 = auto (256x256 4-stage ring when both output dims >= 256, else direct-to-LDS 128x128),
+//               1 = register-staged 128x128, 2 = direct-to-LDS 128x128, 3 = 256x256 ring
+static int tn_variant(const amdnuwa_gemm_desc* d) {
+    const bool x3 = d->Alo != nullptr, big = (long long)d->K >= (1LL << 31);
+    if (x3 || big) return 1;
+    int v = g_amdnuwa_tuning[6];
+    if (v == 0) v = (d->M >= 256 && d->N >= 256) ? 3 : 2;
+    if (v == 3 && !(d->M >= 256 && d->N >= 256)) v = 2;
+    return v;
 }
+// split-K policy: fill the workgroup SLOTS of the chip exactly once (256 CUs x resident workgroups per CU);
+// never exceed them (a 257th workgroup would cost a whole extra round), keep >= minrows token rows per split.
 static int tn_splits(const amdnuwa_gemm_desc* d) {
-    const int tl = tn_use256(d) ? 256 : 128;
+    const int v = tn_variant(d);
+    const int tl = v == 3 ? 256 : 128;
     const int tiles = ((d->M + tl - 1) / tl) * ((d->N + tl - 1) / tl) * (d->batch > 0 ? d->batch : 1);
-    const int target = g_amdnuwa_tuning[1] > 0 ? g_amdnuwa_tuning[1] : (tl == 256 ? 256 : 1024);   // workgroups to aim for
-    const int minrows = g_amdnuwa_tuning[2] > 0 ? g_amdnuwa_tuning[2] : 256;   // token rows per split, at least
-    int splits = (target + tiles - 1) / tiles;
+    const int slots = g_amdnuwa_tuning[1] > 0 ? g_amdnuwa_tuning[1] : (v == 3 ? 256 : 1024);
+    const int minrows = g_amdnuwa_tuning[2] > 0 ? g_amdnuwa_tuning[2] : 256;
+    int splits = slots / tiles;                              // floor: stay within one round
     const int maxs = (d->K + minrows - 1) / minrows;
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
@@ -988,7 +1003,8 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
     dim3 grid(p.tiles_m * p.tiles_n, batch, splits), block(256);
     const size_t lds = (size_t)2 * (x3 ? 4 : 2) * TN_TILE_BYTES;
     float* part = (float*)workspace;
-    if (tn_use256(d)) {
+    const int tnv = tn_variant(d);
+    if (tnv == 3) {
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         dim3 g256(p.tiles_m * p.tiles_n, batch, splits), b256(512);
         const size_t l256 = (size_t)4 * 2 * 32 * 256 * 2;
@@ -1000,7 +1016,7 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
             hipLaunchKernelGGL((gemm_tn_256_kernel<false, 4>), g256, b256, l256, stream, p, part);
         }
     } else
-    if (!x3 && g_amdnuwa_tuning[6] == 1 && (long long)d->K < (1LL << 31)) {     // tuning key 6: direct-to-LDS TN
+    if (tnv == 2) {
         const size_t gl = (size_t)2 * 2 * TN_TILE_BYTES;
         if (sh) hipLaunchKernelGGL((gemm_tn_glds_kernel<true>), grid, block, gl, stream, p, part);
         else    hipLaunchKernelGGL((gemm_tn_glds_kernel<false>), grid, block, gl, stream, p, part);

@@ -65,22 +65,59 @@ __device__ __forceinline__ void store_chunk(bf16_t* hi, bf16_t* lo, const float*
         if (lo) *reinterpret_cast<uint4*>(lo + v8 * 8) = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
     }
 }
+// reductions over the 4 lanes of a (query, head) group with DPP quad permutes (no LDS traffic)
+__device__ __forceinline__ float dpp_quad(float v, int ctrl_b1) {
+    const int i = __builtin_bit_cast(int, v);
+    const int r = ctrl_b1 ? __builtin_amdgcn_mov_dpp(i, 0xB1, 0xF, 0xF, true)     // quad_perm [1,0,3,2]
+                          : __builtin_amdgcn_mov_dpp(i, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    return __builtin_bit_cast(float, r);
+}
 __device__ __forceinline__ float quad_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
+    v += dpp_quad(v, 1);
+    v += dpp_quad(v, 0);
     return v;
 }
 __device__ __forceinline__ float quad_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1, 64));
-    v = fmaxf(v, __shfl_xor(v, 2, 64));
+    v = fmaxf(v, dpp_quad(v, 1));
+    v = fmaxf(v, dpp_quad(v, 0));
     return v;
+}
+
+// packed bf16 arithmetic (bf16 operand mode): v_dot2_f32_bf16 multiplies two bf16 pairs and accumulates in fp32
+template <int CH>
+__device__ __forceinline__ void load_pk(const bf16_t* p, uint32_t* pk) {
+#pragma unroll
+    for (int v8 = 0; v8 < CH / 8; ++v8) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p + v8 * 8);
+        pk[v8 * 4 + 0] = u.x; pk[v8 * 4 + 1] = u.y; pk[v8 * 4 + 2] = u.z; pk[v8 * 4 + 3] = u.w;
+    }
+}
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
+template <int CH>
+__device__ __forceinline__ float dot_pk(const uint32_t* a, const uint32_t* b) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH / 2; i += 2) { s0 = dot2(a[i], b[i], s0); s1 = dot2(a[i + 1], b[i + 1], s1); }
+    return s0 + s1;
+}
+// acc[e] += coef * v[e] with coef rounded to bf16: one dot2 per element, no unpacking
+template <int CH>
+__device__ __forceinline__ void axpy_pk(float* acc, float coef, const uint32_t* v) {
+    const uint32_t clo = f2bf(coef), chi = clo << 16;
+#pragma unroll
+    for (int i = 0; i < CH / 2; ++i) {
+        acc[2 * i] = dot2(v[i], clo, acc[2 * i]);
+        acc[2 * i + 1] = dot2(v[i], chi, acc[2 * i + 1]);
+    }
 }
 
 // Sweep over all causal taps of one query row.  Key/value rows are staged in LDS `GMAX` tap planes at a
 // time (GMAX == KHMAX: the kh rows of one tap FRAME = a "slab"; GMAX == 1: one row), and the NEXT group is
 // fetched into registers while the current one is consumed, so the global-load latency overlaps the FMAs.
-// fn(j, chunk) is called for every valid tap slot j >= 1 of this thread's (query, head) with the staged
-// fp32 chunk of that tap's key/value.  Each active thread moves the chunk of its own (w, h, c).
+// fn(j, hi, lo) is called for every valid tap slot j >= 1 of this thread's (query, head) with LDS pointers to
+// the staged bf16 chunk (hi, and lo or nullptr) of that tap's key/value.  Each active thread moves the chunk of its own (w, h, c).
 constexpr int KHMAX = 3;
 
 template <int CH, int GMAX, typename Fn>
@@ -150,10 +187,8 @@ __device__ __forceinline__ void sweep_taps(const S3Args& a, const bf16_t* src, c
                 for (int tc = 0; tc < a.kw; ++tc) {
                     const int wr = w - (a.kw - 1 - tc) * a.dw;
                     if (wr < 0) continue;
-                    float ch[CH];
                     const int slot = k * slab + ((wr * a.NH + h) * 4 + c) * CH;
-                    load_chunk<CH>(st_hi + slot, srcl ? st_lo + slot : nullptr, ch);
-                    fn(1 + t * a.kw + tc, ch);
+                    fn(1 + t * a.kw + tc, st_hi + slot, srcl ? st_lo + slot : nullptr);
                 }
             }
         }
@@ -164,27 +199,33 @@ __device__ __forceinline__ void sweep_taps(const S3Args& a, const bf16_t* src, c
 // scores + softmax for one query row: fills SP[(w*J + j)*NH + h] with P (fp32).  Shared by fwd and bwd_q.
 template <int DH, int GMAX>
 __device__ __forceinline__ void scores_softmax(const S3Args& a, int b, int f, int y, int w, int h, int c, bool act, bool qvalid,
-                                               const float* qf, float* SP, bf16_t* st_hi, int J) {
+                                               const float* qf, const uint32_t* qp, float* SP, bf16_t* st_hi, int J) {
     constexpr int CH = DH / 4;
     const int t = threadIdx.x, nt = blockDim.x;
     for (int e = t; e < a.W * J * a.NH; e += nt) SP[e] = NEG_MAX;
     __syncthreads();
     // <bos> key: slot j = 0
-    if (qvalid) {
-        float kf_[CH];
-        const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
-        load_chunk<CH>(a.k + g, a.kl ? a.kl + g : nullptr, kf_);
+    auto qk = [&](const bf16_t* khi, const bf16_t* klo) {
         float s = 0.f;
+        if (klo) {
+            float kf_[CH];
+            load_chunk<CH>(khi, klo, kf_);
 #pragma unroll
-        for (int e = 0; e < CH; ++e) s += qf[e] * kf_[e];
-        s = quad_sum(s);
+            for (int e = 0; e < CH; ++e) s += qf[e] * kf_[e];
+        } else {
+            uint32_t kp[CH / 2];
+            load_pk<CH>(khi, kp);
+            s = dot_pk<CH>(qp, kp);
+        }
+        return quad_sum(s);
+    };
+    if (qvalid) {
+        const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
+        const float s = qk(a.k + g, a.kl ? a.kl + g : nullptr);
         if (c == 0) SP[(w * J + 0) * a.NH + h] = s * a.scale;
     }
-    sweep_taps<CH, GMAX>(a, a.k, a.kl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const float* kf_) {
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < CH; ++e) s += qf[e] * kf_[e];
-        s = quad_sum(s);
+    sweep_taps<CH, GMAX>(a, a.k, a.kl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* khi, const bf16_t* klo) {
+        const float s = qk(khi, klo);
         if (c == 0) SP[(w * J + j) * a.NH + h] = s * a.scale;
     });
     __syncthreads();
@@ -232,11 +273,12 @@ __global__ __launch_bounds__(512) void s3_fwd_kernel(S3Args a) {
     }
     if (ry * a.W + 1 >= a.ntok) return;   // whole row beyond the sequence (uniform)
     float qf[CH];
+    uint32_t qp[CH / 2];
     if (qvalid) {
         const size_t g = ((size_t)b * a.ntok + i) * a.ld + h * DH + c * CH;
-        load_chunk<CH>(a.q + g, a.ql ? a.ql + g : nullptr, qf);
+        if (a.ql) load_chunk<CH>(a.q + g, a.ql + g, qf); else load_pk<CH>(a.q + g, qp);
     }
-    scores_softmax<DH, GMAX>(a, b, f, y, w, h, c, act, qvalid, qf, SP, st_hi, J);
+    scores_softmax<DH, GMAX>(a, b, f, y, w, h, c, act, qvalid, qf, qp, SP, st_hi, J);
     // talking heads: P'[g] = sum_h Wth[g][h] P[h] per (w, j), in place
     for (int item = t; item < a.W * J; item += blockDim.x) {
         float pv[8], out[8];
@@ -257,18 +299,24 @@ __global__ __launch_bounds__(512) void s3_fwd_kernel(S3Args a) {
     float of[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) of[e] = 0.f;
+    auto pv = [&](float pj, const bf16_t* vhi, const bf16_t* vlo) {
+        if (vlo) {
+            float vf[CH];
+            load_chunk<CH>(vhi, vlo, vf);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) of[e] += pj * vf[e];
+        } else {
+            uint32_t vp[CH / 2];
+            load_pk<CH>(vhi, vp);
+            axpy_pk<CH>(of, pj, vp);
+        }
+    };
     if (qvalid) {
-        float vf[CH];
         const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
-        load_chunk<CH>(a.v + g, a.vl ? a.vl + g : nullptr, vf);
-        const float pj = SP[(w * J + 0) * a.NH + h];
-#pragma unroll
-        for (int e = 0; e < CH; ++e) of[e] += pj * vf[e];
+        pv(SP[(w * J + 0) * a.NH + h], a.v + g, a.vl ? a.vl + g : nullptr);
     }
-    sweep_taps<CH, GMAX>(a, a.v, a.vl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const float* vf) {
-        const float pj = SP[(w * J + j) * a.NH + h];
-#pragma unroll
-        for (int e = 0; e < CH; ++e) of[e] += pj * vf[e];
+    sweep_taps<CH, GMAX>(a, a.v, a.vl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* vhi, const bf16_t* vlo) {
+        pv(SP[(w * J + j) * a.NH + h], vhi, vlo);
     });
     if (qvalid) {
         const size_t g = ((size_t)b * a.ntok + i) * a.ldo + h * DH + c * CH;
@@ -320,7 +368,14 @@ __global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
         const size_t gd = ((size_t)b * a.ntok + i) * a.lddo + h * DH + c * CH;
         load_chunk<CH>(a.dO + gd, a.dOl ? a.dOl + gd : nullptr, dof);
     }
-    scores_softmax<DH, GMAX>(a, b, f, y, w, h, c, act, qvalid, qf, SP, st_hi, J);
+    uint32_t qp[CH / 2], dop[CH / 2];            // packed bf16 copies for the dot2 path (bf16 operand mode)
+#pragma unroll
+    for (int e = 0; e < CH / 2; ++e) { qp[e] = 0; dop[e] = 0; }
+    if (qvalid && !a.kl) {
+        load_pk<CH>(a.q + ((size_t)b * a.ntok + i) * a.ld + h * DH + c * CH, qp);
+        load_pk<CH>(a.dO + ((size_t)b * a.ntok + i) * a.lddo + h * DH + c * CH, dop);
+    }
+    scores_softmax<DH, GMAX>(a, b, f, y, w, h, c, act, qvalid, qf, qp, SP, st_hi, J);
     // P' = mix(P) -> global (needed by bwd_kv); P stays in SP
     for (int item = t; item < a.W * J; item += blockDim.x) {
         const int wq = item / J, j = item % J;
@@ -342,21 +397,27 @@ __global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
     for (int e = t; e < nsp; e += blockDim.x) DP[e] = 0.f;
     __syncthreads();
     // dP'[w][j][g] = dO[w][g] . v_j[g]
-    if (qvalid) {
-        float vf[CH];
-        const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
-        load_chunk<CH>(a.v + g, a.vl ? a.vl + g : nullptr, vf);
+    auto dov = [&](const bf16_t* vhi, const bf16_t* vlo) {
         float s = 0.f;
+        if (vlo) {
+            float vf[CH];
+            load_chunk<CH>(vhi, vlo, vf);
 #pragma unroll
-        for (int e = 0; e < CH; ++e) s += dof[e] * vf[e];
-        s = quad_sum(s);
+            for (int e = 0; e < CH; ++e) s += dof[e] * vf[e];
+        } else {
+            uint32_t vp[CH / 2];
+            load_pk<CH>(vhi, vp);
+            s = dot_pk<CH>(dop, vp);
+        }
+        return quad_sum(s);
+    };
+    if (qvalid) {
+        const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
+        const float s = dov(a.v + g, a.vl ? a.vl + g : nullptr);
         if (c == 0) DP[(w * J + 0) * a.NH + h] = s;
     }
-    sweep_taps<CH, GMAX>(a, a.v, a.vl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const float* vf) {
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < CH; ++e) s += dof[e] * vf[e];
-        s = quad_sum(s);
+    sweep_taps<CH, GMAX>(a, a.v, a.vl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* vhi, const bf16_t* vlo) {
+        const float s = dov(vhi, vlo);
         if (c == 0) DP[(w * J + j) * a.NH + h] = s;
     });
     __syncthreads();
@@ -426,10 +487,18 @@ __global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
             v0c[e] = pm0 * dof[e];
         }
     }
-    sweep_taps<CH, GMAX>(a, a.k, a.kl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const float* kf_) {
+    sweep_taps<CH, GMAX>(a, a.k, a.kl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* khi, const bf16_t* klo) {
         const float dj = DP[(w * J + j) * a.NH + h];
+        if (klo) {
+            float kf_[CH];
+            load_chunk<CH>(khi, klo, kf_);
 #pragma unroll
-        for (int e = 0; e < CH; ++e) dqf[e] += dj * kf_[e];
+            for (int e = 0; e < CH; ++e) dqf[e] += dj * kf_[e];
+        } else {
+            uint32_t kp[CH / 2];
+            load_pk<CH>(khi, kp);
+            axpy_pk<CH>(dqf, dj, kp);
+        }
     });
     if (qvalid) {
 #pragma unroll
@@ -530,12 +599,20 @@ __global__ __launch_bounds__(512) void s3_bwd_kv_kernel(S3Args a) {
                 const int j = 1 + tp * a.kw + tc;
                 const size_t ci = (((size_t)b * nq + pq) * J + j) * a.NH + h;
                 const float dsv = a.ds[ci], pmv = a.pm[ci];
-                float qq[CH], dd[CH];
                 const int slot = ((wq * a.NH + h) * 4 + c) * CH;
-                load_chunk<CH>(sq_hi + slot, a.ql ? sq_lo + slot : nullptr, qq);
-                load_chunk<CH>(sd_hi + slot, a.dOl ? sd_lo + slot : nullptr, dd);
+                if (a.ql || a.dOl) {
+                    float qq[CH], dd[CH];
+                    load_chunk<CH>(sq_hi + slot, a.ql ? sq_lo + slot : nullptr, qq);
+                    load_chunk<CH>(sd_hi + slot, a.dOl ? sd_lo + slot : nullptr, dd);
 #pragma unroll
-                for (int e = 0; e < CH; ++e) { dkf[e] += dsv * qq[e]; dvf[e] += pmv * dd[e]; }
+                    for (int e = 0; e < CH; ++e) { dkf[e] += dsv * qq[e]; dvf[e] += pmv * dd[e]; }
+                } else {
+                    uint32_t qk2[CH / 2], dk2[CH / 2];
+                    load_pk<CH>(sq_hi + slot, qk2);
+                    load_pk<CH>(sd_hi + slot, dk2);
+                    axpy_pk<CH>(dkf, dsv, qk2);
+                    axpy_pk<CH>(dvf, pmv, dk2);
+                }
             }
         }
         tp = tn;
@@ -623,8 +700,9 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
     a.o = o; a.ol = o_lo; a.ldo = ldo; a.wth = w_th;
     const int J = g->kf * g->kh * g->kw + 1;
     if ((k_lo != nullptr) && (!q_lo || !v_lo)) return AMDNUWA_ERR_ARG;
-    // tuning key 3: 0 = stage the kh rows of a tap frame at once (needs kh <= KHMAX), 1 = one row per round
-    const bool slab = g->kh <= KHMAX && g_amdnuwa_tuning[3] == 0;
+    // tuning key 3: 0 = one key row per staging round (measured faster: 4 resident workgroups per CU),
+    //               1 = stage the kh rows of a tap frame at once (needs kh <= KHMAX)
+    const bool slab = g->kh <= KHMAX && g_amdnuwa_tuning[3] == 1;
     const size_t lds = (size_t)g->W * g->heads * g->dim_head * (k_lo ? 4 : 2) * (slab ? g->kh : 1) + (size_t)g->W * J * g->heads * 4;
     dim3 grid(g->B * g->F * g->H), block(block_threads(g));
 #define S3F(DH_, GM_)                                                                                             \

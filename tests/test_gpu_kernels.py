@@ -288,13 +288,15 @@ def test_sparse3dna_core(K, O, case, x3):
     g = K.s3_geom(B, n, shape, kern, dil, heads, dh)
     qkvp = to_bf_pair(qkv.detach().reshape(B * n, 3 * inner).to(DEV), x3)
     o = K.sparse3dna_fwd(g, qkvp, wth.detach().to(DEV))
-    tol_o = 3e-5 if x3 else 2 ** -8
+    # bf16 mode: the output is rounded to bf16 (2^-9) and the post-softmax probability of each tap enters the
+    # packed v_dot2 accumulation as a bf16 coefficient (another 2^-9 per term); parity mode is all-fp32
+    tol_o = 3e-5 if x3 else 2 ** -7
     tag = f'[{case},x3={x3}]'
     report('s3_fwd' + tag, (bf_value(o) if x3 else o.hi.float()).reshape(B, n, heads, dh), o_ref.detach(), tol_o)
     dqkv, dwth = K.sparse3dna_bwd(g, qkvp, wth.detach().to(DEV), to_bf_pair(do.reshape(B * n, inner).to(DEV), x3))
     gq = qkv.grad.reshape(B * n, 3 * inner)
     got = bf_value(dqkv) if x3 else dqkv.hi.float()
-    tol_g = 5e-5 if x3 else 2 ** -7
+    tol_g = 5e-5 if x3 else 2 ** -6
     for nm, sl in (('dq', slice(0, inner)), ('dk', slice(inner, 2 * inner)), ('dv', slice(2 * inner, 3 * inner))):
         if n > 1 or nm == 'dv':
             report(f's3_bwd_{nm}' + tag, got[:, sl], gq[:, sl], tol_g)
