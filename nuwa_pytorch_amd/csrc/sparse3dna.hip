@@ -40,15 +40,17 @@ struct S3Args {
 
 constexpr float NEG_MAX = -3.4028234663852886e38f;
 
+// hs = element stride between the 8-element halves of a chunk (8 = contiguous; the LDS stage keeps the two
+// 16-byte halves of every chunk in separate regions so that ds_read_b128 lanes are 16 bytes apart: no conflicts)
 template <int CH>
-__device__ __forceinline__ void load_chunk(const bf16_t* hi, const bf16_t* lo, float* f) {
+__device__ __forceinline__ void load_chunk(const bf16_t* hi, const bf16_t* lo, float* f, int hs = 8) {
 #pragma unroll
     for (int v8 = 0; v8 < CH / 8; ++v8) {
-        const uint4 u = *reinterpret_cast<const uint4*>(hi + v8 * 8);
+        const uint4 u = *reinterpret_cast<const uint4*>(hi + v8 * hs);
         f[v8 * 8 + 0] = lo_f(u.x); f[v8 * 8 + 1] = hi_f(u.x); f[v8 * 8 + 2] = lo_f(u.y); f[v8 * 8 + 3] = hi_f(u.y);
         f[v8 * 8 + 4] = lo_f(u.z); f[v8 * 8 + 5] = hi_f(u.z); f[v8 * 8 + 6] = lo_f(u.w); f[v8 * 8 + 7] = hi_f(u.w);
         if (lo) {
-            const uint4 l = *reinterpret_cast<const uint4*>(lo + v8 * 8);
+            const uint4 l = *reinterpret_cast<const uint4*>(lo + v8 * hs);
             f[v8 * 8 + 0] += lo_f(l.x); f[v8 * 8 + 1] += hi_f(l.x); f[v8 * 8 + 2] += lo_f(l.y); f[v8 * 8 + 3] += hi_f(l.y);
             f[v8 * 8 + 4] += lo_f(l.z); f[v8 * 8 + 5] += hi_f(l.z); f[v8 * 8 + 6] += lo_f(l.w); f[v8 * 8 + 7] += hi_f(l.w);
         }
@@ -85,10 +87,10 @@ __device__ __forceinline__ float quad_max(float v) {
 
 // packed bf16 arithmetic (bf16 operand mode): v_dot2_f32_bf16 multiplies two bf16 pairs and accumulates in fp32
 template <int CH>
-__device__ __forceinline__ void load_pk(const bf16_t* p, uint32_t* pk) {
+__device__ __forceinline__ void load_pk(const bf16_t* p, uint32_t* pk, int hs = 8) {
 #pragma unroll
     for (int v8 = 0; v8 < CH / 8; ++v8) {
-        const uint4 u = *reinterpret_cast<const uint4*>(p + v8 * 8);
+        const uint4 u = *reinterpret_cast<const uint4*>(p + v8 * hs);
         pk[v8 * 4 + 0] = u.x; pk[v8 * 4 + 1] = u.y; pk[v8 * 4 + 2] = u.z; pk[v8 * 4 + 3] = u.w;
     }
 }
@@ -113,91 +115,76 @@ __device__ __forceinline__ void axpy_pk(float* acc, float coef, const uint32_t* 
     }
 }
 
-// Sweep over all causal taps of one query row.  Key/value rows are staged in LDS `GMAX` tap planes at a
-// time (GMAX == KHMAX: the kh rows of one tap FRAME = a "slab"; GMAX == 1: one row), and the NEXT group is
-// fetched into registers while the current one is consumed, so the global-load latency overlaps the FMAs.
-// fn(j, hi, lo) is called for every valid tap slot j >= 1 of this thread's (query, head) with LDS pointers to
-// the staged bf16 chunk (hi, and lo or nullptr) of that tap's key/value.  Each active thread moves the chunk of its own (w, h, c).
-constexpr int KHMAX = 3;
+// Sweep over all causal taps of one query row.  One key/value grid row (all heads) is staged in LDS per
+// round; the NEXT valid row is fetched into registers while the current one is consumed.  The tap planes
+// (ta, tb) are enumerated incrementally (fr += df, yr += dh): no integer division on the scalar unit.
+// LDS image of a staged row: half v8 of the chunk of (w, h, c) lives at v8*HS + ((w*NH + h)*4 + c)*8
+// (HS = W*NH*32 elements), so consecutive lanes read consecutive 16-byte words (conflict-free ds_read_b128).
+// fn(j, hi, lo, hs) is called for every valid tap slot j >= 1 of this thread's (query, head).
+constexpr int KHMAX = 3;   // (kept for the launch code; slab staging was measured slower and removed)
 
-template <int CH, int GMAX, typename Fn>
+struct PlaneIt { int ta, tb, fr, yr; };
+
+template <int CH, typename Fn>
 __device__ __forceinline__ void sweep_taps(const S3Args& a, const bf16_t* src, const bf16_t* srcl, int b, int f, int y, int w,
                                            int h, int c, bool act, bool qvalid, bf16_t* st_hi, Fn&& fn) {
-    const int G = GMAX == 1 ? 1 : a.kh;                  // planes staged per round
-    const int ngroups = (a.kf * a.kh) / G;
-    const int slab = a.W * a.NH * CH * 4;                // elements per staged row
-    bf16_t* st_lo = st_hi + G * slab;
-    const int myslot = ((w * a.NH + h) * 4 + c) * CH;
-    uint4 rh[GMAX][CH / 8], rl[GMAX][CH / 8];
-    auto plane = [&](int t, int& fr, int& yr) {
-        const int ta = t / a.kh, tb = t - ta * a.kh;
-        fr = f - (a.kf - 1 - ta) * a.df;
-        yr = y - (a.kh - 1 - tb) * a.dh;
-        return fr >= 0 && yr >= 0;
-    };
-    auto next_group = [&](int g) {
-        for (; g < ngroups; ++g) {
-            bool ok = false;
-            for (int k = 0; k < G; ++k) { int fr, yr; ok |= plane(g * G + k, fr, yr); }
-            if (ok) break;
-        }
-        return g;
-    };
-    auto fetch = [&](int g) {
-#pragma unroll
-        for (int k = 0; k < GMAX; ++k) {
-            int fr = 0, yr = 0;
-            bool ok = act && k < G && plane(g * G + k, fr, yr);
-            size_t gi = 0;
-            if (ok) {
-                const int p = (fr * a.H + yr) * a.W + w;
-                ok = (1 + p) < a.ntok;
-                gi = ((size_t)b * a.ntok + 1 + p) * a.ld + h * (CH * 4) + c * CH;
-            }
-#pragma unroll
-            for (int v8 = 0; v8 < CH / 8; ++v8) {
-                rh[k][v8] = ok ? *reinterpret_cast<const uint4*>(src + gi + v8 * 8) : make_uint4(0, 0, 0, 0);
-                if (srcl) rl[k][v8] = ok ? *reinterpret_cast<const uint4*>(srcl + gi + v8 * 8) : make_uint4(0, 0, 0, 0);
-            }
+    const int HS = a.W * a.NH * 32;                      // elements per half image
+    bf16_t* st_lo = st_hi + (CH / 8) * HS;
+    const int myslot = ((w * a.NH + h) * 4 + c) * 8;
+    const int yr0 = y - (a.kh - 1) * a.dh;
+    uint4 rh[CH / 8], rl[CH / 8];
+    auto seek = [&](PlaneIt& p) {                        // advance to a valid plane (or ta == kf)
+        while (p.ta < a.kf && !(p.fr >= 0 && p.yr >= 0)) {
+            ++p.tb; p.yr += a.dh;
+            if (p.tb == a.kh) { p.tb = 0; p.yr = yr0; ++p.ta; p.fr += a.df; }
         }
     };
-    int g = next_group(0);
-    if (g < ngroups) fetch(g);
-    while (g < ngroups) {
-        __syncthreads();                                 // previous group fully consumed
+    auto step = [&](PlaneIt& p) {
+        ++p.tb; p.yr += a.dh;
+        if (p.tb == a.kh) { p.tb = 0; p.yr = yr0; ++p.ta; p.fr += a.df; }
+        seek(p);
+    };
+    auto fetch = [&](const PlaneIt& p) {
+        const int pos = (p.fr * a.H + p.yr) * a.W + w;
+        const bool ok = act && (1 + pos) < a.ntok;
+        const size_t gi = ((size_t)b * a.ntok + 1 + pos) * a.ld + h * (CH * 4) + c * CH;
+#pragma unroll
+        for (int v8 = 0; v8 < CH / 8; ++v8) {
+            rh[v8] = ok ? *reinterpret_cast<const uint4*>(src + gi + v8 * 8) : make_uint4(0, 0, 0, 0);
+            if (srcl) rl[v8] = ok ? *reinterpret_cast<const uint4*>(srcl + gi + v8 * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    PlaneIt cur{0, 0, f - (a.kf - 1) * a.df, yr0};
+    seek(cur);
+    if (cur.ta < a.kf) fetch(cur);
+    while (cur.ta < a.kf) {
+        __syncthreads();                                 // previous row fully consumed
         if (act) {
 #pragma unroll
-            for (int k = 0; k < GMAX; ++k)
-                if (k < G) {
-#pragma unroll
-                    for (int v8 = 0; v8 < CH / 8; ++v8) {
-                        *reinterpret_cast<uint4*>(st_hi + k * slab + myslot + v8 * 8) = rh[k][v8];
-                        if (srcl) *reinterpret_cast<uint4*>(st_lo + k * slab + myslot + v8 * 8) = rl[k][v8];
-                    }
-                }
-        }
-        __syncthreads();
-        const int gn = next_group(g + 1);
-        if (gn < ngroups) fetch(gn);                     // in flight during the compute below
-        if (qvalid) {
-            for (int k = 0; k < G; ++k) {
-                int fr, yr;
-                const int t = g * G + k;
-                if (!plane(t, fr, yr)) continue;
-                for (int tc = 0; tc < a.kw; ++tc) {
-                    const int wr = w - (a.kw - 1 - tc) * a.dw;
-                    if (wr < 0) continue;
-                    const int slot = k * slab + ((wr * a.NH + h) * 4 + c) * CH;
-                    fn(1 + t * a.kw + tc, st_hi + slot, srcl ? st_lo + slot : nullptr);
-                }
+            for (int v8 = 0; v8 < CH / 8; ++v8) {
+                *reinterpret_cast<uint4*>(st_hi + v8 * HS + myslot) = rh[v8];
+                if (srcl) *reinterpret_cast<uint4*>(st_lo + v8 * HS + myslot) = rl[v8];
             }
         }
-        g = gn;
+        __syncthreads();
+        PlaneIt nxt = cur;
+        step(nxt);
+        if (nxt.ta < a.kf) fetch(nxt);                   // in flight during the compute below
+        if (qvalid) {
+            const int jb = 1 + (cur.ta * a.kh + cur.tb) * a.kw;
+            int wr = w - (a.kw - 1) * a.dw;
+            for (int tc = 0; tc < a.kw; ++tc, wr += a.dw) {
+                if (wr < 0) continue;
+                const int slot = ((wr * a.NH + h) * 4 + c) * 8;
+                fn(jb + tc, st_hi + slot, srcl ? st_lo + slot : nullptr, HS);
+            }
+        }
+        cur = nxt;
     }
 }
 
 // scores + softmax for one query row: fills SP[(w*J + j)*NH + h] with P (fp32).  Shared by fwd and bwd_q.
-template <int DH, int GMAX>
+template <int DH, bool LO>
 __device__ __forceinline__ void scores_softmax(const S3Args& a, int b, int f, int y, int w, int h, int c, bool act, bool qvalid,
                                                const float* qf, const uint32_t* qp, float* SP, bf16_t* st_hi, int J) {
     constexpr int CH = DH / 4;
@@ -205,27 +192,27 @@ __device__ __forceinline__ void scores_softmax(const S3Args& a, int b, int f, in
     for (int e = t; e < a.W * J * a.NH; e += nt) SP[e] = NEG_MAX;
     __syncthreads();
     // <bos> key: slot j = 0
-    auto qk = [&](const bf16_t* khi, const bf16_t* klo) {
+    auto qk = [&](const bf16_t* khi, const bf16_t* klo, int hs) {
         float s = 0.f;
-        if (klo) {
+        if (LO) {
             float kf_[CH];
-            load_chunk<CH>(khi, klo, kf_);
+            load_chunk<CH>(khi, klo, kf_, hs);
 #pragma unroll
             for (int e = 0; e < CH; ++e) s += qf[e] * kf_[e];
         } else {
             uint32_t kp[CH / 2];
-            load_pk<CH>(khi, kp);
+            load_pk<CH>(khi, kp, hs);
             s = dot_pk<CH>(qp, kp);
         }
         return quad_sum(s);
     };
     if (qvalid) {
         const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
-        const float s = qk(a.k + g, a.kl ? a.kl + g : nullptr);
+        const float s = qk(a.k + g, a.kl ? a.kl + g : nullptr, 8);
         if (c == 0) SP[(w * J + 0) * a.NH + h] = s * a.scale;
     }
-    sweep_taps<CH, GMAX>(a, a.k, a.kl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* khi, const bf16_t* klo) {
-        const float s = qk(khi, klo);
+    sweep_taps<CH>(a, a.k, a.kl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* khi, const bf16_t* klo, int hs) {
+        const float s = qk(khi, klo, hs);
         if (c == 0) SP[(w * J + j) * a.NH + h] = s * a.scale;
     });
     __syncthreads();
@@ -246,12 +233,12 @@ __device__ __forceinline__ void scores_softmax(const S3Args& a, int b, int f, in
     __syncthreads();
 }
 
-template <int DH, int GMAX>
-__global__ __launch_bounds__(512) void s3_fwd_kernel(S3Args a) {
+template <int DH, bool LO>
+__global__ __launch_bounds__(512, 4) void s3_fwd_kernel(S3Args a) {
     constexpr int CH = DH / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int J = a.kf * a.kh * a.kw + 1;
-    const int stage_elems = a.W * a.NH * DH * (GMAX == 1 ? 1 : a.kh);
+    const int stage_elems = a.W * a.NH * DH;
     bf16_t* st_hi = reinterpret_cast<bf16_t*>(smem);
     float* SP = reinterpret_cast<float*>(smem + (size_t)stage_elems * (a.kl ? 4 : 2));
     __shared__ float wsh[64];
@@ -276,9 +263,9 @@ __global__ __launch_bounds__(512) void s3_fwd_kernel(S3Args a) {
     uint32_t qp[CH / 2];
     if (qvalid) {
         const size_t g = ((size_t)b * a.ntok + i) * a.ld + h * DH + c * CH;
-        if (a.ql) load_chunk<CH>(a.q + g, a.ql + g, qf); else load_pk<CH>(a.q + g, qp);
+        if (LO) load_chunk<CH>(a.q + g, a.ql ? a.ql + g : nullptr, qf); else load_pk<CH>(a.q + g, qp);
     }
-    scores_softmax<DH, GMAX>(a, b, f, y, w, h, c, act, qvalid, qf, qp, SP, st_hi, J);
+    scores_softmax<DH, LO>(a, b, f, y, w, h, c, act, qvalid, qf, qp, SP, st_hi, J);
     // talking heads: P'[g] = sum_h Wth[g][h] P[h] per (w, j), in place
     for (int item = t; item < a.W * J; item += blockDim.x) {
         float pv[8], out[8];
@@ -299,24 +286,24 @@ __global__ __launch_bounds__(512) void s3_fwd_kernel(S3Args a) {
     float of[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) of[e] = 0.f;
-    auto pv = [&](float pj, const bf16_t* vhi, const bf16_t* vlo) {
-        if (vlo) {
+    auto pv = [&](float pj, const bf16_t* vhi, const bf16_t* vlo, int hs) {
+        if (LO) {
             float vf[CH];
-            load_chunk<CH>(vhi, vlo, vf);
+            load_chunk<CH>(vhi, vlo, vf, hs);
 #pragma unroll
             for (int e = 0; e < CH; ++e) of[e] += pj * vf[e];
         } else {
             uint32_t vp[CH / 2];
-            load_pk<CH>(vhi, vp);
+            load_pk<CH>(vhi, vp, hs);
             axpy_pk<CH>(of, pj, vp);
         }
     };
     if (qvalid) {
         const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
-        pv(SP[(w * J + 0) * a.NH + h], a.v + g, a.vl ? a.vl + g : nullptr);
+        pv(SP[(w * J + 0) * a.NH + h], a.v + g, a.vl ? a.vl + g : nullptr, 8);
     }
-    sweep_taps<CH, GMAX>(a, a.v, a.vl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* vhi, const bf16_t* vlo) {
-        pv(SP[(w * J + j) * a.NH + h], vhi, vlo);
+    sweep_taps<CH>(a, a.v, a.vl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* vhi, const bf16_t* vlo, int hs) {
+        pv(SP[(w * J + j) * a.NH + h], vhi, vlo, hs);
     });
     if (qvalid) {
         const size_t g = ((size_t)b * a.ntok + i) * a.ldo + h * DH + c * CH;
@@ -324,12 +311,12 @@ __global__ __launch_bounds__(512) void s3_fwd_kernel(S3Args a) {
     }
 }
 
-template <int DH, int GMAX>
-__global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
+template <int DH, bool LO>
+__global__ __launch_bounds__(512, 4) void s3_bwd_q_kernel(S3Args a) {
     constexpr int CH = DH / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int J = a.kf * a.kh * a.kw + 1;
-    const int stage_elems = a.W * a.NH * DH * (GMAX == 1 ? 1 : a.kh);
+    const int stage_elems = a.W * a.NH * DH;
     const int nsp = a.W * J * a.NH;
     bf16_t* st_hi = reinterpret_cast<bf16_t*>(smem);
     float* SP = reinterpret_cast<float*>(smem + (size_t)stage_elems * (a.kl ? 4 : 2));   // P, later unchanged
@@ -362,20 +349,21 @@ __global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
     float qf[CH], dof[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) { qf[e] = 0.f; dof[e] = 0.f; }
-    if (qvalid) {
-        const size_t g = ((size_t)b * a.ntok + i) * a.ld + h * DH + c * CH;
-        load_chunk<CH>(a.q + g, a.ql ? a.ql + g : nullptr, qf);
-        const size_t gd = ((size_t)b * a.ntok + i) * a.lddo + h * DH + c * CH;
-        load_chunk<CH>(a.dO + gd, a.dOl ? a.dOl + gd : nullptr, dof);
-    }
-    uint32_t qp[CH / 2], dop[CH / 2];            // packed bf16 copies for the dot2 path (bf16 operand mode)
+    uint32_t qp[CH / 2], dop[CH / 2];            // packed bf16 q / dO for the dot2 path (bf16 operand mode)
 #pragma unroll
     for (int e = 0; e < CH / 2; ++e) { qp[e] = 0; dop[e] = 0; }
-    if (qvalid && !a.kl) {
-        load_pk<CH>(a.q + ((size_t)b * a.ntok + i) * a.ld + h * DH + c * CH, qp);
-        load_pk<CH>(a.dO + ((size_t)b * a.ntok + i) * a.lddo + h * DH + c * CH, dop);
+    if (qvalid) {
+        const size_t g = ((size_t)b * a.ntok + i) * a.ld + h * DH + c * CH;
+        const size_t gd = ((size_t)b * a.ntok + i) * a.lddo + h * DH + c * CH;
+        if (LO) {
+            load_chunk<CH>(a.q + g, a.ql ? a.ql + g : nullptr, qf);
+            load_chunk<CH>(a.dO + gd, a.dOl ? a.dOl + gd : nullptr, dof);
+        } else {
+            load_pk<CH>(a.q + g, qp);
+            load_pk<CH>(a.dO + gd, dop);
+        }
     }
-    scores_softmax<DH, GMAX>(a, b, f, y, w, h, c, act, qvalid, qf, qp, SP, st_hi, J);
+    scores_softmax<DH, LO>(a, b, f, y, w, h, c, act, qvalid, qf, qp, SP, st_hi, J);
     // P' = mix(P) -> global (needed by bwd_kv); P stays in SP
     for (int item = t; item < a.W * J; item += blockDim.x) {
         const int wq = item / J, j = item % J;
@@ -397,27 +385,27 @@ __global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
     for (int e = t; e < nsp; e += blockDim.x) DP[e] = 0.f;
     __syncthreads();
     // dP'[w][j][g] = dO[w][g] . v_j[g]
-    auto dov = [&](const bf16_t* vhi, const bf16_t* vlo) {
+    auto dov = [&](const bf16_t* vhi, const bf16_t* vlo, int hs) {
         float s = 0.f;
-        if (vlo) {
+        if (LO) {
             float vf[CH];
-            load_chunk<CH>(vhi, vlo, vf);
+            load_chunk<CH>(vhi, vlo, vf, hs);
 #pragma unroll
             for (int e = 0; e < CH; ++e) s += dof[e] * vf[e];
         } else {
             uint32_t vp[CH / 2];
-            load_pk<CH>(vhi, vp);
+            load_pk<CH>(vhi, vp, hs);
             s = dot_pk<CH>(dop, vp);
         }
         return quad_sum(s);
     };
     if (qvalid) {
         const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
-        const float s = dov(a.v + g, a.vl ? a.vl + g : nullptr);
+        const float s = dov(a.v + g, a.vl ? a.vl + g : nullptr, 8);
         if (c == 0) DP[(w * J + 0) * a.NH + h] = s;
     }
-    sweep_taps<CH, GMAX>(a, a.v, a.vl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* vhi, const bf16_t* vlo) {
-        const float s = dov(vhi, vlo);
+    sweep_taps<CH>(a, a.v, a.vl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* vhi, const bf16_t* vlo, int hs) {
+        const float s = dov(vhi, vlo, hs);
         if (c == 0) DP[(w * J + j) * a.NH + h] = s;
     });
     __syncthreads();
@@ -482,21 +470,23 @@ __global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
         for (int hh = 0; hh < a.NH; ++hh) pm0 += wsh[h * a.NH + hh] * SP[(w * J + 0) * a.NH + hh];
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
+            const float qe = LO ? qf[e] : ((e & 1) ? hi_f(qp[e >> 1]) : lo_f(qp[e >> 1]));
+            const float de = LO ? dof[e] : ((e & 1) ? hi_f(dop[e >> 1]) : lo_f(dop[e >> 1]));
             dqf[e] += d0 * kf_[e];
-            k0c[e] = a.scale * d0 * qf[e];
-            v0c[e] = pm0 * dof[e];
+            k0c[e] = a.scale * d0 * qe;
+            v0c[e] = pm0 * de;
         }
     }
-    sweep_taps<CH, GMAX>(a, a.k, a.kl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* khi, const bf16_t* klo) {
+    sweep_taps<CH>(a, a.k, a.kl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* khi, const bf16_t* klo, int hs) {
         const float dj = DP[(w * J + j) * a.NH + h];
-        if (klo) {
+        if (LO) {
             float kf_[CH];
-            load_chunk<CH>(khi, klo, kf_);
+            load_chunk<CH>(khi, klo, kf_, hs);
 #pragma unroll
             for (int e = 0; e < CH; ++e) dqf[e] += dj * kf_[e];
         } else {
             uint32_t kp[CH / 2];
-            load_pk<CH>(khi, kp);
+            load_pk<CH>(khi, kp, hs);
             axpy_pk<CH>(dqf, dj, kp);
         }
     });
@@ -525,8 +515,8 @@ __global__ __launch_bounds__(512) void s3_bwd_q_kernel(S3Args a) {
     }
 }
 
-template <int DH>
-__global__ __launch_bounds__(512) void s3_bwd_kv_kernel(S3Args a) {
+template <int DH, bool LO>
+__global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
     constexpr int CH = DH / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int J = a.kf * a.kh * a.kw + 1;
@@ -571,7 +561,8 @@ __global__ __launch_bounds__(512) void s3_bwd_kv_kernel(S3Args a) {
             if (a.dOl) rdl[v8] = ok ? *reinterpret_cast<const uint4*>(a.dOl + gd + v8 * 8) : make_uint4(0, 0, 0, 0);
         }
     };
-    const int myslot = ((w * a.NH + h) * 4 + c) * CH;
+    const int HS = a.W * a.NH * 32;               // half-split LDS image (see sweep_taps): conflict-free b128 reads
+    const int myslot = ((w * a.NH + h) * 4 + c) * 8;
     int tp = next_plane(0);
     if (tp < nplanes) fetch(tp);
     while (tp < nplanes) {
@@ -579,10 +570,10 @@ __global__ __launch_bounds__(512) void s3_bwd_kv_kernel(S3Args a) {
         if (act) {
 #pragma unroll
             for (int v8 = 0; v8 < CH / 8; ++v8) {
-                *reinterpret_cast<uint4*>(sq_hi + myslot + v8 * 8) = rq[v8];
-                *reinterpret_cast<uint4*>(sd_hi + myslot + v8 * 8) = rd[v8];
-                if (a.ql) *reinterpret_cast<uint4*>(sq_lo + myslot + v8 * 8) = rql[v8];
-                if (a.dOl) *reinterpret_cast<uint4*>(sd_lo + myslot + v8 * 8) = rdl[v8];
+                *reinterpret_cast<uint4*>(sq_hi + myslot + v8 * HS) = rq[v8];
+                *reinterpret_cast<uint4*>(sd_hi + myslot + v8 * HS) = rd[v8];
+                if (a.ql) *reinterpret_cast<uint4*>(sq_lo + myslot + v8 * HS) = rql[v8];
+                if (a.dOl) *reinterpret_cast<uint4*>(sd_lo + myslot + v8 * HS) = rdl[v8];
             }
         }
         __syncthreads();
@@ -599,17 +590,17 @@ __global__ __launch_bounds__(512) void s3_bwd_kv_kernel(S3Args a) {
                 const int j = 1 + tp * a.kw + tc;
                 const size_t ci = (((size_t)b * nq + pq) * J + j) * a.NH + h;
                 const float dsv = a.ds[ci], pmv = a.pm[ci];
-                const int slot = ((wq * a.NH + h) * 4 + c) * CH;
-                if (a.ql || a.dOl) {
+                const int slot = ((wq * a.NH + h) * 4 + c) * 8;
+                if (LO) {
                     float qq[CH], dd[CH];
-                    load_chunk<CH>(sq_hi + slot, a.ql ? sq_lo + slot : nullptr, qq);
-                    load_chunk<CH>(sd_hi + slot, a.dOl ? sd_lo + slot : nullptr, dd);
+                    load_chunk<CH>(sq_hi + slot, a.ql ? sq_lo + slot : nullptr, qq, HS);
+                    load_chunk<CH>(sd_hi + slot, a.dOl ? sd_lo + slot : nullptr, dd, HS);
 #pragma unroll
                     for (int e = 0; e < CH; ++e) { dkf[e] += dsv * qq[e]; dvf[e] += pmv * dd[e]; }
                 } else {
                     uint32_t qk2[CH / 2], dk2[CH / 2];
-                    load_pk<CH>(sq_hi + slot, qk2);
-                    load_pk<CH>(sd_hi + slot, dk2);
+                    load_pk<CH>(sq_hi + slot, qk2, HS);
+                    load_pk<CH>(sd_hi + slot, dk2, HS);
                     axpy_pk<CH>(dkf, dsv, qk2);
                     axpy_pk<CH>(dvf, pmv, dk2);
                 }
@@ -702,16 +693,17 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
     if ((k_lo != nullptr) && (!q_lo || !v_lo)) return AMDNUWA_ERR_ARG;
     // tuning key 3: 0 = one key row per staging round (measured faster: 4 resident workgroups per CU),
     //               1 = stage the kh rows of a tap frame at once (needs kh <= KHMAX)
-    const bool slab = g->kh <= KHMAX && g_amdnuwa_tuning[3] == 1;
+    const bool slab = false;   // (slab staging of a whole tap frame measured slower than row staging: retired)
     const size_t lds = (size_t)g->W * g->heads * g->dim_head * (k_lo ? 4 : 2) * (slab ? g->kh : 1) + (size_t)g->W * J * g->heads * 4;
     dim3 grid(g->B * g->F * g->H), block(block_threads(g));
-#define S3F(DH_, GM_)                                                                                             \
+#define S3F(DH_, LO_)                                                                                             \
     do {                                                                                                          \
-        (void)hipFuncSetAttribute((const void*)s3_fwd_kernel<DH_, GM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((s3_fwd_kernel<DH_, GM_>), grid, block, lds, stream, a);                               \
+        (void)hipFuncSetAttribute((const void*)s3_fwd_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((s3_fwd_kernel<DH_, LO_>), grid, block, lds, stream, a);                               \
     } while (0)
-    if (g->dim_head == 64) { if (slab) S3F(64, KHMAX); else S3F(64, 1); }
-    else { if (slab) S3F(32, KHMAX); else S3F(32, 1); }
+    const bool lo_mode = k_lo != nullptr;
+    if (g->dim_head == 64) { if (lo_mode) S3F(64, true); else S3F(64, false); }
+    else { if (lo_mode) S3F(32, true); else S3F(32, false); }
 #undef S3F
     LAUNCH_CHECK();
     return AMDNUWA_OK;
@@ -756,26 +748,23 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     const bool has_lo = k_lo != nullptr;
     if (has_lo && (!q_lo || !v_lo)) return AMDNUWA_ERR_ARG;
     // tuning key 4: 1 = slab staging in bwd_q too (more LDS -> one workgroup per CU), 0 = one row per round
-    const bool slab = g->kh <= KHMAX && g_amdnuwa_tuning[4] == 1;
+    const bool slab = false;
     const size_t lds_q = (size_t)g->W * g->heads * g->dim_head * (has_lo ? 4 : 2) * (slab ? g->kh : 1) + (spdp + 8 * 64) * 4;
     const size_t lds_kv = (size_t)g->W * g->heads * g->dim_head * 8;
     dim3 grid((unsigned)rows), block(block_threads(g));
-#define S3B(DH_, GM_)                                                                                             \
+#define S3B(DH_, LO_)                                                                                             \
     do {                                                                                                          \
-        (void)hipFuncSetAttribute((const void*)s3_bwd_q_kernel<DH_, GM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
-        hipLaunchKernelGGL((s3_bwd_q_kernel<DH_, GM_>), grid, block, lds_q, stream, a);                           \
+        (void)hipFuncSetAttribute((const void*)s3_bwd_q_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
+        hipLaunchKernelGGL((s3_bwd_q_kernel<DH_, LO_>), grid, block, lds_q, stream, a);                           \
+        LAUNCH_CHECK();                                                                                           \
+        (void)hipFuncSetAttribute((const void*)s3_bwd_kv_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv); \
+        hipLaunchKernelGGL((s3_bwd_kv_kernel<DH_, LO_>), grid, block, lds_kv, stream, a);                         \
     } while (0)
-    if (g->dim_head == 64) { if (slab) S3B(64, KHMAX); else S3B(64, 1); }
-    else { if (slab) S3B(32, KHMAX); else S3B(32, 1); }
+    const bool lo_mode = has_lo || dO_lo != nullptr;
+    if (lo_mode && (!has_lo || !dO_lo)) return AMDNUWA_ERR_ARG;     // parity mode needs lo parts for q/k/v AND dO
+    if (g->dim_head == 64) { if (lo_mode) S3B(64, true); else S3B(64, false); }
+    else { if (lo_mode) S3B(32, true); else S3B(32, false); }
 #undef S3B
-    LAUNCH_CHECK();
-    if (g->dim_head == 64) {
-        (void)hipFuncSetAttribute((const void*)s3_bwd_kv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-        hipLaunchKernelGGL(s3_bwd_kv_kernel<64>, grid, block, lds_kv, stream, a);
-    } else {
-        (void)hipFuncSetAttribute((const void*)s3_bwd_kv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-        hipLaunchKernelGGL(s3_bwd_kv_kernel<32>, grid, block, lds_kv, stream, a);
-    }
     LAUNCH_CHECK();
     hipLaunchKernelGGL(s3_bwd_fin_kernel, dim3(g->B * (((int)inner + 63) / 64) + 1), dim3(1024), 0, stream, a, g->dim_head);
     LAUNCH_CHECK();
