@@ -179,6 +179,23 @@ int amdnuwa_xattn_unpack(const amdnuwa_xattn_geom* g, const float* dKp, const fl
                          uint16_t* dkv_lo, int ldkv, float* dnull_k, float* dnull_v, int accumulate,
                          amdnuwa_stream stream);
 
+/* ---- frozen VQGanVAE tokenizer (VQGanVAE.get_video_indices -> encode, reference vqgan_vae.py:431-435, 452-458), exact fp32 ---- */
+typedef struct {
+    int N, Cin, H, W, Cout, KH, KW, stride, pad;
+    int Ho, Wo;             /* must equal (H + 2*pad - KH) / stride + 1 etc. */
+    int leaky;              /* fuse LeakyReLU(0.1) (vqgan_vae.py:94-95) */
+} amdnuwa_conv_desc;
+/* nn.Conv2d forward, NCHW fp32, square stride/padding (replaces the encoders' convs, vqgan_vae.py:352-365, 228-242) */
+int amdnuwa_conv2d_fwd(const amdnuwa_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                       amdnuwa_stream stream);
+/* nn.GroupNorm(groups, C) [+ LeakyReLU(0.1)] on [N][C][HW] fp32 (ResBlock, vqgan_vae.py:233-237) */
+int amdnuwa_groupnorm_fwd(const float* x, const float* w, const float* b, float* y, int N, int C, int HW, int groups,
+                          float eps, int leaky, amdnuwa_stream stream);
+/* cosine-similarity code lookup: indices[r] = argmax_c <l2norm(x[r]), l2norm(codebook[c])>, lowest index on exact ties
+ * (eval path of vector_quantize_pytorch.VectorQuantize as called at vqgan_vae.py:368-378, 433); best_sim optional */
+int amdnuwa_vq_argmax(const float* x, const float* codebook, long long* indices, float* best_sim, long long R,
+                      int n_codes, int code_dim, amdnuwa_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,254 @@
+// Frozen VQGanVAE tokenizer path (VQGanVAE.get_video_indices -> encode, vq.py:431-435, 452-458) in exact fp32.
+//
+// VQ code indices must be bit-exact against the reference, so nothing here drops below fp32: the conv stack
+// and the cosine-similarity search run on the f32-input MFMA (v_mfma_f32_32x32x2_f32: bitwise an fp32 fmaf
+// chain, 157 TFLOP/s peak = the fp32 vector rate, but it leaves the VALU free for the im2col addressing).
+//
+//   conv2d_fwd  : implicit-GEMM convolution  Y[n][co][oy][ox] = b[co] + sum_{ci,ky,kx} W[co][ci][ky][kx] X[n][ci][iy][ix]
+//                 (encoders: 5x5 pad 2; 4x4 stride 2 pad 1 + LeakyReLU(0.1); ResBlock 3x3 / 1x1 -- vq.py:352-365, 228-242)
+//                 GEMM view: M = Cout, N = batch*Ho*Wo pixels, K = Cin*KH*KW; 128x128 tile, K-step 16, 4 waves of 64x64.
+//   groupnorm   : nn.GroupNorm(16, C) (+ LeakyReLU) of ResBlock (vq.py:233-237)
+//   vq_argmax   : idx = argmax_c <l2norm(x), l2norm(codebook[c])>  with the LOWEST index on exact ties
+//                 (restated eval path of vector_quantize_pytorch -- PARITY UNPINNED)
+#include "common.h"
+#include "../../include/amdnuwa.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct ConvArgs {
+    const float *x, *w, *bias;
+    float* y;
+    int N, Cin, H, W, Cout, KH, KW, stride, pad, Ho, Wo, leaky;
+    float slope;
+};
+
+// C/D layout of v_mfma_f32_32x32x2_f32: acc[reg] -> row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31
+// A operand: lane holds A[row = lane & 31][k = lane >> 5];  B operand: lane holds B[k = lane >> 5][col = lane & 31]
+constexpr int CT = 128, CK = 16;
+
+__global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a) {
+    __shared__ float As[CK][CT + 4];     // weights  [k][co]   (+4 pad: conflict-free column reads)
+    __shared__ float Bs[CK][CT + 4];     // im2col   [k][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int K = a.Cin * a.KH * a.KW;
+    const long long NP = (long long)a.N * a.Ho * a.Wo;
+    const int co0 = blockIdx.y * CT;
+    const long long p0 = (long long)blockIdx.x * CT;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // loader: 2048 elements per operand tile / 256 threads = 8 each: thread -> column (tid & 127), k rows (tid >> 7) + 2*i
+    const int lc = tid & 127, lk = tid >> 7;
+    const long long pix = p0 + lc;
+    const bool pok = pix < NP;
+    int pn = 0, oy = 0, ox = 0;
+    if (pok) { pn = (int)(pix / (a.Ho * a.Wo)); const int rem = (int)(pix % (a.Ho * a.Wo)); oy = rem / a.Wo; ox = rem % a.Wo; }
+    const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+    const int co = co0 + lc;
+    for (int k0 = 0; k0 < K; k0 += CK) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kk = lk + 2 * i, k = k0 + kk;
+            float wv = 0.f, xv = 0.f;
+            if (k < K) {
+                if (co < a.Cout) wv = a.w[(size_t)co * K + k];
+                if (pok) {
+                    const int ci = k / (a.KH * a.KW), r = k % (a.KH * a.KW), ky = r / a.KW, kx = r % a.KW;
+                    const int iy = iy0 + ky, ix = ix0 + kx;
+                    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) xv = a.x[(((size_t)pn * a.Cin + ci) * a.H + iy) * a.W + ix];
+                }
+            }
+            As[kk][lc] = wv;
+            Bs[kk][lc] = xv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < CK; kk += 2) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[kk + (lane >> 5)][wm * 64 + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[kk + (lane >> 5)][wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long px = p0 + wn * 64 + j * 32 + (lane & 31);
+            if (px >= NP) continue;
+            const int n = (int)(px / (a.Ho * a.Wo)), rem = (int)(px % (a.Ho * a.Wo));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (c >= a.Cout) continue;
+                float v = acc[i][j][r] + (a.bias ? a.bias[c] : 0.f);
+                if (a.leaky) v = v > 0.f ? v : v * a.slope;
+                a.y[((size_t)n * a.Cout + c) * a.Ho * a.Wo + rem] = v;
+            }
+        }
+}
+
+// GroupNorm over (C/G, H, W) per (n, group), optional LeakyReLU; one block per (n, group)
+__global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y, int C, int HW, int G,
+                                                        float eps, int leaky, float slope) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G;
+    const size_t base = ((size_t)n * C + (size_t)g * cpg) * HW;
+    const int cnt = cpg * HW;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < cnt; e += 256) s += x[base + e];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / cnt;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < cnt; e += 256) { const float d = x[base + e] - mean; q += d * d; }
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = q;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / cnt + eps);
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const int c = g * cpg + e / HW;
+        float v = (x[base + e] - mean) * rstd * w[c] + b[c];
+        if (leaky) v = v > 0.f ? v : v * slope;
+        y[base + e] = v;
+    }
+}
+
+// rows of x [R][Dc] and codebook [Cn][Dc] are l2-normalised (F.normalize: v / max(||v||, 1e-12)), then
+// idx[r] = argmax_c <xn[r], cn[c]>.  One workgroup = 64 rows; codes are scanned in increasing order in tiles of
+// 64 with a strict '>' so the LOWEST index wins exact ties.  sims via the f32 MFMA (64x64 tile per wave pair).
+__global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                        long long* __restrict__ idx, float* __restrict__ best_sim,
+                                                        long long R, int Cn, int Dc) {
+    extern __shared__ float sm[];
+    float* Xs = sm;                          // [64][Dc + 1] normalised rows
+    float* Cs = Xs + 64 * (Dc + 1);          // [64][Dc + 1] normalised code tile
+    float* bv = Cs + 64 * (Dc + 1);          // [4][64] per-wave best value
+    int* bi = reinterpret_cast<int*>(bv + 256);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long r0 = (long long)blockIdx.x * 64;
+    // load + normalise the 64 rows (wave w handles rows w, w+4, ...)
+    for (int rr = wave; rr < 64; rr += 4) {
+        const long long r = r0 + rr;
+        float ss = 0.f;
+        for (int d = lane; d < Dc; d += 64) { const float v = r < R ? x[r * Dc + d] : 0.f; Xs[rr * (Dc + 1) + d] = v; ss += v * v; }
+        ss = wave_sum(ss);
+        const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+        for (int d = lane; d < Dc; d += 64) Xs[rr * (Dc + 1) + d] *= inv;
+    }
+    // each wave owns a 32x32 block of the 64x64 sim tile: rows 32*(wave>>1), cols 32*(wave&1)
+    const int rb = (wave >> 1) * 32, cbk = (wave & 1) * 32;
+    float best[16];
+    int besti[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { best[r] = -3.0e38f; besti[r] = 0; }
+    for (int c0 = 0; c0 < Cn; c0 += 64) {
+        __syncthreads();
+        for (int cc = wave; cc < 64; cc += 4) {
+            const int cidx = c0 + cc;
+            float ss = 0.f;
+            for (int d = lane; d < Dc; d += 64) { const float v = cidx < Cn ? cb[(size_t)cidx * Dc + d] : 0.f; Cs[cc * (Dc + 1) + d] = v; ss += v * v; }
+            ss = wave_sum(ss);
+            const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+            for (int d = lane; d < Dc; d += 64) Cs[cc * (Dc + 1) + d] *= inv;
+        }
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int k = 0; k < Dc; k += 2) {
+            const float af = Xs[(rb + (lane & 31)) * (Dc + 1) + k + (lane >> 5)];
+            const float bf = Cs[(cbk + (lane & 31)) * (Dc + 1) + k + (lane >> 5)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+        }
+        // acc[reg]: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) of the block, col = lane & 31 -> code c0 + cbk + col
+        const int code = c0 + cbk + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (code < Cn && acc[r] > best[r]) { best[r] = acc[r]; besti[r] = code; }
+    }
+    // reduce over the 32 lanes sharing a row (different codes): max value, lowest index on ties
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = best[r];
+        int ix = besti[r];
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const float ov = __shfl_xor(v, o, 64);
+            const int oi = __shfl_xor(ix, o, 64);
+            if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+        }
+        if ((lane & 31) == 0) {
+            const int row = rb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            bv[(wave & 1) * 64 + row] = v;
+            bi[(wave & 1) * 64 + row] = ix;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const long long r = r0 + tid;
+        if (r < R) {
+            float v0 = bv[tid], v1 = bv[64 + tid];
+            int i0 = bi[tid], i1 = bi[64 + tid];
+            const bool take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+            idx[r] = take1 ? i1 : i0;
+            if (best_sim) best_sim[r] = take1 ? v1 : v0;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int amdnuwa_conv2d_fwd(const amdnuwa_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                                  hipStream_t stream) {
+    if (!d || !x || !w || !y) return AMDNUWA_ERR_ARG;
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return AMDNUWA_ERR_ARG;
+    const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    if (Ho != d->Ho || Wo != d->Wo || Ho <= 0 || Wo <= 0) return AMDNUWA_ERR_ARG;
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
+    a.stride = d->stride; a.pad = d->pad; a.Ho = Ho; a.Wo = Wo; a.leaky = d->leaky; a.slope = 0.1f;
+    const long long NP = (long long)d->N * Ho * Wo;
+    dim3 grid((unsigned)((NP + CT - 1) / CT), (d->Cout + CT - 1) / CT), block(256);
+    hipLaunchKernelGGL(conv2d_kernel, grid, block, 0, stream, a);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_groupnorm_fwd(const float* x, const float* w, const float* b, float* y, int N, int C, int HW, int groups,
+                                     float eps, int leaky, hipStream_t stream) {
+    if (!x || !w || !b || !y || groups <= 0 || C % groups) return AMDNUWA_ERR_ARG;
+    if (N <= 0) return AMDNUWA_OK;
+    hipLaunchKernelGGL(groupnorm_kernel, dim3(N * groups), dim3(256), 0, stream, x, w, b, y, C, HW, groups, eps, leaky, 0.1f);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_vq_argmax(const float* x, const float* codebook, long long* indices, float* best_sim, long long R,
+                                 int n_codes, int code_dim, hipStream_t stream) {
+    if (!x || !codebook || !indices || n_codes <= 0 || code_dim <= 0 || code_dim % 2) return AMDNUWA_ERR_ARG;
+    if (R <= 0) return AMDNUWA_OK;
+    const size_t lds = ((size_t)2 * 64 * (code_dim + 1) + 256) * sizeof(float) + 128 * sizeof(int);
+    if (lds > 160 * 1024) return AMDNUWA_ERR_UNSUPPORTED;
+    (void)hipFuncSetAttribute((const void*)vq_argmax_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(vq_argmax_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), lds, stream, x, codebook, indices, best_sim, R,
+                       n_codes, code_dim);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}

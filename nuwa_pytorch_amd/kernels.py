@@ -432,3 +432,48 @@ def xattn_unpack(g, dKp, dVp, lo):
     check(L.amdnuwa_xattn_unpack(C.byref(g), _p(dKp), _p(dVp), _p(dkv.hi), _p(dkv.lo), 2 * inner, _p(dnk), _p(dnv), 0, _stream()),
           'amdnuwa_xattn_unpack')
     return dkv, dnk, dnv
+
+
+# ---- frozen VQGanVAE tokenizer (exact fp32) ----------------------------------------------------------------------
+
+def _f32c(t):
+    assert t.is_cuda, 'libamdnuwa kernels take device tensors'
+    return t.detach().to(torch.float32).contiguous()
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, padding=0, leaky=False):
+    """nn.Conv2d forward [+ LeakyReLU(0.1)], NCHW fp32 (reference vqgan_vae.py:352-365)."""
+    L = _lib.lib()
+    x, w = _f32c(x), _f32c(w)
+    bias = _f32c(bias) if bias is not None else None
+    N, Cin, H, W = x.shape
+    Cout, Cin2, KH, KW = w.shape
+    assert Cin == Cin2, (x.shape, w.shape)
+    d = _lib.ConvDesc()
+    d.N, d.Cin, d.H, d.W, d.Cout, d.KH, d.KW, d.stride, d.pad = N, Cin, H, W, Cout, KH, KW, stride, padding
+    d.Ho, d.Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
+    d.leaky = int(leaky)
+    y = torch.empty((N, Cout, d.Ho, d.Wo), dtype=torch.float32, device=x.device)
+    check(L.amdnuwa_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(y), _stream()), 'amdnuwa_conv2d_fwd')
+    return y
+
+
+def groupnorm_fwd(x, w, b, groups, eps=1e-5, leaky=False):
+    L = _lib.lib()
+    x, w, b = _f32c(x), _f32c(w), _f32c(b)
+    N, Cc = x.shape[:2]
+    y = torch.empty_like(x)
+    check(L.amdnuwa_groupnorm_fwd(_p(x), _p(w), _p(b), _p(y), N, Cc, x[0, 0].numel(), groups, eps, int(leaky), _stream()),
+          'amdnuwa_groupnorm_fwd')
+    return y
+
+
+def vq_argmax(x, codebook, want_sim=False):
+    """x [R, Dc], codebook [Cn, Dc] fp32 -> int64 indices [R] (cosine similarity, lowest index on ties)."""
+    L = _lib.lib()
+    x, codebook = _f32c(x), _f32c(codebook)
+    R, Dc = x.shape
+    idx = torch.empty((R,), dtype=torch.int64, device=x.device)
+    sim = torch.empty((R,), dtype=torch.float32, device=x.device) if want_sim else None
+    check(L.amdnuwa_vq_argmax(_p(x), _p(codebook), _p(idx), _p(sim), R, codebook.shape[0], Dc, _stream()), 'amdnuwa_vq_argmax')
+    return (idx, sim) if want_sim else idx

@@ -296,12 +296,60 @@ class VQGanVAE(nn.Module):
         video = self.decode(codes)
         return video.reshape(b, -1, *video.shape[1:])
 
+    def _hip_module(self, m, x):
+        """one encoder stage through libamdnuwa (exact fp32): the convolutions, GroupNorm(+LeakyReLU); the single
+        VQGanAttention block keeps its 256-position softmax in torch fp32 ops around HIP 1x1 convs."""
+        from . import kernels as K
+        if isinstance(m, nn.Conv2d):
+            assert m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1] and m.dilation == (1, 1) and m.groups == 1
+            return K.conv2d_fwd(x, m.weight, m.bias, m.stride[0], m.padding[0])
+        if isinstance(m, nn.Sequential) and len(m) == 2 and isinstance(m[0], nn.Conv2d) and isinstance(m[1], nn.LeakyReLU):
+            c = m[0]
+            return K.conv2d_fwd(x, c.weight, c.bias, c.stride[0], c.padding[0], leaky=True)
+        if isinstance(m, ResBlock):
+            c1, g1, _, c2, g2, _, c3 = m.net
+            h = K.conv2d_fwd(x, c1.weight, c1.bias, 1, 1)
+            h = K.groupnorm_fwd(h, g1.weight, g1.bias, g1.num_groups, g1.eps, leaky=True)
+            h = K.conv2d_fwd(h, c2.weight, c2.bias, 1, 1)
+            h = K.groupnorm_fwd(h, g2.weight, g2.bias, g2.num_groups, g2.eps, leaky=True)
+            return K.conv2d_fwd(h, c3.weight, c3.bias, 1, 0) + x
+        if isinstance(m, VQGanAttention):
+            h = m.heads
+            B, _, height, width = x.shape
+            q, k, v = K.conv2d_fwd(x, m.to_qkv.weight, None, 1, 0).chunk(3, dim=1)
+            q, k, v = map(lambda t: t.reshape(B, h, -1, height * width), (q, k, v))
+            q, k = map(l2norm, (q, k))
+            sim = einsum('b h c i, b h c j -> b h i j', q, k) * m.scale.exp()
+            attn = stable_softmax(m.cpb(sim), dim=-1)
+            out = einsum('b h i j, b h c j -> b h c i', attn, v).reshape(B, -1, height, width)
+            out = K.conv2d_fwd(out, m.to_out.weight, m.to_out.bias, 1, 0)
+            return m.post_norm(out) + x
+        raise NotImplementedError(f'no libamdnuwa path for encoder stage {type(m).__name__}')
+
+    def _hip_encode_indices(self, images):
+        from . import kernels as K
+        if not self.vq.use_cosine_sim:
+            raise NotImplementedError('libamdnuwa VQ lookup implements the cosine-similarity codebook (vq_use_cosine_sim=True)')
+        fmap = images.float()
+        for enc in self.encoders:
+            fmap = self._hip_module(enc, fmap)
+        B, _, Hh, Ww = fmap.shape
+        pin = self.vq.project_in
+        if isinstance(pin, nn.Linear):
+            fmap = K.conv2d_fwd(fmap, pin.weight[:, :, None, None], pin.bias, 1, 0)
+        rows = fmap.permute(0, 2, 3, 1).reshape(B * Hh * Ww, -1)
+        return K.vq_argmax(rows, self.vq.embed).reshape(B, Hh, Ww)
+
     @torch.no_grad()
     @eval_decorator
     def get_video_indices(self, video):
+        """frozen tokenizer of the NUWA training step (reference vqgan_vae.py:452-458): runs on the MI355X through
+        libamdnuwa; there is no CPU path."""
+        if not video.is_cuda:
+            raise RuntimeError('VQGanVAE.get_video_indices runs through libamdnuwa and needs the video on an MI355X device')
         b, f, _, h, w = video.shape
         images = video.reshape(b * f, *video.shape[2:])
-        _, indices, _ = self.encode(images)
+        indices = self._hip_encode_indices(images)
         return indices.reshape(b, f, *indices.shape[1:])
 
     def forward(self, img, return_loss=False, return_discr_loss=False, return_recons=False, apply_grad_penalty=False):

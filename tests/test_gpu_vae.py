@@ -1,0 +1,120 @@
+"""Frozen VQGanVAE tokenizer on the MI355X: the exact-fp32 HIP kernels behind
+VQGanVAE.get_video_indices against torch fp32 on the CPU, the oracle, and the golden fixture g7_vae captured
+from the reference.  Feature maps: 1e-5 relative (fp32, different summation order).  VQ indices: bit-exact
+wherever the top-2 similarity gap exceeds 1e-5 (in practice: everywhere)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import load  # noqa: E402
+from gpu_util import report  # noqa: E402
+
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from nuwa_pytorch_amd import kernels
+    return kernels
+
+
+@pytest.mark.parametrize('N,Cin,H,W,Cout,k,stride,pad,leaky', [
+    (2, 3, 32, 32, 32, 5, 1, 2, False),        # first conv (vqgan_vae.py:365)
+    (2, 32, 32, 32, 64, 4, 2, 1, True),        # strided encoder conv + LeakyReLU (vqgan_vae.py:352)
+    (3, 64, 8, 8, 64, 3, 1, 1, False),         # ResBlock 3x3
+    (3, 64, 8, 8, 192, 1, 1, 0, False),        # 1x1 (to_qkv / project_in)
+    (1, 5, 7, 9, 130, 3, 1, 1, True),          # ragged: odd sizes, Cout > one tile
+    (1, 128, 16, 16, 256, 4, 2, 1, True),      # cfg-3 sized channel pair
+])
+def test_conv2d(K, N, Cin, H, W, Cout, k, stride, pad, leaky):
+    torch.manual_seed(0)
+    x, w, b = torch.randn(N, Cin, H, W), torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5, torch.randn(Cout)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    if leaky:
+        ref = F.leaky_relu(ref, 0.1)
+    y = K.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), stride, pad, leaky=leaky)
+    report(f'conv2d[{Cin}->{Cout},k{k},s{stride}]', y, ref, 1e-5)
+    y2 = K.conv2d_fwd(x.to(DEV), w.to(DEV), None, stride, pad, leaky=False)
+    report(f'conv2d_nobias[{Cin}->{Cout},k{k}]', y2, F.conv2d(x, w, None, stride=stride, padding=pad), 1e-5)
+
+
+@pytest.mark.parametrize('N,C,H,G,leaky', [(2, 64, 8, 16, True), (3, 32, 5, 16, False), (1, 512, 16, 16, True)])
+def test_groupnorm(K, N, C, H, G, leaky):
+    torch.manual_seed(1)
+    x, w, b = torch.randn(N, C, H, H) * 2 + 0.5, torch.randn(C), torch.randn(C)
+    ref = F.group_norm(x, G, w, b, 1e-5)
+    if leaky:
+        ref = F.leaky_relu(ref, 0.1)
+    report(f'groupnorm[{C}/{G}]', K.groupnorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), G, 1e-5, leaky=leaky), ref, 1e-5)
+
+
+@pytest.mark.parametrize('R,Cn,Dc', [(100, 64, 16), (2560, 8192, 256), (1, 5, 2), (64, 130, 32)])
+def test_vq_argmax(K, O_, R, Cn, Dc):
+    torch.manual_seed(2)
+    x, cb = torch.randn(R, Dc), torch.randn(Cn, Dc)
+    idx_ref, gap = (t.reshape(-1) for t in O_.vq_eval_lookup(x.t()[None, :, :, None], cb))
+    idx, sim = K.vq_argmax(x.to(DEV), cb.to(DEV), want_sim=True)
+    sure = gap > 1e-5
+    assert torch.equal(idx.cpu()[sure], idx_ref[sure])
+    assert float(sure.float().mean()) > 0.99
+    ref_sim = (F.normalize(x, dim=-1) * F.normalize(cb, dim=-1)[idx_ref]).sum(-1)
+    report(f'vq_sim[{R}x{Cn}x{Dc}]', sim, ref_sim, 1e-5)
+
+
+def test_vq_argmax_lowest_index_on_exact_ties(K):
+    """duplicate codes give bit-identical similarities: the lowest index must win, as torch.argmax does"""
+    torch.manual_seed(3)
+    cb = torch.randn(70, 32)
+    cb[65] = cb[3]
+    cb[40] = cb[3]
+    cb[69] = cb[17]
+    x = torch.cat([cb[3:4] * 2.5, cb[17:18] * 0.3, torch.randn(5, 32)])
+    idx = K.vq_argmax(x.to(DEV), cb.to(DEV)).cpu()
+    assert idx[0] == 3 and idx[1] == 17
+
+
+@pytest.fixture(scope='module')
+def O_():
+    from oracle import nuwa_oracle
+    return nuwa_oracle
+
+
+def test_g7_vae_tokenizer_against_reference_fixture(K):
+    import nuwa_pytorch_amd as A
+    Ar, P, _ = load('g7_vae')
+    vae = A.VQGanVAE(dim=32, image_size=32, num_layers=2, vq_codebook_size=64, vq_codebook_dim=16, use_vgg_and_gan=False,
+                     attn_dim_head=16, attn_heads=4)
+    vae.load_state_dict(P)
+    vae = vae.to(DEV).eval()
+    fm = Ar['img'].to(DEV)
+    with torch.no_grad():
+        for i, enc in enumerate(vae.encoders):
+            fm = vae._hip_module(enc, fm)
+            report(f'g7.stage{i}', fm, Ar[f'stage{i}'], 2e-5)
+    video = Ar['img'].to(DEV)[None]                       # [1, f=3, c, h, w]
+    idx = vae.get_video_indices(video)[0].cpu()
+    sure = Ar['top2_gap'].reshape(idx.shape) > 1e-5
+    assert torch.equal(idx[sure], Ar['indices'].reshape(idx.shape)[sure])
+    assert bool(sure.all()), 'fixture has near-ties'
+    with pytest.raises(RuntimeError):
+        vae.get_video_indices(Ar['img'][None])           # no CPU path
+
+
+def test_cfg3_vae_tokenizer_matches_oracle():
+    """full-size cfg-3 VAE (dim 64, 256x256 frames, 4 layers, codebook 8192 x 256): one frame against the oracle"""
+    import nuwa_pytorch_amd as A
+    from oracle import nuwa_oracle as O
+    torch.manual_seed(0)
+    vae = A.VQGanVAE(dim=64, image_size=256, num_layers=4, vq_codebook_size=8192, use_vgg_and_gan=False).eval()
+    img = torch.rand(1, 3, 256, 256)
+    P = {k: v.detach() for k, v in vae.state_dict().items()}
+    fm = O.vae_encode_fmap(img, P, num_layers=4, heads=8)
+    idx_ref, gap = (t.reshape(-1) for t in O.vq_eval_lookup(fm, P['vq.embed'], P['vq.project_in.weight'], P['vq.project_in.bias']))
+    idx = vae.to(DEV).get_video_indices(img.to(DEV)[None])[0, 0].reshape(-1).cpu()
+    sure = gap > 1e-5
+    assert float(sure.float().mean()) > 0.98
+    assert torch.equal(idx[sure], idx_ref[sure])
