@@ -127,15 +127,43 @@ def cpu_baseline(c, budget_layers=3):
                        f'+ embed/norm/logits/CE ({t_rest:.1f}s) -> {t_step:.1f}s per step')
 
 
+def traffic_from_profiles(config, b):
+    """HBM bytes per NT-GEMM launch from the committed PMC passes (profiles/traffic.json, written by tools/pmc_summary.py
+    from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None when no pass matches."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            t = json.load(f)
+        e = t.get(f'{config}_b{b}')
+        return e if e and 'bytes_per_launch' in e else None
+    except (OSError, ValueError):
+        return None
+
+
+def tokenizer_rate(nuwa, c, b, dev):
+    """frozen VQGanVAE tokenizer (get_video_indices, exact-fp32 HIP kernels) on b videos of raw frames; reported beside the
+    decoder metric, never inside its timed region (the decoder bench feeds token ids, as a cached-token trainer would)."""
+    v = c['vae']
+    video = torch.rand(b, c['frames'], 3, v['image_size'], v['image_size'], device=dev)
+    nuwa.vae.get_video_indices(video)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ids = nuwa.vae.get_video_indices(video)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    return {'frames_per_s': b * c['frames'] / dt, 'video_tokens_per_s': ids.numel() / dt, 'ms': dt * 1e3, 'videos': b, 'dtype': 'f32'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8, help='samples per GPU (weak scaling)')
+    ap.add_argument('--batch', type=int, default=32, help='samples per GPU (weak scaling)')
     ap.add_argument('--config', default='cfg3', choices=list(CFGS))
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-tokenizer', action='store_true', help='skip the (untimed, separately reported) frozen-VAE tokenizer rate')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -200,9 +228,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    gemm_ms, gemm_launches, gemm_flops = (0.0, 0, 0.0)
+    gemm_ms, gemm_launches, gemm_flops, gemm_bytes = (0.0, 0, 0.0, 0.0)
     if rank == 0:
-        gemm_ms, gemm_launches, gemm_flops = K.timer_collect()
+        gemm_ms, gemm_launches, gemm_flops, gemm_bytes = K.timer_collect()
         K.timer_arm(False)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -228,11 +256,18 @@ def main():
             'per_gpu_value': value / world,
             'step_tflops_per_gpu': step_flops / (dt / args.steps) / 1e12,
             'step_mfma_frac': step_flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_kernel (bf16 MFMA GEMM, all NT launches of the timed region)',
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_* (bf16 MFMA NT GEMM; every amdnuwa_gemm_nt launch of the timed region, HIP events on the launch stream)',
                          'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                         'traffic': None, 'launches': gemm_launches, 'avg_launch_us': gemm_ms * 1e3 / max(gemm_launches, 1),
+                         'traffic': None, 'algorithmic_bytes_per_launch': gemm_bytes / max(gemm_launches, 1),
+                         'flops_per_launch': gemm_flops / max(gemm_launches, 1), 'launches': gemm_launches, 'avg_launch_us': gemm_ms * 1e3 / max(gemm_launches, 1),
                          'share_of_step': gemm_ms * 1e-3 / dt},
         }
+        tr = traffic_from_profiles(args.config, b)
+        if tr is not None:
+            out['roofline']['traffic'] = tr['bytes_per_launch']
+            out['roofline']['traffic_source'] = tr['source']
+        if not args.no_tokenizer:
+            out['vae_tokenizer'] = tokenizer_rate(nuwa, c, min(b, 8), dev)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(c)

@@ -31,8 +31,13 @@ typedef struct ihipStream_t* amdnuwa_stream;   /* == hipStream_t */
 
 int amdnuwa_abi_version(void);                 /* bumps when any signature below changes */
 const char* amdnuwa_error_string(int code);
-/* runtime tuning knobs (benchmarking): key 0 = NT GEMM variant (0 register-staged, 1 direct-to-LDS BK 64,
- * 2 direct-to-LDS BK 32), key 1 = TN split-K target workgroup count, key 2 = TN minimum rows per split */
+/* runtime tuning knobs (A/B benchmarking only; 0 = the library's auto policy everywhere):
+ *   key 0  NT GEMM variant: 1 direct-to-LDS BK 64, 2 direct-to-LDS BK 32, 3 / 4 256x256 tile with a 4- / 3-stage DMA ring,
+ *          5 register-staged 128x128
+ *   key 1  TN split-K workgroup slots        key 2  TN minimum token rows per split
+ *   key 5  cross-attention forward: 1 = generic (not unrolled) kernel
+ *   key 6  TN GEMM variant: 1 register-staged, 2 direct-to-LDS 128x128, 3 256x256 ring
+ *   key 7  NT probe: bit 0 skips the epilogue stores, bit 1 skips the main loop (tools/gemm_probe.py; results are garbage) */
 int amdnuwa_set_tuning(int key, int value);
 int amdnuwa_get_tuning(int key);
 

@@ -33,6 +33,7 @@ struct GemmArgs {
     int ksplit_len;         // TN: token rows per split
     int batch_inner;        // >0: batch index z -> (z / batch_inner) * stride + (z % batch_inner) * stride_in
     long long sA_in, sB_in, sC_in;
+    int dbg;                // probe only (tuning key 7): bit0 skip epilogue stores, bit1 skip main loop
 };
 
 __device__ __forceinline__ long long boff(const GemmArgs& p, long long z, long long s, long long s_in) {
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / 32;
+    const int nk = (p.dbg & 2) ? 0 : p.K / 32;
     // prologue: NS-1 tiles in flight
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -465,6 +466,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + fg * 4;
             if (n >= p.N) continue;
+            if ((p.dbg & 1) && acc[i][j][0] != 12345.678f) continue;
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -898,6 +900,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     p.shift_ntok = d->shift_ntok; p.shift_fmap = d->shift_fmap; p.shift_dim = d->K;
     p.tiles_m = (d->M + BM - 1) / BM; p.tiles_n = (d->N + BN - 1) / BN;
     p.ksplit_len = 0;
+    p.dbg = g_amdnuwa_tuning[7];
     p.batch_inner = d->batch_inner; p.sA_in = d->strideA_inner; p.sB_in = d->strideB_inner; p.sC_in = d->strideC_inner;
     const bool x3 = d->Alo != nullptr, sh = d->shift_ntok > 0, ob = d->c_is_bf16 != 0;
     dim3 grid(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), block(256);

@@ -82,13 +82,14 @@ def _ld(t):
 def timer_arm(on):
     _TIMER['on'] = bool(on)
     _TIMER['flops'] = 0.0
+    _TIMER['bytes'] = 0.0
     _lib.lib().amdnuwa_timer_arm(1 if on else 0)
 
 
 def timer_collect():
     ms, n = C.c_double(0), C.c_longlong(0)
     check(_lib.lib().amdnuwa_timer_collect(C.byref(ms), C.byref(n)), 'timer_collect')
-    return ms.value, n.value, _TIMER['flops']
+    return ms.value, n.value, _TIMER['flops'], _TIMER.get('bytes', 0.0)
 
 
 def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None, N=None, K=None):
@@ -119,6 +120,8 @@ def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None,
     st = _stream()
     if _TIMER['on']:
         _TIMER['flops'] += 2.0 * M * N * K * (3 if x3 else 1)
+        ob = (2 * (2 if out.lo is not None else 1)) if out_bf16 else 4
+        _TIMER['bytes'] += (2.0 * (M + N) * K) * (2 if x3 else 1) + float(M) * N * ob
         L.amdnuwa_timer_begin(st)
     check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt')
     if _TIMER['on']:

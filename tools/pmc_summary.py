@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Per-kernel-family averages of rocprofv3 --pmc counters (one CSV per pass, `--output-format csv`).
+    python tools/pmc_summary.py gpurun_out/pmcX/*_counter_collection.csv [--json profiles/traffic.json --key cfg3_b32]
+FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950
+tallies a wide (16 B/lane) coalesced read at HALF its bytes, so the corrected read traffic is 2 x FETCH_SIZE; WRITE_SIZE
+is used as reported (uncalibrated).  The --json mode writes the NT-GEMM family's bytes per launch for bench.py."""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def fam(n):
+    n = re.sub(r'^void ', '', n)
+    n = re.sub(r'\(anonymous namespace\)::', '', n)
+    n = re.sub(r'[<(].*$', '', n)
+    return n[:70]
+
+
+def main():
+    files = [a for a in sys.argv[1:] if a.endswith('.csv')]
+    agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    for f in files:
+        with open(f, newline='') as fh:
+            for r in csv.DictReader(fh):
+                a = agg[fam(r['Kernel_Name'])][r['Counter_Name']]
+                a[0] += 1
+                a[1] += float(r['Counter_Value'])
+    counters = sorted({c for k in agg.values() for c in k})
+    print(f'{"kernel family":56s} {"launches":>8s} ' + ' '.join(f'{c:>22s}' for c in counters))
+    keys = sorted(agg, key=lambda k: -sum(v[1] for v in agg[k].values()))
+    for k in keys:
+        n = max(v[0] for v in agg[k].values())
+        if not (k.startswith(('gemm_', 's3_', 'xattn_', 'ln_', 'geglu', 'conv2d', 'vq_', 'groupnorm', 'embed', 'ce_', 'partial', 'splitk', 'cast', 'transpose', 'colsum'))):
+            continue
+        print(f'{k:56s} {n:8d} ' + ' '.join(f'{(agg[k][c][1] / agg[k][c][0]) if c in agg[k] else float("nan"):22.1f}' for c in counters))
+    if '--json' in sys.argv:
+        out, key = sys.argv[sys.argv.index('--json') + 1], sys.argv[sys.argv.index('--key') + 1]
+        nt = [k for k in agg if k.startswith('gemm_nt_')]
+        def tot(c):
+            n = sum(agg[k][c][0] for k in nt if c in agg[k])
+            return (sum(agg[k][c][1] for k in nt if c in agg[k]) / n) if n else None
+        fs, ws = tot('FETCH_SIZE'), tot('WRITE_SIZE')
+        if fs is None or ws is None:
+            raise SystemExit('need FETCH_SIZE and WRITE_SIZE passes')
+        try:
+            cur = json.load(open(out))
+        except (OSError, ValueError):
+            cur = {}
+        cur[key] = {'bytes_per_launch': (2.0 * fs + ws) * 1024.0, 'fetch_kib_raw': fs, 'write_kib_raw': ws,
+                    'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), avg over gemm_nt_* launches; read bytes = 2 x FETCH_SIZE (gfx950 correction), write bytes = WRITE_SIZE'}
+        json.dump(cur, open(out, 'w'), indent=1)
+        print('wrote', out, key, cur[key]['bytes_per_launch'])
+
+
+if __name__ == '__main__':
+    main()

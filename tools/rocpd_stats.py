@@ -7,7 +7,23 @@ import sqlite3
 import sys
 
 
+_DM = {}
+
+
+def demangle(n):
+    """rocpd stores mangled symbols with a .kd suffix; c++filt them (cached)"""
+    if n not in _DM:
+        m = n[:-3] if n.endswith('.kd') else n
+        try:
+            import subprocess
+            _DM[n] = subprocess.run(['c++filt', m], capture_output=True, text=True, timeout=10).stdout.strip() or m
+        except Exception:
+            _DM[n] = m
+    return _DM[n]
+
+
 def short(n):
+    n = demangle(n)
     n = re.sub(r'^void ', '', n)
     n = re.sub(r'\(anonymous namespace\)::', '', n)
     n = re.sub(r'\(.*$', '', n)
@@ -39,6 +55,20 @@ def main():
     print(f'{"kernel":90s} {"calls":>7s} {"total_ms":>10s} {"avg_us":>9s} {"min_us":>9s} {"max_us":>9s} {"pct":>6s}')
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f'{k:90s} {a[0]:7d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:9.2f} {a[2] / 1e3:9.2f} {a[3] / 1e3:9.2f} {100.0 * a[1] / tot:6.2f}')
+    # the same, template instantiations folded into their kernel family (gemm_nt_256_kernel<...> -> gemm_nt_256_kernel)
+    fam = {}
+    for k, a in agg.items():
+        f = fam.setdefault(re.sub(r'<.*$', '', k), [0, 0, 1 << 62, 0])
+        f[0] += a[0]; f[1] += a[1]; f[2] = min(f[2], a[2]); f[3] = max(f[3], a[3])
+    print()
+    print('# by kernel family (template arguments folded); gemm_nt_* together = the bench.py roofline kernel')
+    print(f'{"family":60s} {"calls":>7s} {"total_ms":>10s} {"avg_us":>9s} {"pct":>6s}')
+    for k, a in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        print(f'{k:60s} {a[0]:7d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:9.2f} {100.0 * a[1] / tot:6.2f}')
+    nt = [a for k, a in fam.items() if k.startswith('gemm_nt_')]
+    if nt:
+        c, t = sum(a[0] for a in nt), sum(a[1] for a in nt)
+        print(f'{"gemm_nt_* (all NT GEMM launches)":60s} {c:7d} {t / 1e6:10.3f} {t / c / 1e3:9.2f} {100.0 * t / tot:6.2f}')
 
 
 if __name__ == '__main__':
