@@ -33,6 +33,7 @@ struct GemmArgs {
     int ksplit_len;         // TN: token rows per split
     int batch_inner;        // >0: batch index z -> (z / batch_inner) * stride + (z % batch_inner) * stride_in
     long long sA_in, sB_in, sC_in;
+    int nsplit;             // TN 256 ring: number of K splits (the grid is flattened over (split, tile))
     int dbg;                // probe only (tuning key 7): bit0 skip epilogue stores, bit1 skip main loop
 };
 
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs p) {
         for (int j = 0; j < NJ; ++j) {
             const bf16_t* sa = pa[j];
             if (SHIFT) {
-                const int q = (k0 + cca[j] * 8) / quarter;
+                const int kq = k0 + cca[j] * 8, q = (kq >= quarter) + (kq >= 2 * quarter);   // >= 2 -> unshifted half
                 sa = q == 0 ? pah[j] : (q == 1 ? paw[j] : pa[j]);
             }
             const bf16_t* srca = sa ? sa + k0 : zp;
@@ -373,32 +374,53 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs p) {
 // ---------------------------------------------------------------------------------------------
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <bool SHIFT, int EPI, int NS>
-__global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
+// WNW = waves along N: 4 -> 256x256 tile, 512 threads, one workgroup per CU;  2 -> 256x128 tile, 256 threads, 72 KiB of LDS, so
+// TWO workgroups share a CU and one's epilogue / pipeline fill overlaps the other's main loop.
+// STAG: the two wave rows (waves 0-3 / 4-7 = one wave of each per SIMD) run ONE PHASE APART: every K-step is a read phase
+// (12 ds_read_b128 + the DMA issue for a later tile + the counted vmcnt wait + lgkmcnt(0)) and an MFMA phase (32 MFMAs under
+// s_setprio 1), separated by raw s_barriers; the lagging row takes one extra barrier up front, so each SIMD always has one
+// wave feeding the matrix pipe while its partner pulls the next fragments out of LDS.
+// bf16-output instantiations (EPI 1) read their B fragments with PERMUTED rows: MFMA output row rho = 4*fg + r of fragment j is
+// tile column fg*16 + j*4 + r, so after the four fragments a lane owns 16 CONTIGUOUS output columns of one row (two 16-byte
+// stores, 128 B contiguous per row across the 4 lane groups) instead of four 8-byte pieces.  The B tile then swizzles on
+// row bits 4-5 (the bits that vary across a 16-lane ds_read_b128 group under this permutation) to stay bank-conflict free.
+template <int EPI>
+__device__ __forceinline__ int b256_swz(int row) {
+    const int gsel = EPI == 1 ? (row >> 4) & 3 : (row >> 2) & 3;
+    return (0x1320 >> (gsel * 4)) & 3;
+}
+template <int EPI>
+__device__ __forceinline__ int b256_off(int row, int cc) { return row * 64 + ((cc ^ b256_swz<EPI>(row)) << 4); }
+template <int EPI>
+__device__ __forceinline__ int b256_row(int j, int fr) { return EPI == 1 ? ((fr >> 2) * 16 + j * 4 + (fr & 3)) : (j * 16 + fr); }
+
+template <bool SHIFT, int EPI, int NS, int WNW, bool STAG = false>
+__global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TB = 256 * 32 * 2;             // 16 KiB per operand per stage
-    constexpr int STG = 2 * TB;
+    constexpr int NW = 2 * WNW, BN = 64 * WNW;
+    constexpr int PA = 16 / NW, PB = (BN / 16) / NW;      // 1 KiB DMA pieces (16 rows x 32 k) per wave: A, B
+    constexpr int TB = 256 * 32 * 2;             // A tile: 16 KiB per stage
+    constexpr int STG = TB + BN * 32 * 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WNW, wn = wave % WNW;
     const int nwg = p.tiles_m * p.tiles_n;
     const int lid = xcd_remap(blockIdx.x, nwg);
     const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int m0 = tm * 256, n0 = tn * BN;
     const long long bz = blockIdx.y;
     const long long oA = boff(p, bz, p.sA, p.sA_in), oB = boff(p, bz, p.sB, p.sB_in), oC = boff(p, bz, p.sC, p.sC_in);
     const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
 
-    const bf16_t* pa[2]; const bf16_t* pah[2]; const bf16_t* paw[2]; const bf16_t* pb[2];
-    int cca[2];
+    const bf16_t* pa[PA]; const bf16_t* pah[PA]; const bf16_t* paw[PA]; const bf16_t* pb[PB];
+    int cca[PA];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (j * 8 + wave) * 16 + (lane >> 2);
+    for (int j = 0; j < PA; ++j) {
+        const int row = (j * NW + wave) * 16 + (lane >> 2);
         const int cc = (lane & 3) ^ glds_swz<32>(row);
         cca[j] = cc;
-        const long long ga = (long long)m0 + row, gb = (long long)n0 + row;
+        const long long ga = (long long)m0 + row;
         pa[j] = ga < p.M ? p.A + oA + ga * p.lda + cc * 8 : nullptr;
-        pb[j] = gb < p.N ? p.B + oB + gb * p.ldb + cc * 8 : nullptr;
         pah[j] = paw[j] = pa[j];
         if (SHIFT && pa[j]) {
             const ShiftRow s = shift_row(ga, p.shift_ntok, p.shift_fmap);
@@ -406,21 +428,30 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
             paw[j] = s.off_w == INT_MIN ? nullptr : pa[j] + (long long)s.off_w * p.lda;
         }
     }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int row = (j * NW + wave) * 16 + (lane >> 2);
+        const int cc = (lane & 3) ^ b256_swz<EPI>(row);
+        const long long gb = (long long)n0 + row;
+        pb[j] = gb < p.N ? p.B + oB + gb * p.ldb + cc * 8 : nullptr;
+    }
     const int quarter = SHIFT ? (p.shift_dim >> 2) : 1;
     auto issue = [&](int slot, int k0) {
         char* base = smem + slot * STG;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < PA; ++j) {
             const bf16_t* sa = pa[j];
             if (SHIFT) {
-                const int q = (k0 + cca[j] * 8) / quarter;
+                const int kq = k0 + cca[j] * 8, q = (kq >= quarter) + (kq >= 2 * quarter);   // >= 2 -> unshifted half
                 sa = q == 0 ? pah[j] : (q == 1 ? paw[j] : pa[j]);
             }
             const bf16_t* srca = sa ? sa + k0 : zp;
+            __builtin_amdgcn_global_load_lds((glb_cvptr)srca, (lds_vptr)(base + (j * NW + wave) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
             const bf16_t* srcb = pb[j] ? pb[j] + k0 : zp;
-            const int off = (j * 8 + wave) * 1024;
-            __builtin_amdgcn_global_load_lds((glb_cvptr)srca, (lds_vptr)(base + off), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_cvptr)srcb, (lds_vptr)(base + TB + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_cvptr)srcb, (lds_vptr)(base + TB + (j * NW + wave) * 1024), 16, 0, 0);
         }
     };
 
@@ -436,12 +467,52 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, s * 32);
     const int fr = lane & 15, fg = lane >> 4;
+    if constexpr (STAG) {
+        static_assert(PA + PB == 4 && NS == 4, "staggered schedule is written for the 8-wave 4-stage ring");
+        // tile 0 landed (for this wave: at most the later prologue tiles still in flight), then for everyone
+        if (nk >= 3) VMCNT(8); else if (nk == 2) VMCNT(4); else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();           // this wave row lags one phase
+        for (int kt = 0; kt < nk; ++kt) {
+            // ---- read phase: fragments of tile kt; restage the slot tile kt-1 lived in (its last reader finished a phase ago)
+            const char* base = smem + (kt % NS) * STG;
+            bf16x8 af[8], bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(base + TB + b256_off<EPI>(wn * 64 + b256_row<EPI>(j, fr), fg));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + glds_off<32>(wm * 128 + i * 16 + fr, fg));
+            if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * 32);
+            // tile kt+1 must have landed (this wave's share) before the barrier that precedes anyone's read of it
+            const int rem2 = nk - 2 - kt;
+            if (rem2 >= 2) VMCNT(8); else if (rem2 == 1) VMCNT(4); else VMCNT(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---- MFMA phase
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed for THIS wave once at most (tiles after kt still in flight) x 4 DMAs remain
         const int rem = nk - 1 - kt;
-        if (NS >= 4 && rem >= 2) VMCNT(8);
-        else if (rem >= 1) VMCNT(4);
-        else VMCNT(0);
+        if constexpr (PA + PB == 4) {
+            if (NS >= 4 && rem >= 2) VMCNT(8);
+            else if (rem >= 1) VMCNT(4);
+            else VMCNT(0);
+        } else {
+            if (NS >= 4 && rem >= 2) VMCNT(12);
+            else if (rem >= 1) VMCNT(6);
+            else VMCNT(0);
+        }
         __builtin_amdgcn_s_barrier();            // ... and for every wave; also: everyone finished reading slot (kt-1)%NS
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * 32);
         const char* base = smem + (kt % NS) * STG;
@@ -449,7 +520,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + glds_off<32>(wm * 128 + i * 16 + fr, fg));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(base + TB + glds_off<32>(wn * 64 + j * 16 + fr, fg));
+        for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(base + TB + b256_off<EPI>(wn * 64 + b256_row<EPI>(j, fr), fg));
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -458,6 +529,38 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
     }
 
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
+    if constexpr (EPI == 1) {
+        // lane (fr, fg) owns row m = .. + fr and the 16 contiguous columns n = n0 + wn*64 + fg*16 + [j*4 + r]
+        const bool vec8 = (p.N % 8 == 0) && (p.ldc % 8 == 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
+            if (m >= p.M) continue;
+            const int nb = n0 + wn * 64 + fg * 16;
+            if (nb >= p.N) continue;
+            if ((p.dbg & 1) && acc[i][0][0] != 12345.678f) continue;
+            bf16_t h[16], l[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f2bf_hilo(acc[i][j][r] * p.alpha, h[j * 4 + r], l[j * 4 + r]);
+            bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
+            bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;
+            if (vec8 && nb + 16 <= p.N) {
+                reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
+                reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2(h[8], h[9]), pack2(h[10], h[11]), pack2(h[12], h[13]), pack2(h[14], h[15]));
+                if (Cl) {
+                    reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
+                    reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2(l[8], l[9]), pack2(l[10], l[11]), pack2(l[12], l[13]), pack2(l[14], l[15]));
+                }
+            } else {
+                for (int e = 0; e < 16 && nb + e < p.N; ++e) {
+                    C[e] = h[e];
+                    if (Cl) Cl[e] = l[e];
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
@@ -471,29 +574,14 @@ __global__ __launch_bounds__(512) void gemm_nt_256_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[i][j][r] * p.alpha;
-                if (EPI == 0 && p.bias && n + r < p.N) v[r] += p.bias[n + r];
+                if (p.bias && n + r < p.N) v[r] += p.bias[n + r];
             }
-            if (EPI == 0) {
-                float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
-                if (vec_ok) *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
-            } else {
-                bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + n;
-                bf16_t h[4], l[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) f2bf_hilo(v[r], h[r], l[r]);
-                if (vec_ok) {
-                    *reinterpret_cast<uint2*>(C) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
-                    if (p.Clo) *reinterpret_cast<uint2*>(p.Clo + oC + m * p.ldc + n) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) {
-                        C[r] = h[r];
-                        if (p.Clo) p.Clo[oC + m * p.ldc + n + r] = l[r];
-                    }
-                }
-            }
+            float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
+            if (vec_ok) *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+            else
+                for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
         }
+    }
     }
 }
 
@@ -756,7 +844,7 @@ __device__ __forceinline__ bf16x8 tn256_frag(const char* tile, int colbase, int 
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool SHIFT, int NS>
+template <bool SHIFT, int NS, bool STAG = false>
 __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmArgs p, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 32 * 256 * 2;             // 16 KiB per operand per stage
@@ -765,10 +853,14 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmArgs p, float* __r
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int N1 = p.M, N2 = p.N;
-    const int tmi = blockIdx.x / p.tiles_n, tni = blockIdx.x % p.tiles_n;
+    // flattened (split, tile) index, remapped so that the workgroups of one XCD are consecutive: the tiles of one K split
+    // (which re-read the same token rows of A and B) then share that XCD's L2 instead of fetching the slice eight times
+    const int ntile = p.tiles_m * p.tiles_n;
+    const int vid = xcd_remap(blockIdx.x, ntile * p.nsplit);
+    const int z = vid / ntile, tix = vid % ntile;
+    const int tmi = tix / p.tiles_n, tni = tix % p.tiles_n;
     const int a0 = tmi * 256, b0 = tni * 256;
     const long long bz = blockIdx.y;
-    const int z = blockIdx.z;
     const bf16_t* A = p.A + boff(p, bz, p.sA, p.sA_in);
     const bf16_t* B = p.B + boff(p, bz, p.sB, p.sB_in);
     const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
@@ -790,30 +882,47 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmArgs p, float* __r
         cola[j] = a0 + cc16 * 8; colb[j] = b0 + cc16 * 8;
         oka[j] = cola[j] < N1; okb[j] = colb[j] < N2;
     }
-    auto issue = [&](int slot, long long mk0) {
+    // Tiles are issued strictly in order, so every piece keeps running source pointers / row / token position and advances them
+    // by TK rows per issue: no 64-bit multiply or modulo on the per-K-step path.
+    int ipos[2] = {0, 0};
+    int qb[2] = {2, 2};
+    long long grow[2];
+    const bf16_t* pA[2]; const bf16_t* pB[2];
+    const long long stepA = (long long)TK * p.lda, stepB = (long long)TK * p.ldb;
+    const long long dH = -(long long)p.shift_fmap * p.ldb, dW = -(long long)p.ldb;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        grow[j] = mbeg + prow[j];
+        pA[j] = A + grow[j] * p.lda + cola[j];
+        pB[j] = B + grow[j] * p.ldb + colb[j];
+        if (SHIFT) {
+            ipos[j] = (int)((unsigned long long)grow[j] % (unsigned)p.shift_ntok);
+            qb[j] = (colb[j] >= quarter) + (colb[j] >= 2 * quarter);
+        }
+    }
+    auto issue = [&](int slot, long long) {
         char* base = smem + slot * STG;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const long long g = mk0 + prow[j];
-            const bool rin = g < mend;
-            const bf16_t* sa = (rin && oka[j]) ? A + g * p.lda + cola[j] : zp;
-            const bf16_t* sb = zp;
-            if (rin && okb[j]) {
-                long long gb = g;
-                bool zero = false;
-                if (SHIFT) {
-                    const int i = (int)((unsigned)g % (unsigned)p.shift_ntok);
-                    if (i > 0) {
-                        const int pp = i - 1;
-                        const int w = pow2 ? (pp & (p.shift_fmap - 1)) : pp % p.shift_fmap;
+            const bool rin = grow[j] < mend;
+            const bf16_t* sa = (rin && oka[j]) ? pA[j] : zp;
+            const bf16_t* sb = (rin && okb[j]) ? pB[j] : zp;
+            if (SHIFT) {
+                const int i = ipos[j];
+                if (i > 0 && qb[j] < 2 && rin && okb[j]) {
+                    const int pp = i - 1;
+                    if (qb[j] == 0) {
                         const int y = pow2 ? ((pp >> fsh) & (p.shift_fmap - 1)) : (pp / p.shift_fmap) % p.shift_fmap;
-                        const int q = colb[j] / quarter;
-                        if (q == 0) { if (y > 0) gb -= p.shift_fmap; else zero = true; }
-                        else if (q == 1) { if (w > 0) gb -= 1; else zero = true; }
+                        sb = y > 0 ? pB[j] + dH : zp;
+                    } else {
+                        const int w = pow2 ? (pp & (p.shift_fmap - 1)) : pp % p.shift_fmap;
+                        sb = w > 0 ? pB[j] + dW : zp;
                     }
                 }
-                if (!zero) sb = B + gb * p.ldb + colb[j];
+                ipos[j] += TK;
+                while (ipos[j] >= p.shift_ntok) ipos[j] -= p.shift_ntok;
             }
+            grow[j] += TK; pA[j] += stepA; pB[j] += stepB;
             const int off = (j * 8 + wave) * 1024;
             __builtin_amdgcn_global_load_lds((glb_cvptr)sa, (lds_vptr)(base + off), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_cvptr)sb, (lds_vptr)(base + TB + off), 16, 0, 0);
@@ -830,6 +939,36 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmArgs p, float* __r
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, mbeg + (long long)s * TK);
+    if constexpr (STAG) {                        // staggered wave rows: see gemm_nt_256_kernel
+        static_assert(NS == 4, "staggered schedule is written for the 4-stage ring");
+        if (nk >= 3) VMCNT(8); else if (nk == 2) VMCNT(4); else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* base = smem + (kt % NS) * STG;
+            bf16x8 af[8], bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = tn256_frag(base + TB, wn * 64 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = tn256_frag(base, wm * 128 + i * 16, lane);
+            if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, mbeg + (long long)(kt + NS - 1) * TK);
+            const int rem2 = nk - 2 - kt;
+            if (rem2 >= 2) VMCNT(8); else if (rem2 == 1) VMCNT(4); else VMCNT(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const int rem = nk - 1 - kt;
         if (NS >= 4 && rem >= 2) VMCNT(8);
@@ -850,7 +989,7 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmArgs p, float* __r
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
     const int fr = lane & 15, fg = lane >> 4;
-    float* P = partial + ((size_t)bz * gridDim.z + z) * (size_t)N1 * N2;
+    float* P = partial + ((size_t)bz * p.nsplit + z) * (size_t)N1 * N2;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int n1 = a0 + wm * 128 + i * 16 + fr;
@@ -910,7 +1049,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     int variant = g_amdnuwa_tuning[0];
     if (variant == 0) {
         const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * (d->batch > 0 ? d->batch : 1);
-        variant = (d->K % 32 == 0) ? (t256 >= 512 ? 4 : 2) : 5;
+        variant = (d->K % 32 == 0) ? (t256 >= 512 ? 7 : 2) : 5;
     }
     if (!x3 && (variant == 3 || variant == 4) && d->K % 32 == 0) {        // 256x256 tile, 4- / 3-stage DMA ring
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
@@ -918,12 +1057,40 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
 #define G256(SH, EP, NS_)                                                                                             \
     do {                                                                                                              \
         const size_t l256 = (size_t)NS_ * 2 * 256 * 32 * 2;                                                           \
-        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<SH, EP, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l256); \
-        hipLaunchKernelGGL((gemm_nt_256_kernel<SH, EP, NS_>), g256, b256, l256, stream, p);                            \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<SH, EP, NS_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l256); \
+        hipLaunchKernelGGL((gemm_nt_256_kernel<SH, EP, NS_, 4>), g256, b256, l256, stream, p);                            \
     } while (0)
         if (variant == 3) { if (sh) { if (ob) G256(true, 1, 4); else G256(true, 0, 4); } else { if (ob) G256(false, 1, 4); else G256(false, 0, 4); } }
         else              { if (sh) { if (ob) G256(true, 1, 3); else G256(true, 0, 3); } else { if (ob) G256(false, 1, 3); else G256(false, 0, 3); } }
 #undef G256
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
+    }
+    if (!x3 && variant == 7 && d->K % 32 == 0) {                           // 256x256 tile, 4-stage ring, staggered wave rows
+        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
+        dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(512);
+#define GS(SH, EP)                                                                                                    \
+    do {                                                                                                              \
+        const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;                                                               \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<SH, EP, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
+        hipLaunchKernelGGL((gemm_nt_256_kernel<SH, EP, 4, 4, true>), g2, b2, l2, stream, p);                           \
+    } while (0)
+        if (sh) { if (ob) GS(true, 1); else GS(true, 0); } else { if (ob) GS(false, 1); else GS(false, 0); }
+#undef GS
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
+    }
+    if (!x3 && variant == 6 && d->K % 32 == 0) {                           // 256x128 tile, 3-stage ring, two workgroups per CU
+        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 127) / 128;
+        dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(256);
+#define G2(SH, EP)                                                                                                    \
+    do {                                                                                                              \
+        const size_t l2 = (size_t)3 * (256 + 128) * 32 * 2;                                                           \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<SH, EP, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
+        hipLaunchKernelGGL((gemm_nt_256_kernel<SH, EP, 3, 2>), g2, b2, l2, stream, p);                                 \
+    } while (0)
+        if (sh) { if (ob) G2(true, 1); else G2(true, 0); } else { if (ob) G2(false, 1); else G2(false, 0); }
+#undef G2
         LAUNCH_CHECK();
         return AMDNUWA_OK;
     }
@@ -1009,15 +1176,18 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
     const int tnv = tn_variant(d);
     if (tnv == 3) {
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
-        dim3 g256(p.tiles_m * p.tiles_n, batch, splits), b256(512);
+        p.nsplit = splits;
+        dim3 g256(p.tiles_m * p.tiles_n * splits, batch, 1), b256(512);
         const size_t l256 = (size_t)4 * 2 * 32 * 256 * 2;
-        if (sh) {
-            (void)hipFuncSetAttribute((const void*)gemm_tn_256_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l256);
-            hipLaunchKernelGGL((gemm_tn_256_kernel<true, 4>), g256, b256, l256, stream, p, part);
-        } else {
-            (void)hipFuncSetAttribute((const void*)gemm_tn_256_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l256);
-            hipLaunchKernelGGL((gemm_tn_256_kernel<false, 4>), g256, b256, l256, stream, p, part);
-        }
+#define TN256(SH, ST)                                                                                                  \
+    do {                                                                                                              \
+        (void)hipFuncSetAttribute((const void*)gemm_tn_256_kernel<SH, 4, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l256); \
+        hipLaunchKernelGGL((gemm_tn_256_kernel<SH, 4, ST>), g256, b256, l256, stream, p, part);                        \
+    } while (0)
+        const bool stag = g_amdnuwa_tuning[8] == 0;      // tuning key 8: 1 = lock-step (non-staggered) TN ring
+        if (sh) { if (stag) TN256(true, true); else TN256(true, false); }
+        else    { if (stag) TN256(false, true); else TN256(false, false); }
+#undef TN256
     } else
     if (tnv == 2) {
         const size_t gl = (size_t)2 * 2 * TN_TILE_BYTES;
