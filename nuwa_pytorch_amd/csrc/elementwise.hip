@@ -11,11 +11,13 @@ namespace {
 constexpr int MAXV = 4;        // float4 slots per lane: supports D <= 1024
 constexpr int ROWS_PER_BLOCK = 4;
 
-struct RowVals { float4 v[MAXV]; };
+template <int NV> struct RowValsT { float4 v[NV]; };
+typedef RowValsT<MAXV> RowVals;
 
-__device__ __forceinline__ void row_load(const float* __restrict__ p, int D, int lane, RowVals& r, float fill = 0.f) {
+template <int NV>
+__device__ __forceinline__ void row_load(const float* __restrict__ p, int D, int lane, RowValsT<NV>& r, float fill = 0.f) {
 #pragma unroll
-    for (int it = 0; it < MAXV; ++it) {
+    for (int it = 0; it < NV; ++it) {
         const int e = (lane + it * 64) * 4;
         r.v[it] = (e < D) ? *reinterpret_cast<const float4*>(p + e) : make_float4(fill, fill, fill, fill);
     }
@@ -34,7 +36,7 @@ __device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, floa
 //   STABLE                   : x <- x / amax(x) first (StableLayerNorm np.py:93-95), saves 1/amax
 // saves mean / rstd per row for the backward.
 // ---------------------------------------------------------------------------------------------
-template <int MODE, bool STABLE>
+template <int MODE, bool STABLE, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ resid,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
@@ -44,17 +46,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= R) return;
-    RowVals xv;
+    RowValsT<NV> xv;
     row_load(x + row * D, D, lane, xv, STABLE ? -3.0e38f : 0.f);
     float inv_amax = 1.f;
     if (STABLE) {
         float m = -3.0e38f;
 #pragma unroll
-        for (int it = 0; it < MAXV; ++it) m = fmaxf(m, fmaxf(fmaxf(xv.v[it].x, xv.v[it].y), fmaxf(xv.v[it].z, xv.v[it].w)));
+        for (int it = 0; it < NV; ++it) m = fmaxf(m, fmaxf(fmaxf(xv.v[it].x, xv.v[it].y), fmaxf(xv.v[it].z, xv.v[it].w)));
         m = wave_max(m);
         inv_amax = 1.f / m;
 #pragma unroll
-        for (int it = 0; it < MAXV; ++it) {
+        for (int it = 0; it < NV; ++it) {
             const int e = (lane + it * 64) * 4;
             if (e < D) { xv.v[it].x = xv.v[it].x / m; xv.v[it].y = xv.v[it].y / m; xv.v[it].z = xv.v[it].z / m; xv.v[it].w = xv.v[it].w / m; }
             else xv.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -62,11 +64,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
     float s = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXV; ++it) s += (xv.v[it].x + xv.v[it].y) + (xv.v[it].z + xv.v[it].w);
+    for (int it = 0; it < NV; ++it) s += (xv.v[it].x + xv.v[it].y) + (xv.v[it].z + xv.v[it].w);
     const float mean = wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXV; ++it) {
+    for (int it = 0; it < NV; ++it) {
         const int e = (lane + it * 64) * 4;
         if (e < D) {
             const float a = xv.v[it].x - mean, b_ = xv.v[it].y - mean, c = xv.v[it].z - mean, d = xv.v[it].w - mean;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         if (STABLE) inv_amax_o[row] = inv_amax;
     }
 #pragma unroll
-    for (int it = 0; it < MAXV; ++it) {
+    for (int it = 0; it < NV; ++it) {
         const int e = (lane + it * 64) * 4;
         if (e >= D) continue;
         const float4 wv = *reinterpret_cast<const float4*>(w + e);
@@ -104,22 +106,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Writes per-block partial sums [nblk][3][D]: dw, db, and sum(dx) (= bias grad of the Linear that
 // produced x, when there is one).  Grid-stride over rows, fixed order => deterministic.
 // ---------------------------------------------------------------------------------------------
-template <int OUT, bool STABLE>
+template <int OUT, bool STABLE, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ inv_amax_i, const float* __restrict__ w,
                                                      bf16_t* __restrict__ dx_hi, bf16_t* __restrict__ dx_lo,
                                                      float* dx_acc, const float* dres, float* __restrict__ partial,
                                                      long long R, int D, int shift_ntok, int shift_fmap) {
-    __shared__ float red[ROWS_PER_BLOCK][3][MAXV * 256];
+    __shared__ float red[ROWS_PER_BLOCK][3][NV * 256];
     const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
-    float4 pw[MAXV], pb[MAXV], ps[MAXV];
+    float4 pw[NV], pb[NV], ps[NV];
 #pragma unroll
-    for (int it = 0; it < MAXV; ++it) pw[it] = pb[it] = ps[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int it = 0; it < NV; ++it) pw[it] = pb[it] = ps[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int quarter = D >> 2;
-    for (long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + wv_; row < R; row += (long long)gridDim.x * ROWS_PER_BLOCK) {
-        RowVals xv, gv;
-        row_load(x + row * D, D, lane, xv);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool has_res = OUT == 1 && dres != nullptr;
+    struct RowIn { RowValsT<NV> xv, gv, rv; float mean, rstd, ia; };
+    // everything one row needs from HBM, issued together (the residual-stream gradient included) ...
+    auto load_row = [&](long long row, RowIn& in) {
+        row_load(x + row * D, D, lane, in.xv);
         if (shift_ntok > 0) {
             // d(unshifted)[i][c] = d(shifted)[i + fmap][c] (quarter 0, when that row took its value from i),
             //                      d(shifted)[i + 1][c]    (quarter 1), d(shifted)[i][c] otherwise
@@ -131,38 +136,54 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 if (wq < shift_fmap - 1 && i + 1 < shift_ntok) src_w = row + 1;
             }
 #pragma unroll
-            for (int it = 0; it < MAXV; ++it) {
+            for (int it = 0; it < NV; ++it) {
                 const int e = (lane + it * 64) * 4;
-                if (e >= D) { gv.v[it] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+                if (e >= D) { in.gv.v[it] = zero4; continue; }
                 long long src = row;
                 if (i > 0) { const int qd = e / quarter; if (qd == 0) src = src_h; else if (qd == 1) src = src_w; }
-                gv.v[it] = src >= 0 ? *reinterpret_cast<const float4*>(dy + src * D + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                in.gv.v[it] = src >= 0 ? *reinterpret_cast<const float4*>(dy + src * D + e) : zero4;
             }
         } else {
-            row_load(dy + row * D, D, lane, gv);
+            row_load(dy + row * D, D, lane, in.gv);
         }
-        const float mean = mean_i[row], rstd = rstd_i[row];
-        const float ia = STABLE ? inv_amax_i[row] : 1.f;
+        if (OUT == 1) {
+            if (has_res) row_load(dres + row * D, D, lane, in.rv);
+            else row_load(dx_acc + row * D, D, lane, in.rv);
+        }
+        in.mean = mean_i[row]; in.rstd = rstd_i[row];
+        in.ia = STABLE ? inv_amax_i[row] : 1.f;
+    };
+    // ... and one row AHEAD of the arithmetic: while row r is reduced and stored, row r + stride is already in flight.
+    // Rows are taken grid-stride, so at any moment the chip works on one contiguous window of the tensors.
+    const long long stride = (long long)gridDim.x * ROWS_PER_BLOCK;
+    long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + wv_;
+    RowIn cur, nxt;
+    if (row < R) load_row(row, cur);
+    for (; row < R; row += stride) {
+        const bool more = row + stride < R;
+        if (more) load_row(row + stride, nxt);
+        const float mean = cur.mean, rstd = cur.rstd, ia = cur.ia;
         float s1 = 0.f, s2 = 0.f;
-        float4 xh[MAXV], g[MAXV];
+        float4 xh[NV], g[NV];
 #pragma unroll
-        for (int it = 0; it < MAXV; ++it) {
+        for (int it = 0; it < NV; ++it) {
             const int e = (lane + it * 64) * 4;
-            if (e >= D) { xh[it] = g[it] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            if (e >= D) { xh[it] = g[it] = zero4; continue; }
             const float4 wv = *reinterpret_cast<const float4*>(w + e);
-            float4 xx = xv.v[it];
+            float4 xx = cur.xv.v[it];
+            const float4 gg = cur.gv.v[it];
             if (STABLE) { xx.x *= ia; xx.y *= ia; xx.z *= ia; xx.w *= ia; }
             xh[it] = make_float4((xx.x - mean) * rstd, (xx.y - mean) * rstd, (xx.z - mean) * rstd, (xx.w - mean) * rstd);
-            g[it] = make_float4(gv.v[it].x * wv.x, gv.v[it].y * wv.y, gv.v[it].z * wv.z, gv.v[it].w * wv.w);
+            g[it] = make_float4(gg.x * wv.x, gg.y * wv.y, gg.z * wv.z, gg.w * wv.w);
             s1 += (g[it].x + g[it].y) + (g[it].z + g[it].w);
             s2 += (g[it].x * xh[it].x + g[it].y * xh[it].y) + (g[it].z * xh[it].z + g[it].w * xh[it].w);
-            pw[it].x += gv.v[it].x * xh[it].x; pw[it].y += gv.v[it].y * xh[it].y; pw[it].z += gv.v[it].z * xh[it].z; pw[it].w += gv.v[it].w * xh[it].w;
-            pb[it].x += gv.v[it].x; pb[it].y += gv.v[it].y; pb[it].z += gv.v[it].z; pb[it].w += gv.v[it].w;
+            pw[it].x += gg.x * xh[it].x; pw[it].y += gg.y * xh[it].y; pw[it].z += gg.z * xh[it].z; pw[it].w += gg.w * xh[it].w;
+            pb[it].x += gg.x; pb[it].y += gg.y; pb[it].z += gg.z; pb[it].w += gg.w;
         }
         const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
         const float sc = STABLE ? rstd * ia : rstd;
 #pragma unroll
-        for (int it = 0; it < MAXV; ++it) {
+        for (int it = 0; it < NV; ++it) {
             const int e = (lane + it * 64) * 4;
             if (e >= D) continue;
             const float d0 = sc * (g[it].x - m1 - xh[it].x * m2), d1 = sc * (g[it].y - m1 - xh[it].y * m2);
@@ -171,16 +192,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             if (OUT == 0) {
                 store_bf16x4(dx_hi + row * D, dx_lo ? dx_lo + row * D : nullptr, e, d0, d1, d2, d3);
             } else {
-                float4* a = reinterpret_cast<float4*>(dx_acc + row * D + e);
-                float4 o = dres ? *reinterpret_cast<const float4*>(dres + row * D + e) : *a;
-                o.x += d0; o.y += d1; o.z += d2; o.w += d3;
-                *a = o;
+                const float4 o = cur.rv.v[it];
+                *reinterpret_cast<float4*>(dx_acc + row * D + e) = make_float4(o.x + d0, o.y + d1, o.z + d2, o.w + d3);
             }
         }
+        if (more) cur = nxt;
     }
     // block reduce the 4 waves' partials in fixed order
 #pragma unroll
-    for (int it = 0; it < MAXV; ++it) {
+    for (int it = 0; it < NV; ++it) {
         const int e = (lane + it * 64) * 4;
         *reinterpret_cast<float4*>(&red[wv_][0][e]) = pw[it];
         *reinterpret_cast<float4*>(&red[wv_][1][e]) = pb[it];
@@ -207,18 +227,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 // row parallelism, fixed combine order (deterministic).  grid = ceil(nk*D / 64).
 __global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __restrict__ partial, int nblk, int nk, int D,
                                                               float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2, int accumulate) {
-    __shared__ float red[16][64];
-    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + lane;
+    // 1024 threads = 16 consecutive (k, c) columns x 64 row groups (64-byte segments per row group; 4x the blocks of a
+    // 64-column layout, which left most of the chip idle on these few-MB reductions); fixed combine order.
+    __shared__ float red[64][17];
+    const int col = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + col;
     float s = 0.f;
     if (idx < nk * D)
-        for (int bidx = rg; bidx < nblk; bidx += 16) s += partial[(size_t)bidx * nk * D + idx];
-    red[rg][lane] = s;
+        for (int bidx = rg; bidx < nblk; bidx += 64) s += partial[(size_t)bidx * nk * D + idx];
+    red[rg][col] = s;
     __syncthreads();
     if (rg == 0 && idx < nk * D) {
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += red[r][lane];
+        for (int r = 0; r < 64; ++r) t += red[r][col];
         const int k = idx / D, c = idx % D;
         float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
         if (o) o[c] = accumulate ? o[c] + t : t;
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float hl(const bf16_t* hi, const bf16_t* lo, size_t i) { return bf2f(hi[i]) + (lo ? bf2f(lo[i]) : 0.f); }
 
-__global__ void geglu_fwd_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* __restrict__ u_lo,
+__global__ void geglu_fwd_generic_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* __restrict__ u_lo,
                                  bf16_t* __restrict__ o_hi, bf16_t* __restrict__ o_lo, long long R, int FP) {
     const size_t total = (size_t)R * FP / 4;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -244,7 +266,7 @@ __global__ void geglu_fwd_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* 
     }
 }
 
-__global__ void geglu_bwd_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* __restrict__ u_lo,
+__global__ void geglu_bwd_generic_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* __restrict__ u_lo,
                                  const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
                                  bf16_t* __restrict__ du_hi, bf16_t* __restrict__ du_lo, long long R, int FP) {
     const size_t total = (size_t)R * FP / 4;
@@ -261,6 +283,74 @@ __global__ void geglu_bwd_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* 
         }
         store_bf16x4(du_hi + row * 2 * FP, du_lo ? du_lo + row * 2 * FP : nullptr, c, da[0], da[1], da[2], da[3]);
         store_bf16x4(du_hi + row * 2 * FP, du_lo ? du_lo + row * 2 * FP : nullptr, c + FP, dg[0], dg[1], dg[2], dg[3]);
+    }
+}
+
+// row-streaming forms (FP % 8 == 0): one wave per token row, 16-byte accesses, rows visited in launch order like the LN kernels
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(w[k] << 16); f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+}
+template <bool LO>
+__device__ __forceinline__ void load8(const bf16_t* hi, const bf16_t* lo, size_t off, float* f) {
+    unpack8(*reinterpret_cast<const uint4*>(hi + off), f);
+    if (LO) {
+        float l[8];
+        unpack8(*reinterpret_cast<const uint4*>(lo + off), l);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] += l[k];
+    }
+}
+template <bool LO>
+__device__ __forceinline__ void store8(bf16_t* hi, bf16_t* lo, size_t off, const float* f) {
+    bf16_t h[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (LO) f2bf_hilo(f[k], h[k], l[k]);
+        else h[k] = f2bf(f[k]);
+    }
+    *reinterpret_cast<uint4*>(hi + off) = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
+    if (LO) *reinterpret_cast<uint4*>(lo + off) = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
+}
+
+template <bool LO>
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* __restrict__ u_lo,
+                                                        bf16_t* __restrict__ o_hi, bf16_t* __restrict__ o_lo, long long R, int FP) {
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const size_t ub = (size_t)row * 2 * FP, ob = (size_t)row * FP;
+    for (int c = (threadIdx.x & 63) * 8; c < FP; c += 512) {
+        float a[8], g[8], o[8];
+        load8<LO>(u_hi, u_lo, ub + c, a);
+        load8<LO>(u_hi, u_lo, ub + FP + c, g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = a[k] * gelu_f(g[k]);
+        store8<LO>(o_hi, o_lo, ob + c, o);
+    }
+}
+
+template <bool LO>
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* __restrict__ u_lo,
+                                                        const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
+                                                        bf16_t* __restrict__ du_hi, bf16_t* __restrict__ du_lo, long long R, int FP) {
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const size_t ub = (size_t)row * 2 * FP, db = (size_t)row * FP;
+    for (int c = (threadIdx.x & 63) * 8; c < FP; c += 512) {
+        float a[8], g[8], d[8], da[8], dg[8];
+        load8<LO>(u_hi, u_lo, ub + c, a);
+        load8<LO>(u_hi, u_lo, ub + FP + c, g);
+        load8<LO>(d_hi, d_lo, db + c, d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float y, dy;
+            gelu_both_f(g[k], y, dy);
+            da[k] = d[k] * y;
+            dg[k] = d[k] * a[k] * dy;
+        }
+        store8<LO>(du_hi, du_lo, ub + c, da);
+        store8<LO>(du_hi, du_lo, ub + FP + c, dg);
     }
 }
 
@@ -470,16 +560,20 @@ extern "C" int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w
     if (stable && !inv_amax) return AMDNUWA_ERR_ARG;
     if (R <= 0) return AMDNUWA_OK;
     dim3 grid((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
-    if (mode == 0 && !stable) hipLaunchKernelGGL((ln_fwd_kernel<0, false>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps);
-    else if (mode == 0) hipLaunchKernelGGL((ln_fwd_kernel<0, true>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps);
-    else hipLaunchKernelGGL((ln_fwd_kernel<1, false>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps);
+#define LNF(MO, ST, NV_) hipLaunchKernelGGL((ln_fwd_kernel<MO, ST, NV_>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps)
+#define LNF_NV(MO, ST) do { if (D <= 256) LNF(MO, ST, 1); else if (D <= 512) LNF(MO, ST, 2); else LNF(MO, ST, 4); } while (0)
+    if (mode == 0 && !stable) LNF_NV(0, false);
+    else if (mode == 0) LNF_NV(0, true);
+    else LNF_NV(1, false);
+#undef LNF_NV
+#undef LNF
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
 
 static int ln_bwd_blocks(long long R) {
     long long nb = (R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    if (nb > 1024) nb = 1024;
+    if (nb > 1536) nb = 1536;
     return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -498,15 +592,14 @@ extern "C" int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean
     const int nb = ln_bwd_blocks(R);
     float* part = (float*)workspace;
     dim3 grid(nb), block(256);
-    if (dx_hi) {
-        if (stable) hipLaunchKernelGGL((ln_bwd_kernel<0, true>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap);
-        else hipLaunchKernelGGL((ln_bwd_kernel<0, false>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap);
-    } else {
-        if (stable) hipLaunchKernelGGL((ln_bwd_kernel<1, true>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap);
-        else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap);
-    }
+#define LNB(OU, ST, NV_) hipLaunchKernelGGL((ln_bwd_kernel<OU, ST, NV_>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap)
+#define LNB_NV(OU, ST) do { if (D <= 256) LNB(OU, ST, 1); else if (D <= 512) LNB(OU, ST, 2); else LNB(OU, ST, 4); } while (0)
+    if (dx_hi) { if (stable) LNB_NV(0, true); else LNB_NV(0, false); }
+    else       { if (stable) LNB_NV(1, true); else LNB_NV(1, false); }
+#undef LNB_NV
+#undef LNB
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((3 * D + 63) / 64), dim3(1024), 0, stream, part, nb, 3, D, dw, db, dsum, accumulate);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((3 * D + 15) / 16), dim3(1024), 0, stream, part, nb, 3, D, dw, db, dsum, accumulate);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
@@ -521,7 +614,7 @@ extern "C" int amdnuwa_colsum(const float* x, float* out, long long R, int D, in
     const int nb = (int)(R < 256 ? R : 256);
     hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, stream, x, (float*)workspace, R, D);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, nb, 1, D, out, (float*)nullptr, (float*)nullptr, accumulate);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((D + 15) / 16), dim3(1024), 0, stream, (const float*)workspace, nb, 1, D, out, (float*)nullptr, (float*)nullptr, accumulate);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
@@ -529,7 +622,11 @@ extern "C" int amdnuwa_colsum(const float* x, float* out, long long R, int D, in
 extern "C" int amdnuwa_geglu_fwd(const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* o_hi, uint16_t* o_lo, long long R, int FP, hipStream_t stream) {
     if (!u_hi || !o_hi || FP % 4) return AMDNUWA_ERR_ARG;
     if (R <= 0) return AMDNUWA_OK;
-    hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for((size_t)R * FP / 4)), dim3(256), 0, stream, u_hi, u_lo, o_hi, o_lo, R, FP);
+    const dim3 rg((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    if (FP % 8) hipLaunchKernelGGL(geglu_fwd_generic_kernel, dim3(grid_for((size_t)R * FP / 4)), dim3(256), 0, stream, u_hi, u_lo, o_hi, o_lo, R, FP);
+    else if (u_lo && o_lo) hipLaunchKernelGGL((geglu_fwd_kernel<true>), rg, dim3(256), 0, stream, u_hi, u_lo, o_hi, o_lo, R, FP);
+    else if (!u_lo && !o_lo) hipLaunchKernelGGL((geglu_fwd_kernel<false>), rg, dim3(256), 0, stream, u_hi, u_lo, o_hi, o_lo, R, FP);
+    else hipLaunchKernelGGL(geglu_fwd_generic_kernel, dim3(grid_for((size_t)R * FP / 4)), dim3(256), 0, stream, u_hi, u_lo, o_hi, o_lo, R, FP);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
@@ -538,7 +635,11 @@ extern "C" int amdnuwa_geglu_bwd(const uint16_t* u_hi, const uint16_t* u_lo, con
                                  uint16_t* du_hi, uint16_t* du_lo, long long R, int FP, hipStream_t stream) {
     if (!u_hi || !d_hi || !du_hi || FP % 4) return AMDNUWA_ERR_ARG;
     if (R <= 0) return AMDNUWA_OK;
-    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for((size_t)R * FP / 4)), dim3(256), 0, stream, u_hi, u_lo, d_hi, d_lo, du_hi, du_lo, R, FP);
+    const dim3 rg((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    if (FP % 8) hipLaunchKernelGGL(geglu_bwd_generic_kernel, dim3(grid_for((size_t)R * FP / 4)), dim3(256), 0, stream, u_hi, u_lo, d_hi, d_lo, du_hi, du_lo, R, FP);
+    else if (u_lo && d_lo && du_lo) hipLaunchKernelGGL((geglu_bwd_kernel<true>), rg, dim3(256), 0, stream, u_hi, u_lo, d_hi, d_lo, du_hi, du_lo, R, FP);
+    else if (!u_lo && !d_lo && !du_lo) hipLaunchKernelGGL((geglu_bwd_kernel<false>), rg, dim3(256), 0, stream, u_hi, u_lo, d_hi, d_lo, du_hi, du_lo, R, FP);
+    else hipLaunchKernelGGL(geglu_bwd_generic_kernel, dim3(grid_for((size_t)R * FP / 4)), dim3(256), 0, stream, u_hi, u_lo, d_hi, d_lo, du_hi, du_lo, R, FP);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
