@@ -82,7 +82,11 @@ int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspac
  * F.cross_entropy (np.py:1963).  fp32 statistics, bf16 hi[/lo] outputs where a GEMM consumes them.
  * ---------------------------------------------------------------------------------------- */
 /* mode 0: out_hi[/lo] = LN(x)*w+b (bf16).  mode 1: out_f32 = resid + LN(x)*w+b.
- * stable != 0 (mode 0 only): x is first divided by its row amax (saved as 1/amax). */
+ * stable != 0 (mode 0 only): x is first divided by its row amax (saved as 1/amax).
+ * Input-type flags (fast bf16 mode keeps GEMM outputs in bf16): OR AMDNUWA_LN_X_BF16 into `mode` (ln_fwd) or into
+ * `stable` (ln_bwd) when x points at bf16 values; OR AMDNUWA_LN_DY_BF16 into ln_bwd's `stable` when dy does. */
+#define AMDNUWA_LN_X_BF16 16
+#define AMDNUWA_LN_DY_BF16 32
 int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const float* b, uint16_t* out_hi,
                    uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R, int D,
                    int mode, int stable, float eps, amdnuwa_stream stream);

@@ -42,6 +42,13 @@ __device__ __forceinline__ void f2bf_hilo(float f, bf16_t& hi, bf16_t& lo) {
 }
 
 __device__ __forceinline__ uint32_t pack2(bf16_t a, bf16_t b) { return (uint32_t)a | ((uint32_t)b << 16); }
+// two fp32 -> packed bf16 pair (a in the low half) with the gfx950 converter (v_cvt_pk_bf16_f32, round-to-nearest-even:
+// bit-identical to f2bf on finite values, one instruction instead of eight)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ uint32_t pack2_rne(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
 __device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 

@@ -14,6 +14,24 @@ constexpr int ROWS_PER_BLOCK = 4;
 template <int NV> struct RowValsT { float4 v[NV]; };
 typedef RowValsT<MAXV> RowVals;
 
+// 4 consecutive elements starting at element index i of an fp32 (BF = false) or bf16 (BF = true) array
+template <bool BF>
+__device__ __forceinline__ float4 ld4(const void* base, size_t i) {
+    if (BF) {
+        const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(base) + i);
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + i);
+}
+template <bool BF, int NV>
+__device__ __forceinline__ void row_load_t(const void* base, size_t row_off, int D, int lane, RowValsT<NV>& r, float fill = 0.f) {
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        const int e = (lane + it * 64) * 4;
+        r.v[it] = (e < D) ? ld4<BF>(base, row_off + e) : make_float4(fill, fill, fill, fill);
+    }
+}
+
 template <int NV>
 __device__ __forceinline__ void row_load(const float* __restrict__ p, int D, int lane, RowValsT<NV>& r, float fill = 0.f) {
 #pragma unroll
@@ -23,6 +41,7 @@ __device__ __forceinline__ void row_load(const float* __restrict__ p, int D, int
     }
 }
 __device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, float a, float b, float c, float d) {
+    if (!lo) { *reinterpret_cast<uint2*>(hi + e) = make_uint2(pack2_rne(a, b), pack2_rne(c, d)); return; }
     bf16_t h[4], l[4];
     f2bf_hilo(a, h[0], l[0]); f2bf_hilo(b, h[1], l[1]); f2bf_hilo(c, h[2], l[2]); f2bf_hilo(d, h[3], l[3]);
     *reinterpret_cast<uint2*>(hi + e) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
@@ -36,7 +55,7 @@ __device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, floa
 //   STABLE                   : x <- x / amax(x) first (StableLayerNorm np.py:93-95), saves 1/amax
 // saves mean / rstd per row for the backward.
 // ---------------------------------------------------------------------------------------------
-template <int MODE, bool STABLE, int NV>
+template <int MODE, bool STABLE, int NV, bool XBF>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ resid,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
@@ -44,10 +63,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ rstd_o, float* __restrict__ inv_amax_o,
                                                      long long R, int D, float eps) {
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= R) return;
     RowValsT<NV> xv;
-    row_load(x + row * D, D, lane, xv, STABLE ? -3.0e38f : 0.f);
+    row_load_t<XBF>(x, (size_t)row * D, D, lane, xv, STABLE ? -3.0e38f : 0.f);
     float inv_amax = 1.f;
     if (STABLE) {
         float m = -3.0e38f;
@@ -106,7 +125,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Writes per-block partial sums [nblk][3][D]: dw, db, and sum(dx) (= bias grad of the Linear that
 // produced x, when there is one).  Grid-stride over rows, fixed order => deterministic.
 // ---------------------------------------------------------------------------------------------
-template <int OUT, bool STABLE, int NV>
+template <int OUT, bool STABLE, int NV, int IN>          // IN: 0 = dy, x fp32; 1 = x is bf16; 2 = dy is bf16
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ inv_amax_i, const float* __restrict__ w,
@@ -114,7 +133,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      float* dx_acc, const float* dres, float* __restrict__ partial,
                                                      long long R, int D, int shift_ntok, int shift_fmap) {
     __shared__ float red[ROWS_PER_BLOCK][3][NV * 256];
-    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row math on the SALU
     float4 pw[NV], pb[NV], ps[NV];
 #pragma unroll
     for (int it = 0; it < NV; ++it) pw[it] = pb[it] = ps[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -124,7 +143,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     struct RowIn { RowValsT<NV> xv, gv, rv; float mean, rstd, ia; };
     // everything one row needs from HBM, issued together (the residual-stream gradient included) ...
     auto load_row = [&](long long row, RowIn& in) {
-        row_load(x + row * D, D, lane, in.xv);
+        row_load_t<IN == 1>(x, (size_t)row * D, D, lane, in.xv);
         if (shift_ntok > 0) {
             // d(unshifted)[i][c] = d(shifted)[i + fmap][c] (quarter 0, when that row took its value from i),
             //                      d(shifted)[i + 1][c]    (quarter 1), d(shifted)[i][c] otherwise
@@ -141,10 +160,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 if (e >= D) { in.gv.v[it] = zero4; continue; }
                 long long src = row;
                 if (i > 0) { const int qd = e / quarter; if (qd == 0) src = src_h; else if (qd == 1) src = src_w; }
-                in.gv.v[it] = src >= 0 ? *reinterpret_cast<const float4*>(dy + src * D + e) : zero4;
+                in.gv.v[it] = src >= 0 ? ld4<IN == 2>(dy, (size_t)src * D + e) : zero4;
             }
         } else {
-            row_load(dy + row * D, D, lane, in.gv);
+            row_load_t<IN == 2>(dy, (size_t)row * D, D, lane, in.gv);
         }
         if (OUT == 1) {
             if (has_res) row_load(dres + row * D, D, lane, in.rv);
@@ -304,12 +323,13 @@ __device__ __forceinline__ void load8(const bf16_t* hi, const bf16_t* lo, size_t
 }
 template <bool LO>
 __device__ __forceinline__ void store8(bf16_t* hi, bf16_t* lo, size_t off, const float* f) {
+    if (!LO) {
+        *reinterpret_cast<uint4*>(hi + off) = make_uint4(pack2_rne(f[0], f[1]), pack2_rne(f[2], f[3]), pack2_rne(f[4], f[5]), pack2_rne(f[6], f[7]));
+        return;
+    }
     bf16_t h[8], l[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        if (LO) f2bf_hilo(f[k], h[k], l[k]);
-        else h[k] = f2bf(f[k]);
-    }
+    for (int k = 0; k < 8; ++k) f2bf_hilo(f[k], h[k], l[k]);
     *reinterpret_cast<uint4*>(hi + off) = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
     if (LO) *reinterpret_cast<uint4*>(lo + off) = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
 }
@@ -317,7 +337,7 @@ __device__ __forceinline__ void store8(bf16_t* hi, bf16_t* lo, size_t off, const
 template <bool LO>
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* __restrict__ u_lo,
                                                         bf16_t* __restrict__ o_hi, bf16_t* __restrict__ o_lo, long long R, int FP) {
-    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= R) return;
     const size_t ub = (size_t)row * 2 * FP, ob = (size_t)row * FP;
     for (int c = (threadIdx.x & 63) * 8; c < FP; c += 512) {
@@ -334,7 +354,7 @@ template <bool LO>
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* __restrict__ u_lo,
                                                         const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
                                                         bf16_t* __restrict__ du_hi, bf16_t* __restrict__ du_lo, long long R, int FP) {
-    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= R) return;
     const size_t ub = (size_t)row * 2 * FP, db = (size_t)row * FP;
     for (int c = (threadIdx.x & 63) * 8; c < FP; c += 512) {
@@ -402,7 +422,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
                                                         const float* __restrict__ ax3, const float* __restrict__ bos,
                                                         float* __restrict__ x, int B, int ntok, int D, int H, int Wd, float frac) {
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= (long long)B * ntok) return;
     const int b = (int)(row / ntok), i = (int)(row % ntok);
     float* o = x + row * D;
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
 __global__ __launch_bounds__(256) void embed_bwd_tok_kernel(const long long* __restrict__ ids, const float* __restrict__ dx,
                                                             float* __restrict__ dW, int B, int ntok, int D, float frac) {
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= (long long)B * ntok) return;
     const int b = (int)(row / ntok), i = (int)(row % ntok);
     if (i == 0) return;
@@ -554,13 +574,16 @@ inline int grid_for(size_t work, int per_block = 256, int cap = 4096) {
 extern "C" int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const float* b, uint16_t* out_hi,
                               uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R,
                               int D, int mode, int stable, float eps, hipStream_t stream) {
+    const bool xbf = (mode & AMDNUWA_LN_X_BF16) != 0;        // x points at bf16 values
+    mode &= 1;
     if (!x || !w || !b || !mean || !rstd || D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
     if (mode == 0 && !out_hi) return AMDNUWA_ERR_ARG;
     if (mode == 1 && (!out_f32 || !resid || stable)) return AMDNUWA_ERR_ARG;
     if (stable && !inv_amax) return AMDNUWA_ERR_ARG;
     if (R <= 0) return AMDNUWA_OK;
     dim3 grid((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
-#define LNF(MO, ST, NV_) hipLaunchKernelGGL((ln_fwd_kernel<MO, ST, NV_>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps)
+#define LNF(MO, ST, NV_) do { if (xbf) hipLaunchKernelGGL((ln_fwd_kernel<MO, ST, NV_, true>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps); \
+                              else hipLaunchKernelGGL((ln_fwd_kernel<MO, ST, NV_, false>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps); } while (0)
 #define LNF_NV(MO, ST) do { if (D <= 256) LNF(MO, ST, 1); else if (D <= 512) LNF(MO, ST, 2); else LNF(MO, ST, 4); } while (0)
     if (mode == 0 && !stable) LNF_NV(0, false);
     else if (mode == 0) LNF_NV(0, true);
@@ -583,21 +606,32 @@ extern "C" int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean
                               const float* w, uint16_t* dx_hi, uint16_t* dx_lo, float* dx_acc, const float* dres, float* dw, float* db,
                               float* dsum, long long R, int D, int shift_ntok, int shift_fmap, int stable, int accumulate,
                               void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const int in_kind = (stable & AMDNUWA_LN_X_BF16) ? 1 : ((stable & AMDNUWA_LN_DY_BF16) ? 2 : 0);
+    if ((stable & AMDNUWA_LN_X_BF16) && (stable & AMDNUWA_LN_DY_BF16)) return AMDNUWA_ERR_UNSUPPORTED;
+    stable &= 1;
     if (!dy || !x || !mean || !rstd || !w || D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
     if ((dx_hi == nullptr) == (dx_acc == nullptr)) return AMDNUWA_ERR_ARG;   // exactly one output form
     if (shift_ntok > 0 && (shift_fmap <= 0 || D % 16)) return AMDNUWA_ERR_ARG;
     if (stable && !inv_amax) return AMDNUWA_ERR_ARG;
     if (!workspace || workspace_bytes < amdnuwa_ln_bwd_workspace_bytes(R, D)) return AMDNUWA_ERR_WORKSPACE;
     if (R <= 0) return AMDNUWA_OK;
-    const int nb = ln_bwd_blocks(R);
+    // one resident wave of blocks exactly (occupancy x CUs): a grid-stride kernel with 1.5 rounds of blocks idles half the chip
+    // for its second round
+    int nb = ln_bwd_blocks(R);
     float* part = (float*)workspace;
-    dim3 grid(nb), block(256);
-#define LNB(OU, ST, NV_) hipLaunchKernelGGL((ln_bwd_kernel<OU, ST, NV_>), grid, block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap)
+    const dim3 block(256);
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+#define LNB_OCC(OU, ST, NV_, IN_) do { int o_ = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_, ln_bwd_kernel<OU, ST, NV_, IN_>, 256, 0) == hipSuccess && o_ > 0 && o_ * n_cu < nb) nb = o_ * n_cu; } while (0)
+#define LNB_(OU, ST, NV_, IN_) do { LNB_OCC(OU, ST, NV_, IN_); hipLaunchKernelGGL((ln_bwd_kernel<OU, ST, NV_, IN_>), dim3(nb), block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap); } while (0)
+#define LNB(OU, ST, NV_) do { if (in_kind == 1) LNB_(OU, ST, NV_, 1); else if (in_kind == 2) LNB_(OU, ST, NV_, 2); else LNB_(OU, ST, NV_, 0); } while (0)
 #define LNB_NV(OU, ST) do { if (D <= 256) LNB(OU, ST, 1); else if (D <= 512) LNB(OU, ST, 2); else LNB(OU, ST, 4); } while (0)
     if (dx_hi) { if (stable) LNB_NV(0, true); else LNB_NV(0, false); }
     else       { if (stable) LNB_NV(1, true); else LNB_NV(1, false); }
 #undef LNB_NV
 #undef LNB
+#undef LNB_
+#undef LNB_OCC
     LAUNCH_CHECK();
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((3 * D + 15) / 16), dim3(1024), 0, stream, part, nb, 3, D, dw, db, dsum, accumulate);
     LAUNCH_CHECK();

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[i][j][r] * p.alpha;
-                if (EPI == 0 && p.bias && n + r < p.N) v[r] += p.bias[n + r];
+                if (p.bias && n + r < p.N) v[r] += p.bias[n + r];
             }
             if (EPI == 0) {
                 float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[i][j][r] * p.alpha;
-                if (EPI == 0 && p.bias && n + r < p.N) v[r] += p.bias[n + r];
+                if (p.bias && n + r < p.N) v[r] += p.bias[n + r];
             }
             if (EPI == 0) {
                 float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
@@ -539,13 +539,25 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
             const int nb = n0 + wn * 64 + fg * 16;
             if (nb >= p.N) continue;
             if ((p.dbg & 1) && acc[i][0][0] != 12345.678f) continue;
-            bf16_t h[16], l[16];
+            float vv[16];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) f2bf_hilo(acc[i][j][r] * p.alpha, h[j * 4 + r], l[j * 4 + r]);
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] * p.alpha;
+                    if (p.bias && nb + j * 4 + r < p.N) v += p.bias[nb + j * 4 + r];
+                    vv[j * 4 + r] = v;
+                }
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
             bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;
+            if (!Cl && vec8 && nb + 16 <= p.N) {
+                reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
+                reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
+                continue;
+            }
+            bf16_t h[16], l[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) f2bf_hilo(vv[e], h[e], l[e]);
             if (vec8 && nb + 16 <= p.N) {
                 reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
                 reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2(h[8], h[9]), pack2(h[10], h[11]), pack2(h[12], h[13]), pack2(h[14], h[15]));

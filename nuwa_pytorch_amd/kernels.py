@@ -161,31 +161,44 @@ def gemm_tn_batched(desc, device):
 # row kernels
 # ------------------------------------------------------------------------------------------------
 
+LN_X_BF16, LN_DY_BF16 = 16, 32       # == AMDNUWA_LN_X_BF16 / AMDNUWA_LN_DY_BF16
+
+
+def _f32_or_bf(t):
+    """(data pointer, is_bf16, shape, device) of an fp32 tensor or a BF pair without lo part"""
+    if isinstance(t, BF):
+        assert t.lo is None, 'bf16 inputs to the LN kernels are the fast-mode (hi only) form'
+        return _p(t.hi), True, t.hi.shape, t.hi.device
+    return _p(t), False, t.shape, t.device
+
+
 def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5):
-    """x fp32 [R, D] contiguous.  resid None -> (BF out, mean, rstd, inv_amax); else (fp32 out = resid + LN(x), mean, rstd)"""
+    """x fp32 [R, D] contiguous (or a hi-only BF pair).  resid None -> (BF out, mean, rstd, inv_amax);
+    else (fp32 out = resid + LN(x), mean, rstd)"""
     L = _lib.lib()
-    R, D = x.shape
-    dev = x.device
-    _chk_dev(x)
+    xp, xbf, (R, D), dev = _f32_or_bf(x)
+    flag = LN_X_BF16 if xbf else 0
     mean = torch.empty(R, dtype=torch.float32, device=dev)
     rstd = torch.empty(R, dtype=torch.float32, device=dev)
     if resid is None:
         out = empty_bf((R, D), dev)
         ia = torch.empty(R, dtype=torch.float32, device=dev) if stable else None
-        check(L.amdnuwa_ln_fwd(_p(x), None, _p(w), _p(b), _p(out.hi), _p(out.lo), None, _p(mean), _p(rstd), _p(ia),
-                               R, D, 0, 1 if stable else 0, eps, _stream()), 'amdnuwa_ln_fwd')
+        check(L.amdnuwa_ln_fwd(xp, None, _p(w), _p(b), _p(out.hi), _p(out.lo), None, _p(mean), _p(rstd), _p(ia),
+                               R, D, 0 | flag, 1 if stable else 0, eps, _stream()), 'amdnuwa_ln_fwd')
         return out, mean, rstd, ia
-    out = torch.empty_like(x)
-    check(L.amdnuwa_ln_fwd(_p(x), _p(resid), _p(w), _p(b), None, None, _p(out), _p(mean), _p(rstd), None,
-                           R, D, 1, 0, eps, _stream()), 'amdnuwa_ln_fwd')
+    out = torch.empty_like(resid)
+    check(L.amdnuwa_ln_fwd(xp, _p(resid), _p(w), _p(b), None, None, _p(out), _p(mean), _p(rstd), None,
+                           R, D, 1 | flag, 0, eps, _stream()), 'amdnuwa_ln_fwd')
     return out, mean, rstd
 
 
 def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift=None, want_dsum=False):
-    """returns (dx, dw, db, dsum).  to_bf: dx as BF pair; else dx fp32 = dres + dx_ln (dres may be None -> zeros)."""
+    """returns (dx, dw, db, dsum).  to_bf: dx as BF pair; else dx fp32 = dres + dx_ln (dres may be None -> zeros).
+    dy / x: fp32 tensors, or (one of them) a hi-only BF pair."""
     L = _lib.lib()
-    R, D = x.shape
-    dev = x.device
+    dyp, dybf, _, _ = _f32_or_bf(dy)
+    xp, xbf, (R, D), dev = _f32_or_bf(x)
+    st = (1 if inv_amax is not None else 0) | (LN_X_BF16 if xbf else 0) | (LN_DY_BF16 if dybf else 0)
     dw = torch.empty(D, dtype=torch.float32, device=dev)
     db = torch.empty(D, dtype=torch.float32, device=dev)
     ds = torch.empty(D, dtype=torch.float32, device=dev) if want_dsum else None
@@ -194,9 +207,8 @@ def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift
     sn, sf = (int(shift[0]), int(shift[1])) if shift is not None else (0, 0)
     if to_bf:
         dx = empty_bf((R, D), dev)
-        check(L.amdnuwa_ln_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(inv_amax), _p(w), _p(dx.hi), _p(dx.lo), None, None,
-                               _p(dw), _p(db), _p(ds), R, D, sn, sf, 1 if inv_amax is not None else 0, 0, _p(ws), nb,
-                               _stream()), 'amdnuwa_ln_bwd')
+        check(L.amdnuwa_ln_bwd(dyp, xp, _p(mean), _p(rstd), _p(inv_amax), _p(w), _p(dx.hi), _p(dx.lo), None, None,
+                               _p(dw), _p(db), _p(ds), R, D, sn, sf, st, 0, _p(ws), nb, _stream()), 'amdnuwa_ln_bwd')
     else:
         if dres is None:
             dx = torch.zeros((R, D), dtype=torch.float32, device=dev)
@@ -204,9 +216,8 @@ def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift
         else:
             dx = torch.empty((R, D), dtype=torch.float32, device=dev)
             dr = dres
-        check(L.amdnuwa_ln_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(inv_amax), _p(w), None, None, _p(dx), _p(dr),
-                               _p(dw), _p(db), _p(ds), R, D, sn, sf, 1 if inv_amax is not None else 0, 0, _p(ws), nb,
-                               _stream()), 'amdnuwa_ln_bwd')
+        check(L.amdnuwa_ln_bwd(dyp, xp, _p(mean), _p(rstd), _p(inv_amax), _p(w), None, None, _p(dx), _p(dr),
+                               _p(dw), _p(db), _p(ds), R, D, sn, sf, st, 0, _p(ws), nb, _stream()), 'amdnuwa_ln_bwd')
     return dx, dw, db, ds
 
 

@@ -86,7 +86,7 @@ class S3Inner:
         g = meta['geom']
         qkv = K.gemm_nt(h, W['qkv'], out_bf16=True, shift=meta.get('shift'))
         o = K.sparse3dna_fwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous())
-        y = K.gemm_nt(o, W['out'], bias=bo.detach())
+        y = K.gemm_nt(o, W['out'], bias=bo.detach(), out_bf16=_fast())
         return y, (h, qkv, o)
 
     @staticmethod
@@ -100,11 +100,11 @@ class S3Inner:
         dwo = torch.empty_like(wo)
         K.gemm_tn(dy, o, dwo)
         dqkv, dwth = K.sparse3dna_bwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), d_o)
-        dh = K.gemm_nt(dqkv, W['qkvT'])
-        dwq, dwkv = torch.empty_like(wq), torch.empty_like(wkv)
+        dh = K.gemm_nt(dqkv, W['qkvT'], out_bf16=_fast())
         sh = meta.get('shift')
-        K.gemm_tn(K.view(dqkv, cols=slice(0, inner)), h, dwq, shift=sh)
-        K.gemm_tn(K.view(dqkv, cols=slice(inner, 3 * inner)), h, dwkv, shift=sh)
+        dwqkv = torch.empty((3 * inner, wq.shape[1]), dtype=torch.float32, device=wq.device)   # one wgrad GEMM for [to_q; to_kv]
+        K.gemm_tn(dqkv, h, dwqkv, shift=sh)
+        dwq, dwkv = dwqkv[:inner], dwqkv[inner:]
         dbo = K.colsum(dy_f32) if (need_dbias and dy_f32 is not None) else None
         return dh, None, [dwq, dwkv, dwth.reshape(wth.shape), dwo, dbo]
 
@@ -132,7 +132,7 @@ class XInner:
                           nv.detach().reshape(g.heads, g.dim_head).contiguous(), meta['mask_u8'])
         wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
         o, P, Pm = K.xattn_fwd(g, q, pk, wth2, save=meta.get('save', True))
-        y = K.gemm_nt(o, W['out'])
+        y = K.gemm_nt(o, W['out'], out_bf16=_fast())
         return y, (h, ctx, q, pk, P, Pm, o)
 
     @staticmethod
@@ -148,7 +148,7 @@ class XInner:
         dq, dS, dwth = K.xattn_bwd(g, d_o, pk, wth2, P)
         dKp, dVp = K.xattn_kv_grads(g, dS, Pm, q, d_o)
         dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=dy.lo is not None)
-        dh = K.gemm_nt(dq, W['qT'])
+        dh = K.gemm_nt(dq, W['qT'], out_bf16=_fast())
         dwq, dwkv = torch.empty_like(wq), torch.empty_like(wkv)
         K.gemm_tn(dq, h, dwq)
         K.gemm_tn(dkv, ctx, dwkv)
@@ -187,7 +187,7 @@ class FFInner:
         W = FFInner.weights(meta['cache'], p)
         u = K.gemm_nt(h, W['w1'], out_bf16=True, shift=meta.get('shift'))
         gg = K.geglu_fwd(u, W['FP'])
-        y = K.gemm_nt(gg, W['w2'])
+        y = K.gemm_nt(gg, W['w2'], out_bf16=_fast())
         return y, (h, u, gg)
 
     @staticmethod
@@ -200,15 +200,29 @@ class FFInner:
         dw2 = torch.empty_like(w2)
         K.gemm_tn(dy, gg, dw2, N2=FFI)
         du = K.geglu_bwd(u, dgg, FP)
-        dh = K.gemm_nt(du, W['w1T'])
-        dw1 = torch.empty_like(w1)
+        dh = K.gemm_nt(du, W['w1T'], out_bf16=_fast())
         sh = meta.get('shift')
-        K.gemm_tn(K.view(du, cols=slice(0, FP)), h, dw1[:FFI], shift=sh, N1=FFI)
-        K.gemm_tn(K.view(du, cols=slice(FP, 2 * FP)), h, dw1[FFI:], shift=sh, N1=FFI)
+        if FP == FFI:
+            dw1 = torch.empty_like(w1)
+            K.gemm_tn(du, h, dw1, shift=sh)
+        else:                                   # one wgrad GEMM over the padded [a | gate] layout, then drop the (zero) pad rows
+            dw1p = torch.empty((2 * FP, w1.shape[1]), dtype=torch.float32, device=w1.device)
+            K.gemm_tn(du, h, dw1p, shift=sh)
+            dw1 = torch.cat((dw1p[:FFI], dw1p[FP:FP + FFI]), 0)
         return dh, None, [dw1, dw2]
 
 
 INNERS = {'s3': S3Inner, 'xattn': XInner, 'ff': FFInner}
+
+
+def _fast():
+    """fast bf16 mode: the GEMMs that feed a LayerNorm (to_out / FF w2 outputs, dgrad outputs) write bf16 and the LN kernels
+    read bf16 -- half the epilogue and LN traffic.  Parity mode (bf16x3) keeps those tensors in fp32."""
+    return not K.want_lo()
+
+
+def _as_f32(t):
+    return t.hi.float() if isinstance(t, K.BF) else t
 
 
 def _ctx_to_bf(context):
@@ -242,13 +256,16 @@ class SandwichBlockFn(Function):
         ctx.meta, ctx.inner_saved, ctx.p = meta, saved, p
         ctx.has_ctx = context is not None
         ctx.has_resid = resid is not None
-        ctx.save_for_backward(x2, y, m1, r1, m2, r2, pre_w, post_w)
+        ctx.y_bf = isinstance(y, K.BF)
+        ctx.save_for_backward(x2, y.hi if ctx.y_bf else y, m1, r1, m2, r2, pre_w, post_w)
         ctx.shape = (B, n, D)
         return xo.reshape(B, n, D)
 
     @staticmethod
     def backward(ctx, g):
         x2, y, m1, r1, m2, r2, pre_w, post_w = ctx.saved_tensors
+        if ctx.y_bf:
+            y = K.BF(y, None)
         B, n, D = ctx.shape
         meta, p = ctx.meta, ctx.p
         inner = INNERS[meta['kind']]
@@ -288,6 +305,7 @@ class InnerFn(Function):
         ctx.meta, ctx.inner_saved, ctx.p = meta, saved, p
         ctx.has_ctx = context is not None
         ctx.shape = (B, n, D)
+        y = _as_f32(y)
         return y.reshape(B, n, y.shape[-1])
 
     @staticmethod
@@ -301,7 +319,7 @@ class InnerFn(Function):
         dh, dctx, grads = inner.bwd(ctx.inner_saved, dy, p, meta, need_dbias=True, dy_f32=g2)
         dcontext = dctx.reshape(B, meta['xgeom'].T, D) if ctx.has_ctx else None
         ctx.inner_saved = None
-        return (dh.reshape(B, n, D), dcontext, None, *grads)
+        return (_as_f32(dh).reshape(B, n, D), dcontext, None, *grads)
 
 
 # =================================================================================================

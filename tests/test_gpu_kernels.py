@@ -135,6 +135,29 @@ def test_layernorm_fwd_bwd(K, R, D):
         K.set_precision('bf16')
 
 
+@pytest.mark.parametrize('R,D', [(130, 512), (33, 48)])
+def test_layernorm_bf16_inputs(K, R, D):
+    """fast-mode forms: the LN input (GEMM output) or the incoming gradient arrive as bf16; results must equal the fp32
+    kernels run on the same bf16-rounded values"""
+    torch.manual_seed(14)
+    xb = (torch.randn(R, D) * 2 + 0.5).to(torch.bfloat16)
+    gb = torch.randn(R, D).to(torch.bfloat16)
+    x32, g32 = xb.float().to(DEV), gb.float().to(DEV)
+    res, g = torch.randn(R, D, device=DEV), torch.randn(R, D, device=DEV)
+    w, b = torch.randn(D, device=DEV), torch.randn(D, device=DEV)
+    xbf, gbf = K.BF(xb.to(DEV), None), K.BF(gb.to(DEV), None)
+    y0, m0, r0 = K.ln_fwd(x32, w, b, resid=res)
+    y1, m1, r1 = K.ln_fwd(xbf, w, b, resid=res)
+    assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1)
+    a0 = K.ln_bwd(g, x32, m0, r0, w, to_bf=True, want_dsum=True)
+    a1 = K.ln_bwd(g, xbf, m0, r0, w, to_bf=True, want_dsum=True)
+    assert torch.equal(a0[0].hi, a1[0].hi) and all(torch.equal(p, q) for p, q in zip(a0[1:], a1[1:]))
+    for shift in (None, (11, 2)) if R == 33 else (None,):
+        b0 = K.ln_bwd(g32, res, m0, r0, w, dres=g, shift=shift)
+        b1 = K.ln_bwd(gbf, res, m0, r0, w, dres=g, shift=shift)
+        assert all(torch.equal(p, q) for p, q in zip(b0[:3], b1[:3]))
+
+
 def test_layernorm_bwd_inverse_shift(K, O):
     torch.manual_seed(5)
     B, ntok, fmap, D = 2, 23, 4, 32
