@@ -188,6 +188,19 @@ int amdnuwa_xattn_unpack(const amdnuwa_xattn_geom* g, const float* dKp, const fl
                          uint16_t* dkv_lo, int ldkv, float* dnull_k, float* dnull_v, int accumulate,
                          amdnuwa_stream stream);
 
+/* ---- cross-attention core, second design (fast bf16 mode only: heads == 8, dim_head == 64, T + 1 <= 288) --------------
+ * One wave = 16 queries x all heads, head mix in registers, K/V chunks shared through a direct-to-LDS ring; the forward saves
+ * only the softmax statistics stats[B][heads][n][2] = (row max, 1 / row sum) and the backward recomputes the probabilities.
+ * _bwd writes dS and Pm ([B][heads][n][JP] bf16, as amdnuwa_xattn_bwd / _fwd do) for the batched dK / dV GEMMs, dq, and the
+ * per-workgroup talking-heads partials part_th (reduce with amdnuwa_colsum or the Python side). */
+int amdnuwa_xattn2_supported(const amdnuwa_xattn_geom* g);
+int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const amdnuwa_xattn_kv* packed,
+                       const float* w_th, uint16_t* o, int ldo, float* stats, amdnuwa_stream stream);
+size_t amdnuwa_xattn2_bwd_workspace_bytes(const amdnuwa_xattn_geom* g);
+int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
+                       const amdnuwa_xattn_kv* packed, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm,
+                       uint16_t* dq, int lddq, float* part_th, size_t part_bytes, amdnuwa_stream stream);
+
 /* ---- frozen VQGanVAE tokenizer (VQGanVAE.get_video_indices -> encode, reference vqgan_vae.py:431-435, 452-458), exact fp32 ---- */
 typedef struct {
     int N, Cin, H, W, Cout, KH, KW, stride, pad;

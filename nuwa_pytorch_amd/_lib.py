@@ -81,6 +81,10 @@ SIGNATURES = {
     'amdnuwa_xattn_bwd_workspace_bytes': (SZ, [XG]),
     'amdnuwa_xattn_bwd': (I, [XG, P, P, I, XK, P, P, P, P, P, P, P, I, P, I, P, SZ, P]),
     'amdnuwa_xattn_unpack': (I, [XG, P, P, P, P, I, P, P, I, P]),
+    'amdnuwa_xattn2_supported': (I, [XG]),
+    'amdnuwa_xattn2_fwd': (I, [XG, P, I, XK, P, P, I, P, P]),
+    'amdnuwa_xattn2_bwd_workspace_bytes': (SZ, [XG]),
+    'amdnuwa_xattn2_bwd': (I, [XG, P, I, P, I, XK, P, P, P, P, P, I, P, SZ, P]),
     'amdnuwa_conv2d_fwd': (I, [CD, P, P, P, P, P]),
     'amdnuwa_groupnorm_fwd': (I, [P, P, P, P, I, I, I, I, F, I, P]),
     'amdnuwa_vq_argmax': (I, [P, P, P, P, LL, I, I, P]),

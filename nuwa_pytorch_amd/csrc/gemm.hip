@@ -394,7 +394,7 @@ __device__ __forceinline__ int b256_off(int row, int cc) { return row * 64 + ((c
 template <int EPI>
 __device__ __forceinline__ int b256_row(int j, int fr) { return EPI == 1 ? ((fr >> 2) * 16 + j * 4 + (fr & 3)) : (j * 16 + fr); }
 
-template <bool SHIFT, int EPI, int NS, int WNW, bool STAG = false>
+template <bool SHIFT, int EPI, int NS, int WNW, int STAG = 0>
 __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 2 * WNW, BN = 64 * WNW;
@@ -436,23 +436,24 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
         pb[j] = gb < p.N ? p.B + oB + gb * p.ldb + cc * 8 : nullptr;
     }
     const int quarter = SHIFT ? (p.shift_dim >> 2) : 1;
+    auto issue_a = [&](int j, int slot, int k0) {
+        const bf16_t* sa = pa[j];
+        if (SHIFT) {
+            const int kq = k0 + cca[j] * 8, q = (kq >= quarter) + (kq >= 2 * quarter);   // >= 2 -> unshifted half
+            sa = q == 0 ? pah[j] : (q == 1 ? paw[j] : pa[j]);
+        }
+        const bf16_t* srca = sa ? sa + k0 : zp;
+        __builtin_amdgcn_global_load_lds((glb_cvptr)srca, (lds_vptr)(smem + slot * STG + (j * NW + wave) * 1024), 16, 0, 0);
+    };
+    auto issue_b = [&](int j, int slot, int k0) {
+        const bf16_t* srcb = pb[j] ? pb[j] + k0 : zp;
+        __builtin_amdgcn_global_load_lds((glb_cvptr)srcb, (lds_vptr)(smem + slot * STG + TB + (j * NW + wave) * 1024), 16, 0, 0);
+    };
     auto issue = [&](int slot, int k0) {
-        char* base = smem + slot * STG;
 #pragma unroll
-        for (int j = 0; j < PA; ++j) {
-            const bf16_t* sa = pa[j];
-            if (SHIFT) {
-                const int kq = k0 + cca[j] * 8, q = (kq >= quarter) + (kq >= 2 * quarter);   // >= 2 -> unshifted half
-                sa = q == 0 ? pah[j] : (q == 1 ? paw[j] : pa[j]);
-            }
-            const bf16_t* srca = sa ? sa + k0 : zp;
-            __builtin_amdgcn_global_load_lds((glb_cvptr)srca, (lds_vptr)(base + (j * NW + wave) * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < PA; ++j) issue_a(j, slot, k0);
 #pragma unroll
-        for (int j = 0; j < PB; ++j) {
-            const bf16_t* srcb = pb[j] ? pb[j] + k0 : zp;
-            __builtin_amdgcn_global_load_lds((glb_cvptr)srcb, (lds_vptr)(base + TB + (j * NW + wave) * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < PB; ++j) issue_b(j, slot, k0);
     };
 
     f32x4 acc[8][4];
@@ -467,7 +468,44 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, s * 32);
     const int fr = lane & 15, fg = lane >> 4;
-    if constexpr (STAG) {
+    if constexpr (STAG == 2) {
+        // as STAG 1, but the 4 DMA pieces of the restaged tile are issued INSIDE the MFMA phase, one after every 8 MFMAs (a DMA
+        // issue costs ~60 cycles in the shadow of bare MFMAs against 100-185 in a phase that is also pulling fragments out of
+        // LDS), so the read phase shrinks to the 12 ds_read_b128.  The leading wave row therefore retires tile kt+1 at the END of
+        // its MFMA phase, the lagging row at the end of its read phase -- both one barrier before anyone reads that tile.
+        static_assert(PA + PB == 4 && PA == 2 && NS == 4, "written for the 8-wave 4-stage ring");
+        if (nk >= 3) VMCNT(8); else if (nk == 2) VMCNT(4); else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* base = smem + (kt % NS) * STG;
+            bf16x8 af[8], bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(base + TB + b256_off<EPI>(wn * 64 + b256_row<EPI>(j, fr), fg));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + glds_off<32>(wm * 128 + i * 16 + fr, fg));
+            const int rem2 = nk - 2 - kt;
+            if (wm == 1) { if (rem2 >= 1) VMCNT(4); else VMCNT(0); }      // lagging row: tiles <= kt+2 issued so far
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more = kt + NS - 1 < nk;
+            const int nslot = (kt + NS - 1) % NS, nk0 = (kt + NS - 1) * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int i = 2 * q; i < 2 * q + 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                if (more) { if (q < 2) issue_a(q, nslot, nk0); else issue_b(q - 2, nslot, nk0); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (wm == 0) { if (rem2 >= 2) VMCNT(8); else if (rem2 == 1) VMCNT(4); else VMCNT(0); }   // leading row: tiles <= kt+3 issued
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();
+    } else if constexpr (STAG == 1) {
         static_assert(PA + PB == 4 && NS == 4, "staggered schedule is written for the 8-wave 4-stage ring");
         // tile 0 landed (for this wave: at most the later prologue tiles still in flight), then for everyone
         if (nk >= 3) VMCNT(8); else if (nk == 2) VMCNT(4); else VMCNT(0);
@@ -1078,14 +1116,28 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         LAUNCH_CHECK();
         return AMDNUWA_OK;
     }
+    if (!x3 && variant == 8 && d->K % 32 == 0) {                           // staggered rows + DMA issue inside the MFMA phase
+        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
+        dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(512);
+#define GS2(SH, EP)                                                                                                   \
+    do {                                                                                                              \
+        const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;                                                               \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<SH, EP, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
+        hipLaunchKernelGGL((gemm_nt_256_kernel<SH, EP, 4, 4, 2>), g2, b2, l2, stream, p);                              \
+    } while (0)
+        if (sh) { if (ob) GS2(true, 1); else GS2(true, 0); } else { if (ob) GS2(false, 1); else GS2(false, 0); }
+#undef GS2
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
+    }
     if (!x3 && variant == 7 && d->K % 32 == 0) {                           // 256x256 tile, 4-stage ring, staggered wave rows
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(512);
 #define GS(SH, EP)                                                                                                    \
     do {                                                                                                              \
         const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;                                                               \
-        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<SH, EP, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
-        hipLaunchKernelGGL((gemm_nt_256_kernel<SH, EP, 4, 4, true>), g2, b2, l2, stream, p);                           \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<SH, EP, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
+        hipLaunchKernelGGL((gemm_nt_256_kernel<SH, EP, 4, 4, 1>), g2, b2, l2, stream, p);                           \
     } while (0)
         if (sh) { if (ob) GS(true, 1); else GS(true, 0); } else { if (ob) GS(false, 1); else GS(false, 0); }
 #undef GS

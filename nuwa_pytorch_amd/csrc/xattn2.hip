@@ -1,0 +1,469 @@
+// Text cross-attention core, second design (fast bf16 mode, 8 heads x dim_head 64): np.py:339-378.
+//
+// The first design (xattn.hip) gives every head its own wave and moves the softmax probabilities of a 32-key chunk
+// through LDS so the talking-heads Conv2d(h, h, 1) can mix them -- two workgroup barriers per chunk -- and saves P and P'
+// (2 x [B][h][n][JP] bf16) for the backward.  Here ONE WAVE owns 16 queries and ALL 8 heads:
+//
+//   * S^T[h] = K[h] Q[h]^T (keys x queries) for h = 0..7 lands in the SAME lane positions of 8 accumulators, so the head mix
+//     P'[g] = sum_h W[g][h] P[h] is 64 register FMAs per value set -- no cross-wave traffic at all;
+//   * the 4 waves of a workgroup (64 queries) share each 32-key chunk of K / V (all heads, 64 KiB) through a double-buffered
+//     direct-to-LDS ring (global_load_lds, swizzle on the source address, counted vmcnt + raw s_barrier);
+//   * the softmax is two-pass: pass 1 = running (max, sum) per (head, query) from QK^T only, pass 2 recomputes QK^T (MFMA is
+//     nearly free here), normalises, mixes, and feeds P'^T straight back as the B operand of O^T = V^T P'^T using the
+//     permuted-key trick (C-layout registers = k-slots);
+//   * only the statistics (max, 1/sum) are saved: the backward RECOMPUTES P the same way.
+//
+// Backward (query-centric): pass A = delta[h][q] = sum_j dP[h] P[h], dW_th, and P' (bf16, for dV); pass B = ds = P (dP - delta),
+// dq = scale * ds K (K^T fragments via ds_read_b64_tr_b16 out of the same K tile), ds written bf16.  dK / dV stay batched TN
+// GEMMs over ds / P' (reduction over the 2560 queries), as in the first design.
+#include "common.h"
+#include "../../include/amdnuwa.h"
+
+namespace {
+
+constexpr int NH = 8, DH = 64, KS = 2, DB = 4;
+constexpr int TILE = 32 * DH * 2;            // one head's 32-key tile of K, V ([key][d]) or V^T ([d][key]): 4 KiB
+constexpr int KT_BYTES = NH * TILE;          // 32 KiB
+constexpr int STAGE = 2 * KT_BYTES;          // K + V per chunk
+constexpr float NEG_MAX = -3.4028234663852886e38f;
+
+struct X2Args {
+    const bf16_t* q; int ldq;
+    const bf16_t *Kp, *Vp, *Vt;              // [B][NH][JP][DH] / [B][NH][DH][JP]
+    const uint8_t* valid;                    // [B][JP]
+    const float* wth;                        // [NH][NH]
+    bf16_t* o; int ldo;
+    float* stats;                            // [B][NH][n][2] = (row max of the scaled, masked scores; 1 / sum of exp)
+    const bf16_t* dO; int lddo;
+    bf16_t *dS, *Pm;                         // [B][NH][n][JP]
+    bf16_t* dq; int lddq;
+    float* part_th;                          // [grid][NH*NH]
+    int B, n, JP, nch;
+    float scale;
+};
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef __attribute__((address_space(1))) const void* glb_cvptr;
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+// [key][d] tile (128-byte rows): 16-byte chunk gc of row r sits at chunk position gc ^ (r & 7)
+__device__ __forceinline__ int kd_off(int h, int row, int gc) { return h * TILE + row * 128 + ((gc ^ (row & 7)) << 4); }
+// [d][key] tile (64-byte rows): chunk gc of row d sits at gc ^ ((d >> 2) & 3)
+__device__ __forceinline__ int dk_off(int h, int d, int gc) { return h * TILE + d * 64 + ((gc ^ ((d >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ bf16x8 lds16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 lds8x2(const char* p0, const char* p1) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p0), b = *reinterpret_cast<const uint2*>(p1);
+    return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+}
+__device__ __forceinline__ bf16x8 ldg16(const bf16_t* p, bool ok) {
+    return __builtin_bit_cast(bf16x8, ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0));
+}
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+    return __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(v[0], v[1]), pack2_rne(v[2], v[3]), pack2_rne(v[4], v[5]), pack2_rne(v[6], v[7])));
+}
+// K^T (or any [key][d] tile read transposed): lane (c, g4) gets tile[kb*16 + 4*g4 + j][db*16 + c], j = 0..3, for kb = 0, 1:
+// the A operand [row = d][k-slot (g4, j)] of dq^T = K^T ds^T under the permuted-key convention
+__device__ __forceinline__ bf16x8 lds_tr(const char* base, int h, int db, int c, int g4) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int col = db * 16 + ((c & 3) << 2);                    // first of the 4 d columns this lane ADDRESSES
+    const int r0 = 4 * g4 + (c >> 2), r1 = 16 + r0;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + kd_off(h, r0, col >> 3) + ((col >> 2) & 1) * 8));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + kd_off(h, r1, col >> 3) + ((col >> 2) & 1) * 8));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// one 32-key chunk -> LDS stage `buf`: tile A (always [key][d], from `A`) and tile B ([key][d] when B_KD, else [d][key]).
+// 32 + 32 one-KiB DMA pieces, 8 + 8 per wave.
+template <bool WITH_B, bool B_KD>
+__device__ __forceinline__ void stage_chunk(char* smem, int buf, int ch, int b, int JP, const bf16_t* A, const bf16_t* Bsrc, int wave, int lane) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int pi = wave + 4 * i, h = pi >> 2, p = pi & 3;
+        const int r = 8 * p + (lane >> 3), gc = (lane & 7) ^ (lane >> 3);
+        const bf16_t* src = A + ((size_t)(b * NH + h) * JP + ch * 32 + r) * DH + gc * 8;
+        __builtin_amdgcn_global_load_lds((glb_cvptr)src, (lds_vptr)(base + h * TILE + p * 1024), 16, 0, 0);
+    }
+    if (WITH_B) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pi = wave + 4 * i, h = pi >> 2, p = pi & 3;
+            const bf16_t* src;
+            if (B_KD) {
+                const int r = 8 * p + (lane >> 3), gc = (lane & 7) ^ (lane >> 3);
+                src = Bsrc + ((size_t)(b * NH + h) * JP + ch * 32 + r) * DH + gc * 8;
+            } else {
+                const int d = 16 * p + (lane >> 2), gc = (lane & 3) ^ ((d >> 2) & 3);
+                src = Bsrc + ((size_t)(b * NH + h) * DH + d) * JP + ch * 32 + gc * 8;
+            }
+            __builtin_amdgcn_global_load_lds((glb_cvptr)src, (lds_vptr)(base + KT_BYTES + h * TILE + p * 1024), 16, 0, 0);
+        }
+    }
+}
+
+// S^T chunk of head h: rows = keys (2 blocks of 16), cols = the wave's 16 queries
+__device__ __forceinline__ void qk_chunk(const char* base, int h, int c, int g4, const bf16x8 (&qf)[KS], f32x4& s0, f32x4& s1) {
+    s0 = s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 k0 = lds16(base + kd_off(h, c, ks * 4 + g4));
+        const bf16x8 k1 = lds16(base + kd_off(h, 16 + c, ks * 4 + g4));
+        s0 = MFMA(k0, qf[ks], s0);
+        s1 = MFMA(k1, qf[ks], s1);
+    }
+}
+// normalised probabilities of the 8 keys this lane holds (slots e = kb*4 + r), 0 where the key is masked
+__device__ __forceinline__ void probs(const f32x4& s0, const f32x4& s1, uint32_t vm0, uint32_t vm1, float scale, float m, float il, float* P) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        P[r] = ((vm0 >> (8 * r)) & 0xff) ? __expf(s0[r] * scale - m) * il : 0.f;
+        P[4 + r] = ((vm1 >> (8 * r)) & 0xff) ? __expf(s1[r] * scale - m) * il : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void xattn2_fwd_kernel(X2Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t vsh[96];                                  // valid bytes of this sample (JP <= 288 -> 72 words)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g4 = lane >> 4;
+    const int tiles = (a.n + 63) / 64;
+    const int b = blockIdx.x / tiles, qi = (blockIdx.x % tiles) * 64 + wave * 16 + c;
+    const bool qok = qi < a.n;
+    if (tid < a.JP / 4) vsh[tid] = reinterpret_cast<const uint32_t*>(a.valid + (size_t)b * a.JP)[tid];
+    __syncthreads();                                             // (before any DMA is in flight)
+    float w[NH][NH];
+#pragma unroll
+    for (int g = 0; g < NH; ++g)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) w[g][h] = a.wth[g * NH + h];
+    bf16x8 qf[NH][KS];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[h][ks] = ldg16(a.q + ((size_t)b * a.n + qi) * a.ldq + h * DH + ks * 32 + g4 * 8, qok);
+
+    // ---- pass 1: running (max, sum of exp) per head over the key chunks; only K is staged
+    float m[NH], l[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) { m[h] = NEG_MAX; l[h] = 0.f; }
+    stage_chunk<false, false>(smem, 0, 0, b, a.JP, a.Kp, nullptr, wave, lane);
+    for (int ch = 0; ch < a.nch; ++ch) {
+        if (ch + 1 < a.nch) { stage_chunk<false, false>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, nullptr, wave, lane); VMCNT(8); }
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        const char* base = smem + (ch & 1) * STAGE;
+        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            f32x4 s0, s1;
+            qk_chunk(base, h, c, g4, qf[h], s0, s1);
+            float s[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[r] = ((vm0 >> (8 * r)) & 0xff) ? s0[r] * a.scale : NEG_MAX;
+                s[4 + r] = ((vm1 >> (8 * r)) & 0xff) ? s1[r] * a.scale : NEG_MAX;
+            }
+            const float cm = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+            const float mn = fmaxf(m[h], cm);
+            float acc = l[h] * __expf(m[h] - mn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += __expf(s[e] - mn);
+            l[h] = acc; m[h] = mn;
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    float il[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float m2 = __shfl_xor(m[h], off, 64), l2 = __shfl_xor(l[h], off, 64);
+            const float mn = fmaxf(m[h], m2);
+            l[h] = l[h] * __expf(m[h] - mn) + l2 * __expf(m2 - mn);
+            m[h] = mn;
+        }
+        il[h] = 1.f / l[h];
+        if (a.stats && g4 == 0 && qok) *reinterpret_cast<float2*>(a.stats + (((size_t)b * NH + h) * a.n + qi) * 2) = make_float2(m[h], il[h]);
+    }
+
+    // ---- pass 2: P[h] again, head mix in registers, O^T[g] += V^T[g] P'^T[g]
+    f32x4 O[NH][DB];
+#pragma unroll
+    for (int g = 0; g < NH; ++g)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) O[g][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage_chunk<true, false>(smem, 0, 0, b, a.JP, a.Kp, a.Vt, wave, lane);
+    for (int ch = 0; ch < a.nch; ++ch) {
+        if (ch + 1 < a.nch) { stage_chunk<true, false>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vt, wave, lane); VMCNT(16); }
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        const char* base = smem + (ch & 1) * STAGE;
+        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
+        float P[NH][8];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            f32x4 s0, s1;
+            qk_chunk(base, h, c, g4, qf[h], s0, s1);
+            probs(s0, s1, vm0, vm1, a.scale, m[h], il[h], P[h]);
+        }
+#pragma unroll
+        for (int g = 0; g < NH; ++g) {
+            float pv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float acc = w[g][0] * P[0][e];
+#pragma unroll
+                for (int h = 1; h < NH; ++h) acc = fmaf(w[g][h], P[h][e], acc);
+                pv[e] = acc;
+            }
+            const bf16x8 pf = pack8(pv);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const int d = db * 16 + c;
+                const bf16x8 vf = lds8x2(base + KT_BYTES + dk_off(g, d, g4 >> 1) + (g4 & 1) * 8,
+                                         base + KT_BYTES + dk_off(g, d, 2 + (g4 >> 1)) + (g4 & 1) * 8);
+                O[g][db] = MFMA(vf, pf, O[g][db]);
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (qok) {
+#pragma unroll
+        for (int g = 0; g < NH; ++g)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                bf16_t* dst = a.o + ((size_t)b * a.n + qi) * a.ldo + g * DH + db * 16 + g4 * 4;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(O[g][db][0], O[g][db][1]), pack2_rne(O[g][db][2], O[g][db][3]));
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, query-centric
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void xattn2_bwd_kernel(X2Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t vsh[96];
+    __shared__ float thsh[4][NH * NH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g4 = lane >> 4;
+    const int tiles = (a.n + 63) / 64;
+    const int b = blockIdx.x / tiles, qi = (blockIdx.x % tiles) * 64 + wave * 16 + c;
+    const bool qok = qi < a.n;
+    if (tid < a.JP / 4) vsh[tid] = reinterpret_cast<const uint32_t*>(a.valid + (size_t)b * a.JP)[tid];
+    __syncthreads();                                             // (before any DMA is in flight)
+    float w[NH][NH];
+#pragma unroll
+    for (int g = 0; g < NH; ++g)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) w[g][h] = a.wth[g * NH + h];
+    bf16x8 qf[NH][KS], df[NH][KS];
+    float m[NH], il[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[h][ks] = ldg16(a.q + ((size_t)b * a.n + qi) * a.ldq + h * DH + ks * 32 + g4 * 8, qok);
+            df[h][ks] = ldg16(a.dO + ((size_t)b * a.n + qi) * a.lddo + h * DH + ks * 32 + g4 * 8, qok);
+        }
+        const float2 st = qok ? *reinterpret_cast<const float2*>(a.stats + (((size_t)b * NH + h) * a.n + qi) * 2) : make_float2(0.f, 0.f);
+        m[h] = st.x; il[h] = st.y;
+    }
+    const size_t prow = (size_t)a.n * a.JP;                      // stride between heads in dS / Pm
+
+    // ---- pass A: delta[h] = sum_j dP[h] P[h];  dW_th[g][h] += sum dP'[g] P[h];  P'[g] -> Pm
+    float delta[NH], dth[NH][NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        delta[h] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NH; ++g) dth[g][h] = 0.f;
+    }
+    stage_chunk<true, true>(smem, 0, 0, b, a.JP, a.Kp, a.Vp, wave, lane);
+    for (int ch = 0; ch < a.nch; ++ch) {
+        if (ch + 1 < a.nch) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        const char* base = smem + (ch & 1) * STAGE;
+        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
+        float P[NH][8], dPp[NH][8];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            f32x4 s0, s1;
+            qk_chunk(base, h, c, g4, qf[h], s0, s1);
+            probs(s0, s1, vm0, vm1, a.scale, m[h], il[h], P[h]);
+            qk_chunk(base + KT_BYTES, h, c, g4, df[h], s0, s1);          // dP'^T[h] = V[h] dO[h]^T
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dPp[h][r] = s0[r]; dPp[h][4 + r] = s1[r]; }
+        }
+#pragma unroll
+        for (int g = 0; g < NH; ++g) {
+            float pm[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float acc = w[g][0] * P[0][e];
+#pragma unroll
+                for (int h = 1; h < NH; ++h) acc = fmaf(w[g][h], P[h][e], acc);
+                pm[e] = acc;
+            }
+            if (qok) {
+                bf16_t* dst = a.Pm + ((size_t)b * NH + g) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 4;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(pm[0], pm[1]), pack2_rne(pm[2], pm[3]));
+                *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pack2_rne(pm[4], pm[5]), pack2_rne(pm[6], pm[7]));
+            }
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float acc = dth[g][h];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf(dPp[g][e], P[h][e], acc);
+                dth[g][h] = acc;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            float acc = delta[h];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float dp = w[0][h] * dPp[0][e];
+#pragma unroll
+                for (int g = 1; g < NH; ++g) dp = fmaf(w[g][h], dPp[g][e], dp);
+                acc = fmaf(dp, P[h][e], acc);
+            }
+            delta[h] = acc;
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        delta[h] += __shfl_xor(delta[h], 16, 64);
+        delta[h] += __shfl_xor(delta[h], 32, 64);
+    }
+    // dW_th partial of this workgroup (fixed order over the 4 waves)
+#pragma unroll
+    for (int g = 0; g < NH; ++g)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float s = wave_sum(qok ? dth[g][h] : 0.f);
+            if (lane == 0) thsh[wave][g * NH + h] = s;
+        }
+    __syncthreads();
+    if (tid < NH * NH) a.part_th[(size_t)blockIdx.x * NH * NH + tid] = ((thsh[0][tid] + thsh[1][tid]) + thsh[2][tid]) + thsh[3][tid];
+
+    // ---- pass B: ds[h] = P[h] (dP[h] - delta[h]) -> dS;  dq^T[h] += K^T[h] ds^T[h]
+    f32x4 dQ[NH][DB];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) dQ[h][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage_chunk<true, true>(smem, 0, 0, b, a.JP, a.Kp, a.Vp, wave, lane);
+    for (int ch = 0; ch < a.nch; ++ch) {
+        if (ch + 1 < a.nch) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        const char* base = smem + (ch & 1) * STAGE;
+        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
+        float dPp[NH][8];
+#pragma unroll
+        for (int g = 0; g < NH; ++g) {
+            f32x4 s0, s1;
+            qk_chunk(base + KT_BYTES, g, c, g4, df[g], s0, s1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dPp[g][r] = s0[r]; dPp[g][4 + r] = s1[r]; }
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            f32x4 s0, s1;
+            float P[8], ds[8];
+            qk_chunk(base, h, c, g4, qf[h], s0, s1);
+            probs(s0, s1, vm0, vm1, a.scale, m[h], il[h], P);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float dp = w[0][h] * dPp[0][e];
+#pragma unroll
+                for (int g = 1; g < NH; ++g) dp = fmaf(w[g][h], dPp[g][e], dp);
+                ds[e] = P[e] * (dp - delta[h]);
+            }
+            const uint2 lo = make_uint2(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]));
+            const uint2 hi = make_uint2(pack2_rne(ds[4], ds[5]), pack2_rne(ds[6], ds[7]));
+            if (qok) {
+                bf16_t* dst = a.dS + ((size_t)b * NH + h) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 4;
+                *reinterpret_cast<uint2*>(dst) = lo;
+                *reinterpret_cast<uint2*>(dst + 16) = hi;
+            }
+            const bf16x8 sf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+            for (int db = 0; db < DB; ++db) dQ[h][db] = MFMA(lds_tr(base, h, db, c, g4), sf, dQ[h][db]);
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (qok) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                bf16_t* dst = a.dq + ((size_t)b * a.n + qi) * a.lddq + h * DH + db * 16 + g4 * 4;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(dQ[h][db][0] * a.scale, dQ[h][db][1] * a.scale),
+                                                            pack2_rne(dQ[h][db][2] * a.scale, dQ[h][db][3] * a.scale));
+            }
+    }
+}
+
+int check2(const amdnuwa_xattn_geom* g) {
+    if (!g) return AMDNUWA_ERR_ARG;
+    if (g->heads != NH || g->dim_head != DH || g->JP % 32 || g->JP > 288 || g->JP < g->T + 1) return AMDNUWA_ERR_UNSUPPORTED;
+    return AMDNUWA_OK;
+}
+
+}  // namespace
+
+extern "C" int amdnuwa_xattn2_supported(const amdnuwa_xattn_geom* g) { return check2(g) == AMDNUWA_OK; }
+
+extern "C" int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const amdnuwa_xattn_kv* p, const float* w_th,
+                                  uint16_t* o, int ldo, float* stats, hipStream_t stream) {
+    int rc = check2(g);
+    if (rc) return rc;
+    if (!q || !p || !p->Kp || !p->Vt || !p->valid || !w_th || !o || ldq % 8 || ldo % 4) return AMDNUWA_ERR_ARG;
+    if (g->B <= 0 || g->n <= 0) return AMDNUWA_OK;
+    X2Args a{};
+    a.q = q; a.ldq = ldq; a.Kp = p->Kp; a.Vp = p->Vp; a.Vt = p->Vt; a.valid = p->valid; a.wth = w_th;
+    a.o = o; a.ldo = ldo; a.stats = stats;
+    a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
+    const int tiles = (g->n + 63) / 64;
+    (void)hipFuncSetAttribute((const void*)xattn2_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    hipLaunchKernelGGL(xattn2_fwd_kernel, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" size_t amdnuwa_xattn2_bwd_workspace_bytes(const amdnuwa_xattn_geom* g) {
+    if (check2(g)) return 0;
+    return (size_t)g->B * ((g->n + 63) / 64) * NH * NH * sizeof(float);
+}
+
+extern "C" int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
+                                  const amdnuwa_xattn_kv* p, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm,
+                                  uint16_t* dq, int lddq, float* part_th, size_t part_bytes, hipStream_t stream) {
+    int rc = check2(g);
+    if (rc) return rc;
+    if (!q || !dO || !p || !p->Kp || !p->Vp || !p->valid || !w_th || !stats || !dS || !Pm || !dq || ldq % 8 || lddo % 8 || lddq % 4)
+        return AMDNUWA_ERR_ARG;
+    if (!part_th || part_bytes < amdnuwa_xattn2_bwd_workspace_bytes(g)) return AMDNUWA_ERR_WORKSPACE;
+    if (g->B <= 0 || g->n <= 0) return AMDNUWA_OK;
+    X2Args a{};
+    a.q = q; a.ldq = ldq; a.dO = dO; a.lddo = lddo; a.Kp = p->Kp; a.Vp = p->Vp; a.Vt = p->Vt; a.valid = p->valid; a.wth = w_th;
+    a.stats = const_cast<float*>(stats); a.dS = dS; a.Pm = Pm; a.dq = dq; a.lddq = lddq; a.part_th = part_th;
+    a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
+    const int tiles = (g->n + 63) / 64;
+    (void)hipFuncSetAttribute((const void*)xattn2_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    hipLaunchKernelGGL(xattn2_bwd_kernel, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}

@@ -412,6 +412,39 @@ def xattn_bwd(g, dO, pk, wth, P):
     return dq, dS, dwth
 
 
+def xattn2_supported(g, q):
+    """second-design cross-attention kernels: fast bf16 mode (no lo parts), 8 heads x 64"""
+    return q.lo is None and bool(_lib.lib().amdnuwa_xattn2_supported(C.byref(g)))
+
+
+def xattn2_fwd(g, q, pk, wth):
+    """returns o BF [B*n, inner], stats fp32 [B, h, n, 2] = (row max, 1 / row sum) of the masked, scaled scores"""
+    L = _lib.lib()
+    inner = g.heads * g.dim_head
+    dev = q.hi.device
+    o = empty_bf((g.B * g.n, inner), dev, lo=False)
+    stats = torch.empty((g.B, g.heads, g.n, 2), dtype=torch.float32, device=dev)
+    check(L.amdnuwa_xattn2_fwd(C.byref(g), _p(q.hi), q.hi.stride(0), C.byref(pk.struct), _p(wth), _p(o.hi), inner, _p(stats),
+                               _stream()), 'amdnuwa_xattn2_fwd')
+    return o, stats
+
+
+def xattn2_bwd(g, q, dO, pk, wth, stats):
+    """returns dq BF [B*n, inner], dS BF and Pm BF [B, h, n, JP], dw_th fp32 [h, h]"""
+    L = _lib.lib()
+    inner = g.heads * g.dim_head
+    dev = q.hi.device
+    dq = empty_bf((g.B * g.n, inner), dev, lo=False)
+    dS = empty_bf((g.B, g.heads, g.n, g.JP), dev, lo=False)
+    Pm = empty_bf((g.B, g.heads, g.n, g.JP), dev, lo=False)
+    nb = L.amdnuwa_xattn2_bwd_workspace_bytes(C.byref(g))
+    part = torch.empty((nb // (4 * g.heads * g.heads), g.heads * g.heads), dtype=torch.float32, device=dev)
+    check(L.amdnuwa_xattn2_bwd(C.byref(g), _p(q.hi), q.hi.stride(0), _p(dO.hi), dO.hi.stride(0), C.byref(pk.struct), _p(wth),
+                               _p(stats), _p(dS.hi), _p(Pm.hi), _p(dq.hi), inner, _p(part), nb, _stream()), 'amdnuwa_xattn2_bwd')
+    dwth = colsum(part).reshape(g.heads, g.heads)          # fixed-order reduction over the workgroups
+    return dq, dS, Pm, dwth
+
+
 def xattn_kv_grads(g, dS, Pm, q, dO):
     """dKp = scale * dS^T q, dVp = Pm^T dO per (sample, head): two batched TN GEMMs (reduction over queries).
     returns fp32 [B, h, JP, dh] x 2"""

@@ -131,7 +131,11 @@ class XInner:
         pk = K.xattn_pack(g, kv, nk.detach().reshape(g.heads, g.dim_head).contiguous(),
                           nv.detach().reshape(g.heads, g.dim_head).contiguous(), meta['mask_u8'])
         wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
-        o, P, Pm = K.xattn_fwd(g, q, pk, wth2, save=meta.get('save', True))
+        if K.xattn2_supported(g, q):          # fast mode: statistics only, the backward recomputes the probabilities
+            o, stats = K.xattn2_fwd(g, q, pk, wth2)
+            P, Pm = stats, None
+        else:
+            o, P, Pm = K.xattn_fwd(g, q, pk, wth2, save=meta.get('save', True))
         y = K.gemm_nt(o, W['out'], out_bf16=_fast())
         return y, (h, ctx, q, pk, P, Pm, o)
 
@@ -145,7 +149,10 @@ class XInner:
         d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
         dwo = torch.empty_like(wo)
         K.gemm_tn(dy, o, dwo)
-        dq, dS, dwth = K.xattn_bwd(g, d_o, pk, wth2, P)
+        if Pm is None:
+            dq, dS, Pm, dwth = K.xattn2_bwd(g, q, d_o, pk, wth2, P)
+        else:
+            dq, dS, dwth = K.xattn_bwd(g, d_o, pk, wth2, P)
         dKp, dVp = K.xattn_kv_grads(g, dS, Pm, q, d_o)
         dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=dy.lo is not None)
         dh = K.gemm_nt(dq, W['qT'], out_bf16=_fast())

@@ -365,6 +365,20 @@ def test_cross_attention_core(K, O, case, x3):
     report('xattn_dkv' + tag, val(dkv).reshape(B, T, 2, heads, dh), kv.grad, 1e-4 if x3 else 2 ** -6)
     report('xattn_dnull_k' + tag, dnk, nk.grad, 1e-4 if x3 else 2 ** -6)
     report('xattn_dnull_v' + tag, dnv, nv.grad, 1e-4 if x3 else 2 ** -6)
+    if not x3 and K.xattn2_supported(g, qp):
+        # second design (one wave = 16 queries x all heads, statistics-only forward, recomputing backward)
+        o2, stats = K.xattn2_fwd(g, qp, pk, wth.detach().to(DEV))
+        report('xattn2_fwd' + tag, o2.hi.float().reshape(B, n, heads, dh), o_ref.detach(), 2 ** -7)
+        dq2, dS2, Pm2, dwth2 = K.xattn2_bwd(g, qp, dop, pk, wth.detach().to(DEV), stats)
+        report('xattn2_dq' + tag, dq2.hi.float().reshape(B, n, heads, dh), q.grad, 2 ** -6)
+        report('xattn2_dwth' + tag, dwth2, wth.grad, 2 ** -6)
+        report('xattn2_Pm' + tag, Pm2.hi.float(), Pm.hi.float(), 2 ** -6)
+        report('xattn2_dS' + tag, dS2.hi.float(), dS.hi.float(), 2 ** -5)
+        dKp2, dVp2 = K.xattn_kv_grads(g, dS2, Pm2, qp, dop)
+        dkv2, dnk2, dnv2 = K.xattn_unpack(g, dKp2, dVp2, lo=False)
+        report('xattn2_dkv' + tag, dkv2.hi.float().reshape(B, T, 2, heads, dh), kv.grad, 2 ** -6)
+        report('xattn2_dnull_k' + tag, dnk2, nk.grad, 2 ** -6)
+        report('xattn2_dnull_v' + tag, dnv2, nv.grad, 2 ** -6)
 
 
 # ---------------------------------------------------------------------------------------------------

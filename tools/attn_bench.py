@@ -78,6 +78,12 @@ def main():
         t = bench(lambda: K.xattn_kv_grads(g, dS, Pm, q, do), args.iters)
         print(f'kv grads (2 batched TN, tn variant {v}) {t * 1e6:7.1f} us')
     L.amdnuwa_set_tuning(6, 0)
+    if K.xattn2_supported(g, q):
+        t = bench(lambda: K.xattn2_fwd(g, q, pk, wth), args.iters)
+        print(f'xattn2 fwd  {t * 1e6:7.1f} us ({fl / t / 1e12:6.1f} TF/s MFMA-useful)')
+        o2, stats = K.xattn2_fwd(g, q, pk, wth)
+        t = bench(lambda: K.xattn2_bwd(g, q, do, pk, wth, stats), args.iters)
+        print(f'xattn2 bwd_q {t * 1e6:7.1f} us')
 
 
 if __name__ == '__main__':
