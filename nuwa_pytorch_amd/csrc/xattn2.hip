@@ -19,6 +19,10 @@
 #include "common.h"
 #include "../../include/amdnuwa.h"
 
+// no implicit a*b+c contraction in this file: pass 1 and pass 2 must round the scaled scores identically (every FMA that
+// matters for speed is an explicit fmaf)
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int NH = 8, DH = 64, KS = 2, DB = 4;
@@ -115,13 +119,22 @@ __device__ __forceinline__ void qk_chunk(const char* base, int h, int c, int g4,
         s1 = MFMA(k1, qf[ks], s1);
     }
 }
-// normalised probabilities of the 8 keys this lane holds (slots e = kb*4 + r), 0 where the key is masked
-__device__ __forceinline__ void probs(const f32x4& s0, const f32x4& s1, uint32_t vm0, uint32_t vm1, float scale, float m, float il, float* P) {
+// normalised probabilities of the 8 keys this lane holds (slots e = kb*4 + r), 0 where the key is masked:
+// P = exp2(s * c1 + nb) with c1 = scale * log2(e) and nb = log2(1 / rowsum) - rowmax2 (statistics kept in the log2 domain)
+__device__ __forceinline__ void probs(const f32x4& s0, const f32x4& s1, uint32_t vm0, uint32_t vm1, float c1, float nb, float* P) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        P[r] = ((vm0 >> (8 * r)) & 0xff) ? __expf(s0[r] * scale - m) * il : 0.f;
-        P[4 + r] = ((vm1 >> (8 * r)) & 0xff) ? __expf(s1[r] * scale - m) * il : 0.f;
+        // (rounded product, then add -- exactly the arithmetic of pass 1, so a row whose only visible key is the null key
+        //  reproduces P = 1 and ds = 0 bit for bit instead of 1 + 1e-7)
+        P[r] = ((vm0 >> (8 * r)) & 0xff) ? __builtin_amdgcn_exp2f(__fmul_rn(s0[r], c1) + nb) : 0.f;
+        P[4 + r] = ((vm1 >> (8 * r)) & 0xff) ? __builtin_amdgcn_exp2f(__fmul_rn(s1[r], c1) + nb) : 0.f;
     }
+}
+// row g of the head-mix weight (or column h of it, from the transposed copy) out of LDS: 8 broadcast values
+struct W8 { float v[8]; };
+__device__ __forceinline__ W8 ldw(const float* wsh, int row) {
+    const float4 a = *reinterpret_cast<const float4*>(wsh + row * 8), b = *reinterpret_cast<const float4*>(wsh + row * 8 + 4);
+    return W8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -137,12 +150,10 @@ __global__ __launch_bounds__(256, 1) void xattn2_fwd_kernel(X2Args a) {
     const int b = blockIdx.x / tiles, qi = (blockIdx.x % tiles) * 64 + wave * 16 + c;
     const bool qok = qi < a.n;
     if (tid < a.JP / 4) vsh[tid] = reinterpret_cast<const uint32_t*>(a.valid + (size_t)b * a.JP)[tid];
+    __shared__ __attribute__((aligned(16))) float wsh[NH * NH];
+    if (tid < NH * NH) wsh[tid] = a.wth[tid];
     __syncthreads();                                             // (before any DMA is in flight)
-    float w[NH][NH];
-#pragma unroll
-    for (int g = 0; g < NH; ++g)
-#pragma unroll
-        for (int h = 0; h < NH; ++h) w[g][h] = a.wth[g * NH + h];
+    const float c1 = a.scale * 1.4426950408889634f;              // scores are handled in the log2 domain: exp(x) = exp2(x * log2 e)
     bf16x8 qf[NH][KS];
 #pragma unroll
     for (int h = 0; h < NH; ++h)
@@ -167,30 +178,31 @@ __global__ __launch_bounds__(256, 1) void xattn2_fwd_kernel(X2Args a) {
             float s[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[r] = ((vm0 >> (8 * r)) & 0xff) ? s0[r] * a.scale : NEG_MAX;
-                s[4 + r] = ((vm1 >> (8 * r)) & 0xff) ? s1[r] * a.scale : NEG_MAX;
+                s[r] = ((vm0 >> (8 * r)) & 0xff) ? s0[r] * c1 : NEG_MAX;
+                s[4 + r] = ((vm1 >> (8 * r)) & 0xff) ? s1[r] * c1 : NEG_MAX;
             }
             const float cm = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
             const float mn = fmaxf(m[h], cm);
-            float acc = l[h] * __expf(m[h] - mn);
+            float acc = l[h] * __builtin_amdgcn_exp2f(m[h] - mn);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc += __expf(s[e] - mn);
+            for (int e = 0; e < 8; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
             l[h] = acc; m[h] = mn;
         }
         __builtin_amdgcn_s_barrier();
     }
-    float il[NH];
+    float nb[NH];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
             const float m2 = __shfl_xor(m[h], off, 64), l2 = __shfl_xor(l[h], off, 64);
             const float mn = fmaxf(m[h], m2);
-            l[h] = l[h] * __expf(m[h] - mn) + l2 * __expf(m2 - mn);
+            l[h] = l[h] * __builtin_amdgcn_exp2f(m[h] - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
             m[h] = mn;
         }
-        il[h] = 1.f / l[h];
-        if (a.stats && g4 == 0 && qok) *reinterpret_cast<float2*>(a.stats + (((size_t)b * NH + h) * a.n + qi) * 2) = make_float2(m[h], il[h]);
+        const float il = 1.f / l[h];
+        nb[h] = __log2f(il) - m[h];
+        if (a.stats && g4 == 0 && qok) *reinterpret_cast<float2*>(a.stats + (((size_t)b * NH + h) * a.n + qi) * 2) = make_float2(m[h], il);
     }
 
     // ---- pass 2: P[h] again, head mix in registers, O^T[g] += V^T[g] P'^T[g]
@@ -211,16 +223,17 @@ __global__ __launch_bounds__(256, 1) void xattn2_fwd_kernel(X2Args a) {
         for (int h = 0; h < NH; ++h) {
             f32x4 s0, s1;
             qk_chunk(base, h, c, g4, qf[h], s0, s1);
-            probs(s0, s1, vm0, vm1, a.scale, m[h], il[h], P[h]);
+            probs(s0, s1, vm0, vm1, c1, nb[h], P[h]);
         }
 #pragma unroll
         for (int g = 0; g < NH; ++g) {
+            const W8 wg = ldw(wsh, g);
             float pv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float acc = w[g][0] * P[0][e];
+                float acc = wg.v[0] * P[0][e];
 #pragma unroll
-                for (int h = 1; h < NH; ++h) acc = fmaf(w[g][h], P[h][e], acc);
+                for (int h = 1; h < NH; ++h) acc = fmaf(wg.v[h], P[h][e], acc);
                 pv[e] = acc;
             }
             const bf16x8 pf = pack8(pv);
@@ -259,14 +272,12 @@ __global__ __launch_bounds__(256, 1) void xattn2_bwd_kernel(X2Args a) {
     const int b = blockIdx.x / tiles, qi = (blockIdx.x % tiles) * 64 + wave * 16 + c;
     const bool qok = qi < a.n;
     if (tid < a.JP / 4) vsh[tid] = reinterpret_cast<const uint32_t*>(a.valid + (size_t)b * a.JP)[tid];
+    __shared__ __attribute__((aligned(16))) float wsh[NH * NH], wtsh[NH * NH];          // W[g][h] and its transpose
+    if (tid < NH * NH) { const float v = a.wth[tid]; wsh[tid] = v; wtsh[(tid & 7) * 8 + (tid >> 3)] = v; }
     __syncthreads();                                             // (before any DMA is in flight)
-    float w[NH][NH];
-#pragma unroll
-    for (int g = 0; g < NH; ++g)
-#pragma unroll
-        for (int h = 0; h < NH; ++h) w[g][h] = a.wth[g * NH + h];
+    const float c1 = a.scale * 1.4426950408889634f;
     bf16x8 qf[NH][KS], df[NH][KS];
-    float m[NH], il[NH];
+    float nb[NH];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
 #pragma unroll
@@ -274,8 +285,8 @@ __global__ __launch_bounds__(256, 1) void xattn2_bwd_kernel(X2Args a) {
             qf[h][ks] = ldg16(a.q + ((size_t)b * a.n + qi) * a.ldq + h * DH + ks * 32 + g4 * 8, qok);
             df[h][ks] = ldg16(a.dO + ((size_t)b * a.n + qi) * a.lddo + h * DH + ks * 32 + g4 * 8, qok);
         }
-        const float2 st = qok ? *reinterpret_cast<const float2*>(a.stats + (((size_t)b * NH + h) * a.n + qi) * 2) : make_float2(0.f, 0.f);
-        m[h] = st.x; il[h] = st.y;
+        const float2 st = qok ? *reinterpret_cast<const float2*>(a.stats + (((size_t)b * NH + h) * a.n + qi) * 2) : make_float2(0.f, 1.f);
+        nb[h] = qok ? __log2f(st.y) - st.x : 0.f;                 // statistics: (row max in the log2 domain, 1 / row sum)
     }
     const size_t prow = (size_t)a.n * a.JP;                      // stride between heads in dS / Pm
 
@@ -299,19 +310,20 @@ __global__ __launch_bounds__(256, 1) void xattn2_bwd_kernel(X2Args a) {
         for (int h = 0; h < NH; ++h) {
             f32x4 s0, s1;
             qk_chunk(base, h, c, g4, qf[h], s0, s1);
-            probs(s0, s1, vm0, vm1, a.scale, m[h], il[h], P[h]);
+            probs(s0, s1, vm0, vm1, c1, nb[h], P[h]);
             qk_chunk(base + KT_BYTES, h, c, g4, df[h], s0, s1);          // dP'^T[h] = V[h] dO[h]^T
 #pragma unroll
             for (int r = 0; r < 4; ++r) { dPp[h][r] = s0[r]; dPp[h][4 + r] = s1[r]; }
         }
 #pragma unroll
         for (int g = 0; g < NH; ++g) {
+            const W8 wg = ldw(wsh, g);
             float pm[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float acc = w[g][0] * P[0][e];
+                float acc = wg.v[0] * P[0][e];
 #pragma unroll
-                for (int h = 1; h < NH; ++h) acc = fmaf(w[g][h], P[h][e], acc);
+                for (int h = 1; h < NH; ++h) acc = fmaf(wg.v[h], P[h][e], acc);
                 pm[e] = acc;
             }
             if (qok) {
@@ -329,12 +341,13 @@ __global__ __launch_bounds__(256, 1) void xattn2_bwd_kernel(X2Args a) {
         }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
+            const W8 wh = ldw(wtsh, h);                          // W[.][h]
             float acc = delta[h];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float dp = w[0][h] * dPp[0][e];
+                float dp = wh.v[0] * dPp[0][e];
 #pragma unroll
-                for (int g = 1; g < NH; ++g) dp = fmaf(w[g][h], dPp[g][e], dp);
+                for (int g = 1; g < NH; ++g) dp = fmaf(wh.v[g], dPp[g][e], dp);
                 acc = fmaf(dp, P[h][e], acc);
             }
             delta[h] = acc;
@@ -383,12 +396,13 @@ __global__ __launch_bounds__(256, 1) void xattn2_bwd_kernel(X2Args a) {
             f32x4 s0, s1;
             float P[8], ds[8];
             qk_chunk(base, h, c, g4, qf[h], s0, s1);
-            probs(s0, s1, vm0, vm1, a.scale, m[h], il[h], P);
+            probs(s0, s1, vm0, vm1, c1, nb[h], P);
+            const W8 wh = ldw(wtsh, h);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float dp = w[0][h] * dPp[0][e];
+                float dp = wh.v[0] * dPp[0][e];
 #pragma unroll
-                for (int g = 1; g < NH; ++g) dp = fmaf(w[g][h], dPp[g][e], dp);
+                for (int g = 1; g < NH; ++g) dp = fmaf(wh.v[g], dPp[g][e], dp);
                 ds[e] = P[e] * (dp - delta[h]);
             }
             const uint2 lo = make_uint2(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]));
