@@ -619,24 +619,28 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
 
 // fixed-order reductions: dW_th (+= over all workgroups); per sample dk[bos], dv[bos] (+ dO[bos])
 // 1024 threads = 64 columns x 16 row groups (coalesced reads, fixed combine order).
-// grid = B * ceil(inner/64) blocks for the <bos> k/v rows + 1 block for dW_th.
+// grid = B * ceil(inner/64) blocks for the <bos> k/v rows + ceil(NH*NH/16) blocks for dW_th.
 __global__ __launch_bounds__(1024) void s3_bwd_fin_kernel(S3Args a, int DH) {
     __shared__ float red[2][16][64];
     const int rows = a.F * a.H, inner = a.NH * DH;
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int nchunk = (inner + 63) / 64;
-    if ((int)blockIdx.x == a.B * nchunk) {
+    if ((int)blockIdx.x >= a.B * nchunk) {
+        // dW_th: the last ceil(NH*NH / 16) blocks, each 16 columns x 64 row groups over the B*F*H workgroup partials
+        // (one block summing all of them serially was a 130 us tail on the backward)
+        __shared__ float redw[64][17];
         const int nn = a.NH * a.NH;
+        const int col = (blockIdx.x - a.B * nchunk) * 16 + (threadIdx.x & 15), rg64 = threadIdx.x >> 4;
         float s = 0.f;
-        if (lane < nn)
-            for (int k = rg; k < a.B * rows; k += 16) s += a.part_th[(size_t)k * nn + lane];
-        red[0][rg][lane] = s;
+        if (col < nn)
+            for (int k = rg64; k < a.B * rows; k += 64) s += a.part_th[(size_t)k * nn + col];
+        redw[rg64][threadIdx.x & 15] = s;
         __syncthreads();
-        if (rg == 0 && lane < nn) {
+        if (rg64 == 0 && col < nn) {
             float t = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t += red[0][r][lane];
-            a.dwth[lane] = a.accumulate ? a.dwth[lane] + t : t;
+            for (int r = 0; r < 64; ++r) t += redw[r][threadIdx.x & 15];
+            a.dwth[col] = a.accumulate ? a.dwth[col] + t : t;
         }
         return;
     }
@@ -766,7 +770,7 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     else { if (lo_mode) S3B(32, true); else S3B(32, false); }
 #undef S3B
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(s3_bwd_fin_kernel, dim3(g->B * (((int)inner + 63) / 64) + 1), dim3(1024), 0, stream, a, g->dim_head);
+    hipLaunchKernelGGL(s3_bwd_fin_kernel, dim3(g->B * (((int)inner + 63) / 64) + (g->heads * g->heads + 15) / 16), dim3(1024), 0, stream, a, g->dim_head);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

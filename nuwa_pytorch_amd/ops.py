@@ -12,6 +12,8 @@ are fp32; GEMM / attention operands are bf16 (plus a bf16 residual in 'bf16x3' p
 The same inner stages also back the standalone modules (Sparse3DNA, Attention, FeedForward,
 LayerNorm wrappers) through `InnerFn`, so `Sparse3DNA(...)(x)` alone works as in the reference.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -98,12 +100,12 @@ class S3Inner:
         inner = g.heads * g.dim_head
         d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
         dwo = torch.empty_like(wo)
-        K.gemm_tn(dy, o, dwo)
+        meta['wg'].run(lambda: K.gemm_tn(dy, o, dwo))
         dqkv, dwth = K.sparse3dna_bwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), d_o)
         dh = K.gemm_nt(dqkv, W['qkvT'], out_bf16=_fast())
         sh = meta.get('shift')
         dwqkv = torch.empty((3 * inner, wq.shape[1]), dtype=torch.float32, device=wq.device)   # one wgrad GEMM for [to_q; to_kv]
-        K.gemm_tn(dqkv, h, dwqkv, shift=sh)
+        meta['wg'].run(lambda: K.gemm_tn(dqkv, h, dwqkv, shift=sh))
         dwq, dwkv = dwqkv[:inner], dwqkv[inner:]
         dbo = K.colsum(dy_f32) if (need_dbias and dy_f32 is not None) else None
         return dh, None, [dwq, dwkv, dwth.reshape(wth.shape), dwo, dbo]
@@ -148,7 +150,7 @@ class XInner:
         wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
         d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
         dwo = torch.empty_like(wo)
-        K.gemm_tn(dy, o, dwo)
+        meta['wg'].run(lambda: K.gemm_tn(dy, o, dwo))
         if Pm is None:
             dq, dS, Pm, dwth = K.xattn2_bwd(g, q, d_o, pk, wth2, P)
         else:
@@ -157,8 +159,7 @@ class XInner:
         dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=dy.lo is not None)
         dh = K.gemm_nt(dq, W['qT'], out_bf16=_fast())
         dwq, dwkv = torch.empty_like(wq), torch.empty_like(wkv)
-        K.gemm_tn(dq, h, dwq)
-        K.gemm_tn(dkv, ctx, dwkv)
+        meta['wg'].run(lambda: (K.gemm_tn(dq, h, dwq), K.gemm_tn(dkv, ctx, dwkv)))
         dctx = K.gemm_nt(dkv, W['kvT'])
         return dh, dctx, [dnk.reshape(nk.shape), dnv.reshape(nv.shape), dwth.reshape(wth.shape), dwq, dwkv, dwo]
 
@@ -205,21 +206,53 @@ class FFInner:
         FP, FFI = W['FP'], W['FFI']
         dgg = K.gemm_nt(dy, W['w2T'], out_bf16=True)
         dw2 = torch.empty_like(w2)
-        K.gemm_tn(dy, gg, dw2, N2=FFI)
+        meta['wg'].run(lambda: K.gemm_tn(dy, gg, dw2, N2=FFI))
         du = K.geglu_bwd(u, dgg, FP)
         dh = K.gemm_nt(du, W['w1T'], out_bf16=_fast())
         sh = meta.get('shift')
         if FP == FFI:
             dw1 = torch.empty_like(w1)
-            K.gemm_tn(du, h, dw1, shift=sh)
+            meta['wg'].run(lambda: K.gemm_tn(du, h, dw1, shift=sh))
         else:                                   # one wgrad GEMM over the padded [a | gate] layout, then drop the (zero) pad rows
             dw1p = torch.empty((2 * FP, w1.shape[1]), dtype=torch.float32, device=w1.device)
-            K.gemm_tn(du, h, dw1p, shift=sh)
-            dw1 = torch.cat((dw1p[:FFI], dw1p[FP:FP + FFI]), 0)
+            dw1 = meta['wg'].run(lambda: (K.gemm_tn(du, h, dw1p, shift=sh), torch.cat((dw1p[:FFI], dw1p[FP:FP + FFI]), 0))[1])
         return dh, None, [dw1, dw2]
 
 
 INNERS = {'s3': S3Inner, 'xattn': XInner, 'ff': FFInner}
+
+ASYNC_WGRAD = os.environ.get('AMDNUWA_ASYNC_WGRAD', '0') != '0'      # opt-in: measured neutral on MI355X (the split-K GEMM fills every CU)
+_SIDE = {}
+
+
+class WgradStream:
+    """Weight-gradient GEMMs (dW = dY^T X) feed nothing further down the backward chain, so a block launches them on a side
+    HIP stream: the MFMA-bound split-K GEMM then shares the chip with the HBM-bound LayerNorm / GEGLU kernels that follow on the
+    main stream.  join() makes the main stream wait (device-side) before the block's gradients are handed to autograd."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        self.side = None
+        if ASYNC_WGRAD:
+            key = (device.index, self.main.cuda_stream)
+            if key not in _SIDE:
+                _SIDE[key] = torch.cuda.Stream(device)
+            self.side = _SIDE[key]
+        self.used = False
+
+    def run(self, fn):
+        if self.side is None:
+            return fn()
+        self.side.wait_stream(self.main)              # operands written so far on the main stream are complete
+        with torch.cuda.stream(self.side):
+            out = fn()
+        self.used = True
+        return out
+
+    def join(self):
+        if self.used:
+            self.main.wait_stream(self.side)
+            self.used = False
 
 
 def _fast():
@@ -279,6 +312,8 @@ class SandwichBlockFn(Function):
         g2 = g.contiguous().reshape(B * n, D)
         want_bias = meta['kind'] == 's3'
         dy, dpost_w, dpost_b, dsum = K.ln_bwd(g2, y, m2, r2, post_w.detach(), to_bf=True, want_dsum=want_bias)
+        meta = dict(meta)
+        wg = meta['wg'] = WgradStream(g.device)
         dh, dctx, grads = inner.bwd(ctx.inner_saved, dy, p, meta, need_dbias=False)
         if want_bias:
             grads[4] = dsum                      # to_out.bias grad = column sums of d(to_out output)
@@ -288,6 +323,7 @@ class SandwichBlockFn(Function):
         if ctx.has_ctx:
             T = meta['xgeom'].T
             dcontext = dctx.reshape(B, T, D)
+        wg.join()
         ctx.inner_saved = None
         dresid = g if ctx.has_resid else None
         return (dx.reshape(B, n, D), dresid, dcontext, None, dpre_w, dpre_b, dpost_w, dpost_b, *grads)
@@ -323,7 +359,10 @@ class InnerFn(Function):
         g2 = g.contiguous().reshape(B * n, -1)
         dy = K.empty_bf(tuple(g2.shape), g.device)
         K.cast_pad(g2, dy)
+        meta = dict(meta)
+        wg = meta['wg'] = WgradStream(g.device)
         dh, dctx, grads = inner.bwd(ctx.inner_saved, dy, p, meta, need_dbias=True, dy_f32=g2)
+        wg.join()
         dcontext = dctx.reshape(B, meta['xgeom'].T, D) if ctx.has_ctx else None
         ctx.inner_saved = None
         return (_as_f32(dh).reshape(B, n, D), dcontext, None, *grads)

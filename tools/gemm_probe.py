@@ -32,6 +32,8 @@ for name, m, nn, kk, obf in shapes:
             row.append(f'v{var} {["full", "no-st", "no-ml"][dbg]} {t * 1e6:6.1f}' + ('' if ok else ' MISMATCH'))
         L.amdnuwa_set_tuning(7, 0)
     L.amdnuwa_set_tuning(0, 0)
+    tl = bench(lambda: torch.matmul(A.hi, Bm.hi.t()), 10)          # library yardstick (hipBLASLt / rocBLAS through torch), bf16 out
+    row.append(f'torch.matmul {tl * 1e6:6.1f}')
     fl = 2.0 * m * nn * kk
     tiles = ((m + 255) // 256) * ((nn + 255) // 256)
     print(f'{name:18s} [{m}x{nn}x{kk}] tiles {tiles:6d} ({tiles / 256:.1f}/CU)  ' + ' | '.join(row) + f' | ideal mfma {fl / 2.5e15 * 1e6:6.1f} us')
