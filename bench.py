@@ -159,7 +159,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='samples per GPU (weak scaling)')
+    ap.add_argument('--batch', type=int, default=64, help='samples per GPU (weak scaling)')
     ap.add_argument('--config', default='cfg3', choices=list(CFGS))
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')

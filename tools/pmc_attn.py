@@ -22,4 +22,6 @@ pk = K.xattn_pack(gx, kv, nk, nk, None)
 for _ in range(2):
     o, P, Pm = K.xattn_fwd(gx, q, pk, wth)
     K.xattn_bwd(gx, do, pk, wth, P)
+    o2, st = K.xattn2_fwd(gx, q, pk, wth)
+    K.xattn2_bwd(gx, q, do, pk, wth, st)
 torch.cuda.synchronize()
