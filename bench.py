@@ -163,6 +163,8 @@ def main():
     ap.add_argument('--config', default='cfg3', choices=list(CFGS))
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL over xGMI (default); gloo only for functional checks')
+    ap.add_argument('--single-device', action='store_true', help='functional check only: every rank uses cuda:0 (with --backend gloo)')
     ap.add_argument('--no-tokenizer', action='store_true', help='skip the (untimed, separately reported) frozen-VAE tokenizer rate')
     args = ap.parse_args()
 
@@ -171,11 +173,13 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the decoder path has no CPU fallback)')
+    if args.single_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     import nuwa_pytorch_amd as A
     from nuwa_pytorch_amd import kernels as K
     from nuwa_pytorch_amd.distributed import GradReducer
