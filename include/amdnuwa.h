@@ -116,9 +116,11 @@ int amdnuwa_embed_fwd(const long long* ids, const float* W, const float* ax1, co
                       const float* bos, float* x, int B, int ntok, int D, int H, int Wd, float frac,
                       amdnuwa_stream stream);
 size_t amdnuwa_embed_bwd_workspace_bytes(int ntok, int D);
-int amdnuwa_embed_bwd(const long long* ids, const float* dx, float* dW, float* dax1, float* dax2, float* dax3,
-                      float* dbos, int B, int ntok, int D, int F, int H, int Wd, float frac, void* workspace,
-                      size_t workspace_bytes, amdnuwa_stream stream);
+/* sorted_ids / perm (both [B*(ntok-1)], optional): the token ids stably sorted and their original flat positions -> the
+ * token-embedding gradient is summed in a fixed order (deterministic); NULL selects fp32 atomics */
+int amdnuwa_embed_bwd(const long long* ids, const long long* sorted_ids, const long long* perm, const float* dx, float* dW,
+                      float* dax1, float* dax2, float* dax3, float* dbos, int B, int ntok, int D, int F, int H, int Wd,
+                      float frac, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
 /* row_loss[r] = lse(logits[r]) - logits[r][t]; *loss = mean(row_loss);
  * dl (optional, bf16 hi[/lo], ld = ld_dl) = (softmax - onehot) * grad_scale */
 int amdnuwa_ce_fwd(const float* logits, const long long* targets, float* row_loss, float* loss, uint16_t* dl_hi,

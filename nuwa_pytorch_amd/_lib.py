@@ -6,7 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libamdnuwa.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 P = C.c_void_p
 I = C.c_int
@@ -69,7 +69,7 @@ SIGNATURES = {
     'amdnuwa_transpose_cast': (I, [P, I, P, P, I, I, I, P]),
     'amdnuwa_embed_fwd': (I, [P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
     'amdnuwa_embed_bwd_workspace_bytes': (SZ, [I, I]),
-    'amdnuwa_embed_bwd': (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
+    'amdnuwa_embed_bwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
     'amdnuwa_ce_fwd': (I, [P, P, P, P, P, P, LL, I, I, F, P]),
     'amdnuwa_scale_by_device_scalar': (I, [P, SZ, P, P]),
     'amdnuwa_sparse3dna_fwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P]),

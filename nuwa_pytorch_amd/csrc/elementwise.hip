@@ -461,6 +461,31 @@ __global__ __launch_bounds__(256) void embed_bwd_tok_kernel(const long long* __r
     for (int e = lane; e < D; e += 64) atomicAdd(dW + id * D + e, frac * dx[row * D + e]);
 }
 
+// deterministic form: the caller passes the token ids stably sorted (sid) with their original flat positions (perm); the wave
+// sitting on the head of a run of equal ids sums that run's rows in position order and owns dW[id] -- fixed order, no atomics
+__global__ __launch_bounds__(256) void embed_bwd_tok_sorted_kernel(const long long* __restrict__ sid, const long long* __restrict__ perm,
+                                                                   const float* __restrict__ dx, float* __restrict__ dW, long long N,
+                                                                   int ntok, int D, float frac) {
+    const int lane = threadIdx.x & 63;
+    const long long j = (long long)blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (j >= N) return;
+    const long long id = sid[j];
+    if (j > 0 && sid[j - 1] == id) return;
+    float acc[MAXV * 4];
+#pragma unroll
+    for (int e = 0; e < MAXV * 4; ++e) acc[e] = 0.f;
+    for (long long jj = j; jj < N && sid[jj] == id; ++jj) {
+        const long long src = perm[jj];
+        const long long row = (src / (ntok - 1)) * ntok + (src % (ntok - 1)) + 1;
+#pragma unroll
+        for (int e = 0; e < MAXV * 4; ++e)
+            if (lane + 64 * e < D) acc[e] += dx[row * D + lane + 64 * e];
+    }
+#pragma unroll
+    for (int e = 0; e < MAXV * 4; ++e)
+        if (lane + 64 * e < D) dW[id * D + lane + 64 * e] += frac * acc[e];
+}
+
 // axial / bos gradients, two deterministic stages:
 //  A: T[p][c] = sum_b dx[b][1+p][c]  (p < ntok-1);  T[ntok-1][c] = sum_b dx[b][0][c]  (bos)
 //  B: ax1[f] = sum_{y,w} T, ax2[y] = sum_{f,w} T, ax3[w] = sum_{f,y} T   (one block per axis entry)
@@ -707,14 +732,19 @@ extern "C" int amdnuwa_embed_fwd(const long long* ids, const float* W, const flo
 extern "C" size_t amdnuwa_embed_bwd_workspace_bytes(int ntok, int D) { return (size_t)ntok * D * sizeof(float); }
 
 // all gradient outputs are ACCUMULATED into (caller zero-fills fresh buffers)
-extern "C" int amdnuwa_embed_bwd(const long long* ids, const float* dx, float* dW, float* dax1, float* dax2, float* dax3,
-                                 float* dbos, int B, int ntok, int D, int F, int H, int Wd, float frac, void* workspace,
-                                 size_t workspace_bytes, hipStream_t stream) {
+extern "C" int amdnuwa_embed_bwd(const long long* ids, const long long* sorted_ids, const long long* perm, const float* dx, float* dW,
+                                 float* dax1, float* dax2, float* dax3, float* dbos, int B, int ntok, int D, int F, int H, int Wd,
+                                 float frac, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!ids || !dx || !dW || !dax1 || !dax2 || !dax3 || !dbos) return AMDNUWA_ERR_ARG;
     if (!workspace || workspace_bytes < amdnuwa_embed_bwd_workspace_bytes(ntok, D)) return AMDNUWA_ERR_WORKSPACE;
     const long long R = (long long)B * ntok;
     if (R <= 0) return AMDNUWA_OK;
-    hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, stream, ids, dx, dW, B, ntok, D, frac);
+    if (sorted_ids && perm) {
+        const long long N = (long long)B * (ntok - 1);
+        if (N > 0) hipLaunchKernelGGL(embed_bwd_tok_sorted_kernel, dim3((unsigned)((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, stream, sorted_ids, perm, dx, dW, N, ntok, D, frac);
+    } else {
+        hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, stream, ids, dx, dW, B, ntok, D, frac);
+    }
     LAUNCH_CHECK();
     float* T = (float*)workspace;
     hipLaunchKernelGGL(embed_bwd_possum_kernel, dim3(ntok), dim3(256), 0, stream, dx, T, dbos, B, ntok, D);

@@ -282,8 +282,9 @@ def embed_bwd(ids, dx, dW, dax1, dax2, dax3, dbos, B, ntok, F, H, Wd, frac):
     D = dW.shape[1]
     nb = L.amdnuwa_embed_bwd_workspace_bytes(ntok, D)
     ws = workspace(nb, dx.device)
-    check(L.amdnuwa_embed_bwd(_p(ids), _p(dx), _p(dW), _p(dax1), _p(dax2), _p(dax3), _p(dbos), B, ntok, D, F, H, Wd,
-                              float(frac), _p(ws), nb, _stream()), 'amdnuwa_embed_bwd')
+    sid, perm = torch.sort(ids.reshape(-1), stable=True)      # fixed summation order per embedding row: no atomics
+    check(L.amdnuwa_embed_bwd(_p(ids), _p(sid), _p(perm), _p(dx), _p(dW), _p(dax1), _p(dax2), _p(dax3), _p(dbos), B, ntok, D,
+                              F, H, Wd, float(frac), _p(ws), nb, _stream()), 'amdnuwa_embed_bwd')
 
 
 def ce_fwd(logits, targets, grad_scale, want_grad=True):

@@ -184,3 +184,25 @@ def test_missing_library_fails_loudly(A, monkeypatch):
     m = A.FeedForward(dim=32).to(DEV)
     with pytest.raises(RuntimeError, match='libamdnuwa'):
         m(torch.randn(1, 4, 32, device=DEV))
+
+
+def test_training_step_is_bitwise_reproducible(A):
+    """no atomics anywhere on the libamdnuwa path: two runs of the same step give a bit-identical loss and bit-identical
+    gradients for every decoder-side parameter (the text encoder still runs on torch ops, whose backward is not order-fixed)"""
+    torch.manual_seed(3)
+    nuwa = _tiny_nuwa(A, False).to(DEV).train()
+    g = torch.Generator().manual_seed(9)
+    text = torch.randint(1, 50, (3, 8), generator=g).to(DEV)
+    vid = torch.randint(0, 64, (3, 3, 4, 4), generator=g).to(DEV)
+    vid[:, :, 0, 0] = 7                      # repeated token ids: many rows land on the same embedding row
+    runs = []
+    for _ in range(2):
+        nuwa.zero_grad(set_to_none=True)
+        loss = nuwa(text=text, video=vid, return_loss=True, cond_dropout_prob=0.)
+        loss.backward()
+        runs.append((loss.detach().clone(), {n: p.grad.clone() for n, p in nuwa.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert len(runs[0][1]) > 40
+    for n, gr in runs[0][1].items():
+        if not n.startswith('text_'):
+            assert torch.equal(gr, runs[1][1][n]), n
