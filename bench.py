@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 CFGS = {
     'cfg3': dict(dim=512, dec_depth=24, heads=8, dim_head=64, frames=10, fmap=16, kernel=(5, 3, 3), dilation=(1, 2, 4),
                  text_len=256, codebook=8192, vae=dict(dim=64, image_size=256, num_layers=4)),
+    'cfg4': dict(dim=512, dec_depth=64, heads=8, dim_head=64, frames=10, fmap=16, kernel=(5, 3, 3), dilation=(1, 2, 4),
+                 text_len=256, codebook=8192, vae=dict(dim=64, image_size=256, num_layers=4), reversible=True),
     'cfg2': dict(dim=256, dec_depth=6, heads=8, dim_head=64, frames=4, fmap=16, kernel=(3, 3, 3), dilation=(1,),
                  text_len=256, codebook=512, vae=dict(dim=64, image_size=64, num_layers=2)),
 }
@@ -33,7 +35,8 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
 
 
 def fwd_flops_per_sample(c):
-    """ALGORITHMIC forward FLOPs per sample: GEMMs + attention cores (valid 3DNA taps only)."""
+    """ALGORITHMIC forward FLOPs per sample: GEMMs + attention cores (valid 3DNA taps only).
+    Reversible stacks (cfg 4, np.py:1246-1277) carry a FeedForward after the 3DNA block AND after the cross-attention block."""
     D, h, d, T, C = c['dim'], c['heads'], c['dim_head'], c['text_len'], c['codebook']
     n = c['frames'] * c['fmap'] ** 2
     inner = h * d
@@ -48,7 +51,7 @@ def fwd_flops_per_sample(c):
         dl = c['dilation'][l % len(c['dilation'])]
         m = causal_neighbor_mask((c['frames'], c['fmap'], c['fmap']), c['kernel'], (dl, dl, dl))
         valid = int((~m[:n - 1]).sum())
-        tot += proj3 + (4 * h * d + 2 * h * h) * valid + projx + corex + ff
+        tot += proj3 + (4 * h * d + 2 * h * h) * valid + projx + corex + ff * (2 if c.get('reversible') else 1)
     return tot + 2 * n * D * C
 
 
@@ -58,7 +61,7 @@ def build_model(c, device):
     vae = A.VQGanVAE(dim=c['vae']['dim'], image_size=c['vae']['image_size'], num_layers=c['vae']['num_layers'],
                      vq_codebook_size=c['codebook'], use_vgg_and_gan=False)
     nuwa = A.NUWA(vae=vae, dim=c['dim'], max_video_frames=c['frames'], text_max_seq_len=c['text_len'], text_enc_depth=1,
-                  enc_reversible=True, dec_depth=c['dec_depth'], dec_heads=c['heads'], dec_dim_head=c['dim_head'],
+                  enc_reversible=True, dec_reversible=bool(c.get('reversible')), dec_depth=c['dec_depth'], dec_heads=c['heads'], dec_dim_head=c['dim_head'],
                   sparse_3dna_kernel_size=c['kernel'], sparse_3dna_dilation=c['dilation'], shift_video_tokens=True)
     return nuwa.to(device).train()
 

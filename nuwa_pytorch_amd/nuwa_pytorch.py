@@ -528,11 +528,80 @@ class ReversibleBlock(nn.Module):
             y2 = x2 + g(y1, **g_args)
         return y1, y2
 
+    def backward_pass(self, y1, y2, dy1, dy2, f_args={}, g_args={}):
+        """inputs and input-gradients of this block from its outputs and output-gradients (the role of rev.py:77-106);
+        parameter gradients of f and g are accumulated by the two inner autograd calls"""
+        f, g = self.f.net, self.g.net
+        fuse_f = isinstance(f, SandwichNorm) and f._inner(f_args.get('context')) is not None and y1.is_cuda
+        fuse_g = isinstance(g, SandwichNorm) and g._inner() is not None and y1.is_cuda
+        # g(y1) again.  Fused form: one node computes (-y2) + g(y1) = -x2, whose gradient w.r.t. y1 and g's parameters is g's.
+        with torch.enable_grad():
+            y1g = y1.detach().requires_grad_(True)
+            if fuse_g:
+                neg_x2 = g.fused_residual(y1g, resid=-y2)
+                torch.autograd.backward(neg_x2, dy2)
+            else:
+                gy1 = g(y1g, **g_args)
+                torch.autograd.backward(gy1, dy2)
+        with torch.no_grad():
+            x2 = -neg_x2.detach() if fuse_g else y2 - gy1.detach()
+            dx1 = dy1 + y1g.grad
+        with torch.enable_grad():
+            x2g = x2.detach().requires_grad_(True)
+            if fuse_f:
+                neg_x1 = f.fused_residual(x2g, resid=-y1, context=f_args.get('context'), context_mask=f_args.get('context_mask'))
+                torch.autograd.backward(neg_x1, dx1)
+            else:
+                fx2 = f(x2g, **f_args)
+                torch.autograd.backward(fx2, dx1)
+        with torch.no_grad():
+            x1 = -neg_x1.detach() if fuse_f else y1 - fx2.detach()
+            dx2 = dy2 + x2g.grad
+        return x1, x2, dx1, dx2
+
+
+class _ReversibleStackFn(torch.autograd.Function):
+    """O(1)-activation-memory execution of a stack of reversible blocks (the role of rev.py:108-124): the forward keeps only
+    the output pair; the backward walks the blocks in reverse, reconstructing each block's inputs from its outputs
+    (x2 = y2 - g(y1), x1 = y1 - f(x2)) and back-propagating through one freshly recomputed f / g at a time.  Parameter (and
+    context) gradients accumulate through the inner autograd calls, as in the reference."""
+
+    @staticmethod
+    def forward(ctx, x, context, seq, args):
+        # `context` is an explicit input so that its gradient leaves this node ONCE (summed over the cross-attention blocks)
+        # instead of re-entering the text encoder's graph from every block, as the reference's retain_graph=True does
+        x1 = x2 = x.detach()
+        cdet = context.detach() if context is not None else None
+        args = [tuple({k: (cdet if k == 'context' else v) for k, v in a.items()} for a in pair) for pair in args]
+        for block, (f_args, g_args) in zip(seq.blocks, args):
+            x1, x2 = block(x1, x2, f_args=f_args, g_args=g_args)
+        ctx.seq, ctx.args, ctx.cdet = seq, args, cdet
+        ctx.save_for_backward(x1, x2)
+        return x1 + x2
+
+    @staticmethod
+    def backward(ctx, dy):
+        y1, y2 = ctx.saved_tensors
+        dy1 = dy2 = dy
+        dctx = None
+        for block, (f_args, g_args) in reversed(list(zip(ctx.seq.blocks, ctx.args))):
+            leaf = None
+            if ctx.cdet is not None and ('context' in f_args or 'context' in g_args):
+                leaf = ctx.cdet.detach().requires_grad_(True)
+                f_args = {k: (leaf if k == 'context' else v) for k, v in f_args.items()}
+                g_args = {k: (leaf if k == 'context' else v) for k, v in g_args.items()}
+            y1, y2, dy1, dy2 = block.backward_pass(y1, y2, dy1, dy2, f_args=f_args, g_args=g_args)
+            if leaf is not None and leaf.grad is not None:
+                dctx = leaf.grad if dctx is None else dctx + leaf.grad
+        return dy1 + dy2, dctx, None, None
+
 
 class ReversibleSequence(nn.Module):
-    """rev.py:126-142.  Same arithmetic as the reference (x -> (x, x); blocks; sum of the halves).
-    Activations are kept by autograd (the reference's O(1)-memory recomputation is a memory
-    optimisation, not a numerical one; on a 288 GB MI355X the decoder's activations fit)."""
+    """rev.py:126-142.  Same arithmetic as the reference (x -> (x, x); blocks; sum of the halves).  In training the stack runs
+    through _ReversibleStackFn (activations of one block at a time); `memory_efficient = False` keeps every activation in the
+    autograd graph instead (bit-for-bit the same forward, no recomputation error in the backward)."""
+
+    memory_efficient = True
 
     def __init__(self, blocks, args_route={}):
         super().__init__()
@@ -541,6 +610,9 @@ class ReversibleSequence(nn.Module):
 
     def forward(self, x, **kwargs):
         args = route_args(self.args_route, kwargs, len(self.blocks))
+        if self.memory_efficient and torch.is_grad_enabled() and x.is_cuda and \
+                (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _ReversibleStackFn.apply(x, kwargs.get('context'), self, args)
         x1, x2 = x, x
         for block, (f_args, g_args) in zip(self.blocks, args):
             x1, x2 = block(x1, x2, f_args=f_args, g_args=g_args)

@@ -206,3 +206,47 @@ def test_training_step_is_bitwise_reproducible(A):
     for n, gr in runs[0][1].items():
         if not n.startswith('text_'):
             assert torch.equal(gr, runs[1][1][n]), n
+
+
+def test_reversible_stack_memory_is_depth_independent(A):
+    """cfg-4 path (dec_reversible=True): with the recomputing backward the peak activation memory of a deep stack stays
+    close to that of a shallow one, while the stored-activation mode grows with depth; both give the same gradients"""
+    import nuwa_pytorch_amd.nuwa_pytorch as M
+
+    def run(depth, efficient):
+        torch.manual_seed(0)
+        tr = M.ReversibleTransformer(dim=64, depth=depth, causal=True, heads=2, dim_head=32, cross_attend=True,
+                                     sparse_3dna_attn=True, sparse_3dna_kernel_size=3, sparse_3dna_video_shape=(4, 8, 8),
+                                     sparse_3dna_dilations=(1, 2), shift_video_tokens=True).to(DEV).train()
+        tr.net.memory_efficient = efficient
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(16, 256, 64, generator=g).to(DEV).requires_grad_(True)
+        ctx = torch.randn(16, 16, 64, generator=g).to(DEV).requires_grad_(True)
+        mask = torch.ones(16, 16, dtype=torch.bool, device=DEV)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        y = tr(x, context=ctx, context_mask=mask)
+        y.square().mean().backward()
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - base
+        grads = {n: p.grad.clone() for n, p in tr.named_parameters() if p.grad is not None and n.startswith('layers.0.')}
+        return peak, x.grad.clone(), ctx.grad.clone(), grads
+
+    A.set_precision('bf16x3')
+    try:
+        p2, *_ = run(2, True)
+        p8, dx_e, dc_e, g_e = run(8, True)
+        q2, *_ = run(2, False)
+        q8, dx_s, dc_s, g_s = run(8, False)
+    finally:
+        A.set_precision('bf16')
+    print('peak bytes: recompute depth 2 / 8 =', p2, p8, ' stored depth 2 / 8 =', q2, q8)
+    # going from depth 2 to depth 8 the stored-activation mode grows by 6 layers of activations; the recomputing mode only by
+    # the parameter gradients and cached bf16 weights of those layers
+    assert (p8 - p2) < 0.35 * (q8 - q2), (p2, p8, q2, q8)
+    assert q8 > 1.5 * p8, (p8, q8)
+    report('rev.dx', dx_e, dx_s, 2e-3)
+    report('rev.dctx', dc_e, dc_s, 2e-3)
+    for n in g_s:
+        report(f'rev.grad.{n}', g_e[n], g_s[n], 2e-3)
