@@ -220,6 +220,16 @@ int amdnuwa_groupnorm_fwd(const float* x, const float* w, const float* b, float*
 int amdnuwa_vq_argmax(const float* x, const float* codebook, long long* indices, float* best_sim, long long R,
                       int n_codes, int code_dim, amdnuwa_stream stream);
 
+/* VQGanAttention block of the encoder (vqgan_vae.py:244-286), exact fp32: in-place l2 normalisation of rows (q and k over the
+ * spatial axis), the per-(image, head) attention core with the continuous-position bias [heads][P][P] precomputed from the
+ * module's parameters and the learned log-scale, and LayerNormChan (+ residual) over the channel axis of an NCHW tensor. */
+/* rows: `groups` groups of rows_per_group consecutive rows of length len, group g starting at row g * group_stride_rows */
+int amdnuwa_rows_l2norm(float* x, int groups, int rows_per_group, int group_stride_rows, int len, amdnuwa_stream stream);
+int amdnuwa_vqattn_core(const float* qkv, const float* bias, const float* scale, float* out, int N, int heads, int dim_head,
+                        int P, amdnuwa_stream stream);
+int amdnuwa_chan_layernorm(const float* x, const float* g, const float* b, const float* resid, float* y, int N, int C, int HW,
+                           float eps, amdnuwa_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

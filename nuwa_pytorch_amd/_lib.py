@@ -88,6 +88,9 @@ SIGNATURES = {
     'amdnuwa_conv2d_fwd': (I, [CD, P, P, P, P, P]),
     'amdnuwa_groupnorm_fwd': (I, [P, P, P, P, I, I, I, I, F, I, P]),
     'amdnuwa_vq_argmax': (I, [P, P, P, P, LL, I, I, P]),
+    'amdnuwa_rows_l2norm': (I, [P, I, I, I, I, P]),
+    'amdnuwa_vqattn_core': (I, [P, P, P, P, I, I, I, I, P]),
+    'amdnuwa_chan_layernorm': (I, [P, P, P, P, P, I, I, I, F, P]),
 }
 
 _lib = None

@@ -212,7 +212,151 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
     }
 }
 
+// ---- VQGanAttention core (vq.py:244-286), exact fp32 ----------------------------------------------------------------
+// rows of length len: x <- x / max(||x||_2, 1e-12)   (F.normalize over the SPATIAL axis of q and k, quirk Q9)
+// (rows come in `groups` groups of rows_per_group consecutive rows, group g starting at row g * group_stride_rows)
+__global__ __launch_bounds__(256) void rows_l2norm_kernel(float* __restrict__ x, long long rows, int rows_per_group, int group_stride_rows, int len) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float* p = x + ((r / rows_per_group) * group_stride_rows + r % rows_per_group) * len;
+    float ss = 0.f;
+    for (int i = lane; i < len; i += 64) ss += p[i] * p[i];
+    ss = wave_sum(ss);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    for (int i = lane; i < len; i += 64) p[i] *= inv;
+}
+
+// one workgroup per (image, head), one thread per query position i (P <= 256 positions, c <= 64 channels per head):
+//   s_ij = (sum_c qn[c][i] kn[c][j]) * exp(scale[head]) + bias[head][i][j];  softmax over j;  out[c][i] = sum_j p_ij v[c][j]
+// kn and v of the head sit in LDS and are read by all threads at the same address (broadcast).  Two passes over j (row max,
+// then exp / sum / PV) -- the whole block is < 0.5 % of the tokenizer, clarity over speed.
+__global__ __launch_bounds__(256) void vqattn_core_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                          const float* __restrict__ scale, float* __restrict__ out, int heads, int c,
+                                                          int P) {
+    extern __shared__ float sm[];
+    float* ks = sm;                     // [c][P]
+    float* vs = sm + c * P;             // [c][P]
+    const int n = blockIdx.x / heads, hh = blockIdx.x % heads, i = threadIdx.x;
+    const size_t img = (size_t)n * 3 * heads * c * P;
+    const float* q = qkv + img + (size_t)hh * c * P;
+    const float* k = qkv + img + (size_t)(heads + hh) * c * P;
+    const float* v = qkv + img + (size_t)(2 * heads + hh) * c * P;
+    for (int e = threadIdx.x; e < c * P; e += blockDim.x) { ks[e] = k[e]; vs[e] = v[e]; }
+    __syncthreads();
+    if (i >= P) return;
+    float qv[64], acc[64];
+#pragma unroll
+    for (int cc = 0; cc < 64; ++cc) { qv[cc] = cc < c ? q[(size_t)cc * P + i] : 0.f; acc[cc] = 0.f; }
+    const float se = expf(scale[hh]);
+    const float* brow = bias + ((size_t)hh * P + i) * P;
+    float m = -3.0e38f, l = 0.f;
+    if (P % 4 == 0) {
+        // 4 keys per step: one broadcast float4 LDS read feeds 4 FMAs
+        for (int j = 0; j < P; j += 4) {
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 64; ++cc)
+                if (cc < c) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(ks + cc * P + j);
+                    d0 = fmaf(qv[cc], k4.x, d0); d1 = fmaf(qv[cc], k4.y, d1); d2 = fmaf(qv[cc], k4.z, d2); d3 = fmaf(qv[cc], k4.w, d3);
+                }
+            const float4 b4 = *reinterpret_cast<const float4*>(brow + j);
+            m = fmaxf(fmaxf(m, fmaxf(d0 * se + b4.x, d1 * se + b4.y)), fmaxf(d2 * se + b4.z, d3 * se + b4.w));
+        }
+        for (int j = 0; j < P; j += 4) {
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 64; ++cc)
+                if (cc < c) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(ks + cc * P + j);
+                    d0 = fmaf(qv[cc], k4.x, d0); d1 = fmaf(qv[cc], k4.y, d1); d2 = fmaf(qv[cc], k4.z, d2); d3 = fmaf(qv[cc], k4.w, d3);
+                }
+            const float4 b4 = *reinterpret_cast<const float4*>(brow + j);
+            const float p0 = expf(d0 * se + b4.x - m), p1 = expf(d1 * se + b4.y - m), p2 = expf(d2 * se + b4.z - m), p3 = expf(d3 * se + b4.w - m);
+            l += (p0 + p1) + (p2 + p3);
+#pragma unroll
+            for (int cc = 0; cc < 64; ++cc)
+                if (cc < c) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(vs + cc * P + j);
+                    acc[cc] = fmaf(p3, v4.w, fmaf(p2, v4.z, fmaf(p1, v4.y, fmaf(p0, v4.x, acc[cc]))));
+                }
+        }
+    } else {
+        for (int j = 0; j < P; ++j) {
+            float d = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 64; ++cc) if (cc < c) d = fmaf(qv[cc], ks[cc * P + j], d);
+            m = fmaxf(m, d * se + brow[j]);
+        }
+        for (int j = 0; j < P; ++j) {
+            float d = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 64; ++cc) if (cc < c) d = fmaf(qv[cc], ks[cc * P + j], d);
+            const float pj = expf(d * se + brow[j] - m);
+            l += pj;
+#pragma unroll
+            for (int cc = 0; cc < 64; ++cc) if (cc < c) acc[cc] = fmaf(pj, vs[cc * P + j], acc[cc]);
+        }
+    }
+    const float il = 1.f / l;
+    float* o = out + ((size_t)n * heads + hh) * c * P;
+#pragma unroll
+    for (int cc = 0; cc < 64; ++cc) if (cc < c) o[(size_t)cc * P + i] = acc[cc] * il;
+}
+
+// LayerNormChan (vq.py:178-190) over the channel axis of an NCHW tensor, + residual: one thread per (image, position)
+__global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                             const float* __restrict__ resid, float* __restrict__ y, long long NP, int C, int HW,
+                                                             float eps) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= NP) return;
+    const size_t base = (size_t)(t / HW) * C * HW + (size_t)(t % HW);
+    float s = 0.f;
+    for (int ch = 0; ch < C; ++ch) s += x[base + (size_t)ch * HW];
+    const float mean = s / C;
+    float q = 0.f;
+    for (int ch = 0; ch < C; ++ch) { const float d = x[base + (size_t)ch * HW] - mean; q += d * d; }
+    const float den = sqrtf(q / C + eps);                 // (x - mean) / (var + eps).sqrt() * g + b, var unbiased=False
+    for (int ch = 0; ch < C; ++ch) {
+        float v = (x[base + (size_t)ch * HW] - mean) / den * g[ch] + b[ch];
+        if (resid) v += resid[base + (size_t)ch * HW];
+        y[base + (size_t)ch * HW] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int amdnuwa_rows_l2norm(float* x, int groups, int rows_per_group, int group_stride_rows, int len, hipStream_t stream) {
+    if (!x || len <= 0 || rows_per_group <= 0 || group_stride_rows < rows_per_group) return AMDNUWA_ERR_ARG;
+    const long long rows = (long long)groups * rows_per_group;
+    if (rows <= 0) return AMDNUWA_OK;
+    hipLaunchKernelGGL(rows_l2norm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, rows, rows_per_group, group_stride_rows, len);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_vqattn_core(const float* qkv, const float* bias, const float* scale, float* out, int N, int heads, int dim_head,
+                                   int P, hipStream_t stream) {
+    if (!qkv || !bias || !scale || !out || heads <= 0) return AMDNUWA_ERR_ARG;
+    if (dim_head < 1 || dim_head > 64 || P < 1 || P > 256) return AMDNUWA_ERR_UNSUPPORTED;
+    if (N <= 0) return AMDNUWA_OK;
+    const size_t lds = (size_t)2 * dim_head * P * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)vqattn_core_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(vqattn_core_kernel, dim3(N * heads), dim3(256), lds, stream, qkv, bias, scale, out, heads, dim_head, P);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_chan_layernorm(const float* x, const float* g, const float* b, const float* resid, float* y, int N, int C, int HW,
+                                      float eps, hipStream_t stream) {
+    if (!x || !g || !b || !y || C <= 0 || HW <= 0) return AMDNUWA_ERR_ARG;
+    if (N <= 0) return AMDNUWA_OK;
+    const long long NP = (long long)N * HW;
+    hipLaunchKernelGGL(chan_layernorm_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, x, g, b, resid, y, NP, C, HW, eps);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
 
 extern "C" int amdnuwa_conv2d_fwd(const amdnuwa_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                                   hipStream_t stream) {

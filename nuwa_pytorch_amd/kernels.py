@@ -525,3 +525,24 @@ def vq_argmax(x, codebook, want_sim=False):
     sim = torch.empty((R,), dtype=torch.float32, device=x.device) if want_sim else None
     check(L.amdnuwa_vq_argmax(_p(x), _p(codebook), _p(idx), _p(sim), R, codebook.shape[0], Dc, _stream()), 'amdnuwa_vq_argmax')
     return (idx, sim) if want_sim else idx
+
+
+def vqgan_attention(x, qkv_w, out_w, out_b, bias, scale, ln_g, ln_b, heads, eps):
+    """VQGanAttention.forward (reference vqgan_vae.py:263-286) on NCHW fp32 x: returns post_norm(to_out(attn)) + x.
+    bias: continuous-position bias [heads, P, P] (parameters only); scale: the learned log-scale [heads]."""
+    L = _lib.lib()
+    x = _f32c(x)
+    N, Cc, H, W = x.shape
+    P_ = H * W
+    qkv = conv2d_fwd(x, qkv_w, None, 1, 0)                       # [N, 3*heads*c, H, W]
+    c = qkv.shape[1] // (3 * heads)
+    # q and k = the first 2*heads*c of the 3*heads*c channel rows of every image
+    check(L.amdnuwa_rows_l2norm(_p(qkv), N, 2 * heads * c, 3 * heads * c, P_, _stream()), 'amdnuwa_rows_l2norm')
+    out = torch.empty((N, heads * c, H, W), dtype=torch.float32, device=x.device)
+    check(L.amdnuwa_vqattn_core(_p(qkv), _p(_f32c(bias)), _p(_f32c(scale).reshape(-1)), _p(out), N, heads, c, P_, _stream()),
+          'amdnuwa_vqattn_core')
+    o = conv2d_fwd(out, out_w, out_b, 1, 0)
+    y = torch.empty_like(o)
+    check(L.amdnuwa_chan_layernorm(_p(o), _p(_f32c(ln_g).reshape(-1)), _p(_f32c(ln_b).reshape(-1)), _p(x), _p(y), N, o.shape[1], P_,
+                                   float(eps), _stream()), 'amdnuwa_chan_layernorm')
+    return y

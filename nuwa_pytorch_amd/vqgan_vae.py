@@ -297,8 +297,8 @@ class VQGanVAE(nn.Module):
         return video.reshape(b, -1, *video.shape[1:])
 
     def _hip_module(self, m, x):
-        """one encoder stage through libamdnuwa (exact fp32): the convolutions, GroupNorm(+LeakyReLU); the single
-        VQGanAttention block keeps its 256-position softmax in torch fp32 ops around HIP 1x1 convs."""
+        """one encoder stage through libamdnuwa (exact fp32): convolutions, GroupNorm(+LeakyReLU), and the VQGanAttention
+        block (q/k l2norm over the spatial axis, biased softmax attention, LayerNormChan + residual)."""
         from . import kernels as K
         if isinstance(m, nn.Conv2d):
             assert m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1] and m.dilation == (1, 1) and m.groups == 1
@@ -314,16 +314,12 @@ class VQGanVAE(nn.Module):
             h = K.groupnorm_fwd(h, g2.weight, g2.bias, g2.num_groups, g2.eps, leaky=True)
             return K.conv2d_fwd(h, c3.weight, c3.bias, 1, 0) + x
         if isinstance(m, VQGanAttention):
-            h = m.heads
             B, _, height, width = x.shape
-            q, k, v = K.conv2d_fwd(x, m.to_qkv.weight, None, 1, 0).chunk(3, dim=1)
-            q, k, v = map(lambda t: t.reshape(B, h, -1, height * width), (q, k, v))
-            q, k = map(l2norm, (q, k))
-            sim = einsum('b h c i, b h c j -> b h i j', q, k) * m.scale.exp()
-            attn = stable_softmax(m.cpb(sim), dim=-1)
-            out = einsum('b h i j, b h c j -> b h c i', attn, v).reshape(B, -1, height, width)
-            out = K.conv2d_fwd(out, m.to_out.weight, m.to_out.bias, 1, 0)
-            return m.post_norm(out) + x
+            P_ = height * width
+            # continuous position bias: a function of the module's parameters only (vq.py:192-226) -> [heads, P, P]
+            bias = m.cpb(torch.zeros(1, m.heads, P_, P_, device=x.device))[0]
+            return K.vqgan_attention(x, m.to_qkv.weight, m.to_out.weight, m.to_out.bias, bias, m.scale, m.post_norm.g, m.post_norm.b,
+                                     m.heads, m.post_norm.eps)
         raise NotImplementedError(f'no libamdnuwa path for encoder stage {type(m).__name__}')
 
     def _hip_encode_indices(self, images):
