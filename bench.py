@@ -273,7 +273,7 @@ def main():
         if tr is not None:
             out['roofline']['traffic'] = tr['bytes_per_launch']
             out['roofline']['traffic_source'] = tr['source']
-        if not args.no_tokenizer:
+        if not args.no_tokenizer and world == 1:          # (side measurement, single-GPU runs only: keeps the ranks in step)
             out['vae_tokenizer'] = tokenizer_rate(nuwa, c, min(b, 8), dev)
         if world == 1 and not args.no_cpu_baseline:
             try:

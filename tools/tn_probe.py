@@ -25,4 +25,7 @@ for name, n1, n2, sh in [('dW q (shift)', 512, 512, True), ('dW kv (shift)', 102
         t = bench(f, 10)
         row.append(f'{"lockstep" if st else "stagger "} {t * 1e6:6.1f} us {2.0 * M * n1 * n2 / t / 1e12:6.1f} TF/s' + ('' if err < 1e-5 else f' MISMATCH {err:.1e}'))
     L.amdnuwa_set_tuning(8, 0)
+    At, Bt = A.hi[:, :n1], Bm.hi[:, :n2]
+    tl = bench(lambda: torch.matmul(At.t(), Bt), 10)          # library yardstick (no token shift)
+    row.append(f'torch.matmul {tl * 1e6:6.1f} us {2.0 * M * n1 * n2 / tl / 1e12:6.1f} TF/s')
     print(f'{name:22s} [{n1}x{n2}]  ' + ' | '.join(row))
