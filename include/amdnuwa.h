@@ -139,6 +139,11 @@ typedef struct {
     int df, dh, dw;         /* dilation */
     int heads, dim_head;    /* heads <= 8; dim_head in {32, 64}; W*heads*4 <= 512 */
     float scale;            /* dim_head ** -0.5 */
+    /* relative-position bias (Sparse3DNA(rel_pos_bias=True), np.py:512-516, 542): rel_bias[j][head] is added to the score of
+     * key slot j (j = 0 is <bos>: pass 0 there), fp32 [kf*kh*kw + 1][heads] or NULL.  The backward writes its gradient
+     * (column sums of ds over every query) to d_rel_bias when that is non-NULL. */
+    const float* rel_bias;
+    float* d_rel_bias;
 } amdnuwa_s3_geom;
 
 int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* k, const uint16_t* v,

@@ -6,7 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libamdnuwa.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 P = C.c_void_p
 I = C.c_int
@@ -26,7 +26,8 @@ class GemmDesc(C.Structure):
 
 class S3Geom(C.Structure):
     _fields_ = [('B', I), ('ntok', I), ('F', I), ('H', I), ('W', I), ('kf', I), ('kh', I), ('kw', I),
-                ('df', I), ('dh', I), ('dw', I), ('heads', I), ('dim_head', I), ('scale', F)]
+                ('df', I), ('dh', I), ('dw', I), ('heads', I), ('dim_head', I), ('scale', F),
+                ('rel_bias', P), ('d_rel_bias', P)]
 
 
 class XGeom(C.Structure):

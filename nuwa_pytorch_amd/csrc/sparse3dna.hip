@@ -30,6 +30,7 @@ struct S3Args {
     const bf16_t *dO, *dOl; int lddo;                     // bwd in
     bf16_t *dq, *dk, *dv, *dql, *dkl, *dvl; int ldd;      // bwd out
     const float* wth;                                     // [NH][NH] talking heads (g, h)
+    const float* bias;                                    // [J][NH] relative-position bias per key slot (or NULL)
     float *ds, *pm;                                       // [B][nq][J][NH]
     float *part_th, *part_k0, *part_v0;                   // [B*F*H][NH*NH], [B*F*H][NH*DH] x2
     float* dwth;                                          // [NH*NH] accumulated
@@ -209,11 +210,11 @@ __device__ __forceinline__ void scores_softmax(const S3Args& a, int b, int f, in
     if (qvalid) {
         const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
         const float s = qk(a.k + g, a.kl ? a.kl + g : nullptr, 8);
-        if (c == 0) SP[(w * J + 0) * a.NH + h] = s * a.scale;
+        if (c == 0) SP[(w * J + 0) * a.NH + h] = s * a.scale + (a.bias ? a.bias[h] : 0.f);
     }
     sweep_taps<CH>(a, a.k, a.kl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* khi, const bf16_t* klo, int hs) {
         const float s = qk(khi, klo, hs);
-        if (c == 0) SP[(w * J + j) * a.NH + h] = s * a.scale;
+        if (c == 0) SP[(w * J + j) * a.NH + h] = s * a.scale + (a.bias ? a.bias[j * a.NH + h] : 0.f);
     });
     __syncthreads();
     // fp32 softmax over the J slots of each (w, h): the 4 lanes of the group split j
@@ -676,7 +677,7 @@ int check_geom(const amdnuwa_s3_geom* g) {
 }
 void fill_geom(S3Args& a, const amdnuwa_s3_geom* g) {
     a.B = g->B; a.ntok = g->ntok; a.F = g->F; a.H = g->H; a.W = g->W; a.kf = g->kf; a.kh = g->kh; a.kw = g->kw;
-    a.df = g->df; a.dh = g->dh; a.dw = g->dw; a.NH = g->heads; a.scale = g->scale;
+    a.df = g->df; a.dh = g->dh; a.dw = g->dw; a.NH = g->heads; a.scale = g->scale; a.bias = g->rel_bias;
 }
 int block_threads(const amdnuwa_s3_geom* g) { return ((g->W * g->heads * 4 + 63) / 64) * 64; }
 
@@ -717,7 +718,8 @@ extern "C" size_t amdnuwa_sparse3dna_bwd_workspace_bytes(const amdnuwa_s3_geom* 
     if (check_geom(g)) return 0;
     const size_t J = (size_t)g->kf * g->kh * g->kw + 1, nq = g->ntok - 1, rows = (size_t)g->B * g->F * g->H;
     const size_t inner = (size_t)g->heads * g->dim_head;
-    return (2 * (size_t)g->B * nq * J * g->heads + rows * g->heads * g->heads + 2 * rows * inner) * sizeof(float) + 256;
+    return (2 * (size_t)g->B * nq * J * g->heads + rows * g->heads * g->heads + 2 * rows * inner) * sizeof(float) + 256 +
+           amdnuwa_colsum_workspace_bytes((long long)g->B * nq, (int)(J * g->heads));
 }
 
 extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* k, const uint16_t* v,
@@ -772,5 +774,11 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     LAUNCH_CHECK();
     hipLaunchKernelGGL(s3_bwd_fin_kernel, dim3(g->B * (((int)inner + 63) / 64) + (g->heads * g->heads + 15) / 16), dim3(1024), 0, stream, a, g->dim_head);
     LAUNCH_CHECK();
+    if (g->d_rel_bias) {         // d(bias)[j][h] = sum over every (sample, query) of ds[.][j][h]: fixed-order column sums of the ds workspace
+        float* cws = a.part_v0 + rows * inner;
+        const int rc2 = amdnuwa_colsum(a.ds, g->d_rel_bias, (long long)g->B * nq, (int)(J * g->heads), 0, cws,
+                                       amdnuwa_colsum_workspace_bytes((long long)g->B * nq, (int)(J * g->heads)), stream);
+        if (rc2) return rc2;
+    }
     return AMDNUWA_OK;
 }

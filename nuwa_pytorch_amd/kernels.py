@@ -317,9 +317,10 @@ def s3_geom(B, ntok, video_shape, kernel, dilation, heads, dim_head):
     return g
 
 
-def sparse3dna_fwd(g, qkv, wth):
-    """qkv: BF [B*ntok, 3*inner] (q | k | v);  returns o BF [B*ntok, inner]"""
+def sparse3dna_fwd(g, qkv, wth, rel_bias=None):
+    """qkv: BF [B*ntok, 3*inner] (q | k | v);  returns o BF [B*ntok, inner].  rel_bias: fp32 [J, heads] or None"""
     L = _lib.lib()
+    g.rel_bias, g.d_rel_bias = _p(rel_bias), None
     inner = g.heads * g.dim_head
     R = g.B * g.ntok
     o = empty_bf((R, inner), qkv.hi.device, lo=qkv.lo is not None)
@@ -329,9 +330,12 @@ def sparse3dna_fwd(g, qkv, wth):
     return o
 
 
-def sparse3dna_bwd(g, qkv, wth, dO):
-    """returns (dqkv BF [R, 3*inner], dw_th fp32 [h, h])"""
+def sparse3dna_bwd(g, qkv, wth, dO, rel_bias=None):
+    """returns (dqkv BF [R, 3*inner], dw_th fp32 [h, h]) -- and d(rel_bias) fp32 [J, heads] as a third item when rel_bias is given
+    (callers that pass rel_bias=None through the keyword get a 3-tuple with None)"""
     L = _lib.lib()
+    drel = torch.empty_like(rel_bias) if rel_bias is not None else None
+    g.rel_bias, g.d_rel_bias = _p(rel_bias), _p(drel)
     inner = g.heads * g.dim_head
     R = g.B * g.ntok
     dev = qkv.hi.device
@@ -345,7 +349,8 @@ def sparse3dna_bwd(g, qkv, wth, dO):
                                    _p(wth), _p(dO.hi), _p(dO.lo), dO.hi.stride(0), _p(dq.hi), _p(dk.hi), _p(dv.hi),
                                    _p(dq.lo), _p(dk.lo), _p(dv.lo), dqkv.hi.stride(0), _p(dwth), 0, _p(ws), nb, _stream()),
           'amdnuwa_sparse3dna_bwd')
-    return dqkv, dwth
+    g.d_rel_bias = None
+    return dqkv, dwth, drel
 
 
 def x_geom(B, n, T, heads, dim_head):

@@ -370,11 +370,11 @@ class Sparse3DNA(nn.Module):
         self.kernel_size = cast_tuple(kernel_size, size=3)
         assert all(map(lambda n: n % 2 == 1, self.kernel_size)), 'kernel size must be odd'
         self.kernel_numel = mult_reduce(self.kernel_size)
-        if rel_pos_bias:
-            raise NotImplementedError('Sparse3DNA(rel_pos_bias=True) is not supported by the HIP path yet')
         if not causal:
             raise NotImplementedError('non-causal Sparse3DNA (NUWASketch encoder) is not supported by the HIP path yet')
-        self.rel_pos_bias = None
+        # np.py:416: one bias per (key tap, head), axial over the kernel (the reference's add only broadcasts for batch 1; here
+        # the same per-head bias is applied to every sample)
+        self.rel_pos_bias = AxialPositionalEmbedding(heads, shape=self.kernel_size) if rel_pos_bias else None
         self.video_shape = video_shape
         max_frames, fmap_size, _ = video_shape
         self.max_num_tokens = max_frames * fmap_size * fmap_size
@@ -383,7 +383,11 @@ class Sparse3DNA(nn.Module):
         self._cache = ops.WeightCache()
 
     def _params(self):
-        return (self.to_q.weight, self.to_kv.weight, self.talking_heads.weight, self.to_out.weight, self.to_out.bias)
+        p = (self.to_q.weight, self.to_kv.weight, self.talking_heads.weight, self.to_out.weight, self.to_out.bias)
+        if self.rel_pos_bias is not None:
+            taps = self.rel_pos_bias().reshape(self.kernel_numel, self.heads)             # [taps, heads], raster (a, b, c) order
+            p = p + (torch.cat((taps.new_zeros(1, self.heads), taps), 0).float(),)       # key slot 0 = <bos>: no bias
+        return p
 
     def _meta(self, B, n, device, **_):
         if self.training and self.dropout.p > 0:

@@ -68,7 +68,7 @@ class S3Inner:
 
     @staticmethod
     def weights(cache, p):
-        wq, wkv, wth, wo, bo = p
+        wq, wkv, wth, wo, bo = p[:5]
 
         def build():
             inner, D = wq.shape
@@ -86,8 +86,9 @@ class S3Inner:
         W = S3Inner.weights(meta['cache'], p)
         wth, bo = p[2], p[4]
         g = meta['geom']
+        rel = p[5].detach().contiguous() if len(p) > 5 else None          # [J, heads] relative-position bias (optional)
         qkv = K.gemm_nt(h, W['qkv'], out_bf16=True, shift=meta.get('shift'))
-        o = K.sparse3dna_fwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous())
+        o = K.sparse3dna_fwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), rel_bias=rel)
         y = K.gemm_nt(o, W['out'], bias=bo.detach(), out_bf16=_fast())
         return y, (h, qkv, o)
 
@@ -95,20 +96,24 @@ class S3Inner:
     def bwd(saved, dy, p, meta, need_dbias=True, dy_f32=None):
         h, qkv, o = saved
         W = S3Inner.weights(meta['cache'], p)
-        wq, wkv, wth, wo, bo = p
+        wq, wkv, wth, wo, bo = p[:5]
+        rel = p[5].detach().contiguous() if len(p) > 5 else None
         g = meta['geom']
         inner = g.heads * g.dim_head
         d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
         dwo = torch.empty_like(wo)
         meta['wg'].run(lambda: K.gemm_tn(dy, o, dwo))
-        dqkv, dwth = K.sparse3dna_bwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), d_o)
+        dqkv, dwth, drel = K.sparse3dna_bwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), d_o, rel_bias=rel)
         dh = K.gemm_nt(dqkv, W['qkvT'], out_bf16=_fast())
         sh = meta.get('shift')
         dwqkv = torch.empty((3 * inner, wq.shape[1]), dtype=torch.float32, device=wq.device)   # one wgrad GEMM for [to_q; to_kv]
         meta['wg'].run(lambda: K.gemm_tn(dqkv, h, dwqkv, shift=sh))
         dwq, dwkv = dwqkv[:inner], dwqkv[inner:]
         dbo = K.colsum(dy_f32) if (need_dbias and dy_f32 is not None) else None
-        return dh, None, [dwq, dwkv, dwth.reshape(wth.shape), dwo, dbo]
+        grads = [dwq, dwkv, dwth.reshape(wth.shape), dwo, dbo]
+        if rel is not None:
+            grads.append(drel)
+        return dh, None, grads
 
 
 class XInner:

@@ -65,6 +65,24 @@ def g1_sparse3dna():
              heads=2, **params(m), **grads(m))
 
 
+def g1b_sparse3dna_rel_pos_bias():
+    """Sparse3DNA(rel_pos_bias=True) (np.py:416, 512-516, 542): the axial bias over the key taps, incl. its gradient.
+    Batch 1 only: the reference adds an (h, 1, j) bias to a ((b h), i, j) score tensor, which broadcasts for b == 1 alone."""
+    for ci, (shape, kernel, dil, n) in enumerate([((4, 8, 8), (5, 3, 3), 2, None), ((3, 4, 4), 3, 1, 23)]):
+        torch.manual_seed(0)
+        m = Sparse3DNA(dim=32, video_shape=shape, kernel_size=kernel, dilation=dil, heads=2, dim_head=32, causal=True, rel_pos_bias=True)
+        N = shape[0] * shape[1] * shape[2]
+        n = N if n is None else n
+        torch.manual_seed(1)
+        x = torch.randn(1, n, 32, requires_grad=True)
+        y = m(x)
+        g = torch.randn_like(y)
+        y.backward(g)
+        ks = kernel if isinstance(kernel, tuple) else (kernel,) * 3
+        save(f'g1b_sparse3dna_relpos_{ci}', x=x, y=y, dy=g, dx=x.grad, video_shape=shape, kernel_size=ks, dilation=dil,
+             heads=2, **params(m), **grads(m))
+
+
 def g2_cross_attention():
     torch.manual_seed(0)
     m = Attention(dim=32, heads=2, dim_head=32)
@@ -182,6 +200,7 @@ def g8_decoder_layer():
 
 if __name__ == '__main__':
     g1_sparse3dna()
+    g1b_sparse3dna_rel_pos_bias()
     g2_cross_attention()
     g3_feedforward()
     g4_norms_and_shift()

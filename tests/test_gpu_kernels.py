@@ -316,7 +316,7 @@ def test_sparse3dna_core(K, O, case, x3):
     tol_o = 3e-5 if x3 else 2 ** -7
     tag = f'[{case},x3={x3}]'
     report('s3_fwd' + tag, (bf_value(o) if x3 else o.hi.float()).reshape(B, n, heads, dh), o_ref.detach(), tol_o)
-    dqkv, dwth = K.sparse3dna_bwd(g, qkvp, wth.detach().to(DEV), to_bf_pair(do.reshape(B * n, inner).to(DEV), x3))
+    dqkv, dwth, _ = K.sparse3dna_bwd(g, qkvp, wth.detach().to(DEV), to_bf_pair(do.reshape(B * n, inner).to(DEV), x3))
     gq = qkv.grad.reshape(B * n, 3 * inner)
     got = bf_value(dqkv) if x3 else dqkv.hi.float()
     tol_g = 5e-5 if x3 else 2 ** -6
@@ -401,8 +401,8 @@ def test_sparse3dna_fullsize_causality_and_determinism(K):
     o2 = K.sparse3dna_fwd(g, p1, wth).hi
     assert torch.equal(o1, o2)
     do = to_bf_pair(torch.randn(B * n, inner, device=DEV), False)
-    d1, w1 = K.sparse3dna_bwd(g, p1, wth, do)
-    d2, w2 = K.sparse3dna_bwd(g, p1, wth, do)
+    d1, w1, _ = K.sparse3dna_bwd(g, p1, wth, do)
+    d2, w2, _ = K.sparse3dna_bwd(g, p1, wth, do)
     assert torch.equal(d1.hi, d2.hi) and torch.equal(w1, w2)
     cut = 1500
     qkv2 = qkv.clone()

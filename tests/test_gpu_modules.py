@@ -147,6 +147,27 @@ def test_g8_decoder_stack(A, mode, tol, gtol):
         A.set_precision('bf16')
 
 
+@pytest.mark.parametrize('mode,tol,gtol', MODES)
+@pytest.mark.parametrize('ci', range(2))
+def test_g1b_sparse3dna_rel_pos_bias(A, ci, mode, tol, gtol):
+    """Sparse3DNA(rel_pos_bias=True): the axial per-tap, per-head bias and its gradient against the reference fixture"""
+    Ar, P, G = load(f'g1b_sparse3dna_relpos_{ci}')
+    m = A.Sparse3DNA(dim=32, video_shape=tup(Ar['video_shape']), kernel_size=tup(Ar['kernel_size']), dilation=int(Ar['dilation']),
+                     heads=int(Ar['heads']), dim_head=32, causal=True, rel_pos_bias=True)
+    m.load_state_dict(P)
+    m = m.to(DEV)
+    run_mode(A, mode)
+    try:
+        x = Ar['x'].to(DEV).requires_grad_(True)
+        y = m(x)
+        report(f'g1b[{ci},{mode}].y', y, Ar['y'], tol)
+        y.backward(Ar['dy'].to(DEV))
+        report(f'g1b[{ci},{mode}].dx', x.grad, Ar['dx'], gtol)
+        assert check_grads(m, G, gtol, f'g1b[{ci},{mode}]') >= 8
+    finally:
+        A.set_precision('bf16')
+
+
 def _tiny_nuwa(A, reversible):
     vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
     return A.NUWA(vae=vae, dim=32, text_num_tokens=50, text_max_seq_len=8, max_video_frames=3, text_enc_depth=2,

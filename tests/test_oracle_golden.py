@@ -27,6 +27,20 @@ def test_g1_sparse3dna(ci):
         torch.testing.assert_close(P[k].grad, g, **TOL)
 
 
+@pytest.mark.parametrize('ci', range(2))
+def test_g1b_sparse3dna_rel_pos_bias(ci):
+    A, P, G = load(f'g1b_sparse3dna_relpos_{ci}')
+    P = req(P)
+    x = A['x'].clone().requires_grad_(True)
+    y = O.sparse3dna(x, P, tup(A['video_shape']), tup(A['kernel_size']), int(A['dilation']), int(A['heads']))
+    torch.testing.assert_close(y, A['y'], **TOL)
+    y.backward(A['dy'])
+    torch.testing.assert_close(x.grad, A['dx'], **TOL)
+    assert any(k.startswith('rel_pos_bias.') for k in G)
+    for k, g in G.items():
+        torch.testing.assert_close(P[k].grad, g, **TOL)
+
+
 def test_g2_cross_attention():
     A, P, G = load('g2_cross_attention')
     P = req(P)
