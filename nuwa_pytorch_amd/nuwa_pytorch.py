@@ -231,12 +231,6 @@ class ShiftVideoTokens(nn.Module):
         return self.fn(x, **kwargs)
 
 
-class ShiftAudioTokens(nn.Module):
-    def __init__(self, fn, audio_tokens_per_timestep=1):
-        super().__init__()
-        raise NotImplementedError('NUWAVideoAudio (BASELINE cfg 5) is not built yet in nuwa_pytorch_amd')
-
-
 # ---------------------------------------------------------------------------------------------------
 # feed forward
 # ---------------------------------------------------------------------------------------------------
@@ -401,22 +395,10 @@ class Sparse3DNA(nn.Module):
         return ops.InnerFn.apply(x, None, self._meta(B, n, x.device), *self._params())
 
 
-class SparseCausal2DNA(nn.Module):
-    def __init__(self, *args, **kwargs):
-        super().__init__()
-        raise NotImplementedError('NUWAVideoAudio (BASELINE cfg 5) is not built yet in nuwa_pytorch_amd')
-
-
 class SparseCross2DNA(nn.Module):
     def __init__(self, *args, **kwargs):
         super().__init__()
         raise NotImplementedError('NUWASketch is outside this round (SURVEY.md section 8 row f4)')
-
-
-class CrossModalityCrossAttention(nn.Module):
-    def __init__(self, *args, **kwargs):
-        super().__init__()
-        raise NotImplementedError('NUWAVideoAudio (BASELINE cfg 5) is not built yet in nuwa_pytorch_amd')
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -876,7 +858,7 @@ class NUWASketch(nn.Module):
         raise NotImplementedError('NUWASketch is outside this round (SURVEY.md section 8 row f4)')
 
 
-class NUWAVideoAudio(nn.Module):
-    def __init__(self, *args, **kwargs):
-        super().__init__()
-        raise NotImplementedError('NUWAVideoAudio (BASELINE cfg 5) is not built yet in nuwa_pytorch_amd')
+# BASELINE cfg 5 (video + audio dual decoder) lives in its own module; re-exported here so that the names resolve where the
+# reference defines them
+from .video_audio import (ShiftAudioTokens, SparseCausal2DNA, CrossModalityCrossAttention, DualModalityDecoder,  # noqa: E402
+                          ReversibleDualModalityDecoder, NUWAVideoAudio)

@@ -1,0 +1,336 @@
+"""BASELINE cfg 5: the video + audio dual decoder (reference nuwa_pytorch.py = np.py: ShiftAudioTokens 157-183,
+SparseCausal2DNA 615-759, CrossModalityCrossAttention 908-1067, DualModalityDecoder 1299-1487, NUWAVideoAudio 1968-2293).
+
+Same class names, constructor kwargs, forward() signatures and state-dict keys as the reference.  What runs where:
+  * video tower (Sparse3DNA incl. rel_pos_bias, text cross-attention, GEGLU FF, token shift), the text cross-attention and
+    the FeedForwards of the audio tower, every LayerNorm, and both StableLayerNorm + logits + cross-entropy heads go through
+    libamdnuwa (the same fused autograd nodes as NUWA);
+  * the audio-only pieces -- the 1-D causal window attention over audio tokens, the one-frame-lagged chunked
+    video<->audio attention and the audio channel shift -- are small (321 audio tokens against 2560 video tokens) and are
+    written here with torch ops on the device, formulated as index-table gathers (nothing is unfolded).
+Not built: `dec_reversible=True` (ReversibleDualModalityDecoder, np.py:1489-1655 + reversible_video_audio.py) and generate().
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn, einsum
+
+from . import ops
+from .nuwa_pytorch import (MList, exists, default, eval_decorator, prob_mask_like, SandwichNorm, ShiftVideoTokens, FeedForward,
+                           Attention, Sparse3DNA, StableLayerNorm, Transformer, ReversibleTransformer, Embedding,
+                           AxialPositionalEmbedding, RotaryEmbedding)
+
+NEG = -torch.finfo(torch.float32).max
+
+
+class ShiftAudioTokens(nn.Module):
+    """np.py:157-183: the first half of the channels of token i is replaced by that of token i-1 (zeros for i = 0); the
+    <bos> row takes part like any other token.  (The reference pads to a whole timestep first and crops again: no effect.)"""
+
+    def __init__(self, fn, audio_tokens_per_timestep=1):
+        super().__init__()
+        self.fn = fn
+        self.audio_tokens_per_timestep = audio_tokens_per_timestep
+
+    def forward(self, x, **kwargs):
+        half = (x.shape[-1] + 1) // 2                       # chunk(2): the first chunk is the ceil half
+        prev = F.pad(x[:, :-1, :half], (0, 0, 1, 0))
+        return self.fn(torch.cat((prev, x[..., half:]), dim=-1), **kwargs)
+
+
+class SparseCausal2DNA(nn.Module):
+    """np.py:615-759 with height = 1 (the only way the decoders build it): audio token t (after <bos>) attends <bos> and the
+    taps t - (k-1-a)*dilation, a = 0..k-1, that are >= 0; + per-tap, per-head bias (always present: quirk Q20); fp32 softmax;
+    talking heads; the <bos> row outputs its own value."""
+
+    def __init__(self, *, dim, height=1, heads=8, dim_head=64, dropout=0., kernel_size=5, dilation=1, rel_pos_bias=False):
+        super().__init__()
+        if height != 1:
+            raise NotImplementedError('SparseCausal2DNA: only height = 1 (one audio token per timestep row) is built')
+        inner = heads * dim_head
+        self.heads, self.scale, self.height = heads, dim_head ** -0.5, height
+        self.talking_heads = nn.Conv3d(heads, heads, 1, bias=False)
+        self.dropout = nn.Dropout(dropout)
+        self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
+        self.to_out = nn.Linear(inner, dim, bias=False)
+        self.kernel_size = (kernel_size, height)
+        self.dilation = (dilation, 1)
+        self.rel_pos_bias = AxialPositionalEmbedding(heads, shape=self.kernel_size)      # exists(False) is True in the reference
+
+    def _taps(self, m, device):
+        """[m, k] index of the key token (0-based among the non-<bos> tokens) of every tap, -1 where it falls before the start"""
+        k, dil = self.kernel_size[0], self.dilation[0]
+        t = torch.arange(m, device=device)[:, None]
+        a = torch.arange(k, device=device)[None, :]
+        idx = t - (k - 1 - a) * dil
+        return torch.where(idx >= 0, idx, torch.full_like(idx, -1))
+
+    def forward(self, x, **kwargs):
+        b, n, h = x.shape[0], x.shape[1], self.heads
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError('attention dropout inside SparseCausal2DNA is not built')
+        q, k, v = self.to_qkv(x).chunk(3, dim=-1)
+        if n == 1:
+            return self.to_out(v)
+        split = lambda t: t.reshape(b, n, h, -1).permute(0, 2, 1, 3)            # b h n d
+        q, k, v = split(q) * self.scale, split(k), split(v)
+        m = n - 1
+        idx = self._taps(m, x.device)                                            # [m, kk]
+        ok = idx >= 0
+        gidx = idx.clamp(min=0) + 1                                              # token rows (1-based: row 0 is <bos>)
+        kg, vg = k[:, :, gidx], v[:, :, gidx]                                    # b h m kk d
+        qa = q[:, :, 1:]
+        sim = einsum('b h i d, b h i j d -> b h i j', qa, kg)
+        sim = sim + self.rel_pos_bias().reshape(-1, h).t()[None, :, None, :]     # [kk, h] -> per (head, tap)
+        sim = sim.masked_fill(~ok[None, None], NEG)
+        sim0 = einsum('b h i d, b h d -> b h i', qa, k[:, :, 0])[..., None]      # <bos> key, no bias, never masked
+        attn = torch.cat((sim0, sim), dim=-1).softmax(dim=-1, dtype=torch.float32)
+        attn = einsum('g h, b h i j -> b g i j', self.talking_heads.weight.reshape(h, h), attn)
+        out = einsum('b h i j, b h i j d -> b h i d', attn[..., 1:], vg) + attn[..., :1] * v[:, :, :1]
+        out = torch.cat((v[:, :, :1], out), dim=2)                               # <bos> row: its own value
+        return self.to_out(out.permute(0, 2, 1, 3).reshape(b, n, -1))
+
+
+class CrossModalityCrossAttention(nn.Module):
+    """np.py:908-1067.  The sequence (minus its start token) is cut into frames of `chunk_size` tokens; the context is
+    [0] * (context_chunk_size - 1) + [context start token] + context tokens, cut into frames of `context_chunk_size`: frame t
+    of the sequence attends a learned null key/value + context frame t, i.e. the context one frame EARLIER in time (frame 0
+    sees the context start token and cc - 1 zero rows, which do take softmax mass when no mask is given: quirk Q21).
+    Talking heads here is a Conv3d WITH bias, applied after the softmax.  The start-token row of the output is 0."""
+
+    def __init__(self, *, dim, chunk_size, context_chunk_size, heads=8, dim_head=64, context_dim=None, has_start_token=True,
+                 context_has_start_token=True, norm=False, norm_context=False, dropout=0.):
+        super().__init__()
+        context_dim = default(context_dim, dim)
+        inner = heads * dim_head
+        self.heads, self.scale = heads, dim_head ** -0.5
+        self.norm = nn.LayerNorm(dim) if norm else nn.Identity()
+        self.context_norm = nn.LayerNorm(context_dim) if norm_context else nn.Identity()
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_kv = nn.Linear(context_dim, inner * 2, bias=False)
+        self.to_out = nn.Linear(inner, dim, bias=False)
+        self.null_k = nn.Parameter(torch.randn(heads, dim_head))
+        self.null_v = nn.Parameter(torch.randn(heads, dim_head))
+        self.talking_heads = nn.Conv3d(heads, heads, 1)
+        self.dropout = nn.Dropout(dropout)
+        self.has_start_token, self.context_has_start_token = has_start_token, context_has_start_token
+        self.chunk_size, self.context_chunk_size = chunk_size, context_chunk_size
+
+    def forward(self, seq, context, mask=None, context_mask=None):
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError('attention dropout inside CrossModalityCrossAttention is not built')
+        b, n_in, dim = seq.shape
+        c, cc, h = self.chunk_size, self.context_chunk_size, self.heads
+        body = seq[:, 1:] if self.has_start_token else seq
+        s_len = body.shape[1]
+        ns = -(-s_len // c)
+        body = F.pad(body, (0, 0, 0, ns * c - s_len))
+        c_len = context.shape[1] - (1 if self.context_has_start_token else 0)
+        lead = cc - 1 if cc else 0
+        tail = -(-c_len // cc) * cc - c_len
+        ctx = F.pad(context, (0, 0, lead, tail))
+        cmask = F.pad(context_mask, (lead, tail), value=False) if exists(context_mask) else None
+        nc = ctx.shape[1] // cc
+        nf = min(ns, nc)                                      # frames that have a context frame to look at
+        if nf == 0:
+            return torch.zeros_like(seq)
+        qf = self.norm(body[:, :nf * c].reshape(b, nf, c, dim))
+        cf = self.context_norm(ctx[:, :nf * cc].reshape(b, nf, cc, -1))
+        q = self.to_q(qf).reshape(b, nf, c, h, -1).permute(0, 3, 1, 2, 4) * self.scale          # b h f c d
+        k, v = (t.reshape(b, nf, cc, h, -1).permute(0, 3, 1, 2, 4) for t in self.to_kv(cf).chunk(2, dim=-1))
+        nk = self.null_k[None, :, None, None, :].expand(b, h, nf, 1, -1)
+        nv = self.null_v[None, :, None, None, :].expand(b, h, nf, 1, -1)
+        k, v = torch.cat((nk, k), dim=3), torch.cat((nv, v), dim=3)
+        sim = einsum('b h f i d, b h f j d -> b h f i j', q, k)
+        if exists(cmask):
+            km = F.pad(cmask[:, :nf * cc].reshape(b, nf, cc), (1, 0), value=True)                # the null key is always visible
+            sim = sim.masked_fill(~km[:, None, :, None, :], NEG)
+        attn = sim.softmax(dim=-1, dtype=torch.float32)
+        attn = einsum('g h, b h f i j -> b g f i j', self.talking_heads.weight.reshape(h, h), attn) + \
+            self.talking_heads.bias[None, :, None, None, None]
+        out = einsum('b h f i j, b h f j d -> b h f i d', attn, v)
+        out = self.to_out(out.permute(0, 2, 3, 1, 4).reshape(b, nf * c, -1))
+        out = F.pad(out, (0, 0, 0, max(0, s_len - nf * c)))[:, :s_len]       # frames without context output 0; drop the padding
+        if self.has_start_token:
+            out = F.pad(out, (0, 0, 1, 0))
+        if exists(mask):
+            out = out.masked_fill(~mask[..., None], 0.)
+        return out
+
+
+def _residual(block, x, **kw):
+    """x + block(x) for a SandwichNorm block: the fused libamdnuwa node when its inner module is one of the hot ones"""
+    inner_kw = {k: v for k, v in kw.items() if k in ('context', 'context_mask')}
+    if isinstance(block, SandwichNorm) and x.is_cuda and block._inner(inner_kw.get('context')) is not None:
+        return block.fused_residual(x, **inner_kw)
+    return block(x, **{k: v for k, v in kw.items() if v is not None or k == 'context'}) + x
+
+
+class DualModalityDecoder(nn.Module):
+    """np.py:1299-1487: per depth a video triple (3DNA, text cross-attention, FF) and an audio triple (1-D causal window,
+    text cross-attention, FF); after every `cross_modality_attn_every`-th depth a pair of cross-modality blocks."""
+
+    def __init__(self, *, dim, depth, num_audio_tokens_per_video_frame, num_video_tokens_per_frame, sparse_3dna_video_shape, heads=8,
+                 dim_head=64, ff_mult=4, attn_dropout=0., ff_dropout=0., ff_chunk_size=None, sparse_3dna_kernel_size=3,
+                 sparse_3dna_query_num_frames_chunk=None, sparse_3dna_dilations=(1,), sparse_3dna_rel_pos_bias=False,
+                 sparse_2dna_kernel_size=7, sparse_2dna_dilation=(1,), sparse_2dna_rel_pos_bias=False, shift_video_tokens=False,
+                 shift_audio_tokens=False, audio_tokens_per_timestep=1, cross_modality_attn_every=3):
+        super().__init__()
+        self.layers = MList([])
+        self.layer_types = []
+        sn = lambda fn: SandwichNorm(dim=dim, fn=fn)
+        ff = lambda: FeedForward(dim=dim, mult=ff_mult, dropout=ff_dropout, chunk_size=ff_chunk_size)
+        text_attn = lambda: Attention(dim=dim, heads=heads, dim_head=dim_head, dropout=attn_dropout)
+        fmap = sparse_3dna_video_shape[-1]
+        vshift = (lambda fn: ShiftVideoTokens(fn, image_size=fmap)) if shift_video_tokens else (lambda fn: fn)
+        ashift = (lambda fn: ShiftAudioTokens(fn, audio_tokens_per_timestep=audio_tokens_per_timestep)) if shift_audio_tokens else (lambda fn: fn)
+        for ind in range(depth):
+            video_attn = Sparse3DNA(dim=dim, heads=heads, dim_head=dim_head, causal=True, kernel_size=sparse_3dna_kernel_size,
+                                    dilation=sparse_3dna_dilations[ind % len(sparse_3dna_dilations)],
+                                    video_shape=sparse_3dna_video_shape, query_num_frames_chunk=sparse_3dna_query_num_frames_chunk,
+                                    rel_pos_bias=sparse_3dna_rel_pos_bias)
+            audio_attn = SparseCausal2DNA(dim=dim, heads=heads, dim_head=dim_head, kernel_size=sparse_2dna_kernel_size,
+                                          dilation=sparse_2dna_dilation[ind % len(sparse_2dna_dilation)], dropout=attn_dropout,
+                                          rel_pos_bias=sparse_2dna_rel_pos_bias)
+            self.layer_types.append('intra_modality')
+            self.layers.append(MList([MList([sn(vshift(video_attn)), sn(text_attn()), sn(vshift(ff()))]),
+                                      MList([sn(ashift(audio_attn)), sn(text_attn()), sn(ashift(ff()))])]))
+            if (ind + 1) % cross_modality_attn_every == 0:
+                cross = lambda cs, ccs: MList([sn(CrossModalityCrossAttention(dim=dim, heads=heads, dim_head=dim_head, chunk_size=cs,
+                                                                              context_chunk_size=ccs, has_start_token=True,
+                                                                              context_has_start_token=True)), sn(ff())])
+                self.layer_types.append('inter_modality')
+                self.layers.append(MList([cross(num_video_tokens_per_frame, num_audio_tokens_per_video_frame),
+                                          cross(num_audio_tokens_per_video_frame, num_video_tokens_per_frame)]))
+        self.video_norm = StableLayerNorm(dim)
+        self.audio_norm = StableLayerNorm(dim)
+
+    def forward_layers(self, video, audio, *, context, audio_mask=None, video_mask=None, context_mask=None, **kwargs):
+        for blocks, kind in zip(self.layers, self.layer_types):
+            if kind == 'intra_modality':
+                (v_attn, v_cross, v_ff), (a_attn, a_cross, a_ff) = blocks
+                v = _residual(v_attn, video, mask=video_mask)
+                v = _residual(v_cross, v, context=context, mask=video_mask, context_mask=context_mask)
+                v = _residual(v_ff, v)
+                a = _residual(a_attn, audio, mask=audio_mask)
+                a = _residual(a_cross, a, context=context, mask=audio_mask, context_mask=context_mask)
+                a = _residual(a_ff, a)
+            else:
+                (v_x, v_ff), (a_x, a_ff) = blocks
+                v = v_x(video, context=audio, mask=video_mask, context_mask=audio_mask) + video     # both read the OLD streams
+                a = a_x(audio, context=video, mask=audio_mask, context_mask=video_mask) + audio
+                v, a = _residual(v_ff, v), _residual(a_ff, a)
+            video, audio = v, a
+        return video, audio
+
+    def forward(self, video, audio, **kwargs):
+        video, audio = self.forward_layers(video, audio, **kwargs)
+        return self.video_norm(video), self.audio_norm(audio)
+
+
+class ReversibleDualModalityDecoder(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError('ReversibleDualModalityDecoder (np.py:1489-1655) is not built yet: construct NUWAVideoAudio with '
+                                  'dec_reversible=False')
+
+
+class NUWAVideoAudio(nn.Module):
+    """np.py:1968-2293: identical constructor kwargs and forward() signature (training loss / logits)."""
+
+    def __init__(self, *, vae, dim, image_size, num_audio_tokens, num_audio_tokens_per_video_frame, audio_tokens_per_timestep=1,
+                 max_video_frames=5, text_num_tokens=49408, text_max_seq_len=256, text_enc_depth=6, text_enc_dim_head=64,
+                 text_enc_heads=8, text_rotary_pos_emb=False, enc_reversible=False, dec_reversible=True, dec_depth=6, dec_dim_head=64,
+                 dec_heads=8, attn_dropout=0., ff_dropout=0., ff_chunk_size=None, embed_gradient_frac=0.2, shift_video_tokens=True,
+                 shift_audio_tokens=True, sparse_3dna_kernel_size=3, sparse_3dna_query_num_frames_chunk=None, sparse_3dna_dilation=1,
+                 sparse_3dna_rel_pos_bias=True, sparse_2dna_kernel_size=7, sparse_2dna_dilation=1, sparse_2dna_rel_pos_bias=True,
+                 audio_loss_weight=1., cross_modality_attn_every=3):
+        super().__init__()
+        self.vae = vae.copy_for_eval()
+        num_image_tokens = vae.codebook_size
+        self.text_max_seq_len = text_max_seq_len
+        self.text_embedding = Embedding(text_num_tokens, dim, frac_gradient=embed_gradient_frac)
+        self.text_abs_pos_emb = Embedding(text_max_seq_len, dim) if not text_rotary_pos_emb else None
+        self.text_rotary_pos_emb = RotaryEmbedding(dim=min(32, text_enc_dim_head)) if text_rotary_pos_emb else None
+        enc_klass = ReversibleTransformer if enc_reversible else Transformer
+        self.text_transformer = enc_klass(dim=dim, depth=text_enc_depth, heads=text_enc_heads, dim_head=text_enc_dim_head,
+                                          attn_dropout=attn_dropout, ff_dropout=ff_dropout)
+        self.video_bos = nn.Parameter(torch.randn(dim))
+        self.image_embedding = Embedding(num_image_tokens, dim, frac_gradient=embed_gradient_frac)
+        fmap_size = image_size // (2 ** vae.num_layers)
+        self.video_fmap_size, self.max_video_frames = fmap_size, max_video_frames
+        self.video_shape = (max_video_frames, fmap_size, fmap_size)
+        self.video_pos_emb = AxialPositionalEmbedding(dim, shape=self.video_shape)
+        self.audio_bos = nn.Parameter(torch.randn(dim))
+        self.audio_embedding = Embedding(num_audio_tokens, dim, frac_gradient=embed_gradient_frac)
+        # (the reference sizes this table by the audio CODEBOOK size, not by the sequence length)
+        self.audio_pos_emb = AxialPositionalEmbedding(dim, shape=(num_audio_tokens // audio_tokens_per_timestep, audio_tokens_per_timestep))
+        self.audio_loss_weight = audio_loss_weight
+        self.num_video_tokens_per_frame = fmap_size ** 2
+        self.num_audio_tokens_per_video_frame = num_audio_tokens_per_video_frame
+        as_cycle = lambda d: tuple(d) if isinstance(d, (list, tuple)) else tuple(range(1, d + 1))
+        decoder_klass = ReversibleDualModalityDecoder if dec_reversible else DualModalityDecoder
+        self.video_audio_transformer = decoder_klass(
+            dim=dim, depth=dec_depth, heads=dec_heads, dim_head=dec_dim_head, attn_dropout=attn_dropout, ff_dropout=ff_dropout,
+            ff_chunk_size=ff_chunk_size, audio_tokens_per_timestep=audio_tokens_per_timestep, shift_audio_tokens=shift_audio_tokens,
+            shift_video_tokens=shift_video_tokens, sparse_3dna_video_shape=self.video_shape,
+            sparse_3dna_kernel_size=sparse_3dna_kernel_size, sparse_3dna_dilations=as_cycle(sparse_3dna_dilation),
+            sparse_3dna_query_num_frames_chunk=sparse_3dna_query_num_frames_chunk, sparse_3dna_rel_pos_bias=sparse_3dna_rel_pos_bias,
+            num_audio_tokens_per_video_frame=num_audio_tokens_per_video_frame, num_video_tokens_per_frame=fmap_size * fmap_size,
+            cross_modality_attn_every=cross_modality_attn_every, sparse_2dna_kernel_size=sparse_2dna_kernel_size,
+            sparse_2dna_dilation=as_cycle(sparse_2dna_dilation), sparse_2dna_rel_pos_bias=sparse_2dna_rel_pos_bias)
+        self.to_video_logits = nn.Linear(dim, num_image_tokens, bias=False)
+        self.to_audio_logits = nn.Linear(dim, num_audio_tokens, bias=False)
+        self._cache_v, self._cache_a = ops.WeightCache(), ops.WeightCache()
+
+    def embed_text(self, text, mask=None):
+        batch, seq_len, device = *text.shape, text.device
+        assert seq_len <= self.text_max_seq_len, 'your input text has a greater length than what was designated on initialization'
+        tokens = self.text_embedding(text)
+        if exists(self.text_abs_pos_emb):
+            tokens = tokens + self.text_abs_pos_emb(torch.arange(seq_len, device=device))[None]
+        rotary = self.text_rotary_pos_emb(seq_len, device=device) if exists(self.text_rotary_pos_emb) else None
+        return self.text_transformer(tokens, mask=mask, rotary_pos_emb=rotary)
+
+    def embed_video(self, ids_in):
+        pe = self.video_pos_emb
+        if ids_in.is_cuda and pe.num_axials == 3:
+            frac = self.image_embedding.frac_gradient if self.training else 1.
+            return ops.EmbedAssembleFn.apply(ids_in, self.image_embedding.embed.weight, pe.axial1, pe.axial2, pe.axial3,
+                                             self.video_bos, self.video_shape, float(frac))
+        emb = pe()[:ids_in.shape[1]] + self.image_embedding(ids_in)
+        return torch.cat((self.video_bos[None, None].expand(ids_in.shape[0], 1, -1), emb), dim=1)
+
+    def embed_audio(self, ids_in):
+        emb = self.audio_embedding(ids_in)
+        emb = emb + self.audio_pos_emb()[:emb.shape[1]][None]
+        return torch.cat((self.audio_bos[None, None].expand(ids_in.shape[0], 1, -1), emb), dim=1)
+
+    def generate(self, *args, **kwargs):
+        raise NotImplementedError('NUWAVideoAudio.generate (np.py:2107-2222) is not built: only the training forward is')
+
+    def forward(self, *, text, video, audio, return_loss=False, cond_dropout_prob=0.2):
+        batch, device = text.shape[0], text.device
+        if not text.is_cuda:
+            raise RuntimeError('nuwa_pytorch_amd: the decoder path needs a HIP device; there is no CPU fallback')
+        text_mask = text != 0
+        text_embeds = self.embed_text(text, mask=text_mask)
+        if video.dtype == torch.long:
+            frame_indices = video
+        else:
+            assert video.shape[1] == self.max_video_frames, f'you must give the full video frames ({self.max_video_frames}) during training'
+            frame_indices = self.vae.get_video_indices(video)
+        frame_indices = frame_indices.reshape(batch, -1)
+        frame_emb = self.embed_video(frame_indices[:, :-1] if return_loss else frame_indices)
+        audio_emb = self.embed_audio(audio[:, :-1] if return_loss else audio)
+        if self.training and cond_dropout_prob > 0:
+            uncond = prob_mask_like((batch,), cond_dropout_prob, device=device)
+            text_mask = text_mask & ~uncond[:, None]
+        dec = self.video_audio_transformer
+        v_hid, a_hid = dec.forward_layers(frame_emb, audio_emb, context=text_embeds, context_mask=text_mask)
+        vn, an = dec.video_norm.norm, dec.audio_norm.norm
+        if not return_loss:
+            return (ops.LogitsFn.apply(v_hid, vn.weight, vn.bias, self.to_video_logits.weight, self._cache_v),
+                    ops.LogitsFn.apply(a_hid, an.weight, an.bias, self.to_audio_logits.weight, self._cache_a))
+        video_loss = ops.LogitsLossFn.apply(v_hid, frame_indices, vn.weight, vn.bias, self.to_video_logits.weight, self._cache_v)
+        audio_loss = ops.LogitsLossFn.apply(a_hid, audio, an.weight, an.bias, self.to_audio_logits.weight, self._cache_a)
+        return video_loss + audio_loss * self.audio_loss_weight

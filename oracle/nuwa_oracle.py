@@ -362,6 +362,127 @@ def decoder_loss(P, cfg, ids, context, context_mask, training=True, return_logit
 
 
 # --------------------------------------------------------------------------------------
+# a15  cfg 5: video + audio dual decoder (np.py:157-183, 615-759, 908-1067, 1299-1487, 2224-2293)
+# --------------------------------------------------------------------------------------
+
+def shift_audio_tokens(x):
+    """ShiftAudioTokens np.py:157-183: first chunk(2) half of the channels comes from the previous token (0 for token 0)."""
+    a, b = x.chunk(2, dim=-1)
+    return torch.cat((F.pad(a, (0, 0, 1, -1)), b), dim=-1)
+
+
+def sparse_causal_2dna(x, P, heads, kernel_size, dilation):
+    """SparseCausal2DNA np.py:615-759 at height 1.  P: to_qkv.weight, to_out.weight, talking_heads.weight (h,h,1,1,1),
+    rel_pos_bias.axial1 (kernel_size, h).  Written with a left-padded key/value tensor and one slice per tap."""
+    b, n, _ = x.shape
+    q, k, v = (x @ P['to_qkv.weight'].t()).chunk(3, dim=-1)
+    if n == 1:
+        return v @ P['to_out.weight'].t()
+    hd = lambda t: t.reshape(b, n, heads, -1).permute(0, 2, 1, 3)
+    q, k, v = hd(q), hd(k), hd(v)
+    q = q * q.shape[-1] ** -0.5
+    m, pad = n - 1, (kernel_size - 1) * dilation
+    kp, vp = F.pad(k[:, :, 1:], (0, 0, pad, 0)), F.pad(v[:, :, 1:], (0, 0, pad, 0))
+    t = torch.arange(m)
+    sims, vals = [(q[:, :, 1:] * k[:, :, :1]).sum(-1)], [v[:, :, :1].expand(-1, -1, m, -1)]
+    bias = P['rel_pos_bias.axial1']                                       # (k, h)
+    for a in range(kernel_size):
+        ka, va = kp[:, :, a * dilation:a * dilation + m], vp[:, :, a * dilation:a * dilation + m]
+        s_a = (q[:, :, 1:] * ka).sum(-1) + bias[a][None, :, None]
+        valid = (t - (kernel_size - 1 - a) * dilation) >= 0
+        sims.append(s_a.masked_fill(~valid[None, None], -torch.finfo(x.dtype).max))
+        vals.append(va)
+    attn = torch.stack(sims, dim=-1).softmax(dim=-1, dtype=torch.float32)
+    attn = torch.einsum('gh,bhij->bgij', P['talking_heads.weight'].reshape(heads, heads), attn)
+    out = (attn[..., None] * torch.stack(vals, dim=-2)).sum(-2)           # b h m d
+    out = torch.cat((v[:, :, :1], out), dim=2)
+    return out.permute(0, 2, 1, 3).reshape(b, n, -1) @ P['to_out.weight'].t()
+
+
+def cross_modality_cross_attention(seq, context, P, heads, chunk, ctx_chunk):
+    """CrossModalityCrossAttention np.py:908-1067 with has_start_token = context_has_start_token = True, no masks, no inner
+    norms: frame f of `seq` (after its start token) attends [null] + frame f of ([0]*(cc-1) + context).  Frame by frame."""
+    b, n, d = seq.shape
+    body = seq[:, 1:]
+    ctx = F.pad(context, (0, 0, ctx_chunk - 1, 0))
+    ctx = F.pad(ctx, (0, 0, 0, (-ctx.shape[1]) % ctx_chunk))
+    nf = min(-(-body.shape[1] // chunk), ctx.shape[1] // ctx_chunk)
+    w_th, b_th = P['talking_heads.weight'].reshape(heads, heads), P['talking_heads.bias']
+    outs = []
+    for f in range(nf):
+        qf = body[:, f * chunk:(f + 1) * chunk]
+        qf = F.pad(qf, (0, 0, 0, chunk - qf.shape[1]))
+        cf = ctx[:, f * ctx_chunk:(f + 1) * ctx_chunk]
+        hd = lambda t: t.reshape(b, t.shape[1], heads, -1).permute(0, 2, 1, 3)
+        q = hd(qf @ P['to_q.weight'].t())
+        k, v = (hd(t) for t in (cf @ P['to_kv.weight'].t()).chunk(2, dim=-1))
+        q = q * q.shape[-1] ** -0.5
+        k = torch.cat((P['null_k'][None, :, None].expand(b, -1, -1, -1), k), dim=2)
+        v = torch.cat((P['null_v'][None, :, None].expand(b, -1, -1, -1), v), dim=2)
+        attn = (q @ k.transpose(-1, -2)).softmax(dim=-1, dtype=torch.float32)
+        attn = torch.einsum('gh,bhij->bgij', w_th, attn) + b_th[None, :, None, None]
+        outs.append((attn @ v).permute(0, 2, 1, 3).reshape(b, chunk, -1) @ P['to_out.weight'].t())
+    out = torch.cat(outs, dim=1) if outs else seq.new_zeros(b, 0, d)
+    out = F.pad(out, (0, 0, 0, max(0, body.shape[1] - out.shape[1])))[:, :body.shape[1]]
+    return F.pad(out, (0, 0, 1, 0))
+
+
+def dual_decoder(video, audio, P, cfg, context, context_mask):
+    """DualModalityDecoder.forward np.py:1435-1487.  cfg: depth, heads, video_shape, kernel_size, dilations, rel_pos_bias (video),
+    audio_kernel, audio_dilations, every, v_per_frame, a_per_frame, shift_video, shift_audio."""
+    fmap = cfg['video_shape'][1]
+    shv = (lambda t: shift_video_tokens(t, fmap)) if cfg.get('shift_video', True) else (lambda t: t)
+    sha = shift_audio_tokens if cfg.get('shift_audio', True) else (lambda t: t)
+    kv = '.fn.fn' if cfg.get('shift_video', True) else '.fn'
+    ka = '.fn.fn' if cfg.get('shift_audio', True) else '.fn'
+    li = 0
+    for ind in range(cfg['depth']):
+        L = sub(P, f'layers.{li}')
+        li += 1
+        V, A = sub(L, '0'), sub(L, '1')
+        dv = cfg['dilations'][ind % len(cfg['dilations'])]
+        da = cfg['audio_dilations'][ind % len(cfg['audio_dilations'])]
+        video = sandwich(video, sub(V, '0'), lambda h: sparse3dna(shv(h), sub(V, '0' + kv), cfg['video_shape'], cfg['kernel_size'],
+                                                                 dv, cfg['heads'])) + video
+        video = sandwich(video, sub(V, '1'), lambda h: attention(h, sub(V, '1.fn'), cfg['heads'], context=context,
+                                                                 context_mask=context_mask)) + video
+        video = sandwich(video, sub(V, '2'), lambda h: feedforward(shv(h), sub(V, '2' + kv))) + video
+        audio = sandwich(audio, sub(A, '0'), lambda h: sparse_causal_2dna(sha(h), sub(A, '0' + ka), cfg['heads'], cfg['audio_kernel'],
+                                                                          da)) + audio
+        audio = sandwich(audio, sub(A, '1'), lambda h: attention(h, sub(A, '1.fn'), cfg['heads'], context=context,
+                                                                 context_mask=context_mask)) + audio
+        audio = sandwich(audio, sub(A, '2'), lambda h: feedforward(sha(h), sub(A, '2' + ka))) + audio
+        if (ind + 1) % cfg['every'] == 0:
+            L = sub(P, f'layers.{li}')
+            li += 1
+            V, A = sub(L, '0'), sub(L, '1')
+            v2 = sandwich(video, sub(V, '0'), lambda h: cross_modality_cross_attention(h, audio, sub(V, '0.fn'), cfg['heads'],
+                                                                                        cfg['v_per_frame'], cfg['a_per_frame'])) + video
+            a2 = sandwich(audio, sub(A, '0'), lambda h: cross_modality_cross_attention(h, video, sub(A, '0.fn'), cfg['heads'],
+                                                                                        cfg['a_per_frame'], cfg['v_per_frame'])) + audio
+            video = sandwich(v2, sub(V, '1'), lambda h: feedforward(h, sub(V, '1.fn'))) + v2
+            audio = sandwich(a2, sub(A, '1'), lambda h: feedforward(h, sub(A, '1.fn'))) + a2
+    return (stable_layer_norm(video, P['video_norm.norm.weight'], P['video_norm.norm.bias']),
+            stable_layer_norm(audio, P['audio_norm.norm.weight'], P['audio_norm.norm.bias']))
+
+
+def video_audio_loss(P, cfg, ids, audio_ids, context, context_mask, training=True, return_logits=False):
+    """decoder side of NUWAVideoAudio.forward(return_loss=True) np.py:2245-2293; ids (b, N), audio_ids (b, A) int64."""
+    fr = cfg.get('embed_frac', 0.2)
+    x = embed_assemble(ids[:, :-1], P, training=training, frac=fr)
+    ae = P['audio_embedding.embed.weight'][audio_ids[:, :-1]]
+    if training and fr < 1:
+        ae = ae * fr + ae.detach() * (1 - fr)
+    ae = ae + P['audio_pos_emb.axial1'][:ae.shape[1]][None]
+    a = torch.cat((P['audio_bos'][None, None].expand(ae.shape[0], 1, -1), ae), dim=1)
+    v, a = dual_decoder(x, a, sub(P, 'video_audio_transformer'), cfg, context, context_mask)
+    vl, al = v @ P['to_video_logits.weight'].t(), a @ P['to_audio_logits.weight'].t()
+    loss = F.cross_entropy(vl.reshape(-1, vl.shape[-1]), ids.reshape(-1)) + \
+        cfg.get('audio_loss_weight', 1.) * F.cross_entropy(al.reshape(-1, al.shape[-1]), audio_ids.reshape(-1))
+    return (loss, vl, al) if return_logits else loss
+
+
+# --------------------------------------------------------------------------------------
 # f1  text encoder (embed_text np.py:1821-1839; always a ReversibleTransformer in practice, Q1)
 # --------------------------------------------------------------------------------------
 
@@ -379,7 +500,11 @@ def text_encoder(text, P, cfg, training=True):
     if training and cfg.get('embed_frac', 0.2) < 1:
         fr = cfg.get('embed_frac', 0.2)
         emb = emb * fr + emb.detach() * (1 - fr)
-    rot = rotary_freqs(P['text_rotary_pos_emb.inv_freq'], text.shape[1])
+    if 'text_rotary_pos_emb.inv_freq' in P:
+        rot = rotary_freqs(P['text_rotary_pos_emb.inv_freq'], text.shape[1])
+    else:                                      # learned absolute positions (np.py:1827-1829; NUWAVideoAudio's default)
+        rot = None
+        emb = emb + P['text_abs_pos_emb.embed.weight'][:text.shape[1]][None]
     T = sub(P, 'text_transformer')
     x1, x2 = emb, emb
     for l in range(cfg['text_depth']):

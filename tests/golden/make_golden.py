@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 from oracle import ref_shims  # noqa: E402
 
 ref_shims.install()
-from nuwa_pytorch import NUWA, VQGanVAE  # noqa: E402
+from nuwa_pytorch import NUWA, NUWAVideoAudio, VQGanVAE  # noqa: E402
 from nuwa_pytorch.nuwa_pytorch import (Sparse3DNA, Attention, FeedForward, SandwichNorm,  # noqa: E402
                                        ShiftVideoTokens, StableLayerNorm, Transformer)
 
@@ -198,6 +198,39 @@ def g8_decoder_layer():
          **params(tr), **grads(tr))
 
 
+VA_KW = dict(dim=32, image_size=16, num_audio_tokens=40, num_audio_tokens_per_video_frame=4, max_video_frames=3, text_num_tokens=50,
+             text_max_seq_len=8, text_enc_depth=2, text_enc_dim_head=16, text_enc_heads=2, enc_reversible=True, dec_reversible=False,
+             dec_depth=3, dec_dim_head=32, dec_heads=2, sparse_3dna_kernel_size=3, sparse_3dna_dilation=2, sparse_2dna_kernel_size=7,
+             sparse_2dna_dilation=2, cross_modality_attn_every=3, audio_loss_weight=0.7)
+
+
+def g9_video_audio():
+    """BASELINE cfg 5 path, tiny: NUWAVideoAudio.forward(return_loss=True) with the non-reversible DualModalityDecoder.
+    a: no 3DNA rel-pos bias, batch 2 (padded text);  b: the default 3DNA rel-pos bias, batch 1 (the reference's bias add only
+    broadcasts for one sample)."""
+    for name, rel, b in (('g9a_video_audio', False, 2), ('g9b_video_audio_relpos', True, 1)):
+        torch.manual_seed(0)
+        vae = VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
+        m = NUWAVideoAudio(vae=vae, sparse_3dna_rel_pos_bias=rel, **VA_KW)
+        torch.manual_seed(1)
+        text = torch.randint(1, 50, (b, 8))
+        text[-1, 5:] = 0
+        vid = torch.randint(0, 64, (b, 3, 4, 4))
+        aud = torch.randint(0, 40, (b, 12))
+        cap = {}
+        hooks = [m.to_video_logits.register_forward_hook(lambda mod, i, o: cap.__setitem__('vl', o.detach())),
+                 m.to_audio_logits.register_forward_hook(lambda mod, i, o: cap.__setitem__('al', o.detach())),
+                 m.text_transformer.register_forward_hook(lambda mod, i, o: cap.__setitem__('ctx', o.detach()))]
+        loss = m(text=text, video=vid, audio=aud, return_loss=True, cond_dropout_prob=0.)
+        for h in hooks:
+            h.remove()
+        loss.backward()
+        P = {k: v for k, v in params(m).items() if not k.startswith('p.vae.') and '.net.blocks.' not in k}
+        G = {k: v for k, v in grads(m).items() if '.net.blocks.' not in k}
+        save(name, text=text, video_ids=vid, audio_ids=aud, loss=loss, video_logits=cap['vl'], audio_logits=cap['al'],
+             text_embeds=cap['ctx'], rel_pos_bias=rel, **P, **G)
+
+
 if __name__ == '__main__':
     g1_sparse3dna()
     g1b_sparse3dna_rel_pos_bias()
@@ -207,3 +240,4 @@ if __name__ == '__main__':
     g5_g6_nuwa()
     g7_vae()
     g8_decoder_layer()
+    g9_video_audio()

@@ -271,3 +271,38 @@ def test_reversible_stack_memory_is_depth_independent(A):
     report('rev.dctx', dc_e, dc_s, 2e-3)
     for n in g_s:
         report(f'rev.grad.{n}', g_e[n], g_s[n], 2e-3)
+
+
+VA_KW = dict(dim=32, image_size=16, num_audio_tokens=40, num_audio_tokens_per_video_frame=4, max_video_frames=3, text_num_tokens=50,
+             text_max_seq_len=8, text_enc_depth=2, text_enc_dim_head=16, text_enc_heads=2, enc_reversible=True, dec_reversible=False,
+             dec_depth=3, dec_dim_head=32, dec_heads=2, sparse_3dna_kernel_size=3, sparse_3dna_dilation=2, sparse_2dna_kernel_size=7,
+             sparse_2dna_dilation=2, cross_modality_attn_every=3, audio_loss_weight=0.7)
+
+
+@pytest.mark.parametrize('mode,tol,gtol', MODES)
+@pytest.mark.parametrize('name', ['g9a_video_audio', 'g9b_video_audio_relpos'])
+def test_g9_video_audio_loss_logits_grads(A, name, mode, tol, gtol):
+    """BASELINE cfg 5 (row a15): NUWAVideoAudio with the non-reversible dual decoder, loaded with the reference's state dict,
+    against the reference's loss, video / audio logits and every gradient"""
+    Ar, P, G = load(name)
+    vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
+    m = A.NUWAVideoAudio(vae=vae, sparse_3dna_rel_pos_bias=bool(Ar['rel_pos_bias']), **VA_KW)
+    missing, unexpected = m.load_state_dict(P, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith('vae.') or '.net.blocks.' in k for k in missing), missing
+    m = m.to(DEV).train()
+    run_mode(A, mode)
+    try:
+        text, vid, aud = Ar['text'].to(DEV), Ar['video_ids'].to(DEV), Ar['audio_ids'].to(DEV)
+        b = text.shape[0]
+        vl, al = m(text=text, video=vid.reshape(b, -1)[:, :-1], audio=aud[:, :-1], return_loss=False, cond_dropout_prob=0.)
+        report(f'{name}[{mode}].video_logits', vl, Ar['video_logits'], tol)
+        report(f'{name}[{mode}].audio_logits', al, Ar['audio_logits'], tol)
+        loss = m(text=text, video=vid, audio=aud, return_loss=True, cond_dropout_prob=0.)
+        report(f'{name}[{mode}].loss', loss.reshape(1), Ar['loss'].reshape(1), tol)
+        loss.backward()
+        # (bf16 mode on the batch-1 fixture: single-sample gradients of the text encoder are the noisiest -> x3)
+        n = check_grads(m, G, gtol * (2 if mode == 'bf16x3' else 3), f'{name}[{mode}]', skip=('.net.blocks.',))
+        assert n > 150
+    finally:
+        A.set_precision('bf16')

@@ -101,6 +101,31 @@ def test_g5_g6_nuwa(name):
     assert n > 40
 
 
+VA_CFG = dict(depth=3, heads=2, video_shape=(3, 4, 4), kernel_size=3, dilations=(1, 2), audio_kernel=7, audio_dilations=(1, 2), every=3,
+              v_per_frame=16, a_per_frame=4, shift_video=True, shift_audio=True, audio_loss_weight=0.7, text_depth=2, text_heads=2)
+
+
+@pytest.mark.parametrize('name', ['g9a_video_audio', 'g9b_video_audio_relpos'])
+def test_g9_video_audio(name):
+    """BASELINE cfg 5 (NUWAVideoAudio, non-reversible dual decoder): oracle vs the reference's loss, both logits and every
+    decoder-side gradient"""
+    A, P, G = load(name)
+    P = req(P)
+    b = A['text'].shape[0]
+    ctx, mask = O.text_encoder(A['text'], P, VA_CFG)
+    torch.testing.assert_close(ctx, A['text_embeds'], **TOL)
+    loss, vl, al = O.video_audio_loss(P, VA_CFG, A['video_ids'].reshape(b, -1), A['audio_ids'], ctx, mask, return_logits=True)
+    torch.testing.assert_close(vl, A['video_logits'], **TOL)
+    torch.testing.assert_close(al, A['audio_logits'], **TOL)
+    torch.testing.assert_close(loss, A['loss'], **TOL)
+    loss.backward()
+    n = 0
+    for k, g in G.items():
+        torch.testing.assert_close(P[k].grad, g, rtol=1e-3, atol=2e-5, msg=lambda m, k=k: f'{k}: {m}')
+        n += 1
+    assert n > 150
+
+
 def test_g7_vae_encode():
     A, P, _ = load('g7_vae')
     fm = O.vae_encode_fmap(A['img'], P, num_layers=int(A['num_layers']), heads=int(A['heads']))

@@ -186,3 +186,62 @@ def test_vae_encoder_fmap_and_indices(reference_pkg):
     _, ind, _ = vae.vq(fm)
     idx, gap = O.vq_eval_lookup(fm, S['vq.embed'], S['vq.project_in.weight'], S['vq.project_in.bias'])
     assert torch.equal(idx[gap > 1e-5], ind[gap > 1e-5])
+
+
+# ---- BASELINE cfg 5 pieces (row a15) -----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('n,kernel,dil', [(1, 5, 1), (2, 5, 1), (9, 5, 2), (21, 7, 1), (21, 7, 3)])
+def test_sparse_causal_2dna_fwd_bwd(reference_pkg, n, kernel, dil):
+    from nuwa_pytorch.nuwa_pytorch import SparseCausal2DNA
+    torch.manual_seed(0)
+    m = SparseCausal2DNA(dim=32, heads=2, dim_head=16, kernel_size=kernel, dilation=dil)
+    torch.manual_seed(1)
+    x = torch.randn(2, n, 32, requires_grad=True)
+    y = m(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    P = {k: v.requires_grad_(True) for k, v in sd(m).items()}
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = O.sparse_causal_2dna(x2, P, 2, kernel, dil)
+    torch.testing.assert_close(y2, y, **TOL)
+    y2.backward(g)
+    torch.testing.assert_close(x2.grad, x.grad, **TOL)
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            torch.testing.assert_close(P[k].grad, p.grad, **TOL, msg=lambda s, k=k: f'{k}: {s}')
+
+
+def test_shift_audio_tokens(reference_pkg):
+    from nuwa_pytorch.nuwa_pytorch import ShiftAudioTokens
+    torch.manual_seed(0)
+    for n, d in ((1, 8), (7, 8), (12, 6)):
+        x = torch.randn(2, n, d)
+        assert torch.equal(ShiftAudioTokens(torch.nn.Identity())(x), O.shift_audio_tokens(x))
+
+
+@pytest.mark.parametrize('n_seq,n_ctx,chunk,cchunk', [(1 + 32, 1 + 8, 16, 4), (1 + 30, 1 + 8, 16, 4), (1 + 48, 1 + 6, 16, 4),
+                                                      (1 + 8, 1 + 48, 4, 16), (1 + 5, 1 + 20, 4, 16), (1, 1 + 4, 16, 4)])
+def test_cross_modality_cross_attention_fwd_bwd(reference_pkg, n_seq, n_ctx, chunk, cchunk):
+    from nuwa_pytorch.nuwa_pytorch import CrossModalityCrossAttention
+    torch.manual_seed(0)
+    m = CrossModalityCrossAttention(dim=32, heads=2, dim_head=16, chunk_size=chunk, context_chunk_size=cchunk)
+    torch.manual_seed(1)
+    x = torch.randn(2, n_seq, 32, requires_grad=True)
+    c = torch.randn(2, n_ctx, 32, requires_grad=True)
+    y = m(x, c)
+    g = torch.randn_like(y)
+    P = {k: v.requires_grad_(True) for k, v in sd(m).items()}
+    x2, c2 = x.detach().clone().requires_grad_(True), c.detach().clone().requires_grad_(True)
+    y2 = O.cross_modality_cross_attention(x2, c2, P, 2, chunk, cchunk)
+    torch.testing.assert_close(y2, y, **TOL)
+    if not y.requires_grad:            # only a start token: the reference returns constant zeros
+        assert float(y2.abs().max()) == 0.
+        return
+    y.backward(g)
+    y2.backward(g)
+    if x.grad is not None:
+        torch.testing.assert_close(x2.grad, x.grad, **TOL)
+        torch.testing.assert_close(c2.grad, c.grad, **TOL)
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            torch.testing.assert_close(P[k].grad, p.grad, **TOL, msg=lambda s, k=k: f'{k}: {s}')
