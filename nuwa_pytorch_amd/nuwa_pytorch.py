@@ -132,7 +132,7 @@ class SandwichNorm(nn.Module):
         return ops.LayerNormFn.apply(x, self.postnorm.weight, self.postnorm.bias, False)
 
     # -- fused path -------------------------------------------------------------------------------
-    def _inner(self, context=None):
+    def _inner(self, context=None, seq_len=None):
         """(inner module, shift or None) when fn is one of the fusable hot modules, else None.
         An Attention is fusable only as cross-attention (context given)."""
         fn, shift = self.fn, None
@@ -144,15 +144,17 @@ class SandwichNorm(nn.Module):
             fn = fn.fn
         if isinstance(fn, (Sparse3DNA, FeedForward)):
             return fn, shift
-        if isinstance(fn, Attention) and not fn.causal and context is not None:
+        if isinstance(fn, Attention) and context is not None and fn._hip_ok(context.shape[1]):
             return fn, shift
+        if isinstance(fn, Attention) and context is None and seq_len is not None and fn._hip_ok(seq_len):
+            return fn, shift                      # non-causal self-attention (text encoder): same kernels, keys = the query rows
         return None
 
-    def fused_residual(self, x, resid=None, context=None, context_mask=None):
+    def fused_residual(self, x, resid=None, context=None, context_mask=None, mask=None, rotary_pos_emb=None):
         """x_out = (resid if given else x) + postnorm(fn(prenorm(x)))  as one autograd node"""
-        inner, fmap = self._inner(context)
         B, n, D = x.shape
-        meta = inner._meta(B, n, x.device, context=context, context_mask=context_mask)
+        inner, fmap = self._inner(context, seq_len=n)
+        meta = inner._meta(B, n, x.device, context=context, context_mask=context_mask, mask=mask, rotary_pos_emb=rotary_pos_emb)
         if fmap is not None:
             if D % 32:
                 raise RuntimeError('fused token shift needs dim % 32 == 0')
@@ -297,18 +299,31 @@ class Attention(nn.Module):
     def _params(self):
         return (self.null_k, self.null_v, self.talking_heads.weight, self.to_q.weight, self.to_kv.weight, self.to_out.weight)
 
-    def _meta(self, B, n, device, context=None, context_mask=None, **_):
+    def _hip_ok(self, n_keys):
+        """geometry the cross-attention kernels cover (they also serve non-causal SELF-attention: keys / values = the query rows)"""
+        return (not self.causal) and self.dim_head in (32, 64) and self.heads <= 8 and n_keys + 1 <= 288 and \
+            not (self.training and self.dropout.p > 0)
+
+    def _meta(self, B, n, device, context=None, context_mask=None, mask=None, rotary_pos_emb=None, **_):
         if self.training and self.dropout.p > 0:
             raise NotImplementedError('attn_dropout > 0 is not supported by the HIP path (all BASELINE configs use 0)')
-        T = context.shape[1]
+        self_kv = context is None
+        T = n if self_kv else context.shape[1]
+        key_mask = mask if self_kv else context_mask
         g = K.x_geom(B, n, T, self.heads, self.dim_head)
-        mask_u8 = context_mask.to(torch.uint8).contiguous() if exists(context_mask) else None
-        return dict(kind='xattn', cache=self._cache, xgeom=g, mask_u8=mask_u8, save=torch.is_grad_enabled())
+        mask_u8 = key_mask.to(torch.uint8).contiguous() if exists(key_mask) else None
+        meta = dict(kind='xattn', cache=self._cache, xgeom=g, mask_u8=mask_u8, save=torch.is_grad_enabled())
+        if self_kv:                                   # text encoder (row f1): rotary on q, k and v (quirk Q11), key mask = `mask`
+            meta['self_kv'] = True
+            if exists(rotary_pos_emb):
+                meta['rotary'] = rotary_pos_emb.detach().float()
+        return meta
 
     def forward(self, x, mask=None, context=None, context_mask=None, rotary_pos_emb=None):
-        if exists(context) and not self.causal and x.is_cuda:
-            B, n, _ = x.shape
-            return ops.InnerFn.apply(x, context, self._meta(B, n, x.device, context, context_mask), *self._params())
+        B, n, _ = x.shape
+        if x.is_cuda and self._hip_ok(context.shape[1] if exists(context) else n):
+            meta = self._meta(B, n, x.device, context, context_mask, mask=mask, rotary_pos_emb=rotary_pos_emb)
+            return ops.InnerFn.apply(x, context, meta, *self._params())
         return self._forward_selfattn(x, mask=mask, context=context, context_mask=context_mask,
                                       rotary_pos_emb=rotary_pos_emb)
 
@@ -449,8 +464,8 @@ class Transformer(nn.Module):
 
     def forward_layers(self, x, mask=None, context=None, context_mask=None, rotary_pos_emb=None):
         for attn, cross_attn, ff in self.layers:
-            if attn._inner() is not None and x.is_cuda:
-                x = attn.fused_residual(x)
+            if x.is_cuda and attn._inner(seq_len=x.shape[1]) is not None:
+                x = attn.fused_residual(x, mask=mask, rotary_pos_emb=rotary_pos_emb)
             else:
                 x = attn(x, mask=mask, rotary_pos_emb=rotary_pos_emb) + x
             if exists(cross_attn):
@@ -504,8 +519,8 @@ class ReversibleBlock(nn.Module):
 
     def forward(self, x1, x2, f_args={}, g_args={}):
         f, g = self.f.net, self.g.net
-        if isinstance(f, SandwichNorm) and f._inner(f_args.get('context')) is not None and x1.is_cuda:
-            y1 = f.fused_residual(x2, resid=x1, context=f_args.get('context'), context_mask=f_args.get('context_mask'))
+        if isinstance(f, SandwichNorm) and x1.is_cuda and f._inner(f_args.get('context'), seq_len=x2.shape[1]) is not None:
+            y1 = f.fused_residual(x2, resid=x1, **{k: f_args.get(k) for k in ('context', 'context_mask', 'mask', 'rotary_pos_emb')})
         else:
             y1 = x1 + f(x2, **f_args)
         if isinstance(g, SandwichNorm) and g._inner() is not None and x1.is_cuda:
@@ -518,7 +533,7 @@ class ReversibleBlock(nn.Module):
         """inputs and input-gradients of this block from its outputs and output-gradients (the role of rev.py:77-106);
         parameter gradients of f and g are accumulated by the two inner autograd calls"""
         f, g = self.f.net, self.g.net
-        fuse_f = isinstance(f, SandwichNorm) and f._inner(f_args.get('context')) is not None and y1.is_cuda
+        fuse_f = isinstance(f, SandwichNorm) and y1.is_cuda and f._inner(f_args.get('context'), seq_len=y1.shape[1]) is not None
         fuse_g = isinstance(g, SandwichNorm) and g._inner() is not None and y1.is_cuda
         # g(y1) again.  Fused form: one node computes (-y2) + g(y1) = -x2, whose gradient w.r.t. y1 and g's parameters is g's.
         with torch.enable_grad():
@@ -535,7 +550,7 @@ class ReversibleBlock(nn.Module):
         with torch.enable_grad():
             x2g = x2.detach().requires_grad_(True)
             if fuse_f:
-                neg_x1 = f.fused_residual(x2g, resid=-y1, context=f_args.get('context'), context_mask=f_args.get('context_mask'))
+                neg_x1 = f.fused_residual(x2g, resid=-y1, **{k: f_args.get(k) for k in ('context', 'context_mask', 'mask', 'rotary_pos_emb')})
                 torch.autograd.backward(neg_x1, dx1)
             else:
                 fx2 = f(x2g, **f_args)

@@ -116,6 +116,22 @@ class S3Inner:
         return dh, None, grads
 
 
+def _rotary_bf(t, freqs, B, n, heads_total, inverse=False):
+    """apply_rotary_pos_emb (np.py:144-153) to a bf16 [B*n, heads_total*dh] activation (every dh-wide head chunk: q, k AND v
+    heads alike -- quirk Q11); inverse=True applies the transpose (the backward of the rotation).  Text-encoder sized tensors."""
+    x = t.hi.float() if t.lo is None else t.hi.float() + t.lo.float()
+    R, Cc = x.shape
+    x = x.view(B, n, heads_total, Cc // heads_total)
+    rd = freqs.shape[-1]
+    c, sn = freqs.cos()[None, :, None, :], freqs.sin()[None, :, None, :]
+    a, rest = x[..., :rd], x[..., rd:]
+    rh = torch.cat((-a[..., rd // 2:], a[..., :rd // 2]), dim=-1)
+    a = a * c - rh * sn if inverse else a * c + rh * sn
+    out = K.empty_bf((R, Cc), x.device, lo=t.lo is not None)
+    K.cast_pad(torch.cat((a, rest), dim=-1).reshape(R, Cc).contiguous(), out)
+    return out
+
+
 class XInner:
     """to_q(x), to_kv(context) -> cross-attention core -> to_out (np.py:315-379, context given).
     params: null_k, null_v, talking_heads.w, to_q.w, to_kv.w, to_out.w"""
@@ -132,9 +148,13 @@ class XInner:
         W = XInner.weights(meta['cache'], p)
         nk, nv, wth = p[0], p[1], p[2]
         g = meta['xgeom']
-        ctx = meta['ctx_bf']
+        ctx = h if meta.get('self_kv') else meta['ctx_bf']          # self-attention (text encoder): keys / values from the same rows
         q = K.gemm_nt(h, W['q'], out_bf16=True)
         kv = K.gemm_nt(ctx, W['kv'], out_bf16=True)
+        rot = meta.get('rotary')
+        if rot is not None:
+            q = _rotary_bf(q, rot, g.B, g.n, g.heads)
+            kv = _rotary_bf(kv, rot, g.B, g.T, 2 * g.heads)
         pk = K.xattn_pack(g, kv, nk.detach().reshape(g.heads, g.dim_head).contiguous(),
                           nv.detach().reshape(g.heads, g.dim_head).contiguous(), meta['mask_u8'])
         wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
@@ -162,10 +182,17 @@ class XInner:
             dq, dS, dwth = K.xattn_bwd(g, d_o, pk, wth2, P)
         dKp, dVp = K.xattn_kv_grads(g, dS, Pm, q, d_o)
         dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=dy.lo is not None)
+        rot = meta.get('rotary')
+        if rot is not None:
+            dq = _rotary_bf(dq, rot, g.B, g.n, g.heads, inverse=True)
+            dkv = _rotary_bf(dkv, rot, g.B, g.T, 2 * g.heads, inverse=True)
         dh = K.gemm_nt(dq, W['qT'], out_bf16=_fast())
         dwq, dwkv = torch.empty_like(wq), torch.empty_like(wkv)
         meta['wg'].run(lambda: (K.gemm_tn(dq, h, dwq), K.gemm_tn(dkv, ctx, dwkv)))
         dctx = K.gemm_nt(dkv, W['kvT'])
+        if meta.get('self_kv'):                  # the key/value rows ARE the query rows: one gradient for h
+            dh = _as_f32(dh) + dctx
+            dctx = None
         return dh, dctx, [dnk.reshape(nk.shape), dnv.reshape(nv.shape), dwth.reshape(wth.shape), dwq, dwkv, dwo]
 
 
@@ -293,7 +320,7 @@ class SandwichBlockFn(Function):
         x2 = x.detach().contiguous().reshape(B * n, D)
         r2_ = x2 if resid is None else resid.detach().contiguous().reshape(B * n, D)
         meta = dict(meta)
-        if meta['kind'] == 'xattn':
+        if meta['kind'] == 'xattn' and not meta.get('self_kv'):
             meta['ctx_bf'] = _ctx_to_bf(context)
         h, m1, r1, _ = K.ln_fwd(x2, pre_w.detach(), pre_b.detach())
         y, saved = inner.fwd(h, p, meta)
@@ -345,7 +372,7 @@ class InnerFn(Function):
         B, n, D = x.shape
         x2 = x.detach().contiguous().reshape(B * n, D)
         meta = dict(meta)
-        if meta['kind'] == 'xattn':
+        if meta['kind'] == 'xattn' and not meta.get('self_kv'):
             meta['ctx_bf'] = _ctx_to_bf(context)
         h = K.empty_bf((B * n, D), x.device)
         K.cast_pad(x2, h)

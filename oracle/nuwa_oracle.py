@@ -505,17 +505,21 @@ def text_encoder(text, P, cfg, training=True):
     else:                                      # learned absolute positions (np.py:1827-1829; NUWAVideoAudio's default)
         rot = None
         emb = emb + P['text_abs_pos_emb.embed.weight'][:text.shape[1]][None]
-    T = sub(P, 'text_transformer')
-    x1, x2 = emb, emb
-    for l in range(cfg['text_depth']):
+    return text_encoder_stack(emb, sub(P, 'text_transformer'), cfg['text_depth'], cfg['text_heads'], mask, rot), mask
+
+
+def text_encoder_stack(x, T, depth, heads, mask, rot):
+    """ReversibleTransformer of (self-Attention, FeedForward) blocks + final StableLayerNorm (np.py:1184-1295, rev.py:54-142),
+    plain (stored-activation) evaluation; T = its state dict (`layers.*` keys)."""
+    x1, x2 = x, x
+    for l in range(depth):
         A = sub(T, f'layers.{l}')
-        f = lambda h, A=A: sandwich(h, sub(A, '0'), lambda t: attention(
-            t, sub(A, '0.fn.fn'), cfg['text_heads'], mask=mask, rotary=rot))
+        f = lambda h, A=A: sandwich(h, sub(A, '0'), lambda t: attention(t, sub(A, '0.fn.fn'), heads, mask=mask, rotary=rot))
         g = lambda h, A=A: sandwich(h, sub(A, '1'), lambda t: feedforward(t, sub(A, '1.fn.fn')))
         y1 = x1 + f(x2)
         y2 = x2 + g(y1)
         x1, x2 = y1, y2
-    return stable_layer_norm(x1 + x2, T['norm.norm.weight'], T['norm.norm.bias']), mask
+    return stable_layer_norm(x1 + x2, T['norm.norm.weight'], T['norm.norm.bias'])
 
 
 # --------------------------------------------------------------------------------------

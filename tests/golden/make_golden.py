@@ -24,7 +24,7 @@ from oracle import ref_shims  # noqa: E402
 ref_shims.install()
 from nuwa_pytorch import NUWA, NUWAVideoAudio, VQGanVAE  # noqa: E402
 from nuwa_pytorch.nuwa_pytorch import (Sparse3DNA, Attention, FeedForward, SandwichNorm,  # noqa: E402
-                                       ShiftVideoTokens, StableLayerNorm, Transformer)
+                                       ShiftVideoTokens, StableLayerNorm, Transformer, ReversibleTransformer, RotaryEmbedding)
 
 
 def np_(t):
@@ -198,6 +198,26 @@ def g8_decoder_layer():
          **params(tr), **grads(tr))
 
 
+def g10_text_encoder():
+    """row f1: the text encoder's blocks -- non-causal self-attention (null k/v, key mask, talking heads, rotary on q, k AND v)
+    + FeedForward in a ReversibleTransformer, at a head size the HIP attention kernels cover (32)"""
+    torch.manual_seed(0)
+    tr = ReversibleTransformer(dim=32, depth=2, heads=2, dim_head=32)
+    rot = RotaryEmbedding(dim=32)
+    torch.manual_seed(1)
+    x = torch.randn(3, 12, 32, requires_grad=True)
+    mask = torch.ones(3, 12, dtype=torch.bool)
+    mask[1, 7:] = False
+    mask[2, 1:] = False
+    freqs = rot(12, device=x.device)
+    y = tr(x, mask=mask, rotary_pos_emb=freqs)
+    g = torch.randn_like(y)
+    y.backward(g)
+    P = {k: v for k, v in params(tr).items() if '.net.blocks.' not in k}
+    G = {k: v for k, v in grads(tr).items() if '.net.blocks.' not in k}
+    save('g10_text_encoder', x=x, mask=mask, freqs=freqs, y=y, dy=g, dx=x.grad, **P, **G)
+
+
 VA_KW = dict(dim=32, image_size=16, num_audio_tokens=40, num_audio_tokens_per_video_frame=4, max_video_frames=3, text_num_tokens=50,
              text_max_seq_len=8, text_enc_depth=2, text_enc_dim_head=16, text_enc_heads=2, enc_reversible=True, dec_reversible=False,
              dec_depth=3, dec_dim_head=32, dec_heads=2, sparse_3dna_kernel_size=3, sparse_3dna_dilation=2, sparse_2dna_kernel_size=7,
@@ -241,3 +261,4 @@ if __name__ == '__main__':
     g7_vae()
     g8_decoder_layer()
     g9_video_audio()
+    g10_text_encoder()

@@ -306,3 +306,26 @@ def test_g9_video_audio_loss_logits_grads(A, name, mode, tol, gtol):
         assert n > 150
     finally:
         A.set_precision('bf16')
+
+
+@pytest.mark.parametrize('mode,tol,gtol', MODES)
+def test_g10_text_encoder_on_hip_kernels(A, mode, tol, gtol):
+    """row f1: the text encoder's self-attention blocks run on the cross-attention kernels (keys / values = the query rows,
+    rotary on q, k and v, padded-key mask) inside the reversible stack; against the reference fixture"""
+    import nuwa_pytorch_amd.nuwa_pytorch as M
+    Ar, P, G = load('g10_text_encoder')
+    tr = M.ReversibleTransformer(dim=32, depth=2, heads=2, dim_head=32)
+    missing, unexpected = tr.load_state_dict(P, strict=False)
+    assert not unexpected and all('net.blocks.' in k or k.endswith('.mask') for k in missing), (missing, unexpected)
+    tr = tr.to(DEV).train()
+    assert tr.layers[0][0]._inner(seq_len=12) is not None          # the fused libamdnuwa node is taken, not the torch fallback
+    run_mode(A, mode)
+    try:
+        x = Ar['x'].to(DEV).requires_grad_(True)
+        y = tr(x, mask=Ar['mask'].to(DEV), rotary_pos_emb=Ar['freqs'].to(DEV))
+        report(f'g10[{mode}].y', y, Ar['y'], tol)
+        y.backward(Ar['dy'].to(DEV))
+        report(f'g10[{mode}].dx', x.grad, Ar['dx'], gtol)
+        assert check_grads(tr, G, gtol * 2, f'g10[{mode}]', skip=('net.blocks.',)) > 20
+    finally:
+        A.set_precision('bf16')

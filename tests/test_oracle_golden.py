@@ -126,6 +126,22 @@ def test_g9_video_audio(name):
     assert n > 150
 
 
+def test_g10_text_encoder():
+    A, P, G = load('g10_text_encoder')
+    P = req({k: v for k, v in P.items() if 'net.blocks.' not in k})
+    x = A['x'].clone().requires_grad_(True)
+    y = O.text_encoder_stack(x, P, 2, 2, A['mask'], A['freqs'])
+    torch.testing.assert_close(y, A['y'], **TOL)
+    y.backward(A['dy'])
+    torch.testing.assert_close(x.grad, A['dx'], rtol=1e-3, atol=2e-5)
+    n = 0
+    for k, g in G.items():
+        if 'net.blocks.' not in k:
+            torch.testing.assert_close(P[k].grad, g, rtol=1e-3, atol=2e-5, msg=lambda m, k=k: f'{k}: {m}')
+            n += 1
+    assert n > 20
+
+
 def test_g7_vae_encode():
     A, P, _ = load('g7_vae')
     fm = O.vae_encode_fmap(A['img'], P, num_layers=int(A['num_layers']), heads=int(A['heads']))
