@@ -5,9 +5,11 @@ Same class names, constructor kwargs, forward() signatures and state-dict keys a
   * video tower (Sparse3DNA incl. rel_pos_bias, text cross-attention, GEGLU FF, token shift), the text cross-attention and
     the FeedForwards of the audio tower, every LayerNorm, and both StableLayerNorm + logits + cross-entropy heads go through
     libamdnuwa (the same fused autograd nodes as NUWA);
-  * the audio-only pieces -- the 1-D causal window attention over audio tokens, the one-frame-lagged chunked
-    video<->audio attention and the audio channel shift -- are small (321 audio tokens against 2560 video tokens) and are
-    written here with torch ops on the device, formulated as index-table gathers (nothing is unfolded).
+  * the audio-only attention pieces map onto the same kernels: the 1-D causal window attention over audio tokens IS a
+    Sparse3DNA over a (time, 1, 1) grid with a (k, 1, 1) kernel and the per-tap bias; the one-frame-lagged chunked
+    video<->audio attention is the cross-attention kernel with every (sample, frame) pair as one sample, plus a rank-one
+    correction for the talking-heads Conv3d bias.  Head sizes the kernels do not cover (and `use_hip = False`) run the torch-op
+    formulations kept next to them (index-table gathers, nothing is unfolded); the audio channel shift is a torch op.
 Not built: `dec_reversible=True` (ReversibleDualModalityDecoder, np.py:1489-1655 + reversible_video_audio.py) and generate().
 """
 import torch
@@ -47,7 +49,9 @@ class SparseCausal2DNA(nn.Module):
         if height != 1:
             raise NotImplementedError('SparseCausal2DNA: only height = 1 (one audio token per timestep row) is built')
         inner = heads * dim_head
-        self.heads, self.scale, self.height = heads, dim_head ** -0.5, height
+        self.heads, self.dim_head, self.scale, self.height = heads, dim_head, dim_head ** -0.5, height
+        self._cache = ops.WeightCache()
+        self.use_hip = True            # False: the torch-op formulation below (kept for head sizes the kernels do not cover)
         self.talking_heads = nn.Conv3d(heads, heads, 1, bias=False)
         self.dropout = nn.Dropout(dropout)
         self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
@@ -64,10 +68,26 @@ class SparseCausal2DNA(nn.Module):
         idx = t - (k - 1 - a) * dil
         return torch.where(idx >= 0, idx, torch.full_like(idx, -1))
 
+    def _forward_hip(self, x):
+        """the same attention IS a Sparse3DNA over a (time, 1, 1) grid with kernel (k, 1, 1) and the per-tap bias: run it on
+        the libamdnuwa 3DNA kernels (to_qkv split into the q / kv halves they expect; to_out has no bias -> zeros)"""
+        from . import kernels as K
+        b, n, h = x.shape[0], x.shape[1], self.heads
+        inner = h * self.dim_head
+        w = self.to_qkv.weight
+        taps = self.rel_pos_bias().reshape(self.kernel_size[0], h)
+        bias = torch.cat((taps.new_zeros(1, h), taps), 0).float()
+        g = K.s3_geom(b, n, (max(n - 1, 1), 1, 1), (self.kernel_size[0], 1, 1), (self.dilation[0], 1, 1), h, self.dim_head)
+        meta = dict(kind='s3', cache=self._cache, geom=g)
+        return ops.InnerFn.apply(x, None, meta, w[:inner], w[inner:], self.talking_heads.weight.reshape(h, h, 1, 1),
+                                 self.to_out.weight, x.new_zeros(self.to_out.weight.shape[0]), bias)
+
     def forward(self, x, **kwargs):
         b, n, h = x.shape[0], x.shape[1], self.heads
         if self.training and self.dropout.p > 0:
             raise NotImplementedError('attention dropout inside SparseCausal2DNA is not built')
+        if self.use_hip and x.is_cuda and self.dim_head in (32, 64) and h <= 8 and self.kernel_size[0] > 1:
+            return self._forward_hip(x)
         q, k, v = self.to_qkv(x).chunk(3, dim=-1)
         if n == 1:
             return self.to_out(v)
@@ -114,6 +134,9 @@ class CrossModalityCrossAttention(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.has_start_token, self.context_has_start_token = has_start_token, context_has_start_token
         self.chunk_size, self.context_chunk_size = chunk_size, context_chunk_size
+        self.dim_head = dim_head
+        self._cache = ops.WeightCache()
+        self.use_hip = True            # False: the torch-op formulation (kept for head sizes the kernels do not cover)
 
     def forward(self, seq, context, mask=None, context_mask=None):
         if self.training and self.dropout.p > 0:
@@ -135,6 +158,26 @@ class CrossModalityCrossAttention(nn.Module):
             return torch.zeros_like(seq)
         qf = self.norm(body[:, :nf * c].reshape(b, nf, c, dim))
         cf = self.context_norm(ctx[:, :nf * cc].reshape(b, nf, cc, -1))
+        if self.use_hip and seq.is_cuda and self.dim_head in (32, 64) and h <= 8 and cc + 1 <= 288:
+            # every (sample, frame) pair is one sample of the libamdnuwa cross-attention kernels (null k/v, key mask, talking heads);
+            # the Conv3d BIAS adds bias[g] to every attention weight, i.e. bias[g] * (null_v[g] + sum_j v_j[g]) to the head output
+            from . import kernels as K
+            inner = h * self.dim_head
+            xq, xc = qf.reshape(b * nf, c, dim), cf.reshape(b * nf, cc, -1)
+            g = K.x_geom(b * nf, c, cc, h, self.dim_head)
+            km = cmask[:, :nf * cc].reshape(b * nf, cc).to(torch.uint8).contiguous() if exists(cmask) else None
+            meta = dict(kind='xattn', cache=self._cache, xgeom=g, mask_u8=km, save=torch.is_grad_enabled())
+            out = ops.InnerFn.apply(xq, xc, meta, self.null_k.reshape(h, 1, -1), self.null_v.reshape(h, 1, -1),
+                                    self.talking_heads.weight.reshape(h, h, 1, 1), self.to_q.weight, self.to_kv.weight, self.to_out.weight)
+            vsum = self.null_v[None] + F.linear(xc.sum(1), self.to_kv.weight[inner:]).reshape(b * nf, h, -1)
+            corr = F.linear((self.talking_heads.bias[None, :, None] * vsum).reshape(b * nf, inner), self.to_out.weight)
+            out = (out + corr[:, None]).reshape(b, nf * c, -1)
+            out = F.pad(out, (0, 0, 0, max(0, s_len - nf * c)))[:, :s_len]
+            if self.has_start_token:
+                out = F.pad(out, (0, 0, 1, 0))
+            if exists(mask):
+                out = out.masked_fill(~mask[..., None], 0.)
+            return out
         q = self.to_q(qf).reshape(b, nf, c, h, -1).permute(0, 3, 1, 2, 4) * self.scale          # b h f c d
         k, v = (t.reshape(b, nf, cc, h, -1).permute(0, 3, 1, 2, 4) for t in self.to_kv(cf).chunk(2, dim=-1))
         nk = self.null_k[None, :, None, None, :].expand(b, h, nf, 1, -1)

@@ -329,3 +329,69 @@ def test_g10_text_encoder_on_hip_kernels(A, mode, tol, gtol):
         assert check_grads(tr, G, gtol * 2, f'g10[{mode}]', skip=('net.blocks.',)) > 20
     finally:
         A.set_precision('bf16')
+
+
+def _grads_of(mod):
+    return {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize('n,kernel,dil', [(1, 5, 1), (2, 7, 1), (13, 7, 2), (321, 7, 1)])
+def test_sparse_causal_2dna_hip_equals_torch_formulation(A, O_mod, n, kernel, dil):
+    """cfg-5 audio window attention: the libamdnuwa route (3DNA kernels on a (time, 1, 1) grid) against the oracle"""
+    from nuwa_pytorch_amd.video_audio import SparseCausal2DNA
+    torch.manual_seed(0)
+    m = SparseCausal2DNA(dim=64, heads=2, dim_head=32, kernel_size=kernel, dilation=dil).to(DEV)
+    torch.manual_seed(1)
+    x = torch.randn(2, n, 64)
+    g = torch.randn(2, n, 64)
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O_mod.sparse_causal_2dna(xr, P, 2, kernel, dil)
+    yr.backward(g)
+    A.set_precision('bf16x3')
+    try:
+        xd = x.to(DEV).requires_grad_(True)
+        y = m(xd)
+        report(f'audio2dna[{n},{kernel},{dil}].y', y, yr.detach(), 1e-3)
+        y.backward(g.to(DEV))
+        report(f'audio2dna[{n},{kernel},{dil}].dx', xd.grad, xr.grad, 2e-3)
+        if n > 1:
+            for k, gr in _grads_of(m).items():
+                report(f'audio2dna[{n},{kernel},{dil}].grad.{k}', gr, P[k].grad, 2e-3)
+    finally:
+        A.set_precision('bf16')
+
+
+@pytest.fixture(scope='module')
+def O_mod():
+    from oracle import nuwa_oracle
+    return nuwa_oracle
+
+
+@pytest.mark.parametrize('n_seq,n_ctx,chunk,cchunk', [(1 + 32, 1 + 8, 16, 4), (1 + 30, 1 + 8, 16, 4), (1 + 48, 1 + 6, 16, 4),
+                                                      (1 + 8, 1 + 48, 4, 16), (1 + 2560, 1 + 320, 256, 32)])
+def test_cross_modality_attention_hip_equals_oracle(A, O_mod, n_seq, n_ctx, chunk, cchunk):
+    from nuwa_pytorch_amd.video_audio import CrossModalityCrossAttention
+    torch.manual_seed(0)
+    m = CrossModalityCrossAttention(dim=64, heads=2, dim_head=32, chunk_size=chunk, context_chunk_size=cchunk).to(DEV)
+    with torch.no_grad():
+        m.talking_heads.bias.normal_(0, 0.3)
+    torch.manual_seed(1)
+    x, c, g = torch.randn(2, n_seq, 64), torch.randn(2, n_ctx, 64), torch.randn(2, n_seq, 64)
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    xr, cr = x.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    yr = O_mod.cross_modality_cross_attention(xr, cr, P, 2, chunk, cchunk)
+    yr.backward(g)
+    A.set_precision('bf16x3')
+    try:
+        xd, cd = x.to(DEV).requires_grad_(True), c.to(DEV).requires_grad_(True)
+        y = m(xd, cd)
+        tag = f'xmodal[{n_seq},{n_ctx}]'
+        report(tag + '.y', y, yr.detach(), 1e-3)
+        y.backward(g.to(DEV))
+        report(tag + '.dx', xd.grad, xr.grad, 2e-3)
+        report(tag + '.dctx', cd.grad, cr.grad, 2e-3)
+        for k, gr in _grads_of(m).items():
+            report(tag + f'.grad.{k}', gr, P[k].grad, 2e-3)
+    finally:
+        A.set_precision('bf16')
