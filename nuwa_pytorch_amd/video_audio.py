@@ -10,14 +10,15 @@ Same class names, constructor kwargs, forward() signatures and state-dict keys a
     video<->audio attention is the cross-attention kernel with every (sample, frame) pair as one sample, plus a rank-one
     correction for the talking-heads Conv3d bias.  Head sizes the kernels do not cover (and `use_hip = False`) run the torch-op
     formulations kept next to them (index-table gathers, nothing is unfolded); the audio channel shift is a torch op.
-Not built: `dec_reversible=True` (ReversibleDualModalityDecoder, np.py:1489-1655 + reversible_video_audio.py) and generate().
+`dec_reversible=True` (ReversibleDualModalityDecoder, np.py:1489-1655 + reversible_video_audio.py) runs with the reference's
+arithmetic but keeps its activations (no recomputing backward yet).  Not built: generate().
 """
 import torch
 import torch.nn.functional as F
 from torch import nn, einsum
 
 from . import ops
-from .nuwa_pytorch import (MList, exists, default, eval_decorator, prob_mask_like, SandwichNorm, ShiftVideoTokens, FeedForward,
+from .nuwa_pytorch import (MList, exists, default, eval_decorator, prob_mask_like, SandwichNorm, ShiftVideoTokens, FeedForward, Deterministic,
                            Attention, Sparse3DNA, StableLayerNorm, Transformer, ReversibleTransformer, Embedding,
                            AxialPositionalEmbedding, RotaryEmbedding)
 
@@ -270,11 +271,115 @@ class DualModalityDecoder(nn.Module):
         return self.video_norm(video), self.audio_norm(audio)
 
 
-class ReversibleDualModalityDecoder(nn.Module):
-    def __init__(self, *args, **kwargs):
+class DualReversibleBlock(nn.Module):
+    """one block of the reversible dual decoder (reversible_video_audio.py:27-327): video halves (x1, x2) and audio halves
+    (m1, m2); f / g act on video, j / k on audio -- except in the cross-modality block, where the reference feeds the video
+    stream through `k` and the audio stream through `g` (reversible_video_audio.py:241-244; reproduced)."""
+
+    def __init__(self, kind, f, g, j, k):
         super().__init__()
-        raise NotImplementedError('ReversibleDualModalityDecoder (np.py:1489-1655) is not built yet: construct NUWAVideoAudio with '
-                                  'dec_reversible=False')
+        self.kind = kind
+        self.f, self.g, self.j, self.k = (Deterministic(t) for t in (f, g, j, k))
+
+    def forward(self, x1, x2, m1, m2, *, context, context_mask, video_mask=None, audio_mask=None):
+        f, g, j, k = self.f.net, self.g.net, self.j.net, self.k.net
+        if self.kind == 'intra_modality_self_attn':
+            y1 = _residual_to(f, x2, x1, mask=video_mask)
+            y2 = _residual_to(g, y1, x2)
+            n1 = _residual_to(j, m2, m1, mask=audio_mask)
+            n2 = _residual_to(k, n1, m2)
+        elif self.kind == 'intra_modality_cross_attn':
+            y1 = _residual_to(f, x2, x1, context=context, context_mask=context_mask, mask=video_mask)
+            y2 = _residual_to(g, y1, x2)
+            n1 = _residual_to(j, m2, m1, context=context, context_mask=context_mask, mask=audio_mask)
+            n2 = _residual_to(k, n1, m2)
+        else:
+            y1 = x1 + f(x2, m2, mask=video_mask, context_mask=audio_mask)
+            y2 = _residual_to(k, y1, x2)
+            n1 = m1 + j(m2, y2, mask=audio_mask, context_mask=video_mask)       # the audio side sees the UPDATED video half
+            n2 = _residual_to(g, n1, m2)
+        return y1, y2, n1, n2
+
+
+def _residual_to(block, x, resid, **kw):
+    """resid + block(x): the fused libamdnuwa node (residual taken from a different tensor) where the block allows it"""
+    inner_kw = {a: b for a, b in kw.items() if a in ('context', 'context_mask')}
+    if isinstance(block, SandwichNorm) and x.is_cuda and block._inner(inner_kw.get('context')) is not None:
+        return block.fused_residual(x, resid=resid, **inner_kw)
+    return resid + block(x, **{a: b for a, b in kw.items() if b is not None})
+
+
+class DualModalityReversibleSequence(nn.Module):
+    """reversible_video_audio.py:367-407: both streams are duplicated, run through the blocks, and the two halves AVERAGED.
+    Activations are kept by autograd (the reference's recomputing backward is a memory optimisation; same arithmetic)."""
+
+    def __init__(self, input_blocks, block_types):
+        super().__init__()
+        self.block_types = block_types
+        self.blocks = nn.ModuleList([DualReversibleBlock(kind, *blk) for blk, kind in zip(input_blocks, block_types)])
+
+    def forward(self, video, audio, *, context, context_mask=None, video_mask=None, audio_mask=None, reverse=True):
+        x1 = x2 = video
+        m1 = m2 = audio
+        for block in self.blocks:
+            x1, x2, m1, m2 = block(x1, x2, m1, m2, context=context, context_mask=context_mask, video_mask=video_mask,
+                                   audio_mask=audio_mask)
+        return (x1 + x2) * 0.5, (m1 + m2) * 0.5
+
+
+class ReversibleDualModalityDecoder(nn.Module):
+    """np.py:1489-1655: per depth a self-attention block (video 3DNA + FF, audio window attention + FF), a text
+    cross-attention block, and after every `cross_modality_attn_every`-th depth a cross-modality block whose attention and
+    FeedForward modules are NOT SandwichNorm-wrapped."""
+
+    def __init__(self, *, dim, depth, num_audio_tokens_per_video_frame, num_video_tokens_per_frame, sparse_3dna_video_shape, heads=8,
+                 dim_head=64, ff_mult=4, attn_dropout=0., ff_dropout=0., ff_chunk_size=None, sparse_3dna_kernel_size=3,
+                 sparse_3dna_query_num_frames_chunk=None, sparse_3dna_dilations=(1,), sparse_3dna_rel_pos_bias=False,
+                 sparse_2dna_kernel_size=7, sparse_2dna_dilation=(1,), sparse_2dna_rel_pos_bias=False, shift_video_tokens=False,
+                 shift_audio_tokens=False, audio_tokens_per_timestep=1, cross_modality_attn_every=3):
+        super().__init__()
+        self.layers = MList([])
+        self.layer_types = []
+        sn = lambda fn: SandwichNorm(dim=dim, fn=fn)
+        ff = lambda: FeedForward(dim=dim, mult=ff_mult, dropout=ff_dropout, chunk_size=ff_chunk_size)
+        text_attn = lambda: Attention(dim=dim, heads=heads, dim_head=dim_head, dropout=attn_dropout)
+        fmap = sparse_3dna_video_shape[-1]
+        vshift = (lambda fn: ShiftVideoTokens(fn, image_size=fmap)) if shift_video_tokens else (lambda fn: fn)
+        ashift = (lambda fn: ShiftAudioTokens(fn, audio_tokens_per_timestep=audio_tokens_per_timestep)) if shift_audio_tokens else (lambda fn: fn)
+        for ind in range(depth):
+            video_attn = Sparse3DNA(dim=dim, heads=heads, dim_head=dim_head, causal=True, kernel_size=sparse_3dna_kernel_size,
+                                    dilation=sparse_3dna_dilations[ind % len(sparse_3dna_dilations)],
+                                    video_shape=sparse_3dna_video_shape, query_num_frames_chunk=sparse_3dna_query_num_frames_chunk,
+                                    rel_pos_bias=sparse_3dna_rel_pos_bias)
+            audio_attn = SparseCausal2DNA(dim=dim, heads=heads, dim_head=dim_head, dropout=attn_dropout,
+                                          kernel_size=sparse_2dna_kernel_size,
+                                          dilation=sparse_2dna_dilation[ind % len(sparse_2dna_dilation)], rel_pos_bias=sparse_2dna_rel_pos_bias)
+            # (argument order of the four lambdas = construction order in the reference: attention modules first, then the FFs)
+            v_ff, a_ff = ff(), ff()
+            self.layers.append(MList([sn(vshift(video_attn)), sn(vshift(v_ff)), sn(ashift(audio_attn)), sn(ashift(a_ff))]))
+            self.layer_types.append('intra_modality_self_attn')
+            v_x, a_x = text_attn(), text_attn()
+            self.layers.append(MList([sn(v_x), sn(ff()), sn(a_x), sn(ff())]))
+            self.layer_types.append('intra_modality_cross_attn')
+            if (ind + 1) % cross_modality_attn_every == 0:
+                xm = lambda cs, ccs: CrossModalityCrossAttention(dim=dim, heads=heads, dim_head=dim_head, chunk_size=cs,
+                                                                 context_chunk_size=ccs, has_start_token=True, context_has_start_token=True)
+                v2a = xm(num_video_tokens_per_frame, num_audio_tokens_per_video_frame)
+                v_xff = ff()
+                a2v = xm(num_audio_tokens_per_video_frame, num_video_tokens_per_frame)
+                a_xff = ff()
+                self.layers.append(MList([v2a, v_xff, a2v, a_xff]))
+                self.layer_types.append('inter_modality_cross_attn')
+        self.net = DualModalityReversibleSequence(self.layers, self.layer_types)
+        self.video_norm = StableLayerNorm(dim)
+        self.audio_norm = StableLayerNorm(dim)
+
+    def forward_layers(self, video, audio, *, context, audio_mask=None, video_mask=None, context_mask=None, **kwargs):
+        return self.net(video, audio, context=context, audio_mask=audio_mask, video_mask=video_mask, context_mask=context_mask)
+
+    def forward(self, video, audio, **kwargs):
+        video, audio = self.forward_layers(video, audio, **kwargs)
+        return self.video_norm(video), self.audio_norm(audio)
 
 
 class NUWAVideoAudio(nn.Module):

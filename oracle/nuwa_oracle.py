@@ -466,6 +466,48 @@ def dual_decoder(video, audio, P, cfg, context, context_mask):
             stable_layer_norm(audio, P['audio_norm.norm.weight'], P['audio_norm.norm.bias']))
 
 
+def reversible_dual_decoder(video, audio, P, cfg, context, context_mask):
+    """ReversibleDualModalityDecoder np.py:1489-1655 through DualModalityReversibleSequence (reversible_video_audio.py:27-407),
+    evaluated in plain form: streams duplicated into halves, per block y1 = x1 + f(x2), y2 = x2 + g(y1), n1 = m1 + j(m2),
+    n2 = m2 + k(n1); the cross-modality block feeds y1 through `k` and n1 through `g` and lets the audio side attend the updated
+    video half (reversible_video_audio.py:241-244); halves AVERAGED at the end."""
+    fmap = cfg['video_shape'][1]
+    shv = (lambda t: shift_video_tokens(t, fmap)) if cfg.get('shift_video', True) else (lambda t: t)
+    sha = shift_audio_tokens if cfg.get('shift_audio', True) else (lambda t: t)
+    kv = '.fn.fn' if cfg.get('shift_video', True) else '.fn'
+    ka = '.fn.fn' if cfg.get('shift_audio', True) else '.fn'
+    x1 = x2 = video
+    m1 = m2 = audio
+    li = 0
+    for ind in range(cfg['depth']):
+        L = sub(P, f'layers.{li}')
+        li += 1
+        dv = cfg['dilations'][ind % len(cfg['dilations'])]
+        da = cfg['audio_dilations'][ind % len(cfg['audio_dilations'])]
+        y1 = x1 + sandwich(x2, sub(L, '0'), lambda h: sparse3dna(shv(h), sub(L, '0' + kv), cfg['video_shape'], cfg['kernel_size'], dv, cfg['heads']))
+        y2 = x2 + sandwich(y1, sub(L, '1'), lambda h: feedforward(shv(h), sub(L, '1' + kv)))
+        n1 = m1 + sandwich(m2, sub(L, '2'), lambda h: sparse_causal_2dna(sha(h), sub(L, '2' + ka), cfg['heads'], cfg['audio_kernel'], da))
+        n2 = m2 + sandwich(n1, sub(L, '3'), lambda h: feedforward(sha(h), sub(L, '3' + ka)))
+        x1, x2, m1, m2 = y1, y2, n1, n2
+        L = sub(P, f'layers.{li}')
+        li += 1
+        y1 = x1 + sandwich(x2, sub(L, '0'), lambda h: attention(h, sub(L, '0.fn'), cfg['heads'], context=context, context_mask=context_mask))
+        y2 = x2 + sandwich(y1, sub(L, '1'), lambda h: feedforward(h, sub(L, '1.fn')))
+        n1 = m1 + sandwich(m2, sub(L, '2'), lambda h: attention(h, sub(L, '2.fn'), cfg['heads'], context=context, context_mask=context_mask))
+        n2 = m2 + sandwich(n1, sub(L, '3'), lambda h: feedforward(h, sub(L, '3.fn')))
+        x1, x2, m1, m2 = y1, y2, n1, n2
+        if (ind + 1) % cfg['every'] == 0:
+            L = sub(P, f'layers.{li}')
+            li += 1
+            y1 = x1 + cross_modality_cross_attention(x2, m2, sub(L, '0'), cfg['heads'], cfg['v_per_frame'], cfg['a_per_frame'])
+            y2 = x2 + feedforward(y1, sub(L, '3'))            # the AUDIO FeedForward module (block slot k) on the video stream
+            n1 = m1 + cross_modality_cross_attention(m2, y2, sub(L, '2'), cfg['heads'], cfg['a_per_frame'], cfg['v_per_frame'])
+            n2 = m2 + feedforward(n1, sub(L, '1'))            # the VIDEO FeedForward module (block slot g) on the audio stream
+            x1, x2, m1, m2 = y1, y2, n1, n2
+    return (stable_layer_norm((x1 + x2) * 0.5, P['video_norm.norm.weight'], P['video_norm.norm.bias']),
+            stable_layer_norm((m1 + m2) * 0.5, P['audio_norm.norm.weight'], P['audio_norm.norm.bias']))
+
+
 def video_audio_loss(P, cfg, ids, audio_ids, context, context_mask, training=True, return_logits=False):
     """decoder side of NUWAVideoAudio.forward(return_loss=True) np.py:2245-2293; ids (b, N), audio_ids (b, A) int64."""
     fr = cfg.get('embed_frac', 0.2)
@@ -475,7 +517,8 @@ def video_audio_loss(P, cfg, ids, audio_ids, context, context_mask, training=Tru
         ae = ae * fr + ae.detach() * (1 - fr)
     ae = ae + P['audio_pos_emb.axial1'][:ae.shape[1]][None]
     a = torch.cat((P['audio_bos'][None, None].expand(ae.shape[0], 1, -1), ae), dim=1)
-    v, a = dual_decoder(x, a, sub(P, 'video_audio_transformer'), cfg, context, context_mask)
+    dec = reversible_dual_decoder if cfg.get('reversible', False) else dual_decoder
+    v, a = dec(x, a, sub(P, 'video_audio_transformer'), cfg, context, context_mask)
     vl, al = v @ P['to_video_logits.weight'].t(), a @ P['to_audio_logits.weight'].t()
     loss = F.cross_entropy(vl.reshape(-1, vl.shape[-1]), ids.reshape(-1)) + \
         cfg.get('audio_loss_weight', 1.) * F.cross_entropy(al.reshape(-1, al.shape[-1]), audio_ids.reshape(-1))

@@ -224,14 +224,17 @@ VA_KW = dict(dim=32, image_size=16, num_audio_tokens=40, num_audio_tokens_per_vi
              sparse_2dna_dilation=2, cross_modality_attn_every=3, audio_loss_weight=0.7)
 
 
-def g9_video_audio():
+def g9_video_audio(only=None):
     """BASELINE cfg 5 path, tiny: NUWAVideoAudio.forward(return_loss=True) with the non-reversible DualModalityDecoder.
     a: no 3DNA rel-pos bias, batch 2 (padded text);  b: the default 3DNA rel-pos bias, batch 1 (the reference's bias add only
     broadcasts for one sample)."""
-    for name, rel, b in (('g9a_video_audio', False, 2), ('g9b_video_audio_relpos', True, 1)):
+    for name, rel, b, rev in (('g9a_video_audio', False, 2, False), ('g9b_video_audio_relpos', True, 1, False),
+                              ('g9c_video_audio_reversible', False, 2, True)):
+        if only is not None and name not in only:
+            continue
         torch.manual_seed(0)
         vae = VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
-        m = NUWAVideoAudio(vae=vae, sparse_3dna_rel_pos_bias=rel, **VA_KW)
+        m = NUWAVideoAudio(vae=vae, sparse_3dna_rel_pos_bias=rel, **{**VA_KW, 'dec_reversible': rev})
         torch.manual_seed(1)
         text = torch.randint(1, 50, (b, 8))
         text[-1, 5:] = 0
@@ -248,7 +251,7 @@ def g9_video_audio():
         P = {k: v for k, v in params(m).items() if not k.startswith('p.vae.') and '.net.blocks.' not in k}
         G = {k: v for k, v in grads(m).items() if '.net.blocks.' not in k}
         save(name, text=text, video_ids=vid, audio_ids=aud, loss=loss, video_logits=cap['vl'], audio_logits=cap['al'],
-             text_embeds=cap['ctx'], rel_pos_bias=rel, **P, **G)
+             text_embeds=cap['ctx'], rel_pos_bias=rel, reversible=rev, **P, **G)
 
 
 if __name__ == '__main__':

@@ -280,13 +280,14 @@ VA_KW = dict(dim=32, image_size=16, num_audio_tokens=40, num_audio_tokens_per_vi
 
 
 @pytest.mark.parametrize('mode,tol,gtol', MODES)
-@pytest.mark.parametrize('name', ['g9a_video_audio', 'g9b_video_audio_relpos'])
+@pytest.mark.parametrize('name', ['g9a_video_audio', 'g9b_video_audio_relpos', 'g9c_video_audio_reversible'])
 def test_g9_video_audio_loss_logits_grads(A, name, mode, tol, gtol):
     """BASELINE cfg 5 (row a15): NUWAVideoAudio with the non-reversible dual decoder, loaded with the reference's state dict,
     against the reference's loss, video / audio logits and every gradient"""
     Ar, P, G = load(name)
     vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
-    m = A.NUWAVideoAudio(vae=vae, sparse_3dna_rel_pos_bias=bool(Ar['rel_pos_bias']), **VA_KW)
+    rev = bool(Ar['reversible']) if 'reversible' in Ar else False
+    m = A.NUWAVideoAudio(vae=vae, sparse_3dna_rel_pos_bias=bool(Ar['rel_pos_bias']), **{**VA_KW, 'dec_reversible': rev})
     missing, unexpected = m.load_state_dict(P, strict=False)
     assert not unexpected, unexpected
     assert all(k.startswith('vae.') or '.net.blocks.' in k for k in missing), missing

@@ -105,7 +105,7 @@ VA_CFG = dict(depth=3, heads=2, video_shape=(3, 4, 4), kernel_size=3, dilations=
               v_per_frame=16, a_per_frame=4, shift_video=True, shift_audio=True, audio_loss_weight=0.7, text_depth=2, text_heads=2)
 
 
-@pytest.mark.parametrize('name', ['g9a_video_audio', 'g9b_video_audio_relpos'])
+@pytest.mark.parametrize('name', ['g9a_video_audio', 'g9b_video_audio_relpos', 'g9c_video_audio_reversible'])
 def test_g9_video_audio(name):
     """BASELINE cfg 5 (NUWAVideoAudio, non-reversible dual decoder): oracle vs the reference's loss, both logits and every
     decoder-side gradient"""
@@ -114,7 +114,8 @@ def test_g9_video_audio(name):
     b = A['text'].shape[0]
     ctx, mask = O.text_encoder(A['text'], P, VA_CFG)
     torch.testing.assert_close(ctx, A['text_embeds'], **TOL)
-    loss, vl, al = O.video_audio_loss(P, VA_CFG, A['video_ids'].reshape(b, -1), A['audio_ids'], ctx, mask, return_logits=True)
+    cfg = dict(VA_CFG, reversible=bool(A['reversible'])) if 'reversible' in A else VA_CFG
+    loss, vl, al = O.video_audio_loss(P, cfg, A['video_ids'].reshape(b, -1), A['audio_ids'], ctx, mask, return_logits=True)
     torch.testing.assert_close(vl, A['video_logits'], **TOL)
     torch.testing.assert_close(al, A['audio_logits'], **TOL)
     torch.testing.assert_close(loss, A['loss'], **TOL)

@@ -18,12 +18,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--reversible', action='store_true', help='the class-default ReversibleDualModalityDecoder')
     args = ap.parse_args()
     dev = 'cuda'
     torch.manual_seed(0)
     vae = A.VQGanVAE(dim=64, image_size=256, num_layers=4, vq_codebook_size=8192, use_vgg_and_gan=False)
     m = A.NUWAVideoAudio(vae=vae, dim=512, image_size=256, num_audio_tokens=2048, num_audio_tokens_per_video_frame=32,
-                         max_video_frames=10, text_max_seq_len=256, text_enc_depth=1, enc_reversible=True, dec_reversible=False).to(dev).train()
+                         max_video_frames=10, text_max_seq_len=256, text_enc_depth=1, enc_reversible=True, dec_reversible=args.reversible).to(dev).train()
     b = args.batch
     g = torch.Generator().manual_seed(1)
     text = torch.randint(1, 49408, (b, 256), generator=g).to(dev)
