@@ -547,9 +547,21 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
     };
     auto next_plane = [&](int t) { int fq, yq; while (t < nplanes && !plane(t, fq, yq)) ++t; return t; };
     uint4 rq[CH / 8], rd[CH / 8], rql[CH / 8], rdl[CH / 8];
+    constexpr int KWMAX = 3;                        // taps prefetched one plane ahead; wider kernels load the rest directly
+    float nds[KWMAX], npm[KWMAX];                   // ds / P' of the NEXT plane's taps (this thread's key, head): loaded one plane ahead
     auto fetch = [&](int t) {                       // q row and dO row of the attending query row -> registers
         int fq, yq;
         plane(t, fq, yq);
+#pragma unroll
+        for (int tc = 0; tc < KWMAX; ++tc) {
+            nds[tc] = npm[tc] = 0.f;
+            const int wq = w + (a.kw - 1 - tc) * a.dw;
+            const int pqn = (fq * a.H + yq) * a.W + wq;
+            if (tc < a.kw && kvalid && wq < a.W && 1 + pqn < a.ntok) {
+                const size_t ci = (((size_t)b * nq + pqn) * J + 1 + t * a.kw + tc) * a.NH + h;
+                nds[tc] = a.ds[ci]; npm[tc] = a.pm[ci];
+            }
+        }
         const int pq = (fq * a.H + yq) * a.W + w;
         const bool ok = act && (1 + pq) < a.ntok;
         const size_t gq = ((size_t)b * a.ntok + 1 + pq) * a.ld + h * DH + c * CH;
@@ -578,6 +590,9 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
             }
         }
         __syncthreads();
+        float cds[KWMAX], cpm[KWMAX];
+#pragma unroll
+        for (int tc = 0; tc < KWMAX; ++tc) { cds[tc] = nds[tc]; cpm[tc] = npm[tc]; }
         const int tn = next_plane(tp + 1);
         if (tn < nplanes) fetch(tn);                // in flight during the FMAs below
         if (kvalid) {
@@ -588,9 +603,12 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
                 if (wq >= a.W) continue;
                 const int pq = (fq * a.H + yq) * a.W + wq;
                 if (1 + pq >= a.ntok) continue;
-                const int j = 1 + tp * a.kw + tc;
-                const size_t ci = (((size_t)b * nq + pq) * J + j) * a.NH + h;
-                const float dsv = a.ds[ci], pmv = a.pm[ci];
+                float dsv, pmv;
+                if (tc < KWMAX) { dsv = tc == 0 ? cds[0] : (tc == 1 ? cds[1] : cds[2]); pmv = tc == 0 ? cpm[0] : (tc == 1 ? cpm[1] : cpm[2]); }
+                else {
+                    const size_t ci = (((size_t)b * nq + pq) * J + 1 + tp * a.kw + tc) * a.NH + h;
+                    dsv = a.ds[ci]; pmv = a.pm[ci];
+                }
                 const int slot = ((wq * a.NH + h) * 4 + c) * 8;
                 if (LO) {
                     float qq[CH], dd[CH];
