@@ -339,25 +339,22 @@ __global__ __launch_bounds__(256, 1) void xattn2_bwd_kernel(X2Args a) {
                 dth[g][h] = acc;
             }
         }
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            const W8 wh = ldw(wtsh, h);                          // W[.][h]
-            float acc = delta[h];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float dp = wh.v[0] * dPp[0][e];
-#pragma unroll
-                for (int g = 1; g < NH; ++g) dp = fmaf(wh.v[g], dPp[g][e], dp);
-                acc = fmaf(dp, P[h][e], acc);
-            }
-            delta[h] = acc;
-        }
         __builtin_amdgcn_s_barrier();
     }
+    // delta[h][q] = sum_j dP[h] P[h] = sum_g W[g][h] * (sum_j dP'[g] P[h]): the per-query part of the dW_th accumulators, so it
+    // costs 2 shuffles per (g, h) here instead of a third 512-FMA mix per chunk
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-        delta[h] += __shfl_xor(delta[h], 16, 64);
-        delta[h] += __shfl_xor(delta[h], 32, 64);
+        const W8 wh = ldw(wtsh, h);                              // W[.][h]
+        float acc = 0.f;
+#pragma unroll
+        for (int g = 0; g < NH; ++g) {
+            float t = dth[g][h];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            acc = fmaf(wh.v[g], t, acc);
+        }
+        delta[h] = acc;
     }
     // dW_th partial of this workgroup (fixed order over the 4 waves)
 #pragma unroll
