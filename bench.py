@@ -261,6 +261,7 @@ def main():
                        'per_gpu_batch': b, 'global_batch': b * world, 'tokens_per_sample': N, 'parallelism': f'dp{world}',
                        'loss': float(loss.detach())},
             'per_gpu_value': value / world,
+            'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
             'step_tflops_per_gpu': step_flops / (dt / args.steps) / 1e12,
             'step_mfma_frac': step_flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_* (bf16 MFMA NT GEMM; every amdnuwa_gemm_nt launch of the timed region, HIP events on the launch stream)',

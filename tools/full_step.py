@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""The WHOLE reference training step at BASELINE cfg 3 on one MI355X: NUWA.forward(text ids, raw video frames, return_loss=True)
+= text encoder (depth 6, reversible, rotary) + frozen VAE tokenizer (10 frames of 256x256 per sample) + 24-layer 3DNA decoder + CE,
+then backward.  Every stage runs through libamdnuwa.   python tools/full_step.py [--batch 16] [--steps 3]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nuwa_pytorch_amd as A  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--steps', type=int, default=3)
+    args = ap.parse_args()
+    dev = 'cuda'
+    torch.manual_seed(0)
+    vae = A.VQGanVAE(dim=64, image_size=256, num_layers=4, vq_codebook_size=8192, use_vgg_and_gan=False)
+    nuwa = A.NUWA(vae=vae, dim=512, max_video_frames=10, text_max_seq_len=256, text_enc_depth=6, enc_reversible=True, dec_depth=24,
+                  dec_heads=8, dec_dim_head=64, sparse_3dna_kernel_size=(5, 3, 3), sparse_3dna_dilation=(1, 2, 4),
+                  shift_video_tokens=True).to(dev).train()
+    b = args.batch
+    g = torch.Generator().manual_seed(1)
+    text = torch.randint(1, 49408, (b, 256), generator=g)
+    text[:, -32:] = 0
+    text = text.to(dev)
+    video = torch.rand(b, 10, 3, 256, 256, generator=g).to(dev)
+
+    def step():
+        nuwa.zero_grad(set_to_none=True)
+        loss = nuwa(text=text, video=video, return_loss=True, cond_dropout_prob=0.2)
+        loss.backward()
+        return loss
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(f'full NUWA step (text encoder + VAE tokenizer + decoder fwd/bwd), cfg 3, b={b}: {dt * 1e3:.1f} ms/step, '
+          f'{2560 * b / dt:.0f} video-tokens/s, loss {float(loss.detach()):.4f}, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB')
+
+
+if __name__ == '__main__':
+    main()
