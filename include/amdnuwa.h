@@ -235,6 +235,25 @@ int amdnuwa_vqattn_core(const float* qkv, const float* bias, const float* scale,
 int amdnuwa_chan_layernorm(const float* x, const float* g, const float* b, const float* resid, float* y, int N, int C, int HW,
                            float eps, amdnuwa_stream stream);
 
+/* ---- optimiser step of the trainer (row f2; reference train_nuwa.py:253-255 + optimizer.py:6-31) -------------------------------
+ * "multi-tensor apply": a DEVICE table of chunks (<= 65536 elements each is a good size), every chunk pointing into one fp32
+ * parameter / gradient / first- / second-moment tensor.  g == NULL marks a parameter without gradient this step (skipped). */
+typedef struct {
+    float* p; const float* g; float* m; float* v;
+    long long n;
+    float weight_decay;     /* 0 for the ndim < 2 parameters (optimizer.py:6-9) */
+    float bias_correction1, bias_correction2;   /* 1 - beta^t with t = number of updates THIS parameter has received (torch keeps
+                                                    the step count per parameter: one skipped for lack of a gradient lags behind) */
+} amdnuwa_adamw_chunk;
+/* out2[0] = global L2 norm of all gradients, out2[1] = min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0); fixed-order
+ * reduction; partials: nchunks floats of scratch.  Everything stays on the device. */
+int amdnuwa_grad_norm(const amdnuwa_adamw_chunk* chunks, int nchunks, float max_norm, float* partials, float* out2,
+                      amdnuwa_stream stream);
+int amdnuwa_scale_grads(const amdnuwa_adamw_chunk* chunks, int nchunks, const float* coef, amdnuwa_stream stream);
+/* torch.optim.AdamW semantics (decoupled decay); gradients are multiplied by *clip_coef (device scalar, may be NULL) on the fly */
+int amdnuwa_adamw_step(const amdnuwa_adamw_chunk* chunks, int nchunks, float lr, float beta1, float beta2, float eps,
+                       const float* clip_coef, amdnuwa_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

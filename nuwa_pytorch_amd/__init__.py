@@ -8,6 +8,7 @@ from .nuwa_pytorch import (NUWA, NUWASketch, NUWAVideoAudio, Sparse3DNA, CrossMo
                            ReversibleTransformer)
 from .vqgan_vae import VQGanVAE
 from .kernels import set_precision, get_precision
+from .optimizer import get_optimizer
 
 __all__ = ['NUWA', 'NUWASketch', 'NUWAVideoAudio', 'Sparse3DNA', 'CrossModalityCrossAttention', 'VQGanVAE',
-           'set_precision', 'get_precision']
+           'set_precision', 'get_precision', 'get_optimizer']

@@ -89,6 +89,9 @@ SIGNATURES = {
     'amdnuwa_conv2d_fwd': (I, [CD, P, P, P, P, P]),
     'amdnuwa_groupnorm_fwd': (I, [P, P, P, P, I, I, I, I, F, I, P]),
     'amdnuwa_vq_argmax': (I, [P, P, P, P, LL, I, I, P]),
+    'amdnuwa_grad_norm': (I, [P, I, F, P, P, P]),
+    'amdnuwa_scale_grads': (I, [P, I, P, P]),
+    'amdnuwa_adamw_step': (I, [P, I, F, F, F, F, P, P]),
     'amdnuwa_rows_l2norm': (I, [P, I, I, I, I, P]),
     'amdnuwa_vqattn_core': (I, [P, P, P, P, I, I, I, I, P]),
     'amdnuwa_chan_layernorm': (I, [P, P, P, P, P, I, I, I, F, P]),

@@ -29,11 +29,13 @@ class WeightCache:
     """bf16 (hi[/lo]) operand copies of fp32 master weights; rebuilt when a parameter changes
     (optimizer step bumps `_version`) or the precision mode changes."""
 
+    EPOCH = 0          # bumped by optimisers that update parameters behind autograd's back (FusedAdamW)
+
     def __init__(self):
         self._store = {}
 
     def get(self, key, params, builder):
-        ver = tuple((p.data_ptr(), p._version) for p in params) + (K.get_precision(),)
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (K.get_precision(), WeightCache.EPOCH)
         ent = self._store.get(key)
         if ent is None or ent[0] != ver:
             with torch.no_grad():

@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--optimizer', action='store_true', help='add the fused clip(0.5) + AdamW step of the trainer (row f2)')
     args = ap.parse_args()
     dev = 'cuda'
     torch.manual_seed(0)
@@ -24,6 +25,10 @@ def main():
     nuwa = A.NUWA(vae=vae, dim=512, max_video_frames=10, text_max_seq_len=256, text_enc_depth=6, enc_reversible=True, dec_depth=24,
                   dec_heads=8, dec_dim_head=64, sparse_3dna_kernel_size=(5, 3, 3), sparse_3dna_dilation=(1, 2, 4),
                   shift_video_tokens=True).to(dev).train()
+    opt = None
+    if args.optimizer:
+        from nuwa_pytorch_amd.optimizer import get_optimizer
+        opt = get_optimizer(nuwa.parameters(), lr=3e-4, wd=0.01, filter_by_requires_grad=True)
     b = args.batch
     g = torch.Generator().manual_seed(1)
     text = torch.randint(1, 49408, (b, 256), generator=g)
@@ -35,6 +40,8 @@ def main():
         nuwa.zero_grad(set_to_none=True)
         loss = nuwa(text=text, video=video, return_loss=True, cond_dropout_prob=0.2)
         loss.backward()
+        if opt is not None:
+            opt.step(max_grad_norm=0.5)
         return loss
     step()
     torch.cuda.synchronize()
@@ -43,7 +50,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(f'full NUWA step (text encoder + VAE tokenizer + decoder fwd/bwd), cfg 3, b={b}: {dt * 1e3:.1f} ms/step, '
+    print(f'full NUWA step (text encoder + VAE tokenizer + decoder fwd/bwd{" + clip + AdamW" if opt else ""}), cfg 3, b={b}: {dt * 1e3:.1f} ms/step, '
           f'{2560 * b / dt:.0f} video-tokens/s, loss {float(loss.detach()):.4f}, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB')
 
 
