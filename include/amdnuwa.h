@@ -235,6 +235,11 @@ int amdnuwa_vqattn_core(const float* qkv, const float* bias, const float* scale,
 int amdnuwa_chan_layernorm(const float* x, const float* g, const float* b, const float* resid, float* y, int N, int C, int HW,
                            float eps, amdnuwa_stream stream);
 
+/* VQGanVAE.decode pieces (vqgan_vae.py:437-441, GLUResBlock 212-226): nn.GLU over the channel axis of [N][2C][HW] and the
+ * x2 bilinear nn.Upsample (align_corners=False) of an NCHW tensor; the rest of the decoder reuses conv2d / groupnorm / vqattn */
+int amdnuwa_glu_chan(const float* x, float* y, int N, int C, int HW, amdnuwa_stream stream);
+int amdnuwa_upsample_bilinear2x(const float* x, float* y, int N, int C, int H, int W, amdnuwa_stream stream);
+
 /* ---- optimiser step of the trainer (row f2; reference train_nuwa.py:253-255 + optimizer.py:6-31) -------------------------------
  * "multi-tensor apply": a DEVICE table of chunks (<= 65536 elements each is a good size), every chunk pointing into one fp32
  * parameter / gradient / first- / second-moment tensor.  g == NULL marks a parameter without gradient this step (skipped). */

@@ -325,7 +325,53 @@ __global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __rest
     }
 }
 
+// ---- decoder-only pieces (VQGanVAE.decode, vq.py:437-441; GLUResBlock vq.py:212-226) ---------------------------------
+// nn.GLU(dim=1) on [N][2C][HW]: y[n][c] = x[n][c] * sigmoid(x[n][C + c])
+__global__ __launch_bounds__(256) void glu_chan_kernel(const float* __restrict__ x, float* __restrict__ y, long long total, int C, int HW) {
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const long long n = t / ((long long)C * HW), r = t % ((long long)C * HW);
+        const float a = x[n * 2 * C * HW + r], g = x[n * 2 * C * HW + (long long)C * HW + r];
+        y[t] = a / (1.f + expf(-g));
+    }
+}
+
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) on NCHW: src = (dst + 0.5) / 2 - 0.5, clamped at 0
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long total = planes * Ho * Wo;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const long long pl = t / ((long long)Ho * Wo);
+        const int oy = (int)((t / Wo) % Ho), ox = (int)(t % Wo);
+        const float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx, y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = sy - y0, lx = sx - x0;
+        const float* p = x + pl * H * W;
+        const float top = p[y0 * W + x0] * (1.f - lx) + p[y0 * W + x1] * lx, bot = p[y1 * W + x0] * (1.f - lx) + p[y1 * W + x1] * lx;
+        y[t] = top * (1.f - ly) + bot * ly;
+    }
+}
+
 }  // namespace
+
+extern "C" int amdnuwa_glu_chan(const float* x, float* y, int N, int C, int HW, hipStream_t stream) {
+    if (!x || !y || C <= 0 || HW <= 0) return AMDNUWA_ERR_ARG;
+    const long long total = (long long)N * C * HW;
+    if (total <= 0) return AMDNUWA_OK;
+    const long long nb = (total + 255) / 256;
+    hipLaunchKernelGGL(glu_chan_kernel, dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, stream, x, y, total, C, HW);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_upsample_bilinear2x(const float* x, float* y, int N, int C, int H, int W, hipStream_t stream) {
+    if (!x || !y || H <= 0 || W <= 0) return AMDNUWA_ERR_ARG;
+    const long long planes = (long long)N * C, total = planes * 4 * H * W;
+    if (total <= 0) return AMDNUWA_OK;
+    const long long nb = (total + 255) / 256;
+    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, stream, x, y, planes, H, W);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
 
 extern "C" int amdnuwa_rows_l2norm(float* x, int groups, int rows_per_group, int group_stride_rows, int len, hipStream_t stream) {
     if (!x || len <= 0 || rows_per_group <= 0 || group_stride_rows < rows_per_group) return AMDNUWA_ERR_ARG;

@@ -551,3 +551,23 @@ def vqgan_attention(x, qkv_w, out_w, out_b, bias, scale, ln_g, ln_b, heads, eps)
     check(L.amdnuwa_chan_layernorm(_p(o), _p(_f32c(ln_g).reshape(-1)), _p(_f32c(ln_b).reshape(-1)), _p(x), _p(y), N, o.shape[1], P_,
                                    float(eps), _stream()), 'amdnuwa_chan_layernorm')
     return y
+
+
+def glu_chan(x):
+    """nn.GLU(dim=1) on NCHW fp32"""
+    L = _lib.lib()
+    x = _f32c(x)
+    N, C2, H, W = x.shape
+    y = torch.empty((N, C2 // 2, H, W), dtype=torch.float32, device=x.device)
+    check(L.amdnuwa_glu_chan(_p(x), _p(y), N, C2 // 2, H * W, _stream()), 'amdnuwa_glu_chan')
+    return y
+
+
+def upsample_bilinear2x(x):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) on NCHW fp32"""
+    L = _lib.lib()
+    x = _f32c(x)
+    N, Cc, H, W = x.shape
+    y = torch.empty((N, Cc, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    check(L.amdnuwa_upsample_bilinear2x(_p(x), _p(y), N, Cc, H, W, _stream()), 'amdnuwa_upsample_bilinear2x')
+    return y

@@ -286,6 +286,12 @@ class VQGanVAE(nn.Module):
             fmap = dec(fmap)
         return fmap
 
+    def _hip_decode(self, fmap):
+        fmap = fmap.float()
+        for dec in self.decoders:
+            fmap = self._hip_module(dec, fmap)
+        return fmap
+
     @torch.no_grad()
     @eval_decorator
     def codebook_indices_to_video(self, indices):
@@ -293,7 +299,7 @@ class VQGanVAE(nn.Module):
         codes = self.codebook[indices]
         fs = self.fmap_size
         codes = codes.reshape(b, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
-        video = self.decode(codes)
+        video = self._hip_decode(codes) if codes.is_cuda else self.decode(codes)     # sampling path (np.py:1912): libamdnuwa on device
         return video.reshape(b, -1, *video.shape[1:])
 
     def _hip_module(self, m, x):
@@ -320,7 +326,15 @@ class VQGanVAE(nn.Module):
             bias = m.cpb(torch.zeros(1, m.heads, P_, P_, device=x.device))[0]
             return K.vqgan_attention(x, m.to_qkv.weight, m.to_out.weight, m.to_out.bias, bias, m.scale, m.post_norm.g, m.post_norm.b,
                                      m.heads, m.post_norm.eps)
-        raise NotImplementedError(f'no libamdnuwa path for encoder stage {type(m).__name__}')
+        if isinstance(m, GLUResBlock):                     # decoder (vq.py:212-226)
+            c1, _, g1, c2, _, g2, c3 = m.net
+            h = K.groupnorm_fwd(K.glu_chan(K.conv2d_fwd(x, c1.weight, c1.bias, 1, 1)), g1.weight, g1.bias, g1.num_groups, g1.eps)
+            h = K.groupnorm_fwd(K.glu_chan(K.conv2d_fwd(h, c2.weight, c2.bias, 1, 1)), g2.weight, g2.bias, g2.num_groups, g2.eps)
+            return K.conv2d_fwd(h, c3.weight, c3.bias, 1, 0) + x
+        if isinstance(m, nn.Sequential) and len(m) == 3 and isinstance(m[0], nn.Upsample) and isinstance(m[1], nn.Conv2d):
+            c = m[1]                                       # decoder stage: x2 bilinear upsample, conv 3x3, LeakyReLU
+            return K.conv2d_fwd(K.upsample_bilinear2x(x), c.weight, c.bias, c.stride[0], c.padding[0], leaky=True)
+        raise NotImplementedError(f'no libamdnuwa path for VAE stage {type(m).__name__}')
 
     def _hip_encode_indices(self, images):
         from . import kernels as K

@@ -118,3 +118,22 @@ def test_cfg3_vae_tokenizer_matches_oracle():
     sure = gap > 1e-5
     assert float(sure.float().mean()) > 0.98
     assert torch.equal(idx[sure], idx_ref[sure])
+
+
+def test_g7_vae_decoder_on_hip(K):
+    """VQGanVAE.decode (vq.py:437-441) through libamdnuwa: GLUResBlock, VQGanAttention, x2 bilinear upsample + conv stages,
+    final 1x1 conv, against the reference's reconstruction in fixture g7 (decode of the quantised feature map)"""
+    import nuwa_pytorch_amd as A
+    Ar, P, _ = load('g7_vae')
+    vae = A.VQGanVAE(dim=32, image_size=32, num_layers=2, vq_codebook_size=64, vq_codebook_dim=16, use_vgg_and_gan=False,
+                     attn_dim_head=16, attn_heads=4)
+    vae.load_state_dict(P)
+    vae = vae.to(DEV).eval()
+    with torch.no_grad():
+        ind = Ar['indices'].to(DEV)                                      # [3, 8, 8]
+        quant = vae.vq.project_out(vae.vq.embed[ind]).permute(0, 3, 1, 2).contiguous()
+        rec = vae._hip_decode(quant)
+    report('g7.recon', rec, Ar['recon'], 5e-5)
+    x = torch.randn(2, 6, 5, 7, device=DEV)
+    report('upsample2x', K.upsample_bilinear2x(x), F.interpolate(x.cpu(), scale_factor=2, mode='bilinear', align_corners=False), 1e-6)
+    report('glu', K.glu_chan(x), F.glu(x.cpu(), dim=1), 1e-6)
