@@ -89,7 +89,9 @@ int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspac
 #define AMDNUWA_LN_DY_BF16 32
 int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const float* b, uint16_t* out_hi,
                    uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R, int D,
-                   int mode, int stable, float eps, amdnuwa_stream stream);
+                   int mode, int stable, float eps, int shift_ntok, int shift_fmap, amdnuwa_stream stream);
+/* shift_ntok > 0 (mode 0): the bf16 output is written THROUGH the forward token shift of ShiftVideoTokens (np.py:210-253), i.e.
+ * out = shift(LN(x)): rows are tokens of samples of shift_ntok rows (<bos> first), shift_fmap = tokens per grid row / column */
 size_t amdnuwa_ln_bwd_workspace_bytes(long long R, int D);
 /* dy fp32; shift_ntok > 0 reads dy through the inverse token shift.  Exactly one of dx_hi (bf16
  * hi[/lo] output) / dx_acc (fp32) is non-NULL; dx_acc = (dres ? dres : dx_acc) + dx.  dw, db, dsum

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
                                                      float* __restrict__ out_f32, float* __restrict__ mean_o,
                                                      float* __restrict__ rstd_o, float* __restrict__ inv_amax_o,
-                                                     long long R, int D, float eps) {
+                                                     long long R, int D, float eps, int shift_ntok, int shift_fmap) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= R) return;
@@ -110,7 +110,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const float y2 = (xv.v[it].z - mean) * rstd * wv.z + bv.z;
         const float y3 = (xv.v[it].w - mean) * rstd * wv.w + bv.w;
         if (MODE == 0) {
-            store_bf16x4(out_hi + row * D, out_lo ? out_lo + row * D : nullptr, e, y0, y1, y2, y3);
+            // optional FORWARD token shift folded into the store (ShiftVideoTokens, np.py:210-253): the first quarter of the
+            // channels of token (f, y, w) belongs to token (f, y+1, w), the second to (f, y, w+1); a row writes zeros into its own
+            // quarter when it has no source (y == 0 / w == 0).  The consumers (NT and TN GEMMs) then read a plain matrix.
+            long long drow = row;
+            bool keep = true, zero_own = false;
+            if (shift_ntok > 0) {
+                const int i = (int)(row % shift_ntok);
+                const int qd = e / (D >> 2);
+                if (i > 0 && qd < 2) {
+                    const int p = i - 1, wq = p % shift_fmap, yq = (p / shift_fmap) % shift_fmap;
+                    if (qd == 0) { keep = yq + 1 < shift_fmap && i + shift_fmap < shift_ntok; drow = row + shift_fmap; zero_own = yq == 0; }
+                    else         { keep = wq + 1 < shift_fmap && i + 1 < shift_ntok;          drow = row + 1;          zero_own = wq == 0; }
+                }
+            }
+            if (keep) store_bf16x4(out_hi + drow * D, out_lo ? out_lo + drow * D : nullptr, e, y0, y1, y2, y3);
+            if (zero_own) store_bf16x4(out_hi + row * D, out_lo ? out_lo + row * D : nullptr, e, 0.f, 0.f, 0.f, 0.f);
         } else {
             const float4 rv = *reinterpret_cast<const float4*>(resid + row * D + e);
             *reinterpret_cast<float4*>(out_f32 + row * D + e) = make_float4(rv.x + y0, rv.y + y1, rv.z + y2, rv.w + y3);
@@ -598,17 +613,18 @@ inline int grid_for(size_t work, int per_block = 256, int cap = 4096) {
 
 extern "C" int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const float* b, uint16_t* out_hi,
                               uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R,
-                              int D, int mode, int stable, float eps, hipStream_t stream) {
+                              int D, int mode, int stable, float eps, int shift_ntok, int shift_fmap, hipStream_t stream) {
     const bool xbf = (mode & AMDNUWA_LN_X_BF16) != 0;        // x points at bf16 values
     mode &= 1;
+    if (shift_ntok > 0 && (mode != 0 || shift_fmap <= 0 || D % 16)) return AMDNUWA_ERR_ARG;
     if (!x || !w || !b || !mean || !rstd || D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
     if (mode == 0 && !out_hi) return AMDNUWA_ERR_ARG;
     if (mode == 1 && (!out_f32 || !resid || stable)) return AMDNUWA_ERR_ARG;
     if (stable && !inv_amax) return AMDNUWA_ERR_ARG;
     if (R <= 0) return AMDNUWA_OK;
     dim3 grid((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
-#define LNF(MO, ST, NV_) do { if (xbf) hipLaunchKernelGGL((ln_fwd_kernel<MO, ST, NV_, true>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps); \
-                              else hipLaunchKernelGGL((ln_fwd_kernel<MO, ST, NV_, false>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps); } while (0)
+#define LNF(MO, ST, NV_) do { if (xbf) hipLaunchKernelGGL((ln_fwd_kernel<MO, ST, NV_, true>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps, shift_ntok, shift_fmap); \
+                              else hipLaunchKernelGGL((ln_fwd_kernel<MO, ST, NV_, false>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps, shift_ntok, shift_fmap); } while (0)
 #define LNF_NV(MO, ST) do { if (D <= 256) LNF(MO, ST, 1); else if (D <= 512) LNF(MO, ST, 2); else LNF(MO, ST, 4); } while (0)
     if (mode == 0 && !stable) LNF_NV(0, false);
     else if (mode == 0) LNF_NV(0, true);

@@ -172,7 +172,7 @@ def _f32_or_bf(t):
     return _p(t), False, t.shape, t.device
 
 
-def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5):
+def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5, shift=None):
     """x fp32 [R, D] contiguous (or a hi-only BF pair).  resid None -> (BF out, mean, rstd, inv_amax);
     else (fp32 out = resid + LN(x), mean, rstd)"""
     L = _lib.lib()
@@ -183,12 +183,13 @@ def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5):
     if resid is None:
         out = empty_bf((R, D), dev)
         ia = torch.empty(R, dtype=torch.float32, device=dev) if stable else None
+        sn, sf = (int(shift[0]), int(shift[1])) if shift is not None else (0, 0)      # out = shift(LN(x)) (ShiftVideoTokens)
         check(L.amdnuwa_ln_fwd(xp, None, _p(w), _p(b), _p(out.hi), _p(out.lo), None, _p(mean), _p(rstd), _p(ia),
-                               R, D, 0 | flag, 1 if stable else 0, eps, _stream()), 'amdnuwa_ln_fwd')
+                               R, D, 0 | flag, 1 if stable else 0, eps, sn, sf, _stream()), 'amdnuwa_ln_fwd')
         return out, mean, rstd, ia
     out = torch.empty_like(resid)
     check(L.amdnuwa_ln_fwd(xp, _p(resid), _p(w), _p(b), None, None, _p(out), _p(mean), _p(rstd), None,
-                           R, D, 1 | flag, 0, eps, _stream()), 'amdnuwa_ln_fwd')
+                           R, D, 1 | flag, 0, eps, 0, 0, _stream()), 'amdnuwa_ln_fwd')
     return out, mean, rstd
 
 

@@ -324,7 +324,13 @@ class SandwichBlockFn(Function):
         meta = dict(meta)
         if meta['kind'] == 'xattn' and not meta.get('self_kv'):
             meta['ctx_bf'] = _ctx_to_bf(context)
-        h, m1, r1, _ = K.ln_fwd(x2, pre_w.detach(), pre_b.detach())
+        # the token shift is folded into the pre-LN's STORE: h = shift(LN(x)) is what the forward GEMM and the weight-gradient
+        # GEMM consume (plain loaders); only the pre-LN backward still reads its incoming gradient through the inverse shift
+        sh = meta.get('shift')
+        h, m1, r1, _ = K.ln_fwd(x2, pre_w.detach(), pre_b.detach(), shift=sh)
+        ctx.shift = sh
+        if sh is not None:
+            meta['shift'] = None
         y, saved = inner.fwd(h, p, meta)
         xo, m2, r2 = K.ln_fwd(y, post_w.detach(), post_b.detach(), resid=r2_)
         ctx.meta, ctx.inner_saved, ctx.p = meta, saved, p
@@ -352,7 +358,7 @@ class SandwichBlockFn(Function):
         if want_bias:
             grads[4] = dsum                      # to_out.bias grad = column sums of d(to_out output)
         dx, dpre_w, dpre_b, _ = K.ln_bwd(dh, x2, m1, r1, pre_w.detach(), dres=None if ctx.has_resid else g2,
-                                         shift=meta.get('shift'))
+                                         shift=ctx.shift)
         dcontext = None
         if ctx.has_ctx:
             T = meta['xgeom'].T

@@ -158,6 +158,21 @@ def test_layernorm_bf16_inputs(K, R, D):
         assert all(torch.equal(p, q) for p, q in zip(b0[:3], b1[:3]))
 
 
+@pytest.mark.parametrize('B,ntok,fmap,D', [(2, 23, 4, 32), (1, 49, 4, 64), (2, 2, 4, 32), (1, 2561, 16, 512)])
+def test_layernorm_fwd_with_folded_token_shift(K, O, B, ntok, fmap, D):
+    """pre-LN writing shift(LN(x)) directly (partial last frame, n = 2, full cfg-3 row count)"""
+    torch.manual_seed(6)
+    x = torch.randn(B, ntok, D) * 1.5 + 0.2
+    w, b = torch.randn(D), torch.randn(D)
+    ref = O.shift_video_tokens(F.layer_norm(x, (D,), w, b), fmap)
+    K.set_precision('bf16x3')
+    try:
+        out, m, r, _ = K.ln_fwd(x.reshape(B * ntok, D).to(DEV), w.to(DEV), b.to(DEV), shift=(ntok, fmap))
+        report(f'ln_fwd_shift[{B},{ntok},{fmap},{D}]', bf_value(out).reshape(B, ntok, D), ref, 2e-5)
+    finally:
+        K.set_precision('bf16')
+
+
 def test_layernorm_bwd_inverse_shift(K, O):
     torch.manual_seed(5)
     B, ntok, fmap, D = 2, 23, 4, 32
