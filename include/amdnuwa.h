@@ -92,6 +92,14 @@ int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const flo
                    int mode, int stable, float eps, int shift_ntok, int shift_fmap, amdnuwa_stream stream);
 /* shift_ntok > 0 (mode 0): the bf16 output is written THROUGH the forward token shift of ShiftVideoTokens (np.py:210-253), i.e.
  * out = shift(LN(x)): rows are tokens of samples of shift_ntok rows (<bos> first), shift_fmap = tokens per grid row / column */
+/* Post-norm + residual of one block fused with the pre-norm (+ token shift) of the NEXT block (Transformer.forward runs the
+ * blocks back to back, np.py:1175-1180): out_f32 = resid + LN(y; w, b) with (mean, rstd) saved as mode 1 does, then
+ * h = shift(LN(out_f32; next_w, next_b)) in bf16 hi[/lo] with (next_mean, next_rstd) saved as mode 0 does.
+ * flags: AMDNUWA_LN_X_BF16 when y points at bf16 values. */
+int amdnuwa_ln_post_pre_fwd(const float* y, const float* resid, const float* w, const float* b, float* out_f32,
+                            float* mean, float* rstd, const float* next_w, const float* next_b, uint16_t* h_hi,
+                            uint16_t* h_lo, float* next_mean, float* next_rstd, long long R, int D, int flags, float eps,
+                            int shift_ntok, int shift_fmap, amdnuwa_stream stream);
 size_t amdnuwa_ln_bwd_workspace_bytes(long long R, int D);
 /* dy fp32; shift_ntok > 0 reads dy through the inverse token shift.  Exactly one of dx_hi (bf16
  * hi[/lo] output) / dx_acc (fp32) is non-NULL; dx_acc = (dres ? dres : dx_acc) + dx.  dw, db, dsum

@@ -6,7 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libamdnuwa.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 P = C.c_void_p
 I = C.c_int
@@ -60,6 +60,7 @@ SIGNATURES = {
     'amdnuwa_gemm_tn_workspace_bytes': (SZ, [GD]),
     'amdnuwa_gemm_tn': (I, [GD, P, SZ, P]),
     'amdnuwa_ln_fwd': (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, I, I, P]),
+    'amdnuwa_ln_post_pre_fwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, F, I, I, P]),
     'amdnuwa_ln_bwd_workspace_bytes': (SZ, [LL, I]),
     'amdnuwa_ln_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, I, I, P, SZ, P]),
     'amdnuwa_colsum_workspace_bytes': (SZ, [LL, I]),

@@ -48,6 +48,44 @@ __device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, floa
     if (lo) *reinterpret_cast<uint2*>(lo + e) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
 }
 
+// Pre-norm store with the optional FORWARD token shift folded in (ShiftVideoTokens, np.py:210-253): the first quarter of the
+// channels of token (f, y, w) belongs to token (f, y+1, w), the second to (f, y, w+1); a row writes zeros into its own quarter
+// when it has no source (y == 0 / w == 0).  The consumers (NT and TN GEMMs) then read a plain matrix.
+__device__ __forceinline__ void store_ln_shifted(bf16_t* out_hi, bf16_t* out_lo, long long row, int e, int D, int shift_ntok,
+                                                 int shift_fmap, float y0, float y1, float y2, float y3) {
+    long long drow = row;
+    bool keep = true, zero_own = false;
+    if (shift_ntok > 0) {
+        const int i = (int)(row % shift_ntok);
+        const int qd = e / (D >> 2);
+        if (i > 0 && qd < 2) {
+            const int p = i - 1, wq = p % shift_fmap, yq = (p / shift_fmap) % shift_fmap;
+            if (qd == 0) { keep = yq + 1 < shift_fmap && i + shift_fmap < shift_ntok; drow = row + shift_fmap; zero_own = yq == 0; }
+            else         { keep = wq + 1 < shift_fmap && i + 1 < shift_ntok;          drow = row + 1;          zero_own = wq == 0; }
+        }
+    }
+    if (keep) store_bf16x4(out_hi + drow * D, out_lo ? out_lo + drow * D : nullptr, e, y0, y1, y2, y3);
+    if (zero_own) store_bf16x4(out_hi + row * D, out_lo ? out_lo + row * D : nullptr, e, 0.f, 0.f, 0.f, 0.f);
+}
+
+template <int NV>
+__device__ __forceinline__ void row_mean_rstd(const RowValsT<NV>& xv, int D, int lane, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NV; ++it) s += (xv.v[it].x + xv.v[it].y) + (xv.v[it].z + xv.v[it].w);
+    mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        const int e = (lane + it * 64) * 4;
+        if (e < D) {
+            const float a = xv.v[it].x - mean, b_ = xv.v[it].y - mean, c = xv.v[it].z - mean, d = xv.v[it].w - mean;
+            q += (a * a + b_ * b_) + (c * c + d * d);
+        }
+    }
+    rstd = rsqrtf(wave_sum(q) / D + eps);
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm forward.
 //   MODE 0 (pre-norm)        : out_bf16[hi,lo] = LN(x) * w + b
@@ -81,20 +119,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             else xv.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    float s = 0.f;
-#pragma unroll
-    for (int it = 0; it < NV; ++it) s += (xv.v[it].x + xv.v[it].y) + (xv.v[it].z + xv.v[it].w);
-    const float mean = wave_sum(s) / D;
-    float q = 0.f;
-#pragma unroll
-    for (int it = 0; it < NV; ++it) {
-        const int e = (lane + it * 64) * 4;
-        if (e < D) {
-            const float a = xv.v[it].x - mean, b_ = xv.v[it].y - mean, c = xv.v[it].z - mean, d = xv.v[it].w - mean;
-            q += (a * a + b_ * b_) + (c * c + d * d);
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    float mean, rstd;
+    row_mean_rstd<NV>(xv, D, lane, eps, mean, rstd);
     if (lane == 0) {
         mean_o[row] = mean; rstd_o[row] = rstd;
         if (STABLE) inv_amax_o[row] = inv_amax;
@@ -110,26 +136,59 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const float y2 = (xv.v[it].z - mean) * rstd * wv.z + bv.z;
         const float y3 = (xv.v[it].w - mean) * rstd * wv.w + bv.w;
         if (MODE == 0) {
-            // optional FORWARD token shift folded into the store (ShiftVideoTokens, np.py:210-253): the first quarter of the
-            // channels of token (f, y, w) belongs to token (f, y+1, w), the second to (f, y, w+1); a row writes zeros into its own
-            // quarter when it has no source (y == 0 / w == 0).  The consumers (NT and TN GEMMs) then read a plain matrix.
-            long long drow = row;
-            bool keep = true, zero_own = false;
-            if (shift_ntok > 0) {
-                const int i = (int)(row % shift_ntok);
-                const int qd = e / (D >> 2);
-                if (i > 0 && qd < 2) {
-                    const int p = i - 1, wq = p % shift_fmap, yq = (p / shift_fmap) % shift_fmap;
-                    if (qd == 0) { keep = yq + 1 < shift_fmap && i + shift_fmap < shift_ntok; drow = row + shift_fmap; zero_own = yq == 0; }
-                    else         { keep = wq + 1 < shift_fmap && i + 1 < shift_ntok;          drow = row + 1;          zero_own = wq == 0; }
-                }
-            }
-            if (keep) store_bf16x4(out_hi + drow * D, out_lo ? out_lo + drow * D : nullptr, e, y0, y1, y2, y3);
-            if (zero_own) store_bf16x4(out_hi + row * D, out_lo ? out_lo + row * D : nullptr, e, 0.f, 0.f, 0.f, 0.f);
+            store_ln_shifted(out_hi, out_lo, row, e, D, shift_ntok, shift_fmap, y0, y1, y2, y3);
         } else {
             const float4 rv = *reinterpret_cast<const float4*>(resid + row * D + e);
             *reinterpret_cast<float4*>(out_f32 + row * D + e) = make_float4(rv.x + y0, rv.y + y1, rv.z + y2, rv.w + y3);
         }
+    }
+}
+
+// Post-norm + residual of block k fused with the pre-norm (and token shift) of block k+1: the new residual stream row is
+// still in registers when its second LayerNorm is taken, so the next block's pre-norm kernel (one more full read of the stream)
+// disappears.  Both normalisations are computed exactly as the separate kernels compute them.
+template <int NV, bool XBF>
+__global__ __launch_bounds__(256) void ln_post_pre_kernel(const float* __restrict__ y, const float* __restrict__ resid,
+                                                          const float* __restrict__ w, const float* __restrict__ b,
+                                                          float* __restrict__ out_f32, float* __restrict__ mean_o,
+                                                          float* __restrict__ rstd_o, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, bf16_t* __restrict__ h_hi,
+                                                          bf16_t* __restrict__ h_lo, float* __restrict__ mean2_o,
+                                                          float* __restrict__ rstd2_o, long long R, int D, float eps,
+                                                          int shift_ntok, int shift_fmap) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= R) return;
+    RowValsT<NV> xv;
+    row_load_t<XBF>(y, (size_t)row * D, D, lane, xv, 0.f);
+    float mean, rstd;
+    row_mean_rstd<NV>(xv, D, lane, eps, mean, rstd);
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        const int e = (lane + it * 64) * 4;
+        if (e >= D) { xv.v[it] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+        const float4 wv = *reinterpret_cast<const float4*>(w + e);
+        const float4 bv = *reinterpret_cast<const float4*>(b + e);
+        const float4 rv = *reinterpret_cast<const float4*>(resid + row * D + e);
+        const float y0 = (xv.v[it].x - mean) * rstd * wv.x + bv.x;
+        const float y1 = (xv.v[it].y - mean) * rstd * wv.y + bv.y;
+        const float y2 = (xv.v[it].z - mean) * rstd * wv.z + bv.z;
+        const float y3 = (xv.v[it].w - mean) * rstd * wv.w + bv.w;
+        xv.v[it] = make_float4(rv.x + y0, rv.y + y1, rv.z + y2, rv.w + y3);
+        *reinterpret_cast<float4*>(out_f32 + row * D + e) = xv.v[it];
+    }
+    float mean2, rstd2;
+    row_mean_rstd<NV>(xv, D, lane, eps, mean2, rstd2);
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; mean2_o[row] = mean2; rstd2_o[row] = rstd2; }
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        const int e = (lane + it * 64) * 4;
+        if (e >= D) continue;
+        const float4 wv = *reinterpret_cast<const float4*>(w2 + e);
+        const float4 bv = *reinterpret_cast<const float4*>(b2 + e);
+        store_ln_shifted(h_hi, h_lo, row, e, D, shift_ntok, shift_fmap,
+                         (xv.v[it].x - mean2) * rstd2 * wv.x + bv.x, (xv.v[it].y - mean2) * rstd2 * wv.y + bv.y,
+                         (xv.v[it].z - mean2) * rstd2 * wv.z + bv.z, (xv.v[it].w - mean2) * rstd2 * wv.w + bv.w);
     }
 }
 
@@ -631,6 +690,25 @@ extern "C" int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w
     else LNF_NV(1, false);
 #undef LNF_NV
 #undef LNF
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_ln_post_pre_fwd(const float* y, const float* resid, const float* w, const float* b, float* out_f32,
+                                       float* mean, float* rstd, const float* next_w, const float* next_b, uint16_t* h_hi,
+                                       uint16_t* h_lo, float* next_mean, float* next_rstd, long long R, int D, int flags,
+                                       float eps, int shift_ntok, int shift_fmap, hipStream_t stream) {
+    const bool xbf = (flags & AMDNUWA_LN_X_BF16) != 0;
+    if (!y || !resid || !w || !b || !out_f32 || !mean || !rstd || !next_w || !next_b || !h_hi || !next_mean || !next_rstd)
+        return AMDNUWA_ERR_ARG;
+    if (D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
+    if (shift_ntok > 0 && (shift_fmap <= 0 || D % 16)) return AMDNUWA_ERR_ARG;
+    if (R <= 0) return AMDNUWA_OK;
+    dim3 grid((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+#define LPP(NV_) do { if (xbf) hipLaunchKernelGGL((ln_post_pre_kernel<NV_, true>), grid, block, 0, stream, y, resid, w, b, out_f32, mean, rstd, next_w, next_b, h_hi, h_lo, next_mean, next_rstd, R, D, eps, shift_ntok, shift_fmap); \
+                      else hipLaunchKernelGGL((ln_post_pre_kernel<NV_, false>), grid, block, 0, stream, y, resid, w, b, out_f32, mean, rstd, next_w, next_b, h_hi, h_lo, next_mean, next_rstd, R, D, eps, shift_ntok, shift_fmap); } while (0)
+    if (D <= 256) LPP(1); else if (D <= 512) LPP(2); else LPP(4);
+#undef LPP
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

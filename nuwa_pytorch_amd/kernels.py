@@ -193,6 +193,21 @@ def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5, shift=None):
     return out, mean, rstd
 
 
+def ln_post_pre_fwd(y, resid, w, b, next_w, next_b, *, eps=1e-5, next_shift=None):
+    """post-norm + residual of one block and the pre-norm (+ token shift) of the next in one pass over the stream:
+    returns (out fp32 = resid + LN(y; w, b), mean, rstd, h BF = shift(LN(out; next_w, next_b)), next_mean, next_rstd)"""
+    L = _lib.lib()
+    yp, ybf, (R, D), dev = _f32_or_bf(y)
+    mean, rstd, mean2, rstd2 = (torch.empty(R, dtype=torch.float32, device=dev) for _ in range(4))
+    out = torch.empty_like(resid)
+    h = empty_bf((R, D), dev)
+    sn, sf = (int(next_shift[0]), int(next_shift[1])) if next_shift is not None else (0, 0)
+    check(L.amdnuwa_ln_post_pre_fwd(yp, _p(resid), _p(w), _p(b), _p(out), _p(mean), _p(rstd), _p(next_w), _p(next_b),
+                                    _p(h.hi), _p(h.lo), _p(mean2), _p(rstd2), R, D, LN_X_BF16 if ybf else 0, eps, sn, sf,
+                                    _stream()), 'amdnuwa_ln_post_pre_fwd')
+    return out, mean, rstd, h, mean2, rstd2
+
+
 def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift=None, want_dsum=False):
     """returns (dx, dw, db, dsum).  to_bf: dx as BF pair; else dx fp32 = dres + dx_ln (dres may be None -> zeros).
     dy / x: fp32 tensors, or (one of them) a hi-only BF pair."""

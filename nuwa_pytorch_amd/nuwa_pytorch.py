@@ -150,8 +150,10 @@ class SandwichNorm(nn.Module):
             return fn, shift                      # non-causal self-attention (text encoder): same kernels, keys = the query rows
         return None
 
-    def fused_residual(self, x, resid=None, context=None, context_mask=None, mask=None, rotary_pos_emb=None):
-        """x_out = (resid if given else x) + postnorm(fn(prenorm(x)))  as one autograd node"""
+    def fused_residual(self, x, resid=None, context=None, context_mask=None, mask=None, rotary_pos_emb=None, chain=None):
+        """x_out = (resid if given else x) + postnorm(fn(prenorm(x)))  as one autograd node.
+        chain = (handoff_in or None, next SandwichNorm or None, next block's fmap, handoff_out dict): lets this block's post-norm
+        kernel also emit the next block's pre-norm output (see ops.SandwichBlockFn)"""
         B, n, D = x.shape
         inner, fmap = self._inner(context, seq_len=n)
         meta = inner._meta(B, n, x.device, context=context, context_mask=context_mask, mask=mask, rotary_pos_emb=rotary_pos_emb)
@@ -159,6 +161,12 @@ class SandwichNorm(nn.Module):
             if D % 32:
                 raise RuntimeError('fused token shift needs dim % 32 == 0')
             meta['shift'] = (n, fmap)
+        if chain is not None:
+            hin, nxt, nxt_fmap, hout = chain
+            meta['handoff_in'] = hin
+            if nxt is not None and not (nxt_fmap is not None and D % 32):
+                meta['next_pre'] = (nxt.prenorm.weight, nxt.prenorm.bias, (n, nxt_fmap) if nxt_fmap is not None else None)
+                meta['handoff_out'] = hout
         return ops.SandwichBlockFn.apply(x, resid, context if isinstance(inner, Attention) else None, meta,
                                          self.prenorm.weight, self.prenorm.bias, self.postnorm.weight,
                                          self.postnorm.bias, *inner._params())
@@ -462,21 +470,30 @@ class Transformer(nn.Module):
             ]))
         self.norm = StableLayerNorm(dim)
 
+    chain_blocks = True          # fuse each block's post-norm with the next block's pre-norm (A/B switch for tests / probes)
+
     def forward_layers(self, x, mask=None, context=None, context_mask=None, rotary_pos_emb=None):
+        # the sub-blocks in execution order: (block, kwargs of the fused node, kwargs of the plain call, fusable (fn, fmap) or None)
+        n, cuda = x.shape[1], x.is_cuda
+        calls = []
         for attn, cross_attn, ff in self.layers:
-            if x.is_cuda and attn._inner(seq_len=x.shape[1]) is not None:
-                x = attn.fused_residual(x, mask=mask, rotary_pos_emb=rotary_pos_emb)
-            else:
-                x = attn(x, mask=mask, rotary_pos_emb=rotary_pos_emb) + x
+            calls.append((attn, dict(mask=mask, rotary_pos_emb=rotary_pos_emb), dict(mask=mask, rotary_pos_emb=rotary_pos_emb),
+                          attn._inner(seq_len=n) if cuda else None))
             if exists(cross_attn):
-                if cross_attn._inner(context) is not None and x.is_cuda:
-                    x = cross_attn.fused_residual(x, context=context, context_mask=context_mask)
-                else:
-                    x = cross_attn(x, context=context, mask=mask, context_mask=context_mask) + x
-            if ff._inner() is not None and x.is_cuda:
-                x = ff.fused_residual(x)
-            else:
-                x = ff(x) + x
+                calls.append((cross_attn, dict(context=context, context_mask=context_mask),
+                              dict(context=context, mask=mask, context_mask=context_mask),
+                              cross_attn._inner(context) if cuda else None))
+            calls.append((ff, {}, {}, ff._inner() if cuda else None))
+        handoff = None
+        for i, (block, fused_kw, plain_kw, inner) in enumerate(calls):
+            if inner is None:
+                x, handoff = block(x, **plain_kw) + x, None
+                continue
+            # chain consecutive fused blocks: this block's post-norm kernel also writes the next block's pre-norm output
+            nxt = calls[i + 1] if self.chain_blocks and i + 1 < len(calls) and calls[i + 1][3] is not None else None
+            out = {}
+            x = block.fused_residual(x, chain=(handoff, nxt[0] if nxt else None, nxt[3][1] if nxt else None, out), **fused_kw)
+            handoff = out if out else None
         return x
 
     def forward(self, x, mask=None, context=None, context_mask=None, rotary_pos_emb=None):

@@ -327,12 +327,24 @@ class SandwichBlockFn(Function):
         # the token shift is folded into the pre-LN's STORE: h = shift(LN(x)) is what the forward GEMM and the weight-gradient
         # GEMM consume (plain loaders); only the pre-LN backward still reads its incoming gradient through the inverse shift
         sh = meta.get('shift')
-        h, m1, r1, _ = K.ln_fwd(x2, pre_w.detach(), pre_b.detach(), shift=sh)
+        # block chaining (Transformer.forward_layers): the previous block's post-norm kernel may already have produced this
+        # block's h = shift(LN(x)) while the new stream row was in its registers, and this block does the same for the next
+        hin, nxt, hout = meta.pop('handoff_in', None), meta.pop('next_pre', None), meta.pop('handoff_out', None)
+        if hin is not None and hin.get('ptr') == x.data_ptr() and hin.get('ver') == x._version and hin.get('shift') == sh \
+                and resid is None and tuple(hin['h'].hi.shape) == (B * n, D):
+            h, m1, r1 = hin['h'], hin['m1'], hin['r1']
+        else:
+            h, m1, r1, _ = K.ln_fwd(x2, pre_w.detach(), pre_b.detach(), shift=sh)
         ctx.shift = sh
         if sh is not None:
             meta['shift'] = None
         y, saved = inner.fwd(h, p, meta)
-        xo, m2, r2 = K.ln_fwd(y, post_w.detach(), post_b.detach(), resid=r2_)
+        if nxt is not None and hout is not None:
+            xo, m2, r2, hn, mn, rn = K.ln_post_pre_fwd(y, r2_, post_w.detach(), post_b.detach(), nxt[0].detach(),
+                                                       nxt[1].detach(), next_shift=nxt[2])
+            hout.update(h=hn, m1=mn, r1=rn, ptr=xo.data_ptr(), ver=xo._version, shift=nxt[2])
+        else:
+            xo, m2, r2 = K.ln_fwd(y, post_w.detach(), post_b.detach(), resid=r2_)
         ctx.meta, ctx.inner_saved, ctx.p = meta, saved, p
         ctx.has_ctx = context is not None
         ctx.has_resid = resid is not None

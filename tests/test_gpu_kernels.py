@@ -173,6 +173,36 @@ def test_layernorm_fwd_with_folded_token_shift(K, O, B, ntok, fmap, D):
         K.set_precision('bf16')
 
 
+@pytest.mark.parametrize('B,ntok,fmap,D,ybf', [(2, 23, 4, 32, False), (3, 17, 4, 512, True), (2, 10, None, 1024, True),
+                                                  (1, 5, None, 64, False)])
+def test_layernorm_post_pre_chain(K, O, B, ntok, fmap, D, ybf):
+    """post-norm + residual of block k fused with the pre-norm (+ shift) of block k+1: identical, bit for bit, to the two
+    separate kernels, and equal to the oracle's two layer norms"""
+    torch.manual_seed(8)
+    R = B * ntok
+    y = (torch.randn(R, D) * 1.3).to(DEV)
+    resid = torch.randn(R, D).to(DEV)
+    w, b, w2, b2 = (torch.randn(D).to(DEV) for _ in range(4))
+    shift = (ntok, fmap) if fmap else None
+    yin = y
+    if ybf:
+        hi = K.empty_bf((R, D), DEV)
+        K.cast_pad(y, hi)
+        yin = K.BF(hi.hi, None)
+    xo_a, m_a, r_a = K.ln_fwd(yin, w, b, resid=resid)
+    h_a, m1_a, r1_a, _ = K.ln_fwd(xo_a, w2, b2, shift=shift)
+    xo, m, r, h, m1, r1 = K.ln_post_pre_fwd(yin, resid, w, b, w2, b2, next_shift=shift)
+    for name, u, v in (('xo', xo, xo_a), ('m', m, m_a), ('r', r, r_a), ('h', h.hi, h_a.hi), ('m1', m1, m1_a), ('r1', r1, r1_a)):
+        assert torch.equal(u, v), name
+    yv = bf_value(yin).cpu() if ybf else y.cpu()
+    x_ref = resid.cpu() + F.layer_norm(yv, (D,), w.cpu(), b.cpu())
+    h_ref = F.layer_norm(x_ref, (D,), w2.cpu(), b2.cpu()).reshape(B, ntok, D)
+    if fmap:
+        h_ref = O.shift_video_tokens(h_ref, fmap)
+    report(f'ln_post_pre.x[{R},{D}]', xo, x_ref, 2e-5)
+    report(f'ln_post_pre.h[{R},{D}]', bf_value(h).reshape(B, ntok, D), h_ref, 8e-3)
+
+
 def test_layernorm_bwd_inverse_shift(K, O):
     torch.manual_seed(5)
     B, ntok, fmap, D = 2, 23, 4, 32

@@ -229,6 +229,31 @@ def test_training_step_is_bitwise_reproducible(A):
             assert torch.equal(gr, runs[1][1][n]), n
 
 
+def test_block_chaining_is_bitwise_neutral(A):
+    """Transformer.forward_layers hands each block's pre-norm output over from the previous block's post-norm kernel; the loss
+    and every gradient must be bit-identical with the hand-over switched off"""
+    import nuwa_pytorch_amd.nuwa_pytorch as M
+    torch.manual_seed(4)
+    nuwa = _tiny_nuwa(A, False).to(DEV).train()
+    g = torch.Generator().manual_seed(10)
+    text = torch.randint(1, 50, (2, 8), generator=g).to(DEV)
+    vid = torch.randint(0, 64, (2, 3, 4, 4), generator=g).to(DEV)
+    runs = []
+    try:
+        for chain in (True, False):
+            M.Transformer.chain_blocks = chain
+            nuwa.zero_grad(set_to_none=True)
+            loss = nuwa(text=text, video=vid, return_loss=True, cond_dropout_prob=0.)
+            loss.backward()
+            runs.append((loss.detach().clone(), {n: p.grad.clone() for n, p in nuwa.named_parameters() if p.grad is not None}))
+    finally:
+        M.Transformer.chain_blocks = True
+    assert torch.equal(runs[0][0], runs[1][0])
+    for n, gr in runs[0][1].items():
+        if not n.startswith('text_'):
+            assert torch.equal(gr, runs[1][1][n]), n
+
+
 def test_reversible_stack_memory_is_depth_independent(A):
     """cfg-4 path (dec_reversible=True): with the recomputing backward the peak activation memory of a deep stack stays
     close to that of a shallow one, while the stored-activation mode grows with depth; both give the same gradients"""
