@@ -168,6 +168,24 @@ int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* q, const ui
                            amdnuwa_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Incremental decoding for NUWA.generate (np.py:1841-1915).  The reference recomputes the whole prefix for every sampled
+ * token; every decoder stage is causal, so row `pos` only needs cached rows < pos.  `pos` (row index inside each sample,
+ * 0 = <bos>) is read from DEVICE memory so one captured HIP graph serves every token.
+ * ---------------------------------------------------------------------------------------- */
+/* ShiftVideoTokens (np.py:210-253) for the single new row: h [B, D] (bf16 hi[/lo]) is stored as row pos of
+ * cache [B, cache_rows, D] and out [B, D] = shift(h)[pos] (first channel quarter from row pos - fmap, second from pos - 1,
+ * zero at the frame border; <bos> unchanged). */
+int amdnuwa_decode_shift(const uint16_t* h_hi, const uint16_t* h_lo, uint16_t* cache_hi, uint16_t* cache_lo,
+                         uint16_t* out_hi, uint16_t* out_lo, const int* pos, int B, int cache_rows, int D, int fmap,
+                         amdnuwa_stream stream);
+/* Sparse3DNA core (np.py:488-608) for the single new query: qkv [B, 3*inner] (q | k | v of row pos, q unscaled); its k | v
+ * join kv_cache [B, cache_rows, 2*inner]; o [B, inner] = attention over <bos> + the causal taps read from the cache
+ * (g->rel_bias as in amdnuwa_sparse3dna_fwd; g->ntok is ignored). */
+int amdnuwa_s3_decode(const amdnuwa_s3_geom* g, const uint16_t* qkv, const uint16_t* qkv_lo, uint16_t* kv_cache,
+                      uint16_t* kv_cache_lo, int cache_rows, const int* pos, const float* w_th, uint16_t* o,
+                      uint16_t* o_lo, amdnuwa_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * Text cross-attention core (Attention.forward with context, np.py:339-378): learned null key/value
  * at key slot 0, context key mask, fp32 softmax, talking heads, attn @ v.  q/o are token-row major
  * [B*n, ld]; keys/values are packed per (sample, head) by amdnuwa_xattn_pack.

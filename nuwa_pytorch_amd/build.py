@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libamdnuwa.so')
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'amdnuwa.h')
-SOURCES = ['api.hip', 'gemm.hip', 'elementwise.hip', 'sparse3dna.hip', 'xattn.hip', 'xattn2.hip', 'vae.hip', 'optim.hip']
+SOURCES = ['api.hip', 'gemm.hip', 'elementwise.hip', 'sparse3dna.hip', 'xattn.hip', 'xattn2.hip', 'vae.hip', 'optim.hip', 'decode.hip']
 ARCH = 'gfx950'
 
 

@@ -369,6 +369,27 @@ def sparse3dna_bwd(g, qkv, wth, dO, rel_bias=None):
     return dqkv, dwth, drel
 
 
+def decode_shift(h, cache, pos_dev, fmap):
+    """h BF [B, D] (row pos of every sample) -> stored in cache BF [B, rows, D]; returns shift(h)[pos] as BF [B, D]"""
+    L = _lib.lib()
+    B, D = h.hi.shape
+    out = empty_bf((B, D), h.hi.device, lo=h.lo is not None)
+    check(L.amdnuwa_decode_shift(_p(h.hi), _p(h.lo), _p(cache.hi), _p(cache.lo), _p(out.hi), _p(out.lo), _p(pos_dev), B,
+                                 cache.hi.shape[1], D, fmap, _stream()), 'amdnuwa_decode_shift')
+    return out
+
+
+def s3_decode(g, qkv, kv_cache, pos_dev, wth, rel_bias=None):
+    """qkv BF [B, 3*inner] of the new row; kv_cache BF [B, rows, 2*inner]; returns o BF [B, inner]"""
+    L = _lib.lib()
+    g.rel_bias, g.d_rel_bias = _p(rel_bias), None
+    inner = g.heads * g.dim_head
+    o = empty_bf((g.B, inner), qkv.hi.device, lo=qkv.lo is not None)
+    check(L.amdnuwa_s3_decode(C.byref(g), _p(qkv.hi), _p(qkv.lo), _p(kv_cache.hi), _p(kv_cache.lo), kv_cache.hi.shape[1],
+                              _p(pos_dev), _p(wth), _p(o.hi), _p(o.lo), _stream()), 'amdnuwa_s3_decode')
+    return o
+
+
 def x_geom(B, n, T, heads, dim_head):
     g = XGeom()
     g.B, g.n, g.T = B, n, T

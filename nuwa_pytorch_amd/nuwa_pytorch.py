@@ -786,6 +786,9 @@ class NUWA(nn.Module):
         self.to_logits = nn.Linear(dim, num_image_tokens, bias=False)
         self._cache = ops.WeightCache()
 
+    generate_use_cache = True        # key/value-cached generate() (decode.py); False = the reference's recompute loop
+    generate_use_graph = True        # replay each token's decoder work as one captured HIP graph
+
     # -- text side (adjacent, row f1) ------------------------------------------------------------
     def embed_text(self, text, mask=None):
         batch, seq_len, device = *text.shape, text.device
@@ -803,6 +806,8 @@ class NUWA(nn.Module):
     def embed_video(self, ids_in):
         """ids_in (b, m) -> (b, m+1, dim): <bos> + positional + token embedding (np.py:1940-1944)"""
         pe = self.video_pos_emb
+        if ids_in.shape[1] == 0:                                   # first step of generate(): the sequence is just <bos>
+            return self.video_bos[None, None].expand(ids_in.shape[0], 1, -1).contiguous()
         if ids_in.is_cuda and pe.num_axials == 3:
             frac = self.image_embedding.frac_gradient if self.training else 1.
             return ops.EmbedAssembleFn.apply(ids_in, self.image_embedding.embed.weight, pe.axial1, pe.axial2, pe.axial3,
@@ -827,7 +832,9 @@ class NUWA(nn.Module):
     @torch.no_grad()
     @eval_decorator
     def generate(self, *, text, filter_thres=0.9, temperature=1., decode_max_batchsize=10, cond_scale=2., num_frames=None):
-        """np.py:1841-1915 (token-by-token, whole prefix recomputed as in the reference; KV caching is row f3)."""
+        """np.py:1841-1915.  The reference recomputes the whole prefix (twice) per token; here each token costs one new decoder
+        row against per-layer key/value caches (decode.GuidedStepper, row f3) whenever the sequence fits the video shape and the
+        decoder is the plain Transformer -- otherwise the reference's recompute loop below runs on the same kernels."""
         batch, seq_len, device = *text.shape, text.device
         text_mask = text != 0
         text_embeds = self.embed_text(text, mask=text_mask)
@@ -836,7 +843,20 @@ class NUWA(nn.Module):
         num_frames = default(num_frames, self.max_video_frames)
         total_video_tokens = num_tokens_per_frame * num_frames
         max_video_tokens = num_tokens_per_frame * self.max_video_frames
-        for ind in range(total_video_tokens):
+        stepper = None
+        if self.generate_use_cache and text.is_cuda and isinstance(self.video_transformer, Transformer) and \
+                total_video_tokens <= max_video_tokens:
+            from .decode import GuidedStepper
+            stepper = GuidedStepper(self, text_embeds, text_mask, total_video_tokens, cond_scale, graph=self.generate_use_graph)
+            pos_table = self.video_pos_emb()
+            x_row = self.video_bos[None].expand(batch, -1)
+        for ind in range(total_video_tokens if stepper is not None else 0):
+            logits = stepper(x_row)
+            filtered_logits = top_k(logits, thres=filter_thres)
+            sample = gumbel_sample(filtered_logits, temperature=temperature, dim=-1)
+            video_indices = torch.cat((video_indices, sample[:, None]), dim=1)
+            x_row = self.image_embedding(sample) + pos_table[ind]
+        for ind in range(total_video_tokens if stepper is None else 0):
             video_indices_input = video_indices
             num_video_tokens = video_indices.shape[1]
             if num_video_tokens > max_video_tokens:
@@ -856,10 +876,11 @@ class NUWA(nn.Module):
             filtered_logits = top_k(logits, thres=filter_thres)
             sample = gumbel_sample(filtered_logits, temperature=temperature, dim=-1)
             video_indices = torch.cat((video_indices, sample[:, None]), dim=1)
-        codes = self.vae.codebook[video_indices]
+        codes = self.vae.codes_for_decoder(video_indices)
         fs = self.video_fmap_size
         codes = codes.reshape(batch, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
-        image_reconstructions = batch_process(codes, self.vae.decode, chunks=decode_max_batchsize)
+        decode = self.vae._hip_decode if codes.is_cuda else self.vae.decode
+        image_reconstructions = batch_process(codes.contiguous(), decode, chunks=decode_max_batchsize)
         return image_reconstructions.reshape(batch, -1, *image_reconstructions.shape[1:])
 
     def forward(self, *, text, video=None, return_loss=False, cond_dropout_prob=0.2):

@@ -281,6 +281,13 @@ class VQGanVAE(nn.Module):
             fmap = enc(fmap)
         return self.vq(fmap)
 
+    def codes_for_decoder(self, indices):
+        """codebook rows for `indices`, in the channel width the decoder takes.  The reference indexes the raw codebook
+        (vq.py:447, np.py:1910), which only fits the decoder when vq_codebook_dim equals the last encoder width; otherwise
+        (e.g. the default codebook_dim 256 under a 512-wide cfg-3 encoder) its decode raises.  Here the quantiser's own
+        project_out -- what VQGanVAE.forward feeds the decoder -- bridges the two; it is the identity when the widths agree."""
+        return self.vq.project_out(self.codebook[indices])
+
     def decode(self, fmap):
         for dec in self.decoders:
             fmap = dec(fmap)
@@ -296,7 +303,7 @@ class VQGanVAE(nn.Module):
     @eval_decorator
     def codebook_indices_to_video(self, indices):
         b = indices.shape[0]
-        codes = self.codebook[indices]
+        codes = self.codes_for_decoder(indices)
         fs = self.fmap_size
         codes = codes.reshape(b, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
         video = self._hip_decode(codes) if codes.is_cuda else self.decode(codes)     # sampling path (np.py:1912): libamdnuwa on device
