@@ -178,6 +178,14 @@ int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* q, const ui
 int amdnuwa_decode_shift(const uint16_t* h_hi, const uint16_t* h_lo, uint16_t* cache_hi, uint16_t* cache_lo,
                          uint16_t* out_hi, uint16_t* out_lo, const int* pos, int B, int cache_rows, int D, int fmap,
                          amdnuwa_stream stream);
+/* The norms around a block for the one new row per sample, in one launch (SandwichNorm, np.py:112-128, + the residual add of
+ * Transformer.forward, np.py:1175-1180):  x_new = resid + LN(y; w, b)  [skipped when resid == NULL: x_new = y, fp32];
+ * h = LN(x_new; next_w, next_b)  [skipped when next_w == NULL];  with cache_hi != NULL h also becomes row pos of
+ * cache [B, cache_rows, D] and out = shift(h)[pos] as amdnuwa_decode_shift does, else out = h.  y: fp32 or (y_is_bf16) bf16. */
+int amdnuwa_decode_ln(const void* y, int y_is_bf16, const float* resid, const float* w, const float* b, const float* next_w,
+                      const float* next_b, float* x_new, uint16_t* cache_hi, uint16_t* cache_lo, uint16_t* out_hi,
+                      uint16_t* out_lo, const int* pos, int B, int cache_rows, int D, int fmap, float eps,
+                      amdnuwa_stream stream);
 /* Sparse3DNA core (np.py:488-608) for the single new query: qkv [B, 3*inner] (q | k | v of row pos, q unscaled); its k | v
  * join kv_cache [B, cache_rows, 2*inner]; o [B, inner] = attention over <bos> + the causal taps read from the cache
  * (g->rel_bias as in amdnuwa_sparse3dna_fwd; g->ntok is ignored). */
@@ -235,6 +243,11 @@ size_t amdnuwa_xattn2_bwd_workspace_bytes(const amdnuwa_xattn_geom* g);
 int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
                        const amdnuwa_xattn_kv* packed, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm,
                        uint16_t* dq, int lddq, float* part_th, size_t part_bytes, amdnuwa_stream stream);
+/* Text cross-attention (Attention.forward with context, np.py:339-378) for ONE query row per sample (g->n must be 1):
+ * q [B, ldq] unscaled, keys / values as packed by amdnuwa_xattn_pack (Kp / Vp images and the valid map), o [B, ldo]. */
+int amdnuwa_xattn_decode(const amdnuwa_xattn_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq,
+                         const amdnuwa_xattn_kv* packed, const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo,
+                         amdnuwa_stream stream);
 
 /* ---- frozen VQGanVAE tokenizer (VQGanVAE.get_video_indices -> encode, reference vqgan_vae.py:431-435, 452-458), exact fp32 ---- */
 typedef struct {

@@ -78,7 +78,9 @@ SIGNATURES = {
     'amdnuwa_sparse3dna_bwd_workspace_bytes': (SZ, [SG]),
     'amdnuwa_sparse3dna_bwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P, P, P, P, P, P, I, P, I, P, SZ, P]),
     'amdnuwa_decode_shift': (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    'amdnuwa_decode_ln': (I, [P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P]),
     'amdnuwa_s3_decode': (I, [SG, P, P, P, P, I, P, P, P, P, P]),
+    'amdnuwa_xattn_decode': (I, [XG, P, P, I, XK, P, P, P, I, P]),
     'amdnuwa_xattn_jp': (I, [I]),
     'amdnuwa_xattn_pack': (I, [XG, P, P, I, P, P, P, XK, P]),
     'amdnuwa_xattn_fwd': (I, [XG, P, P, I, XK, P, P, P, I, P, P, P, P, P]),

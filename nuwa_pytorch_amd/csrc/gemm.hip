@@ -1074,6 +1074,126 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// Few-row NT GEMM (M <= 8 per workgroup pass): the decode step of generate() multiplies ONE new row per sample by every
+// weight matrix, so the operation is a stream over the weight (HBM / L2 bound) and the 128x128 / 256x256 MFMA tiles would
+// spend a whole tile round on a handful of rows.  A[m, :] lives in LDS as fp32 (hi + lo); each wave owns ROWS_CPW output
+// columns, every lane multiplies its 8-wide k-slice of those weight rows with the matching slice of all rows of A, and the
+// partial sums are reduced across the wave.  fp32 FMA throughout (more exact than the bf16x3 MFMA path).
+// ---------------------------------------------------------------------------------------------
+constexpr int ROWS_MR = 8, ROWS_CPW = 4;
+
+// one halving step of the wave reduction (compile-time indices only: the values stay in registers)
+template <int HALF, int BIT>
+__device__ __forceinline__ void rows_halve(float (&v)[ROWS_CPW * ROWS_MR], int lane) {
+    const bool up = (lane & BIT) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+        const float send = up ? v[i] : v[HALF + i];
+        const float keep = up ? v[HALF + i] : v[i];
+        v[i] = keep + __shfl_xor(send, BIT, 64);
+    }
+    if constexpr (HALF > 1) rows_halve<HALF / 2, BIT / 2>(v, lane);
+}
+
+template <bool LO>
+__global__ __launch_bounds__(256) void gemm_nt_rows_kernel(GemmArgs p) {
+    extern __shared__ float a_s[];                       // [ROWS_MR][K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * ROWS_MR;
+    const int K = p.K;
+    const int n0 = (blockIdx.x * 4 + wave) * ROWS_CPW;
+    // the first weight slices are requested before A is staged: the two memory latencies overlap
+    uint4 wv[ROWS_CPW], wl[ROWS_CPW];
+    if (lane * 8 < K) {
+#pragma unroll
+        for (int c = 0; c < ROWS_CPW; ++c) {
+            const int n = min(n0 + c, p.N - 1);
+            wv[c] = ldg16(p.B + (size_t)n * p.ldb + lane * 8);
+            if (LO) wl[c] = ldg16(p.Blo + (size_t)n * p.ldb + lane * 8);
+        }
+    }
+    for (int i = tid * 8; i < ROWS_MR * K; i += 256 * 8) {
+        const int m = i / K, k = i - m * K;
+        float v[8];
+        if (m0 + m < p.M) {
+            const uint4 h = ldg16(p.A + (size_t)(m0 + m) * p.lda + k);
+            v[0] = lo_f(h.x); v[1] = hi_f(h.x); v[2] = lo_f(h.y); v[3] = hi_f(h.y);
+            v[4] = lo_f(h.z); v[5] = hi_f(h.z); v[6] = lo_f(h.w); v[7] = hi_f(h.w);
+            if (LO) {
+                const uint4 l = ldg16(p.Alo + (size_t)(m0 + m) * p.lda + k);
+                v[0] += lo_f(l.x); v[1] += hi_f(l.x); v[2] += lo_f(l.y); v[3] += hi_f(l.y);
+                v[4] += lo_f(l.z); v[5] += hi_f(l.z); v[6] += lo_f(l.w); v[7] += hi_f(l.w);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        *reinterpret_cast<float4*>(a_s + i) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(a_s + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    __syncthreads();
+    if (n0 >= p.N) return;
+    float acc[ROWS_CPW][ROWS_MR];
+#pragma unroll
+    for (int c = 0; c < ROWS_CPW; ++c)
+#pragma unroll
+        for (int m = 0; m < ROWS_MR; ++m) acc[c][m] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        if (k >= 512) {
+#pragma unroll
+            for (int c = 0; c < ROWS_CPW; ++c) {
+                const int n = min(n0 + c, p.N - 1);
+                wv[c] = ldg16(p.B + (size_t)n * p.ldb + k);
+                if (LO) wl[c] = ldg16(p.Blo + (size_t)n * p.ldb + k);
+            }
+        }
+        float w[ROWS_CPW][8];
+#pragma unroll
+        for (int c = 0; c < ROWS_CPW; ++c) {
+            w[c][0] = lo_f(wv[c].x); w[c][1] = hi_f(wv[c].x); w[c][2] = lo_f(wv[c].y); w[c][3] = hi_f(wv[c].y);
+            w[c][4] = lo_f(wv[c].z); w[c][5] = hi_f(wv[c].z); w[c][6] = lo_f(wv[c].w); w[c][7] = hi_f(wv[c].w);
+            if (LO) {
+                w[c][0] += lo_f(wl[c].x); w[c][1] += hi_f(wl[c].x); w[c][2] += lo_f(wl[c].y); w[c][3] += hi_f(wl[c].y);
+                w[c][4] += lo_f(wl[c].z); w[c][5] += hi_f(wl[c].z); w[c][6] += lo_f(wl[c].w); w[c][7] += hi_f(wl[c].w);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < ROWS_MR; ++m) {
+            const float4 a0 = *reinterpret_cast<const float4*>(a_s + m * K + k);
+            const float4 a1 = *reinterpret_cast<const float4*>(a_s + m * K + k + 4);
+#pragma unroll
+            for (int c = 0; c < ROWS_CPW; ++c) {
+                float t = acc[c][m];
+                t = fmaf(a0.x, w[c][0], t); t = fmaf(a0.y, w[c][1], t); t = fmaf(a0.z, w[c][2], t); t = fmaf(a0.w, w[c][3], t);
+                t = fmaf(a1.x, w[c][4], t); t = fmaf(a1.y, w[c][5], t); t = fmaf(a1.z, w[c][6], t); t = fmaf(a1.w, w[c][7], t);
+                acc[c][m] = t;
+            }
+        }
+    }
+    // wave reduction of the 32 partial sums by halving: at each step a lane keeps half of its values and receives the partner's
+    // copies of that half (32 cross-lane moves instead of 32 x 6); lane 2 * i (and 2 * i + 1) ends with the total of value i
+    float v[ROWS_CPW * ROWS_MR];
+#pragma unroll
+    for (int c = 0; c < ROWS_CPW; ++c)
+#pragma unroll
+        for (int m = 0; m < ROWS_MR; ++m) v[c * ROWS_MR + m] = acc[c][m];
+    rows_halve<ROWS_CPW * ROWS_MR / 2, 32>(v, lane);
+    const float mine = v[0] + __shfl_xor(v[0], 1, 64);
+    static_assert(ROWS_CPW * ROWS_MR == 32, "the halving reduction is written for 32 values over 64 lanes");
+    if ((lane & 1) == 0) {
+        const int vi = lane >> 1, c = vi / ROWS_MR, m = m0 + vi % ROWS_MR, n = n0 + c;
+        if (m < p.M && n < p.N) {
+            float v = mine * p.alpha;
+            if (p.bias) v += p.bias[n];
+            const size_t o = (size_t)m * p.ldc + n;
+            if (p.Clo) { bf16_t h, l; f2bf_hilo(v, h, l); ((bf16_t*)p.C)[o] = h; p.Clo[o] = l; }
+            else if (p.beta != 0.f) ((bf16_t*)p.C)[o] = f2bf(v);          // beta != 0 marks a bf16 destination here
+            else ((float*)p.C)[o] = v;
+        }
+    }
+}
+
 extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     if (!d || !d->A || !d->B || !d->C) return AMDNUWA_ERR_ARG;
     if (d->M <= 0 || d->N <= 0) return AMDNUWA_OK;
@@ -1092,6 +1212,22 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     p.dbg = g_amdnuwa_tuning[7];
     p.batch_inner = d->batch_inner; p.sA_in = d->strideA_inner; p.sB_in = d->strideB_inner; p.sC_in = d->strideC_inner;
     const bool x3 = d->Alo != nullptr, sh = d->shift_ntok > 0, ob = d->c_is_bf16 != 0;
+    // a handful of rows (the decode step of generate()): stream the weight instead of running MFMA tiles
+    if (g_amdnuwa_tuning[0] == 0 && d->M <= 4 * ROWS_MR && d->batch <= 1 && !sh && (size_t)ROWS_MR * d->K * 4 <= 144 * 1024) {
+        if (d->Clo && !ob) return AMDNUWA_ERR_ARG;
+        p.beta = (ob && !d->Clo) ? 1.f : 0.f;                  // destination-type marker for the rows kernel (see its epilogue)
+        const size_t lds = (size_t)ROWS_MR * d->K * sizeof(float);
+        dim3 g((d->N + 4 * ROWS_CPW - 1) / (4 * ROWS_CPW), (d->M + ROWS_MR - 1) / ROWS_MR);
+        if (x3) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((gemm_nt_rows_kernel<true>), g, dim3(256), lds, stream, p);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((gemm_nt_rows_kernel<false>), g, dim3(256), lds, stream, p);
+        }
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
+    }
     dim3 grid(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), block(256);
     // direct-to-LDS variants (tuning key 0: 0 = register-staged, 1 = glds BK 64, 2 = glds BK 32)
     // tuning key 0: 0 = auto, 1 = direct-to-LDS BK 64, 2 = direct-to-LDS BK 32, 3 / 4 = 256x256 tile with a 4- / 3-stage

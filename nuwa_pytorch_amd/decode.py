@@ -16,7 +16,7 @@ from . import ops
 
 
 class _Block:
-    __slots__ = ('kind', 'sn', 'inner', 'fmap', 'hcache', 'kvcache', 'geom', 'pk', 'xg')
+    __slots__ = ('kind', 'sn', 'inner', 'fmap', 'hcache', 'kvcache', 'geom', 'pk', 'xg', 'o_const')
 
 
 class IncrementalDecoder:
@@ -31,6 +31,9 @@ class IncrementalDecoder:
         D = context.shape[-1]
         ctx_bf = ops._ctx_to_bf(context)
         mask_u8 = context_mask.to(torch.uint8).contiguous() if context_mask is not None else None
+        # the text-masked pass of classifier-free guidance: every query sees only the learned null key, so the attention
+        # output is the same row for every position -- (sum_h W_th[g, h]) * null_v[g] -- and is computed once
+        all_masked = context_mask is not None and not bool(context_mask.any())
         self.blocks = []
         for attn, cross, ff in transformer.layers:
             for sn, ctx_arg in ((attn, None), (cross, context), (ff, None)):
@@ -43,7 +46,7 @@ class IncrementalDecoder:
                 blk = _Block()
                 blk.sn, blk.inner, blk.fmap = sn, inner, fmap
                 blk.hcache = K.zeros_bf((batch, max_rows, D), dev, lo=lo) if fmap is not None else None
-                blk.kvcache = blk.geom = blk.pk = blk.xg = None
+                blk.kvcache = blk.geom = blk.pk = blk.xg = blk.o_const = None
                 if isinstance(inner, Sparse3DNA):
                     if not inner.causal:
                         raise NotImplementedError('IncrementalDecoder needs causal Sparse3DNA')
@@ -59,6 +62,9 @@ class IncrementalDecoder:
                     kv = K.gemm_nt(ctx_bf, W['kv'], out_bf16=True)                 # text keys / values: once per sequence
                     blk.pk = K.xattn_pack(blk.xg, kv, p[0].detach().reshape(inner.heads, inner.dim_head).contiguous(),
                                           p[1].detach().reshape(inner.heads, inner.dim_head).contiguous(), mask_u8)
+                    if all_masked:
+                        q0 = K.zeros_bf((batch, inner.heads * inner.dim_head), dev, lo=lo)
+                        blk.o_const = K.xattn_decode(blk.xg, q0, blk.pk, p[2].detach().reshape(inner.heads, inner.heads).contiguous())
                 elif isinstance(inner, FeedForward):
                     blk.kind = 'ff'
                 else:
@@ -68,12 +74,15 @@ class IncrementalDecoder:
     def step(self, x):
         """x fp32 [B, D]: decoder input row `pos` of every sample -> that row after all layers (before the final norm)"""
         fast = ops._fast()
-        for blk in self.blocks:
+        blocks = self.blocks
+
+        def pre(blk):
+            return (blk.sn.prenorm.weight.detach(), blk.sn.prenorm.bias.detach())
+        first = blocks[0]
+        _, h = K.decode_ln(x, None, None, pre(first), cache=first.hcache, pos_dev=self.pos_dev, fmap=first.fmap or 0)
+        for i, blk in enumerate(blocks):
             sn, inner = blk.sn, blk.inner
             p = inner._params()
-            h, _, _, _ = K.ln_fwd(x, sn.prenorm.weight.detach(), sn.prenorm.bias.detach())
-            if blk.fmap is not None:
-                h = K.decode_shift(h, blk.hcache, self.pos_dev, blk.fmap)
             if blk.kind == 's3':
                 W = ops.S3Inner.weights(inner._cache, p)
                 g = blk.geom
@@ -85,18 +94,21 @@ class IncrementalDecoder:
                 W = ops.XInner.weights(inner._cache, p)
                 g = blk.xg
                 wth = p[2].detach().reshape(g.heads, g.heads).contiguous()
-                q = K.gemm_nt(h, W['q'], out_bf16=True)
-                if K.xattn2_supported(g, q):
-                    o, _ = K.xattn2_fwd(g, q, blk.pk, wth)
+                if blk.o_const is not None:
+                    o = blk.o_const
                 else:
-                    o, _, _ = K.xattn_fwd(g, q, blk.pk, wth, save=False)
+                    q = K.gemm_nt(h, W['q'], out_bf16=True)
+                    o = K.xattn_decode(g, q, blk.pk, wth)
                 y = K.gemm_nt(o, W['out'], out_bf16=fast)
             else:
                 W = ops.FFInner.weights(inner._cache, p)
                 u = K.gemm_nt(h, W['w1'], out_bf16=True)
                 gg = K.geglu_fwd(u, W['FP'])
                 y = K.gemm_nt(gg, W['w2'], out_bf16=fast)
-            x, _, _ = K.ln_fwd(y, sn.postnorm.weight.detach(), sn.postnorm.bias.detach(), resid=x)
+            # post-norm + residual, the next block's pre-norm and its token shift (cache write + gather): one launch
+            nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+            x, h = K.decode_ln(y, x, (sn.postnorm.weight.detach(), sn.postnorm.bias.detach()), pre(nxt) if nxt else None,
+                               cache=nxt.hcache if nxt else None, pos_dev=self.pos_dev, fmap=(nxt.fmap or 0) if nxt else 0)
         return x
 
 
@@ -147,8 +159,15 @@ class GuidedStepper:
                 self._body()
                 self.pos_dev -= 1
             torch.cuda.current_stream().wait_stream(s)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):     # capture records, it does not execute: the replay below is step `pos`
-                self.logits = self._body()
+            try:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):     # capture records, it does not execute: the replay below is step `pos`
+                    self.logits = self._body()
+            except RuntimeError as e:                  # same kernels, launched one by one
+                import warnings
+                warnings.warn(f'nuwa_pytorch_amd: HIP graph capture of the decode step failed ({e}); launching eagerly')
+                self.graph, self._want_graph = None, False
+                torch.cuda.synchronize()
+                return self._body()
         self.graph.replay()
         return self.logits

@@ -379,6 +379,20 @@ def decode_shift(h, cache, pos_dev, fmap):
     return out
 
 
+def decode_ln(y, resid, post, nxt, cache=None, pos_dev=None, fmap=0, eps=1e-5):
+    """the norms around a block for the single new row: post = (w, b) or None, nxt = (w, b) or None.
+    returns (x_new fp32 [B, D] or None when resid is None, h BF [B, D] or None when nxt is None)"""
+    L = _lib.lib()
+    yp, ybf, (B, D), dev = _f32_or_bf(y)
+    x_new = torch.empty((B, D), dtype=torch.float32, device=dev) if resid is not None else None
+    h = empty_bf((B, D), dev) if nxt is not None else BF(None, None)
+    ch, cl, rows = (cache.hi, cache.lo, cache.hi.shape[1]) if cache is not None else (None, None, 0)
+    check(L.amdnuwa_decode_ln(yp, 1 if ybf else 0, _p(resid), _p(post[0]) if post else None, _p(post[1]) if post else None,
+                              _p(nxt[0]) if nxt else None, _p(nxt[1]) if nxt else None, _p(x_new), _p(ch), _p(cl), _p(h.hi),
+                              _p(h.lo), _p(pos_dev), B, rows, D, fmap, eps, _stream()), 'amdnuwa_decode_ln')
+    return x_new, (h if nxt is not None else None)
+
+
 def s3_decode(g, qkv, kv_cache, pos_dev, wth, rel_bias=None):
     """qkv BF [B, 3*inner] of the new row; kv_cache BF [B, rows, 2*inner]; returns o BF [B, inner]"""
     L = _lib.lib()
@@ -387,6 +401,16 @@ def s3_decode(g, qkv, kv_cache, pos_dev, wth, rel_bias=None):
     o = empty_bf((g.B, inner), qkv.hi.device, lo=qkv.lo is not None)
     check(L.amdnuwa_s3_decode(C.byref(g), _p(qkv.hi), _p(qkv.lo), _p(kv_cache.hi), _p(kv_cache.lo), kv_cache.hi.shape[1],
                               _p(pos_dev), _p(wth), _p(o.hi), _p(o.lo), _stream()), 'amdnuwa_s3_decode')
+    return o
+
+
+def xattn_decode(g, q, pk, wth):
+    """single-query text cross-attention (g.n == 1): q BF [B, inner] -> o BF [B, inner]"""
+    L = _lib.lib()
+    inner = g.heads * g.dim_head
+    o = empty_bf((g.B, inner), q.hi.device, lo=q.lo is not None)
+    check(L.amdnuwa_xattn_decode(C.byref(g), _p(q.hi), _p(q.lo), q.hi.stride(0), C.byref(pk.struct), _p(wth), _p(o.hi), _p(o.lo),
+                                 inner, _stream()), 'amdnuwa_xattn_decode')
     return o
 
 

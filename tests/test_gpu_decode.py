@@ -90,6 +90,89 @@ def test_decode_shift_rows_equal_shift_video_tokens(K, O, x3):
     report(f'decode_shift[x3={x3}]', torch.stack(rows, 1), ref, 1e-6 if not x3 else 2e-5)
 
 
+X_CASES = [(3, 7, 2, 32), (2, 33, 8, 64), (2, 256, 8, 64), (4, 31, 4, 32)]
+
+
+@pytest.mark.parametrize('case', range(len(X_CASES)))
+@pytest.mark.parametrize('x3', [False, True])
+def test_xattn_decode_equals_cross_attention_core(K, O, case, x3):
+    """one query per sample against the packed text keys / values: the oracle's cross-attention core (np.py:339-378) with a
+    partially and a fully masked sample"""
+    B, T, heads, dh = X_CASES[case]
+    inner = heads * dh
+    torch.manual_seed(60 + case)
+    q = torch.randn(B, 1, heads, dh)
+    kv = torch.randn(B, T, 2, heads, dh)
+    nk, nv = torch.randn(heads, dh), torch.randn(heads, dh)
+    if not x3:
+        q, kv, nk, nv = (t.bfloat16().float() for t in (q, kv, nk, nv))
+    wth = torch.randn(heads, heads) * 0.5 + torch.eye(heads)
+    mask = torch.rand(B, T) > 0.3
+    mask[0] = False                                     # condition-dropped sample: only the null key
+    o_ref = O.attention_core(q, kv[:, :, 0], kv[:, :, 1], nk, nv, wth, mask, dh ** -0.5)
+    g = K.x_geom(B, 1, T, heads, dh)
+    pk = K.xattn_pack(g, to_bf_pair(kv.reshape(B * T, 2 * inner).to(DEV), x3), nk.to(DEV), nv.to(DEV),
+                      mask.to(torch.uint8).to(DEV))
+    o = K.xattn_decode(g, to_bf_pair(q.reshape(B, inner).to(DEV), x3), pk, wth.to(DEV))
+    report(f'xattn_decode[{case},x3={x3}]', bf_value(o).reshape(B, 1, heads, dh), o_ref, 3e-5 if x3 else 2 ** -7)
+
+
+@pytest.mark.parametrize('M,N,Kd', [(1, 512, 512), (4, 1536, 512), (8, 2752, 512), (9, 512, 1376), (16, 8192, 512), (32, 100, 64),
+                                    (3, 77, 2752)])
+@pytest.mark.parametrize('x3', [False, True])
+def test_few_row_gemm(K, M, N, Kd, x3):
+    """the weight-streaming NT GEMM the decode step uses (M <= 32 rows): fp32 / bf16 outputs, bias, alpha"""
+    torch.manual_seed(M + N)
+    a, w, bias = torch.randn(M, Kd), torch.randn(N, Kd), torch.randn(N)
+    if not x3:
+        a, w = a.bfloat16().float(), w.bfloat16().float()
+    ref = (a.double() @ w.double().t()).float()
+    ap, wp = to_bf_pair(a.to(DEV), x3), to_bf_pair(w.to(DEV), x3)
+    tol = 2e-5 if x3 else 1e-6
+    report(f'rows_gemm.f32[{M},{N},{Kd},x3={x3}]', K.gemm_nt(ap, wp), ref, tol)
+    report(f'rows_gemm.bias[{M},{N},{Kd},x3={x3}]', K.gemm_nt(ap, wp, bias=bias.to(DEV), alpha=0.5), 0.5 * ref + bias, tol)
+    report(f'rows_gemm.bf[{M},{N},{Kd},x3={x3}]', bf_value(K.gemm_nt(ap, wp, out_bf16=True)), ref, tol if x3 else 2 ** -8)
+
+
+@pytest.mark.parametrize('D,ybf', [(64, False), (512, True), (1024, False)])
+@pytest.mark.parametrize('x3', [False, True])
+def test_decode_ln_fuses_post_norm_pre_norm_and_shift(K, O, D, ybf, x3):
+    """one launch = post-norm + residual, next pre-norm, cache write and shift gather; fed row by row it reproduces
+    x + LN(y), and shift(LN(x_new)) over the whole sequence (oracle shift_video_tokens)"""
+    import torch.nn.functional as F
+    torch.manual_seed(9)
+    B, fmap, n = 2, 4, 1 + 2 * 16 - 5
+    y, resid = torch.randn(B, n, D) * 1.2, torch.randn(B, n, D)
+    if ybf:
+        y = y.bfloat16().float()
+    w, b, w2, b2 = (torch.randn(D) for _ in range(4))
+    x_ref = resid + F.layer_norm(y, (D,), w, b)
+    h_ref = O.shift_video_tokens(F.layer_norm(x_ref, (D,), w2, b2), fmap)
+    K.set_precision('bf16x3' if x3 else 'bf16')
+    try:
+        cache = K.zeros_bf((B, n, D), DEV, lo=x3)
+        pos = torch.zeros(1, dtype=torch.int32, device=DEV)
+        xs, hs = [], []
+        for t in range(n):
+            pos.fill_(t)
+            yt = y[:, t].contiguous().to(DEV)
+            yin = K.BF(yt.bfloat16(), None) if ybf else yt
+            xn, h = K.decode_ln(yin, resid[:, t].contiguous().to(DEV), (w.to(DEV), b.to(DEV)), (w2.to(DEV), b2.to(DEV)),
+                                cache=cache, pos_dev=pos, fmap=fmap)
+            xs.append(xn)
+            hs.append(bf_value(h))
+        report(f'decode_ln.x[{D},x3={x3}]', torch.stack(xs, 1), x_ref, 2e-5)
+        report(f'decode_ln.h[{D},x3={x3}]', torch.stack(hs, 1), h_ref, 3e-5 if x3 else 2 ** -7)
+        # the two degenerate forms: pre-norm only (first block) and post-norm only (last block)
+        _, h0 = K.decode_ln(resid[:, 0].contiguous().to(DEV), None, None, (w2.to(DEV), b2.to(DEV)))
+        report(f'decode_ln.pre_only[{D}]', bf_value(h0), F.layer_norm(resid[:, 0], (D,), w2, b2), 3e-5 if x3 else 2 ** -7)
+        xl, hl = K.decode_ln(y[:, 1].contiguous().to(DEV), resid[:, 1].contiguous().to(DEV), (w.to(DEV), b.to(DEV)), None)
+        assert hl is None
+        report(f'decode_ln.post_only[{D}]', xl, x_ref[:, 1], 2e-5)
+    finally:
+        K.set_precision('bf16')
+
+
 def _load_g5(A):
     Ar, P, _ = load('g5_nuwa_tiny')
     nuwa = _tiny_nuwa(A, False)
