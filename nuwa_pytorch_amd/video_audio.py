@@ -11,7 +11,7 @@ Same class names, constructor kwargs, forward() signatures and state-dict keys a
     correction for the talking-heads Conv3d bias.  Head sizes the kernels do not cover (and `use_hip = False`) run the torch-op
     formulations kept next to them (index-table gathers, nothing is unfolded); the audio channel shift is a torch op.
 `dec_reversible=True` (ReversibleDualModalityDecoder, np.py:1489-1655 + reversible_video_audio.py) runs with the reference's
-arithmetic but keeps its activations (no recomputing backward yet).  Not built: generate().
+arithmetic but keeps its activations (no recomputing backward yet).  generate() follows the reference's recompute loop.
 """
 import torch
 import torch.nn.functional as F
@@ -453,8 +453,67 @@ class NUWAVideoAudio(nn.Module):
         emb = emb + self.audio_pos_emb()[:emb.shape[1]][None]
         return torch.cat((self.audio_bos[None, None].expand(ids_in.shape[0], 1, -1), emb), dim=1)
 
-    def generate(self, *args, **kwargs):
-        raise NotImplementedError('NUWAVideoAudio.generate (np.py:2107-2222) is not built: only the training forward is')
+    @torch.no_grad()
+    def generate(self, *, text, filter_thres=0.9, temperature=1., decode_max_batchsize=10, cond_scale=2., num_frames=None):
+        """np.py:2111-2222: video and audio tokens are sampled alternately, one video frame's worth at a time; every step runs the
+        dual decoder over the whole prefix (twice with classifier-free guidance, the second pass fed the first pass's normed
+        OUTPUTS as the reference does).  Returns (video [b, f, 3, H, W], audio token ids [b, f * audio_tokens_per_frame])."""
+        was_training = self.training
+        self.eval()
+        try:
+            return self._generate(text, filter_thres, temperature, decode_max_batchsize, cond_scale, num_frames)
+        finally:
+            self.train(was_training)
+
+    def _generate(self, text, filter_thres, temperature, decode_max_batchsize, cond_scale, num_frames):
+        from .nuwa_pytorch import batch_process, gumbel_sample, top_k
+        if not text.is_cuda:
+            raise RuntimeError('nuwa_pytorch_amd: the decoder path needs a HIP device; there is no CPU fallback')
+        batch, device = text.shape[0], text.device
+        tpf, apf = self.num_video_tokens_per_frame, self.num_audio_tokens_per_video_frame
+        text_mask = text != 0
+        text_embeds = self.embed_text(text, mask=text_mask)
+        video_indices = torch.empty((batch, 0), device=device, dtype=torch.long)
+        audio_indices = torch.empty((batch, 0), device=device, dtype=torch.long)
+        num_frames = default(num_frames, self.max_video_frames)
+        total_video_tokens, total_audio_tokens = num_frames * tpf, num_frames * apf
+        dec = self.video_audio_transformer
+        vn, an = dec.video_norm.norm, dec.audio_norm.norm
+        no_text = torch.zeros_like(text_mask).bool()
+        decoding_video = True
+        while video_indices.shape[1] < total_video_tokens or audio_indices.shape[1] < total_audio_tokens:
+            video_in = video_indices
+            if video_indices.shape[1] > total_video_tokens:           # (np.py:2149-2153; never true inside this loop)
+                curr = video_indices.shape[1] % tpf
+                video_in = video_indices[:, -((self.max_video_frames - (0 if curr == 0 else 1)) * tpf + curr):]
+            frame_emb = self.embed_video(video_in) if video_in.shape[1] > 0 else \
+                self.video_bos[None, None].expand(batch, 1, -1).contiguous()
+            audio_emb = self.embed_audio(audio_indices).contiguous()
+
+            def logits_of(v_hid, a_hid):
+                if decoding_video:
+                    return ops.LogitsFn.apply(v_hid[:, -1:].contiguous(), vn.weight, vn.bias, self.to_video_logits.weight, self._cache_v)
+                return ops.LogitsFn.apply(a_hid[:, -1:].contiguous(), an.weight, an.bias, self.to_audio_logits.weight, self._cache_a)
+            v_hid, a_hid = dec.forward_layers(frame_emb, audio_emb, context=text_embeds, context_mask=text_mask)
+            logits = logits_of(v_hid, a_hid)
+            if cond_scale != 1:
+                uv, ua = dec.forward_layers(dec.video_norm(v_hid), dec.audio_norm(a_hid), context=text_embeds, context_mask=no_text)
+                uncond = logits_of(uv, ua)
+                logits = uncond + (logits - uncond) * cond_scale
+            sample = gumbel_sample(top_k(logits[:, -1], thres=filter_thres), temperature=temperature, dim=-1)[:, None]
+            if decoding_video:
+                video_indices = torch.cat((video_indices, sample), dim=1)
+                boundary = video_indices.shape[1] % tpf == 0
+            else:
+                audio_indices = torch.cat((audio_indices, sample), dim=1)
+                boundary = audio_indices.shape[1] % apf == 0
+            if boundary:                                              # alternate, one video frame at a time
+                decoding_video = not decoding_video
+        fs = self.video_fmap_size
+        codes = self.vae.codes_for_decoder(video_indices)
+        codes = codes.reshape(batch, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
+        images = batch_process(codes.contiguous(), self.vae._hip_decode, chunks=decode_max_batchsize)
+        return images.reshape(batch, -1, *images.shape[1:]), audio_indices
 
     def forward(self, *, text, video, audio, return_loss=False, cond_dropout_prob=0.2):
         batch, device = text.shape[0], text.device

@@ -253,3 +253,28 @@ def test_generate_cached_equals_recompute_under_greedy_sampling(A):
         A.set_precision('bf16')
     assert outs[0].shape == (2, 2, 3, 16, 16)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('reversible', [False, True])
+def test_video_audio_generate_alternates_modalities(A, reversible):
+    """NUWAVideoAudio.generate (np.py:2111-2222): video and audio tokens sampled alternately a frame at a time on the libamdnuwa
+    path (plain and reversible dual decoder): shapes, token ranges, finite frames, determinism under greedy sampling, and the
+    guided (two-pass) variant"""
+    from test_gpu_modules import VA_KW
+    torch.manual_seed(21)
+    vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
+    m = A.NUWAVideoAudio(vae=vae, sparse_3dna_rel_pos_bias=False, **{**VA_KW, 'dec_reversible': reversible}).to(DEV).eval()
+    text = torch.randint(1, 40, (1, 6), generator=torch.Generator().manual_seed(2)).to(DEV)
+    A.set_precision('bf16x3')
+    try:
+        video, audio = m.generate(text=text, filter_thres=0.99, cond_scale=1., num_frames=2)
+        tpf, apf = m.num_video_tokens_per_frame, m.num_audio_tokens_per_video_frame
+        assert video.shape == (1, 2, 3, 16, 16) and audio.shape == (1, 2 * apf) and audio.dtype == torch.long
+        assert int(audio.min()) >= 0 and int(audio.max()) < VA_KW['num_audio_tokens']
+        assert bool(torch.isfinite(video).all())
+        again, audio2 = m.generate(text=text, filter_thres=0.99, cond_scale=1., num_frames=2)
+        assert torch.equal(audio, audio2) and torch.equal(video, again)          # greedy: deterministic
+        guided, _ = m.generate(text=text, filter_thres=0.99, cond_scale=2., num_frames=1)
+        assert guided.shape == (1, 1, 3, 16, 16) and bool(torch.isfinite(guided).all())
+    finally:
+        A.set_precision('bf16')
