@@ -6,8 +6,8 @@ PARAMETER CONTAINERS (identical keys, shapes and default initialisation as the r
 own forward() is never called on the decoder path.
 
 Scope: decoder stack, embeddings, logits/loss = HIP.  The text encoder (row f1,
-256 tokens once per step) currently runs as PyTorch-ROCm ops on the GPU; NUWASketch / NUWAVideoAudio
-are not part of this round and raise NotImplementedError.
+256 tokens once per step) runs its attention / FeedForward blocks through the same kernels.  NUWAVideoAudio (cfg 5) lives in
+video_audio.py; NUWASketch (row f4) shares the decoder kernels, with SparseCross2DNA and the sketch encoder on PyTorch-ROCm ops.
 """
 import functools
 from functools import partial
@@ -101,6 +101,29 @@ def causal_neighbor_mask(video_shape, kernel_size, dilation):
     return torch.stack(cols, dim=1)
 
 
+def neighbor_positions(video_shape, kernel_size, dilation, causal):
+    """(N, K) int64: raster position of tap slot (a, b, c) of every query position, -1 where the tap falls in the zero padding.
+    causal: all padding on the low side (np.py:427); otherwise symmetric 'same' padding (np.py:429)."""
+    Fr, H, W = video_shape
+    kf, kh, kw = kernel_size
+    df, dh, dw = dilation
+    f = torch.arange(Fr)[:, None, None]
+    y = torch.arange(H)[None, :, None]
+    w = torch.arange(W)[None, None, :]
+    cols = []
+    for a in range(kf):
+        for b in range(kh):
+            for c in range(kw):
+                if causal:
+                    ff, yy, ww = f - (kf - 1 - a) * df, y - (kh - 1 - b) * dh, w - (kw - 1 - c) * dw
+                else:
+                    ff, yy, ww = f + (a - (kf - 1) // 2) * df, y + (b - (kh - 1) // 2) * dh, w + (c - (kw - 1) // 2) * dw
+                ok = (ff >= 0) & (ff < Fr) & (yy >= 0) & (yy < H) & (ww >= 0) & (ww < W)
+                pos = ((ff * H + yy) * W + ww).expand(Fr, H, W)
+                cols.append(torch.where(ok.expand(Fr, H, W), pos, torch.full_like(pos, -1)).reshape(-1))
+    return torch.stack(cols, dim=1)
+
+
 # ---------------------------------------------------------------------------------------------------
 # normalisations
 # ---------------------------------------------------------------------------------------------------
@@ -142,7 +165,7 @@ class SandwichNorm(nn.Module):
             if fn.shift_space:
                 shift = fn.image_size
             fn = fn.fn
-        if isinstance(fn, (Sparse3DNA, FeedForward)):
+        if isinstance(fn, FeedForward) or (isinstance(fn, Sparse3DNA) and fn.causal):
             return fn, shift
         if isinstance(fn, Attention) and context is not None and fn._hip_ok(context.shape[1]):
             return fn, shift
@@ -387,8 +410,6 @@ class Sparse3DNA(nn.Module):
         self.kernel_size = cast_tuple(kernel_size, size=3)
         assert all(map(lambda n: n % 2 == 1, self.kernel_size)), 'kernel size must be odd'
         self.kernel_numel = mult_reduce(self.kernel_size)
-        if not causal:
-            raise NotImplementedError('non-causal Sparse3DNA (NUWASketch encoder) is not supported by the HIP path yet')
         # np.py:416: one bias per (key tap, head), axial over the kernel (the reference's add only broadcasts for batch 1; here
         # the same per-head bias is applied to every sample)
         self.rel_pos_bias = AxialPositionalEmbedding(heads, shape=self.kernel_size) if rel_pos_bias else None
@@ -396,7 +417,13 @@ class Sparse3DNA(nn.Module):
         max_frames, fmap_size, _ = video_shape
         self.max_num_tokens = max_frames * fmap_size * fmap_size
         self.query_num_frames_chunk = default(query_num_frames_chunk, max_frames)
-        self.register_buffer('mask', causal_neighbor_mask(video_shape, self.kernel_size, self.dilation))
+        if causal:
+            self.register_buffer('mask', causal_neighbor_mask(video_shape, self.kernel_size, self.dilation))
+        else:
+            # NUWASketch's sketch encoder (sketch_enc_use_sparse_3dna=True): symmetric window, PyTorch-ROCm ops (row f4)
+            nbr = neighbor_positions(video_shape, self.kernel_size, self.dilation, causal=False)
+            self.register_buffer('mask', F.pad(nbr < 0, (1, 0), value=False))
+            self.register_buffer('_nbr', nbr, persistent=False)
         self._cache = ops.WeightCache()
 
     def _params(self):
@@ -415,13 +442,104 @@ class Sparse3DNA(nn.Module):
 
     def forward(self, x, **kwargs):
         B, n, _ = x.shape
+        if not self.causal:
+            return self._forward_noncausal(x)
         return ops.InnerFn.apply(x, None, self._meta(B, n, x.device), *self._params())
+
+    def _forward_noncausal(self, x):
+        """np.py:459-613 with causal=False, as a gather over the neighbour table instead of unfoldNd.  The reference treats
+        row 0 as <bos> here too, pads the remaining rows to whole frames with zero rows, and masks only the taps that leave the
+        FULL video shape -- so zero rows (and frames the sequence does not reach) are attended with score 0."""
+        b, n, _ = x.shape
+        h = self.heads
+        q, (k, v) = self.to_q(x), self.to_kv(x).chunk(2, dim=-1)
+        if n == 1:
+            return self.to_out(v)
+        q, k, v = (t.reshape(b, n, h, -1).transpose(1, 2) for t in (q, k, v))                 # b h n d
+        nq = n - 1
+        qs = q[:, :, 1:] * self.scale
+        tab = self._nbr[:nq]                                                                    # (nq, K)
+        valid = tab >= 0
+        idx = torch.where(valid & (tab < nq), tab, torch.full_like(tab, nq)).reshape(-1)        # row nq = the zero row
+        zero = k.new_zeros(b, h, 1, k.shape[-1])
+        kg = torch.cat((k[:, :, 1:], zero), 2)[:, :, idx].reshape(b, h, nq, -1, k.shape[-1])
+        vg = torch.cat((v[:, :, 1:], zero), 2)[:, :, idx].reshape(b, h, nq, -1, v.shape[-1])
+        sim = torch.cat((einsum('b h i d, b h d -> b h i', qs, k[:, :, 0])[..., None],
+                         einsum('b h i d, b h i j d -> b h i j', qs, kg)), dim=-1)
+        if self.rel_pos_bias is not None:
+            sim = sim + F.pad(self.rel_pos_bias().reshape(self.kernel_numel, h).t(), (1, 0))[None, :, None, :]
+        sim = sim.masked_fill(~F.pad(valid, (1, 0), value=True)[None, None], -torch.finfo(sim.dtype).max)
+        attn = sim.softmax(dim=-1, dtype=torch.float32)
+        attn = self.dropout(einsum('g h, b h i j -> b g i j', self.talking_heads.weight.reshape(h, h), attn))
+        out = attn[..., :1] * v[:, :, :1] + einsum('b h i j, b h i j d -> b h i d', attn[..., 1:], vg)
+        out = torch.cat((v[:, :, :1], out), dim=2)
+        return self.to_out(out.transpose(1, 2).reshape(b, n, -1))
 
 
 class SparseCross2DNA(nn.Module):
-    def __init__(self, *args, **kwargs):
+    """np.py:761-901: cross-attention of video tokens to the sketch tokens in a 2-D neighbourhood of the same feature-map
+    position in EVERY sketch frame (+ a learned null key); the <bos> query attends to all sketch tokens, without talking heads.
+    PyTorch-ROCm ops (row f4): the unfold of the reference is a gather over a (position, tap) table."""
+
+    def __init__(self, *, dim, image_size, heads=8, dim_head=64, dropout=0., kernel_size=3, dilation=1):
         super().__init__()
-        raise NotImplementedError('NUWASketch is outside this round (SURVEY.md section 8 row f4)')
+        inner_dim = heads * dim_head
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.null_k = nn.Parameter(torch.randn(heads, 1, dim_head))
+        self.null_v = nn.Parameter(torch.randn(heads, 1, dim_head))
+        self.talking_heads = nn.Conv3d(heads, heads, 1, bias=False)
+        self.dropout = nn.Dropout(dropout)
+        self.to_q = nn.Linear(dim, inner_dim, bias=False)
+        self.to_kv = nn.Linear(dim, inner_dim * 2, bias=False)
+        self.to_out = nn.Linear(inner_dim, dim, bias=False)
+        self.image_size, self.kernel_size, self.dilation = image_size, kernel_size, dilation
+        self.padding = calc_same_padding(kernel_size, dilation)
+        nbr = neighbor_positions((1, image_size, image_size), (1, kernel_size, kernel_size), (1, dilation, dilation), causal=False)
+        self.register_buffer('_nbr', nbr, persistent=False)                                    # (fmap^2, k^2), -1 = padding
+
+    def forward(self, x, *, context, context_mask=None, **kwargs):
+        b, n, h, device = x.shape[0], x.shape[1], self.heads, x.device
+        tpf = self.image_size ** 2
+        kn = self.kernel_size ** 2
+        if not exists(context_mask):
+            context_mask = torch.ones((b, context.shape[-2]), dtype=torch.bool, device=device)
+        mask_value = -torch.finfo(x.dtype).max
+        q, (k, v) = self.to_q(x), self.to_kv(context).chunk(2, dim=-1)
+        q, k, v = (t.reshape(b, t.shape[1], h, -1).transpose(1, 2) for t in (q, k, v))        # b h n d
+        q = q * self.scale
+        q_bos, q = q[:, :, 0], q[:, :, 1:]
+        nk, nv = self.null_k[None].expand(b, -1, -1, -1), self.null_v[None].expand(b, -1, -1, -1)
+        sim_bos = einsum('b h d, b h j d -> b h j', q_bos, torch.cat((nk, k), dim=-2))
+        sim_bos = sim_bos.masked_fill(~F.pad(context_mask[:, None], (1, 0), value=True), mask_value)
+        out_bos = einsum('b h j, b h j d -> b h d', sim_bos.softmax(dim=-1, dtype=torch.float32), torch.cat((nv, v), dim=-2))
+        out_bos = out_bos.reshape(b, 1, -1)
+        if n == 1:
+            return self.to_out(out_bos)
+        f = context.shape[-2] // tpf
+        tab = self._nbr                                                                         # (tpf, kn)
+        valid = tab >= 0
+        idx = tab.clamp(min=0).reshape(-1)
+        # keys / values of position i: for every sketch frame the kn taps around i -> slot order (frame, tap), np.py:855
+        kf = k.reshape(b, h, f, tpf, -1)[:, :, :, idx].reshape(b, h, f, tpf, kn, -1).permute(0, 1, 3, 2, 4, 5).reshape(b, h, tpf, f * kn, -1)
+        vf = v.reshape(b, h, f, tpf, -1)[:, :, :, idx].reshape(b, h, f, tpf, kn, -1).permute(0, 1, 3, 2, 4, 5).reshape(b, h, tpf, f * kn, -1)
+        vmask = valid[None, None, :, None, :, None].to(kf.dtype).expand(1, 1, tpf, f, kn, 1).reshape(1, 1, tpf, f * kn, 1)
+        kf, vf = kf * vmask, vf * vmask                                                        # F.unfold zero-pads
+        kf = torch.cat((nk[:, :, None].expand(-1, -1, tpf, -1, -1), kf), dim=-2)
+        vf = torch.cat((nv[:, :, None].expand(-1, -1, tpf, -1, -1), vf), dim=-2)
+        nq = q.shape[-2]
+        qpad = (-nq) % tpf
+        qf = F.pad(q, (0, 0, 0, qpad)).reshape(b, h, -1, tpf, q.shape[-1])                     # b h F i d
+        sim = einsum('b h f i d, b h i j d -> b h f i j', qf, kf)
+        cm = context_mask.reshape(b, f, tpf)[:, :, idx].reshape(b, f, tpf, kn) & valid[None, None]
+        cm = F.pad(cm.permute(0, 2, 1, 3).reshape(b, 1, 1, tpf, f * kn), (1, 0), value=True)   # the null key is always visible
+        sim = sim.masked_fill(~cm, mask_value)
+        attn = sim.softmax(dim=-1, dtype=torch.float32)
+        attn = self.dropout(einsum('g h, b h f i j -> b g f i j', self.talking_heads.weight.reshape(h, h), attn))
+        out = einsum('b h f i j, b h i j d -> b h f i d', attn, vf)
+        out = out.permute(0, 2, 3, 1, 4).reshape(b, -1, h * out.shape[-1])
+        out = torch.cat((out_bos, out), dim=1)
+        return self.to_out(out[:, :n])
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -455,7 +573,9 @@ class Transformer(nn.Module):
             cross_attn = None
             if cross_attend:
                 if cross_2dna_attn:
-                    cross_attn = SparseCross2DNA()
+                    cross_attn = SparseCross2DNA(dim=dim, heads=heads, dim_head=dim_head, dropout=attn_dropout,
+                                                 image_size=cross_2dna_image_size, kernel_size=cross_2dna_kernel_size,
+                                                 dilation=cross_2dna_dilations[ind % len(cross_2dna_dilations)])
                 else:
                     cross_attn = Attention(dim=dim, heads=heads, dim_head=dim_head, dropout=attn_dropout)
             ff = FeedForward(dim=dim, mult=ff_mult, dropout=ff_dropout, chunk_size=ff_chunk_size)
@@ -668,7 +788,9 @@ class ReversibleTransformer(nn.Module):
             if not cross_attend:
                 continue
             if cross_2dna_attn:
-                cross_attn = SparseCross2DNA()
+                cross_attn = SparseCross2DNA(dim=dim, heads=heads, dim_head=dim_head, dropout=attn_dropout,
+                                             image_size=cross_2dna_image_size, kernel_size=cross_2dna_kernel_size,
+                                             dilation=cross_2dna_dilations[ind % len(cross_2dna_dilations)])
             else:
                 cross_attn = Attention(dim=dim, heads=heads, dim_head=dim_head, dropout=attn_dropout)
             self.layers.append(MList([
@@ -906,9 +1028,129 @@ class NUWA(nn.Module):
 
 
 class NUWASketch(nn.Module):
-    def __init__(self, *args, **kwargs):
+    """np.py:2297-2571 (row f4): identical constructor kwargs, forward() and generate() signatures.  The video decoder is the
+    same 3DNA stack as NUWA's (libamdnuwa kernels for Sparse3DNA, FeedForward, the norms, logits + loss); its cross-attention
+    is SparseCross2DNA over the sketch tokens and the sketch encoder is a plain (or, optionally, non-causal 3DNA) Transformer,
+    both on PyTorch-ROCm ops for now."""
+
+    def __init__(self, *, vae, sketch_vae, dim, image_size, max_video_frames=5, sketch_max_video_frames=2, sketch_enc_depth=6,
+                 sketch_enc_dim_head=64, sketch_enc_heads=8, sketch_enc_use_sparse_3dna=False, enc_reversible=False, dec_depth=6,
+                 dec_dim_head=64, dec_heads=8, dec_reversible=False, attn_dropout=0., ff_dropout=0., ff_chunk_size=None,
+                 embed_gradient_frac=0.2, shift_video_tokens=True, cross_2dna_kernel_size=3, cross_2dna_dilation=1,
+                 sparse_3dna_kernel_size=3, sparse_3dna_dilation=1, sparse_3dna_query_num_frames_chunk=None):
         super().__init__()
-        raise NotImplementedError('NUWASketch is outside this round (SURVEY.md section 8 row f4)')
+        self.image_size = image_size
+        self.sketch_vae = sketch_vae
+        sketch_fmap_size = image_size // (2 ** sketch_vae.num_layers)
+        sketch_shape = (sketch_max_video_frames, sketch_fmap_size, sketch_fmap_size)
+        self.sketch_max_video_frames = sketch_max_video_frames
+        self.sketch_embedding = Embedding(sketch_vae.codebook_size, dim, frac_gradient=embed_gradient_frac)
+        self.sketch_pos_emb = AxialPositionalEmbedding(dim, shape=sketch_shape)
+        sparse_3dna_dilations = tuple(range(1, sparse_3dna_dilation + 1)) if not isinstance(sparse_3dna_dilation, (list, tuple)) else sparse_3dna_dilation
+        enc_transformer_klass = Transformer if not enc_reversible else ReversibleTransformer
+        self.sketch_transformer = enc_transformer_klass(
+            dim=dim, depth=sketch_enc_depth, heads=sketch_enc_heads, dim_head=sketch_enc_dim_head, attn_dropout=attn_dropout,
+            ff_dropout=ff_dropout, shift_video_tokens=shift_video_tokens, sparse_3dna_video_shape=sketch_shape,
+            sparse_3dna_kernel_size=sparse_3dna_kernel_size, sparse_3dna_dilations=sparse_3dna_dilations,
+            sparse_3dna_query_num_frames_chunk=sparse_3dna_query_num_frames_chunk, sparse_3dna_attn=sketch_enc_use_sparse_3dna)
+        self.vae = vae.copy_for_eval()
+        self.video_bos = nn.Parameter(torch.randn(dim))
+        self.image_embedding = Embedding(vae.codebook_size, dim, frac_gradient=embed_gradient_frac)
+        fmap_size = image_size // (2 ** vae.num_layers)
+        assert fmap_size == sketch_fmap_size, 'feature map size of video must be equal to the feature map size of sketches (VAEs must have same number of layers)'
+        self.video_fmap_size = fmap_size
+        self.max_video_frames = max_video_frames
+        self.video_shape = (max_video_frames, fmap_size, fmap_size)
+        self.video_pos_emb = AxialPositionalEmbedding(dim, shape=self.video_shape)
+        cross_2dna_dilations = tuple(range(1, cross_2dna_dilation + 1)) if not isinstance(cross_2dna_dilation, (list, tuple)) else cross_2dna_dilation
+        dec_transformer_klass = Transformer if not dec_reversible else ReversibleTransformer
+        self.video_transformer = dec_transformer_klass(
+            dim=dim, depth=dec_depth, heads=dec_heads, dim_head=dec_dim_head, causal=True, cross_attend=True, cross_2dna_attn=True,
+            cross_2dna_image_size=fmap_size, cross_2dna_kernel_size=cross_2dna_kernel_size, cross_2dna_dilations=cross_2dna_dilations,
+            attn_dropout=attn_dropout, ff_dropout=ff_dropout, ff_chunk_size=ff_chunk_size, shift_video_tokens=shift_video_tokens,
+            sparse_3dna_video_shape=self.video_shape, sparse_3dna_kernel_size=sparse_3dna_kernel_size,
+            sparse_3dna_dilations=sparse_3dna_dilations, sparse_3dna_query_num_frames_chunk=sparse_3dna_query_num_frames_chunk,
+            sparse_3dna_attn=True)
+        self.to_logits = nn.Linear(dim, vae.codebook_size, bias=False)
+        self._cache = ops.WeightCache()
+
+    embed_video = NUWA.embed_video          # <bos> + positional + token embedding, one libamdnuwa node
+    _final = NUWA._final                    # final StableLayerNorm + logits (+ cross entropy), fused
+
+    def decode_hidden(self, frame_embeddings, sketch_embeds, context_mask):
+        return self.video_transformer.forward_layers(frame_embeddings, context=sketch_embeds, context_mask=context_mask)
+
+    def embed_sketch(self, sketch, mask=None):
+        batch, frames, device = sketch.shape[0], sketch.shape[1], sketch.device
+        if exists(mask):
+            assert mask.shape[:2] == (batch, frames), 'sketch mask must be in shape of (batch x frame)'
+        sketch_indices = self.sketch_vae.get_video_indices(sketch).reshape(batch, -1)
+        sketch_tokens = self.sketch_embedding(sketch_indices)
+        num_tokens = sketch_tokens.shape[1]
+        sketch_tokens = sketch_tokens + self.sketch_pos_emb()[:num_tokens]
+        if exists(mask):
+            mask = mask[:, :, None].expand(-1, -1, num_tokens // frames).reshape(batch, num_tokens)
+        else:
+            mask = torch.ones((batch, num_tokens), dtype=torch.bool, device=device)
+        return self.sketch_transformer(sketch_tokens, mask=mask), mask
+
+    @torch.no_grad()
+    @eval_decorator
+    def generate(self, *, sketch, sketch_mask=None, filter_thres=0.9, temperature=1., decode_max_batchsize=10, cond_scale=2.,
+                 num_frames=None):
+        """np.py:2438-2511: token-by-token with the whole prefix recomputed (and, for guidance, the normed conditioned output fed
+        to a sketch-masked second pass), as the reference does"""
+        if sketch.ndim == 4:
+            sketch = sketch[:, None]
+        batch, device = sketch.shape[0], sketch.device
+        sketch_embeds, context_mask = self.embed_sketch(sketch, mask=sketch_mask)
+        video_indices = torch.empty((batch, 0), device=device, dtype=torch.long)
+        tpf = self.video_fmap_size ** 2
+        num_frames = default(num_frames, self.max_video_frames)
+        total_video_tokens, max_video_tokens = tpf * num_frames, tpf * self.max_video_frames
+        for ind in range(total_video_tokens):
+            video_indices_input = video_indices
+            if video_indices.shape[1] > max_video_tokens:
+                curr = video_indices.shape[1] % tpf
+                video_indices_input = video_indices[:, -((self.max_video_frames - (0 if curr == 0 else 1)) * tpf + curr):]
+            hidden = self.decode_hidden(self.embed_video(video_indices_input), sketch_embeds, context_mask)
+            logits = self._final(hidden[:, -1:].contiguous())
+            if cond_scale != 1:
+                uncond = self.decode_hidden(self.video_transformer.norm(hidden), sketch_embeds, torch.zeros_like(context_mask).bool())
+                uncond_logits = self._final(uncond[:, -1:].contiguous())
+                logits = uncond_logits + (logits - uncond_logits) * cond_scale
+            sample = gumbel_sample(top_k(logits[:, -1], thres=filter_thres), temperature=temperature, dim=-1)
+            video_indices = torch.cat((video_indices, sample[:, None]), dim=1)
+        fs = self.video_fmap_size
+        codes = self.vae.codes_for_decoder(video_indices)
+        codes = codes.reshape(batch, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
+        decode = self.vae._hip_decode if codes.is_cuda else self.vae.decode
+        images = batch_process(codes.contiguous(), decode, chunks=decode_max_batchsize)
+        return images.reshape(batch, -1, *images.shape[1:])
+
+    def forward(self, *, sketch, sketch_mask=None, video=None, return_loss=False, cond_dropout_prob=0.2):
+        if sketch.ndim == 4:                              # one sketch frame
+            sketch = sketch[:, None]
+        batch, sketch_frames, device = sketch.shape[0], sketch.shape[1], sketch.device
+        assert sketch.shape[-1] == self.image_size, 'sketch image size must be equal'
+        assert sketch_frames <= self.sketch_max_video_frames, 'sketch frames must be less than max sketch video frames'
+        sketch_embeds, context_mask = self.embed_sketch(sketch, mask=sketch_mask)
+        if video.dtype == torch.long:                     # pre-tokenised video (as NUWA.forward accepts; the reference only takes frames)
+            frame_indices = video
+        else:
+            assert video.shape[1] == self.max_video_frames, f'you must give the full video frames ({self.max_video_frames}) during training'
+            frame_indices = self.vae.get_video_indices(video)
+        frame_indices = frame_indices.reshape(batch, -1)
+        frame_embeddings = self.embed_video(frame_indices[:, :-1] if return_loss else frame_indices)
+        if self.training and cond_dropout_prob > 0:
+            # the reference multiplies `sketch_mask` in place AFTER the decoder mask was derived from it (np.py:2551-2555), which
+            # drops nothing (and raises when sketch_mask is None); the evident intent -- drop the condition -- is applied here
+            uncond_mask = prob_mask_like((batch,), cond_dropout_prob, device=device)
+            context_mask = context_mask & ~uncond_mask[:, None]
+        hidden = self.decode_hidden(frame_embeddings, sketch_embeds, context_mask)
+        if not return_loss:
+            return self._final(hidden)
+        return self._final(hidden, frame_indices)
 
 
 # BASELINE cfg 5 (video + audio dual decoder) lives in its own module; re-exported here so that the names resolve where the

@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 from oracle import ref_shims  # noqa: E402
 
 ref_shims.install()
-from nuwa_pytorch import NUWA, NUWAVideoAudio, VQGanVAE  # noqa: E402
+from nuwa_pytorch import NUWA, NUWASketch, NUWAVideoAudio, VQGanVAE  # noqa: E402
 from nuwa_pytorch.nuwa_pytorch import (Sparse3DNA, Attention, FeedForward, SandwichNorm,  # noqa: E402
                                        ShiftVideoTokens, StableLayerNorm, Transformer, ReversibleTransformer, RotaryEmbedding)
 
@@ -254,6 +254,46 @@ def g9_video_audio(only=None):
              text_embeds=cap['ctx'], rel_pos_bias=rel, reversible=rev, **P, **G)
 
 
+SKETCH_KW = dict(dim=32, image_size=16, max_video_frames=3, sketch_max_video_frames=2, sketch_enc_depth=2, sketch_enc_dim_head=16,
+                 sketch_enc_heads=2, dec_depth=3, dec_dim_head=32, dec_heads=2, cross_2dna_kernel_size=3, cross_2dna_dilation=2,
+                 sparse_3dna_kernel_size=3, sparse_3dna_dilation=(1, 2))
+
+
+def g11_sketch():
+    """NUWASketch.forward(return_loss=True), tiny (row f4).  a: plain stacks, no sketch mask;  b: reversible encoder and decoder,
+    non-causal Sparse3DNA sketch encoder, second sketch frame of sample 1 masked.  The token ids the reference's (randomly
+    initialised) VAEs produced are recorded so that the decoder parity does not hinge on the tokenizer."""
+    for name, extra, use_mask in (('g11a_sketch', {}, False),
+                                  ('g11b_sketch_reversible_3dna', dict(enc_reversible=True, dec_reversible=True,
+                                                                       sketch_enc_use_sparse_3dna=True), True)):
+        torch.manual_seed(0)
+        vae = VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
+        sketch_vae = VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=48, vq_codebook_dim=32, use_vgg_and_gan=False)
+        m = NUWASketch(vae=vae, sketch_vae=sketch_vae, **{**SKETCH_KW, **extra})
+        torch.manual_seed(1)
+        sketch = torch.rand(2, 2, 3, 16, 16)
+        video = torch.rand(2, 3, 3, 16, 16)
+        smask = None
+        if use_mask:
+            smask = torch.ones(2, 2, dtype=torch.bool)
+            smask[1, 1] = False
+        cap = {}
+        hooks = [m.to_logits.register_forward_hook(lambda mod, i, o: cap.__setitem__('logits', o.detach())),
+                 m.sketch_transformer.register_forward_hook(lambda mod, i, o: cap.__setitem__('ctx', o.detach()))]
+        with torch.no_grad():
+            sketch_ids = m.sketch_vae.get_video_indices(sketch)
+            video_ids = m.vae.get_video_indices(video)
+        loss = m(sketch=sketch, sketch_mask=smask, video=video, return_loss=True, cond_dropout_prob=0.)
+        for h in hooks:
+            h.remove()
+        loss.backward()
+        P = {k: v for k, v in params(m).items() if '.net.blocks.' not in k and not k.startswith(('p.vae.', 'p.sketch_vae.'))}
+        G = {k: v for k, v in grads(m).items() if '.net.blocks.' not in k}
+        save(name, sketch_ids=sketch_ids, video_ids=video_ids, loss=loss, logits=cap['logits'], sketch_embeds=cap['ctx'],
+             sketch_mask=(smask if use_mask else torch.ones(2, 2, dtype=torch.bool)), has_mask=use_mask,
+             reversible=bool(extra), **P, **G)
+
+
 if __name__ == '__main__':
     g1_sparse3dna()
     g1b_sparse3dna_rel_pos_bias()
@@ -265,3 +305,4 @@ if __name__ == '__main__':
     g8_decoder_layer()
     g9_video_audio()
     g10_text_encoder()
+    g11_sketch()

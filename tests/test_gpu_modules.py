@@ -421,3 +421,57 @@ def test_cross_modality_attention_hip_equals_oracle(A, O_mod, n_seq, n_ctx, chun
             report(tag + f'.grad.{k}', gr, P[k].grad, 2e-3)
     finally:
         A.set_precision('bf16')
+
+
+SKETCH_KW = dict(dim=32, image_size=16, max_video_frames=3, sketch_max_video_frames=2, sketch_enc_depth=2, sketch_enc_dim_head=16,
+                 sketch_enc_heads=2, dec_depth=3, dec_dim_head=32, dec_heads=2, cross_2dna_kernel_size=3, cross_2dna_dilation=2,
+                 sparse_3dna_kernel_size=3, sparse_3dna_dilation=(1, 2))
+
+
+@pytest.mark.parametrize('mode,tol,gtol', MODES)
+@pytest.mark.parametrize('name', ['g11a_sketch', 'g11b_sketch_reversible_3dna'])
+def test_g11_sketch_loss_logits_grads(A, name, mode, tol, gtol):
+    """row f4: NUWASketch (sketch encoder, SparseCross2DNA decoder) loaded with the reference's state dict, against the
+    reference's loss, logits and every gradient.  The fixture carries the token ids of the reference's VAEs, so the tokenizer
+    (checked on its own by the g7 tests) is taken out of this comparison."""
+    Ar, P, G = load(name)
+    extra = dict(enc_reversible=True, dec_reversible=True, sketch_enc_use_sparse_3dna=True) if bool(Ar['reversible']) else {}
+    vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
+    sketch_vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=48, vq_codebook_dim=32, use_vgg_and_gan=False)
+    m = A.NUWASketch(vae=vae, sketch_vae=sketch_vae, **{**SKETCH_KW, **extra})
+    missing, unexpected = m.load_state_dict(P, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith(('vae.', 'sketch_vae.')) or '.net.blocks.' in k for k in missing), missing
+    m = m.to(DEV).train()
+    sketch_ids = Ar['sketch_ids'].to(DEV)
+    m.sketch_vae.get_video_indices = lambda frames: sketch_ids
+    run_mode(A, mode)
+    try:
+        sketch = torch.zeros(2, 2, 3, 16, 16, device=DEV)
+        smask = Ar['sketch_mask'].to(DEV) if bool(Ar['has_mask']) else None
+        vid = Ar['video_ids'].to(DEV)
+        logits = m(sketch=sketch, sketch_mask=smask, video=vid.reshape(2, -1)[:, :-1], return_loss=False, cond_dropout_prob=0.)
+        report(f'{name}[{mode}].logits', logits, Ar['logits'], tol)
+        loss = m(sketch=sketch, sketch_mask=smask, video=vid, return_loss=True, cond_dropout_prob=0.)
+        report(f'{name}[{mode}].loss', loss.reshape(1), Ar['loss'].reshape(1), tol)
+        loss.backward()
+        n = check_grads(m, G, gtol * 2, f'{name}[{mode}]', skip=('.net.blocks.',))
+        assert n > 40
+    finally:
+        A.set_precision('bf16')
+
+
+def test_sketch_generate_shapes(A):
+    """NUWASketch.generate (np.py:2438-2511): recompute loop on the HIP decoder, greedy sampling is deterministic"""
+    torch.manual_seed(5)
+    vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
+    sketch_vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=48, vq_codebook_dim=32, use_vgg_and_gan=False)
+    m = A.NUWASketch(vae=vae, sketch_vae=sketch_vae, **SKETCH_KW).to(DEV).eval()
+    sketch = torch.rand(1, 2, 3, 16, 16, generator=torch.Generator().manual_seed(1)).to(DEV)
+    A.set_precision('bf16x3')
+    try:
+        a = m.generate(sketch=sketch, filter_thres=0.99, num_frames=1, cond_scale=2.)
+        b = m.generate(sketch=sketch, filter_thres=0.99, num_frames=1, cond_scale=2.)
+    finally:
+        A.set_precision('bf16')
+    assert a.shape == (1, 1, 3, 16, 16) and bool(torch.isfinite(a).all()) and torch.equal(a, b)
