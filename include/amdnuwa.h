@@ -100,6 +100,17 @@ int amdnuwa_ln_post_pre_fwd(const float* y, const float* resid, const float* w, 
                             float* mean, float* rstd, const float* next_w, const float* next_b, uint16_t* h_hi,
                             uint16_t* h_lo, float* next_mean, float* next_rstd, long long R, int D, int flags, float eps,
                             int shift_ntok, int shift_fmap, amdnuwa_stream stream);
+/* Chained backward across a block boundary (the mirror of amdnuwa_ln_post_pre_fwd): the pre-norm backward of block k+1,
+ *   dx = g + dLN(dh; x, mean, rstd, w)        (dh read through the inverse token shift when shift_ntok > 0; dw, db its weight grads)
+ * and, on the same row while it is in registers, the post-norm backward of block k,
+ *   dy_prev = dLN(dx; y_prev, mean_prev, rstd_prev, w_prev)   (bf16 hi[/lo]; dw_prev, db_prev; dsum_prev = column sums, optional).
+ * inputs_bf16 != 0: dh and y_prev point at bf16 values (fast mode), else fp32. */
+size_t amdnuwa_ln_bwd_chain_workspace_bytes(long long R, int D);
+int amdnuwa_ln_bwd_chain(const void* dh, const float* x, const float* mean, const float* rstd, const float* w, const float* g,
+                         float* dx, float* dw, float* db, const void* y_prev, const float* mean_prev, const float* rstd_prev,
+                         const float* w_prev, uint16_t* dy_prev_hi, uint16_t* dy_prev_lo, float* dw_prev, float* db_prev,
+                         float* dsum_prev, long long R, int D, int shift_ntok, int shift_fmap, int inputs_bf16, void* workspace,
+                         size_t workspace_bytes, amdnuwa_stream stream);
 size_t amdnuwa_ln_bwd_workspace_bytes(long long R, int D);
 /* dy fp32; shift_ntok > 0 reads dy through the inverse token shift.  Exactly one of dx_hi (bf16
  * hi[/lo] output) / dx_acc (fp32) is non-NULL; dx_acc = (dres ? dres : dx_acc) + dx.  dw, db, dsum

@@ -60,6 +60,8 @@ SIGNATURES = {
     'amdnuwa_gemm_tn_workspace_bytes': (SZ, [GD]),
     'amdnuwa_gemm_tn': (I, [GD, P, SZ, P]),
     'amdnuwa_ln_fwd': (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, I, I, P]),
+    'amdnuwa_ln_bwd_chain_workspace_bytes': (SZ, [LL, I]),
+    'amdnuwa_ln_bwd_chain': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, I, P, SZ, P]),
     'amdnuwa_ln_post_pre_fwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, F, I, I, P]),
     'amdnuwa_ln_bwd_workspace_bytes': (SZ, [LL, I]),
     'amdnuwa_ln_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, I, I, P, SZ, P]),

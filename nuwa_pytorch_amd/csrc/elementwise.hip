@@ -306,6 +306,137 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Chained LayerNorm backward across a block boundary: the pre-norm backward of block k+1 produces the residual-stream gradient
+// row  dx = g + dLN_pre(dh)  and, while that row is still in registers, the post-norm backward of block k consumes it
+// (dy_prev = dLN_post(dx)) -- the second read of dx by a separate kernel disappears.
+//   dh (fp32 / bf16, read through the inverse token shift of block k+1), x = stream row (LN input of block k+1), g = gradient of
+//   block k+1's output;  y_prev = inner output of block k (post-norm input).
+// Partials: partA [nblk][3][D] = (dw_pre, db_pre, -) and partB [nblk][3][D] = (dw_post, db_post, sum(dy_prev)).
+// ---------------------------------------------------------------------------------------------
+template <int NV, bool BF>
+__global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+                                                           const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                           const float* __restrict__ w, const float* __restrict__ gres,
+                                                           float* __restrict__ dx_out, const float* __restrict__ yprev,
+                                                           const float* __restrict__ meanp_i, const float* __restrict__ rstdp_i,
+                                                           const float* __restrict__ wprev, bf16_t* __restrict__ dyp_hi,
+                                                           bf16_t* __restrict__ dyp_lo, float* __restrict__ partA,
+                                                           float* __restrict__ partB, long long R, int D, int shift_ntok,
+                                                           int shift_fmap) {
+    __shared__ float red[ROWS_PER_BLOCK][3][NV * 256];
+    const int lane = threadIdx.x & 63, wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4 pwA[NV], pbA[NV], pwB[NV], pbB[NV], psB[NV];
+#pragma unroll
+    for (int it = 0; it < NV; ++it) pwA[it] = pbA[it] = pwB[it] = pbB[it] = psB[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int quarter = D >> 2;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    struct RowIn { RowValsT<NV> xv, gv, rv, yv; float mean, rstd, meanp, rstdp; };
+    auto load_row = [&](long long row, RowIn& in) {
+        row_load(x + row * D, D, lane, in.xv);
+        if (shift_ntok > 0) {
+            const int i = (int)(row % shift_ntok);
+            long long src_h = -1, src_w = -1;
+            if (i > 0) {
+                const int p = i - 1, wq = p % shift_fmap, yq = (p / shift_fmap) % shift_fmap;
+                if (yq < shift_fmap - 1 && i + shift_fmap < shift_ntok) src_h = row + shift_fmap;
+                if (wq < shift_fmap - 1 && i + 1 < shift_ntok) src_w = row + 1;
+            }
+#pragma unroll
+            for (int it = 0; it < NV; ++it) {
+                const int e = (lane + it * 64) * 4;
+                if (e >= D) { in.gv.v[it] = zero4; continue; }
+                long long src = row;
+                if (i > 0) { const int qd = e / quarter; if (qd == 0) src = src_h; else if (qd == 1) src = src_w; }
+                in.gv.v[it] = src >= 0 ? ld4<BF>(dh, (size_t)src * D + e) : zero4;
+            }
+        } else {
+            row_load_t<BF>(dh, (size_t)row * D, D, lane, in.gv);
+        }
+        row_load(gres + row * D, D, lane, in.rv);
+        row_load_t<BF>(yprev, (size_t)row * D, D, lane, in.yv);
+        in.mean = mean_i[row]; in.rstd = rstd_i[row]; in.meanp = meanp_i[row]; in.rstdp = rstdp_i[row];
+    };
+    const long long stride = (long long)gridDim.x * ROWS_PER_BLOCK;
+    long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + wv_;
+    RowIn cur, nxt;
+    if (row < R) load_row(row, cur);
+    for (; row < R; row += stride) {
+        const bool more = row + stride < R;
+        if (more) load_row(row + stride, nxt);
+        // ---- pre-norm backward of block k+1 -> dx
+        float s1 = 0.f, s2 = 0.f;
+        float4 xh[NV], g[NV];
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int e = (lane + it * 64) * 4;
+            if (e >= D) { xh[it] = g[it] = zero4; continue; }
+            const float4 wv = *reinterpret_cast<const float4*>(w + e);
+            const float4 xx = cur.xv.v[it], gg = cur.gv.v[it];
+            xh[it] = make_float4((xx.x - cur.mean) * cur.rstd, (xx.y - cur.mean) * cur.rstd, (xx.z - cur.mean) * cur.rstd, (xx.w - cur.mean) * cur.rstd);
+            g[it] = make_float4(gg.x * wv.x, gg.y * wv.y, gg.z * wv.z, gg.w * wv.w);
+            s1 += (g[it].x + g[it].y) + (g[it].z + g[it].w);
+            s2 += (g[it].x * xh[it].x + g[it].y * xh[it].y) + (g[it].z * xh[it].z + g[it].w * xh[it].w);
+            pwA[it].x += gg.x * xh[it].x; pwA[it].y += gg.y * xh[it].y; pwA[it].z += gg.z * xh[it].z; pwA[it].w += gg.w * xh[it].w;
+            pbA[it].x += gg.x; pbA[it].y += gg.y; pbA[it].z += gg.z; pbA[it].w += gg.w;
+        }
+        const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
+        float4 dx[NV];
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int e = (lane + it * 64) * 4;
+            if (e >= D) { dx[it] = zero4; continue; }
+            const float4 o = cur.rv.v[it];
+            dx[it] = make_float4(o.x + cur.rstd * (g[it].x - m1 - xh[it].x * m2), o.y + cur.rstd * (g[it].y - m1 - xh[it].y * m2),
+                                 o.z + cur.rstd * (g[it].z - m1 - xh[it].z * m2), o.w + cur.rstd * (g[it].w - m1 - xh[it].w * m2));
+            *reinterpret_cast<float4*>(dx_out + row * D + e) = dx[it];
+        }
+        // ---- post-norm backward of block k on the row just produced -> dy_prev
+        s1 = 0.f; s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int e = (lane + it * 64) * 4;
+            if (e >= D) { xh[it] = g[it] = zero4; continue; }
+            const float4 wv = *reinterpret_cast<const float4*>(wprev + e);
+            const float4 yy = cur.yv.v[it], gg = dx[it];
+            xh[it] = make_float4((yy.x - cur.meanp) * cur.rstdp, (yy.y - cur.meanp) * cur.rstdp, (yy.z - cur.meanp) * cur.rstdp, (yy.w - cur.meanp) * cur.rstdp);
+            g[it] = make_float4(gg.x * wv.x, gg.y * wv.y, gg.z * wv.z, gg.w * wv.w);
+            s1 += (g[it].x + g[it].y) + (g[it].z + g[it].w);
+            s2 += (g[it].x * xh[it].x + g[it].y * xh[it].y) + (g[it].z * xh[it].z + g[it].w * xh[it].w);
+            pwB[it].x += gg.x * xh[it].x; pwB[it].y += gg.y * xh[it].y; pwB[it].z += gg.z * xh[it].z; pwB[it].w += gg.w * xh[it].w;
+            pbB[it].x += gg.x; pbB[it].y += gg.y; pbB[it].z += gg.z; pbB[it].w += gg.w;
+        }
+        const float n1 = wave_sum(s1) / D, n2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int e = (lane + it * 64) * 4;
+            if (e >= D) continue;
+            const float d0 = cur.rstdp * (g[it].x - n1 - xh[it].x * n2), d1 = cur.rstdp * (g[it].y - n1 - xh[it].y * n2);
+            const float d2 = cur.rstdp * (g[it].z - n1 - xh[it].z * n2), d3 = cur.rstdp * (g[it].w - n1 - xh[it].w * n2);
+            psB[it].x += d0; psB[it].y += d1; psB[it].z += d2; psB[it].w += d3;
+            store_bf16x4(dyp_hi + row * D, dyp_lo ? dyp_lo + row * D : nullptr, e, d0, d1, d2, d3);
+        }
+        if (more) cur = nxt;
+    }
+    // block reduce the 4 waves' partials in fixed order, one LayerNorm at a time through the same LDS
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int e = (lane + it * 64) * 4;
+            *reinterpret_cast<float4*>(&red[wv_][0][e]) = pass ? pwB[it] : pwA[it];
+            *reinterpret_cast<float4*>(&red[wv_][1][e]) = pass ? pbB[it] : pbA[it];
+            *reinterpret_cast<float4*>(&red[wv_][2][e]) = pass ? psB[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        float* part = pass ? partB : partA;
+        for (int idx = threadIdx.x; idx < 3 * D; idx += 256) {
+            const int k = idx / D, c = idx % D;
+            part[((size_t)blockIdx.x * 3 + k) * D + c] = ((red[0][k][c] + red[1][k][c]) + red[2][k][c]) + red[3][k][c];
+        }
+    }
+}
+
 // column sums of an fp32 [R, D] matrix -> partial[blk][D] (slot k = 0 of a 1-row partial layout)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ partial, long long R, int D) {
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
@@ -753,6 +884,37 @@ extern "C" int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean
 #undef LNB_OCC
     LAUNCH_CHECK();
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((3 * D + 15) / 16), dim3(1024), 0, stream, part, nb, 3, D, dw, db, dsum, accumulate);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" size_t amdnuwa_ln_bwd_chain_workspace_bytes(long long R, int D) { return 2 * amdnuwa_ln_bwd_workspace_bytes(R, D); }
+
+extern "C" int amdnuwa_ln_bwd_chain(const void* dh, const float* x, const float* mean, const float* rstd, const float* w,
+                                    const float* g, float* dx, float* dw, float* db, const void* y_prev, const float* mean_prev,
+                                    const float* rstd_prev, const float* w_prev, uint16_t* dy_prev_hi, uint16_t* dy_prev_lo,
+                                    float* dw_prev, float* db_prev, float* dsum_prev, long long R, int D, int shift_ntok,
+                                    int shift_fmap, int inputs_bf16, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!dh || !x || !mean || !rstd || !w || !g || !dx || !y_prev || !mean_prev || !rstd_prev || !w_prev || !dy_prev_hi)
+        return AMDNUWA_ERR_ARG;
+    if (D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
+    if (shift_ntok > 0 && (shift_fmap <= 0 || D % 16)) return AMDNUWA_ERR_ARG;
+    if (!workspace || workspace_bytes < amdnuwa_ln_bwd_chain_workspace_bytes(R, D)) return AMDNUWA_ERR_WORKSPACE;
+    if (R <= 0) return AMDNUWA_OK;
+    int nb = ln_bwd_blocks(R);
+    float* partA = (float*)workspace;
+    float* partB = partA + (size_t)ln_bwd_blocks(R) * 3 * D;
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+#define LBC_(NV_, BF_) do { int o_ = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_, ln_bwd_chain_kernel<NV_, BF_>, 256, 0) == hipSuccess && o_ > 0 && o_ * n_cu < nb) nb = o_ * n_cu; \
+        hipLaunchKernelGGL((ln_bwd_chain_kernel<NV_, BF_>), dim3(nb), dim3(256), 0, stream, (const float*)dh, x, mean, rstd, w, g, dx, (const float*)y_prev, mean_prev, rstd_prev, w_prev, dy_prev_hi, dy_prev_lo, partA, partB, R, D, shift_ntok, shift_fmap); } while (0)
+#define LBC(NV_) do { if (inputs_bf16) LBC_(NV_, true); else LBC_(NV_, false); } while (0)
+    if (D <= 256) LBC(1); else if (D <= 512) LBC(2); else LBC(4);
+#undef LBC
+#undef LBC_
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * D + 15) / 16), dim3(1024), 0, stream, partA, nb, 3, D, dw, db, (float*)nullptr, 0);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((3 * D + 15) / 16), dim3(1024), 0, stream, partB, nb, 3, D, dw_prev, db_prev, dsum_prev, 0);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

@@ -237,6 +237,26 @@ def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift
     return dx, dw, db, ds
 
 
+def ln_bwd_chain(dh, x, mean, rstd, w, g, y_prev, mean_prev, rstd_prev, w_prev, *, shift=None, want_dsum=False):
+    """pre-norm backward of a block and the post-norm backward of the block before it in one pass over the gradient row.
+    dh, y_prev: both fp32 tensors or both hi-only BF pairs.  returns (dx fp32, dw, db, dy_prev BF, dw_prev, db_prev, dsum_prev)"""
+    L = _lib.lib()
+    dhp, dhbf, _, _ = _f32_or_bf(dh)
+    yp, ybf, (R, D), dev = _f32_or_bf(y_prev)
+    assert dhbf == ybf, 'ln_bwd_chain: dh and y_prev must have the same storage form'
+    dx = torch.empty((R, D), dtype=torch.float32, device=dev)
+    dw, db, dwp, dbp = (torch.empty(D, dtype=torch.float32, device=dev) for _ in range(4))
+    dsp = torch.empty(D, dtype=torch.float32, device=dev) if want_dsum else None
+    dyp = empty_bf((R, D), dev)
+    nb = L.amdnuwa_ln_bwd_chain_workspace_bytes(R, D)
+    ws = workspace(nb, dev)
+    sn, sf = (int(shift[0]), int(shift[1])) if shift is not None else (0, 0)
+    check(L.amdnuwa_ln_bwd_chain(dhp, _p(x), _p(mean), _p(rstd), _p(w), _p(g), _p(dx), _p(dw), _p(db), yp, _p(mean_prev),
+                                 _p(rstd_prev), _p(w_prev), _p(dyp.hi), _p(dyp.lo), _p(dwp), _p(dbp), _p(dsp), R, D, sn, sf,
+                                 1 if ybf else 0, _p(ws), nb, _stream()), 'amdnuwa_ln_bwd_chain')
+    return dx, dw, db, dyp, dwp, dbp, dsp
+
+
 def colsum(x):
     L = _lib.lib()
     R, D = x.shape

@@ -255,6 +255,7 @@ class FFInner:
 
 INNERS = {'s3': S3Inner, 'xattn': XInner, 'ff': FFInner}
 
+CHAIN_BWD = os.environ.get('AMDNUWA_CHAIN_BWD', '1') != '0'      # chain the LayerNorm backwards across block boundaries (A/B switch)
 ASYNC_WGRAD = os.environ.get('AMDNUWA_ASYNC_WGRAD', '0') != '0'      # opt-in: measured neutral on MI355X (the split-K GEMM fills every CU)
 _SIDE = {}
 
@@ -330,9 +331,11 @@ class SandwichBlockFn(Function):
         # block chaining (Transformer.forward_layers): the previous block's post-norm kernel may already have produced this
         # block's h = shift(LN(x)) while the new stream row was in its registers, and this block does the same for the next
         hin, nxt, hout = meta.pop('handoff_in', None), meta.pop('next_pre', None), meta.pop('handoff_out', None)
+        ctx.prev_ctx = None
         if hin is not None and hin.get('ptr') == x.data_ptr() and hin.get('ver') == x._version and hin.get('shift') == sh \
                 and resid is None and tuple(hin['h'].hi.shape) == (B * n, D):
             h, m1, r1 = hin['h'], hin['m1'], hin['r1']
+            ctx.prev_ctx = hin.get('ctx')          # the backward chains the two LayerNorm backwards of this boundary too
         else:
             h, m1, r1, _ = K.ln_fwd(x2, pre_w.detach(), pre_b.detach(), shift=sh)
         ctx.shift = sh
@@ -342,7 +345,7 @@ class SandwichBlockFn(Function):
         if nxt is not None and hout is not None:
             xo, m2, r2, hn, mn, rn = K.ln_post_pre_fwd(y, r2_, post_w.detach(), post_b.detach(), nxt[0].detach(),
                                                        nxt[1].detach(), next_shift=nxt[2])
-            hout.update(h=hn, m1=mn, r1=rn, ptr=xo.data_ptr(), ver=xo._version, shift=nxt[2])
+            hout.update(h=hn, m1=mn, r1=rn, ptr=xo.data_ptr(), ver=xo._version, shift=nxt[2], ctx=ctx if CHAIN_BWD else None)
         else:
             xo, m2, r2 = K.ln_fwd(y, post_w.detach(), post_b.detach(), resid=r2_)
         ctx.meta, ctx.inner_saved, ctx.p = meta, saved, p
@@ -363,14 +366,28 @@ class SandwichBlockFn(Function):
         inner = INNERS[meta['kind']]
         g2 = g.contiguous().reshape(B * n, D)
         want_bias = meta['kind'] == 's3'
-        dy, dpost_w, dpost_b, dsum = K.ln_bwd(g2, y, m2, r2, post_w.detach(), to_bf=True, want_dsum=want_bias)
+        ho, ctx.bwd_handoff = getattr(ctx, 'bwd_handoff', None), None
+        if ho is not None and ho['ptr'] == g2.data_ptr() and ho['ver'] == g2._version:   # the next block's backward already ran this post-norm backward
+            dy, dpost_w, dpost_b, dsum = ho['dy'], ho['dw'], ho['db'], ho['dsum']
+        else:
+            dy, dpost_w, dpost_b, dsum = K.ln_bwd(g2, y, m2, r2, post_w.detach(), to_bf=True, want_dsum=want_bias)
         meta = dict(meta)
         wg = meta['wg'] = WgradStream(g.device)
         dh, dctx, grads = inner.bwd(ctx.inner_saved, dy, p, meta, need_dbias=False)
         if want_bias:
             grads[4] = dsum                      # to_out.bias grad = column sums of d(to_out output)
-        dx, dpre_w, dpre_b, _ = K.ln_bwd(dh, x2, m1, r1, pre_w.detach(), dres=None if ctx.has_resid else g2,
-                                         shift=ctx.shift)
+        prev = ctx.prev_ctx
+        if prev is not None and not ctx.has_resid and isinstance(dh, K.BF) == prev.y_bf and (not isinstance(dh, K.BF) or dh.lo is None):
+            # pre-norm backward of this block + post-norm backward of the previous block on the same gradient row
+            _, py, _, _, pm2, pr2, _, ppost_w = prev.saved_tensors
+            dx, dpre_w, dpre_b, dyp, dwp, dbp, dsp = K.ln_bwd_chain(
+                dh, x2, m1, r1, pre_w.detach(), g2, K.BF(py, None) if prev.y_bf else py, pm2, pr2, ppost_w.detach(),
+                shift=ctx.shift, want_dsum=prev.meta['kind'] == 's3')
+            prev.bwd_handoff = dict(ptr=dx.data_ptr(), ver=dx._version, dy=dyp, dw=dwp, db=dbp, dsum=dsp)
+        else:
+            dx, dpre_w, dpre_b, _ = K.ln_bwd(dh, x2, m1, r1, pre_w.detach(), dres=None if ctx.has_resid else g2,
+                                             shift=ctx.shift)
+        ctx.prev_ctx = None
         dcontext = None
         if ctx.has_ctx:
             T = meta['xgeom'].T

@@ -203,6 +203,58 @@ def test_layernorm_post_pre_chain(K, O, B, ntok, fmap, D, ybf):
     report(f'ln_post_pre.h[{R},{D}]', bf_value(h).reshape(B, ntok, D), h_ref, 8e-3)
 
 
+@pytest.mark.parametrize('B,ntok,fmap,D,bf', [(2, 23, 4, 32, False), (3, 17, 4, 512, True), (2, 10, None, 1024, True),
+                                                 (1, 5, None, 64, False)])
+def test_layernorm_bwd_chain(K, O, B, ntok, fmap, D, bf):
+    """pre-norm backward of block k+1 and post-norm backward of block k in one pass: same dx / dy_prev as the two separate
+    kernels (bit for bit), weight gradients equal up to the order of the per-workgroup partial sums, all equal to autograd"""
+    torch.manual_seed(12)
+    R = B * ntok
+    shift = (ntok, fmap) if fmap else None
+    x = torch.randn(R, D) * 1.3 + 0.1
+    yprev = torch.randn(R, D)
+    dh = torch.randn(R, D)
+    g = torch.randn(R, D)
+    if bf:
+        yprev, dh = yprev.bfloat16().float(), dh.bfloat16().float()
+    w, w_prev = torch.randn(D), torch.randn(D)
+    # autograd reference:  x is the stream row; h = shift(LN(x; w)) receives dh; the row also receives g directly.
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    h = F.layer_norm(xr, (D,), wr, torch.zeros(D)).reshape(B, ntok, D)
+    if fmap:
+        h = O.shift_video_tokens(h, fmap)
+    (h.reshape(R, D) * dh).sum().backward()
+    dx_ref = g + xr.grad
+    yr = yprev.clone().requires_grad_(True)
+    wpr = w_prev.clone().requires_grad_(True)
+    bpr = torch.zeros(D, requires_grad=True)
+    (F.layer_norm(yr, (D,), wpr, bpr) * dx_ref).sum().backward()
+    dev = lambda t: t.to(DEV)
+    xd = dev(x)
+    _, m1, r1, _ = K.ln_fwd(xd, dev(w), dev(torch.zeros(D)))
+    zero = torch.zeros(R, D, device=DEV)
+    _, m2, r2 = K.ln_fwd(dev(yprev), dev(w_prev), dev(torch.zeros(D)), resid=zero)
+    K.set_precision('bf16' if bf else 'bf16x3')
+    try:
+        def form(t):
+            return K.BF(dev(t).bfloat16(), None) if bf else dev(t)
+        dx, dw, db, dyp, dwp, dbp, dsp = K.ln_bwd_chain(form(dh), xd, m1, r1, dev(w), dev(g), form(yprev), m2, r2, dev(w_prev),
+                                                        shift=shift, want_dsum=True)
+        dx_a, dw_a, db_a, _ = K.ln_bwd(form(dh), xd, m1, r1, dev(w), dres=dev(g), shift=shift)
+        dy_a, dwp_a, dbp_a, dsp_a = K.ln_bwd(dx_a, form(yprev), m2, r2, dev(w_prev), to_bf=True, want_dsum=True)
+    finally:
+        K.set_precision('bf16')
+    assert torch.equal(dx, dx_a) and torch.equal(dyp.hi, dy_a.hi)
+    for nm, u, v in (('dw', dw, dw_a), ('db', db, db_a), ('dwp', dwp, dwp_a), ('dbp', dbp, dbp_a), ('dsp', dsp, dsp_a)):
+        report(f'ln_bwd_chain.{nm}[{R},{D}]', u, v, 2e-6)
+    report(f'ln_bwd_chain.dx[{R},{D}]', dx, dx_ref, 2e-5)
+    report(f'ln_bwd_chain.dy_prev[{R},{D}]', bf_value(dyp), yr.grad, 2 ** -7 if bf else 3e-5)
+    report(f'ln_bwd_chain.dw[{R},{D}]', dw, wr.grad, 2e-5)
+    report(f'ln_bwd_chain.dw_prev[{R},{D}]', dwp, wpr.grad, 2e-5)
+    report(f'ln_bwd_chain.db_prev[{R},{D}]', dbp, bpr.grad, 2e-5)
+
+
 def test_layernorm_bwd_inverse_shift(K, O):
     torch.manual_seed(5)
     B, ntok, fmap, D = 2, 23, 4, 32
