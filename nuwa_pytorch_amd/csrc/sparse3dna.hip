@@ -37,9 +37,19 @@ struct S3Args {
     int B, ntok, F, H, W, kf, kh, kw, df, dh, dw, NH;
     float scale;
     int accumulate;
+    int dbg;                                              // probe only (tuning key 9): bit 0 / 1 / 2 skip phase 1 / 2 / 3 of the MFMA forward
 };
 
 constexpr float NEG_MAX = -3.4028234663852886e38f;
+
+// Workgroups are handed to the 8 XCDs round-robin by linear id; every XCD has its own L2.  Consecutive query rows share
+// almost all of their key / value rows, so the logical row id is remapped to give each XCD one CONTIGUOUS range of rows
+// (whole samples): its L2 then holds the few frames in flight instead of an eighth of everything (bijective for any grid).
+__device__ __forceinline__ int xcd_row_id() {
+    const int nb = gridDim.x, id = blockIdx.x, per = nb >> 3, rem = nb & 7, x = id & 7, k = id >> 3;
+    return x * per + (x < rem ? x : rem) + k;
+}
+
 
 // hs = element stride between the 8-element halves of a chunk (8 = contiguous; the LDS stage keeps the two
 // 16-byte halves of every chunk in separate regions so that ds_read_b128 lanes are 16 bytes apart: no conflicts)
@@ -246,7 +256,8 @@ __global__ __launch_bounds__(512, 4) void s3_fwd_kernel(S3Args a) {
     const int t = threadIdx.x, c = t & 3, wh = t >> 2, h = wh % a.NH, w = wh / a.NH;
     const bool act = w < a.W;
     const int rows = a.F * a.H;
-    const int b = blockIdx.x / rows, ry = blockIdx.x % rows, f = ry / a.H, y = ry % a.H;
+    const int bid = xcd_row_id();
+    const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
     const int i = 1 + ry * a.W + w;
     const bool qvalid = act && i < a.ntok;
     if (t < a.NH * a.NH) wsh[t] = a.wth[t];
@@ -327,14 +338,15 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_kernel(S3Args a) {
     const int t = threadIdx.x, c = t & 3, wh = t >> 2, h = wh % a.NH, w = wh / a.NH;
     const bool act = w < a.W;
     const int rows = a.F * a.H, inner = a.NH * DH;
-    const int b = blockIdx.x / rows, ry = blockIdx.x % rows, f = ry / a.H, y = ry % a.H;
+    const int bid = xcd_row_id();
+    const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
     const int i = 1 + ry * a.W + w;
     const bool qvalid = act && i < a.ntok;
     const int nq = a.ntok - 1;
     if (t < a.NH * a.NH) wsh[t] = a.wth[t];
-    float* pth = a.part_th + (size_t)blockIdx.x * a.NH * a.NH;
-    float* pk0 = a.part_k0 + (size_t)blockIdx.x * inner;
-    float* pv0 = a.part_v0 + (size_t)blockIdx.x * inner;
+    float* pth = a.part_th + (size_t)bid * a.NH * a.NH;
+    float* pk0 = a.part_k0 + (size_t)bid * inner;
+    float* pv0 = a.part_v0 + (size_t)bid * inner;
     if (ry == 0) {   // dq of the <bos> row is zero (its query is never used)
         for (int e = t; e < inner; e += blockDim.x) {
             const size_t go = ((size_t)b * a.ntok) * a.ldd + e;
@@ -529,7 +541,8 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
     const int t = threadIdx.x, c = t & 3, wh = t >> 2, h = wh % a.NH, w = wh / a.NH;
     const bool act = w < a.W;
     const int rows = a.F * a.H;
-    const int b = blockIdx.x / rows, ry = blockIdx.x % rows, f = ry / a.H, y = ry % a.H;
+    const int bid = xcd_row_id();
+    const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
     const int ik = 1 + ry * a.W + w;                 // key row index inside the sample
     const bool kvalid = act && ik < a.ntok;
     const int nq = a.ntok - 1;
@@ -693,6 +706,231 @@ int check_geom(const amdnuwa_s3_geom* g) {
     if (g->ntok < 1 || g->ntok - 1 > g->F * g->H * g->W) return AMDNUWA_ERR_ARG;
     return AMDNUWA_OK;
 }
+// ---------------------------------------------------------------------------------------------
+// MFMA forward (fast bf16 mode, W == 16, 8 heads x 64): one workgroup = one query row of the grid, wave h = head h.
+//   phase 1  scores: for every causal tap plane the 16 keys of that grid row go STRAIGHT from global memory into the A operand
+//            (S^T = K . Q^T, 2 x v_mfma_f32_16x16x32_bf16 per plane); a lane then owns 4 keys of one query and drops the
+//            entries that lie on the kw tap diagonals into the compact score table SP[w][j][h] in LDS.  No LDS staging and no
+//            workgroup barrier inside the sweep: the eight waves run free.
+//   phase 2  fp32 softmax over the J slots and the talking-heads mix, in place (as the VALU kernel does).
+//   phase 3  O^T = V^T . P'^T: the value rows of TWO planes (32 keys) are staged in a wave-private 4 KiB LDS tile and read back
+//            transposed (ds_read_b64_tr_b16) as the A operand; the banded P' of the lane's 8 key slots is rebuilt from SP.
+// Instruction count per wave is ~3x below the dot2 kernel's and the only workgroup barriers are the two around phase 2.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+__device__ __forceinline__ int vt_off(int row, int gc) { return row * 128 + ((gc ^ (row & 7)) << 4); }
+__device__ __forceinline__ bf16x8 vt_tr(const char* tile, int db, int c, int g4) {
+    // lane (c, g4) gets tile[kb*16 + 4*g4 + j][db*16 + c], j = 0..3, kb = 0, 1
+    const int col = db * 16 + ((c & 3) << 2);
+    const int r0 = 4 * g4 + (c >> 2), r1 = 16 + r0;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + vt_off(r0, col >> 3) + ((col >> 2) & 1) * 8));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + vt_off(r1, col >> 3) + ((col >> 2) & 1) * 8));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 ldg8(const bf16_t* p, bool ok) {
+    return __builtin_bit_cast(bf16x8, ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0));
+}
+
+constexpr int S3M_KW = 3;        // widest tap row the MFMA kernel handles
+constexpr int S3M_PLANES = 64;   // kf * kh limit (plane list in LDS)
+
+__global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
+    constexpr int NH = 8, DH = 64, W = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int J = a.kf * a.kh * a.kw + 1;
+    float* SP = reinterpret_cast<float*>(smem);                                  // [W][J][NH]
+    char* vt_base = smem + (size_t)W * J * NH * sizeof(float);                   // 8 wave-private [32][64] bf16 tiles
+    __shared__ float wsh[64];
+    // valid planes of this query row: slot (first key slot j of the plane) and token row of its key 0; entry [S3M_PLANES] = count
+    __shared__ int pslot[S3M_PLANES + 1], ptok[S3M_PLANES + 1];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g4 = lane >> 4;
+    const int rows = a.F * a.H;
+    const int bid = xcd_row_id();
+    const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
+    if (t < NH * NH) wsh[t] = a.wth[t];
+    if (ry == 0) {                                                               // <bos> output row = its own value
+        for (int e = t; e < NH * DH; e += blockDim.x)
+            a.o[((size_t)b * a.ntok) * a.ldo + e] = a.v[((size_t)b * a.ntok) * a.ld + e];
+    }
+    if (ry * W + 1 >= a.ntok) return;                                            // whole row beyond the sequence (uniform)
+    for (int e = t; e < W * J * NH; e += blockDim.x) SP[e] = NEG_MAX;
+    if (t == 0) {
+        int n = 0;
+        for (int ta = 0; ta < a.kf; ++ta)
+            for (int tb = 0; tb < a.kh; ++tb) {
+                const int fr = f - (a.kf - 1 - ta) * a.df, yr = y - (a.kh - 1 - tb) * a.dh;
+                if (fr >= 0 && yr >= 0) { pslot[n] = 1 + (ta * a.kh + tb) * a.kw; ptok[n] = 1 + (fr * a.H + yr) * W; ++n; }
+            }
+        pslot[S3M_PLANES] = n;
+    }
+    __syncthreads();
+    const int nplanes = pslot[S3M_PLANES];
+    const size_t tok0 = (size_t)b * a.ntok;
+    const int iq = 1 + ry * W + c;                                               // this lane's query (as MFMA column c)
+    const bool qok = iq < a.ntok;
+    // Which tap (if any) links query c to each of the lane's 4 keys 4*g4 + r: the same for every plane, so all of the band
+    // logic of the sweeps is decided here once.  tsel[r] = tap index tc, or -1.
+    int tsel[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int d = c - (4 * g4 + r);
+        tsel[r] = -1;
+#pragma unroll
+        for (int tc = 0; tc < S3M_KW; ++tc)
+            if (tc < a.kw && d == (a.kw - 1 - tc) * a.dw) tsel[r] = tc;
+    }
+    // ---- phase 1: scores of head `wave`
+    if (!(a.dbg & 1)) {
+        const int h = wave;
+        const bf16_t* qrow = a.q + (tok0 + iq) * a.ld + h * DH + g4 * 8;
+        const bf16x8 qf0 = ldg8(qrow, qok), qf1 = ldg8(qrow + 32, qok);
+        const bf16_t* kbase = a.k + tok0 * a.ld + h * DH + g4 * 8;               // + token * ld
+        const int spb = (c * J) * NH + h;                                        // SP index of (query c, slot 0, head h)
+        int sidx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sidx[r] = spb + (tsel[r] < 0 ? 0 : tsel[r]) * NH;
+        // sequence 0 is <bos> (token 0 for every MFMA row), then the valid planes; PF planes of key fragments are in flight
+        constexpr int PF = 3;
+        bf16x8 kq0[PF], kq1[PF];
+        auto issue = [&](int sq, bf16x8& d0, bf16x8& d1) {
+            if (sq > nplanes) { d0 = d1 = bf16x8{}; return; }
+            const int tok = sq == 0 ? 0 : ptok[sq - 1] + c;
+            const bf16_t* kp = kbase + (size_t)tok * a.ld;
+            const bool ok = tok < a.ntok;
+            d0 = ldg8(kp, ok); d1 = ldg8(kp + 32, ok);
+        };
+#pragma unroll
+        for (int i = 0; i < PF; ++i) issue(i, kq0[i], kq1[i]);
+        for (int sq = 0; sq <= nplanes; ++sq) {
+            const bf16x8 k0 = kq0[0], k1 = kq1[0];
+#pragma unroll
+            for (int i = 0; i + 1 < PF; ++i) { kq0[i] = kq0[i + 1]; kq1[i] = kq1[i + 1]; }
+            issue(sq + PF, kq0[PF - 1], kq1[PF - 1]);
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, sc, 0, 0, 0);
+            if (sq == 0) {
+                if (g4 == 0 && qok) SP[spb] = sc[0] * a.scale + (a.bias ? a.bias[h] : 0.f);
+            } else if (qok) {
+                const int jb = pslot[sq - 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (tsel[r] >= 0)
+                        SP[sidx[r] + jb * NH] = sc[r] * a.scale + (a.bias ? a.bias[(jb + tsel[r]) * NH + h] : 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: softmax over the J slots of each (w, h) (4 lanes split j), then the head mix per (w, j), in place
+    if (!(a.dbg & 2)) {
+        const int cc = t & 3, wh = t >> 2, h = wh % NH, w = wh / NH;
+        float m = NEG_MAX;
+        for (int j = cc; j < J; j += 4) m = fmaxf(m, SP[(w * J + j) * NH + h]);
+        m = quad_max(m);
+        float sum = 0.f;
+        for (int j = cc; j < J; j += 4) {
+            const int idx = (w * J + j) * NH + h;
+            const float e = __expf(SP[idx] - m);
+            SP[idx] = e;
+            sum += e;
+        }
+        sum = quad_sum(sum);
+        const float inv = 1.f / sum;
+        for (int j = cc; j < J; j += 4) SP[(w * J + j) * NH + h] *= inv;
+    }
+    __syncthreads();
+    for (int item = t; item < W * J && !(a.dbg & 2); item += blockDim.x) {
+        float pv[8], out[8];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) pv[hh] = SP[item * NH + hh];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < 8; ++hh) s += wsh[g * NH + hh] * pv[hh];
+            out[g] = s;
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) SP[item * NH + g] = out[g];
+    }
+    __syncthreads();
+    // ---- phase 3: O^T of head `wave`
+    if (!(a.dbg & 4)) {
+        const int g = wave;
+        char* tile = vt_base + wave * 4096;
+        const int spb = (c * J) * NH + g;
+        f32x4 O[4];
+        {   // <bos> slot: P'[0] * v_bos
+            const float p0 = qok ? SP[spb] : 0.f;
+            const bf16_t* vb = a.v + tok0 * a.ld + g * DH + 4 * g4;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const uint2 u = *reinterpret_cast<const uint2*>(vb + db * 16);
+                O[db] = f32x4{p0 * lo_f(u.x), p0 * hi_f(u.x), p0 * lo_f(u.y), p0 * hi_f(u.y)};
+            }
+        }
+        // staging map of a chunk (two planes = 32 value rows x 8 sixteen-byte pieces, 4 per lane): piece i of this lane is
+        // row (lane >> 3) + 8 i, i.e. pieces 0, 1 belong to the first plane and 2, 3 to the second -- all offsets are fixed
+        const int gc = lane & 7, r8 = lane >> 3;
+        const bf16_t* vbase = a.v + tok0 * a.ld + g * DH + gc * 8;
+        int woff[4], sidx[4], troff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) woff[i] = vt_off(r8 + 8 * i, gc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sidx[r] = spb + (tsel[r] < 0 ? 0 : tsel[r]) * NH;
+        {   // transposing-read offsets (vt_tr): rows r0 / 16 + r0, column block db
+            const int r0 = 4 * g4 + (c >> 2);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const int col = db * 16 + ((c & 3) << 2);
+                troff[db] = vt_off(r0, col >> 3) + ((col >> 2) & 1) * 8;       // the row-16 twin: same swizzle (16 & 7 == 0), + 2048 bytes
+            }
+        }
+        uint4 st[4];
+        auto fetch_v = [&](int pi) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pj = pi + (i >> 1);
+                const int tok = pj < nplanes ? ptok[pj] + r8 + 8 * (i & 1) : a.ntok;
+                st[i] = tok < a.ntok ? *reinterpret_cast<const uint4*>(vbase + (size_t)tok * a.ld) : make_uint4(0, 0, 0, 0);
+            }
+        };
+        fetch_v(0);
+        for (int pi = 0; pi < nplanes; pi += 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + woff[i]) = st[i];
+            const int jb0 = pslot[pi] * NH, jb1 = pi + 1 < nplanes ? pslot[pi + 1] * NH : -1;
+            if (pi + 2 < nplanes) fetch_v(pi + 2);                                // the next chunk's rows are in flight below
+            // banded P' of the lane's 8 key slots (kb, j): key 4*g4 + j of plane kb, query c
+            float pf[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = tsel[j] >= 0 && qok;
+                pf[j] = on ? SP[sidx[j] + jb0] : 0.f;
+                pf[4 + j] = (on && jb1 >= 0) ? SP[sidx[j] + jb1] : 0.f;
+            }
+            const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(pf[0], pf[1]), pack2_rne(pf[2], pf[3]),
+                                                                     pack2_rne(pf[4], pf[5]), pack2_rne(pf[6], pf[7])));
+            __builtin_amdgcn_wave_barrier();                                      // LDS is in-order per wave: the tile is complete
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db] + 2048));
+                const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                O[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v8), pb, O[db], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (qok) {
+            bf16_t* orow = a.o + (tok0 + iq) * a.ldo + g * DH + 4 * g4;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                *reinterpret_cast<uint2*>(orow + db * 16) = make_uint2(pack2_rne(O[db][0], O[db][1]), pack2_rne(O[db][2], O[db][3]));
+        }
+    }
+}
+
 void fill_geom(S3Args& a, const amdnuwa_s3_geom* g) {
     a.B = g->B; a.ntok = g->ntok; a.F = g->F; a.H = g->H; a.W = g->W; a.kf = g->kf; a.kh = g->kh; a.kw = g->kw;
     a.df = g->df; a.dh = g->dh; a.dw = g->dw; a.NH = g->heads; a.scale = g->scale; a.bias = g->rel_bias;
@@ -725,6 +963,16 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
         hipLaunchKernelGGL((s3_fwd_kernel<DH_, LO_>), grid, block, lds, stream, a);                               \
     } while (0)
     const bool lo_mode = k_lo != nullptr;
+    // MFMA forward (tuning key 3: 1 = keep the dot2 kernel): bf16 operands, 16 queries per grid row, 8 heads x 64
+    if (!lo_mode && g_amdnuwa_tuning[3] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 && g->kw <= S3M_KW &&
+        g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && ldo % 4 == 0) {
+        a.dbg = g_amdnuwa_tuning[9];
+        const size_t lm = (size_t)16 * J * 8 * sizeof(float) + 8 * 4096;
+        (void)hipFuncSetAttribute((const void*)s3_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+        hipLaunchKernelGGL(s3_fwd_mfma_kernel, grid, dim3(512), lm, stream, a);
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
+    }
     if (g->dim_head == 64) { if (lo_mode) S3F(64, true); else S3F(64, false); }
     else { if (lo_mode) S3F(32, true); else S3F(32, false); }
 #undef S3F

@@ -46,7 +46,7 @@ def main():
         for v in (0, 1):
             L.amdnuwa_set_tuning(3, v)
             t = bench(lambda: K.sparse3dna_fwd(g, qkv, wth), args.iters)
-            row.append(f'fwd[{"row" if v == 0 else "slab"}] {t * 1e6:7.1f} us ({by_f / t / 1e9:6.0f} GB/s)')
+            row.append(f'fwd[{"mfma" if v == 0 else "dot2"}] {t * 1e6:7.1f} us ({by_f / t / 1e9:6.0f} GB/s)')
         L.amdnuwa_set_tuning(3, 0)
         for v in (0, 1):
             L.amdnuwa_set_tuning(4, v)
