@@ -735,16 +735,193 @@ __device__ __forceinline__ bf16x8 ldg8(const bf16_t* p, bool ok) {
 constexpr int S3M_KW = 3;        // widest tap row the MFMA kernel handles
 constexpr int S3M_PLANES = 64;   // kf * kh limit (plane list in LDS)
 
+// per-workgroup state of one query row, shared by the MFMA forward and backward kernels
+struct RowM {
+    int nplanes, J, lane, wave, c, g4, iq;      // lane = (c = MFMA column / query, g4 = k-slice / row quad)
+    bool qok;                                   // query c of this row exists (token iq < ntok)
+    size_t tok0;                                // first token row of the sample
+    int tsel[4];                                // tap index linking query c to key 4*g4 + r (the same in every plane), or -1
+    const int *pslot, *ptok;                    // valid planes: first key slot j, token row of key 0
+};
+constexpr int S3M_NH = 8, S3M_DH = 64, S3M_W = 16;
+
+// fills pslot / ptok (thread 0) and returns after a barrier; `cnt` = &pslot[S3M_PLANES]
+__device__ __forceinline__ void rowm_planes(const S3Args& a, int f, int y, int* pslot, int* ptok) {
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int ta = 0; ta < a.kf; ++ta)
+            for (int tb = 0; tb < a.kh; ++tb) {
+                const int fr = f - (a.kf - 1 - ta) * a.df, yr = y - (a.kh - 1 - tb) * a.dh;
+                if (fr >= 0 && yr >= 0) { pslot[n] = 1 + (ta * a.kh + tb) * a.kw; ptok[n] = 1 + (fr * a.H + yr) * S3M_W; ++n; }
+            }
+        pslot[S3M_PLANES] = n;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ RowM rowm_init(const S3Args& a, int b, int ry, const int* pslot, const int* ptok) {
+    RowM r;
+    r.nplanes = pslot[S3M_PLANES];
+    r.J = a.kf * a.kh * a.kw + 1;
+    r.lane = threadIdx.x & 63; r.wave = threadIdx.x >> 6; r.c = r.lane & 15; r.g4 = r.lane >> 4;
+    r.tok0 = (size_t)b * a.ntok;
+    r.iq = 1 + ry * S3M_W + r.c;
+    r.qok = r.iq < a.ntok;
+    r.pslot = pslot; r.ptok = ptok;
+    // Which tap (if any) links query c to each of the lane's 4 keys 4*g4 + r: the same for every plane, so all of the band
+    // logic of the sweeps is decided here once.
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int d = r.c - (4 * r.g4 + q);
+        r.tsel[q] = -1;
+#pragma unroll
+        for (int tc = 0; tc < S3M_KW; ++tc)
+            if (tc < a.kw && d == (a.kw - 1 - tc) * a.dw) r.tsel[q] = tc;
+    }
+    return r;
+}
+
+// Band scores of head h:  TAB[(c*J + slot)*NH + h] = mul * (frag row of query c) . (row of the slot's key) (+ bias[slot][h])
+// for the <bos> slot and every tap of every valid plane.  S^T = ROWS . FRAG^T: the 16 key rows of a plane go straight from
+// global memory into the A operand; the lane keeps the entries on the tap diagonals.  No LDS staging, no workgroup barrier.
+__device__ __forceinline__ void mfma_band_scores(const S3Args& a, const RowM& r, const bf16_t* rows, int ldr, const bf16_t* frag,
+                                                 int ldf, int h, float* TAB, float mul, const float* bias) {
+    constexpr int NH = S3M_NH, DH = S3M_DH;
+    const bf16_t* qrow = frag + (r.tok0 + r.iq) * ldf + h * DH + r.g4 * 8;
+    const bf16x8 qf0 = ldg8(qrow, r.qok), qf1 = ldg8(qrow + 32, r.qok);
+    const bf16_t* kbase = rows + r.tok0 * ldr + h * DH + r.g4 * 8;                // + token * ld
+    const int spb = (r.c * r.J) * NH + h;                                        // index of (query c, slot 0, head h)
+    int sidx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
+    // sequence 0 is <bos> (token 0 for every MFMA row), then the valid planes; PF planes of key fragments are in flight
+    constexpr int PF = 3;
+    bf16x8 kq0[PF], kq1[PF];
+    auto issue = [&](int sq, bf16x8& d0, bf16x8& d1) {
+        if (sq > r.nplanes) { d0 = d1 = bf16x8{}; return; }
+        const int tok = sq == 0 ? 0 : r.ptok[sq - 1] + r.c;
+        const bf16_t* kp = kbase + (size_t)tok * ldr;
+        const bool ok = tok < a.ntok;
+        d0 = ldg8(kp, ok); d1 = ldg8(kp + 32, ok);
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) issue(i, kq0[i], kq1[i]);
+    for (int sq = 0; sq <= r.nplanes; ++sq) {
+        const bf16x8 k0 = kq0[0], k1 = kq1[0];
+#pragma unroll
+        for (int i = 0; i + 1 < PF; ++i) { kq0[i] = kq0[i + 1]; kq1[i] = kq1[i + 1]; }
+        issue(sq + PF, kq0[PF - 1], kq1[PF - 1]);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, sc, 0, 0, 0);
+        if (sq == 0) {
+            if (r.g4 == 0 && r.qok) TAB[spb] = sc[0] * mul + (bias ? bias[h] : 0.f);
+        } else if (r.qok) {
+            const int jb = r.pslot[sq - 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r.tsel[q] >= 0) TAB[sidx[q] + jb * NH] = sc[q] * mul + (bias ? bias[(jb + r.tsel[q]) * NH + h] : 0.f);
+        }
+    }
+}
+
+// Band apply of head g:  O[query c][d] = TAB[c][0][g] * rows[<bos>][d] + sum over planes / taps TAB[c][slot][g] * rows[key][d]
+// as O^T = ROWS^T . TAB^T: the rows of TWO planes (32 keys) are staged in the wave-private 4 KiB LDS tile and read back
+// transposed (ds_read_b64_tr_b16) as the A operand; the banded coefficients of the lane's 8 key slots come from TAB.
+// Lane (c, g4) ends with O[db][q] = out[query c][db*16 + 4*g4 + q].
+__device__ __forceinline__ void mfma_band_apply(const S3Args& a, const RowM& r, const bf16_t* rows, int ldr, int g, const float* TAB,
+                                                char* tile, f32x4 (&O)[4]) {
+    constexpr int NH = S3M_NH, DH = S3M_DH;
+    const int spb = (r.c * r.J) * NH + g;
+    {   // <bos> slot
+        const float p0 = r.qok ? TAB[spb] : 0.f;
+        const bf16_t* vb = rows + r.tok0 * ldr + g * DH + 4 * r.g4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const uint2 u = *reinterpret_cast<const uint2*>(vb + db * 16);
+            O[db] = f32x4{p0 * lo_f(u.x), p0 * hi_f(u.x), p0 * lo_f(u.y), p0 * hi_f(u.y)};
+        }
+    }
+    // staging map of a chunk (two planes = 32 rows x 8 sixteen-byte pieces, 4 per lane): piece i of this lane is row
+    // (lane >> 3) + 8 i, i.e. pieces 0, 1 belong to the first plane and 2, 3 to the second -- all offsets are fixed
+    const int gc = r.lane & 7, r8 = r.lane >> 3;
+    const bf16_t* vbase = rows + r.tok0 * ldr + g * DH + gc * 8;
+    int woff[4], sidx[4], troff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) woff[i] = vt_off(r8 + 8 * i, gc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
+    {   // transposing-read offsets: rows r0 and 16 + r0 (same swizzle since 16 & 7 == 0: + 2048 bytes), column block db
+        const int r0 = 4 * r.g4 + (r.c >> 2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const int col = db * 16 + ((r.c & 3) << 2);
+            troff[db] = vt_off(r0, col >> 3) + ((col >> 2) & 1) * 8;
+        }
+    }
+    uint4 st[4];
+    auto fetch = [&](int pi) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pj = pi + (i >> 1);
+            const int tok = pj < r.nplanes ? r.ptok[pj] + r8 + 8 * (i & 1) : a.ntok;
+            st[i] = tok < a.ntok ? *reinterpret_cast<const uint4*>(vbase + (size_t)tok * ldr) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    fetch(0);
+    for (int pi = 0; pi < r.nplanes; pi += 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + woff[i]) = st[i];
+        const int jb0 = r.pslot[pi] * NH, jb1 = pi + 1 < r.nplanes ? r.pslot[pi + 1] * NH : -1;
+        if (pi + 2 < r.nplanes) fetch(pi + 2);                                    // the next chunk's rows are in flight below
+        float pf[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool on = r.tsel[j] >= 0 && r.qok;
+            pf[j] = on ? TAB[sidx[j] + jb0] : 0.f;
+            pf[4 + j] = (on && jb1 >= 0) ? TAB[sidx[j] + jb1] : 0.f;
+        }
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(pf[0], pf[1]), pack2_rne(pf[2], pf[3]),
+                                                                 pack2_rne(pf[4], pf[5]), pack2_rne(pf[6], pf[7])));
+        __builtin_amdgcn_wave_barrier();                                          // LDS is in-order per wave: the tile is complete
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db] + 2048));
+            const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            O[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v8), pb, O[db], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// fp32 softmax over the J slots of every (w, h) of TAB, in place (4 lanes split j); masked slots hold NEG_MAX
+__device__ __forceinline__ void rowm_softmax(float* TAB, int J) {
+    constexpr int NH = S3M_NH;
+    const int t = threadIdx.x, cc = t & 3, wh = t >> 2, h = wh % NH, w = wh / NH;
+    float m = NEG_MAX;
+    for (int j = cc; j < J; j += 4) m = fmaxf(m, TAB[(w * J + j) * NH + h]);
+    m = quad_max(m);
+    float sum = 0.f;
+    for (int j = cc; j < J; j += 4) {
+        const int idx = (w * J + j) * NH + h;
+        const float e = __expf(TAB[idx] - m);
+        TAB[idx] = e;
+        sum += e;
+    }
+    sum = quad_sum(sum);
+    const float inv = 1.f / sum;
+    for (int j = cc; j < J; j += 4) TAB[(w * J + j) * NH + h] *= inv;
+}
+
 __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
-    constexpr int NH = 8, DH = 64, W = 16;
+    constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int J = a.kf * a.kh * a.kw + 1;
     float* SP = reinterpret_cast<float*>(smem);                                  // [W][J][NH]
     char* vt_base = smem + (size_t)W * J * NH * sizeof(float);                   // 8 wave-private [32][64] bf16 tiles
     __shared__ float wsh[64];
-    // valid planes of this query row: slot (first key slot j of the plane) and token row of its key 0; entry [S3M_PLANES] = count
     __shared__ int pslot[S3M_PLANES + 1], ptok[S3M_PLANES + 1];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g4 = lane >> 4;
+    const int t = threadIdx.x;
     const int rows = a.F * a.H;
     const int bid = xcd_row_id();
     const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
@@ -755,91 +932,13 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
     }
     if (ry * W + 1 >= a.ntok) return;                                            // whole row beyond the sequence (uniform)
     for (int e = t; e < W * J * NH; e += blockDim.x) SP[e] = NEG_MAX;
-    if (t == 0) {
-        int n = 0;
-        for (int ta = 0; ta < a.kf; ++ta)
-            for (int tb = 0; tb < a.kh; ++tb) {
-                const int fr = f - (a.kf - 1 - ta) * a.df, yr = y - (a.kh - 1 - tb) * a.dh;
-                if (fr >= 0 && yr >= 0) { pslot[n] = 1 + (ta * a.kh + tb) * a.kw; ptok[n] = 1 + (fr * a.H + yr) * W; ++n; }
-            }
-        pslot[S3M_PLANES] = n;
-    }
+    rowm_planes(a, f, y, pslot, ptok);
+    const RowM r = rowm_init(a, b, ry, pslot, ptok);
+    if (!(a.dbg & 1)) mfma_band_scores(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias);
     __syncthreads();
-    const int nplanes = pslot[S3M_PLANES];
-    const size_t tok0 = (size_t)b * a.ntok;
-    const int iq = 1 + ry * W + c;                                               // this lane's query (as MFMA column c)
-    const bool qok = iq < a.ntok;
-    // Which tap (if any) links query c to each of the lane's 4 keys 4*g4 + r: the same for every plane, so all of the band
-    // logic of the sweeps is decided here once.  tsel[r] = tap index tc, or -1.
-    int tsel[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int d = c - (4 * g4 + r);
-        tsel[r] = -1;
-#pragma unroll
-        for (int tc = 0; tc < S3M_KW; ++tc)
-            if (tc < a.kw && d == (a.kw - 1 - tc) * a.dw) tsel[r] = tc;
-    }
-    // ---- phase 1: scores of head `wave`
-    if (!(a.dbg & 1)) {
-        const int h = wave;
-        const bf16_t* qrow = a.q + (tok0 + iq) * a.ld + h * DH + g4 * 8;
-        const bf16x8 qf0 = ldg8(qrow, qok), qf1 = ldg8(qrow + 32, qok);
-        const bf16_t* kbase = a.k + tok0 * a.ld + h * DH + g4 * 8;               // + token * ld
-        const int spb = (c * J) * NH + h;                                        // SP index of (query c, slot 0, head h)
-        int sidx[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sidx[r] = spb + (tsel[r] < 0 ? 0 : tsel[r]) * NH;
-        // sequence 0 is <bos> (token 0 for every MFMA row), then the valid planes; PF planes of key fragments are in flight
-        constexpr int PF = 3;
-        bf16x8 kq0[PF], kq1[PF];
-        auto issue = [&](int sq, bf16x8& d0, bf16x8& d1) {
-            if (sq > nplanes) { d0 = d1 = bf16x8{}; return; }
-            const int tok = sq == 0 ? 0 : ptok[sq - 1] + c;
-            const bf16_t* kp = kbase + (size_t)tok * a.ld;
-            const bool ok = tok < a.ntok;
-            d0 = ldg8(kp, ok); d1 = ldg8(kp + 32, ok);
-        };
-#pragma unroll
-        for (int i = 0; i < PF; ++i) issue(i, kq0[i], kq1[i]);
-        for (int sq = 0; sq <= nplanes; ++sq) {
-            const bf16x8 k0 = kq0[0], k1 = kq1[0];
-#pragma unroll
-            for (int i = 0; i + 1 < PF; ++i) { kq0[i] = kq0[i + 1]; kq1[i] = kq1[i + 1]; }
-            issue(sq + PF, kq0[PF - 1], kq1[PF - 1]);
-            f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, sc, 0, 0, 0);
-            if (sq == 0) {
-                if (g4 == 0 && qok) SP[spb] = sc[0] * a.scale + (a.bias ? a.bias[h] : 0.f);
-            } else if (qok) {
-                const int jb = pslot[sq - 1];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (tsel[r] >= 0)
-                        SP[sidx[r] + jb * NH] = sc[r] * a.scale + (a.bias ? a.bias[(jb + tsel[r]) * NH + h] : 0.f);
-            }
-        }
-    }
+    if (!(a.dbg & 2)) rowm_softmax(SP, J);
     __syncthreads();
-    // ---- phase 2: softmax over the J slots of each (w, h) (4 lanes split j), then the head mix per (w, j), in place
-    if (!(a.dbg & 2)) {
-        const int cc = t & 3, wh = t >> 2, h = wh % NH, w = wh / NH;
-        float m = NEG_MAX;
-        for (int j = cc; j < J; j += 4) m = fmaxf(m, SP[(w * J + j) * NH + h]);
-        m = quad_max(m);
-        float sum = 0.f;
-        for (int j = cc; j < J; j += 4) {
-            const int idx = (w * J + j) * NH + h;
-            const float e = __expf(SP[idx] - m);
-            SP[idx] = e;
-            sum += e;
-        }
-        sum = quad_sum(sum);
-        const float inv = 1.f / sum;
-        for (int j = cc; j < J; j += 4) SP[(w * J + j) * NH + h] *= inv;
-    }
-    __syncthreads();
+    // talking heads: P'[g] = sum_h Wth[g][h] P[h] per (w, j), in place
     for (int item = t; item < W * J && !(a.dbg & 2); item += blockDim.x) {
         float pv[8], out[8];
 #pragma unroll
@@ -855,79 +954,146 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
         for (int g = 0; g < 8; ++g) SP[item * NH + g] = out[g];
     }
     __syncthreads();
-    // ---- phase 3: O^T of head `wave`
     if (!(a.dbg & 4)) {
-        const int g = wave;
-        char* tile = vt_base + wave * 4096;
-        const int spb = (c * J) * NH + g;
+        const int g = r.wave;
         f32x4 O[4];
-        {   // <bos> slot: P'[0] * v_bos
-            const float p0 = qok ? SP[spb] : 0.f;
-            const bf16_t* vb = a.v + tok0 * a.ld + g * DH + 4 * g4;
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const uint2 u = *reinterpret_cast<const uint2*>(vb + db * 16);
-                O[db] = f32x4{p0 * lo_f(u.x), p0 * hi_f(u.x), p0 * lo_f(u.y), p0 * hi_f(u.y)};
-            }
-        }
-        // staging map of a chunk (two planes = 32 value rows x 8 sixteen-byte pieces, 4 per lane): piece i of this lane is
-        // row (lane >> 3) + 8 i, i.e. pieces 0, 1 belong to the first plane and 2, 3 to the second -- all offsets are fixed
-        const int gc = lane & 7, r8 = lane >> 3;
-        const bf16_t* vbase = a.v + tok0 * a.ld + g * DH + gc * 8;
-        int woff[4], sidx[4], troff[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) woff[i] = vt_off(r8 + 8 * i, gc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sidx[r] = spb + (tsel[r] < 0 ? 0 : tsel[r]) * NH;
-        {   // transposing-read offsets (vt_tr): rows r0 / 16 + r0, column block db
-            const int r0 = 4 * g4 + (c >> 2);
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const int col = db * 16 + ((c & 3) << 2);
-                troff[db] = vt_off(r0, col >> 3) + ((col >> 2) & 1) * 8;       // the row-16 twin: same swizzle (16 & 7 == 0), + 2048 bytes
-            }
-        }
-        uint4 st[4];
-        auto fetch_v = [&](int pi) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int pj = pi + (i >> 1);
-                const int tok = pj < nplanes ? ptok[pj] + r8 + 8 * (i & 1) : a.ntok;
-                st[i] = tok < a.ntok ? *reinterpret_cast<const uint4*>(vbase + (size_t)tok * a.ld) : make_uint4(0, 0, 0, 0);
-            }
-        };
-        fetch_v(0);
-        for (int pi = 0; pi < nplanes; pi += 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + woff[i]) = st[i];
-            const int jb0 = pslot[pi] * NH, jb1 = pi + 1 < nplanes ? pslot[pi + 1] * NH : -1;
-            if (pi + 2 < nplanes) fetch_v(pi + 2);                                // the next chunk's rows are in flight below
-            // banded P' of the lane's 8 key slots (kb, j): key 4*g4 + j of plane kb, query c
-            float pf[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool on = tsel[j] >= 0 && qok;
-                pf[j] = on ? SP[sidx[j] + jb0] : 0.f;
-                pf[4 + j] = (on && jb1 >= 0) ? SP[sidx[j] + jb1] : 0.f;
-            }
-            const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(pf[0], pf[1]), pack2_rne(pf[2], pf[3]),
-                                                                     pack2_rne(pf[4], pf[5]), pack2_rne(pf[6], pf[7])));
-            __builtin_amdgcn_wave_barrier();                                      // LDS is in-order per wave: the tile is complete
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db]));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db] + 2048));
-                const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                O[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v8), pb, O[db], 0, 0, 0);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (qok) {
-            bf16_t* orow = a.o + (tok0 + iq) * a.ldo + g * DH + 4 * g4;
+        mfma_band_apply(a, r, a.v, a.ld, g, SP, vt_base + r.wave * 4096, O);
+        if (r.qok) {
+            bf16_t* orow = a.o + (r.tok0 + r.iq) * a.ldo + g * DH + 4 * r.g4;
 #pragma unroll
             for (int db = 0; db < 4; ++db)
                 *reinterpret_cast<uint2*>(orow + db * 16) = make_uint2(pack2_rne(O[db][0], O[db][1]), pack2_rne(O[db][2], O[db][3]));
         }
+    }
+}
+
+// MFMA backward, query side (same row / wave mapping as the forward): recompute P, dP' = dO . V^T (band scores with dO as the
+// fragment and V as the rows), dW_th partial, dP = W^T dP', ds = P (dP - sum P dP), dq = scale * ds . K (band apply over K);
+// ds and P' go to the fp32 workspace for the key-side kernel, the <bos> key / value partials to part_k0 / part_v0.
+// LDS: R1 = SP (P) until ds exists, then the 8 transposed K tiles | DP | RED [8][64] | PM0 [W][NH]
+__global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
+    constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W, inner = NH * DH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int J = a.kf * a.kh * a.kw + 1, nsp = W * J * NH;
+    const size_t r1 = (size_t)nsp * 4 > 8 * 4096 ? (size_t)nsp * 4 : 8 * 4096;
+    float* SP = reinterpret_cast<float*>(smem);
+    float* DP = reinterpret_cast<float*>(smem + r1);
+    float* RED = DP + nsp;                                                       // [8][64]
+    float* PM0 = RED + 8 * 64;                                                   // [W][NH]  P' of the <bos> slot
+    __shared__ float wsh[64];
+    __shared__ int pslot[S3M_PLANES + 1], ptok[S3M_PLANES + 1];
+    const int t = threadIdx.x;
+    const int rows = a.F * a.H;
+    const int bid = xcd_row_id();
+    const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
+    const int nq = a.ntok - 1;
+    if (t < NH * NH) wsh[t] = a.wth[t];
+    float* pth = a.part_th + (size_t)bid * NH * NH;
+    float* pk0 = a.part_k0 + (size_t)bid * inner;
+    float* pv0 = a.part_v0 + (size_t)bid * inner;
+    if (ry == 0)   // dq of the <bos> row is zero (its query is never used)
+        for (int e = t; e < inner; e += blockDim.x) a.dq[((size_t)b * a.ntok) * a.ldd + e] = 0;
+    if (ry * W + 1 >= a.ntok) {   // row beyond the sequence: contributes nothing
+        for (int e = t; e < NH * NH; e += blockDim.x) pth[e] = 0.f;
+        for (int e = t; e < inner; e += blockDim.x) { pk0[e] = 0.f; pv0[e] = 0.f; }
+        return;
+    }
+    for (int e = t; e < nsp; e += blockDim.x) { SP[e] = NEG_MAX; DP[e] = 0.f; }
+    rowm_planes(a, f, y, pslot, ptok);
+    const RowM r = rowm_init(a, b, ry, pslot, ptok);
+    mfma_band_scores(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias);             // scores
+    mfma_band_scores(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, 1.f, nullptr);              // dP'[g] = dO[g] . v_j[g]
+    __syncthreads();
+    rowm_softmax(SP, J);                                                                    // P
+    __syncthreads();
+    // P' = mix(P) -> global (the key side needs it), P stays in SP;  P' of the <bos> slot also to PM0
+    for (int item = t; item < W * J; item += blockDim.x) {
+        const int wq = item / J, j = item - wq * J;
+        const int iq = 1 + ry * W + wq;
+        float pv[8];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) pv[hh] = SP[item * NH + hh];
+        float* dst = a.pm + (((size_t)b * nq + (iq - 1)) * J + j) * NH;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < 8; ++hh) s += wsh[g * NH + hh] * pv[hh];
+            if (iq < a.ntok) dst[g] = s;
+            if (j == 0) PM0[wq * NH + g] = iq < a.ntok ? s : 0.f;
+        }
+    }
+    // dW_th[g][h] partial = sum_{w,j} dP'[g] * P[h]   (thread = (g,h) pair x 8 item groups).  Rows of absent queries hold
+    // dP' = 0 (their dO fragment is zero), so they add nothing.
+    {
+        const int pair = t & 63, grp = t >> 6;
+        const int g = pair / NH, hh = pair % NH;
+        float acc = 0.f;
+        for (int item = grp; item < W * J; item += 8) acc += DP[item * NH + g] * SP[item * NH + hh];
+        RED[grp * 64 + pair] = acc;
+        __syncthreads();
+        if (t < NH * NH) {
+            float s = 0.f;
+            for (int k = 0; k < 8; ++k) s += RED[k * 64 + t];
+            pth[t] = s;
+        }
+        __syncthreads();
+    }
+    // dP[h] = sum_g Wth[g][h] dP'[g]   (in place, item-local)
+    for (int item = t; item < W * J; item += blockDim.x) {
+        float dv_[8], out[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) dv_[g] = DP[item * NH + g];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += wsh[g * NH + hh] * dv_[g];
+            out[hh] = s;
+        }
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) DP[item * NH + hh] = out[hh];
+    }
+    __syncthreads();
+    // ds = P * (dP - sum_j P dP)  -> DP and the global workspace
+    {
+        const int cc = t & 3, wh = t >> 2, h = wh % NH, w = wh / NH;
+        const int i = 1 + ry * W + w;
+        float d = 0.f;
+        for (int j = cc; j < J; j += 4) d += SP[(w * J + j) * NH + h] * DP[(w * J + j) * NH + h];
+        d = quad_sum(d);
+        for (int j = cc; j < J; j += 4) {
+            const int idx = (w * J + j) * NH + h;
+            const float dsv = SP[idx] * (DP[idx] - d);
+            DP[idx] = dsv;
+            if (i < a.ntok) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
+        }
+    }
+    __syncthreads();                                                              // P is dead: its region now holds the K tiles
+    {
+        const int h = r.wave;
+        f32x4 O[4];
+        mfma_band_apply(a, r, a.k, a.ld, h, DP, smem + r.wave * 4096, O);
+        if (r.qok) {
+            bf16_t* orow = a.dq + (r.tok0 + r.iq) * a.ldd + h * DH + 4 * r.g4;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                *reinterpret_cast<uint2*>(orow + db * 16) = make_uint2(pack2_rne(O[db][0] * a.scale, O[db][1] * a.scale),
+                                                                       pack2_rne(O[db][2] * a.scale, O[db][3] * a.scale));
+        }
+    }
+    // <bos> partials of this row: dk0[e] = scale * sum_w ds[w][0][h] q[w][e],  dv0[e] = sum_w P'[w][0][g] dO[w][e]
+    for (int e = t; e < inner; e += blockDim.x) {
+        const int h = e / DH;
+        float sk = 0.f, sv = 0.f;
+        for (int w = 0; w < W; ++w) {
+            const int i = 1 + ry * W + w;
+            if (i >= a.ntok) break;
+            sk += DP[(w * J) * NH + h] * bf2f(a.q[(r.tok0 + i) * a.ld + e]);
+            sv += PM0[w * NH + h] * bf2f(a.dO[(r.tok0 + i) * a.lddo + e]);
+        }
+        pk0[e] = a.scale * sk;
+        pv0[e] = sv;
     }
 }
 
@@ -1024,10 +1190,19 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     const size_t lds_q = (size_t)g->W * g->heads * g->dim_head * (has_lo ? 4 : 2) * (slab ? g->kh : 1) + (spdp + 8 * 64) * 4;
     const size_t lds_kv = (size_t)g->W * g->heads * g->dim_head * 8;
     dim3 grid((unsigned)rows), block(block_threads(g));
+    // MFMA query-side kernel (tuning key 4: 1 = keep the dot2 kernel): bf16 operands, 16 queries per grid row, 8 heads x 64
+    const bool q_mfma = !has_lo && !dO_lo && g_amdnuwa_tuning[4] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 &&
+                        g->kw <= S3M_KW && g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0;
+    const size_t lds_qm = (nsp * 4 > 8 * 4096 ? nsp * 4 : 8 * 4096) + nsp * 4 + (8 * 64 + 16 * 8) * 4;
 #define S3B(DH_, LO_)                                                                                             \
     do {                                                                                                          \
-        (void)hipFuncSetAttribute((const void*)s3_bwd_q_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
-        hipLaunchKernelGGL((s3_bwd_q_kernel<DH_, LO_>), grid, block, lds_q, stream, a);                           \
+        if (q_mfma) {                                                                                             \
+            (void)hipFuncSetAttribute((const void*)s3_bwd_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qm); \
+            hipLaunchKernelGGL(s3_bwd_q_mfma_kernel, grid, dim3(512), lds_qm, stream, a);                         \
+        } else {                                                                                                  \
+            (void)hipFuncSetAttribute((const void*)s3_bwd_q_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
+            hipLaunchKernelGGL((s3_bwd_q_kernel<DH_, LO_>), grid, block, lds_q, stream, a);                       \
+        }                                                                                                         \
         LAUNCH_CHECK();                                                                                           \
         (void)hipFuncSetAttribute((const void*)s3_bwd_kv_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv); \
         hipLaunchKernelGGL((s3_bwd_kv_kernel<DH_, LO_>), grid, block, lds_kv, stream, a);                         \

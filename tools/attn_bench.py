@@ -51,7 +51,7 @@ def main():
         for v in (0, 1):
             L.amdnuwa_set_tuning(4, v)
             t = bench(lambda: K.sparse3dna_bwd(g, qkv, wth, do), args.iters)
-            row.append(f'bwd[{"row" if v == 0 else "slab"}] {t * 1e6:7.1f} us ({by_b / t / 1e9:6.0f} GB/s)')
+            row.append(f'bwd[{"mfma-q" if v == 0 else "dot2"}] {t * 1e6:7.1f} us ({by_b / t / 1e9:6.0f} GB/s)')
         L.amdnuwa_set_tuning(4, 0)
         print(f'dilation {dil}: ' + ' | '.join(row))
     print(f'== cross-attention core, b={b}, n={n}, T={T} ==')
