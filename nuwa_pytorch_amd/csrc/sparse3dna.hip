@@ -1097,6 +1097,131 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     }
 }
 
+// MFMA backward, key side: one workgroup = one KEY row of the grid, wave = head.  Every plane's attending query row sends
+//   dK^T[d][key] += Q^T[d][query] . ds[query][key]      dV^T[d][key] += dO^T[d][query] . P'[query][key]
+// where the (query, key) coefficient is the tap entry of the band (key = query - (kw-1-tc) dw), read from the fp32 workspace
+// the query-side kernel wrote.  The q / dO rows of two planes sit in two wave-private transposed tiles; no atomics, every key
+// pulls from the queries that attend to it.
+__global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
+    constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int pslot[S3M_PLANES + 1], ptok[S3M_PLANES + 1];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g4 = lane >> 4, h = wave;
+    const int rows = a.F * a.H;
+    const int bid = xcd_row_id();
+    const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
+    const int J = a.kf * a.kh * a.kw + 1, nq = a.ntok - 1;
+    if (ry * W + 1 >= a.ntok) return;
+    if (t == 0) {
+        int n = 0;
+        for (int ta = 0; ta < a.kf; ++ta)
+            for (int tb = 0; tb < a.kh; ++tb) {
+                const int fq = f + (a.kf - 1 - ta) * a.df, yq = y + (a.kh - 1 - tb) * a.dh;
+                if (fq < a.F && yq < a.H && (fq * a.H + yq) * W + 1 < a.ntok) {
+                    pslot[n] = 1 + (ta * a.kh + tb) * a.kw; ptok[n] = 1 + (fq * a.H + yq) * W; ++n;
+                }
+            }
+        pslot[S3M_PLANES] = n;
+    }
+    __syncthreads();
+    const int nplanes = pslot[S3M_PLANES];
+    const size_t tok0 = (size_t)b * a.ntok;
+    // tap linking the lane's 4 QUERIES 4*g4 + j to key c (query - key = (kw-1-tc) dw): the same in every plane
+    int tsel[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int d = (4 * g4 + j) - c;
+        tsel[j] = -1;
+#pragma unroll
+        for (int tc = 0; tc < S3M_KW; ++tc)
+            if (tc < a.kw && d == (a.kw - 1 - tc) * a.dw) tsel[j] = tc;
+    }
+    char* tq = smem + wave * 8192;
+    char* td = tq + 4096;
+    const int gc = lane & 7, r8 = lane >> 3;
+    const bf16_t* qbase = a.q + tok0 * a.ld + h * DH + gc * 8;
+    const bf16_t* dbase = a.dO + tok0 * a.lddo + h * DH + gc * 8;
+    int woff[4], troff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) woff[i] = vt_off(r8 + 8 * i, gc);
+    {
+        const int r0 = 4 * g4 + (c >> 2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const int col = db * 16 + ((c & 3) << 2);
+            troff[db] = vt_off(r0, col >> 3) + ((col >> 2) & 1) * 8;
+        }
+    }
+    uint4 sq[4], sd[4];
+    float cs[8], cp[8];                                                          // ds / P' coefficients of the 8 (plane, query) slots
+    auto fetch = [&](int pi) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pj = pi + (i >> 1);
+            const int tok = pj < nplanes ? ptok[pj] + r8 + 8 * (i & 1) : a.ntok;
+            const bool ok = tok < a.ntok;
+            sq[i] = ok ? *reinterpret_cast<const uint4*>(qbase + (size_t)tok * a.ld) : make_uint4(0, 0, 0, 0);
+            sd[i] = ok ? *reinterpret_cast<const uint4*>(dbase + (size_t)tok * a.lddo) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int pj = pi + kb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float vs = 0.f, vp = 0.f;
+                if (pj < nplanes && tsel[j] >= 0) {
+                    const int tok = ptok[pj] + 4 * g4 + j;
+                    if (tok < a.ntok) {
+                        const size_t ci = (((size_t)b * nq + (tok - 1)) * J + pslot[pj] + tsel[j]) * NH + h;
+                        vs = a.ds[ci]; vp = a.pm[ci];
+                    }
+                }
+                cs[kb * 4 + j] = vs; cp[kb * 4 + j] = vp;
+            }
+        }
+    };
+    f32x4 dK[4], dV[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dK[db] = dV[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nplanes > 0) fetch(0);
+    for (int pi = 0; pi < nplanes; pi += 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(tq + woff[i]) = sq[i];
+            *reinterpret_cast<uint4*>(td + woff[i]) = sd[i];
+        }
+        const bf16x8 bs = __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(cs[0], cs[1]), pack2_rne(cs[2], cs[3]),
+                                                                 pack2_rne(cs[4], cs[5]), pack2_rne(cs[6], cs[7])));
+        const bf16x8 bp = __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(cp[0], cp[1]), pack2_rne(cp[2], cp[3]),
+                                                                 pack2_rne(cp[4], cp[5]), pack2_rne(cp[6], cp[7])));
+        if (pi + 2 < nplanes) fetch(pi + 2);                                      // next chunk in flight during the MFMAs
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const s16x4 ql = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tq + troff[db]));
+            const s16x4 qh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tq + troff[db] + 2048));
+            const s16x4 dl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(td + troff[db]));
+            const s16x4 dh_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(td + troff[db] + 2048));
+            const s16x8 q8 = {ql[0], ql[1], ql[2], ql[3], qh[0], qh[1], qh[2], qh[3]};
+            const s16x8 d8 = {dl[0], dl[1], dl[2], dl[3], dh_[0], dh_[1], dh_[2], dh_[3]};
+            dK[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, q8), bs, dK[db], 0, 0, 0);
+            dV[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, d8), bp, dV[db], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int ik = 1 + ry * W + c;
+    if (ik < a.ntok) {
+        bf16_t* kr = a.dk + (tok0 + ik) * a.ldd + h * DH + 4 * g4;
+        bf16_t* vr = a.dv + (tok0 + ik) * a.ldd + h * DH + 4 * g4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            *reinterpret_cast<uint2*>(kr + db * 16) = make_uint2(pack2_rne(dK[db][0] * a.scale, dK[db][1] * a.scale),
+                                                                 pack2_rne(dK[db][2] * a.scale, dK[db][3] * a.scale));
+            *reinterpret_cast<uint2*>(vr + db * 16) = make_uint2(pack2_rne(dV[db][0], dV[db][1]), pack2_rne(dV[db][2], dV[db][3]));
+        }
+    }
+}
+
 void fill_geom(S3Args& a, const amdnuwa_s3_geom* g) {
     a.B = g->B; a.ntok = g->ntok; a.F = g->F; a.H = g->H; a.W = g->W; a.kf = g->kf; a.kh = g->kh; a.kw = g->kw;
     a.df = g->df; a.dh = g->dh; a.dw = g->dw; a.NH = g->heads; a.scale = g->scale; a.bias = g->rel_bias;
@@ -1204,8 +1329,13 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
             hipLaunchKernelGGL((s3_bwd_q_kernel<DH_, LO_>), grid, block, lds_q, stream, a);                       \
         }                                                                                                         \
         LAUNCH_CHECK();                                                                                           \
-        (void)hipFuncSetAttribute((const void*)s3_bwd_kv_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv); \
-        hipLaunchKernelGGL((s3_bwd_kv_kernel<DH_, LO_>), grid, block, lds_kv, stream, a);                         \
+        if (q_mfma && g_amdnuwa_tuning[4] != 2) {                                                                 \
+            (void)hipFuncSetAttribute((const void*)s3_bwd_kv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192); \
+            hipLaunchKernelGGL(s3_bwd_kv_mfma_kernel, grid, dim3(512), 8 * 8192, stream, a);                      \
+        } else {                                                                                                  \
+            (void)hipFuncSetAttribute((const void*)s3_bwd_kv_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv); \
+            hipLaunchKernelGGL((s3_bwd_kv_kernel<DH_, LO_>), grid, block, lds_kv, stream, a);                     \
+        }                                                                                                         \
     } while (0)
     const bool lo_mode = has_lo || dO_lo != nullptr;
     if (lo_mode && (!has_lo || !dO_lo)) return AMDNUWA_ERR_ARG;     // parity mode needs lo parts for q/k/v AND dO
