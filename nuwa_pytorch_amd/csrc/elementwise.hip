@@ -57,7 +57,7 @@ __device__ __forceinline__ void store_ln_shifted(bf16_t* out_hi, bf16_t* out_lo,
     bool keep = true, zero_own = false;
     if (shift_ntok > 0) {
         const int i = (int)(row % shift_ntok);
-        const int qd = e / (D >> 2);
+        const int qd = e < (D >> 2) ? 0 : (e < (D >> 1) ? 1 : 2);            // (no integer division in the row kernels)
         if (i > 0 && qd < 2) {
             const int p = i - 1, wq = p % shift_fmap, yq = (p / shift_fmap) % shift_fmap;
             if (qd == 0) { keep = yq + 1 < shift_fmap && i + shift_fmap < shift_ntok; drow = row + shift_fmap; zero_own = yq == 0; }
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 const int e = (lane + it * 64) * 4;
                 if (e >= D) { in.gv.v[it] = zero4; continue; }
                 long long src = row;
-                if (i > 0) { const int qd = e / quarter; if (qd == 0) src = src_h; else if (qd == 1) src = src_w; }
+                if (i > 0) { if (e < quarter) src = src_h; else if (e < 2 * quarter) src = src_w; }
                 in.gv.v[it] = src >= 0 ? ld4<IN == 2>(dy, (size_t)src * D + e) : zero4;
             }
         } else {
@@ -250,11 +250,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     // Rows are taken grid-stride, so at any moment the chip works on one contiguous window of the tensors.
     const long long stride = (long long)gridDim.x * ROWS_PER_BLOCK;
     long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + wv_;
-    RowIn cur, nxt;
-    if (row < R) load_row(row, cur);
-    for (; row < R; row += stride) {
-        const bool more = row + stride < R;
-        if (more) load_row(row + stride, nxt);
+    // two row buffers used alternately (the loop is unrolled by two): the prefetched row never has to be copied
+    RowIn bufA, bufB;
+    if (row < R) load_row(row, bufA);
+    auto process = [&](const RowIn& cur, long long row) {
         const float mean = cur.mean, rstd = cur.rstd, ia = cur.ia;
         float s1 = 0.f, s2 = 0.f;
         float4 xh[NV], g[NV];
@@ -289,7 +288,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 *reinterpret_cast<float4*>(dx_acc + row * D + e) = make_float4(o.x + d0, o.y + d1, o.z + d2, o.w + d3);
             }
         }
-        if (more) cur = nxt;
+    };
+    for (; row < R; row += 2 * stride) {
+        const bool m1 = row + stride < R;
+        if (m1) load_row(row + stride, bufB);
+        process(bufA, row);
+        if (!m1) break;
+        if (row + 2 * stride < R) load_row(row + 2 * stride, bufA);
+        process(bufB, row + stride);
     }
     // block reduce the 4 waves' partials in fixed order
 #pragma unroll
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
                 const int e = (lane + it * 64) * 4;
                 if (e >= D) { in.gv.v[it] = zero4; continue; }
                 long long src = row;
-                if (i > 0) { const int qd = e / quarter; if (qd == 0) src = src_h; else if (qd == 1) src = src_w; }
+                if (i > 0) { if (e < quarter) src = src_h; else if (e < 2 * quarter) src = src_w; }
                 in.gv.v[it] = src >= 0 ? ld4<BF>(dh, (size_t)src * D + e) : zero4;
             }
         } else {
@@ -359,11 +365,10 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
     };
     const long long stride = (long long)gridDim.x * ROWS_PER_BLOCK;
     long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + wv_;
-    RowIn cur, nxt;
-    if (row < R) load_row(row, cur);
-    for (; row < R; row += stride) {
-        const bool more = row + stride < R;
-        if (more) load_row(row + stride, nxt);
+    // two row buffers used alternately (the loop is unrolled by two): the prefetched row never has to be copied
+    RowIn bufA, bufB;
+    if (row < R) load_row(row, bufA);
+    auto process = [&](const RowIn& cur, long long row) {
         // ---- pre-norm backward of block k+1 -> dx
         float s1 = 0.f, s2 = 0.f;
         float4 xh[NV], g[NV];
@@ -416,7 +421,14 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
             psB[it].x += d0; psB[it].y += d1; psB[it].z += d2; psB[it].w += d3;
             store_bf16x4(dyp_hi + row * D, dyp_lo ? dyp_lo + row * D : nullptr, e, d0, d1, d2, d3);
         }
-        if (more) cur = nxt;
+    };
+    for (; row < R; row += 2 * stride) {
+        const bool m1 = row + stride < R;
+        if (m1) load_row(row + stride, bufB);
+        process(bufA, row);
+        if (!m1) break;
+        if (row + 2 * stride < R) load_row(row + 2 * stride, bufA);
+        process(bufB, row + stride);
     }
     // block reduce the 4 waves' partials in fixed order, one LayerNorm at a time through the same LDS
     for (int pass = 0; pass < 2; ++pass) {
