@@ -776,16 +776,30 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, float* __restr
 // TN, direct-to-LDS variant (bf16 operands only): same [32 token rows][128 columns] tiles and the same
 // 32-byte XOR swizzle as gemm_tn_kernel, but filled by global_load_lds_dwordx4 with the swizzle applied to
 // the per-lane source column.  One 1-KiB DMA piece = 4 token rows of a tile.
-template <bool SHIFT>
+// NARROW (N2 <= 64, e.g. the per-head dK / dV GEMMs of the cross attention: [JP x 64] outputs): the four waves stack along
+// M (32 rows x 64 columns each) instead of forming a 2 x 2 grid whose right half would multiply zeros.
+// NS > 2: NS-stage DMA ring with a counted s_waitcnt (the per-step wait is a fraction of the memory latency instead of all of it;
+// these few-tile GEMMs are a chain of k-steps with little arithmetic per step).
+template <bool SHIFT, bool NARROW = false, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmArgs p, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
+    constexpr int MI = NARROW ? 2 : 4, MSPAN = NARROW ? 32 : 64;      // row fragments per wave, rows per wave
     const int N1 = p.M, N2 = p.N;
-    const int tmi = blockIdx.x / p.tiles_n, tni = blockIdx.x % p.tiles_n;
+    int tile = blockIdx.x;
+    long long bz = blockIdx.y;
+    if (NARROW) {
+        // 1-D grid over (batch, tile): the column slabs of one operand matrix (the M tiles of a batch element) share cache lines
+        // whenever the row pitch is not a multiple of 128 bytes, so they are placed on the SAME XCD (linear id mod 8) and next
+        // to each other in dispatch order: the second and third slab then find those lines in that XCD's L2
+        const int tiles = p.tiles_m * p.tiles_n, L = blockIdx.x, nbat = gridDim.x / tiles;
+        if ((nbat & 7) == 0) { const int k = L >> 3; bz = (long long)(k / tiles) * 8 + (L & 7); tile = k % tiles; }
+        else { bz = L / tiles; tile = L % tiles; }
+    }
+    const int tmi = tile / p.tiles_n, tni = tile % p.tiles_n;
     const int a0 = tmi * 128, b0 = tni * 128;
-    const long long bz = blockIdx.y;
     const int z = blockIdx.z;
     const bf16_t* A = p.A + boff(p, bz, p.sA, p.sA_in);
     const bf16_t* B = p.B + boff(p, bz, p.sB, p.sB_in);
@@ -833,42 +847,59 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmArgs p, float* __
                 if (!zero) sb = B + gb * p.ldb + colb[j];
             }
             const int off = (j * 4 + wave) * 1024;
-            __builtin_amdgcn_global_load_lds((glb_cvptr)sa, (lds_vptr)(base + off), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_cvptr)sb, (lds_vptr)(base + TN_TILE_BYTES + off), 16, 0, 0);
+            // NARROW: columns beyond the operand are never read back (A rows >= N1 are not stored, B columns >= 64 not
+            // multiplied), so those lanes skip their DMA piece instead of fetching the zero page (some lanes of every piece are
+            // always active: the instruction count that s_waitcnt tracks does not change)
+            if (!NARROW || oka[j]) __builtin_amdgcn_global_load_lds((glb_cvptr)sa, (lds_vptr)(base + off), 16, 0, 0);
+            if (!NARROW || okb[j]) __builtin_amdgcn_global_load_lds((glb_cvptr)sb, (lds_vptr)(base + TN_TILE_BYTES + off), 16, 0, 0);
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (int)((mend - mbeg + TK - 1) / TK);
-    if (nk > 0) issue(0, mbeg);
-    __syncthreads();
+    if (NS == 2) {
+        if (nk > 0) issue(0, mbeg);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st)
+            if (st < nk) issue(st, mbeg + (long long)st * TK);
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) issue(cur ^ 1, mbeg + (long long)(kt + 1) * TK);
-        const char* base = smem + cur * 2 * TN_TILE_BYTES;
-        bf16x8 af[4], bfr[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i] = tn_frag(base, wm * 64 + i * 16, lane);
-            bfr[i] = tn_frag(base + TN_TILE_BYTES, wn * 64 + i * 16, lane);
+        const int cur = NS == 2 ? (kt & 1) : kt % NS;
+        if (NS == 2) {
+            if (kt + 1 < nk) issue(cur ^ 1, mbeg + (long long)(kt + 1) * TK);
+        } else {
+            // stage kt has landed once at most the later stages' loads (4 per stage and lane) are outstanding; the barrier also
+            // tells every wave that stage kt - 1 is consumed, so its buffer can take stage kt + NS - 1
+            if (kt + NS - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, mbeg + (long long)(kt + NS - 1) * TK);
         }
+        const char* base = smem + cur * 2 * TN_TILE_BYTES;
+        bf16x8 af[MI], bfr[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i) af[i] = tn_frag(base, wm * MSPAN + i * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bfr[i] = tn_frag(base + TN_TILE_BYTES, wn * 64 + i * 16, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        __syncthreads();
+        if (NS == 2) __syncthreads();
     }
     const int fr = lane & 15, fg = lane >> 4;
     float* P = partial + ((size_t)bz * gridDim.z + z) * (size_t)N1 * N2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n1 = a0 + wm * 64 + i * 16 + fr;
+    for (int i = 0; i < MI; ++i) {
+        const int n1 = a0 + wm * MSPAN + i * 16 + fr;
         if (n1 >= N1) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1392,6 +1423,11 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
     if (tnv == 2) {
         const size_t gl = (size_t)2 * 2 * TN_TILE_BYTES;
         if (sh) hipLaunchKernelGGL((gemm_tn_glds_kernel<true>), grid, block, gl, stream, p, part);
+        else if (d->N <= 64) {
+            const size_t gl4 = (size_t)4 * 2 * TN_TILE_BYTES;
+            (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gl4);
+            hipLaunchKernelGGL((gemm_tn_glds_kernel<false, true, 4>), dim3(grid.x * grid.y, 1, grid.z), block, gl4, stream, p, part);
+        }
         else    hipLaunchKernelGGL((gemm_tn_glds_kernel<false>), grid, block, gl, stream, p, part);
     } else
     if (x3) { if (sh) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, block, lds, stream, p, part);
