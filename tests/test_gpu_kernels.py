@@ -424,6 +424,38 @@ def test_sparse3dna_core(K, O, case, x3):
         report('s3_bwd_dwth' + tag, dwth, wth.grad, 1e-4)
 
 
+@pytest.mark.parametrize('shape,kern,dil,n', [((2, 16, 16), (3, 3, 3), (1, 2, 1), None), ((3, 16, 16), (5, 3, 3), (2, 1, 4), 530)])
+def test_sparse3dna_core_rel_pos_bias_on_the_mfma_kernels(K, O, shape, kern, dil, n):
+    """W = 16, 8 heads x 64 (the geometry the MFMA forward / backward kernels take) with per-axis dilations, a partial last
+    frame and the relative-position bias: output, dq / dk / dv, dW_th and d(bias) against autograd through the oracle"""
+    heads, dh, B = 8, 64, 2
+    N = shape[0] * shape[1] * shape[2]
+    n = N if n is None else n
+    inner = heads * dh
+    J = kern[0] * kern[1] * kern[2] + 1
+    torch.manual_seed(23)
+    qkv = bf_round(torch.randn(B, n, 3, heads, dh)).requires_grad_(True)
+    wth = (torch.randn(heads, heads) * 0.5 + torch.eye(heads)).requires_grad_(True)
+    rel = (torch.randn(heads, J - 1) * 0.7).requires_grad_(True)                   # oracle layout (h, K)
+    idx = O.neighbor_table(shape, kern, dil, causal=True)
+    o_ref = O.sparse3dna_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], wth, idx, dh ** -0.5, rel_pos_bias=rel)
+    do = bf_round(torch.randn_like(o_ref))
+    o_ref.backward(do)
+    g = K.s3_geom(B, n, shape, kern, dil, heads, dh)
+    qkvp = to_bf_pair(qkv.detach().reshape(B * n, 3 * inner).to(DEV), False)
+    rel_dev = torch.cat((torch.zeros(1, heads), rel.detach().t()), 0).contiguous().to(DEV)   # kernel layout [J, heads], slot 0 = <bos>
+    o = K.sparse3dna_fwd(g, qkvp, wth.detach().to(DEV), rel_bias=rel_dev)
+    report('s3_mfma_rel.fwd', o.hi.float().reshape(B, n, heads, dh), o_ref.detach(), 2 ** -7)
+    dqkv, dwth, drel = K.sparse3dna_bwd(g, qkvp, wth.detach().to(DEV), to_bf_pair(do.reshape(B * n, inner).to(DEV), False),
+                                        rel_bias=rel_dev)
+    gq = qkv.grad.reshape(B * n, 3 * inner)
+    got = dqkv.hi.float()
+    for nm, sl in (('dq', slice(0, inner)), ('dk', slice(inner, 2 * inner)), ('dv', slice(2 * inner, 3 * inner))):
+        report(f's3_mfma_rel.{nm}', got[:, sl], gq[:, sl], 2 ** -6)
+    report('s3_mfma_rel.dwth', dwth, wth.grad, 2 ** -6)
+    report('s3_mfma_rel.drel', drel[1:].t(), rel.grad, 2 ** -6)
+
+
 X_CASES = [(3, 20, 7, 2, 32), (2, 100, 33, 8, 64), (1, 64, 256, 8, 64), (2, 33, 31, 4, 32), (2, 70, 64, 3, 64)]
 
 
