@@ -68,6 +68,9 @@ typedef struct {
     int shift_fmap;         /*     activation operand (A for NT, B for TN); ntok = rows per sample */
     int batch_inner;        /* >0: two-level batch: element z lives at (z / batch_inner) * stride +   */
     long long strideA_inner, strideB_inner, strideC_inner;   /*  (z % batch_inner) * stride_inner      */
+    /* NT, bf16 C, batch <= 1: GEGLU gate (np.py:255-258) applied to the product.  C = u [M, N] is in the interleaved-by-8 layout
+     * (see amdnuwa_geglu_il_fwd) and C2 [M, N/2] (bf16 hi[/lo], row pitch ldc2) = a * gelu_erf(gate); NULL = plain GEMM. */
+    uint16_t* C2; uint16_t* C2lo; int ldc2;
 } amdnuwa_gemm_desc;
 
 /* C[M,N] = alpha * A[M,K] . B[N,K]^T (+ bias).  K, lda, ldb multiples of 8. */
@@ -128,6 +131,12 @@ int amdnuwa_colsum(const float* x, float* out, long long R, int D, int accumulat
 /* u = [a | g], each FP columns wide: o = a * gelu_erf(g) */
 int amdnuwa_geglu_fwd(const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* o_hi, uint16_t* o_lo, long long R, int FP,
                       amdnuwa_stream stream);
+/* the same on the interleaved-by-8 layout of u: columns [16 q, 16 q + 8) hold a_{8q..8q+7}, [16 q + 8, 16 q + 16) their gates
+ * (FP % 8 == 0).  The FF1 weight rows are permuted accordingly, so a lane of the GEMM epilogue holds a value and its gate. */
+int amdnuwa_geglu_il_fwd(const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* o_hi, uint16_t* o_lo, long long R, int FP,
+                         amdnuwa_stream stream);
+int amdnuwa_geglu_il_bwd(const uint16_t* u_hi, const uint16_t* u_lo, const uint16_t* d_hi, const uint16_t* d_lo,
+                         uint16_t* du_hi, uint16_t* du_lo, long long R, int FP, amdnuwa_stream stream);
 int amdnuwa_geglu_bwd(const uint16_t* u_hi, const uint16_t* u_lo, const uint16_t* d_hi, const uint16_t* d_lo,
                       uint16_t* du_hi, uint16_t* du_lo, long long R, int FP, amdnuwa_stream stream);
 /* dst[r][c<C] = bf16(src[r][c]), zero for C <= c < Cp */

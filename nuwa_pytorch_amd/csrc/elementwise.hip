@@ -551,7 +551,9 @@ __device__ __forceinline__ void store8(bf16_t* hi, bf16_t* lo, size_t off, const
     if (LO) *reinterpret_cast<uint4*>(lo + off) = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
 }
 
-template <bool LO>
+// IL: u in the interleaved-by-8 layout (columns [16 q, 16 q + 8) = a_{8q..8q+7}, [16 q + 8, 16 q + 16) = the matching gates) that
+// lets the FF1 GEMM epilogue apply the gate itself: a lane of that GEMM owns 16 contiguous output columns
+template <bool LO, bool IL = false>
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* __restrict__ u_lo,
                                                         bf16_t* __restrict__ o_hi, bf16_t* __restrict__ o_lo, long long R, int FP) {
     const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -559,15 +561,15 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict
     const size_t ub = (size_t)row * 2 * FP, ob = (size_t)row * FP;
     for (int c = (threadIdx.x & 63) * 8; c < FP; c += 512) {
         float a[8], g[8], o[8];
-        load8<LO>(u_hi, u_lo, ub + c, a);
-        load8<LO>(u_hi, u_lo, ub + FP + c, g);
+        load8<LO>(u_hi, u_lo, IL ? ub + 2 * c : ub + c, a);
+        load8<LO>(u_hi, u_lo, IL ? ub + 2 * c + 8 : ub + FP + c, g);
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = a[k] * gelu_f(g[k]);
         store8<LO>(o_hi, o_lo, ob + c, o);
     }
 }
 
-template <bool LO>
+template <bool LO, bool IL = false>
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict__ u_hi, const bf16_t* __restrict__ u_lo,
                                                         const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
                                                         bf16_t* __restrict__ du_hi, bf16_t* __restrict__ du_lo, long long R, int FP) {
@@ -576,8 +578,8 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
     const size_t ub = (size_t)row * 2 * FP, db = (size_t)row * FP;
     for (int c = (threadIdx.x & 63) * 8; c < FP; c += 512) {
         float a[8], g[8], d[8], da[8], dg[8];
-        load8<LO>(u_hi, u_lo, ub + c, a);
-        load8<LO>(u_hi, u_lo, ub + FP + c, g);
+        load8<LO>(u_hi, u_lo, IL ? ub + 2 * c : ub + c, a);
+        load8<LO>(u_hi, u_lo, IL ? ub + 2 * c + 8 : ub + FP + c, g);
         load8<LO>(d_hi, d_lo, db + c, d);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -586,8 +588,8 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
             da[k] = d[k] * y;
             dg[k] = d[k] * a[k] * dy;
         }
-        store8<LO>(du_hi, du_lo, ub + c, da);
-        store8<LO>(du_hi, du_lo, ub + FP + c, dg);
+        store8<LO>(du_hi, du_lo, IL ? ub + 2 * c : ub + c, da);
+        store8<LO>(du_hi, du_lo, IL ? ub + 2 * c + 8 : ub + FP + c, dg);
     }
 }
 
@@ -954,6 +956,28 @@ extern "C" int amdnuwa_geglu_fwd(const uint16_t* u_hi, const uint16_t* u_lo, uin
     else if (u_lo && o_lo) hipLaunchKernelGGL((geglu_fwd_kernel<true>), rg, dim3(256), 0, stream, u_hi, u_lo, o_hi, o_lo, R, FP);
     else if (!u_lo && !o_lo) hipLaunchKernelGGL((geglu_fwd_kernel<false>), rg, dim3(256), 0, stream, u_hi, u_lo, o_hi, o_lo, R, FP);
     else hipLaunchKernelGGL(geglu_fwd_generic_kernel, dim3(grid_for((size_t)R * FP / 4)), dim3(256), 0, stream, u_hi, u_lo, o_hi, o_lo, R, FP);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_geglu_il_fwd(const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* o_hi, uint16_t* o_lo, long long R, int FP, hipStream_t stream) {
+    if (!u_hi || !o_hi || FP <= 0 || FP % 8 || (u_lo != nullptr) != (o_lo != nullptr)) return AMDNUWA_ERR_ARG;
+    if (R <= 0) return AMDNUWA_OK;
+    const dim3 rg((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    if (u_lo) hipLaunchKernelGGL((geglu_fwd_kernel<true, true>), rg, dim3(256), 0, stream, u_hi, u_lo, o_hi, o_lo, R, FP);
+    else hipLaunchKernelGGL((geglu_fwd_kernel<false, true>), rg, dim3(256), 0, stream, u_hi, u_lo, o_hi, o_lo, R, FP);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_geglu_il_bwd(const uint16_t* u_hi, const uint16_t* u_lo, const uint16_t* d_hi, const uint16_t* d_lo,
+                                    uint16_t* du_hi, uint16_t* du_lo, long long R, int FP, hipStream_t stream) {
+    if (!u_hi || !d_hi || !du_hi || FP <= 0 || FP % 8) return AMDNUWA_ERR_ARG;
+    if ((u_lo != nullptr) != (d_lo != nullptr) || (u_lo != nullptr) != (du_lo != nullptr)) return AMDNUWA_ERR_ARG;
+    if (R <= 0) return AMDNUWA_OK;
+    const dim3 rg((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    if (u_lo) hipLaunchKernelGGL((geglu_bwd_kernel<true, true>), rg, dim3(256), 0, stream, u_hi, u_lo, d_hi, d_lo, du_hi, du_lo, R, FP);
+    else hipLaunchKernelGGL((geglu_bwd_kernel<false, true>), rg, dim3(256), 0, stream, u_hi, u_lo, d_hi, d_lo, du_hi, du_lo, R, FP);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

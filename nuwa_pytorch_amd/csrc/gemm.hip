@@ -34,6 +34,7 @@ struct GemmArgs {
     int batch_inner;        // >0: batch index z -> (z / batch_inner) * stride + (z % batch_inner) * stride_in
     long long sA_in, sB_in, sC_in;
     int nsplit;             // TN 256 ring: number of K splits (the grid is flattened over (split, tile))
+    bf16_t* C2; int ldc2;   // NT bf16 epilogue: GEGLU output (C in the interleaved-by-8 layout), or NULL
     int dbg;                // probe only (tuning key 7): bit0 skip epilogue stores, bit1 skip main loop
 };
 
@@ -589,8 +590,23 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
             bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;
             if (!Cl && vec8 && nb + 16 <= p.N) {
-                reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
-                reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
+                const uint4 ua = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
+                const uint4 ug = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
+                reinterpret_cast<uint4*>(C)[0] = ua;
+                reinterpret_cast<uint4*>(C)[1] = ug;
+                if (p.C2) {
+                    // GEGLU on the values as STORED (bf16-rounded u), so the result equals the separate kernel's bit for bit:
+                    // the lane's 16 columns are 8 values and their 8 gates (interleaved-by-8 weight rows)
+                    const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w}, wg[4] = {ug.x, ug.y, ug.z, ug.w};
+                    float o[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        o[2 * k] = lo_f(wa[k]) * gelu_f(lo_f(wg[k]));
+                        o[2 * k + 1] = hi_f(wa[k]) * gelu_f(hi_f(wg[k]));
+                    }
+                    *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) =
+                        make_uint4(pack2_rne(o[0], o[1]), pack2_rne(o[2], o[3]), pack2_rne(o[4], o[5]), pack2_rne(o[6], o[7]));
+                }
                 continue;
             }
             bf16_t h[16], l[16];
@@ -1225,9 +1241,29 @@ __global__ __launch_bounds__(256) void gemm_nt_rows_kernel(GemmArgs p) {
     }
 }
 
+extern "C" int amdnuwa_geglu_il_fwd(const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* o_hi, uint16_t* o_lo, long long R, int FP, hipStream_t stream);
+
+// can the GEGLU gate ride in the epilogue of the kernel this product will run on (the 256x256 staggered ring, bf16 output)?
+static bool nt_geglu_fusable(const amdnuwa_gemm_desc* d) {
+    if (d->Alo || d->Clo || d->C2lo || !d->c_is_bf16 || d->batch > 1) return false;
+    if (d->K % 32 || d->N % 16 || d->ldc % 8 || d->ldc2 % 8) return false;
+    const int v = g_amdnuwa_tuning[0];
+    if (v == 7) return true;
+    if (v != 0 || d->M <= 4 * ROWS_MR) return false;
+    return (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 512;
+}
+
 extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     if (!d || !d->A || !d->B || !d->C) return AMDNUWA_ERR_ARG;
     if (d->M <= 0 || d->N <= 0) return AMDNUWA_OK;
+    if (d->C2 && !nt_geglu_fusable(d)) {             // plain product, then the stand-alone gate kernel on the same layout
+        if (!d->c_is_bf16 || d->N % 16 || d->ldc != d->N || d->ldc2 != d->N / 2 || d->batch > 1) return AMDNUWA_ERR_ARG;
+        amdnuwa_gemm_desc plain = *d;
+        plain.C2 = nullptr; plain.C2lo = nullptr;
+        const int rc = amdnuwa_gemm_nt(&plain, stream);
+        if (rc) return rc;
+        return amdnuwa_geglu_il_fwd((const uint16_t*)d->C, d->Clo, d->C2, d->C2lo, d->M, d->N / 2, stream);
+    }
     if (d->K % 8 || d->lda % 8 || d->ldb % 8) return AMDNUWA_ERR_ARG;
     if ((d->Alo == nullptr) != (d->Blo == nullptr)) return AMDNUWA_ERR_ARG;
     if (d->shift_ntok > 0 && (d->shift_fmap <= 0 || d->K % 32)) return AMDNUWA_ERR_ARG;
@@ -1241,6 +1277,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     p.tiles_m = (d->M + BM - 1) / BM; p.tiles_n = (d->N + BN - 1) / BN;
     p.ksplit_len = 0;
     p.dbg = g_amdnuwa_tuning[7];
+    p.C2 = nullptr; p.ldc2 = 0;
     p.batch_inner = d->batch_inner; p.sA_in = d->strideA_inner; p.sB_in = d->strideB_inner; p.sC_in = d->strideC_inner;
     const bool x3 = d->Alo != nullptr, sh = d->shift_ntok > 0, ob = d->c_is_bf16 != 0;
     // a handful of rows (the decode step of generate()): stream the weight instead of running MFMA tiles
@@ -1299,6 +1336,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     }
     if (!x3 && variant == 7 && d->K % 32 == 0) {                           // 256x256 tile, 4-stage ring, staggered wave rows
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
+        if (d->C2) { p.C2 = (bf16_t*)d->C2; p.ldc2 = d->ldc2; }
         dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(512);
 #define GS(SH, EP)                                                                                                    \
     do {                                                                                                              \

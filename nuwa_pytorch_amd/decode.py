@@ -103,7 +103,7 @@ class IncrementalDecoder:
             else:
                 W = ops.FFInner.weights(inner._cache, p)
                 u = K.gemm_nt(h, W['w1'], out_bf16=True)
-                gg = K.geglu_fwd(u, W['FP'])
+                gg = K.geglu_fwd(u, W['FP'], interleaved=True)
                 y = K.gemm_nt(gg, W['w2'], out_bf16=fast)
             # post-norm + residual, the next block's pre-norm and its token shift (cache write + gather): one launch
             nxt = blocks[i + 1] if i + 1 < len(blocks) else None

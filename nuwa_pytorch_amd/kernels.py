@@ -92,7 +92,7 @@ def timer_collect():
     return ms.value, n.value, _TIMER['flops'], _TIMER.get('bytes', 0.0)
 
 
-def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None, N=None, K=None):
+def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None, N=None, K=None, geglu_out=None):
     """C[M,N] = alpha * A[M,K] @ B[N,K]^T (+ bias).  A, B: BF pairs of 2-D views.
     out: fp32 tensor view or BF pair view (allocated when None).  shift = (ntok, fmap) folds the
     token shift into A's loader."""
@@ -115,6 +115,9 @@ def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None,
     d.bias = _p(bias)
     d.alpha, d.beta = float(alpha), 0.0
     d.M, d.N, d.K, d.batch = M, N, K, 1
+    if geglu_out is not None:      # C (bf16, interleaved-by-8 columns) = u; geglu_out BF [M, N/2] = a * gelu(gate), in the epilogue when possible
+        assert out_bf16
+        d.C2, d.C2lo, d.ldc2 = _p(geglu_out.hi), _p(geglu_out.lo), _ld(geglu_out.hi)
     if shift is not None:
         d.shift_ntok, d.shift_fmap = int(shift[0]), int(shift[1])
     st = _stream()
@@ -267,21 +270,39 @@ def colsum(x):
     return out
 
 
-def geglu_fwd(u, FP):
+def geglu_fwd(u, FP, interleaved=False):
+    """u BF [R, 2*FP] -> a * gelu(gate) BF [R, FP].  interleaved: u in the interleaved-by-8 layout (see geglu_interleave)"""
     L = _lib.lib()
     R = u.hi.shape[0]
     out = empty_bf((R, FP), u.hi.device, lo=u.lo is not None)
-    check(L.amdnuwa_geglu_fwd(_p(u.hi), _p(u.lo), _p(out.hi), _p(out.lo), R, FP, _stream()), 'amdnuwa_geglu_fwd')
+    fn = L.amdnuwa_geglu_il_fwd if interleaved else L.amdnuwa_geglu_fwd
+    check(fn(_p(u.hi), _p(u.lo), _p(out.hi), _p(out.lo), R, FP, _stream()), 'amdnuwa_geglu_fwd')
     return out
 
 
-def geglu_bwd(u, dgg, FP):
+def geglu_bwd(u, dgg, FP, interleaved=False):
     L = _lib.lib()
     R = u.hi.shape[0]
     du = empty_bf((R, 2 * FP), u.hi.device, lo=u.lo is not None)
-    check(L.amdnuwa_geglu_bwd(_p(u.hi), _p(u.lo), _p(dgg.hi), _p(dgg.lo), _p(du.hi), _p(du.lo), R, FP, _stream()),
-          'amdnuwa_geglu_bwd')
+    fn = L.amdnuwa_geglu_il_bwd if interleaved else L.amdnuwa_geglu_bwd
+    check(fn(_p(u.hi), _p(u.lo), _p(dgg.hi), _p(dgg.lo), _p(du.hi), _p(du.lo), R, FP, _stream()), 'amdnuwa_geglu_bwd')
     return du
+
+
+def geglu_interleave(t, FP, dim=0):
+    """[a (FP) | gate (FP)] along `dim` -> the interleaved-by-8 order: 8 values, their 8 gates, the next 8 values, ...
+    (FP % 8 == 0).  geglu_deinterleave is the inverse."""
+    shp = list(t.shape)
+    assert shp[dim] == 2 * FP and FP % 8 == 0
+    v = t.reshape(shp[:dim] + [2, FP // 8, 8] + shp[dim + 1:])
+    return v.transpose(dim, dim + 1).reshape(shp)
+
+
+def geglu_deinterleave(t, FP, dim=0):
+    shp = list(t.shape)
+    assert shp[dim] == 2 * FP and FP % 8 == 0
+    v = t.reshape(shp[:dim] + [FP // 8, 2, 8] + shp[dim + 1:])
+    return v.transpose(dim, dim + 1).reshape(shp)
 
 
 def cast_pad(src, out, row0=0, Cp=None):

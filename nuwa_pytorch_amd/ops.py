@@ -211,12 +211,16 @@ class FFInner:
             D, FFI = w2.shape
             FP = _ru(FFI, 32)
             dev = w1.device
+            # FF1 rows in the interleaved-by-8 order (8 value rows, their 8 gate rows, ...): a lane of the GEMM epilogue owns 16
+            # contiguous output columns, so it holds values AND gates and can apply the GEGLU gate itself
+            w1pad = torch.zeros((2 * FP, D), dtype=torch.float32, device=dev)
+            w1pad[:FFI] = w1.detach()[:FFI]
+            w1pad[FP:FP + FFI] = w1.detach()[FFI:]
+            w1il = K.geglu_interleave(w1pad, FP, dim=0).contiguous()
             w1p = K.zeros_bf((2 * FP, D), dev)
-            K.cast_pad(w1.detach()[:FFI], w1p, row0=0)
-            K.cast_pad(w1.detach()[FFI:], w1p, row0=FP)
+            K.cast_pad(w1il, w1p, row0=0)
             w1T = K.zeros_bf((D, 2 * FP), dev)
-            K.transpose_cast(w1.detach()[:FFI], w1T, col0=0)
-            K.transpose_cast(w1.detach()[FFI:], w1T, col0=FP)
+            K.transpose_cast(w1il, w1T, col0=0)
             w2p = K.zeros_bf((D, FP), dev)
             K.cast_pad(w2.detach(), w2p, Cp=FP)
             w2T = K.zeros_bf((FP, D), dev)
@@ -227,8 +231,8 @@ class FFInner:
     @staticmethod
     def fwd(h, p, meta):
         W = FFInner.weights(meta['cache'], p)
-        u = K.gemm_nt(h, W['w1'], out_bf16=True, shift=meta.get('shift'))
-        gg = K.geglu_fwd(u, W['FP'])
+        gg = K.empty_bf((h.hi.shape[0], W['FP']), h.hi.device)
+        u = K.gemm_nt(h, W['w1'], out_bf16=True, shift=meta.get('shift'), geglu_out=gg)   # u (interleaved layout) and a * gelu(gate)
         y = K.gemm_nt(gg, W['w2'], out_bf16=_fast())
         return y, (h, u, gg)
 
@@ -241,15 +245,17 @@ class FFInner:
         dgg = K.gemm_nt(dy, W['w2T'], out_bf16=True)
         dw2 = torch.empty_like(w2)
         meta['wg'].run(lambda: K.gemm_tn(dy, gg, dw2, N2=FFI))
-        du = K.geglu_bwd(u, dgg, FP)
+        du = K.geglu_bwd(u, dgg, FP, interleaved=True)
         dh = K.gemm_nt(du, W['w1T'], out_bf16=_fast())
         sh = meta.get('shift')
-        if FP == FFI:
-            dw1 = torch.empty_like(w1)
-            meta['wg'].run(lambda: K.gemm_tn(du, h, dw1, shift=sh))
-        else:                                   # one wgrad GEMM over the padded [a | gate] layout, then drop the (zero) pad rows
-            dw1p = torch.empty((2 * FP, w1.shape[1]), dtype=torch.float32, device=w1.device)
-            dw1 = meta['wg'].run(lambda: (K.gemm_tn(du, h, dw1p, shift=sh), torch.cat((dw1p[:FFI], dw1p[FP:FP + FFI]), 0))[1])
+        # one wgrad GEMM over the padded, interleaved [8 values | 8 gates | ...] row order, then back to the parameter's layout
+        dw1p = torch.empty((2 * FP, w1.shape[1]), dtype=torch.float32, device=w1.device)
+
+        def wgrad():
+            K.gemm_tn(du, h, dw1p, shift=sh)
+            d = K.geglu_deinterleave(dw1p, FP, dim=0)
+            return torch.cat((d[:FFI], d[FP:FP + FFI]), 0)
+        dw1 = meta['wg'].run(wgrad)
         return dh, None, [dw1, dw2]
 
 

@@ -311,6 +311,56 @@ def test_geglu(K):
         K.set_precision('bf16')
 
 
+@pytest.mark.parametrize('x3', [False, True])
+def test_geglu_interleaved_layout(K, x3):
+    """the interleaved-by-8 form of u (8 values, their 8 gates, ...) that the FF1 GEMM epilogue produces: same numbers as the
+    [a | gate] form, and interleave / de-interleave are inverse permutations"""
+    torch.manual_seed(15)
+    R, FP = 37, 96
+    u = torch.randn(R, 2 * FP)
+    dy = torch.randn(R, FP)
+    if not x3:
+        u, dy = bf_round(u), bf_round(dy)
+    assert torch.equal(K.geglu_deinterleave(K.geglu_interleave(u, FP, dim=1), FP, dim=1), u)
+    ub, db = to_bf_pair(u.to(DEV), x3), to_bf_pair(dy.to(DEV), x3)
+    uil = to_bf_pair(K.geglu_interleave(u, FP, dim=1).contiguous().to(DEV), x3)
+    o_ref, o_il = K.geglu_fwd(ub, FP), K.geglu_fwd(uil, FP, interleaved=True)
+    assert torch.equal(o_ref.hi, o_il.hi)
+    du_ref, du_il = K.geglu_bwd(ub, db, FP), K.geglu_bwd(uil, db, FP, interleaved=True)
+    assert torch.equal(K.geglu_deinterleave(du_il.hi, FP, dim=1), du_ref.hi)
+    if x3:
+        assert torch.equal(o_ref.lo, o_il.lo) and torch.equal(K.geglu_deinterleave(du_il.lo, FP, dim=1), du_ref.lo)
+
+
+@pytest.mark.parametrize('M,N,Kd,x3', [(16384, 2752, 512, False), (300, 96, 64, False), (300, 96, 64, True), (8, 2752, 512, False)])
+def test_gemm_nt_with_geglu_epilogue(K, M, N, Kd, x3):
+    """FF1: u = h W1^T and a * gelu(gate) from one call.  On the 256x256 ring (the first shape) the gate runs in the GEMM
+    epilogue; elsewhere the library falls back to GEMM + gate kernel.  Both must equal the two separate calls bit for bit."""
+    torch.manual_seed(M % 97)
+    a = torch.randn(M, Kd) * 0.5
+    w = torch.randn(N, Kd) * 0.2
+    if not x3:
+        a, w = bf_round(a), bf_round(w)
+    ap, wp = to_bf_pair(a.to(DEV), x3), to_bf_pair(w.to(DEV), x3)
+    FP = N // 2
+    K.set_precision('bf16x3' if x3 else 'bf16')
+    try:
+        u_ref = K.gemm_nt(ap, wp, out_bf16=True)
+        gg_ref = K.geglu_fwd(u_ref, FP, interleaved=True)
+        gg = K.empty_bf((M, FP), DEV)
+        u = K.gemm_nt(ap, wp, out_bf16=True, geglu_out=gg)
+    finally:
+        K.set_precision('bf16')
+    assert torch.equal(u.hi, u_ref.hi) and torch.equal(gg.hi, gg_ref.hi)
+    if x3:
+        assert torch.equal(gg.lo, gg_ref.lo)
+    ud = K.geglu_deinterleave(bf_value(u).cpu(), FP, dim=1)
+    ref = (a.double() @ K.geglu_deinterleave(w, FP, dim=0).double().t()).float()
+    report(f'gemm_geglu.u[{M},{N},x3={x3}]', ud, ref, 2e-5 if x3 else 2 ** -8)
+    y_ref = ud[:, :FP] * F.gelu(ud[:, FP:])
+    report(f'gemm_geglu.gg[{M},{N},x3={x3}]', bf_value(gg).cpu(), y_ref, 2e-5 if x3 else 2 ** -7)
+
+
 def test_casts(K):
     torch.manual_seed(8)
     w = torch.randn(70, 52, device=DEV)
