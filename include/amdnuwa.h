@@ -71,10 +71,17 @@ typedef struct {
     /* NT, bf16 C, batch <= 1: GEGLU gate (np.py:255-258) applied to the product.  C = u [M, N] is in the interleaved-by-8 layout
      * (see amdnuwa_geglu_il_fwd) and C2 [M, N/2] (bf16 hi[/lo], row pitch ldc2) = a * gelu_erf(gate); NULL = plain GEMM. */
     uint16_t* C2; uint16_t* C2lo; int ldc2;
+    /* ... and its backward: with geglu_u != NULL the product is dgg = d(a * gelu(gate)) [M, N] and C2 [M, 2N] (pitch ldc2)
+     * receives du = (dgg * gelu(gate) | dgg * a * gelu'(gate)) in the interleaved layout, computed from geglu_u [M, 2N]
+     * (pitch ld_u, hi[/lo]).  When amdnuwa_gemm_nt_fused(d) != 0 this happens in the GEMM epilogue and C is NOT written;
+     * otherwise C receives dgg and the stand-alone kernel follows. */
+    const uint16_t* geglu_u; const uint16_t* geglu_u_lo; int ld_u;
 } amdnuwa_gemm_desc;
 
 /* C[M,N] = alpha * A[M,K] . B[N,K]^T (+ bias).  K, lda, ldb multiples of 8. */
 int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, amdnuwa_stream stream);
+/* 1 when the C2 (GEGLU) output of this product is produced inside the GEMM epilogue, 0 when the library will run GEMM + gate kernel */
+int amdnuwa_gemm_nt_fused(const amdnuwa_gemm_desc* d);
 /* C[M,N] (fp32) = beta*C + alpha * A[K,M]^T . B[K,N]   (reduction over the K token rows, split-K
  * through `workspace`, fixed summation order => deterministic).  lda, ldb multiples of 8; operand rows
  * must be readable up to the next multiple of 8 columns (padding content is irrelevant). */

@@ -6,7 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libamdnuwa.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 P = C.c_void_p
 I = C.c_int
@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
                 ('c_is_bf16', I), ('bias', P), ('alpha', F), ('beta', F),
                 ('M', I), ('N', I), ('K', I), ('batch', I), ('shift_ntok', I), ('shift_fmap', I),
                 ('batch_inner', I), ('strideA_inner', LL), ('strideB_inner', LL), ('strideC_inner', LL),
-                ('C2', P), ('C2lo', P), ('ldc2', I)]
+                ('C2', P), ('C2lo', P), ('ldc2', I), ('geglu_u', P), ('geglu_u_lo', P), ('ld_u', I)]
 
 
 class S3Geom(C.Structure):
@@ -69,6 +69,7 @@ SIGNATURES = {
     'amdnuwa_colsum_workspace_bytes': (SZ, [LL, I]),
     'amdnuwa_colsum': (I, [P, P, LL, I, I, P, SZ, P]),
     'amdnuwa_geglu_fwd': (I, [P, P, P, P, LL, I, P]),
+    'amdnuwa_gemm_nt_fused': (I, [GD]),
     'amdnuwa_geglu_il_fwd': (I, [P, P, P, P, LL, I, P]),
     'amdnuwa_geglu_il_bwd': (I, [P, P, P, P, P, P, LL, I, P]),
     'amdnuwa_geglu_bwd': (I, [P, P, P, P, P, P, LL, I, P]),

@@ -35,6 +35,7 @@ struct GemmArgs {
     long long sA_in, sB_in, sC_in;
     int nsplit;             // TN 256 ring: number of K splits (the grid is flattened over (split, tile))
     bf16_t* C2; int ldc2;   // NT bf16 epilogue: GEGLU output (C in the interleaved-by-8 layout), or NULL
+    const bf16_t* Uin; int ldu;   // != NULL: GEGLU BACKWARD epilogue: C2 = du from (product = dgg, Uin = u); C is not written
     int dbg;                // probe only (tuning key 7): bit0 skip epilogue stores, bit1 skip main loop
 };
 
@@ -592,6 +593,33 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
             if (!Cl && vec8 && nb + 16 <= p.N) {
                 const uint4 ua = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
                 const uint4 ug = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
+                if (p.Uin) {
+                    // GEGLU backward: the lane's 16 columns of dgg (as bf16, like the stand-alone kernel reads them) meet the two
+                    // 16-column groups [8 values | 8 gates] of u they belong to; du leaves in the same interleaved layout
+                    const uint4* up = reinterpret_cast<const uint4*>(p.Uin + m * p.ldu + 2 * nb);
+                    uint4* dp = reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + 2 * nb);
+                    const uint4 dg2[2] = {ua, ug};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint4 av = up[2 * q], gv = up[2 * q + 1];
+                        const uint32_t wa[4] = {av.x, av.y, av.z, av.w}, wg[4] = {gv.x, gv.y, gv.z, gv.w};
+                        const uint32_t wd[4] = {dg2[q].x, dg2[q].y, dg2[q].z, dg2[q].w};
+                        float da[8], dgt[8];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float y, dy;
+                            gelu_both_f(lo_f(wg[k]), y, dy);
+                            da[2 * k] = lo_f(wd[k]) * y;
+                            dgt[2 * k] = lo_f(wd[k]) * lo_f(wa[k]) * dy;
+                            gelu_both_f(hi_f(wg[k]), y, dy);
+                            da[2 * k + 1] = hi_f(wd[k]) * y;
+                            dgt[2 * k + 1] = hi_f(wd[k]) * hi_f(wa[k]) * dy;
+                        }
+                        dp[2 * q] = make_uint4(pack2_rne(da[0], da[1]), pack2_rne(da[2], da[3]), pack2_rne(da[4], da[5]), pack2_rne(da[6], da[7]));
+                        dp[2 * q + 1] = make_uint4(pack2_rne(dgt[0], dgt[1]), pack2_rne(dgt[2], dgt[3]), pack2_rne(dgt[4], dgt[5]), pack2_rne(dgt[6], dgt[7]));
+                    }
+                    continue;
+                }
                 reinterpret_cast<uint4*>(C)[0] = ua;
                 reinterpret_cast<uint4*>(C)[1] = ug;
                 if (p.C2) {
@@ -1243,25 +1271,37 @@ __global__ __launch_bounds__(256) void gemm_nt_rows_kernel(GemmArgs p) {
 
 extern "C" int amdnuwa_geglu_il_fwd(const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* o_hi, uint16_t* o_lo, long long R, int FP, hipStream_t stream);
 
+extern "C" int amdnuwa_geglu_il_bwd(const uint16_t* u_hi, const uint16_t* u_lo, const uint16_t* d_hi, const uint16_t* d_lo,
+                                    uint16_t* du_hi, uint16_t* du_lo, long long R, int FP, hipStream_t stream);
+
 // can the GEGLU gate ride in the epilogue of the kernel this product will run on (the 256x256 staggered ring, bf16 output)?
 static bool nt_geglu_fusable(const amdnuwa_gemm_desc* d) {
     if (d->Alo || d->Clo || d->C2lo || !d->c_is_bf16 || d->batch > 1) return false;
     if (d->K % 32 || d->N % 16 || d->ldc % 8 || d->ldc2 % 8) return false;
+    if (d->geglu_u && (d->geglu_u_lo || d->ld_u % 8)) return false;
     const int v = g_amdnuwa_tuning[0];
     if (v == 7) return true;
     if (v != 0 || d->M <= 4 * ROWS_MR) return false;
     return (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 512;
 }
 
+extern "C" int amdnuwa_gemm_nt_fused(const amdnuwa_gemm_desc* d) { return d && d->C2 && nt_geglu_fusable(d) ? 1 : 0; }
+
 extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     if (!d || !d->A || !d->B || !d->C) return AMDNUWA_ERR_ARG;
     if (d->M <= 0 || d->N <= 0) return AMDNUWA_OK;
+    if (d->geglu_u && !d->C2) return AMDNUWA_ERR_ARG;
     if (d->C2 && !nt_geglu_fusable(d)) {             // plain product, then the stand-alone gate kernel on the same layout
-        if (!d->c_is_bf16 || d->N % 16 || d->ldc != d->N || d->ldc2 != d->N / 2 || d->batch > 1) return AMDNUWA_ERR_ARG;
+        if (!d->c_is_bf16 || d->ldc != d->N || d->batch > 1) return AMDNUWA_ERR_ARG;
         amdnuwa_gemm_desc plain = *d;
-        plain.C2 = nullptr; plain.C2lo = nullptr;
+        plain.C2 = nullptr; plain.C2lo = nullptr; plain.geglu_u = nullptr; plain.geglu_u_lo = nullptr;
         const int rc = amdnuwa_gemm_nt(&plain, stream);
         if (rc) return rc;
+        if (d->geglu_u) {
+            if (d->N % 8 || d->ld_u != 2 * d->N || d->ldc2 != 2 * d->N) return AMDNUWA_ERR_ARG;
+            return amdnuwa_geglu_il_bwd(d->geglu_u, d->geglu_u_lo, (const uint16_t*)d->C, d->Clo, d->C2, d->C2lo, d->M, d->N, stream);
+        }
+        if (d->N % 16 || d->ldc2 != d->N / 2) return AMDNUWA_ERR_ARG;
         return amdnuwa_geglu_il_fwd((const uint16_t*)d->C, d->Clo, d->C2, d->C2lo, d->M, d->N / 2, stream);
     }
     if (d->K % 8 || d->lda % 8 || d->ldb % 8) return AMDNUWA_ERR_ARG;
@@ -1277,7 +1317,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     p.tiles_m = (d->M + BM - 1) / BM; p.tiles_n = (d->N + BN - 1) / BN;
     p.ksplit_len = 0;
     p.dbg = g_amdnuwa_tuning[7];
-    p.C2 = nullptr; p.ldc2 = 0;
+    p.C2 = nullptr; p.ldc2 = 0; p.Uin = nullptr; p.ldu = 0;
     p.batch_inner = d->batch_inner; p.sA_in = d->strideA_inner; p.sB_in = d->strideB_inner; p.sC_in = d->strideC_inner;
     const bool x3 = d->Alo != nullptr, sh = d->shift_ntok > 0, ob = d->c_is_bf16 != 0;
     // a handful of rows (the decode step of generate()): stream the weight instead of running MFMA tiles
@@ -1336,7 +1376,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     }
     if (!x3 && variant == 7 && d->K % 32 == 0) {                           // 256x256 tile, 4-stage ring, staggered wave rows
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
-        if (d->C2) { p.C2 = (bf16_t*)d->C2; p.ldc2 = d->ldc2; }
+        if (d->C2) { p.C2 = (bf16_t*)d->C2; p.ldc2 = d->ldc2; p.Uin = (const bf16_t*)d->geglu_u; p.ldu = d->ld_u; }
         dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(512);
 #define GS(SH, EP)                                                                                                    \
     do {                                                                                                              \

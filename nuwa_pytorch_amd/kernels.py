@@ -132,6 +132,37 @@ def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None,
     return out
 
 
+def gemm_nt_geglu_bwd(dy, w2T, u, FP):
+    """FF backward through the gate: dgg = dy @ w2T^T [M, FP] and du = (dgg * gelu(gate) | dgg * a * gelu'(gate)) in u's interleaved
+    layout.  On the 256x256 ring the gate runs in the GEMM epilogue and dgg never exists in memory; otherwise GEMM + gate kernel."""
+    L = _lib.lib()
+    M, Kd = dy.hi.shape
+    dev = dy.hi.device
+    x3 = dy.lo is not None and w2T.lo is not None
+    du = empty_bf((M, 2 * FP), dev, lo=u.lo is not None)
+    d = GemmDesc()
+    d.A, d.Alo, d.lda = _p(dy.hi), _p(dy.lo) if x3 else None, _ld(dy.hi)
+    d.B, d.Blo, d.ldb = _p(w2T.hi), _p(w2T.lo) if x3 else None, _ld(w2T.hi)
+    d.c_is_bf16, d.ldc = 1, FP
+    d.alpha, d.beta = 1.0, 0.0
+    d.M, d.N, d.K, d.batch = M, FP, Kd, 1
+    d.C2, d.C2lo, d.ldc2 = _p(du.hi), _p(du.lo), 2 * FP
+    d.geglu_u, d.geglu_u_lo, d.ld_u = _p(u.hi), _p(u.lo), _ld(u.hi)
+    d.C = _p(du.hi)                                   # placeholder: not written when the epilogue is fused
+    if not L.amdnuwa_gemm_nt_fused(C.byref(d)):
+        dgg = empty_bf((M, FP), dev, lo=x3 or want_lo())
+        d.C, d.Clo = _p(dgg.hi), _p(dgg.lo)
+    st = _stream()
+    if _TIMER['on']:
+        _TIMER['flops'] += 2.0 * M * FP * Kd * (3 if x3 else 1)
+        _TIMER['bytes'] += (2.0 * (M + FP) * Kd) * (2 if x3 else 1) + float(M) * FP * 8
+        L.amdnuwa_timer_begin(st)
+    check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(geglu backward)')
+    if _TIMER['on']:
+        L.amdnuwa_timer_end(st)
+    return du
+
+
 def gemm_tn(A, B, out, *, alpha=1.0, beta=0.0, shift=None, N1=None, N2=None):
     """out[N1,N2] (fp32 view) = beta*out + alpha * A[R,N1]^T @ B[R,N2]; shift applies to B's loader."""
     L = _lib.lib()

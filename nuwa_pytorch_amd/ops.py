@@ -242,10 +242,12 @@ class FFInner:
         W = FFInner.weights(meta['cache'], p)
         w1, w2 = p
         FP, FFI = W['FP'], W['FFI']
-        dgg = K.gemm_nt(dy, W['w2T'], out_bf16=True)
+        if FUSE_GEGLU_BWD:
+            du = K.gemm_nt_geglu_bwd(dy, W['w2T'], u, FP)      # dgg = dy W2 and the gate's backward in one pass
+        else:
+            du = K.geglu_bwd(u, K.gemm_nt(dy, W['w2T'], out_bf16=True), FP, interleaved=True)
         dw2 = torch.empty_like(w2)
         meta['wg'].run(lambda: K.gemm_tn(dy, gg, dw2, N2=FFI))
-        du = K.geglu_bwd(u, dgg, FP, interleaved=True)
         dh = K.gemm_nt(du, W['w1T'], out_bf16=_fast())
         sh = meta.get('shift')
         # one wgrad GEMM over the padded, interleaved [8 values | 8 gates | ...] row order, then back to the parameter's layout
@@ -261,6 +263,7 @@ class FFInner:
 
 INNERS = {'s3': S3Inner, 'xattn': XInner, 'ff': FFInner}
 
+FUSE_GEGLU_BWD = os.environ.get('AMDNUWA_FUSE_GEGLU_BWD', '1') != '0'   # gate backward inside the dgg GEMM epilogue (A/B switch)
 CHAIN_BWD = os.environ.get('AMDNUWA_CHAIN_BWD', '1') != '0'      # chain the LayerNorm backwards across block boundaries (A/B switch)
 ASYNC_WGRAD = os.environ.get('AMDNUWA_ASYNC_WGRAD', '0') != '0'      # opt-in: measured neutral on MI355X (the split-K GEMM fills every CU)
 _SIDE = {}

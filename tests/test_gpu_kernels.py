@@ -361,6 +361,33 @@ def test_gemm_nt_with_geglu_epilogue(K, M, N, Kd, x3):
     report(f'gemm_geglu.gg[{M},{N},x3={x3}]', bf_value(gg).cpu(), y_ref, 2e-5 if x3 else 2 ** -7)
 
 
+@pytest.mark.parametrize('M,FP,Kd,x3', [(16384, 1376, 512, False), (300, 48, 64, False), (300, 48, 64, True), (8, 1376, 512, False)])
+def test_gemm_nt_with_geglu_backward_epilogue(K, M, FP, Kd, x3):
+    """FF backward through the gate: dgg = dy W2 and du from one call (in the GEMM epilogue on the 256x256 ring, dgg never
+    written) must equal GEMM + stand-alone gate kernel bit for bit, and autograd through a * gelu(gate)"""
+    torch.manual_seed(FP % 89)
+    dy = torch.randn(M, Kd) * 0.5
+    w2T = torch.randn(FP, Kd) * 0.2                    # dgg = dy @ w2T^T
+    u = torch.randn(M, 2 * FP)                         # interleaved layout
+    if not x3:
+        dy, w2T, u = bf_round(dy), bf_round(w2T), bf_round(u)
+    dyp, wp, up = to_bf_pair(dy.to(DEV), x3), to_bf_pair(w2T.to(DEV), x3), to_bf_pair(u.to(DEV), x3)
+    K.set_precision('bf16x3' if x3 else 'bf16')
+    try:
+        dgg_ref = K.gemm_nt(dyp, wp, out_bf16=True)
+        du_ref = K.geglu_bwd(up, dgg_ref, FP, interleaved=True)
+        du = K.gemm_nt_geglu_bwd(dyp, wp, up, FP)
+    finally:
+        K.set_precision('bf16')
+    assert torch.equal(du.hi, du_ref.hi)
+    if x3:
+        assert torch.equal(du.lo, du_ref.lo)
+    ud = K.geglu_deinterleave(u, FP, dim=1).requires_grad_(True)
+    y = ud[:, :FP] * F.gelu(ud[:, FP:])
+    y.backward(bf_value(dgg_ref).cpu())
+    report(f'gemm_geglu_bwd.du[{M},{FP},x3={x3}]', K.geglu_deinterleave(bf_value(du).cpu(), FP, dim=1), ud.grad, 3e-5 if x3 else 2 ** -7)
+
+
 def test_casts(K):
     torch.manual_seed(8)
     w = torch.randn(70, 52, device=DEV)
