@@ -124,7 +124,7 @@ def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None,
     if _TIMER['on']:
         _TIMER['flops'] += 2.0 * M * N * K * (3 if x3 else 1)
         ob = (2 * (2 if out.lo is not None else 1)) if out_bf16 else 4
-        _TIMER['bytes'] += (2.0 * (M + N) * K) * (2 if x3 else 1) + float(M) * N * ob
+        _TIMER['bytes'] += (2.0 * (M + N) * K) * (2 if x3 else 1) + float(M) * N * ob + (float(M) * N if geglu_out is not None else 0.)
         L.amdnuwa_timer_begin(st)
     check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt')
     if _TIMER['on']:
