@@ -11,7 +11,7 @@ Same class names, constructor kwargs, forward() signatures and state-dict keys a
     correction for the talking-heads Conv3d bias.  Head sizes the kernels do not cover (and `use_hip = False`) run the torch-op
     formulations kept next to them (index-table gathers, nothing is unfolded); the audio channel shift is a torch op.
 `dec_reversible=True` (ReversibleDualModalityDecoder, np.py:1489-1655 + reversible_video_audio.py) runs with the reference's
-arithmetic but keeps its activations (no recomputing backward yet).  generate() follows the reference's recompute loop.
+arithmetic, with the recomputing (O(1)-activation-memory) backward of reversible_video_audio.py.  generate() follows the reference's recompute loop.
 """
 import torch
 import torch.nn.functional as F
@@ -300,6 +300,62 @@ class DualReversibleBlock(nn.Module):
             n2 = _residual_to(g, n1, m2)
         return y1, y2, n1, n2
 
+    def backward_pass(self, y1, y2, n1, n2, dy1, dy2, dn1, dn2, *, context, context_mask, video_mask=None, audio_mask=None):
+        """inputs and input-gradients of this block from its outputs and output-gradients; parameter (and text-context) gradients
+        accumulate through the inner autograd calls"""
+        f, g, j, k = self.f.net, self.g.net, self.j.net, self.k.net
+        leaf = lambda t: t.detach().requires_grad_(True)
+        gr = lambda t: t.grad if t.grad is not None else torch.zeros_like(t)      # (a sub-block may ignore an input, e.g. no context frame yet)
+        if self.kind != 'inter_modality_cross_attn':
+            ckw = dict(context=context, context_mask=context_mask) if self.kind == 'intra_modality_cross_attn' else {}
+            # video halves: y2 = x2 + g(y1), y1 = x1 + f(x2)
+            y1g = leaf(y1)
+            x2 = _rev_step(g, y1g, y2, dy2)
+            dx1 = dy1 + gr(y1g)
+            x2g = leaf(x2)
+            x1 = _rev_step(f, x2g, y1, dx1, mask=video_mask, **ckw)
+            dx2 = dy2 + gr(x2g)
+            # audio halves: n2 = m2 + k(n1), n1 = m1 + j(m2)
+            n1g = leaf(n1)
+            m2 = _rev_step(k, n1g, n2, dn2)
+            dm1 = dn1 + gr(n1g)
+            m2g = leaf(m2)
+            m1 = _rev_step(j, m2g, n1, dm1, mask=audio_mask, **ckw)
+            dm2 = dn2 + gr(m2g)
+            return x1, x2, m1, m2, dx1, dx2, dm1, dm2
+        # cross-modality block: y1 = x1 + f(x2, m2); y2 = x2 + k(y1); n1 = m1 + j(m2, y2); n2 = m2 + g(n1)
+        n1g = leaf(n1)
+        m2 = _rev_step(g, n1g, n2, dn2)
+        dm1 = dn1 + gr(n1g)
+        m2g, y2g = leaf(m2), leaf(y2)
+        m1 = _rev_step(j, m2g, n1, dm1, extra=(y2g,), mask=audio_mask, context_mask=video_mask)
+        dm2 = dn2 + gr(m2g)
+        dy2t = dy2 + gr(y2g)                              # the audio side looked at the updated video half
+        y1g = leaf(y1)
+        x2 = _rev_step(k, y1g, y2, dy2t)
+        dx1 = dy1 + gr(y1g)
+        x2g, m2h = leaf(x2), leaf(m2)
+        x1 = _rev_step(f, x2g, y1, dx1, extra=(m2h,), mask=video_mask, context_mask=audio_mask)
+        dx2 = dy2t + gr(x2g)
+        dm2 = dm2 + gr(m2h)
+        return x1, x2, m1, m2, dx1, dx2, dm1, dm2
+
+
+def _rev_step(block, xg, y, dy, extra=(), **kw):
+    """One reversal step of a reversible half: y = x_prev + block(xg, *extra, **kw).  Returns x_prev (no graph) after
+    back-propagating dy through a freshly recomputed block: gradients land in xg.grad, in the .grad of any `extra` / `context`
+    leaf, and accumulate into the block's parameters (the role of reversible_video_audio.py:246-327).  On the fused libamdnuwa
+    node the recomputation and the subtraction are one pass: (-y) + block(xg) = -x_prev."""
+    inner_kw = {a: b for a, b in kw.items() if a in ('context', 'context_mask')}
+    with torch.enable_grad():
+        if not extra and isinstance(block, SandwichNorm) and xg.is_cuda and block._inner(inner_kw.get('context')) is not None:
+            neg = block.fused_residual(xg, resid=-y, **inner_kw)
+            torch.autograd.backward(neg, dy)
+            return -neg.detach()
+        out = block(xg, *extra, **{a: b for a, b in kw.items() if b is not None})
+        torch.autograd.backward(out, dy)
+        return y - out.detach()
+
 
 def _residual_to(block, x, resid, **kw):
     """resid + block(x): the fused libamdnuwa node (residual taken from a different tensor) where the block allows it"""
@@ -309,9 +365,43 @@ def _residual_to(block, x, resid, **kw):
     return resid + block(x, **{a: b for a, b in kw.items() if b is not None})
 
 
+class _DualReversibleStackFn(torch.autograd.Function):
+    """O(1)-activation-memory execution of the reversible dual decoder (the role of reversible_video_audio.py:329-355): the
+    forward keeps only the four output halves; the backward walks the blocks in reverse, rebuilding each block's inputs from its
+    outputs while back-propagating through one recomputed sub-block at a time.  The text context is an explicit input so that
+    its gradient leaves this node once, summed over the blocks."""
+
+    @staticmethod
+    def forward(ctx, video, audio, context, seq, kw):
+        x1 = x2 = video.detach()
+        m1 = m2 = audio.detach()
+        cdet = context.detach() if context is not None else None
+        for block in seq.blocks:
+            x1, x2, m1, m2 = block(x1, x2, m1, m2, context=cdet, **kw)
+        ctx.seq, ctx.kw, ctx.cdet = seq, kw, cdet
+        ctx.save_for_backward(x1, x2, m1, m2)
+        return (x1 + x2) * 0.5, (m1 + m2) * 0.5
+
+    @staticmethod
+    def backward(ctx, dv, da):
+        y1, y2, n1, n2 = ctx.saved_tensors
+        dy1 = dy2 = dv * 0.5
+        dn1 = dn2 = da * 0.5
+        dctx = None
+        for block in reversed(list(ctx.seq.blocks)):
+            leaf = ctx.cdet.detach().requires_grad_(True) if (ctx.cdet is not None and block.kind == 'intra_modality_cross_attn') else None
+            y1, y2, n1, n2, dy1, dy2, dn1, dn2 = block.backward_pass(y1, y2, n1, n2, dy1, dy2, dn1, dn2, context=leaf, **ctx.kw)
+            if leaf is not None and leaf.grad is not None:
+                dctx = leaf.grad if dctx is None else dctx + leaf.grad
+        return dy1 + dy2, dn1 + dn2, dctx, None, None
+
+
 class DualModalityReversibleSequence(nn.Module):
     """reversible_video_audio.py:367-407: both streams are duplicated, run through the blocks, and the two halves AVERAGED.
-    Activations are kept by autograd (the reference's recomputing backward is a memory optimisation; same arithmetic)."""
+    In training the stack runs through _DualReversibleStackFn (activations of one sub-block at a time, as the reference's
+    recomputing backward); `memory_efficient = False` keeps every activation in the autograd graph instead (same forward)."""
+
+    memory_efficient = True
 
     def __init__(self, input_blocks, block_types):
         super().__init__()
@@ -319,6 +409,10 @@ class DualModalityReversibleSequence(nn.Module):
         self.blocks = nn.ModuleList([DualReversibleBlock(kind, *blk) for blk, kind in zip(input_blocks, block_types)])
 
     def forward(self, video, audio, *, context, context_mask=None, video_mask=None, audio_mask=None, reverse=True):
+        if self.memory_efficient and reverse and torch.is_grad_enabled() and video.is_cuda and \
+                (video.requires_grad or audio.requires_grad or any(p.requires_grad for p in self.parameters())):
+            kw = dict(context_mask=context_mask, video_mask=video_mask, audio_mask=audio_mask)
+            return _DualReversibleStackFn.apply(video, audio, context, self, kw)
         x1 = x2 = video
         m1 = m2 = audio
         for block in self.blocks:

@@ -479,3 +479,46 @@ def test_sketch_generate_shapes(A):
     finally:
         A.set_precision('bf16')
     assert a.shape == (1, 1, 3, 16, 16) and bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
+def test_reversible_dual_decoder_recomputing_backward(A):
+    """cfg 5 default (dec_reversible=True): the recomputing backward of the dual decoder gives the gradients of the
+    stored-activation mode (same arithmetic, up to the reconstruction error of x = y - f(.)) with a fraction of its peak memory"""
+    import nuwa_pytorch_amd.video_audio as VA
+
+    def run(efficient, depth):
+        torch.manual_seed(3)
+        dec = VA.ReversibleDualModalityDecoder(dim=64, depth=depth, heads=2, dim_head=32, num_audio_tokens_per_video_frame=8,
+                                               num_video_tokens_per_frame=64, sparse_3dna_video_shape=(4, 8, 8),
+                                               sparse_3dna_kernel_size=3, sparse_3dna_dilations=(1, 2), shift_video_tokens=True,
+                                               shift_audio_tokens=True, cross_modality_attn_every=2).to(DEV)
+        g = torch.Generator().manual_seed(4)
+        video = torch.randn(2, 1 + 4 * 64, 64, generator=g).to(DEV).requires_grad_(True)
+        audio = torch.randn(2, 1 + 4 * 8, 64, generator=g).to(DEV).requires_grad_(True)
+        ctx = torch.randn(2, 6, 64, generator=g).to(DEV).requires_grad_(True)
+        cmask = torch.ones(2, 6, dtype=torch.bool, device=DEV)
+        cmask[1, 4:] = False
+        VA.DualModalityReversibleSequence.memory_efficient = efficient
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        v, a = dec(video, audio, context=ctx, context_mask=cmask)
+        (v.square().mean() + a.square().mean()).backward()
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - base
+        grads = {n: p.grad.clone() for n, p in dec.named_parameters() if p.grad is not None}
+        return peak, grads, video.grad.clone(), audio.grad.clone(), ctx.grad.clone()
+    A.set_precision('bf16x3')
+    try:
+        pe, ge, dve, dae, dce = run(True, 4)
+        ps, gs, dvs, das, dcs = run(False, 4)
+    finally:
+        VA.DualModalityReversibleSequence.memory_efficient = True
+        A.set_precision('bf16')
+    assert set(ge) == set(gs) and len(ge) > 100
+    for n in ge:
+        report(f'dual_rev.{n}', ge[n], gs[n], 2e-3)
+    report('dual_rev.dvideo', dve, dvs, 2e-3)
+    report('dual_rev.daudio', dae, das, 2e-3)
+    report('dual_rev.dcontext', dce, dcs, 2e-3)
+    assert pe < 0.6 * ps, (pe, ps)
