@@ -136,6 +136,10 @@ def sparse3dna_core(q, k, v, w_th, idx, scale, rel_pos_bias=None):
     tab = idx[:nq]                               # (nq, K)
     valid = tab >= 0
     gidx = tab.clamp(min=0) + 1                  # row index into k / v (row 0 is bos)
+    need = int(gidx.max()) + 1                   # non-causal windows reach positions the sequence has not filled: the reference
+    if k.shape[1] < need:                        # pads them with zero rows, which ARE attended (score 0) -- np.py:472-477, 508
+        k = F.pad(k, (0, 0, 0, 0, 0, need - k.shape[1]))
+        v = F.pad(v, (0, 0, 0, 0, 0, need - v.shape[1]))
     qs = q[:, 1:] * scale                        # np.py:494-498
     kg = k[:, gidx.reshape(-1)].reshape(b, nq, K, h, d)
     vg = v[:, gidx.reshape(-1)].reshape(b, nq, K, h, d)
@@ -157,14 +161,15 @@ def sparse3dna_core(q, k, v, w_th, idx, scale, rel_pos_bias=None):
     return torch.cat((v[:, :1], out), dim=1)                  # np.py:608
 
 
-def sparse3dna(x, P, video_shape, kernel_size, dilation, heads, idx=None):
+def sparse3dna(x, P, video_shape, kernel_size, dilation, heads, idx=None, causal=True):
     """Sparse3DNA.forward np.py:459-613.  P keys: to_q.weight, to_kv.weight,
-    talking_heads.weight (h,h,1,1), to_out.weight, to_out.bias [, rel_pos_bias.axial{1,2,3}]."""
+    talking_heads.weight (h,h,1,1), to_out.weight, to_out.bias [, rel_pos_bias.axial{1,2,3}].
+    causal=False (NUWASketch's sketch encoder): symmetric window; row 0 is still treated as <bos> (the reference does)."""
     b, n, D = x.shape
     inner = P['to_q.weight'].shape[0]
     d = inner // heads
     if idx is None:
-        idx = neighbor_table(video_shape, kernel_size, dilation, causal=True)
+        idx = neighbor_table(video_shape, kernel_size, dilation, causal=causal)
     q = x @ P['to_q.weight'].t()
     kv = x @ P['to_kv.weight'].t()               # zero pad rows give k=v=0 and are never attended
     k, v = kv[..., :inner], kv[..., inner:]
@@ -563,6 +568,125 @@ def text_encoder_stack(x, T, depth, heads, mask, rot):
         y2 = x2 + g(y1)
         x1, x2 = y1, y2
     return stable_layer_norm(x1 + x2, T['norm.norm.weight'], T['norm.norm.bias'])
+
+
+# --------------------------------------------------------------------------------------
+# f4  NUWASketch (np.py:761-901, 2297-2571): SparseCross2DNA, sketch encoder, decoder with 2-D nearby cross-attention
+# --------------------------------------------------------------------------------------
+
+def sparse_cross_2dna(x, context, P, heads, image_size, kernel_size, dilation, context_mask=None):
+    """SparseCross2DNA.forward np.py:796-901.  Video token at feature-map position i attends a learned null key + the
+    kernel_size^2 window around i in EVERY sketch frame; the <bos> row attends null + all sketch tokens, without talking heads."""
+    b, n, _ = x.shape
+    h = heads
+    tpf, kn = image_size ** 2, kernel_size ** 2
+    if context_mask is None:
+        context_mask = torch.ones(b, context.shape[1], dtype=torch.bool)
+    inner = P['to_q.weight'].shape[0]
+    q = (x @ P['to_q.weight'].t()).reshape(b, n, h, -1).transpose(1, 2) * (inner // h) ** -0.5
+    kv = context @ P['to_kv.weight'].t()
+    k, v = (t.reshape(b, -1, h, inner // h).transpose(1, 2) for t in kv.chunk(2, dim=-1))      # b h m d
+    nk, nv = P['null_k'][None].expand(b, -1, -1, -1), P['null_v'][None].expand(b, -1, -1, -1)
+    sim_bos = torch.einsum('bhd,bhjd->bhj', q[:, :, 0], torch.cat((nk, k), dim=-2))
+    sim_bos = sim_bos.masked_fill(~F.pad(context_mask[:, None], (1, 0), value=True), FP32_NEG_MAX)
+    out_bos = torch.einsum('bhj,bhjd->bhd', sim_bos.softmax(dim=-1, dtype=torch.float32), torch.cat((nv, v), dim=-2)).reshape(b, 1, -1)
+    if n == 1:
+        return out_bos @ P['to_out.weight'].t()
+    f = context.shape[1] // tpf
+    tab = neighbor_table((1, image_size, image_size), (1, kernel_size, kernel_size), (1, dilation, dilation), causal=False)  # (tpf, kn)
+    valid = tab >= 0
+    idx = tab.clamp(min=0).reshape(-1)
+    gather = lambda t: t.reshape(b, h, f, tpf, -1)[:, :, :, idx].reshape(b, h, f, tpf, kn, -1).permute(0, 1, 3, 2, 4, 5).reshape(b, h, tpf, f * kn, -1)
+    kf, vf = gather(k), gather(v)                                                         # slot order (frame, tap), np.py:855
+    kf = torch.cat((nk[:, :, None].expand(-1, -1, tpf, -1, -1), kf), dim=-2)
+    vf = torch.cat((nv[:, :, None].expand(-1, -1, tpf, -1, -1), vf), dim=-2)
+    qr = q[:, :, 1:]
+    qr = F.pad(qr, (0, 0, 0, (-qr.shape[2]) % tpf)).reshape(b, h, -1, tpf, qr.shape[-1])
+    sim = torch.einsum('bhfid,bhijd->bhfij', qr, kf)
+    cm = context_mask.reshape(b, f, tpf)[:, :, idx].reshape(b, f, tpf, kn) & valid[None, None]
+    cm = F.pad(cm.permute(0, 2, 1, 3).reshape(b, 1, 1, tpf, f * kn), (1, 0), value=True)
+    attn = sim.masked_fill(~cm, FP32_NEG_MAX).softmax(dim=-1, dtype=torch.float32)
+    attn = torch.einsum('gh,bhfij->bgfij', P['talking_heads.weight'].reshape(h, h), attn)
+    out = torch.einsum('bhfij,bhijd->bhfid', attn, vf).permute(0, 2, 3, 1, 4).reshape(b, -1, inner)
+    return torch.cat((out_bos, out), dim=1)[:, :n] @ P['to_out.weight'].t()
+
+
+def sketch_encoder(tokens, T, cfg, mask):
+    """`sketch_transformer` (np.py:2346-2360): plain Transformer (self-attention, FF) or, reversible, (attn, FF) blocks; with
+    cfg['enc_3dna'] the self-attention is a NON-causal Sparse3DNA under ShiftVideoTokens."""
+    shape, heads, fmap = cfg['sketch_shape'], cfg['enc_heads'], cfg['sketch_shape'][1]
+    use3, rev = cfg.get('enc_3dna', False), cfg.get('enc_reversible', False)
+    shift_on = use3 and cfg.get('shift', True)
+    sh = (lambda t: shift_video_tokens(t, fmap)) if shift_on else (lambda t: t)
+
+    def attn_fn(A, key, l):
+        if use3:
+            dil = cfg['dilations'][l % len(cfg['dilations'])]
+            return lambda t: sparse3dna(sh(t), sub(A, key), shape, cfg['kernel_size'], dil, heads, causal=False)
+        return lambda t: attention(t, sub(A, key), heads, mask=mask)
+    if not rev:
+        x = tokens
+        wrapped = use3 and cfg.get('shift', True)            # the non-reversible Transformer only wraps when it shifts (np.py:1154-1157)
+        for l in range(cfg['enc_depth']):
+            A = sub(T, f'layers.{l}')
+            x = sandwich(x, sub(A, '0'), attn_fn(A, '0.fn.fn' if wrapped else '0.fn', l)) + x
+            x = sandwich(x, sub(A, '2'), lambda t, A=A: feedforward(sh(t), sub(A, '2.fn.fn' if wrapped else '2.fn'))) + x
+        return stable_layer_norm(x, T['norm.norm.weight'], T['norm.norm.bias'])
+    x1 = x2 = tokens
+    for l in range(cfg['enc_depth']):
+        A = sub(T, f'layers.{l}')
+        y1 = x1 + sandwich(x2, sub(A, '0'), attn_fn(A, '0.fn.fn', l))
+        y2 = x2 + sandwich(y1, sub(A, '1'), lambda t, A=A: feedforward(sh(t), sub(A, '1.fn.fn')))
+        x1, x2 = y1, y2
+    return stable_layer_norm(x1 + x2, T['norm.norm.weight'], T['norm.norm.bias'])
+
+
+def sketch_decoder(x, V, cfg, context, context_mask):
+    """`video_transformer` of NUWASketch: causal 3DNA, SparseCross2DNA over the sketch tokens, FF (np.py:2386-2405)."""
+    shape, heads, fmap = cfg['video_shape'], cfg['heads'], cfg['video_shape'][1]
+    shift = cfg.get('shift', True)
+    sh = (lambda t: shift_video_tokens(t, fmap)) if shift else (lambda t: t)
+    cross = lambda A, key, l: (lambda t: sparse_cross_2dna(t, context, sub(A, key), heads, fmap, cfg['cross_kernel'],
+                                                           cfg['cross_dilations'][l % len(cfg['cross_dilations'])], context_mask))
+    s3 = lambda A, key, l: (lambda t: sparse3dna(sh(t), sub(A, key), shape, cfg['kernel_size'],
+                                                 cfg['dilations'][l % len(cfg['dilations'])], heads))
+    if not cfg.get('dec_reversible', False):
+        for l in range(cfg['depth']):
+            A = sub(V, f'layers.{l}')
+            x = sandwich(x, sub(A, '0'), s3(A, '0.fn.fn' if shift else '0.fn', l)) + x
+            x = sandwich(x, sub(A, '1'), cross(A, '1.fn', l)) + x
+            x = sandwich(x, sub(A, '2'), lambda t, A=A: feedforward(sh(t), sub(A, '2.fn.fn' if shift else '2.fn'))) + x
+        return stable_layer_norm(x, V['norm.norm.weight'], V['norm.norm.bias'])
+    x1 = x2 = x
+    for l in range(cfg['depth']):
+        A, B = sub(V, f'layers.{2 * l}'), sub(V, f'layers.{2 * l + 1}')
+        y1 = x1 + sandwich(x2, sub(A, '0'), s3(A, '0.fn.fn', l))
+        y2 = x2 + sandwich(y1, sub(A, '1'), lambda t, A=A: feedforward(sh(t), sub(A, '1.fn.fn')))
+        x1, x2 = y1, y2
+        y1 = x1 + sandwich(x2, sub(B, '0'), cross(B, '0.fn', l))
+        y2 = x2 + sandwich(y1, sub(B, '1'), lambda t, B=B: feedforward(sh(t), sub(B, '1.fn.fn')))
+        x1, x2 = y1, y2
+    return stable_layer_norm(x1 + x2, V['norm.norm.weight'], V['norm.norm.bias'])
+
+
+def sketch_loss(P, cfg, sketch_ids, video_ids, sketch_mask=None, training=True):
+    """NUWASketch.forward(return_loss=True) from token ids (np.py:2514-2571): returns (loss, logits, sketch_embeds)."""
+    b = sketch_ids.shape[0]
+    sk = sketch_ids.reshape(b, -1)
+    fr = cfg.get('embed_frac', 0.2)
+    emb = P['sketch_embedding.embed.weight'][sk]
+    if training and fr < 1:
+        emb = emb * fr + emb.detach() * (1 - fr)
+    tokens = emb + axial_pos(P, 'sketch_pos_emb')[:sk.shape[1]]
+    frames = sketch_ids.shape[1]
+    mask = torch.ones(b, sk.shape[1], dtype=torch.bool) if sketch_mask is None else \
+        sketch_mask[:, :, None].expand(-1, -1, sk.shape[1] // frames).reshape(b, -1)
+    ctx = sketch_encoder(tokens, sub(P, 'sketch_transformer'), cfg, mask)
+    ids = video_ids.reshape(b, -1)
+    x = embed_assemble(ids[:, :-1], P, training=training, frac=fr)
+    h = sketch_decoder(x, sub(P, 'video_transformer'), cfg, ctx, mask)
+    logits = h @ P['to_logits.weight'].t()
+    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), ids.reshape(-1)), logits, ctx
 
 
 # --------------------------------------------------------------------------------------

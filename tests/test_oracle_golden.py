@@ -127,6 +127,31 @@ def test_g9_video_audio(name):
     assert n > 150
 
 
+SKETCH_CFG = dict(video_shape=(3, 4, 4), sketch_shape=(2, 4, 4), kernel_size=3, dilations=(1, 2), heads=2, enc_heads=2, depth=3,
+                  enc_depth=2, shift=True, cross_kernel=3, cross_dilations=(1, 2))
+
+
+@pytest.mark.parametrize('name', ['g11a_sketch', 'g11b_sketch_reversible_3dna'])
+def test_g11_sketch(name):
+    """row f4 (NUWASketch): oracle vs the reference's sketch embeddings, logits, loss and every gradient, from the token ids
+    the fixture carries (plain stacks / reversible stacks + non-causal 3DNA sketch encoder + masked sketch frame)"""
+    A, P, G = load(name)
+    P = req(P)
+    rev = bool(A['reversible'])
+    cfg = dict(SKETCH_CFG, enc_reversible=rev, dec_reversible=rev, enc_3dna=rev)
+    smask = A['sketch_mask'] if bool(A['has_mask']) else None
+    loss, logits, ctx = O.sketch_loss(P, cfg, A['sketch_ids'], A['video_ids'], smask)
+    torch.testing.assert_close(ctx, A['sketch_embeds'], **TOL)
+    torch.testing.assert_close(logits, A['logits'], **TOL)
+    torch.testing.assert_close(loss, A['loss'], **TOL)
+    loss.backward()
+    n = 0
+    for k, g in G.items():
+        torch.testing.assert_close(P[k].grad, g, rtol=1e-3, atol=2e-5, msg=lambda m, k=k: f'{k}: {m}')
+        n += 1
+    assert n > 40
+
+
 def test_g10_text_encoder():
     A, P, G = load('g10_text_encoder')
     P = req({k: v for k, v in P.items() if 'net.blocks.' not in k})
