@@ -9,13 +9,23 @@ Design for 8 x MI355X (xGMI is point-to-point, 7 links per GPU):
     accumulates straight into the bucket -- no flatten/unflatten copies);
   * one bucket per decoder layer (+ one for embeddings/logits, + the text encoder), filled in reverse
     layer order by the backward pass; a per-parameter post-accumulate hook counts arrivals and, when a
-    bucket is complete, enqueues `all_reduce` on a dedicated communication stream that waits on an event
-    recorded on the compute stream -- so layer l's all-reduce overlaps the backward of layers < l;
+    bucket is complete, enqueues its reduction on a dedicated communication stream that waits on an event
+    recorded on the compute stream -- so layer l's reduction overlaps the backward of layers < l;
   * a handful of >= 8 MB messages (fp32: ~16.8 MB per cfg-3 decoder layer) instead of hundreds of small
     ones keeps RCCL in its bandwidth regime on every xGMI link;
+  * `collective='allreduce'` (default) is one RCCL all-reduce per bucket; `collective='rs_ag'` is
+    reduce-scatter + all-gather on the same flat buffer (padded to a multiple of the world size), the
+    pair a direct all-to-all transport over the 7 links favours and the form a sharded optimiser would cut
+    in the middle of;
+  * gradient accumulation (the reference trainer runs 8 micro-steps per optimiser step, train_nuwa.py:243):
+    micro-steps run under `no_sync()` -- their gradients only accumulate locally in the flat buffers -- and
+    the LAST backward of the step, outside `no_sync()`, counts arrivals and launches the reductions.  A second
+    counted backward without `zero_grad()` raises instead of silently mixing reduced and local gradients;
   * frozen parameters (the VAE copy inside NUWA never receives gradients -- quirk Q16) are excluded.
 Works with the `gloo` backend on CPU tensors too (used by the world_size-2 tests).
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -28,11 +38,41 @@ def _layer_key(name):
     return parts[0] if parts[0] in ('text_transformer', 'video_transformer') else '_embeddings_logits'
 
 
+def broadcast_parameters(module, src=0, process_group=None):
+    """make every replica identical to rank `src`'s with ONE collective per dtype: parameters and buffers are packed into a
+    flat tensor, broadcast, and scattered back (hundreds of per-tensor broadcasts cost a launch + a ring set-up each)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return 0
+    by_type, seen = {}, set()
+    for t in list(module.parameters()) + list(module.buffers()):
+        if id(t) in seen:
+            continue
+        seen.add(id(t))
+        by_type.setdefault((t.dtype, t.device), []).append(t)
+    sent = 0
+    with torch.no_grad():
+        for (dtype, device), ts in by_type.items():
+            wire = torch.uint8 if dtype == torch.bool else dtype
+            flat = torch.cat([t.detach().reshape(-1).to(wire) for t in ts])
+            dist.broadcast(flat, src=src, group=process_group)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t).to(dtype))
+                off += t.numel()
+            sent += flat.numel() * flat.element_size()
+    return sent
+
+
 class GradReducer:
-    def __init__(self, module, process_group=None, bucket_fn=_layer_key, average=True):
+    def __init__(self, module, process_group=None, bucket_fn=_layer_key, average=True, collective='allreduce'):
+        if collective not in ('allreduce', 'rs_ag'):
+            raise ValueError(collective)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.average = average
+        self.collective = collective
+        self._sync = True
         seen, groups = set(), {}
         for name, p in module.named_parameters():          # named_parameters() de-duplicates shared params
             if not p.requires_grad or id(p) in seen or name.startswith('vae.'):
@@ -42,12 +82,14 @@ class GradReducer:
         self.buckets = []
         for key, ps in groups.items():
             n = sum(p.numel() for p in ps)
-            flat = torch.zeros(n, dtype=ps[0].dtype, device=ps[0].device)
+            padded = -(-n // self.world) * self.world                      # rs_ag: equal shards
+            store = torch.zeros(padded, dtype=ps[0].dtype, device=ps[0].device)
+            flat = store[:n]
             off = 0
             for p in ps:
                 p.grad = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
-            self.buckets.append(dict(key=key, params=ps, flat=flat, pending=len(ps), work=None, event=None))
+            self.buckets.append(dict(key=key, params=ps, flat=flat, store=store, pending=len(ps), work=None, launched=False))
         self._by_param = {id(p): b for b in self.buckets for p in b['params']}
         self.cuda = bool(self.buckets) and self.buckets[0]['flat'].is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
@@ -58,24 +100,58 @@ class GradReducer:
 
     # ------------------------------------------------------------------------------------------
     def zero_grad(self):
-        """reset buckets for the next step (grads stay views into the flat buffers)"""
+        """reset buckets for the next optimiser step (grads stay views into the flat buffers)"""
         for b in self.buckets:
-            b['flat'].zero_()
+            b['store'].zero_()
             b['pending'] = len(b['params'])
             b['work'] = None
+            b['launched'] = False
             off = 0
             for p in b['params']:
                 if p.grad is None or p.grad.data_ptr() != b['flat'].data_ptr() + off * b['flat'].element_size():
                     p.grad = b['flat'][off:off + p.numel()].view_as(p)
                 off += p.numel()
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """gradient accumulation: backward passes inside this context only add into the local flat buffers; run the step's
+        last micro-batch OUTSIDE it, then finish():
+
+            red.zero_grad()
+            for i, mb in enumerate(micro_batches):
+                with (red.no_sync() if i + 1 < len(micro_batches) else contextlib.nullcontext()):
+                    (loss_fn(mb) / len(micro_batches)).backward()
+            red.finish()
+        """
+        prev, self._sync = self._sync, False
+        try:
+            yield self
+        finally:
+            self._sync = prev
+
     def _on_grad(self, p):
+        if not self._sync:
+            return
         b = self._by_param[id(p)]
+        if b['launched']:
+            raise RuntimeError(f'GradReducer: bucket {b["key"]!r} received a gradient after it was reduced -- run every micro-batch '
+                               f'but the last under no_sync(), and call zero_grad() between optimiser steps')
         b['pending'] -= 1
         if b['pending'] == 0:
             self._launch(b)
 
+    def _reduce(self, b):
+        if self.average:
+            b['store'].div_(self.world)
+        if self.collective == 'allreduce':
+            return dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        shard = b['store'].numel() // self.world
+        mine = b['store'][self.rank * shard:(self.rank + 1) * shard]
+        dist.reduce_scatter_tensor(mine, b['store'], op=dist.ReduceOp.SUM, group=self.pg)
+        return dist.all_gather_into_tensor(b['store'], mine, group=self.pg, async_op=True)
+
     def _launch(self, b):
+        b['launched'] = True
         if self.world == 1:
             return
         if self.cuda:
@@ -83,19 +159,17 @@ class GradReducer:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                if self.average:
-                    b['flat'].div_(self.world)
-                b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                b['work'] = self._reduce(b)
         else:
-            if self.average:
-                b['flat'].div_(self.world)
-            b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            b['work'] = self._reduce(b)
 
     def finish(self):
-        """call after backward(): launches buckets whose params got no grad this step (unused
+        """call after the step's last backward(): launches buckets whose params got no grad this step (unused
         parameters stay zero) and makes the compute stream wait for all reductions."""
+        if not self._sync:
+            raise RuntimeError('GradReducer.finish() inside no_sync(): the last micro-batch must run outside the context')
         for b in self.buckets:
-            if b['pending'] > 0 and b['work'] is None:
+            if not b['launched']:
                 self._launch(b)
         for b in self.buckets:
             if b['work'] is not None:

@@ -1,19 +1,24 @@
 """Host-side mirror of the reference's nuwa_pytorch/vqgan_vae.py (vq.py): VQGanVAE with the same
 constructor kwargs, methods and state-dict keys.  On the NUWA training path the VAE is a FROZEN
-tokenizer (copy_for_eval + get_video_indices under no_grad, vq.py:408-458).
+tokenizer (copy_for_eval + get_video_indices under no_grad, vq.py:408-458) and runs through libamdnuwa;
+`forward(img, return_loss=True)` (BASELINE cfg 1, CPU plumbing) runs on torch ops, as in the reference.
 
 `VectorQuantize` restates the third-party vector_quantize_pytorch module the reference imports
 (vq.py:6, 368-378; source not vendored, not installed): PARITY UNPINNED at that boundary
-(SURVEY.md section 8c).  GAN / VGG training of the VAE (vq.py:145-176, 514-543) is out of scope.
+(SURVEY.md section 8c).  Its buffers live under `vq._codebook.*` like the upstream module's, so a reference
+checkpoint loads strictly; the flat names of this repository's earlier fixtures are accepted too.
+
+GAN / VGG training of the VAE (vq.py:145-176, 514-543) is out of scope: `use_vgg_and_gan=True` (the
+reference's default, which downloads a pretrained VGG16) builds the same autoencoder WITHOUT the
+perceptual / adversarial branch and says so once.
 """
 import copy
 import math
-from functools import partial
-from math import sqrt
+import warnings
 
 import torch
 import torch.nn.functional as F
-from torch import nn, einsum
+from torch import nn
 
 MList = nn.ModuleList
 
@@ -36,18 +41,11 @@ def eval_decorator(fn):
     return inner
 
 
-def group_dict_by_key(cond, d):
-    return_val = [dict(), dict()]
-    for key in d.keys():
-        match = bool(cond(key))
-        return_val[int(not match)][key] = d[key]
-    return (*return_val,)
-
-
-def groupby_prefix_and_trim(prefix, d):
-    kwargs_with_prefix, kwargs = group_dict_by_key(lambda k: k.startswith(prefix), d)
-    kwargs_without_prefix = dict(map(lambda x: (x[0][len(prefix):], x[1]), tuple(kwargs_with_prefix.items())))
-    return kwargs_without_prefix, kwargs
+def split_by_prefix(prefix, kwargs):
+    """(kwargs whose name starts with `prefix`, prefix stripped; the rest) -- the `vq_*` pass-through of vq.py:318"""
+    picked = {k[len(prefix):]: v for k, v in kwargs.items() if k.startswith(prefix)}
+    rest = {k: v for k, v in kwargs.items() if not k.startswith(prefix)}
+    return picked, rest
 
 
 def l2norm(t):
@@ -59,9 +57,24 @@ def leaky_relu(p=0.1):
 
 
 def stable_softmax(t, dim=-1, alpha=32 ** 2):
-    t = t / alpha
-    t = t - torch.amax(t, dim=dim, keepdim=True).detach()
-    return (t * alpha).softmax(dim=dim)
+    """vq.py:97-100: softmax of t with the row maximum removed at 1/alpha scale first (same value, tamer exponent range)"""
+    scaled = t / alpha
+    return ((scaled - scaled.amax(dim=dim, keepdim=True).detach()) * alpha).softmax(dim=dim)
+
+
+# ---------------------------------------------------------------------------------------------------
+# vector quantiser (restatement of vector_quantize_pytorch; PARITY UNPINNED)
+# ---------------------------------------------------------------------------------------------------
+
+class _Codebook(nn.Module):
+    """buffer container with the upstream module's names: initted, cluster_size, embed"""
+
+    def __init__(self, codebook_size, dim, kmeans_init, cosine):
+        super().__init__()
+        embed = torch.randn(codebook_size, dim)
+        self.register_buffer('initted', torch.tensor([not kmeans_init]))
+        self.register_buffer('cluster_size', torch.zeros(codebook_size))
+        self.register_buffer('embed', l2norm(embed) if cosine else embed)
 
 
 class VectorQuantize(nn.Module):
@@ -78,53 +91,81 @@ class VectorQuantize(nn.Module):
         self.decay, self.commitment_weight, self.eps = decay, commitment_weight, eps
         self.accept_image_fmap = accept_image_fmap
         self.use_cosine_sim = use_cosine_sim
-        embed = torch.randn(codebook_size, codebook_dim)
-        self.register_buffer('embed', l2norm(embed) if use_cosine_sim else embed)
-        self.register_buffer('cluster_size', torch.zeros(codebook_size))
-        self.register_buffer('initted', torch.tensor([not kmeans_init]))
+        self._codebook = _Codebook(codebook_size, codebook_dim, kmeans_init, use_cosine_sim)
 
-    @property
-    def codebook(self):
-        return self.embed
+    # the three buffers, under the names the rest of the package uses
+    embed = property(lambda self: self._codebook.embed)
+    cluster_size = property(lambda self: self._codebook.cluster_size)
+    initted = property(lambda self: self._codebook.initted)
+    codebook = property(lambda self: self._codebook.embed)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """accept (i) the flat buffer names of this repository's first fixtures (`vq.embed` ...), (ii) upstream releases that
+        carry a leading num_codebooks axis of 1 and an `embed_avg` EMA numerator, (iii) a float `initted` flag"""
+        cb = prefix + '_codebook.'
+        for name in ('embed', 'cluster_size', 'initted'):
+            if prefix + name in state_dict and cb + name not in state_dict:
+                state_dict[cb + name] = state_dict.pop(prefix + name)
+        state_dict.pop(cb + 'embed_avg', None)
+        for name, nd in (('embed', 2), ('cluster_size', 1)):
+            t = state_dict.get(cb + name)
+            if t is not None and t.dim() == nd + 1 and t.shape[0] == 1:
+                state_dict[cb + name] = t[0]
+        t = state_dict.get(cb + 'initted')
+        if t is not None and t.dtype != torch.bool:
+            state_dict[cb + 'initted'] = t.reshape(-1)[:1] != 0
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def _nearest(self, flat):
+        if self.use_cosine_sim:
+            feats = l2norm(flat)
+            if self.training and not bool(self.initted):          # first training batch seeds the codebook
+                pick = torch.randint(0, feats.shape[0], (self.embed.shape[0],), device=feats.device)
+                self.embed.copy_(feats[pick].detach())
+                self.initted.fill_(True)
+            return feats, (feats @ l2norm(self.embed).t()).argmax(dim=-1)
+        return flat, (-torch.cdist(flat, self.embed)).argmax(dim=-1)
+
+    @torch.no_grad()
+    def _ema_update(self, feats, ind):
+        hits = F.one_hot(ind, self.embed.shape[0]).type(feats.dtype)
+        count = hits.sum(0)
+        self.cluster_size.mul_(self.decay).add_(count, alpha=1 - self.decay)
+        sums = hits.t() @ feats
+        fresh = l2norm(sums) if self.use_cosine_sim else sums / count.clamp(min=1)[:, None]
+        target = torch.where((count > 0)[:, None], fresh, self.embed)
+        blended = self.embed * self.decay + target * (1 - self.decay)
+        self.embed.copy_(l2norm(blended) if self.use_cosine_sim else blended)
 
     def forward(self, x):
+        fmap_shape = None
         if self.accept_image_fmap:
-            B, Cc, Hh, Ww = x.shape
-            x = x.permute(0, 2, 3, 1).reshape(B, Hh * Ww, Cc)
+            fmap_shape = x.shape
+            x = x.flatten(2).transpose(1, 2)                      # b c h w -> b (h w) c
         x = self.project_in(x)
-        flat = x.reshape(-1, x.shape[-1])
-        if self.use_cosine_sim:
-            fn = l2norm(flat)
-            if self.training and not bool(self.initted):
-                perm = torch.randint(0, fn.shape[0], (self.embed.shape[0],), device=fn.device)
-                self.embed.copy_(fn[perm].detach())
-                self.initted.fill_(True)
-            sim = fn @ l2norm(self.embed).t()
-        else:
-            fn = flat
-            sim = -torch.cdist(flat, self.embed)
-        ind = sim.argmax(dim=-1)
+        feats, ind = self._nearest(x.reshape(-1, x.shape[-1]))
         quant = self.embed[ind].reshape(x.shape)
-        loss = torch.zeros(1, device=x.device)
+        loss = x.new_zeros(1)
         if self.training:
-            onehot = F.one_hot(ind, self.embed.shape[0]).type(flat.dtype)
-            self.cluster_size.mul_(self.decay).add_(onehot.sum(0), alpha=1 - self.decay)
-            emb_sum = onehot.t() @ fn.detach()
-            hit = (onehot.sum(0) > 0)[:, None]
-            new = torch.where(hit, l2norm(emb_sum) if self.use_cosine_sim else emb_sum / onehot.sum(0).clamp(min=1)[:, None], self.embed)
-            upd = self.embed * self.decay + new * (1 - self.decay)
-            self.embed.copy_(l2norm(upd) if self.use_cosine_sim else upd)
+            self._ema_update(feats.detach(), ind)
             loss = F.mse_loss(quant.detach(), x) * self.commitment_weight
-            quant = x + (quant - x).detach()
+            quant = x + (quant - x).detach()                      # straight-through
         quant = self.project_out(quant)
         ind = ind.reshape(x.shape[:-1])
-        if self.accept_image_fmap:
-            quant = quant.reshape(B, Hh, Ww, -1).permute(0, 3, 1, 2)
+        if fmap_shape is not None:
+            B, _, Hh, Ww = fmap_shape
+            quant = quant.transpose(1, 2).reshape(B, -1, Hh, Ww)
             ind = ind.reshape(B, Hh, Ww)
         return quant, ind, loss.reshape(1)
 
 
+# ---------------------------------------------------------------------------------------------------
+# blocks
+# ---------------------------------------------------------------------------------------------------
+
 class LayerNormChan(nn.Module):
+    """vq.py:129-143: LayerNorm over the channel axis of an NCHW map"""
+
     def __init__(self, dim, eps=1e-5):
         super().__init__()
         self.eps = eps
@@ -132,43 +173,52 @@ class LayerNormChan(nn.Module):
         self.b = nn.Parameter(torch.zeros(1, dim, 1, 1))
 
     def forward(self, x):
-        var = torch.var(x, dim=1, unbiased=False, keepdim=True)
-        mean = torch.mean(x, dim=1, keepdim=True)
-        return (x - mean) / (var + self.eps).sqrt() * self.g + self.b
+        mu = x.mean(dim=1, keepdim=True)
+        var = (x - mu).pow(2).mean(dim=1, keepdim=True)
+        return (x - mu) * torch.rsqrt(var + self.eps) * self.g + self.b
 
 
 class ContinuousPositionBias(nn.Module):
+    """vq.py:178-210: an MLP maps the signed-log relative (dy, dx) of every pair of feature-map positions to one bias per head"""
+
     def __init__(self, *, dim, heads, layers=2):
         super().__init__()
-        self.net = MList([])
-        self.net.append(nn.Sequential(nn.Linear(2, dim), leaky_relu()))
-        for _ in range(layers - 1):
-            self.net.append(nn.Sequential(nn.Linear(dim, dim), leaky_relu()))
+        widths = [2] + [dim] * layers
+        self.net = MList([nn.Sequential(nn.Linear(a, b), leaky_relu()) for a, b in zip(widths[:-1], widths[1:])])
         self.net.append(nn.Linear(dim, heads))
         self.register_buffer('rel_pos', None, persistent=False)
 
+    def _coords(self, side, device):
+        if self.rel_pos is None or self.rel_pos.shape[0] != side * side or self.rel_pos.device != device:
+            ax = torch.arange(side, device=device)
+            yx = torch.cartesian_prod(ax, ax)                                  # (side^2, 2) as (row, col)
+            delta = (yx[:, None] - yx[None]).float()
+            self.rel_pos = delta.sign() * (delta.abs() + 1).log()
+        return self.rel_pos
+
     def forward(self, x):
-        n, device = x.shape[-1], x.device
-        fmap_size = int(sqrt(n))
-        if not exists(self.rel_pos):
-            pos = torch.arange(fmap_size, device=device)
-            grid = torch.stack(torch.meshgrid(pos, pos, indexing='ij')).reshape(2, -1).t()
-            rel_pos = grid[:, None, :] - grid[None, :, :]
-            rel_pos = torch.sign(rel_pos) * torch.log(rel_pos.abs() + 1)
-            self.register_buffer('rel_pos', rel_pos, persistent=False)
-        rel_pos = self.rel_pos.float()
+        h = self._coords(math.isqrt(x.shape[-1]), x.device)
         for layer in self.net:
-            rel_pos = layer(rel_pos)
-        return x + rel_pos.permute(2, 0, 1)
+            h = layer(h)
+        return x + h.movedim(-1, 0)                                           # (i, j, heads) -> (heads, i, j)
+
+
+def _res_body(chan, groups, glu):
+    """conv3x3 -> [GLU | GroupNorm + LeakyReLU] twice, then conv1x1: GLUResBlock keeps (conv, GLU, GroupNorm) order, ResBlock
+    (conv, GroupNorm, LeakyReLU) (vq.py:212-242) -- the indices of the parameterised layers are part of the state-dict keys"""
+    layers = []
+    for _ in range(2):
+        if glu:
+            layers += [nn.Conv2d(chan, chan * 2, 3, padding=1), nn.GLU(dim=1), nn.GroupNorm(groups, chan)]
+        else:
+            layers += [nn.Conv2d(chan, chan, 3, padding=1), nn.GroupNorm(groups, chan), leaky_relu()]
+    return nn.Sequential(*layers, nn.Conv2d(chan, chan, 1))
 
 
 class GLUResBlock(nn.Module):
     def __init__(self, chan, groups=16):
         super().__init__()
-        self.net = nn.Sequential(
-            nn.Conv2d(chan, chan * 2, 3, padding=1), nn.GLU(dim=1), nn.GroupNorm(groups, chan),
-            nn.Conv2d(chan, chan * 2, 3, padding=1), nn.GLU(dim=1), nn.GroupNorm(groups, chan),
-            nn.Conv2d(chan, chan, 1))
+        self.net = _res_body(chan, groups, glu=True)
 
     def forward(self, x):
         return self.net(x) + x
@@ -177,16 +227,15 @@ class GLUResBlock(nn.Module):
 class ResBlock(nn.Module):
     def __init__(self, chan, groups=16):
         super().__init__()
-        self.net = nn.Sequential(
-            nn.Conv2d(chan, chan, 3, padding=1), nn.GroupNorm(groups, chan), leaky_relu(),
-            nn.Conv2d(chan, chan, 3, padding=1), nn.GroupNorm(groups, chan), leaky_relu(),
-            nn.Conv2d(chan, chan, 1))
+        self.net = _res_body(chan, groups, glu=False)
 
     def forward(self, x):
         return self.net(x) + x
 
 
 class VQGanAttention(nn.Module):
+    """vq.py:244-286"""
+
     def __init__(self, *, dim, dim_head=64, heads=8, dropout=0.):
         super().__init__()
         self.heads = heads
@@ -199,22 +248,23 @@ class VQGanAttention(nn.Module):
         self.to_out = nn.Conv2d(inner_dim, dim, 1)
 
     def forward(self, x):
-        h = self.heads
         B, _, height, width = x.shape
-        residual = x.clone()
-        q, k, v = self.to_qkv(x).chunk(3, dim=1)
-        q, k, v = map(lambda t: t.reshape(B, h, -1, height * width), (q, k, v))
-        q, k = map(l2norm, (q, k))          # over the SPATIAL axis (quirk Q9)
-        sim = einsum('b h c i, b h c j -> b h i j', q, k) * self.scale.exp()
-        sim = self.cpb(sim)
-        attn = self.dropout(stable_softmax(sim, dim=-1))
-        out = einsum('b h i j, b h c j -> b h c i', attn, v).reshape(B, -1, height, width)
-        out = self.to_out(out)
-        return self.post_norm(out) + residual
+        q, k, v = (t.reshape(B, self.heads, -1, height * width) for t in self.to_qkv(x).chunk(3, dim=1))
+        q, k = l2norm(q), l2norm(k)                          # over the SPATIAL axis (quirk Q9)
+        sim = torch.matmul(q.transpose(-1, -2), k) * self.scale.exp()
+        attn = self.dropout(stable_softmax(self.cpb(sim), dim=-1))
+        out = torch.matmul(v, attn.transpose(-1, -2)).reshape(B, -1, height, width)
+        return self.post_norm(self.to_out(out)) + x
 
+
+# ---------------------------------------------------------------------------------------------------
+# the autoencoder
+# ---------------------------------------------------------------------------------------------------
 
 class VQGanVAE(nn.Module):
     """vq.py:288-548 (GAN/VGG branch excluded)."""
+
+    _warned_gan = False
 
     def __init__(self, *, dim, image_size, channels=3, num_layers=4, layer_mults=None, l2_recon_loss=False,
                  use_hinge_loss=True, num_resnet_blocks=1, vgg=None, vq_codebook_dim=256, vq_codebook_size=512,
@@ -224,41 +274,46 @@ class VQGanVAE(nn.Module):
         super().__init__()
         assert dim % resnet_groups == 0, f'dimension {dim} must be divisible by {resnet_groups} (groups for the groupnorm)'
         if use_vgg_and_gan:
-            raise NotImplementedError('VQGanVAE GAN/VGG training (use_vgg_and_gan=True) is outside the accelerated path; '
-                                      'construct with use_vgg_and_gan=False (NUWA uses the VAE frozen)')
-        vq_kwargs, kwargs = groupby_prefix_and_trim('vq_', kwargs)
+            if not VQGanVAE._warned_gan:
+                warnings.warn('nuwa_pytorch_amd.VQGanVAE: the perceptual (VGG16) and adversarial (discriminator) losses of the '
+                              'reference are outside this package; building the autoencoder with use_vgg_and_gan=False '
+                              '(reconstruction loss only).  NUWA uses the VAE frozen, so training it is unaffected.', stacklevel=2)
+                VQGanVAE._warned_gan = True
+            use_vgg_and_gan = False
+        vq_kwargs, kwargs = split_by_prefix('vq_', kwargs)
         self.image_size = image_size
         self.channels = channels
         self.num_layers = num_layers
         self.fmap_size = image_size // (num_layers ** 2)        # as in the reference (quirk Q6)
         self.codebook_size = vq_codebook_size
-        self.encoders = MList([])
-        self.decoders = MList([])
-        layer_mults = default(layer_mults, list(map(lambda t: 2 ** t, range(num_layers))))
+        layer_mults = default(layer_mults, [2 ** i for i in range(num_layers)])
         assert len(layer_mults) == num_layers, 'layer multipliers must be equal to designated number of layers'
-        layer_dims = [dim * mult for mult in layer_mults]
-        dims = (dim, *layer_dims)
-        dim_pairs = zip(dims[:-1], dims[1:])
-        append = lambda arr, t: arr.append(t)
-        prepend = lambda arr, t: arr.insert(0, t)
-        if not isinstance(num_resnet_blocks, tuple):
-            num_resnet_blocks = (*((0,) * (num_layers - 1)), num_resnet_blocks)
-        if not isinstance(use_attn, tuple):
-            use_attn = (*((False,) * (num_layers - 1)), use_attn)
-        assert len(num_resnet_blocks) == num_layers and len(use_attn) == num_layers
-        for layer_index, (dim_in, dim_out), layer_num_resnet_blocks, layer_use_attn in zip(range(num_layers), dim_pairs, num_resnet_blocks, use_attn):
-            append(self.encoders, nn.Sequential(nn.Conv2d(dim_in, dim_out, 4, stride=2, padding=1), leaky_relu()))
-            prepend(self.decoders, nn.Sequential(nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False), nn.Conv2d(dim_out, dim_in, 3, padding=1), leaky_relu()))
-            if layer_use_attn:
-                prepend(self.decoders, VQGanAttention(dim=dim_out, heads=attn_heads, dim_head=attn_dim_head, dropout=attn_dropout))
-            for _ in range(layer_num_resnet_blocks):
-                append(self.encoders, ResBlock(dim_out, groups=resnet_groups))
-                prepend(self.decoders, GLUResBlock(dim_out, groups=resnet_groups))
-            if layer_use_attn:
-                append(self.encoders, VQGanAttention(dim=dim_out, heads=attn_heads, dim_head=attn_dim_head, dropout=attn_dropout))
-        prepend(self.encoders, nn.Conv2d(channels, dim, first_conv_kernel_size, padding=first_conv_kernel_size // 2))
-        append(self.decoders, nn.Conv2d(dim, channels, 1))
-        self.vq = VectorQuantize(dim=layer_dims[-1], codebook_dim=vq_codebook_dim, codebook_size=vq_codebook_size,
+        widths = [dim] + [dim * m for m in layer_mults]
+        # a scalar setting applies to the deepest level only (vq.py:339-345)
+        res_counts = num_resnet_blocks if isinstance(num_resnet_blocks, tuple) else (0,) * (num_layers - 1) + (num_resnet_blocks,)
+        attn_flags = use_attn if isinstance(use_attn, tuple) else (False,) * (num_layers - 1) + (use_attn,)
+        assert len(res_counts) == num_layers and len(attn_flags) == num_layers
+        attn = lambda w: VQGanAttention(dim=w, heads=attn_heads, dim_head=attn_dim_head, dropout=attn_dropout)
+        # stage lists in execution order.  Encoder level i: stride-2 conv, its ResBlocks, its attention.  The decoder mirrors it
+        # (attention / GLU ResBlocks first, then x2 upsample + conv), deepest level first.  Sub-modules of one level are created
+        # in the reference's order (vq.py:349-363), so a seeded default initialisation draws the same numbers.
+        enc, dec = [], []
+        for w_in, w_out, n_res, with_attn in zip(widths[:-1], widths[1:], res_counts, attn_flags):
+            enc.append(nn.Sequential(nn.Conv2d(w_in, w_out, 4, stride=2, padding=1), leaky_relu()))
+            level = [nn.Sequential(nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False),
+                                   nn.Conv2d(w_out, w_in, 3, padding=1), leaky_relu())]
+            if with_attn:
+                level.insert(0, attn(w_out))
+            for _ in range(n_res):
+                enc.append(ResBlock(w_out, groups=resnet_groups))
+                level.insert(0, GLUResBlock(w_out, groups=resnet_groups))
+            if with_attn:
+                enc.append(attn(w_out))
+            dec = level + dec
+        stem = nn.Conv2d(channels, dim, first_conv_kernel_size, padding=first_conv_kernel_size // 2)
+        self.encoders = MList([stem] + enc)
+        self.decoders = MList(dec + [nn.Conv2d(dim, channels, 1)])
+        self.vq = VectorQuantize(dim=widths[-1], codebook_dim=vq_codebook_dim, codebook_size=vq_codebook_size,
                                  decay=vq_decay, commitment_weight=vq_commitment_weight, accept_image_fmap=True,
                                  kmeans_init=vq_kmeans_init, use_cosine_sim=vq_use_cosine_sim, **vq_kwargs)
         self.recon_loss_fn = F.mse_loss if l2_recon_loss else F.l1_loss
@@ -377,7 +432,8 @@ class VQGanVAE(nn.Module):
         fmap = self.decode(fmap)
         if not return_loss and not return_discr_loss:
             return fmap
-        assert not return_discr_loss, 'discriminator training is outside the accelerated path'
+        assert return_loss ^ return_discr_loss, 'you should either return autoencoder loss or discriminator loss, but not both'
+        assert not return_discr_loss, 'discriminator must exist to train it (the adversarial branch is outside this package)'
         recon_loss = self.recon_loss_fn(fmap, img)        # only term when use_vgg_and_gan=False (quirk Q17)
         if return_recons:
             return recon_loss, fmap

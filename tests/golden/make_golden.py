@@ -2,7 +2,7 @@
 oracle/ref_shims.py) in the build container and recording seeded inputs, the parameters
 (state_dict, reference key names) and the reference's outputs / gradients.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [name prefix ...]
 
 The fixtures are DATA (inputs + expected outputs).  They let the GPU box -- where
 /root/reference does not exist -- check both the oracle and the HIP path against the
@@ -181,6 +181,36 @@ def g7_vae():
          recon_loss=loss, num_layers=2, heads=4, **stages, **params(vae))
 
 
+def g12_vae_cfg1():
+    """BASELINE cfg 1 exactly: VQGanVAE dim=64 image_size=32 num_layers=2, batch 4 random images, forward(return_loss=True) on CPU.
+    Weights come from tests/golden_util.fill_params (name-seeded, so the fixture carries no parameters).  Two cases:
+    eval (frozen codebook, no straight-through: gradients reach the decoder only) and train with vq_kmeans_init=False (EMA codebook
+    update + straight-through, gradients reach the encoder too; this leg runs through the restated VectorQuantize: PARITY UNPINNED)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from golden_util import fill_params, sample2048
+    out = {}
+    for mode in ('eval', 'train'):
+        vae = VQGanVAE(dim=64, image_size=32, num_layers=2, use_vgg_and_gan=False, vq_kmeans_init=False)
+        fill_params(vae, seed=12)
+        vae.train(mode == 'train')
+        torch.manual_seed(1)
+        img = torch.rand(4, 3, 32, 32)
+        loss, recon = vae(img, return_loss=True, return_recons=True)
+        loss.backward()
+        G = {k: p.grad for k, p in vae.named_parameters() if p.grad is not None}
+        out.update({f'{mode}.loss': loss, f'{mode}.recon': recon, 'img': img})
+        for k in ('decoders.4.weight', 'decoders.0.net.0.weight', 'decoders.1.to_qkv.weight', 'vq.project_out.weight',
+                  'encoders.0.weight', 'encoders.2.0.bias', 'encoders.4.post_norm.g', 'vq.project_in.weight'):
+            if k in G:                                    # a strided sample + the norm keep the fixture small
+                out[f'{mode}.g.{k}'] = sample2048(G[k])
+                out[f'{mode}.gnorm.{k}'] = G[k].norm()
+        out[f'{mode}.n_grads'] = len(G)
+        if mode == 'train':
+            out['train.embed_after'] = sample2048(vae.vq.embed)
+            out['train.cluster_size_after'] = vae.vq.cluster_size
+    save('g12_vae_cfg1', **out)
+
+
 def g8_decoder_layer():
     torch.manual_seed(0)
     tr = Transformer(dim=32, depth=3, causal=True, heads=2, dim_head=32, cross_attend=True,
@@ -295,14 +325,9 @@ def g11_sketch():
 
 
 if __name__ == '__main__':
-    g1_sparse3dna()
-    g1b_sparse3dna_rel_pos_bias()
-    g2_cross_attention()
-    g3_feedforward()
-    g4_norms_and_shift()
-    g5_g6_nuwa()
-    g7_vae()
-    g8_decoder_layer()
-    g9_video_audio()
-    g10_text_encoder()
-    g11_sketch()
+    makers = [g1_sparse3dna, g1b_sparse3dna_rel_pos_bias, g2_cross_attention, g3_feedforward, g4_norms_and_shift, g5_g6_nuwa, g7_vae,
+              g8_decoder_layer, g9_video_audio, g10_text_encoder, g11_sketch, g12_vae_cfg1]
+    want = sys.argv[1:]                       # e.g. `python tests/golden/make_golden.py g12` regenerates only the g12 fixture
+    for fn in makers:
+        if not want or any(fn.__name__.startswith(w) for w in want):
+            fn()

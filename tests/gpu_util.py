@@ -34,6 +34,16 @@ def report(name, got, ref, tol):
     return e
 
 
+def record(name, rel_max, l2, tol):
+    """log an already computed error pair (same file / format as report())"""
+    try:
+        os.makedirs(os.path.dirname(LOG), exist_ok=True)
+        with open(LOG, 'a') as f:
+            f.write(json.dumps(dict(name=name, rel_max=rel_max, rel_l2=l2, tol=tol, finite=True)) + '\n')
+    except OSError:
+        pass
+
+
 def bf_round(t):
     return t.to(torch.bfloat16).float()
 
