@@ -10,10 +10,23 @@ cycle (1,2,4), 256 text tokens of context), bf16 MFMA operands, synthetic data, 
 One "step" = embedding assemble -> 24 decoder layers -> StableLayerNorm -> to_logits -> cross entropy ->
 backward to all decoder parameter gradients (+ the RCCL gradient all-reduce for N > 1), on `--batch`
 samples per GPU (weak scaling).  Rank 0 prints ONE JSON line.
+
+What the line carries (rank 0):
+  value / ms_per_step   EXACTLY K steps between barrier + synchronize on both sides, wall clock, max over ranks; the per-launch
+                        HIP-event timer of the library is OFF in this region.  `ms_per_step_median` = median of the K per-step
+                        HIP-event intervals recorded on the compute stream in the same region.
+  roofline              the NT GEMM family (largest share of the step), from a SECOND pass of a few steps with the library's
+                        per-launch HIP-event timer armed (events on the launch stream, inside libamdnuwa).
+  parity                the same 24-layer decoder, one sample, logits against the oracle's (fp32 CPU restatement of the
+                        reference) in BOTH precision modes, measured in this run; `parity_mode` = throughput of the 'bf16x3'
+                        mode (the one that meets the 1e-3 logits bound) beside the headline 'bf16' mode.
+  cpu_baseline          the oracle's full step (24 layers forward + backward through the CE loss), b = 1, on the host cores.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,6 +45,7 @@ CFGS = {
                  text_len=256, codebook=512, vae=dict(dim=64, image_size=64, num_layers=2)),
 }
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
+ROOFLINE_SOURCES = ('nuwa_pytorch_amd/csrc/gemm.hip',)      # kernels the committed PMC traffic figure belongs to
 
 
 def fwd_flops_per_sample(c):
@@ -84,62 +98,86 @@ def decoder_step(nuwa, ids, ctx, mask):
     return loss
 
 
-def cpu_baseline(c, budget_layers=3):
-    """the oracle (fp32 CPU restatement of the reference algorithm) on the host cores: b = 1, full cfg
-    geometry; times `budget_layers` decoder layers (one per dilation) + embed/final-norm/logits/CE
-    forward+backward and scales the layer time to the full depth."""
-    from oracle import nuwa_oracle as O
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))     # beyond ~32 threads the fp32 oracle gets slower, not faster
-    cores = torch.get_num_threads()
-    D, h, d, T, C = c['dim'], c['heads'], c['dim_head'], c['text_len'], c['codebook']
+def synthetic_batch(c, b, rank, dev):
     N = c['frames'] * c['fmap'] ** 2
-    L = min(budget_layers, c['dec_depth'])
-    import nuwa_pytorch_amd.nuwa_pytorch as M
-    torch.manual_seed(0)
-    tr = M.Transformer(dim=D, depth=L, causal=True, heads=h, dim_head=d, cross_attend=True, sparse_3dna_attn=True,
-                       sparse_3dna_kernel_size=c['kernel'], sparse_3dna_video_shape=(c['frames'], c['fmap'], c['fmap']),
-                       sparse_3dna_dilations=c['dilation'], shift_video_tokens=True)
-    P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in tr.state_dict().items()}
-    cfg = dict(video_shape=(c['frames'], c['fmap'], c['fmap']), kernel_size=c['kernel'], dilations=c['dilation'], heads=h, depth=L, shift=True)
-    g = torch.Generator().manual_seed(1234)
-    x = torch.randn(1, N, D, generator=g, requires_grad=True)
-    ctx = torch.randn(1, T, D, generator=g)
-    mask = torch.ones(1, T, dtype=torch.bool)
-    t0 = time.perf_counter()
-    y = x
-    for l in range(L):
-        y = O.decoder_layer(y, O.sub(P, f'layers.{l}'), cfg, l, ctx, mask)
-    y.sum().backward()
-    t_layers = time.perf_counter() - t0
-    # embedding + final norm + logits + CE
-    E = {'image_embedding.embed.weight': torch.randn(C, D, requires_grad=True), 'video_bos': torch.randn(D, requires_grad=True),
-         'video_pos_emb.axial1': torch.randn(c['frames'], D, requires_grad=True), 'video_pos_emb.axial2': torch.randn(c['fmap'], D, requires_grad=True),
-         'video_pos_emb.axial3': torch.randn(c['fmap'], D, requires_grad=True)}
-    wl = torch.randn(C, D, requires_grad=True)
-    nw, nb = torch.ones(D, requires_grad=True), torch.zeros(D, requires_grad=True)
-    ids = torch.randint(0, C, (1, N), generator=g)
-    t0 = time.perf_counter()
-    e = O.embed_assemble(ids[:, :-1], E)
-    hn = O.stable_layer_norm(e, nw, nb)
-    loss = torch.nn.functional.cross_entropy((hn @ wl.t()).reshape(-1, C), ids.reshape(-1))
-    loss.backward()
-    t_rest = time.perf_counter() - t0
-    t_step = t_layers * c['dec_depth'] / L + t_rest
-    return dict(value=N / t_step, unit='video-tokens/s', cores=cores, kind='port',
-                sample=f'oracle fp32, b=1, {L} of {c["dec_depth"]} decoder layers fwd+bwd ({t_layers:.1f}s) scaled x{c["dec_depth"] / L:.0f} '
-                       f'+ embed/norm/logits/CE ({t_rest:.1f}s) -> {t_step:.1f}s per step')
+    g = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    ids = torch.randint(0, c['codebook'], (b, N), generator=g)
+    ctx = torch.randn(b, c['text_len'], c['dim'], generator=g)
+    mask = torch.ones(b, c['text_len'], dtype=torch.bool)
+    mask[:, -64:] = torch.rand(b, 64, generator=g) > 0.5        # exercise the key mask
+    return ids.to(dev), ctx.to(dev), mask.to(dev)
+
+
+def cpu_baseline(c, nuwa, ids, ctx, mask, max_runs=3, budget_s=45.0):
+    """the oracle (fp32 CPU restatement of the reference algorithm) on the host cores: ONE sample of the same workload, the FULL
+    step -- embed -> every decoder layer -> StableLayerNorm -> logits -> cross entropy -> backward -- with the benchmarked
+    model's own weights; repeated up to `max_runs` times while the total stays within `budget_s`, median reported.
+    Returns (json object, oracle logits of that sample)."""
+    from oracle import nuwa_oracle as O
+    host = os.cpu_count() or 1
+    torch.set_num_threads(min(host, 32))          # beyond ~32 threads the fp32 oracle gets slower, not faster
+    threads = torch.get_num_threads()
+    N = c['frames'] * c['fmap'] ** 2
+    keep = lambda k: not (k.startswith('vae.') or k.startswith('text_'))
+    P = {k: v.detach().float().cpu().clone() for k, v in nuwa.state_dict().items() if keep(k)}
+    Pg = {k: (v.requires_grad_(True) if v.is_floating_point() else v) for k, v in P.items()}
+    cfg = dict(video_shape=(c['frames'], c['fmap'], c['fmap']), kernel_size=c['kernel'], dilations=c['dilation'], heads=c['heads'],
+               depth=c['dec_depth'], shift=True, reversible=bool(c.get('reversible')))
+    i1, c1, m1 = ids[:1].cpu(), ctx[:1].float().cpu(), mask[:1].cpu()
+    times, logits = [], None
+    t_all = time.perf_counter()
+    while len(times) < max_runs and (not times or time.perf_counter() - t_all + times[-1] <= budget_s):
+        for v in Pg.values():
+            if v.is_floating_point():
+                v.grad = None
+        t0 = time.perf_counter()
+        loss, lg = O.decoder_loss(Pg, cfg, i1, c1, m1, training=True, return_logits=True)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        logits = lg.detach()
+    t_step = statistics.median(times)
+    return dict(value=N / t_step, unit='video-tokens/s', cores=threads, host_cores=host, kind='port', runs=len(times),
+                seconds_per_step=t_step,
+                sample=f'oracle fp32, b=1, the full step ({c["dec_depth"]} decoder layers + embed/norm/logits/CE, forward + backward), '
+                       f'median of {len(times)} run(s): {", ".join(f"{t:.1f}" for t in times)} s'), logits
+
+
+def gpu_logits(nuwa, ids, ctx, mask, mode):
+    import nuwa_pytorch_amd as A
+    A.set_precision(mode)
+    try:
+        with torch.no_grad():
+            x = nuwa.embed_video(ids[:1, :-1])
+            h = nuwa.decode_hidden(x, ctx[:1].contiguous(), mask[:1].contiguous())
+            return nuwa._final(h).float().cpu()
+    finally:
+        A.set_precision('bf16')
+
+
+def file_sha16(paths):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(os.path.join(ROOT, p), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def traffic_from_profiles(config, b):
-    """HBM bytes per NT-GEMM launch from the committed PMC passes (profiles/traffic.json, written by tools/pmc_summary.py
-    from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None when no pass matches."""
+    """HBM bytes per NT-GEMM launch from the committed PMC passes (profiles/traffic.json, written by tools/pmc_summary.py from
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  The entry records the hash of the kernel
+    sources it was measured on; a figure taken on other sources is REFUSED (None + the reason), not reported stale."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
             t = json.load(f)
-        e = t.get(f'{config}_b{b}')
-        return e if e and 'bytes_per_launch' in e else None
     except (OSError, ValueError):
-        return None
+        return None, 'profiles/traffic.json missing'
+    e = t.get(f'{config}_b{b}')
+    if not e or 'bytes_per_launch' not in e:
+        return None, f'no PMC pass committed for {config} at b={b}'
+    now = file_sha16(ROOFLINE_SOURCES)
+    if e.get('src_sha16') != now:
+        return None, f'stale: PMC pass taken on kernel sources {e.get("src_sha16")}, this tree has {now}'
+    return e, e.get('source', '')
 
 
 def tokenizer_rate(nuwa, c, b, dev):
@@ -164,9 +202,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='samples per GPU (weak scaling)')
     ap.add_argument('--config', default='cfg3', choices=list(CFGS))
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3'], help='mode of the HEADLINE value')
+    ap.add_argument('--parity-batch', type=int, default=16, help="samples per GPU of the 'bf16x3' side measurement")
+    ap.add_argument('--no-parity', action='store_true', help="skip the 'bf16x3' throughput pass and the logits-vs-oracle measurement")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL over xGMI (default); gloo only for functional checks')
+    ap.add_argument('--collective', default='allreduce', choices=['allreduce', 'rs_ag'], help='gradient exchange per bucket')
     ap.add_argument('--single-device', action='store_true', help='functional check only: every rank uses cuda:0 (with --backend gloo)')
     ap.add_argument('--no-tokenizer', action='store_true', help='skip the (untimed, separately reported) frozen-VAE tokenizer rate')
     args = ap.parse_args()
@@ -185,64 +226,99 @@ def main():
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     import nuwa_pytorch_amd as A
     from nuwa_pytorch_amd import kernels as K
-    from nuwa_pytorch_amd.distributed import GradReducer
+    from nuwa_pytorch_amd.distributed import GradReducer, broadcast_parameters
     A.set_precision(args.precision)
     c = CFGS[args.config]
     nuwa = build_model(c, dev)
     if world > 1:
-        for p in nuwa.parameters():
-            dist.broadcast(p.data, src=0)
+        broadcast_parameters(nuwa, src=0)                 # one flat collective per dtype, not one per tensor
     params = decoder_params(nuwa)
     for p in nuwa.parameters():
         p.requires_grad_(False)
     for p in params:
         p.requires_grad_(True)
-    reducer = GradReducer(nuwa) if world > 1 else None
+    reducer = GradReducer(nuwa, collective=args.collective) if world > 1 else None
 
     b = args.batch
     N = c['frames'] * c['fmap'] ** 2
-    g = torch.Generator(device='cpu').manual_seed(1234 + rank)
-    ids = torch.randint(0, c['codebook'], (b, N), generator=g).to(dev)
-    ctx = torch.randn(b, c['text_len'], c['dim'], generator=g).to(dev)
-    mask = torch.ones(b, c['text_len'], dtype=torch.bool)
-    mask[:, -64:] = torch.rand(b, 64, generator=g) > 0.5        # exercise the key mask
-    mask = mask.to(dev)
+    ids, ctx, mask = synthetic_batch(c, b, rank, dev)
 
-    def step():
+    def step(batch=(ids, ctx, mask)):
         if reducer is not None:
             reducer.zero_grad()
         else:
             for p in params:
                 p.grad = None
-        loss = decoder_step(nuwa, ids, ctx, mask)
+        loss = decoder_step(nuwa, *batch)
         if reducer is not None:
             reducer.finish()
         return loss
 
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- headline: K steps, wall clock between fences; per-step HIP events on the compute stream for the median
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if rank == 0:
-        K.timer_arm(True)
+    fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+        marks[i + 1].record()
+    fence()
     dt = time.perf_counter() - t0
-    gemm_ms, gemm_launches, gemm_flops, gemm_bytes = (0.0, 0, 0.0, 0.0)
-    if rank == 0:
-        gemm_ms, gemm_launches, gemm_flops, gemm_bytes = K.timer_collect()
-        K.timer_arm(False)
+    per_step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    loss_val = float(loss.detach())
+
+    # ---- second pass (rank 0's numbers): the library's per-launch HIP-event timer armed around every amdnuwa_gemm_nt launch
+    probe_steps = max(1, min(args.steps, 5))
+    gemm_ms, gemm_launches, gemm_flops, gemm_bytes = (0.0, 0, 0.0, 0.0)
+    if rank == 0:
+        K.timer_arm(True)
+    t1 = time.perf_counter()
+    for _ in range(probe_steps):
+        step()
+    fence()
+    dt_probe = time.perf_counter() - t1
+    if rank == 0:
+        gemm_ms, gemm_launches, gemm_flops, gemm_bytes = K.timer_collect()
+        K.timer_arm(False)
+
+    # ---- 'bf16x3' (parity mode) throughput beside the headline, smaller batch (its saved activations are ~2.7x larger)
+    parity_mode = None
+    if not args.no_parity and args.precision == 'bf16':
+        pb = max(1, min(args.parity_batch, b))
+        pbatch = (ids[:pb].contiguous(), ctx[:pb].contiguous(), mask[:pb].contiguous())
+        A.set_precision('bf16x3')
+        try:
+            step(pbatch)
+            fence()
+            ps = max(2, min(args.steps, 4))
+            t2 = time.perf_counter()
+            for _ in range(ps):
+                step(pbatch)
+            fence()
+            d2 = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(d2, op=dist.ReduceOp.MAX)
+            d2 = float(d2.item())
+            parity_mode = {'dtype': 'bf16x3', 'value': world * pb * N * ps / d2, 'unit': 'video-tokens/s', 'ms_per_step': d2 / ps * 1e3,
+                           'per_gpu_batch': pb, 'steps': ps,
+                           'note': 'every MFMA operand as a bf16 hi+lo pair, 3 MFMAs per product; the mode that meets the 1e-3 logits bound'}
+        finally:
+            A.set_precision(args.precision)
+            for p in params:
+                p.grad = None
 
     if rank == 0:
         tokens = world * b * N * args.steps
@@ -253,37 +329,58 @@ def main():
         out = {
             'metric': 'video-tokens/sec, 3DNA decoder fwd+bwd @ 10x16x16' if args.config == 'cfg3' else 'video-tokens/sec, 3DNA decoder fwd+bwd',
             'value': value, 'unit': 'video-tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': dt / args.steps * 1e3, 'ms_per_step_median': statistics.median(per_step_ms),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if args.precision == 'bf16' else 'bf16x3', 'data': 'synthetic',
             'config': {'workload': f'BASELINE {args.config}: NUWA decoder dim={c["dim"]} depth={c["dec_depth"]} heads={c["heads"]}, '
                                    f'{c["frames"]}x{c["fmap"]}x{c["fmap"]} video tokens, 3DNA kernel {c["kernel"]} dilation {c["dilation"]}, '
                                    f'{c["text_len"]} text tokens, codebook {c["codebook"]}',
                        'per_gpu_batch': b, 'global_batch': b * world, 'tokens_per_sample': N, 'parallelism': f'dp{world}',
-                       'loss': float(loss.detach())},
+                       'loss': loss_val, 'collective': args.collective if world > 1 else None},
             'per_gpu_value': value / world,
-            'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+            'peak_hbm_gb': peak_gb,
             'step_tflops_per_gpu': step_flops / (dt / args.steps) / 1e12,
             'step_mfma_frac': step_flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_* (bf16 MFMA NT GEMM; every amdnuwa_gemm_nt launch of the timed region, HIP events on the launch stream)',
+            'timing': 'value: wall clock over exactly `steps` steps between barrier+synchronize fences, max over ranks, library timer off; '
+                      'ms_per_step_median: median of the per-step HIP-event intervals on the compute stream in the same region',
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_* (bf16 MFMA NT GEMM; every amdnuwa_gemm_nt launch of a separate pass of '
+                                                     f'{probe_steps} step(s) with the per-launch HIP-event timer armed, events on the launch stream)',
                          'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                          'traffic': None, 'algorithmic_bytes_per_launch': gemm_bytes / max(gemm_launches, 1),
                          'flops_per_launch': gemm_flops / max(gemm_launches, 1), 'launches': gemm_launches, 'avg_launch_us': gemm_ms * 1e3 / max(gemm_launches, 1),
-                         'share_of_step': gemm_ms * 1e-3 / dt},
+                         'share_of_step': gemm_ms * 1e-3 / dt_probe},
         }
-        tr = traffic_from_profiles(args.config, b)
+        tr, why = traffic_from_profiles(args.config, b)
         if tr is not None:
             out['roofline']['traffic'] = tr['bytes_per_launch']
-            out['roofline']['traffic_source'] = tr['source']
+        out['roofline']['traffic_source'] = why
+        if parity_mode is not None:
+            out['parity_mode'] = parity_mode
         if not args.no_tokenizer and world == 1:          # (side measurement, single-GPU runs only: keeps the ranks in step)
             out['vae_tokenizer'] = tokenizer_rate(nuwa, c, min(b, 8), dev)
+        oracle_logits = None
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out['cpu_baseline'] = cpu_baseline(c)
+                out['cpu_baseline'], oracle_logits = cpu_baseline(c, nuwa, ids, ctx, mask)
             except Exception as e:      # the baseline is a report, never a reason to lose the GPU number
                 out['cpu_baseline'] = {'value': None, 'unit': 'video-tokens/s', 'cores': os.cpu_count(), 'kind': 'port',
                                        'sample': f'failed: {type(e).__name__}: {e}'}
+        if oracle_logits is not None and not args.no_parity:
+            # the checker: this run's GPU logits of the baseline's sample (full depth) against the oracle's, both modes
+            par = {'sample': f'logits [1, {N}, {c["codebook"]}] of sample 0 after all {c["dec_depth"]} layers vs the oracle (fp32 CPU), '
+                             'max-abs error / max-abs reference', 'bound': {'bf16x3': 1e-3, 'bf16': 4e-2}}
+            ref = oracle_logits.double()
+            for mode in ('bf16', 'bf16x3'):
+                try:
+                    got = gpu_logits(nuwa, ids, ctx, mask, mode).double()
+                    par[mode] = {'logits_rel_max': float((got - ref).abs().max() / ref.abs().max()),
+                                 'logits_rel_l2': float((got - ref).norm() / ref.norm())}
+                except Exception as e:
+                    par[mode] = {'error': f'{type(e).__name__}: {e}'}
+            out['parity'] = par
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -773,7 +773,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     s = (sred[0] + sred[1]) + (sred[2] + sred[3]);
     const float lse = m + logf(s);
     const long long t = tgt[row];
-    if (tid == 0) row_loss[row] = lse - lr[t];
+    const bool t_ok = t >= 0 && t < (long long)C;            // an id outside the vocabulary poisons the loss instead of reading out of bounds
+    if (tid == 0) row_loss[row] = t_ok ? lse - lr[t] : __builtin_nanf("");
     if (dl_hi) {
         const float inv = 1.f / s;
         for (int c = tid * 4; c < C; c += 1024) {

@@ -52,35 +52,38 @@ def eval_decorator(fn):
     return inner
 
 
-def log(t, eps=1e-20):
-    return torch.log(t.clamp(min=eps))
+def sample_top_fraction(logits, filter_thres=0.9, temperature=1.):
+    """one token id per row of `logits` (b, C): restrict to the top max(1, int((1 - filter_thres) C)) logits, then a Gumbel-max draw at
+    `temperature` -- the distribution of the reference's top_k + gumbel_sample pair (np.py:55-65, 1713-1720); the noise is drawn for
+    the kept logits only (the filtered ones sit at -inf there and can never win)"""
+    keep = max(int((1 - filter_thres) * logits.shape[-1]), 1)
+    vals, ids = logits.topk(keep, dim=-1)
+    if keep == 1:
+        return ids[..., 0]
+    u = torch.rand_like(vals).clamp_(min=1e-20)
+    gumbel = -torch.log((-torch.log(u)).clamp_(min=1e-20))
+    return ids.gather(-1, (vals / temperature + gumbel).argmax(dim=-1, keepdim=True))[..., 0]
 
 
-def gumbel_noise(t):
-    noise = torch.zeros_like(t).uniform_(0, 1)
-    return -log(-log(noise))
+def bernoulli_rows(count, prob, device):
+    """bool (count,): True with probability `prob` (classifier-free-guidance condition dropout, np.py:67-68, 1952-1954)"""
+    return torch.rand(count, device=device) < prob
 
 
-def gumbel_sample(t, temperature=1., dim=-1):
-    return ((t / temperature) + gumbel_noise(t)).argmax(dim=dim)
+def map_in_chunks(t, fn, chunks=10):
+    """fn over at most `chunks` slices of the leading axis, results concatenated (bounds the VAE decoder's batch, np.py:70-72)"""
+    return torch.cat([fn(piece) for piece in t.chunk(chunks, dim=0)], dim=0)
 
 
-def prob_mask_like(shape, prob, device):
-    return torch.zeros(shape, device=device).float().uniform_(0, 1) < prob
-
-
-def batch_process(t, fn, chunks=10, dim=0):
-    chunks = [fn(t_chunk) for t_chunk in t.chunk(chunks, dim=dim)]
-    return torch.cat(chunks, dim=dim)
-
-
-def top_k(logits, thres=0.5):
-    num_logits = logits.shape[-1]
-    k = max(int((1 - thres) * num_logits), 1)
-    val, ind = torch.topk(logits, k)
-    probs = torch.full_like(logits, float('-inf'))
-    probs.scatter_(1, ind, val)
-    return probs
+def lookback_window(ids, tokens_per_frame, max_frames):
+    """the suffix of a generated id sequence that still fits the decoder's video shape (np.py:1876-1881): whole frames plus the
+    frame being written"""
+    n = ids.shape[1]
+    if n <= tokens_per_frame * max_frames:
+        return ids
+    partial = n % tokens_per_frame
+    keep = (max_frames - (1 if partial else 0)) * tokens_per_frame + partial
+    return ids[:, -keep:]
 
 
 def causal_neighbor_mask(video_shape, kernel_size, dilation):
@@ -165,7 +168,7 @@ class SandwichNorm(nn.Module):
             if fn.shift_space:
                 shift = fn.image_size
             fn = fn.fn
-        if isinstance(fn, FeedForward) or (isinstance(fn, Sparse3DNA) and fn.causal):
+        if (isinstance(fn, FeedForward) and not fn._dropout_active()) or (isinstance(fn, Sparse3DNA) and fn.causal):
             return fn, shift
         if isinstance(fn, Attention) and context is not None and fn._hip_ok(context.shape[1]):
             return fn, shift
@@ -293,13 +296,19 @@ class FeedForward(nn.Module):
     def _params(self):
         return (self.net[0].weight, self.net[3].weight)
 
+    def _dropout_active(self):
+        return self.training and self.net[2].p > 0
+
     def _meta(self, B, n, device, **_):
-        if self.training and self.net[2].p > 0:
-            raise NotImplementedError('ff_dropout > 0 is not supported by the HIP path (all BASELINE configs use 0)')
+        assert not self._dropout_active()
         return dict(kind='ff', cache=self._cache)
 
     def forward(self, x):
         B, n, D = x.shape
+        if self._dropout_active() and x.is_cuda:
+            # ff_dropout > 0 in training (np.py:276): the GEGLU output passes through nn.Dropout -- torch ops, torch's RNG stream;
+            # every BASELINE config trains with dropout 0 and stays on the fused libamdnuwa node
+            return self.net(x)
         return ops.InnerFn.apply(x, None, self._meta(B, n, x.device), *self._params())
 
 
@@ -336,8 +345,7 @@ class Attention(nn.Module):
             not (self.training and self.dropout.p > 0)
 
     def _meta(self, B, n, device, context=None, context_mask=None, mask=None, rotary_pos_emb=None, **_):
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError('attn_dropout > 0 is not supported by the HIP path (all BASELINE configs use 0)')
+        assert not (self.training and self.dropout.p > 0)      # (_hip_ok routes attn_dropout > 0 in training to the torch-op forward)
         self_kv = context is None
         T = n if self_kv else context.shape[1]
         key_mask = mask if self_kv else context_mask
@@ -355,36 +363,31 @@ class Attention(nn.Module):
         if x.is_cuda and self._hip_ok(context.shape[1] if exists(context) else n):
             meta = self._meta(B, n, x.device, context, context_mask, mask=mask, rotary_pos_emb=rotary_pos_emb)
             return ops.InnerFn.apply(x, context, meta, *self._params())
-        return self._forward_selfattn(x, mask=mask, context=context, context_mask=context_mask,
-                                      rotary_pos_emb=rotary_pos_emb)
+        return self._forward_torch(x, mask=mask, context=context, context_mask=context_mask, rotary_pos_emb=rotary_pos_emb)
 
-    def _forward_selfattn(self, x, mask=None, context=None, context_mask=None, rotary_pos_emb=None):
-        # text-encoder path (row f1), PyTorch-ROCm ops
-        b, h = x.shape[0], self.heads
-        has_context = exists(context)
-        kv_input = context if has_context else x
-        q = self.to_q(x)
-        k, v = self.to_kv(kv_input).chunk(2, dim=-1)
-        sp = lambda t: t.reshape(t.shape[0], t.shape[1], h, -1).transpose(1, 2)
-        q, k, v = sp(q), sp(k), sp(v)
-        if not has_context and exists(rotary_pos_emb):
-            q, k, v = (apply_rotary_pos_emb(rotary_pos_emb, t) for t in (q, k, v))   # v too (quirk Q11)
-        k = torch.cat((self.null_k[None].expand(b, -1, -1, -1), k), dim=-2)
-        v = torch.cat((self.null_v[None].expand(b, -1, -1, -1), v), dim=-2)
-        sim = einsum('b h i d, b h j d -> b h i j', q * self.scale, k)
-        mask_value = -torch.finfo(x.dtype).max
-        key_mask = mask if not has_context else context_mask
-        if exists(key_mask):
-            key_mask = F.pad(key_mask, (1, 0), value=True)
-            sim = sim.masked_fill(~key_mask[:, None, None, :], mask_value)
-        if self.causal:
-            i, j = sim.shape[-2:]
-            cm = torch.ones(i, j, device=x.device, dtype=torch.bool).triu_(j - i + 1)
-            sim = sim.masked_fill(cm, mask_value)
-        attn = sim.softmax(dim=-1, dtype=torch.float32)
-        attn = self.dropout(self.talking_heads(attn))
-        out = einsum('b h i j, b h j d -> b h i d', attn, v)
-        out = out.transpose(1, 2).reshape(b, out.shape[2], -1)
+    def _forward_torch(self, x, mask=None, context=None, context_mask=None, rotary_pos_emb=None):
+        """np.py:315-379 on PyTorch-ROCm ops, for what the kernels do not cover: causal self-attention, other head sizes, and
+        attn_dropout > 0 in training.  Keys = [null key | context or x]; one additive bias carries the key mask and the causal band."""
+        b, n, h, dh = x.shape[0], x.shape[1], self.heads, self.dim_head
+        src = x if context is None else context
+        heads_of = lambda t: t.reshape(b, t.shape[1], -1, dh).transpose(1, 2)               # (b, heads, len, dh)
+        q = heads_of(self.to_q(x))
+        k, v = (heads_of(t) for t in self.to_kv(src).chunk(2, dim=-1))
+        if context is None and rotary_pos_emb is not None:
+            q, k, v = (apply_rotary_pos_emb(rotary_pos_emb, t) for t in (q, k, v))         # v too (quirk Q11)
+        k = torch.cat((self.null_k.expand(b, -1, -1, -1), k), dim=2)
+        v = torch.cat((self.null_v.expand(b, -1, -1, -1), v), dim=2)
+        scores = torch.matmul(q * self.scale, k.transpose(-1, -2))
+        j = k.shape[2]
+        hidden = torch.zeros(b, 1, n if self.causal else 1, j, dtype=torch.bool, device=x.device)
+        key_mask = mask if context is None else context_mask
+        if key_mask is not None:
+            hidden = hidden | ~F.pad(key_mask, (1, 0), value=True)[:, None, None, :]
+        if self.causal:                                        # query i sees the null key and keys 0..i of the sequence
+            hidden = hidden | (torch.arange(j, device=x.device)[None, :] > torch.arange(n, device=x.device)[:, None] + (j - n))
+        scores = scores.masked_fill(hidden, -torch.finfo(scores.dtype).max)
+        probs = self.dropout(self.talking_heads(scores.softmax(dim=-1, dtype=torch.float32)))
+        out = torch.matmul(probs, v).transpose(1, 2).reshape(b, n, h * dh)
         return self.to_out(out)
 
 
@@ -624,14 +627,12 @@ class Transformer(nn.Module):
 # reversible plumbing (rev.py) ------------------------------------------------------------------------
 
 def route_args(router, args, depth):
-    routed_args = [(dict(), dict()) for _ in range(depth)]
-    matched_keys = [key for key in args.keys() if key in router]
-    for key in matched_keys:
-        val = args[key]
-        for d, ((f_args, g_args), routes) in enumerate(zip(routed_args, router[key])):
-            new_f_args, new_g_args = map(lambda route: ({key: val} if route else {}), routes)
-            routed_args[d] = ({**f_args, **new_f_args}, {**g_args, **new_g_args})
-    return routed_args
+    """per block d the keyword sets of its two halves: `router[name][d] = (to_f, to_g)` says whether f / g of block d receives the
+    keyword `name` (the routing of rev.py:8-17; keywords without a route are dropped)"""
+    routed = []
+    for d in range(depth):
+        routed.append(tuple({k: v for k, v in args.items() if k in router and router[k][d][half]} for half in (0, 1)))
+    return routed
 
 
 class Deterministic(nn.Module):
@@ -951,59 +952,55 @@ class NUWA(nn.Module):
             return ops.LogitsFn.apply(hidden, nrm.weight, nrm.bias, self.to_logits.weight, self._cache)
         raise RuntimeError('nuwa_pytorch_amd: the decoder path needs a HIP device; there is no CPU fallback')
 
+    def _guided_last_logits(self, ids, context, context_mask, cond_scale):
+        """logits of the NEXT token after `ids` by recomputing the whole prefix -- the reference's decoding algorithm
+        (np.py:1883-1903): with guidance, a second pass is fed the first pass's NORMED output and sees no condition"""
+        hidden = self.decode_hidden(self.embed_video(ids), context, context_mask)
+        logits = self._final(hidden[:, -1:].contiguous())
+        if cond_scale != 1:
+            blind = self.decode_hidden(self.video_transformer.norm(hidden), context, torch.zeros_like(context_mask))
+            base = self._final(blind[:, -1:].contiguous())
+            logits = base + (logits - base) * cond_scale
+        return logits[:, -1]
+
+    def _ids_to_frames(self, ids, decode_max_batchsize):
+        """token ids (b, frames * fmap^2) -> frames (b, frames, c, H, W) through the VAE decoder (np.py:1910-1915)"""
+        batch, fs = ids.shape[0], self.video_fmap_size
+        codes = self.vae.codes_for_decoder(ids)
+        codes = codes.reshape(batch, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
+        decode = self.vae._hip_decode if codes.is_cuda else self.vae.decode
+        frames = map_in_chunks(codes.contiguous(), decode, chunks=decode_max_batchsize)
+        return frames.reshape(batch, -1, *frames.shape[1:])
+
     @torch.no_grad()
     @eval_decorator
     def generate(self, *, text, filter_thres=0.9, temperature=1., decode_max_batchsize=10, cond_scale=2., num_frames=None):
         """np.py:1841-1915.  The reference recomputes the whole prefix (twice) per token; here each token costs one new decoder
         row against per-layer key/value caches (decode.GuidedStepper, row f3) whenever the sequence fits the video shape and the
-        decoder is the plain Transformer -- otherwise the reference's recompute loop below runs on the same kernels."""
-        batch, seq_len, device = *text.shape, text.device
+        decoder is the plain Transformer -- otherwise the reference's recompute algorithm runs on the same kernels."""
+        batch, device = text.shape[0], text.device
         text_mask = text != 0
         text_embeds = self.embed_text(text, mask=text_mask)
-        video_indices = torch.empty((batch, 0), device=device, dtype=torch.long)
-        num_tokens_per_frame = self.video_fmap_size ** 2
-        num_frames = default(num_frames, self.max_video_frames)
-        total_video_tokens = num_tokens_per_frame * num_frames
-        max_video_tokens = num_tokens_per_frame * self.max_video_frames
-        stepper = None
-        if self.generate_use_cache and text.is_cuda and isinstance(self.video_transformer, Transformer) and \
-                total_video_tokens <= max_video_tokens:
+        tpf = self.video_fmap_size ** 2
+        total = tpf * default(num_frames, self.max_video_frames)
+        ids = torch.empty((batch, 0), device=device, dtype=torch.long)
+        cached = self.generate_use_cache and text.is_cuda and isinstance(self.video_transformer, Transformer) and \
+            total <= tpf * self.max_video_frames
+        if cached:
             from .decode import GuidedStepper
-            stepper = GuidedStepper(self, text_embeds, text_mask, total_video_tokens, cond_scale, graph=self.generate_use_graph)
+            stepper = GuidedStepper(self, text_embeds, text_mask, total, cond_scale, graph=self.generate_use_graph)
             pos_table = self.video_pos_emb()
-            x_row = self.video_bos[None].expand(batch, -1)
-        for ind in range(total_video_tokens if stepper is not None else 0):
-            logits = stepper(x_row)
-            filtered_logits = top_k(logits, thres=filter_thres)
-            sample = gumbel_sample(filtered_logits, temperature=temperature, dim=-1)
-            video_indices = torch.cat((video_indices, sample[:, None]), dim=1)
-            x_row = self.image_embedding(sample) + pos_table[ind]
-        for ind in range(total_video_tokens if stepper is None else 0):
-            video_indices_input = video_indices
-            num_video_tokens = video_indices.shape[1]
-            if num_video_tokens > max_video_tokens:
-                curr_frame_tokens = num_video_tokens % num_tokens_per_frame
-                lookback_tokens = (self.max_video_frames - (0 if curr_frame_tokens == 0 else 1)) * num_tokens_per_frame + curr_frame_tokens
-                video_indices_input = video_indices[:, -lookback_tokens:]
-            frame_embeddings = self.embed_video(video_indices_input)
-            hidden = self.decode_hidden(frame_embeddings, text_embeds, text_mask)
-            logits = self._final(hidden)
-            if cond_scale != 1:
-                # the reference feeds the conditioned decoder OUTPUT back in as the unconditional input (np.py:1894-1898)
-                cond_out = self.video_transformer.norm(hidden)
-                uncond_hidden = self.decode_hidden(cond_out, text_embeds, torch.zeros_like(text_mask).bool())
-                uncond_logits = self._final(uncond_hidden)
-                logits = uncond_logits + (logits - uncond_logits) * cond_scale
-            logits = logits[:, -1, :]
-            filtered_logits = top_k(logits, thres=filter_thres)
-            sample = gumbel_sample(filtered_logits, temperature=temperature, dim=-1)
-            video_indices = torch.cat((video_indices, sample[:, None]), dim=1)
-        codes = self.vae.codes_for_decoder(video_indices)
-        fs = self.video_fmap_size
-        codes = codes.reshape(batch, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
-        decode = self.vae._hip_decode if codes.is_cuda else self.vae.decode
-        image_reconstructions = batch_process(codes.contiguous(), decode, chunks=decode_max_batchsize)
-        return image_reconstructions.reshape(batch, -1, *image_reconstructions.shape[1:])
+            row = self.video_bos[None].expand(batch, -1)
+        for t in range(total):
+            if cached:
+                logits = stepper(row)
+            else:
+                logits = self._guided_last_logits(lookback_window(ids, tpf, self.max_video_frames), text_embeds, text_mask, cond_scale)
+            token = sample_top_fraction(logits, filter_thres, temperature)
+            ids = torch.cat((ids, token[:, None]), dim=1)
+            if cached:
+                row = self.image_embedding(token) + pos_table[t]
+        return self._ids_to_frames(ids, decode_max_batchsize)
 
     def forward(self, *, text, video=None, return_loss=False, cond_dropout_prob=0.2):
         batch, seq_len, frames, device = *text.shape, video.shape[1], text.device
@@ -1019,8 +1016,7 @@ class NUWA(nn.Module):
         frame_indices_input = frame_indices[:, :-1] if return_loss else frame_indices
         frame_embeddings = self.embed_video(frame_indices_input)
         if self.training and cond_dropout_prob > 0:
-            uncond_mask = prob_mask_like((batch,), cond_dropout_prob, device=device)
-            text_mask = text_mask * (~uncond_mask)[:, None]
+            text_mask = text_mask & ~bernoulli_rows(batch, cond_dropout_prob, device)[:, None]
         hidden = self.decode_hidden(frame_embeddings, text_embeds, text_mask)
         if not return_loss:
             return self._final(hidden)
@@ -1076,6 +1072,8 @@ class NUWASketch(nn.Module):
 
     embed_video = NUWA.embed_video          # <bos> + positional + token embedding, one libamdnuwa node
     _final = NUWA._final                    # final StableLayerNorm + logits (+ cross entropy), fused
+    _guided_last_logits = NUWA._guided_last_logits
+    _ids_to_frames = NUWA._ids_to_frames
 
     def decode_hidden(self, frame_embeddings, sketch_embeds, context_mask):
         return self.video_transformer.forward_layers(frame_embeddings, context=sketch_embeds, context_mask=context_mask)
@@ -1098,35 +1096,18 @@ class NUWASketch(nn.Module):
     @eval_decorator
     def generate(self, *, sketch, sketch_mask=None, filter_thres=0.9, temperature=1., decode_max_batchsize=10, cond_scale=2.,
                  num_frames=None):
-        """np.py:2438-2511: token-by-token with the whole prefix recomputed (and, for guidance, the normed conditioned output fed
+        """np.py:2438-2511: token by token with the whole prefix recomputed (and, for guidance, the normed conditioned output fed
         to a sketch-masked second pass), as the reference does"""
         if sketch.ndim == 4:
             sketch = sketch[:, None]
         batch, device = sketch.shape[0], sketch.device
         sketch_embeds, context_mask = self.embed_sketch(sketch, mask=sketch_mask)
-        video_indices = torch.empty((batch, 0), device=device, dtype=torch.long)
         tpf = self.video_fmap_size ** 2
-        num_frames = default(num_frames, self.max_video_frames)
-        total_video_tokens, max_video_tokens = tpf * num_frames, tpf * self.max_video_frames
-        for ind in range(total_video_tokens):
-            video_indices_input = video_indices
-            if video_indices.shape[1] > max_video_tokens:
-                curr = video_indices.shape[1] % tpf
-                video_indices_input = video_indices[:, -((self.max_video_frames - (0 if curr == 0 else 1)) * tpf + curr):]
-            hidden = self.decode_hidden(self.embed_video(video_indices_input), sketch_embeds, context_mask)
-            logits = self._final(hidden[:, -1:].contiguous())
-            if cond_scale != 1:
-                uncond = self.decode_hidden(self.video_transformer.norm(hidden), sketch_embeds, torch.zeros_like(context_mask).bool())
-                uncond_logits = self._final(uncond[:, -1:].contiguous())
-                logits = uncond_logits + (logits - uncond_logits) * cond_scale
-            sample = gumbel_sample(top_k(logits[:, -1], thres=filter_thres), temperature=temperature, dim=-1)
-            video_indices = torch.cat((video_indices, sample[:, None]), dim=1)
-        fs = self.video_fmap_size
-        codes = self.vae.codes_for_decoder(video_indices)
-        codes = codes.reshape(batch, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
-        decode = self.vae._hip_decode if codes.is_cuda else self.vae.decode
-        images = batch_process(codes.contiguous(), decode, chunks=decode_max_batchsize)
-        return images.reshape(batch, -1, *images.shape[1:])
+        ids = torch.empty((batch, 0), device=device, dtype=torch.long)
+        for _ in range(tpf * default(num_frames, self.max_video_frames)):
+            logits = self._guided_last_logits(lookback_window(ids, tpf, self.max_video_frames), sketch_embeds, context_mask, cond_scale)
+            ids = torch.cat((ids, sample_top_fraction(logits, filter_thres, temperature)[:, None]), dim=1)
+        return self._ids_to_frames(ids, decode_max_batchsize)
 
     def forward(self, *, sketch, sketch_mask=None, video=None, return_loss=False, cond_dropout_prob=0.2):
         if sketch.ndim == 4:                              # one sketch frame
@@ -1145,8 +1126,7 @@ class NUWASketch(nn.Module):
         if self.training and cond_dropout_prob > 0:
             # the reference multiplies `sketch_mask` in place AFTER the decoder mask was derived from it (np.py:2551-2555), which
             # drops nothing (and raises when sketch_mask is None); the evident intent -- drop the condition -- is applied here
-            uncond_mask = prob_mask_like((batch,), cond_dropout_prob, device=device)
-            context_mask = context_mask & ~uncond_mask[:, None]
+            context_mask = context_mask & ~bernoulli_rows(batch, cond_dropout_prob, device)[:, None]
         hidden = self.decode_hidden(frame_embeddings, sketch_embeds, context_mask)
         if not return_loss:
             return self._final(hidden)

@@ -265,38 +265,19 @@ INNERS = {'s3': S3Inner, 'xattn': XInner, 'ff': FFInner}
 
 FUSE_GEGLU_BWD = os.environ.get('AMDNUWA_FUSE_GEGLU_BWD', '1') != '0'   # gate backward inside the dgg GEMM epilogue (A/B switch)
 CHAIN_BWD = os.environ.get('AMDNUWA_CHAIN_BWD', '1') != '0'      # chain the LayerNorm backwards across block boundaries (A/B switch)
-ASYNC_WGRAD = os.environ.get('AMDNUWA_ASYNC_WGRAD', '0') != '0'      # opt-in: measured neutral on MI355X (the split-K GEMM fills every CU)
-_SIDE = {}
-
-
 class WgradStream:
-    """Weight-gradient GEMMs (dW = dY^T X) feed nothing further down the backward chain, so a block launches them on a side
-    HIP stream: the MFMA-bound split-K GEMM then shares the chip with the HBM-bound LayerNorm / GEGLU kernels that follow on the
-    main stream.  join() makes the main stream wait (device-side) before the block's gradients are handed to autograd."""
+    """Weight-gradient GEMMs (dW = dY^T X) feed nothing further down the backward chain.  They are launched in line on the main
+    stream: running them on a side stream beside the HBM-bound LayerNorm / GEGLU kernels was measured neutral on MI355X (the split-K
+    GEMM fills every CU), so the hook points stay but no second stream -- and no cross-stream tensor lifetime -- is involved."""
 
     def __init__(self, device):
-        self.main = torch.cuda.current_stream(device)
-        self.side = None
-        if ASYNC_WGRAD:
-            key = (device.index, self.main.cuda_stream)
-            if key not in _SIDE:
-                _SIDE[key] = torch.cuda.Stream(device)
-            self.side = _SIDE[key]
-        self.used = False
+        pass
 
     def run(self, fn):
-        if self.side is None:
-            return fn()
-        self.side.wait_stream(self.main)              # operands written so far on the main stream are complete
-        with torch.cuda.stream(self.side):
-            out = fn()
-        self.used = True
-        return out
+        return fn()
 
     def join(self):
-        if self.used:
-            self.main.wait_stream(self.side)
-            self.used = False
+        pass
 
 
 def _fast():
@@ -539,8 +520,12 @@ class LogitsLossFn(Function):
         W = cache.get('logits', (wl,), lambda: dict(w=_cast(wl), wT=_cast_t(wl)))
         hn, m, r, ia = K.ln_fwd(x2, nw.detach(), nb.detach(), stable=True)
         logits = K.gemm_nt(hn, W['w'])
-        t = targets.contiguous().reshape(-1)
-        loss, dl = K.ce_fwd(logits, t, 1.0 / (B * n))
+        if targets.dtype != torch.int64:
+            raise TypeError(f'cross-entropy targets must be int64 token ids, got {targets.dtype}')
+        if targets.numel() != B * n:
+            raise ValueError(f'{targets.numel()} targets for {B * n} logit rows')
+        t = targets.contiguous().reshape(-1)            # ids outside [0, C) give a NaN loss (the kernel never reads out of bounds)
+        loss, dl = K.ce_fwd(logits, t, 1.0 / (B * n), want_grad=any(ctx.needs_input_grad))
         ctx.save_for_backward(x2, m, r, ia, nw, wl)
         ctx.hn, ctx.dl, ctx.W, ctx.shape = hn, dl, W, (B, n, D)
         return loss
@@ -549,6 +534,7 @@ class LogitsLossFn(Function):
     def backward(ctx, g):
         x2, m, r, ia, nw, wl = ctx.saved_tensors
         B, n, D = ctx.shape
+        assert ctx.dl.hi is not None
         dhn = K.gemm_nt(ctx.dl, ctx.W['wT'])
         dwl = torch.empty_like(wl)
         K.gemm_tn(ctx.dl, ctx.hn, dwl)

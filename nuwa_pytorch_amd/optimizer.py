@@ -7,6 +7,7 @@ coefficient on the fly.
 
     opt = get_optimizer(nuwa.parameters(), lr=3e-4, wd=0.01, filter_by_requires_grad=True)
     loss.backward(); opt.step(max_grad_norm=0.5); opt.zero_grad()
+    torch.save(opt.state_dict(), path)          # moments + per-parameter step counts; load_state_dict() resumes them
 """
 import ctypes as C
 import math
@@ -32,25 +33,34 @@ def separate_weight_decayable_params(params):
     return wd, no_wd
 
 
-class FusedAdamW:
-    """torch.optim.AdamW semantics (betas (0.9, 0.999), eps 1e-8, decoupled decay) for fp32 parameters on one HIP device."""
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (betas (0.9, 0.999), eps 1e-8, decoupled decay) for fp32 parameters on one HIP device.
+
+    A regular `torch.optim.Optimizer`: two parameter groups (matrices with weight decay, ndim < 2 without -- optimizer.py:6-9), so
+    learning-rate schedulers attach to `param_groups`; `state[p]` holds `step`, `exp_avg`, `exp_avg_sq`, so `state_dict()` /
+    `load_state_dict()` checkpoint and resume the moments and the per-parameter step counts.  The moments are the SAME storage the
+    fused kernel updates through its chunk table; parameters are written through raw pointers and their autograd version counter is
+    bumped afterwards, so saved-tensor checks see the update."""
 
     def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
-        seen, self.params = set(), []
+        seen, flat = set(), []
         for p in params:
             if id(p) not in seen:
                 seen.add(id(p))
-                self.params.append(p)
-        assert self.params and all(p.is_cuda and p.dtype == torch.float32 for p in self.params), \
+                flat.append(p)
+        assert flat and all(p.is_cuda and p.dtype == torch.float32 for p in flat), \
             'FusedAdamW runs through libamdnuwa: fp32 parameters on an MI355X device'
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        wd_p, no_wd_p = separate_weight_decayable_params(flat)
+        groups = [g for g in ({'params': wd_p, 'weight_decay': weight_decay}, {'params': no_wd_p, 'weight_decay': 0.}) if g['params']]
+        super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.params = [p for g in self.param_groups for p in g['params']]
         self.device = self.params[0].device
         self.state_m = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
         self.state_v = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
-        self.steps = 0
         self.param_steps = [0] * len(self.params)       # torch counts updates per parameter (one without a gradient is skipped)
-        # host image of the chunk table (numpy structured array == amdnuwa_adamw_chunk); everything except the gradient pointers
-        # and the per-parameter bias corrections is filled once
+        self._bind_state()
+        # host image of the chunk table (numpy structured array == amdnuwa_adamw_chunk); everything except the gradient pointers,
+        # the decay and the per-parameter bias corrections is filled once
         self._dtype = np.dtype([('p', '<u8'), ('g', '<u8'), ('m', '<u8'), ('v', '<u8'), ('n', '<i8'), ('weight_decay', '<f4'),
                                 ('bias_correction1', '<f4'), ('bias_correction2', '<f4')], align=True)
         assert self._dtype.itemsize == C.sizeof(_Chunk)
@@ -65,12 +75,46 @@ class FusedAdamW:
         H['m'] = np.array([t.data_ptr() for t in self.state_m], dtype=np.uint64)[self._owner] + self._off
         H['v'] = np.array([t.data_ptr() for t in self.state_v], dtype=np.uint64)[self._owner] + self._off
         H['n'] = np.minimum(CHUNK, numel[self._owner] - (self._off // np.uint64(4)).astype(np.int64))
-        H['weight_decay'] = np.array([self.weight_decay if p.ndim >= 2 else 0. for p in self.params], dtype=np.float32)[self._owner]
         self._host = H
         self._pptr = [p.data_ptr() for p in self.params]
         self._table = torch.empty(self.nchunks * self._dtype.itemsize, dtype=torch.uint8, device=self.device)
         self._partials = torch.empty(max(self.nchunks, 1), dtype=torch.float32, device=self.device)
         self._norm = torch.ones(2, dtype=torch.float32, device=self.device)      # [total norm, clip coefficient]
+
+    # -- hyper-parameters live in param_groups (schedulers edit them there); the fused launch takes ONE lr / betas / eps
+    def _hyper(self):
+        g0 = self.param_groups[0]
+        for g in self.param_groups[1:]:
+            if (g['lr'], tuple(g['betas']), g['eps']) != (g0['lr'], tuple(g0['betas']), g0['eps']):
+                raise RuntimeError('FusedAdamW: lr / betas / eps must agree across the parameter groups (one fused launch)')
+        return float(g0['lr']), tuple(g0['betas']), float(g0['eps'])
+
+    lr = property(lambda self: self._hyper()[0])
+    betas = property(lambda self: self._hyper()[1])
+    eps = property(lambda self: self._hyper()[2])
+
+    def _bind_state(self):
+        """state[p] views the buffers the kernel updates (exp_avg / exp_avg_sq) and the host-side step count"""
+        for i, p in enumerate(self.params):
+            self.state[p] = {'step': torch.tensor(float(self.param_steps[i])), 'exp_avg': self.state_m[i], 'exp_avg_sq': self.state_v[i]}
+
+    def state_dict(self):
+        for i, p in enumerate(self.params):
+            self.state[p]['step'] = torch.tensor(float(self.param_steps[i]))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)              # (torch copies the loaded tensors: move their values into OUR storage)
+        with torch.no_grad():
+            for i, p in enumerate(self.params):
+                st = self.state.get(p, {})
+                if 'exp_avg' in st:
+                    self.state_m[i].copy_(st['exp_avg'])
+                    self.state_v[i].copy_(st['exp_avg_sq'])
+                    self.param_steps[i] = int(float(st['step']))
+                else:
+                    self.state_m[i].zero_(); self.state_v[i].zero_(); self.param_steps[i] = 0
+        self._bind_state()
 
     def _upload(self, advance=False):
         b1, b2 = self.betas
@@ -87,6 +131,7 @@ class FusedAdamW:
         H = self._host
         has = gp[self._owner] != 0
         H['g'] = np.where(has, gp[self._owner] + self._off, np.uint64(0))
+        H['weight_decay'] = np.array([g['weight_decay'] for g in self.param_groups for _ in g['params']], dtype=np.float32)[self._owner]
         H['bias_correction1'] = (1. - b1 ** t).astype(np.float32)[self._owner]
         H['bias_correction2'] = (1. - b2 ** t).astype(np.float32)[self._owner]
         self._table.copy_(torch.from_numpy(H.view(np.uint8).reshape(-1)), non_blocking=False)
@@ -101,19 +146,24 @@ class FusedAdamW:
         return self._norm
 
     @torch.no_grad()
-    def step(self, max_grad_norm=None):
+    def step(self, closure=None, max_grad_norm=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         L = _lib.lib()
         st = torch.cuda.current_stream().cuda_stream
         clip = None
+        lr, (b1, b2), eps = self._hyper()
         self._upload(advance=True)
         if max_grad_norm is not None:
             _lib.check(L.amdnuwa_grad_norm(self._table.data_ptr(), self.nchunks, float(max_grad_norm), self._partials.data_ptr(),
                                            self._norm.data_ptr(), st), 'amdnuwa_grad_norm')
             clip = self._norm.data_ptr() + 4
-        self.steps += 1
-        b1, b2 = self.betas
-        _lib.check(L.amdnuwa_adamw_step(self._table.data_ptr(), self.nchunks, self.lr, b1, b2, self.eps, clip, st), 'amdnuwa_adamw_step')
+        _lib.check(L.amdnuwa_adamw_step(self._table.data_ptr(), self.nchunks, lr, b1, b2, eps, clip, st), 'amdnuwa_adamw_step')
+        torch.autograd.graph.increment_version([p for p in self.params if p.grad is not None])   # written behind autograd's back
         ops.WeightCache.EPOCH += 1               # the bf16 operand copies of the weights are stale now
+        return loss
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:

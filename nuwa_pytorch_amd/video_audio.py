@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from torch import nn, einsum
 
 from . import ops
-from .nuwa_pytorch import (MList, exists, default, eval_decorator, prob_mask_like, SandwichNorm, ShiftVideoTokens, FeedForward, Deterministic,
+from .nuwa_pytorch import (MList, exists, default, eval_decorator, bernoulli_rows, SandwichNorm, ShiftVideoTokens, FeedForward, Deterministic,
                            Attention, Sparse3DNA, StableLayerNorm, Transformer, ReversibleTransformer, Embedding,
                            AxialPositionalEmbedding, RotaryEmbedding)
 
@@ -560,7 +560,7 @@ class NUWAVideoAudio(nn.Module):
             self.train(was_training)
 
     def _generate(self, text, filter_thres, temperature, decode_max_batchsize, cond_scale, num_frames):
-        from .nuwa_pytorch import batch_process, gumbel_sample, top_k
+        from .nuwa_pytorch import map_in_chunks, sample_top_fraction
         if not text.is_cuda:
             raise RuntimeError('nuwa_pytorch_amd: the decoder path needs a HIP device; there is no CPU fallback')
         batch, device = text.shape[0], text.device
@@ -594,7 +594,7 @@ class NUWAVideoAudio(nn.Module):
                 uv, ua = dec.forward_layers(dec.video_norm(v_hid), dec.audio_norm(a_hid), context=text_embeds, context_mask=no_text)
                 uncond = logits_of(uv, ua)
                 logits = uncond + (logits - uncond) * cond_scale
-            sample = gumbel_sample(top_k(logits[:, -1], thres=filter_thres), temperature=temperature, dim=-1)[:, None]
+            sample = sample_top_fraction(logits[:, -1], filter_thres, temperature)[:, None]
             if decoding_video:
                 video_indices = torch.cat((video_indices, sample), dim=1)
                 boundary = video_indices.shape[1] % tpf == 0
@@ -606,7 +606,7 @@ class NUWAVideoAudio(nn.Module):
         fs = self.video_fmap_size
         codes = self.vae.codes_for_decoder(video_indices)
         codes = codes.reshape(batch, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
-        images = batch_process(codes.contiguous(), self.vae._hip_decode, chunks=decode_max_batchsize)
+        images = map_in_chunks(codes.contiguous(), self.vae._hip_decode, chunks=decode_max_batchsize)
         return images.reshape(batch, -1, *images.shape[1:]), audio_indices
 
     def forward(self, *, text, video, audio, return_loss=False, cond_dropout_prob=0.2):
@@ -624,8 +624,7 @@ class NUWAVideoAudio(nn.Module):
         frame_emb = self.embed_video(frame_indices[:, :-1] if return_loss else frame_indices)
         audio_emb = self.embed_audio(audio[:, :-1] if return_loss else audio)
         if self.training and cond_dropout_prob > 0:
-            uncond = prob_mask_like((batch,), cond_dropout_prob, device=device)
-            text_mask = text_mask & ~uncond[:, None]
+            text_mask = text_mask & ~bernoulli_rows(batch, cond_dropout_prob, device)[:, None]
         dec = self.video_audio_transformer
         v_hid, a_hid = dec.forward_layers(frame_emb, audio_emb, context=text_embeds, context_mask=text_mask)
         vn, an = dec.video_norm.norm, dec.audio_norm.norm

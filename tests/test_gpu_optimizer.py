@@ -60,3 +60,44 @@ def test_clip_grad_norm_in_place_and_weight_cache_epoch():
     e0 = ops.WeightCache.EPOCH
     opt.step()
     assert ops.WeightCache.EPOCH == e0 + 1             # cached bf16 weight copies are rebuilt after the update
+
+
+def test_fused_adamw_is_a_torch_optimizer_with_resumable_state():
+    """FusedAdamW is a torch.optim.Optimizer: LR schedulers drive param_groups, state_dict()/load_state_dict() resume the moments and the
+    per-parameter step counts (a resumed run continues bit for bit), and the in-place update bumps the parameters' version counter"""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from nuwa_pytorch_amd.optimizer import FusedAdamW
+    a, b = _model(), _model()
+    opt = FusedAdamW(a.parameters(), lr=1e-2, weight_decay=0.1)
+    assert isinstance(opt, torch.optim.Optimizer) and len(opt.param_groups) == 2
+    assert opt.param_groups[1]['weight_decay'] == 0 and all(p.ndim < 2 for p in opt.param_groups[1]['params'])
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(16, 37, generator=g).to(DEV) for _ in range(4)]
+
+    def run(model, optim, x, scheduler=None):
+        model.zero_grad(set_to_none=True)
+        (model(x).square().mean() * 50).backward()
+        optim.step(max_grad_norm=1.0)
+        if scheduler is not None:
+            scheduler.step()
+
+    v0 = a[0].weight._version
+    run(a, opt, xs[0], sched)
+    run(a, opt, xs[1], sched)
+    assert a[0].weight._version > v0
+    assert abs(opt.lr - 1e-2 * 0.25) < 1e-12                       # the scheduler's edits reach the fused launch
+    sd = opt.state_dict()
+    assert len(sd['state']) == len(list(a.parameters())) and float(sd['state'][0]['step']) == 2.0
+    # resume into a fresh optimiser on a copy of the model
+    b.load_state_dict(a.state_dict())
+    opt2 = FusedAdamW(b.parameters(), lr=1e-2, weight_decay=0.1)
+    opt2.load_state_dict(sd)
+    assert abs(opt2.lr - 1e-2 * 0.25) < 1e-12 and opt2.param_steps == opt.param_steps
+    run(a, opt, xs[2])
+    run(b, opt2, xs[2])
+    for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+        assert torch.equal(pa, pb), n
+    for ma, mb in zip(opt.state_m, opt2.state_m):
+        assert torch.equal(ma, mb)

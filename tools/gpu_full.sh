@@ -1,4 +1,9 @@
 #!/bin/bash
-mkdir -p gpurun_out; export PYTHONUNBUFFERED=1
-timeout 1200 python -m pytest tests -m gpu -q --timeout 300 -p no:cacheprovider > gpurun_out/pytest_g.log 2>&1; echo "rc=$?" >> gpurun_out/pytest_g.log; tail -n 8 gpurun_out/pytest_g.log | cut -c1-220
-timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/bench_g.log 2>&1; tail -n 1 gpurun_out/bench_g.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('tok/s', round(d['value']), 'ms', round(d['ms_per_step'],2), 'step_frac', round(d['step_mfma_frac'],4), 'gemm_nt TF/s', round(d['roofline']['achieved']), 'nt share', round(d['roofline']['share_of_step'],3), 'tokenizer', d.get('vae_tokenizer'))"
+# per-change check on the MI355X: the whole GPU suite + the default bench line (TAG names the logs under gpurun_out/)
+TAG=${TAG:-r02}
+mkdir -p gpurun_out; export PYTHONUNBUFFERED=1 TMPDIR=/tmp
+rm -f gpurun_out/parity_log.jsonl gpurun_out/named_size.json
+timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q --tb=short ${PYTEST_ARGS:-} > gpurun_out/pytest_$TAG.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_$TAG.txt
+tail -n 25 gpurun_out/pytest_$TAG.txt
+timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench_$TAG.log 2>&1; echo "bench rc=$?"
+tail -n 1 gpurun_out/bench_$TAG.log | cut -c1-3000
