@@ -138,6 +138,43 @@ __device__ __forceinline__ W8 ldw(const float* wsh, int row) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The head mix on the matrix pipe (xattn3_* kernels).  P'[g][q, key] = sum_h W[g][h] P[h][q, key] costs 64 FMAs per (q, key) on
+// the VALU -- 512 wave instructions per 32-key chunk, the largest single block of the kernel -- although every lane already holds
+// the 8 per-head values of its own (query, key) slots.  As an MFMA: B operand (32 x 16) = the lane's 8 head values of ONE slot e
+// packed to bf16 (k = 8 * lane_group + h, column = query), A operand (16 x 32) = a constant block pattern of W,
+//     A[(kg, gq)][8 kg' + h] = (kg == kg') * W[4 Q + gq][h]         (Q = 0 / 1 selects output heads 0-3 / 4-7),
+// so D[(kg, gq)][query] = P'[4 Q + gq] of lane group kg's own slot: output row 4 kg + gq is register gq of lane group kg -- the
+// mixed values land in the SAME lanes that own the slot, no data movement.  16 slot-MFMAs per chunk (x 2: W travels as a bf16
+// hi + lo pair, so only P itself is rounded, as it is anyway before P'V) instead of 512 FMAs.  The backward mixes dP = W^T dP' the
+// same way with the transposed matrix.
+// ------------------------------------------------------------------------------------------------
+struct MixA { bf16x8 hi[2], lo[2]; };
+__device__ __forceinline__ MixA mix_operand(const float* wsrc, int lane) {
+    MixA a;
+    const int m = lane & 15;
+    const bool on = (m >> 2) == (lane >> 4);
+#pragma unroll
+    for (int Q = 0; Q < 2; ++Q) {
+        const W8 w = ldw(wsrc, 4 * Q + (m & 3));
+        uint32_t ph[4], pl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ph[t] = pack2_rne(w.v[2 * t], w.v[2 * t + 1]);
+            pl[t] = pack2_rne(w.v[2 * t] - lo_f(ph[t]), w.v[2 * t + 1] - hi_f(ph[t]));
+        }
+        a.hi[Q] = __builtin_bit_cast(bf16x8, on ? make_uint4(ph[0], ph[1], ph[2], ph[3]) : make_uint4(0, 0, 0, 0));
+        a.lo[Q] = __builtin_bit_cast(bf16x8, on ? make_uint4(pl[0], pl[1], pl[2], pl[3]) : make_uint4(0, 0, 0, 0));
+    }
+    return a;
+}
+// the 8 per-head values of slot e, packed as the B operand (element h = head h)
+__device__ __forceinline__ bf16x8 pack_heads(const float (&v)[NH][8], int e) {
+    return __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(v[0][e], v[1][e]), pack2_rne(v[2][e], v[3][e]),
+                                                 pack2_rne(v[4][e], v[5][e]), pack2_rne(v[6][e], v[7][e])));
+}
+#define MIX(A_, Q_, B_) MFMA((A_).lo[Q_], B_, MFMA((A_).hi[Q_], B_, (f32x4{0.f, 0.f, 0.f, 0.f})))
+
+// ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void xattn2_fwd_kernel(X2Args a) {

@@ -113,7 +113,7 @@ def test_cfg3_vae_tokenizer_matches_oracle():
     img = torch.rand(1, 3, 256, 256)
     P = {k: v.detach() for k, v in vae.state_dict().items()}
     fm = O.vae_encode_fmap(img, P, num_layers=4, heads=8)
-    idx_ref, gap = (t.reshape(-1) for t in O.vq_eval_lookup(fm, P['vq.embed'], P['vq.project_in.weight'], P['vq.project_in.bias']))
+    idx_ref, gap = (t.reshape(-1) for t in O.vq_eval_lookup(fm, P['vq._codebook.embed'], P['vq.project_in.weight'], P['vq.project_in.bias']))
     idx = vae.to(DEV).get_video_indices(img.to(DEV)[None])[0, 0].reshape(-1).cpu()
     sure = gap > 1e-5
     assert float(sure.float().mean()) > 0.98
