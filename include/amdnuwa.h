@@ -166,9 +166,18 @@ int amdnuwa_embed_bwd(const long long* ids, const long long* sorted_ids, const l
 int amdnuwa_ce_fwd(const float* logits, const long long* targets, float* row_loss, float* loss, uint16_t* dl_hi,
                    uint16_t* dl_lo, long long R, int C, int ld_dl, float grad_scale, amdnuwa_stream stream);
 int amdnuwa_scale_by_device_scalar(float* x, size_t n, const float* scalar, amdnuwa_stream stream);
+/* Fused to_logits + cross entropy (np.py:1958 `self.to_logits(...)` feeding np.py:1963 `F.cross_entropy`) WITHOUT the fp32 logits in
+ * memory: logits = h[R,K] . w[C,K]^T (bf16 operands, fp32 accumulate) are produced twice inside the 256x256 MFMA ring -- pass 1 keeps
+ * per-(row, 64-column block) (max, sum exp) and the target logit, pass 2 writes dlogits = (softmax - onehot) * grad_scale as bf16
+ * [R, ld_dl] (skipped when dlogits is NULL).  row_loss[r] = lse - logit[target]; *loss = mean (fixed order).  A target outside
+ * [0, C) makes its row loss (and the mean) NaN.  Needs C % 64 == 0, K % 32 == 0 (else AMDNUWA_ERR_UNSUPPORTED: use gemm_nt + ce_fwd). */
+size_t amdnuwa_linear_ce_workspace_bytes(long long R, int C);
+int amdnuwa_linear_ce(const uint16_t* h, int ldh, const uint16_t* w, int ldw, const long long* targets, long long R, int C, int K,
+                      float grad_scale, float* row_loss, float* loss, uint16_t* dlogits, int ld_dl, void* workspace,
+                      size_t workspace_bytes, amdnuwa_stream stream);
 
 /* ------------------------------------------------------------------------------------------
- * Sparse3DNA core (np.py:488-608, incl. the unfoldNd gather np.py:526-534): causal 3-D nearby
+ * Sparse3DNA core (np.py:488-608, incl. the unfoldNd gather np.py:526-534): causal (or symmetric) 3-D nearby
  * attention with <bos> key/value, fp32 softmax and talking heads.  q/k/v/o are token-row major
  * [B*ntok, ld] with head h in columns [h*dim_head, (h+1)*dim_head); q is UNSCALED.
  * ---------------------------------------------------------------------------------------- */
@@ -184,6 +193,11 @@ typedef struct {
      * (column sums of ds over every query) to d_rel_bias when that is non-NULL. */
     const float* rel_bias;
     float* d_rel_bias;
+    /* 0: causal window -- every tap at or before the query on each axis (Sparse3DNA(causal=True), np.py:427);
+     * 1: symmetric 'same' window, tap t of an axis at offset (t - (k-1)/2) * dilation (causal=False, np.py:429: the sketch
+     *    encoder of NUWASketch).  Row 0 stays the <bos> key/value; taps that leave the grid are masked, taps inside the grid but
+     *    past the end of the sequence read the reference's zero padding (score 0, value 0). */
+    int noncausal;
 } amdnuwa_s3_geom;
 
 int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* k, const uint16_t* v,

@@ -6,7 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libamdnuwa.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 P = C.c_void_p
 I = C.c_int
@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
 class S3Geom(C.Structure):
     _fields_ = [('B', I), ('ntok', I), ('F', I), ('H', I), ('W', I), ('kf', I), ('kh', I), ('kw', I),
                 ('df', I), ('dh', I), ('dw', I), ('heads', I), ('dim_head', I), ('scale', F),
-                ('rel_bias', P), ('d_rel_bias', P)]
+                ('rel_bias', P), ('d_rel_bias', P), ('noncausal', I)]
 
 
 class XGeom(C.Structure):
@@ -80,6 +80,8 @@ SIGNATURES = {
     'amdnuwa_embed_bwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, SZ, P]),
     'amdnuwa_ce_fwd': (I, [P, P, P, P, P, P, LL, I, I, F, P]),
     'amdnuwa_scale_by_device_scalar': (I, [P, SZ, P, P]),
+    'amdnuwa_linear_ce_workspace_bytes': (SZ, [LL, I]),
+    'amdnuwa_linear_ce': (I, [P, I, P, I, P, LL, I, I, F, P, P, P, I, P, SZ, P]),
     'amdnuwa_sparse3dna_fwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P]),
     'amdnuwa_sparse3dna_bwd_workspace_bytes': (SZ, [SG]),
     'amdnuwa_sparse3dna_bwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P, P, P, P, P, P, I, P, I, P, SZ, P]),

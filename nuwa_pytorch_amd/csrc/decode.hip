@@ -416,6 +416,7 @@ extern "C" int amdnuwa_s3_decode(const amdnuwa_s3_geom* g, const uint16_t* qkv, 
         g->F <= 0 || g->H <= 0 || g->W <= 0)
         return AMDNUWA_ERR_ARG;
     if ((qkv_lo != nullptr) != (kv_cache_lo != nullptr)) return AMDNUWA_ERR_ARG;
+    if (g->noncausal) return AMDNUWA_ERR_UNSUPPORTED;          // incremental decoding needs every tap behind the query
     if (cache_rows < 1 || cache_rows > 1 + g->F * g->H * g->W) return AMDNUWA_ERR_ARG;
     if (g->B <= 0) return AMDNUWA_OK;
     S3DecArgs a{};

@@ -32,6 +32,27 @@ __device__ __forceinline__ void row_load_t(const void* base, size_t row_off, int
     }
 }
 
+// non-temporal (streaming) forms: the row kernels touch every byte once, so the lines need not displace reusable data in L2 / MALL
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+template <bool BF>
+__device__ __forceinline__ float4 ld4_nt(const void* base, size_t i) {
+    if (BF) {
+        const u32x2v v = __builtin_nontemporal_load(reinterpret_cast<const u32x2v*>(reinterpret_cast<const bf16_t*>(base) + i));
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    }
+    const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(reinterpret_cast<const float*>(base) + i));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+    const f32x4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4v*>(p));
+}
+__device__ __forceinline__ void st_bf16x4_nt(bf16_t* p, float a, float b, float c, float d) {
+    const u32x2v t = {pack2_rne(a, b), pack2_rne(c, d)};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x2v*>(p));
+}
+
 template <int NV>
 __device__ __forceinline__ void row_load(const float* __restrict__ p, int D, int lane, RowValsT<NV>& r, float fill = 0.f) {
 #pragma unroll
@@ -320,7 +341,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 //   block k+1's output;  y_prev = inner output of block k (post-norm input).
 // Partials: partA [nblk][3][D] = (dw_pre, db_pre, -) and partB [nblk][3][D] = (dw_post, db_post, sum(dy_prev)).
 // ---------------------------------------------------------------------------------------------
-template <int NV, bool BF>
+template <int NV, bool BF, int NT = 0>          // NT bit 0: non-temporal stores, bit 1: non-temporal loads (tuning key 11)
 __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restrict__ dh, const float* __restrict__ x,
                                                            const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                            const float* __restrict__ w, const float* __restrict__ gres,
@@ -339,7 +360,10 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     struct RowIn { RowValsT<NV> xv, gv, rv, yv; float mean, rstd, meanp, rstdp; };
     auto load_row = [&](long long row, RowIn& in) {
-        row_load(x + row * D, D, lane, in.xv);
+        if (NT & 2) {
+#pragma unroll
+            for (int it = 0; it < NV; ++it) { const int e = (lane + it * 64) * 4; in.xv.v[it] = e < D ? ld4_nt<false>(x, (size_t)row * D + e) : zero4; }
+        } else row_load(x + row * D, D, lane, in.xv);
         if (shift_ntok > 0) {
             const int i = (int)(row % shift_ntok);
             long long src_h = -1, src_w = -1;
@@ -354,13 +378,22 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
                 if (e >= D) { in.gv.v[it] = zero4; continue; }
                 long long src = row;
                 if (i > 0) { if (e < quarter) src = src_h; else if (e < 2 * quarter) src = src_w; }
-                in.gv.v[it] = src >= 0 ? ld4<BF>(dh, (size_t)src * D + e) : zero4;
+                in.gv.v[it] = src >= 0 ? ((NT & 2) ? ld4_nt<BF>(dh, (size_t)src * D + e) : ld4<BF>(dh, (size_t)src * D + e)) : zero4;
             }
         } else {
             row_load_t<BF>(dh, (size_t)row * D, D, lane, in.gv);
         }
-        row_load(gres + row * D, D, lane, in.rv);
-        row_load_t<BF>(yprev, (size_t)row * D, D, lane, in.yv);
+        if (NT & 2) {
+#pragma unroll
+            for (int it = 0; it < NV; ++it) {
+                const int e = (lane + it * 64) * 4;
+                in.rv.v[it] = e < D ? ld4_nt<false>(gres, (size_t)row * D + e) : zero4;
+                in.yv.v[it] = e < D ? ld4_nt<BF>(yprev, (size_t)row * D + e) : zero4;
+            }
+        } else {
+            row_load(gres + row * D, D, lane, in.rv);
+            row_load_t<BF>(yprev, (size_t)row * D, D, lane, in.yv);
+        }
         in.mean = mean_i[row]; in.rstd = rstd_i[row]; in.meanp = meanp_i[row]; in.rstdp = rstdp_i[row];
     };
     const long long stride = (long long)gridDim.x * ROWS_PER_BLOCK;
@@ -394,7 +427,7 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
             const float4 o = cur.rv.v[it];
             dx[it] = make_float4(o.x + cur.rstd * (g[it].x - m1 - xh[it].x * m2), o.y + cur.rstd * (g[it].y - m1 - xh[it].y * m2),
                                  o.z + cur.rstd * (g[it].z - m1 - xh[it].z * m2), o.w + cur.rstd * (g[it].w - m1 - xh[it].w * m2));
-            *reinterpret_cast<float4*>(dx_out + row * D + e) = dx[it];
+            if (NT & 1) st4_nt(dx_out + row * D + e, dx[it]); else *reinterpret_cast<float4*>(dx_out + row * D + e) = dx[it];
         }
         // ---- post-norm backward of block k on the row just produced -> dy_prev
         s1 = 0.f; s2 = 0.f;
@@ -419,7 +452,8 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
             const float d0 = cur.rstdp * (g[it].x - n1 - xh[it].x * n2), d1 = cur.rstdp * (g[it].y - n1 - xh[it].y * n2);
             const float d2 = cur.rstdp * (g[it].z - n1 - xh[it].z * n2), d3 = cur.rstdp * (g[it].w - n1 - xh[it].w * n2);
             psB[it].x += d0; psB[it].y += d1; psB[it].z += d2; psB[it].w += d3;
-            store_bf16x4(dyp_hi + row * D, dyp_lo ? dyp_lo + row * D : nullptr, e, d0, d1, d2, d3);
+            if ((NT & 1) && !dyp_lo) st_bf16x4_nt(dyp_hi + row * D + e, d0, d1, d2, d3);
+            else store_bf16x4(dyp_hi + row * D, dyp_lo ? dyp_lo + row * D : nullptr, e, d0, d1, d2, d3);
         }
     };
     for (; row < R; row += 2 * stride) {
@@ -921,12 +955,16 @@ extern "C" int amdnuwa_ln_bwd_chain(const void* dh, const float* x, const float*
     float* partB = partA + (size_t)ln_bwd_blocks(R) * 3 * D;
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
-#define LBC_(NV_, BF_) do { int o_ = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_, ln_bwd_chain_kernel<NV_, BF_>, 256, 0) == hipSuccess && o_ > 0 && o_ * n_cu < nb) nb = o_ * n_cu; \
-        hipLaunchKernelGGL((ln_bwd_chain_kernel<NV_, BF_>), dim3(nb), dim3(256), 0, stream, (const float*)dh, x, mean, rstd, w, g, dx, (const float*)y_prev, mean_prev, rstd_prev, w_prev, dy_prev_hi, dy_prev_lo, partA, partB, R, D, shift_ntok, shift_fmap); } while (0)
+    const int nt = g_amdnuwa_tuning[11] & 3;
+#define LBC__(NV_, BF_, NT_) do { int o_ = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_, ln_bwd_chain_kernel<NV_, BF_, NT_>, 256, 0) == hipSuccess && o_ > 0 && o_ * n_cu < nb) nb = o_ * n_cu; \
+        if (g_amdnuwa_tuning[12] > 0 && g_amdnuwa_tuning[12] * n_cu < nb) nb = g_amdnuwa_tuning[12] * n_cu; \
+        hipLaunchKernelGGL((ln_bwd_chain_kernel<NV_, BF_, NT_>), dim3(nb), dim3(256), 0, stream, (const float*)dh, x, mean, rstd, w, g, dx, (const float*)y_prev, mean_prev, rstd_prev, w_prev, dy_prev_hi, dy_prev_lo, partA, partB, R, D, shift_ntok, shift_fmap); } while (0)
+#define LBC_(NV_, BF_) do { if (nt == 0) LBC__(NV_, BF_, 0); else if (nt == 1) LBC__(NV_, BF_, 1); else if (nt == 2) LBC__(NV_, BF_, 2); else LBC__(NV_, BF_, 3); } while (0)
 #define LBC(NV_) do { if (inputs_bf16) LBC_(NV_, true); else LBC_(NV_, false); } while (0)
     if (D <= 256) LBC(1); else if (D <= 512) LBC(2); else LBC(4);
 #undef LBC
 #undef LBC_
+#undef LBC__
     LAUNCH_CHECK();
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * D + 15) / 16), dim3(1024), 0, stream, partA, nb, 3, D, dw, db, (float*)nullptr, 0);
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((3 * D + 15) / 16), dim3(1024), 0, stream, partB, nb, 3, D, dw_prev, db_prev, dsum_prev, 0);

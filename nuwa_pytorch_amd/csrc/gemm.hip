@@ -37,6 +37,9 @@ struct GemmArgs {
     bf16_t* C2; int ldc2;   // NT bf16 epilogue: GEGLU output (C in the interleaved-by-8 layout), or NULL
     const bf16_t* Uin; int ldu;   // != NULL: GEGLU BACKWARD epilogue: C2 = du from (product = dgg, Uin = u); C is not written
     int dbg;                // probe only (tuning key 7): bit0 skip epilogue stores, bit1 skip main loop
+    // fused linear + cross entropy (EPI 2 / 3 of the 256x256 ring): per (row, 64-column block) partial (max, sum exp) and the
+    // target logit in pass 1; dlogits = (exp(logit - lse) - onehot) * ce_scale in pass 2.  The logits never reach memory.
+    float* ce_stats; float* ce_tl; const float* ce_lse; const long long* ce_tgt; float ce_scale; int ce_nblk;
 };
 
 __device__ __forceinline__ long long boff(const GemmArgs& p, long long z, long long s, long long s_in) {
@@ -388,13 +391,13 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs p) {
 // row bits 4-5 (the bits that vary across a 16-lane ds_read_b128 group under this permutation) to stay bank-conflict free.
 template <int EPI>
 __device__ __forceinline__ int b256_swz(int row) {
-    const int gsel = EPI == 1 ? (row >> 4) & 3 : (row >> 2) & 3;
+    const int gsel = EPI >= 1 ? (row >> 4) & 3 : (row >> 2) & 3;
     return (0x1320 >> (gsel * 4)) & 3;
 }
 template <int EPI>
 __device__ __forceinline__ int b256_off(int row, int cc) { return row * 64 + ((cc ^ b256_swz<EPI>(row)) << 4); }
 template <int EPI>
-__device__ __forceinline__ int b256_row(int j, int fr) { return EPI == 1 ? ((fr >> 2) * 16 + j * 4 + (fr & 3)) : (j * 16 + fr); }
+__device__ __forceinline__ int b256_row(int j, int fr) { return EPI >= 1 ? ((fr >> 2) * 16 + j * 4 + (fr & 3)) : (j * 16 + fr); }
 
 template <bool SHIFT, int EPI, int NS, int WNW, int STAG = 0>
 __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kernel(GemmArgs p) {
@@ -569,7 +572,51 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
     }
 
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
-    if constexpr (EPI == 1) {
+    if constexpr (EPI == 2 || EPI == 3) {
+        // fused linear + cross entropy (to_logits + F.cross_entropy, np.py:1958-1963).  Same ownership as the bf16 epilogue: lane
+        // (fr, fg) holds 16 contiguous logits of row m; the 4 lanes fr + 16 fg of a row cover this wave's 64-column block.
+        // (host side guarantees N % 64 == 0)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
+            if (m >= p.M) continue;                                   // (the 4 lanes of a row leave together)
+            const int nb = n0 + wn * 64 + fg * 16;
+            if (nb >= p.N) continue;
+            float vv[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha;
+            const long long t = p.ce_tgt[m];
+            const int tc = (t >= nb && t < nb + 16) ? (int)(t - nb) : -1;      // the target column, if this lane holds it
+            if constexpr (EPI == 2) {
+                float mx = vv[0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, vv[e]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sm = 0.f, tl = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    sm += __builtin_amdgcn_exp2f((vv[e] - mx) * 1.4426950408889634f);
+                    tl = (e == tc) ? vv[e] : tl;
+                }
+                sm += __shfl_xor(sm, 16, 64);
+                sm += __shfl_xor(sm, 32, 64);
+                if (fg == 0) *reinterpret_cast<float2*>(p.ce_stats + (m * p.ce_nblk + ((n0 + wn * 64) >> 6)) * 2) = make_float2(mx, sm);
+                if (tc >= 0) p.ce_tl[m] = tl;
+            } else {
+                const float lse = p.ce_lse[m];
+                float dv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    dv[e] = (__builtin_amdgcn_exp2f((vv[e] - lse) * 1.4426950408889634f) - (e == tc ? 1.f : 0.f)) * p.ce_scale;
+                bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + nb;
+                reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2_rne(dv[0], dv[1]), pack2_rne(dv[2], dv[3]), pack2_rne(dv[4], dv[5]), pack2_rne(dv[6], dv[7]));
+                reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2_rne(dv[8], dv[9]), pack2_rne(dv[10], dv[11]), pack2_rne(dv[12], dv[13]), pack2_rne(dv[14], dv[15]));
+            }
+        }
+    } else if constexpr (EPI == 1) {
         // lane (fr, fg) owns row m = .. + fr and the 16 contiguous columns n = n0 + wn*64 + fg*16 + [j*4 + r]
         const bool vec8 = (p.N % 8 == 0) && (p.ldc % 8 == 0);
 #pragma unroll
@@ -1283,6 +1330,76 @@ static bool nt_geglu_fusable(const amdnuwa_gemm_desc* d) {
     if (v == 7) return true;
     if (v != 0 || d->M <= 4 * ROWS_MR) return false;
     return (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 512;
+}
+
+// ---- fused linear + cross entropy: row statistics -> lse, row loss, mean (fixed order) ------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ stats, const float* __restrict__ tl, int nblk,
+                                                         long long R, float* __restrict__ lse, float* __restrict__ row_loss) {
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= R) return;
+    const float2* st = reinterpret_cast<const float2*>(stats) + row * nblk;
+    float m = st[0].x;
+    for (int b = 1; b < nblk; ++b) m = fmaxf(m, st[b].x);
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += st[b].y * __expf(st[b].x - m);
+    const float l = m + __logf(s);
+    lse[row] = l;
+    row_loss[row] = l - tl[row];                       // tl is NaN where the target id lies outside [0, C)
+}
+__global__ __launch_bounds__(1024) void ce_mean_kernel(const float* __restrict__ v, long long n, float* __restrict__ out) {
+    __shared__ float sred[1024];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) s += v[i];
+    sred[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sred[threadIdx.x] += sred[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sred[0] / (float)n;
+}
+}  // namespace
+
+extern "C" size_t amdnuwa_linear_ce_workspace_bytes(long long R, int C) {
+    if (R <= 0 || C <= 0 || C % 64) return 0;
+    return (size_t)R * (C / 64) * 2 * sizeof(float) + (size_t)R * 2 * sizeof(float);
+}
+
+extern "C" int amdnuwa_linear_ce(const uint16_t* h, int ldh, const uint16_t* w, int ldw, const long long* targets, long long R, int C,
+                                 int K, float grad_scale, float* row_loss, float* loss, uint16_t* dlogits, int ld_dl,
+                                 void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!h || !w || !targets || !row_loss || !loss) return AMDNUWA_ERR_ARG;
+    if (C % 64 || K % 32 || ldh % 8 || ldw % 8 || (dlogits && ld_dl % 8) || R > 0x7fffffffLL) return AMDNUWA_ERR_UNSUPPORTED;
+    if (R <= 0) return AMDNUWA_OK;
+    if (!workspace || workspace_bytes < amdnuwa_linear_ce_workspace_bytes(R, C)) return AMDNUWA_ERR_WORKSPACE;
+    const int nblk = C / 64;
+    float* stats = (float*)workspace;
+    float* lse = stats + (size_t)R * nblk * 2;
+    float* tl = lse + R;
+    hipError_t e = hipMemsetAsync(tl, 0xff, (size_t)R * sizeof(float), stream);          // NaN until a valid target column writes it
+    if (e != hipSuccess) return (int)e;
+    GemmArgs p{};
+    p.A = (const bf16_t*)h; p.lda = ldh; p.B = (const bf16_t*)w; p.ldb = ldw;
+    p.C = dlogits; p.ldc = ld_dl; p.alpha = 1.f;
+    p.M = (int)R; p.N = C; p.K = K; p.shift_dim = K;
+    p.tiles_m = (int)((R + 255) / 256); p.tiles_n = (C + 255) / 256;
+    p.ce_stats = stats; p.ce_tl = tl; p.ce_lse = lse; p.ce_tgt = targets; p.ce_scale = grad_scale; p.ce_nblk = nblk;
+    dim3 grid(p.tiles_m * p.tiles_n, 1), block(512);
+    const size_t lds = (size_t)4 * 2 * 256 * 32 * 2;
+    (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 2, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm_nt_256_kernel<false, 2, 4, 4, 1>), grid, block, lds, stream, p);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, stats, tl, nblk, R, lse, row_loss);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(1024), 0, stream, row_loss, R, loss);
+    LAUNCH_CHECK();
+    if (dlogits) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 3, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm_nt_256_kernel<false, 3, 4, 4, 1>), grid, block, lds, stream, p);
+        LAUNCH_CHECK();
+    }
+    return AMDNUWA_OK;
 }
 
 extern "C" int amdnuwa_gemm_nt_fused(const amdnuwa_gemm_desc* d) { return d && d->C2 && nt_geglu_fusable(d) ? 1 : 0; }

@@ -35,6 +35,7 @@ struct S3Args {
     float *part_th, *part_k0, *part_v0;                   // [B*F*H][NH*NH], [B*F*H][NH*DH] x2
     float* dwth;                                          // [NH*NH] accumulated
     int B, ntok, F, H, W, kf, kh, kw, df, dh, dw, NH;
+    int of, oh, ow;                                       // tap index of the query's own position per axis: k - 1 (causal) / (k - 1) / 2 (symmetric)
     float scale;
     int accumulate;
     int dbg;                                              // probe only (tuning key 9): bit 0 / 1 / 2 skip phase 1 / 2 / 3 of the MFMA forward
@@ -142,10 +143,10 @@ __device__ __forceinline__ void sweep_taps(const S3Args& a, const bf16_t* src, c
     const int HS = a.W * a.NH * 32;                      // elements per half image
     bf16_t* st_lo = st_hi + (CH / 8) * HS;
     const int myslot = ((w * a.NH + h) * 4 + c) * 8;
-    const int yr0 = y - (a.kh - 1) * a.dh;
+    const int yr0 = y - a.oh * a.dh;
     uint4 rh[CH / 8], rl[CH / 8];
     auto seek = [&](PlaneIt& p) {                        // advance to a valid plane (or ta == kf)
-        while (p.ta < a.kf && !(p.fr >= 0 && p.yr >= 0)) {
+        while (p.ta < a.kf && !(p.fr >= 0 && p.yr >= 0 && p.fr < a.F && p.yr < a.H)) {
             ++p.tb; p.yr += a.dh;
             if (p.tb == a.kh) { p.tb = 0; p.yr = yr0; ++p.ta; p.fr += a.df; }
         }
@@ -165,7 +166,7 @@ __device__ __forceinline__ void sweep_taps(const S3Args& a, const bf16_t* src, c
             if (srcl) rl[v8] = ok ? *reinterpret_cast<const uint4*>(srcl + gi + v8 * 8) : make_uint4(0, 0, 0, 0);
         }
     };
-    PlaneIt cur{0, 0, f - (a.kf - 1) * a.df, yr0};
+    PlaneIt cur{0, 0, f - a.of * a.df, yr0};
     seek(cur);
     if (cur.ta < a.kf) fetch(cur);
     while (cur.ta < a.kf) {
@@ -183,9 +184,9 @@ __device__ __forceinline__ void sweep_taps(const S3Args& a, const bf16_t* src, c
         if (nxt.ta < a.kf) fetch(nxt);                   // in flight during the compute below
         if (qvalid) {
             const int jb = 1 + (cur.ta * a.kh + cur.tb) * a.kw;
-            int wr = w - (a.kw - 1) * a.dw;
+            int wr = w - a.ow * a.dw;
             for (int tc = 0; tc < a.kw; ++tc, wr += a.dw) {
-                if (wr < 0) continue;
+                if (wr < 0 || wr >= a.W) continue;
                 const int slot = ((wr * a.NH + h) * 4 + c) * 8;
                 fn(jb + tc, st_hi + slot, srcl ? st_lo + slot : nullptr, HS);
             }
@@ -550,13 +551,13 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
     float dkf[CH], dvf[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) { dkf[e] = 0.f; dvf[e] = 0.f; }
-    // planes t = ta*kh + tb; the attending query row of plane t is (f + (kf-1-ta)df, y + (kh-1-tb)dh)
+    // planes t = ta*kh + tb; the attending query row of plane t is (f + (of-ta)df, y + (oh-tb)dh)  [of = kf-1 when causal]
     const int nplanes = a.kf * a.kh;
     auto plane = [&](int t, int& fq, int& yq) {
         const int ta = t / a.kh, tb = t - ta * a.kh;
-        fq = f + (a.kf - 1 - ta) * a.df;
-        yq = y + (a.kh - 1 - tb) * a.dh;
-        return fq < a.F && yq < a.H && (fq * a.H + yq) * a.W + 1 < a.ntok;
+        fq = f + (a.of - ta) * a.df;
+        yq = y + (a.oh - tb) * a.dh;
+        return fq >= 0 && yq >= 0 && fq < a.F && yq < a.H && (fq * a.H + yq) * a.W + 1 < a.ntok;
     };
     auto next_plane = [&](int t) { int fq, yq; while (t < nplanes && !plane(t, fq, yq)) ++t; return t; };
     uint4 rq[CH / 8], rd[CH / 8], rql[CH / 8], rdl[CH / 8];
@@ -568,9 +569,9 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
 #pragma unroll
         for (int tc = 0; tc < KWMAX; ++tc) {
             nds[tc] = npm[tc] = 0.f;
-            const int wq = w + (a.kw - 1 - tc) * a.dw;
+            const int wq = w + (a.ow - tc) * a.dw;
             const int pqn = (fq * a.H + yq) * a.W + wq;
-            if (tc < a.kw && kvalid && wq < a.W && 1 + pqn < a.ntok) {
+            if (tc < a.kw && kvalid && wq >= 0 && wq < a.W && 1 + pqn < a.ntok) {
                 const size_t ci = (((size_t)b * nq + pqn) * J + 1 + t * a.kw + tc) * a.NH + h;
                 nds[tc] = a.ds[ci]; npm[tc] = a.pm[ci];
             }
@@ -612,8 +613,8 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
             int fq, yq;
             plane(tp, fq, yq);
             for (int tc = 0; tc < a.kw; ++tc) {
-                const int wq = w + (a.kw - 1 - tc) * a.dw;
-                if (wq >= a.W) continue;
+                const int wq = w + (a.ow - tc) * a.dw;
+                if (wq < 0 || wq >= a.W) continue;
                 const int pq = (fq * a.H + yq) * a.W + wq;
                 if (1 + pq >= a.ntok) continue;
                 float dsv, pmv;
@@ -1225,6 +1226,10 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
 void fill_geom(S3Args& a, const amdnuwa_s3_geom* g) {
     a.B = g->B; a.ntok = g->ntok; a.F = g->F; a.H = g->H; a.W = g->W; a.kf = g->kf; a.kh = g->kh; a.kw = g->kw;
     a.df = g->df; a.dh = g->dh; a.dw = g->dw; a.NH = g->heads; a.scale = g->scale; a.bias = g->rel_bias;
+    // causal: every tap at or before the query (np.py:427); symmetric 'same' window otherwise (np.py:429)
+    a.of = g->noncausal ? (g->kf - 1) / 2 : g->kf - 1;
+    a.oh = g->noncausal ? (g->kh - 1) / 2 : g->kh - 1;
+    a.ow = g->noncausal ? (g->kw - 1) / 2 : g->kw - 1;
 }
 int block_threads(const amdnuwa_s3_geom* g) { return ((g->W * g->heads * 4 + 63) / 64) * 64; }
 
@@ -1255,7 +1260,7 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
     } while (0)
     const bool lo_mode = k_lo != nullptr;
     // MFMA forward (tuning key 3: 1 = keep the dot2 kernel): bf16 operands, 16 queries per grid row, 8 heads x 64
-    if (!lo_mode && g_amdnuwa_tuning[3] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 && g->kw <= S3M_KW &&
+    if (!lo_mode && !g->noncausal && g_amdnuwa_tuning[3] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 && g->kw <= S3M_KW &&
         g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && ldo % 4 == 0) {
         a.dbg = g_amdnuwa_tuning[9];
         const size_t lm = (size_t)16 * J * 8 * sizeof(float) + 8 * 4096;
@@ -1316,7 +1321,7 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     const size_t lds_kv = (size_t)g->W * g->heads * g->dim_head * 8;
     dim3 grid((unsigned)rows), block(block_threads(g));
     // MFMA query-side kernel (tuning key 4: 1 = keep the dot2 kernel): bf16 operands, 16 queries per grid row, 8 heads x 64
-    const bool q_mfma = !has_lo && !dO_lo && g_amdnuwa_tuning[4] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 &&
+    const bool q_mfma = !has_lo && !dO_lo && !g->noncausal && g_amdnuwa_tuning[4] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 &&
                         g->kw <= S3M_KW && g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0;
     const size_t lds_qm = (nsp * 4 > 8 * 4096 ? nsp * 4 : 8 * 4096) + nsp * 4 + (8 * 64 + 16 * 8) * 4;
 #define S3B(DH_, LO_)                                                                                             \

@@ -464,6 +464,324 @@ __global__ __launch_bounds__(256, 1) void xattn2_bwd_kernel(X2Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// xattn3: the same two-pass structure as xattn2_fwd / xattn2_bwd with every head mix on the matrix pipe
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void xattn3_fwd_kernel(X2Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t vsh[96];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g4 = lane >> 4;
+    const int tiles = (a.n + 63) / 64;
+    const int b = blockIdx.x / tiles, qi = (blockIdx.x % tiles) * 64 + wave * 16 + c;
+    const bool qok = qi < a.n;
+    if (tid < a.JP / 4) vsh[tid] = reinterpret_cast<const uint32_t*>(a.valid + (size_t)b * a.JP)[tid];
+    __shared__ __attribute__((aligned(16))) float wsh[NH * NH];
+    if (tid < NH * NH) wsh[tid] = a.wth[tid];
+    __syncthreads();                                             // (before any DMA is in flight)
+    const MixA AW = mix_operand(wsh, lane);
+    const float c1 = a.scale * 1.4426950408889634f;
+    bf16x8 qf[NH][KS];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[h][ks] = ldg16(a.q + ((size_t)b * a.n + qi) * a.ldq + h * DH + ks * 32 + g4 * 8, qok);
+
+    // ---- pass 1: running (max, sum of exp) per head over the key chunks; only K is staged (identical to xattn2_fwd)
+    float m[NH], l[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) { m[h] = NEG_MAX; l[h] = 0.f; }
+    stage_chunk<false, false>(smem, 0, 0, b, a.JP, a.Kp, nullptr, wave, lane);
+    for (int ch = 0; ch < a.nch; ++ch) {
+        if (ch + 1 < a.nch) { stage_chunk<false, false>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, nullptr, wave, lane); VMCNT(8); }
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        const char* base = smem + (ch & 1) * STAGE;
+        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            f32x4 s0, s1;
+            qk_chunk(base, h, c, g4, qf[h], s0, s1);
+            float s[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[r] = ((vm0 >> (8 * r)) & 0xff) ? s0[r] * c1 : NEG_MAX;
+                s[4 + r] = ((vm1 >> (8 * r)) & 0xff) ? s1[r] * c1 : NEG_MAX;
+            }
+            const float cm = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+            const float mn = fmaxf(m[h], cm);
+            float acc = l[h] * __builtin_amdgcn_exp2f(m[h] - mn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
+            l[h] = acc; m[h] = mn;
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    float nb[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float m2 = __shfl_xor(m[h], off, 64), l2 = __shfl_xor(l[h], off, 64);
+            const float mn = fmaxf(m[h], m2);
+            l[h] = l[h] * __builtin_amdgcn_exp2f(m[h] - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
+            m[h] = mn;
+        }
+        const float il = 1.f / l[h];
+        nb[h] = __log2f(il) - m[h];
+        if (a.stats && g4 == 0 && qok) *reinterpret_cast<float2*>(a.stats + (((size_t)b * NH + h) * a.n + qi) * 2) = make_float2(m[h], il);
+    }
+
+    // ---- pass 2: P[h] again, head mix on the matrix pipe, O^T[g] += V^T[g] P'^T[g]
+    f32x4 O[NH][DB];
+#pragma unroll
+    for (int g = 0; g < NH; ++g)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) O[g][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage_chunk<true, false>(smem, 0, 0, b, a.JP, a.Kp, a.Vt, wave, lane);
+    for (int ch = 0; ch < a.nch; ++ch) {
+        if (ch + 1 < a.nch) { stage_chunk<true, false>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vt, wave, lane); VMCNT(16); }
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        const char* base = smem + (ch & 1) * STAGE;
+        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
+        bf16x8 bm[8];
+        {
+            float P[NH][8];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                f32x4 s0, s1;
+                qk_chunk(base, h, c, g4, qf[h], s0, s1);
+                probs(s0, s1, vm0, vm1, c1, nb[h], P[h]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bm[e] = pack_heads(P, e);
+        }
+#pragma unroll
+        for (int Q = 0; Q < 2; ++Q) {
+            f32x4 D[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) D[e] = MIX(AW, Q, bm[e]);          // D[e][rp] = P'[4Q + rp] of slot e
+#pragma unroll
+            for (int rp = 0; rp < 4; ++rp) {
+                const int g = 4 * Q + rp;
+                const float pv[8] = {D[0][rp], D[1][rp], D[2][rp], D[3][rp], D[4][rp], D[5][rp], D[6][rp], D[7][rp]};
+                const bf16x8 pf = pack8(pv);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int d = db * 16 + c;
+                    const bf16x8 vf = lds8x2(base + KT_BYTES + dk_off(g, d, g4 >> 1) + (g4 & 1) * 8,
+                                             base + KT_BYTES + dk_off(g, d, 2 + (g4 >> 1)) + (g4 & 1) * 8);
+                    O[g][db] = MFMA(vf, pf, O[g][db]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (qok) {
+#pragma unroll
+        for (int g = 0; g < NH; ++g)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                bf16_t* dst = a.o + ((size_t)b * a.n + qi) * a.ldo + g * DH + db * 16 + g4 * 4;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(O[g][db][0], O[g][db][1]), pack2_rne(O[g][db][2], O[g][db][3]));
+            }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t vsh[96];
+    __shared__ float thsh[4][NH * NH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g4 = lane >> 4;
+    const int tiles = (a.n + 63) / 64;
+    const int b = blockIdx.x / tiles, qi = (blockIdx.x % tiles) * 64 + wave * 16 + c;
+    const bool qok = qi < a.n;
+    if (tid < a.JP / 4) vsh[tid] = reinterpret_cast<const uint32_t*>(a.valid + (size_t)b * a.JP)[tid];
+    __shared__ __attribute__((aligned(16))) float wsh[NH * NH], wtsh[NH * NH];          // W[g][h] and its transpose
+    if (tid < NH * NH) { const float v = a.wth[tid]; wsh[tid] = v; wtsh[(tid & 7) * 8 + (tid >> 3)] = v; }
+    __syncthreads();                                             // (before any DMA is in flight)
+    const MixA AW = mix_operand(wsh, lane), AWT = mix_operand(wtsh, lane);
+    const float c1 = a.scale * 1.4426950408889634f;
+    bf16x8 qf[NH][KS], df[NH][KS];
+    float nb[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[h][ks] = ldg16(a.q + ((size_t)b * a.n + qi) * a.ldq + h * DH + ks * 32 + g4 * 8, qok);
+            df[h][ks] = ldg16(a.dO + ((size_t)b * a.n + qi) * a.lddo + h * DH + ks * 32 + g4 * 8, qok);
+        }
+        const float2 st = qok ? *reinterpret_cast<const float2*>(a.stats + (((size_t)b * NH + h) * a.n + qi) * 2) : make_float2(0.f, 1.f);
+        nb[h] = qok ? __log2f(st.y) - st.x : 0.f;
+    }
+    const size_t prow = (size_t)a.n * a.JP;
+
+    // ---- pass A: P' = W P -> Pm;  dP = W^T dP' (both mixes on the matrix pipe);  delta[h] = sum_j dP[h] P[h];
+    //      dW_th[g][h] += sum dP'[g] P[h] (the one block that stays on the VALU: its contraction runs over lanes)
+    float delta[NH], dth[NH][NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        delta[h] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NH; ++g) dth[g][h] = 0.f;
+    }
+    stage_chunk<true, true>(smem, 0, 0, b, a.JP, a.Kp, a.Vp, wave, lane);
+    for (int ch = 0; ch < a.nch; ++ch) {
+        if (ch + 1 < a.nch) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        const char* base = smem + (ch & 1) * STAGE;
+        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
+        float P[NH][8];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            f32x4 s0, s1;
+            qk_chunk(base, h, c, g4, qf[h], s0, s1);
+            probs(s0, s1, vm0, vm1, c1, nb[h], P[h]);
+        }
+#pragma unroll
+        for (int Q = 0; Q < 2; ++Q) {
+            f32x4 D[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) D[e] = MIX(AW, Q, pack_heads(P, e));
+            if (qok) {
+#pragma unroll
+                for (int rp = 0; rp < 4; ++rp) {
+                    bf16_t* dst = a.Pm + ((size_t)b * NH + 4 * Q + rp) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 4;
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(D[0][rp], D[1][rp]), pack2_rne(D[2][rp], D[3][rp]));
+                    *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pack2_rne(D[4][rp], D[5][rp]), pack2_rne(D[6][rp], D[7][rp]));
+                }
+            }
+        }
+        // dP'^T[g] = V[g] dO[g]^T, two heads at a time: they go straight into the dW_th sums and, packed, into the B operands of
+        // the dP mix (so the full 8 x 8 set never lives in registers)
+        uint32_t bw[8][4];
+#pragma unroll
+        for (int gp = 0; gp < 4; ++gp) {
+            float d0[8], d1[8];
+            {
+                f32x4 s0, s1;
+                qk_chunk(base + KT_BYTES, 2 * gp, c, g4, df[2 * gp], s0, s1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { d0[r] = s0[r]; d0[4 + r] = s1[r]; }
+                qk_chunk(base + KT_BYTES, 2 * gp + 1, c, g4, df[2 * gp + 1], s0, s1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { d1[r] = s0[r]; d1[4 + r] = s1[r]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bw[e][gp] = pack2_rne(d0[e], d1[e]);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float a0 = dth[2 * gp][h], a1 = dth[2 * gp + 1][h];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a0 = fmaf(d0[e], P[h][e], a0); a1 = fmaf(d1[e], P[h][e], a1); }
+                dth[2 * gp][h] = a0; dth[2 * gp + 1][h] = a1;
+            }
+        }
+#pragma unroll
+        for (int Q = 0; Q < 2; ++Q) {
+            f32x4 D[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                D[e] = MIX(AWT, Q, __builtin_bit_cast(bf16x8, make_uint4(bw[e][0], bw[e][1], bw[e][2], bw[e][3])));   // D[e][rp] = dP[4Q + rp]
+#pragma unroll
+            for (int rp = 0; rp < 4; ++rp) {
+                float acc = delta[4 * Q + rp];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf(D[e][rp], P[4 * Q + rp][e], acc);
+                delta[4 * Q + rp] = acc;
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    // a query's keys are spread over the 4 lane groups
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        delta[h] += __shfl_xor(delta[h], 16, 64);
+        delta[h] += __shfl_xor(delta[h], 32, 64);
+    }
+    // dW_th partial of this workgroup (fixed order over the 4 waves)
+#pragma unroll
+    for (int g = 0; g < NH; ++g)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float s = wave_sum(qok ? dth[g][h] : 0.f);
+            if (lane == 0) thsh[wave][g * NH + h] = s;
+        }
+    __syncthreads();
+    if (tid < NH * NH) a.part_th[(size_t)blockIdx.x * NH * NH + tid] = ((thsh[0][tid] + thsh[1][tid]) + thsh[2][tid]) + thsh[3][tid];
+
+    // ---- pass B: ds[h] = P[h] (dP[h] - delta[h]) -> dS;  dq^T[h] += K^T[h] ds^T[h]
+    f32x4 dQ[NH][DB];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) dQ[h][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage_chunk<true, true>(smem, 0, 0, b, a.JP, a.Kp, a.Vp, wave, lane);
+    for (int ch = 0; ch < a.nch; ++ch) {
+        if (ch + 1 < a.nch) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        const char* base = smem + (ch & 1) * STAGE;
+        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
+        bf16x8 bmD[8];
+        {
+            uint32_t bw[8][4];
+#pragma unroll
+            for (int gp = 0; gp < 4; ++gp) {
+                f32x4 s0, s1, t0, t1;
+                qk_chunk(base + KT_BYTES, 2 * gp, c, g4, df[2 * gp], s0, s1);
+                qk_chunk(base + KT_BYTES, 2 * gp + 1, c, g4, df[2 * gp + 1], t0, t1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { bw[r][gp] = pack2_rne(s0[r], t0[r]); bw[4 + r][gp] = pack2_rne(s1[r], t1[r]); }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bmD[e] = __builtin_bit_cast(bf16x8, make_uint4(bw[e][0], bw[e][1], bw[e][2], bw[e][3]));
+        }
+#pragma unroll
+        for (int Q = 0; Q < 2; ++Q) {
+            f32x4 D[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) D[e] = MIX(AWT, Q, bmD[e]);
+#pragma unroll
+            for (int rp = 0; rp < 4; ++rp) {
+                const int h = 4 * Q + rp;
+                f32x4 s0, s1;
+                float P[8], ds[8];
+                qk_chunk(base, h, c, g4, qf[h], s0, s1);
+                probs(s0, s1, vm0, vm1, c1, nb[h], P);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ds[e] = P[e] * (D[e][rp] - delta[h]);
+                const uint2 lo = make_uint2(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]));
+                const uint2 hi = make_uint2(pack2_rne(ds[4], ds[5]), pack2_rne(ds[6], ds[7]));
+                if (qok) {
+                    bf16_t* dst = a.dS + ((size_t)b * NH + h) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 4;
+                    *reinterpret_cast<uint2*>(dst) = lo;
+                    *reinterpret_cast<uint2*>(dst + 16) = hi;
+                }
+                const bf16x8 sf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+                for (int db = 0; db < DB; ++db) dQ[h][db] = MFMA(lds_tr(base, h, db, c, g4), sf, dQ[h][db]);
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (qok) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                bf16_t* dst = a.dq + ((size_t)b * a.n + qi) * a.lddq + h * DH + db * 16 + g4 * 4;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(dQ[h][db][0] * a.scale, dQ[h][db][1] * a.scale),
+                                                            pack2_rne(dQ[h][db][2] * a.scale, dQ[h][db][3] * a.scale));
+            }
+    }
+}
+
 int check2(const amdnuwa_xattn_geom* g) {
     if (!g) return AMDNUWA_ERR_ARG;
     if (g->heads != NH || g->dim_head != DH || g->JP % 32 || g->JP > 288 || g->JP < g->T + 1) return AMDNUWA_ERR_UNSUPPORTED;
@@ -485,8 +803,10 @@ extern "C" int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.o = o; a.ldo = ldo; a.stats = stats;
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
     const int tiles = (g->n + 63) / 64;
-    (void)hipFuncSetAttribute((const void*)xattn2_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-    hipLaunchKernelGGL(xattn2_fwd_kernel, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
+    // tuning key 10: 1 = the VALU head mix (xattn2_fwd_kernel), 0 = the head mix on the matrix pipe (xattn3_fwd_kernel)
+    auto kern = g_amdnuwa_tuning[10] == 1 ? xattn2_fwd_kernel : xattn3_fwd_kernel;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    hipLaunchKernelGGL(kern, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
@@ -510,8 +830,9 @@ extern "C" int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.stats = const_cast<float*>(stats); a.dS = dS; a.Pm = Pm; a.dq = dq; a.lddq = lddq; a.part_th = part_th;
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
     const int tiles = (g->n + 63) / 64;
-    (void)hipFuncSetAttribute((const void*)xattn2_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-    hipLaunchKernelGGL(xattn2_bwd_kernel, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
+    auto kern = g_amdnuwa_tuning[10] == 1 ? xattn2_bwd_kernel : xattn3_bwd_kernel;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    hipLaunchKernelGGL(kern, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

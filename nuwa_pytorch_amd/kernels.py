@@ -387,6 +387,34 @@ def ce_fwd(logits, targets, grad_scale, want_grad=True):
     return loss, dl
 
 
+def linear_ce(h, w, targets, grad_scale, want_grad=True):
+    """fused to_logits + cross entropy on hi-only BF operands: h [R, K], w [C, K] -> (mean loss, dlogits BF [R, C] or BF(None, None)).
+    The fp32 logits are never written; returns None when the shape is outside what the fused kernels take (C % 64, K % 32)."""
+    L = _lib.lib()
+    if h.lo is not None or w.lo is not None:
+        return None
+    R, Kd = h.hi.shape
+    Cc = w.hi.shape[0]
+    nb = L.amdnuwa_linear_ce_workspace_bytes(R, Cc)
+    if nb == 0 or Kd % 32 or _ld(h.hi) % 8 or _ld(w.hi) % 8:
+        return None
+    dev = h.hi.device
+    ws = workspace(nb, dev)
+    row_loss = torch.empty(R, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dl = empty_bf((R, Cc), dev, lo=False) if want_grad else BF(None, None)
+    st = _stream()
+    if _TIMER['on']:                       # two products: both count as NT GEMM work of the step
+        _TIMER['flops'] += 2.0 * R * Cc * Kd * (2 if want_grad else 1)
+        _TIMER['bytes'] += (2.0 * (R + Cc) * Kd) * (2 if want_grad else 1) + (2.0 * R * Cc if want_grad else 0.) + 8.0 * R * (Cc // 64)
+        L.amdnuwa_timer_begin(st)
+    check(L.amdnuwa_linear_ce(_p(h.hi), _ld(h.hi), _p(w.hi), _ld(w.hi), _p(targets), R, Cc, Kd, float(grad_scale), _p(row_loss), _p(loss),
+                              _p(dl.hi), Cc, _p(ws), nb, st), 'amdnuwa_linear_ce')
+    if _TIMER['on']:
+        L.amdnuwa_timer_end(st)
+    return loss, dl
+
+
 def scale_by_device_scalar(x, scalar):
     check(_lib.lib().amdnuwa_scale_by_device_scalar(_p(x), x.numel(), _p(scalar), _stream()), 'amdnuwa_scale_by_device_scalar')
 
@@ -395,8 +423,9 @@ def scale_by_device_scalar(x, scalar):
 # attention cores
 # ------------------------------------------------------------------------------------------------
 
-def s3_geom(B, ntok, video_shape, kernel, dilation, heads, dim_head):
+def s3_geom(B, ntok, video_shape, kernel, dilation, heads, dim_head, causal=True):
     g = S3Geom()
+    g.noncausal = 0 if causal else 1
     g.B, g.ntok = B, ntok
     g.F, g.H, g.W = video_shape
     g.kf, g.kh, g.kw = kernel

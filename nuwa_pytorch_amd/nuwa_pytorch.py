@@ -168,7 +168,7 @@ class SandwichNorm(nn.Module):
             if fn.shift_space:
                 shift = fn.image_size
             fn = fn.fn
-        if (isinstance(fn, FeedForward) and not fn._dropout_active()) or (isinstance(fn, Sparse3DNA) and fn.causal):
+        if (isinstance(fn, FeedForward) and not fn._dropout_active()) or (isinstance(fn, Sparse3DNA) and fn._hip_ok()):
             return fn, shift
         if isinstance(fn, Attention) and context is not None and fn._hip_ok(context.shape[1]):
             return fn, shift
@@ -392,9 +392,10 @@ class Attention(nn.Module):
 
 
 class Sparse3DNA(nn.Module):
-    """np.py:381-613, causal.  forward = qkv GEMM -> fused gfx950 3DNA kernel (no unfold
-    materialisation) -> to_out GEMM.  `query_num_frames_chunk` only bounds the reference's unfolded
-    tensors; it is accepted and ignored (chunked == unchunked bit for bit in the reference)."""
+    """np.py:381-613.  forward = qkv GEMM -> fused gfx950 3DNA kernel (no unfold materialisation) -> to_out GEMM, for the causal
+    window of the video decoder AND the symmetric window of NUWASketch's sketch encoder (causal=False, np.py:429: the same kernels
+    with the tap origin in the middle of the window).  `query_num_frames_chunk` only bounds the reference's unfolded tensors; it is
+    accepted and ignored (chunked == unchunked bit for bit in the reference)."""
 
     def __init__(self, dim, video_shape, kernel_size=3, dilation=1, heads=8, dim_head=64, dropout=0., causal=False,
                  query_num_frames_chunk=None, rel_pos_bias=False):
@@ -423,7 +424,8 @@ class Sparse3DNA(nn.Module):
         if causal:
             self.register_buffer('mask', causal_neighbor_mask(video_shape, self.kernel_size, self.dilation))
         else:
-            # NUWASketch's sketch encoder (sketch_enc_use_sparse_3dna=True): symmetric window, PyTorch-ROCm ops (row f4)
+            # NUWASketch's sketch encoder (sketch_enc_use_sparse_3dna=True): symmetric window (row f4); the neighbour table is
+            # only used by the PyTorch-op formulation kept for geometries the kernels do not take
             nbr = neighbor_positions(video_shape, self.kernel_size, self.dilation, causal=False)
             self.register_buffer('mask', F.pad(nbr < 0, (1, 0), value=False))
             self.register_buffer('_nbr', nbr, persistent=False)
@@ -440,12 +442,20 @@ class Sparse3DNA(nn.Module):
         if self.training and self.dropout.p > 0:
             raise NotImplementedError('dropout inside Sparse3DNA is not supported (never enabled by Transformer, quirk Q14)')
         assert n - 1 <= self.max_num_tokens, 'sequence longer than the video shape allows'
-        g = K.s3_geom(B, n, self.video_shape, self.kernel_size, self.dilation, self.heads, self.dim_head)
+        g = K.s3_geom(B, n, self.video_shape, self.kernel_size, self.dilation, self.heads, self.dim_head, causal=self.causal)
         return dict(kind='s3', cache=self._cache, geom=g)
+
+    def _hip_ok(self):
+        """geometry the 3DNA kernels take.  The causal decoder path never falls back (an unsupported shape raises from the library);
+        the symmetric variant keeps its PyTorch-op formulation for head sizes / widths outside the kernels"""
+        if self.causal:
+            return True
+        return self.dim_head in (32, 64) and self.heads <= 8 and self.video_shape[2] * self.heads * 4 <= 512 and \
+            not (self.training and self.dropout.p > 0)
 
     def forward(self, x, **kwargs):
         B, n, _ = x.shape
-        if not self.causal:
+        if not self.causal and not (x.is_cuda and self._hip_ok()):
             return self._forward_noncausal(x)
         return ops.InnerFn.apply(x, None, self._meta(B, n, x.device), *self._params())
 

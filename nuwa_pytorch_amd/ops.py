@@ -263,6 +263,7 @@ class FFInner:
 
 INNERS = {'s3': S3Inner, 'xattn': XInner, 'ff': FFInner}
 
+FUSE_LINEAR_CE = os.environ.get('AMDNUWA_FUSE_LINEAR_CE', '1') != '0'   # to_logits + cross entropy without the fp32 logits (A/B switch)
 FUSE_GEGLU_BWD = os.environ.get('AMDNUWA_FUSE_GEGLU_BWD', '1') != '0'   # gate backward inside the dgg GEMM epilogue (A/B switch)
 CHAIN_BWD = os.environ.get('AMDNUWA_CHAIN_BWD', '1') != '0'      # chain the LayerNorm backwards across block boundaries (A/B switch)
 class WgradStream:
@@ -519,13 +520,18 @@ class LogitsLossFn(Function):
         x2 = x.detach().contiguous().reshape(B * n, D)
         W = cache.get('logits', (wl,), lambda: dict(w=_cast(wl), wT=_cast_t(wl)))
         hn, m, r, ia = K.ln_fwd(x2, nw.detach(), nb.detach(), stable=True)
-        logits = K.gemm_nt(hn, W['w'])
         if targets.dtype != torch.int64:
             raise TypeError(f'cross-entropy targets must be int64 token ids, got {targets.dtype}')
         if targets.numel() != B * n:
             raise ValueError(f'{targets.numel()} targets for {B * n} logit rows')
         t = targets.contiguous().reshape(-1)            # ids outside [0, C) give a NaN loss (the kernel never reads out of bounds)
-        loss, dl = K.ce_fwd(logits, t, 1.0 / (B * n), want_grad=any(ctx.needs_input_grad))
+        want_grad = any(ctx.needs_input_grad)
+        fused = K.linear_ce(hn, W['w'], t, 1.0 / (B * n), want_grad=want_grad) if FUSE_LINEAR_CE else None
+        if fused is not None:                           # fast mode: logits produced twice inside the GEMM, never written (np.py:1958-1963)
+            loss, dl = fused
+        else:
+            logits = K.gemm_nt(hn, W['w'])
+            loss, dl = K.ce_fwd(logits, t, 1.0 / (B * n), want_grad=want_grad)
         ctx.save_for_backward(x2, m, r, ia, nw, wl)
         ctx.hn, ctx.dl, ctx.W, ctx.shape = hn, dl, W, (B, n, D)
         return loss

@@ -617,3 +617,34 @@ def test_sparse3dna_fullsize_causality_and_determinism(K):
     assert torch.equal(o1[:cut], o3[:cut])
     assert not torch.equal(o1[cut:], o3[cut:])
     assert bool(torch.isfinite(o1.float()).all()) and bool(torch.isfinite(d1.hi.float()).all())
+
+
+@pytest.mark.parametrize('R,C,Kd', [(1000, 8192, 512), (2560, 512, 256), (300, 192, 64)])
+def test_fused_linear_cross_entropy(R, C, Kd):
+    """to_logits + cross entropy without the fp32 logits (np.py:1958-1963): loss, dlogits against torch on the same bf16 operands,
+    against the unfused libamdnuwa pair (gemm_nt + ce_fwd), a ragged last row tile, and the NaN flag for an id outside the vocabulary"""
+    from nuwa_pytorch_amd import kernels as K
+    g = torch.Generator().manual_seed(R + C)
+    h = (torch.randn(R, Kd, generator=g) * 0.8).to(torch.bfloat16)
+    w = (torch.randn(C, Kd, generator=g) * (3.0 / Kd ** 0.5)).to(torch.bfloat16)
+    t = torch.randint(0, C, (R,), generator=g)
+    t[0], t[1], t[-1] = 0, C - 1, C - 1
+    logits = h.float() @ w.float().t()
+    ref_loss = torch.nn.functional.cross_entropy(logits, t)
+    ref_dl = (logits.softmax(-1) - torch.nn.functional.one_hot(t, C).float()) / R
+    hb, wb = K.BF(h.to(DEV), None), K.BF(w.to(DEV), None)
+    out = K.linear_ce(hb, wb, t.to(DEV), 1.0 / R)
+    assert out is not None
+    loss, dl = out
+    report(f'linear_ce[{R},{C}].loss', loss.reshape(1), ref_loss.reshape(1), 2e-6)
+    report(f'linear_ce[{R},{C}].dlogits', dl.hi.float(), ref_dl, 2 ** -8)
+    lg = K.gemm_nt(hb, wb)
+    loss_u, dl_u = K.ce_fwd(lg, t.to(DEV), 1.0 / R)
+    report(f'linear_ce[{R},{C}].loss_vs_unfused', loss.reshape(1), loss_u.reshape(1), 2e-6)
+    report(f'linear_ce[{R},{C}].dlogits_vs_unfused', dl.hi.float(), dl_u.hi.float(), 2 ** -7)
+    loss_only, none = K.linear_ce(hb, wb, t.to(DEV), 1.0 / R, want_grad=False)
+    assert none.hi is None and torch.equal(loss_only, loss)
+    bad = t.clone()
+    bad[5] = C
+    assert torch.isnan(K.linear_ce(hb, wb, bad.to(DEV), 1.0 / R, want_grad=False)[0])
+    assert K.linear_ce(K.BF(h.to(DEV), h.to(DEV)), wb, t.to(DEV), 1.0 / R) is None          # parity-mode operands: unfused path

@@ -522,3 +522,38 @@ def test_reversible_dual_decoder_recomputing_backward(A):
     report('dual_rev.daudio', dae, das, 2e-3)
     report('dual_rev.dcontext', dce, dcs, 2e-3)
     assert pe < 0.6 * ps, (pe, ps)
+
+
+NC_CASES = [((3, 4, 4), 3, 1, 49, 2, 32, False), ((3, 4, 4), 3, 2, 30, 2, 32, True), ((2, 8, 8), (3, 5, 3), 1, 129, 4, 32, False),
+            ((2, 16, 16), 3, (1, 2, 2), 400, 8, 64, False), ((4, 16, 16), (5, 3, 3), 2, 1025, 8, 64, True), ((2, 4, 4), 3, 1, 2, 2, 32, False)]
+
+
+@pytest.mark.parametrize('mode,tol,gtol', MODES)
+@pytest.mark.parametrize('shape,kernel,dil,n,heads,dh,rel', NC_CASES)
+def test_noncausal_sparse3dna_hip_vs_oracle(A, O_mod, shape, kernel, dil, n, heads, dh, rel, mode, tol, gtol):
+    """row f4: the symmetric-window Sparse3DNA of NUWASketch's sketch encoder (causal=False, np.py:429) on the libamdnuwa 3DNA
+    kernels, forward + backward against the oracle (itself pinned on the reference in test_sketch_vs_reference.py): whole and partial
+    sequences (zero-padded rows ARE attended, score 0), dilation, rel-pos bias, mixed kernel shapes, n = 2"""
+    torch.manual_seed(0)
+    dim = 64
+    m = A.Sparse3DNA(dim=dim, video_shape=shape, kernel_size=kernel, dilation=dil, heads=heads, dim_head=dh, causal=False, rel_pos_bias=rel)
+    assert m._hip_ok()
+    P = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(n)
+    x, dy = torch.randn(2, n, dim, generator=g), torch.randn(2, n, dim, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = O_mod.sparse3dna(xr, P, shape, kernel, dil, heads, causal=False)
+    yr.backward(dy)
+    m = m.to(DEV)
+    run_mode(A, mode)
+    try:
+        xd = x.to(DEV).requires_grad_(True)
+        y = m(xd)
+        tag = f'nc3dna[{shape},{kernel},{dil},{n},{mode}]'
+        report(tag + '.y', y, yr.detach(), tol)
+        y.backward(dy.to(DEV))
+        report(tag + '.dx', xd.grad, xr.grad, gtol)
+        for k, gr in _grads_of(m).items():
+            report(tag + f'.grad.{k}', gr, P[k].grad, gtol)
+    finally:
+        A.set_precision('bf16')

@@ -21,3 +21,20 @@ u = K.BF(torch.randn(R, 2 * FP, device=dev).to(torch.bfloat16), None)
 dg = K.BF(torch.randn(R, FP, device=dev).to(torch.bfloat16), None)
 t = bench(lambda: K.geglu_fwd(u, FP), 20); rep('geglu_fwd', t, R * FP * 6)
 t = bench(lambda: K.geglu_bwd(u, dg, FP), 20); rep('geglu_bwd', t, R * FP * 10)
+# chained LayerNorm backward (pre-norm of block k+1 + post-norm of block k): non-temporal variants (tuning 11) and blocks per CU (12)
+from nuwa_pytorch_amd import _lib  # noqa: E402
+L = _lib.lib()
+dhb = K.BF(torch.randn(R, D, device=dev).to(torch.bfloat16), None)
+ypb = K.BF(torch.randn(R, D, device=dev).to(torch.bfloat16), None)
+m2, r2 = torch.randn(R, device=dev), torch.rand(R, device=dev) + 0.5
+ref = None
+for nt in (0, 1, 2, 3):
+    for cap in (0, 2, 1):
+        L.amdnuwa_set_tuning(11, nt); L.amdnuwa_set_tuning(12, cap)
+        f = lambda: K.ln_bwd_chain(dhb, x, m, r, w, g, ypb, m2, r2, bb, shift=(n, 16), want_dsum=True)
+        out = f()
+        if ref is None:
+            ref = out
+        same = all(torch.equal(a.hi if isinstance(a, K.BF) else a, b_.hi if isinstance(b_, K.BF) else b_) for a, b_ in zip(out, ref))
+        t = bench(f, 20); rep(f'ln_bwd_chain nt={nt} blocks/CU cap={cap}{"" if same else " MISMATCH"}', t, R * D * 18)
+L.amdnuwa_set_tuning(11, 0); L.amdnuwa_set_tuning(12, 0)
