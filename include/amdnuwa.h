@@ -211,6 +211,27 @@ int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* q, const ui
                            float* dw_th, int accumulate, void* workspace, size_t workspace_bytes,
                            amdnuwa_stream stream);
 
+/* SparseCross2DNA (np.py:761-901): NUWASketch's decoder cross-attention.  Queries = the video rows q [B*ntok, ldq] (row 0 of every
+ * sample is <bos>); keys / values = the sketch context k, v [B*ctx_rows, ldkv], ctx_rows = g->kf * H * W (g->kf = sketch frames).
+ * Query (f, y, x) attends to the learned null key / value (key slot 0; null_k / null_v: bf16 [heads*dim_head]) and, in EVERY context
+ * frame a, to the g->kh x g->kw neighbourhood of (y, x) with dilation (g->dh, g->dw) and 'same' zero padding -- slot
+ * 1 + (a*kh + b)*kw + c; key_mask [B][ctx_rows] (1 = visible, NULL = all) masks slots; fp32 softmax; talking heads w_th [heads][heads].
+ * g->df, g->noncausal and g->rel_bias are ignored (rel_bias must be NULL).  Row 0 of every sample (the <bos> query attends to ALL
+ * context tokens, without talking heads: np.py:813-830) is NOT read or written here: the caller owns o / dq rows b*ntok.
+ * Backward: dq rows 1.., dk / dv [B*ctx_rows, lddkv], d_null_k / d_null_v fp32 [heads*dim_head], dw_th fp32 [heads*heads]. */
+int amdnuwa_cross2dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq, int ctx_rows,
+                          const uint16_t* k, const uint16_t* v, const uint16_t* k_lo, const uint16_t* v_lo, int ldkv,
+                          const uint16_t* null_k, const uint16_t* null_k_lo, const uint16_t* null_v, const uint16_t* null_v_lo,
+                          const uint8_t* key_mask, const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, amdnuwa_stream stream);
+size_t amdnuwa_cross2dna_bwd_workspace_bytes(const amdnuwa_s3_geom* g);
+int amdnuwa_cross2dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq, int ctx_rows,
+                          const uint16_t* k, const uint16_t* v, const uint16_t* k_lo, const uint16_t* v_lo, int ldkv,
+                          const uint16_t* null_k, const uint16_t* null_k_lo, const uint16_t* null_v, const uint16_t* null_v_lo,
+                          const uint8_t* key_mask, const float* w_th, const uint16_t* dO, const uint16_t* dO_lo, int lddo,
+                          uint16_t* dq, uint16_t* dq_lo, int lddq, uint16_t* dk, uint16_t* dv, uint16_t* dk_lo, uint16_t* dv_lo,
+                          int lddkv, float* d_null_k, float* d_null_v, float* dw_th, void* workspace, size_t workspace_bytes,
+                          amdnuwa_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * Incremental decoding for NUWA.generate (np.py:1841-1915).  The reference recomputes the whole prefix for every sampled
  * token; every decoder stage is causal, so row `pos` only needs cached rows < pos.  `pos` (row index inside each sample,

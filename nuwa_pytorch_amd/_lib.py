@@ -85,6 +85,9 @@ SIGNATURES = {
     'amdnuwa_sparse3dna_fwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P]),
     'amdnuwa_sparse3dna_bwd_workspace_bytes': (SZ, [SG]),
     'amdnuwa_sparse3dna_bwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P, P, P, P, P, P, I, P, I, P, SZ, P]),
+    'amdnuwa_cross2dna_fwd': (I, [SG, P, P, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P, I, P]),
+    'amdnuwa_cross2dna_bwd_workspace_bytes': (SZ, [SG]),
+    'amdnuwa_cross2dna_bwd': (I, [SG, P, P, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P, I, P, P, I, P, P, P, P, I, P, P, P, P, SZ, P]),
     'amdnuwa_decode_shift': (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
     'amdnuwa_decode_ln': (I, [P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P]),
     'amdnuwa_s3_decode': (I, [SG, P, P, P, P, I, P, P, P, P, P]),

@@ -36,6 +36,13 @@ struct S3Args {
     float* dwth;                                          // [NH*NH] accumulated
     int B, ntok, F, H, W, kf, kh, kw, df, dh, dw, NH;
     int of, oh, ow;                                       // tap index of the query's own position per axis: k - 1 (causal) / (k - 1) / 2 (symmetric)
+    // key / value side.  Self-attention (Sparse3DNA): the query sequence itself, row 0 = <bos> = key slot 0.  xmode = 1 (SparseCross2DNA,
+    // np.py:761-901): keys / values are a context grid of FK = kf frames, tap a of the frame axis IS context frame a (absolute), slot 0
+    // is a learned null key / value, keys can be masked, and query row 0 (<bos>) is left to the host (it attends to everything).
+    int xmode, FK, kvrows, kvoff, ldk, lddk;              // rows per sample / first grid row / row strides of the k, v (dk, dv) tensors
+    const bf16_t *k0, *k0l, *v0, *v0l; long long k0_bs;   // slot-0 key / value rows [NH*DH] and their per-sample stride (elements)
+    const uint8_t* kmask;                                 // [B][kvrows] (1 = visible) or NULL
+    float *dnull_k, *dnull_v;                             // xmode: gradients of the null key / value [NH*DH] (fp32)
     float scale;
     int accumulate;
     int dbg;                                              // probe only (tuning key 9): bit 0 / 1 / 2 skip phase 1 / 2 / 3 of the MFMA forward
@@ -146,7 +153,7 @@ __device__ __forceinline__ void sweep_taps(const S3Args& a, const bf16_t* src, c
     const int yr0 = y - a.oh * a.dh;
     uint4 rh[CH / 8], rl[CH / 8];
     auto seek = [&](PlaneIt& p) {                        // advance to a valid plane (or ta == kf)
-        while (p.ta < a.kf && !(p.fr >= 0 && p.yr >= 0 && p.fr < a.F && p.yr < a.H)) {
+        while (p.ta < a.kf && !(p.fr >= 0 && p.yr >= 0 && p.fr < a.FK && p.yr < a.H)) {
             ++p.tb; p.yr += a.dh;
             if (p.tb == a.kh) { p.tb = 0; p.yr = yr0; ++p.ta; p.fr += a.df; }
         }
@@ -158,15 +165,15 @@ __device__ __forceinline__ void sweep_taps(const S3Args& a, const bf16_t* src, c
     };
     auto fetch = [&](const PlaneIt& p) {
         const int pos = (p.fr * a.H + p.yr) * a.W + w;
-        const bool ok = act && (1 + pos) < a.ntok;
-        const size_t gi = ((size_t)b * a.ntok + 1 + pos) * a.ld + h * (CH * 4) + c * CH;
+        const bool ok = act && (a.kvoff + pos) < a.kvrows;
+        const size_t gi = ((size_t)b * a.kvrows + a.kvoff + pos) * a.ldk + h * (CH * 4) + c * CH;
 #pragma unroll
         for (int v8 = 0; v8 < CH / 8; ++v8) {
             rh[v8] = ok ? *reinterpret_cast<const uint4*>(src + gi + v8 * 8) : make_uint4(0, 0, 0, 0);
             if (srcl) rl[v8] = ok ? *reinterpret_cast<const uint4*>(srcl + gi + v8 * 8) : make_uint4(0, 0, 0, 0);
         }
     };
-    PlaneIt cur{0, 0, f - a.of * a.df, yr0};
+    PlaneIt cur{0, 0, (a.xmode ? 0 : f) - a.of * a.df, yr0};
     seek(cur);
     if (cur.ta < a.kf) fetch(cur);
     while (cur.ta < a.kf) {
@@ -185,8 +192,10 @@ __device__ __forceinline__ void sweep_taps(const S3Args& a, const bf16_t* src, c
         if (qvalid) {
             const int jb = 1 + (cur.ta * a.kh + cur.tb) * a.kw;
             int wr = w - a.ow * a.dw;
+            const uint8_t* mrow = a.kmask ? a.kmask + (size_t)b * a.kvrows + a.kvoff + (cur.fr * a.H + cur.yr) * a.W : nullptr;
             for (int tc = 0; tc < a.kw; ++tc, wr += a.dw) {
                 if (wr < 0 || wr >= a.W) continue;
+                if (mrow && !mrow[wr]) continue;          // masked key: its slot keeps the mask value (P = 0) in every sweep
                 const int slot = ((wr * a.NH + h) * 4 + c) * 8;
                 fn(jb + tc, st_hi + slot, srcl ? st_lo + slot : nullptr, HS);
             }
@@ -219,8 +228,8 @@ __device__ __forceinline__ void scores_softmax(const S3Args& a, int b, int f, in
         return quad_sum(s);
     };
     if (qvalid) {
-        const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
-        const float s = qk(a.k + g, a.kl ? a.kl + g : nullptr, 8);
+        const size_t g = (size_t)b * a.k0_bs + h * DH + c * CH;
+        const float s = qk(a.k0 + g, a.k0l ? a.k0l + g : nullptr, 8);
         if (c == 0) SP[(w * J + 0) * a.NH + h] = s * a.scale + (a.bias ? a.bias[h] : 0.f);
     }
     sweep_taps<CH>(a, a.k, a.kl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* khi, const bf16_t* klo, int hs) {
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(512, 4) void s3_fwd_kernel(S3Args a) {
     const bool qvalid = act && i < a.ntok;
     if (t < a.NH * a.NH) wsh[t] = a.wth[t];
     // <bos> output row = its own value (np.py:499, 608)
-    if (ry == 0) {
+    if (ry == 0 && !a.xmode) {
         const int inner = a.NH * DH;
         for (int e = t; e < inner; e += blockDim.x) {
             const size_t gi = ((size_t)b * a.ntok) * a.ld + e, go = ((size_t)b * a.ntok) * a.ldo + e;
@@ -312,8 +321,8 @@ __global__ __launch_bounds__(512, 4) void s3_fwd_kernel(S3Args a) {
         }
     };
     if (qvalid) {
-        const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
-        pv(SP[(w * J + 0) * a.NH + h], a.v + g, a.vl ? a.vl + g : nullptr, 8);
+        const size_t g = (size_t)b * a.k0_bs + h * DH + c * CH;
+        pv(SP[(w * J + 0) * a.NH + h], a.v0 + g, a.v0l ? a.v0l + g : nullptr, 8);
     }
     sweep_taps<CH>(a, a.v, a.vl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* vhi, const bf16_t* vlo, int hs) {
         pv(SP[(w * J + j) * a.NH + h], vhi, vlo, hs);
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_kernel(S3Args a) {
     float* pth = a.part_th + (size_t)bid * a.NH * a.NH;
     float* pk0 = a.part_k0 + (size_t)bid * inner;
     float* pv0 = a.part_v0 + (size_t)bid * inner;
-    if (ry == 0) {   // dq of the <bos> row is zero (its query is never used)
+    if (ry == 0 && !a.xmode) {   // dq of the <bos> row is zero (its query is never used)
         for (int e = t; e < inner; e += blockDim.x) {
             const size_t go = ((size_t)b * a.ntok) * a.ldd + e;
             a.dq[go] = 0;
@@ -414,8 +423,8 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_kernel(S3Args a) {
         return quad_sum(s);
     };
     if (qvalid) {
-        const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
-        const float s = dov(a.v + g, a.vl ? a.vl + g : nullptr, 8);
+        const size_t g = (size_t)b * a.k0_bs + h * DH + c * CH;
+        const float s = dov(a.v0 + g, a.v0l ? a.v0l + g : nullptr, 8);
         if (c == 0) DP[(w * J + 0) * a.NH + h] = s;
     }
     sweep_taps<CH>(a, a.v, a.vl, b, f, y, w, h, c, act, qvalid, st_hi, [&](int j, const bf16_t* vhi, const bf16_t* vlo, int hs) {
@@ -477,8 +486,8 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_kernel(S3Args a) {
     for (int e = 0; e < CH; ++e) { k0c[e] = 0.f; v0c[e] = 0.f; }
     if (qvalid) {
         float kf_[CH];
-        const size_t g = ((size_t)b * a.ntok) * a.ld + h * DH + c * CH;
-        load_chunk<CH>(a.k + g, a.kl ? a.kl + g : nullptr, kf_);
+        const size_t g = (size_t)b * a.k0_bs + h * DH + c * CH;
+        load_chunk<CH>(a.k0 + g, a.k0l ? a.k0l + g : nullptr, kf_);
         const float d0 = DP[(w * J + 0) * a.NH + h];
         float pm0 = 0.f;                                        // P'[w][0][g = h] = sum_hh Wth[h][hh] P[w][0][hh]
         for (int hh = 0; hh < a.NH; ++hh) pm0 += wsh[h * a.NH + hh] * SP[(w * J + 0) * a.NH + hh];
@@ -541,24 +550,26 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
     bf16_t* sd_lo = sd_hi + stage_elems;
     const int t = threadIdx.x, c = t & 3, wh = t >> 2, h = wh % a.NH, w = wh / a.NH;
     const bool act = w < a.W;
-    const int rows = a.F * a.H;
+    const int rows = a.FK * a.H;                     // key rows of the grid (the launch covers B * FK * H workgroups)
     const int bid = xcd_row_id();
     const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
-    const int ik = 1 + ry * a.W + w;                 // key row index inside the sample
-    const bool kvalid = act && ik < a.ntok;
+    const int ik = a.kvoff + ry * a.W + w;           // key row index inside the sample
+    const bool kvalid = act && ik < a.kvrows;
     const int nq = a.ntok - 1;
-    if (ry * a.W + 1 >= a.ntok) return;
+    if (ry * a.W + a.kvoff >= a.kvrows) return;
     float dkf[CH], dvf[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) { dkf[e] = 0.f; dvf[e] = 0.f; }
     // planes t = ta*kh + tb; the attending query row of plane t is (f + (of-ta)df, y + (oh-tb)dh)  [of = kf-1 when causal]
-    const int nplanes = a.kf * a.kh;
+    // (xmode: key frame f is tap f of EVERY query frame, so the sweep runs over the query frames instead of the frame taps)
+    const int nplanes = (a.xmode ? a.F : a.kf) * a.kh;
     auto plane = [&](int t, int& fq, int& yq) {
         const int ta = t / a.kh, tb = t - ta * a.kh;
-        fq = f + (a.of - ta) * a.df;
+        fq = a.xmode ? ta : f + (a.of - ta) * a.df;
         yq = y + (a.oh - tb) * a.dh;
         return fq >= 0 && yq >= 0 && fq < a.F && yq < a.H && (fq * a.H + yq) * a.W + 1 < a.ntok;
     };
+    auto slot_plane = [&](int t) { return a.xmode ? f * a.kh + (t % a.kh) : t; };      // tap-plane index inside the J slots
     auto next_plane = [&](int t) { int fq, yq; while (t < nplanes && !plane(t, fq, yq)) ++t; return t; };
     uint4 rq[CH / 8], rd[CH / 8], rql[CH / 8], rdl[CH / 8];
     constexpr int KWMAX = 3;                        // taps prefetched one plane ahead; wider kernels load the rest directly
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
             const int wq = w + (a.ow - tc) * a.dw;
             const int pqn = (fq * a.H + yq) * a.W + wq;
             if (tc < a.kw && kvalid && wq >= 0 && wq < a.W && 1 + pqn < a.ntok) {
-                const size_t ci = (((size_t)b * nq + pqn) * J + 1 + t * a.kw + tc) * a.NH + h;
+                const size_t ci = (((size_t)b * nq + pqn) * J + 1 + slot_plane(t) * a.kw + tc) * a.NH + h;
                 nds[tc] = a.ds[ci]; npm[tc] = a.pm[ci];
             }
         }
@@ -620,7 +631,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
                 float dsv, pmv;
                 if (tc < KWMAX) { dsv = tc == 0 ? cds[0] : (tc == 1 ? cds[1] : cds[2]); pmv = tc == 0 ? cpm[0] : (tc == 1 ? cpm[1] : cpm[2]); }
                 else {
-                    const size_t ci = (((size_t)b * nq + pq) * J + 1 + tp * a.kw + tc) * a.NH + h;
+                    const size_t ci = (((size_t)b * nq + pq) * J + 1 + slot_plane(tp) * a.kw + tc) * a.NH + h;
                     dsv = a.ds[ci]; pmv = a.pm[ci];
                 }
                 const int slot = ((wq * a.NH + h) * 4 + c) * 8;
@@ -644,7 +655,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_kv_kernel(S3Args a) {
     if (kvalid) {
 #pragma unroll
         for (int e = 0; e < CH; ++e) dkf[e] *= a.scale;
-        const size_t g = ((size_t)b * a.ntok + ik) * a.ldd + h * DH + c * CH;
+        const size_t g = ((size_t)b * a.kvrows + ik) * a.lddk + h * DH + c * CH;
         store_chunk<CH>(a.dk + g, a.dkl ? a.dkl + g : nullptr, dkf);
         store_chunk<CH>(a.dv + g, a.dvl ? a.dvl + g : nullptr, dvf);
     }
@@ -674,6 +685,29 @@ __global__ __launch_bounds__(1024) void s3_bwd_fin_kernel(S3Args a, int DH) {
 #pragma unroll
             for (int r = 0; r < 64; ++r) t += redw[r][threadIdx.x & 15];
             a.dwth[col] = a.accumulate ? a.dwth[col] + t : t;
+        }
+        return;
+    }
+    if (a.xmode) {
+        // SparseCross2DNA: slot 0 is ONE learned null key / value for every sample -> sum the partials of all B * rows workgroups
+        // (blocks 0 .. nchunk-1; the remaining per-sample blocks have nothing to do)
+        if ((int)blockIdx.x >= nchunk) return;
+        const int e = blockIdx.x * 64 + lane;
+        float sk = 0.f, sv = 0.f;
+        if (e < inner)
+            for (int r = rg; r < a.B * rows; r += 16) {
+                sk += a.part_k0[(size_t)r * inner + e];
+                sv += a.part_v0[(size_t)r * inner + e];
+            }
+        red[0][rg][lane] = sk;
+        red[1][rg][lane] = sv;
+        __syncthreads();
+        if (rg == 0 && e < inner) {
+            float tk = 0.f, tv = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { tk += red[0][r][lane]; tv += red[1][r][lane]; }
+            a.dnull_k[e] = tk;
+            a.dnull_v[e] = tv;
         }
         return;
     }
@@ -1230,6 +1264,12 @@ void fill_geom(S3Args& a, const amdnuwa_s3_geom* g) {
     a.of = g->noncausal ? (g->kf - 1) / 2 : g->kf - 1;
     a.oh = g->noncausal ? (g->kh - 1) / 2 : g->kh - 1;
     a.ow = g->noncausal ? (g->kw - 1) / 2 : g->kw - 1;
+    a.xmode = 0; a.FK = g->F; a.kvrows = g->ntok; a.kvoff = 1; a.kmask = nullptr;
+}
+// self-attention: keys / values are the query sequence, slot 0 = its <bos> row
+void self_kv(S3Args& a) {
+    a.ldk = a.ld; a.lddk = a.ldd;
+    a.k0 = a.k; a.k0l = a.kl; a.v0 = a.v; a.v0l = a.vl; a.k0_bs = (long long)a.ntok * a.ld;
 }
 int block_threads(const amdnuwa_s3_geom* g) { return ((g->W * g->heads * 4 + 63) / 64) * 64; }
 
@@ -1246,6 +1286,7 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
     fill_geom(a, g);
     a.q = q; a.k = k; a.v = v; a.ql = q_lo; a.kl = k_lo; a.vl = v_lo; a.ld = ld;
     a.o = o; a.ol = o_lo; a.ldo = ldo; a.wth = w_th;
+    self_kv(a);
     const int J = g->kf * g->kh * g->kw + 1;
     if ((k_lo != nullptr) && (!q_lo || !v_lo)) return AMDNUWA_ERR_ARG;
     // tuning key 3: 0 = one key row per staging round (measured faster: 4 resident workgroups per CU),
@@ -1301,6 +1342,7 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     a.dO = dO; a.dOl = dO_lo; a.lddo = lddo;
     a.dq = dq; a.dk = dk; a.dv = dv; a.dql = dq_lo; a.dkl = dk_lo; a.dvl = dv_lo; a.ldd = ldd;
     a.dwth = dw_th; a.accumulate = accumulate;
+    self_kv(a);
     const size_t J = (size_t)g->kf * g->kh * g->kw + 1, nq = g->ntok - 1, rows = (size_t)g->B * g->F * g->H;
     const size_t inner = (size_t)g->heads * g->dim_head;
     float* ws = (float*)workspace;
@@ -1356,5 +1398,111 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
                                        amdnuwa_colsum_workspace_bytes((long long)g->B * nq, (int)(J * g->heads)), stream);
         if (rc2) return rc2;
     }
+    return AMDNUWA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SparseCross2DNA (np.py:761-901; NUWASketch's decoder cross-attention): the video queries of grid position (y, x) attend, in
+// EVERY sketch frame, to the k x k neighbourhood of (y, x) (+ a learned null key / value), with a key mask, fp32 softmax and talking
+// heads.  Same kernels as the symmetric Sparse3DNA with the key / value side pointed at the context (S3Args::xmode).  Query row 0
+// (<bos>, which attends to every context token without talking heads) is not touched here: the caller owns o[b*ntok] / dq[b*ntok].
+// ------------------------------------------------------------------------------------------------
+namespace {
+int cross_setup(S3Args& a, const amdnuwa_s3_geom* g, int ctx_rows, const uint16_t* k, const uint16_t* v, const uint16_t* k_lo,
+                const uint16_t* v_lo, int ldkv, const uint16_t* null_k, const uint16_t* null_k_lo, const uint16_t* null_v,
+                const uint16_t* null_v_lo, const uint8_t* key_mask) {
+    int rc = check_geom(g);
+    if (rc) return rc;
+    if (!k || !v || !null_k || !null_v || ldkv % 8) return AMDNUWA_ERR_ARG;
+    if (g->rel_bias || ctx_rows != g->kf * g->H * g->W) return AMDNUWA_ERR_ARG;
+    if ((k_lo != nullptr) != (v_lo != nullptr) || (k_lo != nullptr) != (null_k_lo != nullptr) || (k_lo != nullptr) != (null_v_lo != nullptr))
+        return AMDNUWA_ERR_ARG;
+    fill_geom(a, g);
+    a.xmode = 1; a.FK = g->kf; a.kvrows = ctx_rows; a.kvoff = 0; a.kmask = key_mask;
+    a.of = 0; a.df = 1;                                            // frame tap a = context frame a
+    a.oh = (g->kh - 1) / 2; a.ow = (g->kw - 1) / 2;                // 'same' padding on the feature map (np.py:789)
+    a.k = k; a.v = v; a.kl = k_lo; a.vl = v_lo; a.ldk = ldkv;
+    a.k0 = null_k; a.k0l = null_k_lo; a.v0 = null_v; a.v0l = null_v_lo; a.k0_bs = 0;
+    return AMDNUWA_OK;
+}
+}  // namespace
+
+extern "C" int amdnuwa_cross2dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq, int ctx_rows,
+                                     const uint16_t* k, const uint16_t* v, const uint16_t* k_lo, const uint16_t* v_lo, int ldkv,
+                                     const uint16_t* null_k, const uint16_t* null_k_lo, const uint16_t* null_v,
+                                     const uint16_t* null_v_lo, const uint8_t* key_mask, const float* w_th, uint16_t* o,
+                                     uint16_t* o_lo, int ldo, hipStream_t stream) {
+    S3Args a{};
+    int rc = cross_setup(a, g, ctx_rows, k, v, k_lo, v_lo, ldkv, null_k, null_k_lo, null_v, null_v_lo, key_mask);
+    if (rc) return rc;
+    if (!q || !w_th || !o || ldq % 8 || ldo % 8 || (k_lo != nullptr) != (q_lo != nullptr)) return AMDNUWA_ERR_ARG;
+    if (g->B <= 0) return AMDNUWA_OK;
+    a.q = q; a.ql = q_lo; a.ld = ldq; a.o = o; a.ol = o_lo; a.ldo = ldo; a.wth = w_th;
+    const int J = g->kf * g->kh * g->kw + 1;
+    const bool lo_mode = k_lo != nullptr;
+    const size_t lds = (size_t)g->W * g->heads * g->dim_head * (lo_mode ? 4 : 2) + (size_t)g->W * J * g->heads * 4;
+    dim3 grid(g->B * g->F * g->H), block(block_threads(g));
+#define S3F(DH_, LO_)                                                                                             \
+    do {                                                                                                          \
+        (void)hipFuncSetAttribute((const void*)s3_fwd_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((s3_fwd_kernel<DH_, LO_>), grid, block, lds, stream, a);                               \
+    } while (0)
+    if (g->dim_head == 64) { if (lo_mode) S3F(64, true); else S3F(64, false); }
+    else { if (lo_mode) S3F(32, true); else S3F(32, false); }
+#undef S3F
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" size_t amdnuwa_cross2dna_bwd_workspace_bytes(const amdnuwa_s3_geom* g) { return amdnuwa_sparse3dna_bwd_workspace_bytes(g); }
+
+extern "C" int amdnuwa_cross2dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq, int ctx_rows,
+                                     const uint16_t* k, const uint16_t* v, const uint16_t* k_lo, const uint16_t* v_lo, int ldkv,
+                                     const uint16_t* null_k, const uint16_t* null_k_lo, const uint16_t* null_v,
+                                     const uint16_t* null_v_lo, const uint8_t* key_mask, const float* w_th, const uint16_t* dO,
+                                     const uint16_t* dO_lo, int lddo, uint16_t* dq, uint16_t* dq_lo, int lddq, uint16_t* dk,
+                                     uint16_t* dv, uint16_t* dk_lo, uint16_t* dv_lo, int lddkv, float* d_null_k, float* d_null_v,
+                                     float* dw_th, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    S3Args a{};
+    int rc = cross_setup(a, g, ctx_rows, k, v, k_lo, v_lo, ldkv, null_k, null_k_lo, null_v, null_v_lo, key_mask);
+    if (rc) return rc;
+    if (!q || !w_th || !dO || !dq || !dk || !dv || !d_null_k || !d_null_v || !dw_th || ldq % 8 || lddo % 8 || lddq % 8 || lddkv % 8)
+        return AMDNUWA_ERR_ARG;
+    const bool lo_mode = k_lo != nullptr;
+    if (lo_mode != (q_lo != nullptr) || lo_mode != (dO_lo != nullptr)) return AMDNUWA_ERR_ARG;
+    if (!workspace || workspace_bytes < amdnuwa_cross2dna_bwd_workspace_bytes(g)) return AMDNUWA_ERR_WORKSPACE;
+    if (g->B <= 0) return AMDNUWA_OK;
+    a.q = q; a.ql = q_lo; a.ld = ldq; a.wth = w_th;
+    a.dO = dO; a.dOl = dO_lo; a.lddo = lddo;
+    a.dq = dq; a.dql = dq_lo; a.ldd = lddq; a.dk = dk; a.dv = dv; a.dkl = dk_lo; a.dvl = dv_lo; a.lddk = lddkv;
+    a.dwth = dw_th; a.accumulate = 0; a.dnull_k = d_null_k; a.dnull_v = d_null_v;
+    const size_t J = (size_t)g->kf * g->kh * g->kw + 1, nq = g->ntok - 1, rows = (size_t)g->B * g->F * g->H;
+    const size_t inner = (size_t)g->heads * g->dim_head;
+    float* ws = (float*)workspace;
+    a.ds = ws; ws += (size_t)g->B * nq * J * g->heads;
+    a.pm = ws; ws += (size_t)g->B * nq * J * g->heads;
+    a.part_th = ws; ws += rows * g->heads * g->heads;
+    a.part_k0 = ws; ws += rows * inner;
+    a.part_v0 = ws;
+    const size_t nsp = (size_t)g->W * J * g->heads;
+    size_t spdp = 2 * nsp;
+    if (spdp < (size_t)g->W * inner) spdp = (size_t)g->W * inner;
+    const size_t lds_q = (size_t)g->W * g->heads * g->dim_head * (lo_mode ? 4 : 2) + (spdp + 8 * 64) * 4;
+    const size_t lds_kv = (size_t)g->W * g->heads * g->dim_head * 8;
+    dim3 grid_q((unsigned)rows), grid_kv((unsigned)(g->B * g->kf * g->H)), block(block_threads(g));
+#define S3XB(DH_, LO_)                                                                                            \
+    do {                                                                                                          \
+        (void)hipFuncSetAttribute((const void*)s3_bwd_q_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
+        hipLaunchKernelGGL((s3_bwd_q_kernel<DH_, LO_>), grid_q, block, lds_q, stream, a);                         \
+        LAUNCH_CHECK();                                                                                           \
+        (void)hipFuncSetAttribute((const void*)s3_bwd_kv_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv); \
+        hipLaunchKernelGGL((s3_bwd_kv_kernel<DH_, LO_>), grid_kv, block, lds_kv, stream, a);                      \
+    } while (0)
+    if (g->dim_head == 64) { if (lo_mode) S3XB(64, true); else S3XB(64, false); }
+    else { if (lo_mode) S3XB(32, true); else S3XB(32, false); }
+#undef S3XB
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(s3_bwd_fin_kernel, dim3(g->B * (((int)inner + 63) / 64) + (g->heads * g->heads + 15) / 16), dim3(1024), 0, stream, a, g->dim_head);
+    LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

@@ -470,6 +470,42 @@ def sparse3dna_bwd(g, qkv, wth, dO, rel_bias=None):
     return dqkv, dwth, drel
 
 
+def cross2dna_fwd(g, q, kv, null_k, null_v, mask_u8, wth, ctx_rows):
+    """SparseCross2DNA core.  q BF [B*ntok, inner]; kv BF [B*ctx_rows, 2*inner] (k | v); null_k / null_v BF [inner]; mask_u8 [B, ctx_rows]
+    or None.  Returns o BF [B*ntok, inner] whose rows b*ntok (<bos>) are left for the caller."""
+    L = _lib.lib()
+    inner = g.heads * g.dim_head
+    o = empty_bf((g.B * g.ntok, inner), q.hi.device, lo=q.lo is not None)
+    k, v = (view(kv, cols=slice(i * inner, (i + 1) * inner)) for i in range(2))
+    check(L.amdnuwa_cross2dna_fwd(C.byref(g), _p(q.hi), _p(q.lo), q.hi.stride(0), ctx_rows, _p(k.hi), _p(v.hi), _p(k.lo), _p(v.lo),
+                                  kv.hi.stride(0), _p(null_k.hi), _p(null_k.lo), _p(null_v.hi), _p(null_v.lo), _p(mask_u8), _p(wth),
+                                  _p(o.hi), _p(o.lo), inner, _stream()), 'amdnuwa_cross2dna_fwd')
+    return o
+
+
+def cross2dna_bwd(g, q, kv, null_k, null_v, mask_u8, wth, dO, ctx_rows):
+    """returns dq BF [B*ntok, inner] (rows b*ntok untouched), dkv BF [B*ctx_rows, 2*inner], d_null_k, d_null_v fp32 [inner], dw_th [h, h]"""
+    L = _lib.lib()
+    inner = g.heads * g.dim_head
+    dev = q.hi.device
+    lo = q.lo is not None
+    dq = empty_bf((g.B * g.ntok, inner), dev, lo=lo)
+    dkv = empty_bf((g.B * ctx_rows, 2 * inner), dev, lo=lo)
+    dnk = torch.empty(inner, dtype=torch.float32, device=dev)
+    dnv = torch.empty(inner, dtype=torch.float32, device=dev)
+    dwth = torch.empty((g.heads, g.heads), dtype=torch.float32, device=dev)
+    k, v = (view(kv, cols=slice(i * inner, (i + 1) * inner)) for i in range(2))
+    dk, dv = (view(dkv, cols=slice(i * inner, (i + 1) * inner)) for i in range(2))
+    nb = L.amdnuwa_cross2dna_bwd_workspace_bytes(C.byref(g))
+    ws = workspace(nb, dev)
+    check(L.amdnuwa_cross2dna_bwd(C.byref(g), _p(q.hi), _p(q.lo), q.hi.stride(0), ctx_rows, _p(k.hi), _p(v.hi), _p(k.lo), _p(v.lo),
+                                  kv.hi.stride(0), _p(null_k.hi), _p(null_k.lo), _p(null_v.hi), _p(null_v.lo), _p(mask_u8), _p(wth),
+                                  _p(dO.hi), _p(dO.lo), dO.hi.stride(0), _p(dq.hi), _p(dq.lo), dq.hi.stride(0), _p(dk.hi), _p(dv.hi),
+                                  _p(dk.lo), _p(dv.lo), dkv.hi.stride(0), _p(dnk), _p(dnv), _p(dwth), _p(ws), nb, _stream()),
+          'amdnuwa_cross2dna_bwd')
+    return dq, dkv, dnk, dnv, dwth
+
+
 def decode_shift(h, cache, pos_dev, fmap):
     """h BF [B, D] (row pos of every sample) -> stored in cache BF [B, rows, D]; returns shift(h)[pos] as BF [B, D]"""
     L = _lib.lib()

@@ -174,6 +174,8 @@ class SandwichNorm(nn.Module):
             return fn, shift
         if isinstance(fn, Attention) and context is None and seq_len is not None and fn._hip_ok(seq_len):
             return fn, shift                      # non-causal self-attention (text encoder): same kernels, keys = the query rows
+        if isinstance(fn, SparseCross2DNA) and context is not None and fn._hip_ok(context.shape[1]):
+            return fn, shift                      # NUWASketch decoder: 2-D nearby cross-attention on the 3DNA kernels (row f4)
         return None
 
     def fused_residual(self, x, resid=None, context=None, context_mask=None, mask=None, rotary_pos_emb=None, chain=None):
@@ -193,7 +195,7 @@ class SandwichNorm(nn.Module):
             if nxt is not None and not (nxt_fmap is not None and D % 32):
                 meta['next_pre'] = (nxt.prenorm.weight, nxt.prenorm.bias, (n, nxt_fmap) if nxt_fmap is not None else None)
                 meta['handoff_out'] = hout
-        return ops.SandwichBlockFn.apply(x, resid, context if isinstance(inner, Attention) else None, meta,
+        return ops.SandwichBlockFn.apply(x, resid, context if isinstance(inner, (Attention, SparseCross2DNA)) else None, meta,
                                          self.prenorm.weight, self.prenorm.bias, self.postnorm.weight,
                                          self.postnorm.bias, *inner._params())
 
@@ -492,7 +494,9 @@ class Sparse3DNA(nn.Module):
 class SparseCross2DNA(nn.Module):
     """np.py:761-901: cross-attention of video tokens to the sketch tokens in a 2-D neighbourhood of the same feature-map
     position in EVERY sketch frame (+ a learned null key); the <bos> query attends to all sketch tokens, without talking heads.
-    PyTorch-ROCm ops (row f4): the unfold of the reference is a gather over a (position, tap) table."""
+    On the MI355X the windowed queries run on the 3DNA kernels pointed at the sketch context (amdnuwa_cross2dna_*, row f4; the B
+    <bos> rows are glue arithmetic between the kernels); `_forward_torch` keeps the gather formulation on PyTorch ops for shapes the
+    kernels do not take (other head sizes, attention dropout in training)."""
 
     def __init__(self, *, dim, image_size, heads=8, dim_head=64, dropout=0., kernel_size=3, dilation=1):
         super().__init__()
@@ -510,8 +514,32 @@ class SparseCross2DNA(nn.Module):
         self.padding = calc_same_padding(kernel_size, dilation)
         nbr = neighbor_positions((1, image_size, image_size), (1, kernel_size, kernel_size), (1, dilation, dilation), causal=False)
         self.register_buffer('_nbr', nbr, persistent=False)                                    # (fmap^2, k^2), -1 = padding
+        self.dim_head = dim_head
+        self._cache = ops.WeightCache()
+
+    def _params(self):
+        return (self.null_k, self.null_v, self.talking_heads.weight, self.to_q.weight, self.to_kv.weight, self.to_out.weight)
+
+    def _hip_ok(self, ctx_len):
+        return self.dim_head in (32, 64) and self.heads <= 8 and self.image_size * self.heads * 4 <= 512 and \
+            ctx_len > 0 and ctx_len % (self.image_size ** 2) == 0 and not (self.training and self.dropout.p > 0)
+
+    def _meta(self, B, n, device, context=None, context_mask=None, **_):
+        tpf = self.image_size ** 2
+        T = context.shape[1]
+        frames = max(1, -(-(n - 1) // tpf))
+        g = K.s3_geom(B, n, (frames, self.image_size, self.image_size), (T // tpf, self.kernel_size, self.kernel_size),
+                      (1, self.dilation, self.dilation), self.heads, self.dim_head, causal=False)
+        mask_u8 = context_mask.to(torch.uint8).contiguous() if exists(context_mask) else None
+        return dict(kind='xc2', cache=self._cache, geom=g, ctx_T=T, mask_u8=mask_u8)
 
     def forward(self, x, *, context, context_mask=None, **kwargs):
+        if x.is_cuda and self._hip_ok(context.shape[1]):
+            B, n, _ = x.shape
+            return ops.InnerFn.apply(x, context, self._meta(B, n, x.device, context=context, context_mask=context_mask), *self._params())
+        return self._forward_torch(x, context=context, context_mask=context_mask)
+
+    def _forward_torch(self, x, *, context, context_mask=None, **kwargs):
         b, n, h, device = x.shape[0], x.shape[1], self.heads, x.device
         tpf = self.image_size ** 2
         kn = self.kernel_size ** 2

@@ -261,7 +261,108 @@ class FFInner:
         return dh, None, [dw1, dw2]
 
 
-INNERS = {'s3': S3Inner, 'xattn': XInner, 'ff': FFInner}
+def _bf_val(t):
+    """fp32 value of a BF pair"""
+    return t.hi.float() if t.lo is None else t.hi.float() + t.lo.float()
+
+
+def _bf_put(dst, index, value):
+    """dst[index] = value (fp32) for a BF pair, rows selected by `index`"""
+    hi = value.to(torch.bfloat16)
+    dst.hi[index] = hi
+    if dst.lo is not None:
+        dst.lo[index] = (value - hi.float()).to(torch.bfloat16)
+
+
+def _to_bf(value):
+    out = K.empty_bf(tuple(value.shape), value.device)
+    K.cast_pad(value.contiguous(), out)
+    return out
+
+
+class XC2Inner:
+    """to_q(x), to_kv(sketch context) -> SparseCross2DNA core -> to_out (np.py:761-901).
+    params: null_k, null_v, talking_heads.w, to_q.w, to_kv.w, to_out.w  (the layout of XInner)
+    The windowed queries run on the 3DNA kernels pointed at the context (amdnuwa_cross2dna_*); the single <bos> query of every
+    sample -- full attention over all context tokens, no talking heads (np.py:813-830) -- is B rows of glue arithmetic on torch ops
+    between the kernels, forward and backward."""
+    nparams = 6
+
+    @staticmethod
+    def _null(p, lo):
+        nk, nv = p[0], p[1]
+        mk = lambda t: _to_bf(t.detach().reshape(1, -1).float())
+        a, b = mk(nk), mk(nv)
+        return K.BF(a.hi.reshape(-1), None if a.lo is None else a.lo.reshape(-1)), K.BF(b.hi.reshape(-1), None if b.lo is None else b.lo.reshape(-1))
+
+    @staticmethod
+    def _bos_scores(q0, kf, nkf, keep, scale):
+        """q0 [B,h,d], kf [B,T,h,d], nkf [h,d] -> softmax over [null | context] per (sample, head): [B,h,T+1]"""
+        s = torch.cat((torch.einsum('bhd,hd->bh', q0, nkf)[..., None], torch.einsum('bhd,bthd->bht', q0, kf)), dim=-1) * scale
+        if keep is not None:
+            s = s.masked_fill(~torch.nn.functional.pad(keep, (1, 0), value=True)[:, None, :], -torch.finfo(torch.float32).max)
+        return s.softmax(dim=-1)
+
+    @staticmethod
+    def fwd(h, p, meta):
+        W = XInner.weights(meta['cache'], p)
+        g, T = meta['geom'], meta['ctx_T']
+        heads, dh = g.heads, g.dim_head
+        inner = heads * dh
+        wth2 = p[2].detach().reshape(heads, heads).contiguous()
+        q = K.gemm_nt(h, W['q'], out_bf16=True)
+        kv = K.gemm_nt(meta['ctx_bf'], W['kv'], out_bf16=True)
+        nk, nv = XC2Inner._null(p, q.lo is not None)
+        o = K.cross2dna_fwd(g, q, kv, nk, nv, meta['mask_u8'], wth2, T)
+        # <bos> query rows
+        rows0 = torch.arange(g.B, device=q.hi.device) * g.ntok
+        q0 = _bf_val(K.BF(q.hi[rows0], None if q.lo is None else q.lo[rows0])).reshape(g.B, heads, dh)
+        kvf = _bf_val(kv).reshape(g.B, T, 2, heads, dh)
+        keep = meta['mask_u8'].bool() if meta['mask_u8'] is not None else None
+        P0 = XC2Inner._bos_scores(q0, kvf[:, :, 0], _bf_val(nk).reshape(heads, dh), keep, g.scale)
+        o0 = P0[..., :1] * _bf_val(nv).reshape(1, heads, dh) + torch.einsum('bht,bthd->bhd', P0[..., 1:], kvf[:, :, 1])
+        _bf_put(o, rows0, o0.reshape(g.B, inner))
+        y = K.gemm_nt(o, W['out'], out_bf16=_fast())
+        return y, (h, q, kv, nk, nv, o, P0)
+
+    @staticmethod
+    def bwd(saved, dy, p, meta, need_dbias=False, dy_f32=None):
+        h, q, kv, nk, nv, o, P0 = saved
+        W = XInner.weights(meta['cache'], p)
+        nkp, nvp, wth, wq, wkv, wo = p
+        g, T = meta['geom'], meta['ctx_T']
+        heads, dh = g.heads, g.dim_head
+        inner = heads * dh
+        wth2 = wth.detach().reshape(heads, heads).contiguous()
+        d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
+        dwo = torch.empty_like(wo)
+        K.gemm_tn(dy, o, dwo)
+        dq, dkv, dnk, dnv, dwth = K.cross2dna_bwd(g, q, kv, nk, nv, meta['mask_u8'], wth2, d_o, T)
+        # <bos> query rows: softmax attention backward on B rows
+        rows0 = torch.arange(g.B, device=q.hi.device) * g.ntok
+        sub = lambda t: _bf_val(K.BF(t.hi[rows0], None if t.lo is None else t.lo[rows0])).reshape(g.B, heads, dh)
+        q0, dO0 = sub(q), sub(d_o)
+        kvf = _bf_val(kv).reshape(g.B, T, 2, heads, dh)
+        nkf, nvf = _bf_val(nk).reshape(heads, dh), _bf_val(nv).reshape(heads, dh)
+        dP = torch.cat((torch.einsum('bhd,hd->bh', dO0, nvf)[..., None], torch.einsum('bhd,bthd->bht', dO0, kvf[:, :, 1])), dim=-1)
+        dS = P0 * (dP - (P0 * dP).sum(-1, keepdim=True)) * g.scale
+        dq0 = dS[..., :1] * nkf[None] + torch.einsum('bht,bthd->bhd', dS[..., 1:], kvf[:, :, 0])
+        _bf_put(dq, rows0, dq0.reshape(g.B, inner))
+        dkv_f = _bf_val(dkv).reshape(g.B, T, 2, heads, dh)
+        dkv_f[:, :, 0] += torch.einsum('bht,bhd->bthd', dS[..., 1:], q0)
+        dkv_f[:, :, 1] += torch.einsum('bht,bhd->bthd', P0[..., 1:], dO0)
+        dkv = _to_bf(dkv_f.reshape(g.B * T, 2 * inner))
+        dnk = dnk + torch.einsum('bh,bhd->hd', dS[..., 0], q0).reshape(-1)
+        dnv = dnv + torch.einsum('bh,bhd->hd', P0[..., 0], dO0).reshape(-1)
+        dh_ = K.gemm_nt(dq, W['qT'], out_bf16=_fast())
+        dwq, dwkv = torch.empty_like(wq), torch.empty_like(wkv)
+        K.gemm_tn(dq, h, dwq)
+        K.gemm_tn(dkv, meta['ctx_bf'], dwkv)
+        dctx = K.gemm_nt(dkv, W['kvT'])
+        return dh_, dctx, [dnk.reshape(nkp.shape), dnv.reshape(nvp.shape), dwth.reshape(wth.shape), dwq, dwkv, dwo]
+
+
+INNERS = {'s3': S3Inner, 'xattn': XInner, 'ff': FFInner, 'xc2': XC2Inner}
 
 FUSE_LINEAR_CE = os.environ.get('AMDNUWA_FUSE_LINEAR_CE', '1') != '0'   # to_logits + cross entropy without the fp32 logits (A/B switch)
 FUSE_GEGLU_BWD = os.environ.get('AMDNUWA_FUSE_GEGLU_BWD', '1') != '0'   # gate backward inside the dgg GEMM epilogue (A/B switch)
@@ -314,7 +415,7 @@ class SandwichBlockFn(Function):
         x2 = x.detach().contiguous().reshape(B * n, D)
         r2_ = x2 if resid is None else resid.detach().contiguous().reshape(B * n, D)
         meta = dict(meta)
-        if meta['kind'] == 'xattn' and not meta.get('self_kv'):
+        if meta['kind'] in ('xattn', 'xc2') and not meta.get('self_kv'):
             meta['ctx_bf'] = _ctx_to_bf(context)
         # the token shift is folded into the pre-LN's STORE: h = shift(LN(x)) is what the forward GEMM and the weight-gradient
         # GEMM consume (plain loaders); only the pre-LN backward still reads its incoming gradient through the inverse shift
@@ -381,7 +482,7 @@ class SandwichBlockFn(Function):
         ctx.prev_ctx = None
         dcontext = None
         if ctx.has_ctx:
-            T = meta['xgeom'].T
+            T = meta['ctx_T'] if meta['kind'] == 'xc2' else meta['xgeom'].T
             dcontext = dctx.reshape(B, T, D)
         wg.join()
         ctx.inner_saved = None
@@ -400,7 +501,7 @@ class InnerFn(Function):
         B, n, D = x.shape
         x2 = x.detach().contiguous().reshape(B * n, D)
         meta = dict(meta)
-        if meta['kind'] == 'xattn' and not meta.get('self_kv'):
+        if meta['kind'] in ('xattn', 'xc2') and not meta.get('self_kv'):
             meta['ctx_bf'] = _ctx_to_bf(context)
         h = K.empty_bf((B * n, D), x.device)
         K.cast_pad(x2, h)
@@ -423,7 +524,7 @@ class InnerFn(Function):
         wg = meta['wg'] = WgradStream(g.device)
         dh, dctx, grads = inner.bwd(ctx.inner_saved, dy, p, meta, need_dbias=True, dy_f32=g2)
         wg.join()
-        dcontext = dctx.reshape(B, meta['xgeom'].T, D) if ctx.has_ctx else None
+        dcontext = dctx.reshape(B, meta['ctx_T'] if meta['kind'] == 'xc2' else meta['xgeom'].T, -1) if ctx.has_ctx else None
         ctx.inner_saved = None
         return (_as_f32(dh).reshape(B, n, D), dcontext, None, *grads)
 

@@ -557,3 +557,49 @@ def test_noncausal_sparse3dna_hip_vs_oracle(A, O_mod, shape, kernel, dil, n, hea
             report(tag + f'.grad.{k}', gr, P[k].grad, gtol)
     finally:
         A.set_precision('bf16')
+
+
+XC2_CASES = [(4, 2, 32, 3, 1, 2, 1 + 3 * 16, 'frame'), (4, 2, 32, 3, 2, 2, 1 + 21, 'rand'), (8, 4, 32, 5, 1, 1, 1 + 2 * 64, None),
+             (16, 8, 64, 3, 1, 2, 1 + 2 * 256, 'rand'), (16, 8, 64, 3, 2, 2, 1 + 300, 'frame'), (4, 2, 32, 3, 1, 2, 1, None)]
+
+
+@pytest.mark.parametrize('mode,tol,gtol', MODES)
+@pytest.mark.parametrize('fmap,heads,dh,kernel,dil,frames,n,masking', XC2_CASES)
+def test_sparse_cross_2dna_hip_vs_oracle(A, O_mod, fmap, heads, dh, kernel, dil, frames, n, masking, mode, tol, gtol):
+    """row f4: SparseCross2DNA (NUWASketch decoder cross-attention, np.py:761-901) on libamdnuwa: windowed queries on the 3DNA kernels
+    pointed at the sketch context, <bos> query glue; forward + backward (x, context, every parameter incl. the null key / value and
+    the Conv3d talking heads) against the oracle: whole / partial sequences, masked sketch frames, random key masks, dilation, n = 1"""
+    from nuwa_pytorch_amd.nuwa_pytorch import SparseCross2DNA
+    torch.manual_seed(0)
+    dim = 64
+    m = SparseCross2DNA(dim=dim, image_size=fmap, heads=heads, dim_head=dh, kernel_size=kernel, dilation=dil)
+    T = frames * fmap * fmap
+    assert m._hip_ok(T)
+    P = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(n + fmap)
+    x, ctx, dy = torch.randn(2, n, dim, generator=g), torch.randn(2, T, dim, generator=g), torch.randn(2, n, dim, generator=g)
+    mask = None
+    if masking == 'frame':                           # sample 1 hides its last sketch frame (the sketch_mask of NUWASketch.forward)
+        mask = torch.ones(2, T, dtype=torch.bool)
+        mask[1, (frames - 1) * fmap * fmap:] = False
+    elif masking == 'rand':
+        mask = torch.rand(2, T, generator=g) > 0.3
+    xr, cr = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    yr = O_mod.sparse_cross_2dna(xr, cr, P, heads, fmap, kernel, dil, context_mask=mask)
+    yr.backward(dy)
+    m = m.to(DEV)
+    run_mode(A, mode)
+    try:
+        xd, cd = x.to(DEV).requires_grad_(True), ctx.to(DEV).requires_grad_(True)
+        y = m(xd, context=cd, context_mask=mask.to(DEV) if mask is not None else None)
+        tag = f'xc2[{fmap},{heads},{kernel},{dil},{n},{masking},{mode}]'
+        report(tag + '.y', y, yr.detach(), tol)
+        y.backward(dy.to(DEV))
+        report(tag + '.dx', xd.grad, xr.grad, gtol)
+        report(tag + '.dctx', cd.grad, cr.grad, gtol)
+        for k, gr in _grads_of(m).items():
+            if n == 1 and k == 'talking_heads.weight':
+                continue                             # only the <bos> query exists: no talking heads on the path
+            report(tag + f'.grad.{k}', gr, P[k].grad, gtol)
+    finally:
+        A.set_precision('bf16')
