@@ -98,6 +98,9 @@ int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspac
  * stable != 0 (mode 0 only): x is first divided by its row amax (saved as 1/amax).
  * Input-type flags (fast bf16 mode keeps GEMM outputs in bf16): OR AMDNUWA_LN_X_BF16 into `mode` (ln_fwd) or into
  * `stable` (ln_bwd) when x points at bf16 values; OR AMDNUWA_LN_DY_BF16 into ln_bwd's `stable` when dy does. */
+/* Token shift folded into the pre-norm's store / the pre-norm backward's reads (shift_ntok = rows per sample, 0 = none):
+ * shift_fmap > 0: ShiftVideoTokens (np.py:185-253) on a fmap x fmap grid, <bos> row untouched; shift_fmap == -1: ShiftAudioTokens
+ * (np.py:157-183): the first half of the channels of row i comes from row i - 1 (zeros for row 0), every row takes part. */
 #define AMDNUWA_LN_X_BF16 16
 #define AMDNUWA_LN_DY_BF16 32
 int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const float* b, uint16_t* out_hi,

@@ -76,7 +76,12 @@ __device__ __forceinline__ void store_ln_shifted(bf16_t* out_hi, bf16_t* out_lo,
                                                  int shift_fmap, float y0, float y1, float y2, float y3) {
     long long drow = row;
     bool keep = true, zero_own = false;
-    if (shift_ntok > 0) {
+    if (shift_ntok > 0 && shift_fmap < 0) {
+        // ShiftAudioTokens (np.py:157-183): the first HALF of the channels of token i belongs to token i + 1; every row takes part
+        // (<bos> included) and row 0 keeps zeros there
+        const int i = (int)(row % shift_ntok);
+        if (e < (D >> 1)) { keep = i + 1 < shift_ntok; drow = row + 1; zero_own = i == 0; }
+    } else if (shift_ntok > 0) {
         const int i = (int)(row % shift_ntok);
         const int qd = e < (D >> 2) ? 0 : (e < (D >> 1) ? 1 : 2);            // (no integer division in the row kernels)
         if (i > 0 && qd < 2) {
@@ -244,7 +249,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             //                      d(shifted)[i + 1][c]    (quarter 1), d(shifted)[i][c] otherwise
             const int i = (int)(row % shift_ntok);
             long long src_h = -1, src_w = -1;
-            if (i > 0) {
+            const bool audio = shift_fmap < 0;          // ShiftAudioTokens: both channel quarters of the first half come from row i + 1, row 0 included
+            if (audio) {
+                if (i + 1 < shift_ntok) src_h = src_w = row + 1;
+            } else if (i > 0) {
                 const int p = i - 1, wq = p % shift_fmap, yq = (p / shift_fmap) % shift_fmap;
                 if (yq < shift_fmap - 1 && i + shift_fmap < shift_ntok) src_h = row + shift_fmap;
                 if (wq < shift_fmap - 1 && i + 1 < shift_ntok) src_w = row + 1;
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 const int e = (lane + it * 64) * 4;
                 if (e >= D) { in.gv.v[it] = zero4; continue; }
                 long long src = row;
-                if (i > 0) { if (e < quarter) src = src_h; else if (e < 2 * quarter) src = src_w; }
+                if (i > 0 || audio) { if (e < quarter) src = src_h; else if (e < 2 * quarter) src = src_w; }
                 in.gv.v[it] = src >= 0 ? ld4<IN == 2>(dy, (size_t)src * D + e) : zero4;
             }
         } else {
@@ -367,7 +375,10 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
         if (shift_ntok > 0) {
             const int i = (int)(row % shift_ntok);
             long long src_h = -1, src_w = -1;
-            if (i > 0) {
+            const bool audio = shift_fmap < 0;          // ShiftAudioTokens: both channel quarters of the first half come from row i + 1, row 0 included
+            if (audio) {
+                if (i + 1 < shift_ntok) src_h = src_w = row + 1;
+            } else if (i > 0) {
                 const int p = i - 1, wq = p % shift_fmap, yq = (p / shift_fmap) % shift_fmap;
                 if (yq < shift_fmap - 1 && i + shift_fmap < shift_ntok) src_h = row + shift_fmap;
                 if (wq < shift_fmap - 1 && i + 1 < shift_ntok) src_w = row + 1;
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
                 const int e = (lane + it * 64) * 4;
                 if (e >= D) { in.gv.v[it] = zero4; continue; }
                 long long src = row;
-                if (i > 0) { if (e < quarter) src = src_h; else if (e < 2 * quarter) src = src_w; }
+                if (i > 0 || audio) { if (e < quarter) src = src_h; else if (e < 2 * quarter) src = src_w; }
                 in.gv.v[it] = src >= 0 ? ((NT & 2) ? ld4_nt<BF>(dh, (size_t)src * D + e) : ld4<BF>(dh, (size_t)src * D + e)) : zero4;
             }
         } else {
@@ -855,7 +866,7 @@ extern "C" int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w
                               int D, int mode, int stable, float eps, int shift_ntok, int shift_fmap, hipStream_t stream) {
     const bool xbf = (mode & AMDNUWA_LN_X_BF16) != 0;        // x points at bf16 values
     mode &= 1;
-    if (shift_ntok > 0 && (mode != 0 || shift_fmap <= 0 || D % 16)) return AMDNUWA_ERR_ARG;
+    if (shift_ntok > 0 && (mode != 0 || shift_fmap == 0 || shift_fmap < -1 || D % 16)) return AMDNUWA_ERR_ARG;
     if (!x || !w || !b || !mean || !rstd || D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
     if (mode == 0 && !out_hi) return AMDNUWA_ERR_ARG;
     if (mode == 1 && (!out_f32 || !resid || stable)) return AMDNUWA_ERR_ARG;
@@ -882,7 +893,7 @@ extern "C" int amdnuwa_ln_post_pre_fwd(const float* y, const float* resid, const
     if (!y || !resid || !w || !b || !out_f32 || !mean || !rstd || !next_w || !next_b || !h_hi || !next_mean || !next_rstd)
         return AMDNUWA_ERR_ARG;
     if (D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
-    if (shift_ntok > 0 && (shift_fmap <= 0 || D % 16)) return AMDNUWA_ERR_ARG;
+    if (shift_ntok > 0 && (shift_fmap == 0 || shift_fmap < -1 || D % 16)) return AMDNUWA_ERR_ARG;
     if (R <= 0) return AMDNUWA_OK;
     dim3 grid((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
 #define LPP(NV_) do { if (xbf) hipLaunchKernelGGL((ln_post_pre_kernel<NV_, true>), grid, block, 0, stream, y, resid, w, b, out_f32, mean, rstd, next_w, next_b, h_hi, h_lo, next_mean, next_rstd, R, D, eps, shift_ntok, shift_fmap); \
@@ -910,7 +921,7 @@ extern "C" int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean
     stable &= 1;
     if (!dy || !x || !mean || !rstd || !w || D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
     if ((dx_hi == nullptr) == (dx_acc == nullptr)) return AMDNUWA_ERR_ARG;   // exactly one output form
-    if (shift_ntok > 0 && (shift_fmap <= 0 || D % 16)) return AMDNUWA_ERR_ARG;
+    if (shift_ntok > 0 && (shift_fmap == 0 || shift_fmap < -1 || D % 16)) return AMDNUWA_ERR_ARG;
     if (stable && !inv_amax) return AMDNUWA_ERR_ARG;
     if (!workspace || workspace_bytes < amdnuwa_ln_bwd_workspace_bytes(R, D)) return AMDNUWA_ERR_WORKSPACE;
     if (R <= 0) return AMDNUWA_OK;
@@ -947,7 +958,7 @@ extern "C" int amdnuwa_ln_bwd_chain(const void* dh, const float* x, const float*
     if (!dh || !x || !mean || !rstd || !w || !g || !dx || !y_prev || !mean_prev || !rstd_prev || !w_prev || !dy_prev_hi)
         return AMDNUWA_ERR_ARG;
     if (D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
-    if (shift_ntok > 0 && (shift_fmap <= 0 || D % 16)) return AMDNUWA_ERR_ARG;
+    if (shift_ntok > 0 && (shift_fmap == 0 || shift_fmap < -1 || D % 16)) return AMDNUWA_ERR_ARG;
     if (!workspace || workspace_bytes < amdnuwa_ln_bwd_chain_workspace_bytes(R, D)) return AMDNUWA_ERR_WORKSPACE;
     if (R <= 0) return AMDNUWA_OK;
     int nb = ln_bwd_blocks(R);

@@ -40,6 +40,7 @@ struct GemmArgs {
     // fused linear + cross entropy (EPI 2 / 3 of the 256x256 ring): per (row, 64-column block) partial (max, sum exp) and the
     // target logit in pass 1; dlogits = (exp(logit - lse) - onehot) * ce_scale in pass 2.  The logits never reach memory.
     float* ce_stats; float* ce_tl; const float* ce_lse; const long long* ce_tgt; float ce_scale; int ce_nblk;
+    int skew;               // start-phase step of the first-generation workgroups in s_sleep(8) units (tuning key 14; 0 = off)
 };
 
 __device__ __forceinline__ long long boff(const GemmArgs& p, long long z, long long s, long long s_in) {
@@ -468,6 +469,14 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.dbg & 2) ? 0 : p.K / 32;
+    // De-phasing.  Every workgroup of the first generation starts at t = 0, reaches its epilogue at the same moment as all the others
+    // and the whole chip then stores at once (HBM-bound burst) while the matrix pipes idle, tile after tile.  A start delay spread over
+    // 8 phases for the first-generation workgroups (one / two per CU) spreads the epilogues over the tile period: at any moment
+    // some CUs store while the others feed the matrix pipe.  p.skew = phase step in s_sleep(8) units (~0.25 us); 0 = off.
+    if (p.skew > 0 && (int)blockIdx.x < (WNW == 2 ? 512 : 256)) {
+        const int phase = (int)((blockIdx.x * 2654435761u) >> 29);
+        for (int i = 0; i < phase * p.skew; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     // prologue: NS-1 tiles in flight
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -1332,6 +1341,16 @@ static bool nt_geglu_fusable(const amdnuwa_gemm_desc* d) {
     return (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 512;
 }
 
+// start-phase step for the first-generation workgroups (see gemm_nt_256_kernel).  Measured (r02, b = 64): a perfectly regular grid (qkv:
+// 3840 equal tiles = 15 per CU) stays phase-locked and gains 12 % in isolation (380 -> 335 us at step 12), ragged grids (ff1, dgrad ff2)
+// gain nothing, and inside the training step -- where the previous kernel's tail already staggers the CUs -- the whole effect is
+// below the noise (600.3 k vs 600.3 k tokens/s).  Off unless forced through tuning key 14 (> 0 = phase step in s_sleep(8) units).
+static int nt_skew(long long tiles) {
+    (void)tiles;
+    const int t = g_amdnuwa_tuning[14];
+    return t > 0 ? t : 0;
+}
+
 // ---- fused linear + cross entropy: row statistics -> lse, row loss, mean (fixed order) ------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ stats, const float* __restrict__ tl, int nblk,
@@ -1385,6 +1404,7 @@ extern "C" int amdnuwa_linear_ce(const uint16_t* h, int ldh, const uint16_t* w, 
     p.M = (int)R; p.N = C; p.K = K; p.shift_dim = K;
     p.tiles_m = (int)((R + 255) / 256); p.tiles_n = (C + 255) / 256;
     p.ce_stats = stats; p.ce_tl = tl; p.ce_lse = lse; p.ce_tgt = targets; p.ce_scale = grad_scale; p.ce_nblk = nblk;
+    p.skew = nt_skew((long long)p.tiles_m * p.tiles_n);
     dim3 grid(p.tiles_m * p.tiles_n, 1), block(512);
     const size_t lds = (size_t)4 * 2 * 256 * 32 * 2;
     (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 2, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1434,6 +1454,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     p.tiles_m = (d->M + BM - 1) / BM; p.tiles_n = (d->N + BN - 1) / BN;
     p.ksplit_len = 0;
     p.dbg = g_amdnuwa_tuning[7];
+    p.skew = 0;
     p.C2 = nullptr; p.ldc2 = 0; p.Uin = nullptr; p.ldu = 0;
     p.batch_inner = d->batch_inner; p.sA_in = d->strideA_inner; p.sB_in = d->strideB_inner; p.sC_in = d->strideC_inner;
     const bool x3 = d->Alo != nullptr, sh = d->shift_ntok > 0, ob = d->c_is_bf16 != 0;
@@ -1494,6 +1515,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     if (!x3 && variant == 7 && d->K % 32 == 0) {                           // 256x256 tile, 4-stage ring, staggered wave rows
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         if (d->C2) { p.C2 = (bf16_t*)d->C2; p.ldc2 = d->ldc2; p.Uin = (const bf16_t*)d->geglu_u; p.ldu = d->ld_u; }
+        p.skew = nt_skew((long long)p.tiles_m * p.tiles_n);
         dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(512);
 #define GS(SH, EP)                                                                                                    \
     do {                                                                                                              \

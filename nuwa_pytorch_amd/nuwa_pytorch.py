@@ -168,6 +168,10 @@ class SandwichNorm(nn.Module):
             if fn.shift_space:
                 shift = fn.image_size
             fn = fn.fn
+        elif isinstance(fn, ShiftAudioTokens):            # cfg 5 audio tower: the one-row channel shift rides in the pre-norm's store
+            shift, fn = -1, fn.fn
+            if isinstance(fn, SparseCausal2DNA) and fn._hip_ok():
+                return fn, shift
         if (isinstance(fn, FeedForward) and not fn._dropout_active()) or (isinstance(fn, Sparse3DNA) and fn._hip_ok()):
             return fn, shift
         if isinstance(fn, Attention) and context is not None and fn._hip_ok(context.shape[1]):

@@ -69,25 +69,34 @@ class SparseCausal2DNA(nn.Module):
         idx = t - (k - 1 - a) * dil
         return torch.where(idx >= 0, idx, torch.full_like(idx, -1))
 
-    def _forward_hip(self, x):
-        """the same attention IS a Sparse3DNA over a (time, 1, 1) grid with kernel (k, 1, 1) and the per-tap bias: run it on
-        the libamdnuwa 3DNA kernels (to_qkv split into the q / kv halves they expect; to_out has no bias -> zeros)"""
-        from . import kernels as K
-        b, n, h = x.shape[0], x.shape[1], self.heads
-        inner = h * self.dim_head
+    # the same attention IS a Sparse3DNA over a (time, 1, 1) grid with kernel (k, 1, 1) and the per-tap bias: it runs on the
+    # libamdnuwa 3DNA kernels (to_qkv split into the q / kv halves they expect; to_out has no bias -> zeros), stand-alone through
+    # ops.InnerFn or, inside a SandwichNorm, as the inner stage of the fused block node
+    def _hip_ok(self):
+        return self.use_hip and self.dim_head in (32, 64) and self.heads <= 8 and self.kernel_size[0] > 1 and \
+            not (self.training and self.dropout.p > 0)
+
+    def _params(self):
+        h, inner = self.heads, self.heads * self.dim_head
         w = self.to_qkv.weight
         taps = self.rel_pos_bias().reshape(self.kernel_size[0], h)
         bias = torch.cat((taps.new_zeros(1, h), taps), 0).float()
-        g = K.s3_geom(b, n, (max(n - 1, 1), 1, 1), (self.kernel_size[0], 1, 1), (self.dilation[0], 1, 1), h, self.dim_head)
-        meta = dict(kind='s3', cache=self._cache, geom=g)
-        return ops.InnerFn.apply(x, None, meta, w[:inner], w[inner:], self.talking_heads.weight.reshape(h, h, 1, 1),
-                                 self.to_out.weight, x.new_zeros(self.to_out.weight.shape[0]), bias)
+        return (w[:inner], w[inner:], self.talking_heads.weight.reshape(h, h, 1, 1), self.to_out.weight,
+                w.new_zeros(self.to_out.weight.shape[0]), bias)
+
+    def _meta(self, B, n, device, **_):
+        from . import kernels as K
+        g = K.s3_geom(B, n, (max(n - 1, 1), 1, 1), (self.kernel_size[0], 1, 1), (self.dilation[0], 1, 1), self.heads, self.dim_head)
+        return dict(kind='s3', cache=self._cache, geom=g)
+
+    def _forward_hip(self, x):
+        return ops.InnerFn.apply(x, None, self._meta(x.shape[0], x.shape[1], x.device), *self._params())
 
     def forward(self, x, **kwargs):
         b, n, h = x.shape[0], x.shape[1], self.heads
         if self.training and self.dropout.p > 0:
             raise NotImplementedError('attention dropout inside SparseCausal2DNA is not built')
-        if self.use_hip and x.is_cuda and self.dim_head in (32, 64) and h <= 8 and self.kernel_size[0] > 1:
+        if x.is_cuda and self._hip_ok():
             return self._forward_hip(x)
         q, k, v = self.to_qkv(x).chunk(3, dim=-1)
         if n == 1:
