@@ -767,6 +767,9 @@ __device__ __forceinline__ bf16x8 ldg8(const bf16_t* p, bool ok) {
     return __builtin_bit_cast(bf16x8, ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0));
 }
 
+#ifndef S3M_PF
+#define S3M_PF 3
+#endif
 constexpr int S3M_KW = 3;        // widest tap row the MFMA kernel handles
 constexpr int S3M_PLANES = 64;   // kf * kh limit (plane list in LDS)
 
@@ -829,7 +832,7 @@ __device__ __forceinline__ void mfma_band_scores(const S3Args& a, const RowM& r,
 #pragma unroll
     for (int q = 0; q < 4; ++q) sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
     // sequence 0 is <bos> (token 0 for every MFMA row), then the valid planes; PF planes of key fragments are in flight
-    constexpr int PF = 3;
+    constexpr int PF = S3M_PF;
     bf16x8 kq0[PF], kq1[PF];
     auto issue = [&](int sq, bf16x8& d0, bf16x8& d1) {
         if (sq > r.nplanes) { d0 = d1 = bf16x8{}; return; }

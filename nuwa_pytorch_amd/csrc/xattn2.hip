@@ -493,10 +493,10 @@ __global__ __launch_bounds__(256, 1) void xattn3_fwd_kernel(X2Args a) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) { m[h] = NEG_MAX; l[h] = 0.f; }
     stage_chunk<false, false>(smem, 0, 0, b, a.JP, a.Kp, nullptr, wave, lane);
+    if (a.nch > 1) { stage_chunk<false, false>(smem, 1, 1, b, a.JP, a.Kp, nullptr, wave, lane); VMCNT(8); }
+    else VMCNT(0);
+    __builtin_amdgcn_s_barrier();                                 // chunk 0 has landed for every wave
     for (int ch = 0; ch < a.nch; ++ch) {
-        if (ch + 1 < a.nch) { stage_chunk<false, false>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, nullptr, wave, lane); VMCNT(8); }
-        else VMCNT(0);
-        __builtin_amdgcn_s_barrier();
         const char* base = smem + (ch & 1) * STAGE;
         const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
 #pragma unroll
@@ -516,7 +516,11 @@ __global__ __launch_bounds__(256, 1) void xattn3_fwd_kernel(X2Args a) {
             for (int e = 0; e < 8; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
             l[h] = acc; m[h] = mn;
         }
+        // ONE ring barrier per chunk: own pieces of chunk ch + 1 (issued a whole iteration ago) have landed, and after the barrier
+        // (a) everyone's have, (b) everyone is done reading stage ch & 1, which chunk ch + 2 may now overwrite
+        VMCNT(0);
         __builtin_amdgcn_s_barrier();
+        if (ch + 2 < a.nch) stage_chunk<false, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, nullptr, wave, lane);
     }
     float nb[NH];
 #pragma unroll
@@ -540,10 +544,10 @@ __global__ __launch_bounds__(256, 1) void xattn3_fwd_kernel(X2Args a) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) O[g][db] = f32x4{0.f, 0.f, 0.f, 0.f};
     stage_chunk<true, false>(smem, 0, 0, b, a.JP, a.Kp, a.Vt, wave, lane);
+    if (a.nch > 1) { stage_chunk<true, false>(smem, 1, 1, b, a.JP, a.Kp, a.Vt, wave, lane); VMCNT(16); }
+    else VMCNT(0);
+    __builtin_amdgcn_s_barrier();                                 // chunk 0 has landed for every wave
     for (int ch = 0; ch < a.nch; ++ch) {
-        if (ch + 1 < a.nch) { stage_chunk<true, false>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vt, wave, lane); VMCNT(16); }
-        else VMCNT(0);
-        __builtin_amdgcn_s_barrier();
         const char* base = smem + (ch & 1) * STAGE;
         const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
         bf16x8 bm[8];
@@ -577,7 +581,11 @@ __global__ __launch_bounds__(256, 1) void xattn3_fwd_kernel(X2Args a) {
                 }
             }
         }
+        // ONE ring barrier per chunk: own pieces of chunk ch + 1 (issued a whole iteration ago) have landed, and after the barrier
+        // (a) everyone's have, (b) everyone is done reading stage ch & 1, which chunk ch + 2 may now overwrite
+        VMCNT(0);
         __builtin_amdgcn_s_barrier();
+        if (ch + 2 < a.nch) stage_chunk<true, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, a.Vt, wave, lane);
     }
     if (qok) {
 #pragma unroll
@@ -782,6 +790,203 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// xattn4: TWO waves per 16 queries, each owning 4 of the 8 heads (scores, softmax, its 4 output heads' P'V accumulators), so a wave's
+// state (64 accumulator + 32 query-fragment registers + working set) fits 256 VGPRs and the workgroup's 8 waves put two waves on every
+// SIMD.  The xattn2 / xattn3 kernels run ONE wave per SIMD at ~500 registers and are bound by that single wave's instruction issue
+// (PMC r02b: VALU issue 43 % of the wave cycles at ~4.4 cycles per instruction, matrix pipe 10 % busy); two waves per SIMD issue
+// alternately.  The head mix needs all 8 heads of a (query, key) slot: after the softmax the pair exchanges its bf16-packed
+// probabilities through LDS (4 KiB per wave per chunk) and each wave runs the mix MFMAs for its own 4 output heads.
+// LDS: the K / V ring (2 x 64 KiB) + 8 x 4 KiB exchange slots = the whole 160 KiB (the key-valid bytes and W come from global).
+// ------------------------------------------------------------------------------------------------
+constexpr int XCH = 4096;                               // exchange slot per wave: 8 slots e x 64 lanes x 8 bytes
+template <bool WITH_B, bool B_KD>
+__device__ __forceinline__ void stage_chunk8(char* smem, int buf, int ch, int b, int JP, const bf16_t* A, const bf16_t* Bsrc, int wave, int lane) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pi = wave + 8 * i, h = pi >> 2, p = pi & 3;
+        const int r = 8 * p + (lane >> 3), gc = (lane & 7) ^ (lane >> 3);
+        const bf16_t* src = A + ((size_t)(b * NH + h) * JP + ch * 32 + r) * DH + gc * 8;
+        __builtin_amdgcn_global_load_lds((glb_cvptr)src, (lds_vptr)(base + h * TILE + p * 1024), 16, 0, 0);
+    }
+    if (WITH_B) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pi = wave + 8 * i, h = pi >> 2, p = pi & 3;
+            const bf16_t* src;
+            if (B_KD) {
+                const int r = 8 * p + (lane >> 3), gc = (lane & 7) ^ (lane >> 3);
+                src = Bsrc + ((size_t)(b * NH + h) * JP + ch * 32 + r) * DH + gc * 8;
+            } else {
+                const int d = 16 * p + (lane >> 2), gc = (lane & 3) ^ ((d >> 2) & 3);
+                src = Bsrc + ((size_t)(b * NH + h) * DH + d) * JP + ch * 32 + gc * 8;
+            }
+            __builtin_amdgcn_global_load_lds((glb_cvptr)src, (lds_vptr)(base + KT_BYTES + h * TILE + p * 1024), 16, 0, 0);
+        }
+    }
+}
+// A operand of the head-mix MFMA for output heads 4Q .. 4Q+3 (see mix_operand), rows read straight from global memory
+struct MixQ { bf16x8 hi, lo; };
+__device__ __forceinline__ MixQ mix_operand_q(const float* w /* [8][8], row = output head */, int Q, int lane) {
+    const int m = lane & 15;
+    const bool on = (m >> 2) == (lane >> 4);
+    const float* row = w + (4 * Q + (m & 3)) * 8;
+    uint32_t ph[4], pl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float x0 = row[2 * t], x1 = row[2 * t + 1];
+        ph[t] = pack2_rne(x0, x1);
+        pl[t] = pack2_rne(x0 - lo_f(ph[t]), x1 - hi_f(ph[t]));
+    }
+    MixQ a;
+    a.hi = __builtin_bit_cast(bf16x8, on ? make_uint4(ph[0], ph[1], ph[2], ph[3]) : make_uint4(0, 0, 0, 0));
+    a.lo = __builtin_bit_cast(bf16x8, on ? make_uint4(pl[0], pl[1], pl[2], pl[3]) : make_uint4(0, 0, 0, 0));
+    return a;
+}
+#define MIXQ(A_, B_) MFMA((A_).lo, B_, MFMA((A_).hi, B_, (f32x4{0.f, 0.f, 0.f, 0.f})))
+// this wave's half of the B operands (its 4 heads of every slot e) -> its exchange slot; after the workgroup barrier
+// xch_full() returns the complete 8-head operand of slot e (own half + the partner wave's)
+__device__ __forceinline__ void xch_put(char* xch_own, int lane, const float (&v)[4][8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        *reinterpret_cast<uint2*>(xch_own + e * 512 + lane * 8) = make_uint2(pack2_rne(v[0][e], v[1][e]), pack2_rne(v[2][e], v[3][e]));
+}
+__device__ __forceinline__ bf16x8 xch_full(const char* xch_own, const char* xch_par, int lane, int hh, int e) {
+    const uint2 own = *reinterpret_cast<const uint2*>(xch_own + e * 512 + lane * 8);
+    const uint2 par = *reinterpret_cast<const uint2*>(xch_par + e * 512 + lane * 8);
+    return __builtin_bit_cast(bf16x8, hh ? make_uint4(par.x, par.y, own.x, own.y) : make_uint4(own.x, own.y, par.x, par.y));
+}
+
+__global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NHH = NH / 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = wave >> 1, hh = wave & 1;                   // query tile of the workgroup, head half (heads 4 hh .. 4 hh + 3)
+    const int c = lane & 15, g4 = lane >> 4;
+    const int tiles = (a.n + 63) / 64;
+    const int b = blockIdx.x / tiles, qi = (blockIdx.x % tiles) * 64 + tile * 16 + c;
+    const bool qok = qi < a.n;
+    char* xch_own = smem + 2 * STAGE + wave * XCH;
+    const char* xch_par = smem + 2 * STAGE + (wave ^ 1) * XCH;
+    const uint32_t* vwords = reinterpret_cast<const uint32_t*>(a.valid + (size_t)b * a.JP);
+    const MixQ AW = mix_operand_q(a.wth, hh, lane);
+    const float c1 = a.scale * 1.4426950408889634f;
+    bf16x8 qf[NHH][KS];
+#pragma unroll
+    for (int h = 0; h < NHH; ++h)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            qf[h][ks] = ldg16(a.q + ((size_t)b * a.n + qi) * a.ldq + (4 * hh + h) * DH + ks * 32 + g4 * 8, qok);
+
+    // ---- pass 1: running (max, sum of exp) of this wave's 4 heads; only K is staged
+    float m[NHH], l[NHH];
+#pragma unroll
+    for (int h = 0; h < NHH; ++h) { m[h] = NEG_MAX; l[h] = 0.f; }
+    stage_chunk8<false, false>(smem, 0, 0, b, a.JP, a.Kp, nullptr, wave, lane);
+    if (a.nch > 1) { stage_chunk8<false, false>(smem, 1, 1, b, a.JP, a.Kp, nullptr, wave, lane); VMCNT(4); }
+    else VMCNT(0);
+    __builtin_amdgcn_s_barrier();                                 // chunk 0 has landed for every wave
+    for (int ch = 0; ch < a.nch; ++ch) {
+        const char* base = smem + (ch & 1) * STAGE;
+        const uint32_t vm0 = vwords[ch * 8 + g4], vm1 = vwords[ch * 8 + 4 + g4];
+#pragma unroll
+        for (int h = 0; h < NHH; ++h) {
+            f32x4 s0, s1;
+            qk_chunk(base, 4 * hh + h, c, g4, qf[h], s0, s1);
+            float s[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[r] = ((vm0 >> (8 * r)) & 0xff) ? s0[r] * c1 : NEG_MAX;
+                s[4 + r] = ((vm1 >> (8 * r)) & 0xff) ? s1[r] * c1 : NEG_MAX;
+            }
+            const float cm = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+            const float mn = fmaxf(m[h], cm);
+            float acc = l[h] * __builtin_amdgcn_exp2f(m[h] - mn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
+            l[h] = acc; m[h] = mn;
+        }
+        // ONE ring barrier per chunk: own pieces of chunk ch + 1 (issued a whole iteration ago) have landed, and after the barrier
+        // (a) everyone's have, (b) everyone is done reading stage ch & 1, which chunk ch + 2 may now overwrite
+        VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (ch + 2 < a.nch) stage_chunk8<false, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, nullptr, wave, lane);
+    }
+    float nb[NHH];
+#pragma unroll
+    for (int h = 0; h < NHH; ++h) {
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float m2 = __shfl_xor(m[h], off, 64), l2 = __shfl_xor(l[h], off, 64);
+            const float mn = fmaxf(m[h], m2);
+            l[h] = l[h] * __builtin_amdgcn_exp2f(m[h] - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
+            m[h] = mn;
+        }
+        const float il = 1.f / l[h];
+        nb[h] = __log2f(il) - m[h];
+        if (a.stats && g4 == 0 && qok) *reinterpret_cast<float2*>(a.stats + (((size_t)b * NH + 4 * hh + h) * a.n + qi) * 2) = make_float2(m[h], il);
+    }
+
+    // ---- pass 2: P of the own heads, exchange, head mix for the own output heads, O^T[g] += V^T[g] P'^T[g]
+    f32x4 O[NHH][DB];
+#pragma unroll
+    for (int g = 0; g < NHH; ++g)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) O[g][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage_chunk8<true, false>(smem, 0, 0, b, a.JP, a.Kp, a.Vt, wave, lane);
+    if (a.nch > 1) { stage_chunk8<true, false>(smem, 1, 1, b, a.JP, a.Kp, a.Vt, wave, lane); VMCNT(8); }
+    else VMCNT(0);
+    __builtin_amdgcn_s_barrier();                                 // chunk 0 has landed for every wave
+    for (int ch = 0; ch < a.nch; ++ch) {
+        const char* base = smem + (ch & 1) * STAGE;
+        const uint32_t vm0 = vwords[ch * 8 + g4], vm1 = vwords[ch * 8 + 4 + g4];
+        {
+            float P[NHH][8];
+#pragma unroll
+            for (int h = 0; h < NHH; ++h) {
+                f32x4 s0, s1;
+                qk_chunk(base, 4 * hh + h, c, g4, qf[h], s0, s1);
+                probs(s0, s1, vm0, vm1, c1, nb[h], P[h]);
+            }
+            xch_put(xch_own, lane, P);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x4 D[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) D[e] = MIXQ(AW, xch_full(xch_own, xch_par, lane, hh, e));   // D[e][rp] = P'[4 hh + rp] of slot e
+#pragma unroll
+        for (int rp = 0; rp < 4; ++rp) {
+            const int g = 4 * hh + rp;
+            const float pv[8] = {D[0][rp], D[1][rp], D[2][rp], D[3][rp], D[4][rp], D[5][rp], D[6][rp], D[7][rp]};
+            const bf16x8 pf = pack8(pv);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const int d = db * 16 + c;
+                const bf16x8 vf = lds8x2(base + KT_BYTES + dk_off(g, d, g4 >> 1) + (g4 & 1) * 8,
+                                         base + KT_BYTES + dk_off(g, d, 2 + (g4 >> 1)) + (g4 & 1) * 8);
+                O[rp][db] = MFMA(vf, pf, O[rp][db]);
+            }
+        }
+        // ONE ring barrier per chunk: own pieces of chunk ch + 1 (issued a whole iteration ago) have landed, and after the barrier
+        // (a) everyone's have, (b) everyone is done reading stage ch & 1, which chunk ch + 2 may now overwrite
+        VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (ch + 2 < a.nch) stage_chunk8<true, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, a.Vt, wave, lane);
+    }
+    if (qok) {
+#pragma unroll
+        for (int rp = 0; rp < NHH; ++rp)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                bf16_t* dst = a.o + ((size_t)b * a.n + qi) * a.ldo + (4 * hh + rp) * DH + db * 16 + g4 * 4;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(O[rp][db][0], O[rp][db][1]), pack2_rne(O[rp][db][2], O[rp][db][3]));
+            }
+    }
+}
+
 int check2(const amdnuwa_xattn_geom* g) {
     if (!g) return AMDNUWA_ERR_ARG;
     if (g->heads != NH || g->dim_head != DH || g->JP % 32 || g->JP > 288 || g->JP < g->T + 1) return AMDNUWA_ERR_UNSUPPORTED;
@@ -803,7 +1008,15 @@ extern "C" int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.o = o; a.ldo = ldo; a.stats = stats;
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
     const int tiles = (g->n + 63) / 64;
-    // tuning key 10: 1 = the VALU head mix (xattn2_fwd_kernel), 0 = the head mix on the matrix pipe (xattn3_fwd_kernel)
+    // tuning key 10: 0 = xattn4 (two waves per query tile, 4 heads each, two waves per SIMD), 2 = xattn3 (one wave, head mix on the
+    // matrix pipe), 1 = xattn2 (one wave, VALU head mix)
+    if (g_amdnuwa_tuning[10] == 0) {
+        const int lds4 = 2 * STAGE + 8 * XCH;
+        (void)hipFuncSetAttribute((const void*)xattn4_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        hipLaunchKernelGGL(xattn4_fwd_kernel, dim3(g->B * tiles), dim3(512), lds4, stream, a);
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
+    }
     auto kern = g_amdnuwa_tuning[10] == 1 ? xattn2_fwd_kernel : xattn3_fwd_kernel;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
     hipLaunchKernelGGL(kern, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
@@ -830,7 +1043,7 @@ extern "C" int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.stats = const_cast<float*>(stats); a.dS = dS; a.Pm = Pm; a.dq = dq; a.lddq = lddq; a.part_th = part_th;
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
     const int tiles = (g->n + 63) / 64;
-    auto kern = g_amdnuwa_tuning[10] == 1 ? xattn2_bwd_kernel : xattn3_bwd_kernel;
+    auto kern = g_amdnuwa_tuning[10] == 1 ? xattn2_bwd_kernel : xattn3_bwd_kernel;          // (0 and 2: xattn3_bwd)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
     hipLaunchKernelGGL(kern, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
     LAUNCH_CHECK();

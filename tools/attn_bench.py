@@ -80,7 +80,7 @@ def main():
     L.amdnuwa_set_tuning(6, 0)
     if K.xattn2_supported(g, q):
         ref = None
-        for v, name in ((1, 'xattn2 (VALU head mix)'), (0, 'xattn3 (MFMA head mix)')):      # tuning key 10
+        for v, name in ((1, 'xattn2 (1 wave/tile, VALU head mix)'), (2, 'xattn3 (1 wave/tile, MFMA head mix)'), (0, 'xattn4 (2 waves/tile)')):      # tuning key 10
             L.amdnuwa_set_tuning(10, v)
             t = bench(lambda: K.xattn2_fwd(g, q, pk, wth), args.iters)
             o2, stats = K.xattn2_fwd(g, q, pk, wth)

@@ -32,7 +32,7 @@ def main():
     keys = sorted(agg, key=lambda k: -sum(v[1] for v in agg[k].values()))
     for k in keys:
         n = max(v[0] for v in agg[k].values())
-        if not (k.startswith(('gemm_', 's3_', 'xattn_', 'ln_', 'geglu', 'conv2d', 'vq_', 'groupnorm', 'embed', 'ce_', 'partial', 'splitk', 'cast', 'transpose', 'colsum'))):
+        if not (k.startswith(('gemm_', 's3_', 'xattn', 'ln_', 'geglu', 'conv2d', 'vq_', 'groupnorm', 'embed', 'ce_', 'partial', 'splitk', 'cast', 'transpose', 'colsum'))):
             continue
         print(f'{k:56s} {n:8d} ' + ' '.join(f'{(agg[k][c][1] / agg[k][c][0]) if c in agg[k] else float("nan"):22.1f}' for c in counters))
     if '--json' in sys.argv:
