@@ -333,6 +333,11 @@ int amdnuwa_groupnorm_fwd(const float* x, const float* w, const float* b, float*
  * (eval path of vector_quantize_pytorch.VectorQuantize as called at vqgan_vae.py:368-378, 433); best_sim optional */
 int amdnuwa_vq_argmax(const float* x, const float* codebook, long long* indices, float* best_sim, long long R,
                       int n_codes, int code_dim, amdnuwa_stream stream);
+/* the same with a workspace (inverse code norms + per-slice partial arg-max): code_dim 256 runs a kernel that keeps the rows in
+ * registers as MFMA operands and cuts the code axis into slices; other widths fall through to amdnuwa_vq_argmax */
+size_t amdnuwa_vq_argmax_workspace_bytes(long long R, int n_codes);
+int amdnuwa_vq_argmax_ws(const float* x, const float* codebook, long long* indices, float* best_sim, long long R, int n_codes,
+                         int code_dim, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
 
 /* VQGanAttention block of the encoder (vqgan_vae.py:244-286), exact fp32: in-place l2 normalisation of rows (q and k over the
  * spatial axis), the per-(image, head) attention core with the continuous-position bias [heads][P][P] precomputed from the

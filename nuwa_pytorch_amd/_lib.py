@@ -105,6 +105,8 @@ SIGNATURES = {
     'amdnuwa_conv2d_fwd': (I, [CD, P, P, P, P, P]),
     'amdnuwa_groupnorm_fwd': (I, [P, P, P, P, I, I, I, I, F, I, P]),
     'amdnuwa_vq_argmax': (I, [P, P, P, P, LL, I, I, P]),
+    'amdnuwa_vq_argmax_workspace_bytes': (SZ, [LL, I]),
+    'amdnuwa_vq_argmax_ws': (I, [P, P, P, P, LL, I, I, P, SZ, P]),
     'amdnuwa_glu_chan': (I, [P, P, I, I, I, P]),
     'amdnuwa_upsample_bilinear2x': (I, [P, P, I, I, I, I, P]),
     'amdnuwa_grad_norm': (I, [P, I, F, P, P, P]),

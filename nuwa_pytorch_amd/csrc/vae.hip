@@ -212,6 +212,125 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
     }
 }
 
+// ---- VQ lookup, second form (code_dim 256): the 128 rows of a workgroup live in REGISTERS as pre-normalised MFMA A operands (a wave
+// owns 32 rows: 128 registers), the codes stream through a double-buffered k-major LDS tile of 32 codes (scaled by their inverse norm
+// on the way in: the same values F.normalize would store), and the code axis is cut in slices so that rows x slices fills the chip in
+// whole rounds.  Per code tile a wave issues 128 back-to-back v_mfma_f32_32x32x2_f32 on one accumulator (issue interval = dependent
+// latency = 64 cycles).  Ties: strict '>' inside a slice (codes scanned upwards) and across slices (combined upwards) -> lowest index.
+__global__ __launch_bounds__(256) void vq_inv_norm_kernel(const float* __restrict__ cb, float* __restrict__ inv, int Cn, int Dc) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= Cn) return;
+    float ss = 0.f;
+    for (int d = lane; d < Dc; d += 64) { const float v = cb[(size_t)c * Dc + d]; ss += v * v; }
+    ss = wave_sum(ss);
+    if (lane == 0) inv[c] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+}
+
+constexpr int VQ_TC = 32, VQ_LD = 33;        // codes per tile, LDS row stride (k-major [k][code], +1 pad)
+template <int DC>
+__global__ __launch_bounds__(256, 2) void vq_argmax2_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                            const float* __restrict__ inv_cn, float* __restrict__ part_v,
+                                                            int* __restrict__ part_i, long long R, int Cn, int per_slice) {
+    extern __shared__ float sm[];                     // [2][DC][VQ_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+    const long long r0 = (long long)blockIdx.x * 128 + wave * 32;
+    const int cbeg = blockIdx.y * per_slice, cend = min(Cn, cbeg + per_slice);
+    // A operands: a[kk] = xn[row (lane & 31)][2 kk + hi]
+    float a[DC / 2];
+    {
+        const long long row = r0 + (lane & 31);
+        const float* xr = x + (row < R ? row : R - 1) * DC + hi;
+        float ss = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < DC / 2; ++kk) { a[kk] = xr[2 * kk]; ss += a[kk] * a[kk]; }
+        ss += __shfl_xor(ss, 32, 64);
+        const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int kk = 0; kk < DC / 2; ++kk) a[kk] *= inv;
+    }
+    // staging map: thread -> code (tid >> 3) of the tile, 8 pieces of 4 consecutive k at k = (tid & 7) * 4 + 32 j
+    const int scode = tid >> 3, spart = (tid & 7) * 4;
+    float4 pre[DC / 32];
+    auto fetch = [&](int c0) {
+        const int c = c0 + scode;
+        const float sc = c < cend ? inv_cn[c] : 0.f;
+        const float* src = cb + (size_t)(c < cend ? c : cbeg) * DC + spart;
+#pragma unroll
+        for (int j = 0; j < DC / 32; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(src + 32 * j);
+            pre[j] = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+        }
+    };
+    auto stash = [&](int buf) {
+        float* base = sm + (size_t)buf * DC * VQ_LD + scode;
+#pragma unroll
+        for (int j = 0; j < DC / 32; ++j) {
+            const int k = spart + 32 * j;
+            base[(k + 0) * VQ_LD] = pre[j].x; base[(k + 1) * VQ_LD] = pre[j].y; base[(k + 2) * VQ_LD] = pre[j].z; base[(k + 3) * VQ_LD] = pre[j].w;
+        }
+    };
+    float best[16];
+    int besti[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { best[r] = -3.0e38f; besti[r] = cbeg; }
+    fetch(cbeg);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = cbeg; c0 < cend; c0 += VQ_TC, buf ^= 1) {
+        const bool more = c0 + VQ_TC < cend;
+        if (more) fetch(c0 + VQ_TC);                  // in flight under the MFMAs below
+        const float* bt = sm + (size_t)buf * DC * VQ_LD + hi * VQ_LD + (lane & 31);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < DC / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bt[2 * kk * VQ_LD], acc, 0, 0, 0);
+        const int code = c0 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (code < cend && acc[r] > best[r]) { best[r] = acc[r]; besti[r] = code; }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // lanes sharing a row hold different codes: max value, lowest index on ties
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = best[r];
+        int ix = besti[r];
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const float ov = __shfl_xor(v, o, 64);
+            const int oi = __shfl_xor(ix, o, 64);
+            if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+        }
+        const long long row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if ((lane & 31) == 0 && row < R) { part_v[(size_t)blockIdx.y * R + row] = v; part_i[(size_t)blockIdx.y * R + row] = ix; }
+    }
+}
+__global__ __launch_bounds__(256) void vq_combine_kernel(const float* __restrict__ part_v, const int* __restrict__ part_i, int S,
+                                                         long long R, long long* __restrict__ idx, float* __restrict__ best_sim) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float v = part_v[r];
+    int ix = part_i[r];
+    for (int s = 1; s < S; ++s) {                     // slices hold increasing code ranges: strict '>' keeps the lowest index
+        const float ov = part_v[(size_t)s * R + r];
+        if (ov > v) { v = ov; ix = part_i[(size_t)s * R + r]; }
+    }
+    idx[r] = ix;
+    if (best_sim) best_sim[r] = v;
+}
+static int vq_slices(long long R, int Cn) {
+    const long long rb = (R + 127) / 128;
+    int s = (int)((1024 + rb - 1) / rb);              // aim at >= 1024 workgroups (two resident per CU)
+    const int smax = (Cn + 4 * VQ_TC - 1) / (4 * VQ_TC);      // at least 4 code tiles per slice
+    if (s > smax) s = smax;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+
 // ---- VQGanAttention core (vq.py:244-286), exact fp32 ----------------------------------------------------------------
 // rows of length len: x <- x / max(||x||_2, 1e-12)   (F.normalize over the SPATIAL axis of q and k, quirk Q9)
 // (rows come in `groups` groups of rows_per_group consecutive rows, group g starting at row g * group_stride_rows)
@@ -439,6 +558,36 @@ extern "C" int amdnuwa_vq_argmax(const float* x, const float* codebook, long lon
     (void)hipFuncSetAttribute((const void*)vq_argmax_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(vq_argmax_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), lds, stream, x, codebook, indices, best_sim, R,
                        n_codes, code_dim);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" size_t amdnuwa_vq_argmax_workspace_bytes(long long R, int n_codes) {
+    if (R <= 0 || n_codes <= 0) return 0;
+    return ((size_t)n_codes + (size_t)vq_slices(R, n_codes) * (size_t)R * 2) * sizeof(float) + 64;
+}
+
+// as amdnuwa_vq_argmax, with a workspace: code_dim 256 runs the register-resident-rows kernel (~6x faster at the cfg-3 size),
+// anything else the first form
+extern "C" int amdnuwa_vq_argmax_ws(const float* x, const float* codebook, long long* indices, float* best_sim, long long R,
+                                    int n_codes, int code_dim, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (code_dim != 256 || g_amdnuwa_tuning[15] == 1) return amdnuwa_vq_argmax(x, codebook, indices, best_sim, R, n_codes, code_dim, stream);
+    if (!x || !codebook || !indices || n_codes <= 0) return AMDNUWA_ERR_ARG;
+    if (R <= 0) return AMDNUWA_OK;
+    if (!workspace || workspace_bytes < amdnuwa_vq_argmax_workspace_bytes(R, n_codes)) return AMDNUWA_ERR_WORKSPACE;
+    const int S = vq_slices(R, n_codes);
+    const int per_slice = ((n_codes + S - 1) / S + VQ_TC - 1) / VQ_TC * VQ_TC;
+    float* inv = (float*)workspace;
+    float* part_v = inv + n_codes;
+    int* part_i = (int*)(part_v + (size_t)S * R);
+    hipLaunchKernelGGL(vq_inv_norm_kernel, dim3((n_codes + 3) / 4), dim3(256), 0, stream, codebook, inv, n_codes, code_dim);
+    LAUNCH_CHECK();
+    const size_t lds = (size_t)2 * 256 * VQ_LD * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)vq_argmax2_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((vq_argmax2_kernel<256>), dim3((unsigned)((R + 127) / 128), S), dim3(256), lds, stream, x, codebook, inv, part_v,
+                       part_i, R, n_codes, per_slice);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(vq_combine_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, part_v, part_i, S, R, indices, best_sim);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

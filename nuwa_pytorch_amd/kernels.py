@@ -726,7 +726,9 @@ def vq_argmax(x, codebook, want_sim=False):
     R, Dc = x.shape
     idx = torch.empty((R,), dtype=torch.int64, device=x.device)
     sim = torch.empty((R,), dtype=torch.float32, device=x.device) if want_sim else None
-    check(L.amdnuwa_vq_argmax(_p(x), _p(codebook), _p(idx), _p(sim), R, codebook.shape[0], Dc, _stream()), 'amdnuwa_vq_argmax')
+    nb = L.amdnuwa_vq_argmax_workspace_bytes(R, codebook.shape[0])
+    ws = workspace(nb, x.device)
+    check(L.amdnuwa_vq_argmax_ws(_p(x), _p(codebook), _p(idx), _p(sim), R, codebook.shape[0], Dc, _p(ws), nb, _stream()), 'amdnuwa_vq_argmax_ws')
     return (idx, sim) if want_sim else idx
 
 

@@ -52,7 +52,7 @@ def test_groupnorm(K, N, C, H, G, leaky):
     report(f'groupnorm[{C}/{G}]', K.groupnorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), G, 1e-5, leaky=leaky), ref, 1e-5)
 
 
-@pytest.mark.parametrize('R,Cn,Dc', [(100, 64, 16), (2560, 8192, 256), (1, 5, 2), (64, 130, 32)])
+@pytest.mark.parametrize('R,Cn,Dc', [(100, 64, 16), (2560, 8192, 256), (1, 5, 2), (64, 130, 32), (131, 1000, 256), (20480, 8192, 256), (7, 33, 256)])
 def test_vq_argmax(K, O_, R, Cn, Dc):
     torch.manual_seed(2)
     x, cb = torch.randn(R, Dc), torch.randn(Cn, Dc)
@@ -75,6 +75,28 @@ def test_vq_argmax_lowest_index_on_exact_ties(K):
     x = torch.cat([cb[3:4] * 2.5, cb[17:18] * 0.3, torch.randn(5, 32)])
     idx = K.vq_argmax(x.to(DEV), cb.to(DEV)).cpu()
     assert idx[0] == 3 and idx[1] == 17
+
+
+def test_vq_argmax_sliced_form_ties_and_agreement(K):
+    """code_dim 256 runs the register-resident-rows kernel with the code axis cut in slices: duplicates placed in different slices and
+    tiles must still resolve to the lowest index, and both kernel forms must pick the same codes with the same similarity"""
+    from nuwa_pytorch_amd import _lib
+    torch.manual_seed(4)
+    cb = torch.randn(8192, 256)
+    for dup in (31, 32, 700, 4097, 8191):
+        cb[dup] = cb[5]
+    cb[8000] = cb[6000]
+    x = torch.cat([cb[5:6] * 3.0, cb[6000:6001] * 0.2, torch.randn(300, 256)]).to(DEV)
+    idx, sim = K.vq_argmax(x, cb.to(DEV), want_sim=True)
+    assert int(idx[0]) == 5 and int(idx[1]) == 6000
+    L = _lib.lib()
+    L.amdnuwa_set_tuning(15, 1)
+    try:
+        idx1, sim1 = K.vq_argmax(x, cb.to(DEV), want_sim=True)
+    finally:
+        L.amdnuwa_set_tuning(15, 0)
+    assert torch.equal(idx, idx1)
+    report('vq_sim[sliced vs first form]', sim, sim1.cpu(), 1e-5)
 
 
 @pytest.fixture(scope='module')

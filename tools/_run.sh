@@ -1,3 +1,3 @@
-export PYTHONUNBUFFERED=1 TMPDIR=/tmp
-python tools/attn_bench.py --batch 32 2>&1 | grep -i "xattn"
-python -m pytest tests/test_gpu_kernels.py -q -k "cross_attention or xattn or X_CASES or attn" --tb=short 2>&1 | tail -3
+set -x
+python -m pytest tests/test_gpu_vae.py -x -q 2>&1 | tail -5
+python tools/vae_bench.py 2>&1 | tail -25
