@@ -6,7 +6,7 @@
 //
 //   conv2d_fwd  : implicit-GEMM convolution  Y[n][co][oy][ox] = b[co] + sum_{ci,ky,kx} W[co][ci][ky][kx] X[n][ci][iy][ix]
 //                 (encoders: 5x5 pad 2; 4x4 stride 2 pad 1 + LeakyReLU(0.1); ResBlock 3x3 / 1x1 -- vq.py:352-365, 228-242)
-//                 GEMM view: M = Cout, N = batch*Ho*Wo pixels, K = Cin*KH*KW; 128x128 tile, K-step 16, 4 waves of 64x64.
+//                 GEMM view: M = Cout, N = batch*Ho*Wo pixels, K = Cin*KH*KW; 128x128 (or 64x256) tile, K-step 16, 4 waves of 64x64.
 //   groupnorm   : nn.GroupNorm(16, C) (+ LeakyReLU) of ResBlock (vq.py:233-237)
 //   vq_argmax   : idx = argmax_c <l2norm(x), l2norm(codebook[c])>  with the LOWEST index on exact ties
 //                 (restated eval path of vector_quantize_pytorch -- PARITY UNPINNED)
@@ -26,17 +26,31 @@ struct ConvArgs {
 
 // C/D layout of v_mfma_f32_32x32x2_f32: acc[reg] -> row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31
 // A operand: lane holds A[row = lane & 31][k = lane >> 5];  B operand: lane holds B[k = lane >> 5][col = lane & 31]
-constexpr int CT = 128, CK = 16;
+constexpr int CK = 16;
 
+// Tile TM output channels x TN pixels, 4 waves of 64 x 64 (2 x 2 MFMA tiles each): 128 x 128 for wide layers, 64 x 256 where
+// Cout <= 64 (half of a 128-channel tile would multiply zeros).  KS = compile-time kernel size (0: read it from the arguments).
+// The loader is the part that decides the speed of this kernel, not the MFMAs:
+//   * every thread owns ONE pixel column and wave-uniform k rows, so the (ci, ky, kx) split of k is scalar work and, with KS known,
+//     division by constants;
+//   * weights [Cout][K] are read along K (float4 per thread, four lanes per 64-byte row piece): a wave touches 16 lines per load
+//     where a per-channel column read touches 64;
+//   * the next k-tile is fetched into registers under the current tile's MFMAs and stored to the other LDS buffer: one barrier per tile.
+template <int KS, int TM, int TN>
 __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a) {
-    __shared__ float As[CK][CT + 4];     // weights  [k][co]   (+4 pad: conflict-free column reads)
-    __shared__ float Bs[CK][CT + 4];     // im2col   [k][pixel]
+    constexpr int LDA = TM + 4, LDB = TN + 4;             // +4 pad: conflict-free operand reads
+    constexpr int NA4 = TM / 64;                          // float4 weight pieces per thread and k-tile
+    constexpr int NB = CK * TN / 256;                     // im2col elements per thread and k-tile
+    __shared__ float As[2][CK][LDA];                      // weights  [k][co]
+    __shared__ float Bs[2][CK][LDB];                      // im2col   [k][pixel]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int K = a.Cin * a.KH * a.KW;
-    const long long NP = (long long)a.N * a.Ho * a.Wo;
-    const int co0 = blockIdx.y * CT;
-    const long long p0 = (long long)blockIdx.x * CT;
+    const int wm = TM == 128 ? wave >> 1 : 0, wn = TM == 128 ? wave & 1 : wave;
+    const int KH = KS ? KS : a.KH, KW = KS ? KS : a.KW, KHW = KH * KW;
+    const int K = a.Cin * KHW;
+    const int HoWo = a.Ho * a.Wo;
+    const long long NP = (long long)a.N * HoWo;
+    const int co0 = blockIdx.y * TM;
+    const long long p0 = (long long)blockIdx.x * TN;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -44,43 +58,75 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // loader: 2048 elements per operand tile / 256 threads = 8 each: thread -> column (tid & 127), k rows (tid >> 7) + 2*i
-    const int lc = tid & 127, lk = tid >> 7;
+    // im2col side: pixel column lc, k rows kb + (256 / TN) * i
+    const int lc = tid % TN;
+    const int kb = __builtin_amdgcn_readfirstlane(tid / TN);
     const long long pix = p0 + lc;
     const bool pok = pix < NP;
     int pn = 0, oy = 0, ox = 0;
-    if (pok) { pn = (int)(pix / (a.Ho * a.Wo)); const int rem = (int)(pix % (a.Ho * a.Wo)); oy = rem / a.Wo; ox = rem % a.Wo; }
+    if (pok) { pn = (int)(pix / HoWo); const int rem = (int)(pix % HoWo); oy = rem / a.Wo; ox = rem % a.Wo; }
     const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-    const int co = co0 + lc;
-    for (int k0 = 0; k0 < K; k0 += CK) {
+    const float* xb = a.x + (long long)pn * a.Cin * a.H * a.W + (long long)iy0 * a.W + ix0;      // only dereferenced where valid
+    const int HW = a.H * a.W;
+    // weight side: channel (tid >> 2) + 64 q, k piece 4 * (tid & 3)
+    const int wco = tid >> 2, wk = 4 * (tid & 3);
+    const bool w_vec = (K & 3) == 0;
+    float4 wreg[NA4];
+    float xreg[NB];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int kk = lk + 2 * i, k = k0 + kk;
-            float wv = 0.f, xv = 0.f;
-            if (k < K) {
-                if (co < a.Cout) wv = a.w[(size_t)co * K + k];
-                if (pok) {
-                    const int ci = k / (a.KH * a.KW), r = k % (a.KH * a.KW), ky = r / a.KW, kx = r % a.KW;
-                    const int iy = iy0 + ky, ix = ix0 + kx;
-                    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) xv = a.x[(((size_t)pn * a.Cin + ci) * a.H + iy) * a.W + ix];
+        for (int q = 0; q < NA4; ++q) {
+            const int co = co0 + wco + 64 * q, k = k0 + wk;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < a.Cout) {
+                const float* wp = a.w + (size_t)co * K + k;
+                if (w_vec) { if (k < K) v = *reinterpret_cast<const float4*>(wp); }
+                else {
+                    if (k + 0 < K) v.x = wp[0];
+                    if (k + 1 < K) v.y = wp[1];
+                    if (k + 2 < K) v.z = wp[2];
+                    if (k + 3 < K) v.w = wp[3];
                 }
             }
-            As[kk][lc] = wv;
-            Bs[kk][lc] = xv;
+            wreg[q] = v;
         }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int k = k0 + kb + (256 / TN) * i;           // wave-uniform
+            const int ci = k / KHW, r = k - ci * KHW, ky = r / KW, kx = r - ky * KW;
+            const bool ok = k < K && pok && (unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W;
+            xreg[i] = ok ? xb[ci * HW + ky * a.W + kx] : 0.f;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NA4; ++q) {
+            float* d = &As[buf][wk][wco + 64 * q];
+            d[0] = wreg[q].x; d[LDA] = wreg[q].y; d[2 * LDA] = wreg[q].z; d[3 * LDA] = wreg[q].w;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Bs[buf][kb + (256 / TN) * i][lc] = xreg[i];
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += CK, buf ^= 1) {
+        const bool more = k0 + CK < K;
+        if (more) fetch(k0 + CK);
 #pragma unroll
         for (int kk = 0; kk < CK; kk += 2) {
             float af[2], bf[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = As[kk + (lane >> 5)][wm * 64 + i * 32 + (lane & 31)];
+            for (int i = 0; i < 2; ++i) af[i] = As[buf][kk + (lane >> 5)][wm * 64 + i * 32 + (lane & 31)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = Bs[kk + (lane >> 5)][wn * 64 + j * 32 + (lane & 31)];
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[buf][kk + (lane >> 5)][wn * 64 + j * 32 + (lane & 31)];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        if (more) stash(buf ^ 1);
         __syncthreads();
     }
 #pragma unroll
@@ -89,14 +135,14 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a) {
         for (int j = 0; j < 2; ++j) {
             const long long px = p0 + wn * 64 + j * 32 + (lane & 31);
             if (px >= NP) continue;
-            const int n = (int)(px / (a.Ho * a.Wo)), rem = (int)(px % (a.Ho * a.Wo));
+            const int n = (int)(px / HoWo), rem = (int)(px % HoWo);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (c >= a.Cout) continue;
                 float v = acc[i][j][r] + (a.bias ? a.bias[c] : 0.f);
                 if (a.leaky) v = v > 0.f ? v : v * a.slope;
-                a.y[((size_t)n * a.Cout + c) * a.Ho * a.Wo + rem] = v;
+                a.y[((size_t)n * a.Cout + c) * HoWo + rem] = v;
             }
         }
 }
@@ -534,8 +580,25 @@ extern "C" int amdnuwa_conv2d_fwd(const amdnuwa_conv_desc* d, const float* x, co
     a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
     a.stride = d->stride; a.pad = d->pad; a.Ho = Ho; a.Wo = Wo; a.leaky = d->leaky; a.slope = 0.1f;
     const long long NP = (long long)d->N * Ho * Wo;
-    dim3 grid((unsigned)((NP + CT - 1) / CT), (d->Cout + CT - 1) / CT), block(256);
-    hipLaunchKernelGGL(conv2d_kernel, grid, block, 0, stream, a);
+    const int ks = (d->KH == d->KW && (d->KH == 1 || d->KH == 3 || d->KH == 4 || d->KH == 5)) ? d->KH : 0;
+    const bool narrow = d->Cout <= 64;
+#define CONV_GO(KS_)                                                                                                                \
+    do {                                                                                                                             \
+        if (narrow)                                                                                                                  \
+            hipLaunchKernelGGL((conv2d_kernel<KS_, 64, 256>), dim3((unsigned)((NP + 255) / 256), (d->Cout + 63) / 64), dim3(256), 0, \
+                               stream, a);                                                                                           \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((conv2d_kernel<KS_, 128, 128>), dim3((unsigned)((NP + 127) / 128), (d->Cout + 127) / 128), dim3(256), \
+                               0, stream, a);                                                                                        \
+    } while (0)
+    switch (ks) {
+        case 1: CONV_GO(1); break;
+        case 3: CONV_GO(3); break;
+        case 4: CONV_GO(4); break;
+        case 5: CONV_GO(5); break;
+        default: CONV_GO(0); break;
+    }
+#undef CONV_GO
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
