@@ -470,7 +470,119 @@ __global__ __launch_bounds__(256) void vqattn_core_kernel(const float* __restric
     for (int cc = 0; cc < 64; ++cc) if (cc < c) o[(size_t)cc * P + i] = acc[cc] * il;
 }
 
-// LayerNormChan (vq.py:178-190) over the channel axis of an NCHW tensor, + residual: one thread per (image, position)
+// The same block on the f32 MFMA for the cfg-3 shape (64 channels per head, 256 positions).  Workgroup = (image, head, half of the
+// queries), wave = 32 queries.  Everything is computed TRANSPOSED so that no operand ever needs a shuffle or an LDS round trip:
+//   S^T[j][i] = sum_c k[c][j] q[c][i]   A = k from LDS ([c][j]: lanes along j), B = q held in 32 registers ([c][i]: lanes along i)
+//   a lane then owns ONE query (i = lane & 31) and 128 of its 256 scores: the softmax reductions are in-lane plus one xor-32 exchange
+//   O^T[c][i] = sum_j v[c][j] P^T[j][i]   B = the score registers as they are (a k-step pairs key j of the low half-wave with key
+//   j + 4 of the high one; A reads v at the same pairing), A = v from LDS with row stride 257 (lanes along c: conflict-free)
+constexpr int VA_C = 64, VA_P = 256, VA_LDV = 257;
+__global__ __launch_bounds__(256) void vqattn_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                          const float* __restrict__ scale, float* __restrict__ out, int heads) {
+    extern __shared__ float sm[];
+    float* ks = sm;                         // [64][256]
+    float* vs = sm + VA_C * VA_P;           // [64][257]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, ln = lane & 31;
+    const int nh = blockIdx.x >> 1, n = nh / heads, hh = nh % heads;
+    const size_t img = (size_t)n * 3 * heads * VA_C * VA_P;
+    const float* q = qkv + img + (size_t)hh * VA_C * VA_P;
+    const float* k = qkv + img + (size_t)(heads + hh) * VA_C * VA_P;
+    const float* v = qkv + img + (size_t)(2 * heads + hh) * VA_C * VA_P;
+    for (int e = tid; e < VA_C * VA_P / 4; e += 256) {
+        const int cc = e >> 6, j4 = (e & 63) * 4;
+        *reinterpret_cast<float4*>(ks + cc * VA_P + j4) = *reinterpret_cast<const float4*>(k + cc * VA_P + j4);
+        const float4 v4 = *reinterpret_cast<const float4*>(v + cc * VA_P + j4);
+        float* d = vs + cc * VA_LDV + j4;
+        d[0] = v4.x; d[1] = v4.y; d[2] = v4.z; d[3] = v4.w;
+    }
+    const int i = (blockIdx.x & 1) * 128 + wave * 32 + ln;
+    float qb[VA_C / 2];
+#pragma unroll
+    for (int kk = 0; kk < VA_C / 2; ++kk) qb[kk] = q[(2 * kk + hi) * VA_P + i];
+    __syncthreads();
+    f32x16 st[8];
+#pragma unroll
+    for (int T = 0; T < 8; ++T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[T][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < VA_C / 2; ++kk)
+            st[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[(2 * kk + hi) * VA_P + 32 * T + ln], qb[kk], st[T], 0, 0, 0);
+    }
+    // st[T][r] = s(i, j) with j = 32 T + (r & 3) + 8 (r >> 2) + 4 hi: four consecutive keys per register quad
+    const float se = expf(scale[hh]);
+    const float* brow = bias + ((size_t)hh * VA_P + i) * VA_P;
+    float m = -3.0e38f;
+#pragma unroll
+    for (int T = 0; T < 8; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(brow + 32 * T + 8 * g + 4 * hi);
+            st[T][4 * g + 0] = st[T][4 * g + 0] * se + b4.x; st[T][4 * g + 1] = st[T][4 * g + 1] * se + b4.y;
+            st[T][4 * g + 2] = st[T][4 * g + 2] * se + b4.z; st[T][4 * g + 3] = st[T][4 * g + 3] * se + b4.w;
+            m = fmaxf(fmaxf(m, fmaxf(st[T][4 * g + 0], st[T][4 * g + 1])), fmaxf(st[T][4 * g + 2], st[T][4 * g + 3]));
+        }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int T = 0; T < 8; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[T][r] = expf(st[T][r] - m); l += st[T][r]; }
+    l += __shfl_xor(l, 32, 64);
+    f32x16 o[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+#pragma unroll
+    for (int T = 0; T < 8; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = 32 * T + (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(32 * t + ln) * VA_LDV + j], st[T][r], o[t], 0, 0, 0);
+        }
+    const float il = 1.f / l;
+    float* op = out + ((size_t)n * heads + hh) * VA_C * VA_P + i;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) op[(size_t)(32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi) * VA_P] = o[t][r] * il;
+}
+
+// LayerNormChan (vq.py:178-190) over the channel axis of an NCHW tensor, + residual.  A workgroup = 64 consecutive positions of one
+// image x 4 channel quarters: each thread keeps its C / 4 values in registers (one HBM read), statistics meet in LDS.
+template <int CQ>
+__global__ __launch_bounds__(256) void chan_layernorm_reg_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                 const float* __restrict__ b, const float* __restrict__ resid,
+                                                                 float* __restrict__ y, int HW, float eps) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6, C = 4 * CQ;
+    const int per_img = HW / 64, n = blockIdx.x / per_img, p = (blockIdx.x % per_img) * 64 + lane;
+    const size_t base = ((size_t)n * C + (size_t)part * CQ) * HW + p;
+    float v[CQ];
+    float s = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < CQ; ++ch) { v[ch] = x[base + (size_t)ch * HW]; s += v[ch]; }
+    red[0][part][lane] = s;
+    __syncthreads();
+    const float mean = ((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane])) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < CQ; ++ch) { const float d = v[ch] - mean; q += d * d; }
+    red[1][part][lane] = q;
+    __syncthreads();
+    const float den = sqrtf(((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane])) / C + eps);
+#pragma unroll
+    for (int ch = 0; ch < CQ; ++ch) {
+        const int c = part * CQ + ch;
+        float r = (v[ch] - mean) / den * g[c] + b[c];
+        if (resid) r += resid[base + (size_t)ch * HW];
+        y[base + (size_t)ch * HW] = r;
+    }
+}
+
+// LayerNormChan, any shape: one thread per (image, position)
 __global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                              const float* __restrict__ resid, float* __restrict__ y, long long NP, int C, int HW,
                                                              float eps) {
@@ -552,6 +664,13 @@ extern "C" int amdnuwa_vqattn_core(const float* qkv, const float* bias, const fl
     if (!qkv || !bias || !scale || !out || heads <= 0) return AMDNUWA_ERR_ARG;
     if (dim_head < 1 || dim_head > 64 || P < 1 || P > 256) return AMDNUWA_ERR_UNSUPPORTED;
     if (N <= 0) return AMDNUWA_OK;
+    if (dim_head == VA_C && P == VA_P && g_amdnuwa_tuning[15] != 1) {
+        const size_t lds2 = (size_t)(VA_C * VA_P + VA_C * VA_LDV) * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)vqattn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipLaunchKernelGGL(vqattn_mfma_kernel, dim3(2 * N * heads), dim3(256), lds2, stream, qkv, bias, scale, out, heads);
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
+    }
     const size_t lds = (size_t)2 * dim_head * P * sizeof(float);
     (void)hipFuncSetAttribute((const void*)vqattn_core_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(vqattn_core_kernel, dim3(N * heads), dim3(256), lds, stream, qkv, bias, scale, out, heads, dim_head, P);
@@ -564,6 +683,15 @@ extern "C" int amdnuwa_chan_layernorm(const float* x, const float* g, const floa
     if (!x || !g || !b || !y || C <= 0 || HW <= 0) return AMDNUWA_ERR_ARG;
     if (N <= 0) return AMDNUWA_OK;
     const long long NP = (long long)N * HW;
+    if (HW % 64 == 0 && g_amdnuwa_tuning[15] != 1 && (C == 512 || C == 256 || C == 128 || C == 64)) {
+        const dim3 grid((unsigned)(NP / 64));
+        if (C == 512) hipLaunchKernelGGL((chan_layernorm_reg_kernel<128>), grid, dim3(256), 0, stream, x, g, b, resid, y, HW, eps);
+        else if (C == 256) hipLaunchKernelGGL((chan_layernorm_reg_kernel<64>), grid, dim3(256), 0, stream, x, g, b, resid, y, HW, eps);
+        else if (C == 128) hipLaunchKernelGGL((chan_layernorm_reg_kernel<32>), grid, dim3(256), 0, stream, x, g, b, resid, y, HW, eps);
+        else hipLaunchKernelGGL((chan_layernorm_reg_kernel<16>), grid, dim3(256), 0, stream, x, g, b, resid, y, HW, eps);
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
+    }
     hipLaunchKernelGGL(chan_layernorm_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, x, g, b, resid, y, NP, C, HW, eps);
     LAUNCH_CHECK();
     return AMDNUWA_OK;

@@ -99,6 +99,32 @@ def test_vq_argmax_sliced_form_ties_and_agreement(K):
     report('vq_sim[sliced vs first form]', sim, sim1.cpu(), 1e-5)
 
 
+def test_vqgan_attention_mfma_form_at_cfg3_shape(K):
+    """VQGanAttention at the cfg-3 shape (512 channels, 8 heads x 64, 16 x 16 positions) runs the transposed f32-MFMA core and the
+    register LayerNormChan; against the torch module on the CPU and against the first (VALU) form of the same kernels"""
+    import nuwa_pytorch_amd as A
+    from nuwa_pytorch_amd import _lib
+    from nuwa_pytorch_amd.vqgan_vae import VQGanAttention
+    torch.manual_seed(5)
+    m = VQGanAttention(dim=512, dim_head=64, heads=8).eval()
+    with torch.no_grad():
+        m.scale.add_(torch.randn_like(m.scale) * 0.3 + 3.0)      # sharpen the softmax: a flat one would hide indexing errors
+        m.post_norm.g.mul_(torch.rand_like(m.post_norm.g) + 0.5)
+        x = torch.randn(3, 512, 16, 16)
+        ref = m(x)
+        vae = A.VQGanVAE(dim=32, image_size=32, num_layers=2, vq_codebook_size=64, vq_codebook_dim=16, use_vgg_and_gan=False)
+        md = m.to(DEV)
+        y = vae._hip_module(md, x.to(DEV))
+        L = _lib.lib()
+        L.amdnuwa_set_tuning(15, 1)
+        try:
+            y1 = vae._hip_module(md, x.to(DEV))
+        finally:
+            L.amdnuwa_set_tuning(15, 0)
+    report('vqgan_attention[mfma]', y, ref, 2e-5)
+    report('vqgan_attention[mfma vs valu]', y, y1.cpu(), 2e-5)
+
+
 @pytest.fixture(scope='module')
 def O_():
     from oracle import nuwa_oracle
