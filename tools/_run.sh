@@ -1,2 +1,3 @@
-python -m pytest tests/test_gpu_vae.py -x -q 2>&1 | tail -5
-python tools/vae_bench.py 2>&1 | tail -10
+for t in "13=1" "14=-1" "14=-1,7=8" "13=1,7=8" "14=0"; do
+  echo "== $t"; AMDNUWA_TUNING="$t" python bench.py --no-cpu-baseline --no-tokenizer --no-parity --steps 6 --warmup 2 2>&1 | tail -1 | cut -c1-160
+done
