@@ -1,6 +1,6 @@
 #!/bin/bash
 # evidence run for profiles/: default bench.py, the same under rocprofv3 --kernel-trace --stats, then separate PMC passes
-TAG=${TAG:-r02a}
+TAG=${TAG:-r02}
 mkdir -p gpurun_out; export PYTHONUNBUFFERED=1 TMPDIR=/tmp
 R=$PWD
 timeout 900 python bench.py > gpurun_out/bench_$TAG.log 2>&1; tail -n 1 gpurun_out/bench_$TAG.log | cut -c1-1800
