@@ -488,30 +488,59 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(XArgs a) {
 //   Kp, Vp [JP][DH] (row 0 = null, rows 1..T = context, rest 0) and their transposes Kt, Vt [DH][JP];
 //   valid[b][j] = 1 for j == 0, context_mask[b][j-1] for 1 <= j <= T, 0 beyond.
 // ------------------------------------------------------------------------------------------------
+// One workgroup = (b, h, block of 64 keys): 16-byte loads of the 64 x DH tile, 16-byte stores of the row-major copies, the tile
+// through LDS for the transposes (8 consecutive keys of one channel per 16-byte store).  The first form of this kernel moved 2-byte
+// elements with a JP-strided scatter for Kt / Vt and ran at 1.1 TB/s of the 100 MB it touches.
 __global__ __launch_bounds__(256) void xattn_pack_kernel(const bf16_t* __restrict__ kv, const bf16_t* __restrict__ kvl, int ldkv,
                                                          const float* __restrict__ null_k, const float* __restrict__ null_v,
                                                          const uint8_t* __restrict__ mask, bf16_t* Kp, bf16_t* Kpl, bf16_t* Kt,
                                                          bf16_t* Ktl, bf16_t* Vp, bf16_t* Vpl, bf16_t* Vt, bf16_t* Vtl,
                                                          uint8_t* valid, int B, int T, int NH, int DH, int JP) {
-    const int bh = blockIdx.x, b = bh / NH, h = bh % NH, inner = NH * DH;
+    __shared__ bf16_t tile[4][64][72];            // k hi, v hi, k lo, v lo: [key][d], rows padded to 144 bytes (16-byte aligned)
+    const int bh = blockIdx.x, b = bh / NH, h = bh % NH, inner = NH * DH, j0 = blockIdx.y * 64;
     if (h == 0 && blockIdx.y == 0)
         for (int j = threadIdx.x; j < JP; j += blockDim.x)
             valid[(size_t)b * JP + j] = j == 0 ? 1 : (j <= T ? (mask ? mask[(size_t)b * T + j - 1] : 1) : 0);
-    // grid.y slices the JP keys in blocks of 16
-    for (int e = blockIdx.y * 16 * DH + threadIdx.x; e < (blockIdx.y + 1) * 16 * DH; e += blockDim.x) {
-        const int j = e / DH, d = e % DH;
-        bf16_t kh = 0, kl = 0, vh = 0, vl = 0;
+    const int nparts = kvl ? 4 : 2, dchunks = DH / 8;
+    // load: (key, 8-channel chunk) per thread and part
+    for (int e = threadIdx.x; e < 64 * dchunks; e += blockDim.x) {
+        const int jl = e / dchunks, dc = (e % dchunks) * 8, j = j0 + jl;
+        uint4 r[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
         if (j == 0) {
-            f2bf_hilo(null_k[h * DH + d], kh, kl);
-            f2bf_hilo(null_v[h * DH + d], vh, vl);
+            bf16_t hk[8], lk[8], hv[8], lv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { f2bf_hilo(null_k[h * DH + dc + t], hk[t], lk[t]); f2bf_hilo(null_v[h * DH + dc + t], hv[t], lv[t]); }
+            r[0] = make_uint4(pack2(hk[0], hk[1]), pack2(hk[2], hk[3]), pack2(hk[4], hk[5]), pack2(hk[6], hk[7]));
+            r[1] = make_uint4(pack2(hv[0], hv[1]), pack2(hv[2], hv[3]), pack2(hv[4], hv[5]), pack2(hv[6], hv[7]));
+            r[2] = make_uint4(pack2(lk[0], lk[1]), pack2(lk[2], lk[3]), pack2(lk[4], lk[5]), pack2(lk[6], lk[7]));
+            r[3] = make_uint4(pack2(lv[0], lv[1]), pack2(lv[2], lv[3]), pack2(lv[4], lv[5]), pack2(lv[6], lv[7]));
         } else if (j <= T) {
-            const size_t g = ((size_t)b * T + j - 1) * ldkv + h * DH + d;
-            kh = kv[g]; vh = kv[g + inner];
-            if (kvl) { kl = kvl[g]; vl = kvl[g + inner]; }
+            const size_t g = ((size_t)b * T + j - 1) * ldkv + h * DH + dc;
+            r[0] = *reinterpret_cast<const uint4*>(kv + g);
+            r[1] = *reinterpret_cast<const uint4*>(kv + g + inner);
+            if (kvl) { r[2] = *reinterpret_cast<const uint4*>(kvl + g); r[3] = *reinterpret_cast<const uint4*>(kvl + g + inner); }
         }
-        const size_t o1 = ((size_t)bh * JP + j) * DH + d, o2 = ((size_t)bh * DH + d) * JP + j;
-        Kp[o1] = kh; Vp[o1] = vh; Kt[o2] = kh; Vt[o2] = vh;
-        if (Kpl) { Kpl[o1] = kl; Vpl[o1] = vl; Ktl[o2] = kl; Vtl[o2] = vl; }
+        if (j < JP) {
+            const size_t o1 = ((size_t)bh * JP + j) * DH + dc;
+            *reinterpret_cast<uint4*>(Kp + o1) = r[0];
+            *reinterpret_cast<uint4*>(Vp + o1) = r[1];
+            if (Kpl) { *reinterpret_cast<uint4*>(Kpl + o1) = r[2]; *reinterpret_cast<uint4*>(Vpl + o1) = r[3]; }
+        }
+        for (int pt = 0; pt < nparts; ++pt) *reinterpret_cast<uint4*>(&tile[pt][jl][dc]) = r[pt];
+    }
+    __syncthreads();
+    // transposes: (channel, 8-key chunk) per thread and part
+    for (int e = threadIdx.x; e < DH * 8; e += blockDim.x) {
+        const int d = e / 8, jc = (e % 8) * 8, j = j0 + jc;
+        if (j >= JP) continue;                      // (JP is a multiple of 32: whole chunks)
+        const size_t o2 = ((size_t)bh * DH + d) * JP + j;
+        for (int pt = 0; pt < nparts; ++pt) {
+            bf16_t t8[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) t8[t] = tile[pt][jc + t][d];
+            bf16_t* dst = pt == 0 ? Kt : (pt == 1 ? Vt : (pt == 2 ? Ktl : Vtl));
+            *reinterpret_cast<uint4*>(dst + o2) = make_uint4(pack2(t8[0], t8[1]), pack2(t8[2], t8[3]), pack2(t8[4], t8[5]), pack2(t8[6], t8[7]));
+        }
     }
 }
 
@@ -534,14 +563,22 @@ __global__ __launch_bounds__(256) void xattn_unpack_kernel(const float* __restri
         }
         return;
     }
-    const int bh = blockIdx.x, b = bh / NH, h = bh % NH;
-    for (int e = threadIdx.x; e < T * DH; e += blockDim.x) {
-        const int j = 1 + e / DH, d = e % DH;
-        const size_t o1 = ((size_t)bh * JP + j) * DH + d;
-        const size_t g = ((size_t)b * T + j - 1) * ldkv + h * DH + d;
-        bf16_t hh, ll;
-        f2bf_hilo(dKp[o1], hh, ll); dkv[g] = hh; if (dkvl) dkvl[g] = ll;
-        f2bf_hilo(dVp[o1], hh, ll); dkv[g + inner] = hh; if (dkvl) dkvl[g + inner] = ll;
+    const int bh = blockIdx.x, b = bh / NH, h = bh % NH, dchunks = DH / 8;
+    for (int e = threadIdx.x; e < T * dchunks; e += blockDim.x) {             // 8 channels per thread: 16-byte stores
+        const int j = 1 + e / dchunks, dc = (e % dchunks) * 8;
+        const size_t o1 = ((size_t)bh * JP + j) * DH + dc;
+        const size_t g = ((size_t)b * T + j - 1) * ldkv + h * DH + dc;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const float* src = (part ? dVp : dKp) + o1;
+            const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+            const float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            bf16_t hh[8], ll[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) f2bf_hilo(f[t], hh[t], ll[t]);
+            *reinterpret_cast<uint4*>(dkv + g + part * inner) = make_uint4(pack2(hh[0], hh[1]), pack2(hh[2], hh[3]), pack2(hh[4], hh[5]), pack2(hh[6], hh[7]));
+            if (dkvl) *reinterpret_cast<uint4*>(dkvl + g + part * inner) = make_uint4(pack2(ll[0], ll[1]), pack2(ll[2], ll[3]), pack2(ll[4], ll[5]), pack2(ll[6], ll[7]));
+        }
     }
 }
 
@@ -580,10 +617,10 @@ extern "C" int amdnuwa_xattn_pack(const amdnuwa_xattn_geom* g, const uint16_t* k
                                   const amdnuwa_xattn_kv* p, hipStream_t stream) {
     int rc = check(g);
     if (rc) return rc;
-    if (!kv || !null_k || !null_v || !p || !p->Kp || !p->Kt || !p->Vp || !p->Vt || !p->valid) return AMDNUWA_ERR_ARG;
+    if (!kv || !null_k || !null_v || !p || !p->Kp || !p->Kt || !p->Vp || !p->Vt || !p->valid || ldkv % 8) return AMDNUWA_ERR_ARG;
     if (kv_lo && (!p->Kp_lo || !p->Kt_lo || !p->Vp_lo || !p->Vt_lo)) return AMDNUWA_ERR_ARG;
     if (g->B <= 0) return AMDNUWA_OK;
-    hipLaunchKernelGGL(xattn_pack_kernel, dim3(g->B * g->heads, g->JP / 16), dim3(256), 0, stream, kv, kv_lo, ldkv, null_k, null_v, context_mask,
+    hipLaunchKernelGGL(xattn_pack_kernel, dim3(g->B * g->heads, (g->JP + 63) / 64), dim3(256), 0, stream, kv, kv_lo, ldkv, null_k, null_v, context_mask,
                        p->Kp, kv_lo ? p->Kp_lo : nullptr, p->Kt, kv_lo ? p->Kt_lo : nullptr, p->Vp, kv_lo ? p->Vp_lo : nullptr,
                        p->Vt, kv_lo ? p->Vt_lo : nullptr, p->valid, g->B, g->T, g->heads, g->dim_head, g->JP);
     LAUNCH_CHECK();
@@ -672,7 +709,7 @@ extern "C" int amdnuwa_xattn_unpack(const amdnuwa_xattn_geom* g, const float* dK
                                     hipStream_t stream) {
     int rc = check(g);
     if (rc) return rc;
-    if (!dKp || !dVp || !dkv || !dnull_k || !dnull_v) return AMDNUWA_ERR_ARG;
+    if (!dKp || !dVp || !dkv || !dnull_k || !dnull_v || ldkv % 8) return AMDNUWA_ERR_ARG;
     if (g->B <= 0) return AMDNUWA_OK;
     hipLaunchKernelGGL(xattn_unpack_kernel, dim3(g->B * g->heads + 1), dim3(256), 0, stream, dKp, dVp, dkv, dkv_lo, ldkv, dnull_k, dnull_v,
                        g->B, g->T, g->heads, g->dim_head, g->JP, accumulate);

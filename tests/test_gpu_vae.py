@@ -29,6 +29,9 @@ def K():
     (3, 64, 8, 8, 192, 1, 1, 0, False),        # 1x1 (to_qkv / project_in)
     (1, 5, 7, 9, 130, 3, 1, 1, True),          # ragged: odd sizes, Cout > one tile
     (1, 128, 16, 16, 256, 4, 2, 1, True),      # cfg-3 sized channel pair
+    (2, 6, 9, 11, 70, 2, 1, 0, False),         # kernel size without a compiled specialisation (generic k-split), Cout > 64
+    (1, 4, 12, 12, 8, 7, 1, 3, True),          # 7x7 (generic), narrow tile, K = 196 (a multiple of 4: vector weight reads)
+    (1, 3, 10, 10, 20, 3, 2, 1, False),        # K = 27: scalar weight reads, strided
 ])
 def test_conv2d(K, N, Cin, H, W, Cout, k, stride, pad, leaky):
     torch.manual_seed(0)

@@ -1,6 +1,3 @@
-R=$PWD; export TMPDIR=/tmp
-for t in "9=0" "9=8"; do
-OUT=/tmp/prof_$t; mkdir -p $OUT
-( cd /tmp && AMDNUWA_TUNING="$t" rocprofv3 --kernel-trace --stats -d $OUT -o ab -- python $R/tools/attn_bench.py --batch 64 ) > /tmp/log 2>&1
-echo "== $t"; python tools/rocpd_stats.py $OUT/ab_results.db 2>&1 | grep "s3_bwd" | head -8 | cut -c1-150
-done
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_modules.py tests/test_gpu_vae.py -x -q 2>&1 | tail -3
+python tools/attn_bench.py --batch 64 2>&1 | grep "pack"
+python bench.py --no-cpu-baseline --no-tokenizer --no-parity --steps 6 --warmup 2 2>&1 | tail -1 | cut -c1-200
