@@ -38,7 +38,7 @@ const char* amdnuwa_error_string(int code);
  *   key 5  cross-attention forward: 1 = generic (not unrolled) kernel
  *   key 6  TN GEMM variant: 1 register-staged, 2 direct-to-LDS 128x128, 3 256x256 ring
  *   key 7  NT probe: bit 0 skips the epilogue stores, bit 1 skips the main loop (tools/gemm_probe.py; results are garbage)
- *   key 8  TN 256x256 ring: 1 = lock-step wave rows instead of the staggered schedule
+ *   key 8  TN 256x256 ring: 2 = staggered wave rows instead of the lock-step schedule
  *   key 14 NT start-phase step in ~0.25 us units (0 = off)        key 15 VAE kernels: 1 = first (VALU) forms
  * (key 0 also takes 6 = 256x128 tile, two workgroups per CU, 7 = 256x256 ring with staggered wave rows, 8 = 7 + DMA issue inside the
  *  MFMA phase; any non-zero key 0 disables the few-row weight-streaming path that M <= 32 normally takes) */

@@ -52,6 +52,23 @@ __device__ __forceinline__ uint32_t pack2_rne(float a, float b) {
 __device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
+// One 1-KiB LDS-DMA piece (64 lanes x 16 bytes, lane l lands at lds + 16 l) issued through INLINE ASM.
+// Why not __builtin_amdgcn_global_load_lds: the compiler tracks the builtin as a write to LDS and, unable to see the counted
+// s_waitcnt vmcnt(N) + s_barrier that order a DMA ring, puts an `s_waitcnt vmcnt(0)` in front of every later LDS read it considers
+// aliasing (every __builtin_amdgcn_ds_read_tr16_b64, every read through an address-space-3 pointer) -- found in the ISA of all TN
+// GEMM and cross-attention loops: the ring was drained at every K-step, pieces issued a moment earlier included, so a "4-stage"
+// ring prefetched nothing.  Use ONLY where the code orders the ring explicitly (counted vmcnt + barrier); a __syncthreads() does
+// not wait for these.  `lds` must be wave-uniform.
+typedef __attribute__((address_space(3))) void* lds_vptr_t;
+// FENCE = false drops the "memory" clobber: the compiler may then move ordinary loads / stores across the piece (the counted-vmcnt
+// asm statements keep theirs, and asm volatile statements and barriers keep their order among themselves).
+template <bool FENCE = true>
+__device__ __forceinline__ void dma16_asm(const void* gsrc, void* lds) {
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_vptr_t)lds);
+    if (FENCE) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory", "m0");
+    else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "m0");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

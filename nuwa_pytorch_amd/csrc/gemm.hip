@@ -950,8 +950,9 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmArgs p, float* __
             // NARROW: columns beyond the operand are never read back (A rows >= N1 are not stored, B columns >= 64 not
             // multiplied), so those lanes skip their DMA piece instead of fetching the zero page (some lanes of every piece are
             // always active: the instruction count that s_waitcnt tracks does not change)
-            if (!NARROW || oka[j]) __builtin_amdgcn_global_load_lds((glb_cvptr)sa, (lds_vptr)(base + off), 16, 0, 0);
-            if (!NARROW || okb[j]) __builtin_amdgcn_global_load_lds((glb_cvptr)sb, (lds_vptr)(base + TN_TILE_BYTES + off), 16, 0, 0);
+            // asm pieces (common.h): every wait on them below is explicit
+            if (!NARROW || oka[j]) dma16_asm(sa, base + off);
+            if (!NARROW || okb[j]) dma16_asm(sb, base + TN_TILE_BYTES + off);
         }
     };
 
@@ -964,6 +965,7 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmArgs p, float* __
     const int nk = (int)((mend - mbeg + TK - 1) / TK);
     if (NS == 2) {
         if (nk > 0) issue(0, mbeg);
+        VMCNT(0);
         __syncthreads();
     } else {
 #pragma unroll
@@ -993,7 +995,7 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmArgs p, float* __
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        if (NS == 2) __syncthreads();
+        if (NS == 2) { VMCNT(0); __syncthreads(); }      // the other buffer has landed (it travelled under the MFMAs above); this one is free
     }
     const int fr = lane & 15, fg = lane >> 4;
     float* P = partial + ((size_t)bz * gridDim.z + z) * (size_t)N1 * N2;
@@ -1105,8 +1107,8 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmArgs p, float* __r
             }
             grow[j] += TK; pA[j] += stepA; pB[j] += stepB;
             const int off = (j * 8 + wave) * 1024;
-            __builtin_amdgcn_global_load_lds((glb_cvptr)sa, (lds_vptr)(base + off), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_cvptr)sb, (lds_vptr)(base + TB + off), 16, 0, 0);
+            dma16_asm(sa, base + off);               // (asm: see common.h -- the builtin makes the compiler drain the ring before every fragment read)
+            dma16_asm(sb, base + TB + off);
         }
     };
 
@@ -1632,7 +1634,10 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
         (void)hipFuncSetAttribute((const void*)gemm_tn_256_kernel<SH, 4, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l256); \
         hipLaunchKernelGGL((gemm_tn_256_kernel<SH, 4, ST>), g256, b256, l256, stream, p, part);                        \
     } while (0)
-        const bool stag = g_amdnuwa_tuning[8] == 0;      // tuning key 8: 1 = lock-step (non-staggered) TN ring
+        // tuning key 8: 0 = auto = lock-step, 1 = lock-step, 2 = staggered wave rows.  With the DMA pieces issued through asm (common.h:
+        // the compiler no longer drains the ring before the fragment reads) the lock-step loop gained 15-27 % and passed the staggered
+        // one on every weight-gradient shape of the step (r02: dW qkv 466 -> 340 us vs 424 staggered; dW ff1 787 -> 608 vs 773)
+        const bool stag = g_amdnuwa_tuning[8] == 2;
         if (sh) { if (stag) TN256(true, true); else TN256(true, false); }
         else    { if (stag) TN256(false, true); else TN256(false, false); }
 #undef TN256
