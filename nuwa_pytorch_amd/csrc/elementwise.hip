@@ -28,7 +28,12 @@ __device__ __forceinline__ void row_load_t(const void* base, size_t row_off, int
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
         const int e = (lane + it * 64) * 4;
-        r.v[it] = (e < D) ? ld4<BF>(base, row_off + e) : make_float4(fill, fill, fill, fill);
+        // branch-free: a load under a branch sits in its own basic block, the compiler's wait-count pass then loses the in-order count
+        // of the loads in flight and every later use waits with vmcnt(0) -- the row kernels' loads went out one at a time (seen in the
+        // ISA of the chained backward: GL [vmcnt(0)] GL [vmcnt(0)] ...).  Lanes past D re-read element 0 and select the fill.
+        const bool in = e < D;
+        const float4 v = ld4<BF>(base, row_off + (in ? e : 0));
+        r.v[it] = make_float4(in ? v.x : fill, in ? v.y : fill, in ? v.z : fill, in ? v.w : fill);
     }
 }
 
@@ -58,8 +63,16 @@ __device__ __forceinline__ void row_load(const float* __restrict__ p, int D, int
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
         const int e = (lane + it * 64) * 4;
-        r.v[it] = (e < D) ? *reinterpret_cast<const float4*>(p + e) : make_float4(fill, fill, fill, fill);
+        const bool in = e < D;                       // branch-free (see row_load_t)
+        const float4 v = *reinterpret_cast<const float4*>(p + (in ? e : 0));
+        r.v[it] = make_float4(in ? v.x : fill, in ? v.y : fill, in ? v.z : fill, in ? v.w : fill);
     }
+}
+// float4 at p + e when e < D, zeros otherwise -- without a branch (parameter vectors: weights, biases)
+__device__ __forceinline__ float4 ldp4(const float* __restrict__ p, int e, int D) {
+    const bool in = e < D;
+    const float4 v = *reinterpret_cast<const float4*>(p + (in ? e : 0));
+    return make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
 }
 __device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, float a, float b, float c, float d) {
     if (!lo) { *reinterpret_cast<uint2*>(hi + e) = make_uint2(pack2_rne(a, b), pack2_rne(c, d)); return; }
@@ -185,8 +198,9 @@ __global__ __launch_bounds__(256) void ln_post_pre_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= R) return;
-    RowValsT<NV> xv;
+    RowValsT<NV> xv, rres;
     row_load_t<XBF>(y, (size_t)row * D, D, lane, xv, 0.f);
+    row_load(resid + row * D, D, lane, rres);                   // both rows in flight together (the loads are branch-free: row_load_t)
     float mean, rstd;
     row_mean_rstd<NV>(xv, D, lane, eps, mean, rstd);
 #pragma unroll
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(256) void ln_post_pre_kernel(const float* __restric
         if (e >= D) { xv.v[it] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
         const float4 wv = *reinterpret_cast<const float4*>(w + e);
         const float4 bv = *reinterpret_cast<const float4*>(b + e);
-        const float4 rv = *reinterpret_cast<const float4*>(resid + row * D + e);
+        const float4 rv = rres.v[it];
         const float y0 = (xv.v[it].x - mean) * rstd * wv.x + bv.x;
         const float y1 = (xv.v[it].y - mean) * rstd * wv.y + bv.y;
         const float y2 = (xv.v[it].z - mean) * rstd * wv.z + bv.z;
@@ -232,6 +246,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      bf16_t* __restrict__ dx_hi, bf16_t* __restrict__ dx_lo,
                                                      float* dx_acc, const float* dres, float* __restrict__ partial,
                                                      long long R, int D, int shift_ntok, int shift_fmap) {
+#pragma clang fp contract(off)        // this kernel and the chained one must round identically: their results are compared bit for bit
     __shared__ float red[ROWS_PER_BLOCK][3][NV * 256];
     const int lane = threadIdx.x & 63, wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row math on the SALU
     float4 pw[NV], pb[NV], ps[NV];
@@ -258,12 +273,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 if (wq < shift_fmap - 1 && i + 1 < shift_ntok) src_w = row + 1;
             }
 #pragma unroll
-            for (int it = 0; it < NV; ++it) {
-                const int e = (lane + it * 64) * 4;
-                if (e >= D) { in.gv.v[it] = zero4; continue; }
+            for (int it = 0; it < NV; ++it) {                                 // branch-free (see row_load_t)
+                const int e0 = (lane + it * 64) * 4;
+                const bool inr = e0 < D;
+                const int e = inr ? e0 : 0;
                 long long src = row;
                 if (i > 0 || audio) { if (e < quarter) src = src_h; else if (e < 2 * quarter) src = src_w; }
-                in.gv.v[it] = src >= 0 ? ld4<IN == 2>(dy, (size_t)src * D + e) : zero4;
+                const bool has = src >= 0 && inr;
+                const float4 v = ld4<IN == 2>(dy, (size_t)(has ? src : row) * D + e);
+                in.gv.v[it] = make_float4(has ? v.x : 0.f, has ? v.y : 0.f, has ? v.z : 0.f, has ? v.w : 0.f);
             }
         } else {
             row_load_t<IN == 2>(dy, (size_t)row * D, D, lane, in.gv);
@@ -289,8 +307,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
             const int e = (lane + it * 64) * 4;
-            if (e >= D) { xh[it] = g[it] = zero4; continue; }
-            const float4 wv = *reinterpret_cast<const float4*>(w + e);
+            const float4 wv = ldp4(w, e, D);             // (lanes past D hold zeros in every row value: their terms vanish)
             float4 xx = cur.xv.v[it];
             const float4 gg = cur.gv.v[it];
             if (STABLE) { xx.x *= ia; xx.y *= ia; xx.z *= ia; xx.w *= ia; }
@@ -359,6 +376,7 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
                                                            bf16_t* __restrict__ dyp_lo, float* __restrict__ partA,
                                                            float* __restrict__ partB, long long R, int D, int shift_ntok,
                                                            int shift_fmap) {
+#pragma clang fp contract(off)        // (see ln_bwd_kernel)
     __shared__ float red[ROWS_PER_BLOCK][3][NV * 256];
     const int lane = threadIdx.x & 63, wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4 pwA[NV], pbA[NV], pwB[NV], pbB[NV], psB[NV];
@@ -385,11 +403,15 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
             }
 #pragma unroll
             for (int it = 0; it < NV; ++it) {
-                const int e = (lane + it * 64) * 4;
-                if (e >= D) { in.gv.v[it] = zero4; continue; }
+                const int e0 = (lane + it * 64) * 4;
+                const bool inr = e0 < D;
+                const int e = inr ? e0 : 0;
                 long long src = row;
                 if (i > 0 || audio) { if (e < quarter) src = src_h; else if (e < 2 * quarter) src = src_w; }
-                in.gv.v[it] = src >= 0 ? ((NT & 2) ? ld4_nt<BF>(dh, (size_t)src * D + e) : ld4<BF>(dh, (size_t)src * D + e)) : zero4;
+                const bool has = src >= 0 && inr;                                    // branch-free: rows without a source re-read their own row
+                const size_t so = (size_t)(has ? src : row) * D + e;
+                const float4 v = (NT & 2) ? ld4_nt<BF>(dh, so) : ld4<BF>(dh, so);
+                in.gv.v[it] = make_float4(has ? v.x : 0.f, has ? v.y : 0.f, has ? v.z : 0.f, has ? v.w : 0.f);
             }
         } else {
             row_load_t<BF>(dh, (size_t)row * D, D, lane, in.gv);
@@ -419,8 +441,7 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
             const int e = (lane + it * 64) * 4;
-            if (e >= D) { xh[it] = g[it] = zero4; continue; }
-            const float4 wv = *reinterpret_cast<const float4*>(w + e);
+            const float4 wv = ldp4(w, e, D);             // (lanes past D hold zeros in every row value: their terms vanish)
             const float4 xx = cur.xv.v[it], gg = cur.gv.v[it];
             xh[it] = make_float4((xx.x - cur.mean) * cur.rstd, (xx.y - cur.mean) * cur.rstd, (xx.z - cur.mean) * cur.rstd, (xx.w - cur.mean) * cur.rstd);
             g[it] = make_float4(gg.x * wv.x, gg.y * wv.y, gg.z * wv.z, gg.w * wv.w);
@@ -445,8 +466,7 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
             const int e = (lane + it * 64) * 4;
-            if (e >= D) { xh[it] = g[it] = zero4; continue; }
-            const float4 wv = *reinterpret_cast<const float4*>(wprev + e);
+            const float4 wv = ldp4(wprev, e, D);
             const float4 yy = cur.yv.v[it], gg = dx[it];
             xh[it] = make_float4((yy.x - cur.meanp) * cur.rstdp, (yy.y - cur.meanp) * cur.rstdp, (yy.z - cur.meanp) * cur.rstdp, (yy.w - cur.meanp) * cur.rstdp);
             g[it] = make_float4(gg.x * wv.x, gg.y * wv.y, gg.z * wv.z, gg.w * wv.w);
