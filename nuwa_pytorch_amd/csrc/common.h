@@ -69,6 +69,24 @@ __device__ __forceinline__ void dma16_asm(const void* gsrc, void* lds) {
     else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "m0");
 }
 
+// 64 per-lane values v[0..63] -> lane l receives sum over all 64 lanes of v[l].  Halving butterfly: at distance `off` a lane keeps the
+// half of its values whose index has that bit equal to its own lane bit and sends the other half: 32 + 16 + ... + 1 = 63 exchanges,
+// all independent within a step, instead of 64 x 6 dependent ones for 64 separate wave_sum() calls (measured in the cross-attention
+// backward: 384 serialized ds_bpermute round trips per workgroup).  Fixed order: deterministic.
+__device__ __forceinline__ float wave_sum64_transposed(float (&v)[64], int lane) {
+#pragma unroll
+    for (int off = 32, cnt = 32; off >= 1; off >>= 1, cnt >>= 1) {
+        const bool upper = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < cnt; ++i) {
+            const float send = upper ? v[i] : v[i + cnt];
+            const float keep = upper ? v[i + cnt] : v[i];
+            v[i] = keep + __shfl_xor(send, off, 64);
+        }
+    }
+    return v[0];
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

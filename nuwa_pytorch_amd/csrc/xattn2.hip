@@ -393,14 +393,15 @@ __global__ __launch_bounds__(256, 1) void xattn2_bwd_kernel(X2Args a) {
         }
         delta[h] = acc;
     }
-    // dW_th partial of this workgroup (fixed order over the 4 waves)
+    // dW_th partial of this workgroup (fixed order over the 4 waves): lane l ends up with the wave's sum of entry l = g * NH + h
+    {
+        float tv[NH * NH];
 #pragma unroll
-    for (int g = 0; g < NH; ++g)
+        for (int g = 0; g < NH; ++g)
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            const float s = wave_sum(qok ? dth[g][h] : 0.f);
-            if (lane == 0) thsh[wave][g * NH + h] = s;
-        }
+            for (int h = 0; h < NH; ++h) tv[g * NH + h] = qok ? dth[g][h] : 0.f;
+        thsh[wave][lane] = wave_sum64_transposed(tv, lane);
+    }
     __syncthreads();
     if (tid < NH * NH) a.part_th[(size_t)blockIdx.x * NH * NH + tid] = ((thsh[0][tid] + thsh[1][tid]) + thsh[2][tid]) + thsh[3][tid];
 
@@ -712,14 +713,15 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
         delta[h] += __shfl_xor(delta[h], 16, 64);
         delta[h] += __shfl_xor(delta[h], 32, 64);
     }
-    // dW_th partial of this workgroup (fixed order over the 4 waves)
+    // dW_th partial of this workgroup (fixed order over the 4 waves): lane l ends up with the wave's sum of entry l = g * NH + h
+    {
+        float tv[NH * NH];
 #pragma unroll
-    for (int g = 0; g < NH; ++g)
+        for (int g = 0; g < NH; ++g)
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            const float s = wave_sum(qok ? dth[g][h] : 0.f);
-            if (lane == 0) thsh[wave][g * NH + h] = s;
-        }
+            for (int h = 0; h < NH; ++h) tv[g * NH + h] = qok ? dth[g][h] : 0.f;
+        thsh[wave][lane] = wave_sum64_transposed(tv, lane);
+    }
     __syncthreads();
     if (tid < NH * NH) a.part_th[(size_t)blockIdx.x * NH * NH + tid] = ((thsh[0][tid] + thsh[1][tid]) + thsh[2][tid]) + thsh[3][tid];
 
