@@ -628,6 +628,19 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
     } else if constexpr (EPI == 1) {
         // lane (fr, fg) owns row m = .. + fr and the 16 contiguous columns n = n0 + wn*64 + fg*16 + [j*4 + r]
         const bool vec8 = (p.N % 8 == 0) && (p.ldc % 8 == 0);
+        // the lane's 16 columns are the same for all 8 row fragments: their bias values are loaded ONCE, without a branch.  (Loaded
+        // per element inside the row loop each load sat under a branch and was followed by s_waitcnt vmcnt(0) -- which also waits for
+        // the STORES of the previous row fragment: 128 dependent round trips per wave and tile on every Linear with a bias.)
+        float bias16[16];
+        {
+            const int nbl = n0 + wn * 64 + fg * 16;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool in = p.bias != nullptr && nbl + e < p.N;
+                const float bvv = (p.bias ? p.bias : reinterpret_cast<const float*>(g_zero_page))[in ? nbl + e : 0];
+                bias16[e] = in ? bvv : 0.f;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
@@ -639,11 +652,7 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] * p.alpha;
-                    if (p.bias && nb + j * 4 + r < p.N) v += p.bias[nb + j * 4 + r];
-                    vv[j * 4 + r] = v;
-                }
+                for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha + bias16[j * 4 + r];
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
             bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;
             if (!Cl && vec8 && nb + 16 <= p.N) {
@@ -711,6 +720,16 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
             }
         }
     } else {
+    float biasf[4][4];                               // (loaded once, branch-free: see the bf16 epilogue)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * 64 + j * 16 + fg * 4 + r;
+            const bool in = p.bias != nullptr && n < p.N;
+            const float bvv = (p.bias ? p.bias : reinterpret_cast<const float*>(g_zero_page))[in ? n : 0];
+            biasf[j][r] = in ? bvv : 0.f;
+        }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
@@ -722,10 +741,7 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
             if ((p.dbg & 1) && acc[i][j][0] != 12345.678f) continue;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[i][j][r] * p.alpha;
-                if (p.bias && n + r < p.N) v[r] += p.bias[n + r];
-            }
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha + biasf[j][r];
             float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
             if (vec_ok) *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
             else
