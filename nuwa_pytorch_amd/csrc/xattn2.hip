@@ -111,12 +111,18 @@ __device__ __forceinline__ void stage_chunk(char* smem, int buf, int ch, int b, 
 // S^T chunk of head h: rows = keys (2 blocks of 16), cols = the wave's 16 queries
 __device__ __forceinline__ void qk_chunk(const char* base, int h, int c, int g4, const bf16x8 (&qf)[KS], f32x4& s0, f32x4& s1) {
     s0 = s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    // all four fragment reads first, then the four MFMAs: one exposed LDS round trip per head instead of two (the compiler keeps the
+    // source order: "R R wait M M R R wait M M" in the ISA of the first form)
+    bf16x8 k0[KS], k1[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 k0 = lds16(base + kd_off(h, c, ks * 4 + g4));
-        const bf16x8 k1 = lds16(base + kd_off(h, 16 + c, ks * 4 + g4));
-        s0 = MFMA(k0, qf[ks], s0);
-        s1 = MFMA(k1, qf[ks], s1);
+        k0[ks] = lds16(base + kd_off(h, c, ks * 4 + g4));
+        k1[ks] = lds16(base + kd_off(h, 16 + c, ks * 4 + g4));
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        s0 = MFMA(k0[ks], qf[ks], s0);
+        s1 = MFMA(k1[ks], qf[ks], s1);
     }
 }
 // normalised probabilities of the 8 keys this lane holds (slots e = kb*4 + r), 0 where the key is masked:
