@@ -641,6 +641,58 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
                 bias16[e] = in ? bvv : 0.f;
             }
         }
+        // GEGLU backward from (product = dgg, u): du = (dgg * gelu(gate), dgg * value * gelu'(gate)) in u's interleaved layout
+        auto geglu_bwd_store = [&](const uint4& ua, const uint4& ug, const uint4 (&uu)[4], uint4* dp) {
+            const uint4 dg2[2] = {ua, ug};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint4 av = uu[2 * q], gv = uu[2 * q + 1];
+                const uint32_t wa[4] = {av.x, av.y, av.z, av.w}, wg[4] = {gv.x, gv.y, gv.z, gv.w};
+                const uint32_t wd[4] = {dg2[q].x, dg2[q].y, dg2[q].z, dg2[q].w};
+                float da[8], dgt[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float y, dy;
+                    gelu_both_f(lo_f(wg[k]), y, dy);
+                    da[2 * k] = lo_f(wd[k]) * y;
+                    dgt[2 * k] = lo_f(wd[k]) * lo_f(wa[k]) * dy;
+                    gelu_both_f(hi_f(wg[k]), y, dy);
+                    da[2 * k + 1] = hi_f(wd[k]) * y;
+                    dgt[2 * k + 1] = hi_f(wd[k]) * hi_f(wa[k]) * dy;
+                }
+                dp[2 * q] = make_uint4(pack2_rne(da[0], da[1]), pack2_rne(da[2], da[3]), pack2_rne(da[4], da[5]), pack2_rne(da[6], da[7]));
+                dp[2 * q + 1] = make_uint4(pack2_rne(dgt[0], dgt[1]), pack2_rne(dgt[2], dgt[3]), pack2_rne(dgt[4], dgt[5]), pack2_rne(dgt[6], dgt[7]));
+            }
+        };
+        if (p.Uin && !p.Clo && vec8 && m0 + 256 <= p.M && n0 + BN <= p.N && !p.dbg) {
+            // full tile of the GEGLU backward: a straight-line loop with u of the NEXT row fragment in flight while this one is finished
+            // (in the generic loop below every fragment's loads sit behind its row checks and wait with vmcnt(0) -- on the previous
+            // fragment's stores as well)
+            const int nb = n0 + wn * 64 + fg * 16;
+            const bf16_t* ubase = p.Uin + ((long long)m0 + wm * 128 + fr) * p.ldu + 2 * nb;
+            bf16_t* dbase = p.C2 + ((long long)m0 + wm * 128 + fr) * p.ldc2 + 2 * nb;
+            uint4 un[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) un[q] = reinterpret_cast<const uint4*>(ubase)[q];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint4 uc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) uc[q] = un[q];
+                if (i + 1 < 8) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) un[q] = reinterpret_cast<const uint4*>(ubase + (long long)(i + 1) * 16 * p.ldu)[q];
+                }
+                float vv[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha + bias16[j * 4 + r];
+                const uint4 ua = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
+                const uint4 ug = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
+                geglu_bwd_store(ua, ug, uc, reinterpret_cast<uint4*>(dbase + (long long)i * 16 * p.ldc2));
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
@@ -662,27 +714,8 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
                     // GEGLU backward: the lane's 16 columns of dgg (as bf16, like the stand-alone kernel reads them) meet the two
                     // 16-column groups [8 values | 8 gates] of u they belong to; du leaves in the same interleaved layout
                     const uint4* up = reinterpret_cast<const uint4*>(p.Uin + m * p.ldu + 2 * nb);
-                    uint4* dp = reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + 2 * nb);
-                    const uint4 dg2[2] = {ua, ug};
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const uint4 av = up[2 * q], gv = up[2 * q + 1];
-                        const uint32_t wa[4] = {av.x, av.y, av.z, av.w}, wg[4] = {gv.x, gv.y, gv.z, gv.w};
-                        const uint32_t wd[4] = {dg2[q].x, dg2[q].y, dg2[q].z, dg2[q].w};
-                        float da[8], dgt[8];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            float y, dy;
-                            gelu_both_f(lo_f(wg[k]), y, dy);
-                            da[2 * k] = lo_f(wd[k]) * y;
-                            dgt[2 * k] = lo_f(wd[k]) * lo_f(wa[k]) * dy;
-                            gelu_both_f(hi_f(wg[k]), y, dy);
-                            da[2 * k + 1] = hi_f(wd[k]) * y;
-                            dgt[2 * k + 1] = hi_f(wd[k]) * hi_f(wa[k]) * dy;
-                        }
-                        dp[2 * q] = make_uint4(pack2_rne(da[0], da[1]), pack2_rne(da[2], da[3]), pack2_rne(da[4], da[5]), pack2_rne(da[6], da[7]));
-                        dp[2 * q + 1] = make_uint4(pack2_rne(dgt[0], dgt[1]), pack2_rne(dgt[2], dgt[3]), pack2_rne(dgt[4], dgt[5]), pack2_rne(dgt[6], dgt[7]));
-                    }
+                    const uint4 uu[4] = {up[0], up[1], up[2], up[3]};
+                    geglu_bwd_store(ua, ug, uu, reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + 2 * nb));
                     continue;
                 }
                 reinterpret_cast<uint4*>(C)[0] = ua;
