@@ -1243,6 +1243,32 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
                                      int batch_inner, int ldc, int N1, int N2, int splits, float alpha, float beta) {
     const size_t per = (size_t)N1 * N2;
     const int bz = blockIdx.y;
+    if ((N2 & 3) == 0 && (ldc & 3) == 0 && (sC & 3) == 0 && (sC_in & 3) == 0 && (reinterpret_cast<size_t>(C) & 15) == 0) {
+        // four columns per thread, eight splits in flight: the scalar form below issued ONE 4-byte load per iteration and waited for it
+        // (dependent add).  The adds keep their order (split 0, 1, 2, ...), so the sums are bit-identical to the scalar form's.
+        const size_t per4 = per >> 2;
+        for (size_t e4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e4 < per4; e4 += (size_t)gridDim.x * blockDim.x) {
+            const size_t e = e4 << 2;
+            const float* P = partial + (size_t)bz * splits * per + e;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            int z = 0;
+            for (; z + 8 <= splits; z += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(P + (size_t)(z + u) * per);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            }
+            for (; z < splits; ++z) { const float4 v = *reinterpret_cast<const float4*>(P + (size_t)z * per); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+            const int n1 = (int)(e / N2), n2 = (int)(e % N2);
+            const long long oC = batch_inner > 0 ? (long long)(bz / batch_inner) * sC + (long long)(bz % batch_inner) * sC_in : (long long)bz * sC;
+            float* c = C + oC + (size_t)n1 * ldc + n2;
+            float4 o = make_float4(alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w);
+            if (beta != 0.f) { const float4 cv = *reinterpret_cast<const float4*>(c); o.x = beta * cv.x + o.x; o.y = beta * cv.y + o.y; o.z = beta * cv.z + o.z; o.w = beta * cv.w + o.w; }
+            *reinterpret_cast<float4*>(c) = o;
+        }
+        return;
+    }
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         const float* P = partial + (size_t)bz * splits * per + e;
