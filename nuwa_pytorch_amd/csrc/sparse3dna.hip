@@ -676,8 +676,22 @@ __global__ __launch_bounds__(1024) void s3_bwd_fin_kernel(S3Args a, int DH) {
         const int nn = a.NH * a.NH;
         const int col = (blockIdx.x - a.B * nchunk) * 16 + (threadIdx.x & 15), rg64 = threadIdx.x >> 4;
         float s = 0.f;
-        if (col < nn)
-            for (int k = rg64; k < a.B * rows; k += 64) s += a.part_th[(size_t)k * nn + col];
+        if (col < nn) {
+            // eight partials in flight per thread, added in their index order (one dependent 4-byte load per iteration made this
+            // block the 80-us critical path of the kernel); indices past the end re-read row 0 and add zero
+            const int n = a.B * rows;
+            for (int k = rg64; k < n; k += 64 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ku = k + 64 * u;
+                    const float t = a.part_th[(size_t)(ku < n ? ku : 0) * nn + col];
+                    v[u] = ku < n ? t : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+        }
         redw[rg64][threadIdx.x & 15] = s;
         __syncthreads();
         if (rg64 == 0 && col < nn) {
@@ -714,9 +728,17 @@ __global__ __launch_bounds__(1024) void s3_bwd_fin_kernel(S3Args a, int DH) {
     const int b = blockIdx.x / nchunk, e = (blockIdx.x % nchunk) * 64 + lane;
     float sk = 0.f, sv = 0.f;
     if (e < inner)
-        for (int r = rg; r < rows; r += 16) {
-            sk += a.part_k0[((size_t)b * rows + r) * inner + e];
-            sv += a.part_v0[((size_t)b * rows + r) * inner + e];
+        for (int r = rg; r < rows; r += 16 * 4) {                // four row partials in flight per thread, added in order
+            float vk[4], vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ru = r + 16 * u;
+                const size_t o = ((size_t)b * rows + (ru < rows ? ru : 0)) * inner + e;
+                const float tk = a.part_k0[o], tv = a.part_v0[o];
+                vk[u] = ru < rows ? tk : 0.f; vv[u] = ru < rows ? tv : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { sk += vk[u]; sv += vv[u]; }
         }
     red[0][rg][lane] = sk;
     red[1][rg][lane] = sv;
