@@ -535,7 +535,17 @@ __global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __res
     const int idx = blockIdx.x * 16 + col;
     float s = 0.f;
     if (idx < nk * D)
-        for (int bidx = rg; bidx < nblk; bidx += 64) s += partial[(size_t)bidx * nk * D + idx];
+        for (int bidx = rg; bidx < nblk; bidx += 64 * 4) {          // four partials in flight, added in index order
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bu = bidx + 64 * u;
+                const float t = partial[(size_t)(bu < nblk ? bu : 0) * nk * D + idx];
+                v[u] = bu < nblk ? t : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
     red[rg][col] = s;
     __syncthreads();
     if (rg == 0 && idx < nk * D) {

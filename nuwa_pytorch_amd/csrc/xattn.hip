@@ -554,9 +554,17 @@ __global__ __launch_bounds__(256) void xattn_unpack_kernel(const float* __restri
         for (int e = threadIdx.x; e < inner; e += blockDim.x) {
             const int h = e / DH, d = e % DH;
             float sk = 0.f, sv = 0.f;
-            for (int b = 0; b < B; ++b) {
-                const size_t o = (((size_t)b * NH + h) * JP) * DH + d;
-                sk += dKp[o]; sv += dVp[o];
+            for (int b = 0; b < B; b += 8) {                     // eight samples in flight, added in order (was one dependent load per sample)
+                float vk[8], vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = b + u < B;
+                    const size_t o = (((size_t)(in ? b + u : 0) * NH + h) * JP) * DH + d;
+                    const float tk = dKp[o], tv = dVp[o];
+                    vk[u] = in ? tk : 0.f; vv[u] = in ? tv : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { sk += vk[u]; sv += vv[u]; }
             }
             dnull_k[e] = accumulate ? dnull_k[e] + sk : sk;
             dnull_v[e] = accumulate ? dnull_v[e] + sv : sv;
@@ -573,11 +581,15 @@ __global__ __launch_bounds__(256) void xattn_unpack_kernel(const float* __restri
             const float* src = (part ? dVp : dKp) + o1;
             const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
             const float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            if (!dkvl) {                                         // bf16 mode: the hardware converter (RNE, as f2bf)
+                *reinterpret_cast<uint4*>(dkv + g + part * inner) = make_uint4(pack2_rne(f[0], f[1]), pack2_rne(f[2], f[3]), pack2_rne(f[4], f[5]), pack2_rne(f[6], f[7]));
+                continue;
+            }
             bf16_t hh[8], ll[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) f2bf_hilo(f[t], hh[t], ll[t]);
             *reinterpret_cast<uint4*>(dkv + g + part * inner) = make_uint4(pack2(hh[0], hh[1]), pack2(hh[2], hh[3]), pack2(hh[4], hh[5]), pack2(hh[6], hh[7]));
-            if (dkvl) *reinterpret_cast<uint4*>(dkvl + g + part * inner) = make_uint4(pack2(ll[0], ll[1]), pack2(ll[2], ll[3]), pack2(ll[4], ll[5]), pack2(ll[6], ll[7]));
+            *reinterpret_cast<uint4*>(dkvl + g + part * inner) = make_uint4(pack2(ll[0], ll[1]), pack2(ll[2], ll[3]), pack2(ll[4], ll[5]), pack2(ll[6], ll[7]));
         }
     }
 }
