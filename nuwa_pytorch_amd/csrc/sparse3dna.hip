@@ -1145,12 +1145,22 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     // <bos> partials of this row: dk0[e] = scale * sum_w ds[w][0][h] q[w][e],  dv0[e] = sum_w P'[w][0][g] dO[w][e]
     for (int e = t; e < inner; e += blockDim.x) {
         const int h = e / DH;
-        float sk = 0.f, sv = 0.f;
+        // all W rows of q and dO in flight at once, branch-free (rows past the sequence re-read the last valid one and add zero); the
+        // loop with an early exit issued one dependent 2-byte load pair per iteration: 16 L2 round trips at the tail of every workgroup
+        float qv[W], dv_[W];
+#pragma unroll
         for (int w = 0; w < W; ++w) {
             const int i = 1 + ry * W + w;
-            if (i >= a.ntok) break;
-            sk += DP[(w * J) * NH + h] * bf2f(a.q[(r.tok0 + i) * a.ld + e]);
-            sv += PM0[w * NH + h] * bf2f(a.dO[(r.tok0 + i) * a.lddo + e]);
+            const size_t ic = r.tok0 + (i < a.ntok ? i : a.ntok - 1);
+            qv[w] = bf2f(a.q[ic * a.ld + e]);
+            dv_[w] = bf2f(a.dO[ic * a.lddo + e]);
+        }
+        float sk = 0.f, sv = 0.f;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const bool in = 1 + ry * W + w < a.ntok;
+            sk += in ? DP[(w * J) * NH + h] * qv[w] : 0.f;
+            sv += in ? PM0[w * NH + h] * dv_[w] : 0.f;
         }
         pk0[e] = a.scale * sk;
         pv0[e] = sv;
