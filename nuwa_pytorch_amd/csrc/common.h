@@ -87,14 +87,28 @@ __device__ __forceinline__ float wave_sum64_transposed(float (&v)[64], int lane)
     return v[0];
 }
 
+// Wave reductions: the four steps inside a row of 16 lanes are DPP operands of the add itself (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror: no LDS crossbar round trip), the two steps across rows are ds_bpermute.  Every lane ends with the result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_f<0xB1>(v);            // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);            // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);           // row_half_mirror
+    v += dpp_f<0x140>(v);           // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 
