@@ -280,7 +280,8 @@ typedef struct {            /* all [B][heads][JP][dim_head] (Kp, Vp) or [B][head
 } amdnuwa_xattn_kv;
 
 int amdnuwa_xattn_jp(int T);
-/* kv: [B*T, ldkv] bf16, keys in columns [0, inner), values in [inner, 2*inner) (= to_kv(context)) */
+/* kv: [B*T, ldkv] bf16, keys in columns [0, inner), values in [inner, 2*inner) (= to_kv(context)); ldkv % 8 == 0 and 16-byte
+ * aligned bases (the kernels move 16-byte pieces), AMDNUWA_ERR_ARG otherwise -- the same holds for amdnuwa_xattn_unpack */
 int amdnuwa_xattn_pack(const amdnuwa_xattn_geom* g, const uint16_t* kv, const uint16_t* kv_lo, int ldkv,
                        const float* null_k, const float* null_v, const uint8_t* context_mask,
                        const amdnuwa_xattn_kv* packed, amdnuwa_stream stream);
