@@ -200,7 +200,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=64, help='samples per GPU (weak scaling)')
+    ap.add_argument('--batch', type=int, default=None,
+                    help='samples per GPU (weak scaling); default: 128 for cfg3 in bf16 (209 GB of the 288 GB; +2.8 %% tokens/s over 64), 64 for the other configs, 16 in bf16x3')
     ap.add_argument('--config', default='cfg3', choices=list(CFGS))
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3'], help='mode of the HEADLINE value')
     ap.add_argument('--parity-batch', type=int, default=16, help="samples per GPU of the 'bf16x3' side measurement")
@@ -239,7 +240,7 @@ def main():
         p.requires_grad_(True)
     reducer = GradReducer(nuwa, collective=args.collective) if world > 1 else None
 
-    b = args.batch
+    b = args.batch if args.batch else ((128 if args.config == 'cfg3' else 64) if args.precision == 'bf16' else 16)
     N = c['frames'] * c['fmap'] ** 2
     ids, ctx, mask = synthetic_batch(c, b, rank, dev)
 
@@ -296,6 +297,8 @@ def main():
 
     # ---- 'bf16x3' (parity mode) throughput beside the headline, smaller batch (its saved activations are ~2.7x larger)
     parity_mode = None
+    loss = None
+    torch.cuda.empty_cache()          # the parity-mode pass allocates differently sized activations: hand the cached blocks back first
     if not args.no_parity and args.precision == 'bf16':
         pb = max(1, min(args.parity_batch, b))
         pbatch = (ids[:pb].contiguous(), ctx[:pb].contiguous(), mask[:pb].contiguous())
