@@ -16,5 +16,5 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFM
   echo "pmc $tag rc=$?"
 done
 python tools/pmc_summary.py gpurun_out/pmc_${TAG}_*/pmc_counter_collection.csv > gpurun_out/pmc_${TAG}_summary.txt 2>&1
-python tools/pmc_summary.py gpurun_out/pmc_${TAG}_FETCH_SIZE/pmc_counter_collection.csv gpurun_out/pmc_${TAG}_WRITE_SIZE/pmc_counter_collection.csv --json gpurun_out/traffic_$TAG.json --key cfg3_b${BATCH:-64} > gpurun_out/pmc_${TAG}_hbm.txt 2>&1; tail -n 2 gpurun_out/pmc_${TAG}_hbm.txt
+python tools/pmc_summary.py gpurun_out/pmc_${TAG}_FETCH_SIZE/pmc_counter_collection.csv gpurun_out/pmc_${TAG}_WRITE_SIZE/pmc_counter_collection.csv --json gpurun_out/traffic_$TAG.json --key cfg3_b${BATCH:-128} > gpurun_out/pmc_${TAG}_hbm.txt 2>&1; tail -n 2 gpurun_out/pmc_${TAG}_hbm.txt
 find gpurun_out/pmc_${TAG}_* -name "*.csv" -size +8M -delete
