@@ -888,6 +888,57 @@ __device__ __forceinline__ void mfma_band_scores(const S3Args& a, const RowM& r,
 // as O^T = ROWS^T . TAB^T: the rows of TWO planes (32 keys) are staged in the wave-private 4 KiB LDS tile and read back
 // transposed (ds_read_b64_tr_b16) as the A operand; the banded coefficients of the lane's 8 key slots come from TAB.
 // Lane (c, g4) ends with O[db][q] = out[query c][db*16 + 4*g4 + q].
+// The same scores with the key rows STAGED through a wave-private LDS tile ([16 keys][64] bf16, 2 KiB): every lane fetches two
+// 16-byte pieces of FULL 128-byte row slices (8 lanes per row) instead of fragment-shaped 64-byte halves (4 lanes per row, two
+// instructions per row), then reads its two MFMA fragments out of LDS.  Phase ablation of the forward (tuning key 9, dilation 1,
+// b = 64): scores 242 us, apply (which always loaded full lines) 166 us for the same number of bytes.
+__device__ __forceinline__ void mfma_band_scores_staged(const S3Args& a, const RowM& r, const bf16_t* rows, int ldr, const bf16_t* frag,
+                                                        int ldf, int h, float* TAB, float mul, const float* bias, char* tile) {
+    constexpr int NH = S3M_NH, DH = S3M_DH;
+    const bf16_t* qrow = frag + (r.tok0 + r.iq) * ldf + h * DH + r.g4 * 8;
+    const bf16x8 qf0 = ldg8(qrow, r.qok), qf1 = ldg8(qrow + 32, r.qok);
+    const int gc = r.lane & 7, r8 = r.lane >> 3;
+    const bf16_t* kbase = rows + r.tok0 * ldr + h * DH + gc * 8;                  // + token * ld
+    const int spb = (r.c * r.J) * NH + h;
+    int sidx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
+    const int w0 = vt_off(r8, gc), w1 = vt_off(r8 + 8, gc);
+    const int f0 = vt_off(r.c, r.g4), f1 = vt_off(r.c, 4 + r.g4);
+    constexpr int PF = S3M_PF;
+    uint4 st0[PF], st1[PF];
+    auto issue = [&](int sq, uint4& d0, uint4& d1) {
+        if (sq > r.nplanes) { d0 = d1 = make_uint4(0, 0, 0, 0); return; }
+        const int base = sq == 0 ? -1 : r.ptok[sq - 1];                          // sequence 0: every row is token 0 (<bos>)
+        const int t0 = base < 0 ? 0 : base + r8, t1 = base < 0 ? 0 : base + r8 + 8;
+        d0 = t0 < a.ntok ? *reinterpret_cast<const uint4*>(kbase + (size_t)t0 * ldr) : make_uint4(0, 0, 0, 0);
+        d1 = t1 < a.ntok ? *reinterpret_cast<const uint4*>(kbase + (size_t)t1 * ldr) : make_uint4(0, 0, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) issue(i, st0[i], st1[i]);
+    for (int sq = 0; sq <= r.nplanes; ++sq) {
+        *reinterpret_cast<uint4*>(tile + w0) = st0[0];
+        *reinterpret_cast<uint4*>(tile + w1) = st1[0];
+#pragma unroll
+        for (int i = 0; i + 1 < PF; ++i) { st0[i] = st0[i + 1]; st1[i] = st1[i + 1]; }
+        issue(sq + PF, st0[PF - 1], st1[PF - 1]);
+        __builtin_amdgcn_wave_barrier();                                          // LDS is in-order per wave: the tile is complete
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(tile + f0), k1 = *reinterpret_cast<const bf16x8*>(tile + f1);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, sc, 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+        if (sq == 0) {
+            if (r.g4 == 0 && r.qok) TAB[spb] = sc[0] * mul + (bias ? bias[h] : 0.f);
+        } else if (r.qok) {
+            const int jb = r.pslot[sq - 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r.tsel[q] >= 0) TAB[sidx[q] + jb * NH] = sc[q] * mul + (bias ? bias[(jb + r.tsel[q]) * NH + h] : 0.f);
+        }
+    }
+}
+
 __device__ __forceinline__ void mfma_band_apply(const S3Args& a, const RowM& r, const bf16_t* rows, int ldr, int g, const float* TAB,
                                                 char* tile, f32x4 (&O)[4]) {
     constexpr int NH = S3M_NH, DH = S3M_DH;
@@ -994,7 +1045,10 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
     for (int e = t; e < W * J * NH; e += blockDim.x) SP[e] = NEG_MAX;
     rowm_planes(a, f, y, pslot, ptok);
     const RowM r = rowm_init(a, b, ry, pslot, ptok);
-    if (!(a.dbg & 1)) mfma_band_scores(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias);
+    if (!(a.dbg & 1)) {
+        if (a.dbg & 8) mfma_band_scores(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias);
+        else mfma_band_scores_staged(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias, vt_base + r.wave * 4096);
+    }
     __syncthreads();
     if (!(a.dbg & 2)) rowm_softmax(SP, J);
     __syncthreads();
@@ -1061,8 +1115,9 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     for (int e = t; e < nsp; e += blockDim.x) { SP[e] = NEG_MAX; DP[e] = 0.f; }
     rowm_planes(a, f, y, pslot, ptok);
     const RowM r = rowm_init(a, b, ry, pslot, ptok);
-    mfma_band_scores(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias);             // scores
-    mfma_band_scores(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, 1.f, nullptr);              // dP'[g] = dO[g] . v_j[g]
+    char* stile = reinterpret_cast<char*>(PM0 + W * NH) + r.wave * 2048;                    // 8 wave-private [16][64] bf16 staging tiles
+    mfma_band_scores_staged(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias, stile);             // scores
+    mfma_band_scores_staged(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, 1.f, nullptr, stile);              // dP'[g] = dO[g] . v_j[g]
     __syncthreads();
     rowm_softmax(SP, J);                                                                    // P
     __syncthreads();
@@ -1400,7 +1455,7 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     // MFMA query-side kernel (tuning key 4: 1 = keep the dot2 kernel): bf16 operands, 16 queries per grid row, 8 heads x 64
     const bool q_mfma = !has_lo && !dO_lo && !g->noncausal && g_amdnuwa_tuning[4] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 &&
                         g->kw <= S3M_KW && g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0;
-    const size_t lds_qm = (nsp * 4 > 8 * 4096 ? nsp * 4 : 8 * 4096) + nsp * 4 + (8 * 64 + 16 * 8) * 4;
+    const size_t lds_qm = (nsp * 4 > 8 * 4096 ? nsp * 4 : 8 * 4096) + nsp * 4 + (8 * 64 + 16 * 8) * 4 + 8 * 2048;   // + the score staging tiles
 #define S3B(DH_, LO_)                                                                                             \
     do {                                                                                                          \
         if (q_mfma) {                                                                                             \
