@@ -1009,6 +1009,29 @@ __device__ __forceinline__ void mfma_band_apply(const S3Args& a, const RowM& r, 
 __device__ __forceinline__ void rowm_softmax(float* TAB, int J) {
     constexpr int NH = S3M_NH;
     const int t = threadIdx.x, cc = t & 3, wh = t >> 2, h = wh % NH, w = wh / NH;
+    if (J <= 48) {
+        // the thread's <= 12 slots in registers: one batch of LDS reads and one of writes instead of three dependent
+        // read (-modify-write) passes of 12 round trips each; same operations in the same order -> bit-identical
+        float v[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { const int j = cc + 4 * k; v[k] = j < J ? TAB[(w * J + j) * NH + h] : NEG_MAX; }
+        float m = NEG_MAX;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) m = fmaxf(m, v[k]);
+        m = quad_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const float e = cc + 4 * k < J ? __expf(v[k] - m) : 0.f;
+            v[k] = e;
+            if (cc + 4 * k < J) sum += e;
+        }
+        sum = quad_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { const int j = cc + 4 * k; if (j < J) TAB[(w * J + j) * NH + h] = v[k] * inv; }
+        return;
+    }
     float m = NEG_MAX;
     for (int j = cc; j < J; j += 4) m = fmaxf(m, TAB[(w * J + j) * NH + h]);
     m = quad_max(m);
