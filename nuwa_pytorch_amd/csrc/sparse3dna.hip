@@ -1167,7 +1167,16 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
         const int pair = t & 63, grp = t >> 6;
         const int g = pair / NH, hh = pair % NH;
         float acc = 0.f;
-        for (int item = grp; item < W * J; item += 8) acc += DP[item * NH + g] * SP[item * NH + hh];
+        for (int item = grp; item < W * J; item += 8 * 8) {       // eight (dP', P) pairs in flight, added in order (was one dependent LDS pair per iteration, 92 of them)
+            float dv8[8], pv8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = item + 8 * u, itc = it < W * J ? it : grp;
+                dv8[u] = DP[itc * NH + g]; pv8[u] = SP[itc * NH + hh];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += item + 8 * u < W * J ? dv8[u] * pv8[u] : 0.f;
+        }
         RED[grp * 64 + pair] = acc;
         __syncthreads();
         if (t < NH * NH) {
@@ -1197,6 +1206,28 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     {
         const int cc = t & 3, wh = t >> 2, h = wh % NH, w = wh / NH;
         const int i = 1 + ry * W + w;
+        if (J <= 48) {                                            // the thread's <= 12 slots in registers (see rowm_softmax); same order of operations
+            float pv[12], dv[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int j = cc + 4 * k, idx = (w * J + (j < J ? j : cc)) * NH + h;
+                pv[k] = SP[idx]; dv[k] = DP[idx];
+            }
+            float d = 0.f;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) if (cc + 4 * k < J) d += pv[k] * dv[k];
+            d = quad_sum(d);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int j = cc + 4 * k;
+                if (j < J) {
+                    const int idx = (w * J + j) * NH + h;
+                    const float dsv = pv[k] * (dv[k] - d);
+                    DP[idx] = dsv;
+                    if (i < a.ntok) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
+                }
+            }
+        } else {
         float d = 0.f;
         for (int j = cc; j < J; j += 4) d += SP[(w * J + j) * NH + h] * DP[(w * J + j) * NH + h];
         d = quad_sum(d);
@@ -1205,6 +1236,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
             const float dsv = SP[idx] * (DP[idx] - d);
             DP[idx] = dsv;
             if (i < a.ntok) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
+        }
         }
     }
     __syncthreads();                                                              // P is dead: its region now holds the K tiles
