@@ -1076,6 +1076,9 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
     if (!(a.dbg & 2)) rowm_softmax(SP, J);
     __syncthreads();
     // talking heads: P'[g] = sum_h Wth[g][h] P[h] per (w, j), in place
+    float wr[64];                              // the 8 x 8 mix matrix in registers for the loop below: read from LDS inside it, every output row
+#pragma unroll                                     // waited for its own LDS round trip (the stores to the table may alias wsh for the compiler)
+    for (int k = 0; k < 64; ++k) wr[k] = wsh[k];
     for (int item = t; item < W * J && !(a.dbg & 2); item += blockDim.x) {
         float pv[8], out[8];
 #pragma unroll
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
         for (int g = 0; g < 8; ++g) {
             float s = 0.f;
 #pragma unroll
-            for (int hh = 0; hh < 8; ++hh) s += wsh[g * NH + hh] * pv[hh];
+            for (int hh = 0; hh < 8; ++hh) s += wr[g * NH + hh] * pv[hh];
             out[g] = s;
         }
 #pragma unroll
@@ -1145,6 +1148,9 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     rowm_softmax(SP, J);                                                                    // P
     __syncthreads();
     // P' = mix(P) -> global (the key side needs it), P stays in SP;  P' of the <bos> slot also to PM0
+    float wr[64];                              // the 8 x 8 mix matrix in registers for the loop below: read from LDS inside it, every output row
+#pragma unroll                                     // waited for its own LDS round trip (the stores to the table may alias wsh for the compiler)
+    for (int k = 0; k < 64; ++k) wr[k] = wsh[k];
     for (int item = t; item < W * J; item += blockDim.x) {
         const int wq = item / J, j = item - wq * J;
         const int iq = 1 + ry * W + wq;
@@ -1156,7 +1162,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
         for (int g = 0; g < 8; ++g) {
             float s = 0.f;
 #pragma unroll
-            for (int hh = 0; hh < 8; ++hh) s += wsh[g * NH + hh] * pv[hh];
+            for (int hh = 0; hh < 8; ++hh) s += wr[g * NH + hh] * pv[hh];
             if (iq < a.ntok) dst[g] = s;
             if (j == 0) PM0[wq * NH + g] = iq < a.ntok ? s : 0.f;
         }
@@ -1195,7 +1201,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
         for (int hh = 0; hh < 8; ++hh) {
             float s = 0.f;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) s += wsh[g * NH + hh] * dv_[g];
+            for (int g = 0; g < 8; ++g) s += wr[g * NH + hh] * dv_[g];
             out[hh] = s;
         }
 #pragma unroll
