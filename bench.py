@@ -3,6 +3,11 @@
 at 10x16x16 video tokens (BASELINE cfg 3: dim 512, depth 24, 8 heads, 3DNA kernel (5,3,3), dilation
 cycle (1,2,4), 256 text tokens of context), bf16 MFMA operands, synthetic data, random-init weights.
 
+The HEADLINE (`value`) is the precision mode that meets BOTH halves of the north star's sentence: 'bf16x3-fwd' -- the forward
+carries every MFMA operand as a bf16 hi + lo pair (3 MFMAs per product: full-depth logits within 1e-3 of the fp32 reference,
+measured live below in `parity`), the backward runs single bf16 MFMAs on the hi parts.  The all-bf16 mode (faster, logits
+~8e-3) is timed in the same run and reported beside it as `fast_mode`.
+
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -18,8 +23,8 @@ What the line carries (rank 0):
   roofline              the NT GEMM family (largest share of the step), from a SECOND pass of a few steps with the library's
                         per-launch HIP-event timer armed (events on the launch stream, inside libamdnuwa).
   parity                the same 24-layer decoder, one sample, logits against the oracle's (fp32 CPU restatement of the
-                        reference) in BOTH precision modes, measured in this run; `parity_mode` = throughput of the 'bf16x3'
-                        mode (the one that meets the 1e-3 logits bound) beside the headline 'bf16' mode.
+                        reference) in every precision mode, measured in this run.
+  fast_mode             throughput of the all-bf16 mode (no lo parts anywhere; logits error in `parity.bf16`) in the same run.
   cpu_baseline          the oracle's full step (24 layers forward + backward through the CE loss), b = 1, on the host cores.
 """
 import argparse
@@ -108,14 +113,16 @@ def synthetic_batch(c, b, rank, dev):
     return ids.to(dev), ctx.to(dev), mask.to(dev)
 
 
-def cpu_baseline(c, nuwa, ids, ctx, mask, max_runs=3, budget_s=45.0):
+def cpu_baseline(c, nuwa, ids, ctx, mask, max_runs=3, budget_s=75.0, threads=None):
     """the oracle (fp32 CPU restatement of the reference algorithm) on the host cores: ONE sample of the same workload, the FULL
     step -- embed -> every decoder layer -> StableLayerNorm -> logits -> cross entropy -> backward -- with the benchmarked
     model's own weights; repeated up to `max_runs` times while the total stays within `budget_s`, median reported.
     Returns (json object, oracle logits of that sample)."""
     from oracle import nuwa_oracle as O
     host = os.cpu_count() or 1
-    torch.set_num_threads(min(host, 32))          # beyond ~32 threads the fp32 oracle gets slower, not faster
+    # default 32 threads: beyond that the fp32 oracle gets slower, not faster (profiles/r03_cpu_baseline_threads.txt holds the
+    # os.cpu_count() run that shows it; --cpu-threads N re-takes it)
+    torch.set_num_threads(min(host, threads or 32))
     threads = torch.get_num_threads()
     N = c['frames'] * c['fmap'] ** 2
     keep = lambda k: not (k.startswith('vae.') or k.startswith('text_'))
@@ -144,6 +151,7 @@ def cpu_baseline(c, nuwa, ids, ctx, mask, max_runs=3, budget_s=45.0):
 
 def gpu_logits(nuwa, ids, ctx, mask, mode):
     import nuwa_pytorch_amd as A
+    prev = A.get_precision()
     A.set_precision(mode)
     try:
         with torch.no_grad():
@@ -151,7 +159,7 @@ def gpu_logits(nuwa, ids, ctx, mask, mode):
             h = nuwa.decode_hidden(x, ctx[:1].contiguous(), mask[:1].contiguous())
             return nuwa._final(h).float().cpu()
     finally:
-        A.set_precision('bf16')
+        A.set_precision(prev)
 
 
 def file_sha16(paths):
@@ -201,12 +209,14 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=None,
-                    help='samples per GPU (weak scaling); default: 128 for cfg3 in bf16 (209 GB of the 288 GB; +2.8 %% tokens/s over 64), 64 for the other configs, 16 in bf16x3')
+                    help="samples per GPU (weak scaling); default for cfg3: 96 in 'bf16x3-fwd', 128 in 'bf16', 16 in 'bf16x3'; 64 for the other configs")
     ap.add_argument('--config', default='cfg3', choices=list(CFGS))
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'bf16x3'], help='mode of the HEADLINE value')
-    ap.add_argument('--parity-batch', type=int, default=16, help="samples per GPU of the 'bf16x3' side measurement")
-    ap.add_argument('--no-parity', action='store_true', help="skip the 'bf16x3' throughput pass and the logits-vs-oracle measurement")
+    ap.add_argument('--precision', default='bf16x3-fwd', choices=['bf16x3-fwd', 'bf16', 'bf16x3'],
+                    help="mode of the HEADLINE value; the default is the mode that meets the 1e-3 logits bound")
+    ap.add_argument('--side-batch', type=int, default=None, help="samples per GPU of the 'bf16' side measurement (default: the headline batch)")
+    ap.add_argument('--no-parity', action='store_true', help="skip the 'bf16' side pass and the logits-vs-oracle measurement")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-threads', type=int, default=None, help='host threads of the cpu_baseline leg (default 32; 0 = os.cpu_count())')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL over xGMI (default); gloo only for functional checks')
     ap.add_argument('--collective', default='allreduce', choices=['allreduce', 'rs_ag'], help='gradient exchange per bucket')
     ap.add_argument('--single-device', action='store_true', help='functional check only: every rank uses cuda:0 (with --backend gloo)')
@@ -240,7 +250,8 @@ def main():
         p.requires_grad_(True)
     reducer = GradReducer(nuwa, collective=args.collective) if world > 1 else None
 
-    b = args.batch if args.batch else ((128 if args.config == 'cfg3' else 64) if args.precision == 'bf16' else 16)
+    default_b = {'bf16x3-fwd': 96, 'bf16': 128, 'bf16x3': 16}[args.precision] if args.config == 'cfg3' else (16 if args.precision == 'bf16x3' else 64)
+    b = args.batch if args.batch else default_b
     N = c['frames'] * c['fmap'] ** 2
     ids, ctx, mask = synthetic_batch(c, b, rank, dev)
 
@@ -283,7 +294,7 @@ def main():
 
     # ---- second pass (rank 0's numbers): the library's per-launch HIP-event timer armed around every amdnuwa_gemm_nt launch
     probe_steps = max(1, min(args.steps, 5))
-    gemm_ms, gemm_launches, gemm_flops, gemm_bytes = (0.0, 0, 0.0, 0.0)
+    gemm_ms, gemm_launches, gemm_flops, gemm_bytes, gemm_issued = (0.0, 0, 0.0, 0.0, 0.0)
     if rank == 0:
         K.timer_arm(True)
     t1 = time.perf_counter()
@@ -293,20 +304,22 @@ def main():
     dt_probe = time.perf_counter() - t1
     if rank == 0:
         gemm_ms, gemm_launches, gemm_flops, gemm_bytes = K.timer_collect()
+        gemm_issued = K.timer_issued_flops()
         K.timer_arm(False)
 
-    # ---- 'bf16x3' (parity mode) throughput beside the headline, smaller batch (its saved activations are ~2.7x larger)
-    parity_mode = None
+    # ---- the all-bf16 mode beside the headline (same batch unless --side-batch), a few steps
+    fast_mode = None
     loss = None
-    torch.cuda.empty_cache()          # the parity-mode pass allocates differently sized activations: hand the cached blocks back first
-    if not args.no_parity and args.precision == 'bf16':
-        pb = max(1, min(args.parity_batch, b))
-        pbatch = (ids[:pb].contiguous(), ctx[:pb].contiguous(), mask[:pb].contiguous())
-        A.set_precision('bf16x3')
+    torch.cuda.empty_cache()          # the side pass allocates differently sized activations: hand the cached blocks back first
+    if not args.no_parity and args.precision != 'bf16':
+        pb = max(1, args.side_batch or b)
+        pbatch = (ids, ctx, mask) if pb == b else synthetic_batch(c, pb, rank, dev)
+        A.set_precision('bf16')
         try:
             step(pbatch)
+            step(pbatch)
             fence()
-            ps = max(2, min(args.steps, 4))
+            ps = max(2, min(args.steps, 5))
             t2 = time.perf_counter()
             for _ in range(ps):
                 step(pbatch)
@@ -315,13 +328,15 @@ def main():
             if world > 1:
                 dist.all_reduce(d2, op=dist.ReduceOp.MAX)
             d2 = float(d2.item())
-            parity_mode = {'dtype': 'bf16x3', 'value': world * pb * N * ps / d2, 'unit': 'video-tokens/s', 'ms_per_step': d2 / ps * 1e3,
-                           'per_gpu_batch': pb, 'steps': ps,
-                           'note': 'every MFMA operand as a bf16 hi+lo pair, 3 MFMAs per product; the mode that meets the 1e-3 logits bound'}
+            fast_mode = {'dtype': 'bf16', 'value': world * pb * N * ps / d2, 'unit': 'video-tokens/s', 'ms_per_step': d2 / ps * 1e3,
+                         'per_gpu_batch': pb, 'steps': ps,
+                         'step_mfma_frac': 3.0 * fwd_flops_per_sample(c) * pb / (d2 / ps) / 1e12 / PEAK_BF16_TFLOPS,
+                         'note': 'single bf16 MFMA per product in forward and backward; does NOT meet the 1e-3 logits bound (see parity.bf16)'}
         finally:
             A.set_precision(args.precision)
             for p in params:
                 p.grad = None
+        torch.cuda.empty_cache()
 
     if rank == 0:
         tokens = world * b * N * args.steps
@@ -334,7 +349,9 @@ def main():
             'value': value, 'unit': 'video-tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'ms_per_step_median': statistics.median(per_step_ms),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16' if args.precision == 'bf16' else 'bf16x3', 'data': 'synthetic',
+            'dtype': {'bf16': 'bf16', 'bf16x3': 'bf16x3 (bf16 hi+lo operand pairs, 3 MFMAs per product)',
+                      'bf16x3-fwd': 'bf16 (forward: hi+lo operand pairs, 3 MFMAs per product; backward: single bf16 MFMAs)'}[args.precision],
+            'precision_mode': args.precision, 'data': 'synthetic',
             'config': {'workload': f'BASELINE {args.config}: NUWA decoder dim={c["dim"]} depth={c["dec_depth"]} heads={c["heads"]}, '
                                    f'{c["frames"]}x{c["fmap"]}x{c["fmap"]} video tokens, 3DNA kernel {c["kernel"]} dilation {c["dilation"]}, '
                                    f'{c["text_len"]} text tokens, codebook {c["codebook"]}',
@@ -346,34 +363,37 @@ def main():
             'step_mfma_frac': step_flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
             'timing': 'value: wall clock over exactly `steps` steps between barrier+synchronize fences, max over ranks, library timer off; '
                       'ms_per_step_median: median of the per-step HIP-event intervals on the compute stream in the same region',
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_* (bf16 MFMA NT GEMM; every amdnuwa_gemm_nt launch of a separate pass of '
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_* (bf16 MFMA NT GEMM family; `achieved` counts the ALGORITHMIC 2MNK per product, `mfma_issued_tflops` what the hi+lo forward GEMMs really issue; every amdnuwa_gemm_nt launch of a separate pass of '
                                                      f'{probe_steps} step(s) with the per-launch HIP-event timer armed, events on the launch stream)',
                          'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                          'traffic': None, 'algorithmic_bytes_per_launch': gemm_bytes / max(gemm_launches, 1),
-                         'flops_per_launch': gemm_flops / max(gemm_launches, 1), 'launches': gemm_launches, 'avg_launch_us': gemm_ms * 1e3 / max(gemm_launches, 1),
+                         'flops_per_launch': gemm_flops / max(gemm_launches, 1),
+                         'mfma_issued_tflops': gemm_issued / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
+                         'launches': gemm_launches, 'avg_launch_us': gemm_ms * 1e3 / max(gemm_launches, 1),
                          'share_of_step': gemm_ms * 1e-3 / dt_probe},
         }
         tr, why = traffic_from_profiles(args.config, b)
         if tr is not None:
             out['roofline']['traffic'] = tr['bytes_per_launch']
         out['roofline']['traffic_source'] = why
-        if parity_mode is not None:
-            out['parity_mode'] = parity_mode
+        if fast_mode is not None:
+            out['fast_mode'] = fast_mode
         if not args.no_tokenizer and world == 1:          # (side measurement, single-GPU runs only: keeps the ranks in step)
             out['vae_tokenizer'] = tokenizer_rate(nuwa, c, min(b, 8), dev)
         oracle_logits = None
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out['cpu_baseline'], oracle_logits = cpu_baseline(c, nuwa, ids, ctx, mask)
+                out['cpu_baseline'], oracle_logits = cpu_baseline(c, nuwa, ids, ctx, mask, threads=(os.cpu_count() if args.cpu_threads == 0 else args.cpu_threads))
             except Exception as e:      # the baseline is a report, never a reason to lose the GPU number
                 out['cpu_baseline'] = {'value': None, 'unit': 'video-tokens/s', 'cores': os.cpu_count(), 'kind': 'port',
                                        'sample': f'failed: {type(e).__name__}: {e}'}
         if oracle_logits is not None and not args.no_parity:
             # the checker: this run's GPU logits of the baseline's sample (full depth) against the oracle's, both modes
             par = {'sample': f'logits [1, {N}, {c["codebook"]}] of sample 0 after all {c["dec_depth"]} layers vs the oracle (fp32 CPU), '
-                             'max-abs error / max-abs reference', 'bound': {'bf16x3': 1e-3, 'bf16': 4e-2}}
+                             'max-abs error / max-abs reference; the north-star bound is 1e-3',
+                   'bound': {'bf16x3-fwd': 1e-3, 'bf16x3': 1e-3, 'bf16': 1.2e-2}}
             ref = oracle_logits.double()
-            for mode in ('bf16', 'bf16x3'):
+            for mode in ('bf16x3-fwd', 'bf16', 'bf16x3'):
                 try:
                     got = gpu_logits(nuwa, ids, ctx, mask, mode).double()
                     par[mode] = {'logits_rel_max': float((got - ref).abs().max() / ref.abs().max()),

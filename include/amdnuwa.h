@@ -292,6 +292,13 @@ int amdnuwa_xattn_pack(const amdnuwa_xattn_geom* g, const uint16_t* kv, const ui
 int amdnuwa_xattn_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq,
                       const amdnuwa_xattn_kv* packed, const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo,
                       uint16_t* P, uint16_t* P_lo, uint16_t* Pm, uint16_t* Pm_lo, amdnuwa_stream stream);
+/* the same, plus (optional) the softmax statistics [B][heads][n][2] fp32 = (row max of the scaled, masked scores in the log2
+ * domain, 1 / row sum of exp): what amdnuwa_xattn2_bwd recomputes the probabilities from.  This is how the 'bf16x3-fwd' mode
+ * pairs the 3-MFMA forward (Attention.forward, reference nuwa_pytorch.py:339-378) with the recomputing bf16 backward: P / Pm may
+ * then be NULL and nothing of size n x JP is saved */
+int amdnuwa_xattn_fwd_stats(const amdnuwa_xattn_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq,
+                            const amdnuwa_xattn_kv* packed, const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo,
+                            uint16_t* P, uint16_t* P_lo, uint16_t* Pm, uint16_t* Pm_lo, float* stats, amdnuwa_stream stream);
 size_t amdnuwa_xattn_bwd_workspace_bytes(const amdnuwa_xattn_geom* g);
 /* query side of the backward: dq and ds = dL/dsim [B][heads][n][JP]; dK/dV follow as batched
  * amdnuwa_gemm_tn over ds / Pm, then amdnuwa_xattn_unpack */

@@ -6,7 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libamdnuwa.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 P = C.c_void_p
 I = C.c_int
@@ -95,6 +95,7 @@ SIGNATURES = {
     'amdnuwa_xattn_jp': (I, [I]),
     'amdnuwa_xattn_pack': (I, [XG, P, P, I, P, P, P, XK, P]),
     'amdnuwa_xattn_fwd': (I, [XG, P, P, I, XK, P, P, P, I, P, P, P, P, P]),
+    'amdnuwa_xattn_fwd_stats': (I, [XG, P, P, I, XK, P, P, P, I, P, P, P, P, P, P]),
     'amdnuwa_xattn_bwd_workspace_bytes': (SZ, [XG]),
     'amdnuwa_xattn_bwd': (I, [XG, P, P, I, XK, P, P, P, P, P, P, P, I, P, I, P, SZ, P]),
     'amdnuwa_xattn_unpack': (I, [XG, P, P, P, P, I, P, P, I, P]),

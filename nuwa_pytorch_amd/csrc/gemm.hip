@@ -785,6 +785,174 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
 }
 
 // ---------------------------------------------------------------------------------------------
+// NT, 256x256 tile, bf16x3: every operand a bf16 hi + lo pair, three MFMAs per product (lo*hi + hi*lo + hi*hi, the small
+// terms first) -- the arithmetic of the forward in the 'bf16x3' and 'bf16x3-fwd' precision modes (the modes whose logits stay
+// within 1e-3 of the fp32 reference).  Same 8-wave 2 x 4 layout, accumulator ownership, B-row permutation and epilogues as the
+// bf16 ring above; what differs is the staging: a stage holds FOUR 16 KiB operand images (A hi, A lo, B hi, B lo), so the ring
+// is 2 stages deep (128 KiB).  That is enough here: a K-step is 96 MFMAs per wave (~3.2k cycles per SIMD with its two waves)
+// against 24 ds_read_b128 and 8 DMA pieces, i.e. the loop is bound by the matrix pipe and the next stage's DMA has a whole
+// MFMA phase to land.  DMA pieces go through dma16_asm (common.h): with the builtin the compiler drains the ring (vmcnt(0)) in
+// front of the fragment reads that follow the issue in the same basic block.
+// Accumulation order per output element (k ascending; per 32-chunk lo*hi, hi*lo, hi*hi) equals gemm_nt_kernel<true,...>'s, so
+// the two kernels agree bit for bit.
+// ---------------------------------------------------------------------------------------------
+template <int EPI>      // 0: fp32 out (+bias);  1: bf16 hi [+ lo] out (+bias)
+__global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 256 * 32 * 2;             // one operand image of a stage: 16 KiB
+    constexpr int STG = 4 * TB;                  // A hi | A lo | B hi | B lo
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int lid = xcd_remap(blockIdx.x, nwg);
+    const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const long long bz = blockIdx.y;
+    const long long oA = boff(p, bz, p.sA, p.sA_in), oB = boff(p, bz, p.sB, p.sB_in), oC = boff(p, bz, p.sC, p.sC_in);
+    const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+    // this wave's DMA pieces: pieces j*8 + wave (j = 0, 1) of each of the four images; a piece = 16 rows x 32 k (1 KiB)
+    long long offa[2], offb[2];                  // element offsets of the lane's 16-byte chunk at k = 0; < 0: row outside -> zero page
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (j * 8 + wave) * 16 + (lane >> 2);
+        const int cca = (lane & 3) ^ glds_swz<32>(row);
+        const int ccb = (lane & 3) ^ b256_swz<EPI>(row);
+        const long long ga = (long long)m0 + row, gb = (long long)n0 + row;
+        offa[j] = ga < p.M ? oA + ga * p.lda + cca * 8 : -1;
+        offb[j] = gb < p.N ? oB + gb * p.ldb + ccb * 8 : -1;
+    }
+    auto issue = [&](int slot, int k0) {
+        char* base = smem + slot * STG;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int po = (j * 8 + wave) * 1024;
+            const bool ina = offa[j] >= 0, inb = offb[j] >= 0;
+            dma16_asm(ina ? p.A + offa[j] + k0 : zp, base + po);
+            dma16_asm(ina ? p.Alo + offa[j] + k0 : zp, base + TB + po);
+            dma16_asm(inb ? p.B + offb[j] + k0 : zp, base + 2 * TB + po);
+            dma16_asm(inb ? p.Blo + offb[j] + k0 : zp, base + 3 * TB + po);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.dbg & 2) ? 0 : p.K / 32;
+    const int fr = lane & 15, fg = lane >> 4;
+    if (nk > 0) issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        VMCNT(0);                                 // this wave's pieces of tile kt have landed ...
+        __builtin_amdgcn_s_barrier();             // ... and everyone's; also: everyone is done reading the other slot (tile kt-1)
+        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * 32);
+        const char* base = smem + (kt & 1) * STG;
+        bf16x8 bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = b256_off<EPI>(wn * 64 + b256_row<EPI>(j, fr), fg);
+            bh[j] = *reinterpret_cast<const bf16x8*>(base + 2 * TB + o);
+            bl[j] = *reinterpret_cast<const bf16x8*>(base + 3 * TB + o);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            bf16x8 ah[4], al[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = glds_off<32>(wm * 128 + (hf * 4 + i) * 16 + fr, fg);
+                ah[i] = *reinterpret_cast<const bf16x8*>(base + o);
+                al[i] = *reinterpret_cast<const bf16x8*>(base + TB + o);
+            }
+            // three sweeps over the 16 accumulators of this half: consecutive MFMAs never share an accumulator
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[hf * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[hf * 4 + i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[hf * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[hf * 4 + i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[hf * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[hf * 4 + i][j], 0, 0, 0);
+        }
+    }
+
+    if constexpr (EPI == 1) {
+        // lane (fr, fg) owns row m = .. + fr and the 16 contiguous columns n = n0 + wn*64 + fg*16 + [j*4 + r] (permuted B rows)
+        const bool vec8 = (p.N % 8 == 0) && (p.ldc % 8 == 0);
+        const int nb = n0 + wn * 64 + fg * 16;
+        float bias16[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool in = p.bias != nullptr && nb + e < p.N;
+            const float bvv = (p.bias ? p.bias : reinterpret_cast<const float*>(g_zero_page))[in ? nb + e : 0];
+            bias16[e] = in ? bvv : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
+            if (m >= p.M || nb >= p.N) continue;
+            if ((p.dbg & 1) && acc[i][0][0] != 12345.678f) continue;
+            bf16_t h[16], l[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f2bf_hilo(acc[i][j][r] * p.alpha + bias16[j * 4 + r], h[j * 4 + r], l[j * 4 + r]);
+            bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
+            bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;
+            if (vec8 && nb + 16 <= p.N) {
+                reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
+                reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2(h[8], h[9]), pack2(h[10], h[11]), pack2(h[12], h[13]), pack2(h[14], h[15]));
+                if (Cl) {
+                    reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
+                    reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2(l[8], l[9]), pack2(l[10], l[11]), pack2(l[12], l[13]), pack2(l[14], l[15]));
+                }
+            } else {
+                for (int e = 0; e < 16 && nb + e < p.N; ++e) {
+                    C[e] = h[e];
+                    if (Cl) Cl[e] = l[e];
+                }
+            }
+        }
+    } else {
+        const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
+        float biasf[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + j * 16 + fg * 4 + r;
+                const bool in = p.bias != nullptr && n < p.N;
+                const float bvv = (p.bias ? p.bias : reinterpret_cast<const float*>(g_zero_page))[in ? n : 0];
+                biasf[j][r] = in ? bvv : 0.f;
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fg * 4;
+                if (n >= p.N) continue;
+                if ((p.dbg & 1) && acc[i][j][0] != 12345.678f) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha + biasf[j][r];
+                float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
+                if (vec_ok) *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // TN :  P[z][n1][n2] = sum over token rows m of split z of A[m][n1] * B[m][n2]   (fp32 partials)
 // ---------------------------------------------------------------------------------------------
 constexpr int TK = 32;                       // token rows per step
@@ -1559,6 +1727,21 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     if (variant == 0) {
         const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * (d->batch > 0 ? d->batch : 1);
         variant = (d->K % 32 == 0) ? (t256 >= 512 ? 7 : 2) : 5;
+    }
+    // bf16x3 on the 256x256 tile (2-stage ring of hi + lo images); tuning key 13 = 1 keeps the first-generation 128x128 kernel
+    if (x3 && !sh && variant == 7 && d->K % 32 == 0 && g_amdnuwa_tuning[13] != 1) {
+        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
+        dim3 g3(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b3(512);
+        const size_t l3 = (size_t)2 * 4 * 256 * 32 * 2;
+        if (ob) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_256x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3);
+            hipLaunchKernelGGL((gemm_nt_256x3_kernel<1>), g3, b3, l3, stream, p);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_256x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3);
+            hipLaunchKernelGGL((gemm_nt_256x3_kernel<0>), g3, b3, l3, stream, p);
+        }
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
     }
     if (!x3 && (variant == 3 || variant == 4) && d->K % 32 == 0) {        // 256x256 tile, 4- / 3-stage DMA ring
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;

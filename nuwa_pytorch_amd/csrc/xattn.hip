@@ -31,6 +31,7 @@ struct XArgs {
     const float* wth;                              // [NH][NH]
     bf16_t *o, *ol; int ldo;
     bf16_t *P, *Pl, *Pm, *Pml;                     // saved probabilities [B][NH][n][JP]
+    float* stats;                                  // optional [B][NH][n][2]: (row max in the log2 domain, 1 / row sum) -- what xattn2_bwd recomputes from
     const bf16_t *dO, *dOl; int lddo;
     bf16_t *dS, *dSl;                              // [B][NH][n][JP]
     bf16_t *dq, *dql; int lddq;
@@ -182,6 +183,9 @@ __global__ __launch_bounds__(512) void xattn_fwd_kernel(XArgs a) {
         sm[qb] += __shfl_xor(sm[qb], 16, 64);
         sm[qb] += __shfl_xor(sm[qb], 32, 64);
         sm[qb] = 1.f / sm[qb];
+        const int qi = q0 + qb * 16 + c;
+        if (a.stats && g4 == 0 && qi < a.n)
+            *reinterpret_cast<float2*>(a.stats + (bh * a.n + qi) * 2) = make_float2(mx[qb] * 1.4426950408889634f, sm[qb]);
     }
     // normalise + save P
 #pragma unroll
@@ -650,6 +654,12 @@ static XArgs make_args(const amdnuwa_xattn_geom* g, const amdnuwa_xattn_kv* p, c
 extern "C" int amdnuwa_xattn_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq,
                                  const amdnuwa_xattn_kv* p, const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo,
                                  uint16_t* P, uint16_t* P_lo, uint16_t* Pm, uint16_t* Pm_lo, hipStream_t stream) {
+    return amdnuwa_xattn_fwd_stats(g, q, q_lo, ldq, p, w_th, o, o_lo, ldo, P, P_lo, Pm, Pm_lo, nullptr, stream);
+}
+
+extern "C" int amdnuwa_xattn_fwd_stats(const amdnuwa_xattn_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq,
+                                       const amdnuwa_xattn_kv* p, const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo,
+                                       uint16_t* P, uint16_t* P_lo, uint16_t* Pm, uint16_t* Pm_lo, float* stats, hipStream_t stream) {
     int rc = check(g);
     if (rc) return rc;
     if (!q || !p || !w_th || !o || ldq % 8 || ldo % 4) return AMDNUWA_ERR_ARG;
@@ -658,7 +668,7 @@ extern "C" int amdnuwa_xattn_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q,
     if (g->B <= 0 || g->n <= 0) return AMDNUWA_OK;
     XArgs a = make_args(g, p, w_th);
     a.q = q; a.ql = q_lo; a.ldq = ldq; a.o = o; a.ol = o_lo; a.ldo = ldo;
-    a.P = P; a.Pl = P_lo; a.Pm = Pm; a.Pml = Pm_lo;
+    a.P = P; a.Pl = P_lo; a.Pm = Pm; a.Pml = Pm_lo; a.stats = stats;
     const int tiles = (g->n + 31) / 32;
     dim3 grid(g->B * tiles), block(g->heads * 64);
     const size_t lds = (size_t)2 * g->heads * 4 * 64 * 4 * sizeof(float);

@@ -2,6 +2,7 @@
 Tensors only provide device memory (torch caching allocator) and the current HIP stream; all
 arithmetic happens inside libamdnuwa."""
 import ctypes as C
+import threading
 from collections import namedtuple
 
 import torch
@@ -13,14 +14,20 @@ BF = namedtuple('BF', ['hi', 'lo'])     # bf16 hi part + optional bf16 residual 
 
 _PRECISION = 'bf16'
 _TIMER = {'on': False, 'flops': 0.0}
+MODES = ('bf16', 'bf16x3', 'bf16x3-fwd')
+_TL = threading.local()
 
 
 def set_precision(mode):
-    """'bf16'  : bf16 MFMA operands, fp32 accumulate / softmax / LayerNorm / residual stream (fast path)
-    'bf16x3': every MFMA operand carried as a bf16 hi+lo pair, 3 MFMAs per product (~fp32 accuracy;
-              the parity mode that meets the 1e-3 logits tolerance against the fp32 reference)."""
+    """'bf16'      : bf16 MFMA operands, fp32 accumulate / softmax / LayerNorm / residual stream (fastest; logits ~8e-3 of the fp32
+                  reference at full cfg-3 depth).
+    'bf16x3'    : every MFMA operand carried as a bf16 hi+lo pair, 3 MFMAs per product (~fp32 accuracy) in the forward AND the
+                  backward (parity mode for gradients).
+    'bf16x3-fwd': the forward exactly as 'bf16x3' (logits within 1e-3 of the fp32 reference: the north-star bound), the backward
+                  on the hi parts only with single bf16 MFMAs as in 'bf16'.  Logits / loss are bit-identical to 'bf16x3', gradients
+                  carry bf16-level error.  lo parts live only inside the forward of one block (they are not saved)."""
     global _PRECISION
-    if mode not in ('bf16', 'bf16x3'):
+    if mode not in MODES:
         raise ValueError(mode)
     _PRECISION = mode
 
@@ -29,8 +36,42 @@ def get_precision():
     return _PRECISION
 
 
+class phase:
+    """marks the code of an autograd node as forward ('fwd') or backward ('bwd') work.  Only the mixed mode cares: its backward
+    allocates and consumes hi-only operands.  Every Function.forward / backward of ops.py runs inside one (a recomputing
+    backward -- the reversible stacks -- re-enters 'fwd' through the Function.forward calls it makes)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = getattr(_TL, 'phase', 'fwd')
+        _TL.phase = self.name
+
+    def __exit__(self, *exc):
+        _TL.phase = self.prev
+
+
+def in_backward():
+    return getattr(_TL, 'phase', 'fwd') == 'bwd'
+
+
 def want_lo():
-    return _PRECISION == 'bf16x3'
+    return _PRECISION == 'bf16x3' or (_PRECISION == 'bf16x3-fwd' and not in_backward())
+
+
+def mixed():
+    return _PRECISION == 'bf16x3-fwd'
+
+
+def fast_io():
+    """only the all-bf16 mode stores the GEMM outputs that feed a LayerNorm (and the dgrad outputs) as bf16"""
+    return _PRECISION == 'bf16'
+
+
+def hi_only(t):
+    """the hi part of a BF pair (what the mixed mode keeps for its bf16 backward); anything else passes through"""
+    return BF(t.hi, None) if isinstance(t, BF) and t.lo is not None else t
 
 
 def _p(t):
@@ -82,6 +123,7 @@ def _ld(t):
 def timer_arm(on):
     _TIMER['on'] = bool(on)
     _TIMER['flops'] = 0.0
+    _TIMER['issued'] = 0.0
     _TIMER['bytes'] = 0.0
     _lib.lib().amdnuwa_timer_arm(1 if on else 0)
 
@@ -90,6 +132,11 @@ def timer_collect():
     ms, n = C.c_double(0), C.c_longlong(0)
     check(_lib.lib().amdnuwa_timer_collect(C.byref(ms), C.byref(n)), 'timer_collect')
     return ms.value, n.value, _TIMER['flops'], _TIMER.get('bytes', 0.0)
+
+
+def timer_issued_flops():
+    """FLOPs the MFMA pipe was actually asked for in the armed region (3 x the algorithmic 2MNK where operands travel as hi + lo pairs)"""
+    return _TIMER.get('issued', 0.0)
 
 
 def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None, N=None, K=None, geglu_out=None):
@@ -122,7 +169,8 @@ def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None,
         d.shift_ntok, d.shift_fmap = int(shift[0]), int(shift[1])
     st = _stream()
     if _TIMER['on']:
-        _TIMER['flops'] += 2.0 * M * N * K * (3 if x3 else 1)
+        _TIMER['flops'] += 2.0 * M * N * K                     # ALGORITHMIC: one product per (m, n, k) whatever the operand form
+        _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * M * N * K * (3 if x3 else 1)
         ob = (2 * (2 if out.lo is not None else 1)) if out_bf16 else 4
         _TIMER['bytes'] += (2.0 * (M + N) * K) * (2 if x3 else 1) + float(M) * N * ob + (float(M) * N if geglu_out is not None else 0.)
         L.amdnuwa_timer_begin(st)
@@ -154,7 +202,8 @@ def gemm_nt_geglu_bwd(dy, w2T, u, FP):
         d.C, d.Clo = _p(dgg.hi), _p(dgg.lo)
     st = _stream()
     if _TIMER['on']:
-        _TIMER['flops'] += 2.0 * M * FP * Kd * (3 if x3 else 1)
+        _TIMER['flops'] += 2.0 * M * FP * Kd
+        _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * M * FP * Kd * (3 if x3 else 1)
         _TIMER['bytes'] += (2.0 * (M + FP) * Kd) * (2 if x3 else 1) + float(M) * FP * 8
         L.amdnuwa_timer_begin(st)
     check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(geglu backward)')
@@ -375,13 +424,13 @@ def embed_bwd(ids, dx, dW, dax1, dax2, dax3, dbos, B, ntok, F, H, Wd, frac):
                               F, H, Wd, float(frac), _p(ws), nb, _stream()), 'amdnuwa_embed_bwd')
 
 
-def ce_fwd(logits, targets, grad_scale, want_grad=True):
+def ce_fwd(logits, targets, grad_scale, want_grad=True, lo=None):
     L = _lib.lib()
     R, Cc = logits.shape
     dev = logits.device
     row_loss = torch.empty(R, dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
-    dl = empty_bf((R, Cc), dev) if want_grad else BF(None, None)
+    dl = empty_bf((R, Cc), dev, lo=lo) if want_grad else BF(None, None)
     check(L.amdnuwa_ce_fwd(_p(logits), _p(targets), _p(row_loss), _p(loss), _p(dl.hi), _p(dl.lo), R, Cc, Cc,
                            float(grad_scale), _stream()), 'amdnuwa_ce_fwd')
     return loss, dl
@@ -406,6 +455,7 @@ def linear_ce(h, w, targets, grad_scale, want_grad=True):
     st = _stream()
     if _TIMER['on']:                       # two products: both count as NT GEMM work of the step
         _TIMER['flops'] += 2.0 * R * Cc * Kd * (2 if want_grad else 1)
+        _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * R * Cc * Kd * (2 if want_grad else 1)
         _TIMER['bytes'] += (2.0 * (R + Cc) * Kd) * (2 if want_grad else 1) + (2.0 * R * Cc if want_grad else 0.) + 8.0 * R * (Cc // 64)
         L.amdnuwa_timer_begin(st)
     check(L.amdnuwa_linear_ce(_p(h.hi), _ld(h.hi), _p(w.hi), _ld(w.hi), _p(targets), R, Cc, Kd, float(grad_scale), _p(row_loss), _p(loss),
@@ -574,6 +624,13 @@ class PackedKV:
         s.valid = _p(self.valid)
         self.struct = s
 
+    def drop_lo(self):
+        """release the lo images (mixed mode: the bf16 backward reads the hi images only)"""
+        self.Kp, self.Vp, self.Kt, self.Vt = (hi_only(t) for t in (self.Kp, self.Vp, self.Kt, self.Vt))
+        s = self.struct
+        s.Kp_lo = s.Kt_lo = s.Vp_lo = s.Vt_lo = None
+        return self
+
 
 def xattn_pack(g, kv, null_k, null_v, mask_u8):
     L = _lib.lib()
@@ -583,19 +640,24 @@ def xattn_pack(g, kv, null_k, null_v, mask_u8):
     return pk
 
 
-def xattn_fwd(g, q, pk, wth, save=True):
+def xattn_fwd(g, q, pk, wth, save=True, want_stats=False):
+    """first-design kernel (bf16 or bf16x3).  save: keep P / P' for amdnuwa_xattn_bwd.  want_stats: return the softmax statistics
+    [B, h, n, 2] the recomputing backward (xattn2_bwd) takes instead -- (o, stats) is then the result."""
     L = _lib.lib()
     inner = g.heads * g.dim_head
     dev = q.hi.device
     lo = q.lo is not None
     o = empty_bf((g.B * g.n, inner), dev, lo=lo)
-    if save:
+    if save and not want_stats:
         P = empty_bf((g.B, g.heads, g.n, g.JP), dev, lo=lo)
         Pm = empty_bf((g.B, g.heads, g.n, g.JP), dev, lo=lo)
     else:
         P = Pm = BF(None, None)
-    check(L.amdnuwa_xattn_fwd(C.byref(g), _p(q.hi), _p(q.lo), q.hi.stride(0), C.byref(pk.struct), _p(wth), _p(o.hi), _p(o.lo),
-                              inner, _p(P.hi), _p(P.lo), _p(Pm.hi), _p(Pm.lo), _stream()), 'amdnuwa_xattn_fwd')
+    stats = torch.empty((g.B, g.heads, g.n, 2), dtype=torch.float32, device=dev) if want_stats else None
+    check(L.amdnuwa_xattn_fwd_stats(C.byref(g), _p(q.hi), _p(q.lo), q.hi.stride(0), C.byref(pk.struct), _p(wth), _p(o.hi), _p(o.lo),
+                                    inner, _p(P.hi), _p(P.lo), _p(Pm.hi), _p(Pm.lo), _p(stats), _stream()), 'amdnuwa_xattn_fwd_stats')
+    if want_stats:
+        return o, stats
     return o, P, Pm
 
 
@@ -616,9 +678,9 @@ def xattn_bwd(g, dO, pk, wth, P):
     return dq, dS, dwth
 
 
-def xattn2_supported(g, q):
+def xattn2_supported(g, q=None):
     """second-design cross-attention kernels: fast bf16 mode (no lo parts), 8 heads x 64"""
-    return q.lo is None and bool(_lib.lib().amdnuwa_xattn2_supported(C.byref(g)))
+    return (q is None or q.lo is None) and bool(_lib.lib().amdnuwa_xattn2_supported(C.byref(g)))
 
 
 def xattn2_fwd(g, q, pk, wth):

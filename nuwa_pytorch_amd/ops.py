@@ -12,6 +12,7 @@ are fp32; GEMM / attention operands are bf16 (plus a bf16 residual in 'bf16x3' p
 The same inner stages also back the standalone modules (Sparse3DNA, Attention, FeedForward,
 LayerNorm wrappers) through `InnerFn`, so `Sparse3DNA(...)(x)` alone works as in the reference.
 """
+import functools
 import os
 
 import torch
@@ -23,6 +24,18 @@ from .kernels import BF
 
 def _ru(v, m):
     return (v + m - 1) // m * m
+
+
+def _in_phase(name):
+    """run an autograd node's forward / backward body inside K.phase(name) (see kernels.phase: the mixed precision mode allocates
+    and consumes hi-only operands in backward code)"""
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(*a, **k):
+            with K.phase(name):
+                return fn(*a, **k)
+        return wrapped
+    return deco
 
 
 class WeightCache:
@@ -92,7 +105,7 @@ class S3Inner:
         qkv = K.gemm_nt(h, W['qkv'], out_bf16=True, shift=meta.get('shift'))
         o = K.sparse3dna_fwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), rel_bias=rel)
         y = K.gemm_nt(o, W['out'], bias=bo.detach(), out_bf16=_fast())
-        return y, (h, qkv, o)
+        return y, _sv(h, qkv, o)
 
     @staticmethod
     def bwd(saved, dy, p, meta, need_dbias=True, dy_f32=None):
@@ -163,10 +176,15 @@ class XInner:
         if K.xattn2_supported(g, q):          # fast mode: statistics only, the backward recomputes the probabilities
             o, stats = K.xattn2_fwd(g, q, pk, wth2)
             P, Pm = stats, None
+        elif K.mixed() and K.xattn2_supported(g):
+            # 3-MFMA forward that leaves only the softmax statistics; the bf16 backward (xattn2_bwd) recomputes from the hi parts
+            o, stats = K.xattn_fwd(g, q, pk, wth2, want_stats=True)
+            P, Pm = stats, None
+            pk.drop_lo()
         else:
             o, P, Pm = K.xattn_fwd(g, q, pk, wth2, save=meta.get('save', True))
         y = K.gemm_nt(o, W['out'], out_bf16=_fast())
-        return y, (h, ctx, q, pk, P, Pm, o)
+        return y, _sv(h, ctx, q, pk, P, Pm, o)
 
     @staticmethod
     def bwd(saved, dy, p, meta, need_dbias=False, dy_f32=None):
@@ -234,7 +252,7 @@ class FFInner:
         gg = K.empty_bf((h.hi.shape[0], W['FP']), h.hi.device)
         u = K.gemm_nt(h, W['w1'], out_bf16=True, shift=meta.get('shift'), geglu_out=gg)   # u (interleaved layout) and a * gelu(gate)
         y = K.gemm_nt(gg, W['w2'], out_bf16=_fast())
-        return y, (h, u, gg)
+        return y, _sv(h, u, gg)
 
     @staticmethod
     def bwd(saved, dy, p, meta, need_dbias=False, dy_f32=None):
@@ -323,7 +341,7 @@ class XC2Inner:
         o0 = P0[..., :1] * _bf_val(nv).reshape(1, heads, dh) + torch.einsum('bht,bthd->bhd', P0[..., 1:], kvf[:, :, 1])
         _bf_put(o, rows0, o0.reshape(g.B, inner))
         y = K.gemm_nt(o, W['out'], out_bf16=_fast())
-        return y, (h, q, kv, nk, nv, o, P0)
+        return y, _sv(h, q, kv, nk, nv, o, P0)
 
     @staticmethod
     def bwd(saved, dy, p, meta, need_dbias=False, dy_f32=None):
@@ -385,7 +403,13 @@ class WgradStream:
 def _fast():
     """fast bf16 mode: the GEMMs that feed a LayerNorm (to_out / FF w2 outputs, dgrad outputs) write bf16 and the LN kernels
     read bf16 -- half the epilogue and LN traffic.  Parity mode (bf16x3) keeps those tensors in fp32."""
-    return not K.want_lo()
+    return K.fast_io()
+
+
+def _sv(*ts):
+    """what an inner stage keeps for its backward: in the mixed mode ('bf16x3-fwd') the hi parts only -- the lo parts die with the
+    forward of the block"""
+    return tuple(K.hi_only(t) for t in ts) if K.mixed() else ts
 
 
 def _as_f32(t):
@@ -409,6 +433,7 @@ class SandwichBlockFn(Function):
     args: x [B, n, D] fp32, resid (or None), context (or None), meta dict, pre_w, pre_b, post_w, post_b, *inner params"""
 
     @staticmethod
+    @_in_phase('fwd')
     def forward(ctx, x, resid, context, meta, pre_w, pre_b, post_w, post_b, *p):
         inner = INNERS[meta['kind']]
         B, n, D = x.shape
@@ -449,6 +474,7 @@ class SandwichBlockFn(Function):
         return xo.reshape(B, n, D)
 
     @staticmethod
+    @_in_phase('bwd')
     def backward(ctx, g):
         x2, y, m1, r1, m2, r2, pre_w, post_w = ctx.saved_tensors
         if ctx.y_bf:
@@ -496,6 +522,7 @@ class SandwichBlockFn(Function):
 
 class InnerFn(Function):
     @staticmethod
+    @_in_phase('fwd')
     def forward(ctx, x, context, meta, *p):
         inner = INNERS[meta['kind']]
         B, n, D = x.shape
@@ -513,6 +540,7 @@ class InnerFn(Function):
         return y.reshape(B, n, y.shape[-1])
 
     @staticmethod
+    @_in_phase('bwd')
     def backward(ctx, g):
         B, n, D = ctx.shape
         meta, p = ctx.meta, ctx.p
@@ -535,6 +563,7 @@ class InnerFn(Function):
 
 class LayerNormFn(Function):
     @staticmethod
+    @_in_phase('fwd')
     def forward(ctx, x, w, b, stable):
         shp = x.shape
         x2 = x.detach().contiguous().reshape(-1, shp[-1])
@@ -547,6 +576,7 @@ class LayerNormFn(Function):
         return out.reshape(shp)
 
     @staticmethod
+    @_in_phase('bwd')
     def backward(ctx, g):
         x2, m, r, w = ctx.saved_tensors
         g2 = g.contiguous().reshape(x2.shape)
@@ -559,6 +589,7 @@ class StableLNFn(Function):
     produced separately in LogitsFn; standalone use returns fp32)."""
 
     @staticmethod
+    @_in_phase('fwd')
     def forward(ctx, x, w, b):
         shp = x.shape
         x2 = x.detach().contiguous().reshape(-1, shp[-1])
@@ -571,6 +602,7 @@ class StableLNFn(Function):
         return y.reshape(shp)
 
     @staticmethod
+    @_in_phase('bwd')
     def backward(ctx, g):
         x2, m, r, ia, w = ctx.saved_tensors
         g2 = g.contiguous().reshape(x2.shape)
@@ -586,6 +618,7 @@ class LogitsFn(Function):
     """x [B, n, D] -> logits [B, n, C] fp32 (StableLayerNorm then Linear without bias)"""
 
     @staticmethod
+    @_in_phase('fwd')
     def forward(ctx, x, nw, nb, wl, cache):
         B, n, D = x.shape
         x2 = x.detach().contiguous().reshape(B * n, D)
@@ -593,10 +626,11 @@ class LogitsFn(Function):
         hn, m, r, ia = K.ln_fwd(x2, nw.detach(), nb.detach(), stable=True)
         logits = K.gemm_nt(hn, W['w'])
         ctx.save_for_backward(x2, m, r, ia, nw, wl)
-        ctx.hn, ctx.W, ctx.shape = hn, W, (B, n, D)
+        ctx.hn, ctx.W, ctx.shape = _sv(hn)[0], W, (B, n, D)
         return logits.reshape(B, n, -1)
 
     @staticmethod
+    @_in_phase('bwd')
     def backward(ctx, g):
         x2, m, r, ia, nw, wl = ctx.saved_tensors
         B, n, D = ctx.shape
@@ -616,6 +650,7 @@ class LogitsLossFn(Function):
     (bf16 hi[/lo], already divided by the number of targets) so the fp32 logits are read only once."""
 
     @staticmethod
+    @_in_phase('fwd')
     def forward(ctx, x, targets, nw, nb, wl, cache):
         B, n, D = x.shape
         x2 = x.detach().contiguous().reshape(B * n, D)
@@ -632,12 +667,14 @@ class LogitsLossFn(Function):
             loss, dl = fused
         else:
             logits = K.gemm_nt(hn, W['w'])
-            loss, dl = K.ce_fwd(logits, t, 1.0 / (B * n), want_grad=want_grad)
+            loss, dl = K.ce_fwd(logits, t, 1.0 / (B * n), want_grad=want_grad, lo=False if K.mixed() else None)
+            del logits
         ctx.save_for_backward(x2, m, r, ia, nw, wl)
-        ctx.hn, ctx.dl, ctx.W, ctx.shape = hn, dl, W, (B, n, D)
+        ctx.hn, ctx.dl, ctx.W, ctx.shape = _sv(hn)[0], dl, W, (B, n, D)
         return loss
 
     @staticmethod
+    @_in_phase('bwd')
     def backward(ctx, g):
         x2, m, r, ia, nw, wl = ctx.saved_tensors
         B, n, D = ctx.shape
@@ -661,6 +698,7 @@ class EmbedAssembleFn(Function):
     """ids [B, n-1] int64 -> x [B, n, D] fp32 = cat(bos, pos[:n-1] + frac_gradient(emb(ids)))"""
 
     @staticmethod
+    @_in_phase('fwd')
     def forward(ctx, ids, W, ax1, ax2, ax3, bos, video_shape, frac):
         B, n1 = ids.shape
         ntok = n1 + 1
@@ -672,6 +710,7 @@ class EmbedAssembleFn(Function):
         return x.reshape(B, ntok, -1)
 
     @staticmethod
+    @_in_phase('bwd')
     def backward(ctx, g):
         (ids,) = ctx.saved_tensors
         B, ntok, F, H, Wd, frac, ws, s1, s2, s3, sb = ctx.meta

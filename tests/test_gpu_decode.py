@@ -189,7 +189,7 @@ def _rows_in(nuwa, ids):
 
 
 @pytest.mark.parametrize('graph', [False, True])
-@pytest.mark.parametrize('mode,tol', [('bf16x3', 1e-3), ('bf16', 4e-2)])
+@pytest.mark.parametrize('mode,tol', [('bf16x3', 1e-3), ('bf16x3-fwd', 1e-3), ('bf16', 1e-2)])
 def test_teacher_forced_cached_logits_match_reference_golden(A, mode, tol, graph):
     """fixture g5 holds the REFERENCE's logits for a 48-token sequence: the cached decoder, fed the same tokens one row at a
     time (eagerly and through the captured HIP graph), must reproduce every row"""

@@ -110,7 +110,7 @@ def test_bench_py_two_ranks_end_to_end():
     port = 29900 + (os.getpid() % 90)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
-           '--parity-batch', '1', '--backend', 'gloo', '--single-device', '--no-tokenizer', '--no-cpu-baseline']
+           '--side-batch', '1', '--backend', 'gloo', '--single-device', '--no-tokenizer', '--no-cpu-baseline']
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -122,5 +122,5 @@ def test_bench_py_two_ranks_end_to_end():
     assert out['value'] > 0 and abs(out['value'] - 2 * out['per_gpu_value']) < 1e-6 * out['value']
     assert abs(out['value'] - 2 * 2 * 2560 * 2 / (out['ms_per_step'] * 2e-3)) < 1e-3 * out['value']
     assert out['roofline']['launches'] > 0 and 0 < out['roofline']['frac'] < 1
-    assert out['parity_mode']['dtype'] == 'bf16x3' and out['parity_mode']['value'] > 0
+    assert out['precision_mode'] == 'bf16x3-fwd' and out['fast_mode']['dtype'] == 'bf16' and out['fast_mode']['value'] > 0
     assert 8.5 < out['config']['loss'] < 10.0                      # ~ln(8192) at random init

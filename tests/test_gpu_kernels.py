@@ -61,6 +61,32 @@ def test_gemm_nt(K, M, N, K_, x3):
         report(f'gemm_nt_bf16hilo[{M},{N},{K_}]', bf_value(outb), ref.float(), 3e-5)
 
 
+@pytest.mark.parametrize('M,N,K_', [(16384, 2048, 512), (16384 + 37, 2752, 512), (2560 * 8, 1536 + 8, 1376), (256 * 512, 260, 32)])
+def test_gemm_nt_x3_256_ring(K, M, N, K_):
+    """the bf16x3 256x256 ring (forward GEMMs of the 'bf16x3' / 'bf16x3-fwd' modes) against the first-generation 128x128 x3 kernel
+    (tuning key 13 = 1): same accumulation order -> bit-identical; and against fp64 on the hi + lo operand values"""
+    from nuwa_pytorch_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(1)
+    a = (torch.randn(M, K_) * (1 + torch.arange(K_) % 3)).to(DEV)
+    b = (torch.randn(N, K_) + 0.25).to(DEV)
+    A, Bm = to_bf_pair(a, True), to_bf_pair(b, True)
+    bias = torch.randn(N, device=DEV)
+    ref = (bf_value(A).double() @ bf_value(Bm).double().t()) * 0.5 + bias.double()
+    try:
+        L.amdnuwa_set_tuning(13, 1)
+        old_f = K.gemm_nt(A, Bm, bias=bias, alpha=0.5)
+        old_b = K.gemm_nt(A, Bm, bias=bias, alpha=0.5, out_bf16=True)
+    finally:
+        L.amdnuwa_set_tuning(13, 0)
+    new_f = K.gemm_nt(A, Bm, bias=bias, alpha=0.5)
+    new_b = K.gemm_nt(A, Bm, bias=bias, alpha=0.5, out_bf16=True)
+    report(f'gemm_nt_x3_256[{M},{N},{K_}] f32 vs fp64', new_f, ref.float(), 2e-5)
+    report(f'gemm_nt_x3_256[{M},{N},{K_}] hi+lo vs fp64', bf_value(new_b), ref.float(), 3e-5)
+    assert torch.equal(new_f, old_f), f'fp32 output differs from the 128x128 x3 kernel: {(new_f - old_f).abs().max().item():.3e}'
+    assert torch.equal(new_b.hi, old_b.hi) and torch.equal(new_b.lo, old_b.lo)
+
+
 @pytest.mark.parametrize('B,ntok,fmap,D,N', [(2, 17, 4, 32, 24), (3, 48, 4, 64, 130), (2, 129, 8, 128, 64), (1, 2561, 16, 512, 256)])
 def test_gemm_nt_shift_loader(K, B, ntok, fmap, D, N):
     torch.manual_seed(1)

@@ -3,8 +3,11 @@
 state dict, must reproduce the reference's outputs and gradients.
 
 Tolerances (max-abs error / max-abs reference):
-  'bf16x3' parity mode : 1e-3  -- the north-star bound on logits ("within 1e-3 relative"); grads 2e-3
-  'bf16'   fast mode   : 4e-2  -- bf16 MFMA operands (the reference's own bf16 autocast is 4e-3..1e-2 per layer)
+  'bf16x3'     parity mode    : 1e-3  -- the north-star bound on logits ("within 1e-3 relative"); grads 2e-3
+  'bf16x3-fwd' compliant mode : outputs 1e-3 (the bf16x3 forward), gradients as 'bf16' (bf16 backward on the hi parts)
+  'bf16'       fast mode      : outputs 2e-2, gradients 7e-2 = 1.5 x the largest errors these tiny fixtures measured in round 2
+                                (1.34e-2 on g9a's audio logits; 4.46e-2 on one 2x2 talking-heads gradient of g8, everything else
+                                <= 3.3e-2; the reference's own bf16 autocast is 4e-3..1e-2 per layer)
 VQ code indices: bit-exact wherever the fixture's top-2 similarity gap exceeds 1e-5."""
 import pytest
 import torch
@@ -15,7 +18,7 @@ from golden_util import load, load_raw, tup  # noqa: E402
 from gpu_util import report  # noqa: E402
 
 DEV = 'cuda'
-MODES = [('bf16x3', 1e-3, 2e-3), ('bf16', 4e-2, 8e-2)]
+MODES = [('bf16x3', 1e-3, 2e-3), ('bf16x3-fwd', 1e-3, 7e-2), ('bf16', 2e-2, 7e-2)]
 
 
 @pytest.fixture(scope='module')

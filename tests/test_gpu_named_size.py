@@ -10,8 +10,11 @@
   cfg 5  dim 512 dual decoder: one depth (video triple, audio triple, cross-modality pair) fwd + bwd vs the oracle
 
 Tolerances (max-abs error / max-abs reference), as everywhere in tests/:
-  'bf16x3' parity mode: outputs 1e-3 (the north-star bound), gradients 2e-3
-  'bf16'   fast mode  : outputs 4e-2, gradients 8e-2 (bf16 MFMA operands; measured values are recorded)
+  'bf16x3'     parity mode     : outputs 1e-3 (the north-star bound), gradients 2e-3
+  'bf16x3-fwd' compliant mode  : outputs 1e-3 (its forward IS the bf16x3 forward: asserted bit-identical at full depth),
+                                 gradients as 'bf16' (its backward runs single bf16 MFMAs on the hi parts)
+  'bf16'       fast mode       : outputs 9e-3, gradients 1.4e-2 = 1.5 x the largest errors measured at these sizes in round 2
+                                 (5.6e-3 / 9.1e-3, profiles/r02h_named_size.json); full-depth logits 1.2e-2 (measured 7.9e-3)
 """
 import json
 import os
@@ -24,7 +27,7 @@ pytestmark = pytest.mark.gpu
 from gpu_util import report, record, rel_err, rel_l2, ROOT  # noqa: E402
 
 DEV = 'cuda'
-MODES = [('bf16x3', 1e-3, 2e-3), ('bf16', 4e-2, 8e-2)]
+MODES = [('bf16x3', 1e-3, 2e-3), ('bf16x3-fwd', 1e-3, 1.4e-2), ('bf16', 9e-3, 1.4e-2)]
 SUMMARY = os.path.join(ROOT, 'gpurun_out', 'named_size.json')
 
 
@@ -129,7 +132,8 @@ def test_cfg2_decoder_layer_vs_oracle(A, O):
 
 def test_cfg3_full_depth_logits_vs_oracle(A, O):
     """the whole named decoder (24 layers, dim 512, n = 2560, codebook 8192), one sample: logits vs the oracle.
-    'bf16x3' must meet the north-star 1e-3; the fast 'bf16' mode's error is MEASURED here and bounded by its documented 4e-2."""
+    'bf16x3' and 'bf16x3-fwd' (same forward, bit for bit) must meet the north-star 1e-3; the fast 'bf16' mode's error is MEASURED
+    here and bounded by 1.5 x its round-2 value."""
     import bench
     c = bench.CFGS['cfg3']
     torch.manual_seed(0)
@@ -146,7 +150,7 @@ def test_cfg3_full_depth_logits_vs_oracle(A, O):
     with torch.no_grad():
         loss_r, logits_r = O.decoder_loss(P, cfg, ids, ctx, mask, training=True, return_logits=True)
     nuwa = nuwa.to(DEV).train()
-    res = {}
+    res, got = {}, {}
     for mode, tol, _ in MODES:
         A.set_precision(mode)
         try:
@@ -157,6 +161,7 @@ def test_cfg3_full_depth_logits_vs_oracle(A, O):
                 loss = nuwa._final(h, ids.to(DEV))
             res[mode] = dict(logits_rel_max=rel_err(logits, logits_r), logits_rel_l2=rel_l2(logits, logits_r),
                              loss=float(loss), loss_ref=float(loss_r), loss_rel=abs(float(loss) - float(loss_r)) / abs(float(loss_r)))
+            got[mode] = logits.float().cpu()
         finally:
             A.set_precision('bf16')
     _note('cfg3.full_depth_logits', res)
@@ -164,8 +169,10 @@ def test_cfg3_full_depth_logits_vs_oracle(A, O):
         record(f'cfg3.full24[{mode}].logits', res[mode]['logits_rel_max'], res[mode]['logits_rel_l2'], tol)
     assert res['bf16x3']['logits_rel_max'] <= 1e-3, res
     assert res['bf16x3']['loss_rel'] <= 1e-4, res
-    assert res['bf16']['logits_rel_max'] <= 4e-2, res
-    assert res['bf16']['loss_rel'] <= 2e-3, res
+    assert torch.equal(got['bf16x3-fwd'], got['bf16x3']), 'the compliant mode must run the bf16x3 forward bit for bit'
+    assert res['bf16x3-fwd']['logits_rel_max'] <= 1e-3, res
+    assert res['bf16']['logits_rel_max'] <= 1.2e-2, res
+    assert res['bf16']['loss_rel'] <= 2e-5, res
 
 
 def test_cfg4_reversible_blocks_vs_oracle(A, O):
