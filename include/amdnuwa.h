@@ -123,7 +123,8 @@ int amdnuwa_ln_post_pre_fwd(const float* y, const float* resid, const float* w, 
  *   dx = g + dLN(dh; x, mean, rstd, w)        (dh read through the inverse token shift when shift_ntok > 0; dw, db its weight grads)
  * and, on the same row while it is in registers, the post-norm backward of block k,
  *   dy_prev = dLN(dx; y_prev, mean_prev, rstd_prev, w_prev)   (bf16 hi[/lo]; dw_prev, db_prev; dsum_prev = column sums, optional).
- * inputs_bf16 != 0: dh and y_prev point at bf16 values (fast mode), else fp32. */
+ * inputs_bf16: 0 = dh and y_prev point at fp32 values, 1 = both at bf16 values (the all-bf16 mode), 2 = dh bf16 and y_prev fp32
+ * (the 'bf16x3-fwd' mode: fp32 post-norm inputs from its 3-MFMA forward, bf16 dgrad outputs in its backward). */
 size_t amdnuwa_ln_bwd_chain_workspace_bytes(long long R, int D);
 int amdnuwa_ln_bwd_chain(const void* dh, const float* x, const float* mean, const float* rstd, const float* w, const float* g,
                          float* dx, float* dw, float* db, const void* y_prev, const float* mean_prev, const float* rstd_prev,
@@ -206,6 +207,12 @@ typedef struct {
     int noncausal;
 } amdnuwa_s3_geom;
 
+/* 1 when the window kernels (amdnuwa_sparse3dna_*, amdnuwa_cross2dna_*) take this geometry in the given operand form
+ * (lo_operands != 0: bf16 hi + lo pairs): head size 32 / 64, <= 8 heads, W * heads * 4 <= 512, and the window's LDS tables
+ * (they grow with J = kf*kh*kw + 1 key slots: Sparse3DNA / SparseCross2DNA kernel sizes, reference nuwa_pytorch.py:382-394,
+ * 761-790) within the CU's 160 KiB for the forward AND both backward kernels.  The entry points themselves return
+ * AMDNUWA_ERR_UNSUPPORTED for a geometry this query rejects. */
+int amdnuwa_s3_supported(const amdnuwa_s3_geom* g, int lo_operands);
 int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* k, const uint16_t* v,
                            const uint16_t* q_lo, const uint16_t* k_lo, const uint16_t* v_lo, int ld,
                            const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, amdnuwa_stream stream);

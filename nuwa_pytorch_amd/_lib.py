@@ -82,6 +82,7 @@ SIGNATURES = {
     'amdnuwa_scale_by_device_scalar': (I, [P, SZ, P, P]),
     'amdnuwa_linear_ce_workspace_bytes': (SZ, [LL, I]),
     'amdnuwa_linear_ce': (I, [P, I, P, I, P, LL, I, I, F, P, P, P, I, P, SZ, P]),
+    'amdnuwa_s3_supported': (I, [SG, I]),
     'amdnuwa_sparse3dna_fwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P]),
     'amdnuwa_sparse3dna_bwd_workspace_bytes': (SZ, [SG]),
     'amdnuwa_sparse3dna_bwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P, P, P, P, P, P, I, P, I, P, SZ, P]),

@@ -366,7 +366,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 //   block k+1's output;  y_prev = inner output of block k (post-norm input).
 // Partials: partA [nblk][3][D] = (dw_pre, db_pre, -) and partB [nblk][3][D] = (dw_post, db_post, sum(dy_prev)).
 // ---------------------------------------------------------------------------------------------
-template <int NV, bool BF, int NT = 0>          // NT bit 0: non-temporal stores, bit 1: non-temporal loads (tuning key 11)
+// BFM: storage of the two 16-bit-capable inputs -- 0: dh and y_prev fp32; 1: both bf16; 2: dh bf16, y_prev fp32 (the 'bf16x3-fwd' mode:
+// its forward keeps the post-norm input in fp32, its backward produces bf16 dgrad outputs)
+template <int NV, int BFM, int NT = 0>          // NT bit 0: non-temporal stores, bit 1: non-temporal loads (tuning key 11)
 __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restrict__ dh, const float* __restrict__ x,
                                                            const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                            const float* __restrict__ w, const float* __restrict__ gres,
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
                                                            float* __restrict__ partB, long long R, int D, int shift_ntok,
                                                            int shift_fmap) {
 #pragma clang fp contract(off)        // (see ln_bwd_kernel)
+    constexpr bool BF = BFM != 0, YBF = BFM == 1;
     __shared__ float red[ROWS_PER_BLOCK][3][NV * 256];
     const int lane = threadIdx.x & 63, wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4 pwA[NV], pbA[NV], pwB[NV], pbB[NV], psB[NV];
@@ -421,11 +424,11 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
             for (int it = 0; it < NV; ++it) {
                 const int e = (lane + it * 64) * 4;
                 in.rv.v[it] = e < D ? ld4_nt<false>(gres, (size_t)row * D + e) : zero4;
-                in.yv.v[it] = e < D ? ld4_nt<BF>(yprev, (size_t)row * D + e) : zero4;
+                in.yv.v[it] = e < D ? ld4_nt<YBF>(yprev, (size_t)row * D + e) : zero4;
             }
         } else {
             row_load(gres + row * D, D, lane, in.rv);
-            row_load_t<BF>(yprev, (size_t)row * D, D, lane, in.yv);
+            row_load_t<YBF>(yprev, (size_t)row * D, D, lane, in.yv);
         }
         in.mean = mean_i[row]; in.rstd = rstd_i[row]; in.meanp = meanp_i[row]; in.rstdp = rstdp_i[row];
     };
@@ -989,6 +992,7 @@ extern "C" int amdnuwa_ln_bwd_chain(const void* dh, const float* x, const float*
         return AMDNUWA_ERR_ARG;
     if (D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
     if (shift_ntok > 0 && (shift_fmap == 0 || shift_fmap < -1 || D % 16)) return AMDNUWA_ERR_ARG;
+    if (inputs_bf16 < 0 || inputs_bf16 > 2) return AMDNUWA_ERR_ARG;
     if (!workspace || workspace_bytes < amdnuwa_ln_bwd_chain_workspace_bytes(R, D)) return AMDNUWA_ERR_WORKSPACE;
     if (R <= 0) return AMDNUWA_OK;
     int nb = ln_bwd_blocks(R);
@@ -1001,7 +1005,7 @@ extern "C" int amdnuwa_ln_bwd_chain(const void* dh, const float* x, const float*
         if (g_amdnuwa_tuning[12] > 0 && g_amdnuwa_tuning[12] * n_cu < nb) nb = g_amdnuwa_tuning[12] * n_cu; \
         hipLaunchKernelGGL((ln_bwd_chain_kernel<NV_, BF_, NT_>), dim3(nb), dim3(256), 0, stream, (const float*)dh, x, mean, rstd, w, g, dx, (const float*)y_prev, mean_prev, rstd_prev, w_prev, dy_prev_hi, dy_prev_lo, partA, partB, R, D, shift_ntok, shift_fmap); } while (0)
 #define LBC_(NV_, BF_) do { if (nt == 0) LBC__(NV_, BF_, 0); else if (nt == 1) LBC__(NV_, BF_, 1); else if (nt == 2) LBC__(NV_, BF_, 2); else LBC__(NV_, BF_, 3); } while (0)
-#define LBC(NV_) do { if (inputs_bf16) LBC_(NV_, true); else LBC_(NV_, false); } while (0)
+#define LBC(NV_) do { if (inputs_bf16 == 1) LBC_(NV_, 1); else if (inputs_bf16 == 2) LBC_(NV_, 2); else LBC_(NV_, 0); } while (0)
     if (D <= 256) LBC(1); else if (D <= 512) LBC(2); else LBC(4);
 #undef LBC
 #undef LBC_

@@ -35,6 +35,7 @@ struct GemmArgs {
     long long sA_in, sB_in, sC_in;
     int nsplit;             // TN 256 ring: number of K splits (the grid is flattened over (split, tile))
     bf16_t* C2; int ldc2;   // NT bf16 epilogue: GEGLU output (C in the interleaved-by-8 layout), or NULL
+    bf16_t* C2lo;           // its lo part (bf16x3 ring only)
     const bf16_t* Uin; int ldu;   // != NULL: GEGLU BACKWARD epilogue: C2 = du from (product = dgg, Uin = u); C is not written
     int dbg;                // probe only (tuning key 7): bit0 skip epilogue stores, bit1 skip main loop
     // fused linear + cross entropy (EPI 2 / 3 of the 256x256 ring): per (row, 64-column block) partial (max, sum exp) and the
@@ -912,6 +913,21 @@ __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
                     reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
                     reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2(l[8], l[9]), pack2(l[10], l[11]), pack2(l[12], l[13]), pack2(l[14], l[15]));
                 }
+                if (p.C2) {
+                    // FF1 (np.py:274-277): the lane's 16 columns are 8 values and their 8 gates (interleaved-by-8 weight rows); the gate runs
+                    // on the fp32 accumulators themselves and leaves as a hi + lo pair, the A operand of FF2.  u's own lo part is only
+                    // written when the caller wants it (the bf16x3 backward); the bf16x3-fwd mode keeps u.hi for its bf16 backward.
+                    bf16_t gh[8], gl[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float av = acc[i][e >> 2][e & 3] * p.alpha + bias16[e];
+                        const float gv = acc[i][2 + (e >> 2)][e & 3] * p.alpha + bias16[8 + e];
+                        f2bf_hilo(av * gelu_f(gv), gh[e], gl[e]);
+                    }
+                    *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) = make_uint4(pack2(gh[0], gh[1]), pack2(gh[2], gh[3]), pack2(gh[4], gh[5]), pack2(gh[6], gh[7]));
+                    if (p.C2lo)
+                        *reinterpret_cast<uint4*>(p.C2lo + m * p.ldc2 + (nb >> 1)) = make_uint4(pack2(gl[0], gl[1]), pack2(gl[2], gl[3]), pack2(gl[4], gl[5]), pack2(gl[6], gl[7]));
+                }
             } else {
                 for (int e = 0; e < 16 && nb + e < p.N; ++e) {
                     C[e] = h[e];
@@ -1577,7 +1593,10 @@ extern "C" int amdnuwa_geglu_il_bwd(const uint16_t* u_hi, const uint16_t* u_lo, 
 
 // can the GEGLU gate ride in the epilogue of the kernel this product will run on (the 256x256 staggered ring, bf16 output)?
 static bool nt_geglu_fusable(const amdnuwa_gemm_desc* d) {
-    if (d->Alo || d->Clo || d->C2lo || !d->c_is_bf16 || d->batch > 1) return false;
+    if (!d->c_is_bf16 || d->batch > 1) return false;
+    if (d->Alo) {                  // bf16x3 ring: the FORWARD gate only (hi + lo gate output), no token shift in the loader
+        if (!d->Blo || d->geglu_u || d->shift_ntok > 0 || g_amdnuwa_tuning[13] == 1) return false;
+    } else if (d->Clo || d->C2lo) return false;
     if (d->K % 32 || d->N % 16 || d->ldc % 8 || d->ldc2 % 8) return false;
     if (d->geglu_u && (d->geglu_u_lo || d->ld_u % 8)) return false;
     const int v = g_amdnuwa_tuning[0];
@@ -1700,7 +1719,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     p.ksplit_len = 0;
     p.dbg = g_amdnuwa_tuning[7];
     p.skew = 0;
-    p.C2 = nullptr; p.ldc2 = 0; p.Uin = nullptr; p.ldu = 0;
+    p.C2 = nullptr; p.C2lo = nullptr; p.ldc2 = 0; p.Uin = nullptr; p.ldu = 0;
     p.batch_inner = d->batch_inner; p.sA_in = d->strideA_inner; p.sB_in = d->strideB_inner; p.sC_in = d->strideC_inner;
     const bool x3 = d->Alo != nullptr, sh = d->shift_ntok > 0, ob = d->c_is_bf16 != 0;
     // a handful of rows (the decode step of generate()): stream the weight instead of running MFMA tiles
@@ -1733,6 +1752,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         dim3 g3(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b3(512);
         const size_t l3 = (size_t)2 * 4 * 256 * 32 * 2;
+        if (d->C2) { p.C2 = (bf16_t*)d->C2; p.C2lo = (bf16_t*)d->C2lo; p.ldc2 = d->ldc2; }
         if (ob) {
             (void)hipFuncSetAttribute((const void*)gemm_nt_256x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3);
             hipLaunchKernelGGL((gemm_nt_256x3_kernel<1>), g3, b3, l3, stream, p);

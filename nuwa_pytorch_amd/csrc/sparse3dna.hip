@@ -763,6 +763,23 @@ int check_geom(const amdnuwa_s3_geom* g) {
     if (g->ntok < 1 || g->ntok - 1 > g->F * g->H * g->W) return AMDNUWA_ERR_ARG;
     return AMDNUWA_OK;
 }
+// Dynamic LDS of the window kernels grows with the window: J = kf*kh*kw + 1 key slots per query.  The largest request over the
+// forward, the query-side and the key-side backward in the given operand form (lo = hi + lo pairs); the MFMA band kernels of
+// the causal decoder shapes need less.  A launch above the CU's 160 KiB would fail inside hipLaunchKernel -- typically in the
+// backward, after the forward succeeded -- so the entry points refuse the geometry up front (AMDNUWA_ERR_UNSUPPORTED) and
+// amdnuwa_s3_supported() lets the host route such windows to its PyTorch-op formulation.
+constexpr size_t S3_LDS_MAX = 160 * 1024 - 2048;        // leaves room for the kernels' static __shared__ arrays
+size_t s3_lds_need(const amdnuwa_s3_geom* g, bool lo) {
+    const size_t J = (size_t)g->kf * g->kh * g->kw + 1, inner = (size_t)g->heads * g->dim_head, W = (size_t)g->W;
+    const size_t stage = W * inner * (lo ? 4 : 2), nsp = W * J * g->heads;
+    const size_t fwd = stage + nsp * 4;
+    size_t spdp = 2 * nsp;
+    if (spdp < W * inner) spdp = W * inner;
+    const size_t bq = stage + (spdp + 8 * 64) * 4;
+    const size_t bkv = W * inner * 8;
+    size_t m = fwd > bq ? fwd : bq;
+    return m > bkv ? m : bkv;
+}
 // ---------------------------------------------------------------------------------------------
 // MFMA forward (fast bf16 mode, W == 16, 8 heads x 64): one workgroup = one query row of the grid, wave h = head h.
 //   phase 1  scores: for every causal tap plane the 16 keys of that grid row go STRAIGHT from global memory into the A operand
@@ -1431,6 +1448,7 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
                                       const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, hipStream_t stream) {
     int rc = check_geom(g);
     if (rc) return rc;
+    if (s3_lds_need(g, k_lo != nullptr) > S3_LDS_MAX) return AMDNUWA_ERR_UNSUPPORTED;
     if (!q || !k || !v || !w_th || !o || ld % 8 || ldo % 8) return AMDNUWA_ERR_ARG;
     if (g->B <= 0) return AMDNUWA_OK;
     S3Args a{};
@@ -1468,6 +1486,11 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
     return AMDNUWA_OK;
 }
 
+extern "C" int amdnuwa_s3_supported(const amdnuwa_s3_geom* g, int lo_operands) {
+    if (check_geom(g)) return 0;
+    return s3_lds_need(g, lo_operands != 0) <= S3_LDS_MAX ? 1 : 0;
+}
+
 extern "C" size_t amdnuwa_sparse3dna_bwd_workspace_bytes(const amdnuwa_s3_geom* g) {
     if (check_geom(g)) return 0;
     const size_t J = (size_t)g->kf * g->kh * g->kw + 1, nq = g->ntok - 1, rows = (size_t)g->B * g->F * g->H;
@@ -1484,6 +1507,7 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
                                       size_t workspace_bytes, hipStream_t stream) {
     int rc = check_geom(g);
     if (rc) return rc;
+    if (s3_lds_need(g, k_lo != nullptr) > S3_LDS_MAX) return AMDNUWA_ERR_UNSUPPORTED;
     if (!q || !k || !v || !w_th || !dO || !dq || !dk || !dv || !dw_th || ld % 8 || lddo % 8 || ldd % 8) return AMDNUWA_ERR_ARG;
     if (!workspace || workspace_bytes < amdnuwa_sparse3dna_bwd_workspace_bytes(g)) return AMDNUWA_ERR_WORKSPACE;
     if (g->B <= 0) return AMDNUWA_OK;
@@ -1564,6 +1588,7 @@ int cross_setup(S3Args& a, const amdnuwa_s3_geom* g, int ctx_rows, const uint16_
                 const uint16_t* null_v_lo, const uint8_t* key_mask) {
     int rc = check_geom(g);
     if (rc) return rc;
+    if (s3_lds_need(g, k_lo != nullptr) > S3_LDS_MAX) return AMDNUWA_ERR_UNSUPPORTED;
     if (!k || !v || !null_k || !null_v || ldkv % 8) return AMDNUWA_ERR_ARG;
     if (g->rel_bias || ctx_rows != g->kf * g->H * g->W) return AMDNUWA_ERR_ARG;
     if ((k_lo != nullptr) != (v_lo != nullptr) || (k_lo != nullptr) != (null_k_lo != nullptr) || (k_lo != nullptr) != (null_v_lo != nullptr))

@@ -162,11 +162,16 @@ def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None,
     d.bias = _p(bias)
     d.alpha, d.beta = float(alpha), 0.0
     d.M, d.N, d.K, d.batch = M, N, K, 1
+    if shift is not None:
+        d.shift_ntok, d.shift_fmap = int(shift[0]), int(shift[1])
     if geglu_out is not None:      # C (bf16, interleaved-by-8 columns) = u; geglu_out BF [M, N/2] = a * gelu(gate), in the epilogue when possible
         assert out_bf16
         d.C2, d.C2lo, d.ldc2 = _p(geglu_out.hi), _p(geglu_out.lo), _ld(geglu_out.hi)
-    if shift is not None:
-        d.shift_ntok, d.shift_fmap = int(shift[0]), int(shift[1])
+        if x3 and mixed() and out.lo is not None and L.amdnuwa_gemm_nt_fused(C.byref(d)):
+            # 'bf16x3-fwd': the gate runs on the fp32 accumulators inside the epilogue and the bf16 backward reads u.hi only --
+            # u's lo part (a third of this GEMM's output bytes) is never needed, so it is not written
+            out = BF(out.hi, None)
+            d.Clo = None
     st = _stream()
     if _TIMER['on']:
         _TIMER['flops'] += 2.0 * M * N * K                     # ALGORITHMIC: one product per (m, n, k) whatever the operand form
@@ -322,11 +327,12 @@ def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift
 
 def ln_bwd_chain(dh, x, mean, rstd, w, g, y_prev, mean_prev, rstd_prev, w_prev, *, shift=None, want_dsum=False):
     """pre-norm backward of a block and the post-norm backward of the block before it in one pass over the gradient row.
-    dh, y_prev: both fp32 tensors or both hi-only BF pairs.  returns (dx fp32, dw, db, dy_prev BF, dw_prev, db_prev, dsum_prev)"""
+    dh, y_prev: both fp32 tensors, both hi-only BF pairs, or dh a BF pair with an fp32 y_prev ('bf16x3-fwd').  returns (dx fp32, dw, db, dy_prev BF, dw_prev, db_prev, dsum_prev)"""
     L = _lib.lib()
     dhp, dhbf, _, _ = _f32_or_bf(dh)
     yp, ybf, (R, D), dev = _f32_or_bf(y_prev)
-    assert dhbf == ybf, 'ln_bwd_chain: dh and y_prev must have the same storage form'
+    assert dhbf or not ybf, 'ln_bwd_chain: fp32 dh with a bf16 y_prev is not a form any mode produces'
+    form = 1 if (dhbf and ybf) else (2 if dhbf else 0)            # == the inputs_bf16 argument of amdnuwa_ln_bwd_chain
     dx = torch.empty((R, D), dtype=torch.float32, device=dev)
     dw, db, dwp, dbp = (torch.empty(D, dtype=torch.float32, device=dev) for _ in range(4))
     dsp = torch.empty(D, dtype=torch.float32, device=dev) if want_dsum else None
@@ -336,7 +342,7 @@ def ln_bwd_chain(dh, x, mean, rstd, w, g, y_prev, mean_prev, rstd_prev, w_prev, 
     sn, sf = (int(shift[0]), int(shift[1])) if shift is not None else (0, 0)
     check(L.amdnuwa_ln_bwd_chain(dhp, _p(x), _p(mean), _p(rstd), _p(w), _p(g), _p(dx), _p(dw), _p(db), yp, _p(mean_prev),
                                  _p(rstd_prev), _p(w_prev), _p(dyp.hi), _p(dyp.lo), _p(dwp), _p(dbp), _p(dsp), R, D, sn, sf,
-                                 1 if ybf else 0, _p(ws), nb, _stream()), 'amdnuwa_ln_bwd_chain')
+                                 form, _p(ws), nb, _stream()), 'amdnuwa_ln_bwd_chain')
     return dx, dw, db, dyp, dwp, dbp, dsp
 
 
@@ -482,6 +488,13 @@ def s3_geom(B, ntok, video_shape, kernel, dilation, heads, dim_head, causal=True
     g.df, g.dh, g.dw = dilation
     g.heads, g.dim_head, g.scale = heads, dim_head, dim_head ** -0.5
     return g
+
+
+def s3_supported(video_shape, kernel, dilation, heads, dim_head, causal=True, lo=None):
+    """do the window kernels take this geometry (incl. the LDS their key-slot tables need) in the current precision mode?"""
+    g = s3_geom(1, 2, video_shape, kernel, dilation, heads, dim_head, causal=causal)
+    lo = (get_precision() != 'bf16') if lo is None else lo
+    return bool(_lib.lib().amdnuwa_s3_supported(C.byref(g), 1 if lo else 0))
 
 
 def sparse3dna_fwd(g, qkv, wth, rel_bias=None):

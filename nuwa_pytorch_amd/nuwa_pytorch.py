@@ -456,8 +456,10 @@ class Sparse3DNA(nn.Module):
         the symmetric variant keeps its PyTorch-op formulation for head sizes / widths outside the kernels"""
         if self.causal:
             return True
-        return self.dim_head in (32, 64) and self.heads <= 8 and self.video_shape[2] * self.heads * 4 <= 512 and \
-            not (self.training and self.dropout.p > 0)
+        if self.training and self.dropout.p > 0:
+            return False
+        # head size / width limits AND the LDS the window's key-slot tables need (a 7x7x7 sketch-encoder window does not fit)
+        return K.s3_supported(self.video_shape, self.kernel_size, self.dilation, self.heads, self.dim_head, causal=False)
 
     def forward(self, x, **kwargs):
         B, n, _ = x.shape
@@ -525,8 +527,13 @@ class SparseCross2DNA(nn.Module):
         return (self.null_k, self.null_v, self.talking_heads.weight, self.to_q.weight, self.to_kv.weight, self.to_out.weight)
 
     def _hip_ok(self, ctx_len):
-        return self.dim_head in (32, 64) and self.heads <= 8 and self.image_size * self.heads * 4 <= 512 and \
-            ctx_len > 0 and ctx_len % (self.image_size ** 2) == 0 and not (self.training and self.dropout.p > 0)
+        tpf = self.image_size ** 2
+        if ctx_len <= 0 or ctx_len % tpf or (self.training and self.dropout.p > 0):
+            return False
+        # the window holds kernel^2 slots of EVERY sketch frame: with many frames / a large kernel its LDS tables outgrow the CU
+        # (e.g. kernel 5 with 6 frames, kernel 3 with 16) and the PyTorch-op formulation below takes over
+        return K.s3_supported((1, self.image_size, self.image_size), (ctx_len // tpf, self.kernel_size, self.kernel_size),
+                              (1, self.dilation, self.dilation), self.heads, self.dim_head, causal=False)
 
     def _meta(self, B, n, device, context=None, context_mask=None, **_):
         tpf = self.image_size ** 2

@@ -119,7 +119,7 @@ class S3Inner:
         dwo = torch.empty_like(wo)
         meta['wg'].run(lambda: K.gemm_tn(dy, o, dwo))
         dqkv, dwth, drel = K.sparse3dna_bwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), d_o, rel_bias=rel)
-        dh = K.gemm_nt(dqkv, W['qkvT'], out_bf16=_fast())
+        dh = K.gemm_nt(dqkv, W['qkvT'], out_bf16=_fast_bwd())
         sh = meta.get('shift')
         dwqkv = torch.empty((3 * inner, wq.shape[1]), dtype=torch.float32, device=wq.device)   # one wgrad GEMM for [to_q; to_kv]
         meta['wg'].run(lambda: K.gemm_tn(dqkv, h, dwqkv, shift=sh))
@@ -206,7 +206,7 @@ class XInner:
         if rot is not None:
             dq = _rotary_bf(dq, rot, g.B, g.n, g.heads, inverse=True)
             dkv = _rotary_bf(dkv, rot, g.B, g.T, 2 * g.heads, inverse=True)
-        dh = K.gemm_nt(dq, W['qT'], out_bf16=_fast())
+        dh = K.gemm_nt(dq, W['qT'], out_bf16=_fast_bwd())
         dwq, dwkv = torch.empty_like(wq), torch.empty_like(wkv)
         meta['wg'].run(lambda: (K.gemm_tn(dq, h, dwq), K.gemm_tn(dkv, ctx, dwkv)))
         dctx = K.gemm_nt(dkv, W['kvT'])
@@ -266,7 +266,7 @@ class FFInner:
             du = K.geglu_bwd(u, K.gemm_nt(dy, W['w2T'], out_bf16=True), FP, interleaved=True)
         dw2 = torch.empty_like(w2)
         meta['wg'].run(lambda: K.gemm_tn(dy, gg, dw2, N2=FFI))
-        dh = K.gemm_nt(du, W['w1T'], out_bf16=_fast())
+        dh = K.gemm_nt(du, W['w1T'], out_bf16=_fast_bwd())
         sh = meta.get('shift')
         # one wgrad GEMM over the padded, interleaved [8 values | 8 gates | ...] row order, then back to the parameter's layout
         dw1p = torch.empty((2 * FP, w1.shape[1]), dtype=torch.float32, device=w1.device)
@@ -372,7 +372,7 @@ class XC2Inner:
         dkv = _to_bf(dkv_f.reshape(g.B * T, 2 * inner))
         dnk = dnk + torch.einsum('bh,bhd->hd', dS[..., 0], q0).reshape(-1)
         dnv = dnv + torch.einsum('bh,bhd->hd', P0[..., 0], dO0).reshape(-1)
-        dh_ = K.gemm_nt(dq, W['qT'], out_bf16=_fast())
+        dh_ = K.gemm_nt(dq, W['qT'], out_bf16=_fast_bwd())
         dwq, dwkv = torch.empty_like(wq), torch.empty_like(wkv)
         K.gemm_tn(dq, h, dwq)
         K.gemm_tn(dkv, meta['ctx_bf'], dwkv)
@@ -404,6 +404,11 @@ def _fast():
     """fast bf16 mode: the GEMMs that feed a LayerNorm (to_out / FF w2 outputs, dgrad outputs) write bf16 and the LN kernels
     read bf16 -- half the epilogue and LN traffic.  Parity mode (bf16x3) keeps those tensors in fp32."""
     return K.fast_io()
+
+
+def _fast_bwd():
+    """dgrad GEMM outputs that feed a LayerNorm backward are bf16 unless the BACKWARD itself runs 3-MFMA products ('bf16x3')"""
+    return K.get_precision() != 'bf16x3'
 
 
 def _sv(*ts):
@@ -495,7 +500,7 @@ class SandwichBlockFn(Function):
         if want_bias:
             grads[4] = dsum                      # to_out.bias grad = column sums of d(to_out output)
         prev = ctx.prev_ctx
-        if prev is not None and not ctx.has_resid and isinstance(dh, K.BF) == prev.y_bf and (not isinstance(dh, K.BF) or dh.lo is None):
+        if prev is not None and not ctx.has_resid and (isinstance(dh, K.BF) or not prev.y_bf) and (not isinstance(dh, K.BF) or dh.lo is None):
             # pre-norm backward of this block + post-norm backward of the previous block on the same gradient row
             _, py, _, _, pm2, pr2, _, ppost_w = prev.saved_tensors
             dx, dpre_w, dpre_b, dyp, dwp, dbp, dsp = K.ln_bwd_chain(

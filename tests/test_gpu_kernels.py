@@ -230,10 +230,11 @@ def test_layernorm_post_pre_chain(K, O, B, ntok, fmap, D, ybf):
 
 
 @pytest.mark.parametrize('B,ntok,fmap,D,bf', [(2, 23, 4, 32, False), (3, 17, 4, 512, True), (2, 10, None, 1024, True),
-                                                 (1, 5, None, 64, False)])
+                                                 (1, 5, None, 64, False), (3, 17, 4, 512, 'dh'), (2, 23, 4, 32, 'dh')])
 def test_layernorm_bwd_chain(K, O, B, ntok, fmap, D, bf):
     """pre-norm backward of block k+1 and post-norm backward of block k in one pass: same dx / dy_prev as the two separate
-    kernels (bit for bit), weight gradients equal up to the order of the per-workgroup partial sums, all equal to autograd"""
+    kernels (bit for bit), weight gradients equal up to the order of the per-workgroup partial sums, all equal to autograd.
+    bf: False = fp32 dh and y_prev, True = both bf16, 'dh' = bf16 dh with an fp32 y_prev (the 'bf16x3-fwd' mode's form)"""
     torch.manual_seed(12)
     R = B * ntok
     shift = (ntok, fmap) if fmap else None
@@ -242,7 +243,9 @@ def test_layernorm_bwd_chain(K, O, B, ntok, fmap, D, bf):
     dh = torch.randn(R, D)
     g = torch.randn(R, D)
     if bf:
-        yprev, dh = yprev.bfloat16().float(), dh.bfloat16().float()
+        dh = dh.bfloat16().float()
+    if bf is True:
+        yprev = yprev.bfloat16().float()
     w, w_prev = torch.randn(D), torch.randn(D)
     # autograd reference:  x is the stream row; h = shift(LN(x; w)) receives dh; the row also receives g directly.
     xr = x.clone().requires_grad_(True)
@@ -263,12 +266,13 @@ def test_layernorm_bwd_chain(K, O, B, ntok, fmap, D, bf):
     _, m2, r2 = K.ln_fwd(dev(yprev), dev(w_prev), dev(torch.zeros(D)), resid=zero)
     K.set_precision('bf16' if bf else 'bf16x3')
     try:
-        def form(t):
-            return K.BF(dev(t).bfloat16(), None) if bf else dev(t)
-        dx, dw, db, dyp, dwp, dbp, dsp = K.ln_bwd_chain(form(dh), xd, m1, r1, dev(w), dev(g), form(yprev), m2, r2, dev(w_prev),
+        def form(t, as_bf):
+            return K.BF(dev(t).bfloat16(), None) if as_bf else dev(t)
+        fdh, fy = form(dh, bool(bf)), form(yprev, bf is True)
+        dx, dw, db, dyp, dwp, dbp, dsp = K.ln_bwd_chain(fdh, xd, m1, r1, dev(w), dev(g), fy, m2, r2, dev(w_prev),
                                                         shift=shift, want_dsum=True)
-        dx_a, dw_a, db_a, _ = K.ln_bwd(form(dh), xd, m1, r1, dev(w), dres=dev(g), shift=shift)
-        dy_a, dwp_a, dbp_a, dsp_a = K.ln_bwd(dx_a, form(yprev), m2, r2, dev(w_prev), to_bf=True, want_dsum=True)
+        dx_a, dw_a, db_a, _ = K.ln_bwd(fdh, xd, m1, r1, dev(w), dres=dev(g), shift=shift)
+        dy_a, dwp_a, dbp_a, dsp_a = K.ln_bwd(dx_a, fy, m2, r2, dev(w_prev), to_bf=True, want_dsum=True)
     finally:
         K.set_precision('bf16')
     assert torch.equal(dx, dx_a) and torch.equal(dyp.hi, dy_a.hi)
@@ -385,6 +389,36 @@ def test_gemm_nt_with_geglu_epilogue(K, M, N, Kd, x3):
     report(f'gemm_geglu.u[{M},{N},x3={x3}]', ud, ref, 2e-5 if x3 else 2 ** -8)
     y_ref = ud[:, :FP] * F.gelu(ud[:, FP:])
     report(f'gemm_geglu.gg[{M},{N},x3={x3}]', bf_value(gg).cpu(), y_ref, 2e-5 if x3 else 2 ** -7)
+
+
+@pytest.mark.parametrize('mode', ['bf16x3', 'bf16x3-fwd'])
+def test_gemm_nt_x3_ring_with_geglu_epilogue(K, mode):
+    """FF1 on the bf16x3 256x256 ring: the gate runs on the fp32 accumulators in the epilogue (hi + lo gate output).  Against the
+    two separate calls (gate recomputed from the stored u hi + lo: agrees to the pair's 2^-17) and against fp64; in 'bf16x3-fwd'
+    u's lo part is not written at all."""
+    M, N, Kd = 16384, 2752, 512
+    torch.manual_seed(5)
+    a = torch.randn(M, Kd) * 0.5
+    w = torch.randn(N, Kd) * 0.2
+    ap, wp = to_bf_pair(a.to(DEV), True), to_bf_pair(w.to(DEV), True)
+    FP = N // 2
+    K.set_precision(mode)
+    try:
+        u_ref = K.gemm_nt(ap, wp, out_bf16=True)
+        gg_ref = K.geglu_fwd(u_ref, FP, interleaved=True)
+        gg = K.empty_bf((M, FP), DEV)
+        u = K.gemm_nt(ap, wp, out_bf16=True, geglu_out=gg)
+    finally:
+        K.set_precision('bf16')
+    assert torch.equal(u.hi, u_ref.hi)
+    assert (u.lo is None) == (mode == 'bf16x3-fwd')
+    if u.lo is not None:
+        assert torch.equal(u.lo, u_ref.lo)
+    assert gg.lo is not None
+    report(f'gemm_x3_geglu.gg_vs_separate[{mode}]', bf_value(gg), bf_value(gg_ref), 2e-5)
+    ud = K.geglu_deinterleave((bf_value(ap).double() @ bf_value(wp).double().t()).float().cpu(), FP, dim=1)
+    y_ref = ud[:, :FP] * F.gelu(ud[:, FP:])
+    report(f'gemm_x3_geglu.gg_vs_fp64[{mode}]', bf_value(gg).cpu(), y_ref, 3e-5)
 
 
 @pytest.mark.parametrize('M,FP,Kd,x3', [(16384, 1376, 512, False), (300, 48, 64, False), (300, 48, 64, True), (8, 1376, 512, False)])

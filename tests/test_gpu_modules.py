@@ -606,3 +606,38 @@ def test_sparse_cross_2dna_hip_vs_oracle(A, O_mod, fmap, heads, dh, kernel, dil,
             report(tag + f'.grad.{k}', gr, P[k].grad, gtol)
     finally:
         A.set_precision('bf16')
+
+
+@pytest.mark.parametrize('mode,frames,expect_hip', [('bf16', 5, True), ('bf16', 6, False), ('bf16x3', 4, True), ('bf16x3', 5, False)])
+def test_sparse_cross_2dna_window_at_the_lds_limit(A, O_mod, mode, frames, expect_hip):
+    """the window kernels' LDS tables grow with J = frames * kernel^2 + 1 key slots: at fmap 16 / 8 heads x 64 / kernel 5 the backward
+    fits the CU's 160 KiB up to J = 126 with bf16 operands and J = 101 with hi + lo pairs.  amdnuwa_s3_supported() says so, _hip_ok
+    follows it, and the module gives the oracle's result on EITHER side of the limit (kernels below, PyTorch-op formulation above)
+    instead of failing in the backward launch (round-2 advisor finding)."""
+    from nuwa_pytorch_amd.nuwa_pytorch import SparseCross2DNA
+    fmap, heads, dh, kernel, dim, n = 16, 8, 64, 5, 64, 1 + 200
+    torch.manual_seed(0)
+    m = SparseCross2DNA(dim=dim, image_size=fmap, heads=heads, dim_head=dh, kernel_size=kernel, dilation=1)
+    T = frames * fmap * fmap
+    P = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(frames)
+    x, ctx, dy = torch.randn(1, n, dim, generator=g), torch.randn(1, T, dim, generator=g), torch.randn(1, n, dim, generator=g)
+    xr, cr = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    yr = O_mod.sparse_cross_2dna(xr, cr, P, heads, fmap, kernel, 1)
+    yr.backward(dy)
+    m = m.to(DEV)
+    run_mode(A, mode)
+    try:
+        assert m._hip_ok(T) == expect_hip
+        tol, gtol = (1e-3, 2e-3) if (mode == 'bf16x3' or not expect_hip) else (2e-2, 7e-2)
+        xd, cd = x.to(DEV).requires_grad_(True), ctx.to(DEV).requires_grad_(True)
+        y = m(xd, context=cd)
+        tag = f'xc2_lds_limit[{mode},{frames}]'
+        report(tag + '.y', y, yr.detach(), tol)
+        y.backward(dy.to(DEV))
+        report(tag + '.dx', xd.grad, xr.grad, gtol)
+        report(tag + '.dctx', cd.grad, cr.grad, gtol)
+        for k, gr in _grads_of(m).items():
+            report(tag + f'.grad.{k}', gr, P[k].grad, gtol)
+    finally:
+        A.set_precision('bf16')
