@@ -79,12 +79,22 @@ typedef struct {
      * (pitch ld_u, hi[/lo]).  When amdnuwa_gemm_nt_fused(d) != 0 this happens in the GEMM epilogue and C is NOT written;
      * otherwise C receives dgg and the stand-alone kernel follows. */
     const uint16_t* geglu_u; const uint16_t* geglu_u_lo; int ld_u;
+    /* NT, bf16 C, hi + lo operands: with c_lo_f16 != 0 Clo receives the fp16 rendering of the FULL product value (not the bf16
+     * residual) -- the operand form of the fp16 attention cores of the 'bf16x3-fwd' mode (amdnuwa_sparse3dna_fwd_f16,
+     * amdnuwa_xattn2_fwd_f16): q / k / v leave the projection GEMM as a bf16 copy (for the bf16 backward) and an fp16 copy (for the
+     * forward core).  Only the 256x256 hi + lo ring does this: ask amdnuwa_gemm_nt_f16_fused() first; otherwise run the plain
+     * hi + lo product and amdnuwa_hilo_to_f16(). */
+    int c_lo_f16;
 } amdnuwa_gemm_desc;
 
 /* C[M,N] = alpha * A[M,K] . B[N,K]^T (+ bias).  K, lda, ldb multiples of 8. */
 int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, amdnuwa_stream stream);
 /* 1 when the C2 (GEGLU) output of this product is produced inside the GEMM epilogue, 0 when the library will run GEMM + gate kernel */
 int amdnuwa_gemm_nt_fused(const amdnuwa_gemm_desc* d);
+/* 1 when amdnuwa_gemm_nt() honours d->c_lo_f16 for this product (it returns AMDNUWA_ERR_UNSUPPORTED otherwise) */
+int amdnuwa_gemm_nt_f16_fused(const amdnuwa_gemm_desc* d);
+/* out[r][c] = fp16(hi[r][c] + lo[r][c]) over an [R, C] view (row pitches ld_in / ld_out elements, C % 8 == 0) */
+int amdnuwa_hilo_to_f16(const uint16_t* hi, const uint16_t* lo, int ld_in, uint16_t* out, int ld_out, long long R, int C, amdnuwa_stream stream);
 /* C[M,N] (fp32) = beta*C + alpha * A[K,M]^T . B[K,N]   (reduction over the K token rows, split-K
  * through `workspace`, fixed summation order => deterministic).  lda, ldb multiples of 8; operand rows
  * must be readable up to the next multiple of 8 columns (padding content is irrelevant). */
@@ -216,6 +226,13 @@ int amdnuwa_s3_supported(const amdnuwa_s3_geom* g, int lo_operands);
 int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* k, const uint16_t* v,
                            const uint16_t* q_lo, const uint16_t* k_lo, const uint16_t* v_lo, int ld,
                            const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, amdnuwa_stream stream);
+/* the forward core on SINGLE fp16 MFMAs (the MFMA band kernel with fp16 operands): q / k / v hold fp16 values (the second copy
+ * amdnuwa_gemm_nt writes with c_lo_f16), o leaves as a bf16 hi + lo pair (o_lo may be NULL).  Geometry of the band kernels only
+ * (causal window, 16-wide grid, 8 heads x 64, kw <= 3): amdnuwa_s3_f16_supported() says whether it applies.  The forward
+ * Sparse3DNA core (reference nuwa_pytorch.py:488-608) of the 'bf16x3-fwd' mode. */
+int amdnuwa_s3_f16_supported(const amdnuwa_s3_geom* g);
+int amdnuwa_sparse3dna_fwd_f16(const amdnuwa_s3_geom* g, const uint16_t* q_f16, const uint16_t* k_f16, const uint16_t* v_f16, int ld,
+                               const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, amdnuwa_stream stream);
 size_t amdnuwa_sparse3dna_bwd_workspace_bytes(const amdnuwa_s3_geom* g);
 int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* k, const uint16_t* v,
                            const uint16_t* q_lo, const uint16_t* k_lo, const uint16_t* v_lo, int ld,
@@ -294,6 +311,11 @@ int amdnuwa_xattn_jp(int T);
 int amdnuwa_xattn_pack(const amdnuwa_xattn_geom* g, const uint16_t* kv, const uint16_t* kv_lo, int ldkv,
                        const float* null_k, const float* null_v, const uint8_t* context_mask,
                        const amdnuwa_xattn_kv* packed, amdnuwa_stream stream);
+/* the same with kv_f16 = the fp16 rendering of to_kv(context) in place of the bf16 residuals: the *_lo images of `packed` become fp16
+ * images (what amdnuwa_xattn2_fwd_f16 reads); the hi images stay the bf16 ones the backward kernels read */
+int amdnuwa_xattn_pack_f16(const amdnuwa_xattn_geom* g, const uint16_t* kv, const uint16_t* kv_f16, int ldkv,
+                           const float* null_k, const float* null_v, const uint8_t* context_mask,
+                           const amdnuwa_xattn_kv* packed, amdnuwa_stream stream);
 /* P / Pm (optional): softmax probabilities before / after talking heads, [B][heads][n][JP] bf16 hi[/lo],
  * saved for the backward */
 int amdnuwa_xattn_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq,
@@ -325,6 +347,11 @@ int amdnuwa_xattn_unpack(const amdnuwa_xattn_geom* g, const float* dKp, const fl
 int amdnuwa_xattn2_supported(const amdnuwa_xattn_geom* g);
 int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const amdnuwa_xattn_kv* packed,
                        const float* w_th, uint16_t* o, int ldo, float* stats, amdnuwa_stream stream);
+/* the same core on SINGLE fp16 MFMAs: q_f16 [B*n, ldq] and the *_lo images of `packed` (written by amdnuwa_xattn_pack_f16) hold fp16
+ * values; o leaves as a bf16 hi + lo pair (o_lo may be NULL).  The forward cross-attention core of the 'bf16x3-fwd' mode: with
+ * the hi + lo projection GEMMs around it the full-depth logits stay within 1e-3 of the fp32 reference (tools/error_budget.py) */
+int amdnuwa_xattn2_fwd_f16(const amdnuwa_xattn_geom* g, const uint16_t* q_f16, int ldq, const amdnuwa_xattn_kv* packed,
+                           const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, float* stats, amdnuwa_stream stream);
 size_t amdnuwa_xattn2_bwd_workspace_bytes(const amdnuwa_xattn_geom* g);
 int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
                        const amdnuwa_xattn_kv* packed, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm,

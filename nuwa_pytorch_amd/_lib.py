@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
                 ('c_is_bf16', I), ('bias', P), ('alpha', F), ('beta', F),
                 ('M', I), ('N', I), ('K', I), ('batch', I), ('shift_ntok', I), ('shift_fmap', I),
                 ('batch_inner', I), ('strideA_inner', LL), ('strideB_inner', LL), ('strideC_inner', LL),
-                ('C2', P), ('C2lo', P), ('ldc2', I), ('geglu_u', P), ('geglu_u_lo', P), ('ld_u', I)]
+                ('C2', P), ('C2lo', P), ('ldc2', I), ('geglu_u', P), ('geglu_u_lo', P), ('ld_u', I), ('c_lo_f16', I)]
 
 
 class S3Geom(C.Structure):
@@ -70,6 +70,8 @@ SIGNATURES = {
     'amdnuwa_colsum': (I, [P, P, LL, I, I, P, SZ, P]),
     'amdnuwa_geglu_fwd': (I, [P, P, P, P, LL, I, P]),
     'amdnuwa_gemm_nt_fused': (I, [GD]),
+    'amdnuwa_gemm_nt_f16_fused': (I, [GD]),
+    'amdnuwa_hilo_to_f16': (I, [P, P, I, P, I, LL, I, P]),
     'amdnuwa_geglu_il_fwd': (I, [P, P, P, P, LL, I, P]),
     'amdnuwa_geglu_il_bwd': (I, [P, P, P, P, P, P, LL, I, P]),
     'amdnuwa_geglu_bwd': (I, [P, P, P, P, P, P, LL, I, P]),
@@ -84,6 +86,8 @@ SIGNATURES = {
     'amdnuwa_linear_ce': (I, [P, I, P, I, P, LL, I, I, F, P, P, P, I, P, SZ, P]),
     'amdnuwa_s3_supported': (I, [SG, I]),
     'amdnuwa_sparse3dna_fwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P]),
+    'amdnuwa_s3_f16_supported': (I, [SG]),
+    'amdnuwa_sparse3dna_fwd_f16': (I, [SG, P, P, P, I, P, P, P, I, P]),
     'amdnuwa_sparse3dna_bwd_workspace_bytes': (SZ, [SG]),
     'amdnuwa_sparse3dna_bwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P, P, P, P, P, P, I, P, I, P, SZ, P]),
     'amdnuwa_cross2dna_fwd': (I, [SG, P, P, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P, I, P]),
@@ -95,6 +99,7 @@ SIGNATURES = {
     'amdnuwa_xattn_decode': (I, [XG, P, P, I, XK, P, P, P, I, P]),
     'amdnuwa_xattn_jp': (I, [I]),
     'amdnuwa_xattn_pack': (I, [XG, P, P, I, P, P, P, XK, P]),
+    'amdnuwa_xattn_pack_f16': (I, [XG, P, P, I, P, P, P, XK, P]),
     'amdnuwa_xattn_fwd': (I, [XG, P, P, I, XK, P, P, P, I, P, P, P, P, P]),
     'amdnuwa_xattn_fwd_stats': (I, [XG, P, P, I, XK, P, P, P, I, P, P, P, P, P, P]),
     'amdnuwa_xattn_bwd_workspace_bytes': (SZ, [XG]),
@@ -102,6 +107,7 @@ SIGNATURES = {
     'amdnuwa_xattn_unpack': (I, [XG, P, P, P, P, I, P, P, I, P]),
     'amdnuwa_xattn2_supported': (I, [XG]),
     'amdnuwa_xattn2_fwd': (I, [XG, P, I, XK, P, P, I, P, P]),
+    'amdnuwa_xattn2_fwd_f16': (I, [XG, P, I, XK, P, P, P, I, P, P]),
     'amdnuwa_xattn2_bwd_workspace_bytes': (SZ, [XG]),
     'amdnuwa_xattn2_bwd': (I, [XG, P, I, P, I, XK, P, P, P, P, P, I, P, SZ, P]),
     'amdnuwa_conv2d_fwd': (I, [CD, P, P, P, P, P]),

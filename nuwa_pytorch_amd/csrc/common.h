@@ -52,6 +52,28 @@ __device__ __forceinline__ uint32_t pack2_rne(float a, float b) {
 __device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
+// ---- fp16 operand form of the attention cores in the 'bf16x3-fwd' mode -------------------------------------------------------
+// The forward attention cores of that mode run SINGLE fp16 MFMAs (v_mfma_f32_16x16x32_f16: the bf16 rate, 11 significand bits
+// instead of 8) on q / k / v stored as fp16 next to their bf16 copies; everything else about the kernels is the bf16 fast path.
+// 16-bit payloads travel in the same bf16x8 / uint32 registers whatever their type; the helpers below pick the type by a
+// template flag.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint32_t pack2_f16(float a, float b) {          // v_cvt_pk_f16_f32, round to nearest even
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ float f16lo_f(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu)); }
+__device__ __forceinline__ float f16hi_f(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16)); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+template <bool F16> __device__ __forceinline__ uint32_t pack2_t(float a, float b) { return F16 ? pack2_f16(a, b) : pack2_rne(a, b); }
+template <bool F16> __device__ __forceinline__ float lo_t(uint32_t u) { return F16 ? f16lo_f(u) : lo_f(u); }
+template <bool F16> __device__ __forceinline__ float hi_t(uint32_t u) { return F16 ? f16hi_f(u) : hi_f(u); }
+template <bool F16> __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // One 1-KiB LDS-DMA piece (64 lanes x 16 bytes, lane l lands at lds + 16 l) issued through INLINE ASM.
 // Why not __builtin_amdgcn_global_load_lds: the compiler tracks the builtin as a write to LDS and, unable to see the counted
 // s_waitcnt vmcnt(N) + s_barrier that order a DMA ring, puts an `s_waitcnt vmcnt(0)` in front of every later LDS read it considers

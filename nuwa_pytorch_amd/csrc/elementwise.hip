@@ -1017,6 +1017,33 @@ extern "C" int amdnuwa_ln_bwd_chain(const void* dh, const float* x, const float*
     return AMDNUWA_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void hilo_to_f16_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo, int ld_in,
+                                                          uint16_t* __restrict__ out, int ld_out, long long R, int C) {
+    const long long chunks = R * (C / 8);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < chunks; e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / (C / 8);
+        const int c = (int)(e % (C / 8)) * 8;
+        const uint4 a = *reinterpret_cast<const uint4*>(hi + r * ld_in + c);
+        const uint4 b = lo ? *reinterpret_cast<const uint4*>(lo + r * ld_in + c) : make_uint4(0, 0, 0, 0);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack2_f16(lo_f(aw[k]) + lo_f(bw[k]), hi_f(aw[k]) + hi_f(bw[k]));
+        *reinterpret_cast<uint4*>(out + r * ld_out + c) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+}  // namespace
+
+extern "C" int amdnuwa_hilo_to_f16(const uint16_t* hi, const uint16_t* lo, int ld_in, uint16_t* out, int ld_out, long long R, int C,
+                                   hipStream_t stream) {
+    if (!hi || !out || C <= 0 || C % 8 || ld_in % 8 || ld_out % 8) return AMDNUWA_ERR_ARG;
+    if (R <= 0) return AMDNUWA_OK;
+    hipLaunchKernelGGL(hilo_to_f16_kernel, dim3(grid_for((size_t)R * (C / 8))), dim3(256), 0, stream, hi, lo, ld_in, out, ld_out, R, C);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
 extern "C" size_t amdnuwa_colsum_workspace_bytes(long long R, int D) { return (size_t)(R < 256 ? (R < 1 ? 1 : R) : 256) * D * sizeof(float); }
 
 // out[c] (+)= sum_r x[r][c]   (fixed order => deterministic)

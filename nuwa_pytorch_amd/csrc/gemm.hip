@@ -36,6 +36,7 @@ struct GemmArgs {
     int nsplit;             // TN 256 ring: number of K splits (the grid is flattened over (split, tile))
     bf16_t* C2; int ldc2;   // NT bf16 epilogue: GEGLU output (C in the interleaved-by-8 layout), or NULL
     bf16_t* C2lo;           // its lo part (bf16x3 ring only)
+    int lo_f16;             // bf16x3 ring, EPI 1: Clo receives fp16(value) instead of the bf16 residual
     const bf16_t* Uin; int ldu;   // != NULL: GEGLU BACKWARD epilogue: C2 = du from (product = dgg, Uin = u); C is not written
     int dbg;                // probe only (tuning key 7): bit0 skip epilogue stores, bit1 skip main loop
     // fused linear + cross entropy (EPI 2 / 3 of the 256x256 ring): per (row, 64-column block) partial (max, sum exp) and the
@@ -845,6 +846,11 @@ __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
 
     const int nk = (p.dbg & 2) ? 0 : p.K / 32;
     const int fr = lane & 15, fg = lane >> 4;
+    // start-phase skew of the first-generation workgroups (see gemm_nt_256_kernel): spreads the chip-wide epilogue store bursts
+    if (p.skew > 0 && (int)blockIdx.x < 256) {
+        const int phase = (int)((blockIdx.x * 2654435761u) >> 29);
+        for (int i = 0; i < phase * p.skew; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     if (nk > 0) issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         VMCNT(0);                                 // this wave's pieces of tile kt have landed ...
@@ -903,7 +909,11 @@ __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) f2bf_hilo(acc[i][j][r] * p.alpha + bias16[j * 4 + r], h[j * 4 + r], l[j * 4 + r]);
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[i][j][r] * p.alpha + bias16[j * 4 + r];
+                    f2bf_hilo(v, h[j * 4 + r], l[j * 4 + r]);
+                    if (p.lo_f16) l[j * 4 + r] = f2h(v);          // (wave-uniform) the second copy is the fp16 value, not the residual
+                }
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
             bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;
             if (vec8 && nb + 16 <= p.N) {
@@ -1688,6 +1698,18 @@ extern "C" int amdnuwa_linear_ce(const uint16_t* h, int ldh, const uint16_t* w, 
 
 extern "C" int amdnuwa_gemm_nt_fused(const amdnuwa_gemm_desc* d) { return d && d->C2 && nt_geglu_fusable(d) ? 1 : 0; }
 
+// does this product run on the bf16x3 256x256 ring (the only kernel that writes the fp16 second copy)?
+static bool nt_x3_ring(const amdnuwa_gemm_desc* d) {
+    if (!d->Alo || !d->Blo || d->shift_ntok > 0 || d->K % 32 || g_amdnuwa_tuning[13] == 1) return false;
+    const int v = g_amdnuwa_tuning[0];
+    if (v == 7) return true;
+    if (v != 0 || d->M <= 4 * ROWS_MR) return false;
+    return (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * (d->batch > 0 ? d->batch : 1) >= 512;
+}
+extern "C" int amdnuwa_gemm_nt_f16_fused(const amdnuwa_gemm_desc* d) {
+    return d && d->c_is_bf16 && d->Clo && !d->C2 && nt_x3_ring(d) && d->N % 8 == 0 && d->ldc % 8 == 0 ? 1 : 0;
+}
+
 extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     if (!d || !d->A || !d->B || !d->C) return AMDNUWA_ERR_ARG;
     if (d->M <= 0 || d->N <= 0) return AMDNUWA_OK;
@@ -1708,6 +1730,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     if (d->K % 8 || d->lda % 8 || d->ldb % 8) return AMDNUWA_ERR_ARG;
     if ((d->Alo == nullptr) != (d->Blo == nullptr)) return AMDNUWA_ERR_ARG;
     if (d->shift_ntok > 0 && (d->shift_fmap <= 0 || d->K % 32)) return AMDNUWA_ERR_ARG;
+    if (d->c_lo_f16 && !amdnuwa_gemm_nt_f16_fused(d)) return AMDNUWA_ERR_UNSUPPORTED;
     GemmArgs p;
     p.A = (const bf16_t*)d->A; p.Alo = (const bf16_t*)d->Alo; p.sA = d->strideA; p.lda = d->lda;
     p.B = (const bf16_t*)d->B; p.Blo = (const bf16_t*)d->Blo; p.sB = d->strideB; p.ldb = d->ldb;
@@ -1719,7 +1742,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     p.ksplit_len = 0;
     p.dbg = g_amdnuwa_tuning[7];
     p.skew = 0;
-    p.C2 = nullptr; p.C2lo = nullptr; p.ldc2 = 0; p.Uin = nullptr; p.ldu = 0;
+    p.C2 = nullptr; p.C2lo = nullptr; p.ldc2 = 0; p.Uin = nullptr; p.ldu = 0; p.lo_f16 = 0;
     p.batch_inner = d->batch_inner; p.sA_in = d->strideA_inner; p.sB_in = d->strideB_inner; p.sC_in = d->strideC_inner;
     const bool x3 = d->Alo != nullptr, sh = d->shift_ntok > 0, ob = d->c_is_bf16 != 0;
     // a handful of rows (the decode step of generate()): stream the weight instead of running MFMA tiles
@@ -1753,6 +1776,8 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         dim3 g3(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b3(512);
         const size_t l3 = (size_t)2 * 4 * 256 * 32 * 2;
         if (d->C2) { p.C2 = (bf16_t*)d->C2; p.C2lo = (bf16_t*)d->C2lo; p.ldc2 = d->ldc2; }
+        p.lo_f16 = (ob && d->c_lo_f16 && d->Clo) ? 1 : 0;
+        p.skew = nt_skew((long long)p.tiles_m * p.tiles_n);
         if (ob) {
             (void)hipFuncSetAttribute((const void*)gemm_nt_256x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3);
             hipLaunchKernelGGL((gemm_nt_256x3_kernel<1>), g3, b3, l3, stream, p);

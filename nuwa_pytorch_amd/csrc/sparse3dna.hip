@@ -909,6 +909,7 @@ __device__ __forceinline__ void mfma_band_scores(const S3Args& a, const RowM& r,
 // 16-byte pieces of FULL 128-byte row slices (8 lanes per row) instead of fragment-shaped 64-byte halves (4 lanes per row, two
 // instructions per row), then reads its two MFMA fragments out of LDS.  Phase ablation of the forward (tuning key 9, dilation 1,
 // b = 64): scores 242 us, apply (which always loaded full lines) 166 us for the same number of bytes.
+template <bool F16 = false>     // F16: rows / frag hold fp16 values and the products run on the fp16 MFMA (forward core of 'bf16x3-fwd')
 __device__ __forceinline__ void mfma_band_scores_staged(const S3Args& a, const RowM& r, const bf16_t* rows, int ldr, const bf16_t* frag,
                                                         int ldf, int h, float* TAB, float mul, const float* bias, char* tile) {
     constexpr int NH = S3M_NH, DH = S3M_DH;
@@ -942,8 +943,8 @@ __device__ __forceinline__ void mfma_band_scores_staged(const S3Args& a, const R
         __builtin_amdgcn_wave_barrier();                                          // LDS is in-order per wave: the tile is complete
         const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(tile + f0), k1 = *reinterpret_cast<const bf16x8*>(tile + f1);
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, sc, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, sc, 0, 0, 0);
+        sc = mfma16<F16>(k0, qf0, sc);
+        sc = mfma16<F16>(k1, qf1, sc);
         __builtin_amdgcn_wave_barrier();
         if (sq == 0) {
             if (r.g4 == 0 && r.qok) TAB[spb] = sc[0] * mul + (bias ? bias[h] : 0.f);
@@ -956,6 +957,7 @@ __device__ __forceinline__ void mfma_band_scores_staged(const S3Args& a, const R
     }
 }
 
+template <bool F16 = false>
 __device__ __forceinline__ void mfma_band_apply(const S3Args& a, const RowM& r, const bf16_t* rows, int ldr, int g, const float* TAB,
                                                 char* tile, f32x4 (&O)[4]) {
     constexpr int NH = S3M_NH, DH = S3M_DH;
@@ -966,7 +968,7 @@ __device__ __forceinline__ void mfma_band_apply(const S3Args& a, const RowM& r, 
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             const uint2 u = *reinterpret_cast<const uint2*>(vb + db * 16);
-            O[db] = f32x4{p0 * lo_f(u.x), p0 * hi_f(u.x), p0 * lo_f(u.y), p0 * hi_f(u.y)};
+            O[db] = f32x4{p0 * lo_t<F16>(u.x), p0 * hi_t<F16>(u.x), p0 * lo_t<F16>(u.y), p0 * hi_t<F16>(u.y)};
         }
     }
     // staging map of a chunk (two planes = 32 rows x 8 sixteen-byte pieces, 4 per lane): piece i of this lane is row
@@ -1008,15 +1010,15 @@ __device__ __forceinline__ void mfma_band_apply(const S3Args& a, const RowM& r, 
             pf[j] = on ? TAB[sidx[j] + jb0] : 0.f;
             pf[4 + j] = (on && jb1 >= 0) ? TAB[sidx[j] + jb1] : 0.f;
         }
-        const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(pf[0], pf[1]), pack2_rne(pf[2], pf[3]),
-                                                                 pack2_rne(pf[4], pf[5]), pack2_rne(pf[6], pf[7])));
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pack2_t<F16>(pf[0], pf[1]), pack2_t<F16>(pf[2], pf[3]),
+                                                                 pack2_t<F16>(pf[4], pf[5]), pack2_t<F16>(pf[6], pf[7])));
         __builtin_amdgcn_wave_barrier();                                          // LDS is in-order per wave: the tile is complete
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db]));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db] + 2048));
             const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            O[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v8), pb, O[db], 0, 0, 0);
+            O[db] = mfma16<F16>(__builtin_bit_cast(bf16x8, v8), pb, O[db]);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1064,6 +1066,9 @@ __device__ __forceinline__ void rowm_softmax(float* TAB, int J) {
     for (int j = cc; j < J; j += 4) TAB[(w * J + j) * NH + h] *= inv;
 }
 
+// F16: a.q / a.k / a.v hold fp16 values, the score and apply products run on the fp16 MFMA, and o leaves as a bf16 hi + lo pair
+// (a.ol): the forward Sparse3DNA core of the 'bf16x3-fwd' precision mode.
+template <bool F16>
 __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1078,16 +1083,23 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
     const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
     if (t < NH * NH) wsh[t] = a.wth[t];
     if (ry == 0) {                                                               // <bos> output row = its own value
-        for (int e = t; e < NH * DH; e += blockDim.x)
-            a.o[((size_t)b * a.ntok) * a.ldo + e] = a.v[((size_t)b * a.ntok) * a.ld + e];
+        for (int e = t; e < NH * DH; e += blockDim.x) {
+            const bf16_t raw = a.v[((size_t)b * a.ntok) * a.ld + e];
+            if (F16) {
+                bf16_t hi, lo;
+                f2bf_hilo((float)__builtin_bit_cast(_Float16, raw), hi, lo);
+                a.o[((size_t)b * a.ntok) * a.ldo + e] = hi;
+                if (a.ol) a.ol[((size_t)b * a.ntok) * a.ldo + e] = lo;
+            } else a.o[((size_t)b * a.ntok) * a.ldo + e] = raw;
+        }
     }
     if (ry * W + 1 >= a.ntok) return;                                            // whole row beyond the sequence (uniform)
     for (int e = t; e < W * J * NH; e += blockDim.x) SP[e] = NEG_MAX;
     rowm_planes(a, f, y, pslot, ptok);
     const RowM r = rowm_init(a, b, ry, pslot, ptok);
     if (!(a.dbg & 1)) {
-        if (a.dbg & 8) mfma_band_scores(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias);
-        else mfma_band_scores_staged(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias, vt_base + r.wave * 4096);
+        if (!F16 && (a.dbg & 8)) mfma_band_scores(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias);
+        else mfma_band_scores_staged<F16>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias, vt_base + r.wave * 4096);
     }
     __syncthreads();
     if (!(a.dbg & 2)) rowm_softmax(SP, J);
@@ -1114,12 +1126,17 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
     if (!(a.dbg & 4)) {
         const int g = r.wave;
         f32x4 O[4];
-        mfma_band_apply(a, r, a.v, a.ld, g, SP, vt_base + r.wave * 4096, O);
+        mfma_band_apply<F16>(a, r, a.v, a.ld, g, SP, vt_base + r.wave * 4096, O);
         if (r.qok) {
-            bf16_t* orow = a.o + (r.tok0 + r.iq) * a.ldo + g * DH + 4 * r.g4;
+            const size_t go = (r.tok0 + r.iq) * a.ldo + g * DH + 4 * r.g4;
 #pragma unroll
-            for (int db = 0; db < 4; ++db)
-                *reinterpret_cast<uint2*>(orow + db * 16) = make_uint2(pack2_rne(O[db][0], O[db][1]), pack2_rne(O[db][2], O[db][3]));
+            for (int db = 0; db < 4; ++db) {
+                const uint32_t h01 = pack2_rne(O[db][0], O[db][1]), h23 = pack2_rne(O[db][2], O[db][3]);
+                *reinterpret_cast<uint2*>(a.o + go + db * 16) = make_uint2(h01, h23);
+                if (F16 && a.ol)
+                    *reinterpret_cast<uint2*>(a.ol + go + db * 16) = make_uint2(pack2_rne(O[db][0] - lo_f(h01), O[db][1] - hi_f(h01)),
+                                                                                pack2_rne(O[db][2] - lo_f(h23), O[db][3] - hi_f(h23)));
+            }
         }
     }
 }
@@ -1474,14 +1491,40 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
         g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && ldo % 4 == 0) {
         a.dbg = g_amdnuwa_tuning[9];
         const size_t lm = (size_t)16 * J * 8 * sizeof(float) + 8 * 4096;
-        (void)hipFuncSetAttribute((const void*)s3_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
-        hipLaunchKernelGGL(s3_fwd_mfma_kernel, grid, dim3(512), lm, stream, a);
+        (void)hipFuncSetAttribute((const void*)s3_fwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+        hipLaunchKernelGGL(s3_fwd_mfma_kernel<false>, grid, dim3(512), lm, stream, a);
         LAUNCH_CHECK();
         return AMDNUWA_OK;
     }
     if (g->dim_head == 64) { if (lo_mode) S3F(64, true); else S3F(64, false); }
     else { if (lo_mode) S3F(32, true); else S3F(32, false); }
 #undef S3F
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+// the geometry of the MFMA band kernels: the causal decoder window on a 16-wide grid, 8 heads x 64
+static bool s3_mfma_geom(const amdnuwa_s3_geom* g) {
+    return !g->noncausal && g->W == 16 && g->heads == 8 && g->dim_head == 64 && g->kw <= S3M_KW && g->kf * g->kh <= S3M_PLANES;
+}
+extern "C" int amdnuwa_s3_f16_supported(const amdnuwa_s3_geom* g) { return check_geom(g) == AMDNUWA_OK && s3_mfma_geom(g) ? 1 : 0; }
+
+extern "C" int amdnuwa_sparse3dna_fwd_f16(const amdnuwa_s3_geom* g, const uint16_t* q_f16, const uint16_t* k_f16, const uint16_t* v_f16,
+                                          int ld, const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, hipStream_t stream) {
+    int rc = check_geom(g);
+    if (rc) return rc;
+    if (!s3_mfma_geom(g)) return AMDNUWA_ERR_UNSUPPORTED;
+    if (!q_f16 || !k_f16 || !v_f16 || !w_th || !o || ld % 8 || ldo % 8) return AMDNUWA_ERR_ARG;
+    if (g->B <= 0) return AMDNUWA_OK;
+    S3Args a{};
+    fill_geom(a, g);
+    a.q = q_f16; a.k = k_f16; a.v = v_f16; a.ld = ld;
+    a.o = o; a.ol = o_lo; a.ldo = ldo; a.wth = w_th;
+    self_kv(a);
+    const int J = g->kf * g->kh * g->kw + 1;
+    const size_t lm = (size_t)16 * J * 8 * sizeof(float) + 8 * 4096;
+    (void)hipFuncSetAttribute((const void*)s3_fwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+    hipLaunchKernelGGL(s3_fwd_mfma_kernel<true>, dim3(g->B * g->F * g->H), dim3(512), lm, stream, a);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

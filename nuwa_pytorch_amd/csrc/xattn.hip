@@ -499,7 +499,9 @@ __global__ __launch_bounds__(256) void xattn_pack_kernel(const bf16_t* __restric
                                                          const float* __restrict__ null_k, const float* __restrict__ null_v,
                                                          const uint8_t* __restrict__ mask, bf16_t* Kp, bf16_t* Kpl, bf16_t* Kt,
                                                          bf16_t* Ktl, bf16_t* Vp, bf16_t* Vpl, bf16_t* Vt, bf16_t* Vtl,
-                                                         uint8_t* valid, int B, int T, int NH, int DH, int JP) {
+                                                         uint8_t* valid, int B, int T, int NH, int DH, int JP, int lo_f16) {
+    // lo_f16: kvl holds the fp16 rendering of the keys / values (not bf16 residuals) and the "lo" images become fp16 images: the
+    // null key / value row is then rounded to fp16 as well
     __shared__ bf16_t tile[4][64][72];            // k hi, v hi, k lo, v lo: [key][d], rows padded to 144 bytes (16-byte aligned)
     const int bh = blockIdx.x, b = bh / NH, h = bh % NH, inner = NH * DH, j0 = blockIdx.y * 64;
     if (h == 0 && blockIdx.y == 0)
@@ -513,7 +515,10 @@ __global__ __launch_bounds__(256) void xattn_pack_kernel(const bf16_t* __restric
         if (j == 0) {
             bf16_t hk[8], lk[8], hv[8], lv[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { f2bf_hilo(null_k[h * DH + dc + t], hk[t], lk[t]); f2bf_hilo(null_v[h * DH + dc + t], hv[t], lv[t]); }
+            for (int t = 0; t < 8; ++t) {
+                f2bf_hilo(null_k[h * DH + dc + t], hk[t], lk[t]); f2bf_hilo(null_v[h * DH + dc + t], hv[t], lv[t]);
+                if (lo_f16) { lk[t] = f2h(null_k[h * DH + dc + t]); lv[t] = f2h(null_v[h * DH + dc + t]); }
+            }
             r[0] = make_uint4(pack2(hk[0], hk[1]), pack2(hk[2], hk[3]), pack2(hk[4], hk[5]), pack2(hk[6], hk[7]));
             r[1] = make_uint4(pack2(hv[0], hv[1]), pack2(hv[2], hv[3]), pack2(hv[4], hv[5]), pack2(hv[6], hv[7]));
             r[2] = make_uint4(pack2(lk[0], lk[1]), pack2(lk[2], lk[3]), pack2(lk[4], lk[5]), pack2(lk[6], lk[7]));
@@ -628,9 +633,24 @@ int check(const amdnuwa_xattn_geom* g) {
 
 extern "C" int amdnuwa_xattn_jp(int T) { return ((T + 1 + 31) / 32) * 32; }
 
+static int xattn_pack_impl(const amdnuwa_xattn_geom* g, const uint16_t* kv, const uint16_t* kv_lo, int ldkv, const float* null_k,
+                           const float* null_v, const uint8_t* context_mask, const amdnuwa_xattn_kv* p, int lo_f16, hipStream_t stream);
+
 extern "C" int amdnuwa_xattn_pack(const amdnuwa_xattn_geom* g, const uint16_t* kv, const uint16_t* kv_lo, int ldkv,
                                   const float* null_k, const float* null_v, const uint8_t* context_mask,
                                   const amdnuwa_xattn_kv* p, hipStream_t stream) {
+    return xattn_pack_impl(g, kv, kv_lo, ldkv, null_k, null_v, context_mask, p, 0, stream);
+}
+
+extern "C" int amdnuwa_xattn_pack_f16(const amdnuwa_xattn_geom* g, const uint16_t* kv, const uint16_t* kv_f16, int ldkv,
+                                      const float* null_k, const float* null_v, const uint8_t* context_mask,
+                                      const amdnuwa_xattn_kv* p, hipStream_t stream) {
+    if (!kv_f16) return AMDNUWA_ERR_ARG;
+    return xattn_pack_impl(g, kv, kv_f16, ldkv, null_k, null_v, context_mask, p, 1, stream);
+}
+
+static int xattn_pack_impl(const amdnuwa_xattn_geom* g, const uint16_t* kv, const uint16_t* kv_lo, int ldkv, const float* null_k,
+                           const float* null_v, const uint8_t* context_mask, const amdnuwa_xattn_kv* p, int lo_f16, hipStream_t stream) {
     int rc = check(g);
     if (rc) return rc;
     if (!kv || !null_k || !null_v || !p || !p->Kp || !p->Kt || !p->Vp || !p->Vt || !p->valid || ldkv % 8) return AMDNUWA_ERR_ARG;
@@ -638,7 +658,7 @@ extern "C" int amdnuwa_xattn_pack(const amdnuwa_xattn_geom* g, const uint16_t* k
     if (g->B <= 0) return AMDNUWA_OK;
     hipLaunchKernelGGL(xattn_pack_kernel, dim3(g->B * g->heads, (g->JP + 63) / 64), dim3(256), 0, stream, kv, kv_lo, ldkv, null_k, null_v, context_mask,
                        p->Kp, kv_lo ? p->Kp_lo : nullptr, p->Kt, kv_lo ? p->Kt_lo : nullptr, p->Vp, kv_lo ? p->Vp_lo : nullptr,
-                       p->Vt, kv_lo ? p->Vt_lo : nullptr, p->valid, g->B, g->T, g->heads, g->dim_head, g->JP);
+                       p->Vt, kv_lo ? p->Vt_lo : nullptr, p->valid, g->B, g->T, g->heads, g->dim_head, g->JP, lo_f16);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

@@ -37,6 +37,7 @@ struct X2Args {
     const uint8_t* valid;                    // [B][JP]
     const float* wth;                        // [NH][NH]
     bf16_t* o; int ldo;
+    bf16_t* ol;                              // xattn4 fp16-operand form only: the bf16 residual of o (o leaves as a hi + lo pair)
     float* stats;                            // [B][NH][n][2] = (row max of the scaled, masked scores; 1 / sum of exp)
     const bf16_t* dO; int lddo;
     bf16_t *dS, *Pm;                         // [B][NH][n][JP]
@@ -64,8 +65,9 @@ __device__ __forceinline__ bf16x8 lds8x2(const char* p0, const char* p1) {
 __device__ __forceinline__ bf16x8 ldg16(const bf16_t* p, bool ok) {
     return __builtin_bit_cast(bf16x8, ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0));
 }
+template <bool F16 = false>
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
-    return __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(v[0], v[1]), pack2_rne(v[2], v[3]), pack2_rne(v[4], v[5]), pack2_rne(v[6], v[7])));
+    return __builtin_bit_cast(bf16x8, make_uint4(pack2_t<F16>(v[0], v[1]), pack2_t<F16>(v[2], v[3]), pack2_t<F16>(v[4], v[5]), pack2_t<F16>(v[6], v[7])));
 }
 // K^T (or any [key][d] tile read transposed): lane (c, g4) gets tile[kb*16 + 4*g4 + j][db*16 + c], j = 0..3, for kb = 0, 1:
 // the A operand [row = d][k-slot (g4, j)] of dq^T = K^T ds^T under the permuted-key convention
@@ -109,6 +111,7 @@ __device__ __forceinline__ void stage_chunk(char* smem, int buf, int ch, int b, 
 }
 
 // S^T chunk of head h: rows = keys (2 blocks of 16), cols = the wave's 16 queries
+template <bool F16 = false>
 __device__ __forceinline__ void qk_chunk(const char* base, int h, int c, int g4, const bf16x8 (&qf)[KS], f32x4& s0, f32x4& s1) {
     s0 = s1 = f32x4{0.f, 0.f, 0.f, 0.f};
     // all four fragment reads first, then the four MFMAs: one exposed LDS round trip per head instead of two (the compiler keeps the
@@ -121,8 +124,8 @@ __device__ __forceinline__ void qk_chunk(const char* base, int h, int c, int g4,
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        s0 = MFMA(k0[ks], qf[ks], s0);
-        s1 = MFMA(k1[ks], qf[ks], s1);
+        s0 = mfma16<F16>(k0[ks], qf[ks], s0);
+        s1 = mfma16<F16>(k1[ks], qf[ks], s1);
     }
 }
 // normalised probabilities of the 8 keys this lane holds (slots e = kb*4 + r), 0 where the key is masked:
@@ -836,6 +839,7 @@ __device__ __forceinline__ void stage_chunk8(char* smem, int buf, int ch, int b,
 }
 // A operand of the head-mix MFMA for output heads 4Q .. 4Q+3 (see mix_operand), rows read straight from global memory
 struct MixQ { bf16x8 hi, lo; };
+template <bool F16 = false>
 __device__ __forceinline__ MixQ mix_operand_q(const float* w /* [8][8], row = output head */, int Q, int lane) {
     const int m = lane & 15;
     const bool on = (m >> 2) == (lane >> 4);
@@ -844,8 +848,8 @@ __device__ __forceinline__ MixQ mix_operand_q(const float* w /* [8][8], row = ou
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const float x0 = row[2 * t], x1 = row[2 * t + 1];
-        ph[t] = pack2_rne(x0, x1);
-        pl[t] = pack2_rne(x0 - lo_f(ph[t]), x1 - hi_f(ph[t]));
+        ph[t] = pack2_t<F16>(x0, x1);
+        pl[t] = pack2_t<F16>(x0 - lo_t<F16>(ph[t]), x1 - hi_t<F16>(ph[t]));
     }
     MixQ a;
     a.hi = __builtin_bit_cast(bf16x8, on ? make_uint4(ph[0], ph[1], ph[2], ph[3]) : make_uint4(0, 0, 0, 0));
@@ -853,12 +857,17 @@ __device__ __forceinline__ MixQ mix_operand_q(const float* w /* [8][8], row = ou
     return a;
 }
 #define MIXQ(A_, B_) MFMA((A_).lo, B_, MFMA((A_).hi, B_, (f32x4{0.f, 0.f, 0.f, 0.f})))
+template <bool F16>
+__device__ __forceinline__ f32x4 mixq(const MixQ& A, const bf16x8& B) {
+    return mfma16<F16>(A.lo, B, mfma16<F16>(A.hi, B, f32x4{0.f, 0.f, 0.f, 0.f}));
+}
 // this wave's half of the B operands (its 4 heads of every slot e) -> its exchange slot; after the workgroup barrier
 // xch_full() returns the complete 8-head operand of slot e (own half + the partner wave's)
+template <bool F16 = false>
 __device__ __forceinline__ void xch_put(char* xch_own, int lane, const float (&v)[4][8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-        *reinterpret_cast<uint2*>(xch_own + e * 512 + lane * 8) = make_uint2(pack2_rne(v[0][e], v[1][e]), pack2_rne(v[2][e], v[3][e]));
+        *reinterpret_cast<uint2*>(xch_own + e * 512 + lane * 8) = make_uint2(pack2_t<F16>(v[0][e], v[1][e]), pack2_t<F16>(v[2][e], v[3][e]));
 }
 __device__ __forceinline__ bf16x8 xch_full(const char* xch_own, const char* xch_par, int lane, int hh, int e) {
     const uint2 own = *reinterpret_cast<const uint2*>(xch_own + e * 512 + lane * 8);
@@ -866,6 +875,10 @@ __device__ __forceinline__ bf16x8 xch_full(const char* xch_own, const char* xch_
     return __builtin_bit_cast(bf16x8, hh ? make_uint4(par.x, par.y, own.x, own.y) : make_uint4(own.x, own.y, par.x, par.y));
 }
 
+// F16: the operands (q, the K / V images) are fp16 and every MFMA of the kernel -- scores, head mix, P'V -- is the fp16 one; the
+// probabilities are packed to fp16, W travels as an fp16 hi + lo pair, and o leaves as a bf16 hi + lo pair (a.ol): the forward
+// cross-attention core of the 'bf16x3-fwd' precision mode.  Statistics as in the bf16 form (the bf16 backward recomputes from them).
+template <bool F16>
 __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NHH = NH / 2;
@@ -879,7 +892,7 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
     char* xch_own = smem + 2 * STAGE + wave * XCH;
     const char* xch_par = smem + 2 * STAGE + (wave ^ 1) * XCH;
     const uint32_t* vwords = reinterpret_cast<const uint32_t*>(a.valid + (size_t)b * a.JP);
-    const MixQ AW = mix_operand_q(a.wth, hh, lane);
+    const MixQ AW = mix_operand_q<F16>(a.wth, hh, lane);
     const float c1 = a.scale * 1.4426950408889634f;
     bf16x8 qf[NHH][KS];
 #pragma unroll
@@ -902,7 +915,7 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
 #pragma unroll
         for (int h = 0; h < NHH; ++h) {
             f32x4 s0, s1;
-            qk_chunk(base, 4 * hh + h, c, g4, qf[h], s0, s1);
+            qk_chunk<F16>(base, 4 * hh + h, c, g4, qf[h], s0, s1);
             float s[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -955,27 +968,27 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
 #pragma unroll
             for (int h = 0; h < NHH; ++h) {
                 f32x4 s0, s1;
-                qk_chunk(base, 4 * hh + h, c, g4, qf[h], s0, s1);
+                qk_chunk<F16>(base, 4 * hh + h, c, g4, qf[h], s0, s1);
                 probs(s0, s1, vm0, vm1, c1, nb[h], P[h]);
             }
-            xch_put(xch_own, lane, P);
+            xch_put<F16>(xch_own, lane, P);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         f32x4 D[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) D[e] = MIXQ(AW, xch_full(xch_own, xch_par, lane, hh, e));   // D[e][rp] = P'[4 hh + rp] of slot e
+        for (int e = 0; e < 8; ++e) D[e] = mixq<F16>(AW, xch_full(xch_own, xch_par, lane, hh, e));   // D[e][rp] = P'[4 hh + rp] of slot e
 #pragma unroll
         for (int rp = 0; rp < 4; ++rp) {
             const int g = 4 * hh + rp;
             const float pv[8] = {D[0][rp], D[1][rp], D[2][rp], D[3][rp], D[4][rp], D[5][rp], D[6][rp], D[7][rp]};
-            const bf16x8 pf = pack8(pv);
+            const bf16x8 pf = pack8<F16>(pv);
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const int d = db * 16 + c;
                 const bf16x8 vf = lds8x2(base + KT_BYTES + dk_off(g, d, g4 >> 1) + (g4 & 1) * 8,
                                          base + KT_BYTES + dk_off(g, d, 2 + (g4 >> 1)) + (g4 & 1) * 8);
-                O[rp][db] = MFMA(vf, pf, O[rp][db]);
+                O[rp][db] = mfma16<F16>(vf, pf, O[rp][db]);
             }
         }
         // ONE ring barrier per chunk: own pieces of chunk ch + 1 (issued a whole iteration ago) have landed, and after the barrier
@@ -989,8 +1002,12 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
         for (int rp = 0; rp < NHH; ++rp)
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                bf16_t* dst = a.o + ((size_t)b * a.n + qi) * a.ldo + (4 * hh + rp) * DH + db * 16 + g4 * 4;
-                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(O[rp][db][0], O[rp][db][1]), pack2_rne(O[rp][db][2], O[rp][db][3]));
+                const size_t go = ((size_t)b * a.n + qi) * a.ldo + (4 * hh + rp) * DH + db * 16 + g4 * 4;
+                const uint32_t h01 = pack2_rne(O[rp][db][0], O[rp][db][1]), h23 = pack2_rne(O[rp][db][2], O[rp][db][3]);
+                *reinterpret_cast<uint2*>(a.o + go) = make_uint2(h01, h23);
+                if (F16 && a.ol)
+                    *reinterpret_cast<uint2*>(a.ol + go) = make_uint2(pack2_rne(O[rp][db][0] - lo_f(h01), O[rp][db][1] - hi_f(h01)),
+                                                                      pack2_rne(O[rp][db][2] - lo_f(h23), O[rp][db][3] - hi_f(h23)));
             }
     }
 }
@@ -1020,14 +1037,32 @@ extern "C" int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     // matrix pipe), 1 = xattn2 (one wave, VALU head mix)
     if (g_amdnuwa_tuning[10] == 0) {
         const int lds4 = 2 * STAGE + 8 * XCH;
-        (void)hipFuncSetAttribute((const void*)xattn4_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
-        hipLaunchKernelGGL(xattn4_fwd_kernel, dim3(g->B * tiles), dim3(512), lds4, stream, a);
+        (void)hipFuncSetAttribute((const void*)xattn4_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        hipLaunchKernelGGL(xattn4_fwd_kernel<false>, dim3(g->B * tiles), dim3(512), lds4, stream, a);
         LAUNCH_CHECK();
         return AMDNUWA_OK;
     }
     auto kern = g_amdnuwa_tuning[10] == 1 ? xattn2_fwd_kernel : xattn3_fwd_kernel;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
     hipLaunchKernelGGL(kern, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_xattn2_fwd_f16(const amdnuwa_xattn_geom* g, const uint16_t* q_f16, int ldq, const amdnuwa_xattn_kv* p,
+                                      const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, float* stats, hipStream_t stream) {
+    int rc = check2(g);
+    if (rc) return rc;
+    if (!q_f16 || !p || !p->Kp_lo || !p->Vt_lo || !p->valid || !w_th || !o || ldq % 8 || ldo % 4) return AMDNUWA_ERR_ARG;
+    if (g->B <= 0 || g->n <= 0) return AMDNUWA_OK;
+    X2Args a{};
+    a.q = q_f16; a.ldq = ldq; a.Kp = p->Kp_lo; a.Vp = p->Vp_lo; a.Vt = p->Vt_lo; a.valid = p->valid; a.wth = w_th;    // the fp16 images
+    a.o = o; a.ol = o_lo; a.ldo = ldo; a.stats = stats;
+    a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
+    const int tiles = (g->n + 63) / 64;
+    const int lds4 = 2 * STAGE + 8 * XCH;
+    (void)hipFuncSetAttribute((const void*)xattn4_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+    hipLaunchKernelGGL(xattn4_fwd_kernel<true>, dim3(g->B * tiles), dim3(512), lds4, stream, a);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

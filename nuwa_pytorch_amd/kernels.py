@@ -2,6 +2,7 @@
 Tensors only provide device memory (torch caching allocator) and the current HIP stream; all
 arithmetic happens inside libamdnuwa."""
 import ctypes as C
+import os
 import threading
 from collections import namedtuple
 
@@ -10,7 +11,9 @@ import torch
 from . import _lib
 from ._lib import GemmDesc, S3Geom, XGeom, XKV, check
 
-BF = namedtuple('BF', ['hi', 'lo'])     # bf16 hi part + optional bf16 residual (parity mode)
+# bf16 hi part + optional bf16 residual `lo` (hi + lo = the value to ~16 bits: the operand form of the 3-MFMA products) + optional
+# `f16` = the fp16 rendering of the same value (the operand form of the fp16 attention cores of the 'bf16x3-fwd' mode)
+BF = namedtuple('BF', ['hi', 'lo', 'f16'], defaults=(None,))
 
 _PRECISION = 'bf16'
 _TIMER = {'on': False, 'flops': 0.0}
@@ -71,7 +74,21 @@ def fast_io():
 
 def hi_only(t):
     """the hi part of a BF pair (what the mixed mode keeps for its bf16 backward); anything else passes through"""
-    return BF(t.hi, None) if isinstance(t, BF) and t.lo is not None else t
+    return BF(t.hi, None) if isinstance(t, BF) and (t.lo is not None or t.f16 is not None) else t
+
+
+_CORES_F16 = os.environ.get('AMDNUWA_F16_CORES', '1') != '0'
+
+
+def set_cores_f16(on):
+    """'bf16x3-fwd' only: run the forward attention cores on single fp16 MFMAs (default) or, when off, on 3-MFMA bf16 hi + lo
+    products like the projection GEMMs around them (A/B switch; both meet the 1e-3 logits bound)"""
+    global _CORES_F16
+    _CORES_F16 = bool(on)
+
+
+def cores_f16():
+    return _CORES_F16 and mixed()
 
 
 def _p(t):
@@ -139,10 +156,22 @@ def timer_issued_flops():
     return _TIMER.get('issued', 0.0)
 
 
-def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None, N=None, K=None, geglu_out=None):
+def hilo_to_f16(t):
+    """fp16 tensor = fp16(hi + lo) of a 2-D BF pair"""
+    R, Cc = t.hi.shape
+    out = torch.empty((R, Cc), dtype=torch.float16, device=t.hi.device)
+    check(_lib.lib().amdnuwa_hilo_to_f16(_p(t.hi), _p(t.lo), _ld(t.hi), _p(out), _ld(out), R, Cc, _stream()), 'amdnuwa_hilo_to_f16')
+    return out
+
+
+def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None, N=None, K=None, geglu_out=None, out_f16=False):
     """C[M,N] = alpha * A[M,K] @ B[N,K]^T (+ bias).  A, B: BF pairs of 2-D views.
     out: fp32 tensor view or BF pair view (allocated when None).  shift = (ntok, fmap) folds the
-    token shift into A's loader."""
+    token shift into A's loader.  out_f16 (hi + lo operands, bf16 output): the result is BF(hi, None, f16) -- a bf16 copy and
+    an fp16 copy of the product, the operand form of the fp16 attention cores."""
+    if out_f16:
+        assert out is None and out_bf16 and geglu_out is None and A.lo is not None and B.lo is not None
+        return _gemm_nt_f16(A, B, bias=bias, alpha=alpha, shift=shift, N=N, K=K)
     L = _lib.lib()
     M = A.hi.shape[0]
     K = A.hi.shape[1] if K is None else K
@@ -183,6 +212,38 @@ def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None,
     if _TIMER['on']:
         L.amdnuwa_timer_end(st)
     return out
+
+
+def _gemm_nt_f16(A, B, *, bias, alpha, shift, N, K):
+    L = _lib.lib()
+    M = A.hi.shape[0]
+    K = A.hi.shape[1] if K is None else K
+    N = B.hi.shape[0] if N is None else N
+    dev = A.hi.device
+    hi = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    f16 = torch.empty((M, N), dtype=torch.float16, device=dev)
+    d = GemmDesc()
+    d.A, d.Alo, d.lda = _p(A.hi), _p(A.lo), _ld(A.hi)
+    d.B, d.Blo, d.ldb = _p(B.hi), _p(B.lo), _ld(B.hi)
+    d.C, d.Clo, d.ldc, d.c_is_bf16, d.c_lo_f16 = _p(hi), _p(f16), N, 1, 1
+    d.bias, d.alpha, d.beta = _p(bias), float(alpha), 0.0
+    d.M, d.N, d.K, d.batch = M, N, K, 1
+    if shift is not None:
+        d.shift_ntok, d.shift_fmap = int(shift[0]), int(shift[1])
+    if not L.amdnuwa_gemm_nt_f16_fused(C.byref(d)):
+        # shapes outside the hi + lo ring (small M, token shift in the loader): plain hi + lo product, then one conversion pass
+        full = gemm_nt(A, B, out_bf16=True, bias=bias, alpha=alpha, shift=shift, N=N, K=K)
+        return BF(full.hi, None, hilo_to_f16(full))
+    st = _stream()
+    if _TIMER['on']:
+        _TIMER['flops'] += 2.0 * M * N * K
+        _TIMER['issued'] = _TIMER.get('issued', 0.) + 6.0 * M * N * K
+        _TIMER['bytes'] += 4.0 * (M + N) * K + 4.0 * M * N
+        L.amdnuwa_timer_begin(st)
+    check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(f16 copy)')
+    if _TIMER['on']:
+        L.amdnuwa_timer_end(st)
+    return BF(hi, None, f16)
 
 
 def gemm_nt_geglu_bwd(dy, w2T, u, FP):
@@ -497,12 +558,22 @@ def s3_supported(video_shape, kernel, dilation, heads, dim_head, causal=True, lo
     return bool(_lib.lib().amdnuwa_s3_supported(C.byref(g), 1 if lo else 0))
 
 
+def s3_f16_supported(g):
+    return bool(_lib.lib().amdnuwa_s3_f16_supported(C.byref(g)))
+
+
 def sparse3dna_fwd(g, qkv, wth, rel_bias=None):
     """qkv: BF [B*ntok, 3*inner] (q | k | v);  returns o BF [B*ntok, inner].  rel_bias: fp32 [J, heads] or None"""
     L = _lib.lib()
     g.rel_bias, g.d_rel_bias = _p(rel_bias), None
     inner = g.heads * g.dim_head
     R = g.B * g.ntok
+    if qkv.f16 is not None:            # fp16 operand form: single fp16 MFMAs, hi + lo output
+        o = empty_bf((R, inner), qkv.hi.device, lo=True)
+        q16, k16, v16 = (qkv.f16[:, i * inner:(i + 1) * inner] for i in range(3))
+        check(L.amdnuwa_sparse3dna_fwd_f16(C.byref(g), _p(q16), _p(k16), _p(v16), qkv.f16.stride(0), _p(wth), _p(o.hi), _p(o.lo), inner,
+                                           _stream()), 'amdnuwa_sparse3dna_fwd_f16')
+        return o
     o = empty_bf((R, inner), qkv.hi.device, lo=qkv.lo is not None)
     q, k, v = (view(qkv, cols=slice(i * inner, (i + 1) * inner)) for i in range(3))
     check(L.amdnuwa_sparse3dna_fwd(C.byref(g), _p(q.hi), _p(k.hi), _p(v.hi), _p(q.lo), _p(k.lo), _p(v.lo), qkv.hi.stride(0),
@@ -636,6 +707,7 @@ class PackedKV:
         s.Vp, s.Vp_lo, s.Vt, s.Vt_lo = _p(self.Vp.hi), _p(self.Vp.lo), _p(self.Vt.hi), _p(self.Vt.lo)
         s.valid = _p(self.valid)
         self.struct = s
+        self.f16 = False
 
     def drop_lo(self):
         """release the lo images (mixed mode: the bf16 backward reads the hi images only)"""
@@ -646,11 +718,31 @@ class PackedKV:
 
 
 def xattn_pack(g, kv, null_k, null_v, mask_u8):
+    """kv with an f16 copy: the lo images of the result are FP16 images (for xattn2_fwd_f16), not bf16 residuals"""
     L = _lib.lib()
+    if kv.f16 is not None:
+        pk = PackedKV(g, kv.hi.device, True)
+        check(L.amdnuwa_xattn_pack_f16(C.byref(g), _p(kv.hi), _p(kv.f16), kv.hi.stride(0), _p(null_k), _p(null_v), _p(mask_u8),
+                                       C.byref(pk.struct), _stream()), 'amdnuwa_xattn_pack_f16')
+        pk.f16 = True
+        return pk
     pk = PackedKV(g, kv.hi.device, kv.lo is not None)
     check(L.amdnuwa_xattn_pack(C.byref(g), _p(kv.hi), _p(kv.lo), kv.hi.stride(0), _p(null_k), _p(null_v), _p(mask_u8),
                                C.byref(pk.struct), _stream()), 'amdnuwa_xattn_pack')
     return pk
+
+
+def xattn2_fwd_f16(g, q, pk, wth):
+    """the xattn4 core on fp16 operands (q.f16, the fp16 images of pk): returns o BF [B*n, inner] (hi + lo) and the statistics"""
+    L = _lib.lib()
+    assert q.f16 is not None and getattr(pk, 'f16', False)
+    inner = g.heads * g.dim_head
+    dev = q.hi.device
+    o = empty_bf((g.B * g.n, inner), dev, lo=True)
+    stats = torch.empty((g.B, g.heads, g.n, 2), dtype=torch.float32, device=dev)
+    check(L.amdnuwa_xattn2_fwd_f16(C.byref(g), _p(q.f16), q.f16.stride(0), C.byref(pk.struct), _p(wth), _p(o.hi), _p(o.lo), inner,
+                                   _p(stats), _stream()), 'amdnuwa_xattn2_fwd_f16')
+    return o, stats
 
 
 def xattn_fwd(g, q, pk, wth, save=True, want_stats=False):

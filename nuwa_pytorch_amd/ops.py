@@ -102,7 +102,9 @@ class S3Inner:
         wth, bo = p[2], p[4]
         g = meta['geom']
         rel = p[5].detach().contiguous() if len(p) > 5 else None          # [J, heads] relative-position bias (optional)
-        qkv = K.gemm_nt(h, W['qkv'], out_bf16=True, shift=meta.get('shift'))
+        # 'bf16x3-fwd': q / k / v leave the 3-MFMA projection as a bf16 copy (backward) + an fp16 copy, and the core runs single fp16 MFMAs
+        f16 = K.cores_f16() and h.lo is not None and K.s3_f16_supported(g)
+        qkv = K.gemm_nt(h, W['qkv'], out_bf16=True, shift=meta.get('shift'), out_f16=f16)
         o = K.sparse3dna_fwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), rel_bias=rel)
         y = K.gemm_nt(o, W['out'], bias=bo.detach(), out_bf16=_fast())
         return y, _sv(h, qkv, o)
@@ -164,16 +166,21 @@ class XInner:
         nk, nv, wth = p[0], p[1], p[2]
         g = meta['xgeom']
         ctx = h if meta.get('self_kv') else meta['ctx_bf']          # self-attention (text encoder): keys / values from the same rows
-        q = K.gemm_nt(h, W['q'], out_bf16=True)
-        kv = K.gemm_nt(ctx, W['kv'], out_bf16=True)
         rot = meta.get('rotary')
+        f16 = K.cores_f16() and h.lo is not None and ctx.lo is not None and rot is None and K.xattn2_supported(g)
+        q = K.gemm_nt(h, W['q'], out_bf16=True, out_f16=f16)
+        kv = K.gemm_nt(ctx, W['kv'], out_bf16=True, out_f16=f16)
         if rot is not None:
             q = _rotary_bf(q, rot, g.B, g.n, g.heads)
             kv = _rotary_bf(kv, rot, g.B, g.T, 2 * g.heads)
         pk = K.xattn_pack(g, kv, nk.detach().reshape(g.heads, g.dim_head).contiguous(),
                           nv.detach().reshape(g.heads, g.dim_head).contiguous(), meta['mask_u8'])
         wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
-        if K.xattn2_supported(g, q):          # fast mode: statistics only, the backward recomputes the probabilities
+        if f16:                               # 'bf16x3-fwd': the xattn4 core on single fp16 MFMAs, hi + lo output, statistics for the bf16 backward
+            o, stats = K.xattn2_fwd_f16(g, q, pk, wth2)
+            P, Pm = stats, None
+            pk.drop_lo()
+        elif K.xattn2_supported(g, q):        # fast mode: statistics only, the backward recomputes the probabilities
             o, stats = K.xattn2_fwd(g, q, pk, wth2)
             P, Pm = stats, None
         elif K.mixed() and K.xattn2_supported(g):

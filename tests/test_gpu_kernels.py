@@ -648,6 +648,89 @@ def test_cross_attention_core(K, O, case, x3):
 
 
 # ---------------------------------------------------------------------------------------------------
+# the fp16-operand forward cores of the 'bf16x3-fwd' mode
+# ---------------------------------------------------------------------------------------------------
+
+def _f16_pair(t):
+    """fp32 CPU tensor -> BF(hi = bf16 copy, None, f16 = fp16 copy) on the device + the fp16-rounded fp32 values"""
+    h = t.half()
+    return K_BF(t.to(torch.bfloat16).to(DEV), None, h.to(DEV)), h.float()
+
+
+def K_BF(hi, lo, f16):
+    from nuwa_pytorch_amd.kernels import BF
+    return BF(hi.contiguous(), lo, f16.contiguous())
+
+
+@pytest.mark.parametrize('shape,kern,dil,n', [((2, 16, 16), (5, 3, 3), (1, 1, 1), None), ((3, 16, 16), (3, 3, 3), (4, 4, 4), 300),
+                                              ((4, 16, 16), (5, 3, 3), (2, 2, 2), 1 + 3 * 256 + 37)])
+def test_sparse3dna_fwd_f16_core(K, O, shape, kern, dil, n):
+    """the MFMA band kernel on fp16 operands (single fp16 MFMAs, hi + lo output) against the oracle on the SAME fp16-rounded q, k, v:
+    what is left is the fp16 rounding of the probabilities before P'V (2^-11 per term) and fp32 accumulation order"""
+    heads, dh = 8, 64
+    N = shape[0] * shape[1] * shape[2]
+    n = N if n is None else n
+    B, inner = 2, heads * dh
+    torch.manual_seed(3)
+    qkv = torch.randn(B * n, 3 * inner)
+    qkvp, qr = _f16_pair(qkv)
+    wth = torch.randn(heads, heads) * 0.5 + torch.eye(heads)
+    idx = O.neighbor_table(shape, kern, dil, causal=True)
+    q3 = qr.reshape(B, n, 3, heads, dh)
+    o_ref = O.sparse3dna_core(q3[:, :, 0], q3[:, :, 1], q3[:, :, 2], wth, idx, dh ** -0.5)
+    g = K.s3_geom(B, n, shape, kern, dil, heads, dh)
+    assert K.s3_f16_supported(g)
+    o = K.sparse3dna_fwd(g, qkvp, wth.to(DEV))
+    assert o.lo is not None
+    report(f's3_fwd_f16[{shape},{dil},{n}]', bf_value(o).reshape(B, n, heads, dh), o_ref, 6e-4)
+    # and against the 3-MFMA (hi + lo) kernel on the full-precision inputs: the difference IS the fp16 rounding of q, k, v, P
+    o3 = K.sparse3dna_fwd(g, to_bf_pair(qkv.to(DEV), True), wth.to(DEV))
+    report(f's3_fwd_f16_vs_x3[{shape},{dil},{n}]', bf_value(o), bf_value(o3), 3e-3)
+
+
+@pytest.mark.parametrize('B,n,T', [(2, 100, 33), (1, 64, 256), (2, 2560, 256)])
+def test_cross_attention_fwd_f16_core(K, O, B, n, T):
+    """the xattn4 core on fp16 operands (fp16 K / V images from xattn_pack, single fp16 MFMAs incl. the head mix, hi + lo output,
+    statistics for the bf16 backward) against the oracle on the same fp16-rounded inputs, and its statistics against the bf16 kernel's"""
+    heads, dh = 8, 64
+    inner = heads * dh
+    torch.manual_seed(7)
+    q, kv = torch.randn(B * n, inner), torch.randn(B * T, 2 * inner)
+    nk, nv = torch.randn(heads, dh), torch.randn(heads, dh)
+    wth = torch.randn(heads, heads) * 0.5 + torch.eye(heads)
+    mask = torch.rand(B, T) > 0.3
+    mask[0] = False
+    qp, qr = _f16_pair(q)
+    kvp, kvr = _f16_pair(kv)
+    kv4 = kvr.reshape(B, T, 2, heads, dh)
+    o_ref = O.attention_core(qr.reshape(B, n, heads, dh), kv4[:, :, 0], kv4[:, :, 1], nk.half().float(), nv.half().float(), wth, mask, dh ** -0.5)
+    g = K.x_geom(B, n, T, heads, dh)
+    pk = K.xattn_pack(g, kvp, nk.to(DEV), nv.to(DEV), mask.to(torch.uint8).to(DEV))
+    o, stats = K.xattn2_fwd_f16(g, qp, pk, wth.to(DEV))
+    report(f'xattn_fwd_f16[{B},{n},{T}]', bf_value(o).reshape(B, n, heads, dh), o_ref, 1e-3)
+    # the bf16 kernel on the hi images: same statistics up to the operand rounding (row max in the log2 domain, 1 / row sum)
+    o2, stats2 = K.xattn2_fwd(g, K.BF(qp.hi, None), pk, wth.to(DEV))
+    report(f'xattn_fwd_f16.stats[{B},{n},{T}]', stats, stats2, 3e-2)
+    report(f'xattn_fwd_f16_vs_bf16[{B},{n},{T}]', bf_value(o), o2.hi.float(), 3e-2)
+
+
+def test_gemm_nt_f16_second_copy(K):
+    """projection GEMM of the 'bf16x3-fwd' mode: hi + lo operands, output = bf16 copy + fp16 copy of the SAME fp32 accumulator (on the
+    256x256 ring in the epilogue; elsewhere product + conversion pass)"""
+    torch.manual_seed(2)
+    for M, N, Kd in ((16384, 1536, 512), (300, 96, 64)):
+        a, b = torch.randn(M, Kd) * 0.5, torch.randn(N, Kd) * 0.3
+        A, Bm = to_bf_pair(a.to(DEV), True), to_bf_pair(b.to(DEV), True)
+        ref = (bf_value(A).double() @ bf_value(Bm).double().t()).float()
+        out = K.gemm_nt(A, Bm, out_bf16=True, out_f16=True)
+        assert out.lo is None and out.f16.dtype == torch.float16
+        full = K.gemm_nt(A, Bm, out_bf16=True)
+        assert torch.equal(out.hi, full.hi)
+        report(f'gemm_f16_copy[{M},{N}]', out.f16.float(), ref, 2 ** -11)
+        assert torch.equal(out.f16, bf_value(full).half())
+
+
+# ---------------------------------------------------------------------------------------------------
 # full-size (BASELINE cfg 3 geometry) size-independent properties
 # ---------------------------------------------------------------------------------------------------
 

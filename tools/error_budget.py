@@ -179,6 +179,11 @@ POLICIES = {
     'f16_y32_lg_exact': Policy('f16', all_y='f32', lg_all='f32'),
     'f16_ff_exact': Policy('f16', ff_all='f32'),
     'f16_attn_exact': Policy('f16', s3_all='f32', x_all='f32'),
+    # GEMMs exact (= bf16 hi+lo, 3 MFMAs), attention cores on single fp16 MFMAs: q, k, v and the probabilities rounded to fp16,
+    # the core's output leaves as a hi + lo pair (no rounding)
+    'x3_gemm_f16_cores': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16'),
+    'x3_gemm_f16_cores_o': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', s3_o='f16', x_o='f16'),
+    'x3_gemm_bf16_cores': Policy('f32', s3_a='bf16', s3_p='bf16', x_a='bf16', x_p='bf16'),
     # bf16 with the final GEMM exact / the y stores in fp32
     'bf16_y32': Policy('bf16', all_y='f32'),
     'bf16_lg_exact': Policy('bf16', lg_all='f32'),

@@ -37,5 +37,9 @@ for name, m, nn, kk, obf, gate in shapes:
     L.amdnuwa_set_tuning(13, 1)
     t_old = bench(call, 5)
     L.amdnuwa_set_tuning(13, 0)
+    for sk in (15, 40, 80):                      # start-phase skew (tuning key 14), ~0.25 us units per phase step
+        L.amdnuwa_set_tuning(14, sk)
+        row.append(f'skew{sk} {bench(call, 10) * 1e6:7.1f}')
+    L.amdnuwa_set_tuning(14, 0)
     fl = 2.0 * m * nn * kk
     print(f'{name:14s} [{m}x{nn}x{kk}]  ' + ' | '.join(row) + f' | 128x128 kernel {t_old * 1e6:7.1f} | issued {3 * fl / t_full / 1e12:6.0f} TF/s | ideal 3x mfma {3 * fl / 2.5e15 * 1e6:6.1f} us')
