@@ -85,12 +85,18 @@ typedef struct {
      * forward core).  Only the 256x256 hi + lo ring does this: ask amdnuwa_gemm_nt_f16_fused() first; otherwise run the plain
      * hi + lo product and amdnuwa_hilo_to_f16(). */
     int c_lo_f16;
+    /* NT: ab_f16 != 0: A and B hold FP16 values (Alo / Blo / Clo must be NULL) and the product runs on the fp16 MFMA.  C: fp32, or
+     * bf16 with the optional GEGLU output computed on the fp32 accumulators: C2 receives its FP16 copy (the next GEMM's A operand),
+     * C2lo -- if not NULL -- its bf16 copy (the backward's operand).  The FeedForward GEMMs (reference nuwa_pytorch.py:255-286) of
+     * the 'bf16x3-fwd' forward.  256x256 ring only: amdnuwa_gemm_nt_f16ops_supported() first, AMDNUWA_ERR_UNSUPPORTED otherwise. */
+    int ab_f16;
 } amdnuwa_gemm_desc;
 
 /* C[M,N] = alpha * A[M,K] . B[N,K]^T (+ bias).  K, lda, ldb multiples of 8. */
 int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, amdnuwa_stream stream);
 /* 1 when the C2 (GEGLU) output of this product is produced inside the GEMM epilogue, 0 when the library will run GEMM + gate kernel */
 int amdnuwa_gemm_nt_fused(const amdnuwa_gemm_desc* d);
+int amdnuwa_gemm_nt_f16ops_supported(const amdnuwa_gemm_desc* d);
 /* 1 when amdnuwa_gemm_nt() honours d->c_lo_f16 for this product (it returns AMDNUWA_ERR_UNSUPPORTED otherwise) */
 int amdnuwa_gemm_nt_f16_fused(const amdnuwa_gemm_desc* d);
 /* out[r][c] = fp16(hi[r][c] + lo[r][c]) over an [R, C] view (row pitches ld_in / ld_out elements, C % 8 == 0) */
@@ -116,6 +122,9 @@ int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspac
  * (np.py:157-183): the first half of the channels of row i comes from row i - 1 (zeros for row 0), every row takes part. */
 #define AMDNUWA_LN_X_BF16 16
 #define AMDNUWA_LN_DY_BF16 32
+/* ln_fwd (mode 0) / ln_post_pre_fwd: the second 16-bit output (out_lo / h_lo) receives the FP16 rendering of the normalised row
+ * instead of the bf16 residual -- the A operand of the fp16-operand GEMMs (amdnuwa_gemm_desc.ab_f16) */
+#define AMDNUWA_LN_LO_F16 64
 int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const float* b, uint16_t* out_hi,
                    uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R, int D,
                    int mode, int stable, float eps, int shift_ntok, int shift_fmap, amdnuwa_stream stream);

@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
                 ('c_is_bf16', I), ('bias', P), ('alpha', F), ('beta', F),
                 ('M', I), ('N', I), ('K', I), ('batch', I), ('shift_ntok', I), ('shift_fmap', I),
                 ('batch_inner', I), ('strideA_inner', LL), ('strideB_inner', LL), ('strideC_inner', LL),
-                ('C2', P), ('C2lo', P), ('ldc2', I), ('geglu_u', P), ('geglu_u_lo', P), ('ld_u', I), ('c_lo_f16', I)]
+                ('C2', P), ('C2lo', P), ('ldc2', I), ('geglu_u', P), ('geglu_u_lo', P), ('ld_u', I), ('c_lo_f16', I), ('ab_f16', I)]
 
 
 class S3Geom(C.Structure):
@@ -71,6 +71,7 @@ SIGNATURES = {
     'amdnuwa_geglu_fwd': (I, [P, P, P, P, LL, I, P]),
     'amdnuwa_gemm_nt_fused': (I, [GD]),
     'amdnuwa_gemm_nt_f16_fused': (I, [GD]),
+    'amdnuwa_gemm_nt_f16ops_supported': (I, [GD]),
     'amdnuwa_hilo_to_f16': (I, [P, P, I, P, I, LL, I, P]),
     'amdnuwa_geglu_il_fwd': (I, [P, P, P, P, LL, I, P]),
     'amdnuwa_geglu_il_bwd': (I, [P, P, P, P, P, P, LL, I, P]),

@@ -74,8 +74,14 @@ __device__ __forceinline__ float4 ldp4(const float* __restrict__ p, int e, int D
     const float4 v = *reinterpret_cast<const float4*>(p + (in ? e : 0));
     return make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
 }
-__device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, float a, float b, float c, float d) {
+// lo_f16: the second copy is the fp16 rendering of the value (operand of the fp16 GEMMs of 'bf16x3-fwd'), not the bf16 residual
+__device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, float a, float b, float c, float d, bool lo_f16 = false) {
     if (!lo) { *reinterpret_cast<uint2*>(hi + e) = make_uint2(pack2_rne(a, b), pack2_rne(c, d)); return; }
+    if (lo_f16) {
+        *reinterpret_cast<uint2*>(hi + e) = make_uint2(pack2_rne(a, b), pack2_rne(c, d));
+        *reinterpret_cast<uint2*>(lo + e) = make_uint2(pack2_f16(a, b), pack2_f16(c, d));
+        return;
+    }
     bf16_t h[4], l[4];
     f2bf_hilo(a, h[0], l[0]); f2bf_hilo(b, h[1], l[1]); f2bf_hilo(c, h[2], l[2]); f2bf_hilo(d, h[3], l[3]);
     *reinterpret_cast<uint2*>(hi + e) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
@@ -86,7 +92,7 @@ __device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, floa
 // channels of token (f, y, w) belongs to token (f, y+1, w), the second to (f, y, w+1); a row writes zeros into its own quarter
 // when it has no source (y == 0 / w == 0).  The consumers (NT and TN GEMMs) then read a plain matrix.
 __device__ __forceinline__ void store_ln_shifted(bf16_t* out_hi, bf16_t* out_lo, long long row, int e, int D, int shift_ntok,
-                                                 int shift_fmap, float y0, float y1, float y2, float y3) {
+                                                 int shift_fmap, float y0, float y1, float y2, float y3, bool lo_f16 = false) {
     long long drow = row;
     bool keep = true, zero_own = false;
     if (shift_ntok > 0 && shift_fmap < 0) {
@@ -103,8 +109,8 @@ __device__ __forceinline__ void store_ln_shifted(bf16_t* out_hi, bf16_t* out_lo,
             else         { keep = wq + 1 < shift_fmap && i + 1 < shift_ntok;          drow = row + 1;          zero_own = wq == 0; }
         }
     }
-    if (keep) store_bf16x4(out_hi + drow * D, out_lo ? out_lo + drow * D : nullptr, e, y0, y1, y2, y3);
-    if (zero_own) store_bf16x4(out_hi + row * D, out_lo ? out_lo + row * D : nullptr, e, 0.f, 0.f, 0.f, 0.f);
+    if (keep) store_bf16x4(out_hi + drow * D, out_lo ? out_lo + drow * D : nullptr, e, y0, y1, y2, y3, lo_f16);
+    if (zero_own) store_bf16x4(out_hi + row * D, out_lo ? out_lo + row * D : nullptr, e, 0.f, 0.f, 0.f, 0.f, lo_f16);
 }
 
 template <int NV>
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
                                                      float* __restrict__ out_f32, float* __restrict__ mean_o,
                                                      float* __restrict__ rstd_o, float* __restrict__ inv_amax_o,
-                                                     long long R, int D, float eps, int shift_ntok, int shift_fmap) {
+                                                     long long R, int D, float eps, int shift_ntok, int shift_fmap, int lo_f16) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= R) return;
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const float y2 = (xv.v[it].z - mean) * rstd * wv.z + bv.z;
         const float y3 = (xv.v[it].w - mean) * rstd * wv.w + bv.w;
         if (MODE == 0) {
-            store_ln_shifted(out_hi, out_lo, row, e, D, shift_ntok, shift_fmap, y0, y1, y2, y3);
+            store_ln_shifted(out_hi, out_lo, row, e, D, shift_ntok, shift_fmap, y0, y1, y2, y3, lo_f16 != 0);
         } else {
             const float4 rv = *reinterpret_cast<const float4*>(resid + row * D + e);
             *reinterpret_cast<float4*>(out_f32 + row * D + e) = make_float4(rv.x + y0, rv.y + y1, rv.z + y2, rv.w + y3);
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256) void ln_post_pre_kernel(const float* __restric
                                                           const float* __restrict__ b2, bf16_t* __restrict__ h_hi,
                                                           bf16_t* __restrict__ h_lo, float* __restrict__ mean2_o,
                                                           float* __restrict__ rstd2_o, long long R, int D, float eps,
-                                                          int shift_ntok, int shift_fmap) {
+                                                          int shift_ntok, int shift_fmap, int lo_f16) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= R) return;
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256) void ln_post_pre_kernel(const float* __restric
         const float4 bv = *reinterpret_cast<const float4*>(b2 + e);
         store_ln_shifted(h_hi, h_lo, row, e, D, shift_ntok, shift_fmap,
                          (xv.v[it].x - mean2) * rstd2 * wv.x + bv.x, (xv.v[it].y - mean2) * rstd2 * wv.y + bv.y,
-                         (xv.v[it].z - mean2) * rstd2 * wv.z + bv.z, (xv.v[it].w - mean2) * rstd2 * wv.w + bv.w);
+                         (xv.v[it].z - mean2) * rstd2 * wv.z + bv.z, (xv.v[it].w - mean2) * rstd2 * wv.w + bv.w, lo_f16 != 0);
     }
 }
 
@@ -898,6 +904,7 @@ extern "C" int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w
                               uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R,
                               int D, int mode, int stable, float eps, int shift_ntok, int shift_fmap, hipStream_t stream) {
     const bool xbf = (mode & AMDNUWA_LN_X_BF16) != 0;        // x points at bf16 values
+    const int lo_f16 = (mode & AMDNUWA_LN_LO_F16) ? 1 : 0;    // out_lo receives fp16(value) instead of the bf16 residual
     mode &= 1;
     if (shift_ntok > 0 && (mode != 0 || shift_fmap == 0 || shift_fmap < -1 || D % 16)) return AMDNUWA_ERR_ARG;
     if (!x || !w || !b || !mean || !rstd || D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
@@ -906,8 +913,8 @@ extern "C" int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w
     if (stable && !inv_amax) return AMDNUWA_ERR_ARG;
     if (R <= 0) return AMDNUWA_OK;
     dim3 grid((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
-#define LNF(MO, ST, NV_) do { if (xbf) hipLaunchKernelGGL((ln_fwd_kernel<MO, ST, NV_, true>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps, shift_ntok, shift_fmap); \
-                              else hipLaunchKernelGGL((ln_fwd_kernel<MO, ST, NV_, false>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps, shift_ntok, shift_fmap); } while (0)
+#define LNF(MO, ST, NV_) do { if (xbf) hipLaunchKernelGGL((ln_fwd_kernel<MO, ST, NV_, true>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps, shift_ntok, shift_fmap, lo_f16); \
+                              else hipLaunchKernelGGL((ln_fwd_kernel<MO, ST, NV_, false>), grid, block, 0, stream, x, resid, w, b, out_hi, out_lo, out_f32, mean, rstd, inv_amax, R, D, eps, shift_ntok, shift_fmap, lo_f16); } while (0)
 #define LNF_NV(MO, ST) do { if (D <= 256) LNF(MO, ST, 1); else if (D <= 512) LNF(MO, ST, 2); else LNF(MO, ST, 4); } while (0)
     if (mode == 0 && !stable) LNF_NV(0, false);
     else if (mode == 0) LNF_NV(0, true);
@@ -923,14 +930,15 @@ extern "C" int amdnuwa_ln_post_pre_fwd(const float* y, const float* resid, const
                                        uint16_t* h_lo, float* next_mean, float* next_rstd, long long R, int D, int flags,
                                        float eps, int shift_ntok, int shift_fmap, hipStream_t stream) {
     const bool xbf = (flags & AMDNUWA_LN_X_BF16) != 0;
+    const int lo_f16 = (flags & AMDNUWA_LN_LO_F16) ? 1 : 0;
     if (!y || !resid || !w || !b || !out_f32 || !mean || !rstd || !next_w || !next_b || !h_hi || !next_mean || !next_rstd)
         return AMDNUWA_ERR_ARG;
     if (D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
     if (shift_ntok > 0 && (shift_fmap == 0 || shift_fmap < -1 || D % 16)) return AMDNUWA_ERR_ARG;
     if (R <= 0) return AMDNUWA_OK;
     dim3 grid((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
-#define LPP(NV_) do { if (xbf) hipLaunchKernelGGL((ln_post_pre_kernel<NV_, true>), grid, block, 0, stream, y, resid, w, b, out_f32, mean, rstd, next_w, next_b, h_hi, h_lo, next_mean, next_rstd, R, D, eps, shift_ntok, shift_fmap); \
-                      else hipLaunchKernelGGL((ln_post_pre_kernel<NV_, false>), grid, block, 0, stream, y, resid, w, b, out_f32, mean, rstd, next_w, next_b, h_hi, h_lo, next_mean, next_rstd, R, D, eps, shift_ntok, shift_fmap); } while (0)
+#define LPP(NV_) do { if (xbf) hipLaunchKernelGGL((ln_post_pre_kernel<NV_, true>), grid, block, 0, stream, y, resid, w, b, out_f32, mean, rstd, next_w, next_b, h_hi, h_lo, next_mean, next_rstd, R, D, eps, shift_ntok, shift_fmap, lo_f16); \
+                      else hipLaunchKernelGGL((ln_post_pre_kernel<NV_, false>), grid, block, 0, stream, y, resid, w, b, out_f32, mean, rstd, next_w, next_b, h_hi, h_lo, next_mean, next_rstd, R, D, eps, shift_ntok, shift_fmap, lo_f16); } while (0)
     if (D <= 256) LPP(1); else if (D <= 512) LPP(2); else LPP(4);
 #undef LPP
     LAUNCH_CHECK();

@@ -402,7 +402,10 @@ __device__ __forceinline__ int b256_off(int row, int cc) { return row * 64 + ((c
 template <int EPI>
 __device__ __forceinline__ int b256_row(int j, int fr) { return EPI >= 1 ? ((fr >> 2) * 16 + j * 4 + (fr & 3)) : (j * 16 + fr); }
 
-template <bool SHIFT, int EPI, int NS, int WNW, int STAG = 0>
+// F16: A and B hold fp16 values and the products run on v_mfma_f32_16x16x32_f16 (same rate, 11 significand bits): the FeedForward
+// GEMMs of the 'bf16x3-fwd' mode's forward.  Outputs: fp32 (EPI 0) as ever; EPI 1 writes C = bf16 (u, for the bf16 backward) and,
+// with C2, the gate output computed on the fp32 accumulators as an fp16 copy (C2: FF2's operand) + a bf16 copy (C2lo: backward).
+template <bool SHIFT, int EPI, int NS, int WNW, int STAG = 0, bool F16 = false>
 __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 2 * WNW, BN = 64 * WNW;
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
                 for (int i = 2 * q; i < 2 * q + 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<F16>(bfr[j], af[i], acc[i][j]);
                 if (more) { if (q < 2) issue_a(q, nslot, nk0); else issue_b(q - 2, nslot, nk0); }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<F16>(bfr[j], af[i], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16<F16>(bfr[j], af[i], acc[i][j]);
     }
 
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
@@ -722,6 +725,19 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
                 }
                 reinterpret_cast<uint4*>(C)[0] = ua;
                 reinterpret_cast<uint4*>(C)[1] = ug;
+                if constexpr (F16) {
+                    if (p.C2) {            // gate on the fp32 accumulators; fp16 copy -> C2 (FF2's A operand), bf16 copy -> C2lo (backward)
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = vv[e] * gelu_f(vv[8 + e]);
+                        *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) =
+                            make_uint4(pack2_f16(o[0], o[1]), pack2_f16(o[2], o[3]), pack2_f16(o[4], o[5]), pack2_f16(o[6], o[7]));
+                        if (p.C2lo)
+                            *reinterpret_cast<uint4*>(p.C2lo + m * p.ldc2 + (nb >> 1)) =
+                                make_uint4(pack2_rne(o[0], o[1]), pack2_rne(o[2], o[3]), pack2_rne(o[4], o[5]), pack2_rne(o[6], o[7]));
+                    }
+                    continue;
+                }
                 if (p.C2) {
                     // GEGLU on the values as STORED (bf16-rounded u), so the result equals the separate kernel's bit for bit:
                     // the lane's 16 columns are 8 values and their 8 gates (interleaved-by-8 weight rows)
@@ -1698,6 +1714,17 @@ extern "C" int amdnuwa_linear_ce(const uint16_t* h, int ldh, const uint16_t* w, 
 
 extern "C" int amdnuwa_gemm_nt_fused(const amdnuwa_gemm_desc* d) { return d && d->C2 && nt_geglu_fusable(d) ? 1 : 0; }
 
+// fp16 operands (d->ab_f16): the 256x256 ring only -- the FeedForward GEMMs of the 'bf16x3-fwd' forward at training sizes
+extern "C" int amdnuwa_gemm_nt_f16ops_supported(const amdnuwa_gemm_desc* d) {
+    if (!d || !d->A || !d->B || !d->C || d->Alo || d->Blo || d->shift_ntok > 0 || d->batch > 1 || d->geglu_u || d->Clo) return 0;
+    if (d->K % 32 || d->lda % 8 || d->ldb % 8 || d->M <= 4 * ROWS_MR) return 0;
+    if (d->c_is_bf16 && (d->N % 16 || d->ldc % 8 || (d->C2 && d->ldc2 % 8))) return 0;
+    if (!d->c_is_bf16 && (d->C2 || d->N % 4 || d->ldc % 4)) return 0;
+    const int v = g_amdnuwa_tuning[0];
+    if (v != 0 && v != 7) return 0;
+    return (v == 7 || (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 512) ? 1 : 0;
+}
+
 // does this product run on the bf16x3 256x256 ring (the only kernel that writes the fp16 second copy)?
 static bool nt_x3_ring(const amdnuwa_gemm_desc* d) {
     if (!d->Alo || !d->Blo || d->shift_ntok > 0 || d->K % 32 || g_amdnuwa_tuning[13] == 1) return false;
@@ -1714,7 +1741,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     if (!d || !d->A || !d->B || !d->C) return AMDNUWA_ERR_ARG;
     if (d->M <= 0 || d->N <= 0) return AMDNUWA_OK;
     if (d->geglu_u && !d->C2) return AMDNUWA_ERR_ARG;
-    if (d->C2 && !nt_geglu_fusable(d)) {             // plain product, then the stand-alone gate kernel on the same layout
+    if (d->C2 && !d->ab_f16 && !nt_geglu_fusable(d)) {             // plain product, then the stand-alone gate kernel on the same layout
         if (!d->c_is_bf16 || d->ldc != d->N || d->batch > 1) return AMDNUWA_ERR_ARG;
         amdnuwa_gemm_desc plain = *d;
         plain.C2 = nullptr; plain.C2lo = nullptr; plain.geglu_u = nullptr; plain.geglu_u_lo = nullptr;
@@ -1726,6 +1753,28 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         }
         if (d->N % 16 || d->ldc2 != d->N / 2) return AMDNUWA_ERR_ARG;
         return amdnuwa_geglu_il_fwd((const uint16_t*)d->C, d->Clo, d->C2, d->C2lo, d->M, d->N / 2, stream);
+    }
+    if (d->ab_f16) {
+        if (!amdnuwa_gemm_nt_f16ops_supported(d)) return AMDNUWA_ERR_UNSUPPORTED;
+        GemmArgs q{};
+        q.A = (const bf16_t*)d->A; q.lda = d->lda; q.B = (const bf16_t*)d->B; q.ldb = d->ldb;
+        q.C = d->C; q.ldc = d->ldc; q.bias = d->bias; q.alpha = d->alpha;
+        q.M = d->M; q.N = d->N; q.K = d->K; q.shift_dim = d->K;
+        q.tiles_m = (d->M + 255) / 256; q.tiles_n = (d->N + 255) / 256;
+        q.dbg = g_amdnuwa_tuning[7];
+        if (d->C2) { q.C2 = (bf16_t*)d->C2; q.C2lo = (bf16_t*)d->C2lo; q.ldc2 = d->ldc2; }
+        q.skew = nt_skew((long long)q.tiles_m * q.tiles_n);
+        const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;
+        dim3 g2(q.tiles_m * q.tiles_n, 1), b2(512);
+        if (d->c_is_bf16) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 1, 4, 4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            hipLaunchKernelGGL((gemm_nt_256_kernel<false, 1, 4, 4, 1, true>), g2, b2, l2, stream, q);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 0, 4, 4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+            hipLaunchKernelGGL((gemm_nt_256_kernel<false, 0, 4, 4, 1, true>), g2, b2, l2, stream, q);
+        }
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
     }
     if (d->K % 8 || d->lda % 8 || d->ldb % 8) return AMDNUWA_ERR_ARG;
     if ((d->Alo == nullptr) != (d->Blo == nullptr)) return AMDNUWA_ERR_ARG;

@@ -246,6 +246,77 @@ def _gemm_nt_f16(A, B, *, bias, alpha, shift, N, K):
     return BF(hi, None, f16)
 
 
+_FF_F16 = os.environ.get('AMDNUWA_F16_FF', '1') != '0'
+
+
+def set_ff_f16(on):
+    """'bf16x3-fwd' only: run the FeedForward GEMMs of the forward on single fp16 MFMAs (default) or, when off, as 3-MFMA bf16 hi + lo
+    products like the other projections (A/B switch; the full-depth logits stay within 1e-3 either way)"""
+    global _FF_F16
+    _FF_F16 = bool(on)
+
+
+def ff_f16():
+    return _FF_F16 and mixed()
+
+
+def _f16ops_desc(A16, B16, M, N, Kd):
+    d = GemmDesc()
+    d.A, d.lda, d.B, d.ldb = _p(A16), _ld(A16), _p(B16), _ld(B16)
+    d.alpha, d.beta = 1.0, 0.0
+    d.M, d.N, d.K, d.batch, d.ab_f16 = M, N, Kd, 1, 1
+    return d
+
+
+def gemm_nt_f16ops_ok(M, N, Kd, *, out_bf16, gate=False):
+    """will amdnuwa_gemm_nt take this product with fp16 operands (the 256x256 ring at training sizes)?"""
+    d = GemmDesc()
+    one = ctypes_dummy()
+    d.A, d.B, d.C = one, one, one
+    d.lda, d.ldb, d.ldc = Kd, Kd, N
+    d.c_is_bf16 = 1 if out_bf16 else 0
+    if gate:
+        d.C2, d.ldc2 = one, N // 2
+    d.M, d.N, d.K, d.batch, d.ab_f16 = M, N, Kd, 1, 1
+    return bool(_lib.lib().amdnuwa_gemm_nt_f16ops_supported(C.byref(d)))
+
+
+def ctypes_dummy():
+    return 16          # any non-null, 16-byte aligned address: the query never dereferences
+
+
+def gemm_nt_f16ops(A16, B16, *, out_bf16=False, gate=False):
+    """fp16-operand product on the fp16 MFMA.  A16 [M, K], B16 [N, K] fp16 tensors.
+    out_bf16=False -> fp32 [M, N].  out_bf16=True -> u bf16 [M, N]; with gate=True also (gg16 fp16 [M, N/2], gg bf16 [M, N/2]) =
+    a * gelu(gate) computed on the fp32 accumulators (u in the interleaved-by-8 layout)."""
+    L = _lib.lib()
+    M, Kd = A16.shape
+    N = B16.shape[0]
+    dev = A16.device
+    d = _f16ops_desc(A16, B16, M, N, Kd)
+    gg16 = ggb = None
+    if out_bf16:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        d.C, d.ldc, d.c_is_bf16 = _p(out), N, 1
+        if gate:
+            gg16 = torch.empty((M, N // 2), dtype=torch.float16, device=dev)
+            ggb = torch.empty((M, N // 2), dtype=torch.bfloat16, device=dev)
+            d.C2, d.C2lo, d.ldc2 = _p(gg16), _p(ggb), N // 2
+    else:
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+        d.C, d.ldc, d.c_is_bf16 = _p(out), N, 0
+    st = _stream()
+    if _TIMER['on']:
+        _TIMER['flops'] += 2.0 * M * N * Kd
+        _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * M * N * Kd
+        _TIMER['bytes'] += 2.0 * (M + N) * Kd + float(M) * N * (2 if out_bf16 else 4) + (2.0 * M * N if gate else 0.)
+        L.amdnuwa_timer_begin(st)
+    check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(fp16 operands)')
+    if _TIMER['on']:
+        L.amdnuwa_timer_end(st)
+    return (out, gg16, ggb) if gate else out
+
+
 def gemm_nt_geglu_bwd(dy, w2T, u, FP):
     """FF backward through the gate: dgg = dy @ w2T^T [M, FP] and du = (dgg * gelu(gate) | dgg * a * gelu'(gate)) in u's interleaved
     layout.  On the 256x256 ring the gate runs in the GEMM epilogue and dgg never exists in memory; otherwise GEMM + gate kernel."""
@@ -310,7 +381,7 @@ def gemm_tn_batched(desc, device):
 # row kernels
 # ------------------------------------------------------------------------------------------------
 
-LN_X_BF16, LN_DY_BF16 = 16, 32       # == AMDNUWA_LN_X_BF16 / AMDNUWA_LN_DY_BF16
+LN_X_BF16, LN_DY_BF16, LN_LO_F16 = 16, 32, 64       # == AMDNUWA_LN_X_BF16 / AMDNUWA_LN_DY_BF16 / AMDNUWA_LN_LO_F16
 
 
 def _f32_or_bf(t):
@@ -321,20 +392,26 @@ def _f32_or_bf(t):
     return _p(t), False, t.shape, t.device
 
 
-def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5, shift=None):
+def empty_bf_f16(shape, device):
+    """BF(hi = bf16 copy, None, f16 = fp16 copy)"""
+    return BF(torch.empty(shape, dtype=torch.bfloat16, device=device), None, torch.empty(shape, dtype=torch.float16, device=device))
+
+
+def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5, shift=None, f16=False):
     """x fp32 [R, D] contiguous (or a hi-only BF pair).  resid None -> (BF out, mean, rstd, inv_amax);
-    else (fp32 out = resid + LN(x), mean, rstd)"""
+    else (fp32 out = resid + LN(x), mean, rstd).  f16: out = BF(hi, None, f16) (bf16 copy + fp16 copy)"""
     L = _lib.lib()
     xp, xbf, (R, D), dev = _f32_or_bf(x)
     flag = LN_X_BF16 if xbf else 0
     mean = torch.empty(R, dtype=torch.float32, device=dev)
     rstd = torch.empty(R, dtype=torch.float32, device=dev)
     if resid is None:
-        out = empty_bf((R, D), dev)
+        out = empty_bf_f16((R, D), dev) if f16 else empty_bf((R, D), dev)
+        second = out.f16 if f16 else out.lo
         ia = torch.empty(R, dtype=torch.float32, device=dev) if stable else None
         sn, sf = (int(shift[0]), int(shift[1])) if shift is not None else (0, 0)      # out = shift(LN(x)) (ShiftVideoTokens)
-        check(L.amdnuwa_ln_fwd(xp, None, _p(w), _p(b), _p(out.hi), _p(out.lo), None, _p(mean), _p(rstd), _p(ia),
-                               R, D, 0 | flag, 1 if stable else 0, eps, sn, sf, _stream()), 'amdnuwa_ln_fwd')
+        check(L.amdnuwa_ln_fwd(xp, None, _p(w), _p(b), _p(out.hi), _p(second), None, _p(mean), _p(rstd), _p(ia),
+                               R, D, 0 | flag | (LN_LO_F16 if f16 else 0), 1 if stable else 0, eps, sn, sf, _stream()), 'amdnuwa_ln_fwd')
         return out, mean, rstd, ia
     out = torch.empty_like(resid)
     check(L.amdnuwa_ln_fwd(xp, _p(resid), _p(w), _p(b), None, None, _p(out), _p(mean), _p(rstd), None,
@@ -342,17 +419,18 @@ def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5, shift=None):
     return out, mean, rstd
 
 
-def ln_post_pre_fwd(y, resid, w, b, next_w, next_b, *, eps=1e-5, next_shift=None):
+def ln_post_pre_fwd(y, resid, w, b, next_w, next_b, *, eps=1e-5, next_shift=None, next_f16=False):
     """post-norm + residual of one block and the pre-norm (+ token shift) of the next in one pass over the stream:
     returns (out fp32 = resid + LN(y; w, b), mean, rstd, h BF = shift(LN(out; next_w, next_b)), next_mean, next_rstd)"""
     L = _lib.lib()
     yp, ybf, (R, D), dev = _f32_or_bf(y)
     mean, rstd, mean2, rstd2 = (torch.empty(R, dtype=torch.float32, device=dev) for _ in range(4))
     out = torch.empty_like(resid)
-    h = empty_bf((R, D), dev)
+    h = empty_bf_f16((R, D), dev) if next_f16 else empty_bf((R, D), dev)
     sn, sf = (int(next_shift[0]), int(next_shift[1])) if next_shift is not None else (0, 0)
     check(L.amdnuwa_ln_post_pre_fwd(yp, _p(resid), _p(w), _p(b), _p(out), _p(mean), _p(rstd), _p(next_w), _p(next_b),
-                                    _p(h.hi), _p(h.lo), _p(mean2), _p(rstd2), R, D, LN_X_BF16 if ybf else 0, eps, sn, sf,
+                                    _p(h.hi), _p(h.f16 if next_f16 else h.lo), _p(mean2), _p(rstd2), R, D,
+                                    (LN_X_BF16 if ybf else 0) | (LN_LO_F16 if next_f16 else 0), eps, sn, sf,
                                     _stream()), 'amdnuwa_ln_post_pre_fwd')
     return out, mean, rstd, h, mean2, rstd2
 

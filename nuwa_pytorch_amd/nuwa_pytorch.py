@@ -197,7 +197,9 @@ class SandwichNorm(nn.Module):
             hin, nxt, nxt_fmap, hout = chain
             meta['handoff_in'] = hin
             if nxt is not None and not (nxt_fmap is not None and D % 32):
-                meta['next_pre'] = (nxt.prenorm.weight, nxt.prenorm.bias, (n, nxt_fmap) if nxt_fmap is not None else None)
+                nxt_fn = nxt.fn.fn if isinstance(nxt.fn, (ShiftVideoTokens,)) else nxt.fn
+                nxt_ffi = nxt_fn.net[3].weight.shape[1] if isinstance(nxt_fn, FeedForward) else None     # FeedForward next: its inner width
+                meta['next_pre'] = (nxt.prenorm.weight, nxt.prenorm.bias, (n, nxt_fmap) if nxt_fmap is not None else None, nxt_ffi)
                 meta['handoff_out'] = hout
         return ops.SandwichBlockFn.apply(x, resid, context if isinstance(inner, (Attention, SparseCross2DNA)) else None, meta,
                                          self.prenorm.weight, self.prenorm.bias, self.postnorm.weight,

@@ -250,12 +250,33 @@ class FFInner:
             K.cast_pad(w2.detach(), w2p, Cp=FP)
             w2T = K.zeros_bf((FP, D), dev)
             K.transpose_cast(w2.detach(), w2T)
-            return dict(w1=w1p, w1T=w1T, w2=w2p, w2T=w2T, FP=FP, FFI=FFI)
+            out = dict(w1=w1p, w1T=w1T, w2=w2p, w2T=w2T, FP=FP, FFI=FFI)
+            if K.mixed():                       # fp16 copies for the fp16-operand forward GEMMs of 'bf16x3-fwd'
+                out['w1_16'] = w1il.to(torch.float16).contiguous()
+                w2pad = torch.zeros((D, FP), dtype=torch.float32, device=dev)
+                w2pad[:, :FFI] = w2.detach()
+                out['w2_16'] = w2pad.to(torch.float16)
+            return out
         return cache.get('ff', (w1, w2), build)
+
+    @staticmethod
+    def f16_ok(R, D, FP):
+        """the fp16-operand forward applies when 'bf16x3-fwd' wants it and both products run on the 256x256 ring"""
+        return K.ff_f16() and K.gemm_nt_f16ops_ok(R, 2 * FP, D, out_bf16=True, gate=True) and K.gemm_nt_f16ops_ok(R, D, FP, out_bf16=False)
 
     @staticmethod
     def fwd(h, p, meta):
         W = FFInner.weights(meta['cache'], p)
+        R, D = h.hi.shape
+        if meta.get('shift') is None and 'w1_16' in W and FFInner.f16_ok(R, D, W['FP']):
+            # 'bf16x3-fwd': both FeedForward products on single fp16 MFMAs (h arrives with an fp16 copy from the LayerNorm store);
+            # u and the gate output also leave as bf16 copies for the bf16 backward
+            h16 = h.f16 if h.f16 is not None else K.hilo_to_f16(h)
+            u, gg16, ggb = K.gemm_nt_f16ops(h16, W['w1_16'], out_bf16=True, gate=True)
+            y = K.gemm_nt_f16ops(gg16, W['w2_16'])
+            return y, (K.BF(h.hi, None), K.BF(u, None), K.BF(ggb, None))
+        if h.lo is None and h.f16 is not None:
+            raise RuntimeError('FeedForward received an fp16-copy activation but cannot run the fp16-operand path')
         gg = K.empty_bf((h.hi.shape[0], W['FP']), h.hi.device)
         u = K.gemm_nt(h, W['w1'], out_bf16=True, shift=meta.get('shift'), geglu_out=gg)   # u (interleaved layout) and a * gelu(gate)
         y = K.gemm_nt(gg, W['w2'], out_bf16=_fast())
@@ -461,19 +482,21 @@ class SandwichBlockFn(Function):
         # block's h = shift(LN(x)) while the new stream row was in its registers, and this block does the same for the next
         hin, nxt, hout = meta.pop('handoff_in', None), meta.pop('next_pre', None), meta.pop('handoff_out', None)
         ctx.prev_ctx = None
+        want16 = meta['kind'] == 'ff' and FFInner.f16_ok(B * n, D, _ru(p[1].shape[1], 32))      # h as a bf16 + fp16 copy pair
         if hin is not None and hin.get('ptr') == x.data_ptr() and hin.get('ver') == x._version and hin.get('shift') == sh \
                 and resid is None and tuple(hin['h'].hi.shape) == (B * n, D):
             h, m1, r1 = hin['h'], hin['m1'], hin['r1']
             ctx.prev_ctx = hin.get('ctx')          # the backward chains the two LayerNorm backwards of this boundary too
         else:
-            h, m1, r1, _ = K.ln_fwd(x2, pre_w.detach(), pre_b.detach(), shift=sh)
+            h, m1, r1, _ = K.ln_fwd(x2, pre_w.detach(), pre_b.detach(), shift=sh, f16=want16)
         ctx.shift = sh
         if sh is not None:
             meta['shift'] = None
         y, saved = inner.fwd(h, p, meta)
         if nxt is not None and hout is not None:
+            nxt16 = len(nxt) > 3 and nxt[3] is not None and FFInner.f16_ok(B * n, D, _ru(nxt[3], 32))   # the next block is a FeedForward on the fp16 path
             xo, m2, r2, hn, mn, rn = K.ln_post_pre_fwd(y, r2_, post_w.detach(), post_b.detach(), nxt[0].detach(),
-                                                       nxt[1].detach(), next_shift=nxt[2])
+                                                       nxt[1].detach(), next_shift=nxt[2], next_f16=nxt16)
             hout.update(h=hn, m1=mn, r1=rn, ptr=xo.data_ptr(), ver=xo._version, shift=nxt[2], ctx=ctx if CHAIN_BWD else None)
         else:
             xo, m2, r2 = K.ln_fwd(y, post_w.detach(), post_b.detach(), resid=r2_)

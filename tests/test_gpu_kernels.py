@@ -714,6 +714,34 @@ def test_cross_attention_fwd_f16_core(K, O, B, n, T):
     report(f'xattn_fwd_f16_vs_bf16[{B},{n},{T}]', bf_value(o), o2.hi.float(), 3e-2)
 
 
+def test_gemm_nt_fp16_operands_and_ln_fp16_copy(K):
+    """the FeedForward forward of 'bf16x3-fwd': LayerNorm stores a bf16 + fp16 copy pair, FF1 runs on the fp16 MFMA with the gate in its
+    epilogue (u bf16 for the backward, gate output as fp16 + bf16 copies), FF2 on the fp16 MFMA to fp32 -- against fp64 on the same
+    fp16 operand values"""
+    torch.manual_seed(4)
+    R, D, FP = 16384, 512, 1376
+    x = torch.randn(R, D, device=DEV) * 1.5 + 0.2
+    w, b = torch.randn(D, device=DEV), torch.randn(D, device=DEV)
+    h, m, r, _ = K.ln_fwd(x, w, b, f16=True)
+    h2, _, _, _ = K.ln_fwd(x, w, b)
+    assert h.lo is None and h.f16.dtype == torch.float16 and torch.equal(h.hi, h2.hi)
+    ref_h = torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double())
+    report('ln_fwd.f16_copy', h.f16.float(), ref_h.float(), 2 ** -11)
+    w1 = (torch.randn(2 * FP, D, device=DEV) * 0.2).half()
+    w2 = (torch.randn(D, FP, device=DEV) * 0.2).half()
+    assert K.gemm_nt_f16ops_ok(R, 2 * FP, D, out_bf16=True, gate=True) and K.gemm_nt_f16ops_ok(R, D, FP, out_bf16=False)
+    u, gg16, ggb = K.gemm_nt_f16ops(h.f16, w1, out_bf16=True, gate=True)
+    u_ref = h.f16.double() @ w1.double().t()
+    report('gemm_f16ops.u', u.float(), u_ref.float(), 2 ** -8)
+    ud = K.geglu_deinterleave(u_ref, FP, dim=1)
+    g_ref = (ud[:, :FP] * F.gelu(ud[:, FP:])).float()
+    report('gemm_f16ops.gate_f16', gg16.float(), g_ref, 2 ** -10)
+    report('gemm_f16ops.gate_bf16', ggb.float(), g_ref, 2 ** -8)
+    y = K.gemm_nt_f16ops(gg16, w2)
+    report('gemm_f16ops.y_f32', y, (gg16.double() @ w2.double().t()).float(), 2e-6)
+    assert not K.gemm_nt_f16ops_ok(300, 96, 64, out_bf16=False)          # small shapes stay on the hi + lo kernels
+
+
 def test_gemm_nt_f16_second_copy(K):
     """projection GEMM of the 'bf16x3-fwd' mode: hi + lo operands, output = bf16 copy + fp16 copy of the SAME fp32 accumulator (on the
     256x256 ring in the epilogue; elsewhere product + conversion pass)"""

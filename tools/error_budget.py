@@ -184,6 +184,10 @@ POLICIES = {
     'x3_gemm_f16_cores': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16'),
     'x3_gemm_f16_cores_o': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', s3_o='f16', x_o='f16'),
     'x3_gemm_bf16_cores': Policy('f32', s3_a='bf16', s3_p='bf16', x_a='bf16', x_p='bf16'),
+    # ... and additionally the FeedForward block on single fp16 MFMAs (h, weights, gate output in fp16; its output to the post-norm fp32)
+    'f16_cores_f16_ff': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', ff_h='f16', ff_w='f16', ff_o='f16'),
+    'f16_cores_f16_ff_qkv': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', ff_h='f16', ff_w='f16', ff_o='f16', s3_h='f16', s3_w='f16'),
+    'f16_ff_only': Policy('f32', ff_h='f16', ff_w='f16', ff_o='f16'),
     # bf16 with the final GEMM exact / the y stores in fp32
     'bf16_y32': Policy('bf16', all_y='f32'),
     'bf16_lg_exact': Policy('bf16', lg_all='f32'),
