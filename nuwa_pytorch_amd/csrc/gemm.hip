@@ -1714,15 +1714,16 @@ extern "C" int amdnuwa_linear_ce(const uint16_t* h, int ldh, const uint16_t* w, 
 
 extern "C" int amdnuwa_gemm_nt_fused(const amdnuwa_gemm_desc* d) { return d && d->C2 && nt_geglu_fusable(d) ? 1 : 0; }
 
-// fp16 operands (d->ab_f16): the 256x256 ring only -- the FeedForward GEMMs of the 'bf16x3-fwd' forward at training sizes
+// fp16 operands (d->ab_f16): the 256x256 ring only -- the FeedForward GEMMs of the 'bf16x3-fwd' forward
 extern "C" int amdnuwa_gemm_nt_f16ops_supported(const amdnuwa_gemm_desc* d) {
     if (!d || !d->A || !d->B || !d->C || d->Alo || d->Blo || d->shift_ntok > 0 || d->batch > 1 || d->geglu_u || d->Clo) return 0;
     if (d->K % 32 || d->lda % 8 || d->ldb % 8 || d->M <= 4 * ROWS_MR) return 0;
     if (d->c_is_bf16 && (d->N % 16 || d->ldc % 8 || (d->C2 && d->ldc2 % 8))) return 0;
     if (!d->c_is_bf16 && (d->C2 || d->N % 4 || d->ldc % 4)) return 0;
+    // (no tile-count threshold: the arithmetic of a FeedForward block must not depend on the batch size -- a one-sample parity check
+    //  has to run the same fp16 products as the training batch, so small M takes the 256x256 ring too)
     const int v = g_amdnuwa_tuning[0];
-    if (v != 0 && v != 7) return 0;
-    return (v == 7 || (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 512) ? 1 : 0;
+    return (v == 0 || v == 7) ? 1 : 0;
 }
 
 // does this product run on the bf16x3 256x256 ring (the only kernel that writes the fp16 second copy)?

@@ -719,7 +719,7 @@ def test_gemm_nt_fp16_operands_and_ln_fp16_copy(K):
     epilogue (u bf16 for the backward, gate output as fp16 + bf16 copies), FF2 on the fp16 MFMA to fp32 -- against fp64 on the same
     fp16 operand values"""
     torch.manual_seed(4)
-    R, D, FP = 16384, 512, 1376
+    R, D, FP = 16384 + 40, 512, 1376
     x = torch.randn(R, D, device=DEV) * 1.5 + 0.2
     w, b = torch.randn(D, device=DEV), torch.randn(D, device=DEV)
     h, m, r, _ = K.ln_fwd(x, w, b, f16=True)
@@ -739,7 +739,7 @@ def test_gemm_nt_fp16_operands_and_ln_fp16_copy(K):
     report('gemm_f16ops.gate_bf16', ggb.float(), g_ref, 2 ** -8)
     y = K.gemm_nt_f16ops(gg16, w2)
     report('gemm_f16ops.y_f32', y, (gg16.double() @ w2.double().t()).float(), 2e-6)
-    assert not K.gemm_nt_f16ops_ok(300, 96, 64, out_bf16=False)          # small shapes stay on the hi + lo kernels
+    assert not K.gemm_nt_f16ops_ok(20, 96, 64, out_bf16=False)           # the few-row decode shapes stay on the hi + lo kernels
 
 
 def test_gemm_nt_f16_second_copy(K):
