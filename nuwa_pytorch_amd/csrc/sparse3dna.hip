@@ -814,13 +814,22 @@ constexpr int S3M_PLANES = 64;   // kf * kh limit (plane list in LDS)
 
 // per-workgroup state of one query row, shared by the MFMA forward and backward kernels
 struct RowM {
-    int nplanes, J, lane, wave, c, g4, iq;      // lane = (c = MFMA column / query, g4 = k-slice / row quad)
+    int nplanes, J, TS, lane, wave, c, g4, iq;  // lane = (c = MFMA column / query, g4 = k-slice / row quad); TS = table stride per query
     bool qok;                                   // query c of this row exists (token iq < ntok)
     size_t tok0;                                // first token row of the sample
     int tsel[4];                                // tap index linking query c to key 4*g4 + r (the same in every plane), or -1
     const int *pslot, *ptok;                    // valid planes: first key slot j, token row of key 0
 };
 constexpr int S3M_NH = 8, S3M_DH = 64, S3M_W = 16;
+// The score tables SP / DP of the MFMA kernels: entry (query w, slot j, head h) at word  w * TS + j * NH + h  with the per-query
+// stride TS = J * NH + 1.  The band view of the sweeps (mfma_band_scores*, mfma_band_apply) walks the QUERY index across the 16
+// lanes of an MFMA column group at fixed (slot, head); with the dense stride J * NH (= 368 words at J = 46: 16 mod 32) those 16
+// lanes fell on two banks -- 8-way conflicts on every table access of the score and apply passes, the LDS pipe of a CU busy with
+// conflict cycles for most of the backward (r02 PMC: SQ_LDS_BANK_CONFLICT = 67 % of the busy cycles of s3_bwd_q_mfma).  The odd
+// stride spreads the 16 queries over 16 banks.
+__device__ __forceinline__ int s3m_ts(int J) { return J * S3M_NH + 1; }
+// flat item = w * J + j  ->  word index of its 8 heads
+__device__ __forceinline__ int s3m_item(int item, int J) { return item * S3M_NH + item / J; }
 
 // fills pslot / ptok (thread 0) and returns after a barrier; `cnt` = &pslot[S3M_PLANES]
 __device__ __forceinline__ void rowm_planes(const S3Args& a, int f, int y, int* pslot, int* ptok) {
@@ -839,6 +848,7 @@ __device__ __forceinline__ RowM rowm_init(const S3Args& a, int b, int ry, const 
     RowM r;
     r.nplanes = pslot[S3M_PLANES];
     r.J = a.kf * a.kh * a.kw + 1;
+    r.TS = s3m_ts(r.J);
     r.lane = threadIdx.x & 63; r.wave = threadIdx.x >> 6; r.c = r.lane & 15; r.g4 = r.lane >> 4;
     r.tok0 = (size_t)b * a.ntok;
     r.iq = 1 + ry * S3M_W + r.c;
@@ -866,7 +876,7 @@ __device__ __forceinline__ void mfma_band_scores(const S3Args& a, const RowM& r,
     const bf16_t* qrow = frag + (r.tok0 + r.iq) * ldf + h * DH + r.g4 * 8;
     const bf16x8 qf0 = ldg8(qrow, r.qok), qf1 = ldg8(qrow + 32, r.qok);
     const bf16_t* kbase = rows + r.tok0 * ldr + h * DH + r.g4 * 8;                // + token * ld
-    const int spb = (r.c * r.J) * NH + h;                                        // index of (query c, slot 0, head h)
+    const int spb = r.c * r.TS + h;                                              // index of (query c, slot 0, head h)
     int sidx[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
@@ -917,7 +927,7 @@ __device__ __forceinline__ void mfma_band_scores_staged(const S3Args& a, const R
     const bf16x8 qf0 = ldg8(qrow, r.qok), qf1 = ldg8(qrow + 32, r.qok);
     const int gc = r.lane & 7, r8 = r.lane >> 3;
     const bf16_t* kbase = rows + r.tok0 * ldr + h * DH + gc * 8;                  // + token * ld
-    const int spb = (r.c * r.J) * NH + h;
+    const int spb = r.c * r.TS + h;
     int sidx[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
@@ -961,7 +971,7 @@ template <bool F16 = false>
 __device__ __forceinline__ void mfma_band_apply(const S3Args& a, const RowM& r, const bf16_t* rows, int ldr, int g, const float* TAB,
                                                 char* tile, f32x4 (&O)[4]) {
     constexpr int NH = S3M_NH, DH = S3M_DH;
-    const int spb = (r.c * r.J) * NH + g;
+    const int spb = r.c * r.TS + g;
     {   // <bos> slot
         const float p0 = r.qok ? TAB[spb] : 0.f;
         const bf16_t* vb = rows + r.tok0 * ldr + g * DH + 4 * r.g4;
@@ -1028,12 +1038,13 @@ __device__ __forceinline__ void mfma_band_apply(const S3Args& a, const RowM& r, 
 __device__ __forceinline__ void rowm_softmax(float* TAB, int J) {
     constexpr int NH = S3M_NH;
     const int t = threadIdx.x, cc = t & 3, wh = t >> 2, h = wh % NH, w = wh / NH;
+    TAB += w * s3m_ts(J) + h;                                                    // (query w, slot 0, head h); slot j at + j * NH
     if (J <= 48) {
         // the thread's <= 12 slots in registers: one batch of LDS reads and one of writes instead of three dependent
         // read (-modify-write) passes of 12 round trips each; same operations in the same order -> bit-identical
         float v[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) { const int j = cc + 4 * k; v[k] = j < J ? TAB[(w * J + j) * NH + h] : NEG_MAX; }
+        for (int k = 0; k < 12; ++k) { const int j = cc + 4 * k; v[k] = j < J ? TAB[j * NH] : NEG_MAX; }
         float m = NEG_MAX;
 #pragma unroll
         for (int k = 0; k < 12; ++k) m = fmaxf(m, v[k]);
@@ -1048,22 +1059,22 @@ __device__ __forceinline__ void rowm_softmax(float* TAB, int J) {
         sum = quad_sum(sum);
         const float inv = 1.f / sum;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) { const int j = cc + 4 * k; if (j < J) TAB[(w * J + j) * NH + h] = v[k] * inv; }
+        for (int k = 0; k < 12; ++k) { const int j = cc + 4 * k; if (j < J) TAB[j * NH] = v[k] * inv; }
         return;
     }
     float m = NEG_MAX;
-    for (int j = cc; j < J; j += 4) m = fmaxf(m, TAB[(w * J + j) * NH + h]);
+    for (int j = cc; j < J; j += 4) m = fmaxf(m, TAB[j * NH]);
     m = quad_max(m);
     float sum = 0.f;
     for (int j = cc; j < J; j += 4) {
-        const int idx = (w * J + j) * NH + h;
+        const int idx = j * NH;
         const float e = __expf(TAB[idx] - m);
         TAB[idx] = e;
         sum += e;
     }
     sum = quad_sum(sum);
     const float inv = 1.f / sum;
-    for (int j = cc; j < J; j += 4) TAB[(w * J + j) * NH + h] *= inv;
+    for (int j = cc; j < J; j += 4) TAB[j * NH] *= inv;
 }
 
 // F16: a.q / a.k / a.v hold fp16 values, the score and apply products run on the fp16 MFMA, and o leaves as a bf16 hi + lo pair
@@ -1073,8 +1084,8 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int J = a.kf * a.kh * a.kw + 1;
-    float* SP = reinterpret_cast<float*>(smem);                                  // [W][J][NH]
-    char* vt_base = smem + (size_t)W * J * NH * sizeof(float);                   // 8 wave-private [32][64] bf16 tiles
+    float* SP = reinterpret_cast<float*>(smem);                                  // [W][J * NH + 1]  (s3m_ts)
+    char* vt_base = smem + (size_t)W * s3m_ts(J) * sizeof(float);                // 8 wave-private [32][64] bf16 tiles
     __shared__ float wsh[64];
     __shared__ int pslot[S3M_PLANES + 1], ptok[S3M_PLANES + 1];
     const int t = threadIdx.x;
@@ -1094,7 +1105,7 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
         }
     }
     if (ry * W + 1 >= a.ntok) return;                                            // whole row beyond the sequence (uniform)
-    for (int e = t; e < W * J * NH; e += blockDim.x) SP[e] = NEG_MAX;
+    for (int e = t; e < W * s3m_ts(J); e += blockDim.x) SP[e] = NEG_MAX;
     rowm_planes(a, f, y, pslot, ptok);
     const RowM r = rowm_init(a, b, ry, pslot, ptok);
     if (!(a.dbg & 1)) {
@@ -1110,8 +1121,9 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
     for (int k = 0; k < 64; ++k) wr[k] = wsh[k];
     for (int item = t; item < W * J && !(a.dbg & 2); item += blockDim.x) {
         float pv[8], out[8];
+        const int ib = s3m_item(item, J);
 #pragma unroll
-        for (int hh = 0; hh < 8; ++hh) pv[hh] = SP[item * NH + hh];
+        for (int hh = 0; hh < 8; ++hh) pv[hh] = SP[ib + hh];
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             float s = 0.f;
@@ -1120,7 +1132,7 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
             out[g] = s;
         }
 #pragma unroll
-        for (int g = 0; g < 8; ++g) SP[item * NH + g] = out[g];
+        for (int g = 0; g < 8; ++g) SP[ib + g] = out[g];
     }
     __syncthreads();
     if (!(a.dbg & 4)) {
@@ -1148,7 +1160,7 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
 __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W, inner = NH * DH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int J = a.kf * a.kh * a.kw + 1, nsp = W * J * NH;
+    const int J = a.kf * a.kh * a.kw + 1, TS = s3m_ts(J), nsp = W * TS;
     const size_t r1 = (size_t)nsp * 4 > 8 * 4096 ? (size_t)nsp * 4 : 8 * 4096;
     float* SP = reinterpret_cast<float*>(smem);
     float* DP = reinterpret_cast<float*>(smem + r1);
@@ -1190,7 +1202,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
         const int iq = 1 + ry * W + wq;
         float pv[8];
 #pragma unroll
-        for (int hh = 0; hh < 8; ++hh) pv[hh] = SP[item * NH + hh];
+        for (int hh = 0; hh < 8; ++hh) pv[hh] = SP[item * NH + wq + hh];
         float* dst = a.pm + (((size_t)b * nq + (iq - 1)) * J + j) * NH;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
@@ -1212,7 +1224,8 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int it = item + 8 * u, itc = it < W * J ? it : grp;
-                dv8[u] = DP[itc * NH + g]; pv8[u] = SP[itc * NH + hh];
+                const int ib = s3m_item(itc, J);
+                dv8[u] = DP[ib + g]; pv8[u] = SP[ib + hh];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += item + 8 * u < W * J ? dv8[u] * pv8[u] : 0.f;
@@ -1229,8 +1242,9 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     // dP[h] = sum_g Wth[g][h] dP'[g]   (in place, item-local)
     for (int item = t; item < W * J; item += blockDim.x) {
         float dv_[8], out[8];
+        const int ib = s3m_item(item, J);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) dv_[g] = DP[item * NH + g];
+        for (int g = 0; g < 8; ++g) dv_[g] = DP[ib + g];
 #pragma unroll
         for (int hh = 0; hh < 8; ++hh) {
             float s = 0.f;
@@ -1239,7 +1253,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
             out[hh] = s;
         }
 #pragma unroll
-        for (int hh = 0; hh < 8; ++hh) DP[item * NH + hh] = out[hh];
+        for (int hh = 0; hh < 8; ++hh) DP[ib + hh] = out[hh];
     }
     __syncthreads();
     // ds = P * (dP - sum_j P dP)  -> DP and the global workspace
@@ -1250,7 +1264,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
             float pv[12], dv[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
-                const int j = cc + 4 * k, idx = (w * J + (j < J ? j : cc)) * NH + h;
+                const int j = cc + 4 * k, idx = w * TS + (j < J ? j : cc) * NH + h;
                 pv[k] = SP[idx]; dv[k] = DP[idx];
             }
             float d = 0.f;
@@ -1261,7 +1275,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
             for (int k = 0; k < 12; ++k) {
                 const int j = cc + 4 * k;
                 if (j < J) {
-                    const int idx = (w * J + j) * NH + h;
+                    const int idx = w * TS + j * NH + h;
                     const float dsv = pv[k] * (dv[k] - d);
                     DP[idx] = dsv;
                     if (i < a.ntok) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
@@ -1269,10 +1283,10 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
             }
         } else {
         float d = 0.f;
-        for (int j = cc; j < J; j += 4) d += SP[(w * J + j) * NH + h] * DP[(w * J + j) * NH + h];
+        for (int j = cc; j < J; j += 4) d += SP[w * TS + j * NH + h] * DP[w * TS + j * NH + h];
         d = quad_sum(d);
         for (int j = cc; j < J; j += 4) {
-            const int idx = (w * J + j) * NH + h;
+            const int idx = w * TS + j * NH + h;
             const float dsv = SP[idx] * (DP[idx] - d);
             DP[idx] = dsv;
             if (i < a.ntok) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
@@ -1309,7 +1323,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             const bool in = 1 + ry * W + w < a.ntok;
-            sk += in ? DP[(w * J) * NH + h] * qv[w] : 0.f;
+            sk += in ? DP[w * TS + h] * qv[w] : 0.f;
             sv += in ? PM0[w * NH + h] * dv_[w] : 0.f;
         }
         pk0[e] = a.scale * sk;
@@ -1490,7 +1504,7 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
     if (!lo_mode && !g->noncausal && g_amdnuwa_tuning[3] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 && g->kw <= S3M_KW &&
         g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && ldo % 4 == 0) {
         a.dbg = g_amdnuwa_tuning[9];
-        const size_t lm = (size_t)16 * J * 8 * sizeof(float) + 8 * 4096;
+        const size_t lm = (size_t)16 * (J * 8 + 1) * sizeof(float) + 8 * 4096;
         (void)hipFuncSetAttribute((const void*)s3_fwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
         hipLaunchKernelGGL(s3_fwd_mfma_kernel<false>, grid, dim3(512), lm, stream, a);
         LAUNCH_CHECK();
@@ -1522,7 +1536,7 @@ extern "C" int amdnuwa_sparse3dna_fwd_f16(const amdnuwa_s3_geom* g, const uint16
     a.o = o; a.ol = o_lo; a.ldo = ldo; a.wth = w_th;
     self_kv(a);
     const int J = g->kf * g->kh * g->kw + 1;
-    const size_t lm = (size_t)16 * J * 8 * sizeof(float) + 8 * 4096;
+    const size_t lm = (size_t)16 * (J * 8 + 1) * sizeof(float) + 8 * 4096;
     (void)hipFuncSetAttribute((const void*)s3_fwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
     hipLaunchKernelGGL(s3_fwd_mfma_kernel<true>, dim3(g->B * g->F * g->H), dim3(512), lm, stream, a);
     LAUNCH_CHECK();
@@ -1583,7 +1597,8 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     // MFMA query-side kernel (tuning key 4: 1 = keep the dot2 kernel): bf16 operands, 16 queries per grid row, 8 heads x 64
     const bool q_mfma = !has_lo && !dO_lo && !g->noncausal && g_amdnuwa_tuning[4] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 &&
                         g->kw <= S3M_KW && g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0;
-    const size_t lds_qm = (nsp * 4 > 8 * 4096 ? nsp * 4 : 8 * 4096) + nsp * 4 + (8 * 64 + 16 * 8) * 4 + 8 * 2048;   // + the score staging tiles
+    const size_t nspm = (size_t)g->W * (J * g->heads + 1);                          // the MFMA kernels' padded tables (s3m_ts)
+    const size_t lds_qm = (nspm * 4 > 8 * 4096 ? nspm * 4 : 8 * 4096) + nspm * 4 + (8 * 64 + 16 * 8) * 4 + 8 * 2048;   // + the score staging tiles
 #define S3B(DH_, LO_)                                                                                             \
     do {                                                                                                          \
         if (q_mfma) {                                                                                             \
