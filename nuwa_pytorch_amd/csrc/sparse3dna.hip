@@ -822,14 +822,17 @@ struct RowM {
 };
 constexpr int S3M_NH = 8, S3M_DH = 64, S3M_W = 16;
 // The score tables SP / DP of the MFMA kernels: entry (query w, slot j, head h) at word  w * TS + j * NH + h  with the per-query
-// stride TS = J * NH + 1.  The band view of the sweeps (mfma_band_scores*, mfma_band_apply) walks the QUERY index across the 16
+// stride TS = J * NH + 4.  The band view of the sweeps (mfma_band_scores*, mfma_band_apply) walks the QUERY index across the 16
 // lanes of an MFMA column group at fixed (slot, head); with the dense stride J * NH (= 368 words at J = 46: 16 mod 32) those 16
 // lanes fell on two banks -- 8-way conflicts on every table access of the score and apply passes, the LDS pipe of a CU busy with
-// conflict cycles for most of the backward (r02 PMC: SQ_LDS_BANK_CONFLICT = 67 % of the busy cycles of s3_bwd_q_mfma).  The odd
-// stride spreads the 16 queries over 16 banks.
-__device__ __forceinline__ int s3m_ts(int J) { return J * S3M_NH + 1; }
-// flat item = w * J + j  ->  word index of its 8 heads
-__device__ __forceinline__ int s3m_item(int item, int J) { return item * S3M_NH + item / J; }
+// conflict cycles for most of the backward (r02 PMC: SQ_LDS_BANK_CONFLICT = 67 % of the busy cycles of s3_bwd_q_mfma).  A pad of 4
+// words (372: 20 mod 32) spreads the 16 queries over 8 banks and keeps every item's 8 heads 16-byte aligned for the item loops'
+// ds_read_b128 pairs (a pad of 1 word reached 16 banks but turned those into eight 8-way-conflicting ds_read_b32: measured slower).
+constexpr int S3M_PAD = 4;
+__device__ __forceinline__ int s3m_ts(int J) { return J * S3M_NH + S3M_PAD; }
+// flat item = w * J + j  ->  word index of its 8 heads.  rJ = 1.f / J: w = item / J as a float product (exact for item < 2^16, J <= 64;
+// an integer division by the run-time J costs ~35 instructions, and the item loops of the backward need one per item)
+__device__ __forceinline__ int s3m_item(int item, float rJ) { return item * S3M_NH + (int)(((float)item + 0.5f) * rJ) * S3M_PAD; }
 
 // fills pslot / ptok (thread 0) and returns after a barrier; `cnt` = &pslot[S3M_PLANES]
 __device__ __forceinline__ void rowm_planes(const S3Args& a, int f, int y, int* pslot, int* ptok) {
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int J = a.kf * a.kh * a.kw + 1;
-    float* SP = reinterpret_cast<float*>(smem);                                  // [W][J * NH + 1]  (s3m_ts)
+    float* SP = reinterpret_cast<float*>(smem);                                  // [W][J * NH + 4]  (s3m_ts)
     char* vt_base = smem + (size_t)W * s3m_ts(J) * sizeof(float);                // 8 wave-private [32][64] bf16 tiles
     __shared__ float wsh[64];
     __shared__ int pslot[S3M_PLANES + 1], ptok[S3M_PLANES + 1];
@@ -1121,7 +1124,7 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
     for (int k = 0; k < 64; ++k) wr[k] = wsh[k];
     for (int item = t; item < W * J && !(a.dbg & 2); item += blockDim.x) {
         float pv[8], out[8];
-        const int ib = s3m_item(item, J);
+        const int ib = s3m_item(item, 1.f / (float)J);
 #pragma unroll
         for (int hh = 0; hh < 8; ++hh) pv[hh] = SP[ib + hh];
 #pragma unroll
@@ -1161,6 +1164,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W, inner = NH * DH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int J = a.kf * a.kh * a.kw + 1, TS = s3m_ts(J), nsp = W * TS;
+    const float rJ = 1.f / (float)J;
     const size_t r1 = (size_t)nsp * 4 > 8 * 4096 ? (size_t)nsp * 4 : 8 * 4096;
     float* SP = reinterpret_cast<float*>(smem);
     float* DP = reinterpret_cast<float*>(smem + r1);
@@ -1198,11 +1202,11 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
 #pragma unroll                                     // waited for its own LDS round trip (the stores to the table may alias wsh for the compiler)
     for (int k = 0; k < 64; ++k) wr[k] = wsh[k];
     for (int item = t; item < W * J; item += blockDim.x) {
-        const int wq = item / J, j = item - wq * J;
+        const int wq = (int)(((float)item + 0.5f) * rJ), j = item - wq * J;
         const int iq = 1 + ry * W + wq;
         float pv[8];
 #pragma unroll
-        for (int hh = 0; hh < 8; ++hh) pv[hh] = SP[item * NH + wq + hh];
+        for (int hh = 0; hh < 8; ++hh) pv[hh] = SP[item * NH + wq * S3M_PAD + hh];
         float* dst = a.pm + (((size_t)b * nq + (iq - 1)) * J + j) * NH;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
@@ -1224,7 +1228,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int it = item + 8 * u, itc = it < W * J ? it : grp;
-                const int ib = s3m_item(itc, J);
+                const int ib = s3m_item(itc, rJ);
                 dv8[u] = DP[ib + g]; pv8[u] = SP[ib + hh];
             }
 #pragma unroll
@@ -1242,7 +1246,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     // dP[h] = sum_g Wth[g][h] dP'[g]   (in place, item-local)
     for (int item = t; item < W * J; item += blockDim.x) {
         float dv_[8], out[8];
-        const int ib = s3m_item(item, J);
+        const int ib = s3m_item(item, rJ);
 #pragma unroll
         for (int g = 0; g < 8; ++g) dv_[g] = DP[ib + g];
 #pragma unroll
@@ -1504,7 +1508,7 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
     if (!lo_mode && !g->noncausal && g_amdnuwa_tuning[3] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 && g->kw <= S3M_KW &&
         g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && ldo % 4 == 0) {
         a.dbg = g_amdnuwa_tuning[9];
-        const size_t lm = (size_t)16 * (J * 8 + 1) * sizeof(float) + 8 * 4096;
+        const size_t lm = (size_t)16 * (J * 8 + 4) * sizeof(float) + 8 * 4096;
         (void)hipFuncSetAttribute((const void*)s3_fwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
         hipLaunchKernelGGL(s3_fwd_mfma_kernel<false>, grid, dim3(512), lm, stream, a);
         LAUNCH_CHECK();
@@ -1536,7 +1540,7 @@ extern "C" int amdnuwa_sparse3dna_fwd_f16(const amdnuwa_s3_geom* g, const uint16
     a.o = o; a.ol = o_lo; a.ldo = ldo; a.wth = w_th;
     self_kv(a);
     const int J = g->kf * g->kh * g->kw + 1;
-    const size_t lm = (size_t)16 * (J * 8 + 1) * sizeof(float) + 8 * 4096;
+    const size_t lm = (size_t)16 * (J * 8 + 4) * sizeof(float) + 8 * 4096;
     (void)hipFuncSetAttribute((const void*)s3_fwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
     hipLaunchKernelGGL(s3_fwd_mfma_kernel<true>, dim3(g->B * g->F * g->H), dim3(512), lm, stream, a);
     LAUNCH_CHECK();
@@ -1597,7 +1601,7 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     // MFMA query-side kernel (tuning key 4: 1 = keep the dot2 kernel): bf16 operands, 16 queries per grid row, 8 heads x 64
     const bool q_mfma = !has_lo && !dO_lo && !g->noncausal && g_amdnuwa_tuning[4] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 &&
                         g->kw <= S3M_KW && g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0;
-    const size_t nspm = (size_t)g->W * (J * g->heads + 1);                          // the MFMA kernels' padded tables (s3m_ts)
+    const size_t nspm = (size_t)g->W * (J * g->heads + 4);                          // the MFMA kernels' padded tables (s3m_ts)
     const size_t lds_qm = (nspm * 4 > 8 * 4096 ? nspm * 4 : 8 * 4096) + nspm * 4 + (8 * 64 + 16 * 8) * 4 + 8 * 2048;   // + the score staging tiles
 #define S3B(DH_, LO_)                                                                                             \
     do {                                                                                                          \
