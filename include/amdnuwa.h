@@ -87,7 +87,8 @@ typedef struct {
     int c_lo_f16;
     /* NT: ab_f16 != 0: A and B hold FP16 values (Alo / Blo / Clo must be NULL) and the product runs on the fp16 MFMA.  C: fp32, or
      * bf16 with the optional GEGLU output computed on the fp32 accumulators: C2 receives its FP16 copy (the next GEMM's A operand),
-     * C2lo -- if not NULL -- its bf16 copy (the backward's operand).  The FeedForward GEMMs (reference nuwa_pytorch.py:255-286) of
+     * C2lo -- if not NULL -- its bf16 copy (the backward's operand).  Without C2, a non-NULL Clo receives the FP16 copy of the bf16
+     * output itself (q / k / v: bf16 for the backward, fp16 for the forward attention core).  The FeedForward GEMMs (reference nuwa_pytorch.py:255-286) of
      * the 'bf16x3-fwd' forward.  256x256 ring only: amdnuwa_gemm_nt_f16ops_supported() first, AMDNUWA_ERR_UNSUPPORTED otherwise. */
     int ab_f16;
 } amdnuwa_gemm_desc;

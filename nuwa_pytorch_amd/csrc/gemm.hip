@@ -712,7 +712,7 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
                 for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha + bias16[j * 4 + r];
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
             bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;
-            if (!Cl && vec8 && nb + 16 <= p.N) {
+            if ((F16 || !Cl) && vec8 && nb + 16 <= p.N) {          // (F16: Clo, when given, receives the fp16 copy of the product)
                 const uint4 ua = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
                 const uint4 ug = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
                 if (p.Uin) {
@@ -726,6 +726,10 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
                 reinterpret_cast<uint4*>(C)[0] = ua;
                 reinterpret_cast<uint4*>(C)[1] = ug;
                 if constexpr (F16) {
+                    if (Cl) {              // fp16 copy of the product itself (q / k / v for the fp16 attention core)
+                        reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2_f16(vv[0], vv[1]), pack2_f16(vv[2], vv[3]), pack2_f16(vv[4], vv[5]), pack2_f16(vv[6], vv[7]));
+                        reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2_f16(vv[8], vv[9]), pack2_f16(vv[10], vv[11]), pack2_f16(vv[12], vv[13]), pack2_f16(vv[14], vv[15]));
+                    }
                     if (p.C2) {            // gate on the fp32 accumulators; fp16 copy -> C2 (FF2's A operand), bf16 copy -> C2lo (backward)
                         float o[8];
 #pragma unroll
@@ -1716,7 +1720,8 @@ extern "C" int amdnuwa_gemm_nt_fused(const amdnuwa_gemm_desc* d) { return d && d
 
 // fp16 operands (d->ab_f16): the 256x256 ring only -- the FeedForward GEMMs of the 'bf16x3-fwd' forward
 extern "C" int amdnuwa_gemm_nt_f16ops_supported(const amdnuwa_gemm_desc* d) {
-    if (!d || !d->A || !d->B || !d->C || d->Alo || d->Blo || d->shift_ntok > 0 || d->batch > 1 || d->geglu_u || d->Clo) return 0;
+    if (!d || !d->A || !d->B || !d->C || d->Alo || d->Blo || d->shift_ntok > 0 || d->batch > 1 || d->geglu_u) return 0;
+    if (d->Clo && (!d->c_is_bf16 || d->C2)) return 0;              // Clo = fp16 copy of a bf16 output (no gate at the same time)
     if (d->K % 32 || d->lda % 8 || d->ldb % 8 || d->M <= 4 * ROWS_MR) return 0;
     if (d->c_is_bf16 && (d->N % 16 || d->ldc % 8 || (d->C2 && d->ldc2 % 8))) return 0;
     if (!d->c_is_bf16 && (d->C2 || d->N % 4 || d->ldc % 4)) return 0;
@@ -1759,7 +1764,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         if (!amdnuwa_gemm_nt_f16ops_supported(d)) return AMDNUWA_ERR_UNSUPPORTED;
         GemmArgs q{};
         q.A = (const bf16_t*)d->A; q.lda = d->lda; q.B = (const bf16_t*)d->B; q.ldb = d->ldb;
-        q.C = d->C; q.ldc = d->ldc; q.bias = d->bias; q.alpha = d->alpha;
+        q.C = d->C; q.Clo = (bf16_t*)d->Clo; q.ldc = d->ldc; q.bias = d->bias; q.alpha = d->alpha;
         q.M = d->M; q.N = d->N; q.K = d->K; q.shift_dim = d->K;
         q.tiles_m = (d->M + 255) / 256; q.tiles_n = (d->N + 255) / 256;
         q.dbg = g_amdnuwa_tuning[7];

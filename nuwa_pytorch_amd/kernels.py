@@ -285,19 +285,36 @@ def ctypes_dummy():
     return 16          # any non-null, 16-byte aligned address: the query never dereferences
 
 
-def gemm_nt_f16ops(A16, B16, *, out_bf16=False, gate=False):
+_QKV_F16 = os.environ.get('AMDNUWA_F16_QKV', '1') != '0'
+
+
+def set_qkv_f16(on):
+    """'bf16x3-fwd' only: the Sparse3DNA q / k / v projection of the forward on single fp16 MFMAs (default) or as a 3-MFMA product"""
+    global _QKV_F16
+    _QKV_F16 = bool(on)
+
+
+def qkv_f16():
+    return _QKV_F16 and cores_f16()
+
+
+def gemm_nt_f16ops(A16, B16, *, out_bf16=False, gate=False, copy_f16=False):
     """fp16-operand product on the fp16 MFMA.  A16 [M, K], B16 [N, K] fp16 tensors.
     out_bf16=False -> fp32 [M, N].  out_bf16=True -> u bf16 [M, N]; with gate=True also (gg16 fp16 [M, N/2], gg bf16 [M, N/2]) =
-    a * gelu(gate) computed on the fp32 accumulators (u in the interleaved-by-8 layout)."""
+    a * gelu(gate) computed on the fp32 accumulators (u in the interleaved-by-8 layout); with copy_f16=True -> BF(bf16 copy, None, fp16 copy)."""
     L = _lib.lib()
     M, Kd = A16.shape
     N = B16.shape[0]
     dev = A16.device
     d = _f16ops_desc(A16, B16, M, N, Kd)
-    gg16 = ggb = None
+    gg16 = ggb = c16 = None
     if out_bf16:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         d.C, d.ldc, d.c_is_bf16 = _p(out), N, 1
+        if copy_f16:
+            assert not gate
+            c16 = torch.empty((M, N), dtype=torch.float16, device=dev)
+            d.Clo = _p(c16)
         if gate:
             gg16 = torch.empty((M, N // 2), dtype=torch.float16, device=dev)
             ggb = torch.empty((M, N // 2), dtype=torch.bfloat16, device=dev)
@@ -314,6 +331,8 @@ def gemm_nt_f16ops(A16, B16, *, out_bf16=False, gate=False):
     check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(fp16 operands)')
     if _TIMER['on']:
         L.amdnuwa_timer_end(st)
+    if copy_f16:
+        return BF(out, None, c16)
     return (out, gg16, ggb) if gate else out
 
 

@@ -198,8 +198,12 @@ class SandwichNorm(nn.Module):
             meta['handoff_in'] = hin
             if nxt is not None and not (nxt_fmap is not None and D % 32):
                 nxt_fn = nxt.fn.fn if isinstance(nxt.fn, (ShiftVideoTokens,)) else nxt.fn
-                nxt_ffi = nxt_fn.net[3].weight.shape[1] if isinstance(nxt_fn, FeedForward) else None     # FeedForward next: its inner width
-                meta['next_pre'] = (nxt.prenorm.weight, nxt.prenorm.bias, (n, nxt_fmap) if nxt_fmap is not None else None, nxt_ffi)
+                nxt_kind = None                  # what the next block's first GEMM is (it may want an fp16 copy of its input: ops.SandwichBlockFn)
+                if isinstance(nxt_fn, FeedForward):
+                    nxt_kind = ('ff', nxt_fn.net[3].weight.shape[1])
+                elif isinstance(nxt_fn, Sparse3DNA) and nxt_fn.causal:
+                    nxt_kind = ('s3', nxt_fn.to_q.weight.shape[0], nxt_fn._meta(B, n, x.device)['geom'])
+                meta['next_pre'] = (nxt.prenorm.weight, nxt.prenorm.bias, (n, nxt_fmap) if nxt_fmap is not None else None, nxt_kind)
                 meta['handoff_out'] = hout
         return ops.SandwichBlockFn.apply(x, resid, context if isinstance(inner, (Attention, SparseCross2DNA)) else None, meta,
                                          self.prenorm.weight, self.prenorm.bias, self.postnorm.weight,

@@ -93,8 +93,16 @@ class S3Inner:
             qkvT = K.empty_bf((D, 3 * inner), wq.device)
             K.transpose_cast(wq.detach(), qkvT, col0=0)
             K.transpose_cast(wkv.detach(), qkvT, col0=inner)
-            return dict(qkv=qkv, qkvT=qkvT, out=_cast(wo), outT=_cast_t(wo))
+            out = dict(qkv=qkv, qkvT=qkvT, out=_cast(wo), outT=_cast_t(wo))
+            if K.mixed():                       # fp16 copy for the fp16-operand q / k / v projection of 'bf16x3-fwd'
+                out['qkv_16'] = torch.cat((wq.detach(), wkv.detach()), 0).to(torch.float16).contiguous()
+            return out
         return cache.get('s3', (wq, wkv, wo), build)
+
+    @staticmethod
+    def f16_proj_ok(R, D, inner, g):
+        """'bf16x3-fwd': q / k / v projection on single fp16 MFMAs (bf16 + fp16 copies out) feeding the fp16 core"""
+        return K.qkv_f16() and K.s3_f16_supported(g) and K.gemm_nt_f16ops_ok(R, 3 * inner, D, out_bf16=True)
 
     @staticmethod
     def fwd(h, p, meta):
@@ -103,8 +111,15 @@ class S3Inner:
         g = meta['geom']
         rel = p[5].detach().contiguous() if len(p) > 5 else None          # [J, heads] relative-position bias (optional)
         # 'bf16x3-fwd': q / k / v leave the 3-MFMA projection as a bf16 copy (backward) + an fp16 copy, and the core runs single fp16 MFMAs
-        f16 = K.cores_f16() and h.lo is not None and K.s3_f16_supported(g)
-        qkv = K.gemm_nt(h, W['qkv'], out_bf16=True, shift=meta.get('shift'), out_f16=f16)
+        R, D = h.hi.shape
+        if meta.get('shift') is None and 'qkv_16' in W and S3Inner.f16_proj_ok(R, D, g.heads * g.dim_head, g):
+            h16 = h.f16 if h.f16 is not None else K.hilo_to_f16(h)
+            qkv = K.gemm_nt_f16ops(h16, W['qkv_16'], out_bf16=True, copy_f16=True)
+        else:
+            if h.lo is None and h.f16 is not None:
+                raise RuntimeError('Sparse3DNA received an fp16-copy activation but cannot run the fp16-operand projection')
+            f16 = K.cores_f16() and h.lo is not None and K.s3_f16_supported(g)
+            qkv = K.gemm_nt(h, W['qkv'], out_bf16=True, shift=meta.get('shift'), out_f16=f16)
         o = K.sparse3dna_fwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), rel_bias=rel)
         y = K.gemm_nt(o, W['out'], bias=bo.detach(), out_bf16=_fast())
         return y, _sv(h, qkv, o)
@@ -482,7 +497,9 @@ class SandwichBlockFn(Function):
         # block's h = shift(LN(x)) while the new stream row was in its registers, and this block does the same for the next
         hin, nxt, hout = meta.pop('handoff_in', None), meta.pop('next_pre', None), meta.pop('handoff_out', None)
         ctx.prev_ctx = None
-        want16 = meta['kind'] == 'ff' and FFInner.f16_ok(B * n, D, _ru(p[1].shape[1], 32))      # h as a bf16 + fp16 copy pair
+        # h as a bf16 + fp16 copy pair when this block's first GEMM runs fp16 operands ('bf16x3-fwd': FeedForward, the 3DNA projection)
+        want16 = (meta['kind'] == 'ff' and FFInner.f16_ok(B * n, D, _ru(p[1].shape[1], 32))) or \
+                 (meta['kind'] == 's3' and S3Inner.f16_proj_ok(B * n, D, p[0].shape[0], meta['geom']))
         if hin is not None and hin.get('ptr') == x.data_ptr() and hin.get('ver') == x._version and hin.get('shift') == sh \
                 and resid is None and tuple(hin['h'].hi.shape) == (B * n, D):
             h, m1, r1 = hin['h'], hin['m1'], hin['r1']
@@ -494,7 +511,10 @@ class SandwichBlockFn(Function):
             meta['shift'] = None
         y, saved = inner.fwd(h, p, meta)
         if nxt is not None and hout is not None:
-            nxt16 = len(nxt) > 3 and nxt[3] is not None and FFInner.f16_ok(B * n, D, _ru(nxt[3], 32))   # the next block is a FeedForward on the fp16 path
+            # the next block's first GEMM runs fp16 operands: FeedForward (nxt[3] = ('ff', inner width)) or the 3DNA projection (('s3', inner, geom))
+            nk = nxt[3] if len(nxt) > 3 else None
+            nxt16 = nk is not None and ((nk[0] == 'ff' and FFInner.f16_ok(B * n, D, _ru(nk[1], 32))) or
+                                        (nk[0] == 's3' and S3Inner.f16_proj_ok(B * n, D, nk[1], nk[2])))
             xo, m2, r2, hn, mn, rn = K.ln_post_pre_fwd(y, r2_, post_w.detach(), post_b.detach(), nxt[0].detach(),
                                                        nxt[1].detach(), next_shift=nxt[2], next_f16=nxt16)
             hout.update(h=hn, m1=mn, r1=rn, ptr=xo.data_ptr(), ver=xo._version, shift=nxt[2], ctx=ctx if CHAIN_BWD else None)
