@@ -130,12 +130,12 @@ class GradReducer:
             self._sync = prev
 
     def _on_grad(self, p):
-        if not self._sync:
-            return
         b = self._by_param[id(p)]
-        if b['launched']:
+        if b['launched']:          # (checked under no_sync() too: accumulating on top of already reduced = averaged buffers is the same mistake)
             raise RuntimeError(f'GradReducer: bucket {b["key"]!r} received a gradient after it was reduced -- run every micro-batch '
                                f'but the last under no_sync(), and call zero_grad() between optimiser steps')
+        if not self._sync:
+            return
         b['pending'] -= 1
         if b['pending'] == 0:
             self._launch(b)

@@ -80,6 +80,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._table = torch.empty(self.nchunks * self._dtype.itemsize, dtype=torch.uint8, device=self.device)
         self._partials = torch.empty(max(self.nchunks, 1), dtype=torch.float32, device=self.device)
         self._norm = torch.ones(2, dtype=torch.float32, device=self.device)      # [total norm, clip coefficient]
+        self._built = True
 
     # -- hyper-parameters live in param_groups (schedulers edit them there); the fused launch takes ONE lr / betas / eps
     def _hyper(self):
@@ -97,6 +98,13 @@ class FusedAdamW(torch.optim.Optimizer):
         """state[p] views the buffers the kernel updates (exp_avg / exp_avg_sq) and the host-side step count"""
         for i, p in enumerate(self.params):
             self.state[p] = {'step': torch.tensor(float(self.param_steps[i])), 'exp_avg': self.state_m[i], 'exp_avg_sq': self.state_v[i]}
+
+    def add_param_group(self, param_group):
+        """the chunk table of the fused launch is built once, in __init__ (torch's own constructor calls this for the initial groups)"""
+        if getattr(self, '_built', False):
+            raise RuntimeError('FusedAdamW: parameter groups cannot be added after construction (the fused chunk table is fixed); '
+                               'build a new optimiser over all parameters instead')
+        super().add_param_group(param_group)
 
     def state_dict(self):
         for i, p in enumerate(self.params):

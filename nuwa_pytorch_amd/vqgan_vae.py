@@ -5,8 +5,9 @@ tokenizer (copy_for_eval + get_video_indices under no_grad, vq.py:408-458) and r
 
 `VectorQuantize` restates the third-party vector_quantize_pytorch module the reference imports
 (vq.py:6, 368-378; source not vendored, not installed): PARITY UNPINNED at that boundary
-(SURVEY.md section 8c).  Its buffers live under `vq._codebook.*` like the upstream module's, so a reference
-checkpoint loads strictly; the flat names of this repository's earlier fixtures are accepted too.
+(SURVEY.md section 8c).  Its buffers live under `vq._codebook.*` like the upstream module's, so the autoencoder part of a
+reference checkpoint loads strictly (a checkpoint trained with the reference's default use_vgg_and_gan=True also holds
+`discr.*` / `vgg.*` entries: VQGanVAE drops those on load); the flat names of this repository's earlier fixtures are accepted too.
 
 GAN / VGG training of the VAE (vq.py:145-176, 514-543) is out of scope: `use_vgg_and_gan=True` (the
 reference's default, which downloads a pretrained VGG16) builds the same autoencoder WITHOUT the
@@ -264,7 +265,6 @@ class VQGanAttention(nn.Module):
 class VQGanVAE(nn.Module):
     """vq.py:288-548 (GAN/VGG branch excluded)."""
 
-    _warned_gan = False
 
     def __init__(self, *, dim, image_size, channels=3, num_layers=4, layer_mults=None, l2_recon_loss=False,
                  use_hinge_loss=True, num_resnet_blocks=1, vgg=None, vq_codebook_dim=256, vq_codebook_size=512,
@@ -273,12 +273,11 @@ class VQGanVAE(nn.Module):
                  use_vgg_and_gan=True, **kwargs):
         super().__init__()
         assert dim % resnet_groups == 0, f'dimension {dim} must be divisible by {resnet_groups} (groups for the groupnorm)'
-        if use_vgg_and_gan:
-            if not VQGanVAE._warned_gan:
-                warnings.warn('nuwa_pytorch_amd.VQGanVAE: the perceptual (VGG16) and adversarial (discriminator) losses of the '
-                              'reference are outside this package; building the autoencoder with use_vgg_and_gan=False '
-                              '(reconstruction loss only).  NUWA uses the VAE frozen, so training it is unaffected.', stacklevel=2)
-                VQGanVAE._warned_gan = True
+        if use_vgg_and_gan:          # (per instance: every VAE built this way optimises a different objective from the reference's default)
+            warnings.warn('nuwa_pytorch_amd.VQGanVAE: the perceptual (VGG16) and adversarial (discriminator) losses of the '
+                          'reference are outside this package; building the autoencoder with use_vgg_and_gan=False '
+                          '(forward(return_loss=True) = reconstruction loss only).  NUWA uses the VAE frozen, so training it is '
+                          'unaffected; `discr.*` / `vgg.*` entries of a reference checkpoint are skipped on load.', stacklevel=2)
             use_vgg_and_gan = False
         vq_kwargs, kwargs = split_by_prefix('vq_', kwargs)
         self.image_size = image_size
@@ -320,6 +319,12 @@ class VQGanVAE(nn.Module):
         self.vgg = None
         self.discr = None
         self.use_vgg_and_gan = use_vgg_and_gan
+
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        """a reference checkpoint written with use_vgg_and_gan=True also carries the discriminator and the VGG16 (`discr.*`,
+        `vgg.*`, vq.py:396-406): this package builds neither, so those entries are dropped before the (strict) load"""
+        kept = {k: v for k, v in state_dict.items() if not (k.startswith('discr.') or k.startswith('vgg.'))}
+        return super().load_state_dict(kept, strict=strict, **kwargs)
 
     def copy_for_eval(self):
         device = next(self.parameters()).device

@@ -111,6 +111,15 @@ def _accum_worker(rank, world, port, q, collective):
         nn.functional.cross_entropy(m(X[:4]), Y[:4]).backward()
     except RuntimeError as e:
         raised = 'after it was reduced' in str(e)
+    # ... and so must a micro-batch under no_sync() that follows finish() without zero_grad(): it would accumulate local gradients
+    # on top of the already averaged buffers (round-2 advisor finding)
+    raised2 = False
+    try:
+        with red.no_sync():
+            nn.functional.cross_entropy(m(X[:4]), Y[:4]).backward()
+    except RuntimeError as e:
+        raised2 = 'after it was reduced' in str(e)
+    raised = raised and raised2
     q.put((rank, outs, {n: v.numpy() for n, v in w0.items()}, raised))
     dist.barrier()
     dist.destroy_process_group()

@@ -101,3 +101,14 @@ def test_fused_adamw_is_a_torch_optimizer_with_resumable_state():
         assert torch.equal(pa, pb), n
     for ma, mb in zip(opt.state_m, opt2.state_m):
         assert torch.equal(ma, mb)
+
+
+def test_fused_adamw_rejects_late_param_groups():
+    """the fused chunk table is built once: add_param_group after construction raises instead of being silently ignored"""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from nuwa_pytorch_amd.optimizer import FusedAdamW
+    a = torch.nn.Linear(8, 8).cuda()
+    opt = FusedAdamW(a.parameters(), lr=1e-3)
+    with pytest.raises(RuntimeError, match='cannot be added after construction'):
+        opt.add_param_group({'params': [torch.nn.Parameter(torch.zeros(4, device='cuda'))]})

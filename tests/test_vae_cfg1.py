@@ -59,14 +59,13 @@ def test_g12_cfg1_forward_backward_matches_reference(mode):
 
 
 def test_cfg1_default_constructor_builds_without_the_gan_branch():
-    """`VQGanVAE(dim=..., image_size=...)` with the reference's DEFAULT use_vgg_and_gan=True constructs (one warning), trains on the
-    reconstruction loss, and refuses only the discriminator loss"""
-    A.VQGanVAE._warned_gan = False
+    """`VQGanVAE(dim=..., image_size=...)` with the reference's DEFAULT use_vgg_and_gan=True constructs (one warning PER INSTANCE),
+    trains on the reconstruction loss, and refuses only the discriminator loss"""
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
         vae = A.VQGanVAE(dim=64, image_size=32, num_layers=2)
         A.VQGanVAE(dim=64, image_size=32, num_layers=2)
-    assert len([x for x in w if 'perceptual' in str(x.message)]) == 1
+    assert len([x for x in w if 'perceptual' in str(x.message)]) == 2
     assert vae.use_vgg_and_gan is False and vae.vgg is None and vae.discr is None
     img = torch.rand(4, 3, 32, 32)
     loss = vae(img, return_loss=True)
@@ -100,3 +99,23 @@ def test_vq_state_dict_uses_upstream_codebook_layout_and_accepts_variants():
     nuwa = A.NUWA(vae=vae, dim=32, max_video_frames=2, text_num_tokens=20, text_max_seq_len=4, text_enc_depth=1, dec_depth=1,
                   dec_heads=2, dec_dim_head=32, text_enc_heads=2, text_enc_dim_head=16, enc_reversible=True)
     assert 'vae.vq._codebook.embed' in nuwa.state_dict()
+
+
+def test_reference_checkpoint_with_gan_and_vgg_entries_loads_strictly():
+    """a checkpoint written by the reference with its default use_vgg_and_gan=True also carries `discr.*` and `vgg.*` entries
+    (vq.py:396-406): VQGanVAE.load_state_dict drops them and loads the autoencoder strictly; the default constructor warns per
+    instance that the GAN / VGG branch is not built"""
+    import warnings
+    import nuwa_pytorch_amd as A
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        a = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32)
+        b = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32)
+    assert sum('use_vgg_and_gan' in str(x.message) for x in w) == 2
+    sd = dict(a.state_dict())
+    sd['discr.layers.0.0.weight'] = torch.zeros(4, 3, 4, 4)
+    sd['vgg.features.0.weight'] = torch.zeros(64, 3, 3, 3)
+    res = b.load_state_dict(sd)                      # strict
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in a.state_dict().items():
+        assert torch.equal(v, b.state_dict()[k]), k

@@ -38,7 +38,7 @@ echo "# python bench.py --precision bf16x3 --batch 16 --no-cpu-baseline --no-tok
 timeout 900 python bench.py --precision bf16x3 --batch 16 --no-cpu-baseline --no-tokenizer --no-parity --steps 4 --warmup 2 2>/dev/null | tail -n 1 >> gpurun_out/side_bench_$TAG.txt
 find gpurun_out/pmc_${TAG}_* -name "*.csv" -size +8M -delete
 bash tools/gpu_calib.sh > gpurun_out/calib_${TAG}_run.log 2>&1; cat gpurun_out/calib_${TAG}.txt
-timeout 600 python tools/cpu_baseline_threads.py 32,64,0 > gpurun_out/cpu_threads_$TAG.txt 2>&1; cat gpurun_out/cpu_threads_$TAG.txt
+timeout 300 python tools/cpu_baseline_threads.py 16,32,64 > gpurun_out/cpu_threads_$TAG.txt 2>&1; cat gpurun_out/cpu_threads_$TAG.txt
 python tools/attn_bench.py --batch 64 > gpurun_out/side_attn_$TAG.txt 2>&1
 python tools/gemm_probe.py 64 7 > gpurun_out/side_gemm_probe_$TAG.txt 2>&1
 python tools/gemm_x3_probe.py 64 > gpurun_out/side_gemm_x3_probe_$TAG.txt 2>&1
