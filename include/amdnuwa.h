@@ -35,6 +35,9 @@ const char* amdnuwa_error_string(int code);
  *   key 0  NT GEMM variant: 1 direct-to-LDS BK 64, 2 direct-to-LDS BK 32, 3 / 4 256x256 tile with a 4- / 3-stage DMA ring,
  *          5 register-staged 128x128
  *   key 1  TN split-K workgroup slots        key 2  TN minimum token rows per split
+ *   key 3  Sparse3DNA forward: 1 = keep the VALU (dot2) kernel        key 13 hi + lo NT GEMM: 1 = first-generation 128x128 kernel
+ *   key 4  Sparse3DNA backward: 1 = VALU kernels, 2 = MFMA query side + VALU key side, 4 = MFMA query side + RECOMPUTING MFMA key side
+ *          (no ds / P' workspace: 1.5x instead of 2.85x the algorithmic HBM bytes, 15-22 % slower; 0 = MFMA kernels with the workspace)
  *   key 5  cross-attention forward: 1 = generic (not unrolled) kernel
  *   key 6  TN GEMM variant: 1 register-staged, 2 direct-to-LDS 128x128, 3 256x256 ring
  *   key 7  NT probe: bit 0 skips the epilogue stores, bit 1 skips the main loop (tools/gemm_probe.py; results are garbage)

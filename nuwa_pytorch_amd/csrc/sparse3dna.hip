@@ -32,6 +32,8 @@ struct S3Args {
     const float* wth;                                     // [NH][NH] talking heads (g, h)
     const float* bias;                                    // [J][NH] relative-position bias per key slot (or NULL)
     float *ds, *pm;                                       // [B][nq][J][NH]
+    float* stats;                                         // recomputing key side (MFMA path): [B][nq][NH][4] = (row max, 1 / row sum, delta = sum_j P dP, -);
+                                                          // non-NULL = the query side writes these INSTEAD of the ds / pm workspace
     float *part_th, *part_k0, *part_v0;                   // [B*F*H][NH*NH], [B*F*H][NH*DH] x2
     float* dwth;                                          // [NH*NH] accumulated
     int B, ntok, F, H, W, kf, kh, kw, df, dh, dw, NH;
@@ -1038,7 +1040,8 @@ __device__ __forceinline__ void mfma_band_apply(const S3Args& a, const RowM& r, 
 }
 
 // fp32 softmax over the J slots of every (w, h) of TAB, in place (4 lanes split j); masked slots hold NEG_MAX
-__device__ __forceinline__ void rowm_softmax(float* TAB, int J) {
+// gst (optional): [W][NH][4] floats of this query row in the statistics array: (row max, 1 / row sum) of queries w < wvalid go there
+__device__ __forceinline__ void rowm_softmax(float* TAB, int J, float* gst = nullptr, int wvalid = 0) {
     constexpr int NH = S3M_NH;
     const int t = threadIdx.x, cc = t & 3, wh = t >> 2, h = wh % NH, w = wh / NH;
     TAB += w * s3m_ts(J) + h;                                                    // (query w, slot 0, head h); slot j at + j * NH
@@ -1063,6 +1066,7 @@ __device__ __forceinline__ void rowm_softmax(float* TAB, int J) {
         const float inv = 1.f / sum;
 #pragma unroll
         for (int k = 0; k < 12; ++k) { const int j = cc + 4 * k; if (j < J) TAB[j * NH] = v[k] * inv; }
+        if (gst && cc == 0 && w < wvalid) *reinterpret_cast<float2*>(gst + (w * NH + h) * 4) = make_float2(m, inv);
         return;
     }
     float m = NEG_MAX;
@@ -1078,6 +1082,7 @@ __device__ __forceinline__ void rowm_softmax(float* TAB, int J) {
     sum = quad_sum(sum);
     const float inv = 1.f / sum;
     for (int j = cc; j < J; j += 4) TAB[j * NH] *= inv;
+    if (gst && cc == 0 && w < wvalid) *reinterpret_cast<float2*>(gst + (w * NH + h) * 4) = make_float2(m, inv);
 }
 
 // F16: a.q / a.k / a.v hold fp16 values, the score and apply products run on the fp16 MFMA, and o leaves as a bf16 hi + lo pair
@@ -1195,13 +1200,17 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     mfma_band_scores_staged(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias, stile);             // scores
     mfma_band_scores_staged(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, 1.f, nullptr, stile);              // dP'[g] = dO[g] . v_j[g]
     __syncthreads();
-    rowm_softmax(SP, J);                                                                    // P
+    // recomputing key side: this kernel leaves (row max, 1 / row sum, delta) per (query, head) instead of the ds / P' workspace
+    float* gst = a.stats ? a.stats + ((size_t)b * nq + (size_t)ry * W) * NH * 4 : nullptr;
+    const int wvalid = a.ntok - 1 - ry * W;                                                 // queries of this row that exist
+    rowm_softmax(SP, J, gst, wvalid);                                                       // P
     __syncthreads();
     // P' = mix(P) -> global (the key side needs it), P stays in SP;  P' of the <bos> slot also to PM0
     float wr[64];                              // the 8 x 8 mix matrix in registers for the loop below: read from LDS inside it, every output row
 #pragma unroll                                     // waited for its own LDS round trip (the stores to the table may alias wsh for the compiler)
     for (int k = 0; k < 64; ++k) wr[k] = wsh[k];
-    for (int item = t; item < W * J; item += blockDim.x) {
+    for (int item0 = t; item0 < (gst ? W : W * J); item0 += blockDim.x) {           // (recomputing key side: only the <bos> slots are needed)
+        const int item = gst ? item0 * J : item0;
         const int wq = (int)(((float)item + 0.5f) * rJ), j = item - wq * J;
         const int iq = 1 + ry * W + wq;
         float pv[8];
@@ -1213,7 +1222,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
             float s = 0.f;
 #pragma unroll
             for (int hh = 0; hh < 8; ++hh) s += wr[g * NH + hh] * pv[hh];
-            if (iq < a.ntok) dst[g] = s;
+            if (iq < a.ntok && !gst) dst[g] = s;
             if (j == 0) PM0[wq * NH + g] = iq < a.ntok ? s : 0.f;
         }
     }
@@ -1275,6 +1284,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) if (cc + 4 * k < J) d += pv[k] * dv[k];
             d = quad_sum(d);
+            if (gst && cc == 0 && i < a.ntok) gst[(w * NH + h) * 4 + 2] = d;
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
                 const int j = cc + 4 * k;
@@ -1282,18 +1292,19 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
                     const int idx = w * TS + j * NH + h;
                     const float dsv = pv[k] * (dv[k] - d);
                     DP[idx] = dsv;
-                    if (i < a.ntok) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
+                    if (i < a.ntok && !gst) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
                 }
             }
         } else {
         float d = 0.f;
         for (int j = cc; j < J; j += 4) d += SP[w * TS + j * NH + h] * DP[w * TS + j * NH + h];
         d = quad_sum(d);
+        if (gst && cc == 0 && i < a.ntok) gst[(w * NH + h) * 4 + 2] = d;
         for (int j = cc; j < J; j += 4) {
             const int idx = w * TS + j * NH + h;
             const float dsv = SP[idx] * (DP[idx] - d);
             DP[idx] = dsv;
-            if (i < a.ntok) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
+            if (i < a.ntok && !gst) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
         }
         }
     }
@@ -1460,6 +1471,187 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
     }
 }
 
+// MFMA backward, key side, RECOMPUTING form (no ds / P' workspace).  Same mapping as s3_bwd_kv_mfma_kernel (one workgroup = one key
+// row, wave = head), one plane (= one attending query row) per iteration:
+//   S[q][key]   = Q[h] K[h]^T, dP'[q][key] = dO[h] V[h]^T        2 + 2 MFMAs: A = the plane's q / dO rows out of the wave's tile,
+//                                                                 B = this row's k / v fragments, loaded once per workgroup
+//   P[h]        = exp(scale S + bias - m[q][h]) / l[q][h]         on the band entries (key = query - tap offset), from the statistics
+//                                                                 the query side wrote: 3 floats per (query, head)
+//   heads meet through LDS (bf16 x 4 per lane and head, double-buffered by plane parity: ONE workgroup barrier per plane):
+//   P'[g]  = sum_h W[g][h] P[h]          (this wave's output head g = its own index)
+//   dP[h]  = sum_g W[g][h] dP'[g],       ds[h] = P[h] (dP[h] - delta[q][h])
+//   dK^T += Q^T ds,  dV^T += dO^T P'     as before (transposing tile reads; the upper 16 k-slots of the MFMA stay zero)
+// What disappears: the 2 x [B][n][J][8] fp32 workspace (3.9 GB written and read back per call at b = 128) -- the backward's HBM
+// traffic drops from 2.85x to ~1.5x the algorithmic bytes.  What it costs: one workgroup barrier per plane and ~250 VALU instructions
+// per plane and wave; at 180 registers only one workgroup fits a CU.  Measured 15-22 % SLOWER than the workspace form (whole backward,
+// tools/attn_bench.py), so it is an option (tuning key 4 = 4), not the default.  The coefficients meet as bf16 (they are packed to bf16 for the MFMAs
+// anyway); P of the own head stays fp32 in ds.  LDS: 8 x 4 KiB tiles + 16 KiB exchange = 48 KiB.
+__global__ __launch_bounds__(512, 2) void s3_bwd_kv_rc_mfma_kernel(S3Args a) {
+    constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int pslot[S3M_PLANES + 1], ptok[S3M_PLANES + 1];
+    __shared__ float wsh[64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g4 = lane >> 4, h = wave;
+    const int rows = a.F * a.H;
+    const int bid = xcd_row_id();
+    const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
+    const int nq = a.ntok - 1;
+    if (ry * W + 1 >= a.ntok) return;
+    if (t < NH * NH) wsh[t] = a.wth[t];
+    if (t == 0) {
+        int n = 0;
+        for (int ta = 0; ta < a.kf; ++ta)
+            for (int tb = 0; tb < a.kh; ++tb) {
+                const int fq = f + (a.kf - 1 - ta) * a.df, yq = y + (a.kh - 1 - tb) * a.dh;
+                if (fq < a.F && yq < a.H && (fq * a.H + yq) * W + 1 < a.ntok) {
+                    pslot[n] = 1 + (ta * a.kh + tb) * a.kw; ptok[n] = 1 + (fq * a.H + yq) * W; ++n;
+                }
+            }
+        pslot[S3M_PLANES] = n;
+    }
+    __syncthreads();
+    const int nplanes = pslot[S3M_PLANES];
+    const size_t tok0 = (size_t)b * a.ntok;
+    // tap linking the lane's 4 QUERIES 4*g4 + j to key c (query - key = (kw-1-tc) dw): the same in every plane
+    int tsel[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int d = (4 * g4 + j) - c;
+        tsel[j] = -1;
+#pragma unroll
+        for (int tc = 0; tc < S3M_KW; ++tc)
+            if (tc < a.kw && d == (a.kw - 1 - tc) * a.dw) tsel[j] = tc;
+    }
+    // this key row's k / v as B operands (lane: column = key c, k-group g4 -> channels ks * 32 + g4 * 8 ..)
+    const int ik = 1 + ry * W + c;
+    const bool kok = ik < a.ntok;
+    const bf16_t* krow = a.k + (tok0 + (kok ? ik : 0)) * a.ld + h * DH + g4 * 8;
+    const bf16_t* vrow = a.v + (tok0 + (kok ? ik : 0)) * a.ld + h * DH + g4 * 8;
+    const bf16x8 kf0 = ldg8(krow, kok), kf1 = ldg8(krow + 32, kok), vf0 = ldg8(vrow, kok), vf1 = ldg8(vrow + 32, kok);
+    float wg[8], wt[8];                       // row h of W (P'[h] = sum_hh W[h][hh] P[hh]) and column h (dP[h] = sum_g W[g][h] dP'[g])
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {             // wave-uniform: kept in scalar registers
+        wg[e] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wsh[h * NH + e])));
+        wt[e] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wsh[e * NH + h])));
+    }
+    char* tq = smem + wave * 4096;            // [16 queries][64] bf16 (vt_off swizzle)
+    char* td = tq + 2048;
+    uint2* XP = reinterpret_cast<uint2*>(smem + 8 * 4096);        // [2][NH][64] P as 4 x bf16
+    uint2* XD = XP + 2 * NH * 64;                                  // [2][NH][64] dP'
+    const int gc = lane & 7, r8 = lane >> 3;
+    const bf16_t* qbase = a.q + tok0 * a.ld + h * DH + gc * 8;
+    const bf16_t* dbase = a.dO + tok0 * a.lddo + h * DH + gc * 8;
+    const int woff0 = vt_off(r8, gc), woff1 = vt_off(r8 + 8, gc);
+    const int aoff0 = vt_off(c, g4), aoff1 = aoff0 ^ 64;                          // A operand: row = query c (lane & 15), chunk ks * 4 + g4 (chunk + 4 = byte ^ 64)
+    int troff[4];
+    {
+        const int r0 = 4 * g4 + (c >> 2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const int col = db * 16 + ((c & 3) << 2);
+            troff[db] = vt_off(r0, col >> 3) + ((col >> 2) & 1) * 8;
+        }
+    }
+    const float* stb = a.stats + (size_t)b * nq * NH * 4 + h * 4;
+    uint4 sq[2], sd[2];
+    float2 st[4];                                                                // (row max, 1 / row sum) of the lane's 4 queries
+    float dz[4];                                                                 // their delta
+    auto fetch_rows = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int tok = ptok[p] + r8 + 8 * i;
+            const bool ok = tok < a.ntok;
+            const size_t tc = ok ? tok : 0;
+            const uint4 vq = *reinterpret_cast<const uint4*>(qbase + tc * a.ld), vd = *reinterpret_cast<const uint4*>(dbase + tc * a.lddo);
+            sq[i] = ok ? vq : make_uint4(0, 0, 0, 0);
+            sd[i] = ok ? vd : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto fetch_stats = [&](int p) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int tok = ptok[p] + 4 * g4 + j;
+            const bool ok = tok < a.ntok && tsel[j] >= 0;
+            const float* sp = stb + (size_t)((ok ? tok : 1) - 1) * NH * 4;
+            const float2 v = *reinterpret_cast<const float2*>(sp);
+            const float z = sp[2];
+            st[j] = ok ? v : make_float2(0.f, 0.f);                              // inv = 0 -> P = 0 for slots that do not exist
+            dz[j] = ok ? z : 0.f;
+        }
+    };
+    f32x4 dK[4], dV[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dK[db] = dV[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nplanes > 0) { fetch_rows(0); fetch_stats(0); }
+    for (int p = 0; p < nplanes; ++p) {
+        *reinterpret_cast<uint4*>(tq + woff0) = sq[0];
+        *reinterpret_cast<uint4*>(tq + woff1) = sq[1];
+        *reinterpret_cast<uint4*>(td + woff0) = sd[0];
+        *reinterpret_cast<uint4*>(td + woff1) = sd[1];
+        const int jb = pslot[p];
+        if (p + 1 < nplanes) fetch_rows(p + 1);                                   // the next plane's rows are in flight below
+        __builtin_amdgcn_wave_barrier();                                          // LDS is in-order per wave: the tiles are complete
+        const bf16x8 qa0 = *reinterpret_cast<const bf16x8*>(tq + aoff0), qa1 = *reinterpret_cast<const bf16x8*>(tq + aoff1);
+        const bf16x8 da0 = *reinterpret_cast<const bf16x8*>(td + aoff0), da1 = *reinterpret_cast<const bf16x8*>(td + aoff1);
+        f32x4 S = {0.f, 0.f, 0.f, 0.f}, Dp = {0.f, 0.f, 0.f, 0.f};
+        S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf0, S, 0, 0, 0);        // S[query 4 g4 + r][key c]
+        S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf1, S, 0, 0, 0);
+        Dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da0, vf0, Dp, 0, 0, 0);      // dP'[h][query][key] = dO[h] . V[h]
+        Dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da1, vf1, Dp, 0, 0, 0);
+        float P[4], dpp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool on = tsel[j] >= 0 && kok;
+            const int ts = tsel[j] < 0 ? 0 : tsel[j];
+            const float bv = a.bias ? a.bias[(jb + ts) * NH + h] : 0.f;
+            const float e = __expf(S[j] * a.scale + bv - st[j].x) * st[j].y;        // (inv = 0 where the query / slot does not exist)
+            P[j] = on ? e : 0.f;
+            dpp[j] = on ? Dp[j] : 0.f;
+        }
+        float dzc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dzc[j] = dz[j];
+        if (p + 1 < nplanes) fetch_stats(p + 1);                                  // (the statistics of this plane are consumed)
+        const int par = p & 1;
+        XP[(par * NH + h) * 64 + lane] = make_uint2(pack2_rne(P[0], P[1]), pack2_rne(P[2], P[3]));
+        XD[(par * NH + h) * 64 + lane] = make_uint2(pack2_rne(dpp[0], dpp[1]), pack2_rne(dpp[2], dpp[3]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float pm[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < NH; ++e) {
+            const uint2 xp = XP[(par * NH + e) * 64 + lane], xd = XD[(par * NH + e) * 64 + lane];
+            pm[0] += wg[e] * lo_f(xp.x); pm[1] += wg[e] * hi_f(xp.x); pm[2] += wg[e] * lo_f(xp.y); pm[3] += wg[e] * hi_f(xp.y);
+            dp[0] += wt[e] * lo_f(xd.x); dp[1] += wt[e] * hi_f(xd.x); dp[2] += wt[e] * lo_f(xd.y); dp[3] += wt[e] * hi_f(xd.y);
+        }
+        float dsv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dsv[j] = P[j] * (dp[j] - dzc[j]);
+        const bf16x8 bs = __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(dsv[0], dsv[1]), pack2_rne(dsv[2], dsv[3]), 0u, 0u));
+        const bf16x8 bp = __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(pm[0], pm[1]), pack2_rne(pm[2], pm[3]), 0u, 0u));
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const s16x4 ql = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tq + troff[db]));
+            const s16x4 dl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(td + troff[db]));
+            const s16x8 q8 = {ql[0], ql[1], ql[2], ql[3], 0, 0, 0, 0};
+            const s16x8 d8 = {dl[0], dl[1], dl[2], dl[3], 0, 0, 0, 0};
+            dK[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, q8), bs, dK[db], 0, 0, 0);
+            dV[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, d8), bp, dV[db], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (kok) {
+        bf16_t* kr = a.dk + (tok0 + ik) * a.ldd + h * DH + 4 * g4;
+        bf16_t* vr = a.dv + (tok0 + ik) * a.ldd + h * DH + 4 * g4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            *reinterpret_cast<uint2*>(kr + db * 16) = make_uint2(pack2_rne(dK[db][0] * a.scale, dK[db][1] * a.scale),
+                                                                 pack2_rne(dK[db][2] * a.scale, dK[db][3] * a.scale));
+            *reinterpret_cast<uint2*>(vr + db * 16) = make_uint2(pack2_rne(dV[db][0], dV[db][1]), pack2_rne(dV[db][2], dV[db][3]));
+        }
+    }
+}
+
 void fill_geom(S3Args& a, const amdnuwa_s3_geom* g) {
     a.B = g->B; a.ntok = g->ntok; a.F = g->F; a.H = g->H; a.W = g->W; a.kf = g->kf; a.kh = g->kh; a.kw = g->kw;
     a.df = g->df; a.dh = g->dh; a.dw = g->dw; a.NH = g->heads; a.scale = g->scale; a.bias = g->rel_bias;
@@ -1601,6 +1793,11 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     // MFMA query-side kernel (tuning key 4: 1 = keep the dot2 kernel): bf16 operands, 16 queries per grid row, 8 heads x 64
     const bool q_mfma = !has_lo && !dO_lo && !g->noncausal && g_amdnuwa_tuning[4] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 &&
                         g->kw <= S3M_KW && g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0;
+    // recomputing key side (tuning key 4 = 4; OFF by default: it removes the 3.9 GB workspace round trip -- backward traffic 2.85x ->
+    // 1.5x algorithmic -- but runs 15-22 % slower: its per-plane head exchange serialises the eight waves and its 180 registers allow one
+    // workgroup per CU).  Needs the MFMA query side; d(rel_bias) is a column sum of the ds workspace.
+    const bool kv_rc = q_mfma && g_amdnuwa_tuning[4] == 4 && !g->d_rel_bias;
+    a.stats = kv_rc ? a.ds : nullptr;                                              // (lives where the workspace would: B*nq*NH*4 floats <= B*nq*J*NH)
     const size_t nspm = (size_t)g->W * (J * g->heads + 4);                          // the MFMA kernels' padded tables (s3m_ts)
     const size_t lds_qm = (nspm * 4 > 8 * 4096 ? nspm * 4 : 8 * 4096) + nspm * 4 + (8 * 64 + 16 * 8) * 4 + 8 * 2048;   // + the score staging tiles
 #define S3B(DH_, LO_)                                                                                             \
@@ -1613,7 +1810,10 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
             hipLaunchKernelGGL((s3_bwd_q_kernel<DH_, LO_>), grid, block, lds_q, stream, a);                       \
         }                                                                                                         \
         LAUNCH_CHECK();                                                                                           \
-        if (q_mfma && g_amdnuwa_tuning[4] != 2) {                                                                 \
+        if (kv_rc) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)s3_bwd_kv_rc_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 + 16384); \
+            hipLaunchKernelGGL(s3_bwd_kv_rc_mfma_kernel, grid, dim3(512), 8 * 4096 + 16384, stream, a);           \
+        } else if (q_mfma && g_amdnuwa_tuning[4] != 2) {                                                          \
             (void)hipFuncSetAttribute((const void*)s3_bwd_kv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192); \
             hipLaunchKernelGGL(s3_bwd_kv_mfma_kernel, grid, dim3(512), 8 * 8192, stream, a);                      \
         } else {                                                                                                  \

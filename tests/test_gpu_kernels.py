@@ -647,6 +647,42 @@ def test_cross_attention_core(K, O, case, x3):
         report('xattn2_dnull_v' + tag, dnv2, nv.grad, 2 ** -6)
 
 
+@pytest.mark.parametrize('shape,kern,dil,n', [((2, 16, 16), (5, 3, 3), (1, 1, 1), None), ((3, 16, 16), (3, 3, 3), (4, 4, 4), 300),
+                                              ((5, 16, 16), (5, 3, 3), (2, 2, 2), 1 + 4 * 256 + 100)])
+def test_sparse3dna_bwd_recomputing_key_side(K, O, shape, kern, dil, n):
+    """the recomputing key-side backward (tuning key 4 = 4; no ds / P' workspace: statistics + delta from the query side, scores and the
+    head mix redone per plane) against the default workspace form and against the oracle's autograd"""
+    from nuwa_pytorch_amd import _lib
+    L = _lib.lib()
+    heads, dh = 8, 64
+    N = shape[0] * shape[1] * shape[2]
+    n = N if n is None else n
+    B, inner = 2, heads * dh
+    torch.manual_seed(21)
+    qkv = bf_round(torch.randn(B, n, 3, heads, dh)).requires_grad_(True)
+    wth = (torch.randn(heads, heads) * 0.5 + torch.eye(heads)).requires_grad_(True)
+    idx = O.neighbor_table(shape, kern, dil, causal=True)
+    o_ref = O.sparse3dna_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], wth, idx, dh ** -0.5)
+    do = bf_round(torch.randn_like(o_ref))
+    o_ref.backward(do)
+    g = K.s3_geom(B, n, shape, kern, dil, heads, dh)
+    qkvp = to_bf_pair(qkv.detach().reshape(B * n, 3 * inner).to(DEV), False)
+    dop = to_bf_pair(do.reshape(B * n, inner).to(DEV), False)
+    old, dwth_o, _ = K.sparse3dna_bwd(g, qkvp, wth.detach().to(DEV), dop)
+    try:
+        L.amdnuwa_set_tuning(4, 4)
+        new, dwth_n, _ = K.sparse3dna_bwd(g, qkvp, wth.detach().to(DEV), dop)
+    finally:
+        L.amdnuwa_set_tuning(4, 0)
+    gq = qkv.grad.reshape(B * n, 3 * inner)
+    tag = f'[{shape},{dil},{n}]'
+    assert torch.equal(new.hi[:, :inner], old.hi[:, :inner])                   # dq: the query side is the same arithmetic
+    report('s3_bwd_rc.dwth_vs_workspace' + tag, dwth_n, dwth_o, 1e-6)
+    for nm, sl in (('dk', slice(inner, 2 * inner)), ('dv', slice(2 * inner, 3 * inner))):
+        report(f's3_bwd_rc.{nm}_vs_workspace' + tag, new.hi[:, sl].float(), old.hi[:, sl].float(), 2 ** -6)
+        report(f's3_bwd_rc.{nm}_vs_oracle' + tag, new.hi[:, sl].float(), gq[:, sl], 2 ** -6)
+
+
 # ---------------------------------------------------------------------------------------------------
 # the fp16-operand forward cores of the 'bf16x3-fwd' mode
 # ---------------------------------------------------------------------------------------------------
