@@ -48,6 +48,7 @@ struct S3Args {
     float scale;
     int accumulate;
     int dbg;                                              // probe only (tuning key 9): bit 0 / 1 / 2 skip phase 1 / 2 / 3 of the MFMA forward
+    int ymajor;                                           // MFMA kernels: workgroup order inside a sample is (y, f) instead of (f, y) (tuning key 3 bit 1 = old order)
 };
 
 constexpr float NEG_MAX = -3.4028234663852886e38f;
@@ -823,6 +824,20 @@ struct RowM {
     const int *pslot, *ptok;                    // valid planes: first key slot j, token row of key 0
 };
 constexpr int S3M_NH = 8, S3M_DH = 64, S3M_W = 16;
+// Workgroup order inside a sample (a.ymajor; tuning key 3 bit 1 restores the frame-major order).  The ~64 workgroups an XCD runs
+// at a time should share key rows that fit its 4 MB L2 (the whole sample's K + V is 5.2 MB).  Frame-major order keeps 4 query frames
+// + up to 8 earlier key frames x 16 rows in flight: more than the L2 holds, every key row comes from HBM / MALL ~3 times.  Rows whose
+// y agree modulo the dilation dh attend to key rows of the SAME residue class (y - 2 dh, y - dh, y), so the order is: residue class
+// (y mod dh), then y, then frame -- a class is (H / dh) x F rows whose key rows are (H / dh) x F x 32 KB = 5.2 MB / dh.
+__device__ __forceinline__ void s3m_row_order(const S3Args& a, int r2, int& f, int& y) {
+    if (!a.ymajor) { f = r2 / a.H; y = r2 % a.H; return; }
+    if (a.dh > 1 && a.H % a.dh == 0) {
+        const int per = (a.H / a.dh) * a.F, cl = r2 / per, ii = r2 % per;
+        y = cl + (ii / a.F) * a.dh; f = ii % a.F;
+        return;
+    }
+    y = r2 / a.F; f = r2 % a.F;
+}
 // The score tables SP / DP of the MFMA kernels: entry (query w, slot j, head h) at word  w * TS + j * NH + h  with the per-query
 // stride TS = J * NH + 4.  The band view of the sweeps (mfma_band_scores*, mfma_band_apply) walks the QUERY index across the 16
 // lanes of an MFMA column group at fixed (slot, head); with the dense stride J * NH (= 368 words at J = 46: 16 mod 32) those 16
@@ -1099,7 +1114,10 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
     const int t = threadIdx.x;
     const int rows = a.F * a.H;
     const int bid = xcd_row_id();
-    const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
+    const int b = bid / rows, r2 = bid % rows;
+    int f, y;
+    s3m_row_order(a, r2, f, y);
+    const int ry = f * a.H + y;
     if (t < NH * NH) wsh[t] = a.wth[t];
     if (ry == 0) {                                                               // <bos> output row = its own value
         for (int e = t; e < NH * DH; e += blockDim.x) {
@@ -1180,7 +1198,10 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     const int t = threadIdx.x;
     const int rows = a.F * a.H;
     const int bid = xcd_row_id();
-    const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
+    const int b = bid / rows, r2 = bid % rows;
+    int f, y;
+    s3m_row_order(a, r2, f, y);
+    const int ry = f * a.H + y;
     const int nq = a.ntok - 1;
     if (t < NH * NH) wsh[t] = a.wth[t];
     float* pth = a.part_th + (size_t)bid * NH * NH;
@@ -1358,7 +1379,10 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g4 = lane >> 4, h = wave;
     const int rows = a.F * a.H;
     const int bid = xcd_row_id();
-    const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
+    const int b = bid / rows, r2 = bid % rows;
+    int f, y;
+    s3m_row_order(a, r2, f, y);
+    const int ry = f * a.H + y;
     const int J = a.kf * a.kh * a.kw + 1, nq = a.ntok - 1;
     if (ry * W + 1 >= a.ntok) return;
     if (t == 0) {
@@ -1494,7 +1518,10 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_rc_mfma_kernel(S3Args a) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c = lane & 15, g4 = lane >> 4, h = wave;
     const int rows = a.F * a.H;
     const int bid = xcd_row_id();
-    const int b = bid / rows, ry = bid % rows, f = ry / a.H, y = ry % a.H;
+    const int b = bid / rows, r2 = bid % rows;
+    int f, y;
+    s3m_row_order(a, r2, f, y);
+    const int ry = f * a.H + y;
     const int nq = a.ntok - 1;
     if (ry * W + 1 >= a.ntok) return;
     if (t < NH * NH) wsh[t] = a.wth[t];
@@ -1655,6 +1682,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_rc_mfma_kernel(S3Args a) {
 void fill_geom(S3Args& a, const amdnuwa_s3_geom* g) {
     a.B = g->B; a.ntok = g->ntok; a.F = g->F; a.H = g->H; a.W = g->W; a.kf = g->kf; a.kh = g->kh; a.kw = g->kw;
     a.df = g->df; a.dh = g->dh; a.dw = g->dw; a.NH = g->heads; a.scale = g->scale; a.bias = g->rel_bias;
+    a.ymajor = (g_amdnuwa_tuning[3] & 2) ? 0 : 1;
     // causal: every tap at or before the query (np.py:427); symmetric 'same' window otherwise (np.py:429)
     a.of = g->noncausal ? (g->kf - 1) / 2 : g->kf - 1;
     a.oh = g->noncausal ? (g->kh - 1) / 2 : g->kh - 1;
@@ -1697,7 +1725,7 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
     } while (0)
     const bool lo_mode = k_lo != nullptr;
     // MFMA forward (tuning key 3: 1 = keep the dot2 kernel): bf16 operands, 16 queries per grid row, 8 heads x 64
-    if (!lo_mode && !g->noncausal && g_amdnuwa_tuning[3] != 1 && g->W == 16 && g->heads == 8 && g->dim_head == 64 && g->kw <= S3M_KW &&
+    if (!lo_mode && !g->noncausal && !(g_amdnuwa_tuning[3] & 1) && g->W == 16 && g->heads == 8 && g->dim_head == 64 && g->kw <= S3M_KW &&
         g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && ldo % 4 == 0) {
         a.dbg = g_amdnuwa_tuning[9];
         const size_t lm = (size_t)16 * (J * 8 + 4) * sizeof(float) + 8 * 4096;
