@@ -369,6 +369,17 @@ size_t amdnuwa_xattn2_bwd_workspace_bytes(const amdnuwa_xattn_geom* g);
 int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
                        const amdnuwa_xattn_kv* packed, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm,
                        uint16_t* dq, int lddq, float* part_th, size_t part_bytes, amdnuwa_stream stream);
+/* The recomputing backward without the dS / Pm arrays (n % 32 == 0): the query side as above (dq, part_th) leaves nb / delta per
+ * (head, query) in `nbd` (>= amdnuwa_xattn2_bwd_rc_stats_bytes), and a key-side kernel -- one workgroup per 32 keys of a sample,
+ * the queries streamed through LDS -- recomputes ds and P' from them and accumulates dKp / dVp ([B][heads][JP][dim_head] fp32,
+ * dKp already scaled: the inputs of amdnuwa_xattn_unpack).  Same rounding points as _bwd + the two batched amdnuwa_gemm_tn;
+ * 3 GB less written and read back per layer call at b = 128. */
+int amdnuwa_xattn2_bwd_rc_supported(const amdnuwa_xattn_geom* g);
+size_t amdnuwa_xattn2_bwd_rc_stats_bytes(const amdnuwa_xattn_geom* g);
+int amdnuwa_xattn2_bwd_rc(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
+                          const amdnuwa_xattn_kv* packed, const float* w_th, const float* stats, uint16_t* dq, int lddq,
+                          float* part_th, size_t part_bytes, float* nbd, size_t nbd_bytes, float* dKp, float* dVp,
+                          amdnuwa_stream stream);
 /* Text cross-attention (Attention.forward with context, np.py:339-378) for ONE query row per sample (g->n must be 1):
  * q [B, ldq] unscaled, keys / values as packed by amdnuwa_xattn_pack (Kp / Vp images and the valid map), o [B, ldo]. */
 int amdnuwa_xattn_decode(const amdnuwa_xattn_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq,

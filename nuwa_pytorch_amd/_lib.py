@@ -6,7 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libamdnuwa.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 P = C.c_void_p
 I = C.c_int
@@ -111,6 +111,9 @@ SIGNATURES = {
     'amdnuwa_xattn2_fwd_f16': (I, [XG, P, I, XK, P, P, P, I, P, P]),
     'amdnuwa_xattn2_bwd_workspace_bytes': (SZ, [XG]),
     'amdnuwa_xattn2_bwd': (I, [XG, P, I, P, I, XK, P, P, P, P, P, I, P, SZ, P]),
+    'amdnuwa_xattn2_bwd_rc_supported': (I, [XG]),
+    'amdnuwa_xattn2_bwd_rc_stats_bytes': (SZ, [XG]),
+    'amdnuwa_xattn2_bwd_rc': (I, [XG, P, I, P, I, XK, P, P, P, I, P, SZ, P, SZ, P, P, P]),
     'amdnuwa_conv2d_fwd': (I, [CD, P, P, P, P, P]),
     'amdnuwa_groupnorm_fwd': (I, [P, P, P, P, I, I, I, I, F, I, P]),
     'amdnuwa_vq_argmax': (I, [P, P, P, P, LL, I, I, P]),

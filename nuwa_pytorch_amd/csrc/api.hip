@@ -7,7 +7,7 @@
 
 int g_amdnuwa_tuning[16] = {0};
 
-extern "C" int amdnuwa_abi_version(void) { return 11; }
+extern "C" int amdnuwa_abi_version(void) { return 12; }
 
 extern "C" int amdnuwa_set_tuning(int key, int value) {
     if (key < 0 || key >= 16) return AMDNUWA_ERR_ARG;

@@ -45,6 +45,12 @@ struct X2Args {
     float* part_th;                          // [grid][NH*NH]
     int B, n, JP, nch;
     float scale;
+    int nostore;                             // the backward skips its dS / Pm stores (the recomputing key side below replaces them;
+                                             // also the probe of tuning key 10 bit 4)
+    float* nbd;                              // recomputing backward: [2][B][NH][n] = nb (log2 normaliser) and delta per (head, query),
+                                             // written by the query side, read by the key side
+    float *dKp, *dVp;                        // key side: [B][NH][JP][DH] fp32
+    int flags;                               // key side: bit 0 = plain block order (probe)
 };
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
@@ -666,7 +672,7 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
             f32x4 D[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) D[e] = MIX(AW, Q, pack_heads(P, e));
-            if (qok) {
+            if (qok && !a.nostore) {
 #pragma unroll
                 for (int rp = 0; rp < 4; ++rp) {
                     bf16_t* dst = a.Pm + ((size_t)b * NH + 4 * Q + rp) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 4;
@@ -721,6 +727,11 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
     for (int h = 0; h < NH; ++h) {
         delta[h] += __shfl_xor(delta[h], 16, 64);
         delta[h] += __shfl_xor(delta[h], 32, 64);
+        if (a.nbd && g4 == 0 && qok) {                           // what the key side needs per (head, query)
+            const size_t at = ((size_t)b * NH + h) * a.n + qi;
+            a.nbd[at] = nb[h];
+            a.nbd[(size_t)a.B * NH * a.n + at] = delta[h];
+        }
     }
     // dW_th partial of this workgroup (fixed order over the 4 waves): lane l ends up with the wave's sum of entry l = g * NH + h
     {
@@ -777,7 +788,7 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
                 for (int e = 0; e < 8; ++e) ds[e] = P[e] * (D[e][rp] - delta[h]);
                 const uint2 lo = make_uint2(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]));
                 const uint2 hi = make_uint2(pack2_rne(ds[4], ds[5]), pack2_rne(ds[6], ds[7]));
-                if (qok) {
+                if (qok && !a.nostore) {
                     bf16_t* dst = a.dS + ((size_t)b * NH + h) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 4;
                     *reinterpret_cast<uint2*>(dst) = lo;
                     *reinterpret_cast<uint2*>(dst + 16) = hi;
@@ -1012,6 +1023,228 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, key side (xattn5): dK / dV WITHOUT the dS / P' round trip through HBM.
+//
+// The query-centric kernel above used to write ds and P' ([B][h][n][JP] bf16 each: 3 GB at b = 128) for two batched TN GEMMs to
+// read back -- measured 521 us of stores + 989 us of GEMMs per layer call.  This kernel recomputes both with the roles swapped:
+// a workgroup owns 32 KEYS of one sample, its waves hold the K / V fragments of their 16 keys for ALL heads in registers, and the
+// queries stream through LDS, 32 at a time (Q and dO rows of all heads = 64 KiB per step, double-buffered LDS-DMA ring, plus the
+// 2 KiB of per-(head, query) statistics nb / delta the query side left).  Per step, with lane = (key c, query group g4):
+//     S[h]   = Q[h] K[h]^T          A = Q tile rows (LDS), B = K fragment            -> P[h] = exp2(c1 S + nb)   (8 query slots)
+//     P'[g]  = sum_h W[g][h] P[h]   the MFMA head mix of xattn3, layout-agnostic     -> B operand of dV^T[g] += dO[g]^T P'[g]
+//     dP'[g] = dO[g] V[g]^T ,  dP = W^T dP' ,  ds[h] = P[h] (dP[h] - delta[h])       -> B operand of dK^T[h] += Q[h]^T ds[h]
+// The transposed A operands (dO^T, Q^T: rows = d, k-slots = queries) are ds_read_b64_tr_b16 reads of the same tiles.  The 4 waves
+// are 2 key blocks x 2 head halves: both halves compute all 8 heads' S and dP' (inputs of the mixes), each mixes and accumulates
+// only ITS 4 output heads (128 accumulator registers).  Rounding points are those of the old path (ds, P' -> bf16, fp32 sums).
+// ------------------------------------------------------------------------------------------------
+constexpr int ST5 = 2 * KT_BYTES + 2048;         // Q tile + dO tile + nb + delta of 32 queries
+
+__device__ __forceinline__ void stage_queries(char* smem, int buf, int st, int b, const X2Args& a, int wave, int lane) {
+    char* base = smem + buf * ST5;
+    const size_t row0 = (size_t)b * a.n + st * 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int pi = wave + 4 * i, h = pi >> 2, p = pi & 3;
+        const int r = 8 * p + (lane >> 3), gc = (lane & 7) ^ (lane >> 3);
+        dma16_asm(a.q + (row0 + r) * a.ldq + h * DH + gc * 8, base + h * TILE + p * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int pi = wave + 4 * i, h = pi >> 2, p = pi & 3;
+        const int r = 8 * p + (lane >> 3), gc = (lane & 7) ^ (lane >> 3);
+        dma16_asm(a.dO + (row0 + r) * a.lddo + h * DH + gc * 8, base + KT_BYTES + h * TILE + p * 1024);
+    }
+    if (!(wave & 1)) {                           // [h][32 queries] fp32: lane l brings head l >> 3, queries 4 (l & 7) ..+3
+        const int which = wave >> 1;                 // wave 0: nb, wave 2: delta
+        const float* src = a.nbd + (which ? (size_t)a.B * NH * a.n : 0) + ((size_t)b * NH + (lane >> 3)) * a.n + st * 32 + (lane & 7) * 4;
+        dma16_asm(src, base + 2 * KT_BYTES + which * 1024);
+    }
+}
+
+#define MIX1(H_, L_, B_) MFMA(L_, B_, MFMA(H_, B_, (f32x4{0.f, 0.f, 0.f, 0.f})))
+
+// one step (32 queries) of the key side for a wave accumulating heads 4 HH .. 4 HH + 3 (compile-time: the wave's P rows and
+// accumulators must stay in registers, a run-time head offset sends them to scratch)
+// the four A fragments of one head's 32-row tile (rows c / 16 + c, two k-steps)
+struct Frag4 { bf16x8 v[4]; };
+__device__ __forceinline__ Frag4 tile_frags(const char* base, int h, int c, int g4) {
+    Frag4 f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        f.v[2 * ks] = lds16(base + kd_off(h, c, ks * 4 + g4));
+        f.v[2 * ks + 1] = lds16(base + kd_off(h, 16 + c, ks * 4 + g4));
+    }
+    return f;
+}
+struct Tr4 { bf16x8 v[DB]; };
+__device__ __forceinline__ Tr4 tile_tr(const char* base, int h, int c, int g4) {
+    Tr4 t;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) t.v[db] = lds_tr(base, h, db, c, g4);
+    return t;
+}
+
+template <int HH>
+__device__ __forceinline__ void kv_step(const char* base, int c, int g4, float c1, float kbias, const bf16x8 (&kf)[NH][KS],
+                                        const bf16x8 (&vf)[NH][KS], const bf16x8& awh, const bf16x8& awl, const bf16x8& awth,
+                                        const bf16x8& awtl, f32x4 (&dK)[4][DB], f32x4 (&dV)[4][DB]) {
+    // Every LDS read is issued one unit of work (a head, a group of 4 accumulations) ahead of its use: the compiler keeps the source
+    // order, and "read, wait, MFMA" per fragment exposed the full LDS latency 128 times per step (one wave per SIMD: nothing else
+    // to run meanwhile).
+    constexpr int H0 = 4 * HH;
+    const float* nbs = reinterpret_cast<const float*>(base + 2 * KT_BYTES);
+    const char* dob = base + KT_BYTES;
+    float P[NH][8];
+    Frag4 fa = tile_frags(base, 0, c, g4);
+    Tr4 ta;
+    float4 n0 = *reinterpret_cast<const float4*>(nbs + 4 * g4), n1 = *reinterpret_cast<const float4*>(nbs + 16 + 4 * g4);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const Frag4 cur = fa;
+        const float nbv[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+        if (h + 1 < NH) {
+            fa = tile_frags(base, h + 1, c, g4);
+            n0 = *reinterpret_cast<const float4*>(nbs + (h + 1) * 32 + 4 * g4); n1 = *reinterpret_cast<const float4*>(nbs + (h + 1) * 32 + 16 + 4 * g4);
+        } else ta = tile_tr(dob, H0, c, g4);
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { s0 = MFMA(cur.v[2 * ks], kf[h][ks], s0); s1 = MFMA(cur.v[2 * ks + 1], kf[h][ks], s1); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                            // (kbias = -3e38 on a masked key: P = 0)
+            P[h][r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c1, nbv[r] + kbias));
+            P[h][4 + r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c1, nbv[4 + r] + kbias));
+        }
+    }
+    {   // P' of the wave's heads -> dV^T += dO^T P'
+        f32x4 D[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) D[e] = MIX1(awh, awl, pack_heads(P, e));
+#pragma unroll
+        for (int rp = 0; rp < 4; ++rp) {
+            const Tr4 cur = ta;
+            if (rp + 1 < 4) ta = tile_tr(dob, H0 + rp + 1, c, g4);
+            else fa = tile_frags(dob, 0, c, g4);
+            const float t[8] = {D[0][rp], D[1][rp], D[2][rp], D[3][rp], D[4][rp], D[5][rp], D[6][rp], D[7][rp]};
+            const bf16x8 pf = pack8(t);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) dV[rp][db] = MFMA(cur.v[db], pf, dV[rp][db]);
+        }
+    }
+    // dP' of all heads, packed per slot (the B operands of the dP mix)
+    uint32_t bw[8][4];
+#pragma unroll
+    for (int gp = 0; gp < 4; ++gp) {
+        f32x4 s[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int g = 2 * gp + u;
+            const Frag4 cur = fa;
+            if (g + 1 < NH) fa = tile_frags(dob, g + 1, c, g4);
+            else ta = tile_tr(base, H0, c, g4);
+            s[u][0] = s[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { s[u][0] = MFMA(cur.v[2 * ks], vf[g][ks], s[u][0]); s[u][1] = MFMA(cur.v[2 * ks + 1], vf[g][ks], s[u][1]); }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { bw[r][gp] = pack2_rne(s[0][0][r], s[1][0][r]); bw[4 + r][gp] = pack2_rne(s[0][1][r], s[1][1][r]); }
+    }
+    {   // dP of the wave's heads -> ds -> dK^T += Q^T ds
+        f32x4 D[8];
+        const float* dls = nbs + 256;
+        float4 l0 = *reinterpret_cast<const float4*>(dls + H0 * 32 + 4 * g4), l1 = *reinterpret_cast<const float4*>(dls + H0 * 32 + 16 + 4 * g4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) D[e] = MIX1(awth, awtl, __builtin_bit_cast(bf16x8, make_uint4(bw[e][0], bw[e][1], bw[e][2], bw[e][3])));
+#pragma unroll
+        for (int rp = 0; rp < 4; ++rp) {
+            const Tr4 cur = ta;
+            const float dl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+            if (rp + 1 < 4) {
+                ta = tile_tr(base, H0 + rp + 1, c, g4);
+                l0 = *reinterpret_cast<const float4*>(dls + (H0 + rp + 1) * 32 + 4 * g4); l1 = *reinterpret_cast<const float4*>(dls + (H0 + rp + 1) * 32 + 16 + 4 * g4);
+            }
+            float ds[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ds[e] = P[H0 + rp][e] * (D[e][rp] - dl[e]);
+            const bf16x8 sf = pack8(ds);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) dK[rp][db] = MFMA(cur.v[db], sf, dK[rp][db]);
+        }
+    }
+}
+
+// the whole query loop of one wave (no values merge across the two head halves: a select between them doubles the live registers)
+template <int HH>
+__device__ __forceinline__ void kv_run(char* smem, const X2Args& a, int b, int j, int wave, int lane, float c1, float kbias,
+                                       const bf16x8 (&kf)[NH][KS], const bf16x8 (&vf)[NH][KS], const bf16x8& awh, const bf16x8& awl,
+                                       const bf16x8& awth, const bf16x8& awtl) {
+    const int c = lane & 15, g4 = lane >> 4;
+    f32x4 dK[4][DB], dV[4][DB];
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) dK[rp][db] = dV[rp][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nst = a.n / 32;
+    stage_queries(smem, 0, 0, b, a, wave, lane);
+    for (int st = 0; st < nst; ++st) {
+        if (st + 1 < nst) {
+            stage_queries(smem, (st + 1) & 1, st + 1, b, a, wave, lane);
+            if (HH == 0) VMCNT(17); else VMCNT(16);              // (the HH = 0 waves bring the statistics: one more piece)
+        } else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        kv_step<HH>(smem + (st & 1) * ST5, c, g4, c1, kbias, kf, vf, awh, awl, awth, awtl, dK, dV);
+        __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const size_t at = ((size_t)(b * NH + 4 * HH + rp) * a.JP + j) * DH + db * 16 + 4 * g4;
+            *reinterpret_cast<float4*>(a.dKp + at) = make_float4(dK[rp][db][0] * a.scale, dK[rp][db][1] * a.scale, dK[rp][db][2] * a.scale, dK[rp][db][3] * a.scale);
+            *reinterpret_cast<float4*>(a.dVp + at) = make_float4(dV[rp][db][0], dV[rp][db][1], dV[rp][db][2], dV[rp][db][3]);
+        }
+}
+
+__global__ __launch_bounds__(256, 1) void xattn5_bwd_kv_kernel(X2Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) float wsh[NH * NH], wtsh[NH * NH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g4 = lane >> 4;
+    const int kb = wave >> 1, hh = wave & 1;
+    const int nkc = a.JP / 32;
+    // the nkc workgroups of a sample stream the SAME Q / dO rows: keep them on one XCD (one L2) -- block ids go round-robin over the 8
+    // XCDs, the remap hands each XCD a contiguous slab of logical ids
+    const int bid = (a.flags & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bid / nkc, j = (bid % nkc) * 32 + kb * 16 + c;                       // this lane's key
+    if (tid < NH * NH) { const float v = a.wth[tid]; wsh[tid] = v; wtsh[(tid & 7) * 8 + (tid >> 3)] = v; }
+    __syncthreads();                                             // (before any DMA is in flight)
+    bf16x8 awh, awl, awth, awtl;                                 // mix operands of this wave's 4 output heads
+    {
+        const MixA AW = mix_operand(wsh, lane), AWT = mix_operand(wtsh, lane);
+        awh = hh ? AW.hi[1] : AW.hi[0]; awl = hh ? AW.lo[1] : AW.lo[0];
+        awth = hh ? AWT.hi[1] : AWT.hi[0]; awtl = hh ? AWT.lo[1] : AWT.lo[0];
+    }
+    const float c1 = a.scale * 1.4426950408889634f;
+    const float kbias = a.valid[(size_t)b * a.JP + j] ? 0.f : NEG_MAX;
+    bf16x8 kf[NH][KS], vf[NH][KS];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[h][ks] = ldg16(a.Kp + ((size_t)(b * NH + h) * a.JP + j) * DH + ks * 32 + g4 * 8, true);
+            vf[h][ks] = ldg16(a.Vp + ((size_t)(b * NH + h) * a.JP + j) * DH + ks * 32 + g4 * 8, true);
+        }
+    // the fragments are complete HERE as far as the compiler's counter model goes: it cannot see the DMA pieces of the ring, and a
+    // wait it placed inside the loop for "the k-th oldest load" would drain the prefetched stage instead
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(kf[h][ks]), "v"(vf[h][ks]));
+    if (hh) kv_run<1>(smem, a, b, j, wave, lane, c1, kbias, kf, vf, awh, awl, awth, awtl);
+    else kv_run<0>(smem, a, b, j, wave, lane, c1, kbias, kf, vf, awh, awl, awth, awtl);
+}
+
 int check2(const amdnuwa_xattn_geom* g) {
     if (!g) return AMDNUWA_ERR_ARG;
     if (g->heads != NH || g->dim_head != DH || g->JP % 32 || g->JP > 288 || g->JP < g->T + 1) return AMDNUWA_ERR_UNSUPPORTED;
@@ -1035,14 +1268,14 @@ extern "C" int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     const int tiles = (g->n + 63) / 64;
     // tuning key 10: 0 = xattn4 (two waves per query tile, 4 heads each, two waves per SIMD), 2 = xattn3 (one wave, head mix on the
     // matrix pipe), 1 = xattn2 (one wave, VALU head mix)
-    if (g_amdnuwa_tuning[10] == 0) {
+    if ((g_amdnuwa_tuning[10] & 15) == 0) {
         const int lds4 = 2 * STAGE + 8 * XCH;
         (void)hipFuncSetAttribute((const void*)xattn4_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         hipLaunchKernelGGL(xattn4_fwd_kernel<false>, dim3(g->B * tiles), dim3(512), lds4, stream, a);
         LAUNCH_CHECK();
         return AMDNUWA_OK;
     }
-    auto kern = g_amdnuwa_tuning[10] == 1 ? xattn2_fwd_kernel : xattn3_fwd_kernel;
+    auto kern = (g_amdnuwa_tuning[10] & 15) == 1 ? xattn2_fwd_kernel : xattn3_fwd_kernel;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
     hipLaunchKernelGGL(kern, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
     LAUNCH_CHECK();
@@ -1086,9 +1319,39 @@ extern "C" int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.stats = const_cast<float*>(stats); a.dS = dS; a.Pm = Pm; a.dq = dq; a.lddq = lddq; a.part_th = part_th;
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
     const int tiles = (g->n + 63) / 64;
-    auto kern = g_amdnuwa_tuning[10] == 1 ? xattn2_bwd_kernel : xattn3_bwd_kernel;          // (0 and 2: xattn3_bwd)
+    a.nostore = (g_amdnuwa_tuning[10] & 16) ? 1 : 0;
+    auto kern = (g_amdnuwa_tuning[10] & 15) == 1 ? xattn2_bwd_kernel : xattn3_bwd_kernel;          // (0 and 2: xattn3_bwd)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
     hipLaunchKernelGGL(kern, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+// The recomputing backward: query side (dq, dW_th partials, nb / delta) + key side (dKp / dVp), no dS / P' arrays.
+extern "C" int amdnuwa_xattn2_bwd_rc_supported(const amdnuwa_xattn_geom* g) { return check2(g) == AMDNUWA_OK && g->n % 32 == 0; }
+extern "C" size_t amdnuwa_xattn2_bwd_rc_stats_bytes(const amdnuwa_xattn_geom* g) {
+    return amdnuwa_xattn2_bwd_rc_supported(g) ? (size_t)2 * g->B * NH * g->n * sizeof(float) : 0;
+}
+extern "C" int amdnuwa_xattn2_bwd_rc(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
+                                     const amdnuwa_xattn_kv* p, const float* w_th, const float* stats, uint16_t* dq, int lddq,
+                                     float* part_th, size_t part_bytes, float* nbd, size_t nbd_bytes, float* dKp, float* dVp,
+                                     hipStream_t stream) {
+    if (!amdnuwa_xattn2_bwd_rc_supported(g)) return g ? AMDNUWA_ERR_UNSUPPORTED : AMDNUWA_ERR_ARG;
+    if (!q || !dO || !p || !p->Kp || !p->Vp || !p->valid || !w_th || !stats || !dq || !dKp || !dVp || ldq % 8 || lddo % 8 || lddq % 4)
+        return AMDNUWA_ERR_ARG;
+    if (!part_th || part_bytes < amdnuwa_xattn2_bwd_workspace_bytes(g) || !nbd || nbd_bytes < amdnuwa_xattn2_bwd_rc_stats_bytes(g))
+        return AMDNUWA_ERR_WORKSPACE;
+    if (g->B <= 0 || g->n <= 0) return AMDNUWA_OK;
+    X2Args a{};
+    a.q = q; a.ldq = ldq; a.dO = dO; a.lddo = lddo; a.Kp = p->Kp; a.Vp = p->Vp; a.Vt = p->Vt; a.valid = p->valid; a.wth = w_th;
+    a.stats = const_cast<float*>(stats); a.dq = dq; a.lddq = lddq; a.part_th = part_th;
+    a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
+    a.nostore = 1; a.nbd = nbd; a.dKp = dKp; a.dVp = dVp; a.flags = (g_amdnuwa_tuning[10] & 32) ? 1 : 0;
+    (void)hipFuncSetAttribute((const void*)xattn3_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    hipLaunchKernelGGL(xattn3_bwd_kernel, dim3(g->B * ((g->n + 63) / 64)), dim3(256), 2 * STAGE, stream, a);
+    LAUNCH_CHECK();
+    (void)hipFuncSetAttribute((const void*)xattn5_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST5);
+    hipLaunchKernelGGL(xattn5_bwd_kv_kernel, dim3(g->B * (g->JP / 32)), dim3(256), 2 * ST5, stream, a);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

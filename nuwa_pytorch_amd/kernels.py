@@ -913,6 +913,39 @@ def xattn2_bwd(g, q, dO, pk, wth, stats):
     return dq, dS, Pm, dwth
 
 
+_XATTN_RC = os.environ.get('AMDNUWA_XATTN_RC', '0') == '1'
+
+
+def set_xattn_rc(on):
+    """the recomputing key side of the cross-attention backward (amdnuwa_xattn2_bwd_rc: no dS / Pm arrays, 3 GB less workspace and
+    HBM traffic per layer call at b = 128).  Off by default: the kernel is bound by LDS operand reads and the step measured 1.2 %
+    slower with it (558 vs 551 ms); env AMDNUWA_XATTN_RC=1 turns it on."""
+    global _XATTN_RC
+    _XATTN_RC = bool(on)
+
+
+def xattn2_bwd_rc_ok(g):
+    return _XATTN_RC and bool(_lib.lib().amdnuwa_xattn2_bwd_rc_supported(C.byref(g)))
+
+
+def xattn2_bwd_rc(g, q, dO, pk, wth, stats):
+    """query side + recomputing key side: returns dq BF [B*n, inner], dKp / dVp fp32 [B, h, JP, dh], dw_th fp32 [h, h]"""
+    L = _lib.lib()
+    inner = g.heads * g.dim_head
+    dev = q.hi.device
+    dq = empty_bf((g.B * g.n, inner), dev, lo=False)
+    nb = L.amdnuwa_xattn2_bwd_workspace_bytes(C.byref(g))
+    part = torch.empty((nb // (4 * g.heads * g.heads), g.heads * g.heads), dtype=torch.float32, device=dev)
+    sb = L.amdnuwa_xattn2_bwd_rc_stats_bytes(C.byref(g))
+    nbd = torch.empty(sb // 4, dtype=torch.float32, device=dev)
+    dKp = torch.empty((g.B, g.heads, g.JP, g.dim_head), dtype=torch.float32, device=dev)
+    dVp = torch.empty_like(dKp)
+    check(L.amdnuwa_xattn2_bwd_rc(C.byref(g), _p(q.hi), q.hi.stride(0), _p(dO.hi), dO.hi.stride(0), C.byref(pk.struct), _p(wth),
+                                  _p(stats), _p(dq.hi), inner, _p(part), nb, _p(nbd), sb, _p(dKp), _p(dVp), _stream()),
+          'amdnuwa_xattn2_bwd_rc')
+    return dq, dKp, dVp, colsum(part).reshape(g.heads, g.heads)
+
+
 def xattn_kv_grads(g, dS, Pm, q, dO):
     """dKp = scale * dS^T q, dVp = Pm^T dO per (sample, head): two batched TN GEMMs (reduction over queries).
     returns fp32 [B, h, JP, dh] x 2"""

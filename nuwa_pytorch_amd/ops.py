@@ -218,11 +218,14 @@ class XInner:
         d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
         dwo = torch.empty_like(wo)
         meta['wg'].run(lambda: K.gemm_tn(dy, o, dwo))
-        if Pm is None:
-            dq, dS, Pm, dwth = K.xattn2_bwd(g, q, d_o, pk, wth2, P)
+        if Pm is None and K.xattn2_bwd_rc_ok(g):
+            dq, dKp, dVp, dwth = K.xattn2_bwd_rc(g, q, d_o, pk, wth2, P)         # no dS / Pm arrays: the key side recomputes them
         else:
-            dq, dS, dwth = K.xattn_bwd(g, d_o, pk, wth2, P)
-        dKp, dVp = K.xattn_kv_grads(g, dS, Pm, q, d_o)
+            if Pm is None:
+                dq, dS, Pm, dwth = K.xattn2_bwd(g, q, d_o, pk, wth2, P)
+            else:
+                dq, dS, dwth = K.xattn_bwd(g, d_o, pk, wth2, P)
+            dKp, dVp = K.xattn_kv_grads(g, dS, Pm, q, d_o)
         dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=dy.lo is not None)
         rot = meta.get('rotary')
         if rot is not None:

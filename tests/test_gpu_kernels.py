@@ -647,6 +647,51 @@ def test_cross_attention_core(K, O, case, x3):
         report('xattn2_dnull_v' + tag, dnv2, nv.grad, 2 ** -6)
 
 
+@pytest.mark.parametrize('B,n,T', [(2, 96, 33), (1, 64, 256), (3, 160, 100), (2, 32, 287)])
+def test_cross_attention_bwd_recomputing_key_side(K, O, B, n, T):
+    """amdnuwa_xattn2_bwd_rc (query side + recomputing key side, no dS / Pm arrays) against the oracle's autograd and against the
+    dS / Pm + batched TN GEMM form it replaces"""
+    import ctypes as C
+    from nuwa_pytorch_amd import _lib
+    heads, dh = 8, 64
+    inner = heads * dh
+    torch.manual_seed(77 + n)
+    rnd = lambda *s: bf_round(torch.randn(*s))
+    q = rnd(B, n, heads, dh).requires_grad_(True)
+    kv = rnd(B, T, 2, heads, dh).requires_grad_(True)
+    nk, nv = rnd(heads, dh).requires_grad_(True), rnd(heads, dh).requires_grad_(True)
+    wth = (torch.randn(heads, heads) * 0.5 + torch.eye(heads)).requires_grad_(True)
+    mask = torch.rand(B, T) > 0.3
+    mask[0] = False
+    if B > 1:
+        mask[1, T // 2:] = False
+    o_ref = O.attention_core(q, kv[:, :, 0], kv[:, :, 1], nk, nv, wth, mask, dh ** -0.5)
+    do = rnd(B, n, heads, dh)
+    o_ref.backward(do)
+    g = K.x_geom(B, n, T, heads, dh)
+    assert _lib.lib().amdnuwa_xattn2_bwd_rc_supported(C.byref(g))
+    qp = to_bf_pair(q.detach().reshape(B * n, inner).to(DEV), False)
+    kvp = to_bf_pair(kv.detach().reshape(B * T, 2 * inner).to(DEV), False)
+    dop = to_bf_pair(do.reshape(B * n, inner).to(DEV), False)
+    w = wth.detach().to(DEV)
+    pk = K.xattn_pack(g, kvp, nk.detach().to(DEV), nv.detach().to(DEV), mask.to(torch.uint8).to(DEV))
+    _, stats = K.xattn2_fwd(g, qp, pk, w)
+    dq0, dS, Pm, dwth0 = K.xattn2_bwd(g, qp, dop, pk, w, stats)
+    dKp0, dVp0 = K.xattn_kv_grads(g, dS, Pm, qp, dop)
+    dq, dKp, dVp, dwth = K.xattn2_bwd_rc(g, qp, dop, pk, w, stats)
+    tag = f'[{B},{n},{T}]'
+    assert torch.equal(dq.hi, dq0.hi) and torch.equal(dwth, dwth0), 'the query side is the same kernel'
+    report('xattn_rc_dKp_vs_tn' + tag, dKp, dKp0, 2e-3)           # same bf16 operands, another summation order
+    report('xattn_rc_dVp_vs_tn' + tag, dVp, dVp0, 2e-3)
+    dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=False)
+    report('xattn_rc_dkv' + tag, dkv.hi.float().reshape(B, T, 2, heads, dh), kv.grad, 2 ** -6)
+    report('xattn_rc_dnull_k' + tag, dnk, nk.grad, 2 ** -6)
+    report('xattn_rc_dnull_v' + tag, dnv, nv.grad, 2 ** -6)
+    # repeatable bit for bit (fixed summation order, no atomics)
+    _, dKp2, dVp2, _ = K.xattn2_bwd_rc(g, qp, dop, pk, w, stats)
+    assert torch.equal(dKp, dKp2) and torch.equal(dVp, dVp2)
+
+
 @pytest.mark.parametrize('shape,kern,dil,n', [((2, 16, 16), (5, 3, 3), (1, 1, 1), None), ((3, 16, 16), (3, 3, 3), (4, 4, 4), 300),
                                               ((5, 16, 16), (5, 3, 3), (2, 2, 2), 1 + 4 * 256 + 100)])
 def test_sparse3dna_bwd_recomputing_key_side(K, O, shape, kern, dil, n):
