@@ -218,7 +218,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=None, help='host threads of the cpu_baseline leg (default 32; 0 = os.cpu_count())')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL over xGMI (default); gloo only for functional checks')
-    ap.add_argument('--collective', default='allreduce', choices=['allreduce', 'rs_ag'], help='gradient exchange per bucket')
+    ap.add_argument('--collective', default='allreduce', choices=['allreduce', 'rs_ag', 'native', 'native_rs_ag'],
+                    help="gradient exchange per bucket: torch.distributed collectives, or libamdnuwa's own RCCL communicator (native*)")
     ap.add_argument('--single-device', action='store_true', help='functional check only: every rank uses cuda:0 (with --backend gloo)')
     ap.add_argument('--no-tokenizer', action='store_true', help='skip the (untimed, separately reported) frozen-VAE tokenizer rate')
     args = ap.parse_args()

@@ -442,6 +442,30 @@ int amdnuwa_scale_grads(const amdnuwa_adamw_chunk* chunks, int nchunks, const fl
 int amdnuwa_adamw_step(const amdnuwa_adamw_chunk* chunks, int nchunks, float lr, float beta1, float beta2, float eps,
                        const float* clip_coef, amdnuwa_stream stream);
 
+/* ---- gradient exchange of the data-parallel step on RCCL (one process per GPU; SURVEY.md section 8 row e) --------------------
+ * The reference has no multi-GPU code of its own (train_nuwa.py runs one device); this is what nuwa_pytorch_amd/distributed.py's
+ * GradReducer(collective='native') puts under its flat fp32 buckets instead of torch.distributed.  librccl is dlopen()ed at the
+ * first call (amdnuwa_comm_available() == 0 and AMDNUWA_ERR_UNSUPPORTED without it).  Rank 0 draws the 128-byte id, the host side
+ * hands it to every rank (any channel: a torch.distributed object broadcast, a file, MPI), every rank calls _init on ITS device.
+ * All collectives are in place, enqueued on `stream`, and return before the data moved; AMDNUWA_ERR_COMM = an RCCL error
+ * (amdnuwa_comm_last_error() has its text, per thread). */
+#define AMDNUWA_COMM_ID_BYTES 128
+#define AMDNUWA_ERR_COMM -4
+typedef struct amdnuwa_comm amdnuwa_comm;
+int amdnuwa_comm_available(void);
+const char* amdnuwa_comm_last_error(void);
+int amdnuwa_comm_unique_id(void* id_out, size_t bytes);
+int amdnuwa_comm_init(amdnuwa_comm** out, const void* id, size_t id_bytes, int rank, int world, int device);
+int amdnuwa_comm_rank(const amdnuwa_comm* c);
+int amdnuwa_comm_world(const amdnuwa_comm* c);
+/* buf[0..count) <- sum (average != 0: mean, ncclAvg -- no separate division pass) over the ranks */
+int amdnuwa_comm_allreduce(amdnuwa_comm* c, float* buf, size_t count, int average, amdnuwa_stream stream);
+/* the same result over a store of world * shard floats as reduce-scatter + all-gather (rank r reduces buf + r * shard) */
+int amdnuwa_comm_reduce_scatter_allgather(amdnuwa_comm* c, float* buf, size_t shard, int average, amdnuwa_stream stream);
+/* bytes of buf <- rank `root`'s (the initial parameter broadcast) */
+int amdnuwa_comm_broadcast(amdnuwa_comm* c, void* buf, size_t bytes, int root, amdnuwa_stream stream);
+int amdnuwa_comm_destroy(amdnuwa_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -127,6 +127,16 @@ SIGNATURES = {
     'amdnuwa_rows_l2norm': (I, [P, I, I, I, I, P]),
     'amdnuwa_vqattn_core': (I, [P, P, P, P, I, I, I, I, P]),
     'amdnuwa_chan_layernorm': (I, [P, P, P, P, P, I, I, I, F, P]),
+    'amdnuwa_comm_available': (I, []),
+    'amdnuwa_comm_last_error': (C.c_char_p, []),
+    'amdnuwa_comm_unique_id': (I, [P, SZ]),
+    'amdnuwa_comm_init': (I, [P, P, SZ, I, I, I]),
+    'amdnuwa_comm_rank': (I, [P]),
+    'amdnuwa_comm_world': (I, [P]),
+    'amdnuwa_comm_allreduce': (I, [P, P, SZ, I, P]),
+    'amdnuwa_comm_reduce_scatter_allgather': (I, [P, P, SZ, I, P]),
+    'amdnuwa_comm_broadcast': (I, [P, P, SZ, I, P]),
+    'amdnuwa_comm_destroy': (I, [P]),
 }
 
 _lib = None

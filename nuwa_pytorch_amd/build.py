@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libamdnuwa.so')
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'amdnuwa.h')
-SOURCES = ['api.hip', 'gemm.hip', 'elementwise.hip', 'sparse3dna.hip', 'xattn.hip', 'xattn2.hip', 'vae.hip', 'optim.hip', 'decode.hip']
+SOURCES = ['api.hip', 'gemm.hip', 'elementwise.hip', 'sparse3dna.hip', 'xattn.hip', 'xattn2.hip', 'vae.hip', 'optim.hip', 'decode.hip', 'comm.hip']
 ARCH = 'gfx950'
 
 
@@ -54,7 +54,7 @@ def build(force=False, verbose=True):
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs)
+        run([_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl'])
     return LIB
 
 

@@ -21,6 +21,7 @@ extern "C" const char* amdnuwa_error_string(int code) {
     if (code == AMDNUWA_ERR_ARG) return "amdnuwa: invalid argument";
     if (code == AMDNUWA_ERR_UNSUPPORTED) return "amdnuwa: unsupported shape/configuration for the gfx950 kernels";
     if (code == AMDNUWA_ERR_WORKSPACE) return "amdnuwa: workspace missing or too small";
+    if (code == AMDNUWA_ERR_COMM) return "amdnuwa: RCCL error (amdnuwa_comm_last_error() has the text)";
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "amdnuwa: unknown error";
 }

@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define AMDNUWA_ERR_ARG -1
 #define AMDNUWA_ERR_UNSUPPORTED -2
 #define AMDNUWA_ERR_WORKSPACE -3
+#define AMDNUWA_ERR_COMM -4
 
 // runtime tuning knobs (amdnuwa_set_tuning): [0] NT GEMM variant, [1] TN target workgroups, [2] TN min rows per split
 extern int g_amdnuwa_tuning[16];

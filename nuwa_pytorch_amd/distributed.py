@@ -17,6 +17,10 @@ Design for 8 x MI355X (xGMI is point-to-point, 7 links per GPU):
     reduce-scatter + all-gather on the same flat buffer (padded to a multiple of the world size), the
     pair a direct all-to-all transport over the 7 links favours and the form a sharded optimiser would cut
     in the middle of;
+  * `collective='native'` / `'native_rs_ag'` put the same two forms straight on libamdnuwa's communicator (`amdnuwa_comm_*`,
+    include/amdnuwa.h: RCCL opened at run time, one communicator per process, ncclAvg instead of a division pass); the
+    128-byte id travels over the torch process group once, at construction.  With the torch collectives the mean uses
+    ReduceOp.AVG on the RCCL backend (gloo has no AVG: there the store is divided first);
   * gradient accumulation (the reference trainer runs 8 micro-steps per optimiser step, train_nuwa.py:243):
     micro-steps run under `no_sync()` -- their gradients only accumulate locally in the flat buffers -- and
     the LAST backward of the step, outside `no_sync()`, counts arrivals and launches the reductions.  A second
@@ -25,6 +29,7 @@ Design for 8 x MI355X (xGMI is point-to-point, 7 links per GPU):
 Works with the `gloo` backend on CPU tensors too (used by the world_size-2 tests).
 """
 import contextlib
+import ctypes as C
 
 import torch
 import torch.distributed as dist
@@ -63,9 +68,71 @@ def broadcast_parameters(module, src=0, process_group=None):
     return sent
 
 
+class NativeComm:
+    """libamdnuwa's RCCL communicator for this process (include/amdnuwa.h, amdnuwa_comm_*): rank 0 draws the id, the torch process
+    group carries it to the other ranks, every rank joins on its current HIP device."""
+
+    def __init__(self, process_group=None, device=None):
+        from . import _lib
+        self._lib, self._check = _lib.lib(), _lib.check
+        if not self._lib.amdnuwa_comm_available():
+            raise RuntimeError('libamdnuwa: librccl could not be opened (amdnuwa_comm_available() == 0)')
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            self._check(self._lib.amdnuwa_comm_unique_id(ident, 128), 'amdnuwa_comm_unique_id')
+        box = [bytes(ident.raw)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                                       group=process_group)
+        self._h = C.c_void_p()
+        self._check(self._lib.amdnuwa_comm_init(C.byref(self._h), box[0], 128, self.rank, self.world, self.device), 'amdnuwa_comm_init')
+
+    def _rc(self, rc, what):
+        if rc == -4:
+            raise RuntimeError(f'{what}: {self._lib.amdnuwa_comm_last_error().decode()}')
+        self._check(rc, what)
+
+    def allreduce(self, t, average=True, stream=None):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        self._rc(self._lib.amdnuwa_comm_allreduce(self._h, t.data_ptr(), t.numel(), int(average), st), 'amdnuwa_comm_allreduce')
+
+    def reduce_scatter_allgather(self, t, average=True, stream=None):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() % self.world == 0
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        self._rc(self._lib.amdnuwa_comm_reduce_scatter_allgather(self._h, t.data_ptr(), t.numel() // self.world, int(average), st),
+                 'amdnuwa_comm_reduce_scatter_allgather')
+
+    def broadcast(self, t, root=0, stream=None):
+        assert t.is_cuda and t.is_contiguous()
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        self._rc(self._lib.amdnuwa_comm_broadcast(self._h, t.data_ptr(), t.numel() * t.element_size(), int(root), st), 'amdnuwa_comm_broadcast')
+
+    def close(self):
+        if self._h:
+            self._lib.amdnuwa_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Enqueued:
+    """work handle of a collective libamdnuwa enqueued on the communication stream: finish() orders the compute stream after it"""
+
+    def wait(self):
+        return True
+
+
 class GradReducer:
     def __init__(self, module, process_group=None, bucket_fn=_layer_key, average=True, collective='allreduce'):
-        if collective not in ('allreduce', 'rs_ag'):
+        if collective not in ('allreduce', 'rs_ag', 'native', 'native_rs_ag'):
             raise ValueError(collective)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -93,6 +160,12 @@ class GradReducer:
         self._by_param = {id(p): b for b in self.buckets for p in b['params']}
         self.cuda = bool(self.buckets) and self.buckets[0]['flat'].is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
+        self.native = None
+        if collective.startswith('native') and self.world > 1:
+            if not self.cuda or any(b['flat'].dtype != torch.float32 for b in self.buckets):
+                raise RuntimeError("GradReducer(collective='native'): fp32 gradients on a HIP device")
+            self.native = NativeComm(process_group)
+        self._avg_op = bool(self.cuda and dist.is_initialized() and dist.get_backend(process_group) == 'nccl')
         self._hooks = []
         for b in self.buckets:
             for p in b['params']:
@@ -141,13 +214,23 @@ class GradReducer:
             self._launch(b)
 
     def _reduce(self, b):
+        if self.native is not None:                       # (already on the communication stream)
+            if self.collective == 'native':
+                self.native.allreduce(b['flat'], self.average)
+            else:
+                self.native.reduce_scatter_allgather(b['store'], self.average)
+            return _Enqueued()
+        op = dist.ReduceOp.SUM
         if self.average:
-            b['store'].div_(self.world)
-        if self.collective == 'allreduce':
-            return dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if self._avg_op:
+                op = dist.ReduceOp.AVG                    # RCCL divides inside the collective: no extra pass over the bucket
+            else:
+                b['store'].div_(self.world)
+        if self.collective in ('allreduce', 'native'):
+            return dist.all_reduce(b['flat'], op=op, group=self.pg, async_op=True)
         shard = b['store'].numel() // self.world
         mine = b['store'][self.rank * shard:(self.rank + 1) * shard]
-        dist.reduce_scatter_tensor(mine, b['store'], op=dist.ReduceOp.SUM, group=self.pg)
+        dist.reduce_scatter_tensor(mine, b['store'], op=op, group=self.pg)
         return dist.all_gather_into_tensor(b['store'], mine, group=self.pg, async_op=True)
 
     def _launch(self, b):

@@ -33,6 +33,14 @@ def test_argument_validation_without_gpu():
     assert L.amdnuwa_sparse3dna_bwd_workspace_bytes(ctypes.byref(g)) == 0
     assert L.amdnuwa_xattn_jp(256) == 288 and L.amdnuwa_xattn_jp(7) == 32
     assert b'workspace' in L.amdnuwa_error_string(-3)
+    # the RCCL communicator entry points: argument checks come before librccl is touched
+    h = ctypes.c_void_p()
+    assert L.amdnuwa_comm_init(ctypes.byref(h), None, 128, 0, 1, 0) == -1
+    assert L.amdnuwa_comm_init(ctypes.byref(h), ctypes.create_string_buffer(128), 128, 2, 2, 0) == -1     # rank >= world
+    assert L.amdnuwa_comm_unique_id(ctypes.create_string_buffer(16), 16) == -1
+    assert L.amdnuwa_comm_allreduce(None, None, 4, 1, None) == -1
+    assert L.amdnuwa_comm_destroy(None) == 0
+    assert b'RCCL' in L.amdnuwa_error_string(-4)
 
 
 def test_no_product_import_of_oracle():

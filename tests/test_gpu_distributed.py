@@ -124,3 +124,25 @@ def test_bench_py_two_ranks_end_to_end():
     assert out['roofline']['launches'] > 0 and 0 < out['roofline']['frac'] < 1
     assert out['precision_mode'] == 'bf16x3-fwd' and out['fast_mode']['dtype'] == 'bf16' and out['fast_mode']['value'] > 0
     assert 8.5 < out['config']['loss'] < 10.0                      # ~ln(8192) at random init
+
+
+def test_native_comm_single_rank():
+    """libamdnuwa's own RCCL communicator (amdnuwa_comm_*): id, init on this device, the three collectives the reducer uses, destroy.
+    One rank is all a 1-GPU box allows (RCCL refuses two ranks on one device): a world of 1 must leave the buffers as they are."""
+    from nuwa_pytorch_amd.distributed import NativeComm
+    comm = NativeComm()
+    assert (comm.rank, comm.world) == (0, 1)
+    assert comm._lib.amdnuwa_comm_rank(comm._h) == 0 and comm._lib.amdnuwa_comm_world(comm._h) == 1
+    x = torch.randn(1 << 20, device='cuda')
+    ref = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    comm.allreduce(x, average=True, stream=side)
+    comm.reduce_scatter_allgather(x, average=False, stream=side)
+    comm.broadcast(x, root=0, stream=side)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    with pytest.raises(RuntimeError):
+        comm._rc(comm._lib.amdnuwa_comm_broadcast(comm._h, x.data_ptr(), 16, 3, None), 'amdnuwa_comm_broadcast')      # root outside the world
+    comm.close()
