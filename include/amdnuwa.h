@@ -289,7 +289,8 @@ int amdnuwa_decode_shift(const uint16_t* h_hi, const uint16_t* h_lo, uint16_t* c
 /* The norms around a block for the one new row per sample, in one launch (SandwichNorm, np.py:112-128, + the residual add of
  * Transformer.forward, np.py:1175-1180):  x_new = resid + LN(y; w, b)  [skipped when resid == NULL: x_new = y, fp32];
  * h = LN(x_new; next_w, next_b)  [skipped when next_w == NULL];  with cache_hi != NULL h also becomes row pos of
- * cache [B, cache_rows, D] and out = shift(h)[pos] as amdnuwa_decode_shift does, else out = h.  y: fp32 or (y_is_bf16) bf16. */
+ * cache [B, cache_rows, D] and out = shift(h)[pos] as amdnuwa_decode_shift does, else out = h.  y: fp32 or (y_is_bf16) bf16.
+ * fmap = -1 selects ShiftAudioTokens (np.py:157-183): the first half of the channels comes from row pos - 1 (<bos> included). */
 int amdnuwa_decode_ln(const void* y, int y_is_bf16, const float* resid, const float* w, const float* b, const float* next_w,
                       const float* next_b, float* x_new, uint16_t* cache_hi, uint16_t* cache_lo, uint16_t* out_hi,
                       uint16_t* out_lo, const int* pos, int B, int cache_rows, int D, int fmap, float eps,

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void decode_ln_kernel(const void* __restrict__
     if (c_hi) {
         pos = pos_p[0];
         if (pos < 0 || pos >= cache_rows) return;
-        if (pos > 0) { const int p = pos - 1; wq = p % fmap; yq = (p / fmap) % fmap; }
+        if (pos > 0 && fmap > 0) { const int p = pos - 1; wq = p % fmap; yq = (p / fmap) % fmap; }
     }
     const size_t crow = ((size_t)bidx * cache_rows + pos) * D;
     const int qd = D >> 2;
@@ -156,11 +156,15 @@ __global__ __launch_bounds__(256) void decode_ln_kernel(const void* __restrict__
         if (c_hi) {
             *reinterpret_cast<uint2*>(c_hi + crow + e) = oh;
             if (c_lo) *reinterpret_cast<uint2*>(c_lo + crow + e) = ol;
-            if (pos > 0 && e < 2 * qd) {             // D % 16 == 0: a 4-element group never straddles a quarter
+            if (fmap > 0 && pos > 0 && e < 2 * qd) {  // D % 16 == 0: a 4-element group never straddles a quarter
                 const bool up = e < qd, has = up ? (yq > 0) : (wq > 0);
                 const size_t srow = crow - (size_t)(up ? fmap : 1) * D;
                 oh = has ? *reinterpret_cast<const uint2*>(c_hi + srow + e) : make_uint2(0u, 0u);
                 ol = (has && c_lo) ? *reinterpret_cast<const uint2*>(c_lo + srow + e) : make_uint2(0u, 0u);
+            } else if (fmap < 0 && e < 2 * qd) {      // ShiftAudioTokens (np.py:157-183): the first half of the channels comes from
+                const size_t srow = crow - (size_t)D; //  the previous row, <bos> included; zeros for row 0
+                oh = pos > 0 ? *reinterpret_cast<const uint2*>(c_hi + srow + e) : make_uint2(0u, 0u);
+                ol = (pos > 0 && c_lo) ? *reinterpret_cast<const uint2*>(c_lo + srow + e) : make_uint2(0u, 0u);
             }
         }
         *reinterpret_cast<uint2*>(o_hi + row + e) = oh;
@@ -466,7 +470,7 @@ extern "C" int amdnuwa_decode_ln(const void* y, int y_is_bf16, const float* resi
     if (!resid && y_is_bf16) return AMDNUWA_ERR_ARG;                 // without a post-norm, y IS the fp32 stream row
     if (next_w && (!next_b || !out_hi)) return AMDNUWA_ERR_ARG;
     if (!next_w && !resid) return AMDNUWA_ERR_ARG;
-    if (cache_hi && (!pos || fmap <= 0 || cache_rows <= 0 || D % 16 || !next_w)) return AMDNUWA_ERR_ARG;
+    if (cache_hi && (!pos || fmap == 0 || fmap < -1 || cache_rows <= 0 || D % 16 || !next_w)) return AMDNUWA_ERR_ARG;
     if (cache_hi && ((cache_lo != nullptr) != (out_lo != nullptr))) return AMDNUWA_ERR_ARG;
     if (B <= 0) return AMDNUWA_OK;
     if (y_is_bf16)

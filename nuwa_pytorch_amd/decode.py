@@ -8,26 +8,49 @@ text, FeedForward, the norms), so row `pos` of the decoder depends only on rows 
   * the packed text keys / values of the cross-attention (computed once),
 and computes ONE new row per call with the same libamdnuwa kernels the training path uses (GEMMs, LayerNorms, GEGLU, the
 cross-attention core with n = 1) plus the two single-row kernels of csrc/decode.hip.  The row index lives in device memory,
-so the per-token work of a whole guided step can be captured once in a HIP graph and replayed for every token."""
+so the per-token work of a whole guided step can be captured once in a HIP graph and replayed for every token.
+
+NUWAVideoAudio.generate (np.py:2111-2222) decodes two interleaved streams through the DualModalityDecoder (np.py:1299-1487).  Every
+stage is row-causal there too: the audio window attention looks back only, and the chunked video <-> audio attention lets frame t
+of one stream see frame t - 1 of the other (np.py:908-1067), which is complete -- and final -- by the time any row of frame t is
+computed, because the sampler alternates one video frame / one audio frame.  DualIncrementalDecoder therefore keeps one
+IncrementalDecoder per modality (own position counter) and links the two at the cross-modality layers: each stream stores its
+layer-input rows projected with the OTHER direction's to_kv, and attends the other stream's stored rows of the matching frame."""
 import torch
+import torch.nn.functional as F
 
 from . import kernels as K
 from . import ops
 
 
 class _Block:
-    __slots__ = ('kind', 'sn', 'inner', 'fmap', 'hcache', 'kvcache', 'geom', 'pk', 'xg', 'o_const')
+    """one sub-block of a row program: out_slot <- out_slot + post(inner(pre(in_slot)));  pre / post = None for the un-normed modules
+    of the reversible dual decoder's cross-modality layer"""
+    __slots__ = ('kind', 'pre', 'post', 'inner', 'fmap', 'hcache', 'kvcache', 'geom', 'pk', 'xg', 'o_const', 'xm', 'src', 'dst',
+                 'store_before', 'store_after')
+
+
+def _cast_row(x, lo):
+    out = K.empty_bf(tuple(x.shape), x.device, lo=lo)
+    K.cast_pad(x, out)
+    return out
 
 
 class IncrementalDecoder:
     """One decoder pass (conditioned or not) over a growing sequence.  transformer: nuwa_pytorch.Transformer (non-reversible)
-    whose blocks are all on the fused HIP path; context [B, T, D] fp32 and context_mask [B, T] bool as in Transformer.forward."""
+    whose blocks are all on the fused HIP path; context [B, T, D] fp32 and context_mask [B, T] bool as in Transformer.forward.
 
-    def __init__(self, transformer, batch, max_rows, context, context_mask, pos_dev):
-        from .nuwa_pytorch import Attention, FeedForward, Sparse3DNA
+    Instead of `transformer`, `block_list` gives the row program explicitly: dicts with `mod` (a SandwichNorm block, or a bare
+    FeedForward / CrossModalityCrossAttention), optional `context` (text rows for a cross-attention), `xm` (_XmDirection this block
+    attends through), `dst` (the residual half it adds into: reversible stacks keep two, np.py's reversible.py; the block reads the
+    OTHER half), `store_before` / `store_after` (_XmDirection objects that take this row's input / output as context)."""
+
+    def __init__(self, transformer, batch, max_rows, context, context_mask, pos_dev, block_list=None, halves=1):
+        from .nuwa_pytorch import Attention, FeedForward, Sparse3DNA, SandwichNorm
+        from .video_audio import SparseCausal2DNA
         dev = context.device
-        self.B, self.rows, self.pos_dev = batch, max_rows, pos_dev
-        lo = K.want_lo()
+        self.B, self.rows, self.pos_dev, self.halves = batch, max_rows, pos_dev, halves
+        lo = self.lo = K.want_lo()
         D = context.shape[-1]
         ctx_bf = ops._ctx_to_bf(context)
         mask_u8 = context_mask.to(torch.uint8).contiguous() if context_mask is not None else None
@@ -35,62 +58,99 @@ class IncrementalDecoder:
         # output is the same row for every position -- (sum_h W_th[g, h]) * null_v[g] -- and is computed once
         all_masked = context_mask is not None and not bool(context_mask.any())
         self.blocks = []
-        for attn, cross, ff in transformer.layers:
-            for sn, ctx_arg in ((attn, None), (cross, context), (ff, None)):
-                if sn is None:
-                    continue
-                found = sn._inner(ctx_arg, seq_len=max_rows)
-                if found is None:
-                    raise NotImplementedError('IncrementalDecoder: a decoder block is not on the libamdnuwa path')
-                inner, fmap = found
-                blk = _Block()
-                blk.sn, blk.inner, blk.fmap = sn, inner, fmap
-                blk.hcache = K.zeros_bf((batch, max_rows, D), dev, lo=lo) if fmap is not None else None
-                blk.kvcache = blk.geom = blk.pk = blk.xg = blk.o_const = None
-                if isinstance(inner, Sparse3DNA):
-                    if not inner.causal:
-                        raise NotImplementedError('IncrementalDecoder needs causal Sparse3DNA')
-                    blk.kind = 's3'
-                    blk.geom = K.s3_geom(batch, max_rows, inner.video_shape, inner.kernel_size, inner.dilation, inner.heads,
-                                         inner.dim_head)
-                    blk.kvcache = K.zeros_bf((batch, max_rows, 2 * inner.heads * inner.dim_head), dev, lo=lo)
-                elif isinstance(inner, Attention):
-                    blk.kind = 'x'
-                    p = inner._params()
-                    W = ops.XInner.weights(inner._cache, p)
-                    blk.xg = K.x_geom(batch, 1, context.shape[1], inner.heads, inner.dim_head)
-                    kv = K.gemm_nt(ctx_bf, W['kv'], out_bf16=True)                 # text keys / values: once per sequence
-                    blk.pk = K.xattn_pack(blk.xg, kv, p[0].detach().reshape(inner.heads, inner.dim_head).contiguous(),
-                                          p[1].detach().reshape(inner.heads, inner.dim_head).contiguous(), mask_u8)
-                    if all_masked:
-                        q0 = K.zeros_bf((batch, inner.heads * inner.dim_head), dev, lo=lo)
-                        blk.o_const = K.xattn_decode(blk.xg, q0, blk.pk, p[2].detach().reshape(inner.heads, inner.heads).contiguous())
-                elif isinstance(inner, FeedForward):
-                    blk.kind = 'ff'
+        if block_list is None:
+            block_list = [dict(mod=sn, context=ctx_arg) for attn, cross, ff in transformer.layers
+                          for sn, ctx_arg in ((attn, None), (cross, context), (ff, None)) if sn is not None]
+        for spec in block_list:
+            mod, ctx_arg = spec['mod'], spec.get('context')
+            blk = _Block()
+            blk.kvcache = blk.geom = blk.pk = blk.xg = blk.o_const = blk.hcache = blk.fmap = None
+            blk.xm = spec.get('xm')
+            blk.dst = spec.get('dst', 0)
+            blk.src = (1 - blk.dst) if halves == 2 else 0
+            blk.store_before, blk.store_after = spec.get('store_before', ()), spec.get('store_after', ())
+            if isinstance(mod, SandwichNorm):
+                blk.pre = (mod.prenorm.weight.detach(), mod.prenorm.bias.detach())
+                blk.post = (mod.postnorm.weight.detach(), mod.postnorm.bias.detach())
+                if blk.xm is not None:
+                    inner, fmap = mod.fn, None
                 else:
-                    raise NotImplementedError(f'IncrementalDecoder: no single-row path for {type(inner).__name__}')
-                self.blocks.append(blk)
+                    found = mod._inner(ctx_arg, seq_len=max_rows)
+                    if found is None and isinstance(mod.fn, SparseCausal2DNA) and mod.fn._hip_ok():
+                        found = (mod.fn, None)                         # audio tower built without the channel shift
+                    if found is None:
+                        raise NotImplementedError('IncrementalDecoder: a decoder block is not on the libamdnuwa path')
+                    inner, fmap = found
+            else:                                                      # bare module: no norms, no shift
+                blk.pre = blk.post = None
+                inner, fmap = mod, None
+                if not (blk.xm is not None or (isinstance(mod, FeedForward) and not mod._dropout_active())):
+                    raise NotImplementedError(f'IncrementalDecoder: no single-row path for a bare {type(mod).__name__}')
+            blk.inner, blk.fmap = inner, fmap
+            blk.hcache = K.zeros_bf((batch, max_rows, D), dev, lo=lo) if fmap is not None else None
+            if blk.xm is not None:
+                blk.kind = 'xm'
+            elif isinstance(inner, SparseCausal2DNA):               # the audio window attention IS a 3DNA over a (time, 1, 1) grid
+                blk.kind = 's3'
+                blk.geom = K.s3_geom(batch, max_rows, (max(max_rows - 1, 1), 1, 1), (inner.kernel_size[0], 1, 1),
+                                     (inner.dilation[0], 1, 1), inner.heads, inner.dim_head)
+                blk.kvcache = K.zeros_bf((batch, max_rows, 2 * inner.heads * inner.dim_head), dev, lo=lo)
+            elif isinstance(inner, Sparse3DNA):
+                if not inner.causal:
+                    raise NotImplementedError('IncrementalDecoder needs causal Sparse3DNA')
+                blk.kind = 's3'
+                blk.geom = K.s3_geom(batch, max_rows, inner.video_shape, inner.kernel_size, inner.dilation, inner.heads,
+                                     inner.dim_head)
+                blk.kvcache = K.zeros_bf((batch, max_rows, 2 * inner.heads * inner.dim_head), dev, lo=lo)
+            elif isinstance(inner, Attention):
+                blk.kind = 'x'
+                p = inner._params()
+                W = ops.XInner.weights(inner._cache, p)
+                blk.xg = K.x_geom(batch, 1, context.shape[1], inner.heads, inner.dim_head)
+                kv = K.gemm_nt(ctx_bf, W['kv'], out_bf16=True)                 # text keys / values: once per sequence
+                blk.pk = K.xattn_pack(blk.xg, kv, p[0].detach().reshape(inner.heads, inner.dim_head).contiguous(),
+                                      p[1].detach().reshape(inner.heads, inner.dim_head).contiguous(), mask_u8)
+                if all_masked:
+                    q0 = K.zeros_bf((batch, inner.heads * inner.dim_head), dev, lo=lo)
+                    blk.o_const = K.xattn_decode(blk.xg, q0, blk.pk, p[2].detach().reshape(inner.heads, inner.heads).contiguous())
+            elif isinstance(inner, FeedForward):
+                blk.kind = 'ff'
+            else:
+                raise NotImplementedError(f'IncrementalDecoder: no single-row path for {type(inner).__name__}')
+            self.blocks.append(blk)
+
+    def _enter(self, x, nxt):
+        """the operand row of block `nxt` from its fp32 input row: pre-norm (+ token shift through the block's cache), or a plain
+        cast for an un-normed block"""
+        if nxt is None:
+            return None
+        if nxt.pre is None:
+            return _cast_row(x, self.lo)
+        return K.decode_ln(x, None, None, nxt.pre, cache=nxt.hcache, pos_dev=self.pos_dev, fmap=nxt.fmap or 0)[1]
 
     def step(self, x):
         """x fp32 [B, D]: decoder input row `pos` of every sample -> that row after all layers (before the final norm)"""
         fast = ops._fast()
         blocks = self.blocks
-
-        def pre(blk):
-            return (blk.sn.prenorm.weight.detach(), blk.sn.prenorm.bias.detach())
-        first = blocks[0]
-        _, h = K.decode_ln(x, None, None, pre(first), cache=first.hcache, pos_dev=self.pos_dev, fmap=first.fmap or 0)
+        state = [x] * self.halves
+        h = self._enter(x, blocks[0])
         for i, blk in enumerate(blocks):
-            sn, inner = blk.sn, blk.inner
-            p = inner._params()
+            inner = blk.inner
+            for d in blk.store_before:
+                d.store(state[blk.src])
+            raw = blk.post is None                  # (an un-normed block adds its fp32 output itself)
             if blk.kind == 's3':
+                p = inner._params()
                 W = ops.S3Inner.weights(inner._cache, p)
                 g = blk.geom
                 rel = p[5].detach().contiguous() if len(p) > 5 else None
                 qkv = K.gemm_nt(h, W['qkv'], out_bf16=True)
                 o = K.s3_decode(g, qkv, blk.kvcache, self.pos_dev, p[2].detach().reshape(g.heads, g.heads).contiguous(), rel)
-                y = K.gemm_nt(o, W['out'], bias=p[4].detach(), out_bf16=fast)
+                y = K.gemm_nt(o, W['out'], bias=p[4].detach(), out_bf16=fast and not raw)
+            elif blk.kind == 'xm':
+                y = blk.xm.attend(h)
             elif blk.kind == 'x':
+                p = inner._params()
                 W = ops.XInner.weights(inner._cache, p)
                 g = blk.xg
                 wth = p[2].detach().reshape(g.heads, g.heads).contiguous()
@@ -99,17 +159,175 @@ class IncrementalDecoder:
                 else:
                     q = K.gemm_nt(h, W['q'], out_bf16=True)
                     o = K.xattn_decode(g, q, blk.pk, wth)
-                y = K.gemm_nt(o, W['out'], out_bf16=fast)
+                y = K.gemm_nt(o, W['out'], out_bf16=fast and not raw)
             else:
-                W = ops.FFInner.weights(inner._cache, p)
+                W = ops.FFInner.weights(inner._cache, inner._params())
                 u = K.gemm_nt(h, W['w1'], out_bf16=True)
                 gg = K.geglu_fwd(u, W['FP'], interleaved=True)
-                y = K.gemm_nt(gg, W['w2'], out_bf16=fast)
-            # post-norm + residual, the next block's pre-norm and its token shift (cache write + gather): one launch
+                y = K.gemm_nt(gg, W['w2'], out_bf16=fast and not raw)
             nxt = blocks[i + 1] if i + 1 < len(blocks) else None
-            x, h = K.decode_ln(y, x, (sn.postnorm.weight.detach(), sn.postnorm.bias.detach()), pre(nxt) if nxt else None,
-                               cache=nxt.hcache if nxt else None, pos_dev=self.pos_dev, fmap=(nxt.fmap or 0) if nxt else 0)
-        return x
+            if not raw:
+                # post-norm + residual, the next block's pre-norm and its token shift (cache write + gather): one launch
+                fused = nxt is not None and nxt.pre is not None
+                x, h = K.decode_ln(y, state[blk.dst], blk.post, nxt.pre if fused else None, cache=nxt.hcache if fused else None,
+                                   pos_dev=self.pos_dev, fmap=(nxt.fmap or 0) if fused else 0)
+                if nxt is not None and not fused:
+                    h = _cast_row(x, self.lo)
+            else:
+                x = state[blk.dst] + y
+                h = self._enter(x, nxt)
+            state[blk.dst] = x
+            for d in blk.store_after:
+                d.store(x)
+        return x if self.halves == 1 else (state[0] + state[1]) * 0.5
+
+
+class _XmDirection:
+    """One direction of a cross-modality layer (CrossModalityCrossAttention `mod`, np.py:908-1067) for row-at-a-time decoding: the
+    QUERY stream calls attend(), the CONTEXT stream calls store() with the rows `mod` would see as context.  Query row r (0 = start
+    token) belongs to frame (r - 1) // chunk_size and attends a learned null key + context frame f of the sequence
+    [context_chunk_size - 1 zero rows, the context stream's rows]: i.e. the other stream one frame EARLIER (frame 0: zero rows + its
+    start token), complete by the time any query row of frame f exists.  The start-token row outputs 0.  The Conv3d talking heads
+    carry a BIAS: it adds bias[g] * (null_v[g] + sum_j v_j[g]) to the head output, a per-frame constant kept as a correction row."""
+
+    def __init__(self, mod, batch, ctx_rows, dev, lo):
+        from torch import nn
+        if not (isinstance(mod.norm, nn.Identity) and isinstance(mod.context_norm, nn.Identity) and mod.has_start_token and
+                mod.context_has_start_token and mod.dim_head in (32, 64) and mod.heads <= 8 and mod.context_chunk_size + 1 <= 288):
+            raise NotImplementedError('cached decoding: this CrossModalityCrossAttention configuration is not on the libamdnuwa path')
+        self.mod, self.B, self.lo = mod, batch, lo
+        self.c, self.cc = mod.chunk_size, mod.context_chunk_size
+        self.inner = mod.heads * mod.dim_head
+        # context rows under mod.to_kv: cc - 1 zero rows (to_kv has no bias), then context row r at cc - 1 + r, so that context
+        # frame f is rows [f * cc, (f + 1) * cc)
+        self.kv = K.zeros_bf((batch, self.cc - 1 + ctx_rows, 2 * self.inner), dev, lo=lo)
+        self.g = K.x_geom(batch, 1, self.cc, mod.heads, mod.dim_head)
+        self.n_ctx, self.n_q, self.frame, self.pk, self.corr = 0, 0, -1, None, None
+
+    def _weights(self):
+        m, h = self.mod, self.mod.heads
+        p = (m.null_k.detach().reshape(h, 1, -1), m.null_v.detach().reshape(h, 1, -1), m.talking_heads.weight.detach().reshape(h, h, 1, 1),
+             m.to_q.weight, m.to_kv.weight, m.to_out.weight)
+        return ops.XInner.weights(m._cache, p)
+
+    def store(self, x):
+        """x fp32 [B, D]: the next context row"""
+        kv = K.gemm_nt(_cast_row(x, self.lo), self._weights()['kv'], out_bf16=True)
+        at = self.cc - 1 + self.n_ctx
+        self.kv.hi[:, at].copy_(kv.hi)
+        if self.kv.lo is not None:
+            self.kv.lo[:, at].copy_(kv.lo)
+        self.n_ctx += 1
+
+    def _pack(self, f):
+        m, cc = self.mod, self.cc
+        if self.n_ctx < f * cc + 1:
+            raise RuntimeError('cached decoding: the other stream has not produced the frame this row attends')
+        sl = slice(f * cc, (f + 1) * cc)
+        kv = K.BF(self.kv.hi[:, sl].reshape(self.B * cc, 2 * self.inner).contiguous(),
+                  self.kv.lo[:, sl].reshape(self.B * cc, 2 * self.inner).contiguous() if self.kv.lo is not None else None)
+        h, dh = m.heads, m.dim_head
+        self.pk = K.xattn_pack(self.g, kv, m.null_k.detach().reshape(h, dh).contiguous(), m.null_v.detach().reshape(h, dh).contiguous(), None)
+        v = kv.hi[:, self.inner:].float()
+        if kv.lo is not None:
+            v = v + kv.lo[:, self.inner:].float()
+        vsum = m.null_v.detach().reshape(1, h, dh) + v.reshape(self.B, cc, h, dh).sum(1)
+        self.corr = F.linear((m.talking_heads.bias.detach()[None, :, None] * vsum).reshape(self.B, self.inner), m.to_out.weight.detach())
+        self.frame = f
+
+    def attend(self, h):
+        """h BF [B, D]: the operand row of the next query (pre-normed by the caller where the block has norms) -> fp32 [B, D]"""
+        r, m = self.n_q, self.mod
+        self.n_q += 1
+        if r == 0:
+            return torch.zeros((self.B, m.to_out.weight.shape[0]), dtype=torch.float32, device=h.hi.device)
+        f = (r - 1) // self.c
+        if f != self.frame:
+            self._pack(f)
+        W = self._weights()
+        q = K.gemm_nt(h, W['q'], out_bf16=True)
+        o = K.xattn_decode(self.g, q, self.pk, m.talking_heads.weight.detach().reshape(m.heads, m.heads).contiguous())
+        return K.gemm_nt(o, W['out'], out_bf16=False) + self.corr
+
+
+class DualIncrementalDecoder:
+    """One pass (conditioned or text-masked) of the dual decoder -- DualModalityDecoder (np.py:1299-1487) or
+    ReversibleDualModalityDecoder (np.py:1489-1655 + reversible_video_audio.py) -- over two growing sequences: step('v' | 'a', x)
+    takes the decoder input row of the next position of that stream and returns the row after all layers (before the final norm)."""
+
+    def __init__(self, dec, batch, rows_v, rows_a, context, context_mask):
+        from .video_audio import DualModalityDecoder, ReversibleDualModalityDecoder
+        dev, lo = context.device, K.want_lo()
+        self.pos = {'v': torch.zeros(1, dtype=torch.int32, device=dev), 'a': torch.zeros(1, dtype=torch.int32, device=dev)}
+        lists = {'v': [], 'a': []}
+        if isinstance(dec, DualModalityDecoder):
+            halves = 1
+            for blocks, kind in zip(dec.layers, dec.layer_types):
+                if kind == 'intra_modality':
+                    for key, (attn, cross, ff) in zip('va', blocks):
+                        lists[key] += [dict(mod=attn), dict(mod=cross, context=context), dict(mod=ff)]
+                else:                               # both directions read the layer INPUT of the other stream (np.py:1467-1470)
+                    (v_x, v_ff), (a_x, a_ff) = blocks
+                    v_from_a, a_from_v = _XmDirection(v_x.fn, batch, rows_a, dev, lo), _XmDirection(a_x.fn, batch, rows_v, dev, lo)
+                    lists['v'] += [dict(mod=v_x, xm=v_from_a, store_before=(a_from_v,)), dict(mod=v_ff)]
+                    lists['a'] += [dict(mod=a_x, xm=a_from_v, store_before=(v_from_a,)), dict(mod=a_ff)]
+        elif isinstance(dec, ReversibleDualModalityDecoder):
+            halves = 2                              # y1 = x1 + f(x2), y2 = x2 + g(y1) per block; the output is the mean of the halves
+            for (f, g, j, k), kind in zip(dec.layers, dec.layer_types):
+                if kind == 'intra_modality_self_attn':
+                    lists['v'] += [dict(mod=f, dst=0), dict(mod=g, dst=1)]
+                    lists['a'] += [dict(mod=j, dst=0), dict(mod=k, dst=1)]
+                elif kind == 'intra_modality_cross_attn':
+                    lists['v'] += [dict(mod=f, context=context, dst=0), dict(mod=g, dst=1)]
+                    lists['a'] += [dict(mod=j, context=context, dst=0), dict(mod=k, dst=1)]
+                else:
+                    # un-normed modules; video: y1 = x1 + f(x2, ctx = audio m2), y2 = x2 + k(y1); audio: n1 = m1 + j(m2, ctx = the
+                    # UPDATED video half y2), n2 = m2 + g(n1) -- `k` / `g` crossed over as in reversible_video_audio.py:241-244
+                    v_from_a, a_from_v = _XmDirection(f, batch, rows_a, dev, lo), _XmDirection(j, batch, rows_v, dev, lo)
+                    lists['v'] += [dict(mod=f, xm=v_from_a, dst=0), dict(mod=k, dst=1, store_after=(a_from_v,))]
+                    lists['a'] += [dict(mod=j, xm=a_from_v, dst=0, store_before=(v_from_a,)), dict(mod=g, dst=1)]
+        else:
+            raise NotImplementedError(type(dec).__name__)
+        self.streams = {key: IncrementalDecoder(None, batch, rows, context, context_mask, self.pos[key], block_list=lists[key], halves=halves)
+                        for key, rows in (('v', rows_v), ('a', rows_a))}
+
+    def step(self, which, x):
+        out = self.streams[which].step(x.contiguous())
+        self.pos[which] += 1
+        return out
+
+
+class DualGuidedStepper:
+    """The per-token work of NUWAVideoAudio.generate: advance(which, x_row) feeds the next input row of one stream and returns the
+    logits for that stream's next token; with cond_scale != 1 the final-normed conditioned output row is the input of a second,
+    text-masked pass (np.py:2176-2186) and the two logits are mixed."""
+
+    def __init__(self, model, text_embeds, text_mask, rows_v, rows_a, cond_scale):
+        self.m, self.cond_scale = model, cond_scale
+        dec = model.video_audio_transformer
+        B = text_embeds.shape[0]
+        self.cond = DualIncrementalDecoder(dec, B, rows_v, rows_a, text_embeds, text_mask)
+        self.uncond = DualIncrementalDecoder(dec, B, rows_v, rows_a, text_embeds, torch.zeros_like(text_mask).bool()) \
+            if cond_scale != 1 else None
+
+    def _logits(self, which, hidden):
+        m, dec = self.m, self.m.video_audio_transformer
+        if which == 'v':
+            nrm, lin, cache = dec.video_norm.norm, m.to_video_logits, m._cache_v
+        else:
+            nrm, lin, cache = dec.audio_norm.norm, m.to_audio_logits, m._cache_a
+        return ops.LogitsFn.apply(hidden[:, None].contiguous(), nrm.weight, nrm.bias, lin.weight, cache)[:, 0]
+
+    def advance(self, which, x_row):
+        dec = self.m.video_audio_transformer
+        hidden = self.cond.step(which, x_row)
+        logits = self._logits(which, hidden)
+        if self.uncond is not None:
+            nrm = dec.video_norm if which == 'v' else dec.audio_norm
+            uh = self.uncond.step(which, nrm(hidden[:, None])[:, 0])
+            ul = self._logits(which, uh)
+            logits = ul + (logits - ul) * self.cond_scale
+        return logits
 
 
 class GuidedStepper:

@@ -11,7 +11,9 @@ Same class names, constructor kwargs, forward() signatures and state-dict keys a
     correction for the talking-heads Conv3d bias.  Head sizes the kernels do not cover (and `use_hip = False`) run the torch-op
     formulations kept next to them (index-table gathers, nothing is unfolded); the audio channel shift is a torch op.
 `dec_reversible=True` (ReversibleDualModalityDecoder, np.py:1489-1655 + reversible_video_audio.py) runs with the reference's
-arithmetic, with the recomputing (O(1)-activation-memory) backward of reversible_video_audio.py.  generate() follows the reference's recompute loop.
+arithmetic, with the recomputing (O(1)-activation-memory) backward of reversible_video_audio.py.  generate() decodes one new row per
+sampled token against per-layer caches (decode.py: both decoders), falling back to the reference's recompute loop only for
+configurations outside the single-row kernels.
 """
 import torch
 import torch.nn.functional as F
@@ -488,6 +490,8 @@ class ReversibleDualModalityDecoder(nn.Module):
 class NUWAVideoAudio(nn.Module):
     """np.py:1968-2293: identical constructor kwargs and forward() signature (training loss / logits)."""
 
+    generate_use_cache = True          # key/value-cached generate() (decode.DualGuidedStepper; plain and reversible dual decoder)
+
     def __init__(self, *, vae, dim, image_size, num_audio_tokens, num_audio_tokens_per_video_frame, audio_tokens_per_timestep=1,
                  max_video_frames=5, text_num_tokens=49408, text_max_seq_len=256, text_enc_depth=6, text_enc_dim_head=64,
                  text_enc_heads=8, text_rotary_pos_emb=False, enc_reversible=False, dec_reversible=True, dec_depth=6, dec_dim_head=64,
@@ -581,6 +585,15 @@ class NUWAVideoAudio(nn.Module):
         num_frames = default(num_frames, self.max_video_frames)
         total_video_tokens, total_audio_tokens = num_frames * tpf, num_frames * apf
         dec = self.video_audio_transformer
+        if self.generate_use_cache and num_frames <= self.max_video_frames:
+            try:
+                from .decode import DualGuidedStepper
+                stepper = DualGuidedStepper(self, text_embeds, text_mask, total_video_tokens + 1, total_audio_tokens + 1, cond_scale)
+            except NotImplementedError:
+                stepper = None                  # a block outside the single-row kernels: the recompute loop below
+            if stepper is not None:
+                return self._generate_cached(stepper, batch, total_video_tokens, total_audio_tokens, filter_thres, temperature,
+                                             decode_max_batchsize)
         vn, an = dec.video_norm.norm, dec.audio_norm.norm
         no_text = torch.zeros_like(text_mask).bool()
         decoding_video = True
@@ -617,6 +630,38 @@ class NUWAVideoAudio(nn.Module):
         codes = codes.reshape(batch, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
         images = map_in_chunks(codes.contiguous(), self.vae._hip_decode, chunks=decode_max_batchsize)
         return images.reshape(batch, -1, *images.shape[1:]), audio_indices
+
+    def _frames_from_ids(self, video_indices, batch, decode_max_batchsize):
+        from .nuwa_pytorch import map_in_chunks
+        fs = self.video_fmap_size
+        codes = self.vae.codes_for_decoder(video_indices)
+        codes = codes.reshape(batch, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
+        images = map_in_chunks(codes.contiguous(), self.vae._hip_decode, chunks=decode_max_batchsize)
+        return images.reshape(batch, -1, *images.shape[1:])
+
+    def _generate_cached(self, stepper, batch, total_v, total_a, filter_thres, temperature, decode_max_batchsize):
+        """the sampling order of np.py:2143-2207 with one new decoder row per sampled token (decode.DualGuidedStepper) instead of
+        two passes over the whole prefix: a token's row is computed right after it is sampled, and its logits are kept until its
+        stream is next asked for a token (rows never change once computed: see decode.py)"""
+        from .nuwa_pytorch import sample_top_fraction
+        tpf, apf = self.num_video_tokens_per_frame, self.num_audio_tokens_per_video_frame
+        vpos, apos = self.video_pos_emb(), self.audio_pos_emb()
+        ids = {'v': [], 'a': []}
+        total = {'v': total_v, 'a': total_a}
+        logits = {'v': stepper.advance('v', self.video_bos[None].expand(batch, -1)),
+                  'a': stepper.advance('a', self.audio_bos[None].expand(batch, -1))}
+        which = 'v'
+        while len(ids['v']) < total_v or len(ids['a']) < total_a:
+            token = sample_top_fraction(logits[which], filter_thres, temperature)
+            t = len(ids[which])
+            ids[which].append(token)
+            if t + 1 < total[which]:
+                row = (self.image_embedding(token) + vpos[t]) if which == 'v' else (self.audio_embedding(token) + apos[t])
+                logits[which] = stepper.advance(which, row)
+            if (t + 1) % (tpf if which == 'v' else apf) == 0:         # alternate, one video frame at a time
+                which = 'a' if which == 'v' else 'v'
+        video_indices, audio_indices = torch.stack(ids['v'], 1), torch.stack(ids['a'], 1)
+        return self._frames_from_ids(video_indices, batch, decode_max_batchsize), audio_indices
 
     def forward(self, *, text, video, audio, return_loss=False, cond_dropout_prob=0.2):
         batch, device = text.shape[0], text.device

@@ -278,3 +278,72 @@ def test_video_audio_generate_alternates_modalities(A, reversible):
         assert guided.shape == (1, 1, 3, 16, 16) and bool(torch.isfinite(guided).all())
     finally:
         A.set_precision('bf16')
+
+
+def _tiny_va(A, **over):
+    from test_gpu_modules import VA_KW
+    torch.manual_seed(21)
+    vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
+    return A.NUWAVideoAudio(vae=vae, sparse_3dna_rel_pos_bias=True, **{**VA_KW, 'dec_reversible': False, **over}).to(DEV).eval()
+
+
+@pytest.mark.parametrize('reversible', [False, True])
+@pytest.mark.parametrize('shift', [True, False])
+def test_dual_decoder_cached_rows_match_full_sequences(A, shift, reversible):
+    """DualIncrementalDecoder (one new row per call, two linked streams) against the dual decoder run over the complete sequences:
+    rows fed in the sampler's order (start tokens, then one video frame / one audio frame alternately) must reproduce the hidden
+    rows of DualModalityDecoder.forward_layers -- 3DNA + audio window caches, both token shifts, text cross-attention, and the
+    one-frame-lagged video <-> audio attention with its Conv3d bias"""
+    from nuwa_pytorch_amd.decode import DualIncrementalDecoder
+    m = _tiny_va(A, shift_video_tokens=shift, shift_audio_tokens=shift, dec_depth=6, dec_reversible=reversible)
+    with torch.no_grad():                                  # (fresh modules start with a zero Conv3d bias / tap bias: make them count)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Conv3d) and mod.bias is not None:
+                mod.bias.normal_(0, 0.3)
+    gen = torch.Generator().manual_seed(4)
+    tpf, apf, F_ = m.num_video_tokens_per_frame, m.num_audio_tokens_per_video_frame, 3
+    text = torch.randint(1, 50, (2, 8), generator=gen).to(DEV)
+    text[1, 5:] = 0
+    vids = torch.randint(0, 64, (2, F_ * tpf), generator=gen).to(DEV)
+    aids = torch.randint(0, 40, (2, F_ * apf), generator=gen).to(DEV)
+    A.set_precision('bf16x3')
+    try:
+        with torch.no_grad():
+            mask = text != 0
+            emb = m.embed_text(text, mask=mask)
+            v_in, a_in = m.embed_video(vids), m.embed_audio(aids).contiguous()
+            dec = m.video_audio_transformer
+            v_ref, a_ref = dec.forward_layers(v_in, a_in, context=emb, context_mask=mask)
+            d = DualIncrementalDecoder(dec, 2, v_in.shape[1], a_in.shape[1], emb, mask)
+            v_got, a_got = [d.step('v', v_in[:, 0])], [d.step('a', a_in[:, 0])]
+            for f in range(F_):
+                for t in range(f * tpf, (f + 1) * tpf):
+                    v_got.append(d.step('v', v_in[:, 1 + t]))
+                for t in range(f * apf, (f + 1) * apf):
+                    a_got.append(d.step('a', a_in[:, 1 + t]))
+        report(f'dual_cached_video_rows[shift={shift},rev={reversible}]', torch.stack(v_got, 1), v_ref, 1e-4)
+        report(f'dual_cached_audio_rows[shift={shift},rev={reversible}]', torch.stack(a_got, 1), a_ref, 1e-4)
+    finally:
+        A.set_precision('bf16')
+
+
+@pytest.mark.parametrize('reversible', [False, True])
+@pytest.mark.parametrize('cond_scale', [1., 2.])
+def test_video_audio_generate_cached_equals_recompute_under_greedy_sampling(A, cond_scale, reversible):
+    """NUWAVideoAudio.generate with the per-layer caches and with the reference's recompute loop (np.py:2143-2207) choose the same
+    video and audio tokens when the sampler is greedy"""
+    m = _tiny_va(A, dec_reversible=reversible)
+    text = torch.randint(1, 40, (2, 6), generator=torch.Generator().manual_seed(2)).to(DEV)
+    A.set_precision('bf16x3')
+    outs = []
+    try:
+        for cached in (True, False):
+            type(m).generate_use_cache = cached
+            torch.manual_seed(0)
+            outs.append(m.generate(text=text, filter_thres=0.99, cond_scale=cond_scale, num_frames=2))
+    finally:
+        type(m).generate_use_cache = True
+        A.set_precision('bf16')
+    (v0, a0), (v1, a1) = outs
+    assert v0.shape == (2, 2, 3, 16, 16) and a0.shape == (2, 2 * m.num_audio_tokens_per_video_frame)
+    assert torch.equal(a0, a1) and torch.equal(v0, v1)
