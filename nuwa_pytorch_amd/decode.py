@@ -43,13 +43,21 @@ class IncrementalDecoder:
     Instead of `transformer`, `block_list` gives the row program explicitly: dicts with `mod` (a SandwichNorm block, or a bare
     FeedForward / CrossModalityCrossAttention), optional `context` (text rows for a cross-attention), `xm` (_XmDirection this block
     attends through), `dst` (the residual half it adds into: reversible stacks keep two, np.py's reversible.py; the block reads the
-    OTHER half), `store_before` / `store_after` (_XmDirection objects that take this row's input / output as context)."""
+    OTHER half), `store_before` / `store_after` (_XmDirection objects that take this row's input / output as context); `combine`
+    scales the sum of the two halves at the end (1 for the ReversibleTransformer, which is detected and laid out here; 0.5 for the
+    reversible dual decoder)."""
 
-    def __init__(self, transformer, batch, max_rows, context, context_mask, pos_dev, block_list=None, halves=1):
+    def __init__(self, transformer, batch, max_rows, context, context_mask, pos_dev, block_list=None, halves=1, combine=0.5):
         from .nuwa_pytorch import Attention, FeedForward, Sparse3DNA, SandwichNorm
         from .video_audio import SparseCausal2DNA
         dev = context.device
-        self.B, self.rows, self.pos_dev, self.halves = batch, max_rows, pos_dev, halves
+        if block_list is None and hasattr(transformer, 'net'):         # ReversibleTransformer (np.py:1184-1295): (f, g) pairs, y1 = x1 +
+            from .nuwa_pytorch import ShiftVideoTokens                  # f(x2), y2 = x2 + g(y1), output = the SUM of the halves
+            block_list, halves, combine = [], 2, 1.0
+            for f, g in transformer.layers:
+                is_cross = not isinstance(f.fn, ShiftVideoTokens)
+                block_list += [dict(mod=f, context=context if is_cross else None, dst=0), dict(mod=g, dst=1)]
+        self.B, self.rows, self.pos_dev, self.halves, self.combine = batch, max_rows, pos_dev, halves, combine
         lo = self.lo = K.want_lo()
         D = context.shape[-1]
         ctx_bf = ops._ctx_to_bf(context)
@@ -179,7 +187,7 @@ class IncrementalDecoder:
             state[blk.dst] = x
             for d in blk.store_after:
                 d.store(x)
-        return x if self.halves == 1 else (state[0] + state[1]) * 0.5
+        return x if self.halves == 1 else (state[0] + state[1]) * self.combine
 
 
 class _XmDirection:

@@ -1031,19 +1031,22 @@ class NUWA(nn.Module):
     @eval_decorator
     def generate(self, *, text, filter_thres=0.9, temperature=1., decode_max_batchsize=10, cond_scale=2., num_frames=None):
         """np.py:1841-1915.  The reference recomputes the whole prefix (twice) per token; here each token costs one new decoder
-        row against per-layer key/value caches (decode.GuidedStepper, row f3) whenever the sequence fits the video shape and the
-        decoder is the plain Transformer -- otherwise the reference's recompute algorithm runs on the same kernels."""
+        row against per-layer key/value caches (decode.GuidedStepper, row f3) whenever the sequence fits the video shape and every
+        decoder block (Transformer or ReversibleTransformer) is on the single-row kernels -- otherwise the reference's recompute algorithm runs on the same kernels."""
         batch, device = text.shape[0], text.device
         text_mask = text != 0
         text_embeds = self.embed_text(text, mask=text_mask)
         tpf = self.video_fmap_size ** 2
         total = tpf * default(num_frames, self.max_video_frames)
         ids = torch.empty((batch, 0), device=device, dtype=torch.long)
-        cached = self.generate_use_cache and text.is_cuda and isinstance(self.video_transformer, Transformer) and \
-            total <= tpf * self.max_video_frames
+        cached = self.generate_use_cache and text.is_cuda and total <= tpf * self.max_video_frames
         if cached:
             from .decode import GuidedStepper
-            stepper = GuidedStepper(self, text_embeds, text_mask, total, cond_scale, graph=self.generate_use_graph)
+            try:                                 # plain and reversible decoder alike; a block outside the single-row kernels -> recompute
+                stepper = GuidedStepper(self, text_embeds, text_mask, total, cond_scale, graph=self.generate_use_graph)
+            except NotImplementedError:
+                cached = False
+        if cached:
             pos_table = self.video_pos_emb()
             row = self.video_bos[None].expand(batch, -1)
         for t in range(total):

@@ -173,9 +173,9 @@ def test_decode_ln_fuses_post_norm_pre_norm_and_shift(K, O, D, ybf, x3):
         K.set_precision('bf16')
 
 
-def _load_g5(A):
-    Ar, P, _ = load('g5_nuwa_tiny')
-    nuwa = _tiny_nuwa(A, False)
+def _load_g5(A, reversible=False):
+    Ar, P, _ = load('g6_nuwa_tiny_reversible' if reversible else 'g5_nuwa_tiny')
+    nuwa = _tiny_nuwa(A, reversible)
     nuwa.load_state_dict(P, strict=False)
     return Ar, nuwa.to(DEV).eval()
 
@@ -211,6 +211,27 @@ def test_teacher_forced_cached_logits_match_reference_golden(A, mode, tol, graph
 
 
 @pytest.mark.parametrize('graph', [False, True])
+def test_teacher_forced_cached_logits_reversible_decoder_golden(A, graph):
+    """fixture g6 = the REFERENCE's logits with dec_reversible=True (ReversibleTransformer: two residual halves, output = their
+    sum): the cached row program must reproduce every row"""
+    from nuwa_pytorch_amd.decode import GuidedStepper
+    Ar, nuwa = _load_g5(A, reversible=True)
+    A.set_precision('bf16x3')
+    try:
+        with torch.no_grad():
+            text = Ar['text'].to(DEV)
+            ids = Ar['video_ids'].to(DEV).reshape(2, -1)[:, :-1]
+            mask = text != 0
+            emb = nuwa.embed_text(text, mask=mask)
+            rows = _rows_in(nuwa, ids)
+            st = GuidedStepper(nuwa, emb, mask, rows.shape[1], 1., graph=graph)
+            got = torch.stack([st(rows[:, t]).clone() for t in range(rows.shape[1])], 1)
+        report(f'cached_logits_reversible[graph={graph}]', got, Ar['logits'], 1e-3)
+    finally:
+        A.set_precision('bf16')
+
+
+@pytest.mark.parametrize('graph', [False, True])
 def test_guided_step_matches_recompute_loop(A, graph):
     """classifier-free guidance as the reference does it (np.py:1894-1898: the final-normed conditioned output is the input of
     the text-masked pass): cached rows vs the full recompute on the same kernels"""
@@ -235,11 +256,12 @@ def test_guided_step_matches_recompute_loop(A, graph):
         A.set_precision('bf16')
 
 
-def test_generate_cached_equals_recompute_under_greedy_sampling(A):
+@pytest.mark.parametrize('reversible', [False, True])
+def test_generate_cached_equals_recompute_under_greedy_sampling(A, reversible):
     """NUWA.generate with the key/value cache and with the reference's recompute loop choose the same tokens when the sampler is
     greedy (filter_thres keeps one logit), hence decode to the same video; shapes follow np.py:1912-1915"""
     torch.manual_seed(12)
-    nuwa = _tiny_nuwa(A, False).to(DEV).eval()
+    nuwa = _tiny_nuwa(A, reversible).to(DEV).eval()
     text = torch.randint(1, 50, (2, 8), generator=torch.Generator().manual_seed(3)).to(DEV)
     A.set_precision('bf16x3')
     outs = []
