@@ -40,13 +40,15 @@ const char* amdnuwa_error_string(int code);
  *          (no ds / P' workspace: 1.5x instead of 2.85x the algorithmic HBM bytes, 15-22 % slower; 0 = MFMA kernels with the workspace)
  *   key 5  cross-attention forward: 1 = generic (not unrolled) kernel
  *   key 6  TN GEMM variant: 1 register-staged, 2 direct-to-LDS 128x128, 3 256x256 ring
- *   key 7  NT probe: bit 0 skips the epilogue stores, bit 1 skips the main loop (tools/gemm_probe.py; results are garbage)
+ *   key 7  NT probe: bit 0 skips the epilogue stores, bit 1 skips the main loop (tools/gemm_probe.py; results are garbage); with key 0 = 9
+ *          also bit 2 MFMAs, bit 3 LDS fragment reads, bit 4 in-loop DMA pieces (tools/gemm_w4_parts.py)
  *   key 8  TN 256x256 ring: 2 = staggered wave rows instead of the lock-step schedule
  *   key 9  3DNA MFMA forward probe: bits 0 / 1 / 2 skip the score / softmax+mix / apply phase (garbage results), bit 3 = fragment-shaped
  *          key loads in the score pass instead of the staged ones
  *   key 14 NT start-phase step in ~0.25 us units (0 = off)        key 15 VAE kernels: 1 = first (VALU) forms
  * (key 0 also takes 6 = 256x128 tile, two workgroups per CU, 7 = 256x256 ring with staggered wave rows, 8 = 7 + DMA issue inside the
- *  MFMA phase; any non-zero key 0 disables the few-row weight-streaming path that M <= 32 normally takes) */
+ *  MFMA phase, 9 = 256x256 tile on FOUR waves of 128x128 (plain fp32 / bf16 outputs only, else 7; opt-in: DESIGN.md 5n);
+ *  any non-zero key 0 disables the few-row weight-streaming path that M <= 32 normally takes) */
 int amdnuwa_set_tuning(int key, int value);
 int amdnuwa_get_tuning(int key);
 
