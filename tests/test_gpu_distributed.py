@@ -146,3 +146,33 @@ def test_native_comm_single_rank():
     with pytest.raises(RuntimeError):
         comm._rc(comm._lib.amdnuwa_comm_broadcast(comm._h, x.data_ptr(), 16, 3, None), 'amdnuwa_comm_broadcast')      # root outside the world
     comm.close()
+
+
+def _nccl_avg_worker(port, q):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        x = torch.randn(1 << 16, device='cuda')
+        ref = x.clone()
+        dist.all_reduce(x, op=dist.ReduceOp.AVG, async_op=True).wait()
+        out = torch.empty_like(x)
+        dist.reduce_scatter_tensor(out, x, op=dist.ReduceOp.AVG)
+        dist.all_gather_into_tensor(x, out)
+        torch.cuda.synchronize()
+        q.put(bool(torch.equal(x, ref)))
+        dist.destroy_process_group()
+    except Exception as e:      # noqa: BLE001
+        q.put(repr(e))
+
+
+def test_rccl_backend_accepts_the_average_op():
+    """GradReducer averages INSIDE the collective on the RCCL backend (ReduceOp.AVG for all_reduce and reduce_scatter_tensor): a
+    one-rank process group on the real backend must accept both ops and leave the data unchanged"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_avg_worker, args=(29700 + (os.getpid() % 90), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert res is True, res
