@@ -412,17 +412,18 @@ class XC2Inner:
         dS = P0 * (dP - (P0 * dP).sum(-1, keepdim=True)) * g.scale
         dq0 = dS[..., :1] * nkf[None] + torch.einsum('bht,bthd->bhd', dS[..., 1:], kvf[:, :, 0])
         _bf_put(dq, rows0, dq0.reshape(g.B, inner))
-        dkv_f = _bf_val(dkv).reshape(g.B, T, 2, heads, dh)
-        dkv_f[:, :, 0] += torch.einsum('bht,bhd->bthd', dS[..., 1:], q0)
-        dkv_f[:, :, 1] += torch.einsum('bht,bhd->bthd', P0[..., 1:], dO0)
-        dkv = _to_bf(dkv_f.reshape(g.B * T, 2 * inner))
+        # the <bos> query's share of dK / dV is a separate (small) term: it goes through the two products below as its own operand instead
+        # of being added into the kernel's bf16 dkv and rounded a second time
+        dkv0 = _to_bf(torch.stack((torch.einsum('bht,bhd->bthd', dS[..., 1:], q0), torch.einsum('bht,bhd->bthd', P0[..., 1:], dO0)),
+                                  dim=2).reshape(g.B * T, 2 * inner))
         dnk = dnk + torch.einsum('bh,bhd->hd', dS[..., 0], q0).reshape(-1)
         dnv = dnv + torch.einsum('bh,bhd->hd', P0[..., 0], dO0).reshape(-1)
         dh_ = K.gemm_nt(dq, W['qT'], out_bf16=_fast_bwd())
         dwq, dwkv = torch.empty_like(wq), torch.empty_like(wkv)
         K.gemm_tn(dq, h, dwq)
         K.gemm_tn(dkv, meta['ctx_bf'], dwkv)
-        dctx = K.gemm_nt(dkv, W['kvT'])
+        K.gemm_tn(dkv0, meta['ctx_bf'], dwkv, beta=1.0)
+        dctx = K.gemm_nt(dkv, W['kvT']) + K.gemm_nt(dkv0, W['kvT'])
         return dh_, dctx, [dnk.reshape(nkp.shape), dnv.reshape(nvp.shape), dwth.reshape(wth.shape), dwq, dwkv, dwo]
 
 
