@@ -31,6 +31,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+# per-file compiler options.  xattn2.hip: its one-wave-per-SIMD kernels hold > 256 live registers; by default the compiler puts EVERY
+# MFMA result into AGPRs there and moves the transient ones (scores, head mixes: consumed by the VALU right away) back with
+# v_accvgpr_read, zero-initialises their accumulators with v_accvgpr_write, and parks MFMA-only operands in AGPRs to read them back
+# before each use: 1300 v_accvgpr moves in xattn3_bwd.  With the VGPR form the transient results land where they are used (290 moves,
+# 15 % fewer instructions in a kernel that is bound by instruction issue); the long-lived accumulators still sit in AGPRs.
+EXTRA_FLAGS = {'xattn2.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
+
+
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
@@ -40,8 +48,8 @@ def build(force=False, verbose=True):
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIBDIR, s.replace('.hip', '.o'))
         objs.append(obj)
-        if force or _stale(obj, [src] + common):
-            jobs.append([_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj])
+        if force or _stale(obj, [src] + common + [os.path.abspath(__file__)]):
+            jobs.append([_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC'] + EXTRA_FLAGS.get(s, []) + ['-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:
