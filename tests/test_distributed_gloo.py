@@ -161,3 +161,36 @@ def test_reducer_gradient_accumulation_no_sync_allreduce():
 
 def test_reducer_gradient_accumulation_no_sync_reduce_scatter_all_gather():
     _run_accum('rs_ag', 33500)
+
+
+def _native_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nuwa_pytorch_amd.distributed import GradReducer
+    try:
+        GradReducer(Toy(), collective='native')
+        q.put((rank, 'no error'))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    try:
+        GradReducer(Toy(), collective='ring')
+        q.put((rank, 'no error'))
+    except ValueError:
+        q.put((rank, 'ValueError'))
+    dist.destroy_process_group()
+
+
+def test_native_collective_refuses_cpu_buckets():
+    """collective='native' puts the buckets on libamdnuwa's RCCL communicator: fp32 gradients on a HIP device only -- CPU replicas
+    get a RuntimeError at construction, not a silent switch to another transport; an unknown name is a ValueError"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_native_worker, args=(r, 2, 29650 + (os.getpid() % 40), q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(4)]
+    for p in ps:
+        p.join(timeout=60)
+    msgs = sorted(m for _, m in got)
+    assert msgs.count('ValueError') == 2 and sum('HIP device' in m for m in msgs) == 2, msgs
