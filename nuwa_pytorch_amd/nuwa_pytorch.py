@@ -1058,6 +1058,7 @@ class NUWA(nn.Module):
             ids = torch.cat((ids, token[:, None]), dim=1)
             if cached:
                 row = self.image_embedding(token) + pos_table[t]
+        self.last_generated_ids = ids                      # (b, frames * fmap^2) token ids behind the returned frames
         return self._ids_to_frames(ids, decode_max_batchsize)
 
     def forward(self, *, text, video=None, return_loss=False, cond_dropout_prob=0.2):

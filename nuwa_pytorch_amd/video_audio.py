@@ -625,11 +625,8 @@ class NUWAVideoAudio(nn.Module):
                 boundary = audio_indices.shape[1] % apf == 0
             if boundary:                                              # alternate, one video frame at a time
                 decoding_video = not decoding_video
-        fs = self.video_fmap_size
-        codes = self.vae.codes_for_decoder(video_indices)
-        codes = codes.reshape(batch, -1, fs, fs, codes.shape[-1]).permute(0, 1, 4, 2, 3).reshape(-1, codes.shape[-1], fs, fs)
-        images = map_in_chunks(codes.contiguous(), self.vae._hip_decode, chunks=decode_max_batchsize)
-        return images.reshape(batch, -1, *images.shape[1:]), audio_indices
+        self.last_generated_ids = video_indices
+        return self._frames_from_ids(video_indices, batch, decode_max_batchsize), audio_indices
 
     def _frames_from_ids(self, video_indices, batch, decode_max_batchsize):
         from .nuwa_pytorch import map_in_chunks
@@ -661,6 +658,7 @@ class NUWAVideoAudio(nn.Module):
             if (t + 1) % (tpf if which == 'v' else apf) == 0:         # alternate, one video frame at a time
                 which = 'a' if which == 'v' else 'v'
         video_indices, audio_indices = torch.stack(ids['v'], 1), torch.stack(ids['a'], 1)
+        self.last_generated_ids = video_indices            # the token ids behind the returned frames
         return self._frames_from_ids(video_indices, batch, decode_max_batchsize), audio_indices
 
     def forward(self, *, text, video, audio, return_loss=False, cond_dropout_prob=0.2):

@@ -284,6 +284,45 @@ def g9_video_audio(only=None):
              text_embeds=cap['ctx'], rel_pos_bias=rel, reversible=rev, **P, **G)
 
 
+
+def _codes_to_ids(codes, codebook):
+    """rows of the codebook back to their indices (exact match): codes [n, d, h, w] as the reference hands them to vae.decode"""
+    flat = codes.permute(0, 2, 3, 1).reshape(-1, codes.shape[1])
+    d = (flat[:, None, :] - codebook[None]).abs().amax(-1)
+    ids = d.argmin(-1)
+    assert float(d.gather(1, ids[:, None]).max()) == 0.
+    return ids
+
+
+def g13_generate():
+    """The reference's OWN generate() (np.py:1841-1915 and 2111-2222) under greedy sampling (filter_thres 0.99 keeps one logit, so
+    the Gumbel noise cannot change the arg-max): the sampled video (and audio) token ids for tiny models with recorded parameters.
+    The ids handed to vae.decode are recovered from its input (rows of the codebook)."""
+    for name, kind, rev, cs in (('g13a_generate_nuwa', 'nuwa', False, 2.), ('g13b_generate_nuwa_reversible', 'nuwa', True, 2.),
+                                ('g13c_generate_video_audio', 'va', False, 2.), ('g13d_generate_video_audio_reversible', 'va', True, 1.)):
+        torch.manual_seed(0)
+        if kind == 'nuwa':
+            m = tiny_nuwa(rev)
+        else:
+            vae = VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
+            m = NUWAVideoAudio(vae=vae, sparse_3dna_rel_pos_bias=False, **{**VA_KW, 'dec_reversible': rev})
+        m.eval()
+        torch.manual_seed(1)
+        text = torch.randint(1, 50, (2, 8))
+        text[-1, 5:] = 0
+        seen = []
+        orig = m.vae.decode
+        # (only the ids matter here; the tiny VAE's codebook dim differs from its decoder width, which the reference's decode() rejects)
+        m.vae.decode = lambda codes: (seen.append(codes.detach().clone()), torch.zeros(codes.shape[0], 3, 16, 16))[1]
+        torch.manual_seed(2)
+        out = m.generate(text=text, filter_thres=0.99, cond_scale=cs, num_frames=2)
+        m.vae.decode = orig
+        ids = _codes_to_ids(torch.cat(seen, 0), m.vae.codebook).reshape(2, -1)
+        P = {k: v for k, v in params(m).items() if not k.startswith('p.vae.') and '.net.blocks.' not in k}
+        extra = dict(audio_ids=out[1]) if kind == 'va' else {}
+        save(name, text=text, video_ids=ids, cond_scale=cs, reversible=rev, **extra, **P)
+
+
 SKETCH_KW = dict(dim=32, image_size=16, max_video_frames=3, sketch_max_video_frames=2, sketch_enc_depth=2, sketch_enc_dim_head=16,
                  sketch_enc_heads=2, dec_depth=3, dec_dim_head=32, dec_heads=2, cross_2dna_kernel_size=3, cross_2dna_dilation=2,
                  sparse_3dna_kernel_size=3, sparse_3dna_dilation=(1, 2))
@@ -326,7 +365,7 @@ def g11_sketch():
 
 if __name__ == '__main__':
     makers = [g1_sparse3dna, g1b_sparse3dna_rel_pos_bias, g2_cross_attention, g3_feedforward, g4_norms_and_shift, g5_g6_nuwa, g7_vae,
-              g8_decoder_layer, g9_video_audio, g10_text_encoder, g11_sketch, g12_vae_cfg1]
+              g8_decoder_layer, g9_video_audio, g10_text_encoder, g11_sketch, g12_vae_cfg1, g13_generate]
     want = sys.argv[1:]                       # e.g. `python tests/golden/make_golden.py g12` regenerates only the g12 fixture
     for fn in makers:
         if not want or any(fn.__name__.startswith(w) for w in want):

@@ -369,3 +369,35 @@ def test_video_audio_generate_cached_equals_recompute_under_greedy_sampling(A, c
     (v0, a0), (v1, a1) = outs
     assert v0.shape == (2, 2, 3, 16, 16) and a0.shape == (2, 2 * m.num_audio_tokens_per_video_frame)
     assert torch.equal(a0, a1) and torch.equal(v0, v1)
+
+
+@pytest.mark.parametrize('cached', [True, False])
+@pytest.mark.parametrize('name', ['g13a_generate_nuwa', 'g13b_generate_nuwa_reversible', 'g13c_generate_video_audio',
+                                  'g13d_generate_video_audio_reversible'])
+def test_generate_reproduces_the_reference_token_ids(A, name, cached):
+    """fixtures g13 hold the token ids the REFERENCE's own generate() sampled (np.py:1841-1915, 2111-2222; greedy: filter_thres 0.99
+    keeps one logit) for tiny models with recorded parameters: the key/value-cached row program and the recompute loop on the HIP
+    kernels must both sample exactly those video (and audio) tokens"""
+    from test_gpu_modules import VA_KW
+    Ar, P, _ = load(name)
+    rev, cs = bool(Ar['reversible']), float(Ar['cond_scale'])
+    if 'audio_ids' in Ar:
+        vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
+        m = A.NUWAVideoAudio(vae=vae, sparse_3dna_rel_pos_bias=False, **{**VA_KW, 'dec_reversible': rev})
+    else:
+        m = _tiny_nuwa(A, rev)
+    missing, unexpected = m.load_state_dict(P, strict=False)
+    assert not unexpected, unexpected
+    m = m.to(DEV).eval()
+    text = Ar['text'].to(DEV)
+    A.set_precision('bf16x3')
+    try:
+        type(m).generate_use_cache = cached
+        torch.manual_seed(0)
+        out = m.generate(text=text, filter_thres=0.99, cond_scale=cs, num_frames=2)
+    finally:
+        type(m).generate_use_cache = True
+        A.set_precision('bf16')
+    assert torch.equal(m.last_generated_ids.cpu(), Ar['video_ids'].long()), (m.last_generated_ids.cpu(), Ar['video_ids'])
+    if 'audio_ids' in Ar:
+        assert torch.equal(out[1].cpu(), Ar['audio_ids'].long())
