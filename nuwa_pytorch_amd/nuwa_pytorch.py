@@ -1166,6 +1166,7 @@ class NUWASketch(nn.Module):
         for _ in range(tpf * default(num_frames, self.max_video_frames)):
             logits = self._guided_last_logits(lookback_window(ids, tpf, self.max_video_frames), sketch_embeds, context_mask, cond_scale)
             ids = torch.cat((ids, sample_top_fraction(logits, filter_thres, temperature)[:, None]), dim=1)
+        self.last_generated_ids = ids
         return self._ids_to_frames(ids, decode_max_batchsize)
 
     def forward(self, *, sketch, sketch_mask=None, video=None, return_loss=False, cond_dropout_prob=0.2):

@@ -363,9 +363,29 @@ def g11_sketch():
              reversible=bool(extra), **P, **G)
 
 
+def g13e_generate_sketch():
+    """NUWASketch.generate (np.py:2438-2511), greedy, guided: the sampled token ids; the sketch token ids of the (randomly initialised)
+    sketch VAE are recorded so that the product side can be fed the same context"""
+    torch.manual_seed(0)
+    vae = VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
+    sketch_vae = VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=48, vq_codebook_dim=32, use_vgg_and_gan=False)
+    m = NUWASketch(vae=vae, sketch_vae=sketch_vae, **SKETCH_KW).eval()
+    torch.manual_seed(1)
+    sketch = torch.rand(2, 2, 3, 16, 16)
+    with torch.no_grad():
+        sketch_ids = m.sketch_vae.get_video_indices(sketch)
+    seen = []
+    m.vae.decode = lambda codes: (seen.append(codes.detach().clone()), torch.zeros(codes.shape[0], 3, 16, 16))[1]
+    torch.manual_seed(2)
+    m.generate(sketch=sketch, filter_thres=0.99, cond_scale=2., num_frames=2)
+    ids = _codes_to_ids(torch.cat(seen, 0), m.vae.codebook).reshape(2, -1)
+    P = {k: v for k, v in params(m).items() if '.net.blocks.' not in k and not k.startswith(('p.vae.', 'p.sketch_vae.'))}
+    save('g13e_generate_sketch', sketch=sketch, sketch_ids=sketch_ids, video_ids=ids, cond_scale=2., **P)
+
+
 if __name__ == '__main__':
     makers = [g1_sparse3dna, g1b_sparse3dna_rel_pos_bias, g2_cross_attention, g3_feedforward, g4_norms_and_shift, g5_g6_nuwa, g7_vae,
-              g8_decoder_layer, g9_video_audio, g10_text_encoder, g11_sketch, g12_vae_cfg1, g13_generate]
+              g8_decoder_layer, g9_video_audio, g10_text_encoder, g11_sketch, g12_vae_cfg1, g13_generate, g13e_generate_sketch]
     want = sys.argv[1:]                       # e.g. `python tests/golden/make_golden.py g12` regenerates only the g12 fixture
     for fn in makers:
         if not want or any(fn.__name__.startswith(w) for w in want):

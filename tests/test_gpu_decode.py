@@ -401,3 +401,26 @@ def test_generate_reproduces_the_reference_token_ids(A, name, cached):
     assert torch.equal(m.last_generated_ids.cpu(), Ar['video_ids'].long()), (m.last_generated_ids.cpu(), Ar['video_ids'])
     if 'audio_ids' in Ar:
         assert torch.equal(out[1].cpu(), Ar['audio_ids'].long())
+
+
+def test_sketch_generate_reproduces_the_reference_token_ids(A):
+    """fixture g13e: the token ids the reference's NUWASketch.generate (np.py:2438-2511) samples (greedy, guided) for a tiny model with
+    recorded parameters; the sketch token ids of the reference's randomly initialised sketch VAE are part of the fixture"""
+    from test_gpu_modules import SKETCH_KW
+    Ar, P, _ = load('g13e_generate_sketch')
+    vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
+    sketch_vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=48, vq_codebook_dim=32, use_vgg_and_gan=False)
+    m = A.NUWASketch(vae=vae, sketch_vae=sketch_vae, **SKETCH_KW)
+    missing, unexpected = m.load_state_dict(P, strict=False)
+    assert not unexpected, unexpected
+    m = m.to(DEV).eval()
+    sketch_ids = Ar['sketch_ids'].to(DEV)
+    m.sketch_vae.get_video_indices = lambda frames: sketch_ids
+    A.set_precision('bf16x3')
+    try:
+        torch.manual_seed(0)
+        frames = m.generate(sketch=Ar['sketch'].to(DEV), filter_thres=0.99, cond_scale=float(Ar['cond_scale']), num_frames=2)
+    finally:
+        A.set_precision('bf16')
+    assert frames.shape == (2, 2, 3, 16, 16)
+    assert torch.equal(m.last_generated_ids.cpu(), Ar['video_ids'].long()), (m.last_generated_ids.cpu(), Ar['video_ids'])
