@@ -531,6 +531,65 @@ def video_audio_loss(P, cfg, ids, audio_ids, context, context_mask, training=Tru
 
 
 # --------------------------------------------------------------------------------------
+# f3  generate(): the reference's decoding algorithm with a greedy sampler (np.py:1841-1915 and 2111-2222)
+# --------------------------------------------------------------------------------------
+
+def _guided(cond, uncond, cond_scale):
+    return cond if cond_scale == 1 else uncond + (cond - uncond) * cond_scale
+
+
+def nuwa_generate_greedy(P, cfg, text, num_tokens, cond_scale=1.):
+    """NUWA.generate np.py:1870-1908 with arg-max in place of top-k + Gumbel (what filter_thres -> 1 reduces to): every token from a
+    pass over the WHOLE prefix; with guidance a second pass is fed the first pass's final-normed OUTPUT rows and sees no text
+    (np.py:1894-1898).  Returns ids (b, num_tokens)."""
+    ctx, mask = text_encoder(text, P, cfg, training=False)
+    vt = sub(P, 'video_transformer')
+    stack = reversible_decoder_stack if cfg.get('reversible', False) else decoder_stack
+    ids = torch.empty((text.shape[0], 0), dtype=torch.long)
+    for _ in range(num_tokens):
+        h = stack(embed_assemble(ids, P, training=False), vt, cfg, ctx, mask)
+        logits = h[:, -1] @ P['to_logits.weight'].t()
+        if cond_scale != 1:
+            hu = stack(h, vt, cfg, ctx, torch.zeros_like(mask))
+            logits = _guided(logits, hu[:, -1] @ P['to_logits.weight'].t(), cond_scale)
+        ids = torch.cat((ids, logits.argmax(-1, keepdim=True)), dim=1)
+    return ids
+
+
+def video_audio_generate_greedy(P, cfg, text, num_frames, cond_scale=1.):
+    """NUWAVideoAudio.generate np.py:2143-2207, greedy: video and audio tokens alternately, one video frame's worth at a time, each
+    from both decoders run over the whole prefix (the guided second pass takes BOTH normed output streams).  Returns (video ids,
+    audio ids)."""
+    ctx, mask = text_encoder(text, P, cfg, training=False)
+    T = sub(P, 'video_audio_transformer')
+    dec = reversible_dual_decoder if cfg.get('reversible', False) else dual_decoder
+    b = text.shape[0]
+    vids, aids = torch.empty((b, 0), dtype=torch.long), torch.empty((b, 0), dtype=torch.long)
+    tv, ta = num_frames * cfg['v_per_frame'], num_frames * cfg['a_per_frame']
+    video_turn = True
+    while vids.shape[1] < tv or aids.shape[1] < ta:
+        x = embed_assemble(vids, P, training=False)
+        ae = P['audio_embedding.embed.weight'][aids] + P['audio_pos_emb.axial1'][:aids.shape[1]][None]
+        a = torch.cat((P['audio_bos'][None, None].expand(b, 1, -1), ae), dim=1)
+        v, au = dec(x, a, T, cfg, ctx, mask)
+        W = P['to_video_logits.weight'] if video_turn else P['to_audio_logits.weight']
+        logits = (v if video_turn else au)[:, -1] @ W.t()
+        if cond_scale != 1:
+            v2, a2 = dec(v, au, T, cfg, ctx, torch.zeros_like(mask))
+            logits = _guided(logits, (v2 if video_turn else a2)[:, -1] @ W.t(), cond_scale)
+        tok = logits.argmax(-1, keepdim=True)
+        if video_turn:
+            vids = torch.cat((vids, tok), dim=1)
+            boundary = vids.shape[1] % cfg['v_per_frame'] == 0
+        else:
+            aids = torch.cat((aids, tok), dim=1)
+            boundary = aids.shape[1] % cfg['a_per_frame'] == 0
+        if boundary:
+            video_turn = not video_turn
+    return vids, aids
+
+
+# --------------------------------------------------------------------------------------
 # f1  text encoder (embed_text np.py:1821-1839; always a ReversibleTransformer in practice, Q1)
 # --------------------------------------------------------------------------------------
 

@@ -127,6 +127,27 @@ def test_g9_video_audio(name):
     assert n > 150
 
 
+@pytest.mark.parametrize('name', ['g13a_generate_nuwa', 'g13b_generate_nuwa_reversible'])
+def test_g13_nuwa_generate(name):
+    """the oracle's restatement of NUWA.generate (greedy) samples the token ids the REFERENCE's own generate() produced"""
+    A, P, _ = load(name)
+    cfg = dict(video_shape=(3, 4, 4), kernel_size=3, dilations=(1, 2), heads=2, depth=3, shift=True, reversible=bool(A['reversible']),
+               text_depth=2, text_heads=2)
+    with torch.no_grad():
+        ids = O.nuwa_generate_greedy(P, cfg, A['text'], A['video_ids'].shape[1], cond_scale=float(A['cond_scale']))
+    assert torch.equal(ids, A['video_ids'].long())
+
+
+@pytest.mark.parametrize('name', ['g13c_generate_video_audio', 'g13d_generate_video_audio_reversible'])
+def test_g13_video_audio_generate(name):
+    """the same for NUWAVideoAudio.generate: alternating video / audio frames, both dual decoders"""
+    A, P, _ = load(name)
+    cfg = dict(VA_CFG, reversible=bool(A['reversible']), dilations=(1, 2), audio_dilations=(1, 2))
+    with torch.no_grad():
+        vids, aids = O.video_audio_generate_greedy(P, cfg, A['text'], 2, cond_scale=float(A['cond_scale']))
+    assert torch.equal(vids, A['video_ids'].long()) and torch.equal(aids, A['audio_ids'].long())
+
+
 SKETCH_CFG = dict(video_shape=(3, 4, 4), sketch_shape=(2, 4, 4), kernel_size=3, dilations=(1, 2), heads=2, enc_heads=2, depth=3,
                   enc_depth=2, shift=True, cross_kernel=3, cross_dilations=(1, 2))
 
