@@ -748,6 +748,28 @@ def sketch_loss(P, cfg, sketch_ids, video_ids, sketch_mask=None, training=True):
     return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), ids.reshape(-1)), logits, ctx
 
 
+def sketch_generate_greedy(P, cfg, sketch_ids, num_tokens, cond_scale=1., sketch_mask=None):
+    """NUWASketch.generate np.py:2438-2511 from sketch token ids, greedy: as nuwa_generate_greedy with the sketch encoder's output as
+    the context of the SparseCross2DNA decoder; the guided second pass sees a fully masked sketch."""
+    b = sketch_ids.shape[0]
+    sk = sketch_ids.reshape(b, -1)
+    tokens = P['sketch_embedding.embed.weight'][sk] + axial_pos(P, 'sketch_pos_emb')[:sk.shape[1]]
+    frames = sketch_ids.shape[1]
+    mask = torch.ones(b, sk.shape[1], dtype=torch.bool) if sketch_mask is None else \
+        sketch_mask[:, :, None].expand(-1, -1, sk.shape[1] // frames).reshape(b, -1)
+    ctx = sketch_encoder(tokens, sub(P, 'sketch_transformer'), cfg, mask)
+    V = sub(P, 'video_transformer')
+    ids = torch.empty((b, 0), dtype=torch.long)
+    for _ in range(num_tokens):
+        h = sketch_decoder(embed_assemble(ids, P, training=False), V, cfg, ctx, mask)
+        logits = h[:, -1] @ P['to_logits.weight'].t()
+        if cond_scale != 1:
+            hu = sketch_decoder(h, V, cfg, ctx, torch.zeros_like(mask))
+            logits = _guided(logits, hu[:, -1] @ P['to_logits.weight'].t(), cond_scale)
+        ids = torch.cat((ids, logits.argmax(-1, keepdim=True)), dim=1)
+    return ids
+
+
 # --------------------------------------------------------------------------------------
 # a13  VQGanVAE encode path (vq.py:431-435) -- frozen tokenizer, eval mode
 # --------------------------------------------------------------------------------------

@@ -173,6 +173,15 @@ def test_g11_sketch(name):
     assert n > 40
 
 
+def test_g13e_sketch_generate():
+    """the oracle's restatement of NUWASketch.generate (greedy, guided) samples the token ids the reference's own generate() produced"""
+    A, P, _ = load('g13e_generate_sketch')
+    cfg = dict(SKETCH_CFG, enc_reversible=False, dec_reversible=False, enc_3dna=False)
+    with torch.no_grad():
+        ids = O.sketch_generate_greedy(P, cfg, A['sketch_ids'], A['video_ids'].shape[1], cond_scale=float(A['cond_scale']))
+    assert torch.equal(ids, A['video_ids'].long())
+
+
 def test_g10_text_encoder():
     A, P, G = load('g10_text_encoder')
     P = req({k: v for k, v in P.items() if 'net.blocks.' not in k})
