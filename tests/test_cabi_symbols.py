@@ -51,3 +51,14 @@ def test_no_product_import_of_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 src = open(os.path.join(dp, f)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src and 'nuwa_oracle' not in src, f
+
+
+def test_integration_stub_names_the_current_abi_and_real_symbols():
+    """INTEGRATION.md's reference-side binding must quote the ABI version the library reports and only call entry points it exports"""
+    import re
+    from nuwa_pytorch_amd import _lib
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    m = re.search(r'amdnuwa_abi_version\(\) == (\d+)', text)
+    assert m and int(m.group(1)) == _lib.ABI_VERSION
+    called = set(re.findall(r'_L\.(amdnuwa_\w+)', text))
+    assert called and called <= set(_lib.SIGNATURES) | {'amdnuwa_abi_version', 'amdnuwa_error_string'}, called - set(_lib.SIGNATURES)
