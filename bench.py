@@ -3,12 +3,14 @@
 at 10x16x16 video tokens (BASELINE cfg 3: dim 512, depth 24, 8 heads, 3DNA kernel (5,3,3), dilation
 cycle (1,2,4), 256 text tokens of context), bf16 MFMA operands, synthetic data, random-init weights.
 
-The HEADLINE (`value`) is the precision mode that meets BOTH halves of the north star's sentence: 'bf16x3-fwd' -- the forward
-carries every MFMA operand as a bf16 hi + lo pair (3 MFMAs per product: full-depth logits within 1e-3 of the fp32 reference,
-measured live below in `parity`), the backward runs single bf16 MFMAs on the hi parts.  The all-bf16 mode (faster, logits
-~8e-3) is timed in the same run and reported beside it as `fast_mode`.
+The HEADLINE (`value`) is the precision mode that meets BOTH halves of the north star's sentence: 'bf16x3-fwd' = the cheapest
+forward arithmetic that keeps the full-depth logits within 1e-3 of the fp32 reference (measured live below in `parity`):
+bf16 hi + lo operand pairs (3 MFMAs per product) on to_out x2, the cross-attention q / kv projections and to_logits; SINGLE fp16
+MFMAs (fp16 operands, fp32 accumulate) on the Sparse3DNA q / k / v projection, FF1 (+ GEGLU gate), FF2 and both attention cores;
+the backward runs single bf16 MFMAs.  The all-bf16 mode (faster, logits ~8e-3) is timed in the same run as `fast_mode`.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -227,11 +229,29 @@ def main():
     ap.add_argument('--no-tokenizer', action='store_true', help='skip the (untimed, separately reported) frozen-VAE tokenizer rate')
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (the decoder path has no CPU fallback)')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, RCCL), so that the line says n_gpus: N
+        # and measures N devices -- or fail loudly when the box does not have them
+        have = torch.cuda.device_count()
+        if have < args.gpus and not args.single_device:
+            raise SystemExit(f'bench.py --gpus {args.gpus}: this box exposes {have} HIP device(s)')
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a HIP device (the decoder path has no CPU fallback)')
+    if world != args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: the two must agree')
+    if not args.single_device and torch.cuda.device_count() < world:
+        raise SystemExit(f'bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s) on this node')
     if args.single_device:
         local = 0
     torch.cuda.set_device(local)
@@ -381,6 +401,8 @@ def main():
     if rank == 0:
         tokens = world * b * N * args.steps
         value = tokens / dt
+        # which parts of the 'bf16x3-fwd' forward run single fp16 MFMAs in THIS run (AMDNUWA_F16_CORES / _FF / _QKV switches)
+        f16_parts = {'cores': bool(K._CORES_F16), 'ff': bool(K._FF_F16), 'qkv': bool(K._QKV_F16 and K._CORES_F16)}
         fl = fwd_flops_per_sample(c)
         step_flops = 3.0 * fl * b
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -389,9 +411,16 @@ def main():
             'value': value, 'unit': 'video-tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'ms_per_step_median': statistics.median(per_step_ms),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'bf16': 'bf16', 'bf16x3': 'bf16x3 (bf16 hi+lo operand pairs, 3 MFMAs per product)',
-                      'bf16x3-fwd': 'bf16 (forward: hi+lo operand pairs, 3 MFMAs per product; backward: single bf16 MFMAs)'}[args.precision],
-            'precision_mode': args.precision, 'data': 'synthetic',
+            'dtype': {'bf16': 'bf16 operands, fp32 accumulate (single bf16 MFMA per product, forward and backward)',
+                      'bf16x3': 'bf16 hi+lo operand pairs, fp32 accumulate (3 bf16 MFMAs per product, forward and backward)',
+                      'bf16x3-fwd': 'bf16/fp16 operands, fp32 accumulate -- forward: 3-MFMA bf16 hi+lo pairs on to_out x2, cross-attention q/kv '
+                                    'projections and to_logits' + ('' if f16_parts['cores'] else ' and both attention cores') +
+                                    ('' if f16_parts['ff'] else ', FF1, FF2') + ('' if f16_parts['qkv'] else ', 3DNA q/k/v projection') +
+                                    '; single fp16 MFMA on ' + (', '.join(nm for nm, on in (('3DNA q/k/v projection', f16_parts['qkv']), ('FF1 + gate', f16_parts['ff']),
+                                                                                          ('FF2', f16_parts['ff']), ('Sparse3DNA core', f16_parts['cores']),
+                                                                                          ('cross-attention core', f16_parts['cores'])) if on) or 'nothing') +
+                                    '; backward: single bf16 MFMAs'}[args.precision],
+            'precision_mode': args.precision, 'fp16_forward_parts': f16_parts if args.precision == 'bf16x3-fwd' else None, 'data': 'synthetic',
             'config': {'workload': f'BASELINE {args.config}: NUWA decoder dim={c["dim"]} depth={c["dec_depth"]} heads={c["heads"]}, '
                                    f'{c["frames"]}x{c["fmap"]}x{c["fmap"]} video tokens, 3DNA kernel {c["kernel"]} dilation {c["dilation"]}, '
                                    f'{c["text_len"]} text tokens, codebook {c["codebook"]}',

@@ -5,16 +5,16 @@
 #include <vector>
 #include <mutex>
 
-int g_amdnuwa_tuning[16] = {0};
+int g_amdnuwa_tuning[32] = {0};
 
 extern "C" int amdnuwa_abi_version(void) { return 12; }
 
 extern "C" int amdnuwa_set_tuning(int key, int value) {
-    if (key < 0 || key >= 16) return AMDNUWA_ERR_ARG;
+    if (key < 0 || key >= 32) return AMDNUWA_ERR_ARG;
     g_amdnuwa_tuning[key] = value;
     return AMDNUWA_OK;
 }
-extern "C" int amdnuwa_get_tuning(int key) { return (key < 0 || key >= 16) ? 0 : g_amdnuwa_tuning[key]; }
+extern "C" int amdnuwa_get_tuning(int key) { return (key < 0 || key >= 32) ? 0 : g_amdnuwa_tuning[key]; }
 
 extern "C" const char* amdnuwa_error_string(int code) {
     if (code == 0) return "ok";

@@ -4,12 +4,24 @@
 // per GPU owns one communicator; the flat fp32 gradient buckets of nuwa_pytorch_amd/distributed.py go through ncclAllReduce with
 // ncclAvg (no separate division pass), or reduce-scatter + all-gather, on the reducer's private HIP stream.
 //
-// librccl is opened at run time (dlopen): the library has no link-time dependency on it, loads on hosts without RCCL, and inside a
+// librccl is opened at run time (dlopen): the library has no link-time dependency on it, builds without the RCCL headers (the few
+// declarations it needs are restated under __has_include below), loads on hosts without RCCL, and inside a
 // torch process picks up the librccl.so.1 torch already mapped -- one RCCL per process.  xGMI is point to point (7 links per GPU),
 // ring collectives are bound per link: the caller sizes its buckets for that, this file adds no policy.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// ROCm install without the RCCL development headers: the handful of declarations this file uses, as rccl.h (NCCL 2.x ABI) has them.
+// librccl itself is only ever opened at run time; without it every amdnuwa_comm_* entry point reports AMDNUWA_ERR_UNSUPPORTED.
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5,
+               ncclFloat16 = 6, ncclHalf = 6, ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8, ncclBfloat16 = 9 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+#endif
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
@@ -94,12 +106,15 @@ extern "C" int amdnuwa_comm_init(amdnuwa_comm** out, const void* id, size_t id_b
     *out = nullptr;
     const Rccl* r = rccl();
     if (!r) return AMDNUWA_ERR_UNSUPPORTED;
+    int prev = -1;
+    (void)hipGetDevice(&prev);                                   // the caller's current device is restored below
     hipError_t he = hipSetDevice(device);
     if (he != hipSuccess) return (int)he;
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
     ncclComm_t c;
     const ncclResult_t e = r->CommInitRank(&c, world, uid, rank);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (e != ncclSuccess) return fail(r, e, "ncclCommInitRank");
     *out = new amdnuwa_comm{c, rank, world, device};
     return AMDNUWA_OK;

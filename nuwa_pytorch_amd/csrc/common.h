@@ -19,7 +19,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define AMDNUWA_ERR_COMM -4
 
 // runtime tuning knobs (amdnuwa_set_tuning): [0] NT GEMM variant, [1] TN target workgroups, [2] TN min rows per split
-extern int g_amdnuwa_tuning[16];
+extern int g_amdnuwa_tuning[32];
 
 #define LAUNCH_CHECK()                                \
     do {                                              \
@@ -67,6 +67,12 @@ __device__ __forceinline__ uint32_t pack2_f16(float a, float b) {          // v_
 __device__ __forceinline__ float f16lo_f(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu)); }
 __device__ __forceinline__ float f16hi_f(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16)); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// SATURATING forms for activation / weight stores (LayerNorm copies, GEMM epilogues, K / V images): fp16 ends at 65504 and the plain
+// converter returns inf beyond it, which an MFMA turns into NaN rows.  v_med3_f32 clamps first (bit-identical for every in-range value;
+// NaN passes through as NaN).  Probabilities (<= 1) keep the plain converter.
+__device__ __forceinline__ float f16_clamp(float f) { return __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f); }
+__device__ __forceinline__ uint32_t pack2_f16_sat(float a, float b) { return pack2_f16(f16_clamp(a), f16_clamp(b)); }
+__device__ __forceinline__ uint16_t f2h_sat(float f) { return f2h(f16_clamp(f)); }
 template <bool F16> __device__ __forceinline__ uint32_t pack2_t(float a, float b) { return F16 ? pack2_f16(a, b) : pack2_rne(a, b); }
 template <bool F16> __device__ __forceinline__ float lo_t(uint32_t u) { return F16 ? f16lo_f(u) : lo_f(u); }
 template <bool F16> __device__ __forceinline__ float hi_t(uint32_t u) { return F16 ? f16hi_f(u) : hi_f(u); }

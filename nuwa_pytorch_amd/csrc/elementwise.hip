@@ -79,7 +79,7 @@ __device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, floa
     if (!lo) { *reinterpret_cast<uint2*>(hi + e) = make_uint2(pack2_rne(a, b), pack2_rne(c, d)); return; }
     if (lo_f16) {
         *reinterpret_cast<uint2*>(hi + e) = make_uint2(pack2_rne(a, b), pack2_rne(c, d));
-        *reinterpret_cast<uint2*>(lo + e) = make_uint2(pack2_f16(a, b), pack2_f16(c, d));
+        *reinterpret_cast<uint2*>(lo + e) = make_uint2(pack2_f16_sat(a, b), pack2_f16_sat(c, d));
         return;
     }
     bf16_t h[4], l[4];
@@ -871,6 +871,59 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     }
 }
 
+// The same kernel with the row held in REGISTERS (C <= 1024 * NV: 8192 logits = 32 floats per thread): one read of the fp32 logits
+// instead of three (the row max, the exponential sum and the gradient pass each re-read 32 KB per row: FETCH_SIZE = 3.0 x the tensor
+// in the round-3 counter pass).  Same operations in the same order -> bit-identical loss and dlogits.
+template <int NV>
+__global__ __launch_bounds__(256) void ce_fwd_reg_kernel(const float* __restrict__ logits, const long long* __restrict__ tgt,
+                                                         float* __restrict__ row_loss, bf16_t* __restrict__ dl_hi,
+                                                         bf16_t* __restrict__ dl_lo, int C, int ldd, float grad_scale) {
+    __shared__ float sred[4];
+    const long long row = blockIdx.x;
+    const float* lr = logits + row * C;
+    const int tid = threadIdx.x, lane = tid & 63, wv_ = tid >> 6;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = tid * 4 + i * 1024;
+        const float4 ld = *reinterpret_cast<const float4*>(lr + (c < C ? c : 0));       // branch-free: all NV loads in flight together
+        v[i] = c < C ? ld : make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+    }
+    float m = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (tid * 4 + i * 1024 < C) m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+    m = wave_max(m);
+    if (lane == 0) sred[wv_] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (tid * 4 + i * 1024 < C) s += (expf(v[i].x - m) + expf(v[i].y - m)) + (expf(v[i].z - m) + expf(v[i].w - m));
+    s = wave_sum(s);
+    if (lane == 0) sred[wv_] = s;
+    __syncthreads();
+    s = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    const float lse = m + logf(s);
+    const long long t = tgt[row];
+    const bool t_ok = t >= 0 && t < (long long)C;
+    if (tid == 0) row_loss[row] = t_ok ? lse - lr[t] : __builtin_nanf("");
+    if (dl_hi) {
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = tid * 4 + i * 1024;
+            if (c >= C) continue;
+            float pz[4] = {expf(v[i].x - m) * inv, expf(v[i].y - m) * inv, expf(v[i].z - m) * inv, expf(v[i].w - m) * inv};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pz[k] = (pz[k] - ((long long)(c + k) == t ? 1.f : 0.f)) * grad_scale;
+            store_bf16x4(dl_hi + row * ldd, dl_lo ? dl_lo + row * ldd : nullptr, c, pz[0], pz[1], pz[2], pz[3]);
+        }
+    }
+}
+
 // loss = mean(row_loss) in a fixed order (single block)
 __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, long long n, float* __restrict__ out) {
     __shared__ float sred[256];
@@ -1037,7 +1090,7 @@ __global__ __launch_bounds__(256) void hilo_to_f16_kernel(const bf16_t* __restri
         const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
         uint32_t o[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = pack2_f16(lo_f(aw[k]) + lo_f(bw[k]), hi_f(aw[k]) + hi_f(bw[k]));
+        for (int k = 0; k < 4; ++k) o[k] = pack2_f16_sat(lo_f(aw[k]) + lo_f(bw[k]), hi_f(aw[k]) + hi_f(bw[k]));
         *reinterpret_cast<uint4*>(out + r * ld_out + c) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
@@ -1169,7 +1222,12 @@ extern "C" int amdnuwa_ce_fwd(const float* logits, const long long* targets, flo
                               uint16_t* dl_lo, long long R, int C, int ld_dl, float grad_scale, hipStream_t stream) {
     if (!logits || !targets || !row_loss || !loss || C % 4) return AMDNUWA_ERR_ARG;
     if (R <= 0) return AMDNUWA_OK;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, targets, row_loss, dl_hi, dl_lo, C, ld_dl, grad_scale);
+    if (C <= 2048)
+        hipLaunchKernelGGL(ce_fwd_reg_kernel<2>, dim3((unsigned)R), dim3(256), 0, stream, logits, targets, row_loss, dl_hi, dl_lo, C, ld_dl, grad_scale);
+    else if (C <= 8192)
+        hipLaunchKernelGGL(ce_fwd_reg_kernel<8>, dim3((unsigned)R), dim3(256), 0, stream, logits, targets, row_loss, dl_hi, dl_lo, C, ld_dl, grad_scale);
+    else
+        hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, targets, row_loss, dl_hi, dl_lo, C, ld_dl, grad_scale);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, stream, row_loss, R, loss);
     LAUNCH_CHECK();

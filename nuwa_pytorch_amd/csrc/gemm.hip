@@ -728,15 +728,15 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
                 reinterpret_cast<uint4*>(C)[1] = ug;
                 if constexpr (F16) {
                     if (Cl) {              // fp16 copy of the product itself (q / k / v for the fp16 attention core)
-                        reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2_f16(vv[0], vv[1]), pack2_f16(vv[2], vv[3]), pack2_f16(vv[4], vv[5]), pack2_f16(vv[6], vv[7]));
-                        reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2_f16(vv[8], vv[9]), pack2_f16(vv[10], vv[11]), pack2_f16(vv[12], vv[13]), pack2_f16(vv[14], vv[15]));
+                        reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2_f16_sat(vv[0], vv[1]), pack2_f16_sat(vv[2], vv[3]), pack2_f16_sat(vv[4], vv[5]), pack2_f16_sat(vv[6], vv[7]));
+                        reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2_f16_sat(vv[8], vv[9]), pack2_f16_sat(vv[10], vv[11]), pack2_f16_sat(vv[12], vv[13]), pack2_f16_sat(vv[14], vv[15]));
                     }
                     if (p.C2) {            // gate on the fp32 accumulators; fp16 copy -> C2 (FF2's A operand), bf16 copy -> C2lo (backward)
                         float o[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = vv[e] * gelu_f(vv[8 + e]);
                         *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) =
-                            make_uint4(pack2_f16(o[0], o[1]), pack2_f16(o[2], o[3]), pack2_f16(o[4], o[5]), pack2_f16(o[6], o[7]));
+                            make_uint4(pack2_f16_sat(o[0], o[1]), pack2_f16_sat(o[2], o[3]), pack2_f16_sat(o[4], o[5]), pack2_f16_sat(o[6], o[7]));
                         if (p.C2lo)
                             *reinterpret_cast<uint4*>(p.C2lo + m * p.ldc2 + (nb >> 1)) =
                                 make_uint4(pack2_rne(o[0], o[1]), pack2_rne(o[2], o[3]), pack2_rne(o[4], o[5]), pack2_rne(o[6], o[7]));
@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[i][j][r] * p.alpha + bias16[j * 4 + r];
                     f2bf_hilo(v, h[j * 4 + r], l[j * 4 + r]);
-                    if (p.lo_f16) l[j * 4 + r] = f2h(v);          // (wave-uniform) the second copy is the fp16 value, not the residual
+                    if (p.lo_f16) l[j * 4 + r] = f2h_sat(v);          // (wave-uniform) the second copy is the fp16 value, not the residual
                 }
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
             bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;

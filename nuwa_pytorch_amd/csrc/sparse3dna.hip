@@ -1179,6 +1179,317 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Multi-row tiles of the MFMA kernels (tuning key 16).  One workgroup = ROWS query rows (f, y0 + i dh), i = 0 .. ROWS-1, of one
+// residue class of y modulo the dilation: their key rows are (f - a df, y0 + (i - b) dh), i.e. per tap frame only ROWS + kh - 1
+// distinct rows instead of ROWS * kh.  Every key / value row is fetched from L2 and staged in the wave's LDS tile ONCE per tile and
+// its MFMA fragments are read ONCE; the (up to kh) query rows that tap it reuse them from registers: per query row the L2 -> CU
+// gathers, the ds_write_b128 staging stores (13 LDS cycles each) and the fragment reads drop by ROWS kh / (ROWS + kh - 1) = 2x at
+// ROWS = 4, kh = 3 (1.5x at ROWS = 2).  The per-row score tables, the softmax and the head mix are the single-row kernel's, looped
+// over the rows: the score entries are bit-identical, the apply pass pairs its key rows differently inside an MFMA (fp32 summation
+// order only).  LDS: ROWS x 23.8 KiB of fp32 tables + 8 x 4 KiB tiles: two workgroups per CU at ROWS = 2, one at ROWS = 4.
+// ---------------------------------------------------------------------------------------------
+constexpr int S3T_MAXK = 128;                    // key rows of a tile: kf * (kh + ROWS - 1)
+constexpr int S3T_AUTO_ROWS = 1;                 // tuning key 16 = 0 (set from the A/B of tools/attn_bench.py)
+template <int ROWS>
+struct TileM {
+    int nk, nrows, J, TS, WTS, lane, wave, c, g4;
+    size_t tok0;
+    int iq[ROWS];                                // token row of query c in tile row i
+    bool qok[ROWS];
+    int tsel[4];
+    const int *ktok, *kmeta;                     // key-row list: token row of key 0; meta = tap frame ta << 8 | (m + 64), y_key = y0 + m dh
+};
+// tile t2 of a sample -> (frame, first row y0); the order keeps a residue class of y together (see s3m_row_order)
+template <int ROWS>
+__device__ __forceinline__ void s3t_tile_order(const S3Args& a, int t2, int& f, int& y0) {
+    const int ng = a.H / (a.dh * ROWS);          // tiles per residue class and frame
+    int cl, gi;
+    if (a.ymajor) { const int per = ng * a.F; cl = t2 / per; const int rem = t2 % per; gi = rem / a.F; f = rem % a.F; }
+    else { const int per = a.H / ROWS; f = t2 / per; const int rem = t2 % per; cl = rem / ng; gi = rem % ng; }
+    y0 = cl + gi * ROWS * a.dh;
+}
+template <int ROWS>
+__device__ __forceinline__ void s3t_keylist(const S3Args& a, int f, int y0, int* ktok, int* kmeta, int* kcnt) {
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int ta = 0; ta < a.kf; ++ta) {
+            const int fr = f - (a.kf - 1 - ta) * a.df;
+            if (fr < 0) continue;
+            for (int m = -(a.kh - 1); m < ROWS; ++m) {
+                const int yk = y0 + m * a.dh;
+                if (yk < 0) continue;
+                ktok[n] = 1 + (fr * a.H + yk) * S3M_W; kmeta[n] = (ta << 8) | (m + 64); ++n;
+            }
+        }
+        *kcnt = n;
+    }
+    __syncthreads();
+}
+template <int ROWS>
+__device__ __forceinline__ TileM<ROWS> s3t_init(const S3Args& a, int b, int f, int y0, int nrows, const int* ktok, const int* kmeta, int nk) {
+    TileM<ROWS> r;
+    r.nk = nk; r.nrows = nrows;
+    r.J = a.kf * a.kh * a.kw + 1; r.TS = s3m_ts(r.J); r.WTS = S3M_W * r.TS;
+    r.lane = threadIdx.x & 63; r.wave = threadIdx.x >> 6; r.c = r.lane & 15; r.g4 = r.lane >> 4;
+    r.tok0 = (size_t)b * a.ntok;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        r.iq[i] = 1 + (f * a.H + y0 + i * a.dh) * S3M_W + r.c;
+        r.qok[i] = i < nrows && r.iq[i] < a.ntok;
+    }
+    r.ktok = ktok; r.kmeta = kmeta;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int d = r.c - (4 * r.g4 + q);
+        r.tsel[q] = -1;
+#pragma unroll
+        for (int tc = 0; tc < S3M_KW; ++tc)
+            if (tc < a.kw && d == (a.kw - 1 - tc) * a.dw) r.tsel[q] = tc;
+    }
+    return r;
+}
+// 16-byte load from a row that always exists, zero-filled by a select (a load under a branch costs the in-order wait counts)
+__device__ __forceinline__ uint4 ldg16_sel(const bf16_t* p, bool ok) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    return ok ? v : make_uint4(0, 0, 0, 0);
+}
+
+// Band scores of head h for every row of the tile: TAB_i[(c, slot, h)] = mul * (frag row of query c of tile row i) . (key row) (+ bias),
+// key rows staged once through the wave's [16][64] tile (see mfma_band_scores_staged) and multiplied with the fragments of the
+// (up to kh) tile rows that tap them.
+template <int ROWS, bool F16, int PF>
+__device__ __forceinline__ void tile_band_scores(const S3Args& a, const TileM<ROWS>& r, const bf16_t* rows, int ldr, const bf16_t* frag,
+                                                 int ldf, int h, float* TAB, float mul, const float* bias, char* tile) {
+    constexpr int NH = S3M_NH, DH = S3M_DH;
+    bf16x8 qf0[ROWS], qf1[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const bf16_t* qrow = frag + (r.tok0 + (r.qok[i] ? r.iq[i] : 0)) * ldf + h * DH + r.g4 * 8;
+        qf0[i] = __builtin_bit_cast(bf16x8, ldg16_sel(qrow, r.qok[i]));
+        qf1[i] = __builtin_bit_cast(bf16x8, ldg16_sel(qrow + 32, r.qok[i]));
+    }
+    const int gc = r.lane & 7, r8 = r.lane >> 3;
+    const bf16_t* kbase = rows + r.tok0 * ldr + h * DH + gc * 8;                  // + token * ld
+    const int spb = r.c * r.TS + h;
+    int sidx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
+    const int w0 = vt_off(r8, gc), w1 = vt_off(r8 + 8, gc);
+    const int f0 = vt_off(r.c, r.g4), f1 = vt_off(r.c, 4 + r.g4);
+    uint4 st0[PF], st1[PF];
+    auto issue = [&](int sq, uint4& d0, uint4& d1) {                             // sequence 0: every row is token 0 (<bos>)
+        const int base = (sq == 0 || sq > r.nk) ? -1 : r.ktok[sq - 1];
+        const int t0 = base < 0 ? 0 : base + r8, t1 = base < 0 ? 0 : base + r8 + 8;
+        const bool live = sq <= r.nk;
+        d0 = ldg16_sel(kbase + (size_t)(t0 < a.ntok ? t0 : 0) * ldr, live && t0 < a.ntok);
+        d1 = ldg16_sel(kbase + (size_t)(t1 < a.ntok ? t1 : 0) * ldr, live && t1 < a.ntok);
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) issue(i, st0[i], st1[i]);
+    for (int sq = 0; sq <= r.nk; ++sq) {
+        *reinterpret_cast<uint4*>(tile + w0) = st0[0];
+        *reinterpret_cast<uint4*>(tile + w1) = st1[0];
+#pragma unroll
+        for (int i = 0; i + 1 < PF; ++i) { st0[i] = st0[i + 1]; st1[i] = st1[i + 1]; }
+        issue(sq + PF, st0[PF - 1], st1[PF - 1]);
+        __builtin_amdgcn_wave_barrier();                                          // LDS is in-order per wave: the tile is complete
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(tile + f0), k1 = *reinterpret_cast<const bf16x8*>(tile + f1);
+        if (sq == 0) {
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                if (i >= r.nrows) continue;
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+                sc = mfma16<F16>(k0, qf0[i], sc);
+                sc = mfma16<F16>(k1, qf1[i], sc);
+                if (r.g4 == 0 && r.qok[i]) TAB[i * r.WTS + spb] = sc[0] * mul + (bias ? bias[h] : 0.f);
+            }
+        } else {
+            const int meta = r.kmeta[sq - 1], ta = meta >> 8, m = (meta & 255) - 64;
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                const int tb = m - i + a.kh - 1;
+                if (i >= r.nrows || tb < 0 || tb >= a.kh) continue;              // (wave-uniform)
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+                sc = mfma16<F16>(k0, qf0[i], sc);
+                sc = mfma16<F16>(k1, qf1[i], sc);
+                if (r.qok[i]) {
+                    const int jb = 1 + (ta * a.kh + tb) * a.kw;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (r.tsel[q] >= 0)
+                            TAB[i * r.WTS + sidx[q] + jb * NH] = sc[q] * mul + (bias ? bias[(jb + r.tsel[q]) * NH + h] : 0.f);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Band apply of head g for every row of the tile: O_i[query c][d] = TAB_i[c][0][g] rows[<bos>][d] + sum over key rows / taps ...
+// The rows of TWO list entries (32 keys) are staged and read back transposed once per chunk; every tile row that taps one of them
+// runs its 4 MFMAs on the shared A fragments with its own banded coefficients (zeros for an entry it does not tap).
+template <int ROWS, bool F16>
+__device__ __forceinline__ void tile_band_apply(const S3Args& a, const TileM<ROWS>& r, const bf16_t* rows, int ldr, int g, const float* TAB,
+                                                char* tile, f32x4 (&O)[ROWS][4]) {
+    constexpr int NH = S3M_NH, DH = S3M_DH;
+    const int spb = r.c * r.TS + g;
+    {   // <bos> slot
+        const bf16_t* vb = rows + r.tok0 * ldr + g * DH + 4 * r.g4;
+        uint2 u[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) u[db] = *reinterpret_cast<const uint2*>(vb + db * 16);
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const float p0 = r.qok[i] ? TAB[i * r.WTS + spb] : 0.f;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                O[i][db] = f32x4{p0 * lo_t<F16>(u[db].x), p0 * hi_t<F16>(u[db].x), p0 * lo_t<F16>(u[db].y), p0 * hi_t<F16>(u[db].y)};
+        }
+    }
+    const int gc = r.lane & 7, r8 = r.lane >> 3;
+    const bf16_t* vbase = rows + r.tok0 * ldr + g * DH + gc * 8;
+    int woff[4], sidx[4], troff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) woff[i] = vt_off(r8 + 8 * i, gc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
+    {
+        const int r0 = 4 * r.g4 + (r.c >> 2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const int col = db * 16 + ((r.c & 3) << 2);
+            troff[db] = vt_off(r0, col >> 3) + ((col >> 2) & 1) * 8;
+        }
+    }
+    uint4 st[4];
+    auto fetch = [&](int pi) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pj = pi + (i >> 1);
+            const int tok = pj < r.nk ? r.ktok[pj] + r8 + 8 * (i & 1) : a.ntok;
+            st[i] = ldg16_sel(vbase + (size_t)(tok < a.ntok ? tok : 0) * ldr, tok < a.ntok);
+        }
+    };
+    fetch(0);
+    for (int pi = 0; pi < r.nk; pi += 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + woff[i]) = st[i];
+        const int meta0 = r.kmeta[pi], meta1 = pi + 1 < r.nk ? r.kmeta[pi + 1] : -1;
+        if (pi + 2 < r.nk) fetch(pi + 2);                                         // the next chunk's rows are in flight below
+        const int ta0 = meta0 >> 8, m0 = (meta0 & 255) - 64, ta1 = meta1 >> 8, m1 = (meta1 & 255) - 64;
+        __builtin_amdgcn_wave_barrier();                                          // LDS is in-order per wave: the tile is complete
+        bf16x8 A[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db] + 2048));
+            const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            A[db] = __builtin_bit_cast(bf16x8, v8);
+        }
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int tb0 = m0 - i + a.kh - 1, tb1 = m1 - i + a.kh - 1;
+            const bool u0 = i < r.nrows && tb0 >= 0 && tb0 < a.kh, u1 = i < r.nrows && meta1 >= 0 && tb1 >= 0 && tb1 < a.kh;
+            if (!(u0 || u1)) continue;                                            // (wave-uniform)
+            const int jb0 = (1 + (ta0 * a.kh + (u0 ? tb0 : 0)) * a.kw) * NH, jb1 = u1 ? (1 + (ta1 * a.kh + tb1) * a.kw) * NH : 0;
+            float pf[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = r.tsel[j] >= 0 && r.qok[i];
+                pf[j] = (on && u0) ? TAB[i * r.WTS + sidx[j] + jb0] : 0.f;
+                pf[4 + j] = (on && u1) ? TAB[i * r.WTS + sidx[j] + jb1] : 0.f;
+            }
+            const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pack2_t<F16>(pf[0], pf[1]), pack2_t<F16>(pf[2], pf[3]),
+                                                                     pack2_t<F16>(pf[4], pf[5]), pack2_t<F16>(pf[6], pf[7])));
+#pragma unroll
+            for (int db = 0; db < 4; ++db) O[i][db] = mfma16<F16>(A[db], pb, O[i][db]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int ROWS, bool F16>
+__global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3Args a) {
+    constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int J = a.kf * a.kh * a.kw + 1, WTS = W * s3m_ts(J);
+    float* SP = reinterpret_cast<float*>(smem);                                  // [ROWS][W][J * NH + 4]
+    char* vt_base = smem + (size_t)ROWS * WTS * sizeof(float);                   // 8 wave-private [32][64] bf16 tiles
+    __shared__ float wsh[64];
+    __shared__ int ktok[S3T_MAXK], kmeta[S3T_MAXK], kcnt[1];
+    const int t = threadIdx.x;
+    const int tiles = a.F * (a.H / ROWS);
+    const int bid = xcd_row_id();
+    const int b = bid / tiles, t2 = bid % tiles;
+    int f, y0;
+    s3t_tile_order<ROWS>(a, t2, f, y0);
+    const int ry0 = f * a.H + y0;
+    if (t < NH * NH) wsh[t] = a.wth[t];
+    if (ry0 == 0) {                                                              // <bos> output row = its own value
+        for (int e = t; e < NH * DH; e += blockDim.x) {
+            const bf16_t raw = a.v[((size_t)b * a.ntok) * a.ld + e];
+            if (F16) {
+                bf16_t hi, lo;
+                f2bf_hilo((float)__builtin_bit_cast(_Float16, raw), hi, lo);
+                a.o[((size_t)b * a.ntok) * a.ldo + e] = hi;
+                if (a.ol) a.ol[((size_t)b * a.ntok) * a.ldo + e] = lo;
+            } else a.o[((size_t)b * a.ntok) * a.ldo + e] = raw;
+        }
+    }
+    int nrows = 0;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) nrows += ((ry0 + i * a.dh) * W + 1 < a.ntok) ? 1 : 0;   // (rows of a tile exist in order)
+    if (nrows == 0) return;                                                      // whole tile beyond the sequence (uniform)
+    for (int e = t; e < nrows * WTS; e += blockDim.x) SP[e] = NEG_MAX;
+    s3t_keylist<ROWS>(a, f, y0, ktok, kmeta, kcnt);
+    const TileM<ROWS> r = s3t_init<ROWS>(a, b, f, y0, nrows, ktok, kmeta, kcnt[0]);
+    tile_band_scores<ROWS, F16, ROWS >= 4 ? 4 : S3M_PF>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias, vt_base + r.wave * 4096);
+    __syncthreads();
+    for (int i = 0; i < nrows; ++i) rowm_softmax(SP + i * WTS, J);
+    __syncthreads();
+    // talking heads: P'[g] = sum_h Wth[g][h] P[h] per (row, w, j), in place
+    float wr[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) wr[k] = wsh[k];
+    const float rJ = 1.f / (float)J, rWJ = 1.f / (float)(W * J);
+    for (int it = t; it < nrows * W * J; it += blockDim.x) {
+        const int i = (int)(((float)it + 0.5f) * rWJ), item = it - i * W * J;
+        float pv[8], out[8];
+        const int ib = i * WTS + s3m_item(item, rJ);
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) pv[hh] = SP[ib + hh];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < 8; ++hh) s += wr[g * NH + hh] * pv[hh];
+            out[g] = s;
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) SP[ib + g] = out[g];
+    }
+    __syncthreads();
+    {
+        const int g = r.wave;
+        f32x4 O[ROWS][4];
+        tile_band_apply<ROWS, F16>(a, r, a.v, a.ld, g, SP, vt_base + r.wave * 4096, O);
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            if (!r.qok[i]) continue;
+            const size_t go = (r.tok0 + r.iq[i]) * a.ldo + g * DH + 4 * r.g4;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const uint32_t h01 = pack2_rne(O[i][db][0], O[i][db][1]), h23 = pack2_rne(O[i][db][2], O[i][db][3]);
+                *reinterpret_cast<uint2*>(a.o + go + db * 16) = make_uint2(h01, h23);
+                if (F16 && a.ol)
+                    *reinterpret_cast<uint2*>(a.ol + go + db * 16) = make_uint2(pack2_rne(O[i][db][0] - lo_f(h01), O[i][db][1] - hi_f(h01)),
+                                                                                pack2_rne(O[i][db][2] - lo_f(h23), O[i][db][3] - hi_f(h23)));
+            }
+        }
+    }
+}
+
 // MFMA backward, query side (same row / wave mapping as the forward): recompute P, dP' = dO . V^T (band scores with dO as the
 // fragment and V as the rows), dW_th partial, dP = W^T dP', ds = P (dP - sum P dP), dq = scale * ds . K (band apply over K);
 // ds and P' go to the fp32 workspace for the key-side kernel, the <bos> key / value partials to part_k0 / part_v0.
@@ -1696,6 +2007,31 @@ void self_kv(S3Args& a) {
 }
 int block_threads(const amdnuwa_s3_geom* g) { return ((g->W * g->heads * 4 + 63) / 64) * 64; }
 
+// query rows per workgroup of the MFMA kernels (tuning key 16: 0 = auto, 1 / 2 / 4 = forced where the geometry allows it): a tile is
+// ROWS rows of one residue class of y modulo the dilation, so H must split into dh * ROWS
+int s3_tile_rows(const amdnuwa_s3_geom* g) {
+    int want = g_amdnuwa_tuning[16];
+    if (want == 0) want = S3T_AUTO_ROWS;
+    for (int rws = want >= 4 ? 4 : (want >= 2 ? 2 : 1); rws > 1; rws >>= 1)
+        if (g->dh > 0 && g->H % (g->dh * rws) == 0 && g->kf * (g->kh + rws - 1) <= S3T_MAXK) return rws;
+    return 1;
+}
+template <bool F16>
+int s3_fwd_tile_launch(const S3Args& a, const amdnuwa_s3_geom* g, int tr, hipStream_t stream) {
+    const int J = g->kf * g->kh * g->kw + 1;
+    const size_t lm = (size_t)tr * 16 * (J * 8 + 4) * sizeof(float) + 8 * 4096;
+    const dim3 grid(g->B * g->F * (g->H / tr));
+    if (tr == 4) {
+        (void)hipFuncSetAttribute((const void*)s3_fwd_tile_kernel<4, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+        hipLaunchKernelGGL((s3_fwd_tile_kernel<4, F16>), grid, dim3(512), lm, stream, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)s3_fwd_tile_kernel<2, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+        hipLaunchKernelGGL((s3_fwd_tile_kernel<2, F16>), grid, dim3(512), lm, stream, a);
+    }
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
 }  // namespace
 
 extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* k, const uint16_t* v,
@@ -1728,6 +2064,8 @@ extern "C" int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* 
     if (!lo_mode && !g->noncausal && !(g_amdnuwa_tuning[3] & 1) && g->W == 16 && g->heads == 8 && g->dim_head == 64 && g->kw <= S3M_KW &&
         g->kf * g->kh <= S3M_PLANES && ld % 8 == 0 && ldo % 4 == 0) {
         a.dbg = g_amdnuwa_tuning[9];
+        const int tr = s3_tile_rows(g);
+        if (tr > 1) return s3_fwd_tile_launch<false>(a, g, tr, stream);
         const size_t lm = (size_t)16 * (J * 8 + 4) * sizeof(float) + 8 * 4096;
         (void)hipFuncSetAttribute((const void*)s3_fwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
         hipLaunchKernelGGL(s3_fwd_mfma_kernel<false>, grid, dim3(512), lm, stream, a);
@@ -1760,6 +2098,10 @@ extern "C" int amdnuwa_sparse3dna_fwd_f16(const amdnuwa_s3_geom* g, const uint16
     a.o = o; a.ol = o_lo; a.ldo = ldo; a.wth = w_th;
     self_kv(a);
     const int J = g->kf * g->kh * g->kw + 1;
+    {
+        const int tr = s3_tile_rows(g);
+        if (tr > 1) return s3_fwd_tile_launch<true>(a, g, tr, stream);
+    }
     const size_t lm = (size_t)16 * (J * 8 + 4) * sizeof(float) + 8 * 4096;
     (void)hipFuncSetAttribute((const void*)s3_fwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
     hipLaunchKernelGGL(s3_fwd_mfma_kernel<true>, dim3(g->B * g->F * g->H), dim3(512), lm, stream, a);

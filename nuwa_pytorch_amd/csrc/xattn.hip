@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void xattn_pack_kernel(const bf16_t* __restric
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 f2bf_hilo(null_k[h * DH + dc + t], hk[t], lk[t]); f2bf_hilo(null_v[h * DH + dc + t], hv[t], lv[t]);
-                if (lo_f16) { lk[t] = f2h(null_k[h * DH + dc + t]); lv[t] = f2h(null_v[h * DH + dc + t]); }
+                if (lo_f16) { lk[t] = f2h_sat(null_k[h * DH + dc + t]); lv[t] = f2h_sat(null_v[h * DH + dc + t]); }
             }
             r[0] = make_uint4(pack2(hk[0], hk[1]), pack2(hk[2], hk[3]), pack2(hk[4], hk[5]), pack2(hk[6], hk[7]));
             r[1] = make_uint4(pack2(hv[0], hv[1]), pack2(hv[2], hv[3]), pack2(hv[4], hv[5]), pack2(hv[6], hv[7]));

@@ -28,8 +28,10 @@ Design for 8 x MI355X (xGMI is point-to-point, 7 links per GPU):
   * frozen parameters (the VAE copy inside NUWA never receives gradients -- quirk Q16) are excluded.
 Works with the `gloo` backend on CPU tensors too (used by the world_size-2 tests).
 """
+import atexit
 import contextlib
 import ctypes as C
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -88,7 +90,11 @@ class NativeComm:
             dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
                                        group=process_group)
         self._h = C.c_void_p()
-        self._check(self._lib.amdnuwa_comm_init(C.byref(self._h), box[0], 128, self.rank, self.world, self.device), 'amdnuwa_comm_init')
+        self._rc(self._lib.amdnuwa_comm_init(C.byref(self._h), box[0], 128, self.rank, self.world, self.device), 'amdnuwa_comm_init')
+        # the communicator is torn down explicitly (GradReducer.remove() / close()) or at interpreter exit while HIP and the process
+        # group are still alive -- not from __del__ during interpreter teardown
+        ref = weakref.ref(self)
+        atexit.register(lambda: ref() is not None and ref().close())
 
     def _rc(self, rc, what):
         if rc == -4:
@@ -116,11 +122,6 @@ class NativeComm:
             self._lib.amdnuwa_comm_destroy(self._h)
             self._h = C.c_void_p()
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
 
 class _Enqueued:
@@ -131,9 +132,12 @@ class _Enqueued:
 
 
 class GradReducer:
-    def __init__(self, module, process_group=None, bucket_fn=_layer_key, average=True, collective='allreduce'):
+    def __init__(self, module, process_group=None, bucket_fn=_layer_key, average=True, collective='allreduce', always_reduce=False):
+        """always_reduce: run the bucket collectives even in a world of one rank (they are then identities) -- lets a 1-GPU box
+        exercise the exact RCCL call sequence, in-place shard aliasing included, that N ranks would run"""
         if collective not in ('allreduce', 'rs_ag', 'native', 'native_rs_ag'):
             raise ValueError(collective)
+        self.always_reduce = bool(always_reduce)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -161,10 +165,10 @@ class GradReducer:
         self.cuda = bool(self.buckets) and self.buckets[0]['flat'].is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
         self.native = None
-        if collective.startswith('native') and self.world > 1:
+        if collective.startswith('native') and (self.world > 1 or self.always_reduce):
             if not self.cuda or any(b['flat'].dtype != torch.float32 for b in self.buckets):
                 raise RuntimeError("GradReducer(collective='native'): fp32 gradients on a HIP device")
-            self.native = NativeComm(process_group)
+            self.native = NativeComm(process_group, device=self.buckets[0]['flat'].device.index)     # the device that HOLDS the buckets
         self._avg_op = bool(self.cuda and dist.is_initialized() and dist.get_backend(process_group) == 'nccl')
         self._hooks = []
         for b in self.buckets:
@@ -235,7 +239,7 @@ class GradReducer:
 
     def _launch(self, b):
         b['launched'] = True
-        if self.world == 1:
+        if self.world == 1 and not (self.always_reduce and (self.native is not None or dist.is_initialized())):
             return
         if self.cuda:
             ev = torch.cuda.Event()
@@ -257,7 +261,7 @@ class GradReducer:
         for b in self.buckets:
             if b['work'] is not None:
                 b['work'].wait()
-        if self.cuda and self.world > 1:
+        if self.cuda and (self.world > 1 or self.always_reduce):
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def total_bytes(self):
@@ -267,3 +271,8 @@ class GradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self.native is not None:
+            if self.cuda:
+                self.comm_stream.synchronize()
+            self.native.close()
+            self.native = None

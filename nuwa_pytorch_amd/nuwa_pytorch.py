@@ -200,9 +200,9 @@ class SandwichNorm(nn.Module):
                 nxt_fn = nxt.fn.fn if isinstance(nxt.fn, (ShiftVideoTokens,)) else nxt.fn
                 nxt_kind = None                  # what the next block's first GEMM is (it may want an fp16 copy of its input: ops.SandwichBlockFn)
                 if isinstance(nxt_fn, FeedForward):
-                    nxt_kind = ('ff', nxt_fn.net[3].weight.shape[1])
+                    nxt_kind = ('ff', nxt_fn.net[3].weight.shape[1], (nxt_fn.net[0].weight, nxt_fn.net[3].weight))
                 elif isinstance(nxt_fn, Sparse3DNA) and nxt_fn.causal:
-                    nxt_kind = ('s3', nxt_fn.to_q.weight.shape[0], nxt_fn._meta(B, n, x.device)['geom'])
+                    nxt_kind = ('s3', nxt_fn.to_q.weight.shape[0], nxt_fn._meta(B, n, x.device)['geom'], (nxt_fn.to_q.weight, nxt_fn.to_kv.weight))
                 meta['next_pre'] = (nxt.prenorm.weight, nxt.prenorm.bias, (n, nxt_fmap) if nxt_fmap is not None else None, nxt_kind)
                 meta['handoff_out'] = hout
         return ops.SandwichBlockFn.apply(x, resid, context if isinstance(inner, (Attention, SparseCross2DNA)) else None, meta,
@@ -662,6 +662,16 @@ class Transformer(nn.Module):
                               dict(context=context, mask=mask, context_mask=context_mask),
                               cross_attn._inner(context) if cuda else None))
             calls.append((ff, {}, {}, ff._inner() if cuda else None))
+        if cuda and K.mixed():
+            # fp16 range verdicts of every weight the 'bf16x3-fwd' forward may run in fp16, in ONE device -> host transfer per step
+            ws = []
+            for _, _, _, inner in calls:
+                fn = inner[0] if inner is not None else None
+                if isinstance(fn, FeedForward):
+                    ws += [fn.net[0].weight, fn.net[3].weight]
+                elif isinstance(fn, Sparse3DNA):
+                    ws += [fn.to_q.weight, fn.to_kv.weight]
+            ops.f16_ranges_prefetch(ws)
         handoff = None
         for i, (block, fused_kw, plain_kw, inner) in enumerate(calls):
             if inner is None:

@@ -72,6 +72,47 @@ def _cast_t(w):
     return out
 
 
+# fp16 range guard of the 'bf16x3-fwd' forward (its FeedForward / 3DNA q-k-v products run single fp16 MFMAs on fp16 copies of the
+# weights).  fp16 ends at 65504 -- a larger weight would become inf -- and loses significand bits below 6.1e-5, so a weight
+# tensor takes the fp16 form only while its largest magnitude lies in [F16_WMIN, F16_WMAX]; otherwise the block runs the bf16 hi + lo
+# (3-MFMA) products, which have fp32's range.  One device -> host transfer per call of f16_ranges_prefetch() covers every weight
+# whose (storage, version) has not been judged yet: Transformer.forward_layers calls it once per step for the whole stack.
+# (Activations are covered in the kernels: every fp16 activation store saturates at +-65504, csrc/common.h pack2_f16_sat.)
+F16_WMAX = 6.0e4
+F16_WMIN = 2.0 ** -10
+_F16_RANGE = {}
+
+
+def f16_ranges_prefetch(ws):
+    todo, seen = [], set()
+    for w in ws:
+        k = (w.data_ptr(), w._version)
+        if k not in _F16_RANGE and k not in seen and w.is_cuda:
+            seen.add(k)
+            todo.append(w)
+    if not todo:
+        return
+    if len(_F16_RANGE) > 8192:
+        _F16_RANGE.clear()
+    with torch.no_grad():
+        am = torch.stack(torch._foreach_norm([w.detach() for w in todo], float('inf'))).cpu().tolist()     # ONE synchronisation
+    for w, a in zip(todo, am):
+        _F16_RANGE[(w.data_ptr(), w._version)] = bool(F16_WMIN <= a <= F16_WMAX)       # (NaN compares false)
+
+
+def f16_weights_ok(*ws):
+    f16_ranges_prefetch(ws)
+    return all(_F16_RANGE.get((w.data_ptr(), w._version), False) for w in ws)
+
+
+def _f16_to_pair(h):
+    """an activation that arrived as a bf16 + fp16 copy pair, for a block that has to run hi + lo products after all (its weights
+    left the fp16 range): hi + lo with lo = bf16(fp16 value - hi) carries the fp16 value exactly (11 significand bits)"""
+    if h.lo is None and h.f16 is not None:
+        return BF(h.hi, (h.f16.float() - h.hi.float()).to(torch.bfloat16))
+    return h
+
+
 # =================================================================================================
 # inner stages.  fwd(h: BF [R, D], ...) -> (y fp32 [R, D], saved) ; bwd(saved, dy: BF) -> (dh fp32, grads)
 # =================================================================================================
@@ -94,15 +135,17 @@ class S3Inner:
             K.transpose_cast(wq.detach(), qkvT, col0=0)
             K.transpose_cast(wkv.detach(), qkvT, col0=inner)
             out = dict(qkv=qkv, qkvT=qkvT, out=_cast(wo), outT=_cast_t(wo))
-            if K.mixed():                       # fp16 copy for the fp16-operand q / k / v projection of 'bf16x3-fwd'
+            if K.mixed() and f16_weights_ok(wq, wkv):   # fp16 copy for the fp16-operand q / k / v projection of 'bf16x3-fwd'
                 out['qkv_16'] = torch.cat((wq.detach(), wkv.detach()), 0).to(torch.float16).contiguous()
             return out
         return cache.get('s3', (wq, wkv, wo), build)
 
     @staticmethod
-    def f16_proj_ok(R, D, inner, g):
-        """'bf16x3-fwd': q / k / v projection on single fp16 MFMAs (bf16 + fp16 copies out) feeding the fp16 core"""
-        return K.qkv_f16() and K.s3_f16_supported(g) and K.gemm_nt_f16ops_ok(R, 3 * inner, D, out_bf16=True)
+    def f16_proj_ok(R, D, inner, g, ws=None):
+        """'bf16x3-fwd': q / k / v projection on single fp16 MFMAs (bf16 + fp16 copies out) feeding the fp16 core; ws = (to_q.weight,
+        to_kv.weight) adds the fp16 range guard of the weights"""
+        return K.qkv_f16() and K.s3_f16_supported(g) and K.gemm_nt_f16ops_ok(R, 3 * inner, D, out_bf16=True) and \
+            (ws is None or f16_weights_ok(*ws))
 
     @staticmethod
     def fwd(h, p, meta):
@@ -116,8 +159,7 @@ class S3Inner:
             h16 = h.f16 if h.f16 is not None else K.hilo_to_f16(h)
             qkv = K.gemm_nt_f16ops(h16, W['qkv_16'], out_bf16=True, copy_f16=True)
         else:
-            if h.lo is None and h.f16 is not None:
-                raise RuntimeError('Sparse3DNA received an fp16-copy activation but cannot run the fp16-operand projection')
+            h = _f16_to_pair(h)
             f16 = K.cores_f16() and h.lo is not None and K.s3_f16_supported(g)
             qkv = K.gemm_nt(h, W['qkv'], out_bf16=True, shift=meta.get('shift'), out_f16=f16)
         o = K.sparse3dna_fwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), rel_bias=rel)
@@ -269,7 +311,7 @@ class FFInner:
             w2T = K.zeros_bf((FP, D), dev)
             K.transpose_cast(w2.detach(), w2T)
             out = dict(w1=w1p, w1T=w1T, w2=w2p, w2T=w2T, FP=FP, FFI=FFI)
-            if K.mixed():                       # fp16 copies for the fp16-operand forward GEMMs of 'bf16x3-fwd'
+            if K.mixed() and f16_weights_ok(w1, w2):    # fp16 copies for the fp16-operand forward GEMMs of 'bf16x3-fwd'
                 out['w1_16'] = w1il.to(torch.float16).contiguous()
                 w2pad = torch.zeros((D, FP), dtype=torch.float32, device=dev)
                 w2pad[:, :FFI] = w2.detach()
@@ -278,9 +320,11 @@ class FFInner:
         return cache.get('ff', (w1, w2), build)
 
     @staticmethod
-    def f16_ok(R, D, FP):
-        """the fp16-operand forward applies when 'bf16x3-fwd' wants it and both products run on the 256x256 ring"""
-        return K.ff_f16() and K.gemm_nt_f16ops_ok(R, 2 * FP, D, out_bf16=True, gate=True) and K.gemm_nt_f16ops_ok(R, D, FP, out_bf16=False)
+    def f16_ok(R, D, FP, ws=None):
+        """the fp16-operand forward applies when 'bf16x3-fwd' wants it, both products run on the 256x256 ring and (ws = the two
+        weights) the weights sit inside the fp16 range"""
+        return K.ff_f16() and K.gemm_nt_f16ops_ok(R, 2 * FP, D, out_bf16=True, gate=True) and K.gemm_nt_f16ops_ok(R, D, FP, out_bf16=False) and \
+            (ws is None or f16_weights_ok(*ws))
 
     @staticmethod
     def fwd(h, p, meta):
@@ -293,8 +337,7 @@ class FFInner:
             u, gg16, ggb = K.gemm_nt_f16ops(h16, W['w1_16'], out_bf16=True, gate=True)
             y = K.gemm_nt_f16ops(gg16, W['w2_16'])
             return y, (K.BF(h.hi, None), K.BF(u, None), K.BF(ggb, None))
-        if h.lo is None and h.f16 is not None:
-            raise RuntimeError('FeedForward received an fp16-copy activation but cannot run the fp16-operand path')
+        h = _f16_to_pair(h)
         gg = K.empty_bf((h.hi.shape[0], W['FP']), h.hi.device)
         u = K.gemm_nt(h, W['w1'], out_bf16=True, shift=meta.get('shift'), geglu_out=gg)   # u (interleaved layout) and a * gelu(gate)
         y = K.gemm_nt(gg, W['w2'], out_bf16=_fast())
@@ -502,8 +545,8 @@ class SandwichBlockFn(Function):
         hin, nxt, hout = meta.pop('handoff_in', None), meta.pop('next_pre', None), meta.pop('handoff_out', None)
         ctx.prev_ctx = None
         # h as a bf16 + fp16 copy pair when this block's first GEMM runs fp16 operands ('bf16x3-fwd': FeedForward, the 3DNA projection)
-        want16 = (meta['kind'] == 'ff' and FFInner.f16_ok(B * n, D, _ru(p[1].shape[1], 32))) or \
-                 (meta['kind'] == 's3' and S3Inner.f16_proj_ok(B * n, D, p[0].shape[0], meta['geom']))
+        want16 = (meta['kind'] == 'ff' and FFInner.f16_ok(B * n, D, _ru(p[1].shape[1], 32), (p[0], p[1]))) or \
+                 (meta['kind'] == 's3' and S3Inner.f16_proj_ok(B * n, D, p[0].shape[0], meta['geom'], (p[0], p[1])))
         if hin is not None and hin.get('ptr') == x.data_ptr() and hin.get('ver') == x._version and hin.get('shift') == sh \
                 and resid is None and tuple(hin['h'].hi.shape) == (B * n, D):
             h, m1, r1 = hin['h'], hin['m1'], hin['r1']
@@ -517,8 +560,8 @@ class SandwichBlockFn(Function):
         if nxt is not None and hout is not None:
             # the next block's first GEMM runs fp16 operands: FeedForward (nxt[3] = ('ff', inner width)) or the 3DNA projection (('s3', inner, geom))
             nk = nxt[3] if len(nxt) > 3 else None
-            nxt16 = nk is not None and ((nk[0] == 'ff' and FFInner.f16_ok(B * n, D, _ru(nk[1], 32))) or
-                                        (nk[0] == 's3' and S3Inner.f16_proj_ok(B * n, D, nk[1], nk[2])))
+            nxt16 = nk is not None and ((nk[0] == 'ff' and FFInner.f16_ok(B * n, D, _ru(nk[1], 32), nk[2])) or
+                                        (nk[0] == 's3' and S3Inner.f16_proj_ok(B * n, D, nk[1], nk[2], nk[3])))
             xo, m2, r2, hn, mn, rn = K.ln_post_pre_fwd(y, r2_, post_w.detach(), post_b.detach(), nxt[0].detach(),
                                                        nxt[1].detach(), next_shift=nxt[2], next_f16=nxt16)
             hout.update(h=hn, m1=mn, r1=rn, ptr=xo.data_ptr(), ver=xo._version, shift=nxt[2], ctx=ctx if CHAIN_BWD else None)

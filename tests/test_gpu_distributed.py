@@ -100,18 +100,25 @@ def test_two_rank_step_equals_full_batch():
     assert checked > 80
 
 
-def test_bench_py_two_ranks_end_to_end():
+@pytest.mark.parametrize('launcher', ['self', 'torch.distributed.run'])
+def test_bench_py_two_ranks_end_to_end(launcher):
     """the N > 1 code path of bench.py ITSELF (launch contract, flat parameter broadcast, GradReducer around the timed steps, max over
-    ranks, one JSON line from rank 0): two ranks through torch.distributed.run, gloo backend, both on cuda:0."""
+    ranks, one JSON line from rank 0): two ranks, gloo backend, both on cuda:0 -- started the way the driver starts N = 1
+    (`python bench.py --gpus 2`: bench.py re-executes itself under torch.distributed.run) and through the launcher."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     import json
     import subprocess
     port = 29900 + (os.getpid() % 90)
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
-           '--side-batch', '1', '--backend', 'gloo', '--single-device', '--no-tokenizer', '--no-cpu-baseline']
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
+    tail = ['--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2', '--side-batch', '1', '--backend', 'gloo', '--single-device',
+            '--no-tokenizer', '--no-cpu-baseline']
+    if launcher == 'self':
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py')] + tail
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.join(ROOT, 'bench.py')] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='4')
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
@@ -123,6 +130,64 @@ def test_bench_py_two_ranks_end_to_end():
     assert abs(out['value'] - 2 * 2 * 2560 * 2 / (out['ms_per_step'] * 2e-3)) < 1e-3 * out['value']
     assert out['roofline']['launches'] > 0 and 0 < out['roofline']['frac'] < 1
     assert out['precision_mode'] == 'bf16x3-fwd' and out['fast_mode']['dtype'] == 'bf16' and out['fast_mode']['value'] > 0
+    assert 'single fp16 MFMA on' in out['dtype'] and out['fp16_forward_parts'] == {'cores': True, 'ff': True, 'qkv': True}
+
+
+def test_bench_py_refuses_more_gpus_than_the_box_has():
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0 and f'--gpus {n}' in (r.stderr + r.stdout)
+
+
+def _rccl_worker(q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(29700 + (os.getpid() % 200))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    import nuwa_pytorch_amd as A
+    from nuwa_pytorch_amd.distributed import GradReducer
+    A.set_precision('bf16x3')
+    nuwa = _model(A)
+    text, vid = _data()
+    nuwa(text=text.cuda(), video=vid.cuda(), return_loss=True, cond_dropout_prob=0.).backward()
+    torch.cuda.synchronize()
+    ref = _grads(nuwa)
+    out = {}
+    for coll in ('allreduce', 'rs_ag', 'native', 'native_rs_ag'):
+        nuwa.zero_grad(set_to_none=True)
+        red = GradReducer(nuwa, collective=coll, always_reduce=True)
+        red.zero_grad()
+        nuwa(text=text.cuda(), video=vid.cuda(), return_loss=True, cond_dropout_prob=0.).backward()
+        red.finish()
+        torch.cuda.synchronize()
+        got = _grads(nuwa)
+        import numpy as np
+        out[coll] = (all(np.array_equal(got[n], ref[n]) for n in ref), red.native is not None, len(red.buckets))
+        red.remove()
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def test_reducer_collectives_on_rccl_one_rank():
+    """every exchange form of the reducer on the REAL backend (RCCL through torch.distributed and through libamdnuwa's own
+    communicator), one rank on the one device a test box has: with always_reduce the bucket collectives run (AVG all-reduce; the
+    in-place reduce-scatter + all-gather on the padded store, shard aliasing included) on the side stream from the gradient hooks
+    and must hand back exactly the local gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(q,))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    for coll, (same, native, nb) in out.items():
+        assert same, f'{coll}: reduced gradients differ from the local ones in a world of one'
+        assert native == coll.startswith('native') and nb >= 4
     assert 8.5 < out['config']['loss'] < 10.0                      # ~ln(8192) at random init
 
 

@@ -792,6 +792,53 @@ def test_sparse3dna_fwd_f16_core(K, O, shape, kern, dil, n):
     report(f's3_fwd_f16_vs_x3[{shape},{dil},{n}]', bf_value(o), bf_value(o3), 3e-3)
 
 
+@pytest.mark.parametrize('rows', [2, 4])
+@pytest.mark.parametrize('shape,kern,dil,n,bias', [((2, 16, 16), (5, 3, 3), (1, 1, 1), None, False), ((3, 16, 16), (3, 3, 3), (4, 4, 4), 300, False),
+                                                   ((5, 16, 16), (5, 3, 3), (2, 2, 2), 1 + 4 * 256 + 100, False), ((3, 16, 16), (5, 3, 3), (2, 1, 4), 530, True),
+                                                   ((2, 16, 16), (3, 2, 3), (1, 2, 1), 1 + 256 + 16, True), ((10, 16, 16), (5, 3, 3), (4, 4, 4), None, False)])
+def test_sparse3dna_fwd_multi_row_tiles(K, O, rows, shape, kern, dil, n, bias):
+    """the multi-row tiles of the MFMA forward (tuning key 16: ROWS query rows of one residue class of y per workgroup, every key /
+    value row staged once per tile) against the oracle and against the one-row kernel, bf16 and fp16 operand forms, with partial
+    last rows / frames, per-axis dilations and the relative-position bias"""
+    from nuwa_pytorch_amd import _lib
+    L = _lib.lib()
+    heads, dh = 8, 64
+    N = shape[0] * shape[1] * shape[2]
+    n = N if n is None else n
+    B, inner = 2, heads * dh
+    J = kern[0] * kern[1] * kern[2] + 1
+    torch.manual_seed(31)
+    qkv = torch.randn(B * n, 3 * inner)
+    wth = torch.randn(heads, heads) * 0.5 + torch.eye(heads)
+    rel = torch.randn(heads, J - 1) * 0.7 if bias else None
+    rel_dev = torch.cat((torch.zeros(1, heads), rel.t()), 0).contiguous().to(DEV) if bias else None
+    idx = O.neighbor_table(shape, kern, dil, causal=True)
+    g = K.s3_geom(B, n, shape, kern, dil, heads, dh)
+    tag = f'[{rows},{shape},{dil},{n}]'
+    for f16 in (False, True):
+        if f16:
+            qkvp, qr = _f16_pair(qkv)
+        else:
+            qr = bf_round(qkv)
+            qkvp = to_bf_pair(qr.to(DEV), False)
+        q3 = qr.reshape(B, n, 3, heads, dh)
+        o_ref = O.sparse3dna_core(q3[:, :, 0], q3[:, :, 1], q3[:, :, 2], wth, idx, dh ** -0.5, rel_pos_bias=rel)
+        try:
+            L.amdnuwa_set_tuning(16, 1)
+            o1 = K.sparse3dna_fwd(g, qkvp, wth.to(DEV), rel_bias=rel_dev)
+            L.amdnuwa_set_tuning(16, rows)
+            o2 = K.sparse3dna_fwd(g, qkvp, wth.to(DEV), rel_bias=rel_dev)
+            o2b = K.sparse3dna_fwd(g, qkvp, wth.to(DEV), rel_bias=rel_dev)
+        finally:
+            L.amdnuwa_set_tuning(16, 0)
+        assert torch.equal(o2.hi, o2b.hi)
+        v1, v2 = (bf_value(o1), bf_value(o2)) if f16 else (o1.hi.float(), o2.hi.float())
+        report(f's3_tile.vs_oracle[f16={f16}]' + tag, v2.reshape(B, n, heads, dh), o_ref, 6e-4 if f16 else 2 ** -7)
+        # same scores bit for bit; the apply pass pairs its key rows differently inside an MFMA: fp32 summation order, i.e. at most
+        # one bf16 step on the hi part (2^-8 of the value) / a few 2^-17 on the hi + lo pair
+        report(f's3_tile.vs_one_row[f16={f16}]' + tag, v2, v1, 2e-5 if f16 else 2 ** -8)
+
+
 @pytest.mark.parametrize('B,n,T', [(2, 100, 33), (1, 64, 256), (2, 2560, 256)])
 def test_cross_attention_fwd_f16_core(K, O, B, n, T):
     """the xattn4 core on fp16 operands (fp16 K / V images from xattn_pack, single fp16 MFMAs incl. the head mix, hi + lo output,

@@ -48,6 +48,13 @@ def main():
             t = bench(lambda: K.sparse3dna_fwd(g, qkv, wth), args.iters)
             row.append(f'fwd[{"mfma" if v == 0 else "dot2"}] {t * 1e6:7.1f} us ({by_f / t / 1e9:6.0f} GB/s)')
         L.amdnuwa_set_tuning(3, 0)
+        qkv16 = K.BF(qkv.hi, None, qkv.hi.float().half())
+        for rws in (1, 2, 4):                                  # tuning key 16: query rows per workgroup of the MFMA forward
+            L.amdnuwa_set_tuning(16, rws)
+            t = bench(lambda: K.sparse3dna_fwd(g, qkv, wth), args.iters)
+            t16 = bench(lambda: K.sparse3dna_fwd(g, qkv16, wth), args.iters)
+            row.append(f'fwd[rows {rws}] bf16 {t * 1e6:7.1f} / f16 {t16 * 1e6:7.1f} us')
+        L.amdnuwa_set_tuning(16, 0)
         for v in (0, 1):
             L.amdnuwa_set_tuning(4, v)
             t = bench(lambda: K.sparse3dna_bwd(g, qkv, wth, do), args.iters)

@@ -188,6 +188,19 @@ POLICIES = {
     'f16_cores_f16_ff': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', ff_h='f16', ff_w='f16', ff_o='f16'),
     'f16_cores_f16_ff_qkv': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', ff_h='f16', ff_w='f16', ff_o='f16', s3_h='f16', s3_w='f16'),
     'f16_ff_only': Policy('f32', ff_h='f16', ff_w='f16', ff_o='f16'),
+    # round 4: the 2-MFMA form of the remaining hi + lo products -- fp16 ACTIVATION x exact (fp16 hi + lo) WEIGHT -- on to_out x2 (A operand =
+    # the cores' output, class o), the cross-attention q / kv projections (A = LayerNorm output / context, class h) and to_logits (lg_h)
+    'cur': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', ff_h='f16', ff_w='f16', ff_o='f16', s3_h='f16', s3_w='f16'),
+    'cur_o16': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', ff_h='f16', ff_w='f16', ff_o='f16', s3_h='f16', s3_w='f16',
+                      s3_o='f16', x_o='f16'),
+    'cur_o16_xh16': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', ff_h='f16', ff_w='f16', ff_o='f16', s3_h='f16', s3_w='f16',
+                           s3_o='f16', x_o='f16', x_h='f16'),
+    'cur_2mfma_all': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', ff_h='f16', ff_w='f16', ff_o='f16', s3_h='f16', s3_w='f16',
+                            s3_o='f16', x_o='f16', x_h='f16', lg_h='f16'),
+    # every activation operand fp16, every weight exact: what 2-MFMA products everywhere (FeedForward / qkv included) would give
+    'f16_act_exact_w': Policy('f16', all_w='f32', all_y='f32', all_u='f32'),
+    # ... and with the FeedForward / qkv weights back in fp16 but u / y exact (= cur_2mfma_all spelled from the other side)
+    'f16_act_w16_ffqkv': Policy('f16', all_w='f32', all_y='f32', all_u='f32', ff_w='f16', s3_w='f16'),
     # bf16 with the final GEMM exact / the y stores in fp32
     'bf16_y32': Policy('bf16', all_y='f32'),
     'bf16_lg_exact': Policy('bf16', lg_all='f32'),
