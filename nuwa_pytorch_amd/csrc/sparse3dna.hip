@@ -1190,7 +1190,8 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
 // order only).  LDS: ROWS x 23.8 KiB of fp32 tables + 8 x 4 KiB tiles: two workgroups per CU at ROWS = 2, one at ROWS = 4.
 // ---------------------------------------------------------------------------------------------
 constexpr int S3T_MAXK = 128;                    // key rows of a tile: kf * (kh + ROWS - 1)
-constexpr int S3T_AUTO_ROWS = 1;                 // tuning key 16 = 0 (set from the A/B of tools/attn_bench.py)
+constexpr int S3T_AUTO_ROWS = 2;                 // tuning key 16 = 0.  A/B at b = 128 (profiles/r04a_attn.txt): 2 rows -14..-16 % on every dilation
+                                                 // (two workgroups per CU as before); 4 rows +4..+22 % SLOWER (95 KiB of tables: one workgroup per CU)
 template <int ROWS>
 struct TileM {
     int nk, nrows, J, TS, WTS, lane, wave, c, g4;
@@ -1444,16 +1445,17 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
     for (int e = t; e < nrows * WTS; e += blockDim.x) SP[e] = NEG_MAX;
     s3t_keylist<ROWS>(a, f, y0, ktok, kmeta, kcnt);
     const TileM<ROWS> r = s3t_init<ROWS>(a, b, f, y0, nrows, ktok, kmeta, kcnt[0]);
-    tile_band_scores<ROWS, F16, ROWS >= 4 ? 4 : S3M_PF>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias, vt_base + r.wave * 4096);
+    if (!(a.dbg & 1))     // (a.dbg, tuning key 9: bits 0 / 1 / 2 skip the score / softmax + mix / apply phase -- timing probes, garbage results)
+        tile_band_scores<ROWS, F16, ROWS >= 4 ? 4 : S3M_PF>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias, vt_base + r.wave * 4096);
     __syncthreads();
-    for (int i = 0; i < nrows; ++i) rowm_softmax(SP + i * WTS, J);
+    for (int i = 0; i < nrows && !(a.dbg & 2); ++i) rowm_softmax(SP + i * WTS, J);
     __syncthreads();
     // talking heads: P'[g] = sum_h Wth[g][h] P[h] per (row, w, j), in place
     float wr[64];
 #pragma unroll
     for (int k = 0; k < 64; ++k) wr[k] = wsh[k];
     const float rJ = 1.f / (float)J, rWJ = 1.f / (float)(W * J);
-    for (int it = t; it < nrows * W * J; it += blockDim.x) {
+    for (int it = t; it < nrows * W * J && !(a.dbg & 2); it += blockDim.x) {
         const int i = (int)(((float)it + 0.5f) * rWJ), item = it - i * W * J;
         float pv[8], out[8];
         const int ib = i * WTS + s3m_item(item, rJ);
@@ -1473,7 +1475,13 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
     {
         const int g = r.wave;
         f32x4 O[ROWS][4];
-        tile_band_apply<ROWS, F16>(a, r, a.v, a.ld, g, SP, vt_base + r.wave * 4096, O);
+        if (!(a.dbg & 4)) tile_band_apply<ROWS, F16>(a, r, a.v, a.ld, g, SP, vt_base + r.wave * 4096, O);
+        else {
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i)
+#pragma unroll
+                for (int db = 0; db < 4; ++db) O[i][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
             if (!r.qok[i]) continue;
@@ -1529,8 +1537,12 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     rowm_planes(a, f, y, pslot, ptok);
     const RowM r = rowm_init(a, b, ry, pslot, ptok);
     char* stile = reinterpret_cast<char*>(PM0 + W * NH) + r.wave * 2048;                    // 8 wave-private [16][64] bf16 staging tiles
+    // (a.dbg, tuning key 17: timing probes only -- bit 0 skips the two score sweeps, bit 1 the ds / P' workspace stores, bit 2 the dq
+    //  apply sweep, bit 3 the dW_th partial; results are garbage)
+    if (!(a.dbg & 1)) {
     mfma_band_scores_staged(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias, stile);             // scores
     mfma_band_scores_staged(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, 1.f, nullptr, stile);              // dP'[g] = dO[g] . v_j[g]
+    }
     __syncthreads();
     // recomputing key side: this kernel leaves (row max, 1 / row sum, delta) per (query, head) instead of the ds / P' workspace
     float* gst = a.stats ? a.stats + ((size_t)b * nq + (size_t)ry * W) * NH * 4 : nullptr;
@@ -1554,7 +1566,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
             float s = 0.f;
 #pragma unroll
             for (int hh = 0; hh < 8; ++hh) s += wr[g * NH + hh] * pv[hh];
-            if (iq < a.ntok && !gst) dst[g] = s;
+            if (iq < a.ntok && !gst && !(a.dbg & 2)) dst[g] = s;
             if (j == 0) PM0[wq * NH + g] = iq < a.ntok ? s : 0.f;
         }
     }
@@ -1564,7 +1576,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
         const int pair = t & 63, grp = t >> 6;
         const int g = pair / NH, hh = pair % NH;
         float acc = 0.f;
-        for (int item = grp; item < W * J; item += 8 * 8) {       // eight (dP', P) pairs in flight, added in order (was one dependent LDS pair per iteration, 92 of them)
+        for (int item = grp; item < W * J && !(a.dbg & 8); item += 8 * 8) {       // eight (dP', P) pairs in flight, added in order (was one dependent LDS pair per iteration, 92 of them)
             float dv8[8], pv8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1624,7 +1636,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
                     const int idx = w * TS + j * NH + h;
                     const float dsv = pv[k] * (dv[k] - d);
                     DP[idx] = dsv;
-                    if (i < a.ntok && !gst) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
+                    if (i < a.ntok && !gst && !(a.dbg & 2)) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
                 }
             }
         } else {
@@ -1643,8 +1655,8 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     __syncthreads();                                                              // P is dead: its region now holds the K tiles
     {
         const int h = r.wave;
-        f32x4 O[4];
-        mfma_band_apply(a, r, a.k, a.ld, h, DP, smem + r.wave * 4096, O);
+        f32x4 O[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (!(a.dbg & 4)) mfma_band_apply(a, r, a.k, a.ld, h, DP, smem + r.wave * 4096, O);
         if (r.qok) {
             bf16_t* orow = a.dq + (r.tok0 + r.iq) * a.ldd + h * DH + 4 * r.g4;
 #pragma unroll
@@ -1744,8 +1756,8 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
             const int pj = pi + (i >> 1);
             const int tok = pj < nplanes ? ptok[pj] + r8 + 8 * (i & 1) : a.ntok;
             const bool ok = tok < a.ntok;
-            sq[i] = ok ? *reinterpret_cast<const uint4*>(qbase + (size_t)tok * a.ld) : make_uint4(0, 0, 0, 0);
-            sd[i] = ok ? *reinterpret_cast<const uint4*>(dbase + (size_t)tok * a.lddo) : make_uint4(0, 0, 0, 0);
+            sq[i] = (ok && !(a.dbg & 32)) ? *reinterpret_cast<const uint4*>(qbase + (size_t)tok * a.ld) : make_uint4(0, 0, 0, 0);
+            sd[i] = (ok && !(a.dbg & 32)) ? *reinterpret_cast<const uint4*>(dbase + (size_t)tok * a.lddo) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -1753,7 +1765,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float vs = 0.f, vp = 0.f;
-                if (pj < nplanes && tsel[j] >= 0) {
+                if (pj < nplanes && tsel[j] >= 0 && !(a.dbg & 16)) {
                     const int tok = ptok[pj] + 4 * g4 + j;
                     if (tok < a.ntok) {
                         const size_t ci = (((size_t)b * nq + (tok - 1)) * J + pslot[pj] + tsel[j]) * NH + h;
@@ -2096,6 +2108,7 @@ extern "C" int amdnuwa_sparse3dna_fwd_f16(const amdnuwa_s3_geom* g, const uint16
     fill_geom(a, g);
     a.q = q_f16; a.k = k_f16; a.v = v_f16; a.ld = ld;
     a.o = o; a.ol = o_lo; a.ldo = ldo; a.wth = w_th;
+    a.dbg = g_amdnuwa_tuning[9];
     self_kv(a);
     const int J = g->kf * g->kh * g->kw + 1;
     {
@@ -2140,6 +2153,7 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     a.dO = dO; a.dOl = dO_lo; a.lddo = lddo;
     a.dq = dq; a.dk = dk; a.dv = dv; a.dql = dq_lo; a.dkl = dk_lo; a.dvl = dv_lo; a.ldd = ldd;
     a.dwth = dw_th; a.accumulate = accumulate;
+    a.dbg = g_amdnuwa_tuning[17];
     self_kv(a);
     const size_t J = (size_t)g->kf * g->kh * g->kw + 1, nq = g->ntok - 1, rows = (size_t)g->B * g->F * g->H;
     const size_t inner = (size_t)g->heads * g->dim_head;

@@ -51,6 +51,9 @@ struct X2Args {
                                              // written by the query side, read by the key side
     float *dKp, *dVp;                        // key side: [B][NH][JP][DH] fp32
     int flags;                               // key side: bit 0 = plain block order (probe)
+    int dbg;                                 // tuning key 18, timing probes only (garbage results).  xattn4_fwd: bit 0 no re-staging inside the chunk
+                                             // loops, 1 skip pass 1, 2 skip the probability exchange + its barrier, 3 skip the P'V MFMAs, 4 skip the mix.
+                                             // xattn3_bwd: bit 0 no re-staging, 1 skip the dW_th FMAs, 2 skip pass A, 3 skip pass B
 };
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
@@ -654,8 +657,8 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
         for (int g = 0; g < NH; ++g) dth[g][h] = 0.f;
     }
     stage_chunk<true, true>(smem, 0, 0, b, a.JP, a.Kp, a.Vp, wave, lane);
-    for (int ch = 0; ch < a.nch; ++ch) {
-        if (ch + 1 < a.nch) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
+    for (int ch = 0; ch < ((a.dbg & 4) ? 0 : a.nch); ++ch) {
+        if (ch + 1 < a.nch && !(a.dbg & 1)) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
         else VMCNT(0);
         __builtin_amdgcn_s_barrier();
         const char* base = smem + (ch & 1) * STAGE;
@@ -698,12 +701,14 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) bw[e][gp] = pack2_rne(d0[e], d1[e]);
+            if (!(a.dbg & 2)) {
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 float a0 = dth[2 * gp][h], a1 = dth[2 * gp + 1][h];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { a0 = fmaf(d0[e], P[h][e], a0); a1 = fmaf(d1[e], P[h][e], a1); }
                 dth[2 * gp][h] = a0; dth[2 * gp + 1][h] = a1;
+            }
             }
         }
 #pragma unroll
@@ -752,8 +757,8 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) dQ[h][db] = f32x4{0.f, 0.f, 0.f, 0.f};
     stage_chunk<true, true>(smem, 0, 0, b, a.JP, a.Kp, a.Vp, wave, lane);
-    for (int ch = 0; ch < a.nch; ++ch) {
-        if (ch + 1 < a.nch) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
+    for (int ch = 0; ch < ((a.dbg & 8) ? 0 : a.nch); ++ch) {
+        if (ch + 1 < a.nch && !(a.dbg & 1)) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
         else VMCNT(0);
         __builtin_amdgcn_s_barrier();
         const char* base = smem + (ch & 1) * STAGE;
@@ -920,7 +925,7 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
     if (a.nch > 1) { stage_chunk8<false, false>(smem, 1, 1, b, a.JP, a.Kp, nullptr, wave, lane); VMCNT(4); }
     else VMCNT(0);
     __builtin_amdgcn_s_barrier();                                 // chunk 0 has landed for every wave
-    for (int ch = 0; ch < a.nch; ++ch) {
+    for (int ch = 0; ch < ((a.dbg & 2) ? 0 : a.nch); ++ch) {
         const char* base = smem + (ch & 1) * STAGE;
         const uint32_t vm0 = vwords[ch * 8 + g4], vm1 = vwords[ch * 8 + 4 + g4];
 #pragma unroll
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
         // (a) everyone's have, (b) everyone is done reading stage ch & 1, which chunk ch + 2 may now overwrite
         VMCNT(0);
         __builtin_amdgcn_s_barrier();
-        if (ch + 2 < a.nch) stage_chunk8<false, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, nullptr, wave, lane);
+        if (ch + 2 < a.nch && !(a.dbg & 1)) stage_chunk8<false, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, nullptr, wave, lane);
     }
     float nb[NHH];
 #pragma unroll
@@ -982,18 +987,23 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
                 qk_chunk<F16>(base, 4 * hh + h, c, g4, qf[h], s0, s1);
                 probs(s0, s1, vm0, vm1, c1, nb[h], P[h]);
             }
-            xch_put<F16>(xch_own, lane, P);
+            if (!(a.dbg & 4)) xch_put<F16>(xch_own, lane, P);
+            else asm volatile("" ::"v"(P[0][0]), "v"(P[1][3]), "v"(P[2][5]), "v"(P[3][7]));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(a.dbg & 4)) __builtin_amdgcn_s_barrier();
         f32x4 D[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) D[e] = mixq<F16>(AW, xch_full(xch_own, xch_par, lane, hh, e));   // D[e][rp] = P'[4 hh + rp] of slot e
+        for (int e = 0; e < 8; ++e) {
+            if (!(a.dbg & 16)) D[e] = mixq<F16>(AW, xch_full(xch_own, xch_par, lane, hh, e));   // D[e][rp] = P'[4 hh + rp] of slot e
+            else D[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int rp = 0; rp < 4; ++rp) {
             const int g = 4 * hh + rp;
             const float pv[8] = {D[0][rp], D[1][rp], D[2][rp], D[3][rp], D[4][rp], D[5][rp], D[6][rp], D[7][rp]};
             const bf16x8 pf = pack8<F16>(pv);
+            if (a.dbg & 8) { asm volatile("" ::"v"(pf)); continue; }
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const int d = db * 16 + c;
@@ -1006,7 +1016,7 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
         // (a) everyone's have, (b) everyone is done reading stage ch & 1, which chunk ch + 2 may now overwrite
         VMCNT(0);
         __builtin_amdgcn_s_barrier();
-        if (ch + 2 < a.nch) stage_chunk8<true, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, a.Vt, wave, lane);
+        if (ch + 2 < a.nch && !(a.dbg & 1)) stage_chunk8<true, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, a.Vt, wave, lane);
     }
     if (qok) {
 #pragma unroll
@@ -1265,6 +1275,7 @@ extern "C" int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.q = q; a.ldq = ldq; a.Kp = p->Kp; a.Vp = p->Vp; a.Vt = p->Vt; a.valid = p->valid; a.wth = w_th;
     a.o = o; a.ldo = ldo; a.stats = stats;
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
+    a.dbg = g_amdnuwa_tuning[18];
     const int tiles = (g->n + 63) / 64;
     // tuning key 10: 0 = xattn4 (two waves per query tile, 4 heads each, two waves per SIMD), 2 = xattn3 (one wave, head mix on the
     // matrix pipe), 1 = xattn2 (one wave, VALU head mix)
@@ -1292,6 +1303,7 @@ extern "C" int amdnuwa_xattn2_fwd_f16(const amdnuwa_xattn_geom* g, const uint16_
     a.q = q_f16; a.ldq = ldq; a.Kp = p->Kp_lo; a.Vp = p->Vp_lo; a.Vt = p->Vt_lo; a.valid = p->valid; a.wth = w_th;    // the fp16 images
     a.o = o; a.ol = o_lo; a.ldo = ldo; a.stats = stats;
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
+    a.dbg = g_amdnuwa_tuning[18];
     const int tiles = (g->n + 63) / 64;
     const int lds4 = 2 * STAGE + 8 * XCH;
     (void)hipFuncSetAttribute((const void*)xattn4_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
@@ -1320,6 +1332,7 @@ extern "C" int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
     const int tiles = (g->n + 63) / 64;
     a.nostore = (g_amdnuwa_tuning[10] & 16) ? 1 : 0;
+    a.dbg = g_amdnuwa_tuning[18];
     auto kern = (g_amdnuwa_tuning[10] & 15) == 1 ? xattn2_bwd_kernel : xattn3_bwd_kernel;          // (0 and 2: xattn3_bwd)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
     hipLaunchKernelGGL(kern, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);

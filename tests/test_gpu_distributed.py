@@ -165,7 +165,9 @@ def _rccl_worker(q):
         torch.cuda.synchronize()
         got = _grads(nuwa)
         import numpy as np
-        out[coll] = (all(np.array_equal(got[n], ref[n]) for n in ref), red.native is not None, len(red.buckets))
+        # (not bit-equal: the text encoder's 16-wide heads and the text embedding run PyTorch-ROCm ops whose backward uses atomics)
+        worst = max(float(np.abs(got[n] - ref[n]).max()) / max(float(np.abs(ref[n]).max()), 1e-12) for n in ref)
+        out[coll] = (worst, red.native is not None, len(red.buckets))
         red.remove()
     q.put(out)
     dist.destroy_process_group()
@@ -185,8 +187,8 @@ def test_reducer_collectives_on_rccl_one_rank():
     out = q.get(timeout=600)
     p.join(timeout=120)
     assert p.exitcode == 0
-    for coll, (same, native, nb) in out.items():
-        assert same, f'{coll}: reduced gradients differ from the local ones in a world of one'
+    for coll, (worst, native, nb) in out.items():
+        assert worst <= 1e-5, f'{coll}: reduced gradients differ from the local ones in a world of one (rel {worst:.2e})'
         assert native == coll.startswith('native') and nb >= 4
     assert 8.5 < out['config']['loss'] < 10.0                      # ~ln(8192) at random init
 

@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""Ablation probes of the attention kernels at the cfg-3 geometry (timing only: the probe bits produce garbage results).
+Sparse3DNA forward (tuning key 9: phase skips) on one- and two-row tiles, Sparse3DNA backward (key 17), cross-attention forward and
+backward (key 18; key 10 bit 4 = no dS / P' stores)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nuwa_pytorch_amd import kernels as K, _lib  # noqa: E402
+from attn_bench import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=128)
+    ap.add_argument('--iters', type=int, default=8)
+    ap.add_argument('--dil', type=int, default=2)
+    args = ap.parse_args()
+    K.set_precision('bf16')
+    L = _lib.lib()
+    dev = 'cuda'
+    b, n, heads, dh, T = args.batch, 2560, 8, 64, 256
+    inner = heads * dh
+    torch.manual_seed(0)
+    qkv = K.BF((torch.randn(b * n, 3 * inner, device=dev)).to(torch.bfloat16), None)
+    qkv16 = K.BF(qkv.hi, None, qkv.hi.float().half())
+    do = K.BF((torch.randn(b * n, inner, device=dev)).to(torch.bfloat16), None)
+    wth = (torch.randn(heads, heads, device=dev) * 0.3 + torch.eye(heads, device=dev)).contiguous()
+    g = K.s3_geom(b, n, (10, 16, 16), (5, 3, 3), (args.dil,) * 3, heads, dh)
+    print(f'== Sparse3DNA forward (fp16 operands), b={b}, dilation {args.dil}: tuning key 9 phase skips ==')
+    for rws in (1, 2):
+        L.amdnuwa_set_tuning(16, rws)
+        row = []
+        for nm, bits in (('full', 0), ('no scores', 1), ('no softmax+mix', 2), ('no apply', 4), ('scores only', 6), ('apply only', 3), ('nothing', 7)):
+            L.amdnuwa_set_tuning(9, bits)
+            row.append(f'{nm} {bench(lambda: K.sparse3dna_fwd(g, qkv16, wth), args.iters) * 1e6:7.1f}')
+        L.amdnuwa_set_tuning(9, 0)
+        print(f'rows {rws}: ' + ' | '.join(row))
+    L.amdnuwa_set_tuning(16, 0)
+    print('== Sparse3DNA backward: tuning key 17 (bit 0 no score sweeps, 1 no workspace stores, 2 no dq apply, 3 no dW_th; 4 no coefficient gathers, 5 no q / dO row fetch) ==')
+    row = []
+    for nm, bits in (('full', 0), ('q: no sweeps', 1), ('q: no ws stores', 2), ('q: no apply', 4), ('q: no dWth', 8), ('q: none of them', 15),
+                     ('kv: no coef gathers', 16), ('kv: no row fetch', 32), ('kv: neither', 48), ('all off', 63)):
+        L.amdnuwa_set_tuning(17, bits)
+        row.append(f'{nm} {bench(lambda: K.sparse3dna_bwd(g, qkv, wth, do), args.iters) * 1e6:7.1f}')
+    L.amdnuwa_set_tuning(17, 0)
+    print(' | '.join(row))
+    print(f'== cross attention, b={b}, n={n}, T={T}: tuning key 18 ==')
+    gx = K.x_geom(b, n, T, heads, dh)
+    q = K.BF(torch.randn(b * n, inner, device=dev).to(torch.bfloat16), None)
+    kv = K.BF(torch.randn(b * T, 2 * inner, device=dev).to(torch.bfloat16), None)
+    nk = torch.randn(heads, dh, device=dev)
+    mask = (torch.rand(b, T, device=dev) > 0.2).to(torch.uint8)
+    pk = K.xattn_pack(gx, kv, nk, nk, mask)
+    row = []
+    for nm, bits in (('full', 0), ('no re-staging', 1), ('no pass 1', 2), ('no exchange', 4), ('no PV', 8), ('no mix', 16), ('no staging+pass1', 3),
+                     ('pass 2 QK + softmax only', 1 + 2 + 4 + 8 + 16)):
+        L.amdnuwa_set_tuning(18, bits)
+        row.append(f'{nm} {bench(lambda: K.xattn2_fwd(gx, q, pk, wth), args.iters) * 1e6:7.1f}')
+    L.amdnuwa_set_tuning(18, 0)
+    print('xattn4_fwd: ' + ' | '.join(row))
+    o2, stats = K.xattn2_fwd(gx, q, pk, wth)
+    row = []
+    for nm, bits, k10 in (('full', 0, 0), ('no dS/Pm stores', 0, 16), ('no re-staging', 1, 0), ('no dW_th FMAs', 2, 0), ('no pass A', 4, 0), ('no pass B', 8, 0),
+                          ('no stores, no staging', 1, 16), ('no stores/staging/dWth', 3, 16)):
+        L.amdnuwa_set_tuning(18, bits)
+        L.amdnuwa_set_tuning(10, k10)
+        row.append(f'{nm} {bench(lambda: K.xattn2_bwd(gx, q, do, pk, wth, stats), args.iters) * 1e6:7.1f}')
+    L.amdnuwa_set_tuning(18, 0)
+    L.amdnuwa_set_tuning(10, 0)
+    print('xattn3_bwd: ' + ' | '.join(row))
+
+
+if __name__ == '__main__':
+    main()

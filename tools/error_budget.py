@@ -197,6 +197,11 @@ POLICIES = {
                            s3_o='f16', x_o='f16', x_h='f16'),
     'cur_2mfma_all': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', ff_h='f16', ff_w='f16', ff_o='f16', s3_h='f16', s3_w='f16',
                             s3_o='f16', x_o='f16', x_h='f16', lg_h='f16'),
+    # y (to_out / FF2 outputs entering the post-LayerNorm) stored as fp16 instead of fp32: 2 bytes per element less in the GEMM epilogue, the
+    # LayerNorm forward, the saved activations and the LayerNorm backward
+    'cur_y16': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', ff_h='f16', ff_w='f16', ff_o='f16', s3_h='f16', s3_w='f16', all_y='f16'),
+    'cur_y16_2mfma': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16', ff_h='f16', ff_w='f16', ff_o='f16', s3_h='f16', s3_w='f16', all_y='f16',
+                            s3_o='f16', x_o='f16', x_h='f16', lg_h='f16'),
     # every activation operand fp16, every weight exact: what 2-MFMA products everywhere (FeedForward / qkv included) would give
     'f16_act_exact_w': Policy('f16', all_w='f32', all_y='f32', all_u='f32'),
     # ... and with the FeedForward / qkv weights back in fp16 but u / y exact (= cur_2mfma_all spelled from the other side)
