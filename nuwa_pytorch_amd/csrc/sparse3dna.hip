@@ -49,6 +49,7 @@ struct S3Args {
     int accumulate;
     int dbg;                                              // probe only (tuning key 9): bit 0 / 1 / 2 skip phase 1 / 2 / 3 of the MFMA forward
     int ymajor;                                           // MFMA kernels: workgroup order inside a sample is (y, f) instead of (f, y) (tuning key 3 bit 1 = old order)
+    int sep_passes;                                       // MFMA query-side backward: the three separate item passes instead of the fused one (tuning key 19 = 1)
 };
 
 constexpr float NEG_MAX = -3.4028234663852886e38f;
@@ -954,7 +955,7 @@ __device__ __forceinline__ void mfma_band_scores_staged(const S3Args& a, const R
     const int w0 = vt_off(r8, gc), w1 = vt_off(r8 + 8, gc);
     const int f0 = vt_off(r.c, r.g4), f1 = vt_off(r.c, 4 + r.g4);
     constexpr int PF = S3M_PF;
-    uint4 st0[PF], st1[PF];
+    static_assert(PF == 3, "the sweep below names its three register sets");
     auto issue = [&](int sq, uint4& d0, uint4& d1) {
         if (sq > r.nplanes) { d0 = d1 = make_uint4(0, 0, 0, 0); return; }
         const int base = sq == 0 ? -1 : r.ptok[sq - 1];                          // sequence 0: every row is token 0 (<bos>)
@@ -962,14 +963,14 @@ __device__ __forceinline__ void mfma_band_scores_staged(const S3Args& a, const R
         d0 = t0 < a.ntok ? *reinterpret_cast<const uint4*>(kbase + (size_t)t0 * ldr) : make_uint4(0, 0, 0, 0);
         d1 = t1 < a.ntok ? *reinterpret_cast<const uint4*>(kbase + (size_t)t1 * ldr) : make_uint4(0, 0, 0, 0);
     };
-#pragma unroll
-    for (int i = 0; i < PF; ++i) issue(i, st0[i], st1[i]);
-    for (int sq = 0; sq <= r.nplanes; ++sq) {
-        *reinterpret_cast<uint4*>(tile + w0) = st0[0];
-        *reinterpret_cast<uint4*>(tile + w1) = st1[0];
-#pragma unroll
-        for (int i = 0; i + 1 < PF; ++i) { st0[i] = st0[i + 1]; st1[i] = st1[i + 1]; }
-        issue(sq + PF, st0[PF - 1], st1[PF - 1]);
+    // three planes of rows in flight in three NAMED register sets, refilled in place as soon as their rows sit in the tile: the loop is
+    // unrolled by three so no set ever has to be moved (the rotating form spent 16 v_mov per plane, a sixth of the sweep's instructions)
+    uint4 sa0, sa1, sb0, sb1, sc0, sc1;
+    issue(0, sa0, sa1); issue(1, sb0, sb1); issue(2, sc0, sc1);
+    auto step = [&](int sq, uint4& d0, uint4& d1) {
+        *reinterpret_cast<uint4*>(tile + w0) = d0;
+        *reinterpret_cast<uint4*>(tile + w1) = d1;
+        issue(sq + PF, d0, d1);
         __builtin_amdgcn_wave_barrier();                                          // LDS is in-order per wave: the tile is complete
         const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(tile + f0), k1 = *reinterpret_cast<const bf16x8*>(tile + f1);
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
@@ -984,6 +985,11 @@ __device__ __forceinline__ void mfma_band_scores_staged(const S3Args& a, const R
             for (int q = 0; q < 4; ++q)
                 if (r.tsel[q] >= 0) TAB[sidx[q] + jb * NH] = sc[q] * mul + (bias ? bias[(jb + r.tsel[q]) * NH + h] : 0.f);
         }
+    };
+    for (int sq = 0; sq <= r.nplanes; sq += 3) {
+        step(sq, sa0, sa1);
+        if (sq + 1 <= r.nplanes) step(sq + 1, sb0, sb1);
+        if (sq + 2 <= r.nplanes) step(sq + 2, sc0, sc1);
     }
 }
 
@@ -1278,7 +1284,6 @@ __device__ __forceinline__ void tile_band_scores(const S3Args& a, const TileM<RO
     for (int q = 0; q < 4; ++q) sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
     const int w0 = vt_off(r8, gc), w1 = vt_off(r8 + 8, gc);
     const int f0 = vt_off(r.c, r.g4), f1 = vt_off(r.c, 4 + r.g4);
-    uint4 st0[PF], st1[PF];
     auto issue = [&](int sq, uint4& d0, uint4& d1) {                             // sequence 0: every row is token 0 (<bos>)
         const int base = (sq == 0 || sq > r.nk) ? -1 : r.ktok[sq - 1];
         const int t0 = base < 0 ? 0 : base + r8, t1 = base < 0 ? 0 : base + r8 + 8;
@@ -1286,14 +1291,12 @@ __device__ __forceinline__ void tile_band_scores(const S3Args& a, const TileM<RO
         d0 = ldg16_sel(kbase + (size_t)(t0 < a.ntok ? t0 : 0) * ldr, live && t0 < a.ntok);
         d1 = ldg16_sel(kbase + (size_t)(t1 < a.ntok ? t1 : 0) * ldr, live && t1 < a.ntok);
     };
-#pragma unroll
-    for (int i = 0; i < PF; ++i) issue(i, st0[i], st1[i]);
-    for (int sq = 0; sq <= r.nk; ++sq) {
-        *reinterpret_cast<uint4*>(tile + w0) = st0[0];
-        *reinterpret_cast<uint4*>(tile + w1) = st1[0];
-#pragma unroll
-        for (int i = 0; i + 1 < PF; ++i) { st0[i] = st0[i + 1]; st1[i] = st1[i + 1]; }
-        issue(sq + PF, st0[PF - 1], st1[PF - 1]);
+    // one key row: stage, read its two fragments once, multiply with the fragments of the (up to kh) tile rows that tap it; the
+    // register set is refilled in place (see mfma_band_scores_staged: named sets, no rotation moves)
+    auto step = [&](int sq, uint4& d0, uint4& d1) {
+        *reinterpret_cast<uint4*>(tile + w0) = d0;
+        *reinterpret_cast<uint4*>(tile + w1) = d1;
+        issue(sq + PF, d0, d1);
         __builtin_amdgcn_wave_barrier();                                          // LDS is in-order per wave: the tile is complete
         const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(tile + f0), k1 = *reinterpret_cast<const bf16x8*>(tile + f1);
         if (sq == 0) {
@@ -1324,6 +1327,16 @@ __device__ __forceinline__ void tile_band_scores(const S3Args& a, const TileM<RO
             }
         }
         __builtin_amdgcn_wave_barrier();
+    };
+    static_assert(PF == 3 || PF == 4, "named register sets");
+    uint4 sa0, sa1, sb0, sb1, sc0, sc1, sd0, sd1;
+    issue(0, sa0, sa1); issue(1, sb0, sb1); issue(2, sc0, sc1);
+    if (PF == 4) issue(3, sd0, sd1);
+    for (int sq = 0; sq <= r.nk; sq += PF) {
+        step(sq, sa0, sa1);
+        if (sq + 1 <= r.nk) step(sq + 1, sb0, sb1);
+        if (sq + 2 <= r.nk) step(sq + 2, sc0, sc1);
+        if (PF == 4 && sq + 3 <= r.nk) step(sq + 3, sd0, sd1);
     }
 }
 
@@ -1502,7 +1515,7 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
 // fragment and V as the rows), dW_th partial, dP = W^T dP', ds = P (dP - sum P dP), dq = scale * ds . K (band apply over K);
 // ds and P' go to the fp32 workspace for the key-side kernel, the <bos> key / value partials to part_k0 / part_v0.
 // LDS: R1 = SP (P) until ds exists, then the 8 transposed K tiles | DP | RED [8][64] | PM0 [W][NH]
-__global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
+__global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      // (4 waves per SIMD = two workgroups per CU: <= 128 registers)
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W, inner = NH * DH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int J = a.kf * a.kh * a.kw + 1, TS = s3m_ts(J), nsp = W * TS;
@@ -1549,45 +1562,87 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
     const int wvalid = a.ntok - 1 - ry * W;                                                 // queries of this row that exist
     rowm_softmax(SP, J, gst, wvalid);                                                       // P
     __syncthreads();
-    // P' = mix(P) -> global (the key side needs it), P stays in SP;  P' of the <bos> slot also to PM0
-    float wr[64];                              // the 8 x 8 mix matrix in registers for the loop below: read from LDS inside it, every output row
-#pragma unroll                                     // waited for its own LDS round trip (the stores to the table may alias wsh for the compiler)
-    for (int k = 0; k < 64; ++k) wr[k] = wsh[k];
-    for (int item0 = t; item0 < (gst ? W : W * J); item0 += blockDim.x) {           // (recomputing key side: only the <bos> slots are needed)
-        const int item = gst ? item0 * J : item0;
-        const int wq = (int)(((float)item + 0.5f) * rJ), j = item - wq * J;
-        const int iq = 1 + ry * W + wq;
-        float pv[8];
+    // ONE pass over the (query, slot) items, all 8 heads of an item in the thread's registers (tuning key 19 = 1 restores the three
+    // separate passes it replaces):
+    //   P'[g]  = sum_h W[g][h] P[h]          -> global (the key side needs it; two 16-byte stores), the <bos> slot also to PM0
+    //   dW_th[g][h] += dP'[g] P[h]           -> 64 per-thread partial sums, reduced over the workgroup in a fixed order below
+    //   dP[h]  = sum_g W[g][h] dP'[g]        -> in place of dP'
+    // The separate dW_th pass (thread = one (g, h) pair walking all 736 items: 2 LDS reads + ~8 index instructions per FMA) was the
+    // largest block of this kernel (probe: -224 us of 1838 with it skipped, tools/attn_probe.py); here it costs 64 FMAs per item on
+    // values that are in registers anyway.  Absent queries hold dP' = 0 (their dO fragment is zero) and add nothing.
+    if (!a.sep_passes) {
+        // two sweeps over the items so that only 32 of the 64 dW_th partial sums are live at a time (with all 64 next to the mix
+        // operands the compiler spills ~130 registers at the 128-register budget of two workgroups per CU):
+        //   sweep 0: P' (-> global, PM0) and dW_th rows g = 0..3;   sweep 1: dW_th rows g = 4..7 and dP (in place of dP')
+        float red_lane = 0.f;                      // this lane's entry of the wave's 64 sums (entry index = lane)
 #pragma unroll
-        for (int hh = 0; hh < 8; ++hh) pv[hh] = SP[item * NH + wq * S3M_PAD + hh];
-        float* dst = a.pm + (((size_t)b * nq + (iq - 1)) * J + j) * NH;
+        for (int half = 0; half < 2; ++half) {
+            float acc[32];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            float s = 0.f;
+            for (int k = 0; k < 32; ++k) acc[k] = 0.f;
+#pragma unroll 1
+            for (int item = t; item < W * J; item += blockDim.x) {
+                const int wq = (int)(((float)item + 0.5f) * rJ), j = item - wq * J;
+                const int iq = 1 + ry * W + wq;
+                const int ib = item * NH + wq * S3M_PAD;
+                const float4 p0 = *reinterpret_cast<const float4*>(SP + ib), p1 = *reinterpret_cast<const float4*>(SP + ib + 4);
+                const float4 d0 = *reinterpret_cast<const float4*>(DP + ib), d1 = *reinterpret_cast<const float4*>(DP + ib + 4);
+                const float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                const float dv_[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                const float* wv = wsh;                 // (opaque per iteration: hoisted out of the loop the 64 values of W cost registers)
+                asm volatile("" : "+v"(wv));
+                float res[8];                          // sweep 0: P'[g];  sweep 1: dP[h]
 #pragma unroll
-            for (int hh = 0; hh < 8; ++hh) s += wr[g * NH + hh] * pv[hh];
-            if (iq < a.ntok && !gst && !(a.dbg & 2)) dst[g] = s;
-            if (j == 0) PM0[wq * NH + g] = iq < a.ntok ? s : 0.f;
-        }
-    }
-    // dW_th[g][h] partial = sum_{w,j} dP'[g] * P[h]   (thread = (g,h) pair x 8 item groups).  Rows of absent queries hold
-    // dP' = 0 (their dO fragment is zero), so they add nothing.
-    {
-        const int pair = t & 63, grp = t >> 6;
-        const int g = pair / NH, hh = pair % NH;
-        float acc = 0.f;
-        for (int item = grp; item < W * J && !(a.dbg & 8); item += 8 * 8) {       // eight (dP', P) pairs in flight, added in order (was one dependent LDS pair per iteration, 92 of them)
-            float dv8[8], pv8[8];
+                for (int x = 0; x < 8; ++x) res[x] = 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int it = item + 8 * u, itc = it < W * J ? it : grp;
-                const int ib = s3m_item(itc, rJ);
-                dv8[u] = DP[ib + g]; pv8[u] = SP[ib + hh];
+                for (int g = 0; g < 8; ++g) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(wv + g * NH), w1 = *reinterpret_cast<const float4*>(wv + g * NH + 4);
+                    const float wg[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                    if (half == 0) {
+                        float sm = 0.f;
+#pragma unroll
+                        for (int hh = 0; hh < 8; ++hh) sm += wg[hh] * pv[hh];
+                        res[g] = sm;
+                    } else {
+#pragma unroll
+                        for (int hh = 0; hh < 8; ++hh) res[hh] += wg[hh] * dv_[g];
+                    }
+                    if ((g >> 2) == half && !(a.dbg & 8)) {
+#pragma unroll
+                        for (int hh = 0; hh < 8; ++hh) acc[(g & 3) * NH + hh] = fmaf(dv_[g], pv[hh], acc[(g & 3) * NH + hh]);
+                    }
+                }
+                if (half == 0) {
+                    if (iq < a.ntok && !gst && !(a.dbg & 2)) {
+                        float4* dst = reinterpret_cast<float4*>(a.pm + (((size_t)b * nq + (iq - 1)) * J + j) * NH);
+                        dst[0] = make_float4(res[0], res[1], res[2], res[3]);
+                        dst[1] = make_float4(res[4], res[5], res[6], res[7]);
+                    }
+                    if (j == 0) {
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) PM0[wq * NH + g] = iq < a.ntok ? res[g] : 0.f;
+                    }
+                } else {
+                    *reinterpret_cast<float4*>(DP + ib) = make_float4(res[0], res[1], res[2], res[3]);
+                    *reinterpret_cast<float4*>(DP + ib + 4) = make_float4(res[4], res[5], res[6], res[7]);
+                }
             }
+            // wave sums of the 32 partials of this half, fixed order: halving butterfly; lane l (< 32) ends with entry l of the half
+            const int lane = t & 63;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += item + 8 * u < W * J ? dv8[u] * pv8[u] : 0.f;
+            for (int off = 16, cnt = 16; off >= 1; off >>= 1, cnt >>= 1) {
+                const bool upper = (lane & off) != 0;
+#pragma unroll
+                for (int i = 0; i < cnt; ++i) {
+                    const float send = upper ? acc[i] : acc[i + cnt];
+                    const float keep = upper ? acc[i + cnt] : acc[i];
+                    acc[i] = keep + __shfl_xor(send, off, 64);
+                }
+            }
+            const float tot = acc[0] + __shfl_xor(acc[0], 32, 64);       // lanes l and l + 32 hold the two halves of entry l & 31
+            if ((lane >> 5) == half) red_lane = tot;                     // lane = 32 * half + entry: the wave's sum of dW_th[4 half + e / 8][e % 8]
         }
-        RED[grp * 64 + pair] = acc;
+        RED[(t >> 6) * 64 + (t & 63)] = red_lane;
         __syncthreads();
         if (t < NH * NH) {
             float s = 0.f;
@@ -1595,24 +1650,72 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_q_mfma_kernel(S3Args a) {
             pth[t] = s;
         }
         __syncthreads();
-    }
-    // dP[h] = sum_g Wth[g][h] dP'[g]   (in place, item-local)
-    for (int item = t; item < W * J; item += blockDim.x) {
-        float dv_[8], out[8];
-        const int ib = s3m_item(item, rJ);
+    } else {
+        float wr[64];                              // the 8 x 8 mix matrix in registers for the loops below
 #pragma unroll
-        for (int g = 0; g < 8; ++g) dv_[g] = DP[ib + g];
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) {
-            float s = 0.f;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) s += wr[g * NH + hh] * dv_[g];
-            out[hh] = s;
+        for (int k = 0; k < 64; ++k) wr[k] = wsh[k];
+        // P' = mix(P) -> global (the key side needs it), P stays in SP;  P' of the <bos> slot also to PM0
+        for (int item0 = t; item0 < (gst ? W : W * J); item0 += blockDim.x) {           // (recomputing key side: only the <bos> slots are needed)
+            const int item = gst ? item0 * J : item0;
+            const int wq = (int)(((float)item + 0.5f) * rJ), j = item - wq * J;
+            const int iq = 1 + ry * W + wq;
+            float pv[8];
+    #pragma unroll
+            for (int hh = 0; hh < 8; ++hh) pv[hh] = SP[item * NH + wq * S3M_PAD + hh];
+            float* dst = a.pm + (((size_t)b * nq + (iq - 1)) * J + j) * NH;
+    #pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                float s = 0.f;
+    #pragma unroll
+                for (int hh = 0; hh < 8; ++hh) s += wr[g * NH + hh] * pv[hh];
+                if (iq < a.ntok && !gst && !(a.dbg & 2)) dst[g] = s;
+                if (j == 0) PM0[wq * NH + g] = iq < a.ntok ? s : 0.f;
+            }
         }
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) DP[ib + hh] = out[hh];
+        // dW_th[g][h] partial = sum_{w,j} dP'[g] * P[h]   (thread = (g,h) pair x 8 item groups).  Rows of absent queries hold
+        // dP' = 0 (their dO fragment is zero), so they add nothing.
+        {
+            const int pair = t & 63, grp = t >> 6;
+            const int g = pair / NH, hh = pair % NH;
+            float acc = 0.f;
+            for (int item = grp; item < W * J && !(a.dbg & 8); item += 8 * 8) {       // eight (dP', P) pairs in flight, added in order (was one dependent LDS pair per iteration, 92 of them)
+                float dv8[8], pv8[8];
+    #pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int it = item + 8 * u, itc = it < W * J ? it : grp;
+                    const int ib = s3m_item(itc, rJ);
+                    dv8[u] = DP[ib + g]; pv8[u] = SP[ib + hh];
+                }
+    #pragma unroll
+                for (int u = 0; u < 8; ++u) acc += item + 8 * u < W * J ? dv8[u] * pv8[u] : 0.f;
+            }
+            RED[grp * 64 + pair] = acc;
+            __syncthreads();
+            if (t < NH * NH) {
+                float s = 0.f;
+                for (int k = 0; k < 8; ++k) s += RED[k * 64 + t];
+                pth[t] = s;
+            }
+            __syncthreads();
+        }
+        // dP[h] = sum_g Wth[g][h] dP'[g]   (in place, item-local)
+        for (int item = t; item < W * J; item += blockDim.x) {
+            float dv_[8], out[8];
+            const int ib = s3m_item(item, rJ);
+    #pragma unroll
+            for (int g = 0; g < 8; ++g) dv_[g] = DP[ib + g];
+    #pragma unroll
+            for (int hh = 0; hh < 8; ++hh) {
+                float s = 0.f;
+    #pragma unroll
+                for (int g = 0; g < 8; ++g) s += wr[g * NH + hh] * dv_[g];
+                out[hh] = s;
+            }
+    #pragma unroll
+            for (int hh = 0; hh < 8; ++hh) DP[ib + hh] = out[hh];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // ds = P * (dP - sum_j P dP)  -> DP and the global workspace
     {
         const int cc = t & 3, wh = t >> 2, h = wh % NH, w = wh / NH;
@@ -2154,6 +2257,7 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     a.dq = dq; a.dk = dk; a.dv = dv; a.dql = dq_lo; a.dkl = dk_lo; a.dvl = dv_lo; a.ldd = ldd;
     a.dwth = dw_th; a.accumulate = accumulate;
     a.dbg = g_amdnuwa_tuning[17];
+    a.sep_passes = g_amdnuwa_tuning[19] == 1;
     self_kv(a);
     const size_t J = (size_t)g->kf * g->kh * g->kw + 1, nq = g->ntok - 1, rows = (size_t)g->B * g->F * g->H;
     const size_t inner = (size_t)g->heads * g->dim_head;

@@ -48,6 +48,12 @@ def main():
         row.append(f'{nm} {bench(lambda: K.sparse3dna_bwd(g, qkv, wth, do), args.iters) * 1e6:7.1f}')
     L.amdnuwa_set_tuning(17, 0)
     print(' | '.join(row))
+    row = []
+    for nm, v in (('fused item pass', 0), ('three separate item passes', 1), ('fused item pass', 0), ('three separate item passes', 1)):    # tuning key 19
+        L.amdnuwa_set_tuning(19, v)
+        row.append(f'{nm} {bench(lambda: K.sparse3dna_bwd(g, qkv, wth, do), args.iters) * 1e6:7.1f}')
+    L.amdnuwa_set_tuning(19, 0)
+    print('bwd, query side item passes (A/B/A/B): ' + ' | '.join(row))
     print(f'== cross attention, b={b}, n={n}, T={T}: tuning key 18 ==')
     gx = K.x_geom(b, n, T, heads, dh)
     q = K.BF(torch.randn(b * n, inner, device=dev).to(torch.bfloat16), None)
