@@ -403,6 +403,17 @@ __device__ __forceinline__ int b256_off(int row, int cc) { return row * 64 + ((c
 template <int EPI>
 __device__ __forceinline__ int b256_row(int j, int fr) { return EPI >= 1 ? ((fr >> 2) * 16 + j * 4 + (fr & 3)) : (j * 16 + fr); }
 
+// K-step 64 form of the ring (STAG == 3): operand rows are staged as FULL 128-byte lines (8 rows x 128 B per 1-KiB DMA piece, two
+// 64 KiB stages) instead of 64-byte half lines (16 rows x 64 B per piece): half as many L2 requests per byte.  A rows are plain
+// (fragment i covers rows i*16 + fr), so the 16-byte chunk swizzle is row & 7; the permuted B rows of the bf16 epilogues
+// (b256_row: fr -> (fr >> 2) * 16 + j * 4 + (fr & 3)) vary in row bits 0, 1, 4, 5 inside a fragment, so their swizzle takes bits
+// (5, 4, 1): for every ds_read_b128 lane group the 16 addresses then fall on 16 distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int a64_off(int row, int cc) { return row * 128 + ((cc ^ (row & 7)) << 4); }
+template <int EPI>
+__device__ __forceinline__ int b64_swz(int row) { return EPI >= 1 ? ((((row >> 4) & 3) << 1) | ((row >> 1) & 1)) : (row & 7); }
+template <int EPI>
+__device__ __forceinline__ int b64_off(int row, int cc) { return row * 128 + ((cc ^ b64_swz<EPI>(row)) << 4); }
+
 // F16: A and B hold fp16 values and the products run on v_mfma_f32_16x16x32_f16 (same rate, 11 significand bits): the FeedForward
 // GEMMs of the 'bf16x3-fwd' mode's forward.  Outputs: fp32 (EPI 0) as ever; EPI 1 writes C = bf16 (u, for the bf16 backward) and,
 // with C2, the gate output computed on the fp32 accumulators as an fp16 copy (C2: FF2's operand) + a bf16 copy (C2lo: backward).
@@ -483,12 +494,66 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
         const int phase = (int)((blockIdx.x * 2654435761u) >> 29);
         for (int i = 0; i < phase * p.skew; ++i) __builtin_amdgcn_s_sleep(8);
     }
-    // prologue: NS-1 tiles in flight
+    // prologue: NS-1 tiles in flight (the K-64 form, STAG == 3, runs its own prologue: NS == 1 here)
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, s * 32);
     const int fr = lane & 15, fg = lane >> 4;
-    if constexpr (STAG == 2) {
+    if constexpr (STAG == 3) {
+        // (nothing of the K-32 prologue was issued: NS == 1 for this form)
+        static_assert(WNW == 4 && !SHIFT && NS == 1, "K-64 form: 8 waves, plain loader");
+        constexpr int TB6 = 256 * 64 * 2, STG6 = 2 * TB6;
+        const bf16_t* qa[4]; const bf16_t* qb[4];
+        int ka[4], kb[4];                                            // k offset (elements) of the lane's 16-byte chunk inside a 64-wide K tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (j * 8 + wave) * 8 + (lane >> 3), slot = lane & 7;
+            ka[j] = (slot ^ (row & 7)) * 8;
+            kb[j] = (slot ^ b64_swz<EPI>(row)) * 8;
+            const long long ga = (long long)m0 + row, gb = (long long)n0 + row;
+            qa[j] = ga < p.M ? p.A + oA + ga * p.lda + ka[j] : nullptr;
+            qb[j] = gb < p.N ? p.B + oB + gb * p.ldb + kb[j] : nullptr;
+        }
+        auto issue6 = [&](int slot, int k0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16_t* src = (qa[j] && k0 + ka[j] < p.K) ? qa[j] + k0 : zp;
+                __builtin_amdgcn_global_load_lds((glb_cvptr)src, (lds_vptr)(smem + slot * STG6 + (j * 8 + wave) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16_t* src = (qb[j] && k0 + kb[j] < p.K) ? qb[j] + k0 : zp;
+                __builtin_amdgcn_global_load_lds((glb_cvptr)src, (lds_vptr)(smem + slot * STG6 + TB6 + (j * 8 + wave) * 1024), 16, 0, 0);
+            }
+        };
+        const int nk6 = (p.dbg & 2) ? 0 : (p.K + 63) / 64;
+        if (nk6 > 0) issue6(0, 0);
+        for (int kt = 0; kt < nk6; ++kt) {
+            if (kt + 1 < nk6) { issue6((kt + 1) & 1, (kt + 1) * 64); VMCNT(8); }    // tile kt has landed (this wave's pieces); kt + 1 in flight
+            else VMCNT(0);
+            __builtin_amdgcn_s_barrier();                                        // ... for every wave
+            const char* base = smem + (kt & 1) * STG6;
+            bf16x8 af[2][8], bfr[2][4];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bfr[s2][j] = *reinterpret_cast<const bf16x8*>(base + TB6 + b64_off<EPI>(wn * 64 + b256_row<EPI>(j, fr), s2 * 4 + fg));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[s2][i] = *reinterpret_cast<const bf16x8*>(base + a64_off(wm * 128 + i * 16 + fr, s2 * 4 + fg));
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = mfma16<F16>(bfr[s2][j], af[s2][i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                        // everyone is done reading stage kt & 1: iteration kt + 1 re-stages it
+        }
+    } else if constexpr (STAG == 2) {
         // as STAG 1, but the 4 DMA pieces of the restaged tile are issued INSIDE the MFMA phase, one after every 8 MFMAs (a DMA
         // issue costs ~60 cycles in the shadow of bare MFMAs against 100-185 in a phase that is also pulling fragments out of
         // LDS), so the read phase shrinks to the 12 ds_read_b128.  The leading wave row therefore retires tile kt+1 at the END of
@@ -555,6 +620,24 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
                     acc[i][j] = mfma16<F16>(bfr[j], af[i], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            if (p.dbg & 64) {
+                // PROBE (tuning key 7 bit 6, with bit 0 = no epilogue): can a tile's worth of output stores drain in the shadow of a main loop?  Every
+                // K-step issues 1/16 of the wave's bf16 (+ second copy) tile stores from live accumulator registers to the tile's own output rows
+                // (garbage values, real addresses and sizes): 8 rows x 16 K-steps = the 128 row pieces of the epilogue.
+                const int i8 = (kt & 7), fr_ = lane & 15, fg_ = lane >> 4;
+                const long long m = (long long)m0 + wm * 128 + i8 * 16 + fr_;
+                const int nb = n0 + wn * 64 + fg_ * 16;
+                if (m < p.M && nb + 16 <= p.N && (kt >> 3) < 2) {
+                    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
+                    const uint4 v0 = __builtin_bit_cast(uint4, bfr[0]);          // (any live 16 bytes that no MFMA is writing)
+                    if ((kt >> 3) == 0) { reinterpret_cast<uint4*>(C)[0] = v0; reinterpret_cast<uint4*>(C)[1] = v0; }
+                    else if (p.Clo) { bf16_t* Cl = p.Clo + oC + m * p.ldc + nb; reinterpret_cast<uint4*>(Cl)[0] = v0; reinterpret_cast<uint4*>(Cl)[1] = v0; }
+                    else if (p.C2) {
+                        *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) = v0;
+                        if (p.C2lo) *reinterpret_cast<uint4*>(p.C2lo + m * p.ldc2 + (nb >> 1)) = v0;
+                    }
+                }
+            }
             __builtin_amdgcn_s_barrier();
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();
@@ -1946,7 +2029,7 @@ extern "C" int amdnuwa_gemm_nt_f16ops_supported(const amdnuwa_gemm_desc* d) {
     // (no tile-count threshold: the arithmetic of a FeedForward block must not depend on the batch size -- a one-sample parity check
     //  has to run the same fp16 products as the training batch, so small M takes the 256x256 ring too)
     const int v = g_amdnuwa_tuning[0];
-    return (v == 0 || v == 7) ? 1 : 0;
+    return (v == 0 || v == 7 || v == 6 || v == 10) ? 1 : 0;          // (6: the 256x128 two-workgroups-per-CU probe of the same ring; 10: the K-step 64 form)
 }
 
 // does this product run on the bf16x3 256x256 ring (the only kernel that writes the fp16 second copy)?
@@ -1988,6 +2071,34 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         q.dbg = g_amdnuwa_tuning[7];
         if (d->C2) { q.C2 = (bf16_t*)d->C2; q.C2lo = (bf16_t*)d->C2lo; q.ldc2 = d->ldc2; }
         q.skew = nt_skew((long long)q.tiles_m * q.tiles_n);
+        if (g_amdnuwa_tuning[0] == 6) {              // probe: 256x128 tile, 3-stage ring, TWO workgroups per CU (one's epilogue under the other's main loop)
+            q.tiles_n = (d->N + 127) / 128;
+            q.skew = 0;
+            const size_t l6 = (size_t)3 * (256 + 128) * 32 * 2;
+            dim3 g6(q.tiles_m * q.tiles_n, 1), b6(256);
+            if (d->c_is_bf16) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 1, 3, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
+                hipLaunchKernelGGL((gemm_nt_256_kernel<false, 1, 3, 2, 0, true>), g6, b6, l6, stream, q);
+            } else {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 0, 3, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
+                hipLaunchKernelGGL((gemm_nt_256_kernel<false, 0, 3, 2, 0, true>), g6, b6, l6, stream, q);
+            }
+            LAUNCH_CHECK();
+            return AMDNUWA_OK;
+        }
+        if (g_amdnuwa_tuning[0] == 10) {             // K-step 64 form: full 128-byte lines through the DMA ring, two 64 KiB stages
+            const size_t l6 = (size_t)2 * 2 * 256 * 64 * 2;
+            dim3 g6(q.tiles_m * q.tiles_n, 1), b6(512);
+            if (d->c_is_bf16) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 1, 1, 4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
+                hipLaunchKernelGGL((gemm_nt_256_kernel<false, 1, 1, 4, 3, true>), g6, b6, l6, stream, q);
+            } else {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 0, 1, 4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
+                hipLaunchKernelGGL((gemm_nt_256_kernel<false, 0, 1, 4, 3, true>), g6, b6, l6, stream, q);
+            }
+            LAUNCH_CHECK();
+            return AMDNUWA_OK;
+        }
         const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;
         dim3 g2(q.tiles_m * q.tiles_n, 1), b2(512);
         if (d->c_is_bf16) {

@@ -813,6 +813,10 @@ __device__ __forceinline__ bf16x8 ldg8(const bf16_t* p, bool ok) {
 #ifndef S3M_PF
 #define S3M_PF 3
 #endif
+#ifndef S3M_BRANCHFREE
+#define S3M_BRANCHFREE 0          // 1 = row fetches of the single-row sweeps without a branch around the load.  Measured SLOWER again in round 4 (A/B of
+                                  // two builds in one call, b = 128: forward +1.5..4 %, backward +2..3 %; profiles/r04e_s3_branchfree_ab.txt): off
+#endif
 constexpr int S3M_KW = 3;        // widest tap row the MFMA kernel handles
 constexpr int S3M_PLANES = 64;   // kf * kh limit (plane list in LDS)
 
@@ -957,11 +961,22 @@ __device__ __forceinline__ void mfma_band_scores_staged(const S3Args& a, const R
     constexpr int PF = S3M_PF;
     static_assert(PF == 3, "the sweep below names its three register sets");
     auto issue = [&](int sq, uint4& d0, uint4& d1) {
+#if S3M_BRANCHFREE
+        // (no load under a branch: rows that do not exist read token 0 and are zeroed by a select)
+        const int base = (sq == 0 || sq > r.nplanes) ? -1 : r.ptok[sq - 1];        // sequence 0: every row is token 0 (<bos>)
+        const int t0 = base < 0 ? 0 : base + r8, t1 = base < 0 ? 0 : base + r8 + 8;
+        const bool live = sq <= r.nplanes;
+        const uint4 v0 = *reinterpret_cast<const uint4*>(kbase + (size_t)(t0 < a.ntok ? t0 : 0) * ldr);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(kbase + (size_t)(t1 < a.ntok ? t1 : 0) * ldr);
+        d0 = (live && t0 < a.ntok) ? v0 : make_uint4(0, 0, 0, 0);
+        d1 = (live && t1 < a.ntok) ? v1 : make_uint4(0, 0, 0, 0);
+#else
         if (sq > r.nplanes) { d0 = d1 = make_uint4(0, 0, 0, 0); return; }
         const int base = sq == 0 ? -1 : r.ptok[sq - 1];                          // sequence 0: every row is token 0 (<bos>)
         const int t0 = base < 0 ? 0 : base + r8, t1 = base < 0 ? 0 : base + r8 + 8;
         d0 = t0 < a.ntok ? *reinterpret_cast<const uint4*>(kbase + (size_t)t0 * ldr) : make_uint4(0, 0, 0, 0);
         d1 = t1 < a.ntok ? *reinterpret_cast<const uint4*>(kbase + (size_t)t1 * ldr) : make_uint4(0, 0, 0, 0);
+#endif
     };
     // three planes of rows in flight in three NAMED register sets, refilled in place as soon as their rows sit in the tile: the loop is
     // unrolled by three so no set ever has to be moved (the rotating form spent 16 v_mov per plane, a sixth of the sweep's instructions)
@@ -1030,7 +1045,12 @@ __device__ __forceinline__ void mfma_band_apply(const S3Args& a, const RowM& r, 
         for (int i = 0; i < 4; ++i) {
             const int pj = pi + (i >> 1);
             const int tok = pj < r.nplanes ? r.ptok[pj] + r8 + 8 * (i & 1) : a.ntok;
+#if S3M_BRANCHFREE
+            const uint4 v = *reinterpret_cast<const uint4*>(vbase + (size_t)(tok < a.ntok ? tok : 0) * ldr);
+            st[i] = tok < a.ntok ? v : make_uint4(0, 0, 0, 0);
+#else
             st[i] = tok < a.ntok ? *reinterpret_cast<const uint4*>(vbase + (size_t)tok * ldr) : make_uint4(0, 0, 0, 0);
+#endif
         }
     };
     fetch(0);
@@ -1257,9 +1277,16 @@ __device__ __forceinline__ TileM<ROWS> s3t_init(const S3Args& a, int b, int f, i
     return r;
 }
 // 16-byte load from a row that always exists, zero-filled by a select (a load under a branch costs the in-order wait counts)
+#ifndef S3T_BRANCHFREE
+#define S3T_BRANCHFREE 1
+#endif
 __device__ __forceinline__ uint4 ldg16_sel(const bf16_t* p, bool ok) {
+#if S3T_BRANCHFREE
     const uint4 v = *reinterpret_cast<const uint4*>(p);
     return ok ? v : make_uint4(0, 0, 0, 0);
+#else
+    return ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+#endif
 }
 
 // Band scores of head h for every row of the tile: TAB_i[(c, slot, h)] = mul * (frag row of query c of tile row i) . (key row) (+ bias),
