@@ -494,6 +494,10 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
         const int phase = (int)((blockIdx.x * 2654435761u) >> 29);
         for (int i = 0; i < phase * p.skew; ++i) __builtin_amdgcn_s_sleep(8);
     }
+    // probe (two workgroups per CU, negative tuning key 14): the SECOND workgroup of every CU (blocks 256..511 of the first generation) starts
+    // -skew x 0.25 us late, so that one workgroup's epilogue falls under the other's main loop
+    if (WNW == 2 && p.skew < 0 && (int)blockIdx.x >= 256 && (int)blockIdx.x < 512)
+        for (int i = 0; i < -p.skew; ++i) __builtin_amdgcn_s_sleep(8);
     // prologue: NS-1 tiles in flight (the K-64 form, STAG == 3, runs its own prologue: NS == 1 here)
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -2073,7 +2077,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         q.skew = nt_skew((long long)q.tiles_m * q.tiles_n);
         if (g_amdnuwa_tuning[0] == 6) {              // probe: 256x128 tile, 3-stage ring, TWO workgroups per CU (one's epilogue under the other's main loop)
             q.tiles_n = (d->N + 127) / 128;
-            q.skew = 0;
+            q.skew = g_amdnuwa_tuning[14] < 0 ? g_amdnuwa_tuning[14] : 0;
             const size_t l6 = (size_t)3 * (256 + 128) * 32 * 2;
             dim3 g6(q.tiles_m * q.tiles_n, 1), b6(256);
             if (d->c_is_bf16) {

@@ -176,12 +176,12 @@ class S3Inner:
         inner = g.heads * g.dim_head
         d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
         dwo = torch.empty_like(wo)
-        meta['wg'].run(lambda: K.gemm_tn(dy, o, dwo))
+        K.gemm_tn(dy, o, dwo)
         dqkv, dwth, drel = K.sparse3dna_bwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), d_o, rel_bias=rel)
         dh = K.gemm_nt(dqkv, W['qkvT'], out_bf16=_fast_bwd())
         sh = meta.get('shift')
         dwqkv = torch.empty((3 * inner, wq.shape[1]), dtype=torch.float32, device=wq.device)   # one wgrad GEMM for [to_q; to_kv]
-        meta['wg'].run(lambda: K.gemm_tn(dqkv, h, dwqkv, shift=sh))
+        K.gemm_tn(dqkv, h, dwqkv, shift=sh)
         dwq, dwkv = dwqkv[:inner], dwqkv[inner:]
         dbo = K.colsum(dy_f32) if (need_dbias and dy_f32 is not None) else None
         grads = [dwq, dwkv, dwth.reshape(wth.shape), dwo, dbo]
@@ -259,7 +259,7 @@ class XInner:
         wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
         d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
         dwo = torch.empty_like(wo)
-        meta['wg'].run(lambda: K.gemm_tn(dy, o, dwo))
+        K.gemm_tn(dy, o, dwo)
         if Pm is None and K.xattn2_bwd_rc_ok(g):
             dq, dKp, dVp, dwth = K.xattn2_bwd_rc(g, q, d_o, pk, wth2, P)         # no dS / Pm arrays: the key side recomputes them
         else:
@@ -275,7 +275,8 @@ class XInner:
             dkv = _rotary_bf(dkv, rot, g.B, g.T, 2 * g.heads, inverse=True)
         dh = K.gemm_nt(dq, W['qT'], out_bf16=_fast_bwd())
         dwq, dwkv = torch.empty_like(wq), torch.empty_like(wkv)
-        meta['wg'].run(lambda: (K.gemm_tn(dq, h, dwq), K.gemm_tn(dkv, ctx, dwkv)))
+        K.gemm_tn(dq, h, dwq)
+        K.gemm_tn(dkv, ctx, dwkv)
         dctx = K.gemm_nt(dkv, W['kvT'])
         if meta.get('self_kv'):                  # the key/value rows ARE the query rows: one gradient for h
             dh = _as_f32(dh) + dctx
@@ -354,7 +355,7 @@ class FFInner:
         else:
             du = K.geglu_bwd(u, K.gemm_nt(dy, W['w2T'], out_bf16=True), FP, interleaved=True)
         dw2 = torch.empty_like(w2)
-        meta['wg'].run(lambda: K.gemm_tn(dy, gg, dw2, N2=FFI))
+        K.gemm_tn(dy, gg, dw2, N2=FFI)
         dh = K.gemm_nt(du, W['w1T'], out_bf16=_fast_bwd())
         sh = meta.get('shift')
         # one wgrad GEMM over the padded, interleaved [8 values | 8 gates | ...] row order, then back to the parameter's layout
@@ -364,7 +365,7 @@ class FFInner:
             K.gemm_tn(du, h, dw1p, shift=sh)
             d = K.geglu_deinterleave(dw1p, FP, dim=0)
             return torch.cat((d[:FFI], d[FP:FP + FFI]), 0)
-        dw1 = meta['wg'].run(wgrad)
+        dw1 = wgrad()
         return dh, None, [dw1, dw2]
 
 
@@ -475,21 +476,6 @@ INNERS = {'s3': S3Inner, 'xattn': XInner, 'ff': FFInner, 'xc2': XC2Inner}
 FUSE_LINEAR_CE = os.environ.get('AMDNUWA_FUSE_LINEAR_CE', '1') != '0'   # to_logits + cross entropy without the fp32 logits (A/B switch)
 FUSE_GEGLU_BWD = os.environ.get('AMDNUWA_FUSE_GEGLU_BWD', '1') != '0'   # gate backward inside the dgg GEMM epilogue (A/B switch)
 CHAIN_BWD = os.environ.get('AMDNUWA_CHAIN_BWD', '1') != '0'      # chain the LayerNorm backwards across block boundaries (A/B switch)
-class WgradStream:
-    """Weight-gradient GEMMs (dW = dY^T X) feed nothing further down the backward chain.  They are launched in line on the main
-    stream: running them on a side stream beside the HBM-bound LayerNorm / GEGLU kernels was measured neutral on MI355X (the split-K
-    GEMM fills every CU), so the hook points stay but no second stream -- and no cross-stream tensor lifetime -- is involved."""
-
-    def __init__(self, device):
-        pass
-
-    def run(self, fn):
-        return fn()
-
-    def join(self):
-        pass
-
-
 def _fast():
     """fast bf16 mode: the GEMMs that feed a LayerNorm (to_out / FF w2 outputs, dgrad outputs) write bf16 and the LN kernels
     read bf16 -- half the epilogue and LN traffic.  Parity mode (bf16x3) keeps those tensors in fp32."""
@@ -592,7 +578,6 @@ class SandwichBlockFn(Function):
         else:
             dy, dpost_w, dpost_b, dsum = K.ln_bwd(g2, y, m2, r2, post_w.detach(), to_bf=True, want_dsum=want_bias)
         meta = dict(meta)
-        wg = meta['wg'] = WgradStream(g.device)
         dh, dctx, grads = inner.bwd(ctx.inner_saved, dy, p, meta, need_dbias=False)
         if want_bias:
             grads[4] = dsum                      # to_out.bias grad = column sums of d(to_out output)
@@ -612,7 +597,6 @@ class SandwichBlockFn(Function):
         if ctx.has_ctx:
             T = meta['ctx_T'] if meta['kind'] == 'xc2' else meta['xgeom'].T
             dcontext = dctx.reshape(B, T, D)
-        wg.join()
         ctx.inner_saved = None
         dresid = g if ctx.has_resid else None
         return (dx.reshape(B, n, D), dresid, dcontext, None, dpre_w, dpre_b, dpost_w, dpost_b, *grads)
@@ -651,9 +635,7 @@ class InnerFn(Function):
         dy = K.empty_bf(tuple(g2.shape), g.device)
         K.cast_pad(g2, dy)
         meta = dict(meta)
-        wg = meta['wg'] = WgradStream(g.device)
         dh, dctx, grads = inner.bwd(ctx.inner_saved, dy, p, meta, need_dbias=True, dy_f32=g2)
-        wg.join()
         dcontext = dctx.reshape(B, meta['ctx_T'] if meta['kind'] == 'xc2' else meta['xgeom'].T, -1) if ctx.has_ctx else None
         ctx.inner_saved = None
         return (_as_f32(dh).reshape(B, n, D), dcontext, None, *grads)
