@@ -858,15 +858,16 @@ __device__ __forceinline__ int s3m_item(int item, float rJ) { return item * S3M_
 
 // fills pslot / ptok (thread 0) and returns after a barrier; `cnt` = &pslot[S3M_PLANES]
 __device__ __forceinline__ void rowm_planes(const S3Args& a, int f, int y, int* pslot, int* ptok) {
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int ta = 0; ta < a.kf; ++ta)
-            for (int tb = 0; tb < a.kh; ++tb) {
-                const int fr = f - (a.kf - 1 - ta) * a.df, yr = y - (a.kh - 1 - tb) * a.dh;
-                if (fr >= 0 && yr >= 0) { pslot[n] = 1 + (ta * a.kh + tb) * a.kw; ptok[n] = 1 + (fr * a.H + yr) * S3M_W; ++n; }
-            }
-        pslot[S3M_PLANES] = n;
+    // closed form, one thread per plane (was a serial loop of thread 0): taps ta >= ta0 / tb >= tb0 reach a frame / row inside the grid
+    const int ta0 = max(0, a.kf - 1 - f / a.df), tb0 = max(0, a.kh - 1 - y / a.dh);
+    const int nb = a.kh - tb0, n = (a.kf - ta0) * nb;
+    const int e = threadIdx.x;
+    if (e < n) {
+        const int ta = ta0 + e / nb, tb = tb0 + e % nb;
+        pslot[e] = 1 + (ta * a.kh + tb) * a.kw;
+        ptok[e] = 1 + ((f - (a.kf - 1 - ta) * a.df) * a.H + (y - (a.kh - 1 - tb) * a.dh)) * S3M_W;
     }
+    if (e == 0) pslot[S3M_PLANES] = n;
     __syncthreads();
 }
 __device__ __forceinline__ RowM rowm_init(const S3Args& a, int b, int ry, const int* pslot, const int* ptok) {
@@ -1236,21 +1237,21 @@ __device__ __forceinline__ void s3t_tile_order(const S3Args& a, int t2, int& f, 
     else { const int per = a.H / ROWS; f = t2 / per; const int rem = t2 % per; cl = rem / ng; gi = rem % ng; }
     y0 = cl + gi * ROWS * a.dh;
 }
+// The key-row list in closed form (one thread per entry instead of a serial loop of thread 0 with 511 threads waiting at the
+// barrier): frame taps ta >= ta0 have fr = f - (kf - 1 - ta) df >= 0, rows m >= m0 have y0 + m dh >= 0, so the valid entries are the
+// rectangle [ta0, kf) x [m0, ROWS) in (ta, m) order -- the order the serial loop produced.
 template <int ROWS>
 __device__ __forceinline__ void s3t_keylist(const S3Args& a, int f, int y0, int* ktok, int* kmeta, int* kcnt) {
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int ta = 0; ta < a.kf; ++ta) {
-            const int fr = f - (a.kf - 1 - ta) * a.df;
-            if (fr < 0) continue;
-            for (int m = -(a.kh - 1); m < ROWS; ++m) {
-                const int yk = y0 + m * a.dh;
-                if (yk < 0) continue;
-                ktok[n] = 1 + (fr * a.H + yk) * S3M_W; kmeta[n] = (ta << 8) | (m + 64); ++n;
-            }
-        }
-        *kcnt = n;
+    const int ta0 = max(0, a.kf - 1 - f / a.df);                  // (kf - 1 - ta) df <= f
+    const int m0 = max(-(a.kh - 1), -(y0 / a.dh));                // y0 + m dh >= 0
+    const int nm = ROWS - m0, n = (a.kf - ta0) * nm;
+    const int e = threadIdx.x;
+    if (e < n) {
+        const int ta = ta0 + e / nm, m = m0 + e % nm;
+        ktok[e] = 1 + ((f - (a.kf - 1 - ta) * a.df) * a.H + y0 + m * a.dh) * S3M_W;
+        kmeta[e] = (ta << 8) | (m + 64);
     }
+    if (e == 0) *kcnt = n;
     __syncthreads();
 }
 template <int ROWS>
@@ -1482,7 +1483,10 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) nrows += ((ry0 + i * a.dh) * W + 1 < a.ntok) ? 1 : 0;   // (rows of a tile exist in order)
     if (nrows == 0) return;                                                      // whole tile beyond the sequence (uniform)
-    for (int e = t; e < nrows * WTS; e += blockDim.x) SP[e] = NEG_MAX;
+    {   // (WTS is a multiple of 4 floats: 16-byte stores, a quarter of the ds_write instructions)
+        const float4 neg4 = make_float4(NEG_MAX, NEG_MAX, NEG_MAX, NEG_MAX);
+        for (int e = t; e < nrows * WTS / 4; e += blockDim.x) reinterpret_cast<float4*>(SP)[e] = neg4;
+    }
     s3t_keylist<ROWS>(a, f, y0, ktok, kmeta, kcnt);
     const TileM<ROWS> r = s3t_init<ROWS>(a, b, f, y0, nrows, ktok, kmeta, kcnt[0]);
     if (!(a.dbg & 1))     // (a.dbg, tuning key 9: bits 0 / 1 / 2 skip the score / softmax + mix / apply phase -- timing probes, garbage results)
@@ -1573,7 +1577,10 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
         for (int e = t; e < inner; e += blockDim.x) { pk0[e] = 0.f; pv0[e] = 0.f; }
         return;
     }
-    for (int e = t; e < nsp; e += blockDim.x) { SP[e] = NEG_MAX; DP[e] = 0.f; }
+    {   // (nsp is a multiple of 4 floats and both tables start 16-byte aligned: 16-byte stores)
+        const float4 neg4 = make_float4(NEG_MAX, NEG_MAX, NEG_MAX, NEG_MAX), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = t; e < nsp / 4; e += blockDim.x) { reinterpret_cast<float4*>(SP)[e] = neg4; reinterpret_cast<float4*>(DP)[e] = zero4; }
+    }
     rowm_planes(a, f, y, pslot, ptok);
     const RowM r = rowm_init(a, b, ry, pslot, ptok);
     char* stile = reinterpret_cast<char*>(PM0 + W * NH) + r.wave * 2048;                    // 8 wave-private [16][64] bf16 staging tiles
@@ -1838,16 +1845,17 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
     const int ry = f * a.H + y;
     const int J = a.kf * a.kh * a.kw + 1, nq = a.ntok - 1;
     if (ry * W + 1 >= a.ntok) return;
-    if (t == 0) {
-        int n = 0;
-        for (int ta = 0; ta < a.kf; ++ta)
-            for (int tb = 0; tb < a.kh; ++tb) {
-                const int fq = f + (a.kf - 1 - ta) * a.df, yq = y + (a.kh - 1 - tb) * a.dh;
-                if (fq < a.F && yq < a.H && (fq * a.H + yq) * W + 1 < a.ntok) {
-                    pslot[n] = 1 + (ta * a.kh + tb) * a.kw; ptok[n] = 1 + (fq * a.H + yq) * W; ++n;
-                }
-            }
-        pslot[S3M_PLANES] = n;
+    if (t < 64) {
+        // the attending query rows, one lane per (ta, tb) candidate, compacted in (ta, tb) order by a ballot (was a serial loop of thread 0)
+        const int ta = t / a.kh, tb = t % a.kh;
+        const int fq = f + (a.kf - 1 - ta) * a.df, yq = y + (a.kh - 1 - tb) * a.dh;
+        const bool ok = t < a.kf * a.kh && fq < a.F && yq < a.H && (fq * a.H + yq) * W + 1 < a.ntok;
+        const unsigned long long m = __ballot(ok);
+        if (ok) {
+            const int pos = __popcll(m & ((1ull << t) - 1ull));
+            pslot[pos] = 1 + (ta * a.kh + tb) * a.kw; ptok[pos] = 1 + (fq * a.H + yq) * W;
+        }
+        if (t == 0) pslot[S3M_PLANES] = __popcll(m);
     }
     __syncthreads();
     const int nplanes = pslot[S3M_PLANES];
