@@ -789,6 +789,78 @@ __global__ __launch_bounds__(256) void embed_bwd_tok_sorted_kernel(const long lo
         if (lane + 64 * e < D) dW[id * D + lane + 64 * e] += frac * acc[e];
 }
 
+// The same sums with LONG runs cut into segments (round 4).  One wave per run is a serial loop over the run: a frequent code (raw
+// frames through the tokenizer put most positions on a few codes; padding ids do the same to a text embedding) turned this kernel
+// into one wave walking 10^5 rows -- 205 ms per call inside the whole reference step at b = 64 (profiles/r04_full_step_profile.txt).
+// Here a wave owns a fixed SEGMENT of S consecutive sorted positions.  Runs that lie inside the segment are summed and added to dW as
+// before.  A run that crosses a segment boundary leaves one partial row per segment it touches (the segment's "head" piece when the
+// run came in from the left, its "tail" piece when it starts here and goes on to the right); a second kernel lets the wave of the
+// segment where the run STARTS add the pieces in segment order.  Positions are summed in sorted order inside a piece and pieces in
+// segment order: fixed order, no atomics, and a run of any length costs O(S) + O(length / S) serial row additions.
+//   P    [nseg][2][D] floats: head / tail partial of each segment          meta [nseg][4] ints: head valid, head continues, tail valid, -
+__global__ __launch_bounds__(256) void embed_bwd_tok_seg_kernel(const long long* __restrict__ sid, const long long* __restrict__ perm,
+                                                                const float* __restrict__ dx, float* __restrict__ dW, float* __restrict__ P,
+                                                                int* __restrict__ meta, long long N, int S, int nseg, int ntok, int D, float frac) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w >= nseg) return;
+    const long long j0 = (long long)w * S, j1 = j0 + S < N ? j0 + S : N;
+    const bool cont_in = j0 > 0 && sid[j0 - 1] == sid[j0];
+    float acc[MAXV * 4];
+#pragma unroll
+    for (int e = 0; e < MAXV * 4; ++e) acc[e] = 0.f;
+    long long cur = sid[j0];
+    bool first_run = true, head_valid = false;
+    auto put = [&](float* dst, bool add) {           // dst[.] (+)= acc (x frac when it goes to dW)
+#pragma unroll
+        for (int e = 0; e < MAXV * 4; ++e)
+            if (lane + 64 * e < D) dst[lane + 64 * e] = add ? dst[lane + 64 * e] + frac * acc[e] : acc[e];
+    };
+    for (long long jj = j0; jj < j1; ++jj) {
+        const long long id = sid[jj];
+        if (id != cur) {                             // the run of `cur` ends inside this segment
+            if (first_run && cont_in) { put(P + ((size_t)w * 2 + 0) * D, false); head_valid = true; }
+            else put(dW + cur * D, true);
+#pragma unroll
+            for (int e = 0; e < MAXV * 4; ++e) acc[e] = 0.f;
+            cur = id; first_run = false;
+        }
+        const long long src = perm[jj];
+        const long long row = (src / (ntok - 1)) * ntok + (src % (ntok - 1)) + 1;
+#pragma unroll
+        for (int e = 0; e < MAXV * 4; ++e)
+            if (lane + 64 * e < D) acc[e] += dx[row * D + lane + 64 * e];
+    }
+    const bool cont_out = j1 < N && sid[j1] == cur;
+    int head_cont = 0, tail_valid = 0;
+    if (first_run && cont_in) { put(P + ((size_t)w * 2 + 0) * D, false); head_valid = true; head_cont = cont_out ? 1 : 0; }   // one run fills the segment
+    else if (cont_out) { put(P + ((size_t)w * 2 + 1) * D, false); tail_valid = 1; }
+    else put(dW + cur * D, true);
+    if (lane == 0) *reinterpret_cast<int4*>(meta + (size_t)w * 4) = make_int4(head_valid ? 1 : 0, head_cont, tail_valid, 0);
+}
+// the segment where a boundary-crossing run STARTS (it holds the run's tail piece) adds the head pieces of the segments that follow
+__global__ __launch_bounds__(256) void embed_bwd_tok_join_kernel(const long long* __restrict__ sid, const float* __restrict__ P,
+                                                                 const int* __restrict__ meta, float* __restrict__ dW, long long N, int S,
+                                                                 int nseg, int D, float frac) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w >= nseg || !meta[(size_t)w * 4 + 2]) return;
+    const long long jl = (long long)(w + 1) * S - 1;
+    const long long id = sid[jl < N ? jl : N - 1];                   // the id of the segment's last run
+    float acc[MAXV * 4];
+#pragma unroll
+    for (int e = 0; e < MAXV * 4; ++e) acc[e] = lane + 64 * e < D ? P[((size_t)w * 2 + 1) * D + lane + 64 * e] : 0.f;
+    for (int k = w + 1; k < nseg; ++k) {                              // (segment k's head piece exists: the run continued into it)
+#pragma unroll
+        for (int e = 0; e < MAXV * 4; ++e)
+            if (lane + 64 * e < D) acc[e] += P[((size_t)k * 2 + 0) * D + lane + 64 * e];
+        if (!meta[(size_t)k * 4 + 1]) break;
+    }
+#pragma unroll
+    for (int e = 0; e < MAXV * 4; ++e)
+        if (lane + 64 * e < D) dW[id * D + lane + 64 * e] += frac * acc[e];
+}
+
 // axial / bos gradients, two deterministic stages:
 //  A: T[p][c] = sum_b dx[b][1+p][c]  (p < ntok-1);  T[ntok-1][c] = sum_b dx[b][0][c]  (bos)
 //  B: ax1[f] = sum_{y,w} T, ax2[y] = sum_{f,w} T, ax3[w] = sum_{f,y} T   (one block per axis entry)
@@ -1205,7 +1277,21 @@ extern "C" int amdnuwa_embed_bwd(const long long* ids, const long long* sorted_i
     if (R <= 0) return AMDNUWA_OK;
     if (sorted_ids && perm) {
         const long long N = (long long)B * (ntok - 1);
-        if (N > 0) hipLaunchKernelGGL(embed_bwd_tok_sorted_kernel, dim3((unsigned)((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, stream, sorted_ids, perm, dx, dW, N, ntok, D, frac);
+        // segmented form when the workspace (ntok rows of D floats, shared with the positional sums below: they run afterwards on the same
+        // stream) holds two partial rows + 4 ints per segment for at least 8 segments; else one wave per run
+        const long long rows_ws = (long long)(workspace_bytes / ((size_t)D * sizeof(float)));
+        long long nseg_max = (rows_ws * D) / (2LL * D + 4);
+        if (N > 0 && nseg_max >= 8 && N >= 64) {
+            int S = (int)((N + nseg_max - 1) / nseg_max);
+            if (S < 32) S = 32;
+            const int nseg = (int)((N + S - 1) / S);
+            float* P = (float*)workspace;
+            int* meta = (int*)(P + (size_t)nseg * 2 * D);
+            hipLaunchKernelGGL(embed_bwd_tok_seg_kernel, dim3((unsigned)((nseg + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, stream, sorted_ids, perm, dx, dW, P, meta, N, S, nseg, ntok, D, frac);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(embed_bwd_tok_join_kernel, dim3((unsigned)((nseg + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, stream, sorted_ids, P, meta, dW, N, S, nseg, D, frac);
+        } else if (N > 0)
+            hipLaunchKernelGGL(embed_bwd_tok_sorted_kernel, dim3((unsigned)((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, stream, sorted_ids, perm, dx, dW, N, ntok, D, frac);
     } else {
         hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, stream, ids, dx, dW, B, ntok, D, frac);
     }

@@ -494,6 +494,43 @@ def test_embed_fwd_bwd(K, O):
         report(f'embed_bwd_bos[n1={n1}]', db, P['video_bos'].grad, 1e-5)
 
 
+@pytest.mark.parametrize('case', ['one code', 'few codes', 'uniform', 'alternating blocks'])
+def test_embed_bwd_long_runs(K, case):
+    """the token-embedding gradient on skewed id distributions (raw frames through the tokenizer land on a few codes): runs of equal ids
+    that span many of the kernel's segments, against an fp64 index_add; bit-reproducible; and not serial in the run length"""
+    torch.manual_seed(5)
+    B, ntok, D, C = 8, 2560, 512, 8192
+    n1 = ntok - 1
+    if case == 'one code':
+        ids = torch.full((B, n1), 77)
+    elif case == 'few codes':
+        ids = torch.tensor([3, 4000, 8191])[torch.randint(0, 3, (B, n1))]
+        ids[0, :100] = torch.randint(0, C, (100,))
+    elif case == 'uniform':
+        ids = torch.randint(0, C, (B, n1))
+    else:
+        ids = (torch.arange(B * n1) // 700).reshape(B, n1) * 13 % C
+    dx = torch.randn(B * ntok, D)
+    ref = torch.zeros(C, D, dtype=torch.float64)
+    rows = (torch.arange(B)[:, None] * ntok + 1 + torch.arange(n1)[None, :]).reshape(-1)
+    ref.index_add_(0, ids.reshape(-1), 0.2 * dx[rows].double())
+    outs = []
+    for _ in range(2):
+        dW = torch.zeros(C, D, device=DEV)
+        d1, d2, d3 = (torch.zeros(s_, D, device=DEV) for s_ in (10, 16, 16))
+        db = torch.zeros(D, device=DEV)
+        K.embed_bwd(ids.to(DEV), dx.to(DEV), dW, d1, d2, d3, db, B, ntok, 10, 16, 16, 0.2)
+        outs.append(dW)
+    assert torch.equal(outs[0], outs[1])
+    report(f'embed_bwd_long_runs[{case}]', outs[0], ref.float(), 2e-6)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    K.embed_bwd(ids.to(DEV), dx.to(DEV), outs[0], d1, d2, d3, db, B, ntok, 10, 16, 16, 0.2)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.05, 'a run of equal ids must not be walked by one wave'
+
+
 @pytest.mark.parametrize('R,C', [(5, 64), (300, 8192), (17, 1000)])
 def test_cross_entropy(K, R, C):
     torch.manual_seed(10)
