@@ -503,9 +503,9 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, s * 32);
     const int fr = lane & 15, fg = lane >> 4;
-    if constexpr (STAG == 3) {
-        // (nothing of the K-32 prologue was issued: NS == 1 for this form)
-        static_assert(WNW == 4 && !SHIFT && NS == 1, "K-64 form: 8 waves, plain loader");
+    if constexpr (STAG == 3 || STAG == 4) {
+        // (nothing of the K-32 prologue was issued: NS == 1 for these forms)
+        static_assert(WNW == 4 && !SHIFT && NS == 1, "K-64 forms: 8 waves, plain loader");
         constexpr int TB6 = 256 * 64 * 2, STG6 = 2 * TB6;
         const bf16_t* qa[4]; const bf16_t* qb[4];
         int ka[4], kb[4];                                            // k offset (elements) of the lane's 16-byte chunk inside a 64-wide K tile
@@ -518,23 +518,30 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
             qa[j] = ga < p.M ? p.A + oA + ga * p.lda + ka[j] : nullptr;
             qb[j] = gb < p.N ? p.B + oB + gb * p.ldb + kb[j] : nullptr;
         }
-        auto issue6 = [&](int slot, int k0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16_t* src = (qa[j] && k0 + ka[j] < p.K) ? qa[j] + k0 : zp;
-                __builtin_amdgcn_global_load_lds((glb_cvptr)src, (lds_vptr)(smem + slot * STG6 + (j * 8 + wave) * 1024), 16, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16_t* src = (qb[j] && k0 + kb[j] < p.K) ? qb[j] + k0 : zp;
-                __builtin_amdgcn_global_load_lds((glb_cvptr)src, (lds_vptr)(smem + slot * STG6 + TB6 + (j * 8 + wave) * 1024), 16, 0, 0);
-            }
+        auto issue_a6 = [&](int j, int slot, int k0) {
+            const bf16_t* src = (qa[j] && k0 + ka[j] < p.K) ? qa[j] + k0 : zp;
+            __builtin_amdgcn_global_load_lds((glb_cvptr)src, (lds_vptr)(smem + slot * STG6 + (j * 8 + wave) * 1024), 16, 0, 0);
+        };
+        auto issue_b6 = [&](int j, int slot, int k0) {
+            const bf16_t* src = (qb[j] && k0 + kb[j] < p.K) ? qb[j] + k0 : zp;
+            __builtin_amdgcn_global_load_lds((glb_cvptr)src, (lds_vptr)(smem + slot * STG6 + TB6 + (j * 8 + wave) * 1024), 16, 0, 0);
         };
         const int nk6 = (p.dbg & 2) ? 0 : (p.K + 63) / 64;
-        if (nk6 > 0) issue6(0, 0);
+        if (nk6 > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) issue_a6(j, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) issue_b6(j, 0, 0);
+        }
+        if constexpr (STAG == 3) {
         for (int kt = 0; kt < nk6; ++kt) {
-            if (kt + 1 < nk6) { issue6((kt + 1) & 1, (kt + 1) * 64); VMCNT(8); }    // tile kt has landed (this wave's pieces); kt + 1 in flight
-            else VMCNT(0);
+            if (kt + 1 < nk6) {                                                  // tile kt has landed (this wave's pieces); kt + 1 in flight
+#pragma unroll
+                for (int j = 0; j < 4; ++j) issue_a6(j, (kt + 1) & 1, (kt + 1) * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) issue_b6(j, (kt + 1) & 1, (kt + 1) * 64);
+                VMCNT(8);
+            } else VMCNT(0);
             __builtin_amdgcn_s_barrier();                                        // ... for every wave
             const char* base = smem + (kt & 1) * STG6;
             bf16x8 af[2][8], bfr[2][4];
@@ -556,6 +563,50 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
             __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                        // everyone is done reading stage kt & 1: iteration kt + 1 re-stages it
+        }
+        } else {
+        // STAG == 4: the same two 64 KiB stages with the wave rows ONE PHASE APART, as in the K-step 32 ring: every 32-wide half of a stage
+        // is a read phase (12 ds_read_b128 + DMA issue for the NEXT stage) and an MFMA phase (32 MFMAs), raw barriers between them; one row
+        // of waves multiplies while the other reads.  The next stage (the slot the lagging row finished reading one barrier ago) is
+        // filled during the current one: the leading row issues 6 pieces in its first read phase (the 4 A pieces, which come from furthest
+        // away, first) and 2 in its second, and waits for them at the end of its second MFMA phase; the lagging row, whose second read
+        // phase IS that phase, issues all 8 in its first read phase.
+        VMCNT(0);
+        __builtin_amdgcn_s_barrier();                                            // stage 0 has landed for every wave
+        if (wm == 1) __builtin_amdgcn_s_barrier();                               // this wave row lags one phase
+        for (int st = 0; st < 2 * nk6; ++st) {
+            const int kt = st >> 1, s2 = st & 1;
+            const char* base = smem + (kt & 1) * STG6;
+            bf16x8 af[8], bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(base + TB6 + b64_off<EPI>(wn * 64 + b256_row<EPI>(j, fr), s2 * 4 + fg));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a64_off(wm * 128 + i * 16 + fr, s2 * 4 + fg));
+            if (kt + 1 < nk6) {
+                const int ns = (kt + 1) & 1, nk0 = (kt + 1) * 64;
+                if (s2 == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) issue_a6(j, ns, nk0);
+                    issue_b6(0, ns, nk0); issue_b6(1, ns, nk0);
+                    if (wm == 1) { issue_b6(2, ns, nk0); issue_b6(3, ns, nk0); }
+                } else if (wm == 0) { issue_b6(2, ns, nk0); issue_b6(3, ns, nk0); }
+            }
+            if (wm == 1 && s2 == 1) VMCNT(0);                                    // lagging row: its pieces of stage kt + 1 (issued a read phase + an MFMA phase ago)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = mfma16<F16>(bfr[j], af[i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (wm == 0 && s2 == 1) VMCNT(0);                                    // leading row: stage kt + 1 complete before the barrier that opens its first read of it
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();
         }
     } else if constexpr (STAG == 2) {
         // as STAG 1, but the 4 DMA pieces of the restaged tile are issued INSIDE the MFMA phase, one after every 8 MFMAs (a DMA
@@ -2033,7 +2084,7 @@ extern "C" int amdnuwa_gemm_nt_f16ops_supported(const amdnuwa_gemm_desc* d) {
     // (no tile-count threshold: the arithmetic of a FeedForward block must not depend on the batch size -- a one-sample parity check
     //  has to run the same fp16 products as the training batch, so small M takes the 256x256 ring too)
     const int v = g_amdnuwa_tuning[0];
-    return (v == 0 || v == 7 || v == 6 || v == 10) ? 1 : 0;          // (6: the 256x128 two-workgroups-per-CU probe of the same ring; 10: the K-step 64 form)
+    return (v == 0 || v == 7 || v == 6 || v == 10 || v == 11) ? 1 : 0;          // (6: the 256x128 two-workgroups-per-CU probe of the same ring; 10: the K-step 64 form)
 }
 
 // does this product run on the bf16x3 256x256 ring (the only kernel that writes the fp16 second copy)?
@@ -2086,6 +2137,19 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
             } else {
                 (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 0, 3, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
                 hipLaunchKernelGGL((gemm_nt_256_kernel<false, 0, 3, 2, 0, true>), g6, b6, l6, stream, q);
+            }
+            LAUNCH_CHECK();
+            return AMDNUWA_OK;
+        }
+        if (g_amdnuwa_tuning[0] == 11 || (g_amdnuwa_tuning[0] == 0 && d->K >= 1024 && d->K < 2048)) {     // K-step 64 form with staggered wave rows (FF2: -9 %)
+            const size_t l6 = (size_t)2 * 2 * 256 * 64 * 2;
+            dim3 g6(q.tiles_m * q.tiles_n, 1), b6(512);
+            if (d->c_is_bf16) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 1, 1, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
+                hipLaunchKernelGGL((gemm_nt_256_kernel<false, 1, 1, 4, 4, true>), g6, b6, l6, stream, q);
+            } else {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 0, 1, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
+                hipLaunchKernelGGL((gemm_nt_256_kernel<false, 0, 1, 4, 4, true>), g6, b6, l6, stream, q);
             }
             LAUNCH_CHECK();
             return AMDNUWA_OK;
@@ -2208,6 +2272,24 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         return AMDNUWA_OK;
     }
     if (variant == 9) variant = 7;
+    // K-step 64 form with staggered wave rows (two 64 KiB stages of full 128-byte row lines): measured ahead of the K-step 32 ring on the
+    // K = 1376 / 1536 shapes only (FF2 -10 %, dgrad qkv -1.5 %; K = 512 shapes and K >= 2752 equal or slower: profiles/r04g_gemm_k64.txt), so `auto`
+    // takes it for 1024 <= K < 2048; tuning key 0 = 11 forces it, 7 keeps the ring
+    if (!x3 && !sh && (variant == 11 || (g_amdnuwa_tuning[0] == 0 && variant == 7 && d->K >= 1024 && d->K < 2048)) && d->K % 32 == 0 && !d->C2) {
+        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
+        dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(512);
+        const size_t l6 = (size_t)2 * 2 * 256 * 64 * 2;
+        if (ob) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 1, 1, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
+            hipLaunchKernelGGL((gemm_nt_256_kernel<false, 1, 1, 4, 4, false>), g2, b2, l6, stream, p);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 0, 1, 4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
+            hipLaunchKernelGGL((gemm_nt_256_kernel<false, 0, 1, 4, 4, false>), g2, b2, l6, stream, p);
+        }
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
+    }
+    if (variant == 11) variant = 7;
     if (!x3 && variant == 8 && d->K % 32 == 0) {                           // staggered rows + DMA issue inside the MFMA phase
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(512);

@@ -23,11 +23,18 @@ cases = [('qkv (bf16 + fp16 copies)', lambda: K.gemm_nt_f16ops(h16, wqkv, out_bf
          ('FF2 (fp32 out)', lambda: K.gemm_nt_f16ops(gg, w2), 2.0 * M * D * FP, M * FP * 2 + M * D * 4)]
 for name, fn, fl, by in cases:
     row = []
-    for var, sk in ((0, 0), (6, 0), (6, -8), (6, -16), (6, -24), (6, -32), (6, -48), (0, 0)):
+    ref = None
+    for var in (0, 10, 11, 0, 10, 11):
         L.amdnuwa_set_tuning(0, var)
-        L.amdnuwa_set_tuning(14, sk)
-        t = bench(fn, 10)
-        row.append(f'{"256x256" if var == 0 else f"2 x 256x128 skew {-sk * 0.25:.0f} us"} {t * 1e6:7.1f}')
-    L.amdnuwa_set_tuning(14, 0)
+        out = fn()
+        cur = [t.float() for t in (((out.hi, out.f16) if hasattr(out, 'hi') else out) if isinstance(out, tuple) else (out,)) if t is not None]
+        if ref is None:
+            ref = cur
+        same = all(torch.equal(a_, b_) for a_, b_ in zip(cur, ref))
+        for dbg in (0, 1):
+            L.amdnuwa_set_tuning(7, dbg)
+            t = bench(fn, 10)
+            row.append(f'{ {0: "K32 ring", 10: "K64 lock-step", 11: "K64 staggered"}[var]} {["full", "no-st"][dbg]} {t * 1e6:7.1f}' + ('' if same else ' MISMATCH'))
+        L.amdnuwa_set_tuning(7, 0)
     L.amdnuwa_set_tuning(0, 0)
     print(f'{name:40s} ' + ' | '.join(row))
