@@ -351,6 +351,9 @@ int amdnuwa_xattn_bwd(const amdnuwa_xattn_geom* g, const uint16_t* dO, const uin
                       const amdnuwa_xattn_kv* packed, const float* w_th, const uint16_t* P, const uint16_t* P_lo,
                       uint16_t* dS, uint16_t* dS_lo, uint16_t* dq, uint16_t* dq_lo, int lddq, float* dw_th,
                       int accumulate, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
+/* accumulate: bit 0 = add into dnull_k / dnull_v instead of overwriting them; bit 1 = the rows of dKp / dVp follow the chunk-permuted
+ * key order in which amdnuwa_xattn2_bwd writes its dS / Pm columns (key 32 c + kk at row 32 c + 8 ((kk & 15) >> 2) + 4 (kk >> 4) + (kk & 3):
+ * the order a lane of the kernel holds its 8 slots, one 16-byte store each); amdnuwa_xattn_bwd and amdnuwa_xattn2_bwd_rc use the plain order */
 int amdnuwa_xattn_unpack(const amdnuwa_xattn_geom* g, const float* dKp, const float* dVp, uint16_t* dkv,
                          uint16_t* dkv_lo, int ldkv, float* dnull_k, float* dnull_v, int accumulate,
                          amdnuwa_stream stream);

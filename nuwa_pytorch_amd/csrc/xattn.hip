@@ -555,9 +555,16 @@ __global__ __launch_bounds__(256) void xattn_pack_kernel(const bf16_t* __restric
 
 // inverse of the packing for the gradients: dKp/dVp fp32 [B][NH][JP][DH] -> dkv bf16 hi[/lo] [B*T, ldkv];
 // dnull_k / dnull_v (+)= sum_b row 0
+// permuted: the rows of dKp / dVp follow the chunk-permuted key order of the xattn2 / xattn3 backward kernels (their dS / Pm columns):
+// key 32 ch + kk sits at row 32 ch + 8 ((kk & 15) >> 2) + 4 (kk >> 4) + (kk & 3); the null key (0) stays at row 0
+__device__ __forceinline__ int xattn_key_row(int j, int permuted) {
+    if (!permuted) return j;
+    const int kk = j & 31;
+    return (j & ~31) + 8 * ((kk & 15) >> 2) + 4 * (kk >> 4) + (kk & 3);
+}
 __global__ __launch_bounds__(256) void xattn_unpack_kernel(const float* __restrict__ dKp, const float* __restrict__ dVp,
                                                            bf16_t* dkv, bf16_t* dkvl, int ldkv, float* dnull_k, float* dnull_v,
-                                                           int B, int T, int NH, int DH, int JP, int accumulate) {
+                                                           int B, int T, int NH, int DH, int JP, int accumulate, int permuted) {
     const int inner = NH * DH;
     if ((int)blockIdx.x == B * NH) {     // null gradients, fixed order over b
         for (int e = threadIdx.x; e < inner; e += blockDim.x) {
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(256) void xattn_unpack_kernel(const float* __restri
     const int bh = blockIdx.x, b = bh / NH, h = bh % NH, dchunks = DH / 8;
     for (int e = threadIdx.x; e < T * dchunks; e += blockDim.x) {             // 8 channels per thread: 16-byte stores
         const int j = 1 + e / dchunks, dc = (e % dchunks) * 8;
-        const size_t o1 = ((size_t)bh * JP + j) * DH + dc;
+        const size_t o1 = ((size_t)bh * JP + xattn_key_row(j, permuted)) * DH + dc;
         const size_t g = ((size_t)b * T + j - 1) * ldkv + h * DH + dc;
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
@@ -754,7 +761,7 @@ extern "C" int amdnuwa_xattn_unpack(const amdnuwa_xattn_geom* g, const float* dK
     if (!dKp || !dVp || !dkv || !dnull_k || !dnull_v || ldkv % 8) return AMDNUWA_ERR_ARG;
     if (g->B <= 0) return AMDNUWA_OK;
     hipLaunchKernelGGL(xattn_unpack_kernel, dim3(g->B * g->heads + 1), dim3(256), 0, stream, dKp, dVp, dkv, dkv_lo, ldkv, dnull_k, dnull_v,
-                       g->B, g->T, g->heads, g->dim_head, g->JP, accumulate);
+                       g->B, g->T, g->heads, g->dim_head, g->JP, accumulate & 1, (accumulate >> 1) & 1);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

@@ -40,7 +40,11 @@ struct X2Args {
     bf16_t* ol;                              // xattn4 fp16-operand form only: the bf16 residual of o (o leaves as a hi + lo pair)
     float* stats;                            // [B][NH][n][2] = (row max of the scaled, masked scores; 1 / sum of exp)
     const bf16_t* dO; int lddo;
-    bf16_t *dS, *Pm;                         // [B][NH][n][JP]
+    bf16_t *dS, *Pm;                         // [B][NH][n][JP], keys of every 32-key chunk in the PERMUTED order the lanes hold them: position
+                                             // 8 g4 + e of a chunk = key (e < 4 ? 4 g4 + e : 16 + 4 g4 + e - 4), so that a lane's 8 slots are ONE
+                                             // 16-byte store (was two 8-byte stores 32 bytes apart: half the store instructions, 64 contiguous
+                                             // bytes per query row).  The batched TN GEMMs reduce over queries and do not care; their outputs
+                                             // dKp / dVp carry the same row order and amdnuwa_xattn_unpack undoes it (flag bit 1).
     bf16_t* dq; int lddq;
     float* part_th;                          // [grid][NH*NH]
     int B, n, JP, nch;
@@ -382,9 +386,8 @@ __global__ __launch_bounds__(256, 1) void xattn2_bwd_kernel(X2Args a) {
                 pm[e] = acc;
             }
             if (qok) {
-                bf16_t* dst = a.Pm + ((size_t)b * NH + g) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 4;
-                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(pm[0], pm[1]), pack2_rne(pm[2], pm[3]));
-                *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pack2_rne(pm[4], pm[5]), pack2_rne(pm[6], pm[7]));
+                bf16_t* dst = a.Pm + ((size_t)b * NH + g) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 8;      // (chunk-permuted key order: see X2Args::dS)
+                *reinterpret_cast<uint4*>(dst) = make_uint4(pack2_rne(pm[0], pm[1]), pack2_rne(pm[2], pm[3]), pack2_rne(pm[4], pm[5]), pack2_rne(pm[6], pm[7]));
             }
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
@@ -461,9 +464,8 @@ __global__ __launch_bounds__(256, 1) void xattn2_bwd_kernel(X2Args a) {
             const uint2 lo = make_uint2(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]));
             const uint2 hi = make_uint2(pack2_rne(ds[4], ds[5]), pack2_rne(ds[6], ds[7]));
             if (qok) {
-                bf16_t* dst = a.dS + ((size_t)b * NH + h) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 4;
-                *reinterpret_cast<uint2*>(dst) = lo;
-                *reinterpret_cast<uint2*>(dst + 16) = hi;
+                bf16_t* dst = a.dS + ((size_t)b * NH + h) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 8;      // (chunk-permuted key order)
+                *reinterpret_cast<uint4*>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
             const bf16x8 sf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
@@ -678,9 +680,9 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
             if (qok && !a.nostore) {
 #pragma unroll
                 for (int rp = 0; rp < 4; ++rp) {
-                    bf16_t* dst = a.Pm + ((size_t)b * NH + 4 * Q + rp) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 4;
-                    *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(D[0][rp], D[1][rp]), pack2_rne(D[2][rp], D[3][rp]));
-                    *reinterpret_cast<uint2*>(dst + 16) = make_uint2(pack2_rne(D[4][rp], D[5][rp]), pack2_rne(D[6][rp], D[7][rp]));
+                    bf16_t* dst = a.Pm + ((size_t)b * NH + 4 * Q + rp) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 8;   // (chunk-permuted key order)
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(pack2_rne(D[0][rp], D[1][rp]), pack2_rne(D[2][rp], D[3][rp]),
+                                                                pack2_rne(D[4][rp], D[5][rp]), pack2_rne(D[6][rp], D[7][rp]));
                 }
             }
         }
@@ -794,9 +796,8 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
                 const uint2 lo = make_uint2(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]));
                 const uint2 hi = make_uint2(pack2_rne(ds[4], ds[5]), pack2_rne(ds[6], ds[7]));
                 if (qok && !a.nostore) {
-                    bf16_t* dst = a.dS + ((size_t)b * NH + h) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 4;
-                    *reinterpret_cast<uint2*>(dst) = lo;
-                    *reinterpret_cast<uint2*>(dst + 16) = hi;
+                    bf16_t* dst = a.dS + ((size_t)b * NH + h) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 8;  // (chunk-permuted key order)
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 }
                 const bf16x8 sf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll

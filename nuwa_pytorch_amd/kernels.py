@@ -982,14 +982,23 @@ def xattn_kv_grads(g, dS, Pm, q, dO):
     return dKp, dVp
 
 
-def xattn_unpack(g, dKp, dVp, lo):
+def xattn_key_positions(JP, device):
+    """index tensor pos with  natural_order = permuted.index_select(dim, pos):  where key j of the plain order sits in the chunk-permuted
+    order of xattn2_bwd's dS / Pm columns (and of the dKp / dVp rows computed from them)"""
+    j = torch.arange(JP, device=device)
+    kk = j & 31
+    return (j & ~31) + 8 * ((kk & 15) >> 2) + 4 * (kk >> 4) + (kk & 3)
+
+
+def xattn_unpack(g, dKp, dVp, lo, permuted=False):
+    """permuted: dKp / dVp came from xattn_kv_grads over the dS / Pm of xattn2_bwd (chunk-permuted key rows)"""
     L = _lib.lib()
     inner = g.heads * g.dim_head
     dev = dKp.device
     dkv = empty_bf((g.B * g.T, 2 * inner), dev, lo=lo)
     dnk = torch.empty((g.heads, g.dim_head), dtype=torch.float32, device=dev)
     dnv = torch.empty_like(dnk)
-    check(L.amdnuwa_xattn_unpack(C.byref(g), _p(dKp), _p(dVp), _p(dkv.hi), _p(dkv.lo), 2 * inner, _p(dnk), _p(dnv), 0, _stream()),
+    check(L.amdnuwa_xattn_unpack(C.byref(g), _p(dKp), _p(dVp), _p(dkv.hi), _p(dkv.lo), 2 * inner, _p(dnk), _p(dnv), 2 if permuted else 0, _stream()),
           'amdnuwa_xattn_unpack')
     return dkv, dnk, dnv
 

@@ -260,15 +260,17 @@ class XInner:
         d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
         dwo = torch.empty_like(wo)
         K.gemm_tn(dy, o, dwo)
+        permuted = False
         if Pm is None and K.xattn2_bwd_rc_ok(g):
             dq, dKp, dVp, dwth = K.xattn2_bwd_rc(g, q, d_o, pk, wth2, P)         # no dS / Pm arrays: the key side recomputes them
         else:
             if Pm is None:
-                dq, dS, Pm, dwth = K.xattn2_bwd(g, q, d_o, pk, wth2, P)
+                dq, dS, Pm, dwth = K.xattn2_bwd(g, q, d_o, pk, wth2, P)          # dS / Pm columns in the kernel's chunk-permuted key order
+                permuted = True
             else:
                 dq, dS, dwth = K.xattn_bwd(g, d_o, pk, wth2, P)
             dKp, dVp = K.xattn_kv_grads(g, dS, Pm, q, d_o)
-        dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=dy.lo is not None)
+        dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=dy.lo is not None, permuted=permuted)
         rot = meta.get('rotary')
         if rot is not None:
             dq = _rotary_bf(dq, rot, g.B, g.n, g.heads, inverse=True)

@@ -675,10 +675,12 @@ def test_cross_attention_core(K, O, case, x3):
         dq2, dS2, Pm2, dwth2 = K.xattn2_bwd(g, qp, dop, pk, wth.detach().to(DEV), stats)
         report('xattn2_dq' + tag, dq2.hi.float().reshape(B, n, heads, dh), q.grad, 2 ** -6)
         report('xattn2_dwth' + tag, dwth2, wth.grad, 2 ** -6)
-        report('xattn2_Pm' + tag, Pm2.hi.float(), Pm.hi.float(), 2 ** -6)
-        report('xattn2_dS' + tag, dS2.hi.float(), dS.hi.float(), 2 ** -5)
+        # (xattn2_bwd writes the columns of dS / Pm in its chunk-permuted key order: undone here, and by xattn_unpack below)
+        pos = K.xattn_key_positions(g.JP, DEV)
+        report('xattn2_Pm' + tag, Pm2.hi.float().index_select(-1, pos), Pm.hi.float(), 2 ** -6)
+        report('xattn2_dS' + tag, dS2.hi.float().index_select(-1, pos), dS.hi.float(), 2 ** -5)
         dKp2, dVp2 = K.xattn_kv_grads(g, dS2, Pm2, qp, dop)
-        dkv2, dnk2, dnv2 = K.xattn_unpack(g, dKp2, dVp2, lo=False)
+        dkv2, dnk2, dnv2 = K.xattn_unpack(g, dKp2, dVp2, lo=False, permuted=True)
         report('xattn2_dkv' + tag, dkv2.hi.float().reshape(B, T, 2, heads, dh), kv.grad, 2 ** -6)
         report('xattn2_dnull_k' + tag, dnk2, nk.grad, 2 ** -6)
         report('xattn2_dnull_v' + tag, dnv2, nv.grad, 2 ** -6)
@@ -741,8 +743,9 @@ def test_cross_attention_bwd_recomputing_key_side(K, O, B, n, T):
     dq, dKp, dVp, dwth = K.xattn2_bwd_rc(g, qp, dop, pk, w, stats)
     tag = f'[{B},{n},{T}]'
     assert torch.equal(dq.hi, dq0.hi) and torch.equal(dwth, dwth0), 'the query side is the same kernel'
-    report('xattn_rc_dKp_vs_tn' + tag, dKp, dKp0, 2e-3)           # same bf16 operands, another summation order
-    report('xattn_rc_dVp_vs_tn' + tag, dVp, dVp0, 2e-3)
+    pos = K.xattn_key_positions(g.JP, DEV)                        # (the TN form's rows follow xattn2_bwd's chunk-permuted key order)
+    report('xattn_rc_dKp_vs_tn' + tag, dKp, dKp0.index_select(2, pos), 2e-3)           # same bf16 operands, another summation order
+    report('xattn_rc_dVp_vs_tn' + tag, dVp, dVp0.index_select(2, pos), 2e-3)
     dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=False)
     report('xattn_rc_dkv' + tag, dkv.hi.float().reshape(B, T, 2, heads, dh), kv.grad, 2 ** -6)
     report('xattn_rc_dnull_k' + tag, dnk, nk.grad, 2 ** -6)
