@@ -29,7 +29,8 @@ extern "C" {
 
 typedef struct ihipStream_t* amdnuwa_stream;   /* == hipStream_t */
 
-int amdnuwa_abi_version(void);                 /* bumps when any signature below changes */
+int amdnuwa_abi_version(void);                 /* bumps when any signature or documented argument meaning below changes (13: tuning keys 0..31,
+                                                * amdnuwa_xattn_unpack's flag bit 1, chunk-permuted dS / Pm columns of amdnuwa_xattn2_bwd) */
 const char* amdnuwa_error_string(int code);
 /* runtime tuning knobs (A/B benchmarking only; 0 = the library's auto policy everywhere):
  *   key 0  NT GEMM variant: 1 direct-to-LDS BK 64, 2 direct-to-LDS BK 32, 3 / 4 256x256 tile with a 4- / 3-stage DMA ring,
@@ -46,6 +47,16 @@ const char* amdnuwa_error_string(int code);
  *   key 9  3DNA MFMA forward probe: bits 0 / 1 / 2 skip the score / softmax+mix / apply phase (garbage results), bit 3 = fragment-shaped
  *          key loads in the score pass instead of the staged ones
  *   key 14 NT start-phase step in ~0.25 us units (0 = off)        key 15 VAE kernels: 1 = first (VALU) forms
+ *   key 16 Sparse3DNA MFMA forward: query rows per workgroup (0 = auto = 2 where H splits into dh * rows; 1 / 2 / 4 forced): a tile of rows
+ *          of one residue class of y stages every key / value row once for the rows that tap it
+ *   key 17 3DNA backward timing probes (garbage results): bit 0 no score sweeps, 1 no ds / P' workspace stores, 2 no dq apply sweep,
+ *          3 no dW_th sums; key side: bit 4 no coefficient gathers, 5 no q / dO row fetch
+ *   key 18 cross-attention timing probes (garbage results): forward bit 0 no re-staging, 1 no pass 1, 2 no probability exchange, 3 no P'V,
+ *          4 no head mix; backward bit 0 no re-staging, 1 no dW_th FMAs, 2 no pass A, 3 no pass B
+ *   key 19 3DNA MFMA query-side backward: 1 = the three separate item passes (P' mix, dW_th, dP mix) instead of the fused one
+ * (keys run 0..31; key 0 also takes 10 / 11 = the K-step 64 forms of the 256x256 ring (lock-step / staggered wave rows: full 128-byte
+ *  DMA lines, two 64 KiB stages; `auto` uses 11 for 1024 <= K < 2048); key 14 < 0 with key 0 = 6 delays the second workgroup of a CU;
+ *  key 7 bit 6 issues a tile's stores inside the main loop (probe))
  * (key 0 also takes 6 = 256x128 tile, two workgroups per CU, 7 = 256x256 ring with staggered wave rows, 8 = 7 + DMA issue inside the
  *  MFMA phase, 9 = 256x256 tile on FOUR waves of 128x128 (plain fp32 / bf16 outputs only, else 7; opt-in: DESIGN.md 5n);
  *  any non-zero key 0 disables the few-row weight-streaming path that M <= 32 normally takes) */
@@ -372,6 +383,9 @@ int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, 
 int amdnuwa_xattn2_fwd_f16(const amdnuwa_xattn_geom* g, const uint16_t* q_f16, int ldq, const amdnuwa_xattn_kv* packed,
                            const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, float* stats, amdnuwa_stream stream);
 size_t amdnuwa_xattn2_bwd_workspace_bytes(const amdnuwa_xattn_geom* g);
+/* dS / Pm [B][heads][n][JP]: the keys of every 32-key chunk in the order the kernel's lanes hold them (position 8 g + e of a chunk = key
+ * (e < 4 ? 4 g + e : 16 + 4 g + e - 4)): batched amdnuwa_gemm_tn over them yields dKp / dVp rows in the same order, which
+ * amdnuwa_xattn_unpack undoes when its flag bit 1 is set */
 int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
                        const amdnuwa_xattn_kv* packed, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm,
                        uint16_t* dq, int lddq, float* part_th, size_t part_bytes, amdnuwa_stream stream);

@@ -594,6 +594,9 @@ def embed_bwd(ids, dx, dW, dax1, dax2, dax3, dbos, B, ntok, F, H, Wd, frac):
     L = _lib.lib()
     D = dW.shape[1]
     nb = L.amdnuwa_embed_bwd_workspace_bytes(ntok, D)
+    # (the token-gradient kernel cuts the sorted ids into as many segments as the workspace holds two partial rows for: room for 64-row
+    #  segments keeps a wave's serial walk short; the minimum the library asks for still works, with longer segments)
+    nb = max(nb, (2 * ((B * (ntok - 1) + 63) // 64) + 64) * (D + 2) * 4)
     ws = workspace(nb, dx.device)
     sid, perm = torch.sort(ids.reshape(-1), stable=True)      # fixed summation order per embedding row: no atomics
     check(L.amdnuwa_embed_bwd(_p(ids), _p(sid), _p(perm), _p(dx), _p(dW), _p(dax1), _p(dax2), _p(dax3), _p(dbos), B, ntok, D,
