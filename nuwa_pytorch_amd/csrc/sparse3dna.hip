@@ -954,9 +954,14 @@ __device__ __forceinline__ void mfma_band_scores_staged(const S3Args& a, const R
     const int gc = r.lane & 7, r8 = r.lane >> 3;
     const bf16_t* kbase = rows + r.tok0 * ldr + h * DH + gc * 8;                  // + token * ld
     const int spb = r.c * r.TS + h;
-    int sidx[4];
+    int sidx[4], wbase[4], wmul[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
+    for (int q = 0; q < 4; ++q) {
+        sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
+        const bool on = r.tsel[q] >= 0 && r.qok;
+        wbase[q] = on ? sidx[q] : r.c * r.TS + r.J * NH + r.g4;          // (the 4 pad words of query c's table row: one per lane group)
+        wmul[q] = on ? NH : 0;
+    }
     const int w0 = vt_off(r8, gc), w1 = vt_off(r8 + 8, gc);
     const int f0 = vt_off(r.c, r.g4), f1 = vt_off(r.c, 4 + r.g4);
     constexpr int PF = S3M_PF;
@@ -995,11 +1000,17 @@ __device__ __forceinline__ void mfma_band_scores_staged(const S3Args& a, const R
         __builtin_amdgcn_wave_barrier();
         if (sq == 0) {
             if (r.g4 == 0 && r.qok) TAB[spb] = sc[0] * mul + (bias ? bias[h] : 0.f);
+        } else if (!bias) {
+            // band scatter without exec masking: an accumulator entry that lies on no tap diagonal goes to the lane's own pad word of the
+            // table (wbase = the pad, wmul = 0), the others to (slot jb + tap, head h): 4 x (mad, mul, ds_write) instead of 4 masked blocks
+            const int jb = r.pslot[sq - 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) TAB[wbase[q] + jb * wmul[q]] = sc[q] * mul;
         } else if (r.qok) {
             const int jb = r.pslot[sq - 1];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (r.tsel[q] >= 0) TAB[sidx[q] + jb * NH] = sc[q] * mul + (bias ? bias[(jb + r.tsel[q]) * NH + h] : 0.f);
+                if (r.tsel[q] >= 0) TAB[sidx[q] + jb * NH] = sc[q] * mul + bias[(jb + r.tsel[q]) * NH + h];
         }
     };
     for (int sq = 0; sq <= r.nplanes; sq += 3) {
@@ -1307,9 +1318,14 @@ __device__ __forceinline__ void tile_band_scores(const S3Args& a, const TileM<RO
     const int gc = r.lane & 7, r8 = r.lane >> 3;
     const bf16_t* kbase = rows + r.tok0 * ldr + h * DH + gc * 8;                  // + token * ld
     const int spb = r.c * r.TS + h;
-    int sidx[4];
+    const int wpad = r.c * r.TS + r.J * NH + r.g4;                               // the lane's pad word of query c's table row
+    int sidx[4], wbase[4], wmul[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
+    for (int q = 0; q < 4; ++q) {
+        sidx[q] = spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH;
+        wbase[q] = r.tsel[q] >= 0 ? sidx[q] : wpad;
+        wmul[q] = r.tsel[q] >= 0 ? NH : 0;
+    }
     const int w0 = vt_off(r8, gc), w1 = vt_off(r8 + 8, gc);
     const int f0 = vt_off(r.c, r.g4), f1 = vt_off(r.c, 4 + r.g4);
     auto issue = [&](int sq, uint4& d0, uint4& d1) {                             // sequence 0: every row is token 0 (<bos>)
@@ -1345,12 +1361,17 @@ __device__ __forceinline__ void tile_band_scores(const S3Args& a, const TileM<RO
                 f32x4 sc = {0.f, 0.f, 0.f, 0.f};
                 sc = mfma16<F16>(k0, qf0[i], sc);
                 sc = mfma16<F16>(k1, qf1[i], sc);
-                if (r.qok[i]) {
-                    const int jb = 1 + (ta * a.kh + tb) * a.kw;
+                const int jb = 1 + (ta * a.kh + tb) * a.kw;
+                if (!bias) {                                                     // (unmasked band scatter: see mfma_band_scores_staged)
+                    const int wb = r.qok[i] ? 0 : 1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        TAB[i * r.WTS + (wb ? wpad : wbase[q]) + jb * (wb ? 0 : wmul[q])] = sc[q] * mul;
+                } else if (r.qok[i]) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (r.tsel[q] >= 0)
-                            TAB[i * r.WTS + sidx[q] + jb * NH] = sc[q] * mul + (bias ? bias[(jb + r.tsel[q]) * NH + h] : 0.f);
+                            TAB[i * r.WTS + sidx[q] + jb * NH] = sc[q] * mul + bias[(jb + r.tsel[q]) * NH + h];
                 }
             }
         }
