@@ -1094,7 +1094,9 @@ __device__ __forceinline__ void mfma_band_apply(const S3Args& a, const RowM& r, 
 
 // fp32 softmax over the J slots of every (w, h) of TAB, in place (4 lanes split j); masked slots hold NEG_MAX
 // gst (optional): [W][NH][4] floats of this query row in the statistics array: (row max, 1 / row sum) of queries w < wvalid go there
-__device__ __forceinline__ void rowm_softmax(float* TAB, int J, float* gst = nullptr, int wvalid = 0) {
+// pre: the table holds raw q . k products and the softmax scale is applied here (one multiply per slot instead of one per product
+// in the score sweep; the same fp32 multiply of the same value, so nothing changes bit-wise).  Kernels with a bias table scale in the sweep.
+__device__ __forceinline__ void rowm_softmax(float* TAB, int J, float* gst = nullptr, int wvalid = 0, float pre = 1.f) {
     constexpr int NH = S3M_NH;
     const int t = threadIdx.x, cc = t & 3, wh = t >> 2, h = wh % NH, w = wh / NH;
     TAB += w * s3m_ts(J) + h;                                                    // (query w, slot 0, head h); slot j at + j * NH
@@ -1103,7 +1105,7 @@ __device__ __forceinline__ void rowm_softmax(float* TAB, int J, float* gst = nul
         // read (-modify-write) passes of 12 round trips each; same operations in the same order -> bit-identical
         float v[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) { const int j = cc + 4 * k; v[k] = j < J ? TAB[j * NH] : NEG_MAX; }
+        for (int k = 0; k < 12; ++k) { const int j = cc + 4 * k; v[k] = j < J ? TAB[j * NH] * pre : NEG_MAX; }
         float m = NEG_MAX;
 #pragma unroll
         for (int k = 0; k < 12; ++k) m = fmaxf(m, v[k]);
@@ -1123,12 +1125,12 @@ __device__ __forceinline__ void rowm_softmax(float* TAB, int J, float* gst = nul
         return;
     }
     float m = NEG_MAX;
-    for (int j = cc; j < J; j += 4) m = fmaxf(m, TAB[j * NH]);
+    for (int j = cc; j < J; j += 4) m = fmaxf(m, TAB[j * NH] * pre);
     m = quad_max(m);
     float sum = 0.f;
     for (int j = cc; j < J; j += 4) {
         const int idx = j * NH;
-        const float e = __expf(TAB[idx] - m);
+        const float e = __expf(TAB[idx] * pre - m);
         TAB[idx] = e;
         sum += e;
     }
@@ -1343,35 +1345,40 @@ __device__ __forceinline__ void tile_band_scores(const S3Args& a, const TileM<RO
         issue(sq + PF, d0, d1);
         __builtin_amdgcn_wave_barrier();                                          // LDS is in-order per wave: the tile is complete
         const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(tile + f0), k1 = *reinterpret_cast<const bf16x8*>(tile + f1);
+        // all MFMAs of the step first, then the scatters: the result latency of one row's products is covered by the next row's
+        f32x4 sc[ROWS];
         if (sq == 0) {
 #pragma unroll
             for (int i = 0; i < ROWS; ++i) {
                 if (i >= r.nrows) continue;
-                f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-                sc = mfma16<F16>(k0, qf0[i], sc);
-                sc = mfma16<F16>(k1, qf1[i], sc);
-                if (r.g4 == 0 && r.qok[i]) TAB[i * r.WTS + spb] = sc[0] * mul + (bias ? bias[h] : 0.f);
+                sc[i] = mfma16<F16>(k1, qf1[i], mfma16<F16>(k0, qf0[i], f32x4{0.f, 0.f, 0.f, 0.f}));
             }
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i)
+                if (i < r.nrows && r.g4 == 0 && r.qok[i]) TAB[i * r.WTS + spb] = sc[i][0] * mul + (bias ? bias[h] : 0.f);
         } else {
             const int meta = r.kmeta[sq - 1], ta = meta >> 8, m = (meta & 255) - 64;
 #pragma unroll
             for (int i = 0; i < ROWS; ++i) {
                 const int tb = m - i + a.kh - 1;
                 if (i >= r.nrows || tb < 0 || tb >= a.kh) continue;              // (wave-uniform)
-                f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-                sc = mfma16<F16>(k0, qf0[i], sc);
-                sc = mfma16<F16>(k1, qf1[i], sc);
+                sc[i] = mfma16<F16>(k1, qf1[i], mfma16<F16>(k0, qf0[i], f32x4{0.f, 0.f, 0.f, 0.f}));
+            }
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                const int tb = m - i + a.kh - 1;
+                if (i >= r.nrows || tb < 0 || tb >= a.kh) continue;
                 const int jb = 1 + (ta * a.kh + tb) * a.kw;
                 if (!bias) {                                                     // (unmasked band scatter: see mfma_band_scores_staged)
                     const int wb = r.qok[i] ? 0 : 1;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        TAB[i * r.WTS + (wb ? wpad : wbase[q]) + jb * (wb ? 0 : wmul[q])] = sc[q] * mul;
+                        TAB[i * r.WTS + (wb ? wpad : wbase[q]) + jb * (wb ? 0 : wmul[q])] = sc[i][q] * mul;
                 } else if (r.qok[i]) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (r.tsel[q] >= 0)
-                            TAB[i * r.WTS + sidx[q] + jb * NH] = sc[q] * mul + bias[(jb + r.tsel[q]) * NH + h];
+                            TAB[i * r.WTS + sidx[q] + jb * NH] = sc[i][q] * mul + bias[(jb + r.tsel[q]) * NH + h];
                 }
             }
         }
@@ -1472,7 +1479,7 @@ __device__ __forceinline__ void tile_band_apply(const S3Args& a, const TileM<ROW
     }
 }
 
-template <int ROWS, bool F16>
+template <int ROWS, bool F16, bool BIAS>      // BIAS: a.bias != NULL (the relative-position bias of cfg 5; compiled out of the training kernels otherwise)
 __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3Args a) {
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1511,9 +1518,9 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
     s3t_keylist<ROWS>(a, f, y0, ktok, kmeta, kcnt);
     const TileM<ROWS> r = s3t_init<ROWS>(a, b, f, y0, nrows, ktok, kmeta, kcnt[0]);
     if (!(a.dbg & 1))     // (a.dbg, tuning key 9: bits 0 / 1 / 2 skip the score / softmax + mix / apply phase -- timing probes, garbage results)
-        tile_band_scores<ROWS, F16, ROWS >= 4 ? 4 : S3M_PF>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias, vt_base + r.wave * 4096);
+        tile_band_scores<ROWS, F16, ROWS >= 4 ? 4 : S3M_PF>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, BIAS ? a.scale : 1.f, BIAS ? a.bias : nullptr, vt_base + r.wave * 4096);
     __syncthreads();
-    for (int i = 0; i < nrows && !(a.dbg & 2); ++i) rowm_softmax(SP + i * WTS, J);
+    for (int i = 0; i < nrows && !(a.dbg & 2); ++i) rowm_softmax(SP + i * WTS, J, nullptr, 0, BIAS ? 1.f : a.scale);
     __syncthreads();
     // talking heads: P'[g] = sum_h Wth[g][h] P[h] per (row, w, j), in place
     float wr[64];
@@ -1567,6 +1574,7 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
 // fragment and V as the rows), dW_th partial, dP = W^T dP', ds = P (dP - sum P dP), dq = scale * ds . K (band apply over K);
 // ds and P' go to the fp32 workspace for the key-side kernel, the <bos> key / value partials to part_k0 / part_v0.
 // LDS: R1 = SP (P) until ds exists, then the 8 transposed K tiles | DP | RED [8][64] | PM0 [W][NH]
+template <bool BIAS>
 __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      // (4 waves per SIMD = two workgroups per CU: <= 128 registers)
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W, inner = NH * DH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1608,14 +1616,14 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
     // (a.dbg, tuning key 17: timing probes only -- bit 0 skips the two score sweeps, bit 1 the ds / P' workspace stores, bit 2 the dq
     //  apply sweep, bit 3 the dW_th partial; results are garbage)
     if (!(a.dbg & 1)) {
-    mfma_band_scores_staged(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, a.scale, a.bias, stile);             // scores
+    mfma_band_scores_staged(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, BIAS ? a.scale : 1.f, BIAS ? a.bias : nullptr, stile);   // scores (raw products unless a bias table is added: see rowm_softmax)
     mfma_band_scores_staged(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, 1.f, nullptr, stile);              // dP'[g] = dO[g] . v_j[g]
     }
     __syncthreads();
     // recomputing key side: this kernel leaves (row max, 1 / row sum, delta) per (query, head) instead of the ds / P' workspace
     float* gst = a.stats ? a.stats + ((size_t)b * nq + (size_t)ry * W) * NH * 4 : nullptr;
     const int wvalid = a.ntok - 1 - ry * W;                                                 // queries of this row that exist
-    rowm_softmax(SP, J, gst, wvalid);                                                       // P
+    rowm_softmax(SP, J, gst, wvalid, BIAS ? 1.f : a.scale);                                 // P
     __syncthreads();
     // ONE pass over the (query, slot) items, all 8 heads of an item in the thread's registers (tuning key 19 = 1 restores the three
     // separate passes it replaces):
@@ -2192,13 +2200,14 @@ int s3_fwd_tile_launch(const S3Args& a, const amdnuwa_s3_geom* g, int tr, hipStr
     const int J = g->kf * g->kh * g->kw + 1;
     const size_t lm = (size_t)tr * 16 * (J * 8 + 4) * sizeof(float) + 8 * 4096;
     const dim3 grid(g->B * g->F * (g->H / tr));
-    if (tr == 4) {
-        (void)hipFuncSetAttribute((const void*)s3_fwd_tile_kernel<4, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
-        hipLaunchKernelGGL((s3_fwd_tile_kernel<4, F16>), grid, dim3(512), lm, stream, a);
-    } else {
-        (void)hipFuncSetAttribute((const void*)s3_fwd_tile_kernel<2, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
-        hipLaunchKernelGGL((s3_fwd_tile_kernel<2, F16>), grid, dim3(512), lm, stream, a);
-    }
+#define S3T_LAUNCH(R_, B_)                                                                                        \
+    do {                                                                                                          \
+        (void)hipFuncSetAttribute((const void*)s3_fwd_tile_kernel<R_, F16, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm); \
+        hipLaunchKernelGGL((s3_fwd_tile_kernel<R_, F16, B_>), grid, dim3(512), lm, stream, a);                    \
+    } while (0)
+    if (tr == 4) { if (a.bias) S3T_LAUNCH(4, true); else S3T_LAUNCH(4, false); }
+    else { if (a.bias) S3T_LAUNCH(2, true); else S3T_LAUNCH(2, false); }
+#undef S3T_LAUNCH
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
@@ -2346,9 +2355,12 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     const size_t lds_qm = (nspm * 4 > 8 * 4096 ? nspm * 4 : 8 * 4096) + nspm * 4 + (8 * 64 + 16 * 8) * 4 + 8 * 2048;   // + the score staging tiles
 #define S3B(DH_, LO_)                                                                                             \
     do {                                                                                                          \
-        if (q_mfma) {                                                                                             \
-            (void)hipFuncSetAttribute((const void*)s3_bwd_q_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qm); \
-            hipLaunchKernelGGL(s3_bwd_q_mfma_kernel, grid, dim3(512), lds_qm, stream, a);                         \
+        if (q_mfma && a.bias) {                                                                                   \
+            (void)hipFuncSetAttribute((const void*)s3_bwd_q_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qm); \
+            hipLaunchKernelGGL(s3_bwd_q_mfma_kernel<true>, grid, dim3(512), lds_qm, stream, a);                   \
+        } else if (q_mfma) {                                                                                      \
+            (void)hipFuncSetAttribute((const void*)s3_bwd_q_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qm); \
+            hipLaunchKernelGGL(s3_bwd_q_mfma_kernel<false>, grid, dim3(512), lds_qm, stream, a);                  \
         } else {                                                                                                  \
             (void)hipFuncSetAttribute((const void*)s3_bwd_q_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
             hipLaunchKernelGGL((s3_bwd_q_kernel<DH_, LO_>), grid, block, lds_q, stream, a);                       \
