@@ -30,7 +30,8 @@ extern "C" {
 typedef struct ihipStream_t* amdnuwa_stream;   /* == hipStream_t */
 
 int amdnuwa_abi_version(void);                 /* bumps when any signature or documented argument meaning below changes (13: tuning keys 0..31,
-                                                * amdnuwa_xattn_unpack's flag bit 1, chunk-permuted dS / Pm columns of amdnuwa_xattn2_bwd) */
+                                                * amdnuwa_xattn_unpack's flag bit 1, chunk-permuted dS / Pm columns of amdnuwa_xattn2_bwd;
+                                                * 14: amdnuwa_linear_ce_x3 added) */
 const char* amdnuwa_error_string(int code);
 /* runtime tuning knobs (A/B benchmarking only; 0 = the library's auto policy everywhere):
  *   key 0  NT GEMM variant: 1 direct-to-LDS BK 64, 2 direct-to-LDS BK 32, 3 / 4 256x256 tile with a 4- / 3-stage DMA ring,
@@ -218,6 +219,11 @@ size_t amdnuwa_linear_ce_workspace_bytes(long long R, int C);
 int amdnuwa_linear_ce(const uint16_t* h, int ldh, const uint16_t* w, int ldw, const long long* targets, long long R, int C, int K,
                       float grad_scale, float* row_loss, float* loss, uint16_t* dlogits, int ld_dl, void* workspace,
                       size_t workspace_bytes, amdnuwa_stream stream);
+/* The same with both operands as bf16 hi + lo pairs (three MFMAs per product on the hi + lo ring: the to_logits of the 'bf16x3-fwd'
+ * mode, whose logits must stay inside the 1e-3 bound while its backward takes a plain bf16 dlogits).  Same workspace, same outputs. */
+int amdnuwa_linear_ce_x3(const uint16_t* h_hi, const uint16_t* h_lo, int ldh, const uint16_t* w_hi, const uint16_t* w_lo, int ldw,
+                         const long long* targets, long long R, int C, int K, float grad_scale, float* row_loss, float* loss,
+                         uint16_t* dlogits, int ld_dl, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sparse3DNA core (np.py:488-608, incl. the unfoldNd gather np.py:526-534): causal (or symmetric) 3-D nearby

@@ -403,6 +403,54 @@ __device__ __forceinline__ int b256_off(int row, int cc) { return row * 64 + ((c
 template <int EPI>
 __device__ __forceinline__ int b256_row(int j, int fr) { return EPI >= 1 ? ((fr >> 2) * 16 + j * 4 + (fr & 3)) : (j * 16 + fr); }
 
+// Fused linear + cross entropy epilogue (to_logits + F.cross_entropy, np.py:1958-1963), shared by the bf16 ring (gemm_nt_256_kernel)
+// and the hi + lo ring (gemm_nt_256x3_kernel).  Same ownership as the bf16 epilogue: lane (fr, fg) holds 16 contiguous logits of row
+// m; the 4 lanes fr + 16 fg of a row cover this wave's 64-column block (host side guarantees N % 64 == 0).
+// EPI 2: per (row, 64-column block) partial (max, sum exp) + the target logit;  EPI 3: dlogits = (exp(logit - lse) - onehot) * ce_scale.
+template <int EPI>
+__device__ __forceinline__ void ce_epilogue(const GemmArgs& p, const f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int fr, int fg) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
+        if (m >= p.M) continue;                                   // (the 4 lanes of a row leave together)
+        const int nb = n0 + wn * 64 + fg * 16;
+        if (nb >= p.N) continue;
+        float vv[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha;
+        const long long t = p.ce_tgt[m];
+        const int tc = (t >= nb && t < nb + 16) ? (int)(t - nb) : -1;      // the target column, if this lane holds it
+        if constexpr (EPI == 2) {
+            float mx = vv[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, vv[e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sm = 0.f, tl = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                sm += __builtin_amdgcn_exp2f((vv[e] - mx) * 1.4426950408889634f);
+                tl = (e == tc) ? vv[e] : tl;
+            }
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            if (fg == 0) *reinterpret_cast<float2*>(p.ce_stats + (m * p.ce_nblk + ((n0 + wn * 64) >> 6)) * 2) = make_float2(mx, sm);
+            if (tc >= 0) p.ce_tl[m] = tl;
+        } else {
+            const float lse = p.ce_lse[m];
+            float dv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                dv[e] = (__builtin_amdgcn_exp2f((vv[e] - lse) * 1.4426950408889634f) - (e == tc ? 1.f : 0.f)) * p.ce_scale;
+            bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + nb;
+            reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2_rne(dv[0], dv[1]), pack2_rne(dv[2], dv[3]), pack2_rne(dv[4], dv[5]), pack2_rne(dv[6], dv[7]));
+            reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2_rne(dv[8], dv[9]), pack2_rne(dv[10], dv[11]), pack2_rne(dv[12], dv[13]), pack2_rne(dv[14], dv[15]));
+        }
+    }
+}
+
 // K-step 64 form of the ring (STAG == 3): operand rows are staged as FULL 128-byte lines (8 rows x 128 B per 1-KiB DMA piece, two
 // 64 KiB stages) instead of 64-byte half lines (16 rows x 64 B per piece): half as many L2 requests per byte.  A rows are plain
 // (fragment i covers rows i*16 + fr), so the 16-byte chunk swizzle is row & 7; the permuted B rows of the bf16 epilogues
@@ -726,49 +774,7 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
 
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
     if constexpr (EPI == 2 || EPI == 3) {
-        // fused linear + cross entropy (to_logits + F.cross_entropy, np.py:1958-1963).  Same ownership as the bf16 epilogue: lane
-        // (fr, fg) holds 16 contiguous logits of row m; the 4 lanes fr + 16 fg of a row cover this wave's 64-column block.
-        // (host side guarantees N % 64 == 0)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
-            if (m >= p.M) continue;                                   // (the 4 lanes of a row leave together)
-            const int nb = n0 + wn * 64 + fg * 16;
-            if (nb >= p.N) continue;
-            float vv[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha;
-            const long long t = p.ce_tgt[m];
-            const int tc = (t >= nb && t < nb + 16) ? (int)(t - nb) : -1;      // the target column, if this lane holds it
-            if constexpr (EPI == 2) {
-                float mx = vv[0];
-#pragma unroll
-                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, vv[e]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                float sm = 0.f, tl = 0.f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    sm += __builtin_amdgcn_exp2f((vv[e] - mx) * 1.4426950408889634f);
-                    tl = (e == tc) ? vv[e] : tl;
-                }
-                sm += __shfl_xor(sm, 16, 64);
-                sm += __shfl_xor(sm, 32, 64);
-                if (fg == 0) *reinterpret_cast<float2*>(p.ce_stats + (m * p.ce_nblk + ((n0 + wn * 64) >> 6)) * 2) = make_float2(mx, sm);
-                if (tc >= 0) p.ce_tl[m] = tl;
-            } else {
-                const float lse = p.ce_lse[m];
-                float dv[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    dv[e] = (__builtin_amdgcn_exp2f((vv[e] - lse) * 1.4426950408889634f) - (e == tc ? 1.f : 0.f)) * p.ce_scale;
-                bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + nb;
-                reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2_rne(dv[0], dv[1]), pack2_rne(dv[2], dv[3]), pack2_rne(dv[4], dv[5]), pack2_rne(dv[6], dv[7]));
-                reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2_rne(dv[8], dv[9]), pack2_rne(dv[10], dv[11]), pack2_rne(dv[12], dv[13]), pack2_rne(dv[14], dv[15]));
-            }
-        }
+        ce_epilogue<EPI>(p, acc, m0, n0, wm, wn, fr, fg);
     } else if constexpr (EPI == 1) {
         // lane (fr, fg) owns row m = .. + fr and the 16 contiguous columns n = n0 + wn*64 + fg*16 + [j*4 + r]
         const bool vec8 = (p.N % 8 == 0) && (p.ldc % 8 == 0);
@@ -1174,7 +1180,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
 // Accumulation order per output element (k ascending; per 32-chunk lo*hi, hi*lo, hi*hi) equals gemm_nt_kernel<true,...>'s, so
 // the two kernels agree bit for bit.
 // ---------------------------------------------------------------------------------------------
-template <int EPI>      // 0: fp32 out (+bias);  1: bf16 hi [+ lo] out (+bias)
+template <int EPI>      // 0: fp32 out (+bias);  1: bf16 hi [+ lo] out (+bias);  2 / 3: the two passes of the fused cross entropy (ce_epilogue)
 __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 256 * 32 * 2;             // one operand image of a stage: 16 KiB
@@ -1265,7 +1271,9 @@ __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
         }
     }
 
-    if constexpr (EPI == 1) {
+    if constexpr (EPI == 2 || EPI == 3) {
+        ce_epilogue<EPI>(p, acc, m0, n0, wm, wn, fr, fg);        // fused to_logits + cross entropy on the hi + lo product (amdnuwa_linear_ce_x3)
+    } else if constexpr (EPI == 1) {
         // lane (fr, fg) owns row m = .. + fr and the 16 contiguous columns n = n0 + wn*64 + fg*16 + [j*4 + r] (permuted B rows)
         const bool vec8 = (p.N % 8 == 0) && (p.ldc % 8 == 0);
         const int nb = n0 + wn * 64 + fg * 16;
@@ -2035,13 +2043,15 @@ extern "C" size_t amdnuwa_linear_ce_workspace_bytes(long long R, int C) {
     return (size_t)R * (C / 64) * 2 * sizeof(float) + (size_t)R * 2 * sizeof(float);
 }
 
-extern "C" int amdnuwa_linear_ce(const uint16_t* h, int ldh, const uint16_t* w, int ldw, const long long* targets, long long R, int C,
-                                 int K, float grad_scale, float* row_loss, float* loss, uint16_t* dlogits, int ld_dl,
-                                 void* workspace, size_t workspace_bytes, hipStream_t stream) {
+// h_lo / w_lo != NULL: both products on the hi + lo ring (three MFMAs per product: the logits of the 'bf16x3' modes)
+static int linear_ce_run(const uint16_t* h, const uint16_t* h_lo, int ldh, const uint16_t* w, const uint16_t* w_lo, int ldw,
+                         const long long* targets, long long R, int C, int K, float grad_scale, float* row_loss, float* loss,
+                         uint16_t* dlogits, int ld_dl, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!h || !w || !targets || !row_loss || !loss) return AMDNUWA_ERR_ARG;
     if (C % 64 || K % 32 || ldh % 8 || ldw % 8 || (dlogits && ld_dl % 8) || R > 0x7fffffffLL) return AMDNUWA_ERR_UNSUPPORTED;
     if (R <= 0) return AMDNUWA_OK;
     if (!workspace || workspace_bytes < amdnuwa_linear_ce_workspace_bytes(R, C)) return AMDNUWA_ERR_WORKSPACE;
+    const bool x3 = h_lo != nullptr;
     const int nblk = C / 64;
     float* stats = (float*)workspace;
     float* lse = stats + (size_t)R * nblk * 2;
@@ -2049,27 +2059,52 @@ extern "C" int amdnuwa_linear_ce(const uint16_t* h, int ldh, const uint16_t* w, 
     hipError_t e = hipMemsetAsync(tl, 0xff, (size_t)R * sizeof(float), stream);          // NaN until a valid target column writes it
     if (e != hipSuccess) return (int)e;
     GemmArgs p{};
-    p.A = (const bf16_t*)h; p.lda = ldh; p.B = (const bf16_t*)w; p.ldb = ldw;
+    p.A = (const bf16_t*)h; p.Alo = (const bf16_t*)h_lo; p.lda = ldh; p.B = (const bf16_t*)w; p.Blo = (const bf16_t*)w_lo; p.ldb = ldw;
     p.C = dlogits; p.ldc = ld_dl; p.alpha = 1.f;
     p.M = (int)R; p.N = C; p.K = K; p.shift_dim = K;
     p.tiles_m = (int)((R + 255) / 256); p.tiles_n = (C + 255) / 256;
     p.ce_stats = stats; p.ce_tl = tl; p.ce_lse = lse; p.ce_tgt = targets; p.ce_scale = grad_scale; p.ce_nblk = nblk;
     p.skew = nt_skew((long long)p.tiles_m * p.tiles_n);
     dim3 grid(p.tiles_m * p.tiles_n, 1), block(512);
-    const size_t lds = (size_t)4 * 2 * 256 * 32 * 2;
-    (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 2, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((gemm_nt_256_kernel<false, 2, 4, 4, 1>), grid, block, lds, stream, p);
+    const size_t lds = x3 ? (size_t)2 * 4 * 256 * 32 * 2 : (size_t)4 * 2 * 256 * 32 * 2;
+    if (x3) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm_nt_256x3_kernel<2>), grid, block, lds, stream, p);
+    } else {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 2, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm_nt_256_kernel<false, 2, 4, 4, 1>), grid, block, lds, stream, p);
+    }
     LAUNCH_CHECK();
     hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, stats, tl, nblk, R, lse, row_loss);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(1024), 0, stream, row_loss, R, loss);
     LAUNCH_CHECK();
     if (dlogits) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 3, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((gemm_nt_256_kernel<false, 3, 4, 4, 1>), grid, block, lds, stream, p);
+        if (x3) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_256x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((gemm_nt_256x3_kernel<3>), grid, block, lds, stream, p);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 3, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((gemm_nt_256_kernel<false, 3, 4, 4, 1>), grid, block, lds, stream, p);
+        }
         LAUNCH_CHECK();
     }
     return AMDNUWA_OK;
+}
+
+extern "C" int amdnuwa_linear_ce(const uint16_t* h, int ldh, const uint16_t* w, int ldw, const long long* targets, long long R, int C,
+                                 int K, float grad_scale, float* row_loss, float* loss, uint16_t* dlogits, int ld_dl,
+                                 void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return linear_ce_run(h, nullptr, ldh, w, nullptr, ldw, targets, R, C, K, grad_scale, row_loss, loss, dlogits, ld_dl, workspace,
+                         workspace_bytes, stream);
+}
+
+extern "C" int amdnuwa_linear_ce_x3(const uint16_t* h_hi, const uint16_t* h_lo, int ldh, const uint16_t* w_hi, const uint16_t* w_lo, int ldw,
+                                    const long long* targets, long long R, int C, int K, float grad_scale, float* row_loss, float* loss,
+                                    uint16_t* dlogits, int ld_dl, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!h_lo || !w_lo) return AMDNUWA_ERR_ARG;
+    return linear_ce_run(h_hi, h_lo, ldh, w_hi, w_lo, ldw, targets, R, C, K, grad_scale, row_loss, loss, dlogits, ld_dl, workspace,
+                         workspace_bytes, stream);
 }
 
 extern "C" int amdnuwa_gemm_nt_fused(const amdnuwa_gemm_desc* d) { return d && d->C2 && nt_geglu_fusable(d) ? 1 : 0; }

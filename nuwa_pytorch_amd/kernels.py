@@ -616,15 +616,18 @@ def ce_fwd(logits, targets, grad_scale, want_grad=True, lo=None):
 
 
 def linear_ce(h, w, targets, grad_scale, want_grad=True):
-    """fused to_logits + cross entropy on hi-only BF operands: h [R, K], w [C, K] -> (mean loss, dlogits BF [R, C] or BF(None, None)).
-    The fp32 logits are never written; returns None when the shape is outside what the fused kernels take (C % 64, K % 32)."""
+    """fused to_logits + cross entropy: h [R, K], w [C, K] BF operands -> (mean loss, dlogits BF [R, C] (hi only) or BF(None, None)).
+    hi-only operands run on the bf16 ring; hi + lo pairs (the logits of 'bf16x3-fwd', whose backward takes a bf16 dlogits) on the
+    three-MFMA ring.  The fp32 logits are never written.  Returns None when the fused kernels do not take the call: C % 64, K % 32,
+    one operand with and one without a lo part, or hi + lo operands in the 'bf16x3' mode (its backward wants dlogits as a pair)."""
     L = _lib.lib()
-    if h.lo is not None or w.lo is not None:
+    x3 = h.lo is not None and w.lo is not None
+    if (h.lo is None) != (w.lo is None) or (x3 and not mixed()):
         return None
     R, Kd = h.hi.shape
     Cc = w.hi.shape[0]
     nb = L.amdnuwa_linear_ce_workspace_bytes(R, Cc)
-    if nb == 0 or Kd % 32 or _ld(h.hi) % 8 or _ld(w.hi) % 8:
+    if nb == 0 or Kd % 32 or _ld(h.hi) % 8 or _ld(w.hi) % 8 or (x3 and (_ld(h.lo) != _ld(h.hi) or _ld(w.lo) != _ld(w.hi))):
         return None
     dev = h.hi.device
     ws = workspace(nb, dev)
@@ -633,12 +636,17 @@ def linear_ce(h, w, targets, grad_scale, want_grad=True):
     dl = empty_bf((R, Cc), dev, lo=False) if want_grad else BF(None, None)
     st = _stream()
     if _TIMER['on']:                       # two products: both count as NT GEMM work of the step
-        _TIMER['flops'] += 2.0 * R * Cc * Kd * (2 if want_grad else 1)
-        _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * R * Cc * Kd * (2 if want_grad else 1)
-        _TIMER['bytes'] += (2.0 * (R + Cc) * Kd) * (2 if want_grad else 1) + (2.0 * R * Cc if want_grad else 0.) + 8.0 * R * (Cc // 64)
+        npass = 2 if want_grad else 1
+        _TIMER['flops'] += 2.0 * R * Cc * Kd * npass
+        _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * R * Cc * Kd * npass * (3 if x3 else 1)
+        _TIMER['bytes'] += (2.0 * (R + Cc) * Kd) * npass * (2 if x3 else 1) + (2.0 * R * Cc if want_grad else 0.) + 8.0 * R * (Cc // 64)
         L.amdnuwa_timer_begin(st)
-    check(L.amdnuwa_linear_ce(_p(h.hi), _ld(h.hi), _p(w.hi), _ld(w.hi), _p(targets), R, Cc, Kd, float(grad_scale), _p(row_loss), _p(loss),
-                              _p(dl.hi), Cc, _p(ws), nb, st), 'amdnuwa_linear_ce')
+    if x3:
+        check(L.amdnuwa_linear_ce_x3(_p(h.hi), _p(h.lo), _ld(h.hi), _p(w.hi), _p(w.lo), _ld(w.hi), _p(targets), R, Cc, Kd, float(grad_scale),
+                                     _p(row_loss), _p(loss), _p(dl.hi), Cc, _p(ws), nb, st), 'amdnuwa_linear_ce_x3')
+    else:
+        check(L.amdnuwa_linear_ce(_p(h.hi), _ld(h.hi), _p(w.hi), _ld(w.hi), _p(targets), R, Cc, Kd, float(grad_scale), _p(row_loss), _p(loss),
+                                  _p(dl.hi), Cc, _p(ws), nb, st), 'amdnuwa_linear_ce')
     if _TIMER['on']:
         L.amdnuwa_timer_end(st)
     return loss, dl

@@ -749,7 +749,7 @@ class LogitsLossFn(Function):
         t = targets.contiguous().reshape(-1)            # ids outside [0, C) give a NaN loss (the kernel never reads out of bounds)
         want_grad = any(ctx.needs_input_grad)
         fused = K.linear_ce(hn, W['w'], t, 1.0 / (B * n), want_grad=want_grad) if FUSE_LINEAR_CE else None
-        if fused is not None:                           # fast mode: logits produced twice inside the GEMM, never written (np.py:1958-1963)
+        if fused is not None:                           # 'bf16' and 'bf16x3-fwd': logits produced twice inside the GEMM ring, never written (np.py:1958-1963)
             loss, dl = fused
         else:
             logits = K.gemm_nt(hn, W['w'])

@@ -1009,4 +1009,46 @@ def test_fused_linear_cross_entropy(R, C, Kd):
     bad = t.clone()
     bad[5] = C
     assert torch.isnan(K.linear_ce(hb, wb, bad.to(DEV), 1.0 / R, want_grad=False)[0])
-    assert K.linear_ce(K.BF(h.to(DEV), h.to(DEV)), wb, t.to(DEV), 1.0 / R) is None          # parity-mode operands: unfused path
+    assert K.linear_ce(K.BF(h.to(DEV), h.to(DEV)), wb, t.to(DEV), 1.0 / R) is None          # one pair, one plain operand: unfused path
+
+
+@pytest.mark.parametrize('R,C,Kd', [(1000, 8192, 512), (2560, 512, 256), (300, 192, 64)])
+def test_fused_linear_cross_entropy_hi_lo(R, C, Kd):
+    """the same on the hi + lo ring (amdnuwa_linear_ce_x3: the to_logits of 'bf16x3-fwd', np.py:1958-1963): fp32 operands carried as
+    bf16 pairs, loss / dlogits against torch in fp64 on the fp32 operands and against the unfused pair (x3 gemm_nt + ce_fwd);
+    the all-pairs mode 'bf16x3' (dlogits wanted as a pair) keeps the unfused path"""
+    from nuwa_pytorch_amd import kernels as K
+    g = torch.Generator().manual_seed(R + C + 1)
+    h = torch.randn(R, Kd, generator=g) * 0.8
+    w = torch.randn(C, Kd, generator=g) * (3.0 / Kd ** 0.5)
+    t = torch.randint(0, C, (R,), generator=g)
+    t[0], t[1], t[-1] = 0, C - 1, C - 1
+    logits = h.double() @ w.double().t()
+    ref_loss = torch.nn.functional.cross_entropy(logits, t).float()
+    ref_dl = ((logits.softmax(-1) - torch.nn.functional.one_hot(t, C).double()) / R).float()
+    hb, wb = to_bf_pair(h.to(DEV), True), to_bf_pair(w.to(DEV), True)
+    prev = K.get_precision()
+    try:
+        K.set_precision('bf16x3-fwd')
+        out = K.linear_ce(hb, wb, t.to(DEV), 1.0 / R)
+        assert out is not None
+        loss, dl = out
+        assert dl.lo is None
+        report(f'linear_ce_x3[{R},{C}].loss', loss.reshape(1), ref_loss.reshape(1), 2e-6)
+        report(f'linear_ce_x3[{R},{C}].dlogits', dl.hi.float(), ref_dl, 2 ** -8)
+        lg = K.gemm_nt(hb, wb)
+        report(f'linear_ce_x3[{R},{C}].logits_x3', lg, logits.float(), 2e-5)
+        loss_u, dl_u = K.ce_fwd(lg, t.to(DEV), 1.0 / R, lo=False)
+        report(f'linear_ce_x3[{R},{C}].loss_vs_unfused', loss.reshape(1), loss_u.reshape(1), 2e-6)
+        report(f'linear_ce_x3[{R},{C}].dlogits_vs_unfused', dl.hi.float(), dl_u.hi.float(), 2 ** -7)
+        loss_only, none = K.linear_ce(hb, wb, t.to(DEV), 1.0 / R, want_grad=False)
+        assert none.hi is None and torch.equal(loss_only, loss)
+        again = K.linear_ce(hb, wb, t.to(DEV), 1.0 / R)
+        assert torch.equal(again[0], loss) and torch.equal(again[1].hi, dl.hi)               # fixed order: bit-repeatable
+        bad = t.clone()
+        bad[5] = C
+        assert torch.isnan(K.linear_ce(hb, wb, bad.to(DEV), 1.0 / R, want_grad=False)[0])
+        K.set_precision('bf16x3')
+        assert K.linear_ce(hb, wb, t.to(DEV), 1.0 / R) is None
+    finally:
+        K.set_precision(prev)
