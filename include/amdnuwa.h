@@ -219,11 +219,15 @@ size_t amdnuwa_linear_ce_workspace_bytes(long long R, int C);
 int amdnuwa_linear_ce(const uint16_t* h, int ldh, const uint16_t* w, int ldw, const long long* targets, long long R, int C, int K,
                       float grad_scale, float* row_loss, float* loss, uint16_t* dlogits, int ld_dl, void* workspace,
                       size_t workspace_bytes, amdnuwa_stream stream);
-/* The same with both operands as bf16 hi + lo pairs (three MFMAs per product on the hi + lo ring: the to_logits of the 'bf16x3-fwd'
- * mode, whose logits must stay inside the 1e-3 bound while its backward takes a plain bf16 dlogits).  Same workspace, same outputs. */
-int amdnuwa_linear_ce_x3(const uint16_t* h_hi, const uint16_t* h_lo, int ldh, const uint16_t* w_hi, const uint16_t* w_lo, int ldw,
-                         const long long* targets, long long R, int C, int K, float grad_scale, float* row_loss, float* loss,
-                         uint16_t* dlogits, int ld_dl, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
+/* The same with both operands as bf16 hi + lo pairs: the to_logits of the 'bf16x3-fwd' mode, whose logits (and so the loss) must stay
+ * inside the 1e-3 bound while its backward takes a plain bf16 dlogits.  Pass 1 (statistics, lse, loss) runs three MFMAs per product
+ * on the hi + lo ring.  Pass 2 (dlogits): with h_f16 / w_f16 (fp16 renderings of the same operands, same leading dimensions; both or
+ * neither) ONE fp16 MFMA per product against the exact lse of pass 1 -- the error of an fp16 product sits below the bf16 rounding of
+ * dlogits itself; with both NULL the hi + lo ring again.  Same workspace, same outputs as amdnuwa_linear_ce. */
+int amdnuwa_linear_ce_x3(const uint16_t* h_hi, const uint16_t* h_lo, const uint16_t* h_f16, int ldh, const uint16_t* w_hi,
+                         const uint16_t* w_lo, const uint16_t* w_f16, int ldw, const long long* targets, long long R, int C, int K,
+                         float grad_scale, float* row_loss, float* loss, uint16_t* dlogits, int ld_dl, void* workspace,
+                         size_t workspace_bytes, amdnuwa_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sparse3DNA core (np.py:488-608, incl. the unfoldNd gather np.py:526-534): causal (or symmetric) 3-D nearby

@@ -86,7 +86,7 @@ SIGNATURES = {
     'amdnuwa_scale_by_device_scalar': (I, [P, SZ, P, P]),
     'amdnuwa_linear_ce_workspace_bytes': (SZ, [LL, I]),
     'amdnuwa_linear_ce': (I, [P, I, P, I, P, LL, I, I, F, P, P, P, I, P, SZ, P]),
-    'amdnuwa_linear_ce_x3': (I, [P, P, I, P, P, I, P, LL, I, I, F, P, P, P, I, P, SZ, P]),
+    'amdnuwa_linear_ce_x3': (I, [P, P, P, I, P, P, P, I, P, LL, I, I, F, P, P, P, I, P, SZ, P]),
     'amdnuwa_s3_supported': (I, [SG, I]),
     'amdnuwa_sparse3dna_fwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P]),
     'amdnuwa_s3_f16_supported': (I, [SG]),

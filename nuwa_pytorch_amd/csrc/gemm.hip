@@ -2043,9 +2043,11 @@ extern "C" size_t amdnuwa_linear_ce_workspace_bytes(long long R, int C) {
     return (size_t)R * (C / 64) * 2 * sizeof(float) + (size_t)R * 2 * sizeof(float);
 }
 
-// h_lo / w_lo != NULL: both products on the hi + lo ring (three MFMAs per product: the logits of the 'bf16x3' modes)
-static int linear_ce_run(const uint16_t* h, const uint16_t* h_lo, int ldh, const uint16_t* w, const uint16_t* w_lo, int ldw,
-                         const long long* targets, long long R, int C, int K, float grad_scale, float* row_loss, float* loss,
+// h_lo / w_lo != NULL: the statistics pass on the hi + lo ring (three MFMAs per product: the logits of the 'bf16x3' modes); its
+// dlogits pass too, unless fp16 copies of both operands are given (h16 / w16): then dlogits -- a bf16 tensor for a bf16 backward --
+// come from ONE fp16 MFMA per product against the exact lse of pass 1
+static int linear_ce_run(const uint16_t* h, const uint16_t* h_lo, const uint16_t* h16, int ldh, const uint16_t* w, const uint16_t* w_lo,
+                         const uint16_t* w16, int ldw, const long long* targets, long long R, int C, int K, float grad_scale, float* row_loss, float* loss,
                          uint16_t* dlogits, int ld_dl, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!h || !w || !targets || !row_loss || !loss) return AMDNUWA_ERR_ARG;
     if (C % 64 || K % 32 || ldh % 8 || ldw % 8 || (dlogits && ld_dl % 8) || R > 0x7fffffffLL) return AMDNUWA_ERR_UNSUPPORTED;
@@ -2080,7 +2082,12 @@ static int linear_ce_run(const uint16_t* h, const uint16_t* h_lo, int ldh, const
     hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(1024), 0, stream, row_loss, R, loss);
     LAUNCH_CHECK();
     if (dlogits) {
-        if (x3) {
+        if (x3 && h16 && w16) {
+            p.A = (const bf16_t*)h16; p.B = (const bf16_t*)w16; p.Alo = nullptr; p.Blo = nullptr;
+            const size_t l16 = (size_t)4 * 2 * 256 * 32 * 2;
+            (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 3, 4, 4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16);
+            hipLaunchKernelGGL((gemm_nt_256_kernel<false, 3, 4, 4, 1, true>), grid, block, l16, stream, p);
+        } else if (x3) {
             (void)hipFuncSetAttribute((const void*)gemm_nt_256x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((gemm_nt_256x3_kernel<3>), grid, block, lds, stream, p);
         } else {
@@ -2095,15 +2102,16 @@ static int linear_ce_run(const uint16_t* h, const uint16_t* h_lo, int ldh, const
 extern "C" int amdnuwa_linear_ce(const uint16_t* h, int ldh, const uint16_t* w, int ldw, const long long* targets, long long R, int C,
                                  int K, float grad_scale, float* row_loss, float* loss, uint16_t* dlogits, int ld_dl,
                                  void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    return linear_ce_run(h, nullptr, ldh, w, nullptr, ldw, targets, R, C, K, grad_scale, row_loss, loss, dlogits, ld_dl, workspace,
-                         workspace_bytes, stream);
+    return linear_ce_run(h, nullptr, nullptr, ldh, w, nullptr, nullptr, ldw, targets, R, C, K, grad_scale, row_loss, loss, dlogits, ld_dl,
+                         workspace, workspace_bytes, stream);
 }
 
-extern "C" int amdnuwa_linear_ce_x3(const uint16_t* h_hi, const uint16_t* h_lo, int ldh, const uint16_t* w_hi, const uint16_t* w_lo, int ldw,
-                                    const long long* targets, long long R, int C, int K, float grad_scale, float* row_loss, float* loss,
-                                    uint16_t* dlogits, int ld_dl, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (!h_lo || !w_lo) return AMDNUWA_ERR_ARG;
-    return linear_ce_run(h_hi, h_lo, ldh, w_hi, w_lo, ldw, targets, R, C, K, grad_scale, row_loss, loss, dlogits, ld_dl, workspace,
+extern "C" int amdnuwa_linear_ce_x3(const uint16_t* h_hi, const uint16_t* h_lo, const uint16_t* h_f16, int ldh, const uint16_t* w_hi,
+                                    const uint16_t* w_lo, const uint16_t* w_f16, int ldw, const long long* targets, long long R, int C, int K,
+                                    float grad_scale, float* row_loss, float* loss, uint16_t* dlogits, int ld_dl, void* workspace,
+                                    size_t workspace_bytes, hipStream_t stream) {
+    if (!h_lo || !w_lo || ((h_f16 != nullptr) != (w_f16 != nullptr))) return AMDNUWA_ERR_ARG;
+    return linear_ce_run(h_hi, h_lo, h_f16, ldh, w_hi, w_lo, w_f16, ldw, targets, R, C, K, grad_scale, row_loss, loss, dlogits, ld_dl, workspace,
                          workspace_bytes, stream);
 }
 

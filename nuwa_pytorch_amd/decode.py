@@ -27,7 +27,7 @@ class _Block:
     """one sub-block of a row program: out_slot <- out_slot + post(inner(pre(in_slot)));  pre / post = None for the un-normed modules
     of the reversible dual decoder's cross-modality layer"""
     __slots__ = ('kind', 'pre', 'post', 'inner', 'fmap', 'hcache', 'kvcache', 'geom', 'pk', 'xg', 'o_const', 'xm', 'src', 'dst',
-                 'store_before', 'store_after')
+                 'store_before', 'store_after', 'c2')
 
 
 def _cast_row(x, lo):
@@ -48,7 +48,7 @@ class IncrementalDecoder:
     reversible dual decoder)."""
 
     def __init__(self, transformer, batch, max_rows, context, context_mask, pos_dev, block_list=None, halves=1, combine=0.5):
-        from .nuwa_pytorch import Attention, FeedForward, Sparse3DNA, SandwichNorm
+        from .nuwa_pytorch import Attention, FeedForward, Sparse3DNA, SandwichNorm, SparseCross2DNA
         from .video_audio import SparseCausal2DNA
         dev = context.device
         if block_list is None and hasattr(transformer, 'net'):         # ReversibleTransformer (np.py:1184-1295): (f, g) pairs, y1 = x1 +
@@ -72,7 +72,7 @@ class IncrementalDecoder:
         for spec in block_list:
             mod, ctx_arg = spec['mod'], spec.get('context')
             blk = _Block()
-            blk.kvcache = blk.geom = blk.pk = blk.xg = blk.o_const = blk.hcache = blk.fmap = None
+            blk.kvcache = blk.geom = blk.pk = blk.xg = blk.o_const = blk.hcache = blk.fmap = blk.c2 = None
             blk.xm = spec.get('xm')
             blk.dst = spec.get('dst', 0)
             blk.src = (1 - blk.dst) if halves == 2 else 0
@@ -121,11 +121,15 @@ class IncrementalDecoder:
                 if all_masked:
                     q0 = K.zeros_bf((batch, inner.heads * inner.dim_head), dev, lo=lo)
                     blk.o_const = K.xattn_decode(blk.xg, q0, blk.pk, p[2].detach().reshape(inner.heads, inner.heads).contiguous())
+            elif isinstance(inner, SparseCross2DNA):
+                blk.kind = 'xc2'
+                blk.c2 = _Cross2DNARows(inner, batch, ctx_bf, mask_u8, all_masked, lo)
             elif isinstance(inner, FeedForward):
                 blk.kind = 'ff'
             else:
                 raise NotImplementedError(f'IncrementalDecoder: no single-row path for {type(inner).__name__}')
             self.blocks.append(blk)
+        self.bos_row_differs = any(b.kind == 'xc2' for b in self.blocks)       # row 0 takes another code path: not one graph for all rows
 
     def _enter(self, x, nxt):
         """the operand row of block `nxt` from its fp32 input row: pre-norm (+ token shift through the block's cache), or a plain
@@ -136,8 +140,10 @@ class IncrementalDecoder:
             return _cast_row(x, self.lo)
         return K.decode_ln(x, None, None, nxt.pre, cache=nxt.hcache, pos_dev=self.pos_dev, fmap=nxt.fmap or 0)[1]
 
-    def step(self, x):
-        """x fp32 [B, D]: decoder input row `pos` of every sample -> that row after all layers (before the final norm)"""
+    def step(self, x, bos=False):
+        """x fp32 [B, D]: decoder input row `pos` of every sample -> that row after all layers (before the final norm).
+        bos: this is row 0 (only a SparseCross2DNA block cares: its <bos> query attends to the whole context; the position itself
+        lives in device memory and is not read on the host)"""
         fast = ops._fast()
         blocks = self.blocks
         state = [x] * self.halves
@@ -168,6 +174,10 @@ class IncrementalDecoder:
                     q = K.gemm_nt(h, W['q'], out_bf16=True)
                     o = K.xattn_decode(g, q, blk.pk, wth)
                 y = K.gemm_nt(o, W['out'], out_bf16=fast and not raw)
+            elif blk.kind == 'xc2':
+                W = ops.XInner.weights(inner._cache, inner._params())
+                o = blk.c2.attend(h, W, self.pos_dev, bos)
+                y = K.gemm_nt(o, W['out'], out_bf16=fast and not raw)
             else:
                 W = ops.FFInner.weights(inner._cache, inner._params())
                 u = K.gemm_nt(h, W['w1'], out_bf16=True)
@@ -188,6 +198,73 @@ class IncrementalDecoder:
             for d in blk.store_after:
                 d.store(x)
         return x if self.halves == 1 else (state[0] + state[1]) * self.combine
+
+
+class _Cross2DNARows:
+    """SparseCross2DNA (np.py:761-901) for one new query row per sample (NUWASketch.generate, np.py:2440-2512).  The block is row-wise:
+    query row pos (> 0) sits at feature-map position i = (pos - 1) mod fmap^2 and attends to the learned null key + the kernel^2
+    neighbourhood of i in EVERY sketch frame.  to_kv(context) is computed once; per row the window's key / value rows are gathered
+    (index tables on the device, indexed by the device-side position, so the step stays capturable in a HIP graph), packed with
+    amdnuwa_xattn_pack (padding slots and masked sketch tokens through its key mask) and attended with the single-query
+    cross-attention kernel (fp32 softmax, talking heads).  Row 0 (<bos>) attends to ALL context tokens without talking heads
+    (np.py:826-849): B rows of glue arithmetic, as in the training path (ops.XC2Inner).  With every context token masked (the
+    second pass of classifier-free guidance) both outputs are constants, computed once."""
+
+    def __init__(self, mod, batch, ctx_bf, mask_u8, all_masked, lo):
+        dev = ctx_bf.hi.device
+        self.mod, self.B, self.lo = mod, batch, lo
+        h, dh = mod.heads, mod.dim_head
+        self.inner = h * dh
+        tpf = self.tpf = mod.image_size ** 2
+        T = ctx_bf.hi.shape[0] // batch
+        if T % tpf:
+            raise NotImplementedError('cached decoding: the sketch context is not a whole number of frames')
+        fs = T // tpf
+        nbr = mod._nbr.to(dev)                                               # (tpf, k^2) in-frame neighbours, -1 = padding
+        idx = torch.cat([torch.where(nbr >= 0, nbr + a * tpf, torch.zeros_like(nbr)) for a in range(fs)], dim=1)
+        self.win_idx = idx.contiguous()                                      # (tpf, fs * k^2) context rows of every window slot
+        self.win_ok = (nbr >= 0).repeat(1, fs).to(torch.uint8).contiguous()  # 0 = the slot is 'same' padding
+        J = self.win_idx.shape[1]
+        self.xg = K.x_geom(batch, 1, J, h, dh)
+        if self.xg.JP > 288:
+            raise NotImplementedError('cached decoding: SparseCross2DNA window too large for the single-query kernel')
+        p = mod._params()
+        self.nk, self.nv = p[0].detach().reshape(h, dh).contiguous(), p[1].detach().reshape(h, dh).contiguous()
+        self.wth = p[2].detach().reshape(h, h).contiguous()
+        self.mask_u8 = mask_u8 if mask_u8 is not None else torch.ones((batch, T), dtype=torch.uint8, device=dev)
+        self.o_const = self.o_bos = self.kv = None
+        if all_masked:
+            kv0 = K.zeros_bf((batch * J, 2 * self.inner), dev, lo=lo)
+            pk = K.xattn_pack(self.xg, kv0, self.nk, self.nv, torch.zeros((batch, J), dtype=torch.uint8, device=dev))
+            self.o_const = K.xattn_decode(self.xg, K.zeros_bf((batch, self.inner), dev, lo=lo), pk, self.wth)
+            self.o_bos = ops._to_bf(self.nv.float().reshape(1, self.inner).expand(batch, -1).contiguous())      # softmax over the null key alone
+        else:
+            W = ops.XInner.weights(mod._cache, p)
+            kv = K.gemm_nt(ctx_bf, W['kv'], out_bf16=True)                   # sketch keys / values: once per sequence
+            self.kv = K.BF(kv.hi.reshape(batch, T, 2 * self.inner), None if kv.lo is None else kv.lo.reshape(batch, T, 2 * self.inner))
+
+    def attend(self, h, W, pos_dev, bos):
+        """h BF [B, D] (pre-normed operand row) -> o BF [B, inner]"""
+        if self.o_const is not None:
+            return self.o_bos if bos else self.o_const
+        q = K.gemm_nt(h, W['q'], out_bf16=True)
+        B, inner, mod = self.B, self.inner, self.mod
+        hd, dh = mod.heads, mod.dim_head
+        if bos:
+            q0 = ops._bf_val(q).reshape(B, hd, dh)
+            kvf = ops._bf_val(self.kv).reshape(B, -1, 2, hd, dh)
+            P0 = ops.XC2Inner._bos_scores(q0, kvf[:, :, 0], self.nk.float(), self.mask_u8.bool(), mod.scale)
+            o0 = P0[..., :1] * self.nv.float()[None] + torch.einsum('bht,bthd->bhd', P0[..., 1:], kvf[:, :, 1])
+            o = ops._to_bf(o0.reshape(B, inner).contiguous())
+            return o if self.lo else K.BF(o.hi, None)
+        i = torch.remainder(pos_dev.long() - 1, self.tpf)                    # device-side feature-map position of this row
+        idx = self.win_idx.index_select(0, i)[0]
+        J = idx.shape[0]
+        kvw = K.BF(self.kv.hi.index_select(1, idx).reshape(B * J, 2 * inner),
+                   None if self.kv.lo is None else self.kv.lo.index_select(1, idx).reshape(B * J, 2 * inner))
+        m = (self.mask_u8.index_select(1, idx) * self.win_ok.index_select(0, i)).contiguous()
+        pk = K.xattn_pack(self.xg, kvw, self.nk, self.nv, m)
+        return K.xattn_decode(self.xg, q, pk, self.wth)
 
 
 class _XmDirection:
@@ -339,7 +416,7 @@ class DualGuidedStepper:
 
 
 class GuidedStepper:
-    """The per-token work of NUWA.generate: conditioned pass -> logits; if cond_scale != 1 the reference feeds the final-normed
+    """The per-token work of NUWA.generate (and NUWASketch.generate, np.py:2440-2512: same decoder, sketch context): conditioned pass -> logits; if cond_scale != 1 the reference feeds the final-normed
     conditioned OUTPUT row into a second, text-masked pass (np.py:1894-1898) and mixes the two logits.  One call = one new row.
     graph=True captures the step in a HIP graph after a warm-up call (static input / output buffers, device-side position)."""
 
@@ -359,13 +436,13 @@ class GuidedStepper:
         self._want_graph = graph
         self._calls = 0
 
-    def _body(self):
+    def _body(self, bos=False):
         nuwa = self.nuwa
-        hidden = self.cond.step(self.x_in)
+        hidden = self.cond.step(self.x_in, bos)
         logits = nuwa._final(hidden[:, None])[:, 0]
         if self.uncond is not None:
             cond_out = nuwa.video_transformer.norm(hidden[:, None])[:, 0].contiguous()
-            uh = self.uncond.step(cond_out)
+            uh = self.uncond.step(cond_out, bos)
             ul = nuwa._final(uh[:, None])[:, 0]
             logits = ul + (logits - ul) * self.cond_scale
         self.pos_dev += 1
@@ -374,6 +451,10 @@ class GuidedStepper:
     def __call__(self, x_row):
         """x_row fp32 [B, D] = decoder input row at the current position -> logits [B, C] for the next token"""
         self.x_in.copy_(x_row)
+        first = self._calls == 0
+        self._calls += 1
+        if first and self.cond.bos_row_differs:        # NUWASketch: the <bos> row of a SparseCross2DNA block is its own program --
+            return self._body(True)                    # launched eagerly; the graph is captured at row 1 and serves every later row
         if not self._want_graph:
             return self._body()
         if self.graph is None:

@@ -615,11 +615,13 @@ def ce_fwd(logits, targets, grad_scale, want_grad=True, lo=None):
     return loss, dl
 
 
-def linear_ce(h, w, targets, grad_scale, want_grad=True):
+def linear_ce(h, w, targets, grad_scale, want_grad=True, w16=None):
     """fused to_logits + cross entropy: h [R, K], w [C, K] BF operands -> (mean loss, dlogits BF [R, C] (hi only) or BF(None, None)).
     hi-only operands run on the bf16 ring; hi + lo pairs (the logits of 'bf16x3-fwd', whose backward takes a bf16 dlogits) on the
-    three-MFMA ring.  The fp32 logits are never written.  Returns None when the fused kernels do not take the call: C % 64, K % 32,
-    one operand with and one without a lo part, or hi + lo operands in the 'bf16x3' mode (its backward wants dlogits as a pair)."""
+    three-MFMA ring for the statistics / loss pass and -- when w16, an fp16 copy of w, is given -- on ONE fp16 MFMA per product for the
+    dlogits pass (h's fp16 copy is made here).  The fp32 logits are never written.  Returns None when the fused kernels do not take the
+    call: C % 64, K % 32, one operand with and one without a lo part, or hi + lo operands in the 'bf16x3' mode (its backward wants
+    dlogits as a pair)."""
     L = _lib.lib()
     x3 = h.lo is not None and w.lo is not None
     if (h.lo is None) != (w.lo is None) or (x3 and not mixed()):
@@ -634,16 +636,22 @@ def linear_ce(h, w, targets, grad_scale, want_grad=True):
     row_loss = torch.empty(R, dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
     dl = empty_bf((R, Cc), dev, lo=False) if want_grad else BF(None, None)
+    p2_f16 = x3 and want_grad and w16 is not None and _ld(w16) == _ld(w.hi)
+    h16 = hilo_to_f16(h) if p2_f16 else None
+    if p2_f16 and _ld(h16) != _ld(h.hi):
+        p2_f16, h16 = False, None
     st = _stream()
     if _TIMER['on']:                       # two products: both count as NT GEMM work of the step
         npass = 2 if want_grad else 1
+        issued = (3 if x3 else 1) + ((1 if p2_f16 else 3 if x3 else 1) if want_grad else 0)
         _TIMER['flops'] += 2.0 * R * Cc * Kd * npass
-        _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * R * Cc * Kd * npass * (3 if x3 else 1)
-        _TIMER['bytes'] += (2.0 * (R + Cc) * Kd) * npass * (2 if x3 else 1) + (2.0 * R * Cc if want_grad else 0.) + 8.0 * R * (Cc // 64)
+        _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * R * Cc * Kd * issued
+        _TIMER['bytes'] += (2.0 * (R + Cc) * Kd) * issued + (2.0 * R * Cc if want_grad else 0.) + 8.0 * R * (Cc // 64)
         L.amdnuwa_timer_begin(st)
     if x3:
-        check(L.amdnuwa_linear_ce_x3(_p(h.hi), _p(h.lo), _ld(h.hi), _p(w.hi), _p(w.lo), _ld(w.hi), _p(targets), R, Cc, Kd, float(grad_scale),
-                                     _p(row_loss), _p(loss), _p(dl.hi), Cc, _p(ws), nb, st), 'amdnuwa_linear_ce_x3')
+        check(L.amdnuwa_linear_ce_x3(_p(h.hi), _p(h.lo), _p(h16), _ld(h.hi), _p(w.hi), _p(w.lo), _p(w16) if p2_f16 else None, _ld(w.hi),
+                                     _p(targets), R, Cc, Kd, float(grad_scale), _p(row_loss), _p(loss), _p(dl.hi), Cc, _p(ws), nb, st),
+              'amdnuwa_linear_ce_x3')
     else:
         check(L.amdnuwa_linear_ce(_p(h.hi), _ld(h.hi), _p(w.hi), _ld(w.hi), _p(targets), R, Cc, Kd, float(grad_scale), _p(row_loss), _p(loss),
                                   _p(dl.hi), Cc, _p(ws), nb, st), 'amdnuwa_linear_ce')

@@ -1086,6 +1086,8 @@ class NUWA(nn.Module):
         frame_embeddings = self.embed_video(frame_indices_input)
         if self.training and cond_dropout_prob > 0:
             text_mask = text_mask & ~bernoulli_rows(batch, cond_dropout_prob, device)[:, None]
+        if return_loss and frame_embeddings.is_cuda and K.mixed():
+            ops.f16_prefetch_also(self.to_logits.weight)       # judged with the stack's weights: one device -> host transfer per step
         hidden = self.decode_hidden(frame_embeddings, text_embeds, text_mask)
         if not return_loss:
             return self._final(hidden)
@@ -1095,8 +1097,8 @@ class NUWA(nn.Module):
 class NUWASketch(nn.Module):
     """np.py:2297-2571 (row f4): identical constructor kwargs, forward() and generate() signatures.  The video decoder is the
     same 3DNA stack as NUWA's (libamdnuwa kernels for Sparse3DNA, FeedForward, the norms, logits + loss); its cross-attention
-    is SparseCross2DNA over the sketch tokens and the sketch encoder is a plain (or, optionally, non-causal 3DNA) Transformer,
-    both on PyTorch-ROCm ops for now."""
+    is SparseCross2DNA over the sketch tokens (amdnuwa_cross2dna_* in training, the single-query kernels in the cached generate())
+    and the sketch encoder is a plain (or, optionally, non-causal 3DNA) Transformer."""
 
     def __init__(self, *, vae, sketch_vae, dim, image_size, max_video_frames=5, sketch_max_video_frames=2, sketch_enc_depth=6,
                  sketch_enc_dim_head=64, sketch_enc_heads=8, sketch_enc_use_sparse_3dna=False, enc_reversible=False, dec_depth=6,
@@ -1139,6 +1141,8 @@ class NUWASketch(nn.Module):
         self.to_logits = nn.Linear(dim, vae.codebook_size, bias=False)
         self._cache = ops.WeightCache()
 
+    generate_use_cache = True               # key/value-cached generate() (decode.py); False = the reference's recompute loop
+    generate_use_graph = True               # replay each token's decoder work (rows >= 1) as one captured HIP graph
     embed_video = NUWA.embed_video          # <bos> + positional + token embedding, one libamdnuwa node
     _final = NUWA._final                    # final StableLayerNorm + logits (+ cross entropy), fused
     _guided_last_logits = NUWA._guided_last_logits
@@ -1165,17 +1169,36 @@ class NUWASketch(nn.Module):
     @eval_decorator
     def generate(self, *, sketch, sketch_mask=None, filter_thres=0.9, temperature=1., decode_max_batchsize=10, cond_scale=2.,
                  num_frames=None):
-        """np.py:2438-2511: token by token with the whole prefix recomputed (and, for guidance, the normed conditioned output fed
-        to a sketch-masked second pass), as the reference does"""
+        """np.py:2438-2511.  The reference recomputes the whole prefix per token (and, for guidance, feeds the normed conditioned
+        output to a sketch-masked second pass).  Every decoder stage is row-causal or row-wise -- SparseCross2DNA looks at the sketch
+        only -- so each token costs one new decoder row against per-layer caches (decode.GuidedStepper, as NUWA.generate) whenever the
+        sequence fits the video shape and every block has a single-row path; otherwise the recompute algorithm runs on the same kernels."""
         if sketch.ndim == 4:
             sketch = sketch[:, None]
         batch, device = sketch.shape[0], sketch.device
         sketch_embeds, context_mask = self.embed_sketch(sketch, mask=sketch_mask)
         tpf = self.video_fmap_size ** 2
+        total = tpf * default(num_frames, self.max_video_frames)
         ids = torch.empty((batch, 0), device=device, dtype=torch.long)
-        for _ in range(tpf * default(num_frames, self.max_video_frames)):
-            logits = self._guided_last_logits(lookback_window(ids, tpf, self.max_video_frames), sketch_embeds, context_mask, cond_scale)
-            ids = torch.cat((ids, sample_top_fraction(logits, filter_thres, temperature)[:, None]), dim=1)
+        cached = self.generate_use_cache and sketch.is_cuda and total <= tpf * self.max_video_frames
+        if cached:
+            from .decode import GuidedStepper
+            try:
+                stepper = GuidedStepper(self, sketch_embeds, context_mask, total, cond_scale, graph=self.generate_use_graph)
+            except NotImplementedError:
+                cached = False
+        if cached:
+            pos_table = self.video_pos_emb()
+            row = self.video_bos[None].expand(batch, -1)
+        for t in range(total):
+            if cached:
+                logits = stepper(row)
+            else:
+                logits = self._guided_last_logits(lookback_window(ids, tpf, self.max_video_frames), sketch_embeds, context_mask, cond_scale)
+            token = sample_top_fraction(logits, filter_thres, temperature)
+            ids = torch.cat((ids, token[:, None]), dim=1)
+            if cached:
+                row = self.image_embedding(token) + pos_table[t]
         self.last_generated_ids = ids
         return self._ids_to_frames(ids, decode_max_batchsize)
 

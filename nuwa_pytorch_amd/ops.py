@@ -83,8 +83,19 @@ F16_WMIN = 2.0 ** -10
 _F16_RANGE = {}
 
 
+_F16_ALSO = []
+
+
+def f16_prefetch_also(*ws):
+    """weights to be judged together with the next f16_ranges_prefetch() call (no transfer of their own): NUWA.forward registers
+    to_logits.weight here before the decoder stack runs"""
+    _F16_ALSO.extend(ws)
+
+
 def f16_ranges_prefetch(ws):
     todo, seen = [], set()
+    ws = list(ws) + _F16_ALSO
+    del _F16_ALSO[:]
     for w in ws:
         k = (w.data_ptr(), w._version)
         if k not in _F16_RANGE and k not in seen and w.is_cuda:
@@ -741,6 +752,8 @@ class LogitsLossFn(Function):
         B, n, D = x.shape
         x2 = x.detach().contiguous().reshape(B * n, D)
         W = cache.get('logits', (wl,), lambda: dict(w=_cast(wl), wT=_cast_t(wl)))
+        if K.mixed() and 'w16' not in W:       # fp16 copy for the dlogits pass of the fused cross entropy (None: outside the fp16 range)
+            W['w16'] = wl.detach().to(torch.float16).contiguous() if f16_weights_ok(wl) else None
         hn, m, r, ia = K.ln_fwd(x2, nw.detach(), nb.detach(), stable=True)
         if targets.dtype != torch.int64:
             raise TypeError(f'cross-entropy targets must be int64 token ids, got {targets.dtype}')
@@ -748,7 +761,7 @@ class LogitsLossFn(Function):
             raise ValueError(f'{targets.numel()} targets for {B * n} logit rows')
         t = targets.contiguous().reshape(-1)            # ids outside [0, C) give a NaN loss (the kernel never reads out of bounds)
         want_grad = any(ctx.needs_input_grad)
-        fused = K.linear_ce(hn, W['w'], t, 1.0 / (B * n), want_grad=want_grad) if FUSE_LINEAR_CE else None
+        fused = K.linear_ce(hn, W['w'], t, 1.0 / (B * n), want_grad=want_grad, w16=W.get('w16')) if FUSE_LINEAR_CE else None
         if fused is not None:                           # 'bf16' and 'bf16x3-fwd': logits produced twice inside the GEMM ring, never written (np.py:1958-1963)
             loss, dl = fused
         else:

@@ -403,9 +403,12 @@ def test_generate_reproduces_the_reference_token_ids(A, name, cached):
         assert torch.equal(out[1].cpu(), Ar['audio_ids'].long())
 
 
-def test_sketch_generate_reproduces_the_reference_token_ids(A):
+@pytest.mark.parametrize('mode', ['recompute', 'cached', 'cached+graph'])
+def test_sketch_generate_reproduces_the_reference_token_ids(A, mode):
     """fixture g13e: the token ids the reference's NUWASketch.generate (np.py:2438-2511) samples (greedy, guided) for a tiny model with
-    recorded parameters; the sketch token ids of the reference's randomly initialised sketch VAE are part of the fixture"""
+    recorded parameters; the sketch token ids of the reference's randomly initialised sketch VAE are part of the fixture.  Reproduced by
+    the reference's recompute algorithm and by the row-at-a-time decoder (SparseCross2DNA rows through decode._Cross2DNARows), eager and
+    as a captured HIP graph"""
     from test_gpu_modules import SKETCH_KW
     Ar, P, _ = load('g13e_generate_sketch')
     vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
@@ -418,9 +421,48 @@ def test_sketch_generate_reproduces_the_reference_token_ids(A):
     m.sketch_vae.get_video_indices = lambda frames: sketch_ids
     A.set_precision('bf16x3')
     try:
+        type(m).generate_use_cache, type(m).generate_use_graph = mode != 'recompute', mode == 'cached+graph'
         torch.manual_seed(0)
         frames = m.generate(sketch=Ar['sketch'].to(DEV), filter_thres=0.99, cond_scale=float(Ar['cond_scale']), num_frames=2)
     finally:
+        type(m).generate_use_cache = type(m).generate_use_graph = True
         A.set_precision('bf16')
     assert frames.shape == (2, 2, 3, 16, 16)
     assert torch.equal(m.last_generated_ids.cpu(), Ar['video_ids'].long()), (m.last_generated_ids.cpu(), Ar['video_ids'])
+
+
+@pytest.mark.parametrize('cond_scale', [1., 2.5])
+def test_sketch_cached_rows_match_the_recomputed_prefix(A, cond_scale):
+    """NUWASketch decoding row by row (decode.GuidedStepper over a decoder with SparseCross2DNA blocks; a sketch mask that hides the
+    last sketch frame of one sample) against the logits of the whole recomputed prefix (`_guided_last_logits`, the reference's
+    algorithm on the training kernels) at every position of 1.5 frames -- <bos> row, frame border and padding windows included"""
+    from test_gpu_modules import SKETCH_KW
+    from nuwa_pytorch_amd.decode import GuidedStepper
+    torch.manual_seed(21)
+    vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=64, vq_codebook_dim=32, use_vgg_and_gan=False)
+    sketch_vae = A.VQGanVAE(dim=32, image_size=16, num_layers=2, vq_codebook_size=48, vq_codebook_dim=32, use_vgg_and_gan=False)
+    m = A.NUWASketch(vae=vae, sketch_vae=sketch_vae, **SKETCH_KW).to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    sketch = torch.rand(2, 2, 3, 16, 16, generator=g).to(DEV)
+    smask = torch.tensor([[True, True], [True, False]], device=DEV)
+    tpf, total = 16, 24
+    ids = torch.randint(0, 64, (2, total), generator=g).to(DEV)
+    A.set_precision('bf16x3')
+    try:
+        with torch.no_grad():
+            ctx, cmask = m.embed_sketch(sketch, mask=smask)
+            st = GuidedStepper(m, ctx, cmask, total, cond_scale, graph=False)
+            assert sum(b.kind == 'xc2' for b in st.cond.blocks) == SKETCH_KW['dec_depth'] and st.cond.bos_row_differs
+            pos_table = m.video_pos_emb()
+            row = m.video_bos[None].expand(2, -1)
+            worst = 0.
+            for t in range(total):
+                got = st(row)
+                ref = m._guided_last_logits(ids[:, :t], ctx, cmask, cond_scale)
+                worst = max(worst, float((got - ref).abs().max() / ref.abs().max()))
+                row = m.image_embedding(ids[:, t]) + pos_table[t]
+    finally:
+        A.set_precision('bf16')
+    from gpu_util import record
+    record(f'sketch_cached_rows[cond_scale={cond_scale}].logits', worst, worst, 1e-3)
+    assert worst < 1e-3, worst

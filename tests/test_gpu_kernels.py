@@ -1045,6 +1045,11 @@ def test_fused_linear_cross_entropy_hi_lo(R, C, Kd):
         assert none.hi is None and torch.equal(loss_only, loss)
         again = K.linear_ce(hb, wb, t.to(DEV), 1.0 / R)
         assert torch.equal(again[0], loss) and torch.equal(again[1].hi, dl.hi)               # fixed order: bit-repeatable
+        # the dlogits pass on ONE fp16 MFMA per product (what 'bf16x3-fwd' trains with): same loss bit for bit (pass 1 is unchanged),
+        # dlogits inside the same bound against fp64
+        loss16, dl16 = K.linear_ce(hb, wb, t.to(DEV), 1.0 / R, w16=w.to(DEV).half().contiguous())
+        assert torch.equal(loss16, loss)
+        report(f'linear_ce_x3[{R},{C}].dlogits_f16_pass', dl16.hi.float(), ref_dl, 2 ** -8)
         bad = t.clone()
         bad[5] = C
         assert torch.isnan(K.linear_ce(hb, wb, bad.to(DEV), 1.0 / R, want_grad=False)[0])

@@ -206,6 +206,13 @@ POLICIES = {
     'f16_act_exact_w': Policy('f16', all_w='f32', all_y='f32', all_u='f32'),
     # ... and with the FeedForward / qkv weights back in fp16 but u / y exact (= cur_2mfma_all spelled from the other side)
     'f16_act_w16_ffqkv': Policy('f16', all_w='f32', all_y='f32', all_u='f32', ff_w='f16', s3_w='f16'),
+    # decomposition of 'cur' by what is rounded (which part of the 6.8e-4 is whose)
+    'cur_only_cores': Policy('f32', s3_a='f16', s3_p='f16', x_a='f16', x_p='f16'),
+    'cur_only_ff': Policy('f32', ff_h='f16', ff_w='f16', ff_o='f16'),
+    'cur_only_ff_w': Policy('f32', ff_w='f16'),
+    'cur_only_ff_act': Policy('f32', ff_h='f16', ff_o='f16'),
+    'cur_only_qkv': Policy('f32', s3_h='f16', s3_w='f16'),
+    'cur_only_qkv_w': Policy('f32', s3_w='f16'),
     # bf16 with the final GEMM exact / the y stores in fp32
     'bf16_y32': Policy('bf16', all_y='f32'),
     'bf16_lg_exact': Policy('bf16', lg_all='f32'),
