@@ -1086,7 +1086,7 @@ class NUWA(nn.Module):
         frame_embeddings = self.embed_video(frame_indices_input)
         if self.training and cond_dropout_prob > 0:
             text_mask = text_mask & ~bernoulli_rows(batch, cond_dropout_prob, device)[:, None]
-        if return_loss and frame_embeddings.is_cuda and K.mixed():
+        if return_loss and frame_embeddings.is_cuda and K.mixed() and ops.FUSE_LINEAR_CE_X3:
             ops.f16_prefetch_also(self.to_logits.weight)       # judged with the stack's weights: one device -> host transfer per step
         hidden = self.decode_hidden(frame_embeddings, text_embeds, text_mask)
         if not return_loss:

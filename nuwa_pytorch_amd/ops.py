@@ -487,6 +487,10 @@ class XC2Inner:
 INNERS = {'s3': S3Inner, 'xattn': XInner, 'ff': FFInner, 'xc2': XC2Inner}
 
 FUSE_LINEAR_CE = os.environ.get('AMDNUWA_FUSE_LINEAR_CE', '1') != '0'   # to_logits + cross entropy without the fp32 logits (A/B switch)
+# ... in 'bf16x3-fwd' (hi + lo logits): OFF by default.  The fused form needs the three-MFMA product twice (statistics, then dlogits -- the
+# latter on one fp16 MFMA) where the unfused one writes the fp32 logits once and reads them once: measured 532.5-534.1 against 530.2-530.7 ms
+# per step at b = 128, for 9 GB less peak memory (243 -> 234 GB).  Set AMDNUWA_FUSE_LINEAR_CE_X3=1 when the memory matters more.
+FUSE_LINEAR_CE_X3 = os.environ.get('AMDNUWA_FUSE_LINEAR_CE_X3', '0') == '1'
 FUSE_GEGLU_BWD = os.environ.get('AMDNUWA_FUSE_GEGLU_BWD', '1') != '0'   # gate backward inside the dgg GEMM epilogue (A/B switch)
 CHAIN_BWD = os.environ.get('AMDNUWA_CHAIN_BWD', '1') != '0'      # chain the LayerNorm backwards across block boundaries (A/B switch)
 def _fast():
@@ -752,7 +756,7 @@ class LogitsLossFn(Function):
         B, n, D = x.shape
         x2 = x.detach().contiguous().reshape(B * n, D)
         W = cache.get('logits', (wl,), lambda: dict(w=_cast(wl), wT=_cast_t(wl)))
-        if K.mixed() and 'w16' not in W:       # fp16 copy for the dlogits pass of the fused cross entropy (None: outside the fp16 range)
+        if K.mixed() and FUSE_LINEAR_CE_X3 and 'w16' not in W:       # fp16 copy for the dlogits pass of the fused cross entropy (None: outside the fp16 range)
             W['w16'] = wl.detach().to(torch.float16).contiguous() if f16_weights_ok(wl) else None
         hn, m, r, ia = K.ln_fwd(x2, nw.detach(), nb.detach(), stable=True)
         if targets.dtype != torch.int64:
@@ -761,8 +765,8 @@ class LogitsLossFn(Function):
             raise ValueError(f'{targets.numel()} targets for {B * n} logit rows')
         t = targets.contiguous().reshape(-1)            # ids outside [0, C) give a NaN loss (the kernel never reads out of bounds)
         want_grad = any(ctx.needs_input_grad)
-        fused = K.linear_ce(hn, W['w'], t, 1.0 / (B * n), want_grad=want_grad, w16=W.get('w16')) if FUSE_LINEAR_CE else None
-        if fused is not None:                           # 'bf16' and 'bf16x3-fwd': logits produced twice inside the GEMM ring, never written (np.py:1958-1963)
+        fused = K.linear_ce(hn, W['w'], t, 1.0 / (B * n), want_grad=want_grad, w16=W.get('w16')) if (FUSE_LINEAR_CE_X3 if K.mixed() else FUSE_LINEAR_CE) else None
+        if fused is not None:                           # 'bf16' (and 'bf16x3-fwd' on request): logits produced twice inside the GEMM ring, never written (np.py:1958-1963)
             loss, dl = fused
         else:
             logits = K.gemm_nt(hn, W['w'])

@@ -201,6 +201,33 @@ def test_g5_g6_nuwa_loss_logits_grads(A, name, mode, tol, gtol):
         A.set_precision('bf16')
 
 
+def test_g5_with_the_fused_hi_lo_cross_entropy(A, monkeypatch):
+    """'bf16x3-fwd' with the opt-in fused to_logits + cross entropy (AMDNUWA_FUSE_LINEAR_CE_X3: no fp32 logits in memory, dlogits from
+    one fp16 MFMA per product): the reference's loss and gradients of fixture g5 inside the mode's usual bounds, and the loss equal to
+    the default (unfused) path's to 2e-6"""
+    from nuwa_pytorch_amd import ops, kernels as K
+    Ar, P, G = load('g5_nuwa_tiny')
+    nuwa = _tiny_nuwa(A, False)
+    nuwa.load_state_dict(P, strict=False)
+    nuwa = nuwa.to(DEV).train()
+    run_mode(A, 'bf16x3-fwd')
+    try:
+        text, vid = Ar['text'].to(DEV), Ar['video_ids'].to(DEV)
+        base = nuwa(text=text, video=vid, return_loss=True, cond_dropout_prob=0.).detach()
+        monkeypatch.setattr(ops, 'FUSE_LINEAR_CE_X3', True)
+        seen = []
+        real = K.linear_ce
+        monkeypatch.setattr(K, 'linear_ce', lambda *a, **k: (seen.append(k.get('w16') is not None), real(*a, **k))[1])
+        loss = nuwa(text=text, video=vid, return_loss=True, cond_dropout_prob=0.)
+        assert seen == [True]                               # the fused kernels took the call, with the fp16 dlogits pass
+        report('g5[bf16x3-fwd, fused ce].loss', loss.reshape(1), Ar['loss'].reshape(1), 1e-3)
+        report('g5[bf16x3-fwd, fused ce].loss_vs_unfused', loss.detach().reshape(1), base.reshape(1), 2e-6)
+        loss.backward()
+        assert check_grads(nuwa, G, 7e-2 * 2, 'g5[bf16x3-fwd, fused ce]', skip=('.net.blocks.',)) > 40
+    finally:
+        A.set_precision('bf16')
+
+
 def test_missing_library_fails_loudly(A, monkeypatch):
     from nuwa_pytorch_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)
