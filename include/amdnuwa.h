@@ -55,6 +55,8 @@ const char* amdnuwa_error_string(int code);
  *   key 18 cross-attention timing probes (garbage results): forward bit 0 no re-staging, 1 no pass 1, 2 no probability exchange, 3 no P'V,
  *          4 no head mix; backward bit 0 no re-staging, 1 no dW_th FMAs, 2 no pass A, 3 no pass B
  *   key 19 3DNA MFMA query-side backward: 1 = the three separate item passes (P' mix, dW_th, dP mix) instead of the fused one
+ *   key 20 NT 256x256 ring as a PERSISTENT kernel (one workgroup per CU walks the tile list, the DMA ring runs on across tile borders):
+ *          0 = auto (more tiles than CUs and K <= 1024), 1 = never, 2 = always
  * (keys run 0..31; key 0 also takes 10 / 11 = the K-step 64 forms of the 256x256 ring (lock-step / staggered wave rows: full 128-byte
  *  DMA lines, two 64 KiB stages; `auto` uses 11 for 1024 <= K < 2048); key 14 < 0 with key 0 = 6 delays the second workgroup of a CU;
  *  key 7 bit 6 issues a tile's stores inside the main loop (probe))

@@ -465,6 +465,199 @@ __device__ __forceinline__ int b64_off(int row, int cc) { return row * 128 + ((c
 // F16: A and B hold fp16 values and the products run on v_mfma_f32_16x16x32_f16 (same rate, 11 significand bits): the FeedForward
 // GEMMs of the 'bf16x3-fwd' mode's forward.  Outputs: fp32 (EPI 0) as ever; EPI 1 writes C = bf16 (u, for the bf16 backward) and,
 // with C2, the gate output computed on the fp32 accumulators as an fp16 copy (C2: FF2's operand) + a bf16 copy (C2lo: backward).
+// Epilogue of the 256-row ring tiles (gemm_nt_256_kernel and its persistent form): accumulators -> C (and the fused second outputs).
+// Lane (fr, fg) of wave (wm, wn): row fragments i = 0..7 are rows m0 + wm*128 + i*16 + fr; see the EPI notes at the kernel.
+template <int EPI, bool F16, int WNW>
+__device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane, long long oC) {
+    constexpr int BN = 64 * WNW;
+    const int fr = lane & 15, fg = lane >> 4;
+    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
+    if constexpr (EPI == 2 || EPI == 3) {
+        ce_epilogue<EPI>(p, acc, m0, n0, wm, wn, fr, fg);
+    } else if constexpr (EPI == 1) {
+        // lane (fr, fg) owns row m = .. + fr and the 16 contiguous columns n = n0 + wn*64 + fg*16 + [j*4 + r]
+        const bool vec8 = (p.N % 8 == 0) && (p.ldc % 8 == 0);
+        // the lane's 16 columns are the same for all 8 row fragments: their bias values are loaded ONCE, without a branch.  (Loaded
+        // per element inside the row loop each load sat under a branch and was followed by s_waitcnt vmcnt(0) -- which also waits for
+        // the STORES of the previous row fragment: 128 dependent round trips per wave and tile on every Linear with a bias.)
+        float bias16[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bias16[e] = 0.f;
+        if (p.bias != nullptr) {                                   // (one uniform branch per tile; no loads at all without a bias)
+            const int nbl = n0 + wn * 64 + fg * 16;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool in = nbl + e < p.N;
+                const float bvv = p.bias[in ? nbl + e : 0];
+                bias16[e] = in ? bvv : 0.f;
+            }
+        }
+        // GEGLU backward from (product = dgg, u): du = (dgg * gelu(gate), dgg * value * gelu'(gate)) in u's interleaved layout
+        auto geglu_bwd_store = [&](const uint4& ua, const uint4& ug, const uint4 (&uu)[4], uint4* dp) {
+            const uint4 dg2[2] = {ua, ug};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint4 av = uu[2 * q], gv = uu[2 * q + 1];
+                const uint32_t wa[4] = {av.x, av.y, av.z, av.w}, wg[4] = {gv.x, gv.y, gv.z, gv.w};
+                const uint32_t wd[4] = {dg2[q].x, dg2[q].y, dg2[q].z, dg2[q].w};
+                float da[8], dgt[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float y, dy;
+                    gelu_both_f(lo_f(wg[k]), y, dy);
+                    da[2 * k] = lo_f(wd[k]) * y;
+                    dgt[2 * k] = lo_f(wd[k]) * lo_f(wa[k]) * dy;
+                    gelu_both_f(hi_f(wg[k]), y, dy);
+                    da[2 * k + 1] = hi_f(wd[k]) * y;
+                    dgt[2 * k + 1] = hi_f(wd[k]) * hi_f(wa[k]) * dy;
+                }
+                dp[2 * q] = make_uint4(pack2_rne(da[0], da[1]), pack2_rne(da[2], da[3]), pack2_rne(da[4], da[5]), pack2_rne(da[6], da[7]));
+                dp[2 * q + 1] = make_uint4(pack2_rne(dgt[0], dgt[1]), pack2_rne(dgt[2], dgt[3]), pack2_rne(dgt[4], dgt[5]), pack2_rne(dgt[6], dgt[7]));
+            }
+        };
+        if (p.Uin && !p.Clo && vec8 && m0 + 256 <= p.M && n0 + BN <= p.N && !p.dbg) {
+            // full tile of the GEGLU backward: a straight-line loop with u of the NEXT row fragment in flight while this one is finished
+            // (in the generic loop below every fragment's loads sit behind its row checks and wait with vmcnt(0) -- on the previous
+            // fragment's stores as well)
+            const int nb = n0 + wn * 64 + fg * 16;
+            const bf16_t* ubase = p.Uin + ((long long)m0 + wm * 128 + fr) * p.ldu + 2 * nb;
+            bf16_t* dbase = p.C2 + ((long long)m0 + wm * 128 + fr) * p.ldc2 + 2 * nb;
+            uint4 un[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) un[q] = reinterpret_cast<const uint4*>(ubase)[q];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint4 uc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) uc[q] = un[q];
+                if (i + 1 < 8) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) un[q] = reinterpret_cast<const uint4*>(ubase + (long long)(i + 1) * 16 * p.ldu)[q];
+                }
+                float vv[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha + bias16[j * 4 + r];
+                const uint4 ua = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
+                const uint4 ug = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
+                geglu_bwd_store(ua, ug, uc, reinterpret_cast<uint4*>(dbase + (long long)i * 16 * p.ldc2));
+            }
+        } else
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
+            if (m >= p.M) continue;
+            const int nb = n0 + wn * 64 + fg * 16;
+            if (nb >= p.N) continue;
+            if ((p.dbg & 1) && acc[i][0][0] != 12345.678f) continue;
+            float vv[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha + bias16[j * 4 + r];
+            bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
+            bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;
+            if ((F16 || !Cl) && vec8 && nb + 16 <= p.N) {          // (F16: Clo, when given, receives the fp16 copy of the product)
+                const uint4 ua = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
+                const uint4 ug = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
+                if (p.Uin) {
+                    // GEGLU backward: the lane's 16 columns of dgg (as bf16, like the stand-alone kernel reads them) meet the two
+                    // 16-column groups [8 values | 8 gates] of u they belong to; du leaves in the same interleaved layout
+                    const uint4* up = reinterpret_cast<const uint4*>(p.Uin + m * p.ldu + 2 * nb);
+                    const uint4 uu[4] = {up[0], up[1], up[2], up[3]};
+                    geglu_bwd_store(ua, ug, uu, reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + 2 * nb));
+                    continue;
+                }
+                reinterpret_cast<uint4*>(C)[0] = ua;
+                reinterpret_cast<uint4*>(C)[1] = ug;
+                if constexpr (F16) {
+                    if (Cl) {              // fp16 copy of the product itself (q / k / v for the fp16 attention core)
+                        reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2_f16_sat(vv[0], vv[1]), pack2_f16_sat(vv[2], vv[3]), pack2_f16_sat(vv[4], vv[5]), pack2_f16_sat(vv[6], vv[7]));
+                        reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2_f16_sat(vv[8], vv[9]), pack2_f16_sat(vv[10], vv[11]), pack2_f16_sat(vv[12], vv[13]), pack2_f16_sat(vv[14], vv[15]));
+                    }
+                    if (p.C2) {            // gate on the fp32 accumulators; fp16 copy -> C2 (FF2's A operand), bf16 copy -> C2lo (backward)
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = vv[e] * gelu_f(vv[8 + e]);
+                        *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) =
+                            make_uint4(pack2_f16_sat(o[0], o[1]), pack2_f16_sat(o[2], o[3]), pack2_f16_sat(o[4], o[5]), pack2_f16_sat(o[6], o[7]));
+                        if (p.C2lo)
+                            *reinterpret_cast<uint4*>(p.C2lo + m * p.ldc2 + (nb >> 1)) =
+                                make_uint4(pack2_rne(o[0], o[1]), pack2_rne(o[2], o[3]), pack2_rne(o[4], o[5]), pack2_rne(o[6], o[7]));
+                    }
+                    continue;
+                }
+                if (p.C2) {
+                    // GEGLU on the values as STORED (bf16-rounded u), so the result equals the separate kernel's bit for bit:
+                    // the lane's 16 columns are 8 values and their 8 gates (interleaved-by-8 weight rows)
+                    const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w}, wg[4] = {ug.x, ug.y, ug.z, ug.w};
+                    float o[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        o[2 * k] = lo_f(wa[k]) * gelu_f(lo_f(wg[k]));
+                        o[2 * k + 1] = hi_f(wa[k]) * gelu_f(hi_f(wg[k]));
+                    }
+                    *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) =
+                        make_uint4(pack2_rne(o[0], o[1]), pack2_rne(o[2], o[3]), pack2_rne(o[4], o[5]), pack2_rne(o[6], o[7]));
+                }
+                continue;
+            }
+            bf16_t h[16], l[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) f2bf_hilo(vv[e], h[e], l[e]);
+            if (vec8 && nb + 16 <= p.N) {
+                reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
+                reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2(h[8], h[9]), pack2(h[10], h[11]), pack2(h[12], h[13]), pack2(h[14], h[15]));
+                if (Cl) {
+                    reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
+                    reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2(l[8], l[9]), pack2(l[10], l[11]), pack2(l[12], l[13]), pack2(l[14], l[15]));
+                }
+            } else {
+                for (int e = 0; e < 16 && nb + e < p.N; ++e) {
+                    C[e] = h[e];
+                    if (Cl) Cl[e] = l[e];
+                }
+            }
+        }
+    } else {
+    float biasf[4][4];                               // (loaded once per tile: see the bf16 epilogue)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) biasf[j][r] = 0.f;
+    if (p.bias != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + j * 16 + fg * 4 + r;
+                const bool in = n < p.N;
+                const float bvv = p.bias[in ? n : 0];
+                biasf[j][r] = in ? bvv : 0.f;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fg * 4;
+            if (n >= p.N) continue;
+            if ((p.dbg & 1) && acc[i][j][0] != 12345.678f) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha + biasf[j][r];
+            float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
+            if (vec_ok) *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+            else
+                for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
+        }
+    }
+    }
+}
+
 template <bool SHIFT, int EPI, int NS, int WNW, int STAG = 0, bool F16 = false>
 __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -772,182 +965,134 @@ __global__ __launch_bounds__(WNW * 128, WNW == 2 ? 2 : 1) void gemm_nt_256_kerne
                 acc[i][j] = mfma16<F16>(bfr[j], af[i], acc[i][j]);
     }
 
-    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
-    if constexpr (EPI == 2 || EPI == 3) {
-        ce_epilogue<EPI>(p, acc, m0, n0, wm, wn, fr, fg);
-    } else if constexpr (EPI == 1) {
-        // lane (fr, fg) owns row m = .. + fr and the 16 contiguous columns n = n0 + wn*64 + fg*16 + [j*4 + r]
-        const bool vec8 = (p.N % 8 == 0) && (p.ldc % 8 == 0);
-        // the lane's 16 columns are the same for all 8 row fragments: their bias values are loaded ONCE, without a branch.  (Loaded
-        // per element inside the row loop each load sat under a branch and was followed by s_waitcnt vmcnt(0) -- which also waits for
-        // the STORES of the previous row fragment: 128 dependent round trips per wave and tile on every Linear with a bias.)
-        float bias16[16];
-        {
-            const int nbl = n0 + wn * 64 + fg * 16;
+    nt256_epilogue<EPI, F16, WNW>(p, acc, m0, n0, wm, wn, lane, oC);
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT, 256x256 tile, PERSISTENT form of the 8-wave staggered ring (gemm_nt_256_kernel<false, EPI, 4, 4, 1, F16>): one workgroup per CU
+// walks the tile list (virtual block ids blockIdx.x, + gridDim.x, ...: the order the hardware would have dispatched them in, so the
+// XCD remap keeps its meaning) and the 4-stage DMA ring runs ON across tile borders: the last three K-steps of a tile already stage
+// the first three of the next one, so the epilogue's stores leave while those operands are in flight and the next main loop starts on
+// landed data.  A one-tile-per-workgroup launch pays, per tile, the ring fill (HBM / L2 latency, about 2 us) and the drain of its own
+// stores with an idle matrix pipe -- on the K = 512 products a quarter of the 7 us main loop.  (The vendor library's kernels for
+// these shapes are persistent stream-K kernels; that is where the idea comes from.)
+// Memory operations retire in order, so a counted vmcnt wait for a DMA group also covers everything older: right after an epilogue
+// the waits of K-steps 0 and 1 (whose groups were issued BEFORE the stores) allow the epilogue's store count on top of the two younger
+// DMA groups; from K-step 2 on the stores are older than the group waited for and have drained with it.  The store count is exact for
+// full tiles of the plain epilogues and taken as 0 (= wait for everything, always safe) otherwise.
+// Results are bit-identical to the one-tile kernel (same accumulation order).  Needs K / 32 >= 3.
+// ---------------------------------------------------------------------------------------------
+template <int EPI, bool F16>
+__global__ __launch_bounds__(512, 1) void gemm_nt_256p_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NS = 4, NW = 8;
+    constexpr int TB = 256 * 32 * 2, STG = 2 * TB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const long long bz = blockIdx.y;
+    const long long oA = boff(p, bz, p.sA, p.sA_in), oB = boff(p, bz, p.sB, p.sB_in), oC = boff(p, bz, p.sC, p.sC_in);
+    const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = p.K / 32;
+    int vb = blockIdx.x;
+    if (vb >= nwg) return;
+
+    const bf16_t* pa[2]; const bf16_t* pb[2]; const bf16_t* pan[2]; const bf16_t* pbn[2];
+    int m0, n0, m0n = 0, n0n = 0;
+    auto setup = [&](int v, const bf16_t* (&qa)[2], const bf16_t* (&qb)[2], int& mm, int& nn) {
+        const int lid = xcd_remap(v, nwg);
+        const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+        mm = tm * 256; nn = tn * 256;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const bool in = p.bias != nullptr && nbl + e < p.N;
-                const float bvv = (p.bias ? p.bias : reinterpret_cast<const float*>(g_zero_page))[in ? nbl + e : 0];
-                bias16[e] = in ? bvv : 0.f;
-            }
+        for (int j = 0; j < 2; ++j) {
+            const int row = (j * NW + wave) * 16 + (lane >> 2);
+            const long long ga = (long long)mm + row, gb = (long long)nn + row;
+            qa[j] = ga < p.M ? p.A + oA + ga * p.lda + ((lane & 3) ^ glds_swz<32>(row)) * 8 : nullptr;
+            qb[j] = gb < p.N ? p.B + oB + gb * p.ldb + ((lane & 3) ^ b256_swz<EPI>(row)) * 8 : nullptr;
         }
-        // GEGLU backward from (product = dgg, u): du = (dgg * gelu(gate), dgg * value * gelu'(gate)) in u's interleaved layout
-        auto geglu_bwd_store = [&](const uint4& ua, const uint4& ug, const uint4 (&uu)[4], uint4* dp) {
-            const uint4 dg2[2] = {ua, ug};
+    };
+    auto issue = [&](const bf16_t* const (&qa)[2], const bf16_t* const (&qb)[2], int slot, int k0) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const uint4 av = uu[2 * q], gv = uu[2 * q + 1];
-                const uint32_t wa[4] = {av.x, av.y, av.z, av.w}, wg[4] = {gv.x, gv.y, gv.z, gv.w};
-                const uint32_t wd[4] = {dg2[q].x, dg2[q].y, dg2[q].z, dg2[q].w};
-                float da[8], dgt[8];
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((glb_cvptr)(qa[j] ? qa[j] + k0 : zp), (lds_vptr)(smem + slot * STG + (j * NW + wave) * 1024), 16, 0, 0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float y, dy;
-                    gelu_both_f(lo_f(wg[k]), y, dy);
-                    da[2 * k] = lo_f(wd[k]) * y;
-                    dgt[2 * k] = lo_f(wd[k]) * lo_f(wa[k]) * dy;
-                    gelu_both_f(hi_f(wg[k]), y, dy);
-                    da[2 * k + 1] = hi_f(wd[k]) * y;
-                    dgt[2 * k + 1] = hi_f(wd[k]) * hi_f(wa[k]) * dy;
-                }
-                dp[2 * q] = make_uint4(pack2_rne(da[0], da[1]), pack2_rne(da[2], da[3]), pack2_rne(da[4], da[5]), pack2_rne(da[6], da[7]));
-                dp[2 * q + 1] = make_uint4(pack2_rne(dgt[0], dgt[1]), pack2_rne(dgt[2], dgt[3]), pack2_rne(dgt[4], dgt[5]), pack2_rne(dgt[6], dgt[7]));
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((glb_cvptr)(qb[j] ? qb[j] + k0 : zp), (lds_vptr)(smem + slot * STG + TB + (j * NW + wave) * 1024), 16, 0, 0);
+    };
+    auto wait_vm = [&](int n) {                                                  // (uniform; rounds DOWN to an immediate: never too permissive)
+        if (n >= 40) VMCNT(40); else if (n >= 24) VMCNT(24); else if (n >= 8) VMCNT(8); else if (n >= 4) VMCNT(4); else VMCNT(0);
+    };
+    // vector-memory instructions every wave issues in the epilogue of a FULL tile (0 = unknown: wait for everything)
+    int ns_full = 0;
+    if (!p.dbg) {
+        if constexpr (EPI == 0) ns_full = (p.N % 4 == 0 && p.ldc % 4 == 0) ? 32 : 0;
+        else if constexpr (EPI == 1) {
+            if (!p.Uin && p.N % 8 == 0 && p.ldc % 8 == 0 && !p.bias) {
+                if (F16) ns_full = 16 + (p.Clo ? 16 : 0) + (p.C2 ? 8 + (p.C2lo ? 8 : 0) : 0);
+                else ns_full = p.Clo ? 32 : 16 + (p.C2 ? 8 : 0);
             }
-        };
-        if (p.Uin && !p.Clo && vec8 && m0 + 256 <= p.M && n0 + BN <= p.N && !p.dbg) {
-            // full tile of the GEGLU backward: a straight-line loop with u of the NEXT row fragment in flight while this one is finished
-            // (in the generic loop below every fragment's loads sit behind its row checks and wait with vmcnt(0) -- on the previous
-            // fragment's stores as well)
-            const int nb = n0 + wn * 64 + fg * 16;
-            const bf16_t* ubase = p.Uin + ((long long)m0 + wm * 128 + fr) * p.ldu + 2 * nb;
-            bf16_t* dbase = p.C2 + ((long long)m0 + wm * 128 + fr) * p.ldc2 + 2 * nb;
-            uint4 un[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) un[q] = reinterpret_cast<const uint4*>(ubase)[q];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                uint4 uc[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) uc[q] = un[q];
-                if (i + 1 < 8) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) un[q] = reinterpret_cast<const uint4*>(ubase + (long long)(i + 1) * 16 * p.ldu)[q];
-                }
-                float vv[16];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha + bias16[j * 4 + r];
-                const uint4 ua = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
-                const uint4 ug = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
-                geglu_bwd_store(ua, ug, uc, reinterpret_cast<uint4*>(dbase + (long long)i * 16 * p.ldc2));
-            }
-        } else
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
-            if (m >= p.M) continue;
-            const int nb = n0 + wn * 64 + fg * 16;
-            if (nb >= p.N) continue;
-            if ((p.dbg & 1) && acc[i][0][0] != 12345.678f) continue;
-            float vv[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha + bias16[j * 4 + r];
-            bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
-            bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;
-            if ((F16 || !Cl) && vec8 && nb + 16 <= p.N) {          // (F16: Clo, when given, receives the fp16 copy of the product)
-                const uint4 ua = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
-                const uint4 ug = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
-                if (p.Uin) {
-                    // GEGLU backward: the lane's 16 columns of dgg (as bf16, like the stand-alone kernel reads them) meet the two
-                    // 16-column groups [8 values | 8 gates] of u they belong to; du leaves in the same interleaved layout
-                    const uint4* up = reinterpret_cast<const uint4*>(p.Uin + m * p.ldu + 2 * nb);
-                    const uint4 uu[4] = {up[0], up[1], up[2], up[3]};
-                    geglu_bwd_store(ua, ug, uu, reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + 2 * nb));
-                    continue;
-                }
-                reinterpret_cast<uint4*>(C)[0] = ua;
-                reinterpret_cast<uint4*>(C)[1] = ug;
-                if constexpr (F16) {
-                    if (Cl) {              // fp16 copy of the product itself (q / k / v for the fp16 attention core)
-                        reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2_f16_sat(vv[0], vv[1]), pack2_f16_sat(vv[2], vv[3]), pack2_f16_sat(vv[4], vv[5]), pack2_f16_sat(vv[6], vv[7]));
-                        reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2_f16_sat(vv[8], vv[9]), pack2_f16_sat(vv[10], vv[11]), pack2_f16_sat(vv[12], vv[13]), pack2_f16_sat(vv[14], vv[15]));
-                    }
-                    if (p.C2) {            // gate on the fp32 accumulators; fp16 copy -> C2 (FF2's A operand), bf16 copy -> C2lo (backward)
-                        float o[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = vv[e] * gelu_f(vv[8 + e]);
-                        *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) =
-                            make_uint4(pack2_f16_sat(o[0], o[1]), pack2_f16_sat(o[2], o[3]), pack2_f16_sat(o[4], o[5]), pack2_f16_sat(o[6], o[7]));
-                        if (p.C2lo)
-                            *reinterpret_cast<uint4*>(p.C2lo + m * p.ldc2 + (nb >> 1)) =
-                                make_uint4(pack2_rne(o[0], o[1]), pack2_rne(o[2], o[3]), pack2_rne(o[4], o[5]), pack2_rne(o[6], o[7]));
-                    }
-                    continue;
-                }
-                if (p.C2) {
-                    // GEGLU on the values as STORED (bf16-rounded u), so the result equals the separate kernel's bit for bit:
-                    // the lane's 16 columns are 8 values and their 8 gates (interleaved-by-8 weight rows)
-                    const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w}, wg[4] = {ug.x, ug.y, ug.z, ug.w};
-                    float o[8];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        o[2 * k] = lo_f(wa[k]) * gelu_f(lo_f(wg[k]));
-                        o[2 * k + 1] = hi_f(wa[k]) * gelu_f(hi_f(wg[k]));
-                    }
-                    *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) =
-                        make_uint4(pack2_rne(o[0], o[1]), pack2_rne(o[2], o[3]), pack2_rne(o[4], o[5]), pack2_rne(o[6], o[7]));
-                }
-                continue;
-            }
-            bf16_t h[16], l[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) f2bf_hilo(vv[e], h[e], l[e]);
-            if (vec8 && nb + 16 <= p.N) {
-                reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
-                reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2(h[8], h[9]), pack2(h[10], h[11]), pack2(h[12], h[13]), pack2(h[14], h[15]));
-                if (Cl) {
-                    reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
-                    reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2(l[8], l[9]), pack2(l[10], l[11]), pack2(l[12], l[13]), pack2(l[14], l[15]));
-                }
-            } else {
-                for (int e = 0; e < 16 && nb + e < p.N; ++e) {
-                    C[e] = h[e];
-                    if (Cl) Cl[e] = l[e];
-                }
-            }
-        }
-    } else {
-    float biasf[4][4];                               // (loaded once, branch-free: see the bf16 epilogue)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wn * 64 + j * 16 + fg * 4 + r;
-            const bool in = p.bias != nullptr && n < p.N;
-            const float bvv = (p.bias ? p.bias : reinterpret_cast<const float*>(g_zero_page))[in ? n : 0];
-            biasf[j][r] = in ? bvv : 0.f;
-        }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + fg * 4;
-            if (n >= p.N) continue;
-            if ((p.dbg & 1) && acc[i][j][0] != 12345.678f) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha + biasf[j][r];
-            float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
-            if (vec_ok) *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
-            else
-                for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
         }
     }
+
+    setup(vb, pa, pb, m0, n0);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(pa, pb, s, s * 32);                   // (nk >= 3)
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    VMCNT(8);
+    __builtin_amdgcn_s_barrier();                                                // step 0 of the first tile has landed for every wave
+    int slot = 0, ns_prev = 0;                                                   // ns_prev: stores of the epilogue just behind us (this wave)
+    for (;;) {
+        const int vbn = vb + (int)gridDim.x;
+        const bool has_next = vbn < nwg;
+        if (has_next) setup(vbn, pan, pbn, m0n, n0n);
+        if (wm == 1) __builtin_amdgcn_s_barrier();                               // this wave row lags one phase
+        for (int kt = 0; kt < nk; ++kt) {
+            // ---- read phase: fragments of step kt; restage the slot step kt - 1 lived in with step kt + 3 (of this tile or the next)
+            const char* base = smem + slot * STG;
+            bf16x8 af[8], bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(base + TB + b256_off<EPI>(wn * 64 + b256_row<EPI>(j, fr), fg));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + glds_off<32>(wm * 128 + i * 16 + fr, fg));
+            const int tgt = kt + NS - 1, rslot = (slot + NS - 1) & (NS - 1);
+            if (tgt < nk) issue(pa, pb, rslot, tgt * 32);
+            else if (has_next) issue(pan, pbn, rslot, (tgt - nk) * 32);
+            // step kt + 1 (this wave's share) must have landed before the barrier that precedes anyone's read of it: allowed in flight =
+            // the younger DMA groups (steps kt + 2, kt + 3 where they exist) + the previous epilogue's stores while they are younger too
+            const int g2 = (kt + 2 < nk || has_next) ? 4 : 0, g3 = (kt + 3 < nk || has_next) ? 4 : 0;
+            wait_vm(g2 + g3 + (kt <= 1 ? ns_prev : 0));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---- MFMA phase
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = mfma16<F16>(bfr[j], af[i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            slot = (slot + 1) & (NS - 1);
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();                               // rows back in step: both run their epilogues together
+        nt256_epilogue<EPI, F16, 4>(p, acc, m0, n0, wm, wn, lane, oC);
+        if (!has_next) break;
+        ns_prev = (m0 + 256 <= p.M && n0 + 256 <= p.N) ? ns_full : 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        vb = vbn; m0 = m0n; n0 = n0n;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { pa[j] = pan[j]; pb[j] = pbn[j]; }
     }
 }
 
@@ -987,6 +1132,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     const unsigned lds0 = (unsigned)(size_t)(lds_vptr_t)smem;
     const char* baseA = reinterpret_cast<const char*>(p.A + oA + (long long)m0 * p.lda);
     const char* baseB = reinterpret_cast<const char*>(p.B + oB + (long long)n0 * p.ldb);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseA), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB), 0, 0x7fffffff, 0x00020000);
     unsigned offa[4], offb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1001,6 +1148,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sbu), hi = __builtin_amdgcn_readfirstlane((unsigned)(sbu >> 32));
         const unsigned long long sbase = ((unsigned long long)hi << 32) | lo;
         const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds0 + slot * STG + (q < 4 ? 0 : TB) + ((q & 3) * 4 + wave) * 1024);
+        if (PROBE && (p.dbg & 32)) {
+            // PROBE (tuning key 7 bit 5): the same piece through buffer_load_dwordx4 ... lds -- resource descriptor in SGPRs, the lane's constant
+            // byte offset as voffset, the K position as scalar offset (the vendor library's kernels stage their operands this way)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(q < 4 ? rsA : rsB, (lds_vptr)(smem + slot * STG + (q < 4 ? 0 : TB) + ((q & 3) * 4 + wave) * 1024), 16,
+                                                     (int)(q < 4 ? offa[q & 3] : offb[q & 3]), k0 * 2, 0, 0);
+            return;
+        }
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(q < 4 ? offa[q & 3] : offb[q & 3]), "s"(sbase), "s"(lds_addr)
                      : "memory", "m0");
     };
@@ -2038,6 +2192,25 @@ __global__ __launch_bounds__(1024) void ce_mean_kernel(const float* __restrict__
 }
 }  // namespace
 
+// persistent form of the staggered 256x256 ring (gemm_nt_256p_kernel): taken when a CU owns more than one tile and the main loop is short
+// (K <= 1024); tuning key 20 = 1 keeps the one-tile-per-workgroup launch everywhere, = 2 forces the persistent kernel for any shape
+static int nt_persistent_grid() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    return cus;
+}
+static bool nt_persistent(long long tiles, int K, int dbg) {
+    const int v = g_amdnuwa_tuning[20];
+    if (v == 1 || K % 32 || K / 32 < 3 || (dbg & 2)) return false;
+    // measured at b = 128 (tools/gemm_persist_probe.py): K = 512 shapes -2...-9 %, K = 1536 a tie, K >= 2752 +2...+5 % (the ring fill is
+    // nothing next to a long main loop there, and the one-tile launch lets the hardware balance the tail)
+    return v == 2 || (tiles > nt_persistent_grid() && K <= 1024);
+}
+
 extern "C" size_t amdnuwa_linear_ce_workspace_bytes(long long R, int C) {
     if (R <= 0 || C <= 0 || C % 64) return 0;
     return (size_t)R * (C / 64) * 2 * sizeof(float) + (size_t)R * 2 * sizeof(float);
@@ -2212,6 +2385,18 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         }
         const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;
         dim3 g2(q.tiles_m * q.tiles_n, 1), b2(512);
+        if (nt_persistent(q.tiles_m * q.tiles_n, d->K, q.dbg)) {               // one workgroup per CU walks the tile list (gemm_nt_256p_kernel)
+            dim3 gp(nt_persistent_grid(), 1);
+            if (d->c_is_bf16) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_256p_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+                hipLaunchKernelGGL((gemm_nt_256p_kernel<1, true>), gp, b2, l2, stream, q);
+            } else {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_256p_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+                hipLaunchKernelGGL((gemm_nt_256p_kernel<0, true>), gp, b2, l2, stream, q);
+            }
+            LAUNCH_CHECK();
+            return AMDNUWA_OK;
+        }
         if (d->c_is_bf16) {
             (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 1, 4, 4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
             hipLaunchKernelGGL((gemm_nt_256_kernel<false, 1, 4, 4, 1, true>), g2, b2, l2, stream, q);
@@ -2352,6 +2537,19 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         if (d->C2) { p.C2 = (bf16_t*)d->C2; p.ldc2 = d->ldc2; p.Uin = (const bf16_t*)d->geglu_u; p.ldu = d->ld_u; }
         p.skew = nt_skew((long long)p.tiles_m * p.tiles_n);
         dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(512);
+        if (!sh && nt_persistent(p.tiles_m * p.tiles_n, d->K, p.dbg)) {        // one workgroup per CU walks the tile list (gemm_nt_256p_kernel)
+            const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;
+            dim3 gp(nt_persistent_grid(), d->batch > 0 ? d->batch : 1);
+            if (ob) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_256p_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+                hipLaunchKernelGGL((gemm_nt_256p_kernel<1, false>), gp, b2, l2, stream, p);
+            } else {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_256p_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+                hipLaunchKernelGGL((gemm_nt_256p_kernel<0, false>), gp, b2, l2, stream, p);
+            }
+            LAUNCH_CHECK();
+            return AMDNUWA_OK;
+        }
 #define GS(SH, EP)                                                                                                    \
     do {                                                                                                              \
         const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;                                                               \
