@@ -1096,6 +1096,71 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256p_kernel(GemmArgs p) {
     }
 }
 
+// Epilogue of the four-wave 256x256 tiles (2 x 2 waves of 128x128): acc[column half][row fragment][column fragment]; plain fp32 (EPI 0) or
+// bf16 (EPI 1) outputs
+template <int EPI>
+__device__ __forceinline__ void w4_epilogue(const GemmArgs& p, const f32x4 (&acc)[2][8][4], int m0, int n0, int wm, int wn, int lane, long long oC) {
+    const int fr = lane & 15, fg = lane >> 4;
+    const bool skip = (p.dbg & 1) != 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int ncol0 = n0 + (wn * 2 + c) * 64;
+        if constexpr (EPI == 0) {
+            const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
+            float biasf[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = ncol0 + j * 16 + fg * 4 + r;
+                    const bool in = p.bias != nullptr && n < p.N;
+                    const float bvv = (p.bias ? p.bias : reinterpret_cast<const float*>(g_zero_page))[in ? n : 0];
+                    biasf[j][r] = in ? bvv : 0.f;
+                }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = ncol0 + j * 16 + fg * 4;
+                    if (n >= p.N) continue;
+                    if (skip && acc[c][i][j][0] != 12345.678f) continue;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[c][i][j][r] * p.alpha + biasf[j][r];
+                    float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
+                    if (vec_ok) *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+                    else
+                        for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
+                }
+            }
+        } else {
+            // lane (fr, fg) owns row m = .. + fr and the 16 contiguous columns nb + [j * 4 + r] (permuted B rows, as the 8-wave kernel)
+            const bool vec8 = (p.N % 8 == 0) && (p.ldc % 8 == 0);
+            const int nb = ncol0 + fg * 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
+                if (m >= p.M || nb >= p.N) continue;
+                if (skip && acc[c][i][0][0] != 12345.678f) continue;
+                float vv[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[c][i][j][r] * p.alpha;
+                bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
+                if (vec8 && nb + 16 <= p.N) {
+                    reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
+                    reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
+                } else {
+                    for (int e = 0; e < 16 && nb + e < p.N; ++e) C[e] = f2bf(vv[e]);
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // NT, 256x256 tile, FOUR waves (2 x 2, 128x128 each), K-step 32, 4-stage LDS-DMA ring.
 // Why: every MFMA of the 8-wave layout above takes 0.375 KiB of fragments out of LDS (12 ds_read_b128 per 32 MFMAs for a 128x64
@@ -1262,64 +1327,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
 #undef W4_FIRST_HALF
 #undef W4_ROW
 
-    const bool skip = (p.dbg & 1) != 0;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int ncol0 = n0 + (wn * 2 + c) * 64;
-        if constexpr (EPI == 0) {
-            const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
-            float biasf[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = ncol0 + j * 16 + fg * 4 + r;
-                    const bool in = p.bias != nullptr && n < p.N;
-                    const float bvv = (p.bias ? p.bias : reinterpret_cast<const float*>(g_zero_page))[in ? n : 0];
-                    biasf[j][r] = in ? bvv : 0.f;
-                }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
-                if (m >= p.M) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = ncol0 + j * 16 + fg * 4;
-                    if (n >= p.N) continue;
-                    if (skip && acc[c][i][j][0] != 12345.678f) continue;
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[c][i][j][r] * p.alpha + biasf[j][r];
-                    float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
-                    if (vec_ok) *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
-                    else
-                        for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
-                }
-            }
-        } else {
-            // lane (fr, fg) owns row m = .. + fr and the 16 contiguous columns nb + [j * 4 + r] (permuted B rows, as the 8-wave kernel)
-            const bool vec8 = (p.N % 8 == 0) && (p.ldc % 8 == 0);
-            const int nb = ncol0 + fg * 16;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
-                if (m >= p.M || nb >= p.N) continue;
-                if (skip && acc[c][i][0][0] != 12345.678f) continue;
-                float vv[16];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[c][i][j][r] * p.alpha;
-                bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
-                if (vec8 && nb + 16 <= p.N) {
-                    reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
-                    reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
-                } else {
-                    for (int e = 0; e < 16 && nb + e < p.N; ++e) C[e] = f2bf(vv[e]);
-                }
-            }
-        }
-    }
+    w4_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, oC);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1514,6 +1522,171 @@ __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT, 256x256 tile, FOUR waves (2 x 2, 128x128 each), K-step 64, TWO 64 KiB stages with a 1.5-iteration prefetch: the long-K form.
+// Structure after the vendor library's kernels for these shapes: a K-step's fragments -- 16 + 16 ds_read_b128, all 128
+// registers of them -- are double-buffered in registers, so a stage is free for re-staging as soon as its SECOND half has been read,
+// half an iteration before its MFMAs are done:
+//   P1   64 MFMAs on half 0 (registers)   |  the 16 reads of half 1 of stage s
+//        lgkmcnt(0), barrier                 (stage s consumed by every wave)
+//   P2   64 MFMAs on half 1               |  16 DMA pieces of iteration i + 2 -> stage s, then vmcnt + barrier (iteration i + 1 has landed
+//                                            in stage s ^ 1), then the 16 reads of ITS half 0
+// Operand rows travel as full 128-byte lines (8 rows x 128 B per 1-KiB DMA piece; half the L2 requests of the K-step 32 ring), source
+// = a scalar base advanced by 128 bytes per iteration + a constant per-lane byte offset.  Every instruction of the loop is placed by
+// hand (sched_barrier between the slots): one MFMA, at most one other instruction, one MFMA ...  Needs K % 64 == 0.
+// Accumulation order per output element = k ascending in chunks of 32, as every other NT kernel here: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+template <int EPI, bool F16>
+__global__ __launch_bounds__(256, 1) void gemm_nt_w4k_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 256 * 64 * 2;             // one operand image of a stage: 32 KiB
+    constexpr int STG = 2 * TB;                  // 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int lid = xcd_remap(blockIdx.x, nwg);
+    const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const long long bz = blockIdx.y;
+    const long long oA = boff(p, bz, p.sA, p.sA_in), oB = boff(p, bz, p.sB, p.sB_in), oC = boff(p, bz, p.sC, p.sC_in);
+    const unsigned lds0 = (unsigned)(size_t)(lds_vptr_t)smem;
+    const char* baseA = reinterpret_cast<const char*>(p.A + oA + (long long)m0 * p.lda);
+    const char* baseB = reinterpret_cast<const char*>(p.B + oB + (long long)n0 * p.ldb);
+    // this wave's DMA pieces: pieces j * 4 + wave (j = 0..7) of the A and of the B image; a piece = 8 rows x 64 k (1 KiB): lane -> row
+    // lane >> 3, LDS chunk lane & 7, which holds source chunk (lane & 7) ^ swizzle(row).  Rows past M / N are clamped to the last row.
+    unsigned offa[8], offb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = (j * 4 + wave) * 8 + (lane >> 3);
+        const int ra = min(row, p.M - 1 - m0), rb = min(row, p.N - 1 - n0);
+        offa[j] = (unsigned)((ra * p.lda + (((lane & 7) ^ (row & 7)) * 8)) * 2);
+        offb[j] = (unsigned)((rb * p.ldb + (((lane & 7) ^ b64_swz<EPI>(row)) * 8)) * 2);
+    }
+    auto issue_piece = [&](int q, int stage, int it) {            // q = 0..7: A pieces, 8..15: B pieces
+        const char* sb = (q < 8 ? baseA : baseB) + (size_t)it * 128;
+        const unsigned long long sbu = (unsigned long long)sb;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sbu), hi = __builtin_amdgcn_readfirstlane((unsigned)(sbu >> 32));
+        const unsigned long long sbase = ((unsigned long long)hi << 32) | lo;
+        const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds0 + stage * STG + (q < 8 ? 0 : TB) + ((q & 7) * 4 + wave) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(q < 8 ? offa[q & 7] : offb[q & 7]), "s"(sbase), "s"(lds_addr)
+                     : "memory", "m0");
+    };
+
+    f32x4 acc[2][8][4];                          // [column half][row fragment][column fragment]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nit = (p.dbg & 2) ? 0 : p.K / 64;
+    const int fr = lane & 15, fg = lane >> 4;
+    // fragment addresses (stage 0), per K half h: A fragment i at + i * 2048; B fragment (c, j) at + c * 8192 + j * JB
+    constexpr int JB = EPI >= 1 ? 512 : 2048;
+    const int browl = EPI >= 1 ? (fr >> 2) * 16 + (fr & 3) : fr;
+    const int bswz = EPI >= 1 ? (((fr >> 2) << 1) | ((fr >> 1) & 1)) : (fr & 7);
+    unsigned la[2], lb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        la[h] = lds0 + (wm * 128 + fr) * 128 + (((h * 4 + fg) ^ (fr & 7)) << 4);
+        lb[h] = lds0 + TB + (wn * 128 + browl) * 128 + (((h * 4 + fg) ^ bswz) << 4);
+    }
+    bf16x8 af[2][8], bfr[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[h][i] = bfr[h][i] = bf16x8{};
+#define WK_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(DST) : "v"(ADDR), "n"(OFF))
+#define WK_RDA(H, I, ADDR) WK_RD(af[H][I], ADDR, (I) * 2048)
+#define WK_RDB(H, Q, ADDR) WK_RD(bfr[H][Q], ADDR, ((Q) >> 2) * 8192 + ((Q) & 3) * JB)
+#define WK_PIN() __builtin_amdgcn_sched_barrier(0)
+#define WK_MF(H, I, Q) do { acc[(Q) >> 2][I][(Q) & 3] = mfma16<F16>(bfr[H][Q], af[H][I], acc[(Q) >> 2][I][(Q) & 3]); WK_PIN(); } while (0)
+    // everything the MFMAs read has to be known to the compiler as written: tie the fragment registers of a half to the wait that retires them
+#define WK_LGKM0(H)                                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[H][0]), "+v"(af[H][1]), "+v"(af[H][2]), "+v"(af[H][3]), "+v"(af[H][4]), "+v"(af[H][5]), \
+                 "+v"(af[H][6]), "+v"(af[H][7]), "+v"(bfr[H][0]), "+v"(bfr[H][1]), "+v"(bfr[H][2]), "+v"(bfr[H][3]), "+v"(bfr[H][4]),       \
+                 "+v"(bfr[H][5]), "+v"(bfr[H][6]), "+v"(bfr[H][7]) :: "memory")
+    if (nit > 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) issue_piece(q, 0, 0);
+        if (nit > 1) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) issue_piece(q, 1, 1);
+            VMCNT(16);
+        } else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        WK_RDB(0, 0, lb[0]); WK_RDB(0, 1, lb[0]); WK_RDB(0, 2, lb[0]); WK_RDB(0, 3, lb[0]); WK_RDB(0, 4, lb[0]); WK_RDB(0, 5, lb[0]); WK_RDB(0, 6, lb[0]); WK_RDB(0, 7, lb[0]);
+        WK_RDA(0, 0, la[0]); WK_RDA(0, 1, la[0]); WK_RDA(0, 2, la[0]); WK_RDA(0, 3, la[0]); WK_RDA(0, 4, la[0]); WK_RDA(0, 5, la[0]); WK_RDA(0, 6, la[0]); WK_RDA(0, 7, la[0]);
+        WK_LGKM0(0);
+    }
+    WK_PIN();
+    // One branch-free body for every iteration: past the end of K the staging simply repeats the LAST K-step into the stage that has just
+    // been consumed (nobody reads it again) and the fragment reads of a non-existent next step fetch values nobody multiplies -- two
+    // redundant L2-resident K-steps per tile (the kernel is for long K) instead of 37 scalar branches per iteration.
+    for (int it = 0; it < nit; ++it) {
+        constexpr bool more2 = true, more1 = true;
+        const int it2 = min(it + 2, nit - 1);
+        const unsigned so = (unsigned)((it & 1) * STG), sn = (unsigned)(((it + 1) & 1) * STG);
+        const unsigned a1 = la[1] + so, b1 = lb[1] + so, a0n = la[0] + sn, b0n = lb[0] + sn;
+        // ---- P1: half 0 from registers; the 16 reads of half 1 ride between the first 32 MFMAs
+#define WK_ROW_P1(I, R0, R1, R2, R3)                                                                                \
+        WK_MF(0, I, 0); R0; WK_PIN(); WK_MF(0, I, 1); WK_MF(0, I, 2); R1; WK_PIN(); WK_MF(0, I, 3);                  \
+        WK_MF(0, I, 4); R2; WK_PIN(); WK_MF(0, I, 5); WK_MF(0, I, 6); R3; WK_PIN(); WK_MF(0, I, 7)
+        WK_ROW_P1(0, WK_RDB(1, 0, b1), WK_RDB(1, 1, b1), WK_RDB(1, 2, b1), WK_RDB(1, 3, b1));
+        WK_ROW_P1(1, WK_RDB(1, 4, b1), WK_RDB(1, 5, b1), WK_RDB(1, 6, b1), WK_RDB(1, 7, b1));
+        WK_ROW_P1(2, WK_RDA(1, 0, a1), WK_RDA(1, 1, a1), WK_RDA(1, 2, a1), WK_RDA(1, 3, a1));
+        WK_ROW_P1(3, WK_RDA(1, 4, a1), WK_RDA(1, 5, a1), WK_RDA(1, 6, a1), WK_RDA(1, 7, a1));
+        WK_ROW_P1(4, (void)0, (void)0, (void)0, (void)0);
+        WK_ROW_P1(5, (void)0, (void)0, (void)0, (void)0);
+        WK_ROW_P1(6, (void)0, (void)0, (void)0, (void)0);
+        WK_ROW_P1(7, (void)0, (void)0, (void)0, (void)0);
+#undef WK_ROW_P1
+        WK_LGKM0(1);
+        __builtin_amdgcn_s_barrier();                                            // every wave is done with stage it & 1
+        WK_PIN();
+        // ---- P2: half 1 from registers; iteration it + 2 goes out into the freed stage, then iteration it + 1 is awaited and its half 0 read
+#define WK_DMA(Q) do { if (more2) issue_piece(Q, it & 1, it2); WK_PIN(); } while (0)
+        // (DMA issue is spread thin -- one piece per four MFMAs: the four waves issue in step, and the texture-address unit takes 16 cycles
+        //  per 1-KiB piece; a burst of pieces stalls the issuing wave, and its MFMAs with it)
+#define WK_ROW_P2A(I, Q0)                                                                                            \
+        WK_MF(1, I, 0); WK_DMA(Q0); WK_MF(1, I, 1); WK_MF(1, I, 2); WK_MF(1, I, 3);                                   \
+        WK_MF(1, I, 4); WK_DMA(Q0 + 1); WK_MF(1, I, 5); WK_MF(1, I, 6); WK_MF(1, I, 7)
+        WK_ROW_P2A(0, 0); WK_ROW_P2A(1, 2); WK_ROW_P2A(2, 4); WK_ROW_P2A(3, 6);
+#undef WK_ROW_P2A
+        if (more2) VMCNT(8); else VMCNT(0);                                      // this wave's pieces of iteration it + 1 (8 of it + 2 are younger) ...
+        __builtin_amdgcn_s_barrier();                                            // ... and everyone's
+        WK_PIN();
+#define WK_RDN(X) do { if (more1) { X; } WK_PIN(); } while (0)
+        // the 16 reads of the next half 0 sit in rows 4 - 6, so that the last of them has a row of MFMAs to land in before the next P1
+        WK_MF(1, 4, 0); WK_RDN(WK_RDB(0, 0, b0n)); WK_MF(1, 4, 1); WK_RDN(WK_RDB(0, 1, b0n)); WK_MF(1, 4, 2); WK_DMA(8); WK_MF(1, 4, 3); WK_RDN(WK_RDB(0, 2, b0n));
+        WK_MF(1, 4, 4); WK_RDN(WK_RDB(0, 3, b0n)); WK_MF(1, 4, 5); WK_RDN(WK_RDB(0, 4, b0n)); WK_MF(1, 4, 6); WK_DMA(9); WK_MF(1, 4, 7); WK_RDN(WK_RDB(0, 5, b0n));
+        WK_MF(1, 5, 0); WK_RDN(WK_RDB(0, 6, b0n)); WK_MF(1, 5, 1); WK_RDN(WK_RDB(0, 7, b0n)); WK_MF(1, 5, 2); WK_DMA(10); WK_MF(1, 5, 3); WK_RDN(WK_RDA(0, 0, a0n));
+        WK_MF(1, 5, 4); WK_RDN(WK_RDA(0, 1, a0n)); WK_MF(1, 5, 5); WK_RDN(WK_RDA(0, 2, a0n)); WK_MF(1, 5, 6); WK_DMA(11); WK_MF(1, 5, 7); WK_RDN(WK_RDA(0, 3, a0n));
+        WK_MF(1, 6, 0); WK_RDN(WK_RDA(0, 4, a0n)); WK_MF(1, 6, 1); WK_RDN(WK_RDA(0, 5, a0n)); WK_MF(1, 6, 2); WK_DMA(12); WK_MF(1, 6, 3); WK_RDN(WK_RDA(0, 6, a0n));
+        WK_MF(1, 6, 4); WK_RDN(WK_RDA(0, 7, a0n)); WK_MF(1, 6, 5); WK_MF(1, 6, 6); WK_DMA(13); WK_MF(1, 6, 7);
+        WK_MF(1, 7, 0); WK_MF(1, 7, 1); WK_MF(1, 7, 2); WK_DMA(14); WK_MF(1, 7, 3); WK_MF(1, 7, 4); WK_MF(1, 7, 5); WK_MF(1, 7, 6); WK_DMA(15); WK_MF(1, 7, 7);
+#undef WK_RDN
+#define WK_ROW_P2B 0
+#undef WK_ROW_P2B
+#undef WK_DMA
+        WK_LGKM0(0);
+        WK_PIN();
+    }
+    VMCNT(0);                                    // (the redundant pieces of the last two iterations: nothing may land in LDS after the workgroup has left)
+#undef WK_RD
+#undef WK_RDA
+#undef WK_RDB
+#undef WK_PIN
+#undef WK_MF
+#undef WK_LGKM0
+    // the ring's epilogue per 64-column block: column half c of this wave is "wave column" wn * 2 + c of the 8-wave layout (same lane
+    // ownership: 16 contiguous columns of one row), so every fused output of nt256_epilogue is available here too
+    nt256_epilogue<EPI, F16, 4>(p, acc[0], m0, n0, wm, wn * 2, lane, oC);
+    nt256_epilogue<EPI, F16, 4>(p, acc[1], m0, n0, wm, wn * 2 + 1, lane, oC);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2203,6 +2376,13 @@ static int nt_persistent_grid() {
     }
     return cus;
 }
+// the four-wave K-step 64 kernel (gemm_nt_w4k_kernel): the long-K products (tuning key 22 = 1 keeps the 8-wave ring, = 2 takes it for
+// every K that is a multiple of 64)
+static bool nt_long_k(int K, int dbg) {
+    const int v = g_amdnuwa_tuning[22];
+    if (v == 1 || K % 64 || (dbg & 2)) return false;
+    return v == 2 || K >= 1024;
+}
 static bool nt_persistent(long long tiles, int K, int dbg) {
     const int v = g_amdnuwa_tuning[20];
     if (v == 1 || K % 32 || K / 32 < 3 || (dbg & 2)) return false;
@@ -2385,6 +2565,19 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         }
         const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;
         dim3 g2(q.tiles_m * q.tiles_n, 1), b2(512);
+        if (nt_long_k(d->K, q.dbg) && g_amdnuwa_tuning[0] == 0) {              // long K: four waves of 128x128, K-step 64 (gemm_nt_w4k_kernel)
+            const size_t l4 = (size_t)2 * 2 * 256 * 64 * 2;
+            dim3 b4(256);
+            if (d->c_is_bf16) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_w4k_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+                hipLaunchKernelGGL((gemm_nt_w4k_kernel<1, true>), g2, b4, l4, stream, q);
+            } else {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_w4k_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+                hipLaunchKernelGGL((gemm_nt_w4k_kernel<0, true>), g2, b4, l4, stream, q);
+            }
+            LAUNCH_CHECK();
+            return AMDNUWA_OK;
+        }
         if (nt_persistent(q.tiles_m * q.tiles_n, d->K, q.dbg)) {               // one workgroup per CU walks the tile list (gemm_nt_256p_kernel)
             dim3 gp(nt_persistent_grid(), 1);
             if (d->c_is_bf16) {
@@ -2499,11 +2692,26 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         LAUNCH_CHECK();
         return AMDNUWA_OK;
     }
+    if (!x3 && !sh && variant == 12 && d->K % 64 == 0 && !d->C2 && !d->Clo && !(ob && d->bias)) {   // 4 waves x 128x128, K-step 64, 1.5-iteration prefetch
+        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
+        dim3 g4(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b4(256);
+        const size_t l4 = (size_t)2 * 2 * 256 * 64 * 2;
+        if (ob) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_w4k_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+            hipLaunchKernelGGL((gemm_nt_w4k_kernel<1, false>), g4, b4, l4, stream, p);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_w4k_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+            hipLaunchKernelGGL((gemm_nt_w4k_kernel<0, false>), g4, b4, l4, stream, p);
+        }
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
+    }
+    if (variant == 12) variant = 7;
     if (variant == 9) variant = 7;
     // K-step 64 form with staggered wave rows (two 64 KiB stages of full 128-byte row lines): measured ahead of the K-step 32 ring on the
     // K = 1376 / 1536 shapes only (FF2 -10 %, dgrad qkv -1.5 %; K = 512 shapes and K >= 2752 equal or slower: profiles/r04g_gemm_k64.txt), so `auto`
     // takes it for 1024 <= K < 2048; tuning key 0 = 11 forces it, 7 keeps the ring
-    if (!x3 && !sh && (variant == 11 || (g_amdnuwa_tuning[0] == 0 && variant == 7 && d->K >= 1024 && d->K < 2048)) && d->K % 32 == 0 && !d->C2) {
+    if (!x3 && !sh && (variant == 11 || (g_amdnuwa_tuning[0] == 0 && variant == 7 && d->K >= 1024 && d->K < 2048 && !nt_long_k(d->K, p.dbg))) && d->K % 32 == 0 && !d->C2) {
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(512);
         const size_t l6 = (size_t)2 * 2 * 256 * 64 * 2;
@@ -2537,6 +2745,19 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         if (d->C2) { p.C2 = (bf16_t*)d->C2; p.ldc2 = d->ldc2; p.Uin = (const bf16_t*)d->geglu_u; p.ldu = d->ld_u; }
         p.skew = nt_skew((long long)p.tiles_m * p.tiles_n);
         dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(512);
+        if (!sh && nt_long_k(d->K, p.dbg)) {                                   // long K: four waves of 128x128, K-step 64 (gemm_nt_w4k_kernel)
+            const size_t l4 = (size_t)2 * 2 * 256 * 64 * 2;
+            dim3 b4(256);
+            if (ob) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_w4k_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+                hipLaunchKernelGGL((gemm_nt_w4k_kernel<1, false>), g2, b4, l4, stream, p);
+            } else {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_w4k_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+                hipLaunchKernelGGL((gemm_nt_w4k_kernel<0, false>), g2, b4, l4, stream, p);
+            }
+            LAUNCH_CHECK();
+            return AMDNUWA_OK;
+        }
         if (!sh && nt_persistent(p.tiles_m * p.tiles_n, d->K, p.dbg)) {        // one workgroup per CU walks the tile list (gemm_nt_256p_kernel)
             const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;
             dim3 gp(nt_persistent_grid(), d->batch > 0 ? d->batch : 1);

@@ -523,12 +523,17 @@ def test_embed_bwd_long_runs(K, case):
         outs.append(dW)
     assert torch.equal(outs[0], outs[1])
     report(f'embed_bwd_long_runs[{case}]', outs[0], ref.float(), 2e-6)
-    torch.cuda.synchronize()
-    import time
-    t0 = time.perf_counter()
-    K.embed_bwd(ids.to(DEV), dx.to(DEV), outs[0], d1, d2, d3, db, B, ntok, 10, 16, 16, 0.2)
-    torch.cuda.synchronize()
-    assert time.perf_counter() - t0 < 0.05, 'a run of equal ids must not be walked by one wave'
+    # device time of the call alone (inputs resident, best of three: no host hiccup or copy inside the bound)
+    ids_d, dx_d = ids.to(DEV), dx.to(DEV)
+    best = float('inf')
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        K.embed_bwd(ids_d, dx_d, outs[0], d1, d2, d3, db, B, ntok, 10, 16, 16, 0.2)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    assert best < 30.0, f'a run of equal ids must not be walked by one wave ({best:.1f} ms)'
 
 
 @pytest.mark.parametrize('R,C', [(5, 64), (300, 8192), (17, 1000)])
