@@ -2143,6 +2143,157 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmArgs p, float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// TN, 256x256 output tile, FOUR waves (2 x 2, 128x128 each), 64 token rows per iteration, two 64 KiB stages with a 1.5-iteration
+// prefetch: the weight-gradient form of gemm_nt_w4k_kernel (same schedule, same reasons; see there).  Operand tiles are
+// [64 token rows][256 columns] in the layout of gemm_tn_256_kernel (512-byte rows, 32-byte XOR swizzle), fragments come from
+// ds_read_b64_tr_b16 pairs (two per fragment: 32 + 32 reads per K half).  No token shift; every split covers a multiple of 64 rows
+// (host side); columns past N1 / N2 are clamped (they only feed outputs that are never stored).
+// Accumulation order per output element = token rows ascending in chunks of 32, as gemm_tn_256_kernel: bit-identical partials.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void gemm_tn_w4k_kernel(GemmArgs p, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 64 * 256 * 2;             // one operand image of a stage: 32 KiB
+    constexpr int STG = 2 * TB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int N1 = p.M, N2 = p.N;
+    const int ntile = p.tiles_m * p.tiles_n;
+    const int vid = xcd_remap(blockIdx.x, ntile * p.nsplit);
+    const int z = vid / ntile, tix = vid % ntile;
+    const int tmi = tix / p.tiles_n, tni = tix % p.tiles_n;
+    const int a0 = tmi * 256, b0 = tni * 256;
+    const long long bz = blockIdx.y;
+    const long long mbeg = (long long)z * p.ksplit_len;
+    const long long mend = min((long long)p.K, mbeg + p.ksplit_len);
+    const int nit = mend > mbeg ? (int)((mend - mbeg) / 64) : 0;
+    const unsigned lds0 = (unsigned)(size_t)(lds_vptr_t)smem;
+    const char* baseA = reinterpret_cast<const char*>(p.A + boff(p, bz, p.sA, p.sA_in) + mbeg * p.lda);
+    const char* baseB = reinterpret_cast<const char*>(p.B + boff(p, bz, p.sB, p.sB_in) + mbeg * p.ldb);
+    // this wave's DMA pieces: pieces j * 4 + wave (j = 0..7) of each image; a piece = 2 token rows x 256 columns (1 KiB)
+    unsigned offa[8], offb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = (j * 4 + wave) * 2 + (lane >> 5);
+        const int ps = lane & 31;
+        const int cc16 = ((((ps >> 1) ^ tn_f(row)) << 1) | (ps & 1));
+        offa[j] = (unsigned)((row * p.lda + min(a0 + cc16 * 8, N1 - 8)) * 2);
+        offb[j] = (unsigned)((row * p.ldb + min(b0 + cc16 * 8, N2 - 8)) * 2);
+    }
+    const size_t itA = (size_t)64 * p.lda * 2, itB = (size_t)64 * p.ldb * 2;
+    auto issue_piece = [&](int q, int stage, int it) {            // q = 0..7: A pieces, 8..15: B pieces
+        const char* sb = q < 8 ? baseA + it * itA : baseB + it * itB;
+        const unsigned long long sbu = (unsigned long long)sb;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sbu), hi = __builtin_amdgcn_readfirstlane((unsigned)(sbu >> 32));
+        const unsigned long long sbase = ((unsigned long long)hi << 32) | lo;
+        const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds0 + stage * STG + (q < 8 ? 0 : TB) + ((q & 7) * 4 + wave) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(q < 8 ? offa[q & 7] : offb[q & 7]), "s"(sbase), "s"(lds_addr)
+                     : "memory", "m0");
+    };
+    f32x4 acc[2][8][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment addresses in stage 0, K half 0 (half 1: + 16384; the `hi` read of a fragment: + 2048): the column block index is XORed with a
+    // per-lane swizzle term, so every fragment keeps its own address register
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int t16 = lane & 15, g4 = lane >> 4;
+    const int frow = 8 * g4 + (t16 >> 2), ff = tn_f(frow);
+    unsigned ada[8], adb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        ada[i] = (unsigned)(frow * 512 + ((((wm * 8 + i) ^ ff) << 5) | ((t16 & 3) << 3)));
+        adb[i] = (unsigned)(TB + frow * 512 + ((((wn * 8 + i) ^ ff) << 5) | ((t16 & 3) << 3)));
+    }
+    bf16x8 af[2][8], bfr[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[h][i] = bfr[h][i] = bf16x8{};
+    auto rd = [&](unsigned addr) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + addr));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + addr + 2048));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+#define TK_PIN() __builtin_amdgcn_sched_barrier(0)
+#define TK_RDA(H, I, SO) do { af[H][I] = rd(ada[I] + (SO) + (H) * 16384); TK_PIN(); } while (0)
+#define TK_RDB(H, Q, SO) do { bfr[H][Q] = rd(adb[Q] + (SO) + (H) * 16384); TK_PIN(); } while (0)
+#define TK_MF(H, I, Q) do { acc[(Q) >> 2][I][(Q) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[H][Q], af[H][I], acc[(Q) >> 2][I][(Q) & 3], 0, 0, 0); TK_PIN(); } while (0)
+    if (nit > 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) issue_piece(q, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) issue_piece(q, 1, min(1, nit - 1));
+        VMCNT(16);
+        __builtin_amdgcn_s_barrier();
+        TK_RDB(0, 0, 0u); TK_RDB(0, 1, 0u); TK_RDB(0, 2, 0u); TK_RDB(0, 3, 0u); TK_RDB(0, 4, 0u); TK_RDB(0, 5, 0u); TK_RDB(0, 6, 0u); TK_RDB(0, 7, 0u);
+        TK_RDA(0, 0, 0u); TK_RDA(0, 1, 0u); TK_RDA(0, 2, 0u); TK_RDA(0, 3, 0u); TK_RDA(0, 4, 0u); TK_RDA(0, 5, 0u); TK_RDA(0, 6, 0u); TK_RDA(0, 7, 0u);
+    }
+    TK_PIN();
+    // (one branch-free body: past the end of the split the staging repeats the last step into the stage just consumed -- see gemm_nt_w4k_kernel)
+    for (int it = 0; it < nit; ++it) {
+        const unsigned so = (unsigned)((it & 1) * STG), sn = (unsigned)(((it + 1) & 1) * STG);
+        const int it2 = min(it + 2, nit - 1);
+#define TK_DMA(Q) do { issue_piece(Q, it & 1, it2); TK_PIN(); } while (0)
+        // ---- P1: half 0 from registers; the reads of half 1 (16 fragments = 32 reads) between the MFMAs of rows 0 - 3
+#define TK_ROW_P1(I, R0, R1, R2, R3)                                                                                \
+        TK_MF(0, I, 0); R0; TK_MF(0, I, 1); TK_MF(0, I, 2); R1; TK_MF(0, I, 3); TK_MF(0, I, 4); R2; TK_MF(0, I, 5); TK_MF(0, I, 6); R3; TK_MF(0, I, 7)
+        TK_ROW_P1(0, TK_RDB(1, 0, so), TK_RDB(1, 1, so), TK_RDB(1, 2, so), TK_RDB(1, 3, so));
+        TK_ROW_P1(1, TK_RDB(1, 4, so), TK_RDB(1, 5, so), TK_RDB(1, 6, so), TK_RDB(1, 7, so));
+        TK_ROW_P1(2, TK_RDA(1, 0, so), TK_RDA(1, 1, so), TK_RDA(1, 2, so), TK_RDA(1, 3, so));
+        TK_ROW_P1(3, TK_RDA(1, 4, so), TK_RDA(1, 5, so), TK_RDA(1, 6, so), TK_RDA(1, 7, so));
+        TK_ROW_P1(4, (void)0, (void)0, (void)0, (void)0); TK_ROW_P1(5, (void)0, (void)0, (void)0, (void)0);
+        TK_ROW_P1(6, (void)0, (void)0, (void)0, (void)0); TK_ROW_P1(7, (void)0, (void)0, (void)0, (void)0);
+#undef TK_ROW_P1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                            // every wave is done with stage it & 1
+        TK_PIN();
+        // ---- P2: half 1 from registers; eight pieces of iteration it + 2, then iteration it + 1 is awaited and its half 0 read (rows 4 - 6)
+#define TK_ROW_P2A(I, Q0)                                                                                            \
+        TK_MF(1, I, 0); TK_DMA(Q0); TK_MF(1, I, 1); TK_MF(1, I, 2); TK_MF(1, I, 3); TK_MF(1, I, 4); TK_DMA(Q0 + 1); TK_MF(1, I, 5); TK_MF(1, I, 6); TK_MF(1, I, 7)
+        TK_ROW_P2A(0, 0); TK_ROW_P2A(1, 2); TK_ROW_P2A(2, 4); TK_ROW_P2A(3, 6);
+#undef TK_ROW_P2A
+        VMCNT(8);
+        __builtin_amdgcn_s_barrier();
+        TK_PIN();
+        TK_MF(1, 4, 0); TK_RDB(0, 0, sn); TK_MF(1, 4, 1); TK_RDB(0, 1, sn); TK_MF(1, 4, 2); TK_DMA(8); TK_MF(1, 4, 3); TK_RDB(0, 2, sn);
+        TK_MF(1, 4, 4); TK_RDB(0, 3, sn); TK_MF(1, 4, 5); TK_RDB(0, 4, sn); TK_MF(1, 4, 6); TK_DMA(9); TK_MF(1, 4, 7); TK_RDB(0, 5, sn);
+        TK_MF(1, 5, 0); TK_RDB(0, 6, sn); TK_MF(1, 5, 1); TK_RDB(0, 7, sn); TK_MF(1, 5, 2); TK_DMA(10); TK_MF(1, 5, 3); TK_RDA(0, 0, sn);
+        TK_MF(1, 5, 4); TK_RDA(0, 1, sn); TK_MF(1, 5, 5); TK_RDA(0, 2, sn); TK_MF(1, 5, 6); TK_DMA(11); TK_MF(1, 5, 7); TK_RDA(0, 3, sn);
+        TK_MF(1, 6, 0); TK_RDA(0, 4, sn); TK_MF(1, 6, 1); TK_RDA(0, 5, sn); TK_MF(1, 6, 2); TK_DMA(12); TK_MF(1, 6, 3); TK_RDA(0, 6, sn);
+        TK_MF(1, 6, 4); TK_RDA(0, 7, sn); TK_MF(1, 6, 5); TK_MF(1, 6, 6); TK_DMA(13); TK_MF(1, 6, 7);
+        TK_MF(1, 7, 0); TK_MF(1, 7, 1); TK_MF(1, 7, 2); TK_DMA(14); TK_MF(1, 7, 3); TK_MF(1, 7, 4); TK_MF(1, 7, 5); TK_MF(1, 7, 6); TK_DMA(15); TK_MF(1, 7, 7);
+#undef TK_DMA
+    }
+    VMCNT(0);
+#undef TK_PIN
+#undef TK_RDA
+#undef TK_RDB
+#undef TK_MF
+    const int fr = lane & 15, fg = lane >> 4;
+    float* P = partial + ((size_t)bz * p.nsplit + z) * (size_t)N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n1 = a0 + wm * 128 + i * 16 + fr;
+        if (n1 >= N1) continue;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n2 = b0 + wn * 128 + q * 16 + fg * 4;
+            const f32x4 v = acc[q >> 2][i][q & 3];
+            if (n2 + 3 < N2 && (N2 & 3) == 0) *reinterpret_cast<float4*>(P + (size_t)n1 * N2 + n2) = make_float4(v[0], v[1], v[2], v[3]);
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n2 + r < N2) P[(size_t)n1 * N2 + n2 + r] = v[r];
+        }
+    }
+}
+
 // C[bz][n1][n2] = beta*C + alpha * sum_z partial[bz][z][n1][n2]   (fixed order -> deterministic)
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, long long sC, long long sC_in,
                                      int batch_inner, int ldc, int N1, int N2, int splits, float alpha, float beta) {
@@ -2829,6 +2980,12 @@ static int tn_variant(const amdnuwa_gemm_desc* d) {
     if (v == 3 && !(d->M >= 256 && d->N >= 256)) v = 2;
     return v;
 }
+// the four-wave weight-gradient kernel (gemm_tn_w4k_kernel): plain bf16 operands, no token shift, token rows and column counts it can cover
+// without edge handling (tuning key 23 = 1 keeps the 8-wave ring)
+static bool tn_w4k_ok(const amdnuwa_gemm_desc* d) {
+    if (g_amdnuwa_tuning[23] == 1 || d->Alo || d->shift_ntok > 0) return false;
+    return d->K % 64 == 0 && d->K >= 128 && d->M % 8 == 0 && d->N % 8 == 0 && d->M >= 256 && d->N >= 256;
+}
 // split-K policy: fill the workgroup SLOTS of the chip exactly once (256 CUs x resident workgroups per CU);
 // never exceed them (a 257th workgroup would cost a whole extra round), keep >= minrows token rows per split.
 static int tn_splits(const amdnuwa_gemm_desc* d) {
@@ -2868,6 +3025,7 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
     const int splits = tn_splits(d);
     int len = (d->K + splits - 1) / splits;
     len = (len + TK - 1) / TK * TK;
+    if (tn_variant(d) == 3 && d->shift_ntok <= 0 && tn_w4k_ok(d)) len = (len + 63) / 64 * 64;      // whole 64-row iterations per split
     p.ksplit_len = len;
     p.batch_inner = d->batch_inner; p.sA_in = d->strideA_inner; p.sB_in = d->strideB_inner; p.sC_in = d->strideC_inner;
     const int batch = d->batch > 0 ? d->batch : 1;
@@ -2890,6 +3048,12 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
         // the compiler no longer drains the ring before the fragment reads) the lock-step loop gained 15-27 % and passed the staggered
         // one on every weight-gradient shape of the step (r02: dW qkv 466 -> 340 us vs 424 staggered; dW ff1 787 -> 608 vs 773)
         const bool stag = g_amdnuwa_tuning[8] == 2;
+        if (!sh && tn_w4k_ok(d)) {                                               // four waves, 64 token rows per iteration (gemm_tn_w4k_kernel)
+            dim3 b4(256);
+            const size_t l4 = (size_t)2 * 2 * 64 * 256 * 2;
+            (void)hipFuncSetAttribute((const void*)gemm_tn_w4k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+            hipLaunchKernelGGL(gemm_tn_w4k_kernel, g256, b4, l4, stream, p, part);
+        } else
         if (sh) { if (stag) TN256(true, true); else TN256(true, false); }
         else    { if (stag) TN256(false, true); else TN256(false, false); }
 #undef TN256
