@@ -2716,7 +2716,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         }
         const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;
         dim3 g2(q.tiles_m * q.tiles_n, 1), b2(512);
-        if (nt_long_k(d->K, q.dbg) && g_amdnuwa_tuning[0] == 0) {              // long K: four waves of 128x128, K-step 64 (gemm_nt_w4k_kernel)
+        if (nt_long_k(d->K, q.dbg) && (g_amdnuwa_tuning[0] == 0 || g_amdnuwa_tuning[0] == 7)) {              // long K: four waves of 128x128, K-step 64 (gemm_nt_w4k_kernel)
             const size_t l4 = (size_t)2 * 2 * 256 * 64 * 2;
             dim3 b4(256);
             if (d->c_is_bf16) {

@@ -714,6 +714,77 @@ def test_gemm_nt_four_wave_kernel_equals_the_ring(K, M, N, Kd, obf):
     report(f'gemm_nt_w4[{M}x{N}x{Kd}]', outs[1], ref, 2 ** -7 if obf else 1e-5)
 
 
+@pytest.mark.parametrize('M,N,Kd', [(2560, 512, 1536), (4096 + 77, 1536 + 24, 512), (300, 264, 64), (70000, 512, 2752), (2560 * 8, 2752, 1408)])
+def test_gemm_nt_long_k_kernel_equals_the_ring(K, M, N, Kd):
+    """gemm_nt_w4k_kernel (four waves of 128x128, K-step 64, two stages with a 1.5-iteration prefetch; forced for every K % 64 == 0
+    through tuning key 22 = 2) against the 8-wave ring (key 22 = 1): same accumulation order -> bit-identical, on every epilogue it
+    shares with the ring -- fp32 out + bias, bf16 out, bf16 out + GEGLU gate, the GEGLU backward, fp16 operands with an fp16 second
+    copy and with the gate -- ragged edges included; and against fp32 torch on the same operands"""
+    from nuwa_pytorch_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(M % 97)
+    a = (torch.randn(M, Kd, device=DEV) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, Kd, device=DEV) * 0.2).to(torch.bfloat16)
+    A, W = K.BF(a, None), K.BF(w, None)
+    bias = torch.randn(N, device=DEV)
+    gate_ok = N % 32 == 0
+    u = K.BF((torch.randn(M, 2 * N, device=DEV)).to(torch.bfloat16), None) if gate_ok else None
+
+    def run():
+        outs = [K.gemm_nt(A, W, bias=bias, alpha=0.5), K.gemm_nt(A, W, out_bf16=True).hi]
+        if gate_ok:
+            gg = K.empty_bf((M, N // 2), DEV, lo=False)
+            outs += [K.gemm_nt(A, W, out_bf16=True, geglu_out=gg).hi, gg.hi, K.gemm_nt_geglu_bwd(A, W, u, N).hi]
+        if K.gemm_nt_f16ops_ok(M, N, Kd, out_bf16=True):
+            a16, w16 = a.half(), w.half()
+            c = K.gemm_nt_f16ops(a16, w16, out_bf16=True, copy_f16=True)
+            outs += [K.gemm_nt_f16ops(a16, w16), c.hi, c.f16]
+            if gate_ok:
+                outs += list(K.gemm_nt_f16ops(a16, w16, out_bf16=True, gate=True))
+        return [o.float().clone() for o in outs]
+
+    try:
+        L.amdnuwa_set_tuning(0, 7)                  # the 256x256 tile family for every size (auto keeps small problems on smaller tiles)
+        L.amdnuwa_set_tuning(22, 1)
+        ref = run()
+        L.amdnuwa_set_tuning(22, 2)
+        got = run()
+    finally:
+        L.amdnuwa_set_tuning(22, 0)
+        L.amdnuwa_set_tuning(0, 0)
+    assert len(ref) == len(got) and all(torch.equal(x, y) for x, y in zip(ref, got)), [i for i, (x, y) in enumerate(zip(ref, got)) if not torch.equal(x, y)]
+    report(f'gemm_nt_w4k[{M}x{N}x{Kd}]', got[0], 0.5 * (a.float() @ w.float().t()) + bias, 1e-5)
+
+
+@pytest.mark.parametrize('R,N1,N2', [(2560 * 4, 1536, 512), (64 * 37, 2752, 512), (2560 * 2, 520, 264), (128, 256, 256)])
+def test_gemm_tn_four_wave_kernel(K, R, N1, N2):
+    """gemm_tn_w4k_kernel (weight gradients: four waves, 64 token rows per iteration; default when there is no token shift and the row
+    count is a multiple of 64) against fp64 torch on the same bf16 operands and against the 8-wave ring (tuning key 23 = 1; the split
+    boundaries differ, so the comparison is to 2e-6, not bit for bit); bit-repeatable; beta / alpha honoured"""
+    from nuwa_pytorch_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(R % 89)
+    a = K.BF((torch.randn(R, N1, device=DEV) * 0.5).to(torch.bfloat16), None)
+    b = K.BF((torch.randn(R, N2, device=DEV) * 0.5).to(torch.bfloat16), None)
+    ref = (a.hi.double().t() @ b.hi.double()).float()
+    out = torch.empty(N1, N2, device=DEV)
+    K.gemm_tn(a, b, out)
+    again = torch.empty_like(out)
+    K.gemm_tn(a, b, again)
+    assert torch.equal(out, again)
+    report(f'gemm_tn_w4k[{R},{N1},{N2}]', out, ref, 2e-6)
+    try:
+        L.amdnuwa_set_tuning(23, 1)
+        ring = torch.empty_like(out)
+        K.gemm_tn(a, b, ring)
+    finally:
+        L.amdnuwa_set_tuning(23, 0)
+    report(f'gemm_tn_w4k_vs_ring[{R},{N1},{N2}]', out, ring, 2e-6)
+    acc = torch.ones(N1, N2, device=DEV)
+    K.gemm_tn(a, b, acc, beta=1.0)
+    report(f'gemm_tn_w4k_beta[{R},{N1},{N2}]', acc, ref + 1.0, 2e-6)
+
+
 @pytest.mark.parametrize('B,n,T', [(2, 96, 33), (1, 64, 256), (3, 160, 100), (2, 32, 287)])
 def test_cross_attention_bwd_recomputing_key_side(K, O, B, n, T):
     """amdnuwa_xattn2_bwd_rc (query side + recomputing key side, no dS / Pm arrays) against the oracle's autograd and against the
