@@ -2206,8 +2206,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4k_kernel(GemmArgs p, float* 
     unsigned ada[8], adb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        ada[i] = (unsigned)(frow * 512 + ((((wm * 8 + i) ^ ff) << 5) | ((t16 & 3) << 3)));
-        adb[i] = (unsigned)(TB + frow * 512 + ((((wn * 8 + i) ^ ff) << 5) | ((t16 & 3) << 3)));
+        ada[i] = lds0 + (unsigned)(frow * 512 + ((((wm * 8 + i) ^ ff) << 5) | ((t16 & 3) << 3)));
+        adb[i] = lds0 + (unsigned)(TB + frow * 512 + ((((wn * 8 + i) ^ ff) << 5) | ((t16 & 3) << 3)));
     }
     bf16x8 af[2][8], bfr[2][8];
 #pragma unroll
@@ -2215,14 +2215,20 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4k_kernel(GemmArgs p, float* 
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[h][i] = bfr[h][i] = bf16x8{};
     auto rd = [&](unsigned addr) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + addr));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + addr + 2048));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(size_t)addr);              // (a 32-bit LDS address, lds0 included: no generic-pointer arithmetic per read)
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(size_t)(addr + 2048u));
         const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
 #define TK_PIN() __builtin_amdgcn_sched_barrier(0)
-#define TK_RDA(H, I, SO) do { af[H][I] = rd(ada[I] + (SO) + (H) * 16384); TK_PIN(); } while (0)
-#define TK_RDB(H, Q, SO) do { bfr[H][Q] = rd(adb[Q] + (SO) + (H) * 16384); TK_PIN(); } while (0)
+    // the fragments of a K half, named as VGPR operands where the half starts to be multiplied: without it the register allocator lets some
+    // ds_read results land in AGPRs (legal on gfx950) and shuffles accumulator tuples around them, ~80 v_accvgpr moves per iteration
+#define TK_VGPR(H)                                                                                                              \
+    asm volatile("" : "+v"(af[H][0]), "+v"(af[H][1]), "+v"(af[H][2]), "+v"(af[H][3]), "+v"(af[H][4]), "+v"(af[H][5]), "+v"(af[H][6]),      \
+                 "+v"(af[H][7]), "+v"(bfr[H][0]), "+v"(bfr[H][1]), "+v"(bfr[H][2]), "+v"(bfr[H][3]), "+v"(bfr[H][4]), "+v"(bfr[H][5]),   \
+                 "+v"(bfr[H][6]), "+v"(bfr[H][7]))
+#define TK_RDA(H, I, SO) do { af[H][I] = rd(ada[I] + (H) * 16384); TK_PIN(); } while (0)
+#define TK_RDB(H, Q, SO) do { bfr[H][Q] = rd(adb[Q] + (H) * 16384); TK_PIN(); } while (0)
 #define TK_MF(H, I, Q) do { acc[(Q) >> 2][I][(Q) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[H][Q], af[H][I], acc[(Q) >> 2][I][(Q) & 3], 0, 0, 0); TK_PIN(); } while (0)
     if (nit > 0) {
 #pragma unroll
@@ -2237,8 +2243,11 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4k_kernel(GemmArgs p, float* 
     TK_PIN();
     // (one branch-free body: past the end of the split the staging repeats the last step into the stage just consumed -- see gemm_nt_w4k_kernel)
     for (int it = 0; it < nit; ++it) {
-        const unsigned so = (unsigned)((it & 1) * STG), sn = (unsigned)(((it + 1) & 1) * STG);
+        const unsigned so = 0u, sn = 0u;             // (the 16 fragment address registers follow the stage: flipped once per iteration, below)
+        const int flip = (it & 1) ? -STG : STG;
         const int it2 = min(it + 2, nit - 1);
+        TK_VGPR(0);
+        TK_PIN();
 #define TK_DMA(Q) do { issue_piece(Q, it & 1, it2); TK_PIN(); } while (0)
         // ---- P1: half 0 from registers; the reads of half 1 (16 fragments = 32 reads) between the MFMAs of rows 0 - 3
 #define TK_ROW_P1(I, R0, R1, R2, R3)                                                                                \
@@ -2252,11 +2261,15 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4k_kernel(GemmArgs p, float* 
 #undef TK_ROW_P1
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                            // every wave is done with stage it & 1
+        TK_VGPR(1);
         TK_PIN();
         // ---- P2: half 1 from registers; eight pieces of iteration it + 2, then iteration it + 1 is awaited and its half 0 read (rows 4 - 6)
+#define TK_FLIP(X) do { ada[X] += flip; adb[X] += flip; TK_PIN(); } while (0)
 #define TK_ROW_P2A(I, Q0)                                                                                            \
-        TK_MF(1, I, 0); TK_DMA(Q0); TK_MF(1, I, 1); TK_MF(1, I, 2); TK_MF(1, I, 3); TK_MF(1, I, 4); TK_DMA(Q0 + 1); TK_MF(1, I, 5); TK_MF(1, I, 6); TK_MF(1, I, 7)
+        TK_MF(1, I, 0); TK_DMA(Q0); TK_MF(1, I, 1); TK_MF(1, I, 2); TK_FLIP(2 * ((I) & 3)); TK_MF(1, I, 3); TK_MF(1, I, 4); TK_DMA(Q0 + 1);  \
+        TK_MF(1, I, 5); TK_MF(1, I, 6); TK_FLIP(2 * ((I) & 3) + 1); TK_MF(1, I, 7)
         TK_ROW_P2A(0, 0); TK_ROW_P2A(1, 2); TK_ROW_P2A(2, 4); TK_ROW_P2A(3, 6);
+#undef TK_FLIP
 #undef TK_ROW_P2A
         VMCNT(8);
         __builtin_amdgcn_s_barrier();
@@ -2272,6 +2285,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4k_kernel(GemmArgs p, float* 
     }
     VMCNT(0);
 #undef TK_PIN
+#undef TK_VGPR
 #undef TK_RDA
 #undef TK_RDB
 #undef TK_MF
