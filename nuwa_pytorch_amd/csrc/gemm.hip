@@ -2148,7 +2148,7 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmArgs p, float* __r
 // prefetch: the weight-gradient form of gemm_nt_w4k_kernel (same schedule, same reasons; see there).  Operand tiles are
 // [64 token rows][256 columns] in the layout of gemm_tn_256_kernel (512-byte rows, 32-byte XOR swizzle), fragments come from
 // ds_read_b64_tr_b16 pairs (two per fragment: 32 + 32 reads per K half).  No token shift; every split covers a multiple of 64 rows
-// (host side); columns past N1 / N2 are clamped (they only feed outputs that are never stored).
+// (host side); columns past the leading dimension are clamped (columns past N1 / N2 only feed outputs that are never stored).
 // Accumulation order per output element = token rows ascending in chunks of 32, as gemm_tn_256_kernel: bit-identical partials.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void gemm_tn_w4k_kernel(GemmArgs p, float* __restrict__ partial) {
@@ -2178,8 +2178,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4k_kernel(GemmArgs p, float* 
         const int row = (j * 4 + wave) * 2 + (lane >> 5);
         const int ps = lane & 31;
         const int cc16 = ((((ps >> 1) ^ tn_f(row)) << 1) | (ps & 1));
-        offa[j] = (unsigned)((row * p.lda + min(a0 + cc16 * 8, N1 - 8)) * 2);
-        offb[j] = (unsigned)((row * p.ldb + min(b0 + cc16 * 8, N2 - 8)) * 2);
+        offa[j] = (unsigned)((row * p.lda + min(a0 + cc16 * 8, p.lda - 8)) * 2);         // (the row is readable up to its leading dimension)
+        offb[j] = (unsigned)((row * p.ldb + min(b0 + cc16 * 8, p.ldb - 8)) * 2);
     }
     const size_t itA = (size_t)64 * p.lda * 2, itB = (size_t)64 * p.ldb * 2;
     auto issue_piece = [&](int q, int stage, int it) {            // q = 0..7: A pieces, 8..15: B pieces
@@ -2998,7 +2998,7 @@ static int tn_variant(const amdnuwa_gemm_desc* d) {
 // without edge handling (tuning key 23 = 1 keeps the 8-wave ring)
 static bool tn_w4k_ok(const amdnuwa_gemm_desc* d) {
     if (g_amdnuwa_tuning[23] == 1 || d->Alo || d->shift_ntok > 0) return false;
-    return d->K % 64 == 0 && d->K >= 128 && d->M % 8 == 0 && d->N % 8 == 0 && d->M >= 256 && d->N >= 256;
+    return d->K % 64 == 0 && d->K >= 128 && d->M >= 256 && d->N >= 256;
 }
 // split-K policy: fill the workgroup SLOTS of the chip exactly once (256 CUs x resident workgroups per CU);
 // never exceed them (a 257th workgroup would cost a whole extra round), keep >= minrows token rows per split.

@@ -756,7 +756,7 @@ def test_gemm_nt_long_k_kernel_equals_the_ring(K, M, N, Kd):
     report(f'gemm_nt_w4k[{M}x{N}x{Kd}]', got[0], 0.5 * (a.float() @ w.float().t()) + bias, 1e-5)
 
 
-@pytest.mark.parametrize('R,N1,N2', [(2560 * 4, 1536, 512), (64 * 37, 2752, 512), (2560 * 2, 520, 264), (128, 256, 256)])
+@pytest.mark.parametrize('R,N1,N2', [(2560 * 4, 1536, 512), (64 * 37, 2752, 512), (2560 * 2, 520, 264), (128, 256, 256), (2560, 512, 1365)])
 def test_gemm_tn_four_wave_kernel(K, R, N1, N2):
     """gemm_tn_w4k_kernel (weight gradients: four waves, 64 token rows per iteration; default when there is no token shift and the row
     count is a multiple of 64) against fp64 torch on the same bf16 operands and against the 8-wave ring (tuning key 23 = 1; the split
@@ -765,23 +765,25 @@ def test_gemm_tn_four_wave_kernel(K, R, N1, N2):
     L = _lib.lib()
     torch.manual_seed(R % 89)
     a = K.BF((torch.randn(R, N1, device=DEV) * 0.5).to(torch.bfloat16), None)
-    b = K.BF((torch.randn(R, N2, device=DEV) * 0.5).to(torch.bfloat16), None)
+    ldb = (N2 + 15) // 16 * 16                           # (an output width that is no multiple of 8: the operand rows are padded, as FF2's gate output)
+    bfull = (torch.randn(R, ldb, device=DEV) * 0.5).to(torch.bfloat16)
+    b = K.BF(bfull[:, :N2] if ldb != N2 else bfull, None)
     ref = (a.hi.double().t() @ b.hi.double()).float()
     out = torch.empty(N1, N2, device=DEV)
-    K.gemm_tn(a, b, out)
+    K.gemm_tn(a, b, out, N2=N2)
     again = torch.empty_like(out)
-    K.gemm_tn(a, b, again)
+    K.gemm_tn(a, b, again, N2=N2)
     assert torch.equal(out, again)
     report(f'gemm_tn_w4k[{R},{N1},{N2}]', out, ref, 2e-6)
     try:
         L.amdnuwa_set_tuning(23, 1)
         ring = torch.empty_like(out)
-        K.gemm_tn(a, b, ring)
+        K.gemm_tn(a, b, ring, N2=N2)
     finally:
         L.amdnuwa_set_tuning(23, 0)
     report(f'gemm_tn_w4k_vs_ring[{R},{N1},{N2}]', out, ring, 2e-6)
     acc = torch.ones(N1, N2, device=DEV)
-    K.gemm_tn(a, b, acc, beta=1.0)
+    K.gemm_tn(a, b, acc, beta=1.0, N2=N2)
     report(f'gemm_tn_w4k_beta[{R},{N1},{N2}]', acc, ref + 1.0, 2e-6)
 
 
