@@ -1535,7 +1535,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
 //                                            in stage s ^ 1), then the 16 reads of ITS half 0
 // Operand rows travel as full 128-byte lines (8 rows x 128 B per 1-KiB DMA piece; half the L2 requests of the K-step 32 ring), source
 // = a scalar base advanced by 128 bytes per iteration + a constant per-lane byte offset.  Every instruction of the loop is placed by
-// hand (sched_barrier between the slots): one MFMA, at most one other instruction, one MFMA ...  Needs K % 64 == 0.
+// hand (sched_barrier between the slots): one MFMA, at most one other instruction, one MFMA ...  K % 32 == 0 (an odd last half is zeroed).
 // Accumulation order per output element = k ascending in chunks of 32, as every other NT kernel here: bit-identical results.
 // ---------------------------------------------------------------------------------------------
 template <int EPI, bool F16>
@@ -1565,8 +1565,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4k_kernel(GemmArgs p) {
         offa[j] = (unsigned)((ra * p.lda + (((lane & 7) ^ (row & 7)) * 8)) * 2);
         offb[j] = (unsigned)((rb * p.ldb + (((lane & 7) ^ b64_swz<EPI>(row)) * 8)) * 2);
     }
+    // K % 64 == 32 (FF2's 1376; K >= 96): one more iteration, staged from k = K - 64 (so that nothing past the end of a row is read): its
+    // first half repeats the previous iteration's second half and is ZEROED in registers before it is multiplied, its second half is the
+    // last 32 of K.  The sums are exact (x + 0 * finite) and keep their order.
+    const bool odd = (p.K & 63) != 0;
+    const int nit = (p.dbg & 2) ? 0 : (p.K + 63) / 64;
     auto issue_piece = [&](int q, int stage, int it) {            // q = 0..7: A pieces, 8..15: B pieces
-        const char* sb = (q < 8 ? baseA : baseB) + (size_t)it * 128;
+        const char* sb = (q < 8 ? baseA : baseB) + (size_t)it * 128 - ((odd && it == nit - 1) ? 64 : 0);
         const unsigned long long sbu = (unsigned long long)sb;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sbu), hi = __builtin_amdgcn_readfirstlane((unsigned)(sbu >> 32));
         const unsigned long long sbase = ((unsigned long long)hi << 32) | lo;
@@ -1583,7 +1588,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4k_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nit = (p.dbg & 2) ? 0 : p.K / 64;
     const int fr = lane & 15, fg = lane >> 4;
     // fragment addresses (stage 0), per K half h: A fragment i at + i * 2048; B fragment (c, j) at + c * 8192 + j * JB
     constexpr int JB = EPI >= 1 ? 512 : 2048;
@@ -1674,6 +1678,15 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4k_kernel(GemmArgs p) {
 #undef WK_ROW_P2B
 #undef WK_DMA
         WK_LGKM0(0);
+        {   // (a mask, not a branch: a branch here costs the loop its register assignment)
+            const unsigned keep = (odd && it == nit - 2) ? 0u : 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint4 u = __builtin_bit_cast(uint4, af[0][i]);
+                u.x &= keep; u.y &= keep; u.z &= keep; u.w &= keep;
+                af[0][i] = __builtin_bit_cast(bf16x8, u);
+            }
+        }
         WK_PIN();
     }
     VMCNT(0);                                    // (the redundant pieces of the last two iterations: nothing may land in LDS after the workgroup has left)
@@ -2545,8 +2558,9 @@ static int nt_persistent_grid() {
 // every K that is a multiple of 64)
 static bool nt_long_k(int K, int dbg) {
     const int v = g_amdnuwa_tuning[22];
-    if (v == 1 || K % 64 || (dbg & 2)) return false;
-    return v == 2 || K >= 1024;
+    if (v == 1 || K % 32 || K < 96 || (dbg & 2)) return false;
+    // (K % 64 == 32 -- FF2's 1376 -- works, bit-identical, and ties the K-step 64 ring at 592-606 vs 575-662 us: only on request)
+    return v == 2 || (K >= 1024 && K % 64 == 0);
 }
 static bool nt_persistent(long long tiles, int K, int dbg) {
     const int v = g_amdnuwa_tuning[20];

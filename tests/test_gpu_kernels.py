@@ -714,7 +714,8 @@ def test_gemm_nt_four_wave_kernel_equals_the_ring(K, M, N, Kd, obf):
     report(f'gemm_nt_w4[{M}x{N}x{Kd}]', outs[1], ref, 2 ** -7 if obf else 1e-5)
 
 
-@pytest.mark.parametrize('M,N,Kd', [(2560, 512, 1536), (4096 + 77, 1536 + 24, 512), (300, 264, 64), (70000, 512, 2752), (2560 * 8, 2752, 1408)])
+@pytest.mark.parametrize('M,N,Kd', [(2560, 512, 1536), (4096 + 77, 1536 + 24, 512), (300, 264, 64), (70000, 512, 2752), (2560 * 8, 2752, 1408),
+                                    (2560 * 8, 512, 1376), (1000, 600, 96), (777, 512, 160)])       # (the last three: K % 64 == 32, the zeroed half iteration)
 def test_gemm_nt_long_k_kernel_equals_the_ring(K, M, N, Kd):
     """gemm_nt_w4k_kernel (four waves of 128x128, K-step 64, two stages with a 1.5-iteration prefetch; forced for every K % 64 == 0
     through tuning key 22 = 2) against the 8-wave ring (key 22 = 1): same accumulation order -> bit-identical, on every epilogue it
