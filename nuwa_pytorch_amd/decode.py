@@ -151,7 +151,7 @@ class IncrementalDecoder:
         for i, blk in enumerate(blocks):
             inner = blk.inner
             for d in blk.store_before:
-                d.store(state[blk.src])
+                d.store(state[blk.src], self.pos_dev)
             raw = blk.post is None                  # (an un-normed block adds its fp32 output itself)
             if blk.kind == 's3':
                 p = inner._params()
@@ -196,7 +196,7 @@ class IncrementalDecoder:
                 h = self._enter(x, nxt)
             state[blk.dst] = x
             for d in blk.store_after:
-                d.store(x)
+                d.store(x, self.pos_dev)
         return x if self.halves == 1 else (state[0] + state[1]) * self.combine
 
 
@@ -287,7 +287,11 @@ class _XmDirection:
         # frame f is rows [f * cc, (f + 1) * cc)
         self.kv = K.zeros_bf((batch, self.cc - 1 + ctx_rows, 2 * self.inner), dev, lo=lo)
         self.g = K.x_geom(batch, 1, self.cc, mod.heads, mod.dim_head)
-        self.n_ctx, self.n_q, self.frame, self.pk, self.corr = 0, 0, -1, None, None
+        # n_ctx / n_q: HOST row counters (advanced by the decoder that owns the streams, never inside a captured graph);
+        # pk / corr: persistent buffers, re-packed in place at every frame border (a captured step keeps reading them)
+        self.n_ctx, self.n_q, self.frame = 0, 0, -1
+        self.pk = K.PackedKV(self.g, dev, lo)
+        self.corr = torch.zeros((batch, mod.to_out.weight.shape[0]), dtype=torch.float32, device=dev)
 
     def _weights(self):
         m, h = self.mod, self.mod.heads
@@ -295,14 +299,14 @@ class _XmDirection:
              m.to_q.weight, m.to_kv.weight, m.to_out.weight)
         return ops.XInner.weights(m._cache, p)
 
-    def store(self, x):
-        """x fp32 [B, D]: the next context row"""
+    def store(self, x, pos_dev):
+        """x fp32 [B, D]: the context stream's row `pos_dev` (its position counter, in device memory: the write is indexed on the device
+        so that the step can be replayed from a captured graph)"""
         kv = K.gemm_nt(_cast_row(x, self.lo), self._weights()['kv'], out_bf16=True)
-        at = self.cc - 1 + self.n_ctx
-        self.kv.hi[:, at].copy_(kv.hi)
+        at = (pos_dev + (self.cc - 1)).long()
+        self.kv.hi.index_copy_(1, at, kv.hi[:, None])
         if self.kv.lo is not None:
-            self.kv.lo[:, at].copy_(kv.lo)
-        self.n_ctx += 1
+            self.kv.lo.index_copy_(1, at, kv.lo[:, None])
 
     def _pack(self, f):
         m, cc = self.mod, self.cc
@@ -312,18 +316,21 @@ class _XmDirection:
         kv = K.BF(self.kv.hi[:, sl].reshape(self.B * cc, 2 * self.inner).contiguous(),
                   self.kv.lo[:, sl].reshape(self.B * cc, 2 * self.inner).contiguous() if self.kv.lo is not None else None)
         h, dh = m.heads, m.dim_head
-        self.pk = K.xattn_pack(self.g, kv, m.null_k.detach().reshape(h, dh).contiguous(), m.null_v.detach().reshape(h, dh).contiguous(), None)
+        K.xattn_pack(self.g, kv, m.null_k.detach().reshape(h, dh).contiguous(), m.null_v.detach().reshape(h, dh).contiguous(), None, out=self.pk)
         v = kv.hi[:, self.inner:].float()
         if kv.lo is not None:
             v = v + kv.lo[:, self.inner:].float()
         vsum = m.null_v.detach().reshape(1, h, dh) + v.reshape(self.B, cc, h, dh).sum(1)
-        self.corr = F.linear((m.talking_heads.bias.detach()[None, :, None] * vsum).reshape(self.B, self.inner), m.to_out.weight.detach())
+        self.corr.copy_(F.linear((m.talking_heads.bias.detach()[None, :, None] * vsum).reshape(self.B, self.inner), m.to_out.weight.detach()))
         self.frame = f
 
+    def needs_eager_row(self, r):
+        """query row r cannot be replayed from the graph of an ordinary row: the start token (outputs 0) or the first row of a frame (packs)"""
+        return r == 0 or (r - 1) // self.c != self.frame
+
     def attend(self, h):
-        """h BF [B, D]: the operand row of the next query (pre-normed by the caller where the block has norms) -> fp32 [B, D]"""
+        """h BF [B, D]: the operand row of query row n_q (pre-normed by the caller where the block has norms) -> fp32 [B, D]"""
         r, m = self.n_q, self.mod
-        self.n_q += 1
         if r == 0:
             return torch.zeros((self.B, m.to_out.weight.shape[0]), dtype=torch.float32, device=h.hi.device)
         f = (r - 1) // self.c
@@ -376,10 +383,30 @@ class DualIncrementalDecoder:
         self.streams = {key: IncrementalDecoder(None, batch, rows, context, context_mask, self.pos[key], block_list=lists[key], halves=halves)
                         for key, rows in (('v', rows_v), ('a', rows_a))}
 
-    def step(self, which, x):
+    def directions(self, which):
+        """(_XmDirection objects this stream QUERIES through, those it STORES context rows for)"""
+        blocks = self.streams[which].blocks
+        return [b.xm for b in blocks if b.xm is not None], [d for b in blocks for d in tuple(b.store_before) + tuple(b.store_after)]
+
+    def needs_eager_row(self, which):
+        return any(d.needs_eager_row(d.n_q) for d in self.directions(which)[0])
+
+    def step(self, which, x, tick=True):
+        """one row of stream `which`.  tick=False: the device work only (capturable in a HIP graph: no host-side state changes); the
+        caller then calls tick() once per issued or replayed row"""
         out = self.streams[which].step(x.contiguous())
         self.pos[which] += 1
+        if tick:
+            self.tick(which)
         return out
+
+    def tick(self, which):
+        """host bookkeeping of the row step() has just been issued (or replayed) for"""
+        q, st = self.directions(which)
+        for d in q:
+            d.n_q += 1
+        for d in st:
+            d.n_ctx += 1
 
 
 class DualGuidedStepper:
@@ -387,13 +414,19 @@ class DualGuidedStepper:
     logits for that stream's next token; with cond_scale != 1 the final-normed conditioned output row is the input of a second,
     text-masked pass (np.py:2176-2186) and the two logits are mixed."""
 
-    def __init__(self, model, text_embeds, text_mask, rows_v, rows_a, cond_scale):
+    def __init__(self, model, text_embeds, text_mask, rows_v, rows_a, cond_scale, graph=True):
         self.m, self.cond_scale = model, cond_scale
         dec = model.video_audio_transformer
-        B = text_embeds.shape[0]
+        B, D = text_embeds.shape[0], text_embeds.shape[-1]
         self.cond = DualIncrementalDecoder(dec, B, rows_v, rows_a, text_embeds, text_mask)
         self.uncond = DualIncrementalDecoder(dec, B, rows_v, rows_a, text_embeds, torch.zeros_like(text_mask).bool()) \
             if cond_scale != 1 else None
+        # One captured HIP graph per stream for its ORDINARY rows (every row but a stream's start token and the first row of a frame,
+        # where a cross-modality direction re-packs the other stream's frame on the host): static input / output buffers, positions
+        # and context-row writes indexed on the device.
+        self._want_graph = graph
+        self.x_in = {k: torch.zeros(B, D, dtype=torch.float32, device=text_embeds.device) for k in 'va'}
+        self.graphs, self.glogits = {}, {}
 
     def _logits(self, which, hidden):
         m, dec = self.m, self.m.video_audio_transformer
@@ -403,16 +436,56 @@ class DualGuidedStepper:
             nrm, lin, cache = dec.audio_norm.norm, m.to_audio_logits, m._cache_a
         return ops.LogitsFn.apply(hidden[:, None].contiguous(), nrm.weight, nrm.bias, lin.weight, cache)[:, 0]
 
-    def advance(self, which, x_row):
+    def _body(self, which):
         dec = self.m.video_audio_transformer
-        hidden = self.cond.step(which, x_row)
+        hidden = self.cond.step(which, self.x_in[which], tick=False)
         logits = self._logits(which, hidden)
         if self.uncond is not None:
             nrm = dec.video_norm if which == 'v' else dec.audio_norm
-            uh = self.uncond.step(which, nrm(hidden[:, None])[:, 0])
+            uh = self.uncond.step(which, nrm(hidden[:, None])[:, 0], tick=False)
             ul = self._logits(which, uh)
             logits = ul + (logits - ul) * self.cond_scale
         return logits
+
+    def _tick(self, which):
+        self.cond.tick(which)
+        if self.uncond is not None:
+            self.uncond.tick(which)
+
+    def advance(self, which, x_row):
+        self.x_in[which].copy_(x_row)
+        eager = not self._want_graph or self.cond.needs_eager_row(which) or (self.uncond is not None and self.uncond.needs_eager_row(which))
+        if eager:
+            logits = self._body(which)
+            self._tick(which)
+            return logits
+        if which not in self.graphs:
+            # warm-up on a side stream (workspaces, weight caches), positions rewound, then capture; the rows the warm-up wrote are
+            # rewritten by the real step at the same positions
+            decs = [self.cond] + ([self.uncond] if self.uncond is not None else [])
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._body(which)
+                for d in decs:
+                    d.pos[which] -= 1
+            torch.cuda.current_stream().wait_stream(s)
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.glogits[which] = self._body(which)
+                self.graphs[which] = g
+            except RuntimeError as e:
+                import warnings
+                warnings.warn(f'nuwa_pytorch_amd: HIP graph capture of the dual decode step failed ({e}); launching eagerly')
+                self._want_graph = False
+                torch.cuda.synchronize()
+                logits = self._body(which)
+                self._tick(which)
+                return logits
+        self.graphs[which].replay()
+        self._tick(which)
+        return self.glogits[which].clone()
 
 
 class GuidedStepper:

@@ -845,9 +845,15 @@ class PackedKV:
         return self
 
 
-def xattn_pack(g, kv, null_k, null_v, mask_u8):
-    """kv with an f16 copy: the lo images of the result are FP16 images (for xattn2_fwd_f16), not bf16 residuals"""
+def xattn_pack(g, kv, null_k, null_v, mask_u8, out=None):
+    """kv with an f16 copy: the lo images of the result are FP16 images (for xattn2_fwd_f16), not bf16 residuals.
+    out: a PackedKV of the same geometry / operand form to pack INTO (a captured HIP graph keeps reading the same buffers)"""
     L = _lib.lib()
+    if out is not None:
+        assert kv.f16 is None and (out.Kp.lo is not None) == (kv.lo is not None)
+        check(L.amdnuwa_xattn_pack(C.byref(g), _p(kv.hi), _p(kv.lo), kv.hi.stride(0), _p(null_k), _p(null_v), _p(mask_u8),
+                                   C.byref(out.struct), _stream()), 'amdnuwa_xattn_pack')
+        return out
     if kv.f16 is not None:
         pk = PackedKV(g, kv.hi.device, True)
         check(L.amdnuwa_xattn_pack_f16(C.byref(g), _p(kv.hi), _p(kv.f16), kv.hi.stride(0), _p(null_k), _p(null_v), _p(mask_u8),

@@ -491,6 +491,7 @@ class NUWAVideoAudio(nn.Module):
     """np.py:1968-2293: identical constructor kwargs and forward() signature (training loss / logits)."""
 
     generate_use_cache = True          # key/value-cached generate() (decode.DualGuidedStepper; plain and reversible dual decoder)
+    generate_use_graph = True          # ... with the ordinary rows of each stream replayed from a captured HIP graph
 
     def __init__(self, *, vae, dim, image_size, num_audio_tokens, num_audio_tokens_per_video_frame, audio_tokens_per_timestep=1,
                  max_video_frames=5, text_num_tokens=49408, text_max_seq_len=256, text_enc_depth=6, text_enc_dim_head=64,
@@ -588,7 +589,8 @@ class NUWAVideoAudio(nn.Module):
         if self.generate_use_cache and num_frames <= self.max_video_frames:
             try:
                 from .decode import DualGuidedStepper
-                stepper = DualGuidedStepper(self, text_embeds, text_mask, total_video_tokens + 1, total_audio_tokens + 1, cond_scale)
+                stepper = DualGuidedStepper(self, text_embeds, text_mask, total_video_tokens + 1, total_audio_tokens + 1, cond_scale,
+                                            graph=self.generate_use_graph)
             except NotImplementedError:
                 stepper = None                  # a block outside the single-row kernels: the recompute loop below
             if stepper is not None:

@@ -359,19 +359,20 @@ def test_video_audio_generate_cached_equals_recompute_under_greedy_sampling(A, c
     A.set_precision('bf16x3')
     outs = []
     try:
-        for cached in (True, False):
-            type(m).generate_use_cache = cached
+        for cached, graph in ((True, True), (True, False), (False, False)):
+            type(m).generate_use_cache, type(m).generate_use_graph = cached, graph
             torch.manual_seed(0)
             outs.append(m.generate(text=text, filter_thres=0.99, cond_scale=cond_scale, num_frames=2))
     finally:
-        type(m).generate_use_cache = True
+        type(m).generate_use_cache = type(m).generate_use_graph = True
         A.set_precision('bf16')
-    (v0, a0), (v1, a1) = outs
+    (vg, ag), (v0, a0), (v1, a1) = outs
     assert v0.shape == (2, 2, 3, 16, 16) and a0.shape == (2, 2 * m.num_audio_tokens_per_video_frame)
     assert torch.equal(a0, a1) and torch.equal(v0, v1)
+    assert torch.equal(ag, a1) and torch.equal(vg, v1)          # the ordinary rows replayed from the two captured HIP graphs
 
 
-@pytest.mark.parametrize('cached', [True, False])
+@pytest.mark.parametrize('cached', [True, 'eager', False])
 @pytest.mark.parametrize('name', ['g13a_generate_nuwa', 'g13b_generate_nuwa_reversible', 'g13c_generate_video_audio',
                                   'g13d_generate_video_audio_reversible'])
 def test_generate_reproduces_the_reference_token_ids(A, name, cached):
@@ -392,11 +393,11 @@ def test_generate_reproduces_the_reference_token_ids(A, name, cached):
     text = Ar['text'].to(DEV)
     A.set_precision('bf16x3')
     try:
-        type(m).generate_use_cache = cached
+        type(m).generate_use_cache, type(m).generate_use_graph = bool(cached), cached is True       # 'eager': cached rows, no HIP graph
         torch.manual_seed(0)
         out = m.generate(text=text, filter_thres=0.99, cond_scale=cs, num_frames=2)
     finally:
-        type(m).generate_use_cache = True
+        type(m).generate_use_cache = type(m).generate_use_graph = True
         A.set_precision('bf16')
     assert torch.equal(m.last_generated_ids.cpu(), Ar['video_ids'].long()), (m.last_generated_ids.cpu(), Ar['video_ids'])
     if 'audio_ids' in Ar:

@@ -29,8 +29,8 @@ def main():
     text = torch.randint(1, 49408, (args.batch, 256), generator=torch.Generator().manual_seed(1)).to(dev)
     ntok = args.frames * (256 + 32)
     res = {}
-    for cached in (True, False):
-        type(m).generate_use_cache = cached
+    for cached in (True, 'eager', False):
+        type(m).generate_use_cache, type(m).generate_use_graph = bool(cached), cached is True
         torch.manual_seed(0)
         m.generate(text=text, num_frames=1, cond_scale=args.cond_scale) if cached else None        # warm-up (weight caches)
         torch.cuda.synchronize()
@@ -38,10 +38,10 @@ def main():
         video, audio = m.generate(text=text, num_frames=args.frames, cond_scale=args.cond_scale)
         torch.cuda.synchronize()
         res[cached] = time.perf_counter() - t0
-    type(m).generate_use_cache = True
+    type(m).generate_use_cache = type(m).generate_use_graph = True
     kind = 'plain' if args.plain else 'reversible'
     print(f'cfg 5 ({kind} dual decoder), b={args.batch}, {args.frames} frame(s) = {ntok} tokens per sample, cond_scale={args.cond_scale}: '
-          f'cached {res[True]:.2f} s ({res[True] / ntok * 1e3:.1f} ms/token) | recompute loop {res[False]:.2f} s ({res[False] / ntok * 1e3:.1f} ms/token) | '
+          f'cached + HIP graphs {res[True]:.2f} s ({res[True] / ntok * 1e3:.1f} ms/token) | cached, eager launches {res["eager"]:.2f} s ({res["eager"] / ntok * 1e3:.1f} ms/token) | recompute loop {res[False]:.2f} s ({res[False] / ntok * 1e3:.1f} ms/token) | '
           f'{res[False] / res[True]:.1f}x  (video {tuple(video.shape)}, audio {tuple(audio.shape)})')
 
 
