@@ -5,8 +5,9 @@ cycle (1,2,4), 256 text tokens of context), bf16 MFMA operands, synthetic data, 
 
 The HEADLINE (`value`) is the precision mode that meets BOTH halves of the north star's sentence: 'bf16x3-fwd' = the cheapest
 forward arithmetic that keeps the full-depth logits within 1e-3 of the fp32 reference (measured live below in `parity`):
-bf16 hi + lo operand pairs (3 MFMAs per product) on to_out x2, the cross-attention q / kv projections and to_logits; SINGLE fp16
-MFMAs (fp16 operands, fp32 accumulate) on the Sparse3DNA q / k / v projection, FF1 (+ GEGLU gate), FF2 and both attention cores;
+bf16 hi + lo operand pairs (3 MFMAs per product) on the cross-attention kv projection and to_logits; TWO fp16 MFMAs (fp16 activation x
+the weight as an fp16 hi + lo pair) on to_out x2 and the cross-attention q projection; SINGLE fp16 MFMAs (fp16 operands, fp32
+accumulate) on the Sparse3DNA q / k / v projection, FF1 (+ GEGLU gate), FF2 and both attention cores;
 the backward runs single bf16 MFMAs.  The all-bf16 mode (faster, logits ~8e-3) is timed in the same run as `fast_mode`.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
@@ -402,7 +403,14 @@ def main():
         tokens = world * b * N * args.steps
         value = tokens / dt
         # which parts of the 'bf16x3-fwd' forward run single fp16 MFMAs in THIS run (AMDNUWA_F16_CORES / _FF / _QKV switches)
-        f16_parts = {'cores': bool(K._CORES_F16), 'ff': bool(K._FF_F16), 'qkv': bool(K._QKV_F16 and K._CORES_F16)}
+        x2 = K._PROJ_F16X2 if K._CORES_F16 else (K._PROJ_F16X2 & frozenset('l'))      # (to_out / q take the fp16 cores' operands)
+        f16_parts = {'cores': bool(K._CORES_F16), 'ff': bool(K._FF_F16), 'qkv': bool(K._QKV_F16 and K._CORES_F16),
+                     'two_mfma_products': ''.join(sorted(x2))}
+        three = [nm for nm, cls in (('to_out x2', 'o'), ('cross-attention q projection', 'q'), ('cross-attention kv projection', None), ('to_logits', 'l'))
+                 if cls is None or cls not in x2]
+        three += ([] if f16_parts['cores'] else ['both attention cores']) + ([] if f16_parts['ff'] else ['FF1', 'FF2']) + \
+            ([] if f16_parts['qkv'] else ['3DNA q/k/v projection'])
+        two = [nm for nm, cls in (('to_out x2', 'o'), ('cross-attention q projection', 'q'), ('to_logits', 'l')) if cls in x2]
         fl = fwd_flops_per_sample(c)
         step_flops = 3.0 * fl * b
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -413,9 +421,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'bf16': 'bf16 operands, fp32 accumulate (single bf16 MFMA per product, forward and backward)',
                       'bf16x3': 'bf16 hi+lo operand pairs, fp32 accumulate (3 bf16 MFMAs per product, forward and backward)',
-                      'bf16x3-fwd': 'bf16/fp16 operands, fp32 accumulate -- forward: 3-MFMA bf16 hi+lo pairs on to_out x2, cross-attention q/kv '
-                                    'projections and to_logits' + ('' if f16_parts['cores'] else ' and both attention cores') +
-                                    ('' if f16_parts['ff'] else ', FF1, FF2') + ('' if f16_parts['qkv'] else ', 3DNA q/k/v projection') +
+                      'bf16x3-fwd': 'bf16/fp16 operands, fp32 accumulate -- forward: 3-MFMA bf16 hi+lo pairs on ' + ', '.join(three) +
+                                    ('; 2 fp16 MFMAs (fp16 activation x fp16 hi+lo weight) on ' + ', '.join(two) if two else '') +
                                     '; single fp16 MFMA on ' + (', '.join(nm for nm, on in (('3DNA q/k/v projection', f16_parts['qkv']), ('FF1 + gate', f16_parts['ff']),
                                                                                           ('FF2', f16_parts['ff']), ('Sparse3DNA core', f16_parts['cores']),
                                                                                           ('cross-attention core', f16_parts['cores'])) if on) or 'nothing') +

@@ -31,7 +31,8 @@ typedef struct ihipStream_t* amdnuwa_stream;   /* == hipStream_t */
 
 int amdnuwa_abi_version(void);                 /* bumps when any signature or documented argument meaning below changes (13: tuning keys 0..31,
                                                 * amdnuwa_xattn_unpack's flag bit 1, chunk-permuted dS / Pm columns of amdnuwa_xattn2_bwd;
-                                                * 14: amdnuwa_linear_ce_x3 added) */
+                                                * 14: amdnuwa_linear_ce_x3 added; 15: the two-MFMA products -- amdnuwa_gemm_desc.ab_f16 with Blo, amdnuwa_gemm_nt_f16x2_supported,
+                                                *     o_lo_f16 on the two fp16 forward cores) */
 const char* amdnuwa_error_string(int code);
 /* runtime tuning knobs (A/B benchmarking only; 0 = the library's auto policy everywhere):
  *   key 0  NT GEMM variant: 1 direct-to-LDS BK 64, 2 direct-to-LDS BK 32, 3 / 4 256x256 tile with a 4- / 3-stage DMA ring,
@@ -112,6 +113,11 @@ typedef struct {
      * output itself (q / k / v: bf16 for the backward, fp16 for the forward attention core).  The FeedForward GEMMs (reference nuwa_pytorch.py:255-286) of
      * the 'bf16x3-fwd' forward.  256x256 ring only: amdnuwa_gemm_nt_f16ops_supported() first, AMDNUWA_ERR_UNSUPPORTED otherwise. */
     int ab_f16;
+    /* ab_f16 with Blo != NULL: the TWO-MFMA form -- A = fp16 values (an activation rounded to 11 significand bits), B / Blo = an fp16
+     * hi + lo pair with hi + lo = the fp32 weight to ~22 bits; per 32-chunk of k the products lo*a, hi*a accumulate in fp32.  C: fp32
+     * (+ bias), or bf16 whose optional Clo receives the FP16 rendering of the output.  What the 'bf16x3-fwd' mode runs for to_out, the
+     * cross-attention q / kv projections and to_logits (reference nuwa_pytorch.py:370-379, 611-613, 1956) when its two-MFMA switch is
+     * on.  amdnuwa_gemm_nt_f16x2_supported() first; AMDNUWA_ERR_UNSUPPORTED otherwise. */
 } amdnuwa_gemm_desc;
 
 /* C[M,N] = alpha * A[M,K] . B[N,K]^T (+ bias).  K, lda, ldb multiples of 8. */
@@ -119,6 +125,7 @@ int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, amdnuwa_stream stream);
 /* 1 when the C2 (GEGLU) output of this product is produced inside the GEMM epilogue, 0 when the library will run GEMM + gate kernel */
 int amdnuwa_gemm_nt_fused(const amdnuwa_gemm_desc* d);
 int amdnuwa_gemm_nt_f16ops_supported(const amdnuwa_gemm_desc* d);
+int amdnuwa_gemm_nt_f16x2_supported(const amdnuwa_gemm_desc* d);
 /* 1 when amdnuwa_gemm_nt() honours d->c_lo_f16 for this product (it returns AMDNUWA_ERR_UNSUPPORTED otherwise) */
 int amdnuwa_gemm_nt_f16_fused(const amdnuwa_gemm_desc* d);
 /* out[r][c] = fp16(hi[r][c] + lo[r][c]) over an [R, C] view (row pitches ld_in / ld_out elements, C % 8 == 0) */
@@ -271,8 +278,10 @@ int amdnuwa_sparse3dna_fwd(const amdnuwa_s3_geom* g, const uint16_t* q, const ui
  * (causal window, 16-wide grid, 8 heads x 64, kw <= 3): amdnuwa_s3_f16_supported() says whether it applies.  The forward
  * Sparse3DNA core (reference nuwa_pytorch.py:488-608) of the 'bf16x3-fwd' mode. */
 int amdnuwa_s3_f16_supported(const amdnuwa_s3_geom* g);
+/* o_lo_f16 != 0: o_lo receives the FP16 rendering of the output instead of the bf16 residual -- the A operand of the two-MFMA to_out
+ * product (amdnuwa_gemm_desc.ab_f16 with Blo); o stays the bf16 copy the backward reads. */
 int amdnuwa_sparse3dna_fwd_f16(const amdnuwa_s3_geom* g, const uint16_t* q_f16, const uint16_t* k_f16, const uint16_t* v_f16, int ld,
-                               const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, amdnuwa_stream stream);
+                               const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, int o_lo_f16, amdnuwa_stream stream);
 size_t amdnuwa_sparse3dna_bwd_workspace_bytes(const amdnuwa_s3_geom* g);
 int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* q, const uint16_t* k, const uint16_t* v,
                            const uint16_t* q_lo, const uint16_t* k_lo, const uint16_t* v_lo, int ld,
@@ -394,8 +403,9 @@ int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, 
 /* the same core on SINGLE fp16 MFMAs: q_f16 [B*n, ldq] and the *_lo images of `packed` (written by amdnuwa_xattn_pack_f16) hold fp16
  * values; o leaves as a bf16 hi + lo pair (o_lo may be NULL).  The forward cross-attention core of the 'bf16x3-fwd' mode: with
  * the hi + lo projection GEMMs around it the full-depth logits stay within 1e-3 of the fp32 reference (tools/error_budget.py) */
+/* o_lo_f16: as for amdnuwa_sparse3dna_fwd_f16 */
 int amdnuwa_xattn2_fwd_f16(const amdnuwa_xattn_geom* g, const uint16_t* q_f16, int ldq, const amdnuwa_xattn_kv* packed,
-                           const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, float* stats, amdnuwa_stream stream);
+                           const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, int o_lo_f16, float* stats, amdnuwa_stream stream);
 size_t amdnuwa_xattn2_bwd_workspace_bytes(const amdnuwa_xattn_geom* g);
 /* dS / Pm [B][heads][n][JP]: the keys of every 32-key chunk in the order the kernel's lanes hold them (position 8 g + e of a chunk = key
  * (e < 4 ? 4 g + e : 16 + 4 g + e - 4)): batched amdnuwa_gemm_tn over them yields dKp / dVp rows in the same order, which

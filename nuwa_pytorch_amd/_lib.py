@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # AMDNUWA_LIBRARY: another build of the same library (A/B runs of compiler options inside one process group; tools/ only)
 LIB_PATH = os.environ.get('AMDNUWA_LIBRARY') or os.path.join(HERE, 'lib', 'libamdnuwa.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 P = C.c_void_p
 I = C.c_int
@@ -73,6 +73,7 @@ SIGNATURES = {
     'amdnuwa_gemm_nt_fused': (I, [GD]),
     'amdnuwa_gemm_nt_f16_fused': (I, [GD]),
     'amdnuwa_gemm_nt_f16ops_supported': (I, [GD]),
+    'amdnuwa_gemm_nt_f16x2_supported': (I, [GD]),
     'amdnuwa_hilo_to_f16': (I, [P, P, I, P, I, LL, I, P]),
     'amdnuwa_geglu_il_fwd': (I, [P, P, P, P, LL, I, P]),
     'amdnuwa_geglu_il_bwd': (I, [P, P, P, P, P, P, LL, I, P]),
@@ -90,7 +91,7 @@ SIGNATURES = {
     'amdnuwa_s3_supported': (I, [SG, I]),
     'amdnuwa_sparse3dna_fwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P]),
     'amdnuwa_s3_f16_supported': (I, [SG]),
-    'amdnuwa_sparse3dna_fwd_f16': (I, [SG, P, P, P, I, P, P, P, I, P]),
+    'amdnuwa_sparse3dna_fwd_f16': (I, [SG, P, P, P, I, P, P, P, I, I, P]),
     'amdnuwa_sparse3dna_bwd_workspace_bytes': (SZ, [SG]),
     'amdnuwa_sparse3dna_bwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P, P, P, P, P, P, I, P, I, P, SZ, P]),
     'amdnuwa_cross2dna_fwd': (I, [SG, P, P, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P, I, P]),
@@ -110,7 +111,7 @@ SIGNATURES = {
     'amdnuwa_xattn_unpack': (I, [XG, P, P, P, P, I, P, P, I, P]),
     'amdnuwa_xattn2_supported': (I, [XG]),
     'amdnuwa_xattn2_fwd': (I, [XG, P, I, XK, P, P, I, P, P]),
-    'amdnuwa_xattn2_fwd_f16': (I, [XG, P, I, XK, P, P, P, I, P, P]),
+    'amdnuwa_xattn2_fwd_f16': (I, [XG, P, I, XK, P, P, P, I, I, P, P]),
     'amdnuwa_xattn2_bwd_workspace_bytes': (SZ, [XG]),
     'amdnuwa_xattn2_bwd': (I, [XG, P, I, P, I, XK, P, P, P, P, P, I, P, SZ, P]),
     'amdnuwa_xattn2_bwd_rc_supported': (I, [XG]),

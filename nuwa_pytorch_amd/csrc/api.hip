@@ -7,7 +7,7 @@
 
 int g_amdnuwa_tuning[32] = {0};
 
-extern "C" int amdnuwa_abi_version(void) { return 14; }
+extern "C" int amdnuwa_abi_version(void) { return 15; }
 
 extern "C" int amdnuwa_set_tuning(int key, int value) {
     if (key < 0 || key >= 32) return AMDNUWA_ERR_ARG;

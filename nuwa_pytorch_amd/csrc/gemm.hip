@@ -1342,11 +1342,17 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
 // Accumulation order per output element (k ascending; per 32-chunk lo*hi, hi*lo, hi*hi) equals gemm_nt_kernel<true,...>'s, so
 // the two kernels agree bit for bit.
 // ---------------------------------------------------------------------------------------------
-template <int EPI>      // 0: fp32 out (+bias);  1: bf16 hi [+ lo] out (+bias);  2 / 3: the two passes of the fused cross entropy (ce_epilogue)
+// X2: the TWO-MFMA form of the same ring (amdnuwa_gemm_desc.ab_f16 with Blo): A is ONE fp16 image (an activation rounded to 11 significand
+// bits), B an fp16 hi + lo pair (the weight to ~22 bits); per 32-chunk lo*a then hi*a on v_mfma_f32_16x16x32_f16.  A stage holds three
+// images (A | B hi | B lo, 48 KiB); everything else -- wave layout, B-row permutation, epilogues -- is the three-MFMA kernel's.
+// (A third 48 KiB stage fits and was measured: a tie on all three shapes, 407 / 420 / 6441 us with two stages against 411 / 423 / 6486 --
+// the loop is not waiting for its DMA.)
+template <int EPI, bool X2 = false>      // 0: fp32 out (+bias);  1: bf16 hi [+ lo] out (+bias);  2 / 3: the two passes of the fused cross entropy (ce_epilogue)
 __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 256 * 32 * 2;             // one operand image of a stage: 16 KiB
-    constexpr int STG = 4 * TB;                  // A hi | A lo | B hi | B lo
+    constexpr int STG = (X2 ? 3 : 4) * TB;       // A hi | A lo | B hi | B lo   (X2: A | B hi | B lo)
+    constexpr int OBH = (X2 ? 1 : 2) * TB, OBL = OBH + TB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -1376,9 +1382,9 @@ __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
             const int po = (j * 8 + wave) * 1024;
             const bool ina = offa[j] >= 0, inb = offb[j] >= 0;
             dma16_asm(ina ? p.A + offa[j] + k0 : zp, base + po);
-            dma16_asm(ina ? p.Alo + offa[j] + k0 : zp, base + TB + po);
-            dma16_asm(inb ? p.B + offb[j] + k0 : zp, base + 2 * TB + po);
-            dma16_asm(inb ? p.Blo + offb[j] + k0 : zp, base + 3 * TB + po);
+            if constexpr (!X2) dma16_asm(ina ? p.Alo + offa[j] + k0 : zp, base + TB + po);
+            dma16_asm(inb ? p.B + offb[j] + k0 : zp, base + OBH + po);
+            dma16_asm(inb ? p.Blo + offb[j] + k0 : zp, base + OBL + po);
         }
     };
 
@@ -1405,8 +1411,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int o = b256_off<EPI>(wn * 64 + b256_row<EPI>(j, fr), fg);
-            bh[j] = *reinterpret_cast<const bf16x8*>(base + 2 * TB + o);
-            bl[j] = *reinterpret_cast<const bf16x8*>(base + 3 * TB + o);
+            bh[j] = *reinterpret_cast<const bf16x8*>(base + OBH + o);
+            bl[j] = *reinterpret_cast<const bf16x8*>(base + OBL + o);
         }
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -1415,7 +1421,19 @@ __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
             for (int i = 0; i < 4; ++i) {
                 const int o = glds_off<32>(wm * 128 + (hf * 4 + i) * 16 + fr, fg);
                 ah[i] = *reinterpret_cast<const bf16x8*>(base + o);
-                al[i] = *reinterpret_cast<const bf16x8*>(base + TB + o);
+                if constexpr (!X2) al[i] = *reinterpret_cast<const bf16x8*>(base + TB + o);
+            }
+            if constexpr (X2) {
+                // two sweeps over the 16 accumulators of this half (the small term first), fp16 MFMAs
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[hf * 4 + i][j] = mfma16<true>(bl[j], ah[i], acc[hf * 4 + i][j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[hf * 4 + i][j] = mfma16<true>(bh[j], ah[i], acc[hf * 4 + i][j]);
+                continue;
             }
             // three sweeps over the 16 accumulators of this half: consecutive MFMAs never share an accumulator
 #pragma unroll
@@ -2662,6 +2680,16 @@ extern "C" int amdnuwa_gemm_nt_f16ops_supported(const amdnuwa_gemm_desc* d) {
     return (v == 0 || v == 7 || v == 6 || v == 10 || v == 11) ? 1 : 0;          // (6: the 256x128 two-workgroups-per-CU probe of the same ring; 10: the K-step 64 form)
 }
 
+// fp16 A x fp16 (hi + lo) B, two MFMAs per product (d->ab_f16 with Blo): the hi + lo ring's X2 form.  As for the one-MFMA fp16 products
+// there is no tile-count threshold -- the arithmetic of a block must not depend on the batch size.
+extern "C" int amdnuwa_gemm_nt_f16x2_supported(const amdnuwa_gemm_desc* d) {
+    if (!d || !d->A || !d->B || !d->Blo || !d->C || d->Alo || d->shift_ntok > 0 || d->batch > 1 || d->C2 || d->geglu_u) return 0;
+    if (d->K % 32 || d->lda % 8 || d->ldb % 8 || d->M <= 4 * ROWS_MR) return 0;
+    if (d->c_is_bf16 ? (d->N % 8 || d->ldc % 8) : d->Clo != nullptr) return 0;
+    const int v = g_amdnuwa_tuning[0];
+    return (v == 0 || v == 7) ? 1 : 0;
+}
+
 // does this product run on the bf16x3 256x256 ring (the only kernel that writes the fp16 second copy)?
 static bool nt_x3_ring(const amdnuwa_gemm_desc* d) {
     if (!d->Alo || !d->Blo || d->shift_ntok > 0 || d->K % 32 || g_amdnuwa_tuning[13] == 1) return false;
@@ -2690,6 +2718,28 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         }
         if (d->N % 16 || d->ldc2 != d->N / 2) return AMDNUWA_ERR_ARG;
         return amdnuwa_geglu_il_fwd((const uint16_t*)d->C, d->Clo, d->C2, d->C2lo, d->M, d->N / 2, stream);
+    }
+    if (d->ab_f16 && d->Blo) {                 // fp16 activation x fp16 (hi + lo) weight: two MFMAs per product on the hi + lo ring
+        if (!amdnuwa_gemm_nt_f16x2_supported(d)) return AMDNUWA_ERR_UNSUPPORTED;
+        GemmArgs q{};
+        q.A = (const bf16_t*)d->A; q.lda = d->lda; q.B = (const bf16_t*)d->B; q.Blo = (const bf16_t*)d->Blo; q.ldb = d->ldb;
+        q.C = d->C; q.Clo = (bf16_t*)d->Clo; q.ldc = d->ldc; q.bias = d->bias; q.alpha = d->alpha;
+        q.M = d->M; q.N = d->N; q.K = d->K; q.shift_dim = d->K;
+        q.tiles_m = (d->M + 255) / 256; q.tiles_n = (d->N + 255) / 256;
+        q.dbg = g_amdnuwa_tuning[7];
+        q.lo_f16 = d->Clo ? 1 : 0;             // the second copy of a bf16 output is its fp16 rendering (the next fp16 consumer's operand)
+        q.skew = nt_skew((long long)q.tiles_m * q.tiles_n);
+        dim3 g3(q.tiles_m * q.tiles_n, 1), b3(512);
+        const size_t l3 = (size_t)2 * 3 * 256 * 32 * 2;
+        if (d->c_is_bf16) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_256x3_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3);
+            hipLaunchKernelGGL((gemm_nt_256x3_kernel<1, true>), g3, b3, l3, stream, q);
+        } else {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_256x3_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3);
+            hipLaunchKernelGGL((gemm_nt_256x3_kernel<0, true>), g3, b3, l3, stream, q);
+        }
+        LAUNCH_CHECK();
+        return AMDNUWA_OK;
     }
     if (d->ab_f16) {
         if (!amdnuwa_gemm_nt_f16ops_supported(d)) return AMDNUWA_ERR_UNSUPPORTED;

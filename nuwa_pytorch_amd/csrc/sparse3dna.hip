@@ -27,6 +27,7 @@ namespace {
 struct S3Args {
     const bf16_t *q, *k, *v, *ql, *kl, *vl; int ld;       // q/k/v rows: [B*ntok, ld]
     bf16_t *o, *ol; int ldo;                              // fwd out
+    int ol_f16;                                           // fp16 forward: ol receives the FP16 rendering of the output (the to_out GEMM's fp16 operand), not the bf16 residual
     const bf16_t *dO, *dOl; int lddo;                     // bwd in
     bf16_t *dq, *dk, *dv, *dql, *dkl, *dvl; int ldd;      // bwd out
     const float* wth;                                     // [NH][NH] talking heads (g, h)
@@ -1166,7 +1167,7 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
                 bf16_t hi, lo;
                 f2bf_hilo((float)__builtin_bit_cast(_Float16, raw), hi, lo);
                 a.o[((size_t)b * a.ntok) * a.ldo + e] = hi;
-                if (a.ol) a.ol[((size_t)b * a.ntok) * a.ldo + e] = lo;
+                if (a.ol) a.ol[((size_t)b * a.ntok) * a.ldo + e] = a.ol_f16 ? raw : lo;
             } else a.o[((size_t)b * a.ntok) * a.ldo + e] = raw;
         }
     }
@@ -1212,8 +1213,9 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
                 const uint32_t h01 = pack2_rne(O[db][0], O[db][1]), h23 = pack2_rne(O[db][2], O[db][3]);
                 *reinterpret_cast<uint2*>(a.o + go + db * 16) = make_uint2(h01, h23);
                 if (F16 && a.ol)
-                    *reinterpret_cast<uint2*>(a.ol + go + db * 16) = make_uint2(pack2_rne(O[db][0] - lo_f(h01), O[db][1] - hi_f(h01)),
-                                                                                pack2_rne(O[db][2] - lo_f(h23), O[db][3] - hi_f(h23)));
+                    *reinterpret_cast<uint2*>(a.ol + go + db * 16) = a.ol_f16 ?
+                        make_uint2(pack2_f16_sat(O[db][0], O[db][1]), pack2_f16_sat(O[db][2], O[db][3])) :
+                        make_uint2(pack2_rne(O[db][0] - lo_f(h01), O[db][1] - hi_f(h01)), pack2_rne(O[db][2] - lo_f(h23), O[db][3] - hi_f(h23)));
             }
         }
     }
@@ -1503,7 +1505,7 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
                 bf16_t hi, lo;
                 f2bf_hilo((float)__builtin_bit_cast(_Float16, raw), hi, lo);
                 a.o[((size_t)b * a.ntok) * a.ldo + e] = hi;
-                if (a.ol) a.ol[((size_t)b * a.ntok) * a.ldo + e] = lo;
+                if (a.ol) a.ol[((size_t)b * a.ntok) * a.ldo + e] = a.ol_f16 ? raw : lo;
             } else a.o[((size_t)b * a.ntok) * a.ldo + e] = raw;
         }
     }
@@ -1563,8 +1565,9 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
                 const uint32_t h01 = pack2_rne(O[i][db][0], O[i][db][1]), h23 = pack2_rne(O[i][db][2], O[i][db][3]);
                 *reinterpret_cast<uint2*>(a.o + go + db * 16) = make_uint2(h01, h23);
                 if (F16 && a.ol)
-                    *reinterpret_cast<uint2*>(a.ol + go + db * 16) = make_uint2(pack2_rne(O[i][db][0] - lo_f(h01), O[i][db][1] - hi_f(h01)),
-                                                                                pack2_rne(O[i][db][2] - lo_f(h23), O[i][db][3] - hi_f(h23)));
+                    *reinterpret_cast<uint2*>(a.ol + go + db * 16) = a.ol_f16 ?
+                        make_uint2(pack2_f16_sat(O[i][db][0], O[i][db][1]), pack2_f16_sat(O[i][db][2], O[i][db][3])) :
+                        make_uint2(pack2_rne(O[i][db][0] - lo_f(h01), O[i][db][1] - hi_f(h01)), pack2_rne(O[i][db][2] - lo_f(h23), O[i][db][3] - hi_f(h23)));
             }
         }
     }
@@ -2266,7 +2269,7 @@ static bool s3_mfma_geom(const amdnuwa_s3_geom* g) {
 extern "C" int amdnuwa_s3_f16_supported(const amdnuwa_s3_geom* g) { return check_geom(g) == AMDNUWA_OK && s3_mfma_geom(g) ? 1 : 0; }
 
 extern "C" int amdnuwa_sparse3dna_fwd_f16(const amdnuwa_s3_geom* g, const uint16_t* q_f16, const uint16_t* k_f16, const uint16_t* v_f16,
-                                          int ld, const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, hipStream_t stream) {
+                                          int ld, const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, int o_lo_f16, hipStream_t stream) {
     int rc = check_geom(g);
     if (rc) return rc;
     if (!s3_mfma_geom(g)) return AMDNUWA_ERR_UNSUPPORTED;
@@ -2275,7 +2278,7 @@ extern "C" int amdnuwa_sparse3dna_fwd_f16(const amdnuwa_s3_geom* g, const uint16
     S3Args a{};
     fill_geom(a, g);
     a.q = q_f16; a.k = k_f16; a.v = v_f16; a.ld = ld;
-    a.o = o; a.ol = o_lo; a.ldo = ldo; a.wth = w_th;
+    a.o = o; a.ol = o_lo; a.ldo = ldo; a.wth = w_th; a.ol_f16 = (o_lo && o_lo_f16) ? 1 : 0;
     a.dbg = g_amdnuwa_tuning[9];
     self_kv(a);
     const int J = g->kf * g->kh * g->kw + 1;

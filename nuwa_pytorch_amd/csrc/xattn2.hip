@@ -38,6 +38,7 @@ struct X2Args {
     const float* wth;                        // [NH][NH]
     bf16_t* o; int ldo;
     bf16_t* ol;                              // xattn4 fp16-operand form only: the bf16 residual of o (o leaves as a hi + lo pair)
+    int ol_f16;                              // ... or, != 0, the FP16 rendering of o (the to_out GEMM's fp16 operand)
     float* stats;                            // [B][NH][n][2] = (row max of the scaled, masked scores; 1 / sum of exp)
     const bf16_t* dO; int lddo;
     bf16_t *dS, *Pm;                         // [B][NH][n][JP], keys of every 32-key chunk in the PERMUTED order the lanes hold them: position
@@ -1028,8 +1029,9 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
                 const uint32_t h01 = pack2_rne(O[rp][db][0], O[rp][db][1]), h23 = pack2_rne(O[rp][db][2], O[rp][db][3]);
                 *reinterpret_cast<uint2*>(a.o + go) = make_uint2(h01, h23);
                 if (F16 && a.ol)
-                    *reinterpret_cast<uint2*>(a.ol + go) = make_uint2(pack2_rne(O[rp][db][0] - lo_f(h01), O[rp][db][1] - hi_f(h01)),
-                                                                      pack2_rne(O[rp][db][2] - lo_f(h23), O[rp][db][3] - hi_f(h23)));
+                    *reinterpret_cast<uint2*>(a.ol + go) = a.ol_f16 ?
+                        make_uint2(pack2_f16_sat(O[rp][db][0], O[rp][db][1]), pack2_f16_sat(O[rp][db][2], O[rp][db][3])) :
+                        make_uint2(pack2_rne(O[rp][db][0] - lo_f(h01), O[rp][db][1] - hi_f(h01)), pack2_rne(O[rp][db][2] - lo_f(h23), O[rp][db][3] - hi_f(h23)));
             }
     }
 }
@@ -1295,14 +1297,14 @@ extern "C" int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
 }
 
 extern "C" int amdnuwa_xattn2_fwd_f16(const amdnuwa_xattn_geom* g, const uint16_t* q_f16, int ldq, const amdnuwa_xattn_kv* p,
-                                      const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, float* stats, hipStream_t stream) {
+                                      const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, int o_lo_f16, float* stats, hipStream_t stream) {
     int rc = check2(g);
     if (rc) return rc;
     if (!q_f16 || !p || !p->Kp_lo || !p->Vt_lo || !p->valid || !w_th || !o || ldq % 8 || ldo % 4) return AMDNUWA_ERR_ARG;
     if (g->B <= 0 || g->n <= 0) return AMDNUWA_OK;
     X2Args a{};
     a.q = q_f16; a.ldq = ldq; a.Kp = p->Kp_lo; a.Vp = p->Vp_lo; a.Vt = p->Vt_lo; a.valid = p->valid; a.wth = w_th;    // the fp16 images
-    a.o = o; a.ol = o_lo; a.ldo = ldo; a.stats = stats;
+    a.o = o; a.ol = o_lo; a.ldo = ldo; a.stats = stats; a.ol_f16 = (o_lo && o_lo_f16) ? 1 : 0;
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
     a.dbg = g_amdnuwa_tuning[18];
     const int tiles = (g->n + 63) / 64;

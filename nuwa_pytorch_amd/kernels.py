@@ -31,16 +31,19 @@ def set_precision(mode):
                   backward (parity mode for gradients).
     'bf16x3-fwd': (package default) the cheapest forward arithmetic that keeps the full-depth logits within 1e-3 of the fp32
                   reference, placed per product by an error budget:
-                    * to_out (both attention blocks), the cross-attention q / kv projections and to_logits: bf16 hi + lo operand
-                      pairs, 3 MFMAs per product;
+                    * the cross-attention kv projection and to_logits: bf16 hi + lo operand pairs, 3 MFMAs per product;
+                    * to_out (both attention blocks) and the cross-attention q projection: TWO fp16 MFMAs per product -- the
+                      activation as ONE fp16 value (the fp16 cores / the LayerNorm store hand it over), the weight as an fp16
+                      hi + lo pair (exact to ~22 bits); set_proj_f16x2() moves products between this form and the 3-MFMA one;
                     * the Sparse3DNA q / k / v projection, FF1 (+ GEGLU gate) and FF2: SINGLE fp16 MFMAs on fp16 copies of the
                       LayerNorm outputs and of the weights (11 significand bits; weights outside fp16's range fall back to the
                       hi + lo form, activations saturate at +-65504);
-                    * both attention cores: single fp16 MFMAs on fp16 q / k / v and fp16 probabilities, outputs as hi + lo pairs;
+                    * both attention cores: single fp16 MFMAs on fp16 q / k / v and fp16 probabilities, outputs as a bf16 copy (for
+                      the backward) + an fp16 copy (to_out's operand; a bf16 hi + lo pair when to_out runs 3 MFMAs);
                   fp32 everywhere else (LayerNorm, softmax, residual stream, accumulators).  The backward runs single bf16 MFMAs on
-                  the bf16 copies as in 'bf16' (gradients carry bf16-level error).  The three fp16 parts can be switched off one by
-                  one (set_cores_f16 / set_ff_f16 / set_qkv_f16, env AMDNUWA_F16_CORES / _FF / _QKV = 0): with all three off the
-                  forward IS the 'bf16x3' forward, bit for bit.  The 16-bit second copies live only inside the forward of one block."""
+                  the bf16 copies as in 'bf16' (gradients carry bf16-level error).  The fp16 parts can be switched off one by
+                  one (set_cores_f16 / set_ff_f16 / set_qkv_f16 / set_proj_f16x2, env AMDNUWA_F16_CORES / _FF / _QKV / AMDNUWA_F16X2 = 0):
+                  with all of them off the forward IS the 'bf16x3' forward, bit for bit.  The 16-bit second copies live only inside the forward of one block."""
     global _PRECISION
     if mode not in MODES:
         raise ValueError(mode)
@@ -308,6 +311,88 @@ def set_qkv_f16(on):
 
 def qkv_f16():
     return _QKV_F16 and cores_f16()
+
+
+def _x2_classes(v):
+    if v in (True, '1', 'all'):
+        return frozenset('oql')
+    if v in (False, None, '0', ''):
+        return frozenset()
+    assert set(v) <= set('oql'), v
+    return frozenset(v)
+
+
+# default: to_out x2 and the cross-attention q projection.  Measured on the full-depth logits (tests/test_gpu_named_size.py, rel-l2 against the
+# fp32 oracle): none 6.2e-4, 'o' 6.6e-4, 'oq' 6.7e-4, 'oql' 7.0e-4 -- to_logits buys 1.5 ms of the 10 for a third of the added error and stays
+# a three-MFMA product.
+DEFAULT_F16X2 = 'oq'
+_PROJ_F16X2 = _x2_classes(os.environ.get('AMDNUWA_F16X2', DEFAULT_F16X2))
+
+
+def set_proj_f16x2(on):
+    """'bf16x3-fwd' only: the products that are still hi + lo pairs on both sides as TWO fp16 MFMAs -- the activation as ONE fp16 value,
+    the weight as an fp16 hi + lo pair (exact to ~22 bits) -- instead of three bf16 MFMAs.  Priced by tools/error_budget.py before it
+    was built.  on: True / False, or a string of classes: 'o' = to_out of both attention blocks, 'q' = the
+    cross-attention q projection, 'l' = to_logits (env AMDNUWA_F16X2, same values; '0' = off; default DEFAULT_F16X2)."""
+    global _PROJ_F16X2
+    _PROJ_F16X2 = _x2_classes(on)
+
+
+def proj_f16x2(cls=None):
+    """is the two-MFMA form on (for product class `cls`; None: for any)?"""
+    return mixed() and (bool(_PROJ_F16X2) if cls is None else cls in _PROJ_F16X2)
+
+
+def f16_pair(w):
+    """fp32 weight -> (hi, lo) fp16 tensors with hi + lo = w to ~22 significand bits (lo may be subnormal: the fp16 MFMA keeps them)"""
+    w = w.detach().float()
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def gemm_nt_f16x2_ok(M, N, Kd, *, out_bf16):
+    d = GemmDesc()
+    one = ctypes_dummy()
+    d.A, d.B, d.Blo, d.C = one, one, one, one
+    d.lda, d.ldb, d.ldc = Kd, Kd, N
+    d.c_is_bf16 = 1 if out_bf16 else 0
+    d.M, d.N, d.K, d.batch, d.ab_f16 = M, N, Kd, 1, 1
+    return bool(_lib.lib().amdnuwa_gemm_nt_f16x2_supported(C.byref(d)))
+
+
+def gemm_nt_f16x2(A16, B16, *, out_bf16=False, bias=None, copy_f16=False):
+    """two-MFMA product: A16 fp16 [M, K] x (B16 = (hi, lo) fp16 [N, K] pair)^T.  out_bf16=False -> fp32 [M, N] (+ bias);
+    out_bf16=True -> BF(bf16 copy, None, fp16 copy if copy_f16)"""
+    L = _lib.lib()
+    M, Kd = A16.shape
+    Bh, Bl = B16
+    N = Bh.shape[0]
+    dev = A16.device
+    d = GemmDesc()
+    d.A, d.lda, d.B, d.Blo, d.ldb = _p(A16), _ld(A16), _p(Bh), _p(Bl), _ld(Bh)
+    d.alpha, d.beta, d.bias = 1.0, 0.0, _p(bias)
+    d.M, d.N, d.K, d.batch, d.ab_f16 = M, N, Kd, 1, 1
+    c16 = None
+    if out_bf16:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        d.C, d.ldc, d.c_is_bf16 = _p(out), N, 1
+        if copy_f16:
+            c16 = torch.empty((M, N), dtype=torch.float16, device=dev)
+            d.Clo = _p(c16)
+    else:
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+        d.C, d.ldc, d.c_is_bf16 = _p(out), N, 0
+    st = _stream()
+    if _TIMER['on']:
+        _TIMER['flops'] += 2.0 * M * N * Kd
+        _TIMER['issued'] = _TIMER.get('issued', 0.) + 4.0 * M * N * Kd
+        _TIMER['bytes'] += 2.0 * M * Kd + 4.0 * N * Kd + float(M) * N * ((4 if c16 is not None else 2) if out_bf16 else 4)
+        L.amdnuwa_timer_begin(st)
+    check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(f16 x f16 hi+lo)')
+    if _TIMER['on']:
+        L.amdnuwa_timer_end(st)
+    return BF(out, None, c16) if out_bf16 else out
 
 
 def gemm_nt_f16ops(A16, B16, *, out_bf16=False, gate=False, copy_f16=False):
@@ -690,17 +775,22 @@ def s3_f16_supported(g):
     return bool(_lib.lib().amdnuwa_s3_f16_supported(C.byref(g)))
 
 
-def sparse3dna_fwd(g, qkv, wth, rel_bias=None):
-    """qkv: BF [B*ntok, 3*inner] (q | k | v);  returns o BF [B*ntok, inner].  rel_bias: fp32 [J, heads] or None"""
+def sparse3dna_fwd(g, qkv, wth, rel_bias=None, o_f16=False):
+    """qkv: BF [B*ntok, 3*inner] (q | k | v);  returns o BF [B*ntok, inner].  rel_bias: fp32 [J, heads] or None.
+    o_f16 (fp16 operand form only): o = BF(bf16 copy, None, fp16 copy) -- the operand of the two-MFMA to_out product"""
     L = _lib.lib()
     g.rel_bias, g.d_rel_bias = _p(rel_bias), None
     inner = g.heads * g.dim_head
     R = g.B * g.ntok
-    if qkv.f16 is not None:            # fp16 operand form: single fp16 MFMAs, hi + lo output
-        o = empty_bf((R, inner), qkv.hi.device, lo=True)
+    if qkv.f16 is not None:            # fp16 operand form: single fp16 MFMAs; output hi + lo, or (o_f16) a bf16 copy + an fp16 copy
         q16, k16, v16 = (qkv.f16[:, i * inner:(i + 1) * inner] for i in range(3))
-        check(L.amdnuwa_sparse3dna_fwd_f16(C.byref(g), _p(q16), _p(k16), _p(v16), qkv.f16.stride(0), _p(wth), _p(o.hi), _p(o.lo), inner,
-                                           _stream()), 'amdnuwa_sparse3dna_fwd_f16')
+        if o_f16:
+            o = BF(torch.empty((R, inner), dtype=torch.bfloat16, device=qkv.hi.device), None,
+                   torch.empty((R, inner), dtype=torch.float16, device=qkv.hi.device))
+        else:
+            o = empty_bf((R, inner), qkv.hi.device, lo=True)
+        check(L.amdnuwa_sparse3dna_fwd_f16(C.byref(g), _p(q16), _p(k16), _p(v16), qkv.f16.stride(0), _p(wth), _p(o.hi),
+                                           _p(o.f16 if o_f16 else o.lo), inner, 1 if o_f16 else 0, _stream()), 'amdnuwa_sparse3dna_fwd_f16')
         return o
     o = empty_bf((R, inner), qkv.hi.device, lo=qkv.lo is not None)
     q, k, v = (view(qkv, cols=slice(i * inner, (i + 1) * inner)) for i in range(3))
@@ -866,16 +956,21 @@ def xattn_pack(g, kv, null_k, null_v, mask_u8, out=None):
     return pk
 
 
-def xattn2_fwd_f16(g, q, pk, wth):
-    """the xattn4 core on fp16 operands (q.f16, the fp16 images of pk): returns o BF [B*n, inner] (hi + lo) and the statistics"""
+def xattn2_fwd_f16(g, q, pk, wth, o_f16=False):
+    """the xattn4 core on fp16 operands (q.f16, the fp16 images of pk): returns o BF [B*n, inner] (hi + lo; with o_f16 a bf16 copy + an
+    fp16 copy, the operand of the two-MFMA to_out product) and the statistics"""
     L = _lib.lib()
     assert q.f16 is not None and getattr(pk, 'f16', False)
     inner = g.heads * g.dim_head
     dev = q.hi.device
-    o = empty_bf((g.B * g.n, inner), dev, lo=True)
+    if o_f16:
+        o = BF(torch.empty((g.B * g.n, inner), dtype=torch.bfloat16, device=dev), None,
+               torch.empty((g.B * g.n, inner), dtype=torch.float16, device=dev))
+    else:
+        o = empty_bf((g.B * g.n, inner), dev, lo=True)
     stats = torch.empty((g.B, g.heads, g.n, 2), dtype=torch.float32, device=dev)
-    check(L.amdnuwa_xattn2_fwd_f16(C.byref(g), _p(q.f16), q.f16.stride(0), C.byref(pk.struct), _p(wth), _p(o.hi), _p(o.lo), inner,
-                                   _p(stats), _stream()), 'amdnuwa_xattn2_fwd_f16')
+    check(L.amdnuwa_xattn2_fwd_f16(C.byref(g), _p(q.f16), q.f16.stride(0), C.byref(pk.struct), _p(wth), _p(o.hi),
+                                   _p(o.f16 if o_f16 else o.lo), inner, 1 if o_f16 else 0, _p(stats), _stream()), 'amdnuwa_xattn2_fwd_f16')
     return o, stats
 
 

@@ -194,7 +194,8 @@ class SandwichNorm(nn.Module):
                 raise RuntimeError('fused token shift needs dim % 32 == 0')
             meta['shift'] = (n, fmap)
         if chain is not None:
-            hin, nxt, nxt_fmap, hout = chain
+            hin, nxt, nxt_fmap, hout = chain[:4]
+            nxt_ctx = chain[4].get('context') if len(chain) > 4 else None        # the next block's text context (cross-attention)
             meta['handoff_in'] = hin
             if nxt is not None and not (nxt_fmap is not None and D % 32):
                 nxt_fn = nxt.fn.fn if isinstance(nxt.fn, (ShiftVideoTokens,)) else nxt.fn
@@ -203,6 +204,9 @@ class SandwichNorm(nn.Module):
                     nxt_kind = ('ff', nxt_fn.net[3].weight.shape[1], (nxt_fn.net[0].weight, nxt_fn.net[3].weight))
                 elif isinstance(nxt_fn, Sparse3DNA) and nxt_fn.causal:
                     nxt_kind = ('s3', nxt_fn.to_q.weight.shape[0], nxt_fn._meta(B, n, x.device)['geom'], (nxt_fn.to_q.weight, nxt_fn.to_kv.weight))
+                elif isinstance(nxt_fn, Attention) and nxt_ctx is not None and nxt_fn._hip_ok(nxt_ctx.shape[1]):
+                    nxt_kind = ('x', nxt_fn.to_q.weight.shape[0], K.x_geom(B, n, nxt_ctx.shape[1], nxt_fn.heads, nxt_fn.dim_head), {},
+                                (nxt_fn.to_q.weight, nxt_fn.to_out.weight))
                 meta['next_pre'] = (nxt.prenorm.weight, nxt.prenorm.bias, (n, nxt_fmap) if nxt_fmap is not None else None, nxt_kind)
                 meta['handoff_out'] = hout
         return ops.SandwichBlockFn.apply(x, resid, context if isinstance(inner, (Attention, SparseCross2DNA)) else None, meta,
@@ -670,7 +674,9 @@ class Transformer(nn.Module):
                 if isinstance(fn, FeedForward):
                     ws += [fn.net[0].weight, fn.net[3].weight]
                 elif isinstance(fn, Sparse3DNA):
-                    ws += [fn.to_q.weight, fn.to_kv.weight]
+                    ws += [fn.to_q.weight, fn.to_kv.weight, fn.to_out.weight]
+                elif isinstance(fn, Attention):
+                    ws += [fn.to_q.weight, fn.to_out.weight]
             ops.f16_ranges_prefetch(ws)
         handoff = None
         for i, (block, fused_kw, plain_kw, inner) in enumerate(calls):
@@ -680,7 +686,8 @@ class Transformer(nn.Module):
             # chain consecutive fused blocks: this block's post-norm kernel also writes the next block's pre-norm output
             nxt = calls[i + 1] if self.chain_blocks and i + 1 < len(calls) and calls[i + 1][3] is not None else None
             out = {}
-            x = block.fused_residual(x, chain=(handoff, nxt[0] if nxt else None, nxt[3][1] if nxt else None, out), **fused_kw)
+            x = block.fused_residual(x, chain=(handoff, nxt[0] if nxt else None, nxt[3][1] if nxt else None, out, nxt[1] if nxt else {}),
+                                     **fused_kw)
             handoff = out if out else None
         return x
 
@@ -1086,7 +1093,7 @@ class NUWA(nn.Module):
         frame_embeddings = self.embed_video(frame_indices_input)
         if self.training and cond_dropout_prob > 0:
             text_mask = text_mask & ~bernoulli_rows(batch, cond_dropout_prob, device)[:, None]
-        if return_loss and frame_embeddings.is_cuda and K.mixed() and ops.FUSE_LINEAR_CE_X3:
+        if frame_embeddings.is_cuda and K.mixed() and ((return_loss and ops.FUSE_LINEAR_CE_X3) or K.proj_f16x2()):
             ops.f16_prefetch_also(self.to_logits.weight)       # judged with the stack's weights: one device -> host transfer per step
         hidden = self.decode_hidden(frame_embeddings, text_embeds, text_mask)
         if not return_loss:

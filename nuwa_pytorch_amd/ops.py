@@ -148,6 +148,8 @@ class S3Inner:
             out = dict(qkv=qkv, qkvT=qkvT, out=_cast(wo), outT=_cast_t(wo))
             if K.mixed() and f16_weights_ok(wq, wkv):   # fp16 copy for the fp16-operand q / k / v projection of 'bf16x3-fwd'
                 out['qkv_16'] = torch.cat((wq.detach(), wkv.detach()), 0).to(torch.float16).contiguous()
+            if K.mixed() and f16_weights_ok(wo):        # fp16 hi + lo pair for the two-MFMA to_out product
+                out['out_16'] = K.f16_pair(wo)
             return out
         return cache.get('s3', (wq, wkv, wo), build)
 
@@ -173,8 +175,10 @@ class S3Inner:
             h = _f16_to_pair(h)
             f16 = K.cores_f16() and h.lo is not None and K.s3_f16_supported(g)
             qkv = K.gemm_nt(h, W['qkv'], out_bf16=True, shift=meta.get('shift'), out_f16=f16)
-        o = K.sparse3dna_fwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), rel_bias=rel)
-        y = K.gemm_nt(o, W['out'], bias=bo.detach(), out_bf16=_fast())
+        # two-MFMA to_out: the fp16 core hands its output over as a bf16 copy (backward) + an fp16 copy (this product's A operand)
+        o16 = K.proj_f16x2('o') and qkv.f16 is not None and 'out_16' in W and K.gemm_nt_f16x2_ok(R, p[3].shape[0], p[3].shape[1], out_bf16=False)
+        o = K.sparse3dna_fwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), rel_bias=rel, o_f16=o16)
+        y = K.gemm_nt_f16x2(o.f16, W['out_16'], bias=bo.detach()) if o16 else K.gemm_nt(o, W['out'], bias=bo.detach(), out_bf16=_fast())
         return y, _sv(h, qkv, o)
 
     @staticmethod
@@ -225,8 +229,21 @@ class XInner:
     @staticmethod
     def weights(cache, p):
         nk, nv, wth, wq, wkv, wo = p
-        return cache.get('x', (wq, wkv, wo), lambda: dict(q=_cast(wq), qT=_cast_t(wq), kv=_cast(wkv), kvT=_cast_t(wkv),
-                                                        out=_cast(wo), outT=_cast_t(wo)))
+
+        def build():
+            out = dict(q=_cast(wq), qT=_cast_t(wq), kv=_cast(wkv), kvT=_cast_t(wkv), out=_cast(wo), outT=_cast_t(wo))
+            if K.mixed() and f16_weights_ok(wq, wo):    # fp16 hi + lo pairs for the two-MFMA q and to_out products of 'bf16x3-fwd'
+                out['q_16'], out['out_16'] = K.f16_pair(wq), K.f16_pair(wo)
+            return out
+        return cache.get('x', (wq, wkv, wo), build)
+
+    @staticmethod
+    def f16x2_ok(R, D, inner, g, meta, ws=None):
+        """'bf16x3-fwd' with the two-MFMA switch on: the q projection takes the LayerNorm output as ONE fp16 value (so the LayerNorm store
+        should write a bf16 + fp16 copy pair) -- when the fp16 core follows, the product fits the ring and (ws = to_q.weight, to_out.weight)
+        the weights sit inside the fp16 range"""
+        return K.proj_f16x2('q') and K.cores_f16() and not meta.get('self_kv') and meta.get('rotary') is None and K.xattn2_supported(g) and \
+            K.gemm_nt_f16x2_ok(R, inner, D, out_bf16=True) and (ws is None or f16_weights_ok(*ws))
 
     @staticmethod
     def fwd(h, p, meta):
@@ -235,17 +252,27 @@ class XInner:
         g = meta['xgeom']
         ctx = h if meta.get('self_kv') else meta['ctx_bf']          # self-attention (text encoder): keys / values from the same rows
         rot = meta.get('rotary')
-        f16 = K.cores_f16() and h.lo is not None and ctx.lo is not None and rot is None and K.xattn2_supported(g)
-        q = K.gemm_nt(h, W['q'], out_bf16=True, out_f16=f16)
-        kv = K.gemm_nt(ctx, W['kv'], out_bf16=True, out_f16=f16)
+        R, D = h.hi.shape
+        inner = g.heads * g.dim_head
+        x2 = 'q_16' in W and ctx.lo is not None and XInner.f16x2_ok(R, D, inner, g, meta)
+        if not x2:
+            h = _f16_to_pair(h)
+        f16 = K.cores_f16() and (x2 or h.lo is not None) and ctx.lo is not None and rot is None and K.xattn2_supported(g)
+        if x2:      # two MFMAs: fp16 LayerNorm output x the weight as an fp16 hi + lo pair; q leaves as a bf16 copy + an fp16 copy
+            q = K.gemm_nt_f16x2(h.f16 if h.f16 is not None else K.hilo_to_f16(h), W['q_16'], out_bf16=True, copy_f16=True)
+        else:
+            q = K.gemm_nt(h, W['q'], out_bf16=True, out_f16=f16)
+        kv = K.gemm_nt(ctx, W['kv'], out_bf16=True, out_f16=f16)          # (context rows: B * T of them, a 3-MFMA product either way)
         if rot is not None:
             q = _rotary_bf(q, rot, g.B, g.n, g.heads)
             kv = _rotary_bf(kv, rot, g.B, g.T, 2 * g.heads)
         pk = K.xattn_pack(g, kv, nk.detach().reshape(g.heads, g.dim_head).contiguous(),
                           nv.detach().reshape(g.heads, g.dim_head).contiguous(), meta['mask_u8'])
         wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
+        o16 = False
         if f16:                               # 'bf16x3-fwd': the xattn4 core on single fp16 MFMAs, hi + lo output, statistics for the bf16 backward
-            o, stats = K.xattn2_fwd_f16(g, q, pk, wth2)
+            o16 = K.proj_f16x2('o') and 'out_16' in W and K.gemm_nt_f16x2_ok(R, p[5].shape[0], p[5].shape[1], out_bf16=False)
+            o, stats = K.xattn2_fwd_f16(g, q, pk, wth2, o_f16=o16)
             P, Pm = stats, None
             pk.drop_lo()
         elif K.xattn2_supported(g, q):        # fast mode: statistics only, the backward recomputes the probabilities
@@ -258,7 +285,7 @@ class XInner:
             pk.drop_lo()
         else:
             o, P, Pm = K.xattn_fwd(g, q, pk, wth2, save=meta.get('save', True))
-        y = K.gemm_nt(o, W['out'], out_bf16=_fast())
+        y = K.gemm_nt_f16x2(o.f16, W['out_16']) if o16 else K.gemm_nt(o, W['out'], out_bf16=_fast())
         return y, _sv(h, ctx, q, pk, P, Pm, o)
 
     @staticmethod
@@ -549,7 +576,8 @@ class SandwichBlockFn(Function):
         ctx.prev_ctx = None
         # h as a bf16 + fp16 copy pair when this block's first GEMM runs fp16 operands ('bf16x3-fwd': FeedForward, the 3DNA projection)
         want16 = (meta['kind'] == 'ff' and FFInner.f16_ok(B * n, D, _ru(p[1].shape[1], 32), (p[0], p[1]))) or \
-                 (meta['kind'] == 's3' and S3Inner.f16_proj_ok(B * n, D, p[0].shape[0], meta['geom'], (p[0], p[1])))
+                 (meta['kind'] == 's3' and S3Inner.f16_proj_ok(B * n, D, p[0].shape[0], meta['geom'], (p[0], p[1]))) or \
+                 (meta['kind'] == 'xattn' and XInner.f16x2_ok(B * n, D, p[3].shape[0], meta['xgeom'], meta, (p[3], p[5])))
         if hin is not None and hin.get('ptr') == x.data_ptr() and hin.get('ver') == x._version and hin.get('shift') == sh \
                 and resid is None and tuple(hin['h'].hi.shape) == (B * n, D):
             h, m1, r1 = hin['h'], hin['m1'], hin['r1']
@@ -564,7 +592,8 @@ class SandwichBlockFn(Function):
             # the next block's first GEMM runs fp16 operands: FeedForward (nxt[3] = ('ff', inner width)) or the 3DNA projection (('s3', inner, geom))
             nk = nxt[3] if len(nxt) > 3 else None
             nxt16 = nk is not None and ((nk[0] == 'ff' and FFInner.f16_ok(B * n, D, _ru(nk[1], 32), nk[2])) or
-                                        (nk[0] == 's3' and S3Inner.f16_proj_ok(B * n, D, nk[1], nk[2], nk[3])))
+                                        (nk[0] == 's3' and S3Inner.f16_proj_ok(B * n, D, nk[1], nk[2], nk[3])) or
+                                        (nk[0] == 'x' and XInner.f16x2_ok(B * n, D, nk[1], nk[2], nk[3], nk[4])))
             xo, m2, r2, hn, mn, rn = K.ln_post_pre_fwd(y, r2_, post_w.detach(), post_b.detach(), nxt[0].detach(),
                                                        nxt[1].detach(), next_shift=nxt[2], next_f16=nxt16)
             hout.update(h=hn, m1=mn, r1=rn, ptr=xo.data_ptr(), ver=xo._version, shift=nxt[2], ctx=ctx if CHAIN_BWD else None)
@@ -715,6 +744,16 @@ class StableLNFn(Function):
 # final StableLayerNorm + to_logits (+ cross entropy)   np.py:1182, 1958-1963
 # =================================================================================================
 
+def _logits_f16x2(W, wl, R, D):
+    """'bf16x3-fwd' with the two-MFMA switch on: to_logits takes the final LayerNorm output as ONE fp16 value and the weight as an fp16
+    hi + lo pair (built once per weight version; None = outside the fp16 range)"""
+    if not K.proj_f16x2('l'):
+        return False
+    if 'w_16' not in W:
+        W['w_16'] = K.f16_pair(wl) if f16_weights_ok(wl) else None
+    return W['w_16'] is not None and K.gemm_nt_f16x2_ok(R, wl.shape[0], D, out_bf16=False)
+
+
 class LogitsFn(Function):
     """x [B, n, D] -> logits [B, n, C] fp32 (StableLayerNorm then Linear without bias)"""
 
@@ -724,8 +763,9 @@ class LogitsFn(Function):
         B, n, D = x.shape
         x2 = x.detach().contiguous().reshape(B * n, D)
         W = cache.get('logits', (wl,), lambda: dict(w=_cast(wl), wT=_cast_t(wl)))
-        hn, m, r, ia = K.ln_fwd(x2, nw.detach(), nb.detach(), stable=True)
-        logits = K.gemm_nt(hn, W['w'])
+        lx2 = _logits_f16x2(W, wl, B * n, D)
+        hn, m, r, ia = K.ln_fwd(x2, nw.detach(), nb.detach(), stable=True, f16=lx2)
+        logits = K.gemm_nt_f16x2(hn.f16, W['w_16']) if lx2 else K.gemm_nt(hn, W['w'])
         ctx.save_for_backward(x2, m, r, ia, nw, wl)
         ctx.hn, ctx.W, ctx.shape = _sv(hn)[0], W, (B, n, D)
         return logits.reshape(B, n, -1)
@@ -758,18 +798,20 @@ class LogitsLossFn(Function):
         W = cache.get('logits', (wl,), lambda: dict(w=_cast(wl), wT=_cast_t(wl)))
         if K.mixed() and FUSE_LINEAR_CE_X3 and 'w16' not in W:       # fp16 copy for the dlogits pass of the fused cross entropy (None: outside the fp16 range)
             W['w16'] = wl.detach().to(torch.float16).contiguous() if f16_weights_ok(wl) else None
-        hn, m, r, ia = K.ln_fwd(x2, nw.detach(), nb.detach(), stable=True)
+        use_fused = FUSE_LINEAR_CE_X3 if K.mixed() else FUSE_LINEAR_CE
+        lx2 = not use_fused and _logits_f16x2(W, wl, B * n, D)
+        hn, m, r, ia = K.ln_fwd(x2, nw.detach(), nb.detach(), stable=True, f16=lx2)
         if targets.dtype != torch.int64:
             raise TypeError(f'cross-entropy targets must be int64 token ids, got {targets.dtype}')
         if targets.numel() != B * n:
             raise ValueError(f'{targets.numel()} targets for {B * n} logit rows')
         t = targets.contiguous().reshape(-1)            # ids outside [0, C) give a NaN loss (the kernel never reads out of bounds)
         want_grad = any(ctx.needs_input_grad)
-        fused = K.linear_ce(hn, W['w'], t, 1.0 / (B * n), want_grad=want_grad, w16=W.get('w16')) if (FUSE_LINEAR_CE_X3 if K.mixed() else FUSE_LINEAR_CE) else None
+        fused = K.linear_ce(hn, W['w'], t, 1.0 / (B * n), want_grad=want_grad, w16=W.get('w16')) if use_fused else None
         if fused is not None:                           # 'bf16' (and 'bf16x3-fwd' on request): logits produced twice inside the GEMM ring, never written (np.py:1958-1963)
             loss, dl = fused
         else:
-            logits = K.gemm_nt(hn, W['w'])
+            logits = K.gemm_nt_f16x2(hn.f16, W['w_16']) if lx2 else K.gemm_nt(hn, W['w'])
             loss, dl = K.ce_fwd(logits, t, 1.0 / (B * n), want_grad=want_grad, lo=False if K.mixed() else None)
             del logits
         ctx.save_for_backward(x2, m, r, ia, nw, wl)

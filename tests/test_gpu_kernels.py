@@ -1028,6 +1028,63 @@ def test_gemm_nt_f16_second_copy(K):
         assert torch.equal(out.f16, bf_value(full).half())
 
 
+@pytest.mark.parametrize('M,N,Kd', [(16384 + 40, 512, 512), (2560, 8192, 512), (300, 520, 96), (5000, 1024, 1376)])
+def test_gemm_nt_two_mfma_form(K, M, N, Kd):
+    """fp16 activation x fp16 (hi + lo) weight, two fp16 MFMAs per product on the hi + lo ring (amdnuwa_gemm_desc.ab_f16 with Blo): against
+    fp64 on the same operand values (what is left is the fp32 accumulation), against the EXACT fp32 weight (the pair carries it to ~22
+    bits), with a bias, and with the bf16 + fp16 output pair"""
+    torch.manual_seed(M + N)
+    a16 = (torch.randn(M, Kd, device=DEV) * 0.7).half()
+    w = torch.randn(N, Kd, device=DEV) * 0.05
+    bias = torch.randn(N, device=DEV)
+    wp = K.f16_pair(w)
+    assert wp[0].dtype == torch.float16 and wp[1].dtype == torch.float16
+    report(f'f16_pair[{N},{Kd}]', wp[0].double() + wp[1].double(), w.double(), 2 ** -20)
+    assert K.gemm_nt_f16x2_ok(M, N, Kd, out_bf16=False) and K.gemm_nt_f16x2_ok(M, N, Kd, out_bf16=True)
+    ref = a16.double() @ (wp[0].double() + wp[1].double()).t()
+    y = K.gemm_nt_f16x2(a16, wp, bias=bias)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (M, N)
+    report(f"gemm_x2.f32[{M},{N},{Kd}]", y, (ref + bias.double()).float(), 3e-6)
+    report(f'gemm_x2.f32_vs_exact_w[{M},{N},{Kd}]', y, (a16.double() @ w.double().t() + bias.double()).float(), 4e-6)
+    assert torch.equal(y, K.gemm_nt_f16x2(a16, wp, bias=bias))                      # no atomics, fixed order
+    o = K.gemm_nt_f16x2(a16, wp, out_bf16=True, copy_f16=True)
+    assert o.lo is None and o.hi.dtype == torch.bfloat16 and o.f16.dtype == torch.float16
+    report(f'gemm_x2.bf16[{M},{N},{Kd}]', o.hi.float(), ref.float(), 2 ** -8)
+    report(f'gemm_x2.f16_copy[{M},{N},{Kd}]', o.f16.float(), ref.float(), 2 ** -11)
+    # the three-MFMA product of the same values (a16 as an exact hi + lo pair, the weight as a bf16 pair): the two forms agree to the
+    # weight pair's precision
+    A3 = K.BF(a16.to(torch.bfloat16), (a16.float() - a16.to(torch.bfloat16).float()).to(torch.bfloat16))
+    y3 = K.gemm_nt(A3, to_bf_pair(w, True), bias=bias)
+    report(f'gemm_x2_vs_x3[{M},{N},{Kd}]', y, y3, 3e-5)
+    assert not K.gemm_nt_f16x2_ok(20, 512, 512, out_bf16=False)                     # the few-row decode shapes stay on the hi + lo kernels
+
+
+def test_fp16_cores_hand_over_an_fp16_copy(K):
+    """o_f16: both fp16 forward cores write o as a bf16 copy (what the backward reads: unchanged, bit for bit) + the fp16 rendering of the
+    SAME fp32 value in place of the bf16 residual -- the A operand of the two-MFMA to_out product"""
+    heads, dh, B = 8, 64, 2
+    inner = heads * dh
+    torch.manual_seed(5)
+    wth = (torch.randn(heads, heads) * 0.5 + torch.eye(heads)).to(DEV)
+    shape, kern, dil, n = (3, 16, 16), (5, 3, 3), (2, 2, 2), 1 + 2 * 256 + 77
+    qkvp, _ = _f16_pair(torch.randn(B * n, 3 * inner))
+    g = K.s3_geom(B, n, shape, kern, dil, heads, dh)
+    o = K.sparse3dna_fwd(g, qkvp, wth)
+    o2 = K.sparse3dna_fwd(g, qkvp, wth, o_f16=True)
+    assert o2.lo is None and o2.f16.dtype == torch.float16 and torch.equal(o.hi, o2.hi)
+    report('s3_fwd_f16.o_f16', o2.f16.float(), bf_value(o), 2 ** -11)
+    n, T = 700, 256
+    qp, _ = _f16_pair(torch.randn(B * n, inner))
+    kvp, _ = _f16_pair(torch.randn(B * T, 2 * inner))
+    gx = K.x_geom(B, n, T, heads, dh)
+    mask = (torch.rand(B, T) > 0.3).to(torch.uint8).to(DEV)
+    pk = K.xattn_pack(gx, kvp, torch.randn(heads, dh, device=DEV), torch.randn(heads, dh, device=DEV), mask)
+    x, st = K.xattn2_fwd_f16(gx, qp, pk, wth)
+    x2, st2 = K.xattn2_fwd_f16(gx, qp, pk, wth, o_f16=True)
+    assert x2.lo is None and torch.equal(x.hi, x2.hi) and torch.equal(st, st2)
+    report('xattn_fwd_f16.o_f16', x2.f16.float(), bf_value(x), 2 ** -11)
+
+
 # ---------------------------------------------------------------------------------------------------
 # full-size (BASELINE cfg 3 geometry) size-independent properties
 # ---------------------------------------------------------------------------------------------------

@@ -174,17 +174,29 @@ def test_cfg3_full_depth_logits_vs_oracle(A, O):
     from nuwa_pytorch_amd import kernels as KK
     KK.set_cores_f16(False)
     KK.set_ff_f16(False)
+    KK.set_proj_f16x2(False)
     A.set_precision('bf16x3-fwd')
     try:
         with torch.no_grad():
             h = nuwa.decode_hidden(nuwa.embed_video(ids.to(DEV)[:, :-1]), ctx.to(DEV), mask.to(DEV))
             same = nuwa._final(h).float().cpu()
+        # ... and what each class of two-MFMA products (fp16 activation x fp16 hi + lo weight) costs on top of the one-MFMA parts
+        KK.set_cores_f16(True)
+        KK.set_ff_f16(True)
+        for cls in ('', 'o', 'oq', 'oql'):
+            KK.set_proj_f16x2(cls)
+            with torch.no_grad():
+                h = nuwa.decode_hidden(nuwa.embed_video(ids.to(DEV)[:, :-1]), ctx.to(DEV), mask.to(DEV))
+                lg = nuwa._final(h)
+            res[f"bf16x3-fwd (two-MFMA classes '{cls}')"] = dict(logits_rel_max=rel_err(lg, logits_r), logits_rel_l2=rel_l2(lg, logits_r))
     finally:
         KK.set_cores_f16(True)
         KK.set_ff_f16(True)
+        KK.set_proj_f16x2(os.environ.get('AMDNUWA_F16X2', KK.DEFAULT_F16X2))
         A.set_precision('bf16')
     assert torch.equal(same, got['bf16x3']), 'bf16x3-fwd without its fp16 parts must be the bf16x3 forward'
     res['bf16x3-fwd (all 3-MFMA)'] = dict(logits_rel_max=rel_err(same, logits_r))
+    assert all(v['logits_rel_max'] <= 1e-3 for k, v in res.items() if k.startswith('bf16x3-fwd (two-MFMA')), res
     _note('cfg3.full_depth_logits', res)
     assert res['bf16x3-fwd']['logits_rel_max'] <= 1e-3, res
     assert res['bf16']['logits_rel_max'] <= 1.2e-2, res

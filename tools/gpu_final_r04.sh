@@ -27,3 +27,9 @@ if [ -d _ab_prev ]; then
     timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-tokenizer --no-parity 2>/dev/null | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('this tree:          ', round(d['ms_per_step'],1), 'ms/step', round(d['value']), d['unit'])"
   done > gpurun_out/ab_prev_$TAG.txt 2>&1; cat gpurun_out/ab_prev_$TAG.txt
 fi
+# the two-MFMA products of the compliant mode switched off / on (same tree, same box)
+for i in 1 2; do
+  for v in 0 default; do
+    ( [ $v = default ] && unset AMDNUWA_F16X2 || export AMDNUWA_F16X2=$v; timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-tokenizer --no-parity 2>/dev/null | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('AMDNUWA_F16X2=$v:', round(d['ms_per_step'],1), 'ms/step', round(d['value']), d['unit'], '| two-MFMA classes:', repr(d['fp16_forward_parts']['two_mfma_products']))" )
+  done
+done > gpurun_out/ab_x2_$TAG.txt 2>&1; cat gpurun_out/ab_x2_$TAG.txt
