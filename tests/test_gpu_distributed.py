@@ -130,7 +130,8 @@ def test_bench_py_two_ranks_end_to_end(launcher):
     assert abs(out['value'] - 2 * 2 * 2560 * 2 / (out['ms_per_step'] * 2e-3)) < 1e-3 * out['value']
     assert out['roofline']['launches'] > 0 and 0 < out['roofline']['frac'] < 1
     assert out['precision_mode'] == 'bf16x3-fwd' and out['fast_mode']['dtype'] == 'bf16' and out['fast_mode']['value'] > 0
-    assert 'single fp16 MFMA on' in out['dtype'] and out['fp16_forward_parts'] == {'cores': True, 'ff': True, 'qkv': True}
+    assert 'single fp16 MFMA on' in out['dtype'] and out['fp16_forward_parts'] == {'cores': True, 'ff': True, 'qkv': True, 'two_mfma_products': 'oq'} and \
+        '2 fp16 MFMAs (fp16 activation x fp16 hi+lo weight) on to_out x2, cross-attention q projection' in out['dtype']
     assert 8.5 < out['config']['loss'] < 10.0                      # ~ln(8192) at random init
 
 
