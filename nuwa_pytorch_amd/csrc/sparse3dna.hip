@@ -857,6 +857,24 @@ __device__ __forceinline__ int s3m_ts(int J) { return J * S3M_NH + S3M_PAD; }
 // an integer division by the run-time J costs ~35 instructions, and the item loops of the backward need one per item)
 __device__ __forceinline__ int s3m_item(int item, float rJ) { return item * S3M_NH + (int)(((float)item + 0.5f) * rJ) * S3M_PAD; }
 
+// The head-mix loops (read the 8 heads of a table item, 8 x 8 FMAs, write them back in place) and a hazard found late in round 4
+// (tools/determinism_stress.py): compiled freely, the 64 FMAs become 32 v_pk_fma_f32 on register pairs filled by two ds_read_b128 behind a
+// PARTIAL s_waitcnt, with the first ds_write_b128 issued in the middle of them.  With two workgroups of the two-row forward tile on a CU
+// (the LDS queue backed up) a few P' values per launch then came out wrong -- always the LOW half of a packed pair (an even head), a run of
+// lanes of one wave, different ones every run; the tables before the mix were bit-stable, the ones after it were not, and one workgroup per
+// CU never showed it.  Completing the stores before going on did NOT cure it; keeping every head's sum in its own scalar FMA chain (the
+// empty asm below pins `s` per head, so no packed FMAs are formed) did: bit-identical over 12 runs at b = 16, all dilations, both operand
+// forms.  The mechanism inside the packed-FMA sequence is not understood; the one-row kernel and the backward's mix never failed the same
+// stress test but share the source pattern, so all three loops are written this way.  lds_store8_done: 8 consecutive floats -> LDS as two
+// 16-byte stores, completed before the caller goes on, nothing scheduled across.
+__device__ __forceinline__ void lds_store8_done(float* p, const float (&v)[8]) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) p[g] = v[g];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // fills pslot / ptok (thread 0) and returns after a barrier; `cnt` = &pslot[S3M_PLANES]
 __device__ __forceinline__ void rowm_planes(const S3Args& a, int f, int y, int* pslot, int* ptok) {
     // closed form, one thread per plane (was a serial loop of thread 0): taps ta >= ta0 / tb >= tb0 reach a frame / row inside the grid
@@ -1196,10 +1214,10 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
             float s = 0.f;
 #pragma unroll
             for (int hh = 0; hh < 8; ++hh) s += wr[g * NH + hh] * pv[hh];
+            asm volatile("" : "+v"(s));          // (one head at a time: see lds_store8_done)
             out[g] = s;
         }
-#pragma unroll
-        for (int g = 0; g < 8; ++g) SP[ib + g] = out[g];
+        lds_store8_done(SP + ib, out);
     }
     __syncthreads();
     if (!(a.dbg & 4)) {
@@ -1540,10 +1558,10 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
             float s = 0.f;
 #pragma unroll
             for (int hh = 0; hh < 8; ++hh) s += wr[g * NH + hh] * pv[hh];
+            asm volatile("" : "+v"(s));          // (one head at a time: see lds_store8_done)
             out[g] = s;
         }
-#pragma unroll
-        for (int g = 0; g < 8; ++g) SP[ib + g] = out[g];
+        lds_store8_done(SP + ib, out);
     }
     __syncthreads();
     {
@@ -1775,10 +1793,10 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
                 float s = 0.f;
     #pragma unroll
                 for (int g = 0; g < 8; ++g) s += wr[g * NH + hh] * dv_[g];
+                asm volatile("" : "+v"(s));      // (one head at a time: see lds_store8_done)
                 out[hh] = s;
             }
-    #pragma unroll
-            for (int hh = 0; hh < 8; ++hh) DP[ib + hh] = out[hh];
+            lds_store8_done(DP + ib, out);
         }
         __syncthreads();
     }

@@ -1117,6 +1117,58 @@ def test_sparse3dna_fullsize_causality_and_determinism(K):
     assert bool(torch.isfinite(o1.float()).all()) and bool(torch.isfinite(d1.hi.float()).all())
 
 
+def test_attention_kernels_bit_reproducible_with_coresident_workgroups(K):
+    """the attention kernels at a batch that puts two workgroups on every CU and runs several rounds of them: 6 runs on the same inputs,
+    every output bit for bit (the one-sample determinism test above never has two workgroups on a CU).  Round 4: the head mix of the two-row
+    forward tile failed exactly this -- a few wrong P' entries per launch, different ones every run (csrc/sparse3dna.hip, lds_store8_done)"""
+    from nuwa_pytorch_amd import _lib
+    L = _lib.lib()
+    heads, dh, B, n = 8, 64, 16, 2560
+    inner = heads * dh
+    torch.manual_seed(0)
+    wth = (torch.randn(heads, heads) * 0.5 + torch.eye(heads)).to(DEV)
+
+    def outs(o):
+        res = []
+        for x in (o if isinstance(o, (tuple, list)) and not isinstance(o, K.BF) else (o,)):
+            res += [t for t in ((x.hi, x.lo, x.f16) if isinstance(x, K.BF) else (x,)) if torch.is_tensor(t)]
+        return res
+
+    def stable(name, fn):
+        ref = [t.clone() for t in outs(fn())]
+        for _ in range(5):
+            for a, b in zip(outs(fn()), ref):
+                assert torch.equal(a, b), f'{name}: not bit-reproducible'
+
+    for dil in ((1, 1, 1), (2, 2, 2), (4, 4, 4)):
+        qkv = torch.randn(B * n, 3 * inner, device=DEV)
+        g = K.s3_geom(B, n, (10, 16, 16), (5, 3, 3), dil, heads, dh)
+        pbf, p16 = K.BF(qkv.to(torch.bfloat16), None), K.BF(qkv.to(torch.bfloat16), None, qkv.half())
+        dO = K.BF(torch.randn(B * n, inner, device=DEV).to(torch.bfloat16), None)
+        for rows in (1, 2):
+            try:
+                L.amdnuwa_set_tuning(16, rows)
+                stable(f'3DNA fwd bf16 dil {dil[0]} rows {rows}', lambda: K.sparse3dna_fwd(g, pbf, wth))
+                stable(f'3DNA fwd fp16 dil {dil[0]} rows {rows}', lambda: K.sparse3dna_fwd(g, p16, wth))
+            finally:
+                L.amdnuwa_set_tuning(16, 0)
+        stable(f'3DNA bwd dil {dil[0]}', lambda: K.sparse3dna_bwd(g, pbf, wth, dO))
+    T = 256
+    q, kv = torch.randn(B * n, inner, device=DEV), torch.randn(B * T, 2 * inner, device=DEV)
+    gx = K.x_geom(B, n, T, heads, dh)
+    mask = (torch.rand(B, T, device=DEV) > 0.2).to(torch.uint8)
+    nk, nv = torch.randn(heads, dh, device=DEV), torch.randn(heads, dh, device=DEV)
+    q16, kv16 = K.BF(q.to(torch.bfloat16), None, q.half()), K.BF(kv.to(torch.bfloat16), None, kv.half())
+    pk16 = K.xattn_pack(gx, kv16, nk, nv, mask)
+    stable('cross attention fwd fp16', lambda: K.xattn2_fwd_f16(gx, q16, pk16, wth))
+    qb = K.BF(q.to(torch.bfloat16), None)
+    pkb = K.xattn_pack(gx, K.BF(kv.to(torch.bfloat16), None), nk, nv, mask)
+    stable('cross attention fwd bf16', lambda: K.xattn2_fwd(gx, qb, pkb, wth))
+    _, stats = K.xattn2_fwd(gx, qb, pkb, wth)
+    dO = K.BF(torch.randn(B * n, inner, device=DEV).to(torch.bfloat16), None)
+    stable('cross attention bwd', lambda: K.xattn2_bwd(gx, qb, dO, pkb, wth, stats))
+
+
 @pytest.mark.parametrize('R,C,Kd', [(1000, 8192, 512), (2560, 512, 256), (300, 192, 64)])
 def test_fused_linear_cross_entropy(R, C, Kd):
     """to_logits + cross entropy without the fp32 logits (np.py:1958-1963): loss, dlogits against torch on the same bf16 operands,

@@ -385,3 +385,24 @@ def test_fp16_range_guard_of_the_compliant_mode(A):
             ff.net[0].weight.copy_(saved[0]); ff.net[3].weight.copy_(saved[1])
         assert bool(torch.isfinite(outs['bf16x3-fwd']).all()), case
         assert torch.equal(outs['bf16x3-fwd'], outs['bf16x3']), f'{case}: the guarded blocks must run the hi + lo products'
+    # (iii) the two-MFMA products (fp16 activation x fp16 hi + lo weight): a to_out / to_q weight outside the range keeps its three-MFMA
+    # product -- the run equals the one with the two-MFMA switch off, bit for bit, while an in-range stack differs from it
+    s3, xa = tr.layers[0][0].fn, tr.layers[0][1].fn
+    A.set_precision('bf16x3-fwd')
+    try:
+        def run(x2):
+            K.set_proj_f16x2(x2)
+            with torch.no_grad():
+                return tr.forward_layers(x, context=ctx, context_mask=mask).float().cpu()
+        assert not torch.equal(run('oq'), run(False))
+        with torch.no_grad():
+            saved = [s3.to_out.weight.clone(), xa.to_q.weight.clone()]
+            s3.to_out.weight.mul_(2.0e5 / float(s3.to_out.weight.abs().max()))
+            xa.to_q.weight.mul_(1.0e-6 / float(xa.to_q.weight.abs().max()))      # (to_q and to_out of a block are judged together)
+        guarded, plain = run('oq'), run(False)
+        with torch.no_grad():
+            s3.to_out.weight.copy_(saved[0]); xa.to_q.weight.copy_(saved[1])
+        assert bool(torch.isfinite(guarded).all()) and torch.equal(guarded, plain), 'out-of-range to_out / to_q weights must keep the hi + lo products'
+    finally:
+        K.set_proj_f16x2(os.environ.get('AMDNUWA_F16X2', K.DEFAULT_F16X2))
+        A.set_precision('bf16')
