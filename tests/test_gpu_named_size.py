@@ -203,6 +203,38 @@ def test_cfg3_full_depth_logits_vs_oracle(A, O):
     assert res['bf16']['loss_rel'] <= 2e-5, res
 
 
+@pytest.mark.parametrize('mode', ['bf16x3-fwd', 'bf16'])
+def test_cfg3_decoder_step_is_bit_reproducible_at_a_chip_filling_batch(A, mode):
+    """the bench step (embedding -> 3 decoder layers with dilations 1, 2, 4 -> logits -> cross entropy -> backward) at b = 16: every kernel of the
+    path runs with several workgroups per CU and several rounds of them.  Twice from the same inputs: the loss and every gradient bit for
+    bit (no atomics on the path, fixed-order split-K sums).  The one-sample tests cannot see a defect that needs co-resident workgroups."""
+    import bench
+    c = dict(bench.CFGS['cfg3'], dec_depth=3)
+    nuwa = bench.build_model(c, DEV)
+    params = bench.decoder_params(nuwa)
+    g = torch.Generator().manual_seed(5)
+    b, N = 16, c['frames'] * c['fmap'] ** 2
+    ids = torch.randint(0, c['codebook'], (b, N), generator=g).to(DEV)
+    ctx = torch.randn(b, c['text_len'], c['dim'], generator=g).to(DEV)
+    mask = (torch.rand(b, c['text_len'], generator=g) > 0.1).to(DEV)
+    A.set_precision(mode)
+    try:
+        runs = []
+        for _ in range(3):
+            for p in params:
+                p.grad = None
+            loss = bench.decoder_step(nuwa, ids, ctx, mask)
+            torch.cuda.synchronize()
+            runs.append((None if loss is None else loss.detach().clone(), [p.grad.detach().clone() for p in params]))
+    finally:
+        A.set_precision('bf16')
+    for k in (1, 2):
+        if runs[0][0] is not None:
+            assert torch.equal(runs[0][0], runs[k][0]), f'{mode}: loss differs between runs'
+        bad = [i for i, (x, y) in enumerate(zip(runs[0][1], runs[k][1])) if not torch.equal(x, y)]
+        assert not bad, f'{mode}: {len(bad)} of {len(params)} gradients differ between two runs of the same step'
+
+
 def test_cfg4_reversible_blocks_vs_oracle(A, O):
     """cfg 4 (dec_reversible=True) at dim 512 / n = 2560: two reversible depths (3DNA|FF, cross|FF, twice) through the recomputing
     backward against the oracle's plain (stored-activation) evaluation of the same arithmetic"""
