@@ -1,10 +1,11 @@
 #!/bin/bash
-# final check of the round on ONE box: GPU suite, the FETCH / WRITE passes of the default config, the default bench line, its kernel stats,
+# final check of the round on ONE box: the batch-16 bit-reproducibility stress, GPU suite, the FETCH / WRITE passes of the default config, the default bench line, its kernel stats,
 # the attention / whole-step tools and (when an untracked copy of the previous round's tree sits in _ab_prev/) an A/B of the two bench lines
 TAG=${TAG:-r04z}
 mkdir -p gpurun_out; export PYTHONUNBUFFERED=1 TMPDIR=/tmp
 R=$PWD
 rm -f gpurun_out/parity_log.jsonl gpurun_out/named_size.json
+timeout 300 python tools/determinism_stress.py 16 > gpurun_out/determinism_stress_$TAG.txt 2>&1; tail -n 1 gpurun_out/determinism_stress_$TAG.txt
 timeout 1500 python -m pytest tests -m gpu -q --tb=short > gpurun_out/pytest_$TAG.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_$TAG.txt; tail -n 4 gpurun_out/pytest_$TAG.txt
 # counter passes first: the bench line below then carries the HBM traffic measured on THESE kernel sources (bench.py refuses a stale figure)
 for pass in FETCH_SIZE WRITE_SIZE; do
