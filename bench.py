@@ -77,9 +77,9 @@ def fwd_flops_per_sample(c):
     return tot + 2 * n * D * C
 
 
-def build_model(c, device):
+def build_model(c, device, seed=0):
     import nuwa_pytorch_amd as A
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     vae = A.VQGanVAE(dim=c['vae']['dim'], image_size=c['vae']['image_size'], num_layers=c['vae']['num_layers'],
                      vq_codebook_size=c['codebook'], use_vgg_and_gan=False)
     nuwa = A.NUWA(vae=vae, dim=c['dim'], max_video_frames=c['frames'], text_max_seq_len=c['text_len'], text_enc_depth=1,

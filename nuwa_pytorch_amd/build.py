@@ -15,6 +15,7 @@ LIB = os.path.join(LIBDIR, 'libamdnuwa.so')
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'amdnuwa.h')
 SOURCES = ['api.hip', 'gemm.hip', 'elementwise.hip', 'sparse3dna.hip', 'xattn.hip', 'xattn2.hip', 'vae.hip', 'optim.hip', 'decode.hip', 'comm.hip']
 ARCH = 'gfx950'
+DEFAULT_FLAGS = []          # flags of every device compile of the shipped library
 
 
 def _hipcc():
@@ -22,6 +23,11 @@ def _hipcc():
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
             return c
     return 'hipcc'
+
+
+def DEFAULT_FLAGS_FOR(variant):
+    """flags of the shipped build that a variant may switch off ('pk' = the shipped build WITHOUT DEFAULT_FLAGS, for A/B runs)"""
+    return [] if variant in ('pk', 'pk_nofix') else DEFAULT_FLAGS
 
 
 def _stale(target, deps):
@@ -38,8 +44,21 @@ def _stale(target, deps):
 # 15 % fewer instructions in a kernel that is bound by instruction issue); the long-lived accumulators still sit in AGPRs.
 EXTRA_FLAGS = {'xattn2.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
+# Build variants (A/B runs of compiler options: `python -m nuwa_pytorch_amd.build --variant nopk` writes lib_nopk/libamdnuwa.so, which
+# AMDNUWA_LIBRARY=... then selects).  'nopk': no packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the
+# device code -- the instruction shape of the round-4 head-mix defect ("packed fp32"); the host pass ignores the feature flag.
+NOPK_FLAGS = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+VARIANTS = {'': [], 'nopk': NOPK_FLAGS, 'pk': [], 'pk_nofix': ['-DS3_MIX_PIN=0'], 'nopk_nofix': NOPK_FLAGS + ['-DS3_MIX_PIN=0']}
 
-def build(force=False, verbose=True):
+
+def lib_path(variant=''):
+    return os.path.join(HERE, 'lib' + ('_' + variant if variant else ''), 'libamdnuwa.so')
+
+
+def build(force=False, verbose=True, variant=''):
+    LIBDIR = os.path.dirname(lib_path(variant))
+    LIB = lib_path(variant)
+    vflags = VARIANTS[variant] if variant in VARIANTS else variant.split()
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     common = [os.path.join(CSRC, 'common.h'), HEADER]
@@ -49,7 +68,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(LIBDIR, s.replace('.hip', '.o'))
         objs.append(obj)
         if force or _stale(obj, [src] + common + [os.path.abspath(__file__)]):
-            jobs.append([_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC'] + EXTRA_FLAGS.get(s, []) + ['-c', src, '-o', obj])
+            jobs.append([_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC'] + EXTRA_FLAGS.get(s, []) + DEFAULT_FLAGS_FOR(variant) + vflags + ['-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:
@@ -67,4 +86,5 @@ def build(force=False, verbose=True):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    var = sys.argv[sys.argv.index('--variant') + 1] if '--variant' in sys.argv else ''
+    print(build(force='--force' in sys.argv, variant=var))

@@ -1197,8 +1197,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     const unsigned lds0 = (unsigned)(size_t)(lds_vptr_t)smem;
     const char* baseA = reinterpret_cast<const char*>(p.A + oA + (long long)m0 * p.lda);
     const char* baseB = reinterpret_cast<const char*>(p.B + oB + (long long)n0 * p.ldb);
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseA), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB), 0, 0x7fffffff, 0x00020000);
     unsigned offa[4], offb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1213,13 +1211,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sbu), hi = __builtin_amdgcn_readfirstlane((unsigned)(sbu >> 32));
         const unsigned long long sbase = ((unsigned long long)hi << 32) | lo;
         const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds0 + slot * STG + (q < 4 ? 0 : TB) + ((q & 3) * 4 + wave) * 1024);
-        if (PROBE && (p.dbg & 32)) {
-            // PROBE (tuning key 7 bit 5): the same piece through buffer_load_dwordx4 ... lds -- resource descriptor in SGPRs, the lane's constant
-            // byte offset as voffset, the K position as scalar offset (the vendor library's kernels stage their operands this way)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(q < 4 ? rsA : rsB, (lds_vptr)(smem + slot * STG + (q < 4 ? 0 : TB) + ((q & 3) * 4 + wave) * 1024), 16,
-                                                     (int)(q < 4 ? offa[q & 3] : offb[q & 3]), k0 * 2, 0, 0);
-            return;
-        }
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(q < 4 ? offa[q & 3] : offb[q & 3]), "s"(sbase), "s"(lds_addr)
                      : "memory", "m0");
     };

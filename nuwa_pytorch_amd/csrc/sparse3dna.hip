@@ -867,12 +867,27 @@ __device__ __forceinline__ int s3m_item(int item, float rJ) { return item * S3M_
 // forms.  The mechanism inside the packed-FMA sequence is not understood; the one-row kernel and the backward's mix never failed the same
 // stress test but share the source pattern, so all three loops are written this way.  lds_store8_done: 8 consecutive floats -> LDS as two
 // 16-byte stores, completed before the caller goes on, nothing scheduled across.
+// S3_MIX_PIN (compile-time, default 1): 0 writes the three mix loops freely again (the compiler then forms packed FMAs unless the library is
+// built without the packed-fp32 target feature) -- only for the round-5 experiment that separates the two cures
+// (build variants 'pk_nofix' / 'nopk_nofix' in nuwa_pytorch_amd/build.py, tools/determinism_stress.py).
+#ifndef S3_MIX_PIN
+#define S3_MIX_PIN 1
+#endif
+#if S3_MIX_PIN
+#define S3_MIX_PIN_ASM(s) asm volatile("" : "+v"(s))
+#else
+#define S3_MIX_PIN_ASM(s) ((void)0)
+#endif
 __device__ __forceinline__ void lds_store8_done(float* p, const float (&v)[8]) {
+#if S3_MIX_PIN
     __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int g = 0; g < 8; ++g) p[g] = v[g];
+#if S3_MIX_PIN
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 // fills pslot / ptok (thread 0) and returns after a barrier; `cnt` = &pslot[S3M_PLANES]
@@ -1214,7 +1229,7 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
             float s = 0.f;
 #pragma unroll
             for (int hh = 0; hh < 8; ++hh) s += wr[g * NH + hh] * pv[hh];
-            asm volatile("" : "+v"(s));          // (one head at a time: see lds_store8_done)
+            S3_MIX_PIN_ASM(s);                   // (one head at a time: see lds_store8_done)
             out[g] = s;
         }
         lds_store8_done(SP + ib, out);
@@ -1558,7 +1573,7 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
             float s = 0.f;
 #pragma unroll
             for (int hh = 0; hh < 8; ++hh) s += wr[g * NH + hh] * pv[hh];
-            asm volatile("" : "+v"(s));          // (one head at a time: see lds_store8_done)
+            S3_MIX_PIN_ASM(s);                   // (one head at a time: see lds_store8_done)
             out[g] = s;
         }
         lds_store8_done(SP + ib, out);
@@ -1793,7 +1808,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
                 float s = 0.f;
     #pragma unroll
                 for (int g = 0; g < 8; ++g) s += wr[g * NH + hh] * dv_[g];
-                asm volatile("" : "+v"(s));      // (one head at a time: see lds_store8_done)
+                S3_MIX_PIN_ASM(s);               // (one head at a time: see lds_store8_done)
                 out[hh] = s;
             }
             lds_store8_done(DP + ib, out);

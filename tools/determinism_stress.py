@@ -35,7 +35,9 @@ def check(name, fn):
 
 
 def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
+    only_s3 = '--only-s3' in sys.argv           # (the build-variant experiment of round 5: the 3DNA kernels alone)
+    print('library:', _lib.LIB_PATH, flush=True)
     torch.manual_seed(0)
     total = 0
     wth = (torch.randn(heads, heads) * 0.5 + torch.eye(heads)).to(DEV)
@@ -53,6 +55,9 @@ def main():
             total += check(f'3DNA fwd fp16, dilation {dil[0]}, {rows} row(s) per tile, b={B}', lambda: K.sparse3dna_fwd(g, p16, wth))
         L.amdnuwa_set_tuning(16, 0)
         total += check(f'3DNA bwd bf16, dilation {dil[0]}, b={B}', lambda: K.sparse3dna_bwd(g, pbf, wth, dO))
+    if only_s3:
+        print('TOTAL differing elements:', total)
+        return 1 if total else 0
     T = 256
     q = torch.randn(B * n, inner, device=DEV)
     kv = torch.randn(B * T, 2 * inner, device=DEV)
