@@ -67,6 +67,10 @@ const char* amdnuwa_error_string(int code);
  *  MFMA phase, 9 = 256x256 tile on FOUR waves of 128x128 (plain fp32 / bf16 outputs only, else 7; opt-in: DESIGN.md 5n);
  *  any non-zero key 0 disables the few-row weight-streaming path that M <= 32 normally takes) */
 int amdnuwa_set_tuning(int key, int value);
+/* fp16 saturation monitor: number of threads (since the last reset) that handed a value beyond +-65504 to one of the library's saturating
+ * fp16 stores (LayerNorm copies, GEMM epilogue copies, attention outputs, fp16 gradients).  0 in a healthy run: a saturated value is
+ * DEFINED (clamped) but no longer the reference's arithmetic.  Synchronises the device; reset != 0 clears the counters. */
+unsigned long long amdnuwa_f16_sat_count(int reset);
 int amdnuwa_get_tuning(int key);
 
 /* opt-in HIP-event launch timer: while armed, _begin/_end bracket one launch on `stream` with an
@@ -118,6 +122,13 @@ typedef struct {
      * (+ bias), or bf16 whose optional Clo receives the FP16 rendering of the output.  What the 'bf16x3-fwd' mode runs for to_out, the
      * cross-attention q / kv projections and to_logits (reference nuwa_pytorch.py:370-379, 611-613, 1956) when its two-MFMA switch is
      * on.  amdnuwa_gemm_nt_f16x2_supported() first; AMDNUWA_ERR_UNSUPPORTED otherwise. */
+    /* Round 5 (ABI 16), the fp16-gradient backward.  NT with ab_f16 and c_is_bf16: c_f16 != 0 -> C (and the GEGLU-backward output C2) hold
+     * FP16 values, saturating, instead of bf16 (Clo / C2lo NULL): dgrad products whose operands are fp16(S * gradient) and an fp16 weight.
+     * The GEGLU backward (geglu_u) is available on the fp16-operand ring as well then (geglu_u stays bf16: it is read element-wise).
+     * TN: ab_f16 != 0 -> A and B hold fp16 values (weight gradients from fp16 gradients and the fp16 activation copies).
+     * alpha_dev (TN): optional DEVICE scalar multiplied into alpha by the split-K reduction (1 / S of the gradient scale). */
+    int c_f16;
+    const float* alpha_dev;
 } amdnuwa_gemm_desc;
 
 /* C[M,N] = alpha * A[M,K] . B[N,K]^T (+ bias).  K, lda, ldb multiples of 8. */
@@ -133,6 +144,9 @@ int amdnuwa_hilo_to_f16(const uint16_t* hi, const uint16_t* lo, int ld_in, uint1
 /* C[M,N] (fp32) = beta*C + alpha * A[K,M]^T . B[K,N]   (reduction over the K token rows, split-K
  * through `workspace`, fixed summation order => deterministic).  lda, ldb multiples of 8; operand rows
  * must be readable up to the next multiple of 8 columns (padding content is irrelevant). */
+/* 1 when amdnuwa_gemm_tn() takes this product with ab_f16 != 0 (fp16 operands: the four-wave kernel's shapes -- no token shift, token rows
+ * a multiple of 64, both output dimensions >= 256); it returns AMDNUWA_ERR_UNSUPPORTED otherwise */
+int amdnuwa_gemm_tn_f16_supported(const amdnuwa_gemm_desc* d);
 size_t amdnuwa_gemm_tn_workspace_bytes(const amdnuwa_gemm_desc* d);
 int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
 
@@ -154,6 +168,13 @@ int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspac
 /* ln_fwd (mode 0) / ln_post_pre_fwd: the second 16-bit output (out_lo / h_lo) receives the FP16 rendering of the normalised row
  * instead of the bf16 residual -- the A operand of the fp16-operand GEMMs (amdnuwa_gemm_desc.ab_f16) */
 #define AMDNUWA_LN_LO_F16 64
+/* Round 5, fp16 everywhere a block needs ONE 16-bit copy.  AMDNUWA_LN_OUT_F16 -- in ln_fwd's `mode` / ln_post_pre_fwd's `flags`: out_hi /
+ * h_hi itself receives the FP16 rendering (saturating; out_lo / h_lo must be NULL): the block's forward GEMM, its weight-gradient GEMM and
+ * nothing else read it.  In ln_bwd_f16's `stable`: dx_hi receives fp16(S * dx) (dx_lo NULL).  AMDNUWA_LN_DY_F16 (ln_bwd_f16's `stable`):
+ * dy points at fp16(S * value).  S travels as a DEVICE pointer scale2 = {S, 1 / S} (NULL = 1): a power of two chosen once per backward
+ * pass by the host side from the residual-stream gradient, without a host synchronisation (nuwa_pytorch_amd/ops.py: _grad_scale). */
+#define AMDNUWA_LN_OUT_F16 128
+#define AMDNUWA_LN_DY_F16 256
 int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const float* b, uint16_t* out_hi,
                    uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R, int D,
                    int mode, int stable, float eps, int shift_ntok, int shift_fmap, amdnuwa_stream stream);
@@ -179,6 +200,13 @@ int amdnuwa_ln_bwd_chain(const void* dh, const float* x, const float* mean, cons
                          const float* w_prev, uint16_t* dy_prev_hi, uint16_t* dy_prev_lo, float* dw_prev, float* db_prev,
                          float* dsum_prev, long long R, int D, int shift_ntok, int shift_fmap, int inputs_bf16, void* workspace,
                          size_t workspace_bytes, amdnuwa_stream stream);
+/* the same with fp16 gradients: inputs_bf16 = 3 -> dh points at fp16(S * value) (y_prev fp32); dy_prev_f16 != 0 -> dy_prev_hi receives
+ * fp16(S * dy_prev), saturating (dy_prev_lo NULL).  inputs_bf16 0..2 / dy_prev_f16 = 0 / scale2 = NULL is amdnuwa_ln_bwd_chain. */
+int amdnuwa_ln_bwd_chain_f16(const void* dh, const float* x, const float* mean, const float* rstd, const float* w, const float* g,
+                             float* dx, float* dw, float* db, const void* y_prev, const float* mean_prev, const float* rstd_prev,
+                             const float* w_prev, uint16_t* dy_prev_hi, uint16_t* dy_prev_lo, float* dw_prev, float* db_prev,
+                             float* dsum_prev, long long R, int D, int shift_ntok, int shift_fmap, int inputs_bf16, int dy_prev_f16,
+                             const float* scale2, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
 size_t amdnuwa_ln_bwd_workspace_bytes(long long R, int D);
 /* dy fp32; shift_ntok > 0 reads dy through the inverse token shift.  Exactly one of dx_hi (bf16
  * hi[/lo] output) / dx_acc (fp32) is non-NULL; dx_acc = (dres ? dres : dx_acc) + dx.  dw, db, dsum
@@ -187,6 +215,11 @@ int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean, const flo
                    const float* w, uint16_t* dx_hi, uint16_t* dx_lo, float* dx_acc, const float* dres, float* dw,
                    float* db, float* dsum, long long R, int D, int shift_ntok, int shift_fmap, int stable, int accumulate, void* workspace,
                    size_t workspace_bytes, amdnuwa_stream stream);
+/* amdnuwa_ln_bwd with the fp16-gradient flags of `stable` (AMDNUWA_LN_DY_F16, AMDNUWA_LN_OUT_F16) and the device scale pair */
+int amdnuwa_ln_bwd_f16(const float* dy, const float* x, const float* mean, const float* rstd, const float* inv_amax,
+                       const float* w, uint16_t* dx_hi, uint16_t* dx_lo, float* dx_acc, const float* dres, float* dw,
+                       float* db, float* dsum, long long R, int D, int shift_ntok, int shift_fmap, int stable, int accumulate,
+                       const float* scale2, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
 size_t amdnuwa_colsum_workspace_bytes(long long R, int D);
 int amdnuwa_colsum(const float* x, float* out, long long R, int D, int accumulate, void* workspace,
                    size_t workspace_bytes, amdnuwa_stream stream);

@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # AMDNUWA_LIBRARY: another build of the same library (A/B runs of compiler options inside one process group; tools/ only)
 LIB_PATH = os.environ.get('AMDNUWA_LIBRARY') or os.path.join(HERE, 'lib', 'libamdnuwa.so')
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 P = C.c_void_p
 I = C.c_int
@@ -23,7 +23,7 @@ class GemmDesc(C.Structure):
                 ('c_is_bf16', I), ('bias', P), ('alpha', F), ('beta', F),
                 ('M', I), ('N', I), ('K', I), ('batch', I), ('shift_ntok', I), ('shift_fmap', I),
                 ('batch_inner', I), ('strideA_inner', LL), ('strideB_inner', LL), ('strideC_inner', LL),
-                ('C2', P), ('C2lo', P), ('ldc2', I), ('geglu_u', P), ('geglu_u_lo', P), ('ld_u', I), ('c_lo_f16', I), ('ab_f16', I)]
+                ('C2', P), ('C2lo', P), ('ldc2', I), ('geglu_u', P), ('geglu_u_lo', P), ('ld_u', I), ('c_lo_f16', I), ('ab_f16', I), ('c_f16', I), ('alpha_dev', P)]
 
 
 class S3Geom(C.Structure):
@@ -54,19 +54,23 @@ SIGNATURES = {
     'amdnuwa_error_string': (C.c_char_p, [I]),
     'amdnuwa_set_tuning': (I, [I, I]),
     'amdnuwa_get_tuning': (I, [I]),
+    'amdnuwa_f16_sat_count': (C.c_ulonglong, [I]),
     'amdnuwa_timer_arm': (None, [I]),
     'amdnuwa_timer_begin': (I, [P]),
     'amdnuwa_timer_end': (I, [P]),
     'amdnuwa_timer_collect': (I, [C.POINTER(C.c_double), C.POINTER(LL)]),
     'amdnuwa_gemm_nt': (I, [GD, P]),
+    'amdnuwa_gemm_tn_f16_supported': (I, [GD]),
     'amdnuwa_gemm_tn_workspace_bytes': (SZ, [GD]),
     'amdnuwa_gemm_tn': (I, [GD, P, SZ, P]),
     'amdnuwa_ln_fwd': (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, I, I, P]),
     'amdnuwa_ln_bwd_chain_workspace_bytes': (SZ, [LL, I]),
     'amdnuwa_ln_bwd_chain': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, I, P, SZ, P]),
+    'amdnuwa_ln_bwd_chain_f16': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, I, I, P, P, SZ, P]),
     'amdnuwa_ln_post_pre_fwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, F, I, I, P]),
     'amdnuwa_ln_bwd_workspace_bytes': (SZ, [LL, I]),
     'amdnuwa_ln_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, I, I, P, SZ, P]),
+    'amdnuwa_ln_bwd_f16': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, I, I, I, I, P, P, SZ, P]),
     'amdnuwa_colsum_workspace_bytes': (SZ, [LL, I]),
     'amdnuwa_colsum': (I, [P, P, LL, I, I, P, SZ, P]),
     'amdnuwa_geglu_fwd': (I, [P, P, P, P, LL, I, P]),

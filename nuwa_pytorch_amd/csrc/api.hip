@@ -7,7 +7,15 @@
 
 int g_amdnuwa_tuning[32] = {0};
 
-extern "C" int amdnuwa_abi_version(void) { return 15; }
+extern "C" int amdnuwa_abi_version(void) { return 16; }
+
+// fp16 saturation monitor: one counter word per translation unit with saturating fp16 stores (common.h: AMDNUWA_SAT_ACCESSOR)
+extern "C" unsigned amdnuwa_sat_elementwise(int), amdnuwa_sat_gemm(int), amdnuwa_sat_sparse3dna(int), amdnuwa_sat_xattn(int), amdnuwa_sat_xattn2(int);
+extern "C" unsigned long long amdnuwa_f16_sat_count(int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    return (unsigned long long)amdnuwa_sat_elementwise(reset) + amdnuwa_sat_gemm(reset) + amdnuwa_sat_sparse3dna(reset) + amdnuwa_sat_xattn(reset) +
+           amdnuwa_sat_xattn2(reset);
+}
 
 extern "C" int amdnuwa_set_tuning(int key, int value) {
     if (key < 0 || key >= 32) return AMDNUWA_ERR_ARG;

@@ -67,12 +67,37 @@ __device__ __forceinline__ uint32_t pack2_f16(float a, float b) {          // v_
 __device__ __forceinline__ float f16lo_f(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu)); }
 __device__ __forceinline__ float f16hi_f(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16)); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
-// SATURATING forms for activation / weight stores (LayerNorm copies, GEMM epilogues, K / V images): fp16 ends at 65504 and the plain
-// converter returns inf beyond it, which an MFMA turns into NaN rows.  v_med3_f32 clamps first (bit-identical for every in-range value;
-// NaN passes through as NaN).  Probabilities (<= 1) keep the plain converter.
-__device__ __forceinline__ float f16_clamp(float f) { return __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f); }
+// SATURATING forms for activation / weight / gradient stores (LayerNorm copies, GEMM epilogues, K / V images): fp16 ends at 65504 and
+// the plain converter returns inf beyond it, which an MFMA turns into NaN rows.  The clamp is v_minimum3_f32 + v_maximum3_f32 (gfx950:
+// the IEEE-754-2019 forms, which PROPAGATE NaN -- v_med3_f32 / v_min / v_max return the non-NaN operand, so a NaN activation used to become
+// -65504 in the fp16 copy while its bf16 copy held NaN); bit-identical for every in-range value.  Probabilities (<= 1) keep the plain converter.
+__device__ __forceinline__ float f16_clamp(float f) { return __builtin_elementwise_maximum(__builtin_elementwise_minimum(f, 65504.f), -65504.f); }
 __device__ __forceinline__ uint32_t pack2_f16_sat(float a, float b) { return pack2_f16(f16_clamp(a), f16_clamp(b)); }
 __device__ __forceinline__ uint16_t f2h_sat(float f) { return f2h(f16_clamp(f)); }
+// Saturation monitor: a store site keeps the running max |value| it handed to a saturating store (pack2_f16_sat_n: one v_max3_f32 per
+// pair) and reports ONCE per thread at the end (f16_sat_commit: an atomic only when something actually saturated).  The counter is one
+// word per translation unit (internal linkage); amdnuwa_f16_sat_count() sums the units (api.hip, AMDNUWA_SAT_ACCESSOR below).
+namespace { __device__ unsigned int g_f16_sat_events = 0; }
+__device__ __forceinline__ uint32_t pack2_f16_sat_n(float a, float b, float& amax) {
+    amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
+    return pack2_f16_sat(a, b);
+}
+__device__ __forceinline__ void f16_sat_commit(float amax) {
+    if (amax > 65504.f) atomicAdd(&g_f16_sat_events, 1u);
+}
+#define AMDNUWA_SAT_ACCESSOR(NAME)                                                                                  \
+    extern "C" __attribute__((visibility("hidden"))) unsigned amdnuwa_sat_##NAME(int reset) {                       \
+        unsigned v = 0;                                                                                             \
+        if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16_sat_events), sizeof(v)) != hipSuccess) return 0;               \
+        if (reset && v) { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_f16_sat_events), &z, sizeof(z)); } \
+        return v;                                                                                                   \
+    }
+// fp16 GRADIENTS of the 'bf16x3-fwd' backward (round 5): a gradient tensor travels as fp16(S * value) with S a power of two chosen once per
+// backward pass from the largest magnitude of the residual-stream gradient entering it (S * amax in [8, 16): the headroom to 65504 covers the
+// growth through a LayerNorm backward, the 11-bit significand keeps everything down to 2^-17 of that maximum normal).  Kernels receive a
+// device pointer to {S, 1 / S} (NULL = no scaling) so that no host synchronisation is needed.
+__device__ __forceinline__ float f16_gs(const float* scale2) { return scale2 ? scale2[0] : 1.f; }
+__device__ __forceinline__ float f16_gs_inv(const float* scale2) { return scale2 ? scale2[1] : 1.f; }
 template <bool F16> __device__ __forceinline__ uint32_t pack2_t(float a, float b) { return F16 ? pack2_f16(a, b) : pack2_rne(a, b); }
 template <bool F16> __device__ __forceinline__ float lo_t(uint32_t u) { return F16 ? f16lo_f(u) : lo_f(u); }
 template <bool F16> __device__ __forceinline__ float hi_t(uint32_t u) { return F16 ? f16hi_f(u) : hi_f(u); }

@@ -23,6 +23,27 @@ __device__ __forceinline__ float4 ld4(const void* base, size_t i) {
     }
     return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + i);
 }
+// the same for an fp16 array
+__device__ __forceinline__ float4 ld4h(const void* base, size_t i) {
+    const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + i);
+    return make_float4(f16lo_f(v.x), f16hi_f(v.x), f16lo_f(v.y), f16hi_f(v.y));
+}
+// FMT: 0 fp32, 1 bf16, 2 fp16
+template <int FMT>
+__device__ __forceinline__ float4 ld4f(const void* base, size_t i) {
+    if constexpr (FMT == 2) return ld4h(base, i);
+    else return ld4<FMT == 1>(base, i);
+}
+template <int FMT, int NV>
+__device__ __forceinline__ void row_load_f(const void* base, size_t row_off, int D, int lane, RowValsT<NV>& r, float mul = 1.f) {
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        const int e = (lane + it * 64) * 4;
+        const bool in = e < D;                       // branch-free (see row_load_t)
+        const float4 v = ld4f<FMT>(base, row_off + (in ? e : 0));
+        r.v[it] = make_float4(in ? v.x * mul : 0.f, in ? v.y * mul : 0.f, in ? v.z * mul : 0.f, in ? v.w * mul : 0.f);
+    }
+}
 template <bool BF, int NV>
 __device__ __forceinline__ void row_load_t(const void* base, size_t row_off, int D, int lane, RowValsT<NV>& r, float fill = 0.f) {
 #pragma unroll
@@ -75,11 +96,16 @@ __device__ __forceinline__ float4 ldp4(const float* __restrict__ p, int e, int D
     return make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
 }
 // lo_f16: the second copy is the fp16 rendering of the value (operand of the fp16 GEMMs of 'bf16x3-fwd'), not the bf16 residual
-__device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, float a, float b, float c, float d, bool lo_f16 = false) {
+// lo_f16 == 2 (lo must be NULL): `hi` itself receives the fp16 rendering -- the ONE 16-bit copy of the value when the backward of the block
+// runs on fp16 operands as well (round 5: no bf16 copy next to it).  sat: running max |value| of the saturating stores (f16_sat_commit).
+__device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, float a, float b, float c, float d, int lo_f16 = 0, float* sat = nullptr) {
+    float dummy = 0.f;
+    float& mx = sat ? *sat : dummy;
+    if (lo_f16 == 2) { *reinterpret_cast<uint2*>(hi + e) = make_uint2(pack2_f16_sat_n(a, b, mx), pack2_f16_sat_n(c, d, mx)); return; }
     if (!lo) { *reinterpret_cast<uint2*>(hi + e) = make_uint2(pack2_rne(a, b), pack2_rne(c, d)); return; }
     if (lo_f16) {
         *reinterpret_cast<uint2*>(hi + e) = make_uint2(pack2_rne(a, b), pack2_rne(c, d));
-        *reinterpret_cast<uint2*>(lo + e) = make_uint2(pack2_f16_sat(a, b), pack2_f16_sat(c, d));
+        *reinterpret_cast<uint2*>(lo + e) = make_uint2(pack2_f16_sat_n(a, b, mx), pack2_f16_sat_n(c, d, mx));
         return;
     }
     bf16_t h[4], l[4];
@@ -92,7 +118,7 @@ __device__ __forceinline__ void store_bf16x4(bf16_t* hi, bf16_t* lo, int e, floa
 // channels of token (f, y, w) belongs to token (f, y+1, w), the second to (f, y, w+1); a row writes zeros into its own quarter
 // when it has no source (y == 0 / w == 0).  The consumers (NT and TN GEMMs) then read a plain matrix.
 __device__ __forceinline__ void store_ln_shifted(bf16_t* out_hi, bf16_t* out_lo, long long row, int e, int D, int shift_ntok,
-                                                 int shift_fmap, float y0, float y1, float y2, float y3, bool lo_f16 = false) {
+                                                 int shift_fmap, float y0, float y1, float y2, float y3, int lo_f16 = 0, float* sat = nullptr) {
     long long drow = row;
     bool keep = true, zero_own = false;
     if (shift_ntok > 0 && shift_fmap < 0) {
@@ -109,8 +135,8 @@ __device__ __forceinline__ void store_ln_shifted(bf16_t* out_hi, bf16_t* out_lo,
             else         { keep = wq + 1 < shift_fmap && i + 1 < shift_ntok;          drow = row + 1;          zero_own = wq == 0; }
         }
     }
-    if (keep) store_bf16x4(out_hi + drow * D, out_lo ? out_lo + drow * D : nullptr, e, y0, y1, y2, y3, lo_f16);
-    if (zero_own) store_bf16x4(out_hi + row * D, out_lo ? out_lo + row * D : nullptr, e, 0.f, 0.f, 0.f, 0.f, lo_f16);
+    if (keep) store_bf16x4(out_hi + drow * D, out_lo ? out_lo + drow * D : nullptr, e, y0, y1, y2, y3, lo_f16, sat);
+    if (zero_own) store_bf16x4(out_hi + row * D, out_lo ? out_lo + row * D : nullptr, e, 0.f, 0.f, 0.f, 0.f, lo_f16, sat);
 }
 
 template <int NV>
@@ -170,6 +196,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         mean_o[row] = mean; rstd_o[row] = rstd;
         if (STABLE) inv_amax_o[row] = inv_amax;
     }
+    float sat = 0.f;
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
         const int e = (lane + it * 64) * 4;
@@ -181,12 +208,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const float y2 = (xv.v[it].z - mean) * rstd * wv.z + bv.z;
         const float y3 = (xv.v[it].w - mean) * rstd * wv.w + bv.w;
         if (MODE == 0) {
-            store_ln_shifted(out_hi, out_lo, row, e, D, shift_ntok, shift_fmap, y0, y1, y2, y3, lo_f16 != 0);
+            store_ln_shifted(out_hi, out_lo, row, e, D, shift_ntok, shift_fmap, y0, y1, y2, y3, lo_f16, &sat);
         } else {
             const float4 rv = *reinterpret_cast<const float4*>(resid + row * D + e);
             *reinterpret_cast<float4*>(out_f32 + row * D + e) = make_float4(rv.x + y0, rv.y + y1, rv.z + y2, rv.w + y3);
         }
     }
+    if (MODE == 0) f16_sat_commit(sat);
 }
 
 // Post-norm + residual of block k fused with the pre-norm (and token shift) of block k+1: the new residual stream row is
@@ -226,6 +254,7 @@ __global__ __launch_bounds__(256) void ln_post_pre_kernel(const float* __restric
     float mean2, rstd2;
     row_mean_rstd<NV>(xv, D, lane, eps, mean2, rstd2);
     if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; mean2_o[row] = mean2; rstd2_o[row] = rstd2; }
+    float sat = 0.f;
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
         const int e = (lane + it * 64) * 4;
@@ -234,8 +263,9 @@ __global__ __launch_bounds__(256) void ln_post_pre_kernel(const float* __restric
         const float4 bv = *reinterpret_cast<const float4*>(b2 + e);
         store_ln_shifted(h_hi, h_lo, row, e, D, shift_ntok, shift_fmap,
                          (xv.v[it].x - mean2) * rstd2 * wv.x + bv.x, (xv.v[it].y - mean2) * rstd2 * wv.y + bv.y,
-                         (xv.v[it].z - mean2) * rstd2 * wv.z + bv.z, (xv.v[it].w - mean2) * rstd2 * wv.w + bv.w, lo_f16 != 0);
+                         (xv.v[it].z - mean2) * rstd2 * wv.z + bv.z, (xv.v[it].w - mean2) * rstd2 * wv.w + bv.w, lo_f16, &sat);
     }
+    f16_sat_commit(sat);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -245,13 +275,16 @@ __global__ __launch_bounds__(256) void ln_post_pre_kernel(const float* __restric
 // Writes per-block partial sums [nblk][3][D]: dw, db, and sum(dx) (= bias grad of the Linear that
 // produced x, when there is one).  Grid-stride over rows, fixed order => deterministic.
 // ---------------------------------------------------------------------------------------------
-template <int OUT, bool STABLE, int NV, int IN>          // IN: 0 = dy, x fp32; 1 = x is bf16; 2 = dy is bf16
+// fp16 gradients (round 5; scale2 = device {S, 1 / S}, see common.h): IN == 3 reads dy as fp16(S * value) and multiplies by 1 / S;
+// out_f16 != 0 (OUT 0) writes dx_hi = fp16(S * dx), saturating, no lo part.
+template <int OUT, bool STABLE, int NV, int IN>          // IN: 0 = dy, x fp32; 1 = x is bf16; 2 = dy is bf16; 3 = dy is fp16, scaled
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ inv_amax_i, const float* __restrict__ w,
                                                      bf16_t* __restrict__ dx_hi, bf16_t* __restrict__ dx_lo,
                                                      float* dx_acc, const float* dres, float* __restrict__ partial,
-                                                     long long R, int D, int shift_ntok, int shift_fmap) {
+                                                     long long R, int D, int shift_ntok, int shift_fmap,
+                                                     const float* __restrict__ scale2, int out_f16) {
 #pragma clang fp contract(off)        // this kernel and the chained one must round identically: their results are compared bit for bit
     __shared__ float red[ROWS_PER_BLOCK][3][NV * 256];
     const int lane = threadIdx.x & 63, wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row math on the SALU
@@ -261,6 +294,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const int quarter = D >> 2;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool has_res = OUT == 1 && dres != nullptr;
+    constexpr int DYF = IN == 2 ? 1 : (IN == 3 ? 2 : 0);                 // storage of dy: fp32 / bf16 / fp16
+    const float gin = IN == 3 ? f16_gs_inv(scale2) : 1.f, gout = out_f16 ? f16_gs(scale2) : 1.f;
+    float sat = 0.f;
     struct RowIn { RowValsT<NV> xv, gv, rv; float mean, rstd, ia; };
     // everything one row needs from HBM, issued together (the residual-stream gradient included) ...
     auto load_row = [&](long long row, RowIn& in) {
@@ -286,11 +322,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 long long src = row;
                 if (i > 0 || audio) { if (e < quarter) src = src_h; else if (e < 2 * quarter) src = src_w; }
                 const bool has = src >= 0 && inr;
-                const float4 v = ld4<IN == 2>(dy, (size_t)(has ? src : row) * D + e);
-                in.gv.v[it] = make_float4(has ? v.x : 0.f, has ? v.y : 0.f, has ? v.z : 0.f, has ? v.w : 0.f);
+                const float4 v = ld4f<DYF>(dy, (size_t)(has ? src : row) * D + e);
+                if (IN == 3) in.gv.v[it] = make_float4(has ? v.x * gin : 0.f, has ? v.y * gin : 0.f, has ? v.z * gin : 0.f, has ? v.w * gin : 0.f);
+                else in.gv.v[it] = make_float4(has ? v.x : 0.f, has ? v.y : 0.f, has ? v.z : 0.f, has ? v.w : 0.f);
             }
         } else {
-            row_load_t<IN == 2>(dy, (size_t)row * D, D, lane, in.gv);
+            if (IN == 3) row_load_f<2>(dy, (size_t)row * D, D, lane, in.gv, gin);
+            else row_load_t<IN == 2>(dy, (size_t)row * D, D, lane, in.gv);
         }
         if (OUT == 1) {
             if (has_res) row_load(dres + row * D, D, lane, in.rv);
@@ -334,7 +372,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             const float d2 = sc * (g[it].z - m1 - xh[it].z * m2), d3 = sc * (g[it].w - m1 - xh[it].w * m2);
             ps[it].x += d0; ps[it].y += d1; ps[it].z += d2; ps[it].w += d3;
             if (OUT == 0) {
-                store_bf16x4(dx_hi + row * D, dx_lo ? dx_lo + row * D : nullptr, e, d0, d1, d2, d3);
+                if (out_f16) store_bf16x4(dx_hi + row * D, nullptr, e, d0 * gout, d1 * gout, d2 * gout, d3 * gout, 2, &sat);
+                else store_bf16x4(dx_hi + row * D, dx_lo ? dx_lo + row * D : nullptr, e, d0, d1, d2, d3);
             } else {
                 const float4 o = cur.rv.v[it];
                 *reinterpret_cast<float4*>(dx_acc + row * D + e) = make_float4(o.x + d0, o.y + d1, o.z + d2, o.w + d3);
@@ -349,6 +388,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         if (row + 2 * stride < R) load_row(row + 2 * stride, bufA);
         process(bufB, row + stride);
     }
+    if (OUT == 0) f16_sat_commit(sat);
     // block reduce the 4 waves' partials in fixed order
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
@@ -373,7 +413,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 // Partials: partA [nblk][3][D] = (dw_pre, db_pre, -) and partB [nblk][3][D] = (dw_post, db_post, sum(dy_prev)).
 // ---------------------------------------------------------------------------------------------
 // BFM: storage of the two 16-bit-capable inputs -- 0: dh and y_prev fp32; 1: both bf16; 2: dh bf16, y_prev fp32 (the 'bf16x3-fwd' mode:
-// its forward keeps the post-norm input in fp32, its backward produces bf16 dgrad outputs)
+// its forward keeps the post-norm input in fp32, its backward produces bf16 dgrad outputs); 3: dh fp16 = fp16(S * value), y_prev fp32
+// (the fp16-gradient backward of round 5).  out_f16 != 0: dy_prev leaves as fp16(S * value), saturating.  scale2: device {S, 1 / S}.
 template <int NV, int BFM, int NT = 0>          // NT bit 0: non-temporal stores, bit 1: non-temporal loads (tuning key 11)
 __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restrict__ dh, const float* __restrict__ x,
                                                            const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
@@ -383,9 +424,12 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
                                                            const float* __restrict__ wprev, bf16_t* __restrict__ dyp_hi,
                                                            bf16_t* __restrict__ dyp_lo, float* __restrict__ partA,
                                                            float* __restrict__ partB, long long R, int D, int shift_ntok,
-                                                           int shift_fmap) {
+                                                           int shift_fmap, const float* __restrict__ scale2, int out_f16) {
 #pragma clang fp contract(off)        // (see ln_bwd_kernel)
-    constexpr bool BF = BFM != 0, YBF = BFM == 1;
+    constexpr bool BF = BFM == 1 || BFM == 2, YBF = BFM == 1;
+    constexpr int DHF = BFM == 3 ? 2 : (BF ? 1 : 0);                     // storage of dh: fp32 / bf16 / fp16
+    const float gin = BFM == 3 ? f16_gs_inv(scale2) : 1.f, gout = out_f16 ? f16_gs(scale2) : 1.f;
+    float sat = 0.f;
     __shared__ float red[ROWS_PER_BLOCK][3][NV * 256];
     const int lane = threadIdx.x & 63, wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4 pwA[NV], pbA[NV], pwB[NV], pbB[NV], psB[NV];
@@ -419,11 +463,13 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
                 if (i > 0 || audio) { if (e < quarter) src = src_h; else if (e < 2 * quarter) src = src_w; }
                 const bool has = src >= 0 && inr;                                    // branch-free: rows without a source re-read their own row
                 const size_t so = (size_t)(has ? src : row) * D + e;
-                const float4 v = (NT & 2) ? ld4_nt<BF>(dh, so) : ld4<BF>(dh, so);
-                in.gv.v[it] = make_float4(has ? v.x : 0.f, has ? v.y : 0.f, has ? v.z : 0.f, has ? v.w : 0.f);
+                const float4 v = BFM == 3 ? ld4h(dh, so) : ((NT & 2) ? ld4_nt<BF>(dh, so) : ld4<BF>(dh, so));
+                if (BFM == 3) in.gv.v[it] = make_float4(has ? v.x * gin : 0.f, has ? v.y * gin : 0.f, has ? v.z * gin : 0.f, has ? v.w * gin : 0.f);
+                else in.gv.v[it] = make_float4(has ? v.x : 0.f, has ? v.y : 0.f, has ? v.z : 0.f, has ? v.w : 0.f);
             }
         } else {
-            row_load_t<BF>(dh, (size_t)row * D, D, lane, in.gv);
+            if (BFM == 3) row_load_f<2>(dh, (size_t)row * D, D, lane, in.gv, gin);
+            else row_load_t<BF>(dh, (size_t)row * D, D, lane, in.gv);
         }
         if (NT & 2) {
 #pragma unroll
@@ -492,7 +538,8 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
             const float d0 = cur.rstdp * (g[it].x - n1 - xh[it].x * n2), d1 = cur.rstdp * (g[it].y - n1 - xh[it].y * n2);
             const float d2 = cur.rstdp * (g[it].z - n1 - xh[it].z * n2), d3 = cur.rstdp * (g[it].w - n1 - xh[it].w * n2);
             psB[it].x += d0; psB[it].y += d1; psB[it].z += d2; psB[it].w += d3;
-            if ((NT & 1) && !dyp_lo) st_bf16x4_nt(dyp_hi + row * D + e, d0, d1, d2, d3);
+            if (out_f16) store_bf16x4(dyp_hi + row * D, nullptr, e, d0 * gout, d1 * gout, d2 * gout, d3 * gout, 2, &sat);
+            else if ((NT & 1) && !dyp_lo) st_bf16x4_nt(dyp_hi + row * D + e, d0, d1, d2, d3);
             else store_bf16x4(dyp_hi + row * D, dyp_lo ? dyp_lo + row * D : nullptr, e, d0, d1, d2, d3);
         }
     };
@@ -504,6 +551,7 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
         if (row + 2 * stride < R) load_row(row + 2 * stride, bufA);
         process(bufB, row + stride);
     }
+    f16_sat_commit(sat);
     // block reduce the 4 waves' partials in fixed order, one LayerNorm at a time through the same LDS
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();
@@ -1029,7 +1077,8 @@ extern "C" int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w
                               uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R,
                               int D, int mode, int stable, float eps, int shift_ntok, int shift_fmap, hipStream_t stream) {
     const bool xbf = (mode & AMDNUWA_LN_X_BF16) != 0;        // x points at bf16 values
-    const int lo_f16 = (mode & AMDNUWA_LN_LO_F16) ? 1 : 0;    // out_lo receives fp16(value) instead of the bf16 residual
+    const int lo_f16 = (mode & AMDNUWA_LN_OUT_F16) ? 2 : ((mode & AMDNUWA_LN_LO_F16) ? 1 : 0);   // 1: out_lo = fp16 copy; 2: out_hi itself is fp16
+    if (lo_f16 == 2 && out_lo) return AMDNUWA_ERR_ARG;
     mode &= 1;
     if (shift_ntok > 0 && (mode != 0 || shift_fmap == 0 || shift_fmap < -1 || D % 16)) return AMDNUWA_ERR_ARG;
     if (!x || !w || !b || !mean || !rstd || D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
@@ -1055,7 +1104,8 @@ extern "C" int amdnuwa_ln_post_pre_fwd(const float* y, const float* resid, const
                                        uint16_t* h_lo, float* next_mean, float* next_rstd, long long R, int D, int flags,
                                        float eps, int shift_ntok, int shift_fmap, hipStream_t stream) {
     const bool xbf = (flags & AMDNUWA_LN_X_BF16) != 0;
-    const int lo_f16 = (flags & AMDNUWA_LN_LO_F16) ? 1 : 0;
+    const int lo_f16 = (flags & AMDNUWA_LN_OUT_F16) ? 2 : ((flags & AMDNUWA_LN_LO_F16) ? 1 : 0);
+    if (lo_f16 == 2 && h_lo) return AMDNUWA_ERR_ARG;
     if (!y || !resid || !w || !b || !out_f32 || !mean || !rstd || !next_w || !next_b || !h_hi || !next_mean || !next_rstd)
         return AMDNUWA_ERR_ARG;
     if (D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
@@ -1082,8 +1132,19 @@ extern "C" int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean
                               const float* w, uint16_t* dx_hi, uint16_t* dx_lo, float* dx_acc, const float* dres, float* dw, float* db,
                               float* dsum, long long R, int D, int shift_ntok, int shift_fmap, int stable, int accumulate,
                               void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    const int in_kind = (stable & AMDNUWA_LN_X_BF16) ? 1 : ((stable & AMDNUWA_LN_DY_BF16) ? 2 : 0);
-    if ((stable & AMDNUWA_LN_X_BF16) && (stable & AMDNUWA_LN_DY_BF16)) return AMDNUWA_ERR_UNSUPPORTED;
+    return amdnuwa_ln_bwd_f16(dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, dw, db, dsum, R, D, shift_ntok, shift_fmap, stable,
+                              accumulate, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int amdnuwa_ln_bwd_f16(const float* dy, const float* x, const float* mean, const float* rstd, const float* inv_amax,
+                                  const float* w, uint16_t* dx_hi, uint16_t* dx_lo, float* dx_acc, const float* dres, float* dw, float* db,
+                                  float* dsum, long long R, int D, int shift_ntok, int shift_fmap, int stable, int accumulate,
+                                  const float* scale2, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const int dy16 = (stable & AMDNUWA_LN_DY_F16) ? 1 : 0, out_f16 = (stable & AMDNUWA_LN_OUT_F16) ? 1 : 0;
+    const int in_kind = (stable & AMDNUWA_LN_X_BF16) ? 1 : ((stable & AMDNUWA_LN_DY_BF16) ? 2 : (dy16 ? 3 : 0));
+    if ((stable & AMDNUWA_LN_X_BF16) && (stable & (AMDNUWA_LN_DY_BF16 | AMDNUWA_LN_DY_F16))) return AMDNUWA_ERR_UNSUPPORTED;
+    if ((stable & AMDNUWA_LN_DY_BF16) && dy16) return AMDNUWA_ERR_ARG;
+    if (out_f16 && (!dx_hi || dx_lo)) return AMDNUWA_ERR_ARG;
     stable &= 1;
     if (!dy || !x || !mean || !rstd || !w || D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
     if ((dx_hi == nullptr) == (dx_acc == nullptr)) return AMDNUWA_ERR_ARG;   // exactly one output form
@@ -1099,8 +1160,8 @@ extern "C" int amdnuwa_ln_bwd(const float* dy, const float* x, const float* mean
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
 #define LNB_OCC(OU, ST, NV_, IN_) do { int o_ = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_, ln_bwd_kernel<OU, ST, NV_, IN_>, 256, 0) == hipSuccess && o_ > 0 && o_ * n_cu < nb) nb = o_ * n_cu; } while (0)
-#define LNB_(OU, ST, NV_, IN_) do { LNB_OCC(OU, ST, NV_, IN_); hipLaunchKernelGGL((ln_bwd_kernel<OU, ST, NV_, IN_>), dim3(nb), block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap); } while (0)
-#define LNB(OU, ST, NV_) do { if (in_kind == 1) LNB_(OU, ST, NV_, 1); else if (in_kind == 2) LNB_(OU, ST, NV_, 2); else LNB_(OU, ST, NV_, 0); } while (0)
+#define LNB_(OU, ST, NV_, IN_) do { LNB_OCC(OU, ST, NV_, IN_); hipLaunchKernelGGL((ln_bwd_kernel<OU, ST, NV_, IN_>), dim3(nb), block, 0, stream, dy, x, mean, rstd, inv_amax, w, dx_hi, dx_lo, dx_acc, dres, part, R, D, shift_ntok, shift_fmap, scale2, out_f16); } while (0)
+#define LNB(OU, ST, NV_) do { if (in_kind == 1) LNB_(OU, ST, NV_, 1); else if (in_kind == 2) LNB_(OU, ST, NV_, 2); else if (in_kind == 3) LNB_(OU, ST, NV_, 3); else LNB_(OU, ST, NV_, 0); } while (0)
 #define LNB_NV(OU, ST) do { if (D <= 256) LNB(OU, ST, 1); else if (D <= 512) LNB(OU, ST, 2); else LNB(OU, ST, 4); } while (0)
     if (dx_hi) { if (stable) LNB_NV(0, true); else LNB_NV(0, false); }
     else       { if (stable) LNB_NV(1, true); else LNB_NV(1, false); }
@@ -1121,11 +1182,24 @@ extern "C" int amdnuwa_ln_bwd_chain(const void* dh, const float* x, const float*
                                     const float* rstd_prev, const float* w_prev, uint16_t* dy_prev_hi, uint16_t* dy_prev_lo,
                                     float* dw_prev, float* db_prev, float* dsum_prev, long long R, int D, int shift_ntok,
                                     int shift_fmap, int inputs_bf16, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (inputs_bf16 < 0 || inputs_bf16 > 2) return AMDNUWA_ERR_ARG;
+    return amdnuwa_ln_bwd_chain_f16(dh, x, mean, rstd, w, g, dx, dw, db, y_prev, mean_prev, rstd_prev, w_prev, dy_prev_hi, dy_prev_lo, dw_prev,
+                                    db_prev, dsum_prev, R, D, shift_ntok, shift_fmap, inputs_bf16, 0, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int amdnuwa_ln_bwd_chain_f16(const void* dh, const float* x, const float* mean, const float* rstd, const float* w,
+                                        const float* g, float* dx, float* dw, float* db, const void* y_prev, const float* mean_prev,
+                                        const float* rstd_prev, const float* w_prev, uint16_t* dy_prev_hi, uint16_t* dy_prev_lo,
+                                        float* dw_prev, float* db_prev, float* dsum_prev, long long R, int D, int shift_ntok,
+                                        int shift_fmap, int inputs_bf16, int dy_prev_f16, const float* scale2, void* workspace,
+                                        size_t workspace_bytes, hipStream_t stream) {
+    const int out_f16 = dy_prev_f16 ? 1 : 0;
+    if (out_f16 && dy_prev_lo) return AMDNUWA_ERR_ARG;
     if (!dh || !x || !mean || !rstd || !w || !g || !dx || !y_prev || !mean_prev || !rstd_prev || !w_prev || !dy_prev_hi)
         return AMDNUWA_ERR_ARG;
     if (D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;
     if (shift_ntok > 0 && (shift_fmap == 0 || shift_fmap < -1 || D % 16)) return AMDNUWA_ERR_ARG;
-    if (inputs_bf16 < 0 || inputs_bf16 > 2) return AMDNUWA_ERR_ARG;
+    if (inputs_bf16 < 0 || inputs_bf16 > 3) return AMDNUWA_ERR_ARG;
     if (!workspace || workspace_bytes < amdnuwa_ln_bwd_chain_workspace_bytes(R, D)) return AMDNUWA_ERR_WORKSPACE;
     if (R <= 0) return AMDNUWA_OK;
     int nb = ln_bwd_blocks(R);
@@ -1136,9 +1210,9 @@ extern "C" int amdnuwa_ln_bwd_chain(const void* dh, const float* x, const float*
     const int nt = g_amdnuwa_tuning[11] & 3;
 #define LBC__(NV_, BF_, NT_) do { int o_ = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o_, ln_bwd_chain_kernel<NV_, BF_, NT_>, 256, 0) == hipSuccess && o_ > 0 && o_ * n_cu < nb) nb = o_ * n_cu; \
         if (g_amdnuwa_tuning[12] > 0 && g_amdnuwa_tuning[12] * n_cu < nb) nb = g_amdnuwa_tuning[12] * n_cu; \
-        hipLaunchKernelGGL((ln_bwd_chain_kernel<NV_, BF_, NT_>), dim3(nb), dim3(256), 0, stream, (const float*)dh, x, mean, rstd, w, g, dx, (const float*)y_prev, mean_prev, rstd_prev, w_prev, dy_prev_hi, dy_prev_lo, partA, partB, R, D, shift_ntok, shift_fmap); } while (0)
+        hipLaunchKernelGGL((ln_bwd_chain_kernel<NV_, BF_, NT_>), dim3(nb), dim3(256), 0, stream, (const float*)dh, x, mean, rstd, w, g, dx, (const float*)y_prev, mean_prev, rstd_prev, w_prev, dy_prev_hi, dy_prev_lo, partA, partB, R, D, shift_ntok, shift_fmap, scale2, out_f16); } while (0)
 #define LBC_(NV_, BF_) do { if (nt == 0) LBC__(NV_, BF_, 0); else if (nt == 1) LBC__(NV_, BF_, 1); else if (nt == 2) LBC__(NV_, BF_, 2); else LBC__(NV_, BF_, 3); } while (0)
-#define LBC(NV_) do { if (inputs_bf16 == 1) LBC_(NV_, 1); else if (inputs_bf16 == 2) LBC_(NV_, 2); else LBC_(NV_, 0); } while (0)
+#define LBC(NV_) do { if (inputs_bf16 == 1) LBC_(NV_, 1); else if (inputs_bf16 == 2) LBC_(NV_, 2); else if (inputs_bf16 == 3) LBC__(NV_, 3, 0); else LBC_(NV_, 0); } while (0)
     if (D <= 256) LBC(1); else if (D <= 512) LBC(2); else LBC(4);
 #undef LBC
 #undef LBC_
@@ -1149,6 +1223,8 @@ extern "C" int amdnuwa_ln_bwd_chain(const void* dh, const float* x, const float*
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
+
+AMDNUWA_SAT_ACCESSOR(elementwise)
 
 namespace {
 __global__ __launch_bounds__(256) void hilo_to_f16_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo, int ld_in,

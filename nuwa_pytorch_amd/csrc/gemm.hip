@@ -44,6 +44,7 @@ struct GemmArgs {
     // target logit in pass 1; dlogits = (exp(logit - lse) - onehot) * ce_scale in pass 2.  The logits never reach memory.
     float* ce_stats; float* ce_tl; const float* ce_lse; const long long* ce_tgt; float ce_scale; int ce_nblk;
     int skew;               // start-phase step of the first-generation workgroups in s_sleep(8) units (tuning key 14; 0 = off)
+    int c_f16;              // F16 rings, EPI 1: C / the GEGLU-backward output C2 are fp16 (saturating), not bf16 (the fp16-gradient backward)
 };
 
 __device__ __forceinline__ long long boff(const GemmArgs& p, long long z, long long s, long long s_in) {
@@ -515,6 +516,28 @@ __device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&
                 dp[2 * q + 1] = make_uint4(pack2_rne(dgt[0], dgt[1]), pack2_rne(dgt[2], dgt[3]), pack2_rne(dgt[4], dgt[5]), pack2_rne(dgt[6], dgt[7]));
             }
         };
+        float sat = 0.f;                                            // (fp16 saturation monitor: common.h)
+        // the same from fp32 dgg to an FP16 du (the fp16-gradient backward: operands fp16(S * gradient), u still bf16, read element-wise)
+        auto geglu_bwd_store16 = [&](const float (&dgg)[16], const uint4 (&uu)[4], uint4* dp) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint4 av = uu[2 * q], gv = uu[2 * q + 1];
+                const uint32_t wa[4] = {av.x, av.y, av.z, av.w}, wg[4] = {gv.x, gv.y, gv.z, gv.w};
+                float da[8], dgt[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float y, dy;
+                    gelu_both_f(lo_f(wg[k]), y, dy);
+                    da[2 * k] = dgg[8 * q + 2 * k] * y;
+                    dgt[2 * k] = dgg[8 * q + 2 * k] * lo_f(wa[k]) * dy;
+                    gelu_both_f(hi_f(wg[k]), y, dy);
+                    da[2 * k + 1] = dgg[8 * q + 2 * k + 1] * y;
+                    dgt[2 * k + 1] = dgg[8 * q + 2 * k + 1] * hi_f(wa[k]) * dy;
+                }
+                dp[2 * q] = make_uint4(pack2_f16_sat_n(da[0], da[1], sat), pack2_f16_sat_n(da[2], da[3], sat), pack2_f16_sat_n(da[4], da[5], sat), pack2_f16_sat_n(da[6], da[7], sat));
+                dp[2 * q + 1] = make_uint4(pack2_f16_sat_n(dgt[0], dgt[1], sat), pack2_f16_sat_n(dgt[2], dgt[3], sat), pack2_f16_sat_n(dgt[4], dgt[5], sat), pack2_f16_sat_n(dgt[6], dgt[7], sat));
+            }
+        };
         if (p.Uin && !p.Clo && vec8 && m0 + 256 <= p.M && n0 + BN <= p.N && !p.dbg) {
             // full tile of the GEGLU backward: a straight-line loop with u of the NEXT row fragment in flight while this one is finished
             // (in the generic loop below every fragment's loads sit behind its row checks and wait with vmcnt(0) -- on the previous
@@ -539,6 +562,11 @@ __device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha + bias16[j * 4 + r];
+                if (F16 && p.c_f16) {
+                    // (the product value dgg[8 q + k] belongs to value column 8 q + k of the lane's two [8 values | 8 gates] groups)
+                    geglu_bwd_store16(vv, uc, reinterpret_cast<uint4*>(dbase + (long long)i * 16 * p.ldc2));
+                    continue;
+                }
                 const uint4 ua = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
                 const uint4 ug = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
                 geglu_bwd_store(ua, ug, uc, reinterpret_cast<uint4*>(dbase + (long long)i * 16 * p.ldc2));
@@ -559,6 +587,17 @@ __device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
             bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;
             if ((F16 || !Cl) && vec8 && nb + 16 <= p.N) {          // (F16: Clo, when given, receives the fp16 copy of the product)
+                if (F16 && p.c_f16) {                                  // fp16-gradient backward: ONE fp16 output, saturating
+                    if (p.Uin) {
+                        const uint4* up = reinterpret_cast<const uint4*>(p.Uin + m * p.ldu + 2 * nb);
+                        const uint4 uu[4] = {up[0], up[1], up[2], up[3]};
+                        geglu_bwd_store16(vv, uu, reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + 2 * nb));
+                        continue;
+                    }
+                    reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2_f16_sat_n(vv[0], vv[1], sat), pack2_f16_sat_n(vv[2], vv[3], sat), pack2_f16_sat_n(vv[4], vv[5], sat), pack2_f16_sat_n(vv[6], vv[7], sat));
+                    reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2_f16_sat_n(vv[8], vv[9], sat), pack2_f16_sat_n(vv[10], vv[11], sat), pack2_f16_sat_n(vv[12], vv[13], sat), pack2_f16_sat_n(vv[14], vv[15], sat));
+                    continue;
+                }
                 const uint4 ua = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
                 const uint4 ug = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
                 if (p.Uin) {
@@ -573,15 +612,15 @@ __device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&
                 reinterpret_cast<uint4*>(C)[1] = ug;
                 if constexpr (F16) {
                     if (Cl) {              // fp16 copy of the product itself (q / k / v for the fp16 attention core)
-                        reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2_f16_sat(vv[0], vv[1]), pack2_f16_sat(vv[2], vv[3]), pack2_f16_sat(vv[4], vv[5]), pack2_f16_sat(vv[6], vv[7]));
-                        reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2_f16_sat(vv[8], vv[9]), pack2_f16_sat(vv[10], vv[11]), pack2_f16_sat(vv[12], vv[13]), pack2_f16_sat(vv[14], vv[15]));
+                        reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2_f16_sat_n(vv[0], vv[1], sat), pack2_f16_sat_n(vv[2], vv[3], sat), pack2_f16_sat_n(vv[4], vv[5], sat), pack2_f16_sat_n(vv[6], vv[7], sat));
+                        reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2_f16_sat_n(vv[8], vv[9], sat), pack2_f16_sat_n(vv[10], vv[11], sat), pack2_f16_sat_n(vv[12], vv[13], sat), pack2_f16_sat_n(vv[14], vv[15], sat));
                     }
                     if (p.C2) {            // gate on the fp32 accumulators; fp16 copy -> C2 (FF2's A operand), bf16 copy -> C2lo (backward)
                         float o[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = vv[e] * gelu_f(vv[8 + e]);
                         *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) =
-                            make_uint4(pack2_f16_sat(o[0], o[1]), pack2_f16_sat(o[2], o[3]), pack2_f16_sat(o[4], o[5]), pack2_f16_sat(o[6], o[7]));
+                            make_uint4(pack2_f16_sat_n(o[0], o[1], sat), pack2_f16_sat_n(o[2], o[3], sat), pack2_f16_sat_n(o[4], o[5], sat), pack2_f16_sat_n(o[6], o[7], sat));
                         if (p.C2lo)
                             *reinterpret_cast<uint4*>(p.C2lo + m * p.ldc2 + (nb >> 1)) =
                                 make_uint4(pack2_rne(o[0], o[1]), pack2_rne(o[2], o[3]), pack2_rne(o[4], o[5]), pack2_rne(o[6], o[7]));
@@ -620,6 +659,7 @@ __device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&
                 }
             }
         }
+        if constexpr (F16) f16_sat_commit(sat);
     } else {
     float biasf[4][4];                               // (loaded once per tile: see the bf16 epilogue)
 #pragma unroll
@@ -2173,6 +2213,8 @@ __global__ __launch_bounds__(512) void gemm_tn_256_kernel(GemmArgs p, float* __r
 // (host side); columns past the leading dimension are clamped (columns past N1 / N2 only feed outputs that are never stored).
 // Accumulation order per output element = token rows ascending in chunks of 32, as gemm_tn_256_kernel: bit-identical partials.
 // ---------------------------------------------------------------------------------------------
+// F16: both operands hold fp16 values (fp16 gradients x the fp16 activation copies of the 'bf16x3-fwd' mode, round 5): the fp16 MFMA, nothing else differs.
+template <bool F16>
 __global__ __launch_bounds__(256, 1) void gemm_tn_w4k_kernel(GemmArgs p, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 64 * 256 * 2;             // one operand image of a stage: 32 KiB
@@ -2251,7 +2293,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4k_kernel(GemmArgs p, float* 
                  "+v"(bfr[H][6]), "+v"(bfr[H][7]))
 #define TK_RDA(H, I, SO) do { af[H][I] = rd(ada[I] + (H) * 16384); TK_PIN(); } while (0)
 #define TK_RDB(H, Q, SO) do { bfr[H][Q] = rd(adb[Q] + (H) * 16384); TK_PIN(); } while (0)
-#define TK_MF(H, I, Q) do { acc[(Q) >> 2][I][(Q) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[H][Q], af[H][I], acc[(Q) >> 2][I][(Q) & 3], 0, 0, 0); TK_PIN(); } while (0)
+#define TK_MF(H, I, Q) do { acc[(Q) >> 2][I][(Q) & 3] = mfma16<F16>(bfr[H][Q], af[H][I], acc[(Q) >> 2][I][(Q) & 3]); TK_PIN(); } while (0)
     if (nit > 0) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) issue_piece(q, 0, 0);
@@ -2332,7 +2374,9 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4k_kernel(GemmArgs p, float* 
 
 // C[bz][n1][n2] = beta*C + alpha * sum_z partial[bz][z][n1][n2]   (fixed order -> deterministic)
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, long long sC, long long sC_in,
-                                     int batch_inner, int ldc, int N1, int N2, int splits, float alpha, float beta) {
+                                     int batch_inner, int ldc, int N1, int N2, int splits, float alpha, float beta,
+                                     const float* __restrict__ alpha_dev) {
+    if (alpha_dev) alpha *= *alpha_dev;          // (1 / S of an fp16-gradient backward: a device scalar, no host synchronisation)
     const size_t per = (size_t)N1 * N2;
     const int bz = blockIdx.y;
     if ((N2 & 3) == 0 && (ldc & 3) == 0 && (sC & 3) == 0 && (sC_in & 3) == 0 && (reinterpret_cast<size_t>(C) & 15) == 0) {
@@ -2660,7 +2704,9 @@ extern "C" int amdnuwa_gemm_nt_fused(const amdnuwa_gemm_desc* d) { return d && d
 
 // fp16 operands (d->ab_f16): the 256x256 ring only -- the FeedForward GEMMs of the 'bf16x3-fwd' forward
 extern "C" int amdnuwa_gemm_nt_f16ops_supported(const amdnuwa_gemm_desc* d) {
-    if (!d || !d->A || !d->B || !d->C || d->Alo || d->Blo || d->shift_ntok > 0 || d->batch > 1 || d->geglu_u) return 0;
+    if (!d || !d->A || !d->B || !d->C || d->Alo || d->Blo || d->shift_ntok > 0 || d->batch > 1) return 0;
+    if (d->geglu_u && !(d->c_f16 && d->c_is_bf16 && d->C2 && !d->Clo && !d->C2lo && !d->geglu_u_lo && d->ld_u % 8 == 0)) return 0;   // GEGLU backward: fp16 du only
+    if (d->c_f16 && (!d->c_is_bf16 || d->Clo || d->C2lo || (d->C2 && !d->geglu_u))) return 0;     // fp16 output: one copy, no forward gate
     if (d->Clo && (!d->c_is_bf16 || d->C2)) return 0;              // Clo = fp16 copy of a bf16 output (no gate at the same time)
     if (d->K % 32 || d->lda % 8 || d->ldb % 8 || d->M <= 4 * ROWS_MR) return 0;
     if (d->c_is_bf16 && (d->N % 16 || d->ldc % 8 || (d->C2 && d->ldc2 % 8))) return 0;
@@ -2741,6 +2787,8 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         q.tiles_m = (d->M + 255) / 256; q.tiles_n = (d->N + 255) / 256;
         q.dbg = g_amdnuwa_tuning[7];
         if (d->C2) { q.C2 = (bf16_t*)d->C2; q.C2lo = (bf16_t*)d->C2lo; q.ldc2 = d->ldc2; }
+        if (d->geglu_u) { q.Uin = (const bf16_t*)d->geglu_u; q.ldu = d->ld_u; }
+        q.c_f16 = d->c_f16 ? 1 : 0;
         q.skew = nt_skew((long long)q.tiles_m * q.tiles_n);
         if (g_amdnuwa_tuning[0] == 6) {              // probe: 256x128 tile, 3-stage ring, TWO workgroups per CU (one's epilogue under the other's main loop)
             q.tiles_n = (d->N + 127) / 128;
@@ -2835,7 +2883,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     p.ksplit_len = 0;
     p.dbg = g_amdnuwa_tuning[7];
     p.skew = 0;
-    p.C2 = nullptr; p.C2lo = nullptr; p.ldc2 = 0; p.Uin = nullptr; p.ldu = 0; p.lo_f16 = 0;
+    p.C2 = nullptr; p.C2lo = nullptr; p.ldc2 = 0; p.Uin = nullptr; p.ldu = 0; p.lo_f16 = 0; p.c_f16 = 0;
     p.batch_inner = d->batch_inner; p.sA_in = d->strideA_inner; p.sB_in = d->strideB_inner; p.sC_in = d->strideC_inner;
     const bool x3 = d->Alo != nullptr, sh = d->shift_ntok > 0, ob = d->c_is_bf16 != 0;
     // a handful of rows (the decode step of generate()): stream the weight instead of running MFMA tiles
@@ -3070,6 +3118,12 @@ static int tn_splits(const amdnuwa_gemm_desc* d) {
     return splits;
 }
 
+// fp16 operands (d->ab_f16): the four-wave kernel only
+extern "C" int amdnuwa_gemm_tn_f16_supported(const amdnuwa_gemm_desc* d) {
+    if (!d || d->Alo || d->Blo || d->shift_ntok > 0 || d->lda % 8 || d->ldb % 8) return 0;
+    return tn_variant(d) == 3 && tn_w4k_ok(d) ? 1 : 0;
+}
+
 extern "C" size_t amdnuwa_gemm_tn_workspace_bytes(const amdnuwa_gemm_desc* d) {
     if (!d) return 0;
     return (size_t)tn_splits(d) * (d->batch > 0 ? d->batch : 1) * (size_t)d->M * d->N * sizeof(float);
@@ -3083,7 +3137,9 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
     if ((d->Alo == nullptr) != (d->Blo == nullptr)) return AMDNUWA_ERR_ARG;
     if (d->shift_ntok > 0 && (d->shift_fmap <= 0 || d->N % 32)) return AMDNUWA_ERR_ARG;
     if (workspace_bytes < amdnuwa_gemm_tn_workspace_bytes(d) || !workspace) return AMDNUWA_ERR_WORKSPACE;
+    if (d->ab_f16 && !amdnuwa_gemm_tn_f16_supported(d)) return AMDNUWA_ERR_UNSUPPORTED;
     GemmArgs p;
+    p.c_f16 = 0;
     p.A = (const bf16_t*)d->A; p.Alo = (const bf16_t*)d->Alo; p.sA = d->strideA; p.lda = d->lda;
     p.B = (const bf16_t*)d->B; p.Blo = (const bf16_t*)d->Blo; p.sB = d->strideB; p.ldb = d->ldb;
     p.C = d->C; p.Clo = nullptr; p.sC = d->strideC; p.ldc = d->ldc;
@@ -3120,8 +3176,13 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
         if (!sh && tn_w4k_ok(d)) {                                               // four waves, 64 token rows per iteration (gemm_tn_w4k_kernel)
             dim3 b4(256);
             const size_t l4 = (size_t)2 * 2 * 64 * 256 * 2;
-            (void)hipFuncSetAttribute((const void*)gemm_tn_w4k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
-            hipLaunchKernelGGL(gemm_tn_w4k_kernel, g256, b4, l4, stream, p, part);
+            if (d->ab_f16) {
+                (void)hipFuncSetAttribute((const void*)gemm_tn_w4k_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+                hipLaunchKernelGGL(gemm_tn_w4k_kernel<true>, g256, b4, l4, stream, p, part);
+            } else {
+                (void)hipFuncSetAttribute((const void*)gemm_tn_w4k_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+                hipLaunchKernelGGL(gemm_tn_w4k_kernel<false>, g256, b4, l4, stream, p, part);
+            }
         } else
         if (sh) { if (stag) TN256(true, true); else TN256(true, false); }
         else    { if (stag) TN256(false, true); else TN256(false, false); }
@@ -3145,7 +3206,9 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
     const size_t per = (size_t)d->M * d->N;
     int rb = (int)((per + 255) / 256); if (rb > 2048) rb = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb, batch), dim3(256), 0, stream, part, (float*)d->C, (long long)d->strideC,
-                       (long long)d->strideC_inner, d->batch_inner, d->ldc, d->M, d->N, splits, d->alpha, d->beta);
+                       (long long)d->strideC_inner, d->batch_inner, d->ldc, d->M, d->N, splits, d->alpha, d->beta, d->alpha_dev);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
+
+AMDNUWA_SAT_ACCESSOR(gemm)

@@ -2536,3 +2536,5 @@ extern "C" int amdnuwa_cross2dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* q
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
+
+AMDNUWA_SAT_ACCESSOR(sparse3dna)

@@ -765,3 +765,5 @@ extern "C" int amdnuwa_xattn_unpack(const amdnuwa_xattn_geom* g, const float* dK
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
+
+AMDNUWA_SAT_ACCESSOR(xattn)

@@ -1371,3 +1371,5 @@ extern "C" int amdnuwa_xattn2_bwd_rc(const amdnuwa_xattn_geom* g, const uint16_t
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
+
+AMDNUWA_SAT_ACCESSOR(xattn2)

@@ -89,6 +89,8 @@ def fast_io():
 
 def hi_only(t):
     """the hi part of a BF pair (what the mixed mode keeps for its bf16 backward); anything else passes through"""
+    if isinstance(t, BF) and t.hi is None:
+        return t                                   # fp16-only form: the backward of the block reads the fp16 copy
     return BF(t.hi, None) if isinstance(t, BF) and (t.lo is not None or t.f16 is not None) else t
 
 
@@ -104,6 +106,47 @@ def set_cores_f16(on):
 
 def cores_f16():
     return _CORES_F16 and mixed()
+
+
+# fp16 gradients in the backward of 'bf16x3-fwd' (round 5).  A block whose class is switched on keeps ONE 16-bit copy of each activation --
+# the fp16 one its forward reads -- and runs its backward on fp16 MFMAs as well: gradients travel as fp16(S * value), S a power of two taken
+# once per backward pass from the residual-stream gradient (ops._grad_scale), weight gradients leave the split-K reduction multiplied by
+# 1 / S.  Classes: 'f' FeedForward, 's' Sparse3DNA, 'x' cross attention (env AMDNUWA_BWD_F16, '0' / '' = off).
+DEFAULT_BWD_F16 = 'f'
+G16 = namedtuple('G16', ['t', 's2'])        # t: fp16 tensor holding S * value; s2: device tensor {S, 1 / S}
+
+
+def _bwd16_classes(v):
+    if v in (True, '1', 'all'):
+        return frozenset('fsx')
+    if v in (False, None, '0', ''):
+        return frozenset()
+    assert set(v) <= set('fsx'), v
+    return frozenset(v)
+
+
+_BWD_F16 = _bwd16_classes(os.environ.get('AMDNUWA_BWD_F16', DEFAULT_BWD_F16))
+
+
+def set_bwd_f16(on):
+    """'bf16x3-fwd' only: which block classes run their backward on fp16 gradients and keep a single (fp16) copy of their activations"""
+    global _BWD_F16
+    _BWD_F16 = _bwd16_classes(on)
+
+
+def bwd_f16(cls=None):
+    return mixed() and (bool(_BWD_F16) if cls is None else cls in _BWD_F16)
+
+
+def f16_sat_count(reset=True):
+    """threads that handed a value beyond +-65504 to a saturating fp16 store since the last reset (synchronises the device)"""
+    return int(_lib.lib().amdnuwa_f16_sat_count(1 if reset else 0))
+
+
+def bf_rows_cols(t):
+    """(rows, cols, device) of a 2-D BF operand in any of its forms"""
+    x = t.hi if t.hi is not None else t.f16
+    return x.shape[0], x.shape[1], x.device
 
 
 def _p(t):
@@ -283,13 +326,17 @@ def _f16ops_desc(A16, B16, M, N, Kd):
     return d
 
 
-def gemm_nt_f16ops_ok(M, N, Kd, *, out_bf16, gate=False):
-    """will amdnuwa_gemm_nt take this product with fp16 operands (the 256x256 ring at training sizes)?"""
+def gemm_nt_f16ops_ok(M, N, Kd, *, out_bf16, gate=False, out_f16=False, geglu_bwd=False):
+    """will amdnuwa_gemm_nt take this product with fp16 operands (the 256x256 ring at training sizes)?  out_f16: one fp16 output;
+    geglu_bwd: the product is dgg [M, N] and the epilogue writes du fp16 [M, 2 N] from u [M, 2 N]"""
     d = GemmDesc()
     one = ctypes_dummy()
     d.A, d.B, d.C = one, one, one
     d.lda, d.ldb, d.ldc = Kd, Kd, N
-    d.c_is_bf16 = 1 if out_bf16 else 0
+    d.c_is_bf16 = 1 if (out_bf16 or out_f16 or geglu_bwd) else 0
+    d.c_f16 = 1 if (out_f16 or geglu_bwd) else 0
+    if geglu_bwd:
+        d.C2, d.ldc2, d.geglu_u, d.ld_u = one, 2 * N, one, 2 * N
     if gate:
         d.C2, d.ldc2 = one, N // 2
     d.M, d.N, d.K, d.batch, d.ab_f16 = M, N, Kd, 1, 1
@@ -395,17 +442,22 @@ def gemm_nt_f16x2(A16, B16, *, out_bf16=False, bias=None, copy_f16=False):
     return BF(out, None, c16) if out_bf16 else out
 
 
-def gemm_nt_f16ops(A16, B16, *, out_bf16=False, gate=False, copy_f16=False):
+def gemm_nt_f16ops(A16, B16, *, out_bf16=False, gate=False, copy_f16=False, gate_bf16=True, out_f16=False):
     """fp16-operand product on the fp16 MFMA.  A16 [M, K], B16 [N, K] fp16 tensors.
-    out_bf16=False -> fp32 [M, N].  out_bf16=True -> u bf16 [M, N]; with gate=True also (gg16 fp16 [M, N/2], gg bf16 [M, N/2]) =
-    a * gelu(gate) computed on the fp32 accumulators (u in the interleaved-by-8 layout); with copy_f16=True -> BF(bf16 copy, None, fp16 copy)."""
+    out_bf16=False -> fp32 [M, N].  out_bf16=True -> u bf16 [M, N]; with gate=True also (gg16 fp16 [M, N/2], gg bf16 [M, N/2] or None when
+    gate_bf16 is off) = a * gelu(gate) computed on the fp32 accumulators (u in the interleaved-by-8 layout); with copy_f16=True ->
+    BF(bf16 copy, None, fp16 copy).  out_f16=True -> ONE fp16 [M, N] output, saturating (dgrad products of the fp16-gradient backward)."""
     L = _lib.lib()
     M, Kd = A16.shape
     N = B16.shape[0]
     dev = A16.device
     d = _f16ops_desc(A16, B16, M, N, Kd)
     gg16 = ggb = c16 = None
-    if out_bf16:
+    if out_f16:
+        assert not (out_bf16 or gate or copy_f16)
+        out = torch.empty((M, N), dtype=torch.float16, device=dev)
+        d.C, d.ldc, d.c_is_bf16, d.c_f16 = _p(out), N, 1, 1
+    elif out_bf16:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         d.C, d.ldc, d.c_is_bf16 = _p(out), N, 1
         if copy_f16:
@@ -414,7 +466,7 @@ def gemm_nt_f16ops(A16, B16, *, out_bf16=False, gate=False, copy_f16=False):
             d.Clo = _p(c16)
         if gate:
             gg16 = torch.empty((M, N // 2), dtype=torch.float16, device=dev)
-            ggb = torch.empty((M, N // 2), dtype=torch.bfloat16, device=dev)
+            ggb = torch.empty((M, N // 2), dtype=torch.bfloat16, device=dev) if gate_bf16 else None
             d.C2, d.C2lo, d.ldc2 = _p(gg16), _p(ggb), N // 2
     else:
         out = torch.empty((M, N), dtype=torch.float32, device=dev)
@@ -423,7 +475,7 @@ def gemm_nt_f16ops(A16, B16, *, out_bf16=False, gate=False, copy_f16=False):
     if _TIMER['on']:
         _TIMER['flops'] += 2.0 * M * N * Kd
         _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * M * N * Kd
-        _TIMER['bytes'] += 2.0 * (M + N) * Kd + float(M) * N * (2 if out_bf16 else 4) + (2.0 * M * N if gate else 0.)
+        _TIMER['bytes'] += 2.0 * (M + N) * Kd + float(M) * N * (2 if (out_bf16 or out_f16) else 4) + ((2.0 if gate_bf16 else 1.0) * M * N if gate else 0.)
         L.amdnuwa_timer_begin(st)
     check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(fp16 operands)')
     if _TIMER['on']:
@@ -465,6 +517,62 @@ def gemm_nt_geglu_bwd(dy, w2T, u, FP):
     return du
 
 
+def gemm_nt_geglu_bwd16(dy16, w2T16, u, FP):
+    """fp16-gradient form of gemm_nt_geglu_bwd: dy16 fp16 [M, D] (= S * dy), w2T16 fp16 [FP, D], u bf16 [M, 2 FP] (interleaved) ->
+    du fp16 [M, 2 FP] (= S * du), the gate's backward in the GEMM epilogue"""
+    L = _lib.lib()
+    M, Kd = dy16.shape
+    du = torch.empty((M, 2 * FP), dtype=torch.float16, device=dy16.device)
+    d = _f16ops_desc(dy16, w2T16, M, FP, Kd)
+    d.c_is_bf16, d.c_f16, d.ldc = 1, 1, FP
+    d.C2, d.ldc2 = _p(du), 2 * FP
+    d.geglu_u, d.ld_u = _p(u), _ld(u)
+    d.C = _p(du)                                      # placeholder: the fused epilogue does not write C
+    st = _stream()
+    if _TIMER['on']:
+        _TIMER['flops'] += 2.0 * M * FP * Kd
+        _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * M * FP * Kd
+        _TIMER['bytes'] += 2.0 * (M + FP) * Kd + float(M) * FP * 8
+        L.amdnuwa_timer_begin(st)
+    check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(geglu backward, fp16)')
+    if _TIMER['on']:
+        L.amdnuwa_timer_end(st)
+    return du
+
+
+def _tn16_desc(A16, B16, out, N1, N2):
+    d = GemmDesc()
+    d.A, d.lda, d.B, d.ldb = _p(A16), _ld(A16), _p(B16), _ld(B16)
+    d.C, d.ldc, d.c_is_bf16 = _p(out) if out is not None else ctypes_dummy(), (_ld(out) if out is not None else N2), 0
+    d.M, d.N, d.K, d.batch, d.ab_f16 = N1, N2, A16.shape[0], 1, 1
+    return d
+
+
+def gemm_tn16_ok(R, N1, N2, lda=None, ldb=None):
+    """does amdnuwa_gemm_tn take [R, N1]^T [R, N2] with fp16 operands (the four-wave kernel's shapes)?"""
+    d = GemmDesc()
+    one = ctypes_dummy()
+    d.A, d.B, d.C = one, one, one
+    d.lda, d.ldb, d.ldc = (N1 if lda is None else lda), (N2 if ldb is None else ldb), N2
+    d.M, d.N, d.K, d.batch, d.ab_f16 = N1, N2, R, 1, 1
+    return bool(_lib.lib().amdnuwa_gemm_tn_f16_supported(C.byref(d)))
+
+
+def gemm_tn16(A16, B16, out, s2, *, alpha=1.0, beta=0.0, N1=None, N2=None):
+    """out[N1, N2] (fp32) = beta * out + alpha / S * A16[R, N1]^T @ B16[R, N2]: a weight gradient from an fp16 gradient (A16 = S * dY) and
+    an fp16 activation copy; s2 = device {S, 1 / S} (None: no scale)"""
+    L = _lib.lib()
+    N1 = A16.shape[1] if N1 is None else N1
+    N2 = B16.shape[1] if N2 is None else N2
+    d = _tn16_desc(A16, B16, out, N1, N2)
+    d.alpha, d.beta = float(alpha), float(beta)
+    d.alpha_dev = None if s2 is None else s2.data_ptr() + 4
+    nb = L.amdnuwa_gemm_tn_workspace_bytes(C.byref(d))
+    ws = workspace(nb, A16.device)
+    check(L.amdnuwa_gemm_tn(C.byref(d), _p(ws), nb, _stream()), 'amdnuwa_gemm_tn(fp16)')
+    return out
+
+
 def gemm_tn(A, B, out, *, alpha=1.0, beta=0.0, shift=None, N1=None, N2=None):
     """out[N1,N2] (fp32 view) = beta*out + alpha * A[R,N1]^T @ B[R,N2]; shift applies to B's loader."""
     L = _lib.lib()
@@ -498,6 +606,7 @@ def gemm_tn_batched(desc, device):
 # ------------------------------------------------------------------------------------------------
 
 LN_X_BF16, LN_DY_BF16, LN_LO_F16 = 16, 32, 64       # == AMDNUWA_LN_X_BF16 / AMDNUWA_LN_DY_BF16 / AMDNUWA_LN_LO_F16
+LN_OUT_F16, LN_DY_F16 = 128, 256                    # == AMDNUWA_LN_OUT_F16 / AMDNUWA_LN_DY_F16
 
 
 def _f32_or_bf(t):
@@ -522,12 +631,16 @@ def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5, shift=None, f16=False
     mean = torch.empty(R, dtype=torch.float32, device=dev)
     rstd = torch.empty(R, dtype=torch.float32, device=dev)
     if resid is None:
-        out = empty_bf_f16((R, D), dev) if f16 else empty_bf((R, D), dev)
-        second = out.f16 if f16 else out.lo
         ia = torch.empty(R, dtype=torch.float32, device=dev) if stable else None
         sn, sf = (int(shift[0]), int(shift[1])) if shift is not None else (0, 0)      # out = shift(LN(x)) (ShiftVideoTokens)
-        check(L.amdnuwa_ln_fwd(xp, None, _p(w), _p(b), _p(out.hi), _p(second), None, _p(mean), _p(rstd), _p(ia),
-                               R, D, 0 | flag | (LN_LO_F16 if f16 else 0), 1 if stable else 0, eps, sn, sf, _stream()), 'amdnuwa_ln_fwd')
+        if f16 == 'only':                        # ONE fp16 copy (the block's backward runs on fp16 operands too)
+            out = BF(None, None, torch.empty((R, D), dtype=torch.float16, device=dev))
+            first, second, fl = out.f16, None, LN_OUT_F16
+        else:
+            out = empty_bf_f16((R, D), dev) if f16 else empty_bf((R, D), dev)
+            first, second, fl = out.hi, (out.f16 if f16 else out.lo), (LN_LO_F16 if f16 else 0)
+        check(L.amdnuwa_ln_fwd(xp, None, _p(w), _p(b), _p(first), _p(second), None, _p(mean), _p(rstd), _p(ia),
+                               R, D, 0 | flag | fl, 1 if stable else 0, eps, sn, sf, _stream()), 'amdnuwa_ln_fwd')
         return out, mean, rstd, ia
     out = torch.empty_like(resid)
     check(L.amdnuwa_ln_fwd(xp, _p(resid), _p(w), _p(b), None, None, _p(out), _p(mean), _p(rstd), None,
@@ -542,32 +655,45 @@ def ln_post_pre_fwd(y, resid, w, b, next_w, next_b, *, eps=1e-5, next_shift=None
     yp, ybf, (R, D), dev = _f32_or_bf(y)
     mean, rstd, mean2, rstd2 = (torch.empty(R, dtype=torch.float32, device=dev) for _ in range(4))
     out = torch.empty_like(resid)
-    h = empty_bf_f16((R, D), dev) if next_f16 else empty_bf((R, D), dev)
     sn, sf = (int(next_shift[0]), int(next_shift[1])) if next_shift is not None else (0, 0)
+    if next_f16 == 'only':
+        h = BF(None, None, torch.empty((R, D), dtype=torch.float16, device=dev))
+        first, second, fl = h.f16, None, LN_OUT_F16
+    else:
+        h = empty_bf_f16((R, D), dev) if next_f16 else empty_bf((R, D), dev)
+        first, second, fl = h.hi, (h.f16 if next_f16 else h.lo), (LN_LO_F16 if next_f16 else 0)
     check(L.amdnuwa_ln_post_pre_fwd(yp, _p(resid), _p(w), _p(b), _p(out), _p(mean), _p(rstd), _p(next_w), _p(next_b),
-                                    _p(h.hi), _p(h.f16 if next_f16 else h.lo), _p(mean2), _p(rstd2), R, D,
-                                    (LN_X_BF16 if ybf else 0) | (LN_LO_F16 if next_f16 else 0), eps, sn, sf,
+                                    _p(first), _p(second), _p(mean2), _p(rstd2), R, D,
+                                    (LN_X_BF16 if ybf else 0) | fl, eps, sn, sf,
                                     _stream()), 'amdnuwa_ln_post_pre_fwd')
     return out, mean, rstd, h, mean2, rstd2
 
 
-def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift=None, want_dsum=False):
-    """returns (dx, dw, db, dsum).  to_bf: dx as BF pair; else dx fp32 = dres + dx_ln (dres may be None -> zeros).
-    dy / x: fp32 tensors, or (one of them) a hi-only BF pair."""
+def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift=None, want_dsum=False, to_f16=None):
+    """returns (dx, dw, db, dsum).  to_bf: dx as BF pair; to_f16 = s2 (device {S, 1 / S}): dx as G16 = fp16(S * dx); else dx fp32 =
+    dres + dx_ln (dres may be None -> zeros).  dy / x: fp32 tensors, or (one of them) a hi-only BF pair; dy may be a G16."""
     L = _lib.lib()
-    dyp, dybf, _, _ = _f32_or_bf(dy)
+    s2 = to_f16
+    if isinstance(dy, G16):
+        dyp, dybf, s2 = _p(dy.t), False, dy.s2
+    else:
+        dyp, dybf, _, _ = _f32_or_bf(dy)
     xp, xbf, (R, D), dev = _f32_or_bf(x)
-    st = (1 if inv_amax is not None else 0) | (LN_X_BF16 if xbf else 0) | (LN_DY_BF16 if dybf else 0)
+    st = (1 if inv_amax is not None else 0) | (LN_X_BF16 if xbf else 0) | (LN_DY_BF16 if dybf else 0) | (LN_DY_F16 if isinstance(dy, G16) else 0)
     dw = torch.empty(D, dtype=torch.float32, device=dev)
     db = torch.empty(D, dtype=torch.float32, device=dev)
     ds = torch.empty(D, dtype=torch.float32, device=dev) if want_dsum else None
     nb = L.amdnuwa_ln_bwd_workspace_bytes(R, D)
     ws = workspace(nb, dev)
     sn, sf = (int(shift[0]), int(shift[1])) if shift is not None else (0, 0)
-    if to_bf:
+    if to_f16 is not None:
+        dx = G16(torch.empty((R, D), dtype=torch.float16, device=dev), to_f16)
+        check(L.amdnuwa_ln_bwd_f16(dyp, xp, _p(mean), _p(rstd), _p(inv_amax), _p(w), _p(dx.t), None, None, None,
+                                   _p(dw), _p(db), _p(ds), R, D, sn, sf, st | LN_OUT_F16, 0, _p(s2), _p(ws), nb, _stream()), 'amdnuwa_ln_bwd_f16')
+    elif to_bf:
         dx = empty_bf((R, D), dev)
-        check(L.amdnuwa_ln_bwd(dyp, xp, _p(mean), _p(rstd), _p(inv_amax), _p(w), _p(dx.hi), _p(dx.lo), None, None,
-                               _p(dw), _p(db), _p(ds), R, D, sn, sf, st, 0, _p(ws), nb, _stream()), 'amdnuwa_ln_bwd')
+        check(L.amdnuwa_ln_bwd_f16(dyp, xp, _p(mean), _p(rstd), _p(inv_amax), _p(w), _p(dx.hi), _p(dx.lo), None, None,
+                                   _p(dw), _p(db), _p(ds), R, D, sn, sf, st, 0, _p(s2), _p(ws), nb, _stream()), 'amdnuwa_ln_bwd')
     else:
         if dres is None:
             dx = torch.zeros((R, D), dtype=torch.float32, device=dev)
@@ -575,29 +701,41 @@ def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift
         else:
             dx = torch.empty((R, D), dtype=torch.float32, device=dev)
             dr = dres
-        check(L.amdnuwa_ln_bwd(dyp, xp, _p(mean), _p(rstd), _p(inv_amax), _p(w), None, None, _p(dx), _p(dr),
-                               _p(dw), _p(db), _p(ds), R, D, sn, sf, st, 0, _p(ws), nb, _stream()), 'amdnuwa_ln_bwd')
+        check(L.amdnuwa_ln_bwd_f16(dyp, xp, _p(mean), _p(rstd), _p(inv_amax), _p(w), None, None, _p(dx), _p(dr),
+                                   _p(dw), _p(db), _p(ds), R, D, sn, sf, st, 0, _p(s2), _p(ws), nb, _stream()), 'amdnuwa_ln_bwd')
     return dx, dw, db, ds
 
 
-def ln_bwd_chain(dh, x, mean, rstd, w, g, y_prev, mean_prev, rstd_prev, w_prev, *, shift=None, want_dsum=False):
+def ln_bwd_chain(dh, x, mean, rstd, w, g, y_prev, mean_prev, rstd_prev, w_prev, *, shift=None, want_dsum=False, out_f16=None):
     """pre-norm backward of a block and the post-norm backward of the block before it in one pass over the gradient row.
-    dh, y_prev: both fp32 tensors, both hi-only BF pairs, or dh a BF pair with an fp32 y_prev ('bf16x3-fwd').  returns (dx fp32, dw, db, dy_prev BF, dw_prev, db_prev, dsum_prev)"""
+    dh, y_prev: both fp32 tensors, both hi-only BF pairs, or dh a BF pair / a G16 with an fp32 y_prev ('bf16x3-fwd').  out_f16 = s2: dy_prev
+    leaves as a G16.  returns (dx fp32, dw, db, dy_prev BF | G16, dw_prev, db_prev, dsum_prev)"""
     L = _lib.lib()
-    dhp, dhbf, _, _ = _f32_or_bf(dh)
+    s2 = out_f16
     yp, ybf, (R, D), dev = _f32_or_bf(y_prev)
-    assert dhbf or not ybf, 'ln_bwd_chain: fp32 dh with a bf16 y_prev is not a form any mode produces'
-    form = 1 if (dhbf and ybf) else (2 if dhbf else 0)            # == the inputs_bf16 argument of amdnuwa_ln_bwd_chain
+    if isinstance(dh, G16):
+        assert not ybf
+        dhp, form, s2 = _p(dh.t), 3, dh.s2
+        assert out_f16 is None or out_f16.data_ptr() == dh.s2.data_ptr(), 'one gradient scale per backward pass'
+    else:
+        dhp, dhbf, _, _ = _f32_or_bf(dh)
+        assert dhbf or not ybf, 'ln_bwd_chain: fp32 dh with a bf16 y_prev is not a form any mode produces'
+        form = 1 if (dhbf and ybf) else (2 if dhbf else 0)            # == the inputs_bf16 argument of amdnuwa_ln_bwd_chain
     dx = torch.empty((R, D), dtype=torch.float32, device=dev)
     dw, db, dwp, dbp = (torch.empty(D, dtype=torch.float32, device=dev) for _ in range(4))
     dsp = torch.empty(D, dtype=torch.float32, device=dev) if want_dsum else None
-    dyp = empty_bf((R, D), dev)
+    if out_f16 is not None:
+        dyp = G16(torch.empty((R, D), dtype=torch.float16, device=dev), out_f16)
+        o_hi, o_lo = dyp.t, None
+    else:
+        dyp = empty_bf((R, D), dev)
+        o_hi, o_lo = dyp.hi, dyp.lo
     nb = L.amdnuwa_ln_bwd_chain_workspace_bytes(R, D)
     ws = workspace(nb, dev)
     sn, sf = (int(shift[0]), int(shift[1])) if shift is not None else (0, 0)
-    check(L.amdnuwa_ln_bwd_chain(dhp, _p(x), _p(mean), _p(rstd), _p(w), _p(g), _p(dx), _p(dw), _p(db), yp, _p(mean_prev),
-                                 _p(rstd_prev), _p(w_prev), _p(dyp.hi), _p(dyp.lo), _p(dwp), _p(dbp), _p(dsp), R, D, sn, sf,
-                                 form, _p(ws), nb, _stream()), 'amdnuwa_ln_bwd_chain')
+    check(L.amdnuwa_ln_bwd_chain_f16(dhp, _p(x), _p(mean), _p(rstd), _p(w), _p(g), _p(dx), _p(dw), _p(db), yp, _p(mean_prev),
+                                     _p(rstd_prev), _p(w_prev), _p(o_hi), _p(o_lo), _p(dwp), _p(dbp), _p(dsp), R, D, sn, sf,
+                                     form, 1 if out_f16 is not None else 0, _p(s2), _p(ws), nb, _stream()), 'amdnuwa_ln_bwd_chain')
     return dx, dw, db, dyp, dwp, dbp, dsp
 
 

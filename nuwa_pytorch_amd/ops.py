@@ -48,7 +48,7 @@ class WeightCache:
         self._store = {}
 
     def get(self, key, params, builder):
-        ver = tuple((p.data_ptr(), p._version) for p in params) + (K.get_precision(), WeightCache.EPOCH)
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (K.get_precision(), WeightCache.EPOCH, K._BWD_F16)
         ent = self._store.get(key)
         if ent is None or ent[0] != ver:
             with torch.no_grad():
@@ -357,6 +357,9 @@ class FFInner:
                 w2pad = torch.zeros((D, FP), dtype=torch.float32, device=dev)
                 w2pad[:, :FFI] = w2.detach()
                 out['w2_16'] = w2pad.to(torch.float16)
+                if K.bwd_f16('f'):                      # ... and their transposes for the dgrad products of the fp16-gradient backward
+                    out['w1T_16'] = out['w1_16'].t().contiguous()
+                    out['w2T_16'] = out['w2_16'].t().contiguous()
             return out
         return cache.get('ff', (w1, w2), build)
 
@@ -368,13 +371,26 @@ class FFInner:
             (ws is None or f16_weights_ok(*ws))
 
     @staticmethod
+    def bwd16_ok(R, D, FP, FFI, ws=None):
+        """the fp16-gradient backward applies: switched on, the fp16 forward applies, and the four backward products fit their fp16 kernels"""
+        return K.bwd_f16('f') and FFInner.f16_ok(R, D, FP, ws) and \
+            K.gemm_nt_f16ops_ok(R, FP, D, out_bf16=True, geglu_bwd=True) and K.gemm_nt_f16ops_ok(R, D, 2 * FP, out_bf16=False, out_f16=True) and \
+            K.gemm_tn16_ok(R, D, FFI, lda=D, ldb=FP) and K.gemm_tn16_ok(R, 2 * FP, D)
+
+    @staticmethod
     def fwd(h, p, meta):
         W = FFInner.weights(meta['cache'], p)
-        R, D = h.hi.shape
+        R, D, _ = K.bf_rows_cols(h)
         if meta.get('shift') is None and 'w1_16' in W and FFInner.f16_ok(R, D, W['FP']):
             # 'bf16x3-fwd': both FeedForward products on single fp16 MFMAs (h arrives with an fp16 copy from the LayerNorm store);
             # u and the gate output also leave as bf16 copies for the bf16 backward
             h16 = h.f16 if h.f16 is not None else K.hilo_to_f16(h)
+            if meta.get('bwd16') and 'w1T_16' in W:
+                # fp16-gradient backward: ONE copy of h and of the gate output (fp16); u stays bf16 (read element-wise by the gate's backward)
+                u, gg16, _ = K.gemm_nt_f16ops(h16, W['w1_16'], out_bf16=True, gate=True, gate_bf16=False)
+                y = K.gemm_nt_f16ops(gg16, W['w2_16'])
+                return y, (K.BF(None, None, h16), K.BF(u, None), K.BF(None, None, gg16))
+            assert h.hi is not None, 'a bf16 backward needs the bf16 copy of the LayerNorm output'
             u, gg16, ggb = K.gemm_nt_f16ops(h16, W['w1_16'], out_bf16=True, gate=True)
             y = K.gemm_nt_f16ops(gg16, W['w2_16'])
             return y, (K.BF(h.hi, None), K.BF(u, None), K.BF(ggb, None))
@@ -390,6 +406,17 @@ class FFInner:
         W = FFInner.weights(meta['cache'], p)
         w1, w2 = p
         FP, FFI = W['FP'], W['FFI']
+        if isinstance(dy, K.G16):
+            # fp16-gradient backward: dy = fp16(S dy); every product on the fp16 MFMA against the fp16 copies the forward left
+            s2 = dy.s2
+            du = K.gemm_nt_geglu_bwd16(dy.t, W['w2T_16'], u.hi, FP)
+            dw2 = torch.empty_like(w2)
+            K.gemm_tn16(dy.t, gg.f16, dw2, s2, N2=FFI)
+            dh = K.G16(K.gemm_nt_f16ops(du, W['w1T_16'], out_f16=True), s2)
+            dw1p = torch.empty((2 * FP, w1.shape[1]), dtype=torch.float32, device=w1.device)
+            K.gemm_tn16(du, h.f16, dw1p, s2)
+            d = K.geglu_deinterleave(dw1p, FP, dim=0)
+            return dh, None, [torch.cat((d[:FFI], d[FP:FP + FFI]), 0), dw2]
         if FUSE_GEGLU_BWD:
             du = K.gemm_nt_geglu_bwd(dy, W['w2T'], u, FP)      # dgg = dy W2 and the gate's backward in one pass
         else:
@@ -541,6 +568,25 @@ def _as_f32(t):
     return t.hi.float() if isinstance(t, K.BF) else t
 
 
+def _grad_scale(g2):
+    """device tensor {S, 1 / S} for the fp16 gradients of one backward pass: S = the power of two with S * max|g| in [8, 16), g = the
+    residual-stream gradient entering the first block of the pass (kernels.G16).  No host synchronisation."""
+    a = g2.detach().abs().amax().float()
+    ok = torch.isfinite(a) & (a > 0)
+    e = torch.floor(torch.log2(torch.where(ok, a, torch.ones_like(a))))
+    S = torch.where(ok, torch.exp2((3.0 - e).clamp(-60.0, 60.0)), torch.ones_like(a))
+    return torch.stack((S, 1.0 / S)).contiguous()
+
+
+def _block_bwd16(kind, R, D, p, meta):
+    """does this block run the fp16-gradient backward (and so keep only the fp16 copy of its LayerNorm input)?"""
+    if not K.bwd_f16() or meta.get('shift_unfused'):
+        return False
+    if kind == 'ff':
+        return FFInner.bwd16_ok(R, D, _ru(p[1].shape[1], 32), p[1].shape[1], (p[0], p[1]))
+    return False
+
+
 def _ctx_to_bf(context):
     """context fp32 [B, T, D] -> BF [B*T, D]"""
     B, T, D = context.shape
@@ -578,15 +624,17 @@ class SandwichBlockFn(Function):
         want16 = (meta['kind'] == 'ff' and FFInner.f16_ok(B * n, D, _ru(p[1].shape[1], 32), (p[0], p[1]))) or \
                  (meta['kind'] == 's3' and S3Inner.f16_proj_ok(B * n, D, p[0].shape[0], meta['geom'], (p[0], p[1]))) or \
                  (meta['kind'] == 'xattn' and XInner.f16x2_ok(B * n, D, p[3].shape[0], meta['xgeom'], meta, (p[3], p[5])))
+        bw16 = bool(want16) and _block_bwd16(meta['kind'], B * n, D, p, meta)
         if hin is not None and hin.get('ptr') == x.data_ptr() and hin.get('ver') == x._version and hin.get('shift') == sh \
-                and resid is None and tuple(hin['h'].hi.shape) == (B * n, D):
+                and resid is None and K.bf_rows_cols(hin['h'])[:2] == (B * n, D) and (hin['h'].hi is not None or bw16):
             h, m1, r1 = hin['h'], hin['m1'], hin['r1']
             ctx.prev_ctx = hin.get('ctx')          # the backward chains the two LayerNorm backwards of this boundary too
         else:
-            h, m1, r1, _ = K.ln_fwd(x2, pre_w.detach(), pre_b.detach(), shift=sh, f16=want16)
+            h, m1, r1, _ = K.ln_fwd(x2, pre_w.detach(), pre_b.detach(), shift=sh, f16='only' if bw16 else want16)
         ctx.shift = sh
         if sh is not None:
             meta['shift'] = None
+        meta['bwd16'] = ctx.bw16 = bw16 and h.f16 is not None
         y, saved = inner.fwd(h, p, meta)
         if nxt is not None and hout is not None:
             # the next block's first GEMM runs fp16 operands: FeedForward (nxt[3] = ('ff', inner width)) or the 3DNA projection (('s3', inner, geom))
@@ -594,6 +642,8 @@ class SandwichBlockFn(Function):
             nxt16 = nk is not None and ((nk[0] == 'ff' and FFInner.f16_ok(B * n, D, _ru(nk[1], 32), nk[2])) or
                                         (nk[0] == 's3' and S3Inner.f16_proj_ok(B * n, D, nk[1], nk[2], nk[3])) or
                                         (nk[0] == 'x' and XInner.f16x2_ok(B * n, D, nk[1], nk[2], nk[3], nk[4])))
+            if nxt16 and nk[0] == 'ff' and FFInner.bwd16_ok(B * n, D, _ru(nk[1], 32), nk[1], nk[2]):
+                nxt16 = 'only'                    # the next block keeps ONE (fp16) copy of its LayerNorm input: fp16-gradient backward
             xo, m2, r2, hn, mn, rn = K.ln_post_pre_fwd(y, r2_, post_w.detach(), post_b.detach(), nxt[0].detach(),
                                                        nxt[1].detach(), next_shift=nxt[2], next_f16=nxt16)
             hout.update(h=hn, m1=mn, r1=rn, ptr=xo.data_ptr(), ver=xo._version, shift=nxt[2], ctx=ctx if CHAIN_BWD else None)
@@ -619,22 +669,29 @@ class SandwichBlockFn(Function):
         g2 = g.contiguous().reshape(B * n, D)
         want_bias = meta['kind'] == 's3'
         ho, ctx.bwd_handoff = getattr(ctx, 'bwd_handoff', None), None
-        if ho is not None and ho['ptr'] == g2.data_ptr() and ho['ver'] == g2._version:   # the next block's backward already ran this post-norm backward
+        bw16 = getattr(ctx, 'bw16', False)
+        s2 = ho.get('s2') if ho is not None else None          # the gradient scale of this backward pass (fp16-gradient blocks)
+        if s2 is None and K.bwd_f16():
+            s2 = _grad_scale(g2)
+        if ho is not None and ho['ptr'] == g2.data_ptr() and ho['ver'] == g2._version and isinstance(ho['dy'], K.G16) == bw16:   # the next block's backward already ran this post-norm backward
             dy, dpost_w, dpost_b, dsum = ho['dy'], ho['dw'], ho['db'], ho['dsum']
         else:
-            dy, dpost_w, dpost_b, dsum = K.ln_bwd(g2, y, m2, r2, post_w.detach(), to_bf=True, want_dsum=want_bias)
+            dy, dpost_w, dpost_b, dsum = K.ln_bwd(g2, y, m2, r2, post_w.detach(), to_bf=not bw16, want_dsum=want_bias,
+                                                  to_f16=s2 if bw16 else None)
         meta = dict(meta)
         dh, dctx, grads = inner.bwd(ctx.inner_saved, dy, p, meta, need_dbias=False)
         if want_bias:
             grads[4] = dsum                      # to_out.bias grad = column sums of d(to_out output)
         prev = ctx.prev_ctx
-        if prev is not None and not ctx.has_resid and (isinstance(dh, K.BF) or not prev.y_bf) and (not isinstance(dh, K.BF) or dh.lo is None):
+        p16 = prev is not None and getattr(prev, 'bw16', False) and s2 is not None
+        if prev is not None and not ctx.has_resid and (isinstance(dh, (K.BF, K.G16)) or not prev.y_bf) and (not isinstance(dh, K.BF) or dh.lo is None) \
+                and not (isinstance(dh, K.G16) and prev.y_bf):
             # pre-norm backward of this block + post-norm backward of the previous block on the same gradient row
             _, py, _, _, pm2, pr2, _, ppost_w = prev.saved_tensors
             dx, dpre_w, dpre_b, dyp, dwp, dbp, dsp = K.ln_bwd_chain(
                 dh, x2, m1, r1, pre_w.detach(), g2, K.BF(py, None) if prev.y_bf else py, pm2, pr2, ppost_w.detach(),
-                shift=ctx.shift, want_dsum=prev.meta['kind'] == 's3')
-            prev.bwd_handoff = dict(ptr=dx.data_ptr(), ver=dx._version, dy=dyp, dw=dwp, db=dbp, dsum=dsp)
+                shift=ctx.shift, want_dsum=prev.meta['kind'] == 's3', out_f16=s2 if p16 else None)
+            prev.bwd_handoff = dict(ptr=dx.data_ptr(), ver=dx._version, dy=dyp, dw=dwp, db=dbp, dsum=dsp, s2=s2)
         else:
             dx, dpre_w, dpre_b, _ = K.ln_bwd(dh, x2, m1, r1, pre_w.detach(), dres=None if ctx.has_resid else g2,
                                              shift=ctx.shift)

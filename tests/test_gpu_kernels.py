@@ -1245,3 +1245,98 @@ def test_fused_linear_cross_entropy_hi_lo(R, C, Kd):
         assert K.linear_ce(hb, wb, t.to(DEV), 1.0 / R) is None
     finally:
         K.set_precision(prev)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp16 gradients of the 'bf16x3-fwd' backward (round 5): gradients travel as fp16(S * value), S a device-side power of two
+# ---------------------------------------------------------------------------------------------------
+
+def _s2(S):
+    return torch.tensor([S, 1.0 / S], dtype=torch.float32, device=DEV)
+
+
+@pytest.mark.parametrize('S', [1.0, 2.0 ** 18, 2.0 ** -6])
+def test_layernorm_backward_with_fp16_gradients(K, S):
+    """post-norm backward writing dy as fp16(S dy), pre-norm backward / the chained form reading dh = fp16(S dh): against the fp32
+    kernels on the same inputs; the weight-gradient partials must not see the scale"""
+    torch.manual_seed(3)
+    R, D = 2560 + 7, 512
+    gmag = 4.0 / S                                   # a gradient magnitude that S brings to O(1)
+    x = torch.randn(R, D, device=DEV) * 2 + 0.5
+    w = torch.randn(D, device=DEV)
+    b = torch.randn(D, device=DEV)
+    g = torch.randn(R, D, device=DEV) * gmag
+    _, m, r, _ = K.ln_fwd(x, w, b)
+    s2 = _s2(S)
+    dx32, dw32, db32, _ = K.ln_bwd(g, x, m, r, w)                      # fp32 reference: dx = LN backward of g (dres None -> zeros)
+    dy16, dw16, db16, ds16 = K.ln_bwd(g, x, m, r, w, to_f16=s2, want_dsum=True)
+    assert isinstance(dy16, K.G16) and dy16.t.dtype == torch.float16
+    report(f'ln_bwd.f16_out[S={S}]', dy16.t.float() / S, dx32, 2 ** -10)
+    assert torch.equal(dw16, dw32) and torch.equal(db16, db32)
+    report(f'ln_bwd.f16_out.dsum[S={S}]', ds16, dx32.sum(0), 1e-4)
+    # pre-norm backward from an fp16 dh, accumulating into the fp32 stream gradient
+    dh = torch.randn(R, D, device=DEV) * gmag
+    dh16 = K.G16((dh * S).half(), s2)
+    dhv = dh16.t.float() / S                                               # what the kernel sees
+    ref, rw, rb, _ = K.ln_bwd(dhv, x, m, r, w, dres=g)
+    got, gw, gb, _ = K.ln_bwd(dh16, x, m, r, w, dres=g)
+    report(f'ln_bwd.f16_in[S={S}]', got, ref, 2e-6)
+    report(f'ln_bwd.f16_in.dw[S={S}]', gw, rw, 2e-6)
+    # chained: pre-norm backward of block k+1 (fp16 dh) + post-norm backward of block k (fp16 dy out)
+    y = torch.randn(R, D, device=DEV)
+    w2 = torch.randn(D, device=DEV)
+    _, m2, r2, _ = K.ln_fwd(y, w2, b)
+    dxr, dwr, dbr, dypr, dwpr, dbpr, dspr = K.ln_bwd_chain(dhv, x, m, r, w, g, y, m2, r2, w2, want_dsum=True)
+    dxc, dwc, dbc, dypc, dwpc, dbpc, dspc = K.ln_bwd_chain(dh16, x, m, r, w, g, y, m2, r2, w2, want_dsum=True, out_f16=s2)
+    report(f'ln_bwd_chain.f16.dx[S={S}]', dxc, dxr, 2e-6)
+    report(f'ln_bwd_chain.f16.dy_prev[S={S}]', dypc.t.float() / S, bf_value(dypr) if dypr.lo is not None else dypr.hi.float(), 2 ** -7)
+    report(f'ln_bwd_chain.f16.dw_prev[S={S}]', dwpc, dwpr, 2e-6)
+    report(f'ln_bwd_chain.f16.dsum_prev[S={S}]', dspc, dspr, 2e-6)
+    assert K.f16_sat_count() == 0
+
+
+def test_fp16_gradient_gemms(K):
+    """the four products of the FeedForward backward on fp16 operands: dgg (+ the gate's backward in the epilogue, fp16 du), dh (fp16 out),
+    and the two weight gradients (TN, alpha / S from the device scalar) -- against fp64 on the same fp16 operand values"""
+    torch.manual_seed(5)
+    R, D, FP, FFI, S = 2560 * 4, 512, 1376, 1365, 2.0 ** 10
+    s2 = _s2(S)
+    dy = (torch.randn(R, D, device=DEV) * 0.01 * S).half()                 # = S * dy
+    w2T = (torch.randn(FP, D, device=DEV) * 0.2).half()
+    u = (torch.randn(R, 2 * FP, device=DEV)).to(torch.bfloat16)             # interleaved layout
+    assert K.gemm_nt_f16ops_ok(R, FP, D, out_bf16=True, geglu_bwd=True) and K.gemm_nt_f16ops_ok(R, D, 2 * FP, out_bf16=False, out_f16=True)
+    du = K.gemm_nt_geglu_bwd16(dy, w2T, u, FP)
+    assert du.dtype == torch.float16 and du.shape == (R, 2 * FP)
+    dgg = dy.double() @ w2T.double().t()
+    ud = K.geglu_deinterleave(u.double().cpu(), FP, dim=1).requires_grad_(True)
+    (ud[:, :FP] * F.gelu(ud[:, FP:])).backward(dgg.cpu())
+    report('bwd16.du', K.geglu_deinterleave(du.float().cpu(), FP, dim=1), ud.grad.float(), 2 ** -9)
+    w1T = (torch.randn(D, 2 * FP, device=DEV) * 0.1).half()
+    dh = K.gemm_nt_f16ops(du, w1T, out_f16=True)
+    report('bwd16.dh', dh.float(), (du.double() @ w1T.double().t()).float(), 2 ** -10)
+    # weight gradients: the 1 / S comes from the device scalar
+    gg = (torch.randn(R, FP, device=DEV)).half()
+    assert K.gemm_tn16_ok(R, D, FFI, lda=D, ldb=FP) and K.gemm_tn16_ok(R, 2 * FP, D)
+    dw2 = torch.empty(D, FFI, device=DEV)
+    K.gemm_tn16(dy, gg, dw2, s2, N2=FFI)
+    report('bwd16.dw2', dw2, ((dy.double().t() @ gg.double())[:, :FFI] / S).float(), 1e-5)
+    h = torch.randn(R, D, device=DEV).half()
+    dw1 = torch.empty(2 * FP, D, device=DEV)
+    K.gemm_tn16(du, h, dw1, s2)
+    report('bwd16.dw1', dw1, (du.double().t() @ h.double() / S).float(), 1e-5)
+    assert not K.gemm_tn16_ok(321, 512, 512)                                 # odd token counts stay on the bf16 backward
+    # saturation is DEFINED and counted
+    K.f16_sat_count()
+    big = (torch.ones(256 * 5, D, device=DEV) * 300).half()
+    out = K.gemm_nt_f16ops(big, (torch.ones(D, D, device=DEV)).half(), out_f16=True)        # 300 * 512 > 65504
+    assert torch.isfinite(out).all() and float(out.max()) == 65504.0
+    assert K.f16_sat_count() > 0 and K.f16_sat_count() == 0
+
+
+def test_fp16_store_keeps_nan(K):
+    """advisor (round 4): the saturating fp16 stores must not turn a NaN activation into -65504"""
+    x = torch.randn(8, 512, device=DEV)
+    x[3, 7] = float('nan')
+    h, _, _, _ = K.ln_fwd(x, torch.ones(512, device=DEV), torch.zeros(512, device=DEV), f16=True)
+    assert torch.isnan(h.f16[3]).all() and torch.isnan(h.hi[3]).all()
+    assert torch.isfinite(h.f16[2]).all()

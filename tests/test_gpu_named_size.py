@@ -438,3 +438,68 @@ def test_fp16_range_guard_of_the_compliant_mode(A):
     finally:
         K.set_proj_f16x2(os.environ.get('AMDNUWA_F16X2', K.DEFAULT_F16X2))
         A.set_precision('bf16')
+
+
+def test_fp16_gradient_backward_of_the_compliant_mode(A, O):
+    """round 5: blocks whose class is switched on (kernels.set_bwd_f16) keep ONE fp16 copy of their activations and run their backward on
+    fp16 gradients fp16(S g), S taken on the device from the gradient that enters the pass.  One cfg-3 decoder layer at n = 2560:
+      * the forward is bit-identical with the switch on and off (same products, fewer copies);
+      * every gradient stays inside the mode's gradient bound against the oracle, and is no worse than the bf16 backward's;
+      * the result does not depend on the magnitude of the incoming gradient (1e-6 ... 1e3 x): the scale is dynamic;
+      * nothing saturates."""
+    import nuwa_pytorch_amd.nuwa_pytorch as M
+    from nuwa_pytorch_amd import kernels as KK
+    dim, video_shape, kernel, dil, T, b = 512, (10, 16, 16), (5, 3, 3), 2, 256, 1
+    torch.manual_seed(0)
+    tr = M.Transformer(dim=dim, depth=1, causal=True, heads=8, dim_head=64, cross_attend=True, sparse_3dna_attn=True,
+                       sparse_3dna_kernel_size=kernel, sparse_3dna_video_shape=video_shape, sparse_3dna_dilations=(dil,),
+                       shift_video_tokens=True)
+    with torch.no_grad():
+        for n_, p in tr.named_parameters():
+            if 'norm' in n_ or n_.endswith('.bias'):
+                p.add_(0.1 * torch.randn_like(p))
+    P = _cpu_params(tr)
+    n = video_shape[0] * video_shape[1] * video_shape[2]
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(b, n, dim, generator=g)
+    ctx = torch.randn(b, T, dim, generator=g)
+    mask = torch.ones(b, T, dtype=torch.bool)
+    dy = torch.randn(b, n, dim, generator=g)
+    cfg = dict(video_shape=video_shape, kernel_size=kernel, dilations=(dil,), heads=8, depth=1, shift=True)
+    Pr = _req(P)
+    xr, cr = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    yr = O.decoder_layer(xr, O.sub(Pr, 'layers.0'), cfg, 0, cr, mask)
+    yr.backward(dy)
+    tr = tr.to(DEV)
+    A.set_precision('bf16x3-fwd')
+    saved = KK._BWD_F16
+    res = {}
+    try:
+        def run(classes, c):
+            KK.set_bwd_f16(classes)
+            tr.zero_grad(set_to_none=True)
+            xd, cd = x.to(DEV).requires_grad_(True), ctx.to(DEV).requires_grad_(True)
+            y = tr.forward_layers(xd, context=cd, context_mask=mask.to(DEV))
+            y.backward(dy.to(DEV) * c)
+            worst = max(rel_err(xd.grad / c, xr.grad), rel_err(cd.grad / c, cr.grad))
+            for k, p in tr.named_parameters():
+                if Pr[k].grad is not None:
+                    worst = max(worst, rel_err(p.grad / c, Pr[k].grad))
+            ffw = rel_err(dict(tr.named_parameters())['layers.0.2.fn.fn.net.0.weight'].grad / c, Pr['layers.0.2.fn.fn.net.0.weight'].grad)
+            return y.detach().clone(), worst, ffw
+        KK.f16_sat_count()
+        y0, w0, f0 = run('', 1.0)
+        y1, w1, f1 = run('f', 1.0)
+        assert torch.equal(y0, y1), 'the fp16-gradient switch must not change the forward'
+        res.update(worst_bf16_bwd=w0, worst_f16_bwd=w1, ff1_weight_bf16_bwd=f0, ff1_weight_f16_bwd=f1)
+        assert w1 <= 1.4e-2 and f1 <= 1.4e-2, res
+        assert f1 <= f0 * 1.05, res                          # fp16 gradients carry 3 more bits than bf16 ones: the FF weight gradient must not get worse
+        for c in (1e-6, 1e3):
+            _, wc, fc = run('f', c)
+            res[f'worst_f16_bwd_x{c:g}'] = wc
+            assert wc <= 1.4e-2 and fc <= max(f1 * 1.5, 2e-3), res
+        assert KK.f16_sat_count() == 0, 'fp16 stores saturated'
+    finally:
+        KK._BWD_F16 = saved
+        A.set_precision('bf16')
+    _note('cfg3.fp16_gradient_backward', res)
