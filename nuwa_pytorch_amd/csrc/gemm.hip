@@ -516,28 +516,6 @@ __device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&
                 dp[2 * q + 1] = make_uint4(pack2_rne(dgt[0], dgt[1]), pack2_rne(dgt[2], dgt[3]), pack2_rne(dgt[4], dgt[5]), pack2_rne(dgt[6], dgt[7]));
             }
         };
-        float sat = 0.f;                                            // (fp16 saturation monitor: common.h)
-        // the same from fp32 dgg to an FP16 du (the fp16-gradient backward: operands fp16(S * gradient), u still bf16, read element-wise)
-        auto geglu_bwd_store16 = [&](const float (&dgg)[16], const uint4 (&uu)[4], uint4* dp) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const uint4 av = uu[2 * q], gv = uu[2 * q + 1];
-                const uint32_t wa[4] = {av.x, av.y, av.z, av.w}, wg[4] = {gv.x, gv.y, gv.z, gv.w};
-                float da[8], dgt[8];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float y, dy;
-                    gelu_both_f(lo_f(wg[k]), y, dy);
-                    da[2 * k] = dgg[8 * q + 2 * k] * y;
-                    dgt[2 * k] = dgg[8 * q + 2 * k] * lo_f(wa[k]) * dy;
-                    gelu_both_f(hi_f(wg[k]), y, dy);
-                    da[2 * k + 1] = dgg[8 * q + 2 * k + 1] * y;
-                    dgt[2 * k + 1] = dgg[8 * q + 2 * k + 1] * hi_f(wa[k]) * dy;
-                }
-                dp[2 * q] = make_uint4(pack2_f16_sat_n(da[0], da[1], sat), pack2_f16_sat_n(da[2], da[3], sat), pack2_f16_sat_n(da[4], da[5], sat), pack2_f16_sat_n(da[6], da[7], sat));
-                dp[2 * q + 1] = make_uint4(pack2_f16_sat_n(dgt[0], dgt[1], sat), pack2_f16_sat_n(dgt[2], dgt[3], sat), pack2_f16_sat_n(dgt[4], dgt[5], sat), pack2_f16_sat_n(dgt[6], dgt[7], sat));
-            }
-        };
         if (p.Uin && !p.Clo && vec8 && m0 + 256 <= p.M && n0 + BN <= p.N && !p.dbg) {
             // full tile of the GEGLU backward: a straight-line loop with u of the NEXT row fragment in flight while this one is finished
             // (in the generic loop below every fragment's loads sit behind its row checks and wait with vmcnt(0) -- on the previous
@@ -562,11 +540,6 @@ __device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha + bias16[j * 4 + r];
-                if (F16 && p.c_f16) {
-                    // (the product value dgg[8 q + k] belongs to value column 8 q + k of the lane's two [8 values | 8 gates] groups)
-                    geglu_bwd_store16(vv, uc, reinterpret_cast<uint4*>(dbase + (long long)i * 16 * p.ldc2));
-                    continue;
-                }
                 const uint4 ua = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
                 const uint4 ug = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
                 geglu_bwd_store(ua, ug, uc, reinterpret_cast<uint4*>(dbase + (long long)i * 16 * p.ldc2));
@@ -587,17 +560,6 @@ __device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
             bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;
             if ((F16 || !Cl) && vec8 && nb + 16 <= p.N) {          // (F16: Clo, when given, receives the fp16 copy of the product)
-                if (F16 && p.c_f16) {                                  // fp16-gradient backward: ONE fp16 output, saturating
-                    if (p.Uin) {
-                        const uint4* up = reinterpret_cast<const uint4*>(p.Uin + m * p.ldu + 2 * nb);
-                        const uint4 uu[4] = {up[0], up[1], up[2], up[3]};
-                        geglu_bwd_store16(vv, uu, reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + 2 * nb));
-                        continue;
-                    }
-                    reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2_f16_sat_n(vv[0], vv[1], sat), pack2_f16_sat_n(vv[2], vv[3], sat), pack2_f16_sat_n(vv[4], vv[5], sat), pack2_f16_sat_n(vv[6], vv[7], sat));
-                    reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2_f16_sat_n(vv[8], vv[9], sat), pack2_f16_sat_n(vv[10], vv[11], sat), pack2_f16_sat_n(vv[12], vv[13], sat), pack2_f16_sat_n(vv[14], vv[15], sat));
-                    continue;
-                }
                 const uint4 ua = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
                 const uint4 ug = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
                 if (p.Uin) {
@@ -612,15 +574,15 @@ __device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&
                 reinterpret_cast<uint4*>(C)[1] = ug;
                 if constexpr (F16) {
                     if (Cl) {              // fp16 copy of the product itself (q / k / v for the fp16 attention core)
-                        reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2_f16_sat_n(vv[0], vv[1], sat), pack2_f16_sat_n(vv[2], vv[3], sat), pack2_f16_sat_n(vv[4], vv[5], sat), pack2_f16_sat_n(vv[6], vv[7], sat));
-                        reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2_f16_sat_n(vv[8], vv[9], sat), pack2_f16_sat_n(vv[10], vv[11], sat), pack2_f16_sat_n(vv[12], vv[13], sat), pack2_f16_sat_n(vv[14], vv[15], sat));
+                        reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2_f16_sat(vv[0], vv[1]), pack2_f16_sat(vv[2], vv[3]), pack2_f16_sat(vv[4], vv[5]), pack2_f16_sat(vv[6], vv[7]));
+                        reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2_f16_sat(vv[8], vv[9]), pack2_f16_sat(vv[10], vv[11]), pack2_f16_sat(vv[12], vv[13]), pack2_f16_sat(vv[14], vv[15]));
                     }
                     if (p.C2) {            // gate on the fp32 accumulators; fp16 copy -> C2 (FF2's A operand), bf16 copy -> C2lo (backward)
                         float o[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = vv[e] * gelu_f(vv[8 + e]);
                         *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) =
-                            make_uint4(pack2_f16_sat_n(o[0], o[1], sat), pack2_f16_sat_n(o[2], o[3], sat), pack2_f16_sat_n(o[4], o[5], sat), pack2_f16_sat_n(o[6], o[7], sat));
+                            make_uint4(pack2_f16_sat(o[0], o[1]), pack2_f16_sat(o[2], o[3]), pack2_f16_sat(o[4], o[5]), pack2_f16_sat(o[6], o[7]));
                         if (p.C2lo)
                             *reinterpret_cast<uint4*>(p.C2lo + m * p.ldc2 + (nb >> 1)) =
                                 make_uint4(pack2_rne(o[0], o[1]), pack2_rne(o[2], o[3]), pack2_rne(o[4], o[5]), pack2_rne(o[6], o[7]));
@@ -659,7 +621,87 @@ __device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&
                 }
             }
         }
-        if constexpr (F16) f16_sat_commit(sat);
+    } else if constexpr (EPI == 4 || EPI == 5) {
+        // fp16-gradient backward (round 5; F16 rings only): the product's operands are fp16(S * gradient) and an fp16 weight; ONE fp16 output,
+        // saturating.  EPI 4: C itself (dgrad).  EPI 5: du = the GEGLU backward of (product = S dgg, u) in u's interleaved layout (C2; u is
+        // bf16 and read element-wise; C is not written).  Separate EPIs so that the forward epilogues (EPI 1) and the long-K kernel (EPI 4
+        // only) keep their register budgets: as run-time branches of EPI 1 they cost gemm_nt_256p_kernel 616 B of scratch per lane.
+        const int nb = n0 + wn * 64 + fg * 16;
+        float sat = 0.f;
+        if constexpr (EPI == 4) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
+                if (m >= p.M || nb >= p.N) continue;               // (host side: N % 16 == 0, so a lane's 16 columns exist together)
+                float vv[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha;
+                bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
+                reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2_f16_sat_n(vv[0], vv[1], sat), pack2_f16_sat_n(vv[2], vv[3], sat), pack2_f16_sat_n(vv[4], vv[5], sat), pack2_f16_sat_n(vv[6], vv[7], sat));
+                reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2_f16_sat_n(vv[8], vv[9], sat), pack2_f16_sat_n(vv[10], vv[11], sat), pack2_f16_sat_n(vv[12], vv[13], sat), pack2_f16_sat_n(vv[14], vv[15], sat));
+            }
+        } else {
+            auto geglu_bwd_store16 = [&](const float (&dgg)[16], const uint4 (&uu)[4], uint4* dp) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const uint4 av = uu[2 * q], gv = uu[2 * q + 1];
+                    const uint32_t wa[4] = {av.x, av.y, av.z, av.w}, wg[4] = {gv.x, gv.y, gv.z, gv.w};
+                    float da[8], dgt[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float y, dy;
+                        gelu_both_f(lo_f(wg[k]), y, dy);
+                        da[2 * k] = dgg[8 * q + 2 * k] * y;
+                        dgt[2 * k] = dgg[8 * q + 2 * k] * lo_f(wa[k]) * dy;
+                        gelu_both_f(hi_f(wg[k]), y, dy);
+                        da[2 * k + 1] = dgg[8 * q + 2 * k + 1] * y;
+                        dgt[2 * k + 1] = dgg[8 * q + 2 * k + 1] * hi_f(wa[k]) * dy;
+                    }
+                    dp[2 * q] = make_uint4(pack2_f16_sat_n(da[0], da[1], sat), pack2_f16_sat_n(da[2], da[3], sat), pack2_f16_sat_n(da[4], da[5], sat), pack2_f16_sat_n(da[6], da[7], sat));
+                    dp[2 * q + 1] = make_uint4(pack2_f16_sat_n(dgt[0], dgt[1], sat), pack2_f16_sat_n(dgt[2], dgt[3], sat), pack2_f16_sat_n(dgt[4], dgt[5], sat), pack2_f16_sat_n(dgt[6], dgt[7], sat));
+                }
+            };
+            if (m0 + 256 <= p.M && n0 + BN <= p.N) {
+                // full tile: u of the NEXT row fragment in flight while this one is finished (see the bf16 form in EPI 1)
+                const bf16_t* ubase = p.Uin + ((long long)m0 + wm * 128 + fr) * p.ldu + 2 * nb;
+                bf16_t* dbase = p.C2 + ((long long)m0 + wm * 128 + fr) * p.ldc2 + 2 * nb;
+                uint4 un[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) un[q] = reinterpret_cast<const uint4*>(ubase)[q];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    uint4 uc[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) uc[q] = un[q];
+                    if (i + 1 < 8) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) un[q] = reinterpret_cast<const uint4*>(ubase + (long long)(i + 1) * 16 * p.ldu)[q];
+                    }
+                    float vv[16];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha;
+                    geglu_bwd_store16(vv, uc, reinterpret_cast<uint4*>(dbase + (long long)i * 16 * p.ldc2));
+                }
+            } else
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
+                if (m >= p.M || nb >= p.N) continue;
+                float vv[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha;
+                const uint4* up = reinterpret_cast<const uint4*>(p.Uin + m * p.ldu + 2 * nb);
+                const uint4 uu[4] = {up[0], up[1], up[2], up[3]};
+                geglu_bwd_store16(vv, uu, reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + 2 * nb));
+            }
+        }
+        f16_sat_commit(sat);
     } else {
     float biasf[4][4];                               // (loaded once per tile: see the bf16 epilogue)
 #pragma unroll
@@ -1073,6 +1115,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256p_kernel(GemmArgs p) {
                 if (F16) ns_full = 16 + (p.Clo ? 16 : 0) + (p.C2 ? 8 + (p.C2lo ? 8 : 0) : 0);
                 else ns_full = p.Clo ? 32 : 16 + (p.C2 ? 8 : 0);
             }
+        } else if constexpr (EPI == 4) {
+            if (p.N % 16 == 0 && p.ldc % 8 == 0) ns_full = 16;
         }
     }
 
@@ -2790,83 +2834,69 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         if (d->geglu_u) { q.Uin = (const bf16_t*)d->geglu_u; q.ldu = d->ld_u; }
         q.c_f16 = d->c_f16 ? 1 : 0;
         q.skew = nt_skew((long long)q.tiles_m * q.tiles_n);
-        if (g_amdnuwa_tuning[0] == 6) {              // probe: 256x128 tile, 3-stage ring, TWO workgroups per CU (one's epilogue under the other's main loop)
+        // epilogue: 0 = fp32, 1 = bf16 (+ fp16 copy / forward gate), 4 = ONE fp16 output or the fp16 GEGLU backward (fp16-gradient backward)
+        const int epi = d->c_f16 ? (d->geglu_u ? 5 : 4) : (d->c_is_bf16 ? 1 : 0);
+#define F16_LAUNCH(KERNEL, GRID, BLOCK, LDS, ...)                                                                         \
+    do {                                                                                                                  \
+        if (epi == 4) {                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)KERNEL<__VA_ARGS__ 4 F16_TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ 4 F16_TAIL>), GRID, BLOCK, LDS, stream, q);                            \
+        } else if (epi == 5) {                                                                                            \
+            (void)hipFuncSetAttribute((const void*)KERNEL<__VA_ARGS__ EPI5 F16_TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ EPI5 F16_TAIL>), GRID, BLOCK, LDS, stream, q);                         \
+        } else if (epi == 1) {                                                                                            \
+            (void)hipFuncSetAttribute((const void*)KERNEL<__VA_ARGS__ 1 F16_TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ 1 F16_TAIL>), GRID, BLOCK, LDS, stream, q);                            \
+        } else {                                                                                                          \
+            (void)hipFuncSetAttribute((const void*)KERNEL<__VA_ARGS__ 0 F16_TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ 0 F16_TAIL>), GRID, BLOCK, LDS, stream, q);                            \
+        }                                                                                                                 \
+        LAUNCH_CHECK();                                                                                                   \
+        return AMDNUWA_OK;                                                                                                \
+    } while (0)
+        // (EPI5: the GEGLU-backward epilogue exists on the persistent ring and the plain ring only; elsewhere the name stands for EPI 4 and is never reached)
+#define EPI5 4
+        if (g_amdnuwa_tuning[0] == 6 && epi < 4) {  // probe: 256x128 tile, 3-stage ring, TWO workgroups per CU (one's epilogue under the other's main loop)
             q.tiles_n = (d->N + 127) / 128;
             q.skew = g_amdnuwa_tuning[14] < 0 ? g_amdnuwa_tuning[14] : 0;
             const size_t l6 = (size_t)3 * (256 + 128) * 32 * 2;
             dim3 g6(q.tiles_m * q.tiles_n, 1), b6(256);
-            if (d->c_is_bf16) {
-                (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 1, 3, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
-                hipLaunchKernelGGL((gemm_nt_256_kernel<false, 1, 3, 2, 0, true>), g6, b6, l6, stream, q);
-            } else {
-                (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 0, 3, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
-                hipLaunchKernelGGL((gemm_nt_256_kernel<false, 0, 3, 2, 0, true>), g6, b6, l6, stream, q);
-            }
-            LAUNCH_CHECK();
-            return AMDNUWA_OK;
+#define F16_TAIL , 3, 2, 0, true
+            F16_LAUNCH(gemm_nt_256_kernel, g6, b6, l6, false,);
+#undef F16_TAIL
         }
-        if (g_amdnuwa_tuning[0] == 11 || (g_amdnuwa_tuning[0] == 0 && d->K >= 1024 && d->K < 2048)) {     // K-step 64 form with staggered wave rows (FF2: -9 %)
-            const size_t l6 = (size_t)2 * 2 * 256 * 64 * 2;
-            dim3 g6(q.tiles_m * q.tiles_n, 1), b6(512);
-            if (d->c_is_bf16) {
-                (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 1, 1, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
-                hipLaunchKernelGGL((gemm_nt_256_kernel<false, 1, 1, 4, 4, true>), g6, b6, l6, stream, q);
-            } else {
-                (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 0, 1, 4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
-                hipLaunchKernelGGL((gemm_nt_256_kernel<false, 0, 1, 4, 4, true>), g6, b6, l6, stream, q);
-            }
-            LAUNCH_CHECK();
-            return AMDNUWA_OK;
+        const size_t l64 = (size_t)2 * 2 * 256 * 64 * 2;
+        dim3 g2(q.tiles_m * q.tiles_n, 1), b2(512);
+        if (epi != 5 && (g_amdnuwa_tuning[0] == 11 || (g_amdnuwa_tuning[0] == 0 && d->K >= 1024 && d->K < 2048))) {     // K-step 64 form with staggered wave rows (FF2: -9 %)
+#define F16_TAIL , 1, 4, 4, true
+            F16_LAUNCH(gemm_nt_256_kernel, g2, b2, l64, false,);
+#undef F16_TAIL
         }
-        if (g_amdnuwa_tuning[0] == 10) {             // K-step 64 form: full 128-byte lines through the DMA ring, two 64 KiB stages
-            const size_t l6 = (size_t)2 * 2 * 256 * 64 * 2;
-            dim3 g6(q.tiles_m * q.tiles_n, 1), b6(512);
-            if (d->c_is_bf16) {
-                (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 1, 1, 4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
-                hipLaunchKernelGGL((gemm_nt_256_kernel<false, 1, 1, 4, 3, true>), g6, b6, l6, stream, q);
-            } else {
-                (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 0, 1, 4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l6);
-                hipLaunchKernelGGL((gemm_nt_256_kernel<false, 0, 1, 4, 3, true>), g6, b6, l6, stream, q);
-            }
-            LAUNCH_CHECK();
-            return AMDNUWA_OK;
+        if (epi != 5 && g_amdnuwa_tuning[0] == 10) { // K-step 64 form: full 128-byte lines through the DMA ring, two 64 KiB stages
+#define F16_TAIL , 1, 4, 3, true
+            F16_LAUNCH(gemm_nt_256_kernel, g2, b2, l64, false,);
+#undef F16_TAIL
         }
         const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;
-        dim3 g2(q.tiles_m * q.tiles_n, 1), b2(512);
-        if (nt_long_k(d->K, q.dbg) && (g_amdnuwa_tuning[0] == 0 || g_amdnuwa_tuning[0] == 7)) {              // long K: four waves of 128x128, K-step 64 (gemm_nt_w4k_kernel)
-            const size_t l4 = (size_t)2 * 2 * 256 * 64 * 2;
+        if (epi != 5 && nt_long_k(d->K, q.dbg) && (g_amdnuwa_tuning[0] == 0 || g_amdnuwa_tuning[0] == 7)) { // long K: four waves of 128x128, K-step 64 (gemm_nt_w4k_kernel)
             dim3 b4(256);
-            if (d->c_is_bf16) {
-                (void)hipFuncSetAttribute((const void*)gemm_nt_w4k_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
-                hipLaunchKernelGGL((gemm_nt_w4k_kernel<1, true>), g2, b4, l4, stream, q);
-            } else {
-                (void)hipFuncSetAttribute((const void*)gemm_nt_w4k_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
-                hipLaunchKernelGGL((gemm_nt_w4k_kernel<0, true>), g2, b4, l4, stream, q);
-            }
-            LAUNCH_CHECK();
-            return AMDNUWA_OK;
+#define F16_TAIL , true
+            F16_LAUNCH(gemm_nt_w4k_kernel, g2, b4, l64, );
+#undef F16_TAIL
         }
+#undef EPI5
+#define EPI5 5
         if (nt_persistent(q.tiles_m * q.tiles_n, d->K, q.dbg)) {               // one workgroup per CU walks the tile list (gemm_nt_256p_kernel)
             dim3 gp(nt_persistent_grid(), 1);
-            if (d->c_is_bf16) {
-                (void)hipFuncSetAttribute((const void*)gemm_nt_256p_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-                hipLaunchKernelGGL((gemm_nt_256p_kernel<1, true>), gp, b2, l2, stream, q);
-            } else {
-                (void)hipFuncSetAttribute((const void*)gemm_nt_256p_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-                hipLaunchKernelGGL((gemm_nt_256p_kernel<0, true>), gp, b2, l2, stream, q);
-            }
-            LAUNCH_CHECK();
-            return AMDNUWA_OK;
+#define F16_TAIL , true
+            F16_LAUNCH(gemm_nt_256p_kernel, gp, b2, l2, );
+#undef F16_TAIL
         }
-        if (d->c_is_bf16) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 1, 4, 4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-            hipLaunchKernelGGL((gemm_nt_256_kernel<false, 1, 4, 4, 1, true>), g2, b2, l2, stream, q);
-        } else {
-            (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false, 0, 4, 4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-            hipLaunchKernelGGL((gemm_nt_256_kernel<false, 0, 4, 4, 1, true>), g2, b2, l2, stream, q);
-        }
-        LAUNCH_CHECK();
-        return AMDNUWA_OK;
+#define F16_TAIL , 4, 4, 1, true
+        F16_LAUNCH(gemm_nt_256_kernel, g2, b2, l2, false,);
+#undef F16_TAIL
+#undef EPI5
+#undef F16_LAUNCH
     }
     if (d->K % 8 || d->lda % 8 || d->ldb % 8) return AMDNUWA_ERR_ARG;
     if ((d->Alo == nullptr) != (d->Blo == nullptr)) return AMDNUWA_ERR_ARG;
