@@ -15,7 +15,13 @@ LIB = os.path.join(LIBDIR, 'libamdnuwa.so')
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'amdnuwa.h')
 SOURCES = ['api.hip', 'gemm.hip', 'elementwise.hip', 'sparse3dna.hip', 'xattn.hip', 'xattn2.hip', 'vae.hip', 'optim.hip', 'decode.hip', 'comm.hip']
 ARCH = 'gfx950'
-DEFAULT_FLAGS = []          # flags of every device compile of the shipped library
+# Flags of every device compile of the SHIPPED library: no packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).
+# Round 4 found the head-mix loop of the two-row Sparse3DNA forward tile returning wrong LOW halves out of a packed-FMA sequence once two
+# workgroups shared a CU.  Round 5 separated the two cures on the GPU (profiles/r05a_mix_variants.txt): packed ops ON + loops written freely
+# -> 431 k differing elements in 8 runs; packed ops OFF + the same free loops -> bit-identical; so the instruction class is the necessary
+# ingredient, and the whole library is compiled without it (+1 % on the step: two kernels pay).  tools/isa_lint.py --forbid-pk
+# (run by __graft_entry__.build() and tests/test_cabi_symbols.py) fails if a packed op reappears.
+DEFAULT_FLAGS = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 
 
 def _hipcc():
@@ -44,11 +50,11 @@ def _stale(target, deps):
 # 15 % fewer instructions in a kernel that is bound by instruction issue); the long-lived accumulators still sit in AGPRs.
 EXTRA_FLAGS = {'xattn2.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
-# Build variants (A/B runs of compiler options: `python -m nuwa_pytorch_amd.build --variant nopk` writes lib_nopk/libamdnuwa.so, which
-# AMDNUWA_LIBRARY=... then selects).  'nopk': no packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the
-# device code -- the instruction shape of the round-4 head-mix defect ("packed fp32"); the host pass ignores the feature flag.
+# Build variants (A/B runs of compiler options: `python -m nuwa_pytorch_amd.build --variant pk` writes lib_pk/libamdnuwa.so, which
+# AMDNUWA_LIBRARY=... then selects).  'pk' / 'pk_nofix': WITH packed fp32 ops (DEFAULT_FLAGS dropped); '*_nofix': the Sparse3DNA head-mix
+# loops written freely (S3_MIX_PIN=0) -- the experiment that separated the two cures of the round-4 defect.  The host pass ignores the flag.
 NOPK_FLAGS = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
-VARIANTS = {'': [], 'nopk': NOPK_FLAGS, 'pk': [], 'pk_nofix': ['-DS3_MIX_PIN=0'], 'nopk_nofix': NOPK_FLAGS + ['-DS3_MIX_PIN=0']}
+VARIANTS = {'': [], 'nopk': [], 'pk': [], 'pk_nofix': ['-DS3_MIX_PIN=0'], 'nopk_nofix': ['-DS3_MIX_PIN=0']}
 
 
 def lib_path(variant=''):

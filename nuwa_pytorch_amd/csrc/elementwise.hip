@@ -464,11 +464,10 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
                 const bool has = src >= 0 && inr;                                    // branch-free: rows without a source re-read their own row
                 const size_t so = (size_t)(has ? src : row) * D + e;
                 const float4 v = BFM == 3 ? ld4h(dh, so) : ((NT & 2) ? ld4_nt<BF>(dh, so) : ld4<BF>(dh, so));
-                if (BFM == 3) in.gv.v[it] = make_float4(has ? v.x * gin : 0.f, has ? v.y * gin : 0.f, has ? v.z * gin : 0.f, has ? v.w * gin : 0.f);
-                else in.gv.v[it] = make_float4(has ? v.x : 0.f, has ? v.y : 0.f, has ? v.z : 0.f, has ? v.w : 0.f);
+                in.gv.v[it] = make_float4(has ? v.x : 0.f, has ? v.y : 0.f, has ? v.z : 0.f, has ? v.w : 0.f);
             }
         } else {
-            if (BFM == 3) row_load_f<2>(dh, (size_t)row * D, D, lane, in.gv, gin);
+            if (BFM == 3) row_load_f<2>(dh, (size_t)row * D, D, lane, in.gv);
             else row_load_t<BF>(dh, (size_t)row * D, D, lane, in.gv);
         }
         if (NT & 2) {
@@ -512,8 +511,11 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
             const int e = (lane + it * 64) * 4;
             if (e >= D) { dx[it] = zero4; continue; }
             const float4 o = cur.rv.v[it];
-            dx[it] = make_float4(o.x + cur.rstd * (g[it].x - m1 - xh[it].x * m2), o.y + cur.rstd * (g[it].y - m1 - xh[it].y * m2),
-                                 o.z + cur.rstd * (g[it].z - m1 - xh[it].z * m2), o.w + cur.rstd * (g[it].w - m1 - xh[it].w * m2));
+            // (fp16 dh = S * value: every term in the bracket is linear in dh, so the 1 / S rides on rstd -- one scalar product per row
+            //  instead of one per element; the weight-gradient partials pwA / pbA are unscaled once, after the row loop)
+            const float rs = BFM == 3 ? cur.rstd * gin : cur.rstd;
+            dx[it] = make_float4(o.x + rs * (g[it].x - m1 - xh[it].x * m2), o.y + rs * (g[it].y - m1 - xh[it].y * m2),
+                                 o.z + rs * (g[it].z - m1 - xh[it].z * m2), o.w + rs * (g[it].w - m1 - xh[it].w * m2));
             if (NT & 1) st4_nt(dx_out + row * D + e, dx[it]); else *reinterpret_cast<float4*>(dx_out + row * D + e) = dx[it];
         }
         // ---- post-norm backward of block k on the row just produced -> dy_prev
@@ -535,10 +537,12 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
         for (int it = 0; it < NV; ++it) {
             const int e = (lane + it * 64) * 4;
             if (e >= D) continue;
-            const float d0 = cur.rstdp * (g[it].x - n1 - xh[it].x * n2), d1 = cur.rstdp * (g[it].y - n1 - xh[it].y * n2);
-            const float d2 = cur.rstdp * (g[it].z - n1 - xh[it].z * n2), d3 = cur.rstdp * (g[it].w - n1 - xh[it].w * n2);
+            // (fp16 dy_prev = S * value: S rides on rstd_prev; the column sums psB are unscaled once, after the row loop -- S is a power of two)
+            const float rp = cur.rstdp * gout;
+            const float d0 = rp * (g[it].x - n1 - xh[it].x * n2), d1 = rp * (g[it].y - n1 - xh[it].y * n2);
+            const float d2 = rp * (g[it].z - n1 - xh[it].z * n2), d3 = rp * (g[it].w - n1 - xh[it].w * n2);
             psB[it].x += d0; psB[it].y += d1; psB[it].z += d2; psB[it].w += d3;
-            if (out_f16) store_bf16x4(dyp_hi + row * D, nullptr, e, d0 * gout, d1 * gout, d2 * gout, d3 * gout, 2, &sat);
+            if (out_f16) store_bf16x4(dyp_hi + row * D, nullptr, e, d0, d1, d2, d3, 2, &sat);
             else if ((NT & 1) && !dyp_lo) st_bf16x4_nt(dyp_hi + row * D + e, d0, d1, d2, d3);
             else store_bf16x4(dyp_hi + row * D, dyp_lo ? dyp_lo + row * D : nullptr, e, d0, d1, d2, d3);
         }
@@ -552,6 +556,15 @@ __global__ __launch_bounds__(256) void ln_bwd_chain_kernel(const float* __restri
         process(bufB, row + stride);
     }
     f16_sat_commit(sat);
+    if (BFM == 3 || out_f16) {
+        const float ginv = BFM == 3 ? gin : 1.f, goutinv = out_f16 ? f16_gs_inv(scale2) : 1.f;
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            pwA[it].x *= ginv; pwA[it].y *= ginv; pwA[it].z *= ginv; pwA[it].w *= ginv;
+            pbA[it].x *= ginv; pbA[it].y *= ginv; pbA[it].z *= ginv; pbA[it].w *= ginv;
+            psB[it].x *= goutinv; psB[it].y *= goutinv; psB[it].z *= goutinv; psB[it].w *= goutinv;
+        }
+    }
     // block reduce the 4 waves' partials in fixed order, one LayerNorm at a time through the same LDS
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();

@@ -21,6 +21,16 @@ def test_library_exports_every_declared_symbol():
     assert so.amdnuwa_abi_version() == _lib.ABI_VERSION
 
 
+def test_shipped_isa_has_no_packed_fp32_ops_and_no_new_spills():
+    """ISA lint of the shipped code objects (tools/isa_lint.py): the library is compiled without packed fp32 VALU instructions -- the
+    instruction class of the round-4 head-mix defect -- and the hot kernels stay inside their scratch bounds"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import isa_lint
+    from nuwa_pytorch_amd import build as B
+    bad = isa_lint.check_shipped(B.build(verbose=False))
+    assert not bad, bad
+
+
 def test_argument_validation_without_gpu():
     """entry points reject bad descriptors before touching the device"""
     from nuwa_pytorch_amd import _lib

@@ -111,6 +111,32 @@ def kernel_scratch(lib):
     return res
 
 
+# scratch (spill) bounds of the hot kernels of the training step, bytes per lane: a change that pushes one of them over its register budget
+# shows up here (CPU, seconds) instead of as a slower step on the GPU.  Round 5 lesson: two run-time branches added to the bf16 epilogue
+# cost gemm_nt_256p_kernel<1, true> 616 B of scratch per lane and the step 17 %, with every test green.
+SCRATCH_BOUNDS = [('gemm_nt_256p_kernel', 0), ('gemm_nt_256_kernel', 0), ('gemm_nt_w4k_kernel', 16), ('gemm_tn_w4k_kernel', 0), ('gemm_tn_256_kernel', 0),
+                  ('gemm_nt_256x3_kernel', 80), ('ln_post_pre_kernel', 0), ('ln_bwd_chain_kernel', 0), ('ln_fwd_kernel', 0), ('s3_fwd_tile_kernel', 0),
+                  ('s3_fwd_mfma_kernel', 0), ('s3_bwd_q_mfma_kernel', 60), ('s3_bwd_kv_mfma_kernel', 0), ('xattn4_fwd_kernel', 0), ('xattn3_bwd_kernel', 272),
+                  ('ce_fwd_reg_kernel', 0), ('splitk_reduce_kernel', 0)]
+
+
+def check_shipped(lib=None):
+    """the build / test gate: list of failures (empty = fine) -- packed fp32 VALU ops anywhere, or a hot kernel above its scratch bound"""
+    lib = lib or os.path.join(ROOT, 'nuwa_pytorch_amd', 'lib', 'libamdnuwa.so')
+    bad = []
+    res = scan(lib)
+    npk = sum(e['pk'] for e in res.values())
+    if npk:
+        worst = max(res, key=lambda k: res[k]['pk'])
+        bad.append(f'{npk} packed fp32 VALU ops in {sum(1 for e in res.values() if e["pk"])} kernels (e.g. {res[worst]["pk"]} in {worst[:80]})')
+    sc = kernel_scratch(lib)
+    for k, v in sc.items():
+        for name, bound in SCRATCH_BOUNDS:
+            if name in k and v > bound:
+                bad.append(f'{v} B/lane of scratch in {k[:100]} (bound {bound})')
+    return bad
+
+
 M0_READERS = re.compile(r'^(global_load_lds_|buffer_load_\w+.*\blds\b|s_movrel|v_movrel|ds_gws|s_sendmsg|v_interp)')
 
 
