@@ -426,8 +426,10 @@ def main():
                                     '; single fp16 MFMA on ' + (', '.join(nm for nm, on in (('3DNA q/k/v projection', f16_parts['qkv']), ('FF1 + gate', f16_parts['ff']),
                                                                                           ('FF2', f16_parts['ff']), ('Sparse3DNA core', f16_parts['cores']),
                                                                                           ('cross-attention core', f16_parts['cores'])) if on) or 'nothing') +
-                                    '; backward: single bf16 MFMAs'}[args.precision],
-            'precision_mode': args.precision, 'fp16_forward_parts': f16_parts if args.precision == 'bf16x3-fwd' else None, 'data': 'synthetic',
+                                    '; backward: single bf16 MFMAs' + ('' if not K._BWD_F16 else ' except ' + ', '.join(nm for nm, cl in (('FeedForward', 'f'), ('Sparse3DNA', 's'), ('cross attention', 'x')) if cl in K._BWD_F16) +
+                                                                        ' (single fp16 MFMAs on fp16(S x gradient), device-side power-of-two S, one fp16 copy per activation)')}[args.precision],
+            'precision_mode': args.precision, 'fp16_forward_parts': f16_parts if args.precision == 'bf16x3-fwd' else None,
+            'fp16_gradient_blocks': (''.join(sorted(K._BWD_F16)) if args.precision == 'bf16x3-fwd' else None), 'data': 'synthetic',
             'config': {'workload': f'BASELINE {args.config}: NUWA decoder dim={c["dim"]} depth={c["dec_depth"]} heads={c["heads"]}, '
                                    f'{c["frames"]}x{c["fmap"]}x{c["fmap"]} video tokens, 3DNA kernel {c["kernel"]} dilation {c["dilation"]}, '
                                    f'{c["text_len"]} text tokens, codebook {c["codebook"]}',
@@ -479,6 +481,11 @@ def main():
                 except Exception as e:
                     par[mode] = {'error': f'{type(e).__name__}: {e}'}
             out['parity'] = par
+        # fp16 saturation monitor over everything this process ran (timed steps included): 0 in a healthy run
+        try:
+            out.setdefault('parity', {})['f16_saturations'] = K.f16_sat_count(reset=False)
+        except Exception as e:
+            out.setdefault('parity', {})['f16_saturations'] = f'{type(e).__name__}: {e}'
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

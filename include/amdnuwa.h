@@ -175,6 +175,9 @@ int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspac
  * pass by the host side from the residual-stream gradient, without a host synchronisation (nuwa_pytorch_amd/ops.py: _grad_scale). */
 #define AMDNUWA_LN_OUT_F16 128
 #define AMDNUWA_LN_DY_F16 256
+/* ln_bwd_f16's `stable`: the fp32 dy is multiplied by the device scalar scale2[1] on the way in (the upstream gradient of the loss entering the
+ * final norm's backward: no separate scaling pass over dy) */
+#define AMDNUWA_LN_DY_SCALED 512
 int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const float* b, uint16_t* out_hi,
                    uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R, int D,
                    int mode, int stable, float eps, int shift_ntok, int shift_fmap, amdnuwa_stream stream);

@@ -2755,14 +2755,16 @@ extern "C" int amdnuwa_gemm_nt_f16ops_supported(const amdnuwa_gemm_desc* d) {
     if (d->K % 32 || d->lda % 8 || d->ldb % 8 || d->M <= 4 * ROWS_MR) return 0;
     if (d->c_is_bf16 && (d->N % 16 || d->ldc % 8 || (d->C2 && d->ldc2 % 8))) return 0;
     if (!d->c_is_bf16 && (d->C2 || d->N % 4 || d->ldc % 4)) return 0;
-    // (no tile-count threshold: the arithmetic of a FeedForward block must not depend on the batch size -- a one-sample parity check
-    //  has to run the same fp16 products as the training batch, so small M takes the 256x256 ring too)
+    // (no tile-count threshold above M = 4 * ROWS_MR = 32 rows: the arithmetic of a FeedForward block must not depend on the batch size -- a
+    //  one-sample parity check (M = n = 2560) has to run the same fp16 products as the training batch, so small M takes the 256x256 ring too.
+    //  M <= 32 -- the few-row steps of generate() -- stays on the hi + lo row kernel: more exact, and documented in DESIGN.md section 3)
     const int v = g_amdnuwa_tuning[0];
     return (v == 0 || v == 7 || v == 6 || v == 10 || v == 11) ? 1 : 0;          // (6: the 256x128 two-workgroups-per-CU probe of the same ring; 10: the K-step 64 form)
 }
 
 // fp16 A x fp16 (hi + lo) B, two MFMAs per product (d->ab_f16 with Blo): the hi + lo ring's X2 form.  As for the one-MFMA fp16 products
-// there is no tile-count threshold -- the arithmetic of a block must not depend on the batch size.
+// there is no tile-count threshold above M = 32 rows -- the arithmetic of a block must not depend on the batch size; the few-row decode
+// steps (M <= 4 * ROWS_MR) run the more exact hi + lo row kernel instead.
 extern "C" int amdnuwa_gemm_nt_f16x2_supported(const amdnuwa_gemm_desc* d) {
     if (!d || !d->A || !d->B || !d->Blo || !d->C || d->Alo || d->shift_ntok > 0 || d->batch > 1 || d->C2 || d->geglu_u) return 0;
     if (d->K % 32 || d->lda % 8 || d->ldb % 8 || d->M <= 4 * ROWS_MR) return 0;

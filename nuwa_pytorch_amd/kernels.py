@@ -606,7 +606,7 @@ def gemm_tn_batched(desc, device):
 # ------------------------------------------------------------------------------------------------
 
 LN_X_BF16, LN_DY_BF16, LN_LO_F16 = 16, 32, 64       # == AMDNUWA_LN_X_BF16 / AMDNUWA_LN_DY_BF16 / AMDNUWA_LN_LO_F16
-LN_OUT_F16, LN_DY_F16 = 128, 256                    # == AMDNUWA_LN_OUT_F16 / AMDNUWA_LN_DY_F16
+LN_OUT_F16, LN_DY_F16, LN_DY_SCALED = 128, 256, 512   # == AMDNUWA_LN_OUT_F16 / AMDNUWA_LN_DY_F16 / AMDNUWA_LN_DY_SCALED
 
 
 def _f32_or_bf(t):
@@ -669,7 +669,7 @@ def ln_post_pre_fwd(y, resid, w, b, next_w, next_b, *, eps=1e-5, next_shift=None
     return out, mean, rstd, h, mean2, rstd2
 
 
-def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift=None, want_dsum=False, to_f16=None):
+def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift=None, want_dsum=False, to_f16=None, dy_scale2=None):
     """returns (dx, dw, db, dsum).  to_bf: dx as BF pair; to_f16 = s2 (device {S, 1 / S}): dx as G16 = fp16(S * dx); else dx fp32 =
     dres + dx_ln (dres may be None -> zeros).  dy / x: fp32 tensors, or (one of them) a hi-only BF pair; dy may be a G16."""
     L = _lib.lib()
@@ -678,8 +678,12 @@ def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift
         dyp, dybf, s2 = _p(dy.t), False, dy.s2
     else:
         dyp, dybf, _, _ = _f32_or_bf(dy)
+        if dy_scale2 is not None:                # fp32 dy multiplied by the DEVICE scalar dy_scale2[1] on the way in
+            assert not dybf and to_f16 is None
+            s2 = dy_scale2
     xp, xbf, (R, D), dev = _f32_or_bf(x)
-    st = (1 if inv_amax is not None else 0) | (LN_X_BF16 if xbf else 0) | (LN_DY_BF16 if dybf else 0) | (LN_DY_F16 if isinstance(dy, G16) else 0)
+    st = (1 if inv_amax is not None else 0) | (LN_X_BF16 if xbf else 0) | (LN_DY_BF16 if dybf else 0) | (LN_DY_F16 if isinstance(dy, G16) else 0) | \
+        (LN_DY_SCALED if dy_scale2 is not None else 0)
     dw = torch.empty(D, dtype=torch.float32, device=dev)
     db = torch.empty(D, dtype=torch.float32, device=dev)
     ds = torch.empty(D, dtype=torch.float32, device=dev) if want_dsum else None

@@ -14,6 +14,8 @@ LayerNorm wrappers) through `InnerFn`, so `Sparse3DNA(...)(x)` alone works as in
 """
 import functools
 import os
+import warnings
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -98,7 +100,7 @@ def f16_ranges_prefetch(ws):
     del _F16_ALSO[:]
     for w in ws:
         k = (w.data_ptr(), w._version)
-        if k not in _F16_RANGE and k not in seen and w.is_cuda:
+        if not _f16_known(w) and k not in seen and w.is_cuda:
             seen.add(k)
             todo.append(w)
     if not todo:
@@ -108,12 +110,25 @@ def f16_ranges_prefetch(ws):
     with torch.no_grad():
         am = torch.stack(torch._foreach_norm([w.detach() for w in todo], float('inf'))).cpu().tolist()     # ONE synchronisation
     for w, a in zip(todo, am):
-        _F16_RANGE[(w.data_ptr(), w._version)] = bool(F16_WMIN <= a <= F16_WMAX)       # (NaN compares false)
+        _F16_RANGE[(w.data_ptr(), w._version)] = (weakref.ref(w), bool(F16_WMIN <= a <= F16_WMAX))       # (NaN compares false)
+    # the stream is drained at this point anyway (once per optimiser step): look at the fp16 saturation monitor of the step before
+    nsat = K.f16_sat_count(reset=True)
+    if nsat:
+        warnings.warn(f'nuwa_pytorch_amd: {nsat} thread(s) clamped a value beyond +-65504 in an fp16 store of the last step (activation copies or '
+                      "fp16 gradients of the 'bf16x3-fwd' mode): the step ran on saturated values; set_precision('bf16x3') has fp32's range",
+                      RuntimeWarning, stacklevel=3)
+
+
+def _f16_known(w):
+    """the verdict recorded for THIS tensor object at this version, or None: a verdict is tied to the tensor by a weak reference, so a new
+    weight allocated at a freed weight's address (same data_ptr, same version counter) does not inherit a stale one"""
+    ent = _F16_RANGE.get((w.data_ptr(), w._version))
+    return ent[1] if ent is not None and ent[0]() is w else None
 
 
 def f16_weights_ok(*ws):
     f16_ranges_prefetch(ws)
-    return all(_F16_RANGE.get((w.data_ptr(), w._version), False) for w in ws)
+    return all(_f16_known(w) is True for w in ws)
 
 
 def _f16_to_pair(h):
@@ -885,9 +900,9 @@ class LogitsLossFn(Function):
         dwl = torch.empty_like(wl)
         K.gemm_tn(ctx.dl, ctx.hn, dwl)
         gs = g.detach().reshape(1).float().contiguous()
-        K.scale_by_device_scalar(dhn, gs)
         K.scale_by_device_scalar(dwl, gs)
-        dx, dnw, dnb, _ = K.ln_bwd(dhn, x2, m, r, nw.detach(), inv_amax=ia)
+        # the upstream gradient of the loss rides into the final norm's backward as a device scalar (it cost a read-modify-write pass over dhn)
+        dx, dnw, dnb, _ = K.ln_bwd(dhn, x2, m, r, nw.detach(), inv_amax=ia, dy_scale2=torch.cat((gs, gs)))
         ctx.hn = ctx.dl = None
         return dx.reshape(B, n, D), None, dnw, dnb, dwl, None
 

@@ -1340,3 +1340,71 @@ def test_fp16_store_keeps_nan(K):
     h, _, _, _ = K.ln_fwd(x, torch.ones(512, device=DEV), torch.zeros(512, device=DEV), f16=True)
     assert torch.isnan(h.f16[3]).all() and torch.isnan(h.hi[3]).all()
     assert torch.isfinite(h.f16[2]).all()
+
+
+def test_every_kernel_family_bit_reproducible_with_coresident_workgroups(K):
+    """round 5: the reproducibility stress of round 4 covered the attention kernels; the GEMM epilogues (fp16 forward forms, two-MFMA form,
+    GEGLU backward in bf16 and in fp16), the weight gradients, the LayerNorm kernels and the cross entropy share the source patterns of the
+    defect it found, so they take the same test: 5 runs on the same inputs at a batch that fills every CU several times over (b = 32),
+    element for element (tools/determinism_stress.py; the evidence run of the round is b = 128 x 10: profiles/r05_determinism_stress.txt)"""
+    import os
+    import sys
+    from gpu_util import ROOT
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import determinism_stress as DS
+    DS.REP = 5
+    bad = []
+
+    def check(name, fn):
+        n = DS.check(name, fn)
+        if n:
+            bad.append((name, n))
+        return n
+    assert DS.other_families(32, check) == 0, bad
+
+
+def test_attention_cores_at_batch_16_equal_their_one_sample_results(K):
+    """round 5 (review): reproducibility says 'the same wrong value every time' is fine; this does not.  The attention cores work per sample,
+    so sample s of a batch-16 launch -- two workgroups per CU, several rounds -- must equal the batch-1 launch on that sample's data BIT FOR
+    BIT (forward outputs, statistics, dq / dk / dv, dS / P'): a defect that needs co-resident workgroups shows up as a difference."""
+    heads, dh, B, n, T = 8, 64, 16, 2560, 256
+    inner = heads * dh
+    torch.manual_seed(2)
+    wth = (torch.randn(heads, heads) * 0.5 + torch.eye(heads)).to(DEV)
+    pick = (0, 7, 15)
+    for dil in ((1, 1, 1), (2, 2, 2), (4, 4, 4)):
+        qkv = torch.randn(B * n, 3 * inner, device=DEV)
+        dO = torch.randn(B * n, inner, device=DEV).to(torch.bfloat16)
+        g = K.s3_geom(B, n, (10, 16, 16), (5, 3, 3), dil, heads, dh)
+        g1 = K.s3_geom(1, n, (10, 16, 16), (5, 3, 3), dil, heads, dh)
+        p16 = K.BF(qkv.to(torch.bfloat16), None, qkv.half())
+        o = K.sparse3dna_fwd(g, p16, wth, o_f16=True)
+        dqkv, _, _ = K.sparse3dna_bwd(g, K.BF(p16.hi, None), wth, K.BF(dO, None))
+        for s in pick:
+            rows = slice(s * n, (s + 1) * n)
+            p1 = K.BF(p16.hi[rows].contiguous(), None, p16.f16[rows].contiguous())
+            o1 = K.sparse3dna_fwd(g1, p1, wth, o_f16=True)
+            assert torch.equal(o.hi[rows], o1.hi) and torch.equal(o.f16[rows], o1.f16), f'3DNA forward, dilation {dil[0]}, sample {s}'
+            d1, _, _ = K.sparse3dna_bwd(g1, K.BF(p1.hi, None), wth, K.BF(dO[rows].contiguous(), None))
+            assert torch.equal(dqkv.hi[rows], d1.hi), f'3DNA backward, dilation {dil[0]}, sample {s}'
+    q, kv = torch.randn(B * n, inner, device=DEV), torch.randn(B * T, 2 * inner, device=DEV)
+    mask = (torch.rand(B, T, device=DEV) > 0.2).to(torch.uint8)
+    nk, nv = torch.randn(heads, dh, device=DEV), torch.randn(heads, dh, device=DEV)
+    dO = torch.randn(B * n, inner, device=DEV).to(torch.bfloat16)
+    gx, gx1 = K.x_geom(B, n, T, heads, dh), K.x_geom(1, n, T, heads, dh)
+    q16, kv16 = K.BF(q.to(torch.bfloat16), None, q.half()), K.BF(kv.to(torch.bfloat16), None, kv.half())
+    pk = K.xattn_pack(gx, kv16, nk, nv, mask)
+    o, st = K.xattn2_fwd_f16(gx, q16, pk, wth, o_f16=True)
+    pkb = K.xattn_pack(gx, K.BF(kv16.hi, None), nk, nv, mask)
+    dq, dS, Pm, _ = K.xattn2_bwd(gx, K.BF(q16.hi, None), K.BF(dO, None), pkb, wth, st)
+    for s in pick:
+        rows, krows = slice(s * n, (s + 1) * n), slice(s * T, (s + 1) * T)
+        q1 = K.BF(q16.hi[rows].contiguous(), None, q16.f16[rows].contiguous())
+        kv1 = K.BF(kv16.hi[krows].contiguous(), None, kv16.f16[krows].contiguous())
+        pk1 = K.xattn_pack(gx1, kv1, nk, nv, mask[s:s + 1].contiguous())
+        o1, st1 = K.xattn2_fwd_f16(gx1, q1, pk1, wth, o_f16=True)
+        assert torch.equal(o.hi[rows], o1.hi) and torch.equal(o.f16[rows], o1.f16), f'cross attention forward, sample {s}'
+        assert torch.equal(st.reshape(B, -1)[s], st1.reshape(-1)), f'cross attention statistics, sample {s}'
+        pkb1 = K.xattn_pack(gx1, K.BF(kv1.hi, None), nk, nv, mask[s:s + 1].contiguous())
+        dq1, dS1, Pm1, _ = K.xattn2_bwd(gx1, K.BF(q1.hi, None), K.BF(dO[rows].contiguous(), None), pkb1, wth, st1)
+        assert torch.equal(dq.hi[rows], dq1.hi) and torch.equal(dS.hi[s], dS1.hi[0]) and torch.equal(Pm.hi[s], Pm1.hi[0]), f'cross attention backward, sample {s}'

@@ -503,3 +503,29 @@ def test_fp16_gradient_backward_of_the_compliant_mode(A, O):
         KK._BWD_F16 = saved
         A.set_precision('bf16')
     _note('cfg3.fp16_gradient_backward', res)
+
+
+def test_cfg3_full_depth_logits_worst_of_several_models_and_samples(A, O):
+    """round 5: the 1e-3 logits bound of the compliant mode asserted on the WORST of eight samples, not on one sample of one random-init model:
+    two random initialisations (three samples each) and a 'trained-like' variant (heavier weight tails on 1 % of the entries, LayerNorm gains
+    drawn from [0.3, 3]; two samples) -- tools/parity_sweep.py.  Measured in round 5 (profiles/r05a_parity_sweep.txt): 7.2e-4 ... 8.2e-4 on the
+    random initialisations, 7.5e-4 / 9.3e-4 on the trained-like model, rel-l2 6.5e-4 ... 7.6e-4.
+    A second, HARSHER trained-like model (x4 tails on 2 % of the entries, LayerNorm gains in [0.1, 8]: attention scores ~64x larger, so an
+    11-bit operand moves the softmax by percents) is measured and recorded, not asserted against 1e-3: no form with fp16 / bf16 operands holds
+    there (5e-3 ... 7e-3 with and without the two-MFMA products) -- the mode for such weights is 'bf16x3', whose figure is recorded beside it."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import parity_sweep as PS
+    from nuwa_pytorch_amd import kernels as KK
+    res = PS.sweep(classes=(KK.DEFAULT_F16X2,), models=[PS.MODELS[0], PS.MODELS[1], PS.MODELS[3]], log=lambda *_: None)
+    worst = max(res, key=lambda e: e['rel_max'])
+    for e in res:
+        record(f"cfg3.full24[bf16x3-fwd].logits[{e['model'][:24]}, sample {e['sample']}]", e['rel_max'], e['rel_l2'], 1e-3)
+    harsh = PS.sweep(classes=(KK.DEFAULT_F16X2,), models=[PS.MODELS[2]], modes=('bf16x3-fwd', 'bf16x3'), log=lambda *_: None)
+    _note('cfg3.full_depth_logits_sweep', dict(samples=res, worst=worst, harsh_model=harsh))
+    assert all(e['finite'] for e in res + harsh)
+    assert all(e['f16_saturations'] == 0 for e in res), 'fp16 stores saturated on an in-range model'
+    assert len(res) == 8 and worst['rel_max'] <= 1e-3, worst
+    assert max(e['rel_l2'] for e in res) <= 8.5e-4, res
+    hx3 = [e for e in harsh if e['mode'] == 'bf16x3']
+    assert hx3 and max(e['rel_max'] for e in hx3) <= max(e['rel_max'] for e in harsh if e['mode'] == 'bf16x3-fwd'), harsh

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
-"""Bit-reproducibility of the attention kernels at batches that fill the chip (several workgroups per CU, several rounds): every kernel is
-run 8 times on the same inputs and every output compared with the first run's, element for element.  The full-size determinism tests of
-the GPU suite use one sample (one workgroup per CU at most); a race that needs co-resident workgroups only shows up here."""
+"""Bit-reproducibility of every kernel family of the training step at batches that fill the chip (several workgroups per CU, several
+rounds): every kernel is run REP times on the same inputs and every output compared with the first run's, element for element.  The
+full-size determinism tests of the GPU suite use one sample (one workgroup per CU at most); a race that needs co-resident workgroups only
+shows up here.
+
+    python tools/determinism_stress.py [B = 16] [--rep 8] [--only-s3]        (round-5 evidence: B = 128, --rep 10)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +14,7 @@ L = _lib.lib()
 DEV = 'cuda'
 heads, dh = 8, 64
 inner = heads * dh
-REP = 8
+REP = int(sys.argv[sys.argv.index('--rep') + 1]) if '--rep' in sys.argv else 8
 
 
 def tensors(o):
@@ -19,6 +22,8 @@ def tensors(o):
     for x in (o if isinstance(o, (tuple, list)) else (o,)):
         if isinstance(x, K.BF):
             out += [t for t in (x.hi, x.lo, x.f16) if t is not None]
+        elif isinstance(x, K.G16):
+            out.append(x.t)
         elif torch.is_tensor(x):
             out.append(x)
     return out
@@ -74,8 +79,54 @@ def main():
     o, stats = K.xattn2_fwd(gx, qb, pkb, wth)
     dO = K.BF(torch.randn(B * n, inner, device=DEV).to(torch.bfloat16), None)
     total += check(f'cross attention bwd (xattn3, query side), b={B}', lambda: K.xattn2_bwd(gx, qb, dO, pkb, wth, stats))
+    total += other_families(B, check)
     print('TOTAL differing elements:', total)
     return 1 if total else 0
+
+
+def other_families(B, check):
+    """GEMM epilogues (fp16 forward forms, two-MFMA form, GEGLU backward in bf16 and fp16), weight gradients, LayerNorm kernels, cross entropy"""
+    total = 0
+    torch.manual_seed(1)
+    R, D, FP, FFI = B * 2560, 512, 1376, 1365
+    x = torch.randn(R, D, device=DEV)
+    w, b = torch.randn(D, device=DEV), torch.randn(D, device=DEV)
+    h, m1, r1, _ = K.ln_fwd(x, w, b, f16=True)
+    w1 = (torch.randn(2 * FP, D, device=DEV) * 0.2).half()
+    w2 = (torch.randn(D, FP, device=DEV) * 0.2).half()
+    total += check(f'FF1 + gate, fp16 operands (persistent ring), R={R}', lambda: K.gemm_nt_f16ops(h.f16, w1, out_bf16=True, gate=True))
+    u, gg16, ggb = K.gemm_nt_f16ops(h.f16, w1, out_bf16=True, gate=True)
+    total += check(f'FF2, fp16 operands (K-step 64 ring), R={R}', lambda: K.gemm_nt_f16ops(gg16, w2))
+    wqkv = (torch.randn(3 * 512, D, device=DEV) * 0.1).half()
+    total += check(f'q/k/v projection, fp16 operands, bf16 + fp16 copies, R={R}', lambda: K.gemm_nt_f16ops(h.f16, wqkv, out_bf16=True, copy_f16=True))
+    wo = K.f16_pair(torch.randn(D, 512, device=DEV) * 0.1)
+    total += check(f'to_out, two-MFMA form (fp16 x fp16 hi + lo), R={R}', lambda: K.gemm_nt_f16x2(h.f16, wo))
+    dy = K.BF((torch.randn(R, D, device=DEV) * 0.01).to(torch.bfloat16), None)
+    w2T = K.BF((torch.randn(FP, D, device=DEV) * 0.2).to(torch.bfloat16), None)
+    total += check(f'dgrad ff2 + GEGLU backward epilogue, bf16, R={R}', lambda: K.gemm_nt_geglu_bwd(dy, w2T, K.BF(u, None), FP))
+    s2 = torch.tensor([1024.0, 1.0 / 1024.0], device=DEV)
+    dy16 = (dy.hi.float() * 1024.0).half()
+    total += check(f'dgrad ff2 + GEGLU backward epilogue, fp16 gradients, R={R}', lambda: K.gemm_nt_geglu_bwd16(dy16, w2T.hi.half(), u, FP))
+    du16 = K.gemm_nt_geglu_bwd16(dy16, w2T.hi.half(), u, FP)
+    w1T = w1.t().contiguous()
+    total += check(f'dgrad ff1 (long-K four-wave kernel), fp16 gradients, R={R}', lambda: K.gemm_nt_f16ops(du16, w1T, out_f16=True))
+    dw1 = torch.empty(2 * FP, D, device=DEV)
+    total += check(f'dW ff1 (four-wave TN kernel), fp16, R={R}', lambda: K.gemm_tn16(du16, h.f16, dw1, s2).clone())
+    dwb = torch.empty(D, FFI, device=DEV)
+    total += check(f'dW ff2 (four-wave TN kernel), bf16, R={R}', lambda: K.gemm_tn(dy, K.BF(ggb, None), dwb, N2=FFI).clone())
+    y = torch.randn(R, D, device=DEV)
+    total += check(f'ln_post_pre (bf16 + fp16 copies), R={R}', lambda: K.ln_post_pre_fwd(y, x, w, b, b, w, next_shift=(2560, 16), next_f16=True))
+    _, m2, r2, _ = K.ln_fwd(y, w, b)
+    g = torch.randn(R, D, device=DEV) * 1e-3
+    dh = K.BF((torch.randn(R, D, device=DEV) * 1e-3).to(torch.bfloat16), None)
+    total += check(f'ln_bwd_chain (bf16 dh), R={R}', lambda: K.ln_bwd_chain(dh, x, m1, r1, w, g, y, m2, r2, w, shift=(2560, 16), want_dsum=True))
+    dh16 = K.G16((dh.hi.float() * 1024.0).half(), s2)
+    total += check(f'ln_bwd_chain (fp16 dh, fp16 dy_prev), R={R}', lambda: K.ln_bwd_chain(dh16, x, m1, r1, w, g, y, m2, r2, w, shift=(2560, 16), want_dsum=True, out_f16=s2))
+    Rc = min(R, 16 * 2560)
+    logits = torch.randn(Rc, 8192, device=DEV)
+    tg = torch.randint(0, 8192, (Rc,), device=DEV)
+    total += check(f'cross entropy (register-resident rows), R={Rc}', lambda: K.ce_fwd(logits, tg, 1.0 / Rc, lo=False))
+    return total
 
 
 if __name__ == '__main__':

@@ -45,7 +45,7 @@ MODELS = [('init seed 0', 0, None, 3), ('init seed 1', 1, None, 3),
           ('trained-like, mild (tails x3 on 1 %, LN gains in [0.3, 3])', 0, dict(tail=3.0, frac=0.01, glo=0.3, ghi=3.0), 2)]
 
 
-def sweep(classes=('oq',), quick=False, models=None, log=print):
+def sweep(classes=('oq',), quick=False, models=None, log=print, modes=('bf16x3-fwd',)):
     import nuwa_pytorch_amd as A
     from nuwa_pytorch_amd import kernels as KK
     from oracle import nuwa_oracle as O
@@ -71,23 +71,24 @@ def sweep(classes=('oq',), quick=False, models=None, log=print):
         with torch.no_grad():
             _, logits_r = O.decoder_loss(P, cfg, ids, ctx, mask, training=True, return_logits=True)
         nuwa = nuwa.to(DEV).train()
-        A.set_precision('bf16x3-fwd')
-        try:
-            for cls in classes:
-                KK.set_proj_f16x2(cls)
-                with torch.no_grad():
-                    h = nuwa.decode_hidden(nuwa.embed_video(ids.to(DEV)[:, :-1]), ctx.to(DEV), mask.to(DEV))
-                    lg = nuwa._final(h).float().cpu()
-                for s in range(ns):
-                    e = dict(model=name, sample=s, two_mfma=cls, rel_max=rel_err(lg[s], logits_r[s]), rel_l2=rel_l2(lg[s], logits_r[s]),
-                             logit_amax=float(logits_r[s].abs().max()), finite=bool(torch.isfinite(lg[s]).all()))
-                    if hasattr(KK, 'f16_sat_count'):
-                        e['f16_saturations'] = KK.f16_sat_count()
-                    out.append(e)
-                    log(f"{name:62s} sample {s}  two-MFMA '{cls}':  rel-max {e['rel_max']:.2e}  rel-l2 {e['rel_l2']:.2e}  |logit|max {e['logit_amax']:.1f}")
-        finally:
-            KK.set_proj_f16x2(os.environ.get('AMDNUWA_F16X2', KK.DEFAULT_F16X2))
-            A.set_precision('bf16')
+        for mode in modes:
+            A.set_precision(mode)
+            try:
+                for cls in (classes if mode == 'bf16x3-fwd' else ('',)):
+                    KK.set_proj_f16x2(cls)
+                    KK.f16_sat_count()
+                    with torch.no_grad():
+                        h = nuwa.decode_hidden(nuwa.embed_video(ids.to(DEV)[:, :-1]), ctx.to(DEV), mask.to(DEV))
+                        lg = nuwa._final(h).float().cpu()
+                    nsat = KK.f16_sat_count()
+                    for s in range(ns):
+                        e = dict(model=name, sample=s, mode=mode, two_mfma=cls, rel_max=rel_err(lg[s], logits_r[s]), rel_l2=rel_l2(lg[s], logits_r[s]),
+                                 logit_amax=float(logits_r[s].abs().max()), finite=bool(torch.isfinite(lg[s]).all()), f16_saturations=nsat)
+                        out.append(e)
+                        log(f"{name:62s} sample {s}  {mode:10s} two-MFMA '{cls}':  rel-max {e['rel_max']:.2e}  rel-l2 {e['rel_l2']:.2e}  |logit|max {e['logit_amax']:.1f}  fp16 saturations {nsat}")
+            finally:
+                KK.set_proj_f16x2(os.environ.get('AMDNUWA_F16X2', KK.DEFAULT_F16X2))
+                A.set_precision('bf16')
         del nuwa
         torch.cuda.empty_cache()
     return out
@@ -97,12 +98,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--classes', nargs='*', default=['', 'oq'])
     ap.add_argument('--quick', action='store_true')
+    ap.add_argument('--modes', nargs='*', default=['bf16x3-fwd'])
     a = ap.parse_args()
-    res = sweep(tuple(a.classes), a.quick)
+    res = sweep(tuple(a.classes), a.quick, modes=tuple(a.modes))
     for cls in a.classes:
-        w = max((e for e in res if e['two_mfma'] == cls), key=lambda e: e['rel_max'])
-        print(f"WORST two-MFMA '{cls}': rel-max {w['rel_max']:.2e} ({w['model']}, sample {w['sample']}); "
-              f"worst rel-l2 {max(e['rel_l2'] for e in res if e['two_mfma'] == cls):.2e}")
+        sel = [e for e in res if e['two_mfma'] == cls and e['mode'] == 'bf16x3-fwd']
+        if sel:
+            w = max(sel, key=lambda e: e['rel_max'])
+            print(f"WORST two-MFMA '{cls}': rel-max {w['rel_max']:.2e} ({w['model']}, sample {w['sample']}); worst rel-l2 {max(e['rel_l2'] for e in sel):.2e}")
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     with open(os.path.join(ROOT, 'gpurun_out', 'parity_sweep.json'), 'w') as f:
         json.dump(res, f, indent=1)
