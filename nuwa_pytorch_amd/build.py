@@ -54,7 +54,7 @@ EXTRA_FLAGS = {'xattn2.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 # AMDNUWA_LIBRARY=... then selects).  'pk' / 'pk_nofix': WITH packed fp32 ops (DEFAULT_FLAGS dropped); '*_nofix': the Sparse3DNA head-mix
 # loops written freely (S3_MIX_PIN=0) -- the experiment that separated the two cures of the round-4 defect.  The host pass ignores the flag.
 NOPK_FLAGS = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
-VARIANTS = {'': [], 'nopk': [], 'pk': [], 'pk_nofix': ['-DS3_MIX_PIN=0'], 'nopk_nofix': ['-DS3_MIX_PIN=0']}
+VARIANTS = {'': [], 'pk': [], 'pk_nofix': ['-DS3_MIX_PIN=0'], 'nofix': ['-DS3_MIX_PIN=0']}
 
 
 def lib_path(variant=''):

@@ -1544,43 +1544,52 @@ __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
             const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
             if (m >= p.M || nb >= p.N) continue;
             if ((p.dbg & 1) && acc[i][0][0] != 12345.678f) continue;
-            bf16_t h[16], l[16];
+            // the lane's 16 values as 8 packed pairs through the gfx950 converters (v_cvt_pk_bf16_f32: round-to-nearest-even, bit-identical
+            // to the integer form f2bf_hilo on finite values): hi pair, then EITHER the bf16 residual pair OR (lo_f16, wave-uniform) the fp16
+            // rendering -- the first form computed both for all 16 elements with ~20 integer instructions each, which under the build
+            // without packed fp32 ops pushed this epilogue 80 B per lane over its register budget
+            uint32_t hp[8], lp[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[i][j][r] * p.alpha + bias16[j * 4 + r];
-                    f2bf_hilo(v, h[j * 4 + r], l[j * 4 + r]);
-                    if (p.lo_f16) l[j * 4 + r] = f2h_sat(v);          // (wave-uniform) the second copy is the fp16 value, not the residual
-                }
+            for (int k = 0; k < 8; ++k) {
+                const int e0 = 2 * k, e1 = 2 * k + 1;
+                const float v0 = acc[i][e0 >> 2][e0 & 3] * p.alpha + bias16[e0], v1 = acc[i][e1 >> 2][e1 & 3] * p.alpha + bias16[e1];
+                hp[k] = pack2_rne(v0, v1);
+                lp[k] = p.lo_f16 ? pack2_f16_sat(v0, v1) : pack2_rne(v0 - lo_f(hp[k]), v1 - hi_f(hp[k]));
+            }
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
             bf16_t* Cl = p.Clo ? p.Clo + oC + m * p.ldc + nb : nullptr;
             if (vec8 && nb + 16 <= p.N) {
-                reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
-                reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2(h[8], h[9]), pack2(h[10], h[11]), pack2(h[12], h[13]), pack2(h[14], h[15]));
+                reinterpret_cast<uint4*>(C)[0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+                reinterpret_cast<uint4*>(C)[1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
                 if (Cl) {
-                    reinterpret_cast<uint4*>(Cl)[0] = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
-                    reinterpret_cast<uint4*>(Cl)[1] = make_uint4(pack2(l[8], l[9]), pack2(l[10], l[11]), pack2(l[12], l[13]), pack2(l[14], l[15]));
+                    reinterpret_cast<uint4*>(Cl)[0] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+                    reinterpret_cast<uint4*>(Cl)[1] = make_uint4(lp[4], lp[5], lp[6], lp[7]);
                 }
                 if (p.C2) {
                     // FF1 (np.py:274-277): the lane's 16 columns are 8 values and their 8 gates (interleaved-by-8 weight rows); the gate runs
                     // on the fp32 accumulators themselves and leaves as a hi + lo pair, the A operand of FF2.  u's own lo part is only
                     // written when the caller wants it (the bf16x3 backward); the bf16x3-fwd mode keeps u.hi for its bf16 backward.
-                    bf16_t gh[8], gl[8];
+                    uint32_t gh[4], gl[4];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float av = acc[i][e >> 2][e & 3] * p.alpha + bias16[e];
-                        const float gv = acc[i][2 + (e >> 2)][e & 3] * p.alpha + bias16[8 + e];
-                        f2bf_hilo(av * gelu_f(gv), gh[e], gl[e]);
+                    for (int k = 0; k < 4; ++k) {
+                        float o2[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const int e = 2 * k + t;
+                            const float av = acc[i][e >> 2][e & 3] * p.alpha + bias16[e];
+                            const float gv = acc[i][2 + (e >> 2)][e & 3] * p.alpha + bias16[8 + e];
+                            o2[t] = av * gelu_f(gv);
+                        }
+                        gh[k] = pack2_rne(o2[0], o2[1]);
+                        gl[k] = pack2_rne(o2[0] - lo_f(gh[k]), o2[1] - hi_f(gh[k]));
                     }
-                    *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) = make_uint4(pack2(gh[0], gh[1]), pack2(gh[2], gh[3]), pack2(gh[4], gh[5]), pack2(gh[6], gh[7]));
-                    if (p.C2lo)
-                        *reinterpret_cast<uint4*>(p.C2lo + m * p.ldc2 + (nb >> 1)) = make_uint4(pack2(gl[0], gl[1]), pack2(gl[2], gl[3]), pack2(gl[4], gl[5]), pack2(gl[6], gl[7]));
+                    *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + (nb >> 1)) = make_uint4(gh[0], gh[1], gh[2], gh[3]);
+                    if (p.C2lo) *reinterpret_cast<uint4*>(p.C2lo + m * p.ldc2 + (nb >> 1)) = make_uint4(gl[0], gl[1], gl[2], gl[3]);
                 }
             } else {
                 for (int e = 0; e < 16 && nb + e < p.N; ++e) {
-                    C[e] = h[e];
-                    if (Cl) Cl[e] = l[e];
+                    C[e] = (bf16_t)((e & 1) ? (hp[e >> 1] >> 16) : (hp[e >> 1] & 0xffffu));
+                    if (Cl) Cl[e] = (bf16_t)((e & 1) ? (lp[e >> 1] >> 16) : (lp[e >> 1] & 0xffffu));
                 }
             }
         }

@@ -115,7 +115,7 @@ def kernel_scratch(lib):
 # shows up here (CPU, seconds) instead of as a slower step on the GPU.  Round 5 lesson: two run-time branches added to the bf16 epilogue
 # cost gemm_nt_256p_kernel<1, true> 616 B of scratch per lane and the step 17 %, with every test green.
 SCRATCH_BOUNDS = [('gemm_nt_256p_kernel', 0), ('gemm_nt_256_kernel', 0), ('gemm_nt_w4k_kernel', 16), ('gemm_tn_w4k_kernel', 0), ('gemm_tn_256_kernel', 0),
-                  ('gemm_nt_256x3_kernel', 80), ('ln_post_pre_kernel', 0), ('ln_bwd_chain_kernel', 0), ('ln_fwd_kernel', 0), ('s3_fwd_tile_kernel', 0),
+                  ('gemm_nt_256x3_kernel', 0), ('ln_post_pre_kernel', 0), ('ln_bwd_chain_kernel', 0), ('ln_fwd_kernel', 0), ('s3_fwd_tile_kernel', 0),
                   ('s3_fwd_mfma_kernel', 0), ('s3_bwd_q_mfma_kernel', 60), ('s3_bwd_kv_mfma_kernel', 0), ('xattn4_fwd_kernel', 0), ('xattn3_bwd_kernel', 272),
                   ('ce_fwd_reg_kernel', 0), ('splitk_reduce_kernel', 0)]
 
