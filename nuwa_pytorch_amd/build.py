@@ -51,10 +51,11 @@ def _stale(target, deps):
 EXTRA_FLAGS = {'xattn2.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
 # Build variants (A/B runs of compiler options: `python -m nuwa_pytorch_amd.build --variant pk` writes lib_pk/libamdnuwa.so, which
-# AMDNUWA_LIBRARY=... then selects).  'pk' / 'pk_nofix': WITH packed fp32 ops (DEFAULT_FLAGS dropped); '*_nofix': the Sparse3DNA head-mix
-# loops written freely (S3_MIX_PIN=0) -- the experiment that separated the two cures of the round-4 defect.  The host pass ignores the flag.
+# AMDNUWA_LIBRARY=... then selects).  'pk' / 'pk_nofix': WITH packed fp32 ops (DEFAULT_FLAGS dropped), the Sparse3DNA head-mix loops pinned
+# (round 4's cure) / written freely (fails the stress: the experiment that separated the two cures); 'pin': the shipped flags + the pin.
+# The host pass ignores the feature flag.
 NOPK_FLAGS = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
-VARIANTS = {'': [], 'pk': [], 'pk_nofix': ['-DS3_MIX_PIN=0'], 'nofix': ['-DS3_MIX_PIN=0']}
+VARIANTS = {'': [], 'pk': ['-DS3_MIX_PIN=1'], 'pk_nofix': ['-DS3_MIX_PIN=0'], 'pin': ['-DS3_MIX_PIN=1']}
 
 
 def lib_path(variant=''):

@@ -867,11 +867,14 @@ __device__ __forceinline__ int s3m_item(int item, float rJ) { return item * S3M_
 // forms.  The mechanism inside the packed-FMA sequence is not understood; the one-row kernel and the backward's mix never failed the same
 // stress test but share the source pattern, so all three loops are written this way.  lds_store8_done: 8 consecutive floats -> LDS as two
 // 16-byte stores, completed before the caller goes on, nothing scheduled across.
-// S3_MIX_PIN (compile-time, default 1): 0 writes the three mix loops freely again (the compiler then forms packed FMAs unless the library is
-// built without the packed-fp32 target feature) -- only for the round-5 experiment that separates the two cures
-// (build variants 'pk_nofix' / 'nopk_nofix' in nuwa_pytorch_amd/build.py, tools/determinism_stress.py).
+// S3_MIX_PIN (compile-time): 1 pins every head's sum of the three mix loops in its own scalar FMA chain and completes the stores before going on
+// -- the round-4 cure, found empirically.  Round 5 separated the cures on the GPU (profiles/r05a_mix_variants.txt, r05e_stress_nofix.txt): with
+// packed fp32 ops ON and the loops written freely the stress fails (431 k differing elements in 8 runs at b = 16); with packed ops OFF and the
+// SAME free loops it is clean (b = 16 x 8 runs and b = 128 x 10 runs, every dilation, both operand forms).  The library ships without packed
+// fp32 ops (build.py DEFAULT_FLAGS, gated by tools/isa_lint.py), so the pin is no longer needed and costs 0.5 % of the step: default 0.
+// Build variant 'pin' (-DS3_MIX_PIN=1) keeps it for A/B runs.
 #ifndef S3_MIX_PIN
-#define S3_MIX_PIN 1
+#define S3_MIX_PIN 0
 #endif
 #if S3_MIX_PIN
 #define S3_MIX_PIN_ASM(s) asm volatile("" : "+v"(s))
