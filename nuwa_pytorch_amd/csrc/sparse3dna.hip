@@ -51,6 +51,7 @@ struct S3Args {
     int dbg;                                              // probe only (tuning key 9): bit 0 / 1 / 2 skip phase 1 / 2 / 3 of the MFMA forward
     int ymajor;                                           // MFMA kernels: workgroup order inside a sample is (y, f) instead of (f, y) (tuning key 3 bit 1 = old order)
     int sep_passes;                                       // MFMA query-side backward: the three separate item passes instead of the fused one (tuning key 19 = 1)
+    int packed;                                           // MFMA backward (round 5): the ds / P' workspace is ONE array of (bf16 ds | bf16 P') words at `pm`
 };
 
 constexpr float NEG_MAX = -3.4028234663852886e38f;
@@ -1701,10 +1702,12 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
                     const float4 w0 = *reinterpret_cast<const float4*>(wv + g * NH), w1 = *reinterpret_cast<const float4*>(wv + g * NH + 4);
                     const float wg[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
                     if (half == 0) {
-                        float sm = 0.f;
+                        if (!a.packed) {                   // (packed workspace: P' is mixed in the pack loop further down, next to ds)
+                            float sm = 0.f;
 #pragma unroll
-                        for (int hh = 0; hh < 8; ++hh) sm += wg[hh] * pv[hh];
-                        res[g] = sm;
+                            for (int hh = 0; hh < 8; ++hh) sm += wg[hh] * pv[hh];
+                            res[g] = sm;
+                        }
                     } else {
 #pragma unroll
                         for (int hh = 0; hh < 8; ++hh) res[hh] += wg[hh] * dv_[g];
@@ -1715,14 +1718,16 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
                     }
                 }
                 if (half == 0) {
-                    if (iq < a.ntok && !gst && !(a.dbg & 2)) {
-                        float4* dst = reinterpret_cast<float4*>(a.pm + (((size_t)b * nq + (iq - 1)) * J + j) * NH);
-                        dst[0] = make_float4(res[0], res[1], res[2], res[3]);
-                        dst[1] = make_float4(res[4], res[5], res[6], res[7]);
-                    }
-                    if (j == 0) {
+                    if (!a.packed) {
+                        if (iq < a.ntok && !gst && !(a.dbg & 2)) {
+                            float4* dst = reinterpret_cast<float4*>(a.pm + (((size_t)b * nq + (iq - 1)) * J + j) * NH);
+                            dst[0] = make_float4(res[0], res[1], res[2], res[3]);
+                            dst[1] = make_float4(res[4], res[5], res[6], res[7]);
+                        }
+                        if (j == 0) {
 #pragma unroll
-                        for (int g = 0; g < 8; ++g) PM0[wq * NH + g] = iq < a.ntok ? res[g] : 0.f;
+                            for (int g = 0; g < 8; ++g) PM0[wq * NH + g] = iq < a.ntok ? res[g] : 0.f;
+                        }
                     }
                 } else {
                     *reinterpret_cast<float4*>(DP + ib) = make_float4(res[0], res[1], res[2], res[3]);
@@ -1841,7 +1846,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
                     const int idx = w * TS + j * NH + h;
                     const float dsv = pv[k] * (dv[k] - d);
                     DP[idx] = dsv;
-                    if (i < a.ntok && !gst && !(a.dbg & 2)) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
+                    if (i < a.ntok && !gst && !a.packed && !(a.dbg & 2)) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
                 }
             }
         } else {
@@ -1853,11 +1858,44 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
             const int idx = w * TS + j * NH + h;
             const float dsv = SP[idx] * (DP[idx] - d);
             DP[idx] = dsv;
-            if (i < a.ntok && !gst) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
+            if (i < a.ntok && !gst && !a.packed) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
         }
         }
     }
-    __syncthreads();                                                              // P is dead: its region now holds the K tiles
+    __syncthreads();
+    // Packed workspace (round 5): ONE pass over the items writes (bf16 ds | bf16 P') words, 8 heads = two 16-byte stores per (query, slot) -- the
+    // fp32 form wrote P' as two 16-byte stores in the item pass above and ds as twelve scattered 4-byte stores per thread in the ds pass: 1.98 GB
+    // per call at b = 128, read back by the key side with two 4-byte loads per coefficient.  Same values as before: the key side rounded both to
+    // bf16 (round to nearest even) for its MFMA operands anyway, so dK / dV do not change by a bit.  P' is mixed here (the item pass skips it).
+    if (a.packed) {
+        const float* wv = wsh;
+        for (int item = t; item < W * J; item += blockDim.x) {
+            const int wq = (int)(((float)item + 0.5f) * rJ), j = item - wq * J;
+            const int iq = 1 + ry * W + wq;
+            const int ib = item * NH + wq * S3M_PAD;
+            const float4 p0 = *reinterpret_cast<const float4*>(SP + ib), p1 = *reinterpret_cast<const float4*>(SP + ib + 4);
+            const float4 s0 = *reinterpret_cast<const float4*>(DP + ib), s1 = *reinterpret_cast<const float4*>(DP + ib + 4);
+            const float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+            const float dsv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            uint32_t pw[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wv + g * NH), w1 = *reinterpret_cast<const float4*>(wv + g * NH + 4);
+                const float wg[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                float sm = 0.f;
+#pragma unroll
+                for (int hh = 0; hh < 8; ++hh) sm += wg[hh] * pv[hh];
+                if (j == 0) PM0[wq * NH + g] = iq < a.ntok ? sm : 0.f;
+                pw[g] = pack2_rne(dsv[g], sm);                                    // low half: ds[head g], high half: P'[head g]
+            }
+            if (iq < a.ntok && !gst && !(a.dbg & 2)) {
+                uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(a.pm) + (((size_t)b * nq + (iq - 1)) * J + j) * NH);
+                dst[0] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+                dst[1] = make_uint4(pw[4], pw[5], pw[6], pw[7]);
+            }
+        }
+        __syncthreads();                                                          // P is dead: its region now holds the K tiles
+    }
     {
         const int h = r.wave;
         f32x4 O[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -1900,6 +1938,9 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
 // where the (query, key) coefficient is the tap entry of the band (key = query - (kw-1-tc) dw), read from the fp32 workspace
 // the query-side kernel wrote.  The q / dO rows of two planes sit in two wave-private transposed tiles; no atomics, every key
 // pulls from the queries that attend to it.
+// PACKED: the workspace holds (bf16 ds | bf16 P') words (one 4-byte load per coefficient pair, the MFMA operands assembled with byte
+// permutes); else two fp32 arrays (two loads, two round-to-nearest conversions): the same operand bits either way.
+template <bool PACKED>
 __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1956,6 +1997,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
     }
     uint4 sq[4], sd[4];
     float cs[8], cp[8];                                                          // ds / P' coefficients of the 8 (plane, query) slots
+    uint32_t cw[8];                                                              // ... or (PACKED) their (bf16 ds | bf16 P') words
     auto fetch = [&](int pi) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1971,14 +2013,16 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float vs = 0.f, vp = 0.f;
+                uint32_t vw = 0u;
                 if (pj < nplanes && tsel[j] >= 0 && !(a.dbg & 16)) {
                     const int tok = ptok[pj] + 4 * g4 + j;
                     if (tok < a.ntok) {
                         const size_t ci = (((size_t)b * nq + (tok - 1)) * J + pslot[pj] + tsel[j]) * NH + h;
-                        vs = a.ds[ci]; vp = a.pm[ci];
+                        if constexpr (PACKED) vw = reinterpret_cast<const uint32_t*>(a.pm)[ci];
+                        else { vs = a.ds[ci]; vp = a.pm[ci]; }
                     }
                 }
-                cs[kb * 4 + j] = vs; cp[kb * 4 + j] = vp;
+                cs[kb * 4 + j] = vs; cp[kb * 4 + j] = vp; cw[kb * 4 + j] = vw;
             }
         }
     };
@@ -1992,10 +2036,17 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
             *reinterpret_cast<uint4*>(tq + woff[i]) = sq[i];
             *reinterpret_cast<uint4*>(td + woff[i]) = sd[i];
         }
-        const bf16x8 bs = __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(cs[0], cs[1]), pack2_rne(cs[2], cs[3]),
-                                                                 pack2_rne(cs[4], cs[5]), pack2_rne(cs[6], cs[7])));
-        const bf16x8 bp = __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(cp[0], cp[1]), pack2_rne(cp[2], cp[3]),
-                                                                 pack2_rne(cp[4], cp[5]), pack2_rne(cp[6], cp[7])));
+        bf16x8 bs, bp;
+        if constexpr (PACKED) {
+            // low halves -> the ds operand, high halves -> the P' operand (v_perm_b32 selectors: bytes 1,0 of each word / bytes 3,2)
+            bs = __builtin_bit_cast(bf16x8, make_uint4(__builtin_amdgcn_perm(cw[1], cw[0], 0x05040100u), __builtin_amdgcn_perm(cw[3], cw[2], 0x05040100u),
+                                                       __builtin_amdgcn_perm(cw[5], cw[4], 0x05040100u), __builtin_amdgcn_perm(cw[7], cw[6], 0x05040100u)));
+            bp = __builtin_bit_cast(bf16x8, make_uint4(__builtin_amdgcn_perm(cw[1], cw[0], 0x07060302u), __builtin_amdgcn_perm(cw[3], cw[2], 0x07060302u),
+                                                       __builtin_amdgcn_perm(cw[5], cw[4], 0x07060302u), __builtin_amdgcn_perm(cw[7], cw[6], 0x07060302u)));
+        } else {
+            bs = __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(cs[0], cs[1]), pack2_rne(cs[2], cs[3]), pack2_rne(cs[4], cs[5]), pack2_rne(cs[6], cs[7])));
+            bp = __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(cp[0], cp[1]), pack2_rne(cp[2], cp[3]), pack2_rne(cp[4], cp[5]), pack2_rne(cp[6], cp[7])));
+        }
         if (pi + 2 < nplanes) fetch(pi + 2);                                      // next chunk in flight during the MFMAs
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -2390,6 +2441,8 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
     // workgroup per CU).  Needs the MFMA query side; d(rel_bias) is a column sum of the ds workspace.
     const bool kv_rc = q_mfma && g_amdnuwa_tuning[4] == 4 && !g->d_rel_bias;
     a.stats = kv_rc ? a.ds : nullptr;                                              // (lives where the workspace would: B*nq*NH*4 floats <= B*nq*J*NH)
+    // packed (bf16 ds | bf16 P') workspace: MFMA query side + MFMA key side, no d(rel_bias) column sum over ds (tuning key 24 = 1: the fp32 pair)
+    a.packed = (q_mfma && g_amdnuwa_tuning[4] != 2 && !g->d_rel_bias && g_amdnuwa_tuning[24] != 1 && !a.sep_passes) ? 1 : 0;
     const size_t nspm = (size_t)g->W * (J * g->heads + 4);                          // the MFMA kernels' padded tables (s3m_ts)
     const size_t lds_qm = (nspm * 4 > 8 * 4096 ? nspm * 4 : 8 * 4096) + nspm * 4 + (8 * 64 + 16 * 8) * 4 + 8 * 2048;   // + the score staging tiles
 #define S3B(DH_, LO_)                                                                                             \
@@ -2408,9 +2461,12 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
         if (kv_rc) {                                                                                              \
             (void)hipFuncSetAttribute((const void*)s3_bwd_kv_rc_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 + 16384); \
             hipLaunchKernelGGL(s3_bwd_kv_rc_mfma_kernel, grid, dim3(512), 8 * 4096 + 16384, stream, a);           \
+        } else if (q_mfma && g_amdnuwa_tuning[4] != 2 && a.packed) {                                              \
+            (void)hipFuncSetAttribute((const void*)s3_bwd_kv_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192); \
+            hipLaunchKernelGGL(s3_bwd_kv_mfma_kernel<true>, grid, dim3(512), 8 * 8192, stream, a);                \
         } else if (q_mfma && g_amdnuwa_tuning[4] != 2) {                                                          \
-            (void)hipFuncSetAttribute((const void*)s3_bwd_kv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192); \
-            hipLaunchKernelGGL(s3_bwd_kv_mfma_kernel, grid, dim3(512), 8 * 8192, stream, a);                      \
+            (void)hipFuncSetAttribute((const void*)s3_bwd_kv_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192); \
+            hipLaunchKernelGGL(s3_bwd_kv_mfma_kernel<false>, grid, dim3(512), 8 * 8192, stream, a);               \
         } else {                                                                                                  \
             (void)hipFuncSetAttribute((const void*)s3_bwd_kv_kernel<DH_, LO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv); \
             hipLaunchKernelGGL((s3_bwd_kv_kernel<DH_, LO_>), grid, block, lds_kv, stream, a);                     \

@@ -495,6 +495,10 @@ __global__ __launch_bounds__(512) void xattn_bwd_kernel(XArgs a) {
 // One workgroup = (b, h, block of 64 keys): 16-byte loads of the 64 x DH tile, 16-byte stores of the row-major copies, the tile
 // through LDS for the transposes (8 consecutive keys of one channel per 16-byte store).  The first form of this kernel moved 2-byte
 // elements with a JP-strided scatter for Kt / Vt and ran at 1.1 TB/s of the 100 MB it touches.
+// Any image pointer may be NULL: the image is skipped (the fp16 forward + bf16 backward of the 'bf16x3-fwd' training step read four of the
+// eight: K [key][d] and V^T in fp16, K and V [key][d] in bf16 -- half of the 300 MB this kernel wrote per layer was never read).  LO: a
+// compile-time flag (the first form indexed its four register images with a run-time part count: 80 B of scratch per lane).
+template <bool LO>
 __global__ __launch_bounds__(256) void xattn_pack_kernel(const bf16_t* __restrict__ kv, const bf16_t* __restrict__ kvl, int ldkv,
                                                          const float* __restrict__ null_k, const float* __restrict__ null_v,
                                                          const uint8_t* __restrict__ mask, bf16_t* Kp, bf16_t* Kpl, bf16_t* Kt,
@@ -507,7 +511,8 @@ __global__ __launch_bounds__(256) void xattn_pack_kernel(const bf16_t* __restric
     if (h == 0 && blockIdx.y == 0)
         for (int j = threadIdx.x; j < JP; j += blockDim.x)
             valid[(size_t)b * JP + j] = j == 0 ? 1 : (j <= T ? (mask ? mask[(size_t)b * T + j - 1] : 1) : 0);
-    const int nparts = kvl ? 4 : 2, dchunks = DH / 8;
+    constexpr int nparts = LO ? 4 : 2;
+    const int dchunks = DH / 8;
     // load: (key, 8-channel chunk) per thread and part
     for (int e = threadIdx.x; e < 64 * dchunks; e += blockDim.x) {
         const int jl = e / dchunks, dc = (e % dchunks) * 8, j = j0 + jl;
@@ -527,14 +532,16 @@ __global__ __launch_bounds__(256) void xattn_pack_kernel(const bf16_t* __restric
             const size_t g = ((size_t)b * T + j - 1) * ldkv + h * DH + dc;
             r[0] = *reinterpret_cast<const uint4*>(kv + g);
             r[1] = *reinterpret_cast<const uint4*>(kv + g + inner);
-            if (kvl) { r[2] = *reinterpret_cast<const uint4*>(kvl + g); r[3] = *reinterpret_cast<const uint4*>(kvl + g + inner); }
+            if (LO) { r[2] = *reinterpret_cast<const uint4*>(kvl + g); r[3] = *reinterpret_cast<const uint4*>(kvl + g + inner); }
         }
         if (j < JP) {
             const size_t o1 = ((size_t)bh * JP + j) * DH + dc;
-            *reinterpret_cast<uint4*>(Kp + o1) = r[0];
-            *reinterpret_cast<uint4*>(Vp + o1) = r[1];
-            if (Kpl) { *reinterpret_cast<uint4*>(Kpl + o1) = r[2]; *reinterpret_cast<uint4*>(Vpl + o1) = r[3]; }
+            if (Kp) *reinterpret_cast<uint4*>(Kp + o1) = r[0];
+            if (Vp) *reinterpret_cast<uint4*>(Vp + o1) = r[1];
+            if (LO && Kpl) *reinterpret_cast<uint4*>(Kpl + o1) = r[2];
+            if (LO && Vpl) *reinterpret_cast<uint4*>(Vpl + o1) = r[3];
         }
+#pragma unroll
         for (int pt = 0; pt < nparts; ++pt) *reinterpret_cast<uint4*>(&tile[pt][jl][dc]) = r[pt];
     }
     __syncthreads();
@@ -543,11 +550,13 @@ __global__ __launch_bounds__(256) void xattn_pack_kernel(const bf16_t* __restric
         const int d = e / 8, jc = (e % 8) * 8, j = j0 + jc;
         if (j >= JP) continue;                      // (JP is a multiple of 32: whole chunks)
         const size_t o2 = ((size_t)bh * DH + d) * JP + j;
+#pragma unroll
         for (int pt = 0; pt < nparts; ++pt) {
+            bf16_t* dst = pt == 0 ? Kt : (pt == 1 ? Vt : (pt == 2 ? Ktl : Vtl));
+            if (!dst) continue;
             bf16_t t8[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) t8[t] = tile[pt][jc + t][d];
-            bf16_t* dst = pt == 0 ? Kt : (pt == 1 ? Vt : (pt == 2 ? Ktl : Vtl));
             *reinterpret_cast<uint4*>(dst + o2) = make_uint4(pack2(t8[0], t8[1]), pack2(t8[2], t8[3]), pack2(t8[4], t8[5]), pack2(t8[6], t8[7]));
         }
     }
@@ -660,12 +669,18 @@ static int xattn_pack_impl(const amdnuwa_xattn_geom* g, const uint16_t* kv, cons
                            const float* null_v, const uint8_t* context_mask, const amdnuwa_xattn_kv* p, int lo_f16, hipStream_t stream) {
     int rc = check(g);
     if (rc) return rc;
-    if (!kv || !null_k || !null_v || !p || !p->Kp || !p->Kt || !p->Vp || !p->Vt || !p->valid || ldkv % 8) return AMDNUWA_ERR_ARG;
-    if (kv_lo && (!p->Kp_lo || !p->Kt_lo || !p->Vp_lo || !p->Vt_lo)) return AMDNUWA_ERR_ARG;
+    // (every image is optional -- a NULL pointer skips it -- but something must be asked for)
+    if (!kv || !null_k || !null_v || !p || !p->valid || ldkv % 8) return AMDNUWA_ERR_ARG;
+    if (!p->Kp && !p->Kt && !p->Vp && !p->Vt && !p->Kp_lo && !p->Kt_lo && !p->Vp_lo && !p->Vt_lo) return AMDNUWA_ERR_ARG;
+    if (!kv_lo && (p->Kp_lo || p->Kt_lo || p->Vp_lo || p->Vt_lo)) return AMDNUWA_ERR_ARG;
     if (g->B <= 0) return AMDNUWA_OK;
-    hipLaunchKernelGGL(xattn_pack_kernel, dim3(g->B * g->heads, (g->JP + 63) / 64), dim3(256), 0, stream, kv, kv_lo, ldkv, null_k, null_v, context_mask,
-                       p->Kp, kv_lo ? p->Kp_lo : nullptr, p->Kt, kv_lo ? p->Kt_lo : nullptr, p->Vp, kv_lo ? p->Vp_lo : nullptr,
-                       p->Vt, kv_lo ? p->Vt_lo : nullptr, p->valid, g->B, g->T, g->heads, g->dim_head, g->JP, lo_f16);
+    const dim3 grid(g->B * g->heads, (g->JP + 63) / 64);
+    if (kv_lo)
+        hipLaunchKernelGGL(xattn_pack_kernel<true>, grid, dim3(256), 0, stream, kv, kv_lo, ldkv, null_k, null_v, context_mask, p->Kp, p->Kp_lo, p->Kt,
+                           p->Kt_lo, p->Vp, p->Vp_lo, p->Vt, p->Vt_lo, p->valid, g->B, g->T, g->heads, g->dim_head, g->JP, lo_f16);
+    else
+        hipLaunchKernelGGL(xattn_pack_kernel<false>, grid, dim3(256), 0, stream, kv, kv_lo, ldkv, null_k, null_v, context_mask, p->Kp, (bf16_t*)nullptr, p->Kt,
+                           (bf16_t*)nullptr, p->Vp, (bf16_t*)nullptr, p->Vt, (bf16_t*)nullptr, p->valid, g->B, g->T, g->heads, g->dim_head, g->JP, lo_f16);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

@@ -1056,11 +1056,18 @@ def x_geom(B, n, T, heads, dim_head):
 class PackedKV:
     """per-(sample, head) key/value images for the cross-attention kernels"""
 
-    def __init__(self, g, device, lo):
+    def __init__(self, g, device, lo, lean=False):
+        """lean (fp16 lo images only): just the four images the fp16 forward core (K [key][d] and V^T in fp16) and the bf16 backward (K and V
+        [key][d] in bf16) of the 'bf16x3-fwd' training step read; the other four are neither allocated nor written"""
         sh1 = (g.B, g.heads, g.JP, g.dim_head)
         sh2 = (g.B, g.heads, g.dim_head, g.JP)
         mk = lambda s: empty_bf(s, device, lo=lo)
-        self.Kp, self.Vp, self.Kt, self.Vt = mk(sh1), mk(sh1), mk(sh2), mk(sh2)
+        if lean:
+            e16 = lambda s: torch.empty(s, dtype=torch.bfloat16, device=device)
+            self.Kp, self.Vp = BF(e16(sh1), e16(sh1)), BF(e16(sh1), None)
+            self.Kt, self.Vt = BF(None, None), BF(None, e16(sh2))
+        else:
+            self.Kp, self.Vp, self.Kt, self.Vt = mk(sh1), mk(sh1), mk(sh2), mk(sh2)
         self.valid = torch.empty((g.B, g.JP), dtype=torch.uint8, device=device)
         s = XKV()
         s.Kp, s.Kp_lo, s.Kt, s.Kt_lo = _p(self.Kp.hi), _p(self.Kp.lo), _p(self.Kt.hi), _p(self.Kt.lo)
@@ -1071,13 +1078,13 @@ class PackedKV:
 
     def drop_lo(self):
         """release the lo images (mixed mode: the bf16 backward reads the hi images only)"""
-        self.Kp, self.Vp, self.Kt, self.Vt = (hi_only(t) for t in (self.Kp, self.Vp, self.Kt, self.Vt))
+        self.Kp, self.Vp, self.Kt, self.Vt = (BF(t.hi, None) for t in (self.Kp, self.Vp, self.Kt, self.Vt))
         s = self.struct
         s.Kp_lo = s.Kt_lo = s.Vp_lo = s.Vt_lo = None
         return self
 
 
-def xattn_pack(g, kv, null_k, null_v, mask_u8, out=None):
+def xattn_pack(g, kv, null_k, null_v, mask_u8, out=None, lean=False):
     """kv with an f16 copy: the lo images of the result are FP16 images (for xattn2_fwd_f16), not bf16 residuals.
     out: a PackedKV of the same geometry / operand form to pack INTO (a captured HIP graph keeps reading the same buffers)"""
     L = _lib.lib()
@@ -1087,7 +1094,7 @@ def xattn_pack(g, kv, null_k, null_v, mask_u8, out=None):
                                    C.byref(out.struct), _stream()), 'amdnuwa_xattn_pack')
         return out
     if kv.f16 is not None:
-        pk = PackedKV(g, kv.hi.device, True)
+        pk = PackedKV(g, kv.hi.device, True, lean=lean)
         check(L.amdnuwa_xattn_pack_f16(C.byref(g), _p(kv.hi), _p(kv.f16), kv.hi.stride(0), _p(null_k), _p(null_v), _p(mask_u8),
                                        C.byref(pk.struct), _stream()), 'amdnuwa_xattn_pack_f16')
         pk.f16 = True

@@ -282,7 +282,7 @@ class XInner:
             q = _rotary_bf(q, rot, g.B, g.n, g.heads)
             kv = _rotary_bf(kv, rot, g.B, g.T, 2 * g.heads)
         pk = K.xattn_pack(g, kv, nk.detach().reshape(g.heads, g.dim_head).contiguous(),
-                          nv.detach().reshape(g.heads, g.dim_head).contiguous(), meta['mask_u8'])
+                          nv.detach().reshape(g.heads, g.dim_head).contiguous(), meta['mask_u8'], lean=f16 and not K.xattn2_bwd_rc_ok(g))
         wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
         o16 = False
         if f16:                               # 'bf16x3-fwd': the xattn4 core on single fp16 MFMAs, hi + lo output, statistics for the bf16 backward

@@ -1408,3 +1408,29 @@ def test_attention_cores_at_batch_16_equal_their_one_sample_results(K):
         pkb1 = K.xattn_pack(gx1, K.BF(kv1.hi, None), nk, nv, mask[s:s + 1].contiguous())
         dq1, dS1, Pm1, _ = K.xattn2_bwd(gx1, K.BF(q1.hi, None), K.BF(dO[rows].contiguous(), None), pkb1, wth, st1)
         assert torch.equal(dq.hi[rows], dq1.hi) and torch.equal(dS.hi[s], dS1.hi[0]) and torch.equal(Pm.hi[s], Pm1.hi[0]), f'cross attention backward, sample {s}'
+
+
+@pytest.mark.parametrize('dil', [1, 2, 4])
+def test_sparse3dna_bwd_packed_workspace_equals_the_fp32_workspace(K, dil):
+    """round 5: the MFMA backward hands ds / P' from the query side to the key side as ONE array of (bf16 ds | bf16 P') words instead of two
+    fp32 arrays.  The key side rounded both to bf16 for its MFMA operands anyway: dq, dk, dv and dW_th must not change by a bit
+    (tuning key 24 = 1 selects the fp32 pair); partial last rows included (n = 2000)."""
+    from nuwa_pytorch_amd import _lib
+    L = _lib.lib()
+    heads, dh, B = 8, 64, 3
+    inner = heads * dh
+    torch.manual_seed(dil)
+    wth = (torch.randn(heads, heads) * 0.5 + torch.eye(heads)).to(DEV)
+    for n in (2560, 2000):
+        qkv = K.BF(torch.randn(B * n, 3 * inner, device=DEV).to(torch.bfloat16), None)
+        dO = K.BF(torch.randn(B * n, inner, device=DEV).to(torch.bfloat16), None)
+        g = K.s3_geom(B, n, (10, 16, 16), (5, 3, 3), (dil, dil, dil), heads, dh)
+        try:
+            L.amdnuwa_set_tuning(24, 1)
+            d_ref, w_ref, _ = K.sparse3dna_bwd(g, qkv, wth, dO)
+            L.amdnuwa_set_tuning(24, 0)
+            d_new, w_new, _ = K.sparse3dna_bwd(g, qkv, wth, dO)
+        finally:
+            L.amdnuwa_set_tuning(24, 0)
+        assert torch.equal(d_ref.hi, d_new.hi), f'dqkv differs (dilation {dil}, n = {n})'
+        assert torch.equal(w_ref, w_new), f'dW_th differs (dilation {dil}, n = {n})'
