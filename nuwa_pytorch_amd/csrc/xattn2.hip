@@ -49,6 +49,7 @@ struct X2Args {
     bf16_t* dq; int lddq;
     float* part_th;                          // [grid][NH*NH]
     int B, n, JP, nch;
+    int T;                                   // context keys (the null key is key 0, keys 1..T the context, the rest of JP padding)
     float scale;
     int nostore;                             // the backward skips its dS / Pm stores (the recomputing key side below replaces them;
                                              // also the probe of tuning key 10 bit 4)
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
             f32x4 D[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) D[e] = MIX(AW, Q, pack_heads(P, e));
-            if (qok && !a.nostore) {
+            if (qok && !a.nostore && 32 * ch + 4 * g4 <= a.T) {     // (a lane group whose 8 keys are all padding -- 3 of the 4 groups of the last chunk at T = 256 -- writes nothing: the TN GEMMs stop at the last group that holds a key)
 #pragma unroll
                 for (int rp = 0; rp < 4; ++rp) {
                     bf16_t* dst = a.Pm + ((size_t)b * NH + 4 * Q + rp) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 8;   // (chunk-permuted key order)
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
                 for (int e = 0; e < 8; ++e) ds[e] = P[e] * (D[e][rp] - delta[h]);
                 const uint2 lo = make_uint2(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]));
                 const uint2 hi = make_uint2(pack2_rne(ds[4], ds[5]), pack2_rne(ds[6], ds[7]));
-                if (qok && !a.nostore) {
+                if (qok && !a.nostore && 32 * ch + 4 * g4 <= a.T) {
                     bf16_t* dst = a.dS + ((size_t)b * NH + h) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 8;  // (chunk-permuted key order)
                     *reinterpret_cast<uint4*>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 }
@@ -1277,7 +1278,7 @@ extern "C" int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     X2Args a{};
     a.q = q; a.ldq = ldq; a.Kp = p->Kp; a.Vp = p->Vp; a.Vt = p->Vt; a.valid = p->valid; a.wth = w_th;
     a.o = o; a.ldo = ldo; a.stats = stats;
-    a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
+    a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.T = g->T; a.scale = g->scale;
     a.dbg = g_amdnuwa_tuning[18];
     const int tiles = (g->n + 63) / 64;
     // tuning key 10: 0 = xattn4 (two waves per query tile, 4 heads each, two waves per SIMD), 2 = xattn3 (one wave, head mix on the
@@ -1305,7 +1306,7 @@ extern "C" int amdnuwa_xattn2_fwd_f16(const amdnuwa_xattn_geom* g, const uint16_
     X2Args a{};
     a.q = q_f16; a.ldq = ldq; a.Kp = p->Kp_lo; a.Vp = p->Vp_lo; a.Vt = p->Vt_lo; a.valid = p->valid; a.wth = w_th;    // the fp16 images
     a.o = o; a.ol = o_lo; a.ldo = ldo; a.stats = stats; a.ol_f16 = (o_lo && o_lo_f16) ? 1 : 0;
-    a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
+    a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.T = g->T; a.scale = g->scale;
     a.dbg = g_amdnuwa_tuning[18];
     const int tiles = (g->n + 63) / 64;
     const int lds4 = 2 * STAGE + 8 * XCH;
@@ -1332,7 +1333,7 @@ extern "C" int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     X2Args a{};
     a.q = q; a.ldq = ldq; a.dO = dO; a.lddo = lddo; a.Kp = p->Kp; a.Vp = p->Vp; a.Vt = p->Vt; a.valid = p->valid; a.wth = w_th;
     a.stats = const_cast<float*>(stats); a.dS = dS; a.Pm = Pm; a.dq = dq; a.lddq = lddq; a.part_th = part_th;
-    a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
+    a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.T = g->T; a.scale = g->scale;
     const int tiles = (g->n + 63) / 64;
     a.nostore = (g_amdnuwa_tuning[10] & 16) ? 1 : 0;
     a.dbg = g_amdnuwa_tuning[18];
@@ -1361,7 +1362,7 @@ extern "C" int amdnuwa_xattn2_bwd_rc(const amdnuwa_xattn_geom* g, const uint16_t
     X2Args a{};
     a.q = q; a.ldq = ldq; a.dO = dO; a.lddo = lddo; a.Kp = p->Kp; a.Vp = p->Vp; a.Vt = p->Vt; a.valid = p->valid; a.wth = w_th;
     a.stats = const_cast<float*>(stats); a.dq = dq; a.lddq = lddq; a.part_th = part_th;
-    a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.scale = g->scale;
+    a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.T = g->T; a.scale = g->scale;
     a.nostore = 1; a.nbd = nbd; a.dKp = dKp; a.dVp = dVp; a.flags = (g_amdnuwa_tuning[10] & 32) ? 1 : 0;
     (void)hipFuncSetAttribute((const void*)xattn3_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
     hipLaunchKernelGGL(xattn3_bwd_kernel, dim3(g->B * ((g->n + 63) / 64)), dim3(256), 2 * STAGE, stream, a);

@@ -1191,7 +1191,16 @@ def xattn2_bwd(g, q, dO, pk, wth, stats):
     check(L.amdnuwa_xattn2_bwd(C.byref(g), _p(q.hi), q.hi.stride(0), _p(dO.hi), dO.hi.stride(0), C.byref(pk.struct), _p(wth),
                                _p(stats), _p(dS.hi), _p(Pm.hi), _p(dq.hi), inner, _p(part), nb, _stream()), 'amdnuwa_xattn2_bwd')
     dwth = colsum(part).reshape(g.heads, g.heads)          # fixed-order reduction over the workgroups
-    return dq, dS, Pm, dwth
+    # lane groups of the last chunk whose 8 keys are all padding write nothing: hand out the columns that exist (views: the row pitch stays JP)
+    mx = xattn_permuted_extent(g)
+    return dq, BF(dS.hi[..., :mx], None), BF(Pm.hi[..., :mx], None), dwth
+
+
+def xattn_permuted_extent(g):
+    """columns of the chunk-permuted dS / Pm arrays (rows of dKp / dVp) that hold a key: the kernel's lane group g4 of chunk ch owns keys
+    32 ch + {4 g4 .. 4 g4 + 3, 16 + 4 g4 .. 16 + 4 g4 + 3} at positions 32 ch + 8 g4 .. + 7, and key T is the last one"""
+    ch, kk = g.T // 32, g.T % 32
+    return 32 * ch + 8 * (min(kk // 4, 3) + 1)
 
 
 _XATTN_RC = os.environ.get('AMDNUWA_XATTN_RC', '0') == '1'
@@ -1229,8 +1238,9 @@ def xattn2_bwd_rc(g, q, dO, pk, wth, stats):
 
 def xattn_kv_grads(g, dS, Pm, q, dO):
     """dKp = scale * dS^T q, dVp = Pm^T dO per (sample, head): two batched TN GEMMs (reduction over queries).
-    returns fp32 [B, h, JP, dh] x 2"""
+    returns fp32 [B, h, JP, dh] x 2 (rows past the last column of dS / Pm -- padding keys -- are not written)"""
     dev = q.hi.device
+    Mx = dS.hi.shape[-1]                       # (xattn2_bwd hands out only the columns that hold a key)
     dKp = torch.empty((g.B, g.heads, g.JP, g.dim_head), dtype=torch.float32, device=dev)
     dVp = torch.empty_like(dKp)
     for (A, Bm, out, alpha) in ((dS, q, dKp, g.scale), (Pm, dO, dVp, 1.0)):
@@ -1241,7 +1251,7 @@ def xattn_kv_grads(g, dS, Pm, q, dO):
         d.strideB, d.strideB_inner = g.n * Bm.hi.stride(0), g.dim_head
         d.C, d.ldc, d.strideC, d.c_is_bf16 = _p(out), g.dim_head, g.JP * g.dim_head, 0
         d.alpha, d.beta = float(alpha), 0.0
-        d.M, d.N, d.K = g.JP, g.dim_head, g.n
+        d.M, d.N, d.K = Mx, g.dim_head, g.n
         d.batch, d.batch_inner = g.B * g.heads, g.heads
         d.strideA_inner = g.n * g.JP            # A / C are dense over (b, h): inner stride = one head
         d.strideA = g.heads * g.n * g.JP

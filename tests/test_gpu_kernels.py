@@ -681,9 +681,10 @@ def test_cross_attention_core(K, O, case, x3):
         report('xattn2_dq' + tag, dq2.hi.float().reshape(B, n, heads, dh), q.grad, 2 ** -6)
         report('xattn2_dwth' + tag, dwth2, wth.grad, 2 ** -6)
         # (xattn2_bwd writes the columns of dS / Pm in its chunk-permuted key order: undone here, and by xattn_unpack below)
-        pos = K.xattn_key_positions(g.JP, DEV)
-        report('xattn2_Pm' + tag, Pm2.hi.float().index_select(-1, pos), Pm.hi.float(), 2 ** -6)
-        report('xattn2_dS' + tag, dS2.hi.float().index_select(-1, pos), dS.hi.float(), 2 ** -5)
+        # (... and only the columns up to the last lane group that holds a key exist: compare the keys 0 .. T)
+        pos = K.xattn_key_positions(g.JP, DEV)[:T + 1]
+        report('xattn2_Pm' + tag, Pm2.hi.float().index_select(-1, pos), Pm.hi.float()[..., :T + 1], 2 ** -6)
+        report('xattn2_dS' + tag, dS2.hi.float().index_select(-1, pos), dS.hi.float()[..., :T + 1], 2 ** -5)
         dKp2, dVp2 = K.xattn_kv_grads(g, dS2, Pm2, qp, dop)
         dkv2, dnk2, dnv2 = K.xattn_unpack(g, dKp2, dVp2, lo=False, permuted=True)
         report('xattn2_dkv' + tag, dkv2.hi.float().reshape(B, T, 2, heads, dh), kv.grad, 2 ** -6)
@@ -822,9 +823,9 @@ def test_cross_attention_bwd_recomputing_key_side(K, O, B, n, T):
     dq, dKp, dVp, dwth = K.xattn2_bwd_rc(g, qp, dop, pk, w, stats)
     tag = f'[{B},{n},{T}]'
     assert torch.equal(dq.hi, dq0.hi) and torch.equal(dwth, dwth0), 'the query side is the same kernel'
-    pos = K.xattn_key_positions(g.JP, DEV)                        # (the TN form's rows follow xattn2_bwd's chunk-permuted key order)
-    report('xattn_rc_dKp_vs_tn' + tag, dKp, dKp0.index_select(2, pos), 2e-3)           # same bf16 operands, another summation order
-    report('xattn_rc_dVp_vs_tn' + tag, dVp, dVp0.index_select(2, pos), 2e-3)
+    pos = K.xattn_key_positions(g.JP, DEV)[:T + 1]                # (the TN form's rows follow xattn2_bwd's chunk-permuted key order; rows of padding keys are not written)
+    report('xattn_rc_dKp_vs_tn' + tag, dKp[:, :, :T + 1], dKp0.index_select(2, pos), 2e-3)           # same bf16 operands, another summation order
+    report('xattn_rc_dVp_vs_tn' + tag, dVp[:, :, :T + 1], dVp0.index_select(2, pos), 2e-3)
     dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=False)
     report('xattn_rc_dkv' + tag, dkv.hi.float().reshape(B, T, 2, heads, dh), kv.grad, 2 ** -6)
     report('xattn_rc_dnull_k' + tag, dnk, nk.grad, 2 ** -6)
