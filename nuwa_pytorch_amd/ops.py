@@ -639,7 +639,9 @@ class SandwichBlockFn(Function):
         want16 = (meta['kind'] == 'ff' and FFInner.f16_ok(B * n, D, _ru(p[1].shape[1], 32), (p[0], p[1]))) or \
                  (meta['kind'] == 's3' and S3Inner.f16_proj_ok(B * n, D, p[0].shape[0], meta['geom'], (p[0], p[1]))) or \
                  (meta['kind'] == 'xattn' and XInner.f16x2_ok(B * n, D, p[3].shape[0], meta['xgeom'], meta, (p[3], p[5])))
-        bw16 = bool(want16) and _block_bwd16(meta['kind'], B * n, D, p, meta)
+        # (blocks of a reversible stack -- a separate residual input -- keep the bf16 backward: they are not chained, so every one of them would
+        #  take its own gradient scale: one amax pass per block, -2.7 % on cfg 4)
+        bw16 = bool(want16) and resid is None and _block_bwd16(meta['kind'], B * n, D, p, meta)
         if hin is not None and hin.get('ptr') == x.data_ptr() and hin.get('ver') == x._version and hin.get('shift') == sh \
                 and resid is None and K.bf_rows_cols(hin['h'])[:2] == (B * n, D) and (hin['h'].hi is not None or bw16):
             h, m1, r1 = hin['h'], hin['m1'], hin['r1']

@@ -72,3 +72,18 @@ def test_integration_stub_names_the_current_abi_and_real_symbols():
     assert m and int(m.group(1)) == _lib.ABI_VERSION
     called = set(re.findall(r'_L\.(amdnuwa_\w+)', text))
     assert called and called <= set(_lib.SIGNATURES) | {'amdnuwa_abi_version', 'amdnuwa_error_string'}, called - set(_lib.SIGNATURES)
+
+
+def test_profiles_readme_lists_only_files_that_exist():
+    """round-4 review: profiles/README.md listed seven files that were gone.  Every file named in the first column of its tables must exist."""
+    import re
+    pdir = os.path.join(ROOT, 'profiles')
+    have = set(os.listdir(pdir))
+    missing = []
+    for line in open(os.path.join(pdir, 'README.md')):
+        if not line.startswith('| `'):
+            continue
+        for name in re.findall(r'`([^`]+)`', line.split('|')[1]):
+            if '*' not in name and name not in have:
+                missing.append(name)
+    assert not missing, missing

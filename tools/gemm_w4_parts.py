@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """What bounds the 4-wave NT main loop (tuning key 0 = 9)?  Same launch with parts switched off through tuning key 7 (results are
-garbage then): bit 0 stores, bit 2 MFMAs, bit 3 LDS fragment reads, bit 4 the in-loop DMA pieces, bit 5 = the DMA pieces as buffer_load ... lds."""
+garbage then): bit 0 stores, bit 2 MFMAs, bit 3 LDS fragment reads, bit 4 the in-loop DMA pieces."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -35,21 +35,31 @@ def main():
         if not (k.startswith(('gemm_', 's3_', 'xattn', 'ln_', 'geglu', 'conv2d', 'vq_', 'groupnorm', 'embed', 'ce_', 'partial', 'splitk', 'cast', 'transpose', 'colsum'))):
             continue
         print(f'{k:56s} {n:8d} ' + ' '.join(f'{(agg[k][c][1] / agg[k][c][0]) if c in agg[k] else float("nan"):22.1f}' for c in counters))
-    if all(c in counters for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES')):
-        # MFMA-busy fraction per family.  Normalisation (checked against the round-2 passes: NT GEMMs 0.26 next to 0.26 of the MFMA peak in
-        # algorithmic FLOP/s, cross-attention backward 0.12): SQ_VALU_MFMA_BUSY_CYCLES is summed over the 256 CUs, SQ_BUSY_CYCLES over 64 SQ
-        # instances, so busy fraction of one CU's matrix pipe = MFMA_BUSY / 256 / (SQ_BUSY / 64) = MFMA_BUSY / (4 SQ_BUSY).
-        print()
-        print(f'{"kernel family":56s} {"launches":>8s} {"MFMA busy fraction":>20s} {"HBM GB per launch (2 FETCH + WRITE)":>36s}')
-        for k in keys:
-            a = agg[k]
-            if 'SQ_VALU_MFMA_BUSY_CYCLES' not in a or 'SQ_BUSY_CYCLES' not in a or not k.startswith(('gemm_', 's3_', 'xattn', 'ln_', 'ce_', 'splitk', 'embed')):
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in counters:
+        # MFMA-busy fraction per family = sum of SQ_VALU_MFMA_BUSY_CYCLES (cycles of matrix-pipe occupancy, summed over every SIMD of the chip: 16 per
+        # v_mfma_f32_16x16x32) / (1024 SIMDs x kernel duration x 2.4 GHz), i.e. against the clock the 2.5 PFLOP/s peak is quoted at; durations
+        # from the kernel trace of the SAME counter pass (pmc_kernel_trace.csv next to the counter CSV, joined on Dispatch_Id).
+        import os
+        busy, dur = defaultdict(float), defaultdict(float)
+        nlaunch = defaultdict(int)
+        for f in files:
+            kt = os.path.join(os.path.dirname(f), 'pmc_kernel_trace.csv')
+            rows = [r for r in csv.DictReader(open(f, newline='')) if r['Counter_Name'] == 'SQ_VALU_MFMA_BUSY_CYCLES']
+            if not rows or not os.path.exists(kt):
                 continue
-            mf, sb = a['SQ_VALU_MFMA_BUSY_CYCLES'][1] / a['SQ_VALU_MFMA_BUSY_CYCLES'][0], a['SQ_BUSY_CYCLES'][1] / a['SQ_BUSY_CYCLES'][0]
-            gb = ''
-            if 'FETCH_SIZE' in a and 'WRITE_SIZE' in a:
-                gb = f"{(2 * a['FETCH_SIZE'][1] / a['FETCH_SIZE'][0] + a['WRITE_SIZE'][1] / a['WRITE_SIZE'][0]) * 1024 / 1e9:.3f}"
-            print(f'{k:56s} {max(v[0] for v in a.values()):8d} {mf / (4 * sb) if sb else float("nan"):20.3f} {gb:>36s}')
+            d = {r['Dispatch_Id']: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9 for r in csv.DictReader(open(kt, newline=''))}
+            seen = set()
+            for r in rows:
+                k = fam(r['Kernel_Name'])
+                busy[k] += float(r['Counter_Value'])
+                if r['Dispatch_Id'] not in seen and r['Dispatch_Id'] in d:
+                    seen.add(r['Dispatch_Id']); dur[k] += d[r['Dispatch_Id']]; nlaunch[k] += 1
+        if dur:
+            print()
+            print(f'{"kernel family":56s} {"launches":>8s} {"avg us (counter pass)":>22s} {"MFMA-busy fraction of the 2.4 GHz peak":>40s}')
+            for k in sorted(dur, key=lambda x: -dur[x]):
+                if busy[k] > 0:
+                    print(f'{k:56s} {nlaunch[k]:8d} {dur[k] / nlaunch[k] * 1e6:22.1f} {busy[k] / (1024 * dur[k] * 2.4e9):40.3f}')
     if '--json' in sys.argv:
         out, key = sys.argv[sys.argv.index('--json') + 1], sys.argv[sys.argv.index('--key') + 1]
         nt = [k for k in agg if k.startswith('gemm_nt_')]
