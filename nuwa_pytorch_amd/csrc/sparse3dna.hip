@@ -1869,9 +1869,20 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
     // bf16 (round to nearest even) for its MFMA operands anyway, so dK / dV do not change by a bit.  P' is mixed here (the item pass skips it).
     if (a.packed) {
         const float* wv = wsh;
+        // entries the key side never reads are not written: slots of planes that lie before the grid for this row (ta < ta0 or tb < tb0, as in
+        // rowm_planes: 78 % of the slots at dilation 4) and taps whose key column would be negative.  The key side walks the attending query
+        // rows of every key that EXISTS, so it only ever asks for the entries kept here.
+        const int ta0 = max(0, a.kf - 1 - f / a.df), tb0 = max(0, a.kh - 1 - y / a.dh);
+        const float rkw = 1.f / (float)a.kw, rkh = 1.f / (float)a.kh;
         for (int item = t; item < W * J; item += blockDim.x) {
             const int wq = (int)(((float)item + 0.5f) * rJ), j = item - wq * J;
             const int iq = 1 + ry * W + wq;
+            bool keep = false;                                                    // (slot 0, <bos>: its dk / dv come from this kernel's own partials, never from the workspace)
+            if (j > 0) {
+                const int pl = (int)(((float)(j - 1) + 0.5f) * rkw), tc = j - 1 - pl * a.kw;
+                const int ta = (int)(((float)pl + 0.5f) * rkh), tb = pl - ta * a.kh;
+                keep = ta >= ta0 && tb >= tb0 && wq - (a.kw - 1 - tc) * a.dw >= 0;
+            }
             const int ib = item * NH + wq * S3M_PAD;
             const float4 p0 = *reinterpret_cast<const float4*>(SP + ib), p1 = *reinterpret_cast<const float4*>(SP + ib + 4);
             const float4 s0 = *reinterpret_cast<const float4*>(DP + ib), s1 = *reinterpret_cast<const float4*>(DP + ib + 4);
@@ -1888,7 +1899,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
                 if (j == 0) PM0[wq * NH + g] = iq < a.ntok ? sm : 0.f;
                 pw[g] = pack2_rne(dsv[g], sm);                                    // low half: ds[head g], high half: P'[head g]
             }
-            if (iq < a.ntok && !gst && !(a.dbg & 2)) {
+            if (iq < a.ntok && keep && !gst && !(a.dbg & 2)) {
                 uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(a.pm) + (((size_t)b * nq + (iq - 1)) * J + j) * NH);
                 dst[0] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
                 dst[1] = make_uint4(pw[4], pw[5], pw[6], pw[7]);
