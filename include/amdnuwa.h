@@ -61,6 +61,8 @@ const char* amdnuwa_error_string(int code);
  *   key 22 NT long-K kernel (four waves of 128x128, K-step 64, hand-placed main loop: gemm_nt_w4k_kernel): 0 = auto (K >= 1024 and K % 64 == 0),
  *          1 = never (8-wave ring), 2 = for every K % 64 == 0        key 23 TN four-wave kernel (gemm_tn_w4k_kernel): 1 = keep the 8-wave ring
  *   key 24 Sparse3DNA MFMA backward workspace: 0 = ONE array of (bf16 ds | bf16 P') words (round 5), 1 = the two fp32 arrays (same dK / dV bits)
+ *   key 25 batched narrow TN (N <= 64, 128 < M <= 384: the cross attention's dK / dV): 1 = 128-row tiles instead of one workgroup per batch element,
+ *          2 = always through the split-K reduction (no direct store of a one-split result)
  * (keys run 0..31; key 0 also takes 10 / 11 = the K-step 64 forms of the 256x256 ring (lock-step / staggered wave rows: full 128-byte
  *  DMA lines, two 64 KiB stages; `auto` uses 11 for 1024 <= K < 2048); key 14 < 0 with key 0 = 6 delays the second workgroup of a CU;
  *  key 7 bit 6 issues a tile's stores inside the main loop (probe))

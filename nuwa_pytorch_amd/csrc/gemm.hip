@@ -2082,6 +2082,111 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmArgs p, float* __
     }
 }
 
+// TN, WHOLE-M narrow form (round 5): the batched dK / dV products of the cross attention ([264 x 64] outputs, 2560 token rows, b * h
+// batch elements).  On 128-row tiles a batch element was three workgroups -- the third with 8 live rows of 128 -- each walking all 80
+// K-steps of 8 MFMAs per wave behind a barrier and each reading the whole B operand: a chain of latencies, not a stream.  Here ONE
+// workgroup owns a batch element: MT [32][128] A tiles + one B tile per stage, NS-stage ring, the 16-row fragments dealt round-robin to
+// the four waves (frag f -> wave f & 3), B read once.  Same fragment reads, same per-element order of accumulation (token rows ascending
+// in steps of 32) as gemm_tn_glds_kernel: bit-identical results.  Every tile t < MT holds a live column (host: (MT - 1) * 128 < M), so
+// every DMA instruction has an active lane and the vmcnt arithmetic is exact.  b = 128: 391 us against 425 + a 20-us reduction (five stages: 423).
+template <int MT, int NS>
+__global__ __launch_bounds__(256) void gemm_tn_wm_kernel(GemmArgs p, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STG = (MT + 1) * TN_TILE_BYTES;
+    constexpr int MI = 2 * MT;                                               // row fragments per wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N1 = p.M, N2 = p.N;
+    const long long bz = blockIdx.x;
+    const int z = blockIdx.y;
+    const bf16_t* A = p.A + boff(p, bz, p.sA, p.sA_in);
+    const bf16_t* B = p.B + boff(p, bz, p.sB, p.sB_in);
+    const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
+    const long long mbeg = (long long)z * p.ksplit_len;
+    const long long mend = min((long long)p.K, mbeg + p.ksplit_len);
+
+    int prow[2], col[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (j * 4 + wave) * 4 + (lane >> 4);
+        const int ps = lane & 15;
+        prow[j] = row;
+        col[j] = ((((ps >> 1) ^ tn_f(row)) << 1) | (ps & 1)) * 8;
+    }
+    auto issue = [&](int buf, long long mk0) {
+        char* base = smem + buf * STG;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long g = mk0 + prow[j];
+            const bool rin = g < mend;
+            const int off = (j * 4 + wave) * 1024;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int c = t * 128 + col[j];
+                if (c < N1) dma16_asm(rin ? A + g * p.lda + c : zp, base + t * TN_TILE_BYTES + off);
+            }
+            if (col[j] < N2) dma16_asm(rin ? B + g * p.ldb + col[j] : zp, base + MT * TN_TILE_BYTES + off);
+        }
+    };
+    constexpr int PER_STAGE = 2 * (MT + 1);                                    // vector-memory instructions per stage and wave
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)((mend - mbeg + TK - 1) / TK);
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nk) issue(st, mbeg + (long long)st * TK);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt % NS;
+        if (kt + NS - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (NS - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, mbeg + (long long)(kt + NS - 1) * TK);
+        const char* base = smem + cur * STG;
+        bf16x8 bfr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = tn_frag(base + MT * TN_TILE_BYTES, j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int f = i * 4 + wave;
+            if (f * 16 >= N1) continue;                                        // (wave-uniform)
+            const bf16x8 af = tn_frag(base + (f >> 3) * TN_TILE_BYTES, (f & 7) * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
+        }
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+    // one split, beta = 0, no device scale (host: p.nsplit = 0): alpha * sum goes straight to C -- what splitk_reduce_kernel would have
+    // written from the one partial (0 + x = x), without the round trip
+    const bool direct = p.nsplit == 0;
+    float* P = direct ? reinterpret_cast<float*>(p.C) + boff(p, bz, p.sC, p.sC_in) : partial + ((size_t)bz * gridDim.y + z) * (size_t)N1 * N2;
+    const int ldp = direct ? p.ldc : N2;
+    const float al = direct ? p.alpha : 1.f;
+    const bool v4 = (N2 & 3) == 0 && (ldp & 3) == 0 && (reinterpret_cast<size_t>(P) & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int n1 = (i * 4 + wave) * 16 + fr;
+        if (n1 >= N1) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n2 = j * 16 + fg * 4;
+            if (direct) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = al * acc[i][j][r];
+            }
+            if (v4 && n2 + 3 < N2) *reinterpret_cast<float4*>(P + (size_t)n1 * ldp + n2) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n2 + r < N2) P[(size_t)n1 * ldp + n2 + r] = acc[i][j][r];
+        }
+    }
+}
+
 // TN, 256x256 output tile, 8 waves (2 x 4, 128 x 64 each), 32 token rows per K-step, NS-stage DMA ring with
 // counted vmcnt + raw barrier (see gemm_nt_256_kernel).  Operand tiles are [32 rows][256 columns] (512-byte
 // rows, 32-byte XOR swizzle on the source column), fragments come from ds_read_b64_tr_b16.
@@ -3144,13 +3249,21 @@ static bool tn_w4k_ok(const amdnuwa_gemm_desc* d) {
     if (g_amdnuwa_tuning[23] == 1 || d->Alo || d->shift_ntok > 0) return false;
     return d->K % 64 == 0 && d->K >= 128 && d->M >= 256 && d->N >= 256;
 }
+// the whole-M narrow kernel (gemm_tn_wm_kernel): batched, N <= 64, 128 < M <= 384 (tuning key 25 = 1 keeps the 128-row tiles).  Returns MT or 0.
+static int tn_whole_m(const amdnuwa_gemm_desc* d) {
+    if (g_amdnuwa_tuning[25] == 1 || d->Alo || d->shift_ntok > 0 || d->ab_f16 || (long long)d->K >= (1LL << 31)) return 0;
+    const int v = g_amdnuwa_tuning[6];
+    if ((v != 0 && v != 2) || d->N > 64 || d->N < 1 || d->M <= 128 || d->M > 384 || d->batch < 2) return 0;
+    return (d->M + 127) / 128;
+}
 // split-K policy: fill the workgroup SLOTS of the chip exactly once (256 CUs x resident workgroups per CU);
 // never exceed them (a 257th workgroup would cost a whole extra round), keep >= minrows token rows per split.
 static int tn_splits(const amdnuwa_gemm_desc* d) {
     const int v = tn_variant(d);
     const int tl = v == 3 ? 256 : 128;
-    const int tiles = ((d->M + tl - 1) / tl) * ((d->N + tl - 1) / tl) * (d->batch > 0 ? d->batch : 1);
-    const int slots = g_amdnuwa_tuning[1] > 0 ? g_amdnuwa_tuning[1] : (v == 3 ? 256 : 1024);
+    const bool wm = tn_whole_m(d) != 0;                      // one workgroup per batch element, one workgroup per CU
+    const int tiles = wm ? d->batch : ((d->M + tl - 1) / tl) * ((d->N + tl - 1) / tl) * (d->batch > 0 ? d->batch : 1);
+    const int slots = g_amdnuwa_tuning[1] > 0 ? g_amdnuwa_tuning[1] : (v == 3 || wm ? 256 : 1024);
     const int minrows = g_amdnuwa_tuning[2] > 0 ? g_amdnuwa_tuning[2] : 256;
     int splits = slots / tiles;                              // floor: stay within one round
     const int maxs = (d->K + minrows - 1) / minrows;
@@ -3229,6 +3342,21 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
         else    { if (stag) TN256(false, true); else TN256(false, false); }
 #undef TN256
     } else
+    if (tnv == 2 && tn_whole_m(d) != 0) {
+        const int mt = tn_whole_m(d);
+        const dim3 gw(batch, splits);
+        const bool direct = splits == 1 && d->beta == 0.f && !d->alpha_dev && g_amdnuwa_tuning[25] != 2;
+        p.nsplit = direct ? 0 : splits;
+        if (mt == 3) {
+            const size_t l = (size_t)4 * 4 * TN_TILE_BYTES;
+            (void)hipFuncSetAttribute((const void*)gemm_tn_wm_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
+            hipLaunchKernelGGL((gemm_tn_wm_kernel<3, 4>), gw, block, l, stream, p, part);
+        } else {
+            const size_t l = (size_t)4 * 3 * TN_TILE_BYTES;
+            (void)hipFuncSetAttribute((const void*)gemm_tn_wm_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
+            hipLaunchKernelGGL((gemm_tn_wm_kernel<2, 4>), gw, block, l, stream, p, part);
+        }
+    } else
     if (tnv == 2) {
         const size_t gl = (size_t)2 * 2 * TN_TILE_BYTES;
         if (sh) hipLaunchKernelGGL((gemm_tn_glds_kernel<true>), grid, block, gl, stream, p, part);
@@ -3244,6 +3372,7 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
     else    { if (sh) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, block, lds, stream, p, part);
               else    hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, block, lds, stream, p, part); }
     LAUNCH_CHECK();
+    if (tnv == 2 && tn_whole_m(d) != 0 && p.nsplit == 0) return AMDNUWA_OK;      // (the whole-M kernel wrote C itself)
     const size_t per = (size_t)d->M * d->N;
     int rb = (int)((per + 255) / 256); if (rb > 2048) rb = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb, batch), dim3(256), 0, stream, part, (float*)d->C, (long long)d->strideC,

@@ -835,6 +835,32 @@ def test_cross_attention_bwd_recomputing_key_side(K, O, B, n, T):
     assert torch.equal(dKp, dKp2) and torch.equal(dVp, dVp2)
 
 
+@pytest.mark.parametrize('Bq,heads,n,T,dh', [(2, 8, 2560, 256, 64), (3, 4, 100, 200, 32), (1, 2, 71, 300, 64), (5, 8, 640, 129, 64)])
+def test_batched_tn_whole_m_kernel_equals_the_tiled_one(K, Bq, heads, n, T, dh):
+    """gemm_tn_wm_kernel (one workgroup per (sample, head) owns all JP rows of dK / dV) sums every element in the order of the 128-row
+    tiles of gemm_tn_glds_kernel (tuning key 25 = 1): bit-identical, ragged token counts and column counts included"""
+    from nuwa_pytorch_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(5 + n)
+    g = K.x_geom(Bq, n, T, heads, dh)
+    inner = heads * dh
+    mx = (T + 1 + 7) // 8 * 8
+    dS = K.BF(bf_round(torch.randn(Bq, heads, n, g.JP)).to(torch.bfloat16).to(DEV)[..., :mx], None)
+    Pm = K.BF(bf_round(torch.rand(Bq, heads, n, g.JP)).to(torch.bfloat16).to(DEV)[..., :mx], None)
+    qp = to_bf_pair(torch.randn(Bq * n, inner).to(DEV), False)
+    dop = to_bf_pair(torch.randn(Bq * n, inner).to(DEV), False)
+    got = K.xattn_kv_grads(g, dS, Pm, qp, dop)
+    L.amdnuwa_set_tuning(25, 1)
+    try:
+        ref = K.xattn_kv_grads(g, dS, Pm, qp, dop)
+    finally:
+        L.amdnuwa_set_tuning(25, 0)
+    for a, b in zip(got, ref):
+        assert torch.equal(a[:, :, :mx], b[:, :, :mx])
+    want = torch.einsum('bhnj,bnhd->bhjd', dS.hi.float(), qp.hi.float().reshape(Bq, n, heads, dh)) * g.scale
+    report(f'tn_whole_m[{Bq},{heads},{n},{T}]', got[0][:, :, :mx], want, 2e-3)
+
+
 @pytest.mark.parametrize('shape,kern,dil,n', [((2, 16, 16), (5, 3, 3), (1, 1, 1), None), ((3, 16, 16), (3, 3, 3), (4, 4, 4), 300),
                                               ((5, 16, 16), (5, 3, 3), (2, 2, 2), 1 + 4 * 256 + 100)])
 def test_sparse3dna_bwd_recomputing_key_side(K, O, shape, kern, dil, n):
