@@ -32,7 +32,8 @@ typedef struct ihipStream_t* amdnuwa_stream;   /* == hipStream_t */
 int amdnuwa_abi_version(void);                 /* bumps when any signature or documented argument meaning below changes (13: tuning keys 0..31,
                                                 * amdnuwa_xattn_unpack's flag bit 1, chunk-permuted dS / Pm columns of amdnuwa_xattn2_bwd;
                                                 * 14: amdnuwa_linear_ce_x3 added; 15: the two-MFMA products -- amdnuwa_gemm_desc.ab_f16 with Blo, amdnuwa_gemm_nt_f16x2_supported,
-                                                *     o_lo_f16 on the two fp16 forward cores) */
+                                                *     o_lo_f16 on the two fp16 forward cores; 16: the fp16-gradient backward; 17: amdnuwa_gemm_desc.a_chunk32, amdnuwa_gemm_tn_chunked_a_supported,
+                                                *     amdnuwa_xattn2_bwd_ex, tuning key 25) */
 const char* amdnuwa_error_string(int code);
 /* runtime tuning knobs (A/B benchmarking only; 0 = the library's auto policy everywhere):
  *   key 0  NT GEMM variant: 1 direct-to-LDS BK 64, 2 direct-to-LDS BK 32, 3 / 4 256x256 tile with a 4- / 3-stage DMA ring,
@@ -132,6 +133,10 @@ typedef struct {
      * alpha_dev (TN): optional DEVICE scalar multiplied into alpha by the split-K reduction (1 / S of the gradient scale). */
     int c_f16;
     const float* alpha_dev;
+    /* ABI 17, TN only: a_chunk32 != 0 -> A is stored in planes of 32 columns, element (token row g, column c) at
+     * A[(c / 32) * K * 32 + g * 32 + c % 32] (lda unused; batch strides as before).  The layout amdnuwa_xattn2_bwd_ex writes its dS / Pm in
+     * with flag bit 0.  amdnuwa_gemm_tn_chunked_a_supported() first; AMDNUWA_ERR_UNSUPPORTED otherwise. */
+    int a_chunk32;
 } amdnuwa_gemm_desc;
 
 /* C[M,N] = alpha * A[M,K] . B[N,K]^T (+ bias).  K, lda, ldb multiples of 8. */
@@ -150,6 +155,8 @@ int amdnuwa_hilo_to_f16(const uint16_t* hi, const uint16_t* lo, int ld_in, uint1
 /* 1 when amdnuwa_gemm_tn() takes this product with ab_f16 != 0 (fp16 operands: the four-wave kernel's shapes -- no token shift, token rows
  * a multiple of 64, both output dimensions >= 256); it returns AMDNUWA_ERR_UNSUPPORTED otherwise */
 int amdnuwa_gemm_tn_f16_supported(const amdnuwa_gemm_desc* d);
+/* 1 when amdnuwa_gemm_tn takes this product with A in planes of 32 columns (a_chunk32): batched, N <= 64, 128 < M <= 384 (the whole-M kernel) */
+int amdnuwa_gemm_tn_chunked_a_supported(const amdnuwa_gemm_desc* d);
 size_t amdnuwa_gemm_tn_workspace_bytes(const amdnuwa_gemm_desc* d);
 int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
 
@@ -452,6 +459,13 @@ size_t amdnuwa_xattn2_bwd_workspace_bytes(const amdnuwa_xattn_geom* g);
 int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
                        const amdnuwa_xattn_kv* packed, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm,
                        uint16_t* dq, int lddq, float* part_th, size_t part_bytes, amdnuwa_stream stream);
+/* ABI 17: the same with flags.  Bit 0: dS / Pm are written CHUNK-MAJOR, [B][heads][JP / 32][n][32] (same chunk-permuted key order inside a
+ * chunk): a store instruction of the kernel then covers 1 KiB of contiguous memory (16 queries x 64 B) instead of sixteen 64-byte pieces at
+ * the 2 JP-byte row pitch (xattn3_bwd 2035 -> 1878 us at b = 128).  Read them with amdnuwa_gemm_tn and a_chunk32.  AMDNUWA_ERR_UNSUPPORTED when
+ * tuning key 10 selects the first-generation kernel. */
+int amdnuwa_xattn2_bwd_ex(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
+                          const amdnuwa_xattn_kv* packed, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm,
+                          uint16_t* dq, int lddq, float* part_th, size_t part_bytes, int flags, amdnuwa_stream stream);
 /* The recomputing backward without the dS / Pm arrays (n % 32 == 0): the query side as above (dq, part_th) leaves nb / delta per
  * (head, query) in `nbd` (>= amdnuwa_xattn2_bwd_rc_stats_bytes), and a key-side kernel -- one workgroup per 32 keys of a sample,
  * the queries streamed through LDS -- recomputes ds and P' from them and accumulates dKp / dVp ([B][heads][JP][dim_head] fp32,

@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # AMDNUWA_LIBRARY: another build of the same library (A/B runs of compiler options inside one process group; tools/ only)
 LIB_PATH = os.environ.get('AMDNUWA_LIBRARY') or os.path.join(HERE, 'lib', 'libamdnuwa.so')
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 P = C.c_void_p
 I = C.c_int
@@ -23,7 +23,7 @@ class GemmDesc(C.Structure):
                 ('c_is_bf16', I), ('bias', P), ('alpha', F), ('beta', F),
                 ('M', I), ('N', I), ('K', I), ('batch', I), ('shift_ntok', I), ('shift_fmap', I),
                 ('batch_inner', I), ('strideA_inner', LL), ('strideB_inner', LL), ('strideC_inner', LL),
-                ('C2', P), ('C2lo', P), ('ldc2', I), ('geglu_u', P), ('geglu_u_lo', P), ('ld_u', I), ('c_lo_f16', I), ('ab_f16', I), ('c_f16', I), ('alpha_dev', P)]
+                ('C2', P), ('C2lo', P), ('ldc2', I), ('geglu_u', P), ('geglu_u_lo', P), ('ld_u', I), ('c_lo_f16', I), ('ab_f16', I), ('c_f16', I), ('alpha_dev', P), ('a_chunk32', I)]
 
 
 class S3Geom(C.Structure):
@@ -61,6 +61,7 @@ SIGNATURES = {
     'amdnuwa_timer_collect': (I, [C.POINTER(C.c_double), C.POINTER(LL)]),
     'amdnuwa_gemm_nt': (I, [GD, P]),
     'amdnuwa_gemm_tn_f16_supported': (I, [GD]),
+    'amdnuwa_gemm_tn_chunked_a_supported': (I, [GD]),
     'amdnuwa_gemm_tn_workspace_bytes': (SZ, [GD]),
     'amdnuwa_gemm_tn': (I, [GD, P, SZ, P]),
     'amdnuwa_ln_fwd': (I, [P, P, P, P, P, P, P, P, P, P, LL, I, I, I, F, I, I, P]),
@@ -118,6 +119,7 @@ SIGNATURES = {
     'amdnuwa_xattn2_fwd_f16': (I, [XG, P, I, XK, P, P, P, I, I, P, P]),
     'amdnuwa_xattn2_bwd_workspace_bytes': (SZ, [XG]),
     'amdnuwa_xattn2_bwd': (I, [XG, P, I, P, I, XK, P, P, P, P, P, I, P, SZ, P]),
+    'amdnuwa_xattn2_bwd_ex': (I, [XG, P, I, P, I, XK, P, P, P, P, P, I, P, SZ, I, P]),
     'amdnuwa_xattn2_bwd_rc_supported': (I, [XG]),
     'amdnuwa_xattn2_bwd_rc_stats_bytes': (SZ, [XG]),
     'amdnuwa_xattn2_bwd_rc': (I, [XG, P, I, P, I, XK, P, P, P, I, P, SZ, P, SZ, P, P, P]),

@@ -45,6 +45,7 @@ struct GemmArgs {
     float* ce_stats; float* ce_tl; const float* ce_lse; const long long* ce_tgt; float ce_scale; int ce_nblk;
     int skew;               // start-phase step of the first-generation workgroups in s_sleep(8) units (tuning key 14; 0 = off)
     int c_f16;              // F16 rings, EPI 1: C / the GEGLU-backward output C2 are fp16 (saturating), not bf16 (the fp16-gradient backward)
+    int a_chunk;            // TN whole-M kernel: A is stored as planes of 32 columns, [M / 32][K token rows][32] (amdnuwa_gemm_desc.a_chunk32)
 };
 
 __device__ __forceinline__ long long boff(const GemmArgs& p, long long z, long long s, long long s_in) {
@@ -2123,7 +2124,10 @@ __global__ __launch_bounds__(256) void gemm_tn_wm_kernel(GemmArgs p, float* __re
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 const int c = t * 128 + col[j];
-                if (c < N1) dma16_asm(rin ? A + g * p.lda + c : zp, base + t * TN_TILE_BYTES + off);
+                // (a_chunk: column c lives in plane c / 32 -- the cross-attention backward writes its dS / P' chunk by chunk, 16 queries x 64 B
+                //  = 1 KiB contiguous per store instruction instead of 64-byte pieces at the row pitch; here 4 rows x 64 B per plane and piece)
+                const bf16_t* src = p.a_chunk ? A + ((size_t)(c >> 5) * p.K + g) * 32 + (c & 31) : A + g * p.lda + c;
+                if (c < N1) dma16_asm(rin ? src : zp, base + t * TN_TILE_BYTES + off);
             }
             if (col[j] < N2) dma16_asm(rin ? B + g * p.ldb + col[j] : zp, base + MT * TN_TILE_BYTES + off);
         }
@@ -3272,6 +3276,12 @@ static int tn_splits(const amdnuwa_gemm_desc* d) {
     return splits;
 }
 
+// A in planes of 32 columns (d->a_chunk32): the whole-M narrow kernel only
+extern "C" int amdnuwa_gemm_tn_chunked_a_supported(const amdnuwa_gemm_desc* d) {
+    if (!d || d->lda % 8 || d->ldb % 8) return 0;
+    return tn_variant(d) == 2 && tn_whole_m(d) != 0 ? 1 : 0;
+}
+
 // fp16 operands (d->ab_f16): the four-wave kernel only
 extern "C" int amdnuwa_gemm_tn_f16_supported(const amdnuwa_gemm_desc* d) {
     if (!d || d->Alo || d->Blo || d->shift_ntok > 0 || d->lda % 8 || d->ldb % 8) return 0;
@@ -3292,8 +3302,9 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
     if (d->shift_ntok > 0 && (d->shift_fmap <= 0 || d->N % 32)) return AMDNUWA_ERR_ARG;
     if (workspace_bytes < amdnuwa_gemm_tn_workspace_bytes(d) || !workspace) return AMDNUWA_ERR_WORKSPACE;
     if (d->ab_f16 && !amdnuwa_gemm_tn_f16_supported(d)) return AMDNUWA_ERR_UNSUPPORTED;
+    if (d->a_chunk32 && !amdnuwa_gemm_tn_chunked_a_supported(d)) return AMDNUWA_ERR_UNSUPPORTED;
     GemmArgs p;
-    p.c_f16 = 0;
+    p.c_f16 = 0; p.a_chunk = d->a_chunk32 ? 1 : 0;
     p.A = (const bf16_t*)d->A; p.Alo = (const bf16_t*)d->Alo; p.sA = d->strideA; p.lda = d->lda;
     p.B = (const bf16_t*)d->B; p.Blo = (const bf16_t*)d->Blo; p.sB = d->strideB; p.ldb = d->ldb;
     p.C = d->C; p.Clo = nullptr; p.sC = d->strideC; p.ldc = d->ldc;

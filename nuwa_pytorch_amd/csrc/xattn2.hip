@@ -51,6 +51,7 @@ struct X2Args {
     int B, n, JP, nch;
     int T;                                   // context keys (the null key is key 0, keys 1..T the context, the rest of JP padding)
     float scale;
+    int cm;                                  // xattn3_bwd: dS / Pm chunk-major, [b][h][chunk][n][32] instead of [b][h][n][JP] (1 KiB contiguous per store instruction)
     int nostore;                             // the backward skips its dS / Pm stores (the recomputing key side below replaces them;
                                              // also the probe of tuning key 10 bit 4)
     float* nbd;                              // recomputing backward: [2][B][NH][n] = nb (log2 normaliser) and delta per (head, query),
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
             if (qok && !a.nostore && 32 * ch + 4 * g4 <= a.T) {     // (a lane group whose 8 keys are all padding -- 3 of the 4 groups of the last chunk at T = 256 -- writes nothing: the TN GEMMs stop at the last group that holds a key)
 #pragma unroll
                 for (int rp = 0; rp < 4; ++rp) {
-                    bf16_t* dst = a.Pm + ((size_t)b * NH + 4 * Q + rp) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 8;   // (chunk-permuted key order)
+                    bf16_t* dst = a.Pm + ((size_t)b * NH + 4 * Q + rp) * prow + (a.cm ? ((size_t)ch * a.n + qi) * 32 + g4 * 8 : (size_t)qi * a.JP + ch * 32 + g4 * 8);   // (chunk-permuted key order)
                     *reinterpret_cast<uint4*>(dst) = make_uint4(pack2_rne(D[0][rp], D[1][rp]), pack2_rne(D[2][rp], D[3][rp]),
                                                                 pack2_rne(D[4][rp], D[5][rp]), pack2_rne(D[6][rp], D[7][rp]));
                 }
@@ -798,7 +799,7 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
                 const uint2 lo = make_uint2(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]));
                 const uint2 hi = make_uint2(pack2_rne(ds[4], ds[5]), pack2_rne(ds[6], ds[7]));
                 if (qok && !a.nostore && 32 * ch + 4 * g4 <= a.T) {
-                    bf16_t* dst = a.dS + ((size_t)b * NH + h) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 8;  // (chunk-permuted key order)
+                    bf16_t* dst = a.dS + ((size_t)b * NH + h) * prow + (a.cm ? ((size_t)ch * a.n + qi) * 32 + g4 * 8 : (size_t)qi * a.JP + ch * 32 + g4 * 8);  // (chunk-permuted key order)
                     *reinterpret_cast<uint4*>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 }
                 const bf16x8 sf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
@@ -1321,9 +1322,18 @@ extern "C" size_t amdnuwa_xattn2_bwd_workspace_bytes(const amdnuwa_xattn_geom* g
     return (size_t)g->B * ((g->n + 63) / 64) * NH * NH * sizeof(float);
 }
 
+extern "C" int amdnuwa_xattn2_bwd_ex(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
+                                     const amdnuwa_xattn_kv* p, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm,
+                                     uint16_t* dq, int lddq, float* part_th, size_t part_bytes, int flags, hipStream_t stream);
 extern "C" int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
                                   const amdnuwa_xattn_kv* p, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm,
                                   uint16_t* dq, int lddq, float* part_th, size_t part_bytes, hipStream_t stream) {
+    return amdnuwa_xattn2_bwd_ex(g, q, ldq, dO, lddo, p, w_th, stats, dS, Pm, dq, lddq, part_th, part_bytes, 0, stream);
+}
+// flags bit 0: dS / Pm chunk-major (see X2Args::cm; what the whole-M batched amdnuwa_gemm_tn reads with a_chunk32)
+extern "C" int amdnuwa_xattn2_bwd_ex(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
+                                     const amdnuwa_xattn_kv* p, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm,
+                                     uint16_t* dq, int lddq, float* part_th, size_t part_bytes, int flags, hipStream_t stream) {
     int rc = check2(g);
     if (rc) return rc;
     if (!q || !dO || !p || !p->Kp || !p->Vp || !p->valid || !w_th || !stats || !dS || !Pm || !dq || ldq % 8 || lddo % 8 || lddq % 4)
@@ -1338,6 +1348,8 @@ extern "C" int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.nostore = (g_amdnuwa_tuning[10] & 16) ? 1 : 0;
     a.dbg = g_amdnuwa_tuning[18];
     auto kern = (g_amdnuwa_tuning[10] & 15) == 1 ? xattn2_bwd_kernel : xattn3_bwd_kernel;          // (0 and 2: xattn3_bwd)
+    a.cm = flags & 1;
+    if (a.cm && kern != xattn3_bwd_kernel) return AMDNUWA_ERR_UNSUPPORTED;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
     hipLaunchKernelGGL(kern, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
     LAUNCH_CHECK();

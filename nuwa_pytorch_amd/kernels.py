@@ -1178,19 +1178,56 @@ def xattn2_fwd(g, q, pk, wth):
     return o, stats
 
 
-def xattn2_bwd(g, q, dO, pk, wth, stats):
-    """returns dq BF [B*n, inner], dS BF and Pm BF [B, h, n, JP], dw_th fp32 [h, h]"""
+def _xattn_tn_desc(g, Mx, chunked):
+    """the batched TN product of the cross attention's dK / dV (shape part only): A = dS or Pm per (sample, head), B = q or dO"""
+    d = GemmDesc()
+    d.lda, d.ldb = g.JP, g.heads * g.dim_head
+    d.M, d.N, d.K = Mx, g.dim_head, g.n
+    d.batch, d.batch_inner = g.B * g.heads, g.heads
+    d.strideA_inner = g.n * g.JP                # A / C are dense over (b, h): inner stride = one head
+    d.strideA = g.heads * g.n * g.JP
+    d.strideC_inner = g.JP * g.dim_head
+    d.strideC = g.heads * g.JP * g.dim_head
+    d.ldc, d.c_is_bf16, d.beta = g.dim_head, 0, 0.0
+    d.a_chunk32 = 1 if chunked else 0
+    return d
+
+
+def xattn_chunk_major_ok(g):
+    """dS / Pm of xattn2_bwd chunk-major ([B, h, JP / 32, n, 32]: 1 KiB contiguous per store instruction of the kernel) -- when the batched
+    TN product that reads them runs on the whole-M kernel, the one that takes that layout"""
+    L = _lib.lib()
+    if (L.amdnuwa_get_tuning(10) & 15) == 1 or os.environ.get('AMDNUWA_XATTN_CM', '1') == '0':      # (env: A/B against the row-major arrays)
+        return False
+    return bool(L.amdnuwa_gemm_tn_chunked_a_supported(C.byref(_xattn_tn_desc(g, xattn_permuted_extent(g), True))))
+
+
+def xattn_rows(g, t):
+    """dS / Pm as [B, h, n, columns] whichever layout xattn2_bwd wrote (tests, tools)"""
+    if t.dim() == 5:
+        return t.permute(0, 1, 3, 2, 4).reshape(g.B, g.heads, g.n, g.JP)[..., :xattn_permuted_extent(g)]
+    return t
+
+
+def xattn2_bwd(g, q, dO, pk, wth, stats, chunk_major=None):
+    """returns dq BF [B*n, inner], dS BF and Pm BF, dw_th fp32 [h, h].  dS / Pm: [B, h, n, columns] (views of JP-pitch rows), or -- chunk_major,
+    the default wherever xattn_chunk_major_ok -- [B, h, JP / 32, n, 32]; xattn_kv_grads takes either, xattn_rows shows either as rows"""
     L = _lib.lib()
     inner = g.heads * g.dim_head
     dev = q.hi.device
+    cm = xattn_chunk_major_ok(g) if chunk_major is None else bool(chunk_major)
     dq = empty_bf((g.B * g.n, inner), dev, lo=False)
-    dS = empty_bf((g.B, g.heads, g.n, g.JP), dev, lo=False)
-    Pm = empty_bf((g.B, g.heads, g.n, g.JP), dev, lo=False)
+    shape = (g.B, g.heads, g.JP // 32, g.n, 32) if cm else (g.B, g.heads, g.n, g.JP)
+    dS = empty_bf(shape, dev, lo=False)
+    Pm = empty_bf(shape, dev, lo=False)
     nb = L.amdnuwa_xattn2_bwd_workspace_bytes(C.byref(g))
     part = torch.empty((nb // (4 * g.heads * g.heads), g.heads * g.heads), dtype=torch.float32, device=dev)
-    check(L.amdnuwa_xattn2_bwd(C.byref(g), _p(q.hi), q.hi.stride(0), _p(dO.hi), dO.hi.stride(0), C.byref(pk.struct), _p(wth),
-                               _p(stats), _p(dS.hi), _p(Pm.hi), _p(dq.hi), inner, _p(part), nb, _stream()), 'amdnuwa_xattn2_bwd')
+    check(L.amdnuwa_xattn2_bwd_ex(C.byref(g), _p(q.hi), q.hi.stride(0), _p(dO.hi), dO.hi.stride(0), C.byref(pk.struct), _p(wth),
+                                  _p(stats), _p(dS.hi), _p(Pm.hi), _p(dq.hi), inner, _p(part), nb, 1 if cm else 0, _stream()),
+          'amdnuwa_xattn2_bwd_ex')
     dwth = colsum(part).reshape(g.heads, g.heads)          # fixed-order reduction over the workgroups
+    if cm:
+        return dq, BF(dS.hi, None), BF(Pm.hi, None), dwth
     # lane groups of the last chunk whose 8 keys are all padding write nothing: hand out the columns that exist (views: the row pitch stays JP)
     mx = xattn_permuted_extent(g)
     return dq, BF(dS.hi[..., :mx], None), BF(Pm.hi[..., :mx], None), dwth
@@ -1240,23 +1277,17 @@ def xattn_kv_grads(g, dS, Pm, q, dO):
     """dKp = scale * dS^T q, dVp = Pm^T dO per (sample, head): two batched TN GEMMs (reduction over queries).
     returns fp32 [B, h, JP, dh] x 2 (rows past the last column of dS / Pm -- padding keys -- are not written)"""
     dev = q.hi.device
-    Mx = dS.hi.shape[-1]                       # (xattn2_bwd hands out only the columns that hold a key)
+    cm = dS.hi.dim() == 5                      # chunk-major dS / Pm (xattn2_bwd)
+    Mx = xattn_permuted_extent(g) if cm else dS.hi.shape[-1]      # (xattn2_bwd hands out only the columns that hold a key)
     dKp = torch.empty((g.B, g.heads, g.JP, g.dim_head), dtype=torch.float32, device=dev)
     dVp = torch.empty_like(dKp)
     for (A, Bm, out, alpha) in ((dS, q, dKp, g.scale), (Pm, dO, dVp, 1.0)):
         x3 = A.lo is not None and Bm.lo is not None
-        d = GemmDesc()
-        d.A, d.Alo, d.lda, d.strideA = _p(A.hi), _p(A.lo) if x3 else None, g.JP, g.n * g.JP
+        d = _xattn_tn_desc(g, Mx, cm)
+        d.A, d.Alo = _p(A.hi), _p(A.lo) if x3 else None
         d.B, d.Blo, d.ldb = _p(Bm.hi), _p(Bm.lo) if x3 else None, Bm.hi.stride(0)
         d.strideB, d.strideB_inner = g.n * Bm.hi.stride(0), g.dim_head
-        d.C, d.ldc, d.strideC, d.c_is_bf16 = _p(out), g.dim_head, g.JP * g.dim_head, 0
-        d.alpha, d.beta = float(alpha), 0.0
-        d.M, d.N, d.K = Mx, g.dim_head, g.n
-        d.batch, d.batch_inner = g.B * g.heads, g.heads
-        d.strideA_inner = g.n * g.JP            # A / C are dense over (b, h): inner stride = one head
-        d.strideA = g.heads * g.n * g.JP
-        d.strideC_inner = g.JP * g.dim_head
-        d.strideC = g.heads * g.JP * g.dim_head
+        d.C, d.alpha = _p(out), float(alpha)
         gemm_tn_batched(d, dev)
     return dKp, dVp
 

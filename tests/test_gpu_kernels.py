@@ -683,9 +683,17 @@ def test_cross_attention_core(K, O, case, x3):
         # (xattn2_bwd writes the columns of dS / Pm in its chunk-permuted key order: undone here, and by xattn_unpack below)
         # (... and only the columns up to the last lane group that holds a key exist: compare the keys 0 .. T)
         pos = K.xattn_key_positions(g.JP, DEV)[:T + 1]
-        report('xattn2_Pm' + tag, Pm2.hi.float().index_select(-1, pos), Pm.hi.float()[..., :T + 1], 2 ** -6)
-        report('xattn2_dS' + tag, dS2.hi.float().index_select(-1, pos), dS.hi.float()[..., :T + 1], 2 ** -5)
+        report('xattn2_Pm' + tag, K.xattn_rows(g, Pm2.hi).float().index_select(-1, pos), Pm.hi.float()[..., :T + 1], 2 ** -6)
+        report('xattn2_dS' + tag, K.xattn_rows(g, dS2.hi).float().index_select(-1, pos), dS.hi.float()[..., :T + 1], 2 ** -5)
+        if dS2.hi.dim() == 5:
+            # the chunk-major arrays (what the step uses where the whole-M TN kernel takes them) hold the bits of the row-major ones
+            _, dS3, Pm3, _ = K.xattn2_bwd(g, qp, dop, pk, wth.detach().to(DEV), stats, chunk_major=False)
+            assert torch.equal(K.xattn_rows(g, dS2.hi), dS3.hi) and torch.equal(K.xattn_rows(g, Pm2.hi), Pm3.hi)
+            dKp3, dVp3 = K.xattn_kv_grads(g, dS3, Pm3, qp, dop)
         dKp2, dVp2 = K.xattn_kv_grads(g, dS2, Pm2, qp, dop)
+        if dS2.hi.dim() == 5:
+            mx = K.xattn_permuted_extent(g)
+            assert torch.equal(dKp2[:, :, :mx], dKp3[:, :, :mx]) and torch.equal(dVp2[:, :, :mx], dVp3[:, :, :mx])
         dkv2, dnk2, dnv2 = K.xattn_unpack(g, dKp2, dVp2, lo=False, permuted=True)
         report('xattn2_dkv' + tag, dkv2.hi.float().reshape(B, T, 2, heads, dh), kv.grad, 2 ** -6)
         report('xattn2_dnull_k' + tag, dnk2, nk.grad, 2 ** -6)
@@ -856,6 +864,11 @@ def test_batched_tn_whole_m_kernel_equals_the_tiled_one(K, Bq, heads, n, T, dh):
     finally:
         L.amdnuwa_set_tuning(25, 0)
     for a, b in zip(got, ref):
+        assert torch.equal(a[:, :, :mx], b[:, :, :mx])
+    # the same operands in planes of 32 columns (a_chunk32: how xattn2_bwd writes them for this kernel)
+    assert K.xattn_chunk_major_ok(g)
+    cm = lambda t: K.BF(torch.nn.functional.pad(t.hi, (0, g.JP - mx)).reshape(Bq, heads, n, g.JP // 32, 32).permute(0, 1, 3, 2, 4).contiguous(), None)
+    for a, b in zip(K.xattn_kv_grads(g, cm(dS), cm(Pm), qp, dop), got):
         assert torch.equal(a[:, :, :mx], b[:, :, :mx])
     want = torch.einsum('bhnj,bnhd->bhjd', dS.hi.float(), qp.hi.float().reshape(Bq, n, heads, dh)) * g.scale
     report(f'tn_whole_m[{Bq},{heads},{n},{T}]', got[0][:, :, :mx], want, 2e-3)
@@ -1193,7 +1206,10 @@ def test_attention_kernels_bit_reproducible_with_coresident_workgroups(K):
     stable('cross attention fwd bf16', lambda: K.xattn2_fwd(gx, qb, pkb, wth))
     _, stats = K.xattn2_fwd(gx, qb, pkb, wth)
     dO = K.BF(torch.randn(B * n, inner, device=DEV).to(torch.bfloat16), None)
-    stable('cross attention bwd', lambda: K.xattn2_bwd(gx, qb, dO, pkb, wth, stats))
+    # (chunk-major dS / Pm: the lane groups of the last chunk that hold no key write nothing -- compare the columns that exist)
+    rows = lambda r: (r[0], K.xattn_rows(gx, r[1].hi), K.xattn_rows(gx, r[2].hi), r[3])
+    stable('cross attention bwd', lambda: rows(K.xattn2_bwd(gx, qb, dO, pkb, wth, stats)))
+    stable('cross attention bwd, row-major dS / Pm', lambda: K.xattn2_bwd(gx, qb, dO, pkb, wth, stats, chunk_major=False))
 
 
 @pytest.mark.parametrize('R,C,Kd', [(1000, 8192, 512), (2560, 512, 256), (300, 192, 64)])
@@ -1434,7 +1450,9 @@ def test_attention_cores_at_batch_16_equal_their_one_sample_results(K):
         assert torch.equal(st.reshape(B, -1)[s], st1.reshape(-1)), f'cross attention statistics, sample {s}'
         pkb1 = K.xattn_pack(gx1, K.BF(kv1.hi, None), nk, nv, mask[s:s + 1].contiguous())
         dq1, dS1, Pm1, _ = K.xattn2_bwd(gx1, K.BF(q1.hi, None), K.BF(dO[rows].contiguous(), None), pkb1, wth, st1)
-        assert torch.equal(dq.hi[rows], dq1.hi) and torch.equal(dS.hi[s], dS1.hi[0]) and torch.equal(Pm.hi[s], Pm1.hi[0]), f'cross attention backward, sample {s}'
+        # (chunk-major arrays: the columns that hold a key -- the padding lane groups of the last chunk write nothing)
+        assert torch.equal(dq.hi[rows], dq1.hi) and torch.equal(K.xattn_rows(gx, dS.hi)[s], K.xattn_rows(gx1, dS1.hi)[0]) and \
+            torch.equal(K.xattn_rows(gx, Pm.hi)[s], K.xattn_rows(gx1, Pm1.hi)[0]), f'cross attention backward, sample {s}'
 
 
 @pytest.mark.parametrize('dil', [1, 2, 4])

@@ -93,7 +93,7 @@ def main():
             o2, stats = K.xattn2_fwd(g, q, pk, wth)
             t2 = bench(lambda: K.xattn2_bwd(g, q, do, pk, wth, stats), args.iters)
             dq2, dS2, Pm2, dw2 = K.xattn2_bwd(g, q, do, pk, wth, stats)
-            cur = [o2.hi.float(), dq2.hi.float(), dS2.hi.float(), Pm2.hi.float(), dw2]
+            cur = [o2.hi.float(), dq2.hi.float(), K.xattn_rows(g, dS2.hi).float(), K.xattn_rows(g, Pm2.hi).float(), dw2]
             diff = '' if ref is None else '  max rel diff vs xattn2: ' + ' '.join(
                 f'{nm} {float((a_ - b_).abs().max() / b_.abs().max()):.1e}' for nm, a_, b_ in zip(('o', 'dq', 'dS', 'Pm', 'dWth'), cur, ref))
             ref = cur if ref is None else ref
