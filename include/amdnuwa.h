@@ -33,7 +33,7 @@ int amdnuwa_abi_version(void);                 /* bumps when any signature or do
                                                 * amdnuwa_xattn_unpack's flag bit 1, chunk-permuted dS / Pm columns of amdnuwa_xattn2_bwd;
                                                 * 14: amdnuwa_linear_ce_x3 added; 15: the two-MFMA products -- amdnuwa_gemm_desc.ab_f16 with Blo, amdnuwa_gemm_nt_f16x2_supported,
                                                 *     o_lo_f16 on the two fp16 forward cores; 16: the fp16-gradient backward; 17: amdnuwa_gemm_desc.a_chunk32, amdnuwa_gemm_tn_chunked_a_supported,
-                                                *     amdnuwa_xattn2_bwd_ex, tuning key 25) */
+                                                *     amdnuwa_xattn2_bwd_ex, AMDNUWA_LN_RESID_MINUS, tuning key 25) */
 const char* amdnuwa_error_string(int code);
 /* runtime tuning knobs (A/B benchmarking only; 0 = the library's auto policy everywhere):
  *   key 0  NT GEMM variant: 1 direct-to-LDS BK 64, 2 direct-to-LDS BK 32, 3 / 4 256x256 tile with a 4- / 3-stage DMA ring,
@@ -188,6 +188,9 @@ int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size_t workspac
 /* ln_bwd_f16's `stable`: the fp32 dy is multiplied by the device scalar scale2[1] on the way in (the upstream gradient of the loss entering the
  * final norm's backward: no separate scaling pass over dy) */
 #define AMDNUWA_LN_DY_SCALED 512
+/* ln_fwd's `mode` (with bit 0, the post-norm form): out_f32 = resid - LN(x) instead of resid + LN(x): a reversible block's input recomputed from
+ * its output (rev.py:77-106: x2 = y2 - g(y1), x1 = y1 - f(x2)) without negation passes over the stream */
+#define AMDNUWA_LN_RESID_MINUS 1024
 int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w, const float* b, uint16_t* out_hi,
                    uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R, int D,
                    int mode, int stable, float eps, int shift_ntok, int shift_fmap, amdnuwa_stream stream);

@@ -211,7 +211,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             store_ln_shifted(out_hi, out_lo, row, e, D, shift_ntok, shift_fmap, y0, y1, y2, y3, lo_f16, &sat);
         } else {
             const float4 rv = *reinterpret_cast<const float4*>(resid + row * D + e);
-            *reinterpret_cast<float4*>(out_f32 + row * D + e) = make_float4(rv.x + y0, rv.y + y1, rv.z + y2, rv.w + y3);
+            // lo_f16 & 4 (AMDNUWA_LN_RESID_MINUS): resid - LN(x) -- a reversible block's input from its output, x2 = y2 - g(y1), in one pass
+            // (the same bits as -((-y2) + g): the sign flips are exact)
+            const float sg = (lo_f16 & 4) ? -1.f : 1.f;
+            *reinterpret_cast<float4*>(out_f32 + row * D + e) = make_float4(fmaf(sg, y0, rv.x), fmaf(sg, y1, rv.y), fmaf(sg, y2, rv.z), fmaf(sg, y3, rv.w));
         }
     }
     if (MODE == 0) f16_sat_commit(sat);
@@ -1105,8 +1108,9 @@ extern "C" int amdnuwa_ln_fwd(const float* x, const float* resid, const float* w
                               uint16_t* out_lo, float* out_f32, float* mean, float* rstd, float* inv_amax, long long R,
                               int D, int mode, int stable, float eps, int shift_ntok, int shift_fmap, hipStream_t stream) {
     const bool xbf = (mode & AMDNUWA_LN_X_BF16) != 0;        // x points at bf16 values
-    const int lo_f16 = (mode & AMDNUWA_LN_OUT_F16) ? 2 : ((mode & AMDNUWA_LN_LO_F16) ? 1 : 0);   // 1: out_lo = fp16 copy; 2: out_hi itself is fp16
+    int lo_f16 = (mode & AMDNUWA_LN_OUT_F16) ? 2 : ((mode & AMDNUWA_LN_LO_F16) ? 1 : 0);   // 1: out_lo = fp16 copy; 2: out_hi itself is fp16
     if (lo_f16 == 2 && out_lo) return AMDNUWA_ERR_ARG;
+    if (mode & AMDNUWA_LN_RESID_MINUS) { if (!(mode & 1)) return AMDNUWA_ERR_ARG; lo_f16 = 4; }     // (mode 1 only: out_f32 = resid - LN(x))
     mode &= 1;
     if (shift_ntok > 0 && (mode != 0 || shift_fmap == 0 || shift_fmap < -1 || D % 16)) return AMDNUWA_ERR_ARG;
     if (!x || !w || !b || !mean || !rstd || D % 4 || D > MAXV * 256 || D <= 0) return AMDNUWA_ERR_ARG;

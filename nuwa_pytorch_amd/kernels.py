@@ -607,6 +607,7 @@ def gemm_tn_batched(desc, device):
 
 LN_X_BF16, LN_DY_BF16, LN_LO_F16 = 16, 32, 64       # == AMDNUWA_LN_X_BF16 / AMDNUWA_LN_DY_BF16 / AMDNUWA_LN_LO_F16
 LN_OUT_F16, LN_DY_F16, LN_DY_SCALED = 128, 256, 512   # == AMDNUWA_LN_OUT_F16 / AMDNUWA_LN_DY_F16 / AMDNUWA_LN_DY_SCALED
+LN_RESID_MINUS = 1024                                # == AMDNUWA_LN_RESID_MINUS
 
 
 def _f32_or_bf(t):
@@ -622,9 +623,9 @@ def empty_bf_f16(shape, device):
     return BF(torch.empty(shape, dtype=torch.bfloat16, device=device), None, torch.empty(shape, dtype=torch.float16, device=device))
 
 
-def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5, shift=None, f16=False):
+def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5, shift=None, f16=False, minus=False):
     """x fp32 [R, D] contiguous (or a hi-only BF pair).  resid None -> (BF out, mean, rstd, inv_amax);
-    else (fp32 out = resid + LN(x), mean, rstd).  f16: out = BF(hi, None, f16) (bf16 copy + fp16 copy)"""
+    else (fp32 out = resid + LN(x) -- minus: resid - LN(x) --, mean, rstd).  f16: out = BF(hi, None, f16) (bf16 copy + fp16 copy)"""
     L = _lib.lib()
     xp, xbf, (R, D), dev = _f32_or_bf(x)
     flag = LN_X_BF16 if xbf else 0
@@ -644,7 +645,7 @@ def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5, shift=None, f16=False
         return out, mean, rstd, ia
     out = torch.empty_like(resid)
     check(L.amdnuwa_ln_fwd(xp, _p(resid), _p(w), _p(b), None, None, _p(out), _p(mean), _p(rstd), None,
-                           R, D, 1 | flag, 0, eps, 0, 0, _stream()), 'amdnuwa_ln_fwd')
+                           R, D, 1 | flag | (LN_RESID_MINUS if minus else 0), 0, eps, 0, 0, _stream()), 'amdnuwa_ln_fwd')
     return out, mean, rstd
 
 

@@ -182,8 +182,10 @@ class SandwichNorm(nn.Module):
             return fn, shift                      # NUWASketch decoder: 2-D nearby cross-attention on the 3DNA kernels (row f4)
         return None
 
-    def fused_residual(self, x, resid=None, context=None, context_mask=None, mask=None, rotary_pos_emb=None, chain=None):
+    def fused_residual(self, x, resid=None, context=None, context_mask=None, mask=None, rotary_pos_emb=None, chain=None, minus=False):
         """x_out = (resid if given else x) + postnorm(fn(prenorm(x)))  as one autograd node.
+        minus (with resid; the reversible reconstruction): the VALUE is resid - postnorm(...), the backward stays that of the sum -- the
+        node then returns a reversible block's input (x2 = y2 - g(y1)) and, fed the block's output gradient, g's gradients.
         chain = (handoff_in or None, next SandwichNorm or None, next block's fmap, handoff_out dict): lets this block's post-norm
         kernel also emit the next block's pre-norm output (see ops.SandwichBlockFn)"""
         B, n, D = x.shape
@@ -193,6 +195,9 @@ class SandwichNorm(nn.Module):
             if D % 32:
                 raise RuntimeError('fused token shift needs dim % 32 == 0')
             meta['shift'] = (n, fmap)
+        if minus:
+            assert resid is not None and chain is None
+            meta['resid_minus'] = True
         if chain is not None:
             hin, nxt, nxt_fmap, hout = chain[:4]
             nxt_ctx = chain[4].get('context') if len(chain) > 4 else None        # the next block's text context (cross-attention)
@@ -745,29 +750,33 @@ class ReversibleBlock(nn.Module):
         f, g = self.f.net, self.g.net
         fuse_f = isinstance(f, SandwichNorm) and y1.is_cuda and f._inner(f_args.get('context'), seq_len=y1.shape[1]) is not None
         fuse_g = isinstance(g, SandwichNorm) and g._inner() is not None and y1.is_cuda
-        # g(y1) again.  Fused form: one node computes (-y2) + g(y1) = -x2, whose gradient w.r.t. y1 and g's parameters is g's.
+        # g(y1) again.  Fused form: one node whose value is y2 - g(y1) = x2 (the post-norm kernel subtracts: no negation passes over the
+        # stream -- four of them per block, 6 % of the cfg-4 step, in the (-y2) + g(y1) = -x2 form of rounds 2-4; the same bits) and whose
+        # gradient w.r.t. y1 and g's parameters is g's.
         with torch.enable_grad():
             y1g = y1.detach().requires_grad_(True)
             if fuse_g:
-                neg_x2 = g.fused_residual(y1g, resid=-y2)
-                torch.autograd.backward(neg_x2, dy2)
+                x2n = g.fused_residual(y1g, resid=y2, minus=True)
+                x2n.grad_fn.dx_add = dy1                  # (the node's backward returns dy1 + dL/dy1: ops.SandwichBlockFn.backward)
+                torch.autograd.backward(x2n, dy2)
             else:
                 gy1 = g(y1g, **g_args)
                 torch.autograd.backward(gy1, dy2)
         with torch.no_grad():
-            x2 = -neg_x2.detach() if fuse_g else y2 - gy1.detach()
-            dx1 = dy1 + y1g.grad
+            x2 = x2n.detach() if fuse_g else y2 - gy1.detach()
+            dx1 = y1g.grad if fuse_g else dy1 + y1g.grad
         with torch.enable_grad():
             x2g = x2.detach().requires_grad_(True)
             if fuse_f:
-                neg_x1 = f.fused_residual(x2g, resid=-y1, **{k: f_args.get(k) for k in ('context', 'context_mask', 'mask', 'rotary_pos_emb')})
-                torch.autograd.backward(neg_x1, dx1)
+                x1n = f.fused_residual(x2g, resid=y1, minus=True, **{k: f_args.get(k) for k in ('context', 'context_mask', 'mask', 'rotary_pos_emb')})
+                x1n.grad_fn.dx_add = dy2
+                torch.autograd.backward(x1n, dx1)
             else:
                 fx2 = f(x2g, **f_args)
                 torch.autograd.backward(fx2, dx1)
         with torch.no_grad():
-            x1 = -neg_x1.detach() if fuse_f else y1 - fx2.detach()
-            dx2 = dy2 + x2g.grad
+            x1 = x1n.detach() if fuse_f else y1 - fx2.detach()
+            dx2 = x2g.grad if fuse_f else dy2 + x2g.grad
         return x1, x2, dx1, dx2
 
 

@@ -665,7 +665,7 @@ class SandwichBlockFn(Function):
                                                        nxt[1].detach(), next_shift=nxt[2], next_f16=nxt16)
             hout.update(h=hn, m1=mn, r1=rn, ptr=xo.data_ptr(), ver=xo._version, shift=nxt[2], ctx=ctx if CHAIN_BWD else None)
         else:
-            xo, m2, r2 = K.ln_fwd(y, post_w.detach(), post_b.detach(), resid=r2_)
+            xo, m2, r2 = K.ln_fwd(y, post_w.detach(), post_b.detach(), resid=r2_, minus=bool(meta.get('resid_minus')))
         ctx.meta, ctx.inner_saved, ctx.p = meta, saved, p
         ctx.has_ctx = context is not None
         ctx.has_resid = resid is not None
@@ -688,7 +688,9 @@ class SandwichBlockFn(Function):
         ho, ctx.bwd_handoff = getattr(ctx, 'bwd_handoff', None), None
         bw16 = getattr(ctx, 'bw16', False)
         s2 = ho.get('s2') if ho is not None else None          # the gradient scale of this backward pass (fp16-gradient blocks)
-        if s2 is None and K.bwd_f16():
+        # (only where this block or the one its chained LayerNorm backward feeds runs on fp16 gradients: a reversible stack -- no such block --
+        #  paid one amax pass over the stream per block for a scale nobody read: cfg 4 -4 %)
+        if s2 is None and K.bwd_f16() and (bw16 or getattr(ctx.prev_ctx, 'bw16', False)):
             s2 = _grad_scale(g2)
         if ho is not None and ho['ptr'] == g2.data_ptr() and ho['ver'] == g2._version and isinstance(ho['dy'], K.G16) == bw16:   # the next block's backward already ran this post-norm backward
             dy, dpost_w, dpost_b, dsum = ho['dy'], ho['dw'], ho['db'], ho['dsum']
@@ -710,8 +712,13 @@ class SandwichBlockFn(Function):
                 shift=ctx.shift, want_dsum=prev.meta['kind'] == 's3', out_f16=s2 if p16 else None)
             prev.bwd_handoff = dict(ptr=dx.data_ptr(), ver=dx._version, dy=dyp, dw=dwp, db=dbp, dsum=dsp, s2=s2)
         else:
-            dx, dpre_w, dpre_b, _ = K.ln_bwd(dh, x2, m1, r1, pre_w.detach(), dres=None if ctx.has_resid else g2,
-                                             shift=ctx.shift)
+            # (dx_add: a gradient the caller would add to dx anyway -- the reversible reconstruction's dy1 + dL/dy1 -- rides in as the pre-norm
+            #  backward's accumulator, as the residual-stream gradient does on the plain stack: no separate add pass over the stream)
+            add = getattr(ctx, 'dx_add', None)
+            ctx.dx_add = None
+            if add is not None:
+                add = add.detach().contiguous().reshape(B * n, D)
+            dx, dpre_w, dpre_b, _ = K.ln_bwd(dh, x2, m1, r1, pre_w.detach(), dres=(add if ctx.has_resid else g2), shift=ctx.shift)
         ctx.prev_ctx = None
         dcontext = None
         if ctx.has_ctx:

@@ -356,13 +356,13 @@ def _rev_step(block, xg, y, dy, extra=(), **kw):
     """One reversal step of a reversible half: y = x_prev + block(xg, *extra, **kw).  Returns x_prev (no graph) after
     back-propagating dy through a freshly recomputed block: gradients land in xg.grad, in the .grad of any `extra` / `context`
     leaf, and accumulate into the block's parameters (the role of reversible_video_audio.py:246-327).  On the fused libamdnuwa
-    node the recomputation and the subtraction are one pass: (-y) + block(xg) = -x_prev."""
+    node the recomputation and the subtraction are one pass: the node's value is y - block(xg) = x_prev (`minus`)."""
     inner_kw = {a: b for a, b in kw.items() if a in ('context', 'context_mask')}
     with torch.enable_grad():
         if not extra and isinstance(block, SandwichNorm) and xg.is_cuda and block._inner(inner_kw.get('context')) is not None:
-            neg = block.fused_residual(xg, resid=-y, **inner_kw)
-            torch.autograd.backward(neg, dy)
-            return -neg.detach()
+            xp = block.fused_residual(xg, resid=y, minus=True, **inner_kw)
+            torch.autograd.backward(xp, dy)
+            return xp.detach()
         out = block(xg, *extra, **{a: b for a, b in kw.items() if b is not None})
         torch.autograd.backward(out, dy)
         return y - out.detach()

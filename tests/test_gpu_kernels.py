@@ -149,6 +149,11 @@ def test_layernorm_fwd_bwd(K, R, D):
         report(f'ln_fwd_pre[{R},{D}]', bf_value(out), y_ref.detach(), 2e-5)
         yo, m2, r2 = K.ln_fwd(xd, wd, bd, resid=rd)
         report(f'ln_fwd_post[{R},{D}]', yo, (y_ref + res).detach(), 2e-6)
+        # resid - LN(x) (the reversible reconstruction x2 = y2 - g(y1)): the bits of -((-resid) + LN(x)), the two-negation form it replaced
+        ym, _, _ = K.ln_fwd(xd, wd, bd, resid=rd, minus=True)
+        yn, _, _ = K.ln_fwd(xd, wd, bd, resid=-rd)
+        assert torch.equal(ym, -yn)
+        report(f'ln_fwd_post_minus[{R},{D}]', ym, (res - y_ref).detach(), 2e-6)
         dx, dw, db, ds = K.ln_bwd(g.to(DEV), xd, m2, r2, wd, to_bf=True, want_dsum=True)
         report(f'ln_bwd_dx_bf[{R},{D}]', bf_value(dx), x.grad, 3e-5)
         report(f'ln_bwd_dw[{R},{D}]', dw, w.grad, 1e-5)
