@@ -558,8 +558,25 @@ INNERS = {'s3': S3Inner, 'xattn': XInner, 'ff': FFInner, 'xc2': XC2Inner}
 FUSE_LINEAR_CE = os.environ.get('AMDNUWA_FUSE_LINEAR_CE', '1') != '0'   # to_logits + cross entropy without the fp32 logits (A/B switch)
 # ... in 'bf16x3-fwd' (hi + lo logits): OFF by default.  The fused form needs the three-MFMA product twice (statistics, then dlogits -- the
 # latter on one fp16 MFMA) where the unfused one writes the fp32 logits once and reads them once: measured 532.5-534.1 against 530.2-530.7 ms
-# per step at b = 128, for 9 GB less peak memory (243 -> 234 GB).  Set AMDNUWA_FUSE_LINEAR_CE_X3=1 when the memory matters more.
-FUSE_LINEAR_CE_X3 = os.environ.get('AMDNUWA_FUSE_LINEAR_CE_X3', '0') == '1'
+# per step at b = 128, for 9 GB less peak memory (243 -> 234 GB).  AMDNUWA_FUSE_LINEAR_CE_X3 = 1 turns it on -- a trainer that runs the WHOLE
+# reference step at b = 128 wants it: with tokenizer, text encoder and optimiser state next to the decoder the unfused step sits at 244 GiB of
+# 288 and ran 708-919 ms depending on how often the allocator had to retry; fused it runs 701-713 ms at 235 GiB (tools/full_step.py turns it on
+# from b = 112).  'auto' = fused when the fp32 logits + bf16 dlogits would push the device past AMDNUWA_FUSE_LINEAR_CE_X3_MEM_FRAC of its memory.
+_F = os.environ.get('AMDNUWA_FUSE_LINEAR_CE_X3', '0')
+FUSE_LINEAR_CE_X3 = True if _F == '1' else ('auto' if _F == 'auto' else False)
+FUSE_LINEAR_CE_X3_MEM_FRAC = float(os.environ.get('AMDNUWA_FUSE_LINEAR_CE_X3_MEM_FRAC', '0.82'))
+
+
+def _fuse_ce_x3(rows, classes, device):
+    if FUSE_LINEAR_CE_X3 != 'auto':
+        return bool(FUSE_LINEAR_CE_X3)
+    if device.type != 'cuda':
+        return False
+    need = rows * classes * (4 + 2)             # fp32 logits + bf16 dlogits
+    total = torch.cuda.get_device_properties(device).total_memory
+    return torch.cuda.memory_allocated(device) + need > FUSE_LINEAR_CE_X3_MEM_FRAC * total
+
+
 FUSE_GEGLU_BWD = os.environ.get('AMDNUWA_FUSE_GEGLU_BWD', '1') != '0'   # gate backward inside the dgg GEMM epilogue (A/B switch)
 CHAIN_BWD = os.environ.get('AMDNUWA_CHAIN_BWD', '1') != '0'      # chain the LayerNorm backwards across block boundaries (A/B switch)
 def _fast():
@@ -877,9 +894,10 @@ class LogitsLossFn(Function):
         B, n, D = x.shape
         x2 = x.detach().contiguous().reshape(B * n, D)
         W = cache.get('logits', (wl,), lambda: dict(w=_cast(wl), wT=_cast_t(wl)))
-        if K.mixed() and FUSE_LINEAR_CE_X3 and 'w16' not in W:       # fp16 copy for the dlogits pass of the fused cross entropy (None: outside the fp16 range)
+        fuse_x3 = K.mixed() and _fuse_ce_x3(B * n, wl.shape[0], x.device)
+        if fuse_x3 and 'w16' not in W:       # fp16 copy for the dlogits pass of the fused cross entropy (None: outside the fp16 range)
             W['w16'] = wl.detach().to(torch.float16).contiguous() if f16_weights_ok(wl) else None
-        use_fused = FUSE_LINEAR_CE_X3 if K.mixed() else FUSE_LINEAR_CE
+        use_fused = fuse_x3 if K.mixed() else FUSE_LINEAR_CE
         lx2 = not use_fused and _logits_f16x2(W, wl, B * n, D)
         hn, m, r, ia = K.ln_fwd(x2, nw.detach(), nb.detach(), stable=True, f16=lx2)
         if targets.dtype != torch.int64:

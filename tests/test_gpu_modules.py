@@ -228,6 +228,32 @@ def test_g5_with_the_fused_hi_lo_cross_entropy(A, monkeypatch):
         A.set_precision('bf16')
 
 
+def test_fused_cross_entropy_auto_policy_follows_the_memory_headroom(A, monkeypatch):
+    """AMDNUWA_FUSE_LINEAR_CE_X3 = auto (opt-in): the fused form exactly when the fp32 logits + dlogits would push the device past
+    the policy's fraction of its memory (what keeps the whole b = 128 step out of allocator retries), the unfused one otherwise"""
+    from nuwa_pytorch_amd import ops, kernels as K
+    Ar, P, G = load('g5_nuwa_tiny')
+    nuwa = _tiny_nuwa(A, False)
+    nuwa.load_state_dict(P, strict=False)
+    nuwa = nuwa.to(DEV).train()
+    run_mode(A, 'bf16x3-fwd')
+    try:
+        text, vid = Ar['text'].to(DEV), Ar['video_ids'].to(DEV)
+        monkeypatch.setattr(ops, 'FUSE_LINEAR_CE_X3', 'auto')
+        seen = []
+        real = K.linear_ce
+        monkeypatch.setattr(K, 'linear_ce', lambda *a, **k: (seen.append(1), real(*a, **k))[1])
+        monkeypatch.setattr(ops, 'FUSE_LINEAR_CE_X3_MEM_FRAC', 10.0)           # never tight
+        a = nuwa(text=text, video=vid, return_loss=True, cond_dropout_prob=0.).detach()
+        assert seen == []
+        monkeypatch.setattr(ops, 'FUSE_LINEAR_CE_X3_MEM_FRAC', 0.0)            # always tight
+        b = nuwa(text=text, video=vid, return_loss=True, cond_dropout_prob=0.).detach()
+        assert seen == [1]
+        report('g5[bf16x3-fwd, auto ce].loss_fused_vs_unfused', b.reshape(1), a.reshape(1), 2e-6)
+    finally:
+        A.set_precision('bf16')
+
+
 def test_missing_library_fails_loudly(A, monkeypatch):
     from nuwa_pytorch_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)

@@ -25,6 +25,11 @@ def main():
     ap.add_argument('--optimizer', action='store_true', help='add the fused clip(0.5) + AdamW step of the trainer (row f2)')
     args = ap.parse_args()
     dev = 'cuda'
+    # from b = 112 the fused to_logits + cross entropy (no fp32 logits: 9 GiB less at the peak) unless the environment says otherwise: at 244 of
+    # 288 GiB the unfused step ran 708-919 ms depending on the allocator's retries, fused 701-713 ms (profiles/r05o_full_step_auto_ce.txt)
+    from nuwa_pytorch_amd import ops
+    if 'AMDNUWA_FUSE_LINEAR_CE_X3' not in os.environ and args.batch >= 112:
+        ops.FUSE_LINEAR_CE_X3 = True
     torch.manual_seed(0)
     vae = A.VQGanVAE(dim=64, image_size=256, num_layers=4, vq_codebook_size=8192, use_vgg_and_gan=False)
     nuwa = A.NUWA(vae=vae, dim=512, max_video_frames=10, text_max_seq_len=256, text_enc_depth=6, enc_reversible=True, dec_depth=24,
@@ -55,7 +60,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(f'[{A.get_precision()}] full NUWA step (text encoder + VAE tokenizer + decoder fwd/bwd{" + clip + AdamW" if opt else ""}), cfg 3, b={b}: {dt * 1e3:.1f} ms/step, '
+    print(f'[{A.get_precision()}] full NUWA step (text encoder + VAE tokenizer + decoder fwd/bwd{" + clip + AdamW" if opt else ""}), cfg 3, b={b}, {'fused' if ops.FUSE_LINEAR_CE_X3 is True else ('auto' if ops.FUSE_LINEAR_CE_X3 else 'unfused')} logits + CE: {dt * 1e3:.1f} ms/step, '
           f'{2560 * b / dt:.0f} video-tokens/s, loss {float(loss.detach()):.4f}, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB')
 
 
