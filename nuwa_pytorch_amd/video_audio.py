@@ -320,31 +320,26 @@ class DualReversibleBlock(nn.Module):
         if self.kind != 'inter_modality_cross_attn':
             ckw = dict(context=context, context_mask=context_mask) if self.kind == 'intra_modality_cross_attn' else {}
             # video halves: y2 = x2 + g(y1), y1 = x1 + f(x2)
+            # (add = the gradient the step's input gradient is summed with: on the fused node it rides in as the pre-norm backward's accumulator)
             y1g = leaf(y1)
-            x2 = _rev_step(g, y1g, y2, dy2)
-            dx1 = dy1 + gr(y1g)
+            x2, dx1 = _rev_step(g, y1g, y2, dy2, add=dy1)
             x2g = leaf(x2)
-            x1 = _rev_step(f, x2g, y1, dx1, mask=video_mask, **ckw)
-            dx2 = dy2 + gr(x2g)
+            x1, dx2 = _rev_step(f, x2g, y1, dx1, add=dy2, mask=video_mask, **ckw)
             # audio halves: n2 = m2 + k(n1), n1 = m1 + j(m2)
             n1g = leaf(n1)
-            m2 = _rev_step(k, n1g, n2, dn2)
-            dm1 = dn1 + gr(n1g)
+            m2, dm1 = _rev_step(k, n1g, n2, dn2, add=dn1)
             m2g = leaf(m2)
-            m1 = _rev_step(j, m2g, n1, dm1, mask=audio_mask, **ckw)
-            dm2 = dn2 + gr(m2g)
+            m1, dm2 = _rev_step(j, m2g, n1, dm1, add=dn2, mask=audio_mask, **ckw)
             return x1, x2, m1, m2, dx1, dx2, dm1, dm2
         # cross-modality block: y1 = x1 + f(x2, m2); y2 = x2 + k(y1); n1 = m1 + j(m2, y2); n2 = m2 + g(n1)
         n1g = leaf(n1)
-        m2 = _rev_step(g, n1g, n2, dn2)
-        dm1 = dn1 + gr(n1g)
+        m2, dm1 = _rev_step(g, n1g, n2, dn2, add=dn1)
         m2g, y2g = leaf(m2), leaf(y2)
         m1 = _rev_step(j, m2g, n1, dm1, extra=(y2g,), mask=audio_mask, context_mask=video_mask)
         dm2 = dn2 + gr(m2g)
         dy2t = dy2 + gr(y2g)                              # the audio side looked at the updated video half
         y1g = leaf(y1)
-        x2 = _rev_step(k, y1g, y2, dy2t)
-        dx1 = dy1 + gr(y1g)
+        x2, dx1 = _rev_step(k, y1g, y2, dy2t, add=dy1)
         x2g, m2h = leaf(x2), leaf(m2)
         x1 = _rev_step(f, x2g, y1, dx1, extra=(m2h,), mask=video_mask, context_mask=audio_mask)
         dx2 = dy2t + gr(x2g)
@@ -352,20 +347,26 @@ class DualReversibleBlock(nn.Module):
         return x1, x2, m1, m2, dx1, dx2, dm1, dm2
 
 
-def _rev_step(block, xg, y, dy, extra=(), **kw):
+def _rev_step(block, xg, y, dy, extra=(), add=None, **kw):
     """One reversal step of a reversible half: y = x_prev + block(xg, *extra, **kw).  Returns x_prev (no graph) after
     back-propagating dy through a freshly recomputed block: gradients land in xg.grad, in the .grad of any `extra` / `context`
-    leaf, and accumulate into the block's parameters (the role of reversible_video_audio.py:246-327).  On the fused libamdnuwa
+    leaf, and accumulate into the block's parameters (the role of reversible_video_audio.py:246-327).  add: also returns add + xg.grad.
+    On the fused libamdnuwa
     node the recomputation and the subtraction are one pass: the node's value is y - block(xg) = x_prev (`minus`)."""
     inner_kw = {a: b for a, b in kw.items() if a in ('context', 'context_mask')}
     with torch.enable_grad():
         if not extra and isinstance(block, SandwichNorm) and xg.is_cuda and block._inner(inner_kw.get('context')) is not None:
             xp = block.fused_residual(xg, resid=y, minus=True, **inner_kw)
+            if add is not None:
+                xp.grad_fn.dx_add = add                  # (xg.grad = add + dL/dxg: ops.SandwichBlockFn.backward)
             torch.autograd.backward(xp, dy)
-            return xp.detach()
+            return xp.detach() if add is None else (xp.detach(), xg.grad)
         out = block(xg, *extra, **{a: b for a, b in kw.items() if b is not None})
         torch.autograd.backward(out, dy)
-        return y - out.detach()
+        x_prev = y - out.detach()
+    if add is None:
+        return x_prev
+    return x_prev, (add + xg.grad if xg.grad is not None else add)
 
 
 def _residual_to(block, x, resid, **kw):
