@@ -87,3 +87,19 @@ def test_profiles_readme_lists_only_files_that_exist():
             if '*' not in name and name not in have:
                 missing.append(name)
     assert not missing, missing
+
+
+def test_committed_pmc_traffic_belongs_to_the_current_gemm_kernels():
+    """bench.py refuses a PMC traffic figure taken on other kernel sources (roofline.traffic = null).  The figure of the headline
+    configuration must therefore be re-taken (tools/gpu_final_r05.sh; copy gpurun_out/<TAG>_traffic.json over profiles/traffic.json)
+    whenever csrc/gemm.hip changes: a stale file fails HERE, not silently in the round's final bench line."""
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, 'profiles', 'traffic.json')) as f:
+        entry = json.load(f)['cfg3_b128_bf16x3-fwd']
+    h = hashlib.sha256()
+    with open(os.path.join(root, 'nuwa_pytorch_amd', 'csrc', 'gemm.hip'), 'rb') as f:
+        h.update(f.read())
+    assert entry['src_sha16'] == h.hexdigest()[:16], 'profiles/traffic.json is stale: re-take the FETCH_SIZE / WRITE_SIZE passes'
+    assert entry['bytes_per_launch'] > 1e9

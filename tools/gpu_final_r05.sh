@@ -1,7 +1,8 @@
 #!/bin/bash
 # the evidence run of round 5 on ONE box (TAG=r05m mid-round, r05z final): reproducibility stress at b = 128 x 10, GPU suite, FETCH / WRITE
 # passes of the default config (bench.py's roofline.traffic), two SQ passes (MFMA busy, LDS), the default bench line, its kernel stats,
-# attention tools, the whole reference step, side configurations
+# attention tools, the whole reference step, side configurations.  AFTER the call: copy gpurun_out/${TAG}_traffic.json over profiles/traffic.json (the
+# file the script updates lives on the box; tests/test_cabi_symbols.py fails on a stale one) and the gpurun_out/${TAG}_* summaries into profiles/
 TAG=${TAG:-r05z}
 mkdir -p gpurun_out; export PYTHONUNBUFFERED=1 TMPDIR=/tmp
 R=$PWD
