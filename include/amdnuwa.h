@@ -33,7 +33,7 @@ int amdnuwa_abi_version(void);                 /* bumps when any signature or do
                                                 * amdnuwa_xattn_unpack's flag bit 1, chunk-permuted dS / Pm columns of amdnuwa_xattn2_bwd;
                                                 * 14: amdnuwa_linear_ce_x3 added; 15: the two-MFMA products -- amdnuwa_gemm_desc.ab_f16 with Blo, amdnuwa_gemm_nt_f16x2_supported,
                                                 *     o_lo_f16 on the two fp16 forward cores; 16: the fp16-gradient backward; 17: amdnuwa_gemm_desc.a_chunk32, amdnuwa_gemm_tn_chunked_a_supported,
-                                                *     amdnuwa_xattn2_bwd_ex, AMDNUWA_LN_RESID_MINUS, tuning key 25) */
+                                                *     amdnuwa_xattn2_bwd_ex, AMDNUWA_LN_RESID_MINUS, tuning key 25; 18: the amdnuwa_xattn6_* family) */
 const char* amdnuwa_error_string(int code);
 /* runtime tuning knobs (A/B benchmarking only; 0 = the library's auto policy everywhere):
  *   key 0  NT GEMM variant: 1 direct-to-LDS BK 64, 2 direct-to-LDS BK 32, 3 / 4 256x256 tile with a 4- / 3-stage DMA ring,
@@ -480,6 +480,24 @@ int amdnuwa_xattn2_bwd_rc(const amdnuwa_xattn_geom* g, const uint16_t* q, int ld
                           const amdnuwa_xattn_kv* packed, const float* w_th, const float* stats, uint16_t* dq, int lddq,
                           float* part_th, size_t part_bytes, float* nbd, size_t nbd_bytes, float* dKp, float* dVp,
                           amdnuwa_stream stream);
+/* ---- cross-attention core, third design ("xattn6", ABI 18; reference nuwa_pytorch.py:339-378): heads == 8, dim_head == 64, ANY context
+ * length T >= 1 (g->JP is ignored).  Keys / values travel as images in the kernels' LDS order, written once per layer call by
+ * amdnuwa_xattn6_pack from the 16-bit to_kv(context) rows: K6 / V6 [B][nch][heads][32][64] 16-bit with nch = amdnuwa_xattn6_nch(T) =
+ * 2 * ceil(T / 64) chunks of 32 keys (K pre-multiplied by scale * log2 e; V transposed, key slots in the lanes' order; bank swizzles baked in),
+ * vbits [B][nch]: bit j of word c = context key 32 c + j exists and passes context_mask.  The learned null key / value (np.py:343-347) are
+ * NOT image rows: the kernels take null_k / null_v [heads][dim_head] fp32 and treat the null key as a rank-one term.
+ * f16 != 0: q16 / kv16 and the images are fp16 and every MFMA is the fp16 one ('bf16x3-fwd'); else bf16.
+ * stats [B][heads][n][2] as amdnuwa_xattn2_fwd writes them (any reference maximum m in the log2 domain, 1 / sum of exp2(s - m) incl. the
+ * null key): what amdnuwa_xattn2_bwd* recompute the probabilities from.  o / o_lo / o_lo_f16 as amdnuwa_xattn2_fwd_f16. */
+typedef struct { uint16_t *K6, *V6; uint32_t* vbits; } amdnuwa_xattn6_kv;
+int amdnuwa_xattn6_supported(const amdnuwa_xattn_geom* g);
+int amdnuwa_xattn6_nch(int T);
+size_t amdnuwa_xattn6_image_bytes(const amdnuwa_xattn_geom* g);      /* bytes of K6 (and of V6); vbits: B * nch words */
+int amdnuwa_xattn6_pack(const amdnuwa_xattn_geom* g, const uint16_t* kv16, int ldkv, const uint8_t* context_mask, int f16,
+                        const amdnuwa_xattn6_kv* out, amdnuwa_stream stream);
+int amdnuwa_xattn6_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q16, int ldq, const amdnuwa_xattn6_kv* kv, const float* null_k,
+                       const float* null_v, const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, int o_lo_f16, float* stats,
+                       int f16, amdnuwa_stream stream);
 /* Text cross-attention (Attention.forward with context, np.py:339-378) for ONE query row per sample (g->n must be 1):
  * q [B, ldq] unscaled, keys / values as packed by amdnuwa_xattn_pack (Kp / Vp images and the valid map), o [B, ldo]. */
 int amdnuwa_xattn_decode(const amdnuwa_xattn_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq,

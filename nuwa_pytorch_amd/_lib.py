@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # AMDNUWA_LIBRARY: another build of the same library (A/B runs of compiler options inside one process group; tools/ only)
 LIB_PATH = os.environ.get('AMDNUWA_LIBRARY') or os.path.join(HERE, 'lib', 'libamdnuwa.so')
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 P = C.c_void_p
 I = C.c_int
@@ -41,12 +41,16 @@ class XKV(C.Structure):
                 ('valid', P)]
 
 
+class X6KV(C.Structure):
+    _fields_ = [('K6', P), ('V6', P), ('vbits', P)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [('N', I), ('Cin', I), ('H', I), ('W', I), ('Cout', I), ('KH', I), ('KW', I), ('stride', I), ('pad', I),
                 ('Ho', I), ('Wo', I), ('leaky', I)]
 
 
-GD, SG, XG, XK, CD = (C.POINTER(t) for t in (GemmDesc, S3Geom, XGeom, XKV, ConvDesc))
+GD, SG, XG, XK, CD, X6 = (C.POINTER(t) for t in (GemmDesc, S3Geom, XGeom, XKV, ConvDesc, X6KV))
 
 # name -> (restype, argtypes).  Mirrors include/amdnuwa.h declaration by declaration.
 SIGNATURES = {
@@ -120,6 +124,11 @@ SIGNATURES = {
     'amdnuwa_xattn2_bwd_workspace_bytes': (SZ, [XG]),
     'amdnuwa_xattn2_bwd': (I, [XG, P, I, P, I, XK, P, P, P, P, P, I, P, SZ, P]),
     'amdnuwa_xattn2_bwd_ex': (I, [XG, P, I, P, I, XK, P, P, P, P, P, I, P, SZ, I, P]),
+    'amdnuwa_xattn6_supported': (I, [XG]),
+    'amdnuwa_xattn6_nch': (I, [I]),
+    'amdnuwa_xattn6_image_bytes': (SZ, [XG]),
+    'amdnuwa_xattn6_pack': (I, [XG, P, I, P, I, X6, P]),
+    'amdnuwa_xattn6_fwd': (I, [XG, P, I, X6, P, P, P, P, P, I, I, P, I, P]),
     'amdnuwa_xattn2_bwd_rc_supported': (I, [XG]),
     'amdnuwa_xattn2_bwd_rc_stats_bytes': (SZ, [XG]),
     'amdnuwa_xattn2_bwd_rc': (I, [XG, P, I, P, I, XK, P, P, P, I, P, SZ, P, SZ, P, P, P]),

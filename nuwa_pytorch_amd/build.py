@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libamdnuwa.so')
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'amdnuwa.h')
-SOURCES = ['api.hip', 'gemm.hip', 'elementwise.hip', 'sparse3dna.hip', 'xattn.hip', 'xattn2.hip', 'vae.hip', 'optim.hip', 'decode.hip', 'comm.hip']
+SOURCES = ['api.hip', 'gemm.hip', 'elementwise.hip', 'sparse3dna.hip', 'xattn.hip', 'xattn2.hip', 'xattn6.hip', 'vae.hip', 'optim.hip', 'decode.hip', 'comm.hip']
 ARCH = 'gfx950'
 # Flags of every device compile of the SHIPPED library: no packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).
 # Round 4 found the head-mix loop of the two-row Sparse3DNA forward tile returning wrong LOW halves out of a packed-FMA sequence once two

@@ -1124,6 +1124,58 @@ def xattn2_fwd_f16(g, q, pk, wth, o_f16=False):
     return o, stats
 
 
+class PackedKV6:
+    """key / value images of the xattn6 cross-attention kernels (amdnuwa_xattn6_pack): K6 / V6 [B, nch, heads, 32, 64] 16-bit in the
+    kernels' LDS order, vbits [B, nch] (bit j of word c: context key 32 c + j takes part)"""
+
+    def __init__(self, g, device, f16):
+        L = _lib.lib()
+        self.nch = L.amdnuwa_xattn6_nch(g.T)
+        dt = torch.float16 if f16 else torch.bfloat16
+        sh = (g.B, self.nch, g.heads, 32, g.dim_head)
+        self.K6, self.V6 = torch.empty(sh, dtype=dt, device=device), torch.empty(sh, dtype=dt, device=device)
+        self.vbits = torch.empty((g.B, self.nch), dtype=torch.int32, device=device)
+        self.f16 = bool(f16)
+        s = _lib.X6KV()
+        s.K6, s.V6, s.vbits = _p(self.K6), _p(self.V6), _p(self.vbits)
+        self.struct = s
+
+
+def xattn6_supported(g):
+    return bool(_lib.lib().amdnuwa_xattn6_supported(C.byref(g)))
+
+
+def xattn6_pack(g, kv16, mask_u8, out=None):
+    """kv16: [B*T, ld] fp16 or bf16 tensor, keys in columns [0, inner), values in [inner, 2 inner) (= to_kv(context))"""
+    f16 = kv16.dtype == torch.float16
+    assert kv16.dtype in (torch.float16, torch.bfloat16) and kv16.stride(1) == 1
+    pk = out if out is not None else PackedKV6(g, kv16.device, f16)
+    assert pk.f16 == f16
+    check(_lib.lib().amdnuwa_xattn6_pack(C.byref(g), _p(kv16), kv16.stride(0), _p(mask_u8), 1 if f16 else 0, C.byref(pk.struct), _stream()),
+          'amdnuwa_xattn6_pack')
+    return pk
+
+
+def xattn6_fwd(g, q16, pk, null_k, null_v, wth, o_f16=False, lo=True):
+    """the xattn6 forward core on q16 [B*n, ld] (fp16 with fp16 images: every MFMA the fp16 one; else bf16).  Returns o BF [B*n, inner]
+    (hi + lo pair; with o_f16 a bf16 copy + an fp16 copy; lo=False: the bf16 copy alone) and the softmax statistics [B, h, n, 2]"""
+    L = _lib.lib()
+    f16 = q16.dtype == torch.float16
+    assert pk.f16 == f16 and q16.stride(1) == 1
+    inner = g.heads * g.dim_head
+    dev = q16.device
+    if o_f16:
+        o = BF(torch.empty((g.B * g.n, inner), dtype=torch.bfloat16, device=dev), None,
+               torch.empty((g.B * g.n, inner), dtype=torch.float16, device=dev))
+    else:
+        o = empty_bf((g.B * g.n, inner), dev, lo=lo)
+    stats = torch.empty((g.B, g.heads, g.n, 2), dtype=torch.float32, device=dev)
+    check(L.amdnuwa_xattn6_fwd(C.byref(g), _p(q16), q16.stride(0), C.byref(pk.struct), _p(null_k), _p(null_v), _p(wth), _p(o.hi),
+                               _p(o.f16 if o_f16 else o.lo), inner, 1 if o_f16 else 0, _p(stats), 1 if f16 else 0, _stream()),
+          'amdnuwa_xattn6_fwd')
+    return o, stats
+
+
 def xattn_fwd(g, q, pk, wth, save=True, want_stats=False):
     """first-design kernel (bf16 or bf16x3).  save: keep P / P' for amdnuwa_xattn_bwd.  want_stats: return the softmax statistics
     [B, h, n, 2] the recomputing backward (xattn2_bwd) takes instead -- (o, stats) is then the result."""

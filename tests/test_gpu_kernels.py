@@ -1029,6 +1029,50 @@ def test_cross_attention_fwd_f16_core(K, O, B, n, T):
     report(f'xattn_fwd_f16_vs_bf16[{B},{n},{T}]', bf_value(o), o2.hi.float(), 3e-2)
 
 
+@pytest.mark.parametrize('B,n,T', [(2, 100, 33), (1, 64, 256), (2, 2560, 256), (3, 70, 1), (2, 130, 64), (1, 200, 300)])
+@pytest.mark.parametrize('f16', [True, False])
+def test_cross_attention_xattn6_fwd(K, O, B, n, T, f16):
+    """the third-design forward core (images in LDS order, K pre-scaled into the log2 domain, the key mask as the C operand of the score MFMAs,
+    the null key as a rank-one term -- any context length) against the oracle on the same 16-bit-rounded inputs; its statistics
+    reproduce the probabilities (checked through the old kernel's statistics: same normaliser up to the operand rounding)"""
+    heads, dh = 8, 64
+    inner = heads * dh
+    torch.manual_seed(11)
+    q, kv = torch.randn(B * n, inner), torch.randn(B * T, 2 * inner)
+    nk, nv = torch.randn(heads, dh), torch.randn(heads, dh)
+    wth = torch.randn(heads, heads) * 0.5 + torch.eye(heads)
+    mask = torch.rand(B, T) > 0.3
+    mask[0] = False                     # a fully masked sample attends only the null key
+    dt = torch.float16 if f16 else torch.bfloat16
+    q16, kv16 = q.to(dt).to(DEV), kv.to(dt).to(DEV)
+    kv4 = kv16.float().cpu().reshape(B, T, 2, heads, dh)
+    o_ref = O.attention_core(q16.float().cpu().reshape(B, n, heads, dh), kv4[:, :, 0], kv4[:, :, 1], nk, nv, wth, mask, dh ** -0.5)
+    g = K.x_geom(B, n, T, heads, dh)
+    assert K.xattn6_supported(g)
+    pk = K.xattn6_pack(g, kv16, mask.to(torch.uint8).to(DEV))
+    o, stats = K.xattn6_fwd(g, q16, pk, nk.to(DEV), nv.to(DEV), wth.to(DEV))
+    tag = f'[{B},{n},{T},f16={f16}]'
+    report('xattn6_fwd' + tag, bf_value(o).reshape(B, n, heads, dh), o_ref, 1e-3 if f16 else 2 ** -7)
+    # the fp16 copy of the output (what the two-MFMA to_out product reads)
+    o2, _ = K.xattn6_fwd(g, q16, pk, nk.to(DEV), nv.to(DEV), wth.to(DEV), o_f16=True)
+    assert torch.equal(o2.hi, o.hi)
+    report('xattn6_fwd.o_f16' + tag, o2.f16.float().reshape(B, n, heads, dh), o_ref, 1e-3 if f16 else 2 ** -7)
+    # statistics: log2-domain normaliser  log2(sum_j exp2(s_j)) = m + log2(1 / il)  against fp32 torch on the same operands
+    sc = torch.einsum('bihd,bjhd->bhij', q16.float().cpu().reshape(B, n, heads, dh), kv4[:, :, 0]) * (dh ** -0.5)
+    sn = torch.einsum('bihd,hd->bhi', q16.float().cpu().reshape(B, n, heads, dh), nk) * (dh ** -0.5)
+    sc = sc.masked_fill(~mask[:, None, None, :], float('-inf'))
+    lse = torch.logsumexp(torch.cat([sn[..., None], sc], dim=-1), dim=-1) * math.log2(math.e)
+    got = stats[..., 0].cpu() - torch.log2(stats[..., 1].cpu())
+    assert (got - lse).abs().max().item() < (2e-2 if f16 else 1e-1), (got - lse).abs().max().item()
+    if T + 1 <= 287:
+        # and the old pair (xattn_pack + xattn4): same result up to the rounding of K * c1 / the null key's fp32 treatment
+        kvp = K.BF(kv16.to(torch.bfloat16) if f16 else kv16, None, kv16 if f16 else None)
+        if f16:
+            pko = K.xattn_pack(g, kvp, nk.to(DEV), nv.to(DEV), mask.to(torch.uint8).to(DEV))
+            o4, _ = K.xattn2_fwd_f16(g, K.BF(q16.to(torch.bfloat16), None, q16), pko, wth.to(DEV))
+            report('xattn6_vs_xattn4' + tag, bf_value(o), bf_value(o4), 2e-3)
+
+
 def test_gemm_nt_fp16_operands_and_ln_fp16_copy(K):
     """the FeedForward forward of 'bf16x3-fwd': LayerNorm stores a bf16 + fp16 copy pair, FF1 runs on the fp16 MFMA with the gate in its
     epilogue (u bf16 for the backward, gate output as fp16 + bf16 copies), FF2 on the fp16 MFMA to fp32 -- against fp64 on the same
