@@ -55,7 +55,7 @@ EXTRA_FLAGS = {'xattn2.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 # (round 4's cure) / written freely (fails the stress: the experiment that separated the two cures); 'pin': the shipped flags + the pin.
 # The host pass ignores the feature flag.
 NOPK_FLAGS = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
-VARIANTS = {'': [], 'pk': ['-DS3_MIX_PIN=1'], 'pk_nofix': ['-DS3_MIX_PIN=0'], 'pin': ['-DS3_MIX_PIN=1']}
+VARIANTS = {'': [], 'pk': ['-DS3_MIX_PIN=1'], 'pk_nofix': ['-DS3_MIX_PIN=0'], 'pin': ['-DS3_MIX_PIN=1'], 'x6t': ['-DX6_TIMING=1']}
 
 
 def lib_path(variant=''):

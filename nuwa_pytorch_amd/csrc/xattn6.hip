@@ -17,6 +17,7 @@
 // The structure is xattn4's otherwise: TWO waves per 16 queries, 4 heads each, probabilities exchanged through LDS for the head mix
 // on the matrix pipe (see xattn2.hip), O^T = V^T P'^T with the permuted-key trick, two passes (the head mix after the softmax forbids
 // an online rescale).  LDS: 2 x 64 KiB ring + 4 x 8 KiB exchange = 160 KiB.
+#include <type_traits>
 #include "common.h"
 #include "../../include/amdnuwa.h"
 
@@ -30,7 +31,7 @@ constexpr int TILE = 32 * DH * 2;            // one head's 32-key tile: 4 KiB
 constexpr int KT = NH * TILE;                // one chunk of K (or of V^T), all heads: 32 KiB
 constexpr int STAGE = 2 * KT;                // pass 2: K + V^T of a chunk
 constexpr int XT = 8 * 1024;                 // exchange area of one query tile: 8 slots x 64 lanes x 16 bytes
-constexpr int LDS_BYTES = 2 * STAGE + 4 * XT;
+constexpr int LDS_BYTES = 4 * KT + 4 * XT;
 constexpr float MASK_BIAS = -60000.f;        // log2-domain score of a masked key: exp2(MASK_BIAS - max) == 0
 
 struct X6Args {
@@ -42,10 +43,35 @@ struct X6Args {
     uint16_t *o, *ol; int ldo, ol_f16;
     float* stats;                            // [B][NH][n][2] = (reference maximum in the log2 domain, 1 / sum of exp2)
     int B, n, nch;
+    int dbg;                                 // tuning key 18, timing probes only (garbage results): bit 0 no pass 1, bit 1 no pass 2 (loop bounds only)
     float c1;                                // scale * log2(e)
 };
 
+// One 1-KiB LDS-DMA piece with a SCALAR base: source = sbase (wave-uniform, SGPR pair) + voff (per-lane byte offset, one VGPR), lane l lands at
+// lds + 16 l.  (dma16_asm of common.h takes a per-lane 64-bit address: eight of them per stage call are 16 VGPRs the persistent kernel
+// does not have -- spilled, their reloads carried vmcnt(0) waits into the ring loops.)
+__device__ __forceinline__ void dma16_s(const char* sbase, uint32_t voff, void* lds) {
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_vptr_t)lds);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// build variant 'x6t' (-DX6_TIMING=1, tools only): s_memtime stamps of workgroup 0's first item, [wave][step][8]
+#ifndef X6_TIMING
+#define X6_TIMING 0
+#endif
+#if X6_TIMING
+__device__ unsigned long long* g_x6_stamps = nullptr;
+#define STAMP(step, k)                                                                                             \
+    do {                                                                                                           \
+        if (g_x6_stamps && blockIdx.x == 0 && item == (int)gridDim.x) {   /* the SECOND item of workgroup 0 */                                                         \
+            const unsigned long long t__ = __builtin_amdgcn_s_memtime();                                           \
+            if (lane == 0) g_x6_stamps[(wave * 16 + (step)) * 8 + (k)] = t__;                                      \
+        }                                                                                                          \
+    } while (0)
+#else
+#define STAMP(step, k) do { } while (0)
+#endif
 #define LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // byte offset of the 16-byte piece (8 d values from 8 gc) of key row `row` inside a head's K tile
@@ -106,244 +132,303 @@ __device__ __forceinline__ KF k_frags(const char* kbase, int h, int c, int g4) {
 
 template <bool F16>
 __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
+    // PERSISTENT: one workgroup per CU walks the (sample, 64-query tile) list; the ring prologue of the NEXT item is issued under the last
+    // chunks of this one.
+    // LDS: four 32-KiB ring slots + the exchange.  Pass 1 (K only): chunk ch in slot SL[ch & 3], SL = {0, 2, 1, 3}, two chunks per step.
+    // Pass 2: K of chunk c in slot 2 (c & 1), V^T of chunk c in slot 2 (c & 1) + 1.  Pass 2 is SKEWED by one chunk: iteration c runs the
+    // scores + softmax + exchange puts of chunk c next to the head mix + P'V of chunk c - 1 (independent instruction streams of one wave:
+    // the round-6 stamps showed 59 % of an un-skewed iteration in waits -- LDS round trips and two barriers in series with every phase).
+    // Hazards of iteration c, all closed by two barriers with almost nothing between them:
+    //   reads  xb(c-1) [exchange], kf(c) [K slot c&1] ............... then barrier P: every wave holds its xb(c-1) -> puts(c) may overwrite
+    //   reads  vf(c-1) [V slot (c-1)&1]; puts(c); DMA K(c+1) -> K slot (c+1)&1 (held K(c-1): read before Q(c-1)), V(c) -> V slot c&1
+    //   (held V(c-2): read before Q(c-1)) .......................... then vmcnt(0) + barrier Q: puts and pieces visible, all reads done
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = wave >> 1, hh = wave & 1;                   // query tile of the workgroup, head half (heads 4 hh .. 4 hh + 3)
     const int c = lane & 15, g4 = lane >> 4;
-    const int tiles = (a.n + 63) / 64;
-    // the workgroups of a sample stream the same images: keep them on one XCD (one L2)
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = bid / tiles, qi = (bid % tiles) * 64 + tile * 16 + c;
-    const bool qok = qi < a.n;
+    const int tiles = (a.n + 63) / 64, NT = a.B * tiles;
     const int nch = a.nch;
-    char* xch = smem + 2 * STAGE + tile * XT;
-    const char* k6 = a.K6 + (size_t)b * nch * KT;
-    const char* v6 = a.V6 + (size_t)b * nch * KT;
-    // the key-mask words of the sample (nch <= 64): one vector load here, a v_readlane per chunk later (a load inside the ring loops would
-    // be waited for with vmcnt(0), i.e. drain the DMA ring)
-    const uint32_t wv = lane < nch ? a.vbits[(size_t)b * nch + lane] : 0u;
+    char* xch = smem + 4 * KT + tile * XT;
     const int H0 = 4 * hh;
 
-    // K of chunk ch -> 32 KiB slot: 32 pieces, 4 per wave
-    auto stage_k = [&](int slot, int ch) {
+    // one 32-KiB image chunk -> ring slot: 32 pieces, 4 per wave
+    auto stage = [&](const char* img, int slot, int ch) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int piece = wave + 8 * i;
-            dma16_asm(k6 + (size_t)ch * KT + piece * 1024 + lane * 16, smem + slot * KT + piece * 1024);
+            dma16_s(img + (size_t)ch * KT + piece * 1024, lane * 16, smem + slot * KT + piece * 1024);
         }
     };
-    // K + V^T of chunk ch -> 64 KiB stage: 8 pieces per wave
-    auto stage_kv = [&](int stg, int ch) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave + 8 * i;
-            dma16_asm(k6 + (size_t)ch * KT + piece * 1024 + lane * 16, smem + stg * STAGE + piece * 1024);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave + 8 * i;
-            dma16_asm(v6 + (size_t)ch * KT + piece * 1024 + lane * 16, smem + stg * STAGE + KT + piece * 1024);
-        }
-    };
+    auto p1_slot = [](int ch) { return ((ch & 1) << 1) | ((ch >> 1) & 1); };      // SL = {0, 2, 1, 3}
+    // the workgroups of a sample stream the same images: the list is cut into one contiguous slab per XCD (workgroup w runs on XCD w % 8
+    // and takes items w, w + grid, ...: all of them = w (mod 8) as the grid is a multiple of 8)
+    auto sample_of = [&](int item) { return xcd_remap(item, NT) / tiles; };
 
-    // pass-1 ring prologue first: the images are on their way while q arrives
-    stage_k(0, 0); stage_k(1, 1);
-    if (nch > 2) { stage_k(2, 2); stage_k(3, 3); }
-
-    bf16x8 qf[NHH][KS];
-#pragma unroll
-    for (int h = 0; h < NHH; ++h)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            qf[h][ks] = ldg16(a.q + ((size_t)b * a.n + qi) * a.ldq + (H0 + h) * DH + ks * 32 + g4 * 8, qok);
     MixQ AW = mix_operand_q<F16>(a.wth, hh, lane);
-    // (pinned here: left to itself the compiler sinks the W loads to the head of pass 2 and waits for them with vmcnt(0) -- behind the
-    //  pass-2 ring prologue, whose DMA pieces that wait would drain)
+    // (pinned here: left to itself the compiler sinks the W loads to the head of pass 2 and waits for them with vmcnt(0) -- behind
+    //  ring pieces that wait would drain)
     asm volatile("" : "+v"(AW.hi), "+v"(AW.lo));
 
-    // ---- the null key: s_null[h] = c1 * q[h] . null_k[h] (fp32), the same value in all four lane groups of a query
-    float sn[NHH];
-#pragma unroll
-    for (int h = 0; h < NHH; ++h) {
-        float acc = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const float4 k0 = *reinterpret_cast<const float4*>(a.null_k + (H0 + h) * DH + ks * 32 + g4 * 8);
-            const float4 k1 = *reinterpret_cast<const float4*>(a.null_k + (H0 + h) * DH + ks * 32 + g4 * 8 + 4);
-            const uint4 u = __builtin_bit_cast(uint4, qf[h][ks]);
-            acc = fmaf(h2f<F16>((uint16_t)(u.x & 0xffff)), k0.x, acc); acc = fmaf(h2f<F16>((uint16_t)(u.x >> 16)), k0.y, acc);
-            acc = fmaf(h2f<F16>((uint16_t)(u.y & 0xffff)), k0.z, acc); acc = fmaf(h2f<F16>((uint16_t)(u.y >> 16)), k0.w, acc);
-            acc = fmaf(h2f<F16>((uint16_t)(u.z & 0xffff)), k1.x, acc); acc = fmaf(h2f<F16>((uint16_t)(u.z >> 16)), k1.y, acc);
-            acc = fmaf(h2f<F16>((uint16_t)(u.w & 0xffff)), k1.z, acc); acc = fmaf(h2f<F16>((uint16_t)(u.w >> 16)), k1.w, acc);
-        }
-        acc += __shfl_xor(acc, 16, 64);
-        acc += __shfl_xor(acc, 32, 64);
-        sn[h] = acc * a.c1;
+    int item = blockIdx.x;
+    if (item < NT) {                                             // pass-1 ring prologue of the first item
+        const char* k6 = a.K6 + (size_t)sample_of(item) * nch * KT;
+        stage(k6, p1_slot(0), 0); stage(k6, p1_slot(1), 1);
+        if (nch > 2) { stage(k6, p1_slot(2), 2); stage(k6, p1_slot(3), 3); }
     }
-
-    // ---- pass 1: running (reference maximum, sum of exp2) of this wave's 4 heads, 64 keys per ring step; the null key opens the sums
-    // (counted once: in lane group 0)
-    float m[NHH], l[NHH];
+    for (; item < NT; item += gridDim.x) {
+        STAMP(12, 0);
+        const int bid = xcd_remap(item, NT);
+        const int b = bid / tiles, qi = (bid % tiles) * 64 + tile * 16 + c;
+        const bool qok = qi < a.n;
+        const char* k6 = a.K6 + (size_t)b * nch * KT;
+        const char* v6 = a.V6 + (size_t)b * nch * KT;
+        const int nitem = item + gridDim.x;
+        const char* k6n = nitem < NT ? a.K6 + (size_t)sample_of(nitem) * nch * KT : nullptr;
+        // the key-mask words of the sample (nch <= 64): one vector load here, a v_readlane per chunk later (a load inside the ring loops
+        // would be waited for with vmcnt(0), i.e. drain the DMA ring)
+        const uint32_t wv = lane < nch ? a.vbits[(size_t)b * nch + lane] : 0u;
+        bf16x8 qf[NHH][KS];
 #pragma unroll
-    for (int h = 0; h < NHH; ++h) { m[h] = sn[h]; l[h] = g4 == 0 ? 1.f : 0.f; }
-    if (nch > 2) VMCNT(8); else VMCNT(0);
-    __builtin_amdgcn_s_barrier();                                 // chunks 0, 1 have landed for every wave
-    for (int p = 0; 2 * p < nch; ++p) {
-        const char* kb0 = smem + ((2 * p) & 3) * KT;
-        const char* kb1 = smem + ((2 * p + 1) & 3) * KT;
-        f32x4 ba0, ba1, bb0, bb1;
-        chunk_bias(__builtin_amdgcn_readlane(wv, 2 * p), g4, ba0, ba1);
-        chunk_bias(__builtin_amdgcn_readlane(wv, 2 * p + 1), g4, bb0, bb1);
+        for (int h = 0; h < NHH; ++h)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qf[h][ks] = ldg16(a.q + ((size_t)b * a.n + qi) * a.ldq + (H0 + h) * DH + ks * 32 + g4 * 8, qok);
+
+        // ---- the null key: s_null[h] = c1 * q[h] . null_k[h] (fp32), the same value in all four lane groups of a query
+        float sn[NHH];
 #pragma unroll
         for (int h = 0; h < NHH; ++h) {
-            const KF fa = k_frags(kb0, H0 + h, c, g4), fb = k_frags(kb1, H0 + h, c, g4);
-            f32x4 s0 = ba0, s1 = ba1, t0 = bb0, t1 = bb1;
+            float acc = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s0 = mfma16<F16>(fa.v[0][ks], qf[h][ks], s0);
-                s1 = mfma16<F16>(fa.v[1][ks], qf[h][ks], s1);
-                t0 = mfma16<F16>(fb.v[0][ks], qf[h][ks], t0);
-                t1 = mfma16<F16>(fb.v[1][ks], qf[h][ks], t1);
+                const float4 k0 = *reinterpret_cast<const float4*>(a.null_k + (H0 + h) * DH + ks * 32 + g4 * 8);
+                const float4 k1 = *reinterpret_cast<const float4*>(a.null_k + (H0 + h) * DH + ks * 32 + g4 * 8 + 4);
+                const uint4 u = __builtin_bit_cast(uint4, qf[h][ks]);
+                acc = fmaf(h2f<F16>((uint16_t)(u.x & 0xffff)), k0.x, acc); acc = fmaf(h2f<F16>((uint16_t)(u.x >> 16)), k0.y, acc);
+                acc = fmaf(h2f<F16>((uint16_t)(u.y & 0xffff)), k0.z, acc); acc = fmaf(h2f<F16>((uint16_t)(u.y >> 16)), k0.w, acc);
+                acc = fmaf(h2f<F16>((uint16_t)(u.z & 0xffff)), k1.x, acc); acc = fmaf(h2f<F16>((uint16_t)(u.z >> 16)), k1.y, acc);
+                acc = fmaf(h2f<F16>((uint16_t)(u.w & 0xffff)), k1.z, acc); acc = fmaf(h2f<F16>((uint16_t)(u.w >> 16)), k1.w, acc);
             }
-            const float ca = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-            const float cb = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), fmaxf(t0[2], t0[3])), fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])));
-            const float mn = fmaxf(m[h], fmaxf(ca, cb));
-            float acc = l[h] * __builtin_amdgcn_exp2f(m[h] - mn);
-            float acc2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc += __builtin_amdgcn_exp2f(s0[r] - mn);
-                acc2 += __builtin_amdgcn_exp2f(s1[r] - mn);
-                acc += __builtin_amdgcn_exp2f(t0[r] - mn);
-                acc2 += __builtin_amdgcn_exp2f(t1[r] - mn);
-            }
-            l[h] = acc + acc2; m[h] = mn;
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            sn[h] = acc * a.c1;
         }
-        // ONE ring barrier per step: own pieces of the next pair (issued a whole step ago) have landed, and after the barrier
-        // (a) everyone's have, (b) everyone is done reading this pair's slots, which pair p + 2 may now overwrite
-        VMCNT(0);
+
+        // ---- pass 1: running (reference maximum, sum of exp2) of this wave's 4 heads, 64 keys per ring step; the null key opens the
+        // sums (counted once: in lane group 0)
+        float m[NHH], l[NHH];
+#pragma unroll
+        for (int h = 0; h < NHH; ++h) { m[h] = sn[h]; l[h] = g4 == 0 ? 1.f : 0.f; }
+        STAMP(12, 1);
+        VMCNT(0);                                                 // the ring prologue (issued long ago, or just now for the first item)
+        STAMP(12, 2);
         __builtin_amdgcn_s_barrier();
-        if (2 * p + 4 < nch) { stage_k((2 * p) & 3, 2 * p + 4); stage_k((2 * p + 1) & 3, 2 * p + 5); }
-    }
-    // pass-2 ring prologue (nothing of pass 1 is in flight or being read any more)
-    stage_kv(0, 0);
-    stage_kv(1, 1);
-
-    float nb[NHH];
+        STAMP(12, 3);
+        const int np1 = (a.dbg & 1) ? 0 : nch;
+        bool k0_staged = false;                                   // chunk 0 of pass 2 already on its way (wave-uniform)
+        for (int p = 0; 2 * p < nch; ++p) {
+            const int sl0 = p1_slot(2 * p), sl1 = p1_slot(2 * p + 1);
+            if (2 * p < np1) {
+            STAMP(p, 0);
+            const char* kb0 = smem + sl0 * KT;
+            const char* kb1 = smem + sl1 * KT;
+            f32x4 ba0, ba1, bb0, bb1;
+            chunk_bias(__builtin_amdgcn_readlane(wv, 2 * p), g4, ba0, ba1);
+            chunk_bias(__builtin_amdgcn_readlane(wv, 2 * p + 1), g4, bb0, bb1);
 #pragma unroll
-    for (int h = 0; h < NHH; ++h) {
+            for (int h = 0; h < NHH; ++h) {
+                const KF fa = k_frags(kb0, H0 + h, c, g4), fb = k_frags(kb1, H0 + h, c, g4);
+                f32x4 s0v = ba0, s1v = ba1, t0 = bb0, t1 = bb1;
 #pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            const float m2 = __shfl_xor(m[h], off, 64), l2 = __shfl_xor(l[h], off, 64);
-            const float mn = fmaxf(m[h], m2);
-            l[h] = l[h] * __builtin_amdgcn_exp2f(m[h] - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
-            m[h] = mn;
+                for (int ks = 0; ks < KS; ++ks) {
+                    s0v = mfma16<F16>(fa.v[0][ks], qf[h][ks], s0v);
+                    s1v = mfma16<F16>(fa.v[1][ks], qf[h][ks], s1v);
+                    t0 = mfma16<F16>(fb.v[0][ks], qf[h][ks], t0);
+                    t1 = mfma16<F16>(fb.v[1][ks], qf[h][ks], t1);
+                }
+                const float ca = fmaxf(fmaxf(fmaxf(s0v[0], s0v[1]), fmaxf(s0v[2], s0v[3])), fmaxf(fmaxf(s1v[0], s1v[1]), fmaxf(s1v[2], s1v[3])));
+                const float cb = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), fmaxf(t0[2], t0[3])), fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])));
+                const float mn = fmaxf(m[h], fmaxf(ca, cb));
+                float acc = l[h] * __builtin_amdgcn_exp2f(m[h] - mn);
+                float acc2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc += __builtin_amdgcn_exp2f(s0v[r] - mn);
+                    acc2 += __builtin_amdgcn_exp2f(s1v[r] - mn);
+                    acc += __builtin_amdgcn_exp2f(t0[r] - mn);
+                    acc2 += __builtin_amdgcn_exp2f(t1[r] - mn);
+                }
+                l[h] = acc + acc2; m[h] = mn;
+            }
+            STAMP(p, 1);
+            }
+            // ONE ring barrier per step: own pieces of the next pair (issued a whole step ago) have landed, and after the barrier
+            // (a) everyone's have, (b) everyone is done reading this pair's slots, which may now be overwritten: by pair p + 2, or -- if
+            // the pair sat in the K slots of pass 2 and is the last but one -- by K of chunk 0 of pass 2
+            VMCNT(0);
+            STAMP(p, 2);
+            __builtin_amdgcn_s_barrier();
+            STAMP(p, 3);
+            if (2 * p + 4 < nch) { stage(k6, sl0, 2 * p + 4); stage(k6, sl1, 2 * p + 5); }
+            else if (2 * p + 2 < nch && sl0 == 0) { stage(k6, 0, 0); k0_staged = true; }
         }
-        const float il = 1.f / l[h];
-        nb[h] = __log2f(il) - m[h];
-        if (a.stats && g4 == 0 && qok) *reinterpret_cast<float2*>(a.stats + (((size_t)b * NH + H0 + h) * a.n + qi) * 2) = make_float2(m[h], il);
-    }
+        if (!k0_staged) stage(k6, 0, 0);
+        STAMP(12, 4);
 
-    // ---- pass 2: P of the own heads, exchange, head mix for the own output heads, O^T[g] += V^T[g] P'^T[g]
-    f32x4 O[NHH][DB];
-#pragma unroll
-    for (int g = 0; g < NHH; ++g)
-#pragma unroll
-        for (int db = 0; db < DB; ++db) O[g][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-    VMCNT(8);
-    __builtin_amdgcn_s_barrier();                                 // chunk 0 has landed for every wave
-    for (int ch = 0; ch < nch; ++ch) {
-        const char* kbase = smem + (ch & 1) * STAGE;
-        const char* vbase = kbase + KT;
-        f32x4 b0, b1;
-        chunk_bias(__builtin_amdgcn_readlane(wv, ch), g4, b0, b1);
-        // all 16 K fragments first, then the 16 score MFMAs
-        KF kf[NHH];
-#pragma unroll
-        for (int h = 0; h < NHH; ++h) kf[h] = k_frags(kbase, H0 + h, c, g4);
-        f32x4 s0[NHH], s1[NHH];
+        float nb[NHH];
 #pragma unroll
         for (int h = 0; h < NHH; ++h) {
-            s0[h] = b0; s1[h] = b1;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                s0[h] = mfma16<F16>(kf[h].v[0][ks], qf[h][ks], s0[h]);
-                s1[h] = mfma16<F16>(kf[h].v[1][ks], qf[h][ks], s1[h]);
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float m2 = __shfl_xor(m[h], off, 64), l2 = __shfl_xor(l[h], off, 64);
+                const float mn = fmaxf(m[h], m2);
+                l[h] = l[h] * __builtin_amdgcn_exp2f(m[h] - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
+                m[h] = mn;
             }
+            const float il = 1.f / l[h];
+            nb[h] = __log2f(il) - m[h];
+            if (a.stats && g4 == 0 && qok) *reinterpret_cast<float2*>(a.stats + (((size_t)b * NH + H0 + h) * a.n + qi) * 2) = make_float2(m[h], il);
         }
-        // the V^T fragments of this chunk are asked for now: they arrive under the softmax and the exchange barrier
-        bf16x8 vf[NHH][DB];
+
+        // ---- pass 2 (skewed): iteration cc = scores / softmax / puts of chunk cc  +  head mix / P'V of chunk cc - 1
+        f32x4 O[NHH][DB];
 #pragma unroll
         for (int g = 0; g < NHH; ++g)
 #pragma unroll
-            for (int db = 0; db < DB; ++db) vf[g][db] = lds16(vbase + v6_off(H0 + g, db * 16 + c, g4));
-        // probabilities of the own 4 heads -> exchange (slot e: 16 bytes per lane = heads 0..7, own half at byte 8 hh)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float pe[NHH];
-#pragma unroll
-            for (int h = 0; h < NHH; ++h) pe[h] = __builtin_amdgcn_exp2f((e < 4 ? s0[h][e & 3] : s1[h][e & 3]) + nb[h]);
-            *reinterpret_cast<uint2*>(xch + e * 1024 + lane * 16 + hh * 8) = make_uint2(pack2_t<F16>(pe[0], pe[1]), pack2_t<F16>(pe[2], pe[3]));
-        }
-        LGKM0();
-        __builtin_amdgcn_s_barrier();                             // (A) the partner's half of every slot is there
-        bf16x8 xb[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xb[e] = lds16(xch + e * 1024 + lane * 16);
-        f32x4 D[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) D[e] = mfma16<F16>(AW.hi, xb[e], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-        for (int e = 0; e < 8; ++e) D[e] = mfma16<F16>(AW.lo, xb[e], D[e]);       // D[e][rp] = P'[4 hh + rp] of slot e
-#pragma unroll
-        for (int rp = 0; rp < NHH; ++rp) {
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pack2_t<F16>(D[0][rp], D[1][rp]), pack2_t<F16>(D[2][rp], D[3][rp]),
-                                                                  pack2_t<F16>(D[4][rp], D[5][rp]), pack2_t<F16>(D[6][rp], D[7][rp])));
-#pragma unroll
-            for (int db = 0; db < DB; ++db) O[rp][db] = mfma16<F16>(vf[rp][db], pf, O[rp][db]);
-        }
-        // (B) ring barrier: own pieces of chunk ch + 1 (issued a whole iteration ago) have landed, and after the barrier everyone's
-        // have, everyone is done reading stage ch & 1 (chunk ch + 2 may overwrite it) and the exchange slots (the next puts may)
-        LGKM0();                                                  // (the exchange reads have returned before anyone may overwrite the slots)
+            for (int db = 0; db < DB; ++db) O[g][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+        STAMP(12, 5);
         VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-        if (ch + 2 < nch) stage_kv(ch & 1, ch + 2);
-    }
+        __builtin_amdgcn_s_barrier();                             // K of chunk 0 has landed for every wave
+        STAMP(12, 6);
+        const int np2 = (a.dbg & 2) ? 0 : nch;
+        auto body = [&](auto FIRST_, auto LAST_, int cc) {
+            constexpr bool FIRST = decltype(FIRST_)::value, LAST = decltype(LAST_)::value;
+            STAMP(4 + (cc > 11 ? 11 : cc), 0);
+            // the pieces of the next iteration: K of chunk cc + 1, V^T of chunk cc (LAST: the first two pass-1 chunks of the next item go
+            // into the K slots -- both free)
+            if (!LAST) {
+                if (cc + 1 < nch) stage(k6, 2 * ((cc + 1) & 1), cc + 1);
+                stage(v6, 2 * (cc & 1) + 1, cc);
+            } else if (k6n) { stage(k6n, p1_slot(0), 0); stage(k6n, p1_slot(1), 1); }
+            bf16x8 xb[8];
+            KF kf[NHH];
+            if (!FIRST) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xb[e] = lds16(xch + e * 1024 + lane * 16);
+            }
+            if (!LAST) {
+                const char* kbase = smem + 2 * (cc & 1) * KT;
+#pragma unroll
+                for (int h = 0; h < NHH; ++h) kf[h] = k_frags(kbase, H0 + h, c, g4);
+            }
+            if (!FIRST) {
+                LGKM0();
+                STAMP(4 + (cc > 11 ? 11 : cc), 1);
+                __builtin_amdgcn_s_barrier();                     // (P) every wave holds its xb: the exchange may be overwritten
+                STAMP(4 + (cc > 11 ? 11 : cc), 2);
+            }
+            f32x4 D[8];
+            if (!FIRST) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) D[e] = mfma16<F16>(AW.hi, xb[e], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int e = 0; e < 8; ++e) D[e] = mfma16<F16>(AW.lo, xb[e], D[e]);   // D[e][rp] = P'[4 hh + rp] of slot e (chunk cc - 1)
+            }
+            f32x4 s0v[NHH], s1v[NHH];
+            if (!LAST) {
+                f32x4 b0, b1;
+                chunk_bias(__builtin_amdgcn_readlane(wv, cc), g4, b0, b1);
+#pragma unroll
+                for (int h = 0; h < NHH; ++h) {
+                    s0v[h] = b0; s1v[h] = b1;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        s0v[h] = mfma16<F16>(kf[h].v[0][ks], qf[h][ks], s0v[h]);
+                        s1v[h] = mfma16<F16>(kf[h].v[1][ks], qf[h][ks], s1v[h]);
+                    }
+                }
+            }
+            bf16x8 vf[NHH][DB];
+            if (!FIRST) {
+                const char* vbase = smem + (2 * ((cc - 1) & 1) + 1) * KT;
+#pragma unroll
+                for (int g = 0; g < NHH; ++g)
+#pragma unroll
+                    for (int db = 0; db < DB; ++db) vf[g][db] = lds16(vbase + v6_off(H0 + g, db * 16 + c, g4));
+            }
+            if (!LAST) {
+                // probabilities of the own 4 heads -> exchange (slot e: 16 bytes per lane = heads 0..7, own half at byte 8 hh)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float pe[NHH];
+#pragma unroll
+                    for (int h = 0; h < NHH; ++h) pe[h] = __builtin_amdgcn_exp2f((e < 4 ? s0v[h][e & 3] : s1v[h][e & 3]) + nb[h]);
+                    *reinterpret_cast<uint2*>(xch + e * 1024 + lane * 16 + hh * 8) = make_uint2(pack2_t<F16>(pe[0], pe[1]), pack2_t<F16>(pe[2], pe[3]));
+                }
+            }
+            if (!FIRST) {
+#pragma unroll
+                for (int rp = 0; rp < NHH; ++rp) {
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pack2_t<F16>(D[0][rp], D[1][rp]), pack2_t<F16>(D[2][rp], D[3][rp]),
+                                                                          pack2_t<F16>(D[4][rp], D[5][rp]), pack2_t<F16>(D[6][rp], D[7][rp])));
+#pragma unroll
+                    for (int db = 0; db < DB; ++db) O[rp][db] = mfma16<F16>(vf[rp][db], pf, O[rp][db]);
+                }
+            }
+            STAMP(4 + (cc > 11 ? 11 : cc), 3);
+            LGKM0();
+            VMCNT(0);
+            STAMP(4 + (cc > 11 ? 11 : cc), 4);
+            __builtin_amdgcn_s_barrier();                         // (Q)
+            STAMP(4 + (cc > 11 ? 11 : cc), 5);
+        };
+        if (np2) {
+            body(std::true_type{}, std::false_type{}, 0);
+            for (int cc = 1; cc < nch; ++cc) body(std::false_type{}, std::false_type{}, cc);
+            body(std::false_type{}, std::true_type{}, nch);
+        } else if (k6n) { stage(k6n, p1_slot(0), 0); stage(k6n, p1_slot(1), 1); }
+        if (k6n && nch > 2) { stage(k6n, p1_slot(2), 2); stage(k6n, p1_slot(3), 3); }
 
-    // ---- the null key's share: P_null of all 8 heads through the exchange (slot 0), one more head mix, a rank-one update of O
-    {
-        float pn[NHH];
+        STAMP(13, 0);
+        // ---- the null key's share: P_null of all 8 heads through the exchange (slot 0), one more head mix, a rank-one update of O
+        {
+            float pn[NHH];
 #pragma unroll
-        for (int h = 0; h < NHH; ++h) pn[h] = __builtin_amdgcn_exp2f(sn[h] + nb[h]);
-        *reinterpret_cast<uint2*>(xch + lane * 16 + hh * 8) = make_uint2(pack2_t<F16>(pn[0], pn[1]), pack2_t<F16>(pn[2], pn[3]));
-        LGKM0();
-        __builtin_amdgcn_s_barrier();
-        const bf16x8 xn = lds16(xch + lane * 16);
-        f32x4 Dn = mfma16<F16>(AW.hi, xn, f32x4{0.f, 0.f, 0.f, 0.f});
-        Dn = mfma16<F16>(AW.lo, xn, Dn);                         // Dn[rp] = P'_null[4 hh + rp] of this lane's query (all lane groups alike)
+            for (int h = 0; h < NHH; ++h) pn[h] = __builtin_amdgcn_exp2f(sn[h] + nb[h]);
+            *reinterpret_cast<uint2*>(xch + lane * 16 + hh * 8) = make_uint2(pack2_t<F16>(pn[0], pn[1]), pack2_t<F16>(pn[2], pn[3]));
+            LGKM0();
+            __builtin_amdgcn_s_barrier();
+            const bf16x8 xn = lds16(xch + lane * 16);
+            f32x4 Dn = mfma16<F16>(AW.hi, xn, f32x4{0.f, 0.f, 0.f, 0.f});
+            Dn = mfma16<F16>(AW.lo, xn, Dn);                     // Dn[rp] = P'_null[4 hh + rp] of this lane's query (all lane groups alike)
 #pragma unroll
-        for (int rp = 0; rp < NHH; ++rp)
+            for (int rp = 0; rp < NHH; ++rp)
 #pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                const float4 vn = *reinterpret_cast<const float4*>(a.null_v + (H0 + rp) * DH + db * 16 + g4 * 4);
-                O[rp][db][0] = fmaf(vn.x, Dn[rp], O[rp][db][0]); O[rp][db][1] = fmaf(vn.y, Dn[rp], O[rp][db][1]);
-                O[rp][db][2] = fmaf(vn.z, Dn[rp], O[rp][db][2]); O[rp][db][3] = fmaf(vn.w, Dn[rp], O[rp][db][3]);
-            }
-    }
-    if (qok) {
+                for (int db = 0; db < DB; ++db) {
+                    const float4 vn = *reinterpret_cast<const float4*>(a.null_v + (H0 + rp) * DH + db * 16 + g4 * 4);
+                    O[rp][db][0] = fmaf(vn.x, Dn[rp], O[rp][db][0]); O[rp][db][1] = fmaf(vn.y, Dn[rp], O[rp][db][1]);
+                    O[rp][db][2] = fmaf(vn.z, Dn[rp], O[rp][db][2]); O[rp][db][3] = fmaf(vn.w, Dn[rp], O[rp][db][3]);
+                }
+            LGKM0();
+            __builtin_amdgcn_s_barrier();                         // (the slot is read: the next item's puts may come)
+        }
+        STAMP(13, 1);
+        if (qok) {
 #pragma unroll
-        for (int rp = 0; rp < NHH; ++rp)
+            for (int rp = 0; rp < NHH; ++rp)
 #pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                const size_t go = ((size_t)b * a.n + qi) * a.ldo + (H0 + rp) * DH + db * 16 + g4 * 4;
-                const uint32_t h01 = pack2_rne(O[rp][db][0], O[rp][db][1]), h23 = pack2_rne(O[rp][db][2], O[rp][db][3]);
-                *reinterpret_cast<uint2*>(a.o + go) = make_uint2(h01, h23);
-                if (a.ol)
-                    *reinterpret_cast<uint2*>(a.ol + go) = a.ol_f16 ?
-                        make_uint2(pack2_f16_sat(O[rp][db][0], O[rp][db][1]), pack2_f16_sat(O[rp][db][2], O[rp][db][3])) :
-                        make_uint2(pack2_rne(O[rp][db][0] - lo_f(h01), O[rp][db][1] - hi_f(h01)), pack2_rne(O[rp][db][2] - lo_f(h23), O[rp][db][3] - hi_f(h23)));
-            }
+                for (int db = 0; db < DB; ++db) {
+                    const size_t go = ((size_t)b * a.n + qi) * a.ldo + (H0 + rp) * DH + db * 16 + g4 * 4;
+                    const uint32_t h01 = pack2_rne(O[rp][db][0], O[rp][db][1]), h23 = pack2_rne(O[rp][db][2], O[rp][db][3]);
+                    *reinterpret_cast<uint2*>(a.o + go) = make_uint2(h01, h23);
+                    if (a.ol)
+                        *reinterpret_cast<uint2*>(a.ol + go) = a.ol_f16 ?
+                            make_uint2(pack2_f16_sat(O[rp][db][0], O[rp][db][1]), pack2_f16_sat(O[rp][db][2], O[rp][db][3])) :
+                            make_uint2(pack2_rne(O[rp][db][0] - lo_f(h01), O[rp][db][1] - hi_f(h01)), pack2_rne(O[rp][db][2] - lo_f(h23), O[rp][db][3] - hi_f(h23)));
+                }
+        }
+        STAMP(13, 2);
     }
 }
 
@@ -400,6 +485,16 @@ __global__ __launch_bounds__(256) void xattn6_pack_kernel(const uint16_t* __rest
     }
 }
 
+int cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) cus = n;
+        else cus = 256;
+    }
+    return cus;
+}
+
 int check6(const amdnuwa_xattn_geom* g) {
     if (!g) return AMDNUWA_ERR_ARG;
     if (g->heads != NH || g->dim_head != DH || g->T < 1 || g->T > 2048) return AMDNUWA_ERR_UNSUPPORTED;   // (nch <= 64: one mask word per lane)
@@ -443,17 +538,23 @@ extern "C" int amdnuwa_xattn6_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.q = q16; a.ldq = ldq; a.K6 = (const char*)kv->K6; a.V6 = (const char*)kv->V6; a.vbits = kv->vbits;
     a.null_k = null_k; a.null_v = null_v; a.wth = w_th;
     a.o = o; a.ol = o_lo; a.ldo = ldo; a.ol_f16 = (o_lo && o_lo_f16) ? 1 : 0; a.stats = stats;
-    a.B = g->B; a.n = g->n; a.nch = amdnuwa_xattn6_nch(g->T); a.c1 = g->scale * 1.4426950408889634f;
-    const int tiles = (g->n + 63) / 64;
+    a.B = g->B; a.n = g->n; a.nch = amdnuwa_xattn6_nch(g->T); a.dbg = g_amdnuwa_tuning[18]; a.c1 = g->scale * 1.4426950408889634f;
+    const int tiles = (g->n + 63) / 64, NT = g->B * tiles;
+    // one workgroup per CU (160 KiB of LDS each); the grid stays a multiple of 8 so that a workgroup's items all lie in one XCD's slab
+    const int grid = NT < cu_count() ? NT : cu_count() / 8 * 8;
     if (f16) {
         (void)hipFuncSetAttribute((const void*)xattn6_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipLaunchKernelGGL(xattn6_fwd_kernel<true>, dim3(g->B * tiles), dim3(512), LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(xattn6_fwd_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
     } else {
         (void)hipFuncSetAttribute((const void*)xattn6_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipLaunchKernelGGL(xattn6_fwd_kernel<false>, dim3(g->B * tiles), dim3(512), LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(xattn6_fwd_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
     }
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
+
+#if X6_TIMING
+extern "C" int amdnuwa_xattn6_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x6_stamps), &p, sizeof(p)); }
+#endif
 
 AMDNUWA_SAT_ACCESSOR(xattn6)
