@@ -43,7 +43,6 @@ struct X6Args {
     uint16_t *o, *ol; int ldo, ol_f16;
     float* stats;                            // [B][NH][n][2] = (reference maximum in the log2 domain, 1 / sum of exp2)
     int B, n, nch;
-    int dbg;                                 // tuning key 18, timing probes only (garbage results): bit 0 no pass 1, bit 1 no pass 2 (loop bounds only)
     float c1;                                // scale * log2(e)
 };
 
@@ -120,13 +119,16 @@ __device__ __forceinline__ void chunk_bias(uint32_t w, int g4, f32x4& b0, f32x4&
 }
 
 // the 4 K fragments of one head (rows c / 16 + c, two k-steps)
+// (the lane part of k6_off does not depend on the head or the row block: (16 kb + c) & 7 == c & 7 -- two per-lane offsets, one per k-step,
+//  and compile-time immediates for everything else; likewise ONE per-lane offset for V^T: ((16 db + c) >> 3) & 1 == (c >> 3) & 1)
 struct KF { bf16x8 v[2][KS]; };
-__device__ __forceinline__ KF k_frags(const char* kbase, int h, int c, int g4) {
+__device__ __forceinline__ KF k_frags(const char* kbase, int h, int ko0, int ko1) {
     KF f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) f.v[kb][ks] = lds16(kbase + k6_off(h, kb * 16 + c, ks * 4 + g4));
+    for (int kb = 0; kb < 2; ++kb) {
+        f.v[kb][0] = lds16(kbase + h * TILE + kb * 2048 + ko0);
+        f.v[kb][1] = lds16(kbase + h * TILE + kb * 2048 + ko1);
+    }
     return f;
 }
 
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
     const int nch = a.nch;
     char* xch = smem + 4 * KT + tile * XT;
     const int H0 = 4 * hh;
+    const int ko0 = k6_off(0, c, g4), ko1 = k6_off(0, c, 4 + g4), vo = v6_off(0, c, g4), xo = lane * 16;
 
     // one 32-KiB image chunk -> ring slot: 32 pieces, 4 per wave
     auto stage = [&](const char* img, int slot, int ch) {
@@ -225,11 +228,9 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
         STAMP(12, 2);
         __builtin_amdgcn_s_barrier();
         STAMP(12, 3);
-        const int np1 = (a.dbg & 1) ? 0 : nch;
         bool k0_staged = false;                                   // chunk 0 of pass 2 already on its way (wave-uniform)
         for (int p = 0; 2 * p < nch; ++p) {
             const int sl0 = p1_slot(2 * p), sl1 = p1_slot(2 * p + 1);
-            if (2 * p < np1) {
             STAMP(p, 0);
             const char* kb0 = smem + sl0 * KT;
             const char* kb1 = smem + sl1 * KT;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
             chunk_bias(__builtin_amdgcn_readlane(wv, 2 * p + 1), g4, bb0, bb1);
 #pragma unroll
             for (int h = 0; h < NHH; ++h) {
-                const KF fa = k_frags(kb0, H0 + h, c, g4), fb = k_frags(kb1, H0 + h, c, g4);
+                const KF fa = k_frags(kb0, H0 + h, ko0, ko1), fb = k_frags(kb1, H0 + h, ko0, ko1);
                 f32x4 s0v = ba0, s1v = ba1, t0 = bb0, t1 = bb1;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
@@ -262,7 +263,6 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
                 l[h] = acc + acc2; m[h] = mn;
             }
             STAMP(p, 1);
-            }
             // ONE ring barrier per step: own pieces of the next pair (issued a whole step ago) have landed, and after the barrier
             // (a) everyone's have, (b) everyone is done reading this pair's slots, which may now be overwritten: by pair p + 2, or -- if
             // the pair sat in the K slots of pass 2 and is the last but one -- by K of chunk 0 of pass 2
@@ -286,22 +286,37 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
                 l[h] = l[h] * __builtin_amdgcn_exp2f(m[h] - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
                 m[h] = mn;
             }
-            const float il = 1.f / l[h];
-            nb[h] = __log2f(il) - m[h];
+            const float il = __builtin_amdgcn_rcpf(l[h]);
+            nb[h] = -__log2f(l[h]) - m[h];
             if (a.stats && g4 == 0 && qok) *reinterpret_cast<float2*>(a.stats + (((size_t)b * NH + H0 + h) * a.n + qi) * 2) = make_float2(m[h], il);
         }
 
+        // ---- the null key's share first: P_null of all 8 heads through LDS (1 KiB per tile inside ring slot 3: free from the end of pass 1
+        // to the top of pass-2 iteration 1), one head mix, and O starts as the rank-one term v_null x P'_null instead of zero
+        char* nx = smem + 3 * KT + tile * 1024;
+        {
+            float pn[NHH];
+#pragma unroll
+            for (int h = 0; h < NHH; ++h) pn[h] = __builtin_amdgcn_exp2f(sn[h] + nb[h]);
+            *reinterpret_cast<uint2*>(nx + lane * 16 + hh * 8) = make_uint2(pack2_t<F16>(pn[0], pn[1]), pack2_t<F16>(pn[2], pn[3]));
+        }
+        STAMP(12, 5);
+        LGKM0();
+        VMCNT(0);
+        __builtin_amdgcn_s_barrier();                             // K of chunk 0 has landed for every wave; the partner's P_null is there
+        STAMP(12, 6);
         // ---- pass 2 (skewed): iteration cc = scores / softmax / puts of chunk cc  +  head mix / P'V of chunk cc - 1
         f32x4 O[NHH][DB];
 #pragma unroll
         for (int g = 0; g < NHH; ++g)
 #pragma unroll
             for (int db = 0; db < DB; ++db) O[g][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-        STAMP(12, 5);
-        VMCNT(0);
-        __builtin_amdgcn_s_barrier();                             // K of chunk 0 has landed for every wave
-        STAMP(12, 6);
-        const int np2 = (a.dbg & 2) ? 0 : nch;
+        f32x4 Dn;                                                 // Dn[rp] = P'_null[4 hh + rp] of this lane's query (all lane groups alike)
+        {
+            const bf16x8 xn = lds16(nx + lane * 16);
+            Dn = mfma16<F16>(AW.hi, xn, f32x4{0.f, 0.f, 0.f, 0.f});
+            Dn = mfma16<F16>(AW.lo, xn, Dn);
+        }
         auto body = [&](auto FIRST_, auto LAST_, int cc) {
             constexpr bool FIRST = decltype(FIRST_)::value, LAST = decltype(LAST_)::value;
             STAMP(4 + (cc > 11 ? 11 : cc), 0);
@@ -315,12 +330,12 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
             KF kf[NHH];
             if (!FIRST) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xb[e] = lds16(xch + e * 1024 + lane * 16);
+                for (int e = 0; e < 8; ++e) xb[e] = lds16(xch + e * 1024 + xo);
             }
             if (!LAST) {
                 const char* kbase = smem + 2 * (cc & 1) * KT;
 #pragma unroll
-                for (int h = 0; h < NHH; ++h) kf[h] = k_frags(kbase, H0 + h, c, g4);
+                for (int h = 0; h < NHH; ++h) kf[h] = k_frags(kbase, H0 + h, ko0, ko1);
             }
             if (!FIRST) {
                 LGKM0();
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
 #pragma unroll
                 for (int g = 0; g < NHH; ++g)
 #pragma unroll
-                    for (int db = 0; db < DB; ++db) vf[g][db] = lds16(vbase + v6_off(H0 + g, db * 16 + c, g4));
+                    for (int db = 0; db < DB; ++db) vf[g][db] = lds16(vbase + (H0 + g) * TILE + db * 1024 + vo);
             }
             if (!LAST) {
                 // probabilities of the own 4 heads -> exchange (slot e: 16 bytes per lane = heads 0..7, own half at byte 8 hh)
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
                     float pe[NHH];
 #pragma unroll
                     for (int h = 0; h < NHH; ++h) pe[h] = __builtin_amdgcn_exp2f((e < 4 ? s0v[h][e & 3] : s1v[h][e & 3]) + nb[h]);
-                    *reinterpret_cast<uint2*>(xch + e * 1024 + lane * 16 + hh * 8) = make_uint2(pack2_t<F16>(pe[0], pe[1]), pack2_t<F16>(pe[2], pe[3]));
+                    *reinterpret_cast<uint2*>(xch + e * 1024 + xo + hh * 8) = make_uint2(pack2_t<F16>(pe[0], pe[1]), pack2_t<F16>(pe[2], pe[3]));
                 }
             }
             if (!FIRST) {
@@ -383,49 +398,58 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
             __builtin_amdgcn_s_barrier();                         // (Q)
             STAMP(4 + (cc > 11 ? 11 : cc), 5);
         };
-        if (np2) {
+        {
             body(std::true_type{}, std::false_type{}, 0);
             for (int cc = 1; cc < nch; ++cc) body(std::false_type{}, std::false_type{}, cc);
+            // (the null value rows are asked for before the last body: they arrive under it)
+            float4 vn[NHH][DB];
+#pragma unroll
+            for (int rp = 0; rp < NHH; ++rp)
+#pragma unroll
+                for (int db = 0; db < DB; ++db) vn[rp][db] = *reinterpret_cast<const float4*>(a.null_v + (H0 + rp) * DH + db * 16 + g4 * 4);
             body(std::false_type{}, std::true_type{}, nch);
-        } else if (k6n) { stage(k6n, p1_slot(0), 0); stage(k6n, p1_slot(1), 1); }
+#pragma unroll
+            for (int rp = 0; rp < NHH; ++rp)
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    O[rp][db][0] = fmaf(vn[rp][db].x, Dn[rp], O[rp][db][0]); O[rp][db][1] = fmaf(vn[rp][db].y, Dn[rp], O[rp][db][1]);
+                    O[rp][db][2] = fmaf(vn[rp][db].z, Dn[rp], O[rp][db][2]); O[rp][db][3] = fmaf(vn[rp][db].w, Dn[rp], O[rp][db][3]);
+                }
+        }
         if (k6n && nch > 2) { stage(k6n, p1_slot(2), 2); stage(k6n, p1_slot(3), 3); }
 
         STAMP(13, 0);
-        // ---- the null key's share: P_null of all 8 heads through the exchange (slot 0), one more head mix, a rank-one update of O
-        {
-            float pn[NHH];
-#pragma unroll
-            for (int h = 0; h < NHH; ++h) pn[h] = __builtin_amdgcn_exp2f(sn[h] + nb[h]);
-            *reinterpret_cast<uint2*>(xch + lane * 16 + hh * 8) = make_uint2(pack2_t<F16>(pn[0], pn[1]), pack2_t<F16>(pn[2], pn[3]));
-            LGKM0();
-            __builtin_amdgcn_s_barrier();
-            const bf16x8 xn = lds16(xch + lane * 16);
-            f32x4 Dn = mfma16<F16>(AW.hi, xn, f32x4{0.f, 0.f, 0.f, 0.f});
-            Dn = mfma16<F16>(AW.lo, xn, Dn);                     // Dn[rp] = P'_null[4 hh + rp] of this lane's query (all lane groups alike)
-#pragma unroll
-            for (int rp = 0; rp < NHH; ++rp)
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const float4 vn = *reinterpret_cast<const float4*>(a.null_v + (H0 + rp) * DH + db * 16 + g4 * 4);
-                    O[rp][db][0] = fmaf(vn.x, Dn[rp], O[rp][db][0]); O[rp][db][1] = fmaf(vn.y, Dn[rp], O[rp][db][1]);
-                    O[rp][db][2] = fmaf(vn.z, Dn[rp], O[rp][db][2]); O[rp][db][3] = fmaf(vn.w, Dn[rp], O[rp][db][3]);
-                }
-            LGKM0();
-            __builtin_amdgcn_s_barrier();                         // (the slot is read: the next item's puts may come)
-        }
         STAMP(13, 1);
-        if (qok) {
+        // Output rows.  A lane holds 4 consecutive channels (8 bytes) per (head, 16-channel block); v_permlane16_swap pairs the blocks
+        // (db, db + 1) so that every lane owns 8 consecutive channels = ONE 16-byte store (lane group g4: channels 16 (g4 & 1) + 8 (g4 >> 1) ..
+        // of the 32-channel pair): half the store instructions for the same bytes (the tail was store-issue-bound: 10 k cycles per item)
+        if (true) {
+            const int dlane = 16 * (g4 & 1) + 8 * (g4 >> 1);
 #pragma unroll
             for (int rp = 0; rp < NHH; ++rp)
 #pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const size_t go = ((size_t)b * a.n + qi) * a.ldo + (H0 + rp) * DH + db * 16 + g4 * 4;
-                    const uint32_t h01 = pack2_rne(O[rp][db][0], O[rp][db][1]), h23 = pack2_rne(O[rp][db][2], O[rp][db][3]);
-                    *reinterpret_cast<uint2*>(a.o + go) = make_uint2(h01, h23);
-                    if (a.ol)
-                        *reinterpret_cast<uint2*>(a.ol + go) = a.ol_f16 ?
-                            make_uint2(pack2_f16_sat(O[rp][db][0], O[rp][db][1]), pack2_f16_sat(O[rp][db][2], O[rp][db][3])) :
-                            make_uint2(pack2_rne(O[rp][db][0] - lo_f(h01), O[rp][db][1] - hi_f(h01)), pack2_rne(O[rp][db][2] - lo_f(h23), O[rp][db][3] - hi_f(h23)));
+                for (int dp = 0; dp < DB; dp += 2) {
+                    const size_t go = ((size_t)b * a.n + qi) * a.ldo + (H0 + rp) * DH + dp * 16 + dlane;
+                    uint32_t x0 = pack2_rne(O[rp][dp][0], O[rp][dp][1]), x1 = pack2_rne(O[rp][dp][2], O[rp][dp][3]);
+                    uint32_t y0 = pack2_rne(O[rp][dp + 1][0], O[rp][dp + 1][1]), y1 = pack2_rne(O[rp][dp + 1][2], O[rp][dp + 1][3]);
+                    uint32_t lx0, lx1, ly0, ly1;                  // the second output: fp16 copy or bf16 residual
+                    if (a.ol_f16) {
+                        lx0 = pack2_f16_sat(O[rp][dp][0], O[rp][dp][1]); lx1 = pack2_f16_sat(O[rp][dp][2], O[rp][dp][3]);
+                        ly0 = pack2_f16_sat(O[rp][dp + 1][0], O[rp][dp + 1][1]); ly1 = pack2_f16_sat(O[rp][dp + 1][2], O[rp][dp + 1][3]);
+                    } else {
+                        lx0 = pack2_rne(O[rp][dp][0] - lo_f(x0), O[rp][dp][1] - hi_f(x0)); lx1 = pack2_rne(O[rp][dp][2] - lo_f(x1), O[rp][dp][3] - hi_f(x1));
+                        ly0 = pack2_rne(O[rp][dp + 1][0] - lo_f(y0), O[rp][dp + 1][1] - hi_f(y0)); ly1 = pack2_rne(O[rp][dp + 1][2] - lo_f(y1), O[rp][dp + 1][3] - hi_f(y1));
+                    }
+                    auto swap = [](uint32_t& x, uint32_t& y) {
+                        const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+                        x = r[0]; y = r[1];
+                    };
+                    swap(x0, y0); swap(x1, y1);
+                    if (qok) *reinterpret_cast<uint4*>(a.o + go) = make_uint4(x0, x1, y0, y1);
+                    if (a.ol) {
+                        swap(lx0, ly0); swap(lx1, ly1);
+                        if (qok) *reinterpret_cast<uint4*>(a.ol + go) = make_uint4(lx0, lx1, ly0, ly1);
+                    }
                 }
         }
         STAMP(13, 2);
@@ -538,7 +562,7 @@ extern "C" int amdnuwa_xattn6_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.q = q16; a.ldq = ldq; a.K6 = (const char*)kv->K6; a.V6 = (const char*)kv->V6; a.vbits = kv->vbits;
     a.null_k = null_k; a.null_v = null_v; a.wth = w_th;
     a.o = o; a.ol = o_lo; a.ldo = ldo; a.ol_f16 = (o_lo && o_lo_f16) ? 1 : 0; a.stats = stats;
-    a.B = g->B; a.n = g->n; a.nch = amdnuwa_xattn6_nch(g->T); a.dbg = g_amdnuwa_tuning[18]; a.c1 = g->scale * 1.4426950408889634f;
+    a.B = g->B; a.n = g->n; a.nch = amdnuwa_xattn6_nch(g->T); a.c1 = g->scale * 1.4426950408889634f;
     const int tiles = (g->n + 63) / 64, NT = g->B * tiles;
     // one workgroup per CU (160 KiB of LDS each); the grid stays a multiple of 8 so that a workgroup's items all lie in one XCD's slab
     const int grid = NT < cu_count() ? NT : cu_count() / 8 * 8;

@@ -1063,7 +1063,11 @@ class PackedKV:
         sh1 = (g.B, g.heads, g.JP, g.dim_head)
         sh2 = (g.B, g.heads, g.dim_head, g.JP)
         mk = lambda s: empty_bf(s, device, lo=lo)
-        if lean:
+        if lean == 'bwd':                        # the two bf16 [key][d] images of the recomputing backward alone (the forward runs on xattn6 images)
+            e16 = lambda s: torch.empty(s, dtype=torch.bfloat16, device=device)
+            self.Kp, self.Vp = BF(e16(sh1), None), BF(e16(sh1), None)
+            self.Kt, self.Vt = BF(None, None), BF(None, None)
+        elif lean:
             e16 = lambda s: torch.empty(s, dtype=torch.bfloat16, device=device)
             self.Kp, self.Vp = BF(e16(sh1), e16(sh1)), BF(e16(sh1), None)
             self.Kt, self.Vt = BF(None, None), BF(None, e16(sh2))
@@ -1094,6 +1098,11 @@ def xattn_pack(g, kv, null_k, null_v, mask_u8, out=None, lean=False):
         check(L.amdnuwa_xattn_pack(C.byref(g), _p(kv.hi), _p(kv.lo), kv.hi.stride(0), _p(null_k), _p(null_v), _p(mask_u8),
                                    C.byref(out.struct), _stream()), 'amdnuwa_xattn_pack')
         return out
+    if lean == 'bwd':
+        pk = PackedKV(g, kv.hi.device, False, lean='bwd')
+        check(L.amdnuwa_xattn_pack(C.byref(g), _p(kv.hi), None, kv.hi.stride(0), _p(null_k), _p(null_v), _p(mask_u8),
+                                   C.byref(pk.struct), _stream()), 'amdnuwa_xattn_pack')
+        return pk
     if kv.f16 is not None:
         pk = PackedKV(g, kv.hi.device, True, lean=lean)
         check(L.amdnuwa_xattn_pack_f16(C.byref(g), _p(kv.hi), _p(kv.f16), kv.hi.stride(0), _p(null_k), _p(null_v), _p(mask_u8),
@@ -1139,6 +1148,19 @@ class PackedKV6:
         s = _lib.X6KV()
         s.K6, s.V6, s.vbits = _p(self.K6), _p(self.V6), _p(self.vbits)
         self.struct = s
+
+
+_XATTN6 = os.environ.get('AMDNUWA_XATTN6', '1') != '0'
+
+
+def set_xattn6(on):
+    """the third-design cross-attention forward (amdnuwa_xattn6_*; AMDNUWA_XATTN6=0 keeps xattn4)"""
+    global _XATTN6
+    _XATTN6 = bool(on)
+
+
+def xattn6_on():
+    return _XATTN6
 
 
 def xattn6_supported(g):

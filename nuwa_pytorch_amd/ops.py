@@ -281,17 +281,26 @@ class XInner:
         if rot is not None:
             q = _rotary_bf(q, rot, g.B, g.n, g.heads)
             kv = _rotary_bf(kv, rot, g.B, g.T, 2 * g.heads)
-        pk = K.xattn_pack(g, kv, nk.detach().reshape(g.heads, g.dim_head).contiguous(),
-                          nv.detach().reshape(g.heads, g.dim_head).contiguous(), meta['mask_u8'], lean=f16 and not K.xattn2_bwd_rc_ok(g))
+        nk2, nv2 = nk.detach().reshape(g.heads, g.dim_head).contiguous(), nv.detach().reshape(g.heads, g.dim_head).contiguous()
+        # third-design forward core (xattn6: images in LDS order, null key as a rank-one term) wherever the second design ran; the bf16
+        # recomputing backward keeps its two [key][d] images
+        x6 = K.xattn6_on() and K.xattn6_supported(g) and (f16 or K.xattn2_supported(g, q)) and nk2.dtype == torch.float32
+        pk = K.xattn_pack(g, kv, nk2, nv2, meta['mask_u8'], lean=('bwd' if x6 and not K.xattn2_bwd_rc_ok(g) else (f16 and not K.xattn2_bwd_rc_ok(g))))
         wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
         o16 = False
-        if f16:                               # 'bf16x3-fwd': the xattn4 core on single fp16 MFMAs, hi + lo output, statistics for the bf16 backward
+        if f16:                               # 'bf16x3-fwd': the forward core on single fp16 MFMAs, hi + lo output, statistics for the bf16 backward
             o16 = K.proj_f16x2('o') and 'out_16' in W and K.gemm_nt_f16x2_ok(R, p[5].shape[0], p[5].shape[1], out_bf16=False)
-            o, stats = K.xattn2_fwd_f16(g, q, pk, wth2, o_f16=o16)
+            if x6:
+                o, stats = K.xattn6_fwd(g, q.f16, K.xattn6_pack(g, kv.f16, meta['mask_u8']), nk2, nv2, wth2, o_f16=o16)
+            else:
+                o, stats = K.xattn2_fwd_f16(g, q, pk, wth2, o_f16=o16)
+                pk.drop_lo()
             P, Pm = stats, None
-            pk.drop_lo()
         elif K.xattn2_supported(g, q):        # fast mode: statistics only, the backward recomputes the probabilities
-            o, stats = K.xattn2_fwd(g, q, pk, wth2)
+            if x6:
+                o, stats = K.xattn6_fwd(g, q.hi, K.xattn6_pack(g, kv.hi, meta['mask_u8']), nk2, nv2, wth2, lo=False)
+            else:
+                o, stats = K.xattn2_fwd(g, q, pk, wth2)
             P, Pm = stats, None
         elif K.mixed() and K.xattn2_supported(g):
             # 3-MFMA forward that leaves only the softmax statistics; the bf16 backward (xattn2_bwd) recomputes from the hi parts
