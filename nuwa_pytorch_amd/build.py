@@ -48,7 +48,7 @@ def _stale(target, deps):
 # v_accvgpr_read, zero-initialises their accumulators with v_accvgpr_write, and parks MFMA-only operands in AGPRs to read them back
 # before each use: 1300 v_accvgpr moves in xattn3_bwd.  With the VGPR form the transient results land where they are used (290 moves,
 # 15 % fewer instructions in a kernel that is bound by instruction issue); the long-lived accumulators still sit in AGPRs.
-EXTRA_FLAGS = {'xattn2.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
+EXTRA_FLAGS = {'xattn2.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'], 'xattn6.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
 # Build variants (A/B runs of compiler options: `python -m nuwa_pytorch_amd.build --variant pk` writes lib_pk/libamdnuwa.so, which
 # AMDNUWA_LIBRARY=... then selects).  'pk' / 'pk_nofix': WITH packed fp32 ops (DEFAULT_FLAGS dropped), the Sparse3DNA head-mix loops pinned

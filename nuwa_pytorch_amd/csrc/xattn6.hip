@@ -205,8 +205,13 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
             float acc = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const float4 k0 = *reinterpret_cast<const float4*>(a.null_k + (H0 + h) * DH + ks * 32 + g4 * 8);
-                const float4 k1 = *reinterpret_cast<const float4*>(a.null_k + (H0 + h) * DH + ks * 32 + g4 * 8 + 4);
+                // (rounded to the operand type of the mode, as a key row of the images would be: in the bf16 mode the recomputing backward,
+                //  whose images hold the bf16 null key, then sees the very same products -- a sample with no visible context key gets
+                //  P_null = 1 and ds = 0 instead of 1 +- 2^-9)
+                float4 k0 = *reinterpret_cast<const float4*>(a.null_k + (H0 + h) * DH + ks * 32 + g4 * 8);
+                float4 k1 = *reinterpret_cast<const float4*>(a.null_k + (H0 + h) * DH + ks * 32 + g4 * 8 + 4);
+                auto r16 = [](float x) { return h2f<F16>(F16 ? f2h_sat(x) : f2bf(x)); };
+                k0 = make_float4(r16(k0.x), r16(k0.y), r16(k0.z), r16(k0.w)); k1 = make_float4(r16(k1.x), r16(k1.y), r16(k1.z), r16(k1.w));
                 const uint4 u = __builtin_bit_cast(uint4, qf[h][ks]);
                 acc = fmaf(h2f<F16>((uint16_t)(u.x & 0xffff)), k0.x, acc); acc = fmaf(h2f<F16>((uint16_t)(u.x >> 16)), k0.y, acc);
                 acc = fmaf(h2f<F16>((uint16_t)(u.y & 0xffff)), k0.z, acc); acc = fmaf(h2f<F16>((uint16_t)(u.y >> 16)), k0.w, acc);
@@ -509,6 +514,322 @@ __global__ __launch_bounds__(256) void xattn6_pack_kernel(const uint16_t* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, query side (xattn6_bwd): the two-pass recomputing backward of xattn3_bwd (xattn2.hip) -- one wave = 16 queries x all 8
+// heads, both head mixes on the matrix pipe, dS / Pm written chunk-major for the batched dK / dV products -- on the forward's recipe:
+// bf16 K and V images in LDS order (linear 1-KiB DMA pieces with a scalar base: the per-lane address arithmetic of 16 pieces per chunk
+// and wave is gone), the key mask as the C operand of the score MFMAs (no per-element compare / select), the score scale folded into
+// ONE fma per probability, no run-time probe branches inside the chunk loops, XCD-aware item order.  Keys keep the order of the dS / Pm
+// consumers (amdnuwa_gemm_tn + amdnuwa_xattn_unpack): key 0 = the null key, keys 1..T the context, JP / 32 chunks.
+// ------------------------------------------------------------------------------------------------
+struct X6BArgs {
+    const uint16_t* q; int ldq;
+    const uint16_t* dO; int lddo;
+    const char *K6, *V6;                     // [B][nch][NH][32][64] bf16, [key][d] tiles in k6_off order (K unscaled)
+    const uint32_t* vbits;                   // [B][nch]
+    const float* wth;
+    const float* stats;                      // [B][NH][n][2]
+    uint16_t *dS, *Pm;                       // [B][NH][nch][n][32] (chunk-major, chunk-permuted slots)
+    uint16_t* dq; int lddq;
+    float* part_th;                          // [grid][NH*NH]
+    int B, n, nch, T;
+    float scale;
+};
+constexpr float MASK_BIAS_RAW = -400000.f;   // unscaled score of a masked key (x scale * log2 e = -72 000 in the log2 domain)
+#define MFMAB(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+struct MixA { bf16x8 hi[2], lo[2]; };
+__device__ __forceinline__ MixA mix_operand_lds(const float* wsrc, int lane) {      // (xattn2.hip, mix_operand)
+    MixA a;
+    const int m = lane & 15;
+    const bool on = (m >> 2) == (lane >> 4);
+#pragma unroll
+    for (int Q = 0; Q < 2; ++Q) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wsrc + (4 * Q + (m & 3)) * 8), w1 = *reinterpret_cast<const float4*>(wsrc + (4 * Q + (m & 3)) * 8 + 4);
+        const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        uint32_t ph[4], pl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ph[t] = pack2_rne(w[2 * t], w[2 * t + 1]);
+            pl[t] = pack2_rne(w[2 * t] - lo_f(ph[t]), w[2 * t + 1] - hi_f(ph[t]));
+        }
+        a.hi[Q] = __builtin_bit_cast(bf16x8, on ? make_uint4(ph[0], ph[1], ph[2], ph[3]) : make_uint4(0, 0, 0, 0));
+        a.lo[Q] = __builtin_bit_cast(bf16x8, on ? make_uint4(pl[0], pl[1], pl[2], pl[3]) : make_uint4(0, 0, 0, 0));
+    }
+    return a;
+}
+__device__ __forceinline__ bf16x8 pack_heads8(const float (&v)[NH][8], int e) {
+    return __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(v[0][e], v[1][e]), pack2_rne(v[2][e], v[3][e]),
+                                                 pack2_rne(v[4][e], v[5][e]), pack2_rne(v[6][e], v[7][e])));
+}
+#define MIXB(A_, Q_, B_) MFMAB((A_).lo[Q_], B_, MFMAB((A_).hi[Q_], B_, (f32x4{0.f, 0.f, 0.f, 0.f})))
+// K^T (a [key][d] tile read transposed): lane (c, g4) gets tile[kb*16 + 4*g4 + j][db*16 + c], j = 0..3, for kb = 0, 1
+__device__ __forceinline__ bf16x8 lds_tr6(const char* base, int h, int db, int c, int g4) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int col = db * 16 + ((c & 3) << 2);
+    const int r0 = 4 * g4 + (c >> 2), r1 = 16 + r0;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + k6_off(h, r0, col >> 3) + ((col >> 2) & 1) * 8));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + k6_off(h, r1, col >> 3) + ((col >> 2) & 1) * 8));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float thsh[4][NH * NH];
+    __shared__ __attribute__((aligned(16))) float wsh[NH * NH], wtsh[NH * NH];          // W[g][h] and its transpose
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g4 = lane >> 4;
+    const int tiles = (a.n + 63) / 64;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bid / tiles, qi = (bid % tiles) * 64 + wave * 16 + c;
+    const bool qok = qi < a.n;
+    const int nch = a.nch;
+    const char* k6 = a.K6 + (size_t)b * nch * KT;
+    const char* v6 = a.V6 + (size_t)b * nch * KT;
+    const int ko0 = k6_off(0, c, g4), ko1 = k6_off(0, c, 4 + g4);
+    if (tid < NH * NH) { const float v = a.wth[tid]; wsh[tid] = v; wtsh[(tid & 7) * 8 + (tid >> 3)] = v; }
+    const uint32_t wv = lane < nch ? a.vbits[(size_t)b * nch + lane] : 0u;
+    __syncthreads();                                             // (before any DMA is in flight)
+    // K + V of chunk ch -> stage: 64 pieces, 16 per wave
+    auto stage = [&](int stg, int ch) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int piece = wave + 4 * i;
+            dma16_s(k6 + (size_t)ch * KT + piece * 1024, lane * 16, smem + stg * STAGE + piece * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int piece = wave + 4 * i;
+            dma16_s(v6 + (size_t)ch * KT + piece * 1024, lane * 16, smem + stg * STAGE + KT + piece * 1024);
+        }
+    };
+    auto bias_raw = [&](int ch, f32x4& b0, f32x4& b1) {
+        const uint32_t u = __builtin_amdgcn_readlane(wv, ch) >> (4 * g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            b0[r] = ((u >> r) & 1u) ? 0.f : MASK_BIAS_RAW;
+            b1[r] = ((u >> (16 + r)) & 1u) ? 0.f : MASK_BIAS_RAW;
+        }
+    };
+    stage(0, 0);
+    const MixA AW = mix_operand_lds(wsh, lane), AWT = mix_operand_lds(wtsh, lane);
+    const float c1 = a.scale * 1.4426950408889634f;
+    bf16x8 qf[NH][KS], df[NH][KS];
+    float nb[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[h][ks] = ldg16(a.q + ((size_t)b * a.n + qi) * a.ldq + h * DH + ks * 32 + g4 * 8, qok);
+            df[h][ks] = ldg16(a.dO + ((size_t)b * a.n + qi) * a.lddo + h * DH + ks * 32 + g4 * 8, qok);
+        }
+        const float2 st = qok ? *reinterpret_cast<const float2*>(a.stats + (((size_t)b * NH + h) * a.n + qi) * 2) : make_float2(0.f, 1.f);
+        nb[h] = qok ? __log2f(st.y) - st.x : 0.f;
+    }
+    // (the compiler's counter model must see these loads complete before the ring's counted waits: see xattn5_bwd_kv_kernel)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[h][ks]), "v"(df[h][ks]));
+        asm volatile("" ::"v"(nb[h]));
+    }
+    const size_t hplane = (size_t)nch * a.n * 32;                // elements between heads in dS / Pm
+    // probabilities of head h for this lane's 8 slots of the chunk in `kbase`
+    auto probs = [&](const char* kbase, int h, const f32x4& b0, const f32x4& b1, float* P) {
+        const KF f = k_frags(kbase, h, ko0, ko1);
+        f32x4 s0 = b0, s1 = b1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { s0 = MFMAB(f.v[0][ks], qf[h][ks], s0); s1 = MFMAB(f.v[1][ks], qf[h][ks], s1); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            P[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c1, nb[h]));
+            P[4 + r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c1, nb[h]));
+        }
+    };
+    // dP'^T[g] = V[g] dO[g]^T for this lane's 8 slots
+    auto dpp = [&](const char* vbase, int g, float* d) {
+        const KF f = k_frags(vbase, g, ko0, ko1);
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { s0 = MFMAB(f.v[0][ks], df[g][ks], s0); s1 = MFMAB(f.v[1][ks], df[g][ks], s1); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { d[r] = s0[r]; d[4 + r] = s1[r]; }
+    };
+
+    // ---- pass A: P' = W P -> Pm;  dP = W^T dP' (both mixes on the matrix pipe);  delta[h] = sum_j dP[h] P[h];
+    //      dW_th[g][h] += sum dP'[g] P[h] (the one block that stays on the VALU: its contraction runs over lanes)
+    float delta[NH], dth[NH][NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        delta[h] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NH; ++g) dth[g][h] = 0.f;
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) { stage((ch + 1) & 1, ch + 1); VMCNT(16); }
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        const char* kbase = smem + (ch & 1) * STAGE;
+        const char* vbase = kbase + KT;
+        f32x4 b0, b1;
+        bias_raw(ch, b0, b1);
+        float P[NH][8];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) probs(kbase, h, b0, b1, P[h]);
+        const bool st = qok && 32 * ch + 4 * g4 <= a.T;          // (a lane group whose 8 keys are all padding writes nothing)
+#pragma unroll
+        for (int Q = 0; Q < 2; ++Q) {
+            f32x4 D[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) D[e] = MIXB(AW, Q, pack_heads8(P, e));
+            if (st) {
+#pragma unroll
+                for (int rp = 0; rp < 4; ++rp) {
+                    uint16_t* dst = a.Pm + ((size_t)b * NH + 4 * Q + rp) * hplane + ((size_t)ch * a.n + qi) * 32 + g4 * 8;
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(pack2_rne(D[0][rp], D[1][rp]), pack2_rne(D[2][rp], D[3][rp]),
+                                                                pack2_rne(D[4][rp], D[5][rp]), pack2_rne(D[6][rp], D[7][rp]));
+                }
+            }
+        }
+        uint32_t bw[8][4];
+#pragma unroll
+        for (int gp = 0; gp < 4; ++gp) {
+            float d0[8], d1[8];
+            dpp(vbase, 2 * gp, d0);
+            dpp(vbase, 2 * gp + 1, d1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bw[e][gp] = pack2_rne(d0[e], d1[e]);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float a0 = dth[2 * gp][h], a1 = dth[2 * gp + 1][h];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a0 = fmaf(d0[e], P[h][e], a0); a1 = fmaf(d1[e], P[h][e], a1); }
+                dth[2 * gp][h] = a0; dth[2 * gp + 1][h] = a1;
+            }
+        }
+#pragma unroll
+        for (int Q = 0; Q < 2; ++Q) {
+            f32x4 D[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                D[e] = MIXB(AWT, Q, __builtin_bit_cast(bf16x8, make_uint4(bw[e][0], bw[e][1], bw[e][2], bw[e][3])));   // D[e][rp] = dP[4Q + rp]
+#pragma unroll
+            for (int rp = 0; rp < 4; ++rp) {
+                float acc = delta[4 * Q + rp];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf(D[e][rp], P[4 * Q + rp][e], acc);
+                delta[4 * Q + rp] = acc;
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    // pass B's first chunk is on its way while the statistics are reduced
+    stage(0, 0);
+    // a query's keys are spread over the 4 lane groups
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        delta[h] += __shfl_xor(delta[h], 16, 64);
+        delta[h] += __shfl_xor(delta[h], 32, 64);
+    }
+    // dW_th partial of this workgroup (fixed order over the 4 waves): lane l ends up with the wave's sum of entry l = g * NH + h
+    {
+        float tv[NH * NH];
+#pragma unroll
+        for (int g = 0; g < NH; ++g)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) tv[g * NH + h] = qok ? dth[g][h] : 0.f;
+        thsh[wave][lane] = wave_sum64_transposed(tv, lane);
+    }
+    __syncthreads();
+    if (tid < NH * NH) a.part_th[(size_t)bid * NH * NH + tid] = ((thsh[0][tid] + thsh[1][tid]) + thsh[2][tid]) + thsh[3][tid];
+
+    // ---- pass B: ds[h] = P[h] (dP[h] - delta[h]) -> dS;  dq^T[h] += K^T[h] ds^T[h]
+    f32x4 dQ[NH][DB];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) dQ[h][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) { stage((ch + 1) & 1, ch + 1); VMCNT(16); }
+        else VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        const char* kbase = smem + (ch & 1) * STAGE;
+        const char* vbase = kbase + KT;
+        f32x4 b0, b1;
+        bias_raw(ch, b0, b1);
+        bf16x8 bmD[8];
+        {
+            uint32_t bw[8][4];
+#pragma unroll
+            for (int gp = 0; gp < 4; ++gp) {
+                float d0[8], d1[8];
+                dpp(vbase, 2 * gp, d0);
+                dpp(vbase, 2 * gp + 1, d1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bw[e][gp] = pack2_rne(d0[e], d1[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bmD[e] = __builtin_bit_cast(bf16x8, make_uint4(bw[e][0], bw[e][1], bw[e][2], bw[e][3]));
+        }
+        const bool st = qok && 32 * ch + 4 * g4 <= a.T;
+#pragma unroll
+        for (int Q = 0; Q < 2; ++Q) {
+            f32x4 D[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) D[e] = MIXB(AWT, Q, bmD[e]);
+#pragma unroll
+            for (int rp = 0; rp < 4; ++rp) {
+                const int h = 4 * Q + rp;
+                float P[8], ds[8];
+                probs(kbase, h, b0, b1, P);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ds[e] = P[e] * (D[e][rp] - delta[h]);
+                const uint4 pk = make_uint4(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]), pack2_rne(ds[4], ds[5]), pack2_rne(ds[6], ds[7]));
+                if (st) *reinterpret_cast<uint4*>(a.dS + ((size_t)b * NH + h) * hplane + ((size_t)ch * a.n + qi) * 32 + g4 * 8) = pk;
+                const bf16x8 sf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) dQ[h][db] = MFMAB(lds_tr6(kbase, h, db, c, g4), sf, dQ[h][db]);
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (qok) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                uint16_t* dst = a.dq + ((size_t)b * a.n + qi) * a.lddq + h * DH + db * 16 + g4 * 4;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(dQ[h][db][0] * a.scale, dQ[h][db][1] * a.scale),
+                                                            pack2_rne(dQ[h][db][2] * a.scale, dQ[h][db][3] * a.scale));
+            }
+    }
+}
+
+// images of the backward: kv [B*T, ldkv] bf16 + the null key / value -> K6 / V6 ([key][d] tiles, key 0 = null, keys 1..T the context) / vbits
+__global__ __launch_bounds__(256) void xattn6_pack_bwd_kernel(const uint16_t* __restrict__ kv, int ldkv, const float* __restrict__ null_k,
+                                                              const float* __restrict__ null_v, const uint8_t* __restrict__ mask,
+                                                              char* __restrict__ K6, char* __restrict__ V6, uint32_t* __restrict__ vbits, int T, int nch) {
+    const int b = blockIdx.x / nch, ch = blockIdx.x % nch, tid = threadIdx.x;
+    const size_t cbase = ((size_t)b * nch + ch) * KT;
+    if (tid < 64) {
+        const int j = 32 * ch + tid;
+        const bool ok = tid < 32 && (j == 0 || (j <= T && (mask ? mask[(size_t)b * T + j - 1] != 0 : true)));
+        const unsigned long long bal = __ballot(ok);
+        if (tid == 0) vbits[(size_t)b * nch + ch] = (uint32_t)bal;
+    }
+    for (int e = tid; e < 2 * NH * 32 * 8; e += 256) {
+        const int part = e >> 11, h = (e >> 8) & 7, row = (e >> 3) & 31, pos = e & 7, gc = pos ^ (row & 7), j = 32 * ch + row;
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (j == 0) {
+            const float* src = (part ? null_v : null_k) + h * DH + gc * 8;
+            r = make_uint4(pack2_rne(src[0], src[1]), pack2_rne(src[2], src[3]), pack2_rne(src[4], src[5]), pack2_rne(src[6], src[7]));
+        } else if (j <= T) r = *reinterpret_cast<const uint4*>(kv + ((size_t)b * T + j - 1) * ldkv + part * NH * DH + h * DH + gc * 8);
+        *reinterpret_cast<uint4*>((part ? V6 : K6) + cbase + h * TILE + row * 128 + pos * 16) = r;
+    }
+}
+
 int cu_count() {
     static int cus = 0;
     if (!cus) {
@@ -573,6 +894,41 @@ extern "C" int amdnuwa_xattn6_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
         (void)hipFuncSetAttribute((const void*)xattn6_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         hipLaunchKernelGGL(xattn6_fwd_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
     }
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+
+extern "C" size_t amdnuwa_xattn6_bwd_image_bytes(const amdnuwa_xattn_geom* g) {
+    return (check6(g) || g->JP % 32 || g->JP < g->T + 1 || g->JP / 32 > 64) ? 0 : (size_t)g->B * (g->JP / 32) * KT;
+}
+extern "C" int amdnuwa_xattn6_pack_bwd(const amdnuwa_xattn_geom* g, const uint16_t* kv, int ldkv, const float* null_k, const float* null_v,
+                                       const uint8_t* context_mask, const amdnuwa_xattn6_kv* out, hipStream_t stream) {
+    if (!amdnuwa_xattn6_bwd_image_bytes(g)) return g ? AMDNUWA_ERR_UNSUPPORTED : AMDNUWA_ERR_ARG;
+    if (!kv || !null_k || !null_v || !out || !out->K6 || !out->V6 || !out->vbits || ldkv % 8 || ldkv < 2 * NH * DH) return AMDNUWA_ERR_ARG;
+    if (g->B <= 0) return AMDNUWA_OK;
+    const int nch = g->JP / 32;
+    hipLaunchKernelGGL(xattn6_pack_bwd_kernel, dim3(g->B * nch), dim3(256), 0, stream, kv, ldkv, null_k, null_v, context_mask, (char*)out->K6,
+                       (char*)out->V6, out->vbits, g->T, nch);
+    LAUNCH_CHECK();
+    return AMDNUWA_OK;
+}
+extern "C" size_t amdnuwa_xattn6_bwd_workspace_bytes(const amdnuwa_xattn_geom* g) {
+    return amdnuwa_xattn6_bwd_image_bytes(g) ? (size_t)g->B * ((g->n + 63) / 64) * NH * NH * sizeof(float) : 0;
+}
+extern "C" int amdnuwa_xattn6_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo, const amdnuwa_xattn6_kv* kv,
+                                  const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm, uint16_t* dq, int lddq, float* part_th,
+                                  size_t part_bytes, hipStream_t stream) {
+    if (!amdnuwa_xattn6_bwd_image_bytes(g)) return g ? AMDNUWA_ERR_UNSUPPORTED : AMDNUWA_ERR_ARG;
+    if (!q || !dO || !kv || !kv->K6 || !kv->V6 || !kv->vbits || !w_th || !stats || !dS || !Pm || !dq || ldq % 8 || lddo % 8 || lddq % 4)
+        return AMDNUWA_ERR_ARG;
+    if (!part_th || part_bytes < amdnuwa_xattn6_bwd_workspace_bytes(g)) return AMDNUWA_ERR_WORKSPACE;
+    if (g->B <= 0 || g->n <= 0) return AMDNUWA_OK;
+    X6BArgs a{};
+    a.q = q; a.ldq = ldq; a.dO = dO; a.lddo = lddo; a.K6 = (const char*)kv->K6; a.V6 = (const char*)kv->V6; a.vbits = kv->vbits;
+    a.wth = w_th; a.stats = stats; a.dS = dS; a.Pm = Pm; a.dq = dq; a.lddq = lddq; a.part_th = part_th;
+    a.B = g->B; a.n = g->n; a.nch = g->JP / 32; a.T = g->T; a.scale = g->scale;
+    (void)hipFuncSetAttribute((const void*)xattn6_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    hipLaunchKernelGGL(xattn6_bwd_kernel, dim3(g->B * ((g->n + 63) / 64)), dim3(256), 2 * STAGE, stream, a);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

@@ -1198,6 +1198,49 @@ def xattn6_fwd(g, q16, pk, null_k, null_v, wth, o_f16=False, lo=True):
     return o, stats
 
 
+class PackedKV6B:
+    """bf16 [key][d] images of the xattn6 backward (amdnuwa_xattn6_pack_bwd): key 0 = the null key, keys 1..T the context, JP / 32 chunks"""
+
+    def __init__(self, g, device):
+        self.nch = g.JP // 32
+        sh = (g.B, self.nch, g.heads, 32, g.dim_head)
+        self.K6, self.V6 = torch.empty(sh, dtype=torch.bfloat16, device=device), torch.empty(sh, dtype=torch.bfloat16, device=device)
+        self.vbits = torch.empty((g.B, self.nch), dtype=torch.int32, device=device)
+        s = _lib.X6KV()
+        s.K6, s.V6, s.vbits = _p(self.K6), _p(self.V6), _p(self.vbits)
+        self.struct = s
+
+
+def xattn6_bwd_ok(g):
+    return _XATTN6 and os.environ.get('AMDNUWA_XATTN6_BWD', '1') != '0' and _lib.lib().amdnuwa_xattn6_bwd_image_bytes(C.byref(g)) > 0 and \
+        xattn_chunk_major_ok(g)
+
+
+def xattn6_pack_bwd(g, kv_bf16, null_k, null_v, mask_u8):
+    assert kv_bf16.dtype == torch.bfloat16 and kv_bf16.stride(1) == 1
+    pk = PackedKV6B(g, kv_bf16.device)
+    check(_lib.lib().amdnuwa_xattn6_pack_bwd(C.byref(g), _p(kv_bf16), kv_bf16.stride(0), _p(null_k), _p(null_v), _p(mask_u8), C.byref(pk.struct),
+                                             _stream()), 'amdnuwa_xattn6_pack_bwd')
+    return pk
+
+
+def xattn6_bwd(g, q, dO, pk, wth, stats):
+    """the query side of the recomputing backward on xattn6 images: returns dq BF [B*n, inner], dS BF and Pm BF chunk-major
+    [B, h, JP / 32, n, 32] (what xattn_kv_grads takes), dw_th fp32 [h, h] -- the results of xattn2_bwd(chunk_major=True)"""
+    L = _lib.lib()
+    inner = g.heads * g.dim_head
+    dev = q.hi.device
+    dq = empty_bf((g.B * g.n, inner), dev, lo=False)
+    shape = (g.B, g.heads, g.JP // 32, g.n, 32)
+    dS, Pm = empty_bf(shape, dev, lo=False), empty_bf(shape, dev, lo=False)
+    nb = L.amdnuwa_xattn6_bwd_workspace_bytes(C.byref(g))
+    part = torch.empty((nb // (4 * g.heads * g.heads), g.heads * g.heads), dtype=torch.float32, device=dev)
+    check(L.amdnuwa_xattn6_bwd(C.byref(g), _p(q.hi), q.hi.stride(0), _p(dO.hi), dO.hi.stride(0), C.byref(pk.struct), _p(wth), _p(stats),
+                               _p(dS.hi), _p(Pm.hi), _p(dq.hi), inner, _p(part), nb, _stream()), 'amdnuwa_xattn6_bwd')
+    dwth = colsum(part).reshape(g.heads, g.heads)          # fixed-order reduction over the workgroups
+    return dq, BF(dS.hi, None), BF(Pm.hi, None), dwth
+
+
 def xattn_fwd(g, q, pk, wth, save=True, want_stats=False):
     """first-design kernel (bf16 or bf16x3).  save: keep P / P' for amdnuwa_xattn_bwd.  want_stats: return the softmax statistics
     [B, h, n, 2] the recomputing backward (xattn2_bwd) takes instead -- (o, stats) is then the result."""

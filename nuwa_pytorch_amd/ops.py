@@ -285,7 +285,11 @@ class XInner:
         # third-design forward core (xattn6: images in LDS order, null key as a rank-one term) wherever the second design ran; the bf16
         # recomputing backward keeps its two [key][d] images
         x6 = K.xattn6_on() and K.xattn6_supported(g) and (f16 or K.xattn2_supported(g, q)) and nk2.dtype == torch.float32
-        pk = K.xattn_pack(g, kv, nk2, nv2, meta['mask_u8'], lean=('bwd' if x6 and not K.xattn2_bwd_rc_ok(g) else (f16 and not K.xattn2_bwd_rc_ok(g))))
+        x6b = x6 and K.xattn6_bwd_ok(g) and not K.xattn2_bwd_rc_ok(g)
+        if x6b:       # the backward's own images (bf16 [key][d] tiles in LDS order)
+            pk = K.xattn6_pack_bwd(g, kv.hi, nk2, nv2, meta['mask_u8'])
+        else:
+            pk = K.xattn_pack(g, kv, nk2, nv2, meta['mask_u8'], lean=('bwd' if x6 and not K.xattn2_bwd_rc_ok(g) else (f16 and not K.xattn2_bwd_rc_ok(g))))
         wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
         o16 = False
         if f16:                               # 'bf16x3-fwd': the forward core on single fp16 MFMAs, hi + lo output, statistics for the bf16 backward
@@ -327,7 +331,10 @@ class XInner:
             dq, dKp, dVp, dwth = K.xattn2_bwd_rc(g, q, d_o, pk, wth2, P)         # no dS / Pm arrays: the key side recomputes them
         else:
             if Pm is None:
-                dq, dS, Pm, dwth = K.xattn2_bwd(g, q, d_o, pk, wth2, P)          # dS / Pm columns in the kernel's chunk-permuted key order
+                if isinstance(pk, K.PackedKV6B):
+                    dq, dS, Pm, dwth = K.xattn6_bwd(g, q, d_o, pk, wth2, P)
+                else:
+                    dq, dS, Pm, dwth = K.xattn2_bwd(g, q, d_o, pk, wth2, P)      # dS / Pm columns in the kernel's chunk-permuted key order
                 permuted = True
             else:
                 dq, dS, dwth = K.xattn_bwd(g, d_o, pk, wth2, P)

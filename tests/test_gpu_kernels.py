@@ -1073,6 +1073,52 @@ def test_cross_attention_xattn6_fwd(K, O, B, n, T, f16):
             report('xattn6_vs_xattn4' + tag, bf_value(o), bf_value(o4), 2e-3)
 
 
+@pytest.mark.parametrize('B,n,T', [(2, 100, 33), (2, 64, 256), (2, 2560, 256), (3, 70, 1), (2, 130, 64), (4, 300, 200)])
+def test_cross_attention_xattn6_bwd(K, O, B, n, T):
+    """the query side of the recomputing backward on xattn6 images against the oracle's gradients (through the batched dK / dV products and
+    xattn_unpack) and against xattn2_bwd on the same statistics (same rounding points; the score scale is one fma instead of mul + add)"""
+    heads, dh = 8, 64
+    inner = heads * dh
+    torch.manual_seed(13)
+    q = bf_round(torch.randn(B, n, heads, dh)).requires_grad_(True)
+    kv = bf_round(torch.randn(B, T, 2, heads, dh)).requires_grad_(True)
+    nk, nv = bf_round(torch.randn(heads, dh)).requires_grad_(True), bf_round(torch.randn(heads, dh)).requires_grad_(True)
+    wth = (torch.randn(heads, heads) * 0.5 + torch.eye(heads)).requires_grad_(True)
+    mask = torch.rand(B, T) > 0.3
+    mask[0] = False                     # a fully masked sample attends only the null key: its dq is exactly zero
+    o_ref = O.attention_core(q, kv[:, :, 0], kv[:, :, 1], nk, nv, wth, mask, dh ** -0.5)
+    do = bf_round(torch.randn(B, n, heads, dh))
+    o_ref.backward(do)
+    g = K.x_geom(B, n, T, heads, dh)
+    if not K.xattn6_bwd_ok(g):
+        pytest.skip('whole-M chunk-major TN product not taken for this shape')
+    qp = K.BF(q.detach().reshape(B * n, inner).to(torch.bfloat16).to(DEV), None)
+    kvp = K.BF(kv.detach().reshape(B * T, 2 * inner).to(torch.bfloat16).to(DEV), None)
+    dop = K.BF(do.reshape(B * n, inner).to(torch.bfloat16).to(DEV), None)
+    m8 = mask.to(torch.uint8).to(DEV)
+    w = wth.detach().to(DEV)
+    pk6 = K.xattn6_pack(g, kvp.hi, m8)
+    o, stats = K.xattn6_fwd(g, qp.hi, pk6, nk.detach().to(DEV), nv.detach().to(DEV), w, lo=False)
+    pkb = K.xattn6_pack_bwd(g, kvp.hi, nk.detach().to(DEV), nv.detach().to(DEV), m8)
+    dq, dS, Pm, dwth = K.xattn6_bwd(g, qp, dop, pkb, w, stats)
+    tag = f'[{B},{n},{T}]'
+    report('xattn6_bwd.dq' + tag, dq.hi.float().reshape(B, n, heads, dh), q.grad, 2 ** -6)
+    report('xattn6_bwd.dwth' + tag, dwth, wth.grad, 2 ** -6)
+    dKp, dVp = K.xattn_kv_grads(g, dS, Pm, qp, dop)
+    dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=False, permuted=True)
+    report('xattn6_bwd.dkv' + tag, dkv.hi.float().reshape(B, T, 2, heads, dh), kv.grad, 2 ** -6)
+    report('xattn6_bwd.dnull_k' + tag, dnk, nk.grad, 2 ** -6)
+    report('xattn6_bwd.dnull_v' + tag, dnv, nv.grad, 2 ** -6)
+    # the second design on the same statistics
+    pko = K.xattn_pack(g, kvp, nk.detach().to(DEV), nv.detach().to(DEV), m8)
+    dq2, dS2, Pm2, dwth2 = K.xattn2_bwd(g, qp, dop, pko, w, stats, chunk_major=True)
+    mx = K.xattn_permuted_extent(g)
+    report('xattn6_bwd.vs_xattn2.dq' + tag, dq.hi.float(), dq2.hi.float(), 2 ** -7)
+    report('xattn6_bwd.vs_xattn2.dS' + tag, K.xattn_rows(g, dS.hi).float()[..., :mx], K.xattn_rows(g, dS2.hi).float()[..., :mx], 2 ** -6)
+    report('xattn6_bwd.vs_xattn2.Pm' + tag, K.xattn_rows(g, Pm.hi).float()[..., :mx], K.xattn_rows(g, Pm2.hi).float()[..., :mx], 2 ** -7)
+    report('xattn6_bwd.vs_xattn2.dwth' + tag, dwth, dwth2, 2 ** -8)
+
+
 def test_gemm_nt_fp16_operands_and_ln_fp16_copy(K):
     """the FeedForward forward of 'bf16x3-fwd': LayerNorm stores a bf16 + fp16 copy pair, FF1 runs on the fp16 MFMA with the gate in its
     epilogue (u bf16 for the backward, gate output as fp16 + bf16 copies), FF2 on the fp16 MFMA to fp32 -- against fp64 on the same

@@ -65,5 +65,40 @@ def main():
         print(f'max |o6 - o4| / max |o4| = {d:.2e}')
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and not (len(sys.argv) > 1 and sys.argv[1] == 'bwd'):
     main()
+
+
+def bwd_main():
+    """python tools/xattn6_bench.py bwd [--batch b]: query side of the backward, third design against the second, A/B/A/B"""
+    b = int(sys.argv[sys.argv.index('--batch') + 1]) if '--batch' in sys.argv else 128
+    dev = 'cuda'
+    n, heads, dh, T = 2560, 8, 64, 256
+    inner = heads * dh
+    torch.manual_seed(0)
+    g = K.x_geom(b, n, T, heads, dh)
+    q = K.BF(torch.randn(b * n, inner, device=dev).to(torch.bfloat16), None)
+    do = K.BF(torch.randn(b * n, inner, device=dev).to(torch.bfloat16), None)
+    kv = K.BF(torch.randn(b * T, 2 * inner, device=dev).to(torch.bfloat16), None)
+    nk, nv = torch.randn(heads, dh, device=dev), torch.randn(heads, dh, device=dev)
+    wth = (torch.randn(heads, heads, device=dev) * 0.3 + torch.eye(heads, device=dev)).contiguous()
+    mask = (torch.rand(b, T, device=dev) > 0.2).to(torch.uint8)
+    pk6 = K.xattn6_pack(g, kv.hi, mask)
+    o, stats = K.xattn6_fwd(g, q.hi, pk6, nk, nv, wth, lo=False)
+    pkb = K.xattn6_pack_bwd(g, kv.hi, nk, nv, mask)
+    pko = K.xattn_pack(g, kv, nk, nv, mask)
+    rows = []
+    for rnd in range(2):
+        rows.append(f'pack_bwd6 {bench(lambda: K.xattn6_pack_bwd(g, kv.hi, nk, nv, mask), 10):6.1f}')
+        rows.append(f'xattn6_bwd {bench(lambda: K.xattn6_bwd(g, q, do, pkb, wth, stats), 10):7.1f}')
+        rows.append(f'xattn3_bwd {bench(lambda: K.xattn2_bwd(g, q, do, pko, wth, stats, chunk_major=True), 10):7.1f}')
+    print(f'== cross-attention backward, query side, b={b} (incl. the colsum of the dW_th partials) ==')
+    print(' | '.join(rows))
+    dq, dS, Pm, dwth = K.xattn6_bwd(g, q, do, pkb, wth, stats)
+    rows = []
+    rows.append(f'kv grads (2 batched TN) {bench(lambda: K.xattn_kv_grads(g, dS, Pm, q, do), 10):7.1f}')
+    print(' | '.join(rows))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'bwd':
+    bwd_main()
