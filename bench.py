@@ -23,10 +23,14 @@ What the line carries (rank 0):
   value / ms_per_step   EXACTLY K steps between barrier + synchronize on both sides, wall clock, max over ranks; the per-launch
                         HIP-event timer of the library is OFF in this region.  `ms_per_step_median` = median of the K per-step
                         HIP-event intervals recorded on the compute stream in the same region.
-  roofline              the NT GEMM family (largest share of the step), from a SECOND pass of a few steps with the library's
+  roofline              SURVEY 8(d): the WHOLE decoder step -- algorithmic FLOPs of forward + backward / ms_per_step against the dense bf16
+                        MFMA peak (`frac` == `step_mfma_frac`); `families` = the same object per kernel family (gemm_nt, xattn: MFMA-bound;
+                        s3, ln: HBM-bound, algorithmic bytes / time against 8 TB/s) from a SECOND pass of a few steps with the library's
                         per-launch HIP-event timer armed (events on the launch stream, inside libamdnuwa).
   parity                the same 24-layer decoder, one sample, logits against the oracle's (fp32 CPU restatement of the
-                        reference) in every precision mode, measured in this run.
+                        reference) in every precision mode, measured in this run; `worst_of_8` = the committed sweep over 8 samples / 3
+                        models (tools/parity_sweep.py -> profiles/parity_sweep.json); `grad_rel_max` = worst gradient error of ONE cfg-3
+                        decoder layer (dx, dcontext, every parameter) against the oracle, live, in the headline mode and in 'bf16'.
   fast_mode             throughput of the all-bf16 mode (no lo parts anywhere; logits error in `parity.bf16`) in the same run.
   cpu_baseline          the oracle's full step (24 layers forward + backward through the CE loss), b = 1, on the host cores.
 """
@@ -53,6 +57,7 @@ CFGS = {
                  text_len=256, codebook=512, vae=dict(dim=64, image_size=64, num_layers=2)),
 }
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0          # HBM3E peak, MI355X_MICROARCH.md
 ROOFLINE_SOURCES = ('nuwa_pytorch_amd/csrc/gemm.hip',)      # kernels the committed PMC traffic figure belongs to
 
 
@@ -163,6 +168,48 @@ def gpu_logits(nuwa, ids, ctx, mask, mode):
             return nuwa._final(h).float().cpu()
     finally:
         A.set_precision(prev)
+
+
+def layer_grad_parity(A, c, modes=('bf16x3-fwd', 'bf16')):
+    """worst max-abs / max-abs gradient error of ONE decoder layer (3DNA dilation 1 + text cross attention + FeedForward) at the named
+    size against the oracle on the same inputs, per precision mode -- the number that says what the benchmarked backward computes
+    (tests/test_gpu_named_size.py asserts the same quantity for every dilation)"""
+    import nuwa_pytorch_amd.nuwa_pytorch as M
+    from oracle import nuwa_oracle as O
+    vs, T = (c['frames'], c['fmap'], c['fmap']), c['text_len']
+    torch.manual_seed(0)
+    tr = M.Transformer(dim=c['dim'], depth=1, causal=True, heads=c['heads'], dim_head=c['dim_head'], cross_attend=True, sparse_3dna_attn=True,
+                       sparse_3dna_kernel_size=c['kernel'], sparse_3dna_video_shape=vs, sparse_3dna_dilations=(c['dilation'][0],),
+                       shift_video_tokens=True)
+    with torch.no_grad():
+        for n_, p in tr.named_parameters():
+            if 'norm' in n_ or n_.endswith('.bias'):
+                p.add_(0.1 * torch.randn_like(p))
+    P = {k: v.detach().cpu().clone() for k, v in tr.state_dict().items()}
+    Pr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in P.items()}
+    n = vs[0] * vs[1] * vs[2]
+    g = torch.Generator().manual_seed(7)
+    x, ctx = torch.randn(1, n, c['dim'], generator=g), torch.randn(1, T, c['dim'], generator=g)
+    mask = torch.ones(1, T, dtype=torch.bool)
+    mask[:, -T // 4:] = torch.rand(1, T // 4, generator=g) > 0.5
+    dy = torch.randn(1, n, c['dim'], generator=g)
+    cfg = dict(video_shape=vs, kernel_size=c['kernel'], dilations=(c['dilation'][0],), heads=c['heads'], depth=1, shift=True)
+    xr, cr = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    O.decoder_layer(xr, O.sub(Pr, 'layers.0'), cfg, 0, cr, mask).backward(dy)
+    tr = tr.to('cuda')
+    rel = lambda a, b: float((a.detach().double().cpu() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+    out = {}
+    for mode in modes:
+        A.set_precision(mode)
+        tr.zero_grad(set_to_none=True)
+        xd, cd = x.cuda().requires_grad_(True), ctx.cuda().requires_grad_(True)
+        tr.forward_layers(xd, context=cd, context_mask=mask.cuda()).backward(dy.cuda())
+        worst = max(rel(xd.grad, xr.grad), rel(cd.grad, cr.grad))
+        for k, p in tr.named_parameters():
+            if Pr[k].grad is not None:
+                worst = max(worst, rel(p.grad, Pr[k].grad))
+        out[mode] = worst
+    return out
 
 
 def file_sha16(paths):
@@ -356,6 +403,7 @@ def main():
     # ---- second pass (rank 0's numbers): the library's per-launch HIP-event timer armed around every amdnuwa_gemm_nt launch
     probe_steps = max(1, min(args.steps, 5))
     gemm_ms, gemm_launches, gemm_flops, gemm_bytes, gemm_issued = (0.0, 0, 0.0, 0.0, 0.0)
+    families = {}
     if rank == 0:
         K.timer_arm(True)
     t1 = time.perf_counter()
@@ -366,6 +414,7 @@ def main():
     if rank == 0:
         gemm_ms, gemm_launches, gemm_flops, gemm_bytes = K.timer_collect()
         gemm_issued = K.timer_issued_flops()
+        families = K.timer_families()
         K.timer_arm(False)
 
     # ---- the all-bf16 mode beside the headline (same batch unless --side-batch), a few steps
@@ -443,18 +492,38 @@ def main():
             'step_mfma_frac': step_flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
             'timing': 'value: wall clock over exactly `steps` steps between barrier+synchronize fences, max over ranks, library timer off; '
                       'ms_per_step_median: median of the per-step HIP-event intervals on the compute stream in the same region',
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_nt_* (bf16 MFMA NT GEMM family; `achieved` counts the ALGORITHMIC 2MNK per product, `mfma_issued_tflops` what the hi+lo forward GEMMs really issue; every amdnuwa_gemm_nt launch of a separate pass of '
-                                                     f'{probe_steps} step(s) with the per-launch HIP-event timer armed, events on the launch stream)',
-                         'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                         'traffic': None, 'algorithmic_bytes_per_launch': gemm_bytes / max(gemm_launches, 1),
-                         'flops_per_launch': gemm_flops / max(gemm_launches, 1),
-                         'mfma_issued_tflops': gemm_issued / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
-                         'launches': gemm_launches, 'avg_launch_us': gemm_ms * 1e3 / max(gemm_launches, 1),
-                         'share_of_step': gemm_ms * 1e-3 / dt_probe},
+            'roofline': {'bound': 'mfma', 'kernel': 'the whole decoder step (SURVEY 8(d)): algorithmic FLOPs of forward + backward (3 x the forward products) / ms_per_step '
+                                                     'against the dense bf16 MFMA peak; `traffic` = HBM bytes per step from the committed FETCH / WRITE counter passes',
+                         'achieved': step_flops / (dt / args.steps) / 1e12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': step_flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 'traffic': None,
+                         'flops_per_step': step_flops, 'families': {}},
         }
+        gemm_fam = {'bound': 'mfma', 'kernel': 'gemm_nt_* (bf16 / fp16 MFMA NT GEMM family; `achieved` counts the ALGORITHMIC 2MNK per product, `mfma_issued_tflops` what the hi+lo forward GEMMs really issue; every amdnuwa_gemm_nt launch of a separate pass of '
+                              f'{probe_steps} step(s) with the per-launch HIP-event timer armed, events on the launch stream)',
+                    'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
+                    'traffic': None, 'algorithmic_bytes_per_launch': gemm_bytes / max(gemm_launches, 1),
+                    'flops_per_launch': gemm_flops / max(gemm_launches, 1),
+                    'mfma_issued_tflops': gemm_issued / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
+                    'launches': gemm_launches, 'avg_launch_us': gemm_ms * 1e3 / max(gemm_launches, 1),
+                    'ms_per_step': gemm_ms / probe_steps, 'share_of_step': gemm_ms * 1e-3 / dt_probe}
+        out['roofline']['families']['gemm_nt'] = gemm_fam
+        for nm, bound, what in (('xattn', 'mfma', 'cross-attention cores: forward, backward query side, batched dK / dV products (algorithmic QK^T / P\'V / head-mix FLOPs)'),
+                                ('s3', 'hbm', 'Sparse3DNA cores: forward (reads q, k, v, writes o) and backward (reads q, k, v, dO, writes dq, dk, dv)'),
+                                ('ln', 'hbm', 'LayerNorm kernels: every large operand read once, every result written once')):
+            f = families.get(nm)
+            if not f or f['ms'] <= 0:
+                continue
+            if bound == 'mfma':
+                a_, pk_, un_ = f['flops'] / (f['ms'] * 1e-3) / 1e12, PEAK_BF16_TFLOPS, 'TFLOP/s'
+            else:
+                a_, pk_, un_ = f['bytes'] / (f['ms'] * 1e-3) / 1e9, PEAK_HBM_GBS, 'GB/s'
+            out['roofline']['families'][nm] = {'bound': bound, 'kernel': what, 'achieved': a_, 'peak': pk_, 'unit': un_, 'frac': a_ / pk_, 'traffic': None,
+                                               'launches': f['launches'], 'avg_launch_us': f['ms'] * 1e3 / max(f['launches'], 1),
+                                               'ms_per_step': f['ms'] / probe_steps, 'share_of_step': f['ms'] * 1e-3 / dt_probe}
         tr, why = traffic_from_profiles(args.config, b, args.precision)
         if tr is not None:
-            out['roofline']['traffic'] = tr['bytes_per_launch']
+            gemm_fam['traffic'] = tr['bytes_per_launch']
+            out['roofline']['traffic'] = tr.get('step_bytes')
         out['roofline']['traffic_source'] = why
         if fast_mode is not None:
             out['fast_mode'] = fast_mode
@@ -480,6 +549,19 @@ def main():
                                  'logits_rel_l2': float((got - ref).norm() / ref.norm())}
                 except Exception as e:
                     par[mode] = {'error': f'{type(e).__name__}: {e}'}
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'parity_sweep.json')) as f:
+                    par['worst_of_8'] = json.load(f)
+            except (OSError, ValueError):
+                par['worst_of_8'] = None
+            try:
+                gr = layer_grad_parity(A, c)
+                par['grad_rel_max'] = {'sample': 'one cfg-3 decoder layer (dilation 1) forward + backward vs the oracle: worst of dx, dcontext and every parameter gradient, '
+                                                 'max-abs error / max-abs reference', **gr}
+            except Exception as e:
+                par['grad_rel_max'] = {'error': f'{type(e).__name__}: {e}'}
+            finally:
+                A.set_precision(args.precision)
             out['parity'] = par
         # fp16 saturation monitor over everything this process ran (timed steps included): 0 in a healthy run
         try:

@@ -83,6 +83,8 @@ void amdnuwa_timer_arm(int on);
 int amdnuwa_timer_begin(amdnuwa_stream stream);
 int amdnuwa_timer_end(amdnuwa_stream stream);
 int amdnuwa_timer_collect(double* total_ms, long long* launches);
+/* ABI 18: the same per launch -- ms[i] = duration of the i-th bracketed launch since the last collect (cap >= their number) */
+int amdnuwa_timer_collect_each(double* ms, long long cap, long long* launches);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM (replaces every nn.Linear on the path: np.py:274-277 FeedForward, np.py:311-313 Attention,
@@ -483,7 +485,7 @@ int amdnuwa_xattn2_bwd_rc(const amdnuwa_xattn_geom* g, const uint16_t* q, int ld
 /* ---- cross-attention core, third design ("xattn6", ABI 18; reference nuwa_pytorch.py:339-378): heads == 8, dim_head == 64, ANY context
  * length T >= 1 (g->JP is ignored).  Keys / values travel as images in the kernels' LDS order, written once per layer call by
  * amdnuwa_xattn6_pack from the 16-bit to_kv(context) rows: K6 / V6 [B][nch][heads][32][64] 16-bit with nch = amdnuwa_xattn6_nch(T) =
- * 2 * ceil(T / 64) chunks of 32 keys (K pre-multiplied by scale * log2 e; V transposed, key slots in the lanes' order; bank swizzles baked in),
+ * 2 * ceil(T / 64) chunks of 32 keys (K [key][d]; V transposed, key slots in the lanes' order; bank swizzles baked in),
  * vbits [B][nch]: bit j of word c = context key 32 c + j exists and passes context_mask.  The learned null key / value (np.py:343-347) are
  * NOT image rows: the kernels take null_k / null_v [heads][dim_head] fp32 and treat the null key as a rank-one term.
  * f16 != 0: q16 / kv16 and the images are fp16 and every MFMA is the fp16 one ('bf16x3-fwd'); else bf16.

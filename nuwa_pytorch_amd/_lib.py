@@ -63,6 +63,7 @@ SIGNATURES = {
     'amdnuwa_timer_begin': (I, [P]),
     'amdnuwa_timer_end': (I, [P]),
     'amdnuwa_timer_collect': (I, [C.POINTER(C.c_double), C.POINTER(LL)]),
+    'amdnuwa_timer_collect_each': (I, [C.POINTER(C.c_double), LL, C.POINTER(LL)]),
     'amdnuwa_gemm_nt': (I, [GD, P]),
     'amdnuwa_gemm_tn_f16_supported': (I, [GD]),
     'amdnuwa_gemm_tn_chunked_a_supported': (I, [GD]),

@@ -10,11 +10,11 @@ int g_amdnuwa_tuning[32] = {0};
 extern "C" int amdnuwa_abi_version(void) { return 18; }
 
 // fp16 saturation monitor: one counter word per translation unit with saturating fp16 stores (common.h: AMDNUWA_SAT_ACCESSOR)
-extern "C" unsigned amdnuwa_sat_elementwise(int), amdnuwa_sat_gemm(int), amdnuwa_sat_sparse3dna(int), amdnuwa_sat_xattn(int), amdnuwa_sat_xattn2(int);
+extern "C" unsigned amdnuwa_sat_elementwise(int), amdnuwa_sat_gemm(int), amdnuwa_sat_sparse3dna(int), amdnuwa_sat_xattn(int), amdnuwa_sat_xattn2(int), amdnuwa_sat_xattn6(int);
 extern "C" unsigned long long amdnuwa_f16_sat_count(int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return 0;
     return (unsigned long long)amdnuwa_sat_elementwise(reset) + amdnuwa_sat_gemm(reset) + amdnuwa_sat_sparse3dna(reset) + amdnuwa_sat_xattn(reset) +
-           amdnuwa_sat_xattn2(reset);
+           amdnuwa_sat_xattn2(reset) + amdnuwa_sat_xattn6(reset);
 }
 
 extern "C" int amdnuwa_set_tuning(int key, int value) {
@@ -67,6 +67,24 @@ extern "C" int amdnuwa_timer_end(hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_armed || g_pairs.empty()) return 0;
     return (int)hipEventRecord(g_pairs.back().b, stream);
+}
+
+// per-launch durations in bracketing order (ms[i] of the i-th amdnuwa_timer_begin since the last collect); returns like _collect and
+// leaves the pairs collected.  cap < number of pairs: AMDNUWA_ERR_ARG, nothing consumed.
+extern "C" int amdnuwa_timer_collect_each(double* ms, long long cap, long long* launches) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!ms || cap < (long long)g_pairs.size()) { if (launches) *launches = (long long)g_pairs.size(); return AMDNUWA_ERR_ARG; }
+    long long n = 0;
+    for (auto& p : g_pairs) {
+        if (hipEventSynchronize(p.b) != hipSuccess) return (int)hipGetLastError();
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p.a, p.b) != hipSuccess) return (int)hipGetLastError();
+        ms[n++] = t;
+        g_pool.push_back(p);
+    }
+    g_pairs.clear();
+    if (launches) *launches = n;
+    return 0;
 }
 
 extern "C" int amdnuwa_timer_collect(double* total_ms, long long* launches) {

@@ -7,9 +7,9 @@
 //     ([head][key][d], bank swizzle baked in) and 32 KiB of V^T ([head][d][key slot], key slots in the order a lane holds its 8
 //     probabilities, swizzle baked in): staging is a linear copy (1 KiB DMA pieces, no per-lane address arithmetic) and EVERY MFMA
 //     operand is ONE conflict-free ds_read_b128;
-//   * K is stored pre-multiplied by scale * log2(e): the scores come out of the MFMA in the log2 domain;
-//   * the key mask is the C operand of the first score MFMA (0 or MASK_BIAS per key row, built from one 32-bit word per chunk that
-//     arrives through the scalar cache): masking costs no per-element VALU work;
+//   * the score scale (scale * log2 e) is the multiplier of the ONE fma that feeds each exp2 (no separate multiply; K itself stays as the
+//     projection rounded it: pre-scaling the image costs a second rounding of every key -- 7.0e-4 -> 7.8e-4 on the full-depth logits);
+//   * the key mask is the C operand of the first score MFMA (0 or MASK_BIAS per key row, built from one 32-bit word per chunk): masking costs no per-element VALU work;
 //   * the learned null key is NOT a key row: its score is a 64-long dot product per (query, head), its probability enters the softmax
 //     statistics analytically and its value row is a rank-one update of the output -- T = 256 context keys are 8 chunks, not 9;
 //   * all LDS reads of a phase are issued before the first MFMA that needs one;
@@ -32,7 +32,7 @@ constexpr int KT = NH * TILE;                // one chunk of K (or of V^T), all 
 constexpr int STAGE = 2 * KT;                // pass 2: K + V^T of a chunk
 constexpr int XT = 8 * 1024;                 // exchange area of one query tile: 8 slots x 64 lanes x 16 bytes
 constexpr int LDS_BYTES = 4 * KT + 4 * XT;
-constexpr float MASK_BIAS = -60000.f;        // log2-domain score of a masked key: exp2(MASK_BIAS - max) == 0
+constexpr float MASK_BIAS = -400000.f;       // raw (unscaled) score of a masked key: x scale * log2 e = -72 000 in the log2 domain, exp2 of it == 0
 
 struct X6Args {
     const uint16_t* q; int ldq;              // [B*n, ldq] fp16 (F16) or bf16
@@ -255,15 +255,15 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
                 }
                 const float ca = fmaxf(fmaxf(fmaxf(s0v[0], s0v[1]), fmaxf(s0v[2], s0v[3])), fmaxf(fmaxf(s1v[0], s1v[1]), fmaxf(s1v[2], s1v[3])));
                 const float cb = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), fmaxf(t0[2], t0[3])), fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])));
-                const float mn = fmaxf(m[h], fmaxf(ca, cb));
+                const float mn = fmaxf(m[h], fmaxf(ca, cb) * a.c1);       // (c1 > 0: the maximum of the scaled scores)
                 float acc = l[h] * __builtin_amdgcn_exp2f(m[h] - mn);
                 float acc2 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    acc += __builtin_amdgcn_exp2f(s0v[r] - mn);
-                    acc2 += __builtin_amdgcn_exp2f(s1v[r] - mn);
-                    acc += __builtin_amdgcn_exp2f(t0[r] - mn);
-                    acc2 += __builtin_amdgcn_exp2f(t1[r] - mn);
+                    acc += __builtin_amdgcn_exp2f(fmaf(s0v[r], a.c1, -mn));
+                    acc2 += __builtin_amdgcn_exp2f(fmaf(s1v[r], a.c1, -mn));
+                    acc += __builtin_amdgcn_exp2f(fmaf(t0[r], a.c1, -mn));
+                    acc2 += __builtin_amdgcn_exp2f(fmaf(t1[r], a.c1, -mn));
                 }
                 l[h] = acc + acc2; m[h] = mn;
             }
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
                 for (int e = 0; e < 8; ++e) {
                     float pe[NHH];
 #pragma unroll
-                    for (int h = 0; h < NHH; ++h) pe[h] = __builtin_amdgcn_exp2f((e < 4 ? s0v[h][e & 3] : s1v[h][e & 3]) + nb[h]);
+                    for (int h = 0; h < NHH; ++h) pe[h] = __builtin_amdgcn_exp2f(fmaf(e < 4 ? s0v[h][e & 3] : s1v[h][e & 3], a.c1, nb[h]));
                     *reinterpret_cast<uint2*>(xch + e * 1024 + xo + hh * 8) = make_uint2(pack2_t<F16>(pe[0], pe[1]), pack2_t<F16>(pe[2], pe[3]));
                 }
             }
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
 template <bool F16>
 __global__ __launch_bounds__(256) void xattn6_pack_kernel(const uint16_t* __restrict__ kv, int ldkv, const uint8_t* __restrict__ mask,
                                                           char* __restrict__ K6, char* __restrict__ V6, uint32_t* __restrict__ vbits,
-                                                          int T, int nch, float c1) {
+                                                          int T, int nch) {
     __shared__ __attribute__((aligned(16))) uint16_t vt[32][NH * DH + 8];   // the chunk's value rows (row pitch 1040 bytes)
     const int b = blockIdx.x / nch, ch = blockIdx.x % nch, tid = threadIdx.x;
     const size_t cbase = ((size_t)b * nch + ch) * KT;
@@ -485,20 +485,12 @@ __global__ __launch_bounds__(256) void xattn6_pack_kernel(const uint16_t* __rest
         if (j < T) r = *reinterpret_cast<const uint4*>(kv + ((size_t)b * T + j) * ldkv + NH * DH + pc * 8);
         *reinterpret_cast<uint4*>(&vt[row][pc * 8]) = r;
     }
-    // K image: piece (h, row, pos) holds the 8 d values of chunk gc = pos ^ (row & 7), times c1
+    // K image: piece (h, row, pos) holds the 8 d values of chunk gc = pos ^ (row & 7)
     for (int e = tid; e < NH * 32 * 8; e += 256) {
         const int h = e >> 8, row = (e >> 3) & 31, pos = e & 7, gc = pos ^ (row & 7), j = 32 * ch + row;
         uint4 r = make_uint4(0, 0, 0, 0);
         if (j < T) {
-            const uint4 u = *reinterpret_cast<const uint4*>(kv + ((size_t)b * T + j) * ldkv + h * DH + gc * 8);
-            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-            uint32_t o[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float x0 = h2f<F16>((uint16_t)(w[t] & 0xffff)) * c1, x1 = h2f<F16>((uint16_t)(w[t] >> 16)) * c1;
-                o[t] = F16 ? pack2_f16_sat(x0, x1) : pack2_rne(x0, x1);
-            }
-            r = make_uint4(o[0], o[1], o[2], o[3]);
+            r = *reinterpret_cast<const uint4*>(kv + ((size_t)b * T + j) * ldkv + h * DH + gc * 8);
         }
         *reinterpret_cast<uint4*>(K6 + cbase + h * TILE + row * 128 + pos * 16) = r;
     }
@@ -861,13 +853,12 @@ extern "C" int amdnuwa_xattn6_pack(const amdnuwa_xattn_geom* g, const uint16_t* 
     if (!kv16 || !out || !out->K6 || !out->V6 || !out->vbits || ldkv % 8 || ldkv < 2 * NH * DH) return AMDNUWA_ERR_ARG;
     if (g->B <= 0) return AMDNUWA_OK;
     const int nch = amdnuwa_xattn6_nch(g->T);
-    const float c1 = g->scale * 1.4426950408889634f;
     if (f16)
         hipLaunchKernelGGL(xattn6_pack_kernel<true>, dim3(g->B * nch), dim3(256), 0, stream, kv16, ldkv, context_mask, (char*)out->K6, (char*)out->V6,
-                           out->vbits, g->T, nch, c1);
+                           out->vbits, g->T, nch);
     else
         hipLaunchKernelGGL(xattn6_pack_kernel<false>, dim3(g->B * nch), dim3(256), 0, stream, kv16, ldkv, context_mask, (char*)out->K6, (char*)out->V6,
-                           out->vbits, g->T, nch, c1);
+                           out->vbits, g->T, nch);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

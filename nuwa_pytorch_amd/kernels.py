@@ -17,7 +17,7 @@ BF = namedtuple('BF', ['hi', 'lo', 'f16'], defaults=(None,))
 
 DEFAULT_PRECISION = 'bf16x3-fwd'          # the mode that meets the north star's 1e-3 logits bound (and the one bench.py reports)
 _PRECISION = os.environ.get('AMDNUWA_PRECISION', DEFAULT_PRECISION)
-_TIMER = {'on': False, 'flops': 0.0}
+_TIMER = {'on': False, 'flops': 0.0, 'tags': [], 'fam': {}}
 MODES = ('bf16', 'bf16x3', 'bf16x3-fwd')
 _TL = threading.local()
 if _PRECISION not in MODES:
@@ -200,13 +200,106 @@ def timer_arm(on):
     _TIMER['flops'] = 0.0
     _TIMER['issued'] = 0.0
     _TIMER['bytes'] = 0.0
+    _TIMER['tags'] = []
+    _TIMER['fam'] = {}
     _lib.lib().amdnuwa_timer_arm(1 if on else 0)
 
 
 def timer_collect():
-    ms, n = C.c_double(0), C.c_longlong(0)
-    check(_lib.lib().amdnuwa_timer_collect(C.byref(ms), C.byref(n)), 'timer_collect')
-    return ms.value, n.value, _TIMER['flops'], _TIMER.get('bytes', 0.0)
+    """(ms, launches, algorithmic flops, algorithmic bytes) of the NT GEMM family + timer_families() for every bracketed family"""
+    tags = _TIMER['tags']
+    n = C.c_longlong(0)
+    buf = (C.c_double * max(len(tags), 1))()
+    check(_lib.lib().amdnuwa_timer_collect_each(buf, len(buf), C.byref(n)), 'timer_collect_each')
+    assert n.value == len(tags), (n.value, len(tags))
+    per = {}
+    for t, ms in zip(tags, buf):
+        e = per.setdefault(t, [0.0, 0])
+        e[0] += ms
+        e[1] += 1
+    fam = _TIMER['fam']
+    fam['gemm_nt'] = [_TIMER['flops'], _TIMER.get('bytes', 0.0)]
+    _TIMER['families'] = {k: dict(ms=v[0], launches=v[1], flops=fam.get(k, [0.0, 0.0])[0], bytes=fam.get(k, [0.0, 0.0])[1]) for k, v in per.items()}
+    _TIMER['tags'] = []
+    g = per.get('gemm_nt', [0.0, 0])
+    return g[0], g[1], _TIMER['flops'], _TIMER.get('bytes', 0.0)
+
+
+def timer_families():
+    """per family of the last timer_collect(): {'ms', 'launches', 'flops', 'bytes'} -- gemm_nt, xattn, s3, ln"""
+    return _TIMER.get('families', {})
+
+
+def _big_bytes(*objs):
+    """bytes of the distinct large tensors among the arguments / results of a kernel wrapper: its algorithmic HBM traffic (every operand
+    read once, every result written once)"""
+    seen, tot = set(), 0
+
+    def walk(o):
+        nonlocal tot
+        if isinstance(o, torch.Tensor):
+            if o.is_cuda and o.numel() >= 65536 and o.data_ptr() not in seen:
+                seen.add(o.data_ptr())
+                tot += o.numel() * o.element_size()
+        elif isinstance(o, (list, tuple)):
+            for x in o:
+                walk(x)
+        elif isinstance(o, dict):
+            for x in o.values():
+                walk(x)
+        elif isinstance(o, BF):
+            walk((o.hi, o.lo, o.f16))
+        elif hasattr(o, 't') and isinstance(getattr(o, 't'), torch.Tensor):
+            walk(o.t)
+    walk(objs)
+    return float(tot)
+
+
+def _family(name, work=None):
+    """bench.py's per-family launch timer: brackets the wrapper's launches while the timer is armed (work(args, kwargs, result) ->
+    (algorithmic flops, algorithmic bytes); default: no flops, the large tensors of the call)"""
+    def deco(fn):
+        def wrap(*a, **k):
+            if not _TIMER['on']:
+                return fn(*a, **k)
+            L, st = _lib.lib(), _stream()
+            _TIMER['tags'].append(name)
+            L.amdnuwa_timer_begin(st)
+            r = fn(*a, **k)
+            L.amdnuwa_timer_end(st)
+            fl, by = work(a, k, r) if work else (0.0, _big_bytes(a, k, r))
+            e = _TIMER['fam'].setdefault(name, [0.0, 0.0])
+            e[0] += fl
+            e[1] += by
+            return r
+        wrap.__name__, wrap.__doc__ = fn.__name__, fn.__doc__
+        return wrap
+    return deco
+
+
+def _x_work(kind):
+    """algorithmic MFMA work of the cross-attention cores (U = one 2 n (T + 1) d h product): forward QK^T + P'V + head mix; backward query
+    side S, dP', dq + two mixes + dW_th; the batched dK / dV products 2 U"""
+    def w(a, k, r):
+        g = a[0]
+        U = 2.0 * g.B * g.n * (g.T + 1) * g.dim_head * g.heads
+        mix = 2.0 * g.B * g.n * (g.T + 1) * g.heads * g.heads
+        fl = {'fwd': 2 * U + mix, 'bwd': 3 * U + 3 * mix, 'kv': 2 * U}[kind]
+        act = 2.0 * g.B * g.n * g.heads * g.dim_head                       # one 16-bit [B*n, inner] tensor
+        by = {'fwd': 3 * act, 'bwd': 3 * act + 4.0 * g.B * g.heads * g.n * (g.T + 1), 'kv': 2 * act + 4.0 * g.B * g.heads * g.n * (g.T + 1)}[kind]
+        return fl, by
+    return w
+
+
+def _s3_work(kind):
+    """algorithmic HBM bytes of the Sparse3DNA cores: forward reads q, k, v and writes o; backward reads q, k, v, dO and writes dq, dk, dv"""
+    def w(a, k, r):
+        g = a[0]
+        act = 2.0 * g.B * g.ntok * g.heads * g.dim_head
+        J = g.kf * g.kh * g.kw + 1
+        fl = 4.0 * g.B * g.ntok * J * g.heads * g.dim_head * (1 if kind == 'fwd' else 2.5)
+        return fl, act * (4 if kind == 'fwd' else 8)
+    return w
 
 
 def timer_issued_flops():
@@ -265,7 +358,7 @@ def gemm_nt(A, B, *, out=None, out_bf16=False, bias=None, alpha=1.0, shift=None,
         _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * M * N * K * (3 if x3 else 1)
         ob = (2 * (2 if out.lo is not None else 1)) if out_bf16 else 4
         _TIMER['bytes'] += (2.0 * (M + N) * K) * (2 if x3 else 1) + float(M) * N * ob + (float(M) * N if geglu_out is not None else 0.)
-        L.amdnuwa_timer_begin(st)
+        _TIMER['tags'].append('gemm_nt'); L.amdnuwa_timer_begin(st)
     check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt')
     if _TIMER['on']:
         L.amdnuwa_timer_end(st)
@@ -297,7 +390,7 @@ def _gemm_nt_f16(A, B, *, bias, alpha, shift, N, K):
         _TIMER['flops'] += 2.0 * M * N * K
         _TIMER['issued'] = _TIMER.get('issued', 0.) + 6.0 * M * N * K
         _TIMER['bytes'] += 4.0 * (M + N) * K + 4.0 * M * N
-        L.amdnuwa_timer_begin(st)
+        _TIMER['tags'].append('gemm_nt'); L.amdnuwa_timer_begin(st)
     check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(f16 copy)')
     if _TIMER['on']:
         L.amdnuwa_timer_end(st)
@@ -435,7 +528,7 @@ def gemm_nt_f16x2(A16, B16, *, out_bf16=False, bias=None, copy_f16=False):
         _TIMER['flops'] += 2.0 * M * N * Kd
         _TIMER['issued'] = _TIMER.get('issued', 0.) + 4.0 * M * N * Kd
         _TIMER['bytes'] += 2.0 * M * Kd + 4.0 * N * Kd + float(M) * N * ((4 if c16 is not None else 2) if out_bf16 else 4)
-        L.amdnuwa_timer_begin(st)
+        _TIMER['tags'].append('gemm_nt'); L.amdnuwa_timer_begin(st)
     check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(f16 x f16 hi+lo)')
     if _TIMER['on']:
         L.amdnuwa_timer_end(st)
@@ -476,7 +569,7 @@ def gemm_nt_f16ops(A16, B16, *, out_bf16=False, gate=False, copy_f16=False, gate
         _TIMER['flops'] += 2.0 * M * N * Kd
         _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * M * N * Kd
         _TIMER['bytes'] += 2.0 * (M + N) * Kd + float(M) * N * (2 if (out_bf16 or out_f16) else 4) + ((2.0 if gate_bf16 else 1.0) * M * N if gate else 0.)
-        L.amdnuwa_timer_begin(st)
+        _TIMER['tags'].append('gemm_nt'); L.amdnuwa_timer_begin(st)
     check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(fp16 operands)')
     if _TIMER['on']:
         L.amdnuwa_timer_end(st)
@@ -510,7 +603,7 @@ def gemm_nt_geglu_bwd(dy, w2T, u, FP):
         _TIMER['flops'] += 2.0 * M * FP * Kd
         _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * M * FP * Kd * (3 if x3 else 1)
         _TIMER['bytes'] += (2.0 * (M + FP) * Kd) * (2 if x3 else 1) + float(M) * FP * 8
-        L.amdnuwa_timer_begin(st)
+        _TIMER['tags'].append('gemm_nt'); L.amdnuwa_timer_begin(st)
     check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(geglu backward)')
     if _TIMER['on']:
         L.amdnuwa_timer_end(st)
@@ -533,7 +626,7 @@ def gemm_nt_geglu_bwd16(dy16, w2T16, u, FP):
         _TIMER['flops'] += 2.0 * M * FP * Kd
         _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * M * FP * Kd
         _TIMER['bytes'] += 2.0 * (M + FP) * Kd + float(M) * FP * 8
-        L.amdnuwa_timer_begin(st)
+        _TIMER['tags'].append('gemm_nt'); L.amdnuwa_timer_begin(st)
     check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(geglu backward, fp16)')
     if _TIMER['on']:
         L.amdnuwa_timer_end(st)
@@ -623,6 +716,7 @@ def empty_bf_f16(shape, device):
     return BF(torch.empty(shape, dtype=torch.bfloat16, device=device), None, torch.empty(shape, dtype=torch.float16, device=device))
 
 
+@_family('ln')
 def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5, shift=None, f16=False, minus=False):
     """x fp32 [R, D] contiguous (or a hi-only BF pair).  resid None -> (BF out, mean, rstd, inv_amax);
     else (fp32 out = resid + LN(x) -- minus: resid - LN(x) --, mean, rstd).  f16: out = BF(hi, None, f16) (bf16 copy + fp16 copy)"""
@@ -649,6 +743,7 @@ def ln_fwd(x, w, b, *, resid=None, stable=False, eps=1e-5, shift=None, f16=False
     return out, mean, rstd
 
 
+@_family('ln')
 def ln_post_pre_fwd(y, resid, w, b, next_w, next_b, *, eps=1e-5, next_shift=None, next_f16=False):
     """post-norm + residual of one block and the pre-norm (+ token shift) of the next in one pass over the stream:
     returns (out fp32 = resid + LN(y; w, b), mean, rstd, h BF = shift(LN(out; next_w, next_b)), next_mean, next_rstd)"""
@@ -670,6 +765,7 @@ def ln_post_pre_fwd(y, resid, w, b, next_w, next_b, *, eps=1e-5, next_shift=None
     return out, mean, rstd, h, mean2, rstd2
 
 
+@_family('ln')
 def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift=None, want_dsum=False, to_f16=None, dy_scale2=None):
     """returns (dx, dw, db, dsum).  to_bf: dx as BF pair; to_f16 = s2 (device {S, 1 / S}): dx as G16 = fp16(S * dx); else dx fp32 =
     dres + dx_ln (dres may be None -> zeros).  dy / x: fp32 tensors, or (one of them) a hi-only BF pair; dy may be a G16."""
@@ -711,6 +807,7 @@ def ln_bwd(dy, x, mean, rstd, w, *, inv_amax=None, to_bf=False, dres=None, shift
     return dx, dw, db, ds
 
 
+@_family('ln')
 def ln_bwd_chain(dh, x, mean, rstd, w, g, y_prev, mean_prev, rstd_prev, w_prev, *, shift=None, want_dsum=False, out_f16=None):
     """pre-norm backward of a block and the post-norm backward of the block before it in one pass over the gradient row.
     dh, y_prev: both fp32 tensors, both hi-only BF pairs, or dh a BF pair / a G16 with an fp32 y_prev ('bf16x3-fwd').  out_f16 = s2: dy_prev
@@ -875,7 +972,7 @@ def linear_ce(h, w, targets, grad_scale, want_grad=True, w16=None):
         _TIMER['flops'] += 2.0 * R * Cc * Kd * npass
         _TIMER['issued'] = _TIMER.get('issued', 0.) + 2.0 * R * Cc * Kd * issued
         _TIMER['bytes'] += (2.0 * (R + Cc) * Kd) * issued + (2.0 * R * Cc if want_grad else 0.) + 8.0 * R * (Cc // 64)
-        L.amdnuwa_timer_begin(st)
+        _TIMER['tags'].append('gemm_nt'); L.amdnuwa_timer_begin(st)
     if x3:
         check(L.amdnuwa_linear_ce_x3(_p(h.hi), _p(h.lo), _p(h16), _ld(h.hi), _p(w.hi), _p(w.lo), _p(w16) if p2_f16 else None, _ld(w.hi),
                                      _p(targets), R, Cc, Kd, float(grad_scale), _p(row_loss), _p(loss), _p(dl.hi), Cc, _p(ws), nb, st),
@@ -918,6 +1015,7 @@ def s3_f16_supported(g):
     return bool(_lib.lib().amdnuwa_s3_f16_supported(C.byref(g)))
 
 
+@_family('s3', _s3_work('fwd'))
 def sparse3dna_fwd(g, qkv, wth, rel_bias=None, o_f16=False):
     """qkv: BF [B*ntok, 3*inner] (q | k | v);  returns o BF [B*ntok, inner].  rel_bias: fp32 [J, heads] or None.
     o_f16 (fp16 operand form only): o = BF(bf16 copy, None, fp16 copy) -- the operand of the two-MFMA to_out product"""
@@ -942,6 +1040,7 @@ def sparse3dna_fwd(g, qkv, wth, rel_bias=None, o_f16=False):
     return o
 
 
+@_family('s3', _s3_work('bwd'))
 def sparse3dna_bwd(g, qkv, wth, dO, rel_bias=None):
     """returns (dqkv BF [R, 3*inner], dw_th fp32 [h, h]) -- and d(rel_bias) fp32 [J, heads] as a third item when rel_bias is given
     (callers that pass rel_bias=None through the keyword get a 3-tuple with None)"""
@@ -1115,6 +1214,7 @@ def xattn_pack(g, kv, null_k, null_v, mask_u8, out=None, lean=False):
     return pk
 
 
+@_family('xattn', _x_work('fwd'))
 def xattn2_fwd_f16(g, q, pk, wth, o_f16=False):
     """the xattn4 core on fp16 operands (q.f16, the fp16 images of pk): returns o BF [B*n, inner] (hi + lo; with o_f16 a bf16 copy + an
     fp16 copy, the operand of the two-MFMA to_out product) and the statistics"""
@@ -1178,6 +1278,7 @@ def xattn6_pack(g, kv16, mask_u8, out=None):
     return pk
 
 
+@_family('xattn', _x_work('fwd'))
 def xattn6_fwd(g, q16, pk, null_k, null_v, wth, o_f16=False, lo=True):
     """the xattn6 forward core on q16 [B*n, ld] (fp16 with fp16 images: every MFMA the fp16 one; else bf16).  Returns o BF [B*n, inner]
     (hi + lo pair; with o_f16 a bf16 copy + an fp16 copy; lo=False: the bf16 copy alone) and the softmax statistics [B, h, n, 2]"""
@@ -1224,6 +1325,7 @@ def xattn6_pack_bwd(g, kv_bf16, null_k, null_v, mask_u8):
     return pk
 
 
+@_family('xattn', _x_work('bwd'))
 def xattn6_bwd(g, q, dO, pk, wth, stats):
     """the query side of the recomputing backward on xattn6 images: returns dq BF [B*n, inner], dS BF and Pm BF chunk-major
     [B, h, JP / 32, n, 32] (what xattn_kv_grads takes), dw_th fp32 [h, h] -- the results of xattn2_bwd(chunk_major=True)"""
@@ -1284,6 +1386,7 @@ def xattn2_supported(g, q=None):
     return (q is None or q.lo is None) and bool(_lib.lib().amdnuwa_xattn2_supported(C.byref(g)))
 
 
+@_family('xattn', _x_work('fwd'))
 def xattn2_fwd(g, q, pk, wth):
     """returns o BF [B*n, inner], stats fp32 [B, h, n, 2] = (row max, 1 / row sum) of the masked, scaled scores"""
     L = _lib.lib()
@@ -1327,6 +1430,7 @@ def xattn_rows(g, t):
     return t
 
 
+@_family('xattn', _x_work('bwd'))
 def xattn2_bwd(g, q, dO, pk, wth, stats, chunk_major=None):
     """returns dq BF [B*n, inner], dS BF and Pm BF, dw_th fp32 [h, h].  dS / Pm: [B, h, n, columns] (views of JP-pitch rows), or -- chunk_major,
     the default wherever xattn_chunk_major_ok -- [B, h, JP / 32, n, 32]; xattn_kv_grads takes either, xattn_rows shows either as rows"""
@@ -1391,6 +1495,7 @@ def xattn2_bwd_rc(g, q, dO, pk, wth, stats):
     return dq, dKp, dVp, colsum(part).reshape(g.heads, g.heads)
 
 
+@_family('xattn', _x_work('kv'))
 def xattn_kv_grads(g, dS, Pm, q, dO):
     """dKp = scale * dS^T q, dVp = Pm^T dO per (sample, head): two batched TN GEMMs (reduction over queries).
     returns fp32 [B, h, JP, dh] x 2 (rows past the last column of dS / Pm -- padding keys -- are not written)"""

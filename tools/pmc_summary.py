@@ -76,7 +76,12 @@ def main():
         import os
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench                          # the hash bench.py will compare against: a figure from other kernel sources is refused
-        cur[key] = {'bytes_per_launch': (2.0 * fs + ws) * 1024.0, 'fetch_kib_raw': fs, 'write_kib_raw': ws,
+        # whole-step traffic: every kernel of the pass / the number of decoder steps in it (= launches of the once-per-step cross-entropy kernel)
+        def allsum(c):
+            return sum(v[c][1] for v in agg.values() if c in v)
+        nsteps = max((v['FETCH_SIZE'][0] for k, v in agg.items() if k.startswith('ce_fwd') and 'FETCH_SIZE' in v), default=0)
+        step_bytes = ((2.0 * allsum('FETCH_SIZE') + allsum('WRITE_SIZE')) * 1024.0 / nsteps) if nsteps else None
+        cur[key] = {'bytes_per_launch': (2.0 * fs + ws) * 1024.0, 'fetch_kib_raw': fs, 'write_kib_raw': ws, 'step_bytes': step_bytes, 'steps_in_pass': nsteps,
                     'src_sha16': bench.file_sha16(bench.ROOFLINE_SOURCES),
                     'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), avg over gemm_nt_* launches; read bytes = 2 x FETCH_SIZE (gfx950 correction), write bytes = WRITE_SIZE'}
         json.dump(cur, open(out, 'w'), indent=1)
