@@ -438,7 +438,8 @@ int amdnuwa_xattn_bwd(const amdnuwa_xattn_geom* g, const uint16_t* dO, const uin
                       int accumulate, void* workspace, size_t workspace_bytes, amdnuwa_stream stream);
 /* accumulate: bit 0 = add into dnull_k / dnull_v instead of overwriting them; bit 1 = the rows of dKp / dVp follow the chunk-permuted
  * key order in which amdnuwa_xattn2_bwd writes its dS / Pm columns (key 32 c + kk at row 32 c + 8 ((kk & 15) >> 2) + 4 (kk >> 4) + (kk & 3):
- * the order a lane of the kernel holds its 8 slots, one 16-byte store each); amdnuwa_xattn_bwd and amdnuwa_xattn2_bwd_rc use the plain order */
+ * the order a lane of the kernel holds its 8 slots, one 16-byte store each); amdnuwa_xattn_bwd and amdnuwa_xattn2_bwd_rc use the plain order;
+ * bit 2 (ABI 18) = key order of amdnuwa_xattn6_bwd: context key t at position t, the null key at position T (else: null key 0, context key t at t + 1) */
 int amdnuwa_xattn_unpack(const amdnuwa_xattn_geom* g, const float* dKp, const float* dVp, uint16_t* dkv,
                          uint16_t* dkv_lo, int ldkv, float* dnull_k, float* dnull_v, int accumulate,
                          amdnuwa_stream stream);
@@ -501,8 +502,8 @@ int amdnuwa_xattn6_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q16, int ldq
                        const float* null_v, const float* w_th, uint16_t* o, uint16_t* o_lo, int ldo, int o_lo_f16, float* stats,
                        int f16, amdnuwa_stream stream);
 /* The query side of the recomputing backward on the same recipe (bf16; replaces amdnuwa_xattn2_bwd_ex with flag bit 0 where g->JP / 32 <= 64):
- * amdnuwa_xattn6_pack_bwd writes K6 / V6 [B][JP / 32][heads][32][64] bf16 ([key][d] tiles in LDS order; key 0 = the null key, keys 1..T the
- * context: the key order of dS / Pm and of amdnuwa_xattn_unpack) and vbits [B][JP / 32]; amdnuwa_xattn6_bwd takes them, q / dO [B*n, ld] bf16
+ * amdnuwa_xattn6_pack_bwd writes K6 / V6 [B][JP / 32][heads][32][64] bf16 ([key][d] tiles in LDS order; positions 0..T-1 = the context keys,
+ * position T = the null key: the key order of its dS / Pm, which amdnuwa_xattn_unpack reads with flag bit 2 set) and vbits [B][JP / 32]; amdnuwa_xattn6_bwd takes them, q / dO [B*n, ld] bf16
  * and the forward's statistics and writes dq, dS / Pm CHUNK-MAJOR ([B][heads][JP / 32][n][32], chunk-permuted slots, lane groups without a
  * key unwritten -- exactly amdnuwa_xattn2_bwd_ex's flag-bit-0 layout) and the talking-heads partials part_th (>= _workspace_bytes). */
 size_t amdnuwa_xattn6_bwd_image_bytes(const amdnuwa_xattn_geom* g);
@@ -510,7 +511,7 @@ int amdnuwa_xattn6_pack_bwd(const amdnuwa_xattn_geom* g, const uint16_t* kv, int
                             const uint8_t* context_mask, const amdnuwa_xattn6_kv* out, amdnuwa_stream stream);
 size_t amdnuwa_xattn6_bwd_workspace_bytes(const amdnuwa_xattn_geom* g);
 int amdnuwa_xattn6_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo, const amdnuwa_xattn6_kv* kv,
-                       const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm, uint16_t* dq, int lddq, float* part_th,
+                       const float* null_k, const float* null_v, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm, uint16_t* dq, int lddq, float* part_th,
                        size_t part_bytes, amdnuwa_stream stream);
 /* Text cross-attention (Attention.forward with context, np.py:339-378) for ONE query row per sample (g->n must be 1):
  * q [B, ldq] unscaled, keys / values as packed by amdnuwa_xattn_pack (Kp / Vp images and the valid map), o [B, ldo]. */

@@ -573,8 +573,10 @@ __device__ __forceinline__ int xattn_key_row(int j, int permuted) {
 }
 __global__ __launch_bounds__(256) void xattn_unpack_kernel(const float* __restrict__ dKp, const float* __restrict__ dVp,
                                                            bf16_t* dkv, bf16_t* dkvl, int ldkv, float* dnull_k, float* dnull_v,
-                                                           int B, int T, int NH, int DH, int JP, int accumulate, int permuted) {
+                                                           int B, int T, int NH, int DH, int JP, int accumulate, int permuted, int null_last) {
+    // null_last (flag bit 2): rows in the key order of amdnuwa_xattn6_bwd -- context key t at position t, the null key at position T
     const int inner = NH * DH;
+    const int nrow = xattn_key_row(null_last ? T : 0, permuted);
     if ((int)blockIdx.x == B * NH) {     // null gradients, fixed order over b
         for (int e = threadIdx.x; e < inner; e += blockDim.x) {
             const int h = e / DH, d = e % DH;
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(256) void xattn_unpack_kernel(const float* __restri
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool in = b + u < B;
-                    const size_t o = (((size_t)(in ? b + u : 0) * NH + h) * JP) * DH + d;
+                    const size_t o = (((size_t)(in ? b + u : 0) * NH + h) * JP + nrow) * DH + d;
                     const float tk = dKp[o], tv = dVp[o];
                     vk[u] = in ? tk : 0.f; vv[u] = in ? tv : 0.f;
                 }
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(256) void xattn_unpack_kernel(const float* __restri
     const int bh = blockIdx.x, b = bh / NH, h = bh % NH, dchunks = DH / 8;
     for (int e = threadIdx.x; e < T * dchunks; e += blockDim.x) {             // 8 channels per thread: 16-byte stores
         const int j = 1 + e / dchunks, dc = (e % dchunks) * 8;
-        const size_t o1 = ((size_t)bh * JP + xattn_key_row(j, permuted)) * DH + dc;
+        const size_t o1 = ((size_t)bh * JP + xattn_key_row(null_last ? j - 1 : j, permuted)) * DH + dc;
         const size_t g = ((size_t)b * T + j - 1) * ldkv + h * DH + dc;
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
@@ -776,7 +778,7 @@ extern "C" int amdnuwa_xattn_unpack(const amdnuwa_xattn_geom* g, const float* dK
     if (!dKp || !dVp || !dkv || !dnull_k || !dnull_v || ldkv % 8) return AMDNUWA_ERR_ARG;
     if (g->B <= 0) return AMDNUWA_OK;
     hipLaunchKernelGGL(xattn_unpack_kernel, dim3(g->B * g->heads + 1), dim3(256), 0, stream, dKp, dVp, dkv, dkv_lo, ldkv, dnull_k, dnull_v,
-                       g->B, g->T, g->heads, g->dim_head, g->JP, accumulate & 1, (accumulate >> 1) & 1);
+                       g->B, g->T, g->heads, g->dim_head, g->JP, accumulate & 1, (accumulate >> 1) & 1, (accumulate >> 2) & 1);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

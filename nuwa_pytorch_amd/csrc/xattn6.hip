@@ -49,8 +49,11 @@ struct X6Args {
 // One 1-KiB LDS-DMA piece with a SCALAR base: source = sbase (wave-uniform, SGPR pair) + voff (per-lane byte offset, one VGPR), lane l lands at
 // lds + 16 l.  (dma16_asm of common.h takes a per-lane 64-bit address: eight of them per stage call are 16 VGPRs the persistent kernel
 // does not have -- spilled, their reloads carried vmcnt(0) waits into the ring loops.)
-__device__ __forceinline__ void dma16_s(const char* sbase, uint32_t voff, void* lds) {
-    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_vptr_t)lds);
+// (the LDS destination travels as a byte ADDRESS computed from lds_addr_of(smem) once per kernel: a flat -> LDS pointer cast per piece made
+//  the compiler emit a null check that it then mis-selected -- "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base")
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(lds_vptr_t)p; }
+__device__ __forceinline__ void dma16_s(const char* sbase, uint32_t voff, unsigned lds_byte_addr) {
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
 
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
     //   reads  vf(c-1) [V slot (c-1)&1]; puts(c); DMA K(c+1) -> K slot (c+1)&1 (held K(c-1): read before Q(c-1)), V(c) -> V slot c&1
     //   (held V(c-2): read before Q(c-1)) .......................... then vmcnt(0) + barrier Q: puts and pieces visible, all reads done
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned sm0 = lds_addr_of(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = wave >> 1, hh = wave & 1;                   // query tile of the workgroup, head half (heads 4 hh .. 4 hh + 3)
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int piece = wave + 8 * i;
-            dma16_s(img + (size_t)ch * KT + piece * 1024, lane * 16, smem + slot * KT + piece * 1024);
+            dma16_s(img + (size_t)ch * KT + piece * 1024, lane * 16, sm0 + slot * KT + piece * 1024);
         }
     };
     auto p1_slot = [](int ch) { return ((ch & 1) << 1) | ((ch >> 1) & 1); };      // SL = {0, 2, 1, 3}
@@ -511,14 +515,16 @@ __global__ __launch_bounds__(256) void xattn6_pack_kernel(const uint16_t* __rest
 // heads, both head mixes on the matrix pipe, dS / Pm written chunk-major for the batched dK / dV products -- on the forward's recipe:
 // bf16 K and V images in LDS order (linear 1-KiB DMA pieces with a scalar base: the per-lane address arithmetic of 16 pieces per chunk
 // and wave is gone), the key mask as the C operand of the score MFMAs (no per-element compare / select), the score scale folded into
-// ONE fma per probability, no run-time probe branches inside the chunk loops, XCD-aware item order.  Keys keep the order of the dS / Pm
-// consumers (amdnuwa_gemm_tn + amdnuwa_xattn_unpack): key 0 = the null key, keys 1..T the context, JP / 32 chunks.
+// ONE fma per probability, no run-time probe branches inside the chunk loops, XCD-aware item order.  Key order of the images and of dS / Pm:
+// positions 0..T-1 = the context keys (chunk-aligned), position T = the null key (amdnuwa_xattn_unpack flag bit 2 reads dKp / dVp that way).
+// With T % 32 == 0 the null key would be alone in the last chunk: that chunk is no matrix iteration but a rank-one term per pass.
 // ------------------------------------------------------------------------------------------------
 struct X6BArgs {
     const uint16_t* q; int ldq;
     const uint16_t* dO; int lddo;
-    const char *K6, *V6;                     // [B][nch][NH][32][64] bf16, [key][d] tiles in k6_off order (K unscaled)
+    const char *K6, *V6;                     // [B][nch][NH][32][64] bf16, [key][d] tiles in k6_off order (K unscaled); keys 0..T-1 the context, key T the null key
     const uint32_t* vbits;                   // [B][nch]
+    const float *null_k, *null_v;            // [NH][DH]
     const float* wth;
     const float* stats;                      // [B][NH][n][2]
     uint16_t *dS, *Pm;                       // [B][NH][nch][n][32] (chunk-major, chunk-permuted slots)
@@ -568,6 +574,7 @@ __device__ __forceinline__ bf16x8 lds_tr6(const char* base, int h, int db, int c
 
 __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned sm0 = lds_addr_of(smem);
     __shared__ float thsh[4][NH * NH];
     __shared__ __attribute__((aligned(16))) float wsh[NH * NH], wtsh[NH * NH];          // W[g][h] and its transpose
     const int tid = threadIdx.x, lane = tid & 63;
@@ -582,19 +589,25 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     const char* v6 = a.V6 + (size_t)b * nch * KT;
     const int ko0 = k6_off(0, c, g4), ko1 = k6_off(0, c, 4 + g4);
     if (tid < NH * NH) { const float v = a.wth[tid]; wsh[tid] = v; wtsh[(tid & 7) * 8 + (tid >> 3)] = v; }
+    float* nks = reinterpret_cast<float*>(smem + 2 * STAGE);     // the null key / value, rounded to bf16 as an image row is: 2 x 2 KiB behind the ring
+    float* nvs = nks + NH * DH;
+    for (int e = tid; e < NH * DH; e += 256) { nks[e] = bf2f(f2bf(a.null_k[e])); nvs[e] = bf2f(f2bf(a.null_v[e])); }
     const uint32_t wv = lane < nch ? a.vbits[(size_t)b * nch + lane] : 0u;
+    // T % 32 == 0: the null key (position T) is alone in the last chunk -- that chunk is not a matrix iteration but a rank-one term
+    const bool rank1 = (a.T & 31) == 0;
+    const int nfull = rank1 ? nch - 1 : nch;
     __syncthreads();                                             // (before any DMA is in flight)
     // K + V of chunk ch -> stage: 64 pieces, 16 per wave
     auto stage = [&](int stg, int ch) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int piece = wave + 4 * i;
-            dma16_s(k6 + (size_t)ch * KT + piece * 1024, lane * 16, smem + stg * STAGE + piece * 1024);
+            dma16_s(k6 + (size_t)ch * KT + piece * 1024, lane * 16, sm0 + stg * STAGE + piece * 1024);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int piece = wave + 4 * i;
-            dma16_s(v6 + (size_t)ch * KT + piece * 1024, lane * 16, smem + stg * STAGE + KT + piece * 1024);
+            dma16_s(v6 + (size_t)ch * KT + piece * 1024, lane * 16, sm0 + stg * STAGE + KT + piece * 1024);
         }
     };
     auto bias_raw = [&](int ch, f32x4& b0, f32x4& b1) {
@@ -659,8 +672,8 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
 #pragma unroll
         for (int g = 0; g < NH; ++g) dth[g][h] = 0.f;
     }
-    for (int ch = 0; ch < nch; ++ch) {
-        if (ch + 1 < nch) { stage((ch + 1) & 1, ch + 1); VMCNT(16); }
+    for (int ch = 0; ch < nfull; ++ch) {
+        if (ch + 1 < nfull) { stage((ch + 1) & 1, ch + 1); VMCNT(16); }
         else VMCNT(0);
         __builtin_amdgcn_s_barrier();
         const char* kbase = smem + (ch & 1) * STAGE;
@@ -719,6 +732,54 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     }
     // pass B's first chunk is on its way while the statistics are reduced
     stage(0, 0);
+    // ---- the null key as a rank-one term (T % 32 == 0), pass A part: P_null, dP'_null, their mixes, the shares of delta and dW_th, Pm
+    float PN[NH], dPN[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) PN[h] = dPN[h] = 0.f;
+    if (rank1) {
+        float dN[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            float sa = 0.f, da = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint4 uq = __builtin_bit_cast(uint4, qf[h][ks]), ud = __builtin_bit_cast(uint4, df[h][ks]);
+                const uint32_t wq[4] = {uq.x, uq.y, uq.z, uq.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
+                const int o8 = h * DH + ks * 32 + g4 * 8;            // (indexed, not through a generic pointer: the address-space cast of a
+                                                                     //  static LDS array trips the compiler's register-class check here)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    sa = fmaf(lo_f(wq[t]), nks[o8 + 2 * t], sa); sa = fmaf(hi_f(wq[t]), nks[o8 + 2 * t + 1], sa);
+                    da = fmaf(lo_f(wd[t]), nvs[o8 + 2 * t], da); da = fmaf(hi_f(wd[t]), nvs[o8 + 2 * t + 1], da);
+                }
+            }
+            sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+            da += __shfl_xor(da, 16, 64); da += __shfl_xor(da, 32, 64);
+            PN[h] = __builtin_amdgcn_exp2f(fmaf(sa, c1, nb[h]));
+            dN[h] = da;
+        }
+        float PmN[NH];
+#pragma unroll
+        for (int g = 0; g < NH; ++g) {                           // (operands rounded to bf16 as the matrix-pipe mixes round theirs)
+            float pm = 0.f, dp = 0.f;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) { pm = fmaf(wsh[g * NH + h], bf2f(f2bf(PN[h])), pm); dp = fmaf(wtsh[g * NH + h], bf2f(f2bf(dN[h])), dp); }
+            PmN[g] = pm; dPN[g] = dp;                            // dPN[h = g] = sum_g' W[g'][h] dP'_null[g']  (wtsh row h)
+        }
+        if (g4 == 0) {                                           // one lane per query carries the null key's shares
+#pragma unroll
+            for (int g = 0; g < NH; ++g)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) dth[g][h] = fmaf(dN[g], PN[h], dth[g][h]);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) delta[h] = fmaf(dPN[h], PN[h], delta[h]);
+        }
+        // (stored outside the block above: as part of it the compiler dies with "Illegal instruction detected: Operand has incorrect register class")
+        uint16_t* pmn = a.Pm + ((size_t)(nch - 1) * a.n + qi) * 32;
+#pragma unroll
+        for (int g = 0; g < NH; ++g)
+            if (g4 == 0 && qok) *reinterpret_cast<uint4*>(pmn + ((size_t)b * NH + g) * hplane) = make_uint4(pack2_rne(PmN[g], 0.f), 0u, 0u, 0u);
+    }
     // a query's keys are spread over the 4 lane groups
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -743,8 +804,8 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int db = 0; db < DB; ++db) dQ[h][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ch = 0; ch < nch; ++ch) {
-        if (ch + 1 < nch) { stage((ch + 1) & 1, ch + 1); VMCNT(16); }
+    for (int ch = 0; ch < nfull; ++ch) {
+        if (ch + 1 < nfull) { stage((ch + 1) & 1, ch + 1); VMCNT(16); }
         else VMCNT(0);
         __builtin_amdgcn_s_barrier();
         const char* kbase = smem + (ch & 1) * STAGE;
@@ -787,6 +848,20 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
         }
         __builtin_amdgcn_s_barrier();
     }
+    if (rank1) {                                                 // pass B part: ds_null -> dS, dq += ds_null k_null
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const uint32_t dsb = pack2_rne(PN[h] * (dPN[h] - delta[h]), 0.f);
+            if (g4 == 0 && qok) *reinterpret_cast<uint4*>(a.dS + ((size_t)b * NH + h) * hplane + ((size_t)(nch - 1) * a.n + qi) * 32) = make_uint4(dsb, 0u, 0u, 0u);
+            const float dsr = lo_f(dsb);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const int o4 = h * DH + db * 16 + g4 * 4;
+                dQ[h][db][0] = fmaf(dsr, nks[o4], dQ[h][db][0]); dQ[h][db][1] = fmaf(dsr, nks[o4 + 1], dQ[h][db][1]);
+                dQ[h][db][2] = fmaf(dsr, nks[o4 + 2], dQ[h][db][2]); dQ[h][db][3] = fmaf(dsr, nks[o4 + 3], dQ[h][db][3]);
+            }
+        }
+    }
     if (qok) {
 #pragma unroll
         for (int h = 0; h < NH; ++h)
@@ -799,7 +874,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     }
 }
 
-// images of the backward: kv [B*T, ldkv] bf16 + the null key / value -> K6 / V6 ([key][d] tiles, key 0 = null, keys 1..T the context) / vbits
+// images of the backward: kv [B*T, ldkv] bf16 + the null key / value -> K6 / V6 ([key][d] tiles, keys 0..T-1 the context, key T = null) / vbits
 __global__ __launch_bounds__(256) void xattn6_pack_bwd_kernel(const uint16_t* __restrict__ kv, int ldkv, const float* __restrict__ null_k,
                                                               const float* __restrict__ null_v, const uint8_t* __restrict__ mask,
                                                               char* __restrict__ K6, char* __restrict__ V6, uint32_t* __restrict__ vbits, int T, int nch) {
@@ -807,17 +882,17 @@ __global__ __launch_bounds__(256) void xattn6_pack_bwd_kernel(const uint16_t* __
     const size_t cbase = ((size_t)b * nch + ch) * KT;
     if (tid < 64) {
         const int j = 32 * ch + tid;
-        const bool ok = tid < 32 && (j == 0 || (j <= T && (mask ? mask[(size_t)b * T + j - 1] != 0 : true)));
+        const bool ok = tid < 32 && (j == T || (j < T && (mask ? mask[(size_t)b * T + j] != 0 : true)));
         const unsigned long long bal = __ballot(ok);
         if (tid == 0) vbits[(size_t)b * nch + ch] = (uint32_t)bal;
     }
     for (int e = tid; e < 2 * NH * 32 * 8; e += 256) {
         const int part = e >> 11, h = (e >> 8) & 7, row = (e >> 3) & 31, pos = e & 7, gc = pos ^ (row & 7), j = 32 * ch + row;
         uint4 r = make_uint4(0, 0, 0, 0);
-        if (j == 0) {
+        if (j == T) {
             const float* src = (part ? null_v : null_k) + h * DH + gc * 8;
             r = make_uint4(pack2_rne(src[0], src[1]), pack2_rne(src[2], src[3]), pack2_rne(src[4], src[5]), pack2_rne(src[6], src[7]));
-        } else if (j <= T) r = *reinterpret_cast<const uint4*>(kv + ((size_t)b * T + j - 1) * ldkv + part * NH * DH + h * DH + gc * 8);
+        } else if (j < T) r = *reinterpret_cast<const uint4*>(kv + ((size_t)b * T + j) * ldkv + part * NH * DH + h * DH + gc * 8);
         *reinterpret_cast<uint4*>((part ? V6 : K6) + cbase + h * TILE + row * 128 + pos * 16) = r;
     }
 }
@@ -907,19 +982,19 @@ extern "C" size_t amdnuwa_xattn6_bwd_workspace_bytes(const amdnuwa_xattn_geom* g
     return amdnuwa_xattn6_bwd_image_bytes(g) ? (size_t)g->B * ((g->n + 63) / 64) * NH * NH * sizeof(float) : 0;
 }
 extern "C" int amdnuwa_xattn6_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo, const amdnuwa_xattn6_kv* kv,
-                                  const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm, uint16_t* dq, int lddq, float* part_th,
+                                  const float* null_k, const float* null_v, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm, uint16_t* dq, int lddq, float* part_th,
                                   size_t part_bytes, hipStream_t stream) {
     if (!amdnuwa_xattn6_bwd_image_bytes(g)) return g ? AMDNUWA_ERR_UNSUPPORTED : AMDNUWA_ERR_ARG;
-    if (!q || !dO || !kv || !kv->K6 || !kv->V6 || !kv->vbits || !w_th || !stats || !dS || !Pm || !dq || ldq % 8 || lddo % 8 || lddq % 4)
+    if (!q || !dO || !kv || !kv->K6 || !kv->V6 || !kv->vbits || !null_k || !null_v || !w_th || !stats || !dS || !Pm || !dq || ldq % 8 || lddo % 8 || lddq % 4)
         return AMDNUWA_ERR_ARG;
     if (!part_th || part_bytes < amdnuwa_xattn6_bwd_workspace_bytes(g)) return AMDNUWA_ERR_WORKSPACE;
     if (g->B <= 0 || g->n <= 0) return AMDNUWA_OK;
     X6BArgs a{};
     a.q = q; a.ldq = ldq; a.dO = dO; a.lddo = lddo; a.K6 = (const char*)kv->K6; a.V6 = (const char*)kv->V6; a.vbits = kv->vbits;
-    a.wth = w_th; a.stats = stats; a.dS = dS; a.Pm = Pm; a.dq = dq; a.lddq = lddq; a.part_th = part_th;
+    a.null_k = null_k; a.null_v = null_v; a.wth = w_th; a.stats = stats; a.dS = dS; a.Pm = Pm; a.dq = dq; a.lddq = lddq; a.part_th = part_th;
     a.B = g->B; a.n = g->n; a.nch = g->JP / 32; a.T = g->T; a.scale = g->scale;
-    (void)hipFuncSetAttribute((const void*)xattn6_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-    hipLaunchKernelGGL(xattn6_bwd_kernel, dim3(g->B * ((g->n + 63) / 64)), dim3(256), 2 * STAGE, stream, a);
+    (void)hipFuncSetAttribute((const void*)xattn6_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 4096);
+    hipLaunchKernelGGL(xattn6_bwd_kernel, dim3(g->B * ((g->n + 63) / 64)), dim3(256), 2 * STAGE + 4096, stream, a);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }

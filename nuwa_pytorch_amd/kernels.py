@@ -1320,6 +1320,7 @@ def xattn6_bwd_ok(g):
 def xattn6_pack_bwd(g, kv_bf16, null_k, null_v, mask_u8):
     assert kv_bf16.dtype == torch.bfloat16 and kv_bf16.stride(1) == 1
     pk = PackedKV6B(g, kv_bf16.device)
+    pk.null_k, pk.null_v = null_k, null_v
     check(_lib.lib().amdnuwa_xattn6_pack_bwd(C.byref(g), _p(kv_bf16), kv_bf16.stride(0), _p(null_k), _p(null_v), _p(mask_u8), C.byref(pk.struct),
                                              _stream()), 'amdnuwa_xattn6_pack_bwd')
     return pk
@@ -1337,7 +1338,7 @@ def xattn6_bwd(g, q, dO, pk, wth, stats):
     dS, Pm = empty_bf(shape, dev, lo=False), empty_bf(shape, dev, lo=False)
     nb = L.amdnuwa_xattn6_bwd_workspace_bytes(C.byref(g))
     part = torch.empty((nb // (4 * g.heads * g.heads), g.heads * g.heads), dtype=torch.float32, device=dev)
-    check(L.amdnuwa_xattn6_bwd(C.byref(g), _p(q.hi), q.hi.stride(0), _p(dO.hi), dO.hi.stride(0), C.byref(pk.struct), _p(wth), _p(stats),
+    check(L.amdnuwa_xattn6_bwd(C.byref(g), _p(q.hi), q.hi.stride(0), _p(dO.hi), dO.hi.stride(0), C.byref(pk.struct), _p(pk.null_k), _p(pk.null_v), _p(wth), _p(stats),
                                _p(dS.hi), _p(Pm.hi), _p(dq.hi), inner, _p(part), nb, _stream()), 'amdnuwa_xattn6_bwd')
     dwth = colsum(part).reshape(g.heads, g.heads)          # fixed-order reduction over the workgroups
     return dq, BF(dS.hi, None), BF(Pm.hi, None), dwth
@@ -1523,15 +1524,16 @@ def xattn_key_positions(JP, device):
     return (j & ~31) + 8 * ((kk & 15) >> 2) + 4 * (kk >> 4) + (kk & 3)
 
 
-def xattn_unpack(g, dKp, dVp, lo, permuted=False):
-    """permuted: dKp / dVp came from xattn_kv_grads over the dS / Pm of xattn2_bwd (chunk-permuted key rows)"""
+def xattn_unpack(g, dKp, dVp, lo, permuted=False, null_last=False):
+    """permuted: dKp / dVp came from xattn_kv_grads over the dS / Pm of xattn2_bwd (chunk-permuted key rows); null_last: ... of xattn6_bwd
+    (context key t at position t, the null key at position T)"""
     L = _lib.lib()
     inner = g.heads * g.dim_head
     dev = dKp.device
     dkv = empty_bf((g.B * g.T, 2 * inner), dev, lo=lo)
     dnk = torch.empty((g.heads, g.dim_head), dtype=torch.float32, device=dev)
     dnv = torch.empty_like(dnk)
-    check(L.amdnuwa_xattn_unpack(C.byref(g), _p(dKp), _p(dVp), _p(dkv.hi), _p(dkv.lo), 2 * inner, _p(dnk), _p(dnv), 2 if permuted else 0, _stream()),
+    check(L.amdnuwa_xattn_unpack(C.byref(g), _p(dKp), _p(dVp), _p(dkv.hi), _p(dkv.lo), 2 * inner, _p(dnk), _p(dnv), (2 if permuted else 0) | (4 if null_last else 0), _stream()),
           'amdnuwa_xattn_unpack')
     return dkv, dnk, dnv
 

@@ -339,7 +339,7 @@ class XInner:
             else:
                 dq, dS, dwth = K.xattn_bwd(g, d_o, pk, wth2, P)
             dKp, dVp = K.xattn_kv_grads(g, dS, Pm, q, d_o)
-        dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=dy.lo is not None, permuted=permuted)
+        dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=dy.lo is not None, permuted=permuted, null_last=isinstance(pk, K.PackedKV6B))
         rot = meta.get('rotary')
         if rot is not None:
             dq = _rotary_bf(dq, rot, g.B, g.n, g.heads, inverse=True)
