@@ -563,7 +563,8 @@ def main():
             finally:
                 A.set_precision(args.precision)
             out['parity'] = par
-        # fp16 saturation monitor over everything this process ran (timed steps included): 0 in a healthy run
+        # fp16 saturation monitor over everything this process ran (timed steps included): the COUNTED stores (LayerNorm fp16 copies, cross-attention
+        # output copy, fp16-gradient epilogues; include/amdnuwa.h says which clamp without counting): 0 in a healthy run
         try:
             out.setdefault('parity', {})['f16_saturations'] = K.f16_sat_count(reset=False)
         except Exception as e:

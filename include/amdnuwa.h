@@ -54,8 +54,7 @@ const char* amdnuwa_error_string(int code);
  *          of one residue class of y stages every key / value row once for the rows that tap it
  *   key 17 3DNA backward timing probes (garbage results): bit 0 no score sweeps, 1 no ds / P' workspace stores, 2 no dq apply sweep,
  *          3 no dW_th sums; key side: bit 4 no coefficient gathers, 5 no q / dO row fetch
- *   key 18 cross-attention timing probes (garbage results): forward bit 0 no re-staging, 1 no pass 1, 2 no probability exchange, 3 no P'V,
- *          4 no head mix; backward bit 0 no re-staging, 1 no dW_th FMAs, 2 no pass A, 3 no pass B
+ *   key 18 (unused since ABI 18: the cross-attention timing probes were run-time branches inside the chunk loops -- removed)
  *   key 19 3DNA MFMA query-side backward: 1 = the three separate item passes (P' mix, dW_th, dP mix) instead of the fused one
  *   key 20 NT 256x256 ring as a PERSISTENT kernel (one workgroup per CU walks the tile list, the DMA ring runs on across tile borders):
  *          0 = auto (more tiles than CUs and K <= 1024), 1 = never, 2 = always
@@ -72,8 +71,11 @@ const char* amdnuwa_error_string(int code);
  *  any non-zero key 0 disables the few-row weight-streaming path that M <= 32 normally takes) */
 int amdnuwa_set_tuning(int key, int value);
 /* fp16 saturation monitor: number of threads (since the last reset) that handed a value beyond +-65504 to one of the library's saturating
- * fp16 stores (LayerNorm copies, GEMM epilogue copies, attention outputs, fp16 gradients).  0 in a healthy run: a saturated value is
- * DEFINED (clamped) but no longer the reference's arithmetic.  Synchronises the device; reset != 0 clears the counters. */
+ * COUNTED fp16 stores: the LayerNorm fp16 copies, the fp16-gradient epilogues (GEMM EPI 4 / 5, LayerNorm backward) and the fp16 copy of
+ * the cross-attention output (amdnuwa_xattn6_fwd).  The forward GEMM epilogue copies (q / k / v, the FeedForward gate), the Sparse3DNA output
+ * copy and amdnuwa_xattn2_fwd_f16 clamp to +-65504 as well but are NOT counted (one more live register there sends the persistent ring to
+ * scratch): their inputs are LayerNorm outputs times weights inside the checked fp16 range.  0 in a healthy run: a saturated value is DEFINED
+ * (clamped) but no longer the reference's arithmetic.  Synchronises the device; reset != 0 clears the counters. */
 unsigned long long amdnuwa_f16_sat_count(int reset);
 int amdnuwa_get_tuning(int key);
 
@@ -468,7 +470,7 @@ int amdnuwa_xattn2_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, 
 /* ABI 17: the same with flags.  Bit 0: dS / Pm are written CHUNK-MAJOR, [B][heads][JP / 32][n][32] (same chunk-permuted key order inside a
  * chunk): a store instruction of the kernel then covers 1 KiB of contiguous memory (16 queries x 64 B) instead of sixteen 64-byte pieces at
  * the 2 JP-byte row pitch (xattn3_bwd 2035 -> 1878 us at b = 128).  Read them with amdnuwa_gemm_tn and a_chunk32.  AMDNUWA_ERR_UNSUPPORTED when
- * tuning key 10 selects the first-generation kernel. */
+ * the shape is not supported. */
 int amdnuwa_xattn2_bwd_ex(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo,
                           const amdnuwa_xattn_kv* packed, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm,
                           uint16_t* dq, int lddq, float* part_th, size_t part_bytes, int flags, amdnuwa_stream stream);

@@ -58,9 +58,6 @@ struct X2Args {
                                              // written by the query side, read by the key side
     float *dKp, *dVp;                        // key side: [B][NH][JP][DH] fp32
     int flags;                               // key side: bit 0 = plain block order (probe)
-    int dbg;                                 // tuning key 18, timing probes only (garbage results).  xattn4_fwd: bit 0 no re-staging inside the chunk
-                                             // loops, 1 skip pass 1, 2 skip the probability exchange + its barrier, 3 skip the P'V MFMAs, 4 skip the mix.
-                                             // xattn3_bwd: bit 0 no re-staging, 1 skip the dW_th FMAs, 2 skip pass A, 3 skip pass B
 };
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
@@ -200,428 +197,8 @@ __device__ __forceinline__ bf16x8 pack_heads(const float (&v)[NH][8], int e) {
 #define MIX(A_, Q_, B_) MFMA((A_).lo[Q_], B_, MFMA((A_).hi[Q_], B_, (f32x4{0.f, 0.f, 0.f, 0.f})))
 
 // ------------------------------------------------------------------------------------------------
-// forward
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void xattn2_fwd_kernel(X2Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ uint32_t vsh[96];                                  // valid bytes of this sample (JP <= 288 -> 72 words)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, g4 = lane >> 4;
-    const int tiles = (a.n + 63) / 64;
-    const int b = blockIdx.x / tiles, qi = (blockIdx.x % tiles) * 64 + wave * 16 + c;
-    const bool qok = qi < a.n;
-    if (tid < a.JP / 4) vsh[tid] = reinterpret_cast<const uint32_t*>(a.valid + (size_t)b * a.JP)[tid];
-    __shared__ __attribute__((aligned(16))) float wsh[NH * NH];
-    if (tid < NH * NH) wsh[tid] = a.wth[tid];
-    __syncthreads();                                             // (before any DMA is in flight)
-    const float c1 = a.scale * 1.4426950408889634f;              // scores are handled in the log2 domain: exp(x) = exp2(x * log2 e)
-    bf16x8 qf[NH][KS];
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[h][ks] = ldg16(a.q + ((size_t)b * a.n + qi) * a.ldq + h * DH + ks * 32 + g4 * 8, qok);
-
-    // ---- pass 1: running (max, sum of exp) per head over the key chunks; only K is staged
-    float m[NH], l[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) { m[h] = NEG_MAX; l[h] = 0.f; }
-    stage_chunk<false, false>(smem, 0, 0, b, a.JP, a.Kp, nullptr, wave, lane);
-    for (int ch = 0; ch < a.nch; ++ch) {
-        if (ch + 1 < a.nch) { stage_chunk<false, false>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, nullptr, wave, lane); VMCNT(8); }
-        else VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-        const char* base = smem + (ch & 1) * STAGE;
-        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            f32x4 s0, s1;
-            qk_chunk(base, h, c, g4, qf[h], s0, s1);
-            float s[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[r] = ((vm0 >> (8 * r)) & 0xff) ? s0[r] * c1 : NEG_MAX;
-                s[4 + r] = ((vm1 >> (8 * r)) & 0xff) ? s1[r] * c1 : NEG_MAX;
-            }
-            const float cm = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-            const float mn = fmaxf(m[h], cm);
-            float acc = l[h] * __builtin_amdgcn_exp2f(m[h] - mn);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
-            l[h] = acc; m[h] = mn;
-        }
-        __builtin_amdgcn_s_barrier();
-    }
-    float nb[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            const float m2 = __shfl_xor(m[h], off, 64), l2 = __shfl_xor(l[h], off, 64);
-            const float mn = fmaxf(m[h], m2);
-            l[h] = l[h] * __builtin_amdgcn_exp2f(m[h] - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
-            m[h] = mn;
-        }
-        const float il = 1.f / l[h];
-        nb[h] = __log2f(il) - m[h];
-        if (a.stats && g4 == 0 && qok) *reinterpret_cast<float2*>(a.stats + (((size_t)b * NH + h) * a.n + qi) * 2) = make_float2(m[h], il);
-    }
-
-    // ---- pass 2: P[h] again, head mix in registers, O^T[g] += V^T[g] P'^T[g]
-    f32x4 O[NH][DB];
-#pragma unroll
-    for (int g = 0; g < NH; ++g)
-#pragma unroll
-        for (int db = 0; db < DB; ++db) O[g][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-    stage_chunk<true, false>(smem, 0, 0, b, a.JP, a.Kp, a.Vt, wave, lane);
-    for (int ch = 0; ch < a.nch; ++ch) {
-        if (ch + 1 < a.nch) { stage_chunk<true, false>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vt, wave, lane); VMCNT(16); }
-        else VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-        const char* base = smem + (ch & 1) * STAGE;
-        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
-        float P[NH][8];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            f32x4 s0, s1;
-            qk_chunk(base, h, c, g4, qf[h], s0, s1);
-            probs(s0, s1, vm0, vm1, c1, nb[h], P[h]);
-        }
-#pragma unroll
-        for (int g = 0; g < NH; ++g) {
-            const W8 wg = ldw(wsh, g);
-            float pv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float acc = wg.v[0] * P[0][e];
-#pragma unroll
-                for (int h = 1; h < NH; ++h) acc = fmaf(wg.v[h], P[h][e], acc);
-                pv[e] = acc;
-            }
-            const bf16x8 pf = pack8(pv);
-#pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                const int d = db * 16 + c;
-                const bf16x8 vf = lds8x2(base + KT_BYTES + dk_off(g, d, g4 >> 1) + (g4 & 1) * 8,
-                                         base + KT_BYTES + dk_off(g, d, 2 + (g4 >> 1)) + (g4 & 1) * 8);
-                O[g][db] = MFMA(vf, pf, O[g][db]);
-            }
-        }
-        __builtin_amdgcn_s_barrier();
-    }
-    if (qok) {
-#pragma unroll
-        for (int g = 0; g < NH; ++g)
-#pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                bf16_t* dst = a.o + ((size_t)b * a.n + qi) * a.ldo + g * DH + db * 16 + g4 * 4;
-                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(O[g][db][0], O[g][db][1]), pack2_rne(O[g][db][2], O[g][db][3]));
-            }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// backward, query-centric
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void xattn2_bwd_kernel(X2Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ uint32_t vsh[96];
-    __shared__ float thsh[4][NH * NH];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, g4 = lane >> 4;
-    const int tiles = (a.n + 63) / 64;
-    const int b = blockIdx.x / tiles, qi = (blockIdx.x % tiles) * 64 + wave * 16 + c;
-    const bool qok = qi < a.n;
-    if (tid < a.JP / 4) vsh[tid] = reinterpret_cast<const uint32_t*>(a.valid + (size_t)b * a.JP)[tid];
-    __shared__ __attribute__((aligned(16))) float wsh[NH * NH], wtsh[NH * NH];          // W[g][h] and its transpose
-    if (tid < NH * NH) { const float v = a.wth[tid]; wsh[tid] = v; wtsh[(tid & 7) * 8 + (tid >> 3)] = v; }
-    __syncthreads();                                             // (before any DMA is in flight)
-    const float c1 = a.scale * 1.4426950408889634f;
-    bf16x8 qf[NH][KS], df[NH][KS];
-    float nb[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qf[h][ks] = ldg16(a.q + ((size_t)b * a.n + qi) * a.ldq + h * DH + ks * 32 + g4 * 8, qok);
-            df[h][ks] = ldg16(a.dO + ((size_t)b * a.n + qi) * a.lddo + h * DH + ks * 32 + g4 * 8, qok);
-        }
-        const float2 st = qok ? *reinterpret_cast<const float2*>(a.stats + (((size_t)b * NH + h) * a.n + qi) * 2) : make_float2(0.f, 1.f);
-        nb[h] = qok ? __log2f(st.y) - st.x : 0.f;                 // statistics: (row max in the log2 domain, 1 / row sum)
-    }
-    const size_t prow = (size_t)a.n * a.JP;                      // stride between heads in dS / Pm
-
-    // ---- pass A: delta[h] = sum_j dP[h] P[h];  dW_th[g][h] += sum dP'[g] P[h];  P'[g] -> Pm
-    float delta[NH], dth[NH][NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-        delta[h] = 0.f;
-#pragma unroll
-        for (int g = 0; g < NH; ++g) dth[g][h] = 0.f;
-    }
-    stage_chunk<true, true>(smem, 0, 0, b, a.JP, a.Kp, a.Vp, wave, lane);
-    for (int ch = 0; ch < a.nch; ++ch) {
-        if (ch + 1 < a.nch) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
-        else VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-        const char* base = smem + (ch & 1) * STAGE;
-        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
-        float P[NH][8], dPp[NH][8];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            f32x4 s0, s1;
-            qk_chunk(base, h, c, g4, qf[h], s0, s1);
-            probs(s0, s1, vm0, vm1, c1, nb[h], P[h]);
-            qk_chunk(base + KT_BYTES, h, c, g4, df[h], s0, s1);          // dP'^T[h] = V[h] dO[h]^T
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { dPp[h][r] = s0[r]; dPp[h][4 + r] = s1[r]; }
-        }
-#pragma unroll
-        for (int g = 0; g < NH; ++g) {
-            const W8 wg = ldw(wsh, g);
-            float pm[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float acc = wg.v[0] * P[0][e];
-#pragma unroll
-                for (int h = 1; h < NH; ++h) acc = fmaf(wg.v[h], P[h][e], acc);
-                pm[e] = acc;
-            }
-            if (qok) {
-                bf16_t* dst = a.Pm + ((size_t)b * NH + g) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 8;      // (chunk-permuted key order: see X2Args::dS)
-                *reinterpret_cast<uint4*>(dst) = make_uint4(pack2_rne(pm[0], pm[1]), pack2_rne(pm[2], pm[3]), pack2_rne(pm[4], pm[5]), pack2_rne(pm[6], pm[7]));
-            }
-#pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                float acc = dth[g][h];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc = fmaf(dPp[g][e], P[h][e], acc);
-                dth[g][h] = acc;
-            }
-        }
-        __builtin_amdgcn_s_barrier();
-    }
-    // delta[h][q] = sum_j dP[h] P[h] = sum_g W[g][h] * (sum_j dP'[g] P[h]): the per-query part of the dW_th accumulators, so it
-    // costs 2 shuffles per (g, h) here instead of a third 512-FMA mix per chunk
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-        const W8 wh = ldw(wtsh, h);                              // W[.][h]
-        float acc = 0.f;
-#pragma unroll
-        for (int g = 0; g < NH; ++g) {
-            float t = dth[g][h];
-            t += __shfl_xor(t, 16, 64);
-            t += __shfl_xor(t, 32, 64);
-            acc = fmaf(wh.v[g], t, acc);
-        }
-        delta[h] = acc;
-    }
-    // dW_th partial of this workgroup (fixed order over the 4 waves): lane l ends up with the wave's sum of entry l = g * NH + h
-    {
-        float tv[NH * NH];
-#pragma unroll
-        for (int g = 0; g < NH; ++g)
-#pragma unroll
-            for (int h = 0; h < NH; ++h) tv[g * NH + h] = qok ? dth[g][h] : 0.f;
-        thsh[wave][lane] = wave_sum64_transposed(tv, lane);
-    }
-    __syncthreads();
-    if (tid < NH * NH) a.part_th[(size_t)blockIdx.x * NH * NH + tid] = ((thsh[0][tid] + thsh[1][tid]) + thsh[2][tid]) + thsh[3][tid];
-
-    // ---- pass B: ds[h] = P[h] (dP[h] - delta[h]) -> dS;  dq^T[h] += K^T[h] ds^T[h]
-    f32x4 dQ[NH][DB];
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-        for (int db = 0; db < DB; ++db) dQ[h][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-    stage_chunk<true, true>(smem, 0, 0, b, a.JP, a.Kp, a.Vp, wave, lane);
-    for (int ch = 0; ch < a.nch; ++ch) {
-        if (ch + 1 < a.nch) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
-        else VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-        const char* base = smem + (ch & 1) * STAGE;
-        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
-        float dPp[NH][8];
-#pragma unroll
-        for (int g = 0; g < NH; ++g) {
-            f32x4 s0, s1;
-            qk_chunk(base + KT_BYTES, g, c, g4, df[g], s0, s1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { dPp[g][r] = s0[r]; dPp[g][4 + r] = s1[r]; }
-        }
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            f32x4 s0, s1;
-            float P[8], ds[8];
-            qk_chunk(base, h, c, g4, qf[h], s0, s1);
-            probs(s0, s1, vm0, vm1, c1, nb[h], P);
-            const W8 wh = ldw(wtsh, h);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float dp = wh.v[0] * dPp[0][e];
-#pragma unroll
-                for (int g = 1; g < NH; ++g) dp = fmaf(wh.v[g], dPp[g][e], dp);
-                ds[e] = P[e] * (dp - delta[h]);
-            }
-            const uint2 lo = make_uint2(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]));
-            const uint2 hi = make_uint2(pack2_rne(ds[4], ds[5]), pack2_rne(ds[6], ds[7]));
-            if (qok) {
-                bf16_t* dst = a.dS + ((size_t)b * NH + h) * prow + (size_t)qi * a.JP + ch * 32 + g4 * 8;      // (chunk-permuted key order)
-                *reinterpret_cast<uint4*>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            }
-            const bf16x8 sf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-#pragma unroll
-            for (int db = 0; db < DB; ++db) dQ[h][db] = MFMA(lds_tr(base, h, db, c, g4), sf, dQ[h][db]);
-        }
-        __builtin_amdgcn_s_barrier();
-    }
-    if (qok) {
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-#pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                bf16_t* dst = a.dq + ((size_t)b * a.n + qi) * a.lddq + h * DH + db * 16 + g4 * 4;
-                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(dQ[h][db][0] * a.scale, dQ[h][db][1] * a.scale),
-                                                            pack2_rne(dQ[h][db][2] * a.scale, dQ[h][db][3] * a.scale));
-            }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // xattn3: the same two-pass structure as xattn2_fwd / xattn2_bwd with every head mix on the matrix pipe
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void xattn3_fwd_kernel(X2Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ uint32_t vsh[96];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, g4 = lane >> 4;
-    const int tiles = (a.n + 63) / 64;
-    const int b = blockIdx.x / tiles, qi = (blockIdx.x % tiles) * 64 + wave * 16 + c;
-    const bool qok = qi < a.n;
-    if (tid < a.JP / 4) vsh[tid] = reinterpret_cast<const uint32_t*>(a.valid + (size_t)b * a.JP)[tid];
-    __shared__ __attribute__((aligned(16))) float wsh[NH * NH];
-    if (tid < NH * NH) wsh[tid] = a.wth[tid];
-    __syncthreads();                                             // (before any DMA is in flight)
-    const MixA AW = mix_operand(wsh, lane);
-    const float c1 = a.scale * 1.4426950408889634f;
-    bf16x8 qf[NH][KS];
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[h][ks] = ldg16(a.q + ((size_t)b * a.n + qi) * a.ldq + h * DH + ks * 32 + g4 * 8, qok);
-
-    // ---- pass 1: running (max, sum of exp) per head over the key chunks; only K is staged (identical to xattn2_fwd)
-    float m[NH], l[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) { m[h] = NEG_MAX; l[h] = 0.f; }
-    stage_chunk<false, false>(smem, 0, 0, b, a.JP, a.Kp, nullptr, wave, lane);
-    if (a.nch > 1) { stage_chunk<false, false>(smem, 1, 1, b, a.JP, a.Kp, nullptr, wave, lane); VMCNT(8); }
-    else VMCNT(0);
-    __builtin_amdgcn_s_barrier();                                 // chunk 0 has landed for every wave
-    for (int ch = 0; ch < a.nch; ++ch) {
-        const char* base = smem + (ch & 1) * STAGE;
-        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            f32x4 s0, s1;
-            qk_chunk(base, h, c, g4, qf[h], s0, s1);
-            float s[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[r] = ((vm0 >> (8 * r)) & 0xff) ? s0[r] * c1 : NEG_MAX;
-                s[4 + r] = ((vm1 >> (8 * r)) & 0xff) ? s1[r] * c1 : NEG_MAX;
-            }
-            const float cm = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-            const float mn = fmaxf(m[h], cm);
-            float acc = l[h] * __builtin_amdgcn_exp2f(m[h] - mn);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
-            l[h] = acc; m[h] = mn;
-        }
-        // ONE ring barrier per chunk: own pieces of chunk ch + 1 (issued a whole iteration ago) have landed, and after the barrier
-        // (a) everyone's have, (b) everyone is done reading stage ch & 1, which chunk ch + 2 may now overwrite
-        VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-        if (ch + 2 < a.nch) stage_chunk<false, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, nullptr, wave, lane);
-    }
-    float nb[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            const float m2 = __shfl_xor(m[h], off, 64), l2 = __shfl_xor(l[h], off, 64);
-            const float mn = fmaxf(m[h], m2);
-            l[h] = l[h] * __builtin_amdgcn_exp2f(m[h] - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
-            m[h] = mn;
-        }
-        const float il = 1.f / l[h];
-        nb[h] = __log2f(il) - m[h];
-        if (a.stats && g4 == 0 && qok) *reinterpret_cast<float2*>(a.stats + (((size_t)b * NH + h) * a.n + qi) * 2) = make_float2(m[h], il);
-    }
-
-    // ---- pass 2: P[h] again, head mix on the matrix pipe, O^T[g] += V^T[g] P'^T[g]
-    f32x4 O[NH][DB];
-#pragma unroll
-    for (int g = 0; g < NH; ++g)
-#pragma unroll
-        for (int db = 0; db < DB; ++db) O[g][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-    stage_chunk<true, false>(smem, 0, 0, b, a.JP, a.Kp, a.Vt, wave, lane);
-    if (a.nch > 1) { stage_chunk<true, false>(smem, 1, 1, b, a.JP, a.Kp, a.Vt, wave, lane); VMCNT(16); }
-    else VMCNT(0);
-    __builtin_amdgcn_s_barrier();                                 // chunk 0 has landed for every wave
-    for (int ch = 0; ch < a.nch; ++ch) {
-        const char* base = smem + (ch & 1) * STAGE;
-        const uint32_t vm0 = vsh[ch * 8 + g4], vm1 = vsh[ch * 8 + 4 + g4];
-        bf16x8 bm[8];
-        {
-            float P[NH][8];
-#pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                f32x4 s0, s1;
-                qk_chunk(base, h, c, g4, qf[h], s0, s1);
-                probs(s0, s1, vm0, vm1, c1, nb[h], P[h]);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bm[e] = pack_heads(P, e);
-        }
-#pragma unroll
-        for (int Q = 0; Q < 2; ++Q) {
-            f32x4 D[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) D[e] = MIX(AW, Q, bm[e]);          // D[e][rp] = P'[4Q + rp] of slot e
-#pragma unroll
-            for (int rp = 0; rp < 4; ++rp) {
-                const int g = 4 * Q + rp;
-                const float pv[8] = {D[0][rp], D[1][rp], D[2][rp], D[3][rp], D[4][rp], D[5][rp], D[6][rp], D[7][rp]};
-                const bf16x8 pf = pack8(pv);
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const int d = db * 16 + c;
-                    const bf16x8 vf = lds8x2(base + KT_BYTES + dk_off(g, d, g4 >> 1) + (g4 & 1) * 8,
-                                             base + KT_BYTES + dk_off(g, d, 2 + (g4 >> 1)) + (g4 & 1) * 8);
-                    O[g][db] = MFMA(vf, pf, O[g][db]);
-                }
-            }
-        }
-        // ONE ring barrier per chunk: own pieces of chunk ch + 1 (issued a whole iteration ago) have landed, and after the barrier
-        // (a) everyone's have, (b) everyone is done reading stage ch & 1, which chunk ch + 2 may now overwrite
-        VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-        if (ch + 2 < a.nch) stage_chunk<true, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, a.Vt, wave, lane);
-    }
-    if (qok) {
-#pragma unroll
-        for (int g = 0; g < NH; ++g)
-#pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                bf16_t* dst = a.o + ((size_t)b * a.n + qi) * a.ldo + g * DH + db * 16 + g4 * 4;
-                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(O[g][db][0], O[g][db][1]), pack2_rne(O[g][db][2], O[g][db][3]));
-            }
-    }
-}
-
 __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t vsh[96];
@@ -662,8 +239,8 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
         for (int g = 0; g < NH; ++g) dth[g][h] = 0.f;
     }
     stage_chunk<true, true>(smem, 0, 0, b, a.JP, a.Kp, a.Vp, wave, lane);
-    for (int ch = 0; ch < ((a.dbg & 4) ? 0 : a.nch); ++ch) {
-        if (ch + 1 < a.nch && !(a.dbg & 1)) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
+    for (int ch = 0; ch < a.nch; ++ch) {
+        if (ch + 1 < a.nch) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
         else VMCNT(0);
         __builtin_amdgcn_s_barrier();
         const char* base = smem + (ch & 1) * STAGE;
@@ -706,14 +283,12 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) bw[e][gp] = pack2_rne(d0[e], d1[e]);
-            if (!(a.dbg & 2)) {
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 float a0 = dth[2 * gp][h], a1 = dth[2 * gp + 1][h];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { a0 = fmaf(d0[e], P[h][e], a0); a1 = fmaf(d1[e], P[h][e], a1); }
                 dth[2 * gp][h] = a0; dth[2 * gp + 1][h] = a1;
-            }
             }
         }
 #pragma unroll
@@ -762,8 +337,8 @@ __global__ __launch_bounds__(256, 1) void xattn3_bwd_kernel(X2Args a) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) dQ[h][db] = f32x4{0.f, 0.f, 0.f, 0.f};
     stage_chunk<true, true>(smem, 0, 0, b, a.JP, a.Kp, a.Vp, wave, lane);
-    for (int ch = 0; ch < ((a.dbg & 8) ? 0 : a.nch); ++ch) {
-        if (ch + 1 < a.nch && !(a.dbg & 1)) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
+    for (int ch = 0; ch < a.nch; ++ch) {
+        if (ch + 1 < a.nch) { stage_chunk<true, true>(smem, (ch + 1) & 1, ch + 1, b, a.JP, a.Kp, a.Vp, wave, lane); VMCNT(16); }
         else VMCNT(0);
         __builtin_amdgcn_s_barrier();
         const char* base = smem + (ch & 1) * STAGE;
@@ -929,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
     if (a.nch > 1) { stage_chunk8<false, false>(smem, 1, 1, b, a.JP, a.Kp, nullptr, wave, lane); VMCNT(4); }
     else VMCNT(0);
     __builtin_amdgcn_s_barrier();                                 // chunk 0 has landed for every wave
-    for (int ch = 0; ch < ((a.dbg & 2) ? 0 : a.nch); ++ch) {
+    for (int ch = 0; ch < a.nch; ++ch) {
         const char* base = smem + (ch & 1) * STAGE;
         const uint32_t vm0 = vwords[ch * 8 + g4], vm1 = vwords[ch * 8 + 4 + g4];
 #pragma unroll
@@ -953,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
         // (a) everyone's have, (b) everyone is done reading stage ch & 1, which chunk ch + 2 may now overwrite
         VMCNT(0);
         __builtin_amdgcn_s_barrier();
-        if (ch + 2 < a.nch && !(a.dbg & 1)) stage_chunk8<false, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, nullptr, wave, lane);
+        if (ch + 2 < a.nch) stage_chunk8<false, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, nullptr, wave, lane);
     }
     float nb[NHH];
 #pragma unroll
@@ -991,23 +566,20 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
                 qk_chunk<F16>(base, 4 * hh + h, c, g4, qf[h], s0, s1);
                 probs(s0, s1, vm0, vm1, c1, nb[h], P[h]);
             }
-            if (!(a.dbg & 4)) xch_put<F16>(xch_own, lane, P);
-            else asm volatile("" ::"v"(P[0][0]), "v"(P[1][3]), "v"(P[2][5]), "v"(P[3][7]));
+            xch_put<F16>(xch_own, lane, P);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(a.dbg & 4)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         f32x4 D[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            if (!(a.dbg & 16)) D[e] = mixq<F16>(AW, xch_full(xch_own, xch_par, lane, hh, e));   // D[e][rp] = P'[4 hh + rp] of slot e
-            else D[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+            D[e] = mixq<F16>(AW, xch_full(xch_own, xch_par, lane, hh, e));   // D[e][rp] = P'[4 hh + rp] of slot e
         }
 #pragma unroll
         for (int rp = 0; rp < 4; ++rp) {
             const int g = 4 * hh + rp;
             const float pv[8] = {D[0][rp], D[1][rp], D[2][rp], D[3][rp], D[4][rp], D[5][rp], D[6][rp], D[7][rp]};
             const bf16x8 pf = pack8<F16>(pv);
-            if (a.dbg & 8) { asm volatile("" ::"v"(pf)); continue; }
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const int d = db * 16 + c;
@@ -1020,7 +592,7 @@ __global__ __launch_bounds__(512, 2) void xattn4_fwd_kernel(X2Args a) {
         // (a) everyone's have, (b) everyone is done reading stage ch & 1, which chunk ch + 2 may now overwrite
         VMCNT(0);
         __builtin_amdgcn_s_barrier();
-        if (ch + 2 < a.nch && !(a.dbg & 1)) stage_chunk8<true, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, a.Vt, wave, lane);
+        if (ch + 2 < a.nch) stage_chunk8<true, false>(smem, ch & 1, ch + 2, b, a.JP, a.Kp, a.Vt, wave, lane);
     }
     if (qok) {
 #pragma unroll
@@ -1280,20 +852,10 @@ extern "C" int amdnuwa_xattn2_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.q = q; a.ldq = ldq; a.Kp = p->Kp; a.Vp = p->Vp; a.Vt = p->Vt; a.valid = p->valid; a.wth = w_th;
     a.o = o; a.ldo = ldo; a.stats = stats;
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.T = g->T; a.scale = g->scale;
-    a.dbg = g_amdnuwa_tuning[18];
     const int tiles = (g->n + 63) / 64;
-    // tuning key 10: 0 = xattn4 (two waves per query tile, 4 heads each, two waves per SIMD), 2 = xattn3 (one wave, head mix on the
-    // matrix pipe), 1 = xattn2 (one wave, VALU head mix)
-    if ((g_amdnuwa_tuning[10] & 15) == 0) {
-        const int lds4 = 2 * STAGE + 8 * XCH;
-        (void)hipFuncSetAttribute((const void*)xattn4_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
-        hipLaunchKernelGGL(xattn4_fwd_kernel<false>, dim3(g->B * tiles), dim3(512), lds4, stream, a);
-        LAUNCH_CHECK();
-        return AMDNUWA_OK;
-    }
-    auto kern = (g_amdnuwa_tuning[10] & 15) == 1 ? xattn2_fwd_kernel : xattn3_fwd_kernel;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-    hipLaunchKernelGGL(kern, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
+    const int lds4 = 2 * STAGE + 8 * XCH;
+    (void)hipFuncSetAttribute((const void*)xattn4_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+    hipLaunchKernelGGL(xattn4_fwd_kernel<false>, dim3(g->B * tiles), dim3(512), lds4, stream, a);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
@@ -1308,7 +870,6 @@ extern "C" int amdnuwa_xattn2_fwd_f16(const amdnuwa_xattn_geom* g, const uint16_
     a.q = q_f16; a.ldq = ldq; a.Kp = p->Kp_lo; a.Vp = p->Vp_lo; a.Vt = p->Vt_lo; a.valid = p->valid; a.wth = w_th;    // the fp16 images
     a.o = o; a.ol = o_lo; a.ldo = ldo; a.stats = stats; a.ol_f16 = (o_lo && o_lo_f16) ? 1 : 0;
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.T = g->T; a.scale = g->scale;
-    a.dbg = g_amdnuwa_tuning[18];
     const int tiles = (g->n + 63) / 64;
     const int lds4 = 2 * STAGE + 8 * XCH;
     (void)hipFuncSetAttribute((const void*)xattn4_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
@@ -1345,13 +906,9 @@ extern "C" int amdnuwa_xattn2_bwd_ex(const amdnuwa_xattn_geom* g, const uint16_t
     a.stats = const_cast<float*>(stats); a.dS = dS; a.Pm = Pm; a.dq = dq; a.lddq = lddq; a.part_th = part_th;
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.T = g->T; a.scale = g->scale;
     const int tiles = (g->n + 63) / 64;
-    a.nostore = (g_amdnuwa_tuning[10] & 16) ? 1 : 0;
-    a.dbg = g_amdnuwa_tuning[18];
-    auto kern = (g_amdnuwa_tuning[10] & 15) == 1 ? xattn2_bwd_kernel : xattn3_bwd_kernel;          // (0 and 2: xattn3_bwd)
     a.cm = flags & 1;
-    if (a.cm && kern != xattn3_bwd_kernel) return AMDNUWA_ERR_UNSUPPORTED;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-    hipLaunchKernelGGL(kern, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
+    (void)hipFuncSetAttribute((const void*)xattn3_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    hipLaunchKernelGGL(xattn3_bwd_kernel, dim3(g->B * tiles), dim3(256), 2 * STAGE, stream, a);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
@@ -1375,7 +932,7 @@ extern "C" int amdnuwa_xattn2_bwd_rc(const amdnuwa_xattn_geom* g, const uint16_t
     a.q = q; a.ldq = ldq; a.dO = dO; a.lddo = lddo; a.Kp = p->Kp; a.Vp = p->Vp; a.Vt = p->Vt; a.valid = p->valid; a.wth = w_th;
     a.stats = const_cast<float*>(stats); a.dq = dq; a.lddq = lddq; a.part_th = part_th;
     a.B = g->B; a.n = g->n; a.JP = g->JP; a.nch = g->JP / 32; a.T = g->T; a.scale = g->scale;
-    a.nostore = 1; a.nbd = nbd; a.dKp = dKp; a.dVp = dVp; a.flags = (g_amdnuwa_tuning[10] & 32) ? 1 : 0;
+    a.nostore = 1; a.nbd = nbd; a.dKp = dKp; a.dVp = dVp; a.flags = 0;
     (void)hipFuncSetAttribute((const void*)xattn3_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
     hipLaunchKernelGGL(xattn3_bwd_kernel, dim3(g->B * ((g->n + 63) / 64)), dim3(256), 2 * STAGE, stream, a);
     LAUNCH_CHECK();

@@ -434,6 +434,7 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
         // of the 32-channel pair): half the store instructions for the same bytes (the tail was store-issue-bound: 10 k cycles per item)
         if (true) {
             const int dlane = 16 * (g4 & 1) + 8 * (g4 >> 1);
+            float amax = 0.f;
 #pragma unroll
             for (int rp = 0; rp < NHH; ++rp)
 #pragma unroll
@@ -442,9 +443,9 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
                     uint32_t x0 = pack2_rne(O[rp][dp][0], O[rp][dp][1]), x1 = pack2_rne(O[rp][dp][2], O[rp][dp][3]);
                     uint32_t y0 = pack2_rne(O[rp][dp + 1][0], O[rp][dp + 1][1]), y1 = pack2_rne(O[rp][dp + 1][2], O[rp][dp + 1][3]);
                     uint32_t lx0, lx1, ly0, ly1;                  // the second output: fp16 copy or bf16 residual
-                    if (a.ol_f16) {
-                        lx0 = pack2_f16_sat(O[rp][dp][0], O[rp][dp][1]); lx1 = pack2_f16_sat(O[rp][dp][2], O[rp][dp][3]);
-                        ly0 = pack2_f16_sat(O[rp][dp + 1][0], O[rp][dp + 1][1]); ly1 = pack2_f16_sat(O[rp][dp + 1][2], O[rp][dp + 1][3]);
+                    if (a.ol_f16) {                               // (saturating AND counted: amdnuwa_f16_sat_count)
+                        lx0 = pack2_f16_sat_n(O[rp][dp][0], O[rp][dp][1], amax); lx1 = pack2_f16_sat_n(O[rp][dp][2], O[rp][dp][3], amax);
+                        ly0 = pack2_f16_sat_n(O[rp][dp + 1][0], O[rp][dp + 1][1], amax); ly1 = pack2_f16_sat_n(O[rp][dp + 1][2], O[rp][dp + 1][3], amax);
                     } else {
                         lx0 = pack2_rne(O[rp][dp][0] - lo_f(x0), O[rp][dp][1] - hi_f(x0)); lx1 = pack2_rne(O[rp][dp][2] - lo_f(x1), O[rp][dp][3] - hi_f(x1));
                         ly0 = pack2_rne(O[rp][dp + 1][0] - lo_f(y0), O[rp][dp + 1][1] - hi_f(y0)); ly1 = pack2_rne(O[rp][dp + 1][2] - lo_f(y1), O[rp][dp + 1][3] - hi_f(y1));
@@ -460,6 +461,7 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
                         if (qok) *reinterpret_cast<uint4*>(a.ol + go) = make_uint4(lx0, lx1, ly0, ly1);
                     }
                 }
+            if (qok) f16_sat_commit(amax);
         }
         STAMP(13, 2);
     }

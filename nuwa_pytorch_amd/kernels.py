@@ -1419,7 +1419,7 @@ def xattn_chunk_major_ok(g):
     """dS / Pm of xattn2_bwd chunk-major ([B, h, JP / 32, n, 32]: 1 KiB contiguous per store instruction of the kernel) -- when the batched
     TN product that reads them runs on the whole-M kernel, the one that takes that layout"""
     L = _lib.lib()
-    if (L.amdnuwa_get_tuning(10) & 15) == 1 or os.environ.get('AMDNUWA_XATTN_CM', '1') == '0':      # (env: A/B against the row-major arrays)
+    if os.environ.get('AMDNUWA_XATTN_CM', '1') == '0':      # (env: A/B against the row-major arrays)
         return False
     return bool(L.amdnuwa_gemm_tn_chunked_a_supported(C.byref(_xattn_tn_desc(g, xattn_permuted_extent(g), True))))
 

@@ -114,8 +114,8 @@ def f16_ranges_prefetch(ws):
     # the stream is drained at this point anyway (once per optimiser step): look at the fp16 saturation monitor of the step before
     nsat = K.f16_sat_count(reset=True)
     if nsat:
-        warnings.warn(f'nuwa_pytorch_amd: {nsat} thread(s) clamped a value beyond +-65504 in an fp16 store of the last step (activation copies or '
-                      "fp16 gradients of the 'bf16x3-fwd' mode): the step ran on saturated values; set_precision('bf16x3') has fp32's range",
+        warnings.warn(f'nuwa_pytorch_amd: {nsat} thread(s) clamped a value beyond +-65504 in a counted fp16 store of the last step (LayerNorm copies, the cross-attention '
+                      "output copy or fp16 gradients of the 'bf16x3-fwd' mode; the q / k / v and gate copies clamp without counting): the step ran on saturated values; set_precision('bf16x3') has fp32's range",
                       RuntimeWarning, stacklevel=3)
 
 

@@ -85,20 +85,11 @@ def main():
         t = bench(lambda: K.xattn_kv_grads(g, dS, Pm, q, do), args.iters)
         print(f'kv grads (2 batched TN, tn variant {v}) {t * 1e6:7.1f} us')
     L.amdnuwa_set_tuning(6, 0)
-    if K.xattn2_supported(g, q):
-        ref = None
-        for v, name in ((1, 'xattn2 (1 wave/tile, VALU head mix)'), (2, 'xattn3 (1 wave/tile, MFMA head mix)'), (0, 'xattn4 (2 waves/tile)')):      # tuning key 10
-            L.amdnuwa_set_tuning(10, v)
-            t = bench(lambda: K.xattn2_fwd(g, q, pk, wth), args.iters)
-            o2, stats = K.xattn2_fwd(g, q, pk, wth)
-            t2 = bench(lambda: K.xattn2_bwd(g, q, do, pk, wth, stats), args.iters)
-            dq2, dS2, Pm2, dw2 = K.xattn2_bwd(g, q, do, pk, wth, stats)
-            cur = [o2.hi.float(), dq2.hi.float(), K.xattn_rows(g, dS2.hi).float(), K.xattn_rows(g, Pm2.hi).float(), dw2]
-            diff = '' if ref is None else '  max rel diff vs xattn2: ' + ' '.join(
-                f'{nm} {float((a_ - b_).abs().max() / b_.abs().max()):.1e}' for nm, a_, b_ in zip(('o', 'dq', 'dS', 'Pm', 'dWth'), cur, ref))
-            ref = cur if ref is None else ref
-            print(f'{name}: fwd {t * 1e6:7.1f} us ({fl / t / 1e12:6.1f} TF/s MFMA-useful)  bwd_q {t2 * 1e6:7.1f} us{diff}')
-        L.amdnuwa_set_tuning(10, 0)
+    if K.xattn2_supported(g, q):       # second design (xattn4 forward, xattn3 backward) beside the third (tools/xattn6_bench.py times both A/B)
+        t = bench(lambda: K.xattn2_fwd(g, q, pk, wth), args.iters)
+        o2, stats = K.xattn2_fwd(g, q, pk, wth)
+        t2 = bench(lambda: K.xattn2_bwd(g, q, do, pk, wth, stats), args.iters)
+        print(f'xattn4 fwd {t * 1e6:7.1f} us ({fl / t / 1e12:6.1f} TF/s MFMA-useful)  xattn3 bwd_q {t2 * 1e6:7.1f} us')
 
 
 if __name__ == '__main__':

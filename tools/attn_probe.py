@@ -54,30 +54,6 @@ def main():
         row.append(f'{nm} {bench(lambda: K.sparse3dna_bwd(g, qkv, wth, do), args.iters) * 1e6:7.1f}')
     L.amdnuwa_set_tuning(19, 0)
     print('bwd, query side item passes (A/B/A/B): ' + ' | '.join(row))
-    print(f'== cross attention, b={b}, n={n}, T={T}: tuning key 18 ==')
-    gx = K.x_geom(b, n, T, heads, dh)
-    q = K.BF(torch.randn(b * n, inner, device=dev).to(torch.bfloat16), None)
-    kv = K.BF(torch.randn(b * T, 2 * inner, device=dev).to(torch.bfloat16), None)
-    nk = torch.randn(heads, dh, device=dev)
-    mask = (torch.rand(b, T, device=dev) > 0.2).to(torch.uint8)
-    pk = K.xattn_pack(gx, kv, nk, nk, mask)
-    row = []
-    for nm, bits in (('full', 0), ('no re-staging', 1), ('no pass 1', 2), ('no exchange', 4), ('no PV', 8), ('no mix', 16), ('no staging+pass1', 3),
-                     ('pass 2 QK + softmax only', 1 + 2 + 4 + 8 + 16)):
-        L.amdnuwa_set_tuning(18, bits)
-        row.append(f'{nm} {bench(lambda: K.xattn2_fwd(gx, q, pk, wth), args.iters) * 1e6:7.1f}')
-    L.amdnuwa_set_tuning(18, 0)
-    print('xattn4_fwd: ' + ' | '.join(row))
-    o2, stats = K.xattn2_fwd(gx, q, pk, wth)
-    row = []
-    for nm, bits, k10 in (('full', 0, 0), ('no dS/Pm stores', 0, 16), ('no re-staging', 1, 0), ('no dW_th FMAs', 2, 0), ('no pass A', 4, 0), ('no pass B', 8, 0),
-                          ('no stores, no staging', 1, 16), ('no stores/staging/dWth', 3, 16)):
-        L.amdnuwa_set_tuning(18, bits)
-        L.amdnuwa_set_tuning(10, k10)
-        row.append(f'{nm} {bench(lambda: K.xattn2_bwd(gx, q, do, pk, wth, stats), args.iters) * 1e6:7.1f}')
-    L.amdnuwa_set_tuning(18, 0)
-    L.amdnuwa_set_tuning(10, 0)
-    print('xattn3_bwd: ' + ' | '.join(row))
 
 
 if __name__ == '__main__':
