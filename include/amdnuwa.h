@@ -33,7 +33,7 @@ int amdnuwa_abi_version(void);                 /* bumps when any signature or do
                                                 * amdnuwa_xattn_unpack's flag bit 1, chunk-permuted dS / Pm columns of amdnuwa_xattn2_bwd;
                                                 * 14: amdnuwa_linear_ce_x3 added; 15: the two-MFMA products -- amdnuwa_gemm_desc.ab_f16 with Blo, amdnuwa_gemm_nt_f16x2_supported,
                                                 *     o_lo_f16 on the two fp16 forward cores; 16: the fp16-gradient backward; 17: amdnuwa_gemm_desc.a_chunk32, amdnuwa_gemm_tn_chunked_a_supported,
-                                                *     amdnuwa_xattn2_bwd_ex, AMDNUWA_LN_RESID_MINUS, tuning key 25; 18: the amdnuwa_xattn6_* family) */
+                                                *     amdnuwa_xattn2_bwd_ex, AMDNUWA_LN_RESID_MINUS, tuning key 25; 18: the amdnuwa_xattn6_* family; 19: amdnuwa_sparse3dna_bwd_f16, o == NULL in amdnuwa_sparse3dna_fwd_f16) */
 const char* amdnuwa_error_string(int code);
 /* runtime tuning knobs (A/B benchmarking only; 0 = the library's auto policy everywhere):
  *   key 0  NT GEMM variant: 1 direct-to-LDS BK 64, 2 direct-to-LDS BK 32, 3 / 4 256x256 tile with a 4- / 3-stage DMA ring,
@@ -342,6 +342,17 @@ int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* q, const ui
                            uint16_t* dk, uint16_t* dv, uint16_t* dq_lo, uint16_t* dk_lo, uint16_t* dv_lo, int ldd,
                            float* dw_th, int accumulate, void* workspace, size_t workspace_bytes,
                            amdnuwa_stream stream);
+/* ABI 19, the fp16-gradient form of the backward (reference nuwa_pytorch.py:488-608 differentiated; block class 's' of the 'bf16x3-fwd' mode):
+ * q / k / v are the fp16 arrays the fp16 forward read -- the block then keeps ONE 16-bit copy of them --, dO_f16 = fp16(S dO), and dq / dk / dv
+ * leave as fp16(S gradient), saturating and counted by amdnuwa_f16_sat_count; dw_th leaves as fp32 WITHOUT the factor.  scale2 = device
+ * pointer to {S, 1 / S} (S a power of two, see amdnuwa_gemm_desc.alpha_dev).  Same workspace as amdnuwa_sparse3dna_bwd.  Band-kernel
+ * geometry without a relative-position bias only: amdnuwa_sparse3dna_bwd_f16_supported(), AMDNUWA_ERR_UNSUPPORTED otherwise.
+ * amdnuwa_sparse3dna_fwd_f16 accepts o == NULL together with o_lo_f16 (the fp16 copy is then the only output). */
+int amdnuwa_sparse3dna_bwd_f16_supported(const amdnuwa_s3_geom* g);
+int amdnuwa_sparse3dna_bwd_f16(const amdnuwa_s3_geom* g, const uint16_t* q_f16, const uint16_t* k_f16, const uint16_t* v_f16, int ld,
+                               const float* w_th, const uint16_t* dO_f16, int lddo, uint16_t* dq_f16, uint16_t* dk_f16, uint16_t* dv_f16,
+                               int ldd, float* dw_th, int accumulate, const float* scale2, void* workspace, size_t workspace_bytes,
+                               amdnuwa_stream stream);
 
 /* SparseCross2DNA (np.py:761-901): NUWASketch's decoder cross-attention.  Queries = the video rows q [B*ntok, ldq] (row 0 of every
  * sample is <bos>); keys / values = the sketch context k, v [B*ctx_rows, ldkv], ctx_rows = g->kf * H * W (g->kf = sketch frames).

@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # AMDNUWA_LIBRARY: another build of the same library (A/B runs of compiler options inside one process group; tools/ only)
 LIB_PATH = os.environ.get('AMDNUWA_LIBRARY') or os.path.join(HERE, 'lib', 'libamdnuwa.so')
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 P = C.c_void_p
 I = C.c_int
@@ -104,6 +104,8 @@ SIGNATURES = {
     'amdnuwa_sparse3dna_fwd_f16': (I, [SG, P, P, P, I, P, P, P, I, I, P]),
     'amdnuwa_sparse3dna_bwd_workspace_bytes': (SZ, [SG]),
     'amdnuwa_sparse3dna_bwd': (I, [SG, P, P, P, P, P, P, I, P, P, P, I, P, P, P, P, P, P, I, P, I, P, SZ, P]),
+    'amdnuwa_sparse3dna_bwd_f16_supported': (I, [SG]),
+    'amdnuwa_sparse3dna_bwd_f16': (I, [SG, P, P, P, I, P, P, I, P, P, P, I, P, I, P, P, SZ, P]),
     'amdnuwa_cross2dna_fwd': (I, [SG, P, P, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P, I, P]),
     'amdnuwa_cross2dna_bwd_workspace_bytes': (SZ, [SG]),
     'amdnuwa_cross2dna_bwd': (I, [SG, P, P, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P, I, P, P, I, P, P, P, P, I, P, P, P, P, SZ, P]),

@@ -7,7 +7,7 @@
 
 int g_amdnuwa_tuning[32] = {0};
 
-extern "C" int amdnuwa_abi_version(void) { return 18; }
+extern "C" int amdnuwa_abi_version(void) { return 19; }
 
 // fp16 saturation monitor: one counter word per translation unit with saturating fp16 stores (common.h: AMDNUWA_SAT_ACCESSOR)
 extern "C" unsigned amdnuwa_sat_elementwise(int), amdnuwa_sat_gemm(int), amdnuwa_sat_sparse3dna(int), amdnuwa_sat_xattn(int), amdnuwa_sat_xattn2(int), amdnuwa_sat_xattn6(int);

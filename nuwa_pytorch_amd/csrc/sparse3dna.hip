@@ -52,7 +52,11 @@ struct S3Args {
     int ymajor;                                           // MFMA kernels: workgroup order inside a sample is (y, f) instead of (f, y) (tuning key 3 bit 1 = old order)
     int sep_passes;                                       // MFMA query-side backward: the three separate item passes instead of the fused one (tuning key 19 = 1)
     int packed;                                           // MFMA backward (round 5): the ds / P' workspace is ONE array of (bf16 ds | bf16 P') words at `pm`
+    const float* gs2;                                     // fp16-gradient backward (round 6, amdnuwa_sparse3dna_bwd_f16): device {S, 1 / S}; q / k / v / dO hold fp16 values,
+                                                          // dO = fp16(S dO), dq / dk / dv leave as fp16(S gradient), the workspace words are (fp16 S ds | fp16 P'), dW_th leaves times 1 / S
 };
+// a 16-bit element of an operand array as fp32: bf16, or (F16) fp16
+template <bool F16> __device__ __forceinline__ float ld16_t(bf16_t v) { return F16 ? (float)__builtin_bit_cast(_Float16, v) : bf2f(v); }
 
 constexpr float NEG_MAX = -3.4028234663852886e38f;
 
@@ -704,6 +708,7 @@ __global__ __launch_bounds__(1024) void s3_bwd_fin_kernel(S3Args a, int DH) {
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 64; ++r) t += redw[r][threadIdx.x & 15];
+            t *= f16_gs_inv(a.gs2);                                   // (fp16-gradient form: the partials carry the factor S)
             a.dwth[col] = a.accumulate ? a.dwth[col] + t : t;
         }
         return;
@@ -754,6 +759,13 @@ __global__ __launch_bounds__(1024) void s3_bwd_fin_kernel(S3Args a, int DH) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { tk += red[0][r][lane]; tv += red[1][r][lane]; }
         const size_t gi = ((size_t)b * a.ntok) * a.lddo + e, go = ((size_t)b * a.ntok) * a.ldd + e;
+        if (a.gs2) {                                                  // fp16-gradient form: fp16 in, fp16 out (still times S)
+            tv += ld16_t<true>(a.dO[gi]);
+            float amax = fmaxf(fabsf(tk), fabsf(tv));
+            a.dk[go] = f2h_sat(tk); a.dv[go] = f2h_sat(tv);
+            f16_sat_commit(amax);
+            return;
+        }
         tv += bf2f(a.dO[gi]) + (a.dOl ? bf2f(a.dOl[gi]) : 0.f);
         bf16_t hh, ll;
         f2bf_hilo(tk, hh, ll); a.dk[go] = hh; if (a.dkl) a.dkl[go] = ll;
@@ -1203,7 +1215,7 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
             if (F16) {
                 bf16_t hi, lo;
                 f2bf_hilo((float)__builtin_bit_cast(_Float16, raw), hi, lo);
-                a.o[((size_t)b * a.ntok) * a.ldo + e] = hi;
+                if (a.o) a.o[((size_t)b * a.ntok) * a.ldo + e] = hi;     // (o == NULL: the fp16 copy alone -- the fp16-gradient backward reads nothing else)
                 if (a.ol) a.ol[((size_t)b * a.ntok) * a.ldo + e] = a.ol_f16 ? raw : lo;
             } else a.o[((size_t)b * a.ntok) * a.ldo + e] = raw;
         }
@@ -1248,7 +1260,7 @@ __global__ __launch_bounds__(512, 2) void s3_fwd_mfma_kernel(S3Args a) {
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
                 const uint32_t h01 = pack2_rne(O[db][0], O[db][1]), h23 = pack2_rne(O[db][2], O[db][3]);
-                *reinterpret_cast<uint2*>(a.o + go + db * 16) = make_uint2(h01, h23);
+                if (!F16 || a.o) *reinterpret_cast<uint2*>(a.o + go + db * 16) = make_uint2(h01, h23);
                 if (F16 && a.ol)
                     *reinterpret_cast<uint2*>(a.ol + go + db * 16) = a.ol_f16 ?
                         make_uint2(pack2_f16_sat(O[db][0], O[db][1]), pack2_f16_sat(O[db][2], O[db][3])) :
@@ -1541,7 +1553,7 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
             if (F16) {
                 bf16_t hi, lo;
                 f2bf_hilo((float)__builtin_bit_cast(_Float16, raw), hi, lo);
-                a.o[((size_t)b * a.ntok) * a.ldo + e] = hi;
+                if (a.o) a.o[((size_t)b * a.ntok) * a.ldo + e] = hi;     // (o == NULL: the fp16 copy alone -- the fp16-gradient backward reads nothing else)
                 if (a.ol) a.ol[((size_t)b * a.ntok) * a.ldo + e] = a.ol_f16 ? raw : lo;
             } else a.o[((size_t)b * a.ntok) * a.ldo + e] = raw;
         }
@@ -1600,7 +1612,7 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
                 const uint32_t h01 = pack2_rne(O[i][db][0], O[i][db][1]), h23 = pack2_rne(O[i][db][2], O[i][db][3]);
-                *reinterpret_cast<uint2*>(a.o + go + db * 16) = make_uint2(h01, h23);
+                if (!F16 || a.o) *reinterpret_cast<uint2*>(a.o + go + db * 16) = make_uint2(h01, h23);
                 if (F16 && a.ol)
                     *reinterpret_cast<uint2*>(a.ol + go + db * 16) = a.ol_f16 ?
                         make_uint2(pack2_f16_sat(O[i][db][0], O[i][db][1]), pack2_f16_sat(O[i][db][2], O[i][db][3])) :
@@ -1614,7 +1626,7 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
 // fragment and V as the rows), dW_th partial, dP = W^T dP', ds = P (dP - sum P dP), dq = scale * ds . K (band apply over K);
 // ds and P' go to the fp32 workspace for the key-side kernel, the <bos> key / value partials to part_k0 / part_v0.
 // LDS: R1 = SP (P) until ds exists, then the 8 transposed K tiles | DP | RED [8][64] | PM0 [W][NH]
-template <bool BIAS>
+template <bool BIAS, bool G16 = false>     // G16: the fp16-gradient form (S3Args::gs2)
 __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      // (4 waves per SIMD = two workgroups per CU: <= 128 registers)
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W, inner = NH * DH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1656,8 +1668,8 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
     // (a.dbg, tuning key 17: timing probes only -- bit 0 skips the two score sweeps, bit 1 the ds / P' workspace stores, bit 2 the dq
     //  apply sweep, bit 3 the dW_th partial; results are garbage)
     if (!(a.dbg & 1)) {
-    mfma_band_scores_staged(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, BIAS ? a.scale : 1.f, BIAS ? a.bias : nullptr, stile);   // scores (raw products unless a bias table is added: see rowm_softmax)
-    mfma_band_scores_staged(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, 1.f, nullptr, stile);              // dP'[g] = dO[g] . v_j[g]
+    mfma_band_scores_staged<G16>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, BIAS ? a.scale : 1.f, BIAS ? a.bias : nullptr, stile);   // scores (raw products unless a bias table is added: see rowm_softmax)
+    mfma_band_scores_staged<G16>(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, 1.f, nullptr, stile);         // dP'[g] = dO[g] . v_j[g]  (G16: times S, as everything derived from it below)
     }
     __syncthreads();
     // recomputing key side: this kernel leaves (row max, 1 / row sum, delta) per (query, head) instead of the ds / P' workspace
@@ -1827,6 +1839,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
     {
         const int cc = t & 3, wh = t >> 2, h = wh % NH, w = wh / NH;
         const int i = 1 + ry * W + w;
+        float ds_amax = 0.f;                                      // G16: S ds is clamped to the fp16 range HERE (every later use packs it to fp16) and counted
         if (J <= 48) {                                            // the thread's <= 12 slots in registers (see rowm_softmax); same order of operations
             float pv[12], dv[12];
 #pragma unroll
@@ -1844,7 +1857,8 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
                 const int j = cc + 4 * k;
                 if (j < J) {
                     const int idx = w * TS + j * NH + h;
-                    const float dsv = pv[k] * (dv[k] - d);
+                    float dsv = pv[k] * (dv[k] - d);
+                    if constexpr (G16) { ds_amax = fmaxf(ds_amax, fabsf(dsv)); dsv = f16_clamp(dsv); }
                     DP[idx] = dsv;
                     if (i < a.ntok && !gst && !a.packed && !(a.dbg & 2)) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
                 }
@@ -1856,11 +1870,13 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
         if (gst && cc == 0 && i < a.ntok) gst[(w * NH + h) * 4 + 2] = d;
         for (int j = cc; j < J; j += 4) {
             const int idx = w * TS + j * NH + h;
-            const float dsv = SP[idx] * (DP[idx] - d);
+            float dsv = SP[idx] * (DP[idx] - d);
+            if constexpr (G16) { ds_amax = fmaxf(ds_amax, fabsf(dsv)); dsv = f16_clamp(dsv); }
             DP[idx] = dsv;
             if (i < a.ntok && !gst && !a.packed) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
         }
         }
+        if constexpr (G16) f16_sat_commit(ds_amax);
     }
     __syncthreads();
     // Packed workspace (round 5): ONE pass over the items writes (bf16 ds | bf16 P') words, 8 heads = two 16-byte stores per (query, slot) -- the
@@ -1897,7 +1913,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
 #pragma unroll
                 for (int hh = 0; hh < 8; ++hh) sm += wg[hh] * pv[hh];
                 if (j == 0) PM0[wq * NH + g] = iq < a.ntok ? sm : 0.f;
-                pw[g] = pack2_rne(dsv[g], sm);                                    // low half: ds[head g], high half: P'[head g]
+                pw[g] = pack2_t<G16>(dsv[g], sm);                                 // low half: ds[head g], high half: P'[head g]  (G16: fp16 halves; ds was clamped in the ds pass)
             }
             if (iq < a.ntok && keep && !gst && !(a.dbg & 2)) {
                 uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(a.pm) + (((size_t)b * nq + (iq - 1)) * J + j) * NH);
@@ -1910,13 +1926,16 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
     {
         const int h = r.wave;
         f32x4 O[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        if (!(a.dbg & 4)) mfma_band_apply(a, r, a.k, a.ld, h, DP, smem + r.wave * 4096, O);
+        if (!(a.dbg & 4)) mfma_band_apply<G16>(a, r, a.k, a.ld, h, DP, smem + r.wave * 4096, O);
         if (r.qok) {
             bf16_t* orow = a.dq + (r.tok0 + r.iq) * a.ldd + h * DH + 4 * r.g4;
+            float amax = 0.f;
 #pragma unroll
             for (int db = 0; db < 4; ++db)
-                *reinterpret_cast<uint2*>(orow + db * 16) = make_uint2(pack2_rne(O[db][0] * a.scale, O[db][1] * a.scale),
-                                                                       pack2_rne(O[db][2] * a.scale, O[db][3] * a.scale));
+                *reinterpret_cast<uint2*>(orow + db * 16) = G16 ?
+                    make_uint2(pack2_f16_sat_n(O[db][0] * a.scale, O[db][1] * a.scale, amax), pack2_f16_sat_n(O[db][2] * a.scale, O[db][3] * a.scale, amax)) :
+                    make_uint2(pack2_rne(O[db][0] * a.scale, O[db][1] * a.scale), pack2_rne(O[db][2] * a.scale, O[db][3] * a.scale));
+            if constexpr (G16) f16_sat_commit(amax);
         }
     }
     // <bos> partials of this row: dk0[e] = scale * sum_w ds[w][0][h] q[w][e],  dv0[e] = sum_w P'[w][0][g] dO[w][e]
@@ -1929,8 +1948,8 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
         for (int w = 0; w < W; ++w) {
             const int i = 1 + ry * W + w;
             const size_t ic = r.tok0 + (i < a.ntok ? i : a.ntok - 1);
-            qv[w] = bf2f(a.q[ic * a.ld + e]);
-            dv_[w] = bf2f(a.dO[ic * a.lddo + e]);
+            qv[w] = ld16_t<G16>(a.q[ic * a.ld + e]);
+            dv_[w] = ld16_t<G16>(a.dO[ic * a.lddo + e]);
         }
         float sk = 0.f, sv = 0.f;
 #pragma unroll
@@ -1951,7 +1970,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
 // pulls from the queries that attend to it.
 // PACKED: the workspace holds (bf16 ds | bf16 P') words (one 4-byte load per coefficient pair, the MFMA operands assembled with byte
 // permutes); else two fp32 arrays (two loads, two round-to-nearest conversions): the same operand bits either way.
-template <bool PACKED>
+template <bool PACKED, bool G16 = false>     // G16: fp16 q / dO rows, (fp16 S ds | fp16 P') workspace words, fp16 outputs (S3Args::gs2)
 __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2068,8 +2087,8 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
             const s16x4 dh_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(td + troff[db] + 2048));
             const s16x8 q8 = {ql[0], ql[1], ql[2], ql[3], qh[0], qh[1], qh[2], qh[3]};
             const s16x8 d8 = {dl[0], dl[1], dl[2], dl[3], dh_[0], dh_[1], dh_[2], dh_[3]};
-            dK[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, q8), bs, dK[db], 0, 0, 0);
-            dV[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, d8), bp, dV[db], 0, 0, 0);
+            dK[db] = mfma16<G16>(__builtin_bit_cast(bf16x8, q8), bs, dK[db]);
+            dV[db] = mfma16<G16>(__builtin_bit_cast(bf16x8, d8), bp, dV[db]);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -2077,12 +2096,20 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
     if (ik < a.ntok) {
         bf16_t* kr = a.dk + (tok0 + ik) * a.ldd + h * DH + 4 * g4;
         bf16_t* vr = a.dv + (tok0 + ik) * a.ldd + h * DH + 4 * g4;
+        float amax = 0.f;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            *reinterpret_cast<uint2*>(kr + db * 16) = make_uint2(pack2_rne(dK[db][0] * a.scale, dK[db][1] * a.scale),
-                                                                 pack2_rne(dK[db][2] * a.scale, dK[db][3] * a.scale));
-            *reinterpret_cast<uint2*>(vr + db * 16) = make_uint2(pack2_rne(dV[db][0], dV[db][1]), pack2_rne(dV[db][2], dV[db][3]));
+            if constexpr (G16) {
+                *reinterpret_cast<uint2*>(kr + db * 16) = make_uint2(pack2_f16_sat_n(dK[db][0] * a.scale, dK[db][1] * a.scale, amax),
+                                                                     pack2_f16_sat_n(dK[db][2] * a.scale, dK[db][3] * a.scale, amax));
+                *reinterpret_cast<uint2*>(vr + db * 16) = make_uint2(pack2_f16_sat_n(dV[db][0], dV[db][1], amax), pack2_f16_sat_n(dV[db][2], dV[db][3], amax));
+            } else {
+                *reinterpret_cast<uint2*>(kr + db * 16) = make_uint2(pack2_rne(dK[db][0] * a.scale, dK[db][1] * a.scale),
+                                                                     pack2_rne(dK[db][2] * a.scale, dK[db][3] * a.scale));
+                *reinterpret_cast<uint2*>(vr + db * 16) = make_uint2(pack2_rne(dV[db][0], dV[db][1]), pack2_rne(dV[db][2], dV[db][3]));
+            }
         }
+        if constexpr (G16) f16_sat_commit(amax);
     }
 }
 
@@ -2103,6 +2130,7 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
 // anyway); P of the own head stays fp32 in ds.  LDS: 8 x 4 KiB tiles + 16 KiB exchange = 48 KiB.
 __global__ __launch_bounds__(512, 2) void s3_bwd_kv_rc_mfma_kernel(S3Args a) {
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W;
+    constexpr bool G16 = false;                                                  // (the bf16 form only: shares its tail with s3_bwd_kv_mfma_kernel)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int pslot[S3M_PLANES + 1], ptok[S3M_PLANES + 1];
     __shared__ float wsh[64];
@@ -2253,20 +2281,28 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_rc_mfma_kernel(S3Args a) {
             const s16x4 dl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(td + troff[db]));
             const s16x8 q8 = {ql[0], ql[1], ql[2], ql[3], 0, 0, 0, 0};
             const s16x8 d8 = {dl[0], dl[1], dl[2], dl[3], 0, 0, 0, 0};
-            dK[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, q8), bs, dK[db], 0, 0, 0);
-            dV[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, d8), bp, dV[db], 0, 0, 0);
+            dK[db] = mfma16<G16>(__builtin_bit_cast(bf16x8, q8), bs, dK[db]);
+            dV[db] = mfma16<G16>(__builtin_bit_cast(bf16x8, d8), bp, dV[db]);
         }
         __builtin_amdgcn_wave_barrier();
     }
     if (kok) {
         bf16_t* kr = a.dk + (tok0 + ik) * a.ldd + h * DH + 4 * g4;
         bf16_t* vr = a.dv + (tok0 + ik) * a.ldd + h * DH + 4 * g4;
+        float amax = 0.f;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            *reinterpret_cast<uint2*>(kr + db * 16) = make_uint2(pack2_rne(dK[db][0] * a.scale, dK[db][1] * a.scale),
-                                                                 pack2_rne(dK[db][2] * a.scale, dK[db][3] * a.scale));
-            *reinterpret_cast<uint2*>(vr + db * 16) = make_uint2(pack2_rne(dV[db][0], dV[db][1]), pack2_rne(dV[db][2], dV[db][3]));
+            if constexpr (G16) {
+                *reinterpret_cast<uint2*>(kr + db * 16) = make_uint2(pack2_f16_sat_n(dK[db][0] * a.scale, dK[db][1] * a.scale, amax),
+                                                                     pack2_f16_sat_n(dK[db][2] * a.scale, dK[db][3] * a.scale, amax));
+                *reinterpret_cast<uint2*>(vr + db * 16) = make_uint2(pack2_f16_sat_n(dV[db][0], dV[db][1], amax), pack2_f16_sat_n(dV[db][2], dV[db][3], amax));
+            } else {
+                *reinterpret_cast<uint2*>(kr + db * 16) = make_uint2(pack2_rne(dK[db][0] * a.scale, dK[db][1] * a.scale),
+                                                                     pack2_rne(dK[db][2] * a.scale, dK[db][3] * a.scale));
+                *reinterpret_cast<uint2*>(vr + db * 16) = make_uint2(pack2_rne(dV[db][0], dV[db][1]), pack2_rne(dV[db][2], dV[db][3]));
+            }
         }
+        if constexpr (G16) f16_sat_commit(amax);
     }
 }
 
@@ -2371,7 +2407,8 @@ extern "C" int amdnuwa_sparse3dna_fwd_f16(const amdnuwa_s3_geom* g, const uint16
     int rc = check_geom(g);
     if (rc) return rc;
     if (!s3_mfma_geom(g)) return AMDNUWA_ERR_UNSUPPORTED;
-    if (!q_f16 || !k_f16 || !v_f16 || !w_th || !o || ld % 8 || ldo % 8) return AMDNUWA_ERR_ARG;
+    if (!q_f16 || !k_f16 || !v_f16 || !w_th || ld % 8 || ldo % 8) return AMDNUWA_ERR_ARG;
+    if (!o && !(o_lo && o_lo_f16)) return AMDNUWA_ERR_ARG;        // o == NULL: the fp16 copy is the only output
     if (g->B <= 0) return AMDNUWA_OK;
     S3Args a{};
     fill_geom(a, g);
@@ -2497,6 +2534,55 @@ extern "C" int amdnuwa_sparse3dna_bwd(const amdnuwa_s3_geom* g, const uint16_t* 
                                        amdnuwa_colsum_workspace_bytes((long long)g->B * nq, (int)(J * g->heads)), stream);
         if (rc2) return rc2;
     }
+    return AMDNUWA_OK;
+}
+
+// fp16-gradient form of the backward ('bf16x3-fwd' with block class 's' of AMDNUWA_BWD_F16): q / k / v are the fp16 copies the forward core
+// read (the ONLY 16-bit copies the block keeps), dO = fp16(S dO), dq / dk / dv leave as fp16(S gradient), dW_th as fp32 without the factor.
+// scale2 = device {S, 1 / S}.  MFMA band kernels + packed workspace only (the causal decoder window, no relative-position bias):
+// AMDNUWA_ERR_UNSUPPORTED otherwise (amdnuwa_sparse3dna_bwd_f16_supported).
+extern "C" int amdnuwa_sparse3dna_bwd_f16_supported(const amdnuwa_s3_geom* g) {
+    return check_geom(g) == AMDNUWA_OK && s3_mfma_geom(g) && !g->rel_bias && !g->d_rel_bias ? 1 : 0;
+}
+extern "C" int amdnuwa_sparse3dna_bwd_f16(const amdnuwa_s3_geom* g, const uint16_t* q_f16, const uint16_t* k_f16, const uint16_t* v_f16, int ld,
+                                          const float* w_th, const uint16_t* dO_f16, int lddo, uint16_t* dq_f16, uint16_t* dk_f16,
+                                          uint16_t* dv_f16, int ldd, float* dw_th, int accumulate, const float* scale2, void* workspace,
+                                          size_t workspace_bytes, hipStream_t stream) {
+    int rc = check_geom(g);
+    if (rc) return rc;
+    if (!amdnuwa_sparse3dna_bwd_f16_supported(g)) return AMDNUWA_ERR_UNSUPPORTED;
+    if (!q_f16 || !k_f16 || !v_f16 || !w_th || !dO_f16 || !dq_f16 || !dk_f16 || !dv_f16 || !dw_th || !scale2 || ld % 8 || lddo % 8 || ldd % 8)
+        return AMDNUWA_ERR_ARG;
+    if (!workspace || workspace_bytes < amdnuwa_sparse3dna_bwd_workspace_bytes(g)) return AMDNUWA_ERR_WORKSPACE;
+    if (g->B <= 0) return AMDNUWA_OK;
+    S3Args a{};
+    fill_geom(a, g);
+    a.q = q_f16; a.k = k_f16; a.v = v_f16; a.ld = ld; a.wth = w_th;
+    a.dO = dO_f16; a.lddo = lddo;
+    a.dq = dq_f16; a.dk = dk_f16; a.dv = dv_f16; a.ldd = ldd;
+    a.dwth = dw_th; a.accumulate = accumulate; a.gs2 = scale2;
+    a.dbg = g_amdnuwa_tuning[17];
+    self_kv(a);
+    const size_t J = (size_t)g->kf * g->kh * g->kw + 1, nq = g->ntok - 1, rows = (size_t)g->B * g->F * g->H;
+    const size_t inner = (size_t)g->heads * g->dim_head;
+    float* ws = (float*)workspace;
+    a.ds = ws; ws += (size_t)g->B * nq * J * g->heads;
+    a.pm = ws; ws += (size_t)g->B * nq * J * g->heads;
+    a.part_th = ws; ws += rows * g->heads * g->heads;
+    a.part_k0 = ws; ws += rows * inner;
+    a.part_v0 = ws;
+    a.packed = 1;
+    const size_t nspm = (size_t)g->W * (J * g->heads + 4);
+    const size_t lds_qm = (nspm * 4 > 8 * 4096 ? nspm * 4 : 8 * 4096) + nspm * 4 + (8 * 64 + 16 * 8) * 4 + 8 * 2048;
+    const dim3 grid((unsigned)rows);
+    (void)hipFuncSetAttribute((const void*)s3_bwd_q_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qm);
+    hipLaunchKernelGGL((s3_bwd_q_mfma_kernel<false, true>), grid, dim3(512), lds_qm, stream, a);
+    LAUNCH_CHECK();
+    (void)hipFuncSetAttribute((const void*)s3_bwd_kv_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
+    hipLaunchKernelGGL((s3_bwd_kv_mfma_kernel<true, true>), grid, dim3(512), 8 * 8192, stream, a);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(s3_bwd_fin_kernel, dim3(g->B * (((int)inner + 63) / 64) + (g->heads * g->heads + 15) / 16), dim3(1024), 0, stream, a, g->dim_head);
+    LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
 

@@ -1025,11 +1025,14 @@ def sparse3dna_fwd(g, qkv, wth, rel_bias=None, o_f16=False):
     R = g.B * g.ntok
     if qkv.f16 is not None:            # fp16 operand form: single fp16 MFMAs; output hi + lo, or (o_f16) a bf16 copy + an fp16 copy
         q16, k16, v16 = (qkv.f16[:, i * inner:(i + 1) * inner] for i in range(3))
-        if o_f16:
-            o = BF(torch.empty((R, inner), dtype=torch.bfloat16, device=qkv.hi.device), None,
-                   torch.empty((R, inner), dtype=torch.float16, device=qkv.hi.device))
+        dev = qkv.f16.device
+        if o_f16 == 'only':            # ... or the fp16 copy alone (the block's backward runs on fp16 gradients: sparse3dna_bwd16)
+            o = BF(None, None, torch.empty((R, inner), dtype=torch.float16, device=dev))
+        elif o_f16:
+            o = BF(torch.empty((R, inner), dtype=torch.bfloat16, device=dev), None,
+                   torch.empty((R, inner), dtype=torch.float16, device=dev))
         else:
-            o = empty_bf((R, inner), qkv.hi.device, lo=True)
+            o = empty_bf((R, inner), dev, lo=True)
         check(L.amdnuwa_sparse3dna_fwd_f16(C.byref(g), _p(q16), _p(k16), _p(v16), qkv.f16.stride(0), _p(wth), _p(o.hi),
                                            _p(o.f16 if o_f16 else o.lo), inner, 1 if o_f16 else 0, _stream()), 'amdnuwa_sparse3dna_fwd_f16')
         return o
@@ -1038,6 +1041,31 @@ def sparse3dna_fwd(g, qkv, wth, rel_bias=None, o_f16=False):
     check(L.amdnuwa_sparse3dna_fwd(C.byref(g), _p(q.hi), _p(k.hi), _p(v.hi), _p(q.lo), _p(k.lo), _p(v.lo), qkv.hi.stride(0),
                                    _p(wth), _p(o.hi), _p(o.lo), inner, _stream()), 'amdnuwa_sparse3dna_fwd')
     return o
+
+
+def s3_bwd16_supported(g):
+    return bool(_lib.lib().amdnuwa_sparse3dna_bwd_f16_supported(C.byref(g)))
+
+
+@_family('s3', _s3_work('bwd'))
+def sparse3dna_bwd16(g, qkv16, wth, dO16, s2):
+    """fp16-gradient form: qkv16 fp16 [R, 3*inner] (the forward's operands), dO16 = fp16(S dO) [R, inner], s2 = device {S, 1 / S};
+    returns (dqkv fp16 [R, 3*inner] = fp16(S dqkv), dw_th fp32 [h, h])"""
+    L = _lib.lib()
+    g.rel_bias, g.d_rel_bias = None, None
+    inner = g.heads * g.dim_head
+    R = g.B * g.ntok
+    dev = qkv16.device
+    dqkv = torch.empty((R, 3 * inner), dtype=torch.float16, device=dev)
+    dwth = torch.empty((g.heads, g.heads), dtype=torch.float32, device=dev)
+    q, k, v = (qkv16[:, i * inner:(i + 1) * inner] for i in range(3))
+    dq, dk, dv = (dqkv[:, i * inner:(i + 1) * inner] for i in range(3))
+    nb = L.amdnuwa_sparse3dna_bwd_workspace_bytes(C.byref(g))
+    ws = workspace(nb, dev)
+    check(L.amdnuwa_sparse3dna_bwd_f16(C.byref(g), _p(q), _p(k), _p(v), qkv16.stride(0), _p(wth), _p(dO16), dO16.stride(0),
+                                       _p(dq), _p(dk), _p(dv), dqkv.stride(0), _p(dwth), 0, _p(s2), _p(ws), nb, _stream()),
+          'amdnuwa_sparse3dna_bwd_f16')
+    return dqkv, dwth
 
 
 @_family('s3', _s3_work('bwd'))

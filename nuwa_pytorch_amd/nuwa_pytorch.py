@@ -208,7 +208,8 @@ class SandwichNorm(nn.Module):
                 if isinstance(nxt_fn, FeedForward):
                     nxt_kind = ('ff', nxt_fn.net[3].weight.shape[1], (nxt_fn.net[0].weight, nxt_fn.net[3].weight))
                 elif isinstance(nxt_fn, Sparse3DNA) and nxt_fn.causal:
-                    nxt_kind = ('s3', nxt_fn.to_q.weight.shape[0], nxt_fn._meta(B, n, x.device)['geom'], (nxt_fn.to_q.weight, nxt_fn.to_kv.weight))
+                    nxt_kind = ('s3', nxt_fn.to_q.weight.shape[0], nxt_fn._meta(B, n, x.device)['geom'], (nxt_fn.to_q.weight, nxt_fn.to_kv.weight),
+                                nxt_fn.to_out.weight, nxt_fn.rel_pos_bias is not None)
                 elif isinstance(nxt_fn, Attention) and nxt_ctx is not None and nxt_fn._hip_ok(nxt_ctx.shape[1]):
                     nxt_kind = ('x', nxt_fn.to_q.weight.shape[0], K.x_geom(B, n, nxt_ctx.shape[1], nxt_fn.heads, nxt_fn.dim_head), {},
                                 (nxt_fn.to_q.weight, nxt_fn.to_out.weight))

@@ -165,8 +165,20 @@ class S3Inner:
                 out['qkv_16'] = torch.cat((wq.detach(), wkv.detach()), 0).to(torch.float16).contiguous()
             if K.mixed() and f16_weights_ok(wo):        # fp16 hi + lo pair for the two-MFMA to_out product
                 out['out_16'] = K.f16_pair(wo)
+            if K.bwd_f16('s') and 'qkv_16' in out and 'out_16' in out:    # transposes for the dgrad products of the fp16-gradient backward
+                out['qkvT_16'] = out['qkv_16'].t().contiguous()
+                out['outT_16'] = wo.detach().t().contiguous().to(torch.float16)
             return out
         return cache.get('s3', (wq, wkv, wo), build)
+
+    @staticmethod
+    def bwd16_ok(R, D, inner, g, ws=None, wo=None, rel=False):
+        """the fp16-gradient backward applies (class 's'): the fp16 projection + core + two-MFMA to_out of the forward apply, the band kernels take
+        the geometry without a relative-position bias, and the five backward products fit their fp16 kernels"""
+        return K.bwd_f16('s') and not rel and S3Inner.f16_proj_ok(R, D, inner, g, ws) and K.proj_f16x2('o') and \
+            K.gemm_nt_f16x2_ok(R, D, inner, out_bf16=False) and (wo is None or f16_weights_ok(wo)) and K.s3_bwd16_supported(g) and \
+            K.gemm_nt_f16ops_ok(R, 3 * inner, D, out_bf16=False, out_f16=True) and K.gemm_nt_f16ops_ok(R, inner, D, out_bf16=False, out_f16=True) and \
+            K.gemm_nt_f16ops_ok(R, D, 3 * inner, out_bf16=False, out_f16=True) and K.gemm_tn16_ok(R, D, inner) and K.gemm_tn16_ok(R, 3 * inner, D)
 
     @staticmethod
     def f16_proj_ok(R, D, inner, g, ws=None):
@@ -182,7 +194,14 @@ class S3Inner:
         g = meta['geom']
         rel = p[5].detach().contiguous() if len(p) > 5 else None          # [J, heads] relative-position bias (optional)
         # 'bf16x3-fwd': q / k / v leave the 3-MFMA projection as a bf16 copy (backward) + an fp16 copy, and the core runs single fp16 MFMAs
-        R, D = h.hi.shape
+        R, D, _ = K.bf_rows_cols(h)
+        if meta.get('bwd16') and 'qkvT_16' in W and rel is None:
+            # fp16-gradient backward: ONE (fp16) copy of h, of q / k / v and of the core's output
+            qkv = K.BF(None, None, K.gemm_nt_f16ops(h.f16, W['qkv_16'], out_f16=True))
+            o = K.sparse3dna_fwd(g, qkv, wth.detach().reshape(g.heads, g.heads).contiguous(), o_f16='only')
+            y = K.gemm_nt_f16x2(o.f16, W['out_16'], bias=bo.detach())
+            return y, (K.BF(None, None, h.f16), qkv, o)
+        assert h.hi is not None, 'a bf16 backward needs the bf16 copy of the LayerNorm output'
         if meta.get('shift') is None and 'qkv_16' in W and S3Inner.f16_proj_ok(R, D, g.heads * g.dim_head, g):
             h16 = h.f16 if h.f16 is not None else K.hilo_to_f16(h)
             qkv = K.gemm_nt_f16ops(h16, W['qkv_16'], out_bf16=True, copy_f16=True)
@@ -204,6 +223,17 @@ class S3Inner:
         rel = p[5].detach().contiguous() if len(p) > 5 else None
         g = meta['geom']
         inner = g.heads * g.dim_head
+        if isinstance(dy, K.G16):
+            # fp16-gradient backward: dy = fp16(S dy); every product on the fp16 MFMA against the fp16 copies the forward left
+            s2 = dy.s2
+            d_o = K.gemm_nt_f16ops(dy.t, W['outT_16'], out_f16=True)
+            dwo = torch.empty_like(wo)
+            K.gemm_tn16(dy.t, o.f16, dwo, s2)
+            dqkv, dwth = K.sparse3dna_bwd16(g, qkv.f16, wth.detach().reshape(g.heads, g.heads).contiguous(), d_o, s2)
+            dh = K.G16(K.gemm_nt_f16ops(dqkv, W['qkvT_16'], out_f16=True), s2)
+            dwqkv = torch.empty((3 * inner, wq.shape[1]), dtype=torch.float32, device=wq.device)
+            K.gemm_tn16(dqkv, h.f16, dwqkv, s2)
+            return dh, None, [dwqkv[:inner], dwqkv[inner:], dwth.reshape(wth.shape), dwo, None]
         d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
         dwo = torch.empty_like(wo)
         K.gemm_tn(dy, o, dwo)
@@ -632,6 +662,8 @@ def _block_bwd16(kind, R, D, p, meta):
         return False
     if kind == 'ff':
         return FFInner.bwd16_ok(R, D, _ru(p[1].shape[1], 32), p[1].shape[1], (p[0], p[1]))
+    if kind == 's3':
+        return S3Inner.bwd16_ok(R, D, p[0].shape[0], meta['geom'], (p[0], p[1]), p[3], len(p) > 5)
     return False
 
 
@@ -692,7 +724,8 @@ class SandwichBlockFn(Function):
             nxt16 = nk is not None and ((nk[0] == 'ff' and FFInner.f16_ok(B * n, D, _ru(nk[1], 32), nk[2])) or
                                         (nk[0] == 's3' and S3Inner.f16_proj_ok(B * n, D, nk[1], nk[2], nk[3])) or
                                         (nk[0] == 'x' and XInner.f16x2_ok(B * n, D, nk[1], nk[2], nk[3], nk[4])))
-            if nxt16 and nk[0] == 'ff' and FFInner.bwd16_ok(B * n, D, _ru(nk[1], 32), nk[1], nk[2]):
+            if nxt16 and ((nk[0] == 'ff' and FFInner.bwd16_ok(B * n, D, _ru(nk[1], 32), nk[1], nk[2])) or
+                          (nk[0] == 's3' and len(nk) > 5 and S3Inner.bwd16_ok(B * n, D, nk[1], nk[2], nk[3], nk[4], nk[5]))):
                 nxt16 = 'only'                    # the next block keeps ONE (fp16) copy of its LayerNorm input: fp16-gradient backward
             xo, m2, r2, hn, mn, rn = K.ln_post_pre_fwd(y, r2_, post_w.detach(), post_b.detach(), nxt[0].detach(),
                                                        nxt[1].detach(), next_shift=nxt[2], next_f16=nxt16)

@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 6, call g: default bench line + kernel stats of the tree with xattn6 forward + backward in the model path
+TAG=${TAG:-r06g}
+mkdir -p gpurun_out; export PYTHONUNBUFFERED=1 TMPDIR=/tmp
+R=$PWD
+timeout 900 python bench.py --no-cpu-baseline --no-tokenizer --no-parity > gpurun_out/${TAG}_bench_b128.log 2>&1; tail -n 1 gpurun_out/${TAG}_bench_b128.log > gpurun_out/${TAG}_bench_b128.json; cut -c1-300 gpurun_out/${TAG}_bench_b128.json
+OUT=$R/gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o bench -- python $R/bench.py --no-cpu-baseline --no-tokenizer --no-parity ) > gpurun_out/prof_${TAG}_run.log 2>&1
+python tools/rocpd_stats.py $OUT/bench_results.db > gpurun_out/${TAG}_bench_b128_kernel_stats.txt 2>&1; head -n 60 gpurun_out/${TAG}_bench_b128_kernel_stats.txt | cut -c1-180
+find $OUT -name "*.db" -size +40M -delete
