@@ -666,14 +666,32 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     };
 
     // ---- pass A: P' = W P -> Pm;  dP = W^T dP' (both mixes on the matrix pipe);  delta[h] = sum_j dP[h] P[h];
-    //      dW_th[g][h] += sum dP'[g] P[h] (the one block that stays on the VALU: its contraction runs over lanes)
-    float delta[NH], dth[NH][NH];
+    //      dW_th[g][h] += sum over (query, key) of dP'[g] P[h].  The contraction of that last one runs over a query's keys with the HEADS as
+    //      rows and columns, while the lanes hold (query, 8 keys) with the heads in separate registers: as 8 x 8 x 8 FMAs per lane and chunk it
+    //      was 512 of the ~1000 VALU instructions of a pass-A chunk.  Now on the matrix pipe too: the wave turns its bf16 dP' and P through a
+    //      private 4-KiB LDS tile ([4 heads][16 queries][4 key groups] of 16 bytes, written as the lanes hold them, read back with MFMA row
+    //      m = (query m >> 2 of a quad, head m & 3)), and one MFMA per query quad and pair of head halves adds
+    //      C[(qa, g)][(qb, h)] += sum over the chunk's 32 keys of dP'[g][qa] P[h][qb]: the entries with qa == qb are the wanted products, the rest
+    //      is ignored.  Four accumulator tiles (16 registers) for the whole kernel instead of 64 sums; 16 MFMAs + 32 LDS pieces per chunk.
+    float delta[NH];
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-        delta[h] = 0.f;
+    for (int h = 0; h < NH; ++h) delta[h] = 0.f;
+    f32x4 CT[2][2];
 #pragma unroll
-        for (int g = 0; g < NH; ++g) dth[g][h] = 0.f;
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) CT[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+    char* tb = smem + 2 * STAGE + 4096 + wave * 4096;
+    const int tw = c * 64 + ((g4 ^ ((c >> 1) & 3)) << 4);        // where lane (query c, key group g4) puts its 16 bytes inside a head's 1-KiB plane
+    int tro[4];                                                  // ... and where lane (row / column m = c, key group g4) finds its operand of query quad t
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int qq = 4 * t + (c >> 2);
+        tro[t] = (c & 3) * 1024 + qq * 64 + ((g4 ^ ((qq >> 1) & 3)) << 4);
     }
+    auto tput = [&](int hl, const float* v) {                    // 8 fp32 values of head-in-half hl -> bf16 -> the tile
+        *reinterpret_cast<uint4*>(tb + hl * 1024 + tw) = make_uint4(pack2_rne(v[0], v[1]), pack2_rne(v[2], v[3]), pack2_rne(v[4], v[5]), pack2_rne(v[6], v[7]));
+    };
     for (int ch = 0; ch < nfull; ++ch) {
         if (ch + 1 < nfull) { stage((ch + 1) & 1, ch + 1); VMCNT(16); }
         else VMCNT(0);
@@ -701,6 +719,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
             }
         }
         uint32_t bw[8][4];
+        bf16x8 TA[2][4];                                         // dP' of the two head halves as MFMA row operands, one per query quad
 #pragma unroll
         for (int gp = 0; gp < 4; ++gp) {
             float d0[8], d1[8];
@@ -708,12 +727,22 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
             dpp(vbase, 2 * gp + 1, d1);
 #pragma unroll
             for (int e = 0; e < 8; ++e) bw[e][gp] = pack2_rne(d0[e], d1[e]);
+            tput((2 * gp) & 3, d0);
+            tput((2 * gp + 1) & 3, d1);
+            if (gp & 1) {
 #pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                float a0 = dth[2 * gp][h], a1 = dth[2 * gp + 1][h];
+                for (int t = 0; t < 4; ++t) TA[gp >> 1][t] = lds16(tb + tro[t]);
+            }
+        }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { a0 = fmaf(d0[e], P[h][e], a0); a1 = fmaf(d1[e], P[h][e], a1); }
-                dth[2 * gp][h] = a0; dth[2 * gp + 1][h] = a1;
+        for (int hh = 0; hh < 2; ++hh) {                         // P of head half hh as the column operand
+#pragma unroll
+            for (int hl = 0; hl < 4; ++hl) tput(hl, P[4 * hh + hl]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 tbv = lds16(tb + tro[t]);
+                CT[0][hh] = MFMAB(TA[0][t], tbv, CT[0][hh]);
+                CT[1][hh] = MFMAB(TA[1][t], tbv, CT[1][hh]);
             }
         }
 #pragma unroll
@@ -768,11 +797,35 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
             for (int h = 0; h < NH; ++h) { pm = fmaf(wsh[g * NH + h], bf2f(f2bf(PN[h])), pm); dp = fmaf(wtsh[g * NH + h], bf2f(f2bf(dN[h])), dp); }
             PmN[g] = pm; dPN[g] = dp;                            // dPN[h = g] = sum_g' W[g'][h] dP'_null[g']  (wtsh row h)
         }
-        if (g4 == 0) {                                           // one lane per query carries the null key's shares
+        {   // dW_th share of the null key through the same tile and tiles: a "chunk" whose only key sits in slot 0 of key group 0
+            bf16x8 TN[2][4];
+            const bool one = g4 == 0 && qok;
 #pragma unroll
-            for (int g = 0; g < NH; ++g)
+            for (int gh = 0; gh < 2; ++gh) {
 #pragma unroll
-                for (int h = 0; h < NH; ++h) dth[g][h] = fmaf(dN[g], PN[h], dth[g][h]);
+                for (int hl = 0; hl < 4; ++hl) {
+                    const float v8[8] = {one ? dN[4 * gh + hl] : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    tput(hl, v8);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) TN[gh][t] = lds16(tb + tro[t]);
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                for (int hl = 0; hl < 4; ++hl) {
+                    const float v8[8] = {one ? PN[4 * hh + hl] : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    tput(hl, v8);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const bf16x8 tbv = lds16(tb + tro[t]);
+                    CT[0][hh] = MFMAB(TN[0][t], tbv, CT[0][hh]);
+                    CT[1][hh] = MFMAB(TN[1][t], tbv, CT[1][hh]);
+                }
+            }
+        }
+        if (g4 == 0) {                                           // one lane per query carries the null key's share of delta
 #pragma unroll
             for (int h = 0; h < NH; ++h) delta[h] = fmaf(dPN[h], PN[h], delta[h]);
         }
@@ -789,13 +842,20 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
         delta[h] += __shfl_xor(delta[h], 32, 64);
     }
     // dW_th partial of this workgroup (fixed order over the 4 waves): lane l ends up with the wave's sum of entry l = g * NH + h
+    // (a tile entry is a wanted product where the row's and the column's query agree: lanes with c >> 2 == g4; rows 4 g4 + r = (query g4, head
+    //  r of the row half), column c = (query c >> 2, head c & 3 of the column half).  Sum over the wave's lanes with equal c & 3 in a fixed order.)
     {
-        float tv[NH * NH];
+        const bool diag = (c >> 2) == g4;
 #pragma unroll
-        for (int g = 0; g < NH; ++g)
+        for (int gh = 0; gh < 2; ++gh)
 #pragma unroll
-            for (int h = 0; h < NH; ++h) tv[g * NH + h] = qok ? dth[g][h] : 0.f;
-        thsh[wave][lane] = wave_sum64_transposed(tv, lane);
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = diag ? CT[gh][hh][r] : 0.f;
+                    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                    if (lane < 4) thsh[wave][(4 * gh + r) * NH + 4 * hh + lane] = v;
+                }
     }
     __syncthreads();
     if (tid < NH * NH) a.part_th[(size_t)bid * NH * NH + tid] = ((thsh[0][tid] + thsh[1][tid]) + thsh[2][tid]) + thsh[3][tid];
@@ -995,8 +1055,9 @@ extern "C" int amdnuwa_xattn6_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.q = q; a.ldq = ldq; a.dO = dO; a.lddo = lddo; a.K6 = (const char*)kv->K6; a.V6 = (const char*)kv->V6; a.vbits = kv->vbits;
     a.null_k = null_k; a.null_v = null_v; a.wth = w_th; a.stats = stats; a.dS = dS; a.Pm = Pm; a.dq = dq; a.lddq = lddq; a.part_th = part_th;
     a.B = g->B; a.n = g->n; a.nch = g->JP / 32; a.T = g->T; a.scale = g->scale;
-    (void)hipFuncSetAttribute((const void*)xattn6_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 4096);
-    hipLaunchKernelGGL(xattn6_bwd_kernel, dim3(g->B * ((g->n + 63) / 64)), dim3(256), 2 * STAGE + 4096, stream, a);
+    // LDS: the two-stage K + V ring, the null key / value rows, one 4-KiB turning tile per wave (the dW_th products)
+    (void)hipFuncSetAttribute((const void*)xattn6_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 4096 + 4 * 4096);
+    hipLaunchKernelGGL(xattn6_bwd_kernel, dim3(g->B * ((g->n + 63) / 64)), dim3(256), 2 * STAGE + 4096 + 4 * 4096, stream, a);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
