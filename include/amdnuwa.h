@@ -33,7 +33,8 @@ int amdnuwa_abi_version(void);                 /* bumps when any signature or do
                                                 * amdnuwa_xattn_unpack's flag bit 1, chunk-permuted dS / Pm columns of amdnuwa_xattn2_bwd;
                                                 * 14: amdnuwa_linear_ce_x3 added; 15: the two-MFMA products -- amdnuwa_gemm_desc.ab_f16 with Blo, amdnuwa_gemm_nt_f16x2_supported,
                                                 *     o_lo_f16 on the two fp16 forward cores; 16: the fp16-gradient backward; 17: amdnuwa_gemm_desc.a_chunk32, amdnuwa_gemm_tn_chunked_a_supported,
-                                                *     amdnuwa_xattn2_bwd_ex, AMDNUWA_LN_RESID_MINUS, tuning key 25; 18: the amdnuwa_xattn6_* family; 19: amdnuwa_sparse3dna_bwd_f16, o == NULL in amdnuwa_sparse3dna_fwd_f16) */
+                                                *     amdnuwa_xattn2_bwd_ex, AMDNUWA_LN_RESID_MINUS, tuning key 25; 18: the amdnuwa_xattn6_* family; 19: amdnuwa_sparse3dna_bwd_f16, amdnuwa_xattn6_bwd_f16, amdnuwa_xattn6_pack_bwd_f16, o == NULL in the two fp16 forward cores,
+                                                *     ab_f16 on the whole-M TN kernel with alpha_dev in its direct epilogue, c_f16 on the two-MFMA NT product) */
 const char* amdnuwa_error_string(int code);
 /* runtime tuning knobs (A/B benchmarking only; 0 = the library's auto policy everywhere):
  *   key 0  NT GEMM variant: 1 direct-to-LDS BK 64, 2 direct-to-LDS BK 32, 3 / 4 256x256 tile with a 4- / 3-stage DMA ring,
@@ -526,6 +527,16 @@ size_t amdnuwa_xattn6_bwd_workspace_bytes(const amdnuwa_xattn_geom* g);
 int amdnuwa_xattn6_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo, const amdnuwa_xattn6_kv* kv,
                        const float* null_k, const float* null_v, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm, uint16_t* dq, int lddq, float* part_th,
                        size_t part_bytes, amdnuwa_stream stream);
+/* ABI 19, the fp16-gradient form (block class 'x' of the 'bf16x3-fwd' mode): images from the FP16 copy of to_kv(context)
+ * (amdnuwa_xattn6_pack_bwd_f16; the null key / value rounded to fp16), q = the fp16 copy the forward read, dO = fp16(S dO); dq and dS leave
+ * as fp16(S value), saturating and counted by amdnuwa_f16_sat_count, Pm as fp16, and the part_th partials carry the factor S.  Every MFMA is
+ * the fp16 one.  The dK / dV products over dS / Pm then run amdnuwa_gemm_tn with ab_f16 + a_chunk32 and alpha_dev = 1 / S.
+ * amdnuwa_xattn6_fwd accepts o == NULL together with o_lo_f16 (the fp16 copy is then the only output). */
+int amdnuwa_xattn6_pack_bwd_f16(const amdnuwa_xattn_geom* g, const uint16_t* kv_f16, int ldkv, const float* null_k, const float* null_v,
+                                const uint8_t* context_mask, const amdnuwa_xattn6_kv* out, amdnuwa_stream stream);
+int amdnuwa_xattn6_bwd_f16(const amdnuwa_xattn_geom* g, const uint16_t* q_f16, int ldq, const uint16_t* dO_f16, int lddo, const amdnuwa_xattn6_kv* kv,
+                           const float* null_k, const float* null_v, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm, uint16_t* dq,
+                           int lddq, float* part_th, size_t part_bytes, amdnuwa_stream stream);
 /* Text cross-attention (Attention.forward with context, np.py:339-378) for ONE query row per sample (g->n must be 1):
  * q [B, ldq] unscaled, keys / values as packed by amdnuwa_xattn_pack (Kp / Vp images and the valid map), o [B, ldo]. */
 int amdnuwa_xattn_decode(const amdnuwa_xattn_geom* g, const uint16_t* q, const uint16_t* q_lo, int ldq,

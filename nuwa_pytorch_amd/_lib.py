@@ -136,6 +136,8 @@ SIGNATURES = {
     'amdnuwa_xattn6_pack_bwd': (I, [XG, P, I, P, P, P, X6, P]),
     'amdnuwa_xattn6_bwd_workspace_bytes': (SZ, [XG]),
     'amdnuwa_xattn6_bwd': (I, [XG, P, I, P, I, X6, P, P, P, P, P, P, P, I, P, SZ, P]),
+    'amdnuwa_xattn6_pack_bwd_f16': (I, [XG, P, I, P, P, P, X6, P]),
+    'amdnuwa_xattn6_bwd_f16': (I, [XG, P, I, P, I, X6, P, P, P, P, P, P, P, I, P, SZ, P]),
     'amdnuwa_xattn2_bwd_rc_supported': (I, [XG]),
     'amdnuwa_xattn2_bwd_rc_stats_bytes': (SZ, [XG]),
     'amdnuwa_xattn2_bwd_rc': (I, [XG, P, I, P, I, XK, P, P, P, I, P, SZ, P, SZ, P, P, P]),

@@ -46,6 +46,7 @@ struct GemmArgs {
     int skew;               // start-phase step of the first-generation workgroups in s_sleep(8) units (tuning key 14; 0 = off)
     int c_f16;              // F16 rings, EPI 1: C / the GEGLU-backward output C2 are fp16 (saturating), not bf16 (the fp16-gradient backward)
     int a_chunk;            // TN whole-M kernel: A is stored as planes of 32 columns, [M / 32][K token rows][32] (amdnuwa_gemm_desc.a_chunk32)
+    const float* alpha_dev; // TN whole-M kernel writing C directly: a DEVICE factor on top of alpha (1 / S of the fp16-gradient backward), or NULL
 };
 
 __device__ __forceinline__ long long boff(const GemmArgs& p, long long z, long long s, long long s_in) {
@@ -1554,7 +1555,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256x3_kernel(GemmArgs p) {
             for (int k = 0; k < 8; ++k) {
                 const int e0 = 2 * k, e1 = 2 * k + 1;
                 const float v0 = acc[i][e0 >> 2][e0 & 3] * p.alpha + bias16[e0], v1 = acc[i][e1 >> 2][e1 & 3] * p.alpha + bias16[e1];
-                hp[k] = pack2_rne(v0, v1);
+                hp[k] = p.c_f16 ? pack2_f16_sat(v0, v1) : pack2_rne(v0, v1);      // (c_f16, wave-uniform: C is ONE fp16 output, no second copy)
                 lp[k] = p.lo_f16 ? pack2_f16_sat(v0, v1) : pack2_rne(v0 - lo_f(hp[k]), v1 - hi_f(hp[k]));
             }
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
@@ -2090,7 +2091,7 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmArgs p, float* __
 // the four waves (frag f -> wave f & 3), B read once.  Same fragment reads, same per-element order of accumulation (token rows ascending
 // in steps of 32) as gemm_tn_glds_kernel: bit-identical results.  Every tile t < MT holds a live column (host: (MT - 1) * 128 < M), so
 // every DMA instruction has an active lane and the vmcnt arithmetic is exact.  b = 128: 391 us against 425 + a 20-us reduction (five stages: 423).
-template <int MT, int NS>
+template <int MT, int NS, bool F16 = false>     // F16: both operands hold fp16 values (the fp16-gradient backward of the cross attention)
 __global__ __launch_bounds__(256) void gemm_tn_wm_kernel(GemmArgs p, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STG = (MT + 1) * TN_TILE_BYTES;
@@ -2160,16 +2161,16 @@ __global__ __launch_bounds__(256) void gemm_tn_wm_kernel(GemmArgs p, float* __re
             if (f * 16 >= N1) continue;                                        // (wave-uniform)
             const bf16x8 af = tn_frag(base + (f >> 3) * TN_TILE_BYTES, (f & 7) * 16, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<F16>(bfr[j], af, acc[i][j]);
         }
     }
     const int fr = lane & 15, fg = lane >> 4;
-    // one split, beta = 0, no device scale (host: p.nsplit = 0): alpha * sum goes straight to C -- what splitk_reduce_kernel would have
+    // one split, beta = 0 (host: p.nsplit = 0): alpha * sum goes straight to C -- what splitk_reduce_kernel would have
     // written from the one partial (0 + x = x), without the round trip
     const bool direct = p.nsplit == 0;
     float* P = direct ? reinterpret_cast<float*>(p.C) + boff(p, bz, p.sC, p.sC_in) : partial + ((size_t)bz * gridDim.y + z) * (size_t)N1 * N2;
     const int ldp = direct ? p.ldc : N2;
-    const float al = direct ? p.alpha : 1.f;
+    const float al = direct ? p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.f) : 1.f;
     const bool v4 = (N2 & 3) == 0 && (ldp & 3) == 0 && (reinterpret_cast<size_t>(P) & 15) == 0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -2887,6 +2888,7 @@ extern "C" int amdnuwa_gemm_nt_f16x2_supported(const amdnuwa_gemm_desc* d) {
     if (!d || !d->A || !d->B || !d->Blo || !d->C || d->Alo || d->shift_ntok > 0 || d->batch > 1 || d->C2 || d->geglu_u) return 0;
     if (d->K % 32 || d->lda % 8 || d->ldb % 8 || d->M <= 4 * ROWS_MR) return 0;
     if (d->c_is_bf16 ? (d->N % 8 || d->ldc % 8) : d->Clo != nullptr) return 0;
+    if (d->c_f16 && (!d->c_is_bf16 || d->Clo)) return 0;          // one fp16 output: a 16-bit C, no second copy
     const int v = g_amdnuwa_tuning[0];
     return (v == 0 || v == 7) ? 1 : 0;
 }
@@ -2929,6 +2931,7 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         q.tiles_m = (d->M + 255) / 256; q.tiles_n = (d->N + 255) / 256;
         q.dbg = g_amdnuwa_tuning[7];
         q.lo_f16 = d->Clo ? 1 : 0;             // the second copy of a bf16 output is its fp16 rendering (the next fp16 consumer's operand)
+        q.c_f16 = d->c_f16 ? 1 : 0;            // ... or C itself is the fp16 rendering and there is no other copy (fp16-gradient backward of the block)
         q.skew = nt_skew((long long)q.tiles_m * q.tiles_n);
         dim3 g3(q.tiles_m * q.tiles_n, 1), b3(512);
         const size_t l3 = (size_t)2 * 3 * 256 * 32 * 2;
@@ -3255,7 +3258,7 @@ static bool tn_w4k_ok(const amdnuwa_gemm_desc* d) {
 }
 // the whole-M narrow kernel (gemm_tn_wm_kernel): batched, N <= 64, 128 < M <= 384 (tuning key 25 = 1 keeps the 128-row tiles).  Returns MT or 0.
 static int tn_whole_m(const amdnuwa_gemm_desc* d) {
-    if (g_amdnuwa_tuning[25] == 1 || d->Alo || d->shift_ntok > 0 || d->ab_f16 || (long long)d->K >= (1LL << 31)) return 0;
+    if (g_amdnuwa_tuning[25] == 1 || d->Alo || d->shift_ntok > 0 || (long long)d->K >= (1LL << 31)) return 0;
     const int v = g_amdnuwa_tuning[6];
     if ((v != 0 && v != 2) || d->N > 64 || d->N < 1 || d->M <= 128 || d->M > 384 || d->batch < 2) return 0;
     return (d->M + 127) / 128;
@@ -3282,9 +3285,10 @@ extern "C" int amdnuwa_gemm_tn_chunked_a_supported(const amdnuwa_gemm_desc* d) {
     return tn_variant(d) == 2 && tn_whole_m(d) != 0 ? 1 : 0;
 }
 
-// fp16 operands (d->ab_f16): the four-wave kernel only
+// fp16 operands (d->ab_f16): the four-wave kernel and the whole-M narrow kernel only
 extern "C" int amdnuwa_gemm_tn_f16_supported(const amdnuwa_gemm_desc* d) {
     if (!d || d->Alo || d->Blo || d->shift_ntok > 0 || d->lda % 8 || d->ldb % 8) return 0;
+    if (tn_variant(d) == 2) return tn_whole_m(d) != 0 ? 1 : 0;
     return tn_variant(d) == 3 && tn_w4k_ok(d) ? 1 : 0;
 }
 
@@ -3304,7 +3308,7 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
     if (d->ab_f16 && !amdnuwa_gemm_tn_f16_supported(d)) return AMDNUWA_ERR_UNSUPPORTED;
     if (d->a_chunk32 && !amdnuwa_gemm_tn_chunked_a_supported(d)) return AMDNUWA_ERR_UNSUPPORTED;
     GemmArgs p;
-    p.c_f16 = 0; p.a_chunk = d->a_chunk32 ? 1 : 0;
+    p.c_f16 = 0; p.a_chunk = d->a_chunk32 ? 1 : 0; p.alpha_dev = d->alpha_dev;
     p.A = (const bf16_t*)d->A; p.Alo = (const bf16_t*)d->Alo; p.sA = d->strideA; p.lda = d->lda;
     p.B = (const bf16_t*)d->B; p.Blo = (const bf16_t*)d->Blo; p.sB = d->strideB; p.ldb = d->ldb;
     p.C = d->C; p.Clo = nullptr; p.sC = d->strideC; p.ldc = d->ldc;
@@ -3356,17 +3360,17 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
     if (tnv == 2 && tn_whole_m(d) != 0) {
         const int mt = tn_whole_m(d);
         const dim3 gw(batch, splits);
-        const bool direct = splits == 1 && d->beta == 0.f && !d->alpha_dev && g_amdnuwa_tuning[25] != 2;
+        const bool direct = splits == 1 && d->beta == 0.f && g_amdnuwa_tuning[25] != 2;      // (a device factor rides in the direct epilogue too)
         p.nsplit = direct ? 0 : splits;
-        if (mt == 3) {
-            const size_t l = (size_t)4 * 4 * TN_TILE_BYTES;
-            (void)hipFuncSetAttribute((const void*)gemm_tn_wm_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
-            hipLaunchKernelGGL((gemm_tn_wm_kernel<3, 4>), gw, block, l, stream, p, part);
-        } else {
-            const size_t l = (size_t)4 * 3 * TN_TILE_BYTES;
-            (void)hipFuncSetAttribute((const void*)gemm_tn_wm_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
-            hipLaunchKernelGGL((gemm_tn_wm_kernel<2, 4>), gw, block, l, stream, p, part);
-        }
+#define TNWM(MT_, F_)                                                                                                    \
+    do {                                                                                                                 \
+        const size_t l = (size_t)4 * (MT_ + 1) * TN_TILE_BYTES;                                                          \
+        (void)hipFuncSetAttribute((const void*)gemm_tn_wm_kernel<MT_, 4, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
+        hipLaunchKernelGGL((gemm_tn_wm_kernel<MT_, 4, F_>), gw, block, l, stream, p, part);                               \
+    } while (0)
+        if (mt == 3) { if (d->ab_f16) TNWM(3, true); else TNWM(3, false); }
+        else         { if (d->ab_f16) TNWM(2, true); else TNWM(2, false); }
+#undef TNWM
     } else
     if (tnv == 2) {
         const size_t gl = (size_t)2 * 2 * TN_TILE_BYTES;

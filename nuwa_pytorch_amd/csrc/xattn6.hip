@@ -454,8 +454,10 @@ __global__ __launch_bounds__(512, 2) void xattn6_fwd_kernel(X6Args a) {
                         const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
                         x = r[0]; y = r[1];
                     };
-                    swap(x0, y0); swap(x1, y1);
-                    if (qok) *reinterpret_cast<uint4*>(a.o + go) = make_uint4(x0, x1, y0, y1);
+                    if (a.o) {                                    // (o == NULL: the fp16 copy alone -- the fp16-gradient backward reads nothing else)
+                        swap(x0, y0); swap(x1, y1);
+                        if (qok) *reinterpret_cast<uint4*>(a.o + go) = make_uint4(x0, x1, y0, y1);
+                    }
                     if (a.ol) {
                         swap(lx0, ly0); swap(lx1, ly1);
                         if (qok) *reinterpret_cast<uint4*>(a.ol + go) = make_uint4(lx0, lx1, ly0, ly1);
@@ -521,6 +523,8 @@ __global__ __launch_bounds__(256) void xattn6_pack_kernel(const uint16_t* __rest
 // positions 0..T-1 = the context keys (chunk-aligned), position T = the null key (amdnuwa_xattn_unpack flag bit 2 reads dKp / dVp that way).
 // With T % 32 == 0 the null key would be alone in the last chunk: that chunk is no matrix iteration but a rank-one term per pass.
 // ------------------------------------------------------------------------------------------------
+// a value rounded as an image row of the backward holds it: bf16, or (F16) fp16
+template <bool F16> __device__ __forceinline__ float rnd16(float v) { return F16 ? (float)(_Float16)v : bf2f(f2bf(v)); }
 struct X6BArgs {
     const uint16_t* q; int ldq;
     const uint16_t* dO; int lddo;
@@ -536,9 +540,12 @@ struct X6BArgs {
     float scale;
 };
 constexpr float MASK_BIAS_RAW = -400000.f;   // unscaled score of a masked key (x scale * log2 e = -72 000 in the log2 domain)
-#define MFMAB(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+// (G16, a template flag of everything below: the fp16-gradient form -- q / dO / the images hold fp16 values, dO = fp16(S dO), every MFMA the fp16
+//  one, Pm / dS / dq leave as fp16 -- dS and dq saturating and counted; amdnuwa_xattn6_bwd_f16)
+#define MFMAB(a, b, c) mfma16<G16>(a, b, c)
 
 struct MixA { bf16x8 hi[2], lo[2]; };
+template <bool G16>
 __device__ __forceinline__ MixA mix_operand_lds(const float* wsrc, int lane) {      // (xattn2.hip, mix_operand)
     MixA a;
     const int m = lane & 15;
@@ -550,17 +557,18 @@ __device__ __forceinline__ MixA mix_operand_lds(const float* wsrc, int lane) {  
         uint32_t ph[4], pl[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            ph[t] = pack2_rne(w[2 * t], w[2 * t + 1]);
-            pl[t] = pack2_rne(w[2 * t] - lo_f(ph[t]), w[2 * t + 1] - hi_f(ph[t]));
+            ph[t] = pack2_t<G16>(w[2 * t], w[2 * t + 1]);
+            pl[t] = pack2_t<G16>(w[2 * t] - lo_t<G16>(ph[t]), w[2 * t + 1] - hi_t<G16>(ph[t]));
         }
         a.hi[Q] = __builtin_bit_cast(bf16x8, on ? make_uint4(ph[0], ph[1], ph[2], ph[3]) : make_uint4(0, 0, 0, 0));
         a.lo[Q] = __builtin_bit_cast(bf16x8, on ? make_uint4(pl[0], pl[1], pl[2], pl[3]) : make_uint4(0, 0, 0, 0));
     }
     return a;
 }
+template <bool G16>
 __device__ __forceinline__ bf16x8 pack_heads8(const float (&v)[NH][8], int e) {
-    return __builtin_bit_cast(bf16x8, make_uint4(pack2_rne(v[0][e], v[1][e]), pack2_rne(v[2][e], v[3][e]),
-                                                 pack2_rne(v[4][e], v[5][e]), pack2_rne(v[6][e], v[7][e])));
+    return __builtin_bit_cast(bf16x8, make_uint4(pack2_t<G16>(v[0][e], v[1][e]), pack2_t<G16>(v[2][e], v[3][e]),
+                                                 pack2_t<G16>(v[4][e], v[5][e]), pack2_t<G16>(v[6][e], v[7][e])));
 }
 #define MIXB(A_, Q_, B_) MFMAB((A_).lo[Q_], B_, MFMAB((A_).hi[Q_], B_, (f32x4{0.f, 0.f, 0.f, 0.f})))
 // K^T (a [key][d] tile read transposed): lane (c, g4) gets tile[kb*16 + 4*g4 + j][db*16 + c], j = 0..3, for kb = 0, 1
@@ -574,6 +582,7 @@ __device__ __forceinline__ bf16x8 lds_tr6(const char* base, int h, int db, int c
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <bool G16>
 __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned sm0 = lds_addr_of(smem);
@@ -593,7 +602,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     if (tid < NH * NH) { const float v = a.wth[tid]; wsh[tid] = v; wtsh[(tid & 7) * 8 + (tid >> 3)] = v; }
     float* nks = reinterpret_cast<float*>(smem + 2 * STAGE);     // the null key / value, rounded to bf16 as an image row is: 2 x 2 KiB behind the ring
     float* nvs = nks + NH * DH;
-    for (int e = tid; e < NH * DH; e += 256) { nks[e] = bf2f(f2bf(a.null_k[e])); nvs[e] = bf2f(f2bf(a.null_v[e])); }
+    for (int e = tid; e < NH * DH; e += 256) { nks[e] = rnd16<G16>(a.null_k[e]); nvs[e] = rnd16<G16>(a.null_v[e]); }
     const uint32_t wv = lane < nch ? a.vbits[(size_t)b * nch + lane] : 0u;
     // T % 32 == 0: the null key (position T) is alone in the last chunk -- that chunk is not a matrix iteration but a rank-one term
     const bool rank1 = (a.T & 31) == 0;
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
         }
     };
     stage(0, 0);
-    const MixA AW = mix_operand_lds(wsh, lane), AWT = mix_operand_lds(wtsh, lane);
+    const MixA AW = mix_operand_lds<G16>(wsh, lane), AWT = mix_operand_lds<G16>(wtsh, lane);
     const float c1 = a.scale * 1.4426950408889634f;
     bf16x8 qf[NH][KS], df[NH][KS];
     float nb[NH];
@@ -690,7 +699,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
         tro[t] = (c & 3) * 1024 + qq * 64 + ((g4 ^ ((qq >> 1) & 3)) << 4);
     }
     auto tput = [&](int hl, const float* v) {                    // 8 fp32 values of head-in-half hl -> bf16 -> the tile
-        *reinterpret_cast<uint4*>(tb + hl * 1024 + tw) = make_uint4(pack2_rne(v[0], v[1]), pack2_rne(v[2], v[3]), pack2_rne(v[4], v[5]), pack2_rne(v[6], v[7]));
+        *reinterpret_cast<uint4*>(tb + hl * 1024 + tw) = make_uint4(pack2_t<G16>(v[0], v[1]), pack2_t<G16>(v[2], v[3]), pack2_t<G16>(v[4], v[5]), pack2_t<G16>(v[6], v[7]));
     };
     for (int ch = 0; ch < nfull; ++ch) {
         if (ch + 1 < nfull) { stage((ch + 1) & 1, ch + 1); VMCNT(16); }
@@ -708,13 +717,13 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
         for (int Q = 0; Q < 2; ++Q) {
             f32x4 D[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) D[e] = MIXB(AW, Q, pack_heads8(P, e));
+            for (int e = 0; e < 8; ++e) D[e] = MIXB(AW, Q, pack_heads8<G16>(P, e));
             if (st) {
 #pragma unroll
                 for (int rp = 0; rp < 4; ++rp) {
                     uint16_t* dst = a.Pm + ((size_t)b * NH + 4 * Q + rp) * hplane + ((size_t)ch * a.n + qi) * 32 + g4 * 8;
-                    *reinterpret_cast<uint4*>(dst) = make_uint4(pack2_rne(D[0][rp], D[1][rp]), pack2_rne(D[2][rp], D[3][rp]),
-                                                                pack2_rne(D[4][rp], D[5][rp]), pack2_rne(D[6][rp], D[7][rp]));
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(pack2_t<G16>(D[0][rp], D[1][rp]), pack2_t<G16>(D[2][rp], D[3][rp]),
+                                                                pack2_t<G16>(D[4][rp], D[5][rp]), pack2_t<G16>(D[6][rp], D[7][rp]));
                 }
             }
         }
@@ -726,7 +735,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
             dpp(vbase, 2 * gp, d0);
             dpp(vbase, 2 * gp + 1, d1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bw[e][gp] = pack2_rne(d0[e], d1[e]);
+            for (int e = 0; e < 8; ++e) bw[e][gp] = pack2_t<G16>(d0[e], d1[e]);
             tput((2 * gp) & 3, d0);
             tput((2 * gp + 1) & 3, d1);
             if (gp & 1) {
@@ -780,8 +789,8 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
                                                                      //  static LDS array trips the compiler's register-class check here)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    sa = fmaf(lo_f(wq[t]), nks[o8 + 2 * t], sa); sa = fmaf(hi_f(wq[t]), nks[o8 + 2 * t + 1], sa);
-                    da = fmaf(lo_f(wd[t]), nvs[o8 + 2 * t], da); da = fmaf(hi_f(wd[t]), nvs[o8 + 2 * t + 1], da);
+                    sa = fmaf(lo_t<G16>(wq[t]), nks[o8 + 2 * t], sa); sa = fmaf(hi_t<G16>(wq[t]), nks[o8 + 2 * t + 1], sa);
+                    da = fmaf(lo_t<G16>(wd[t]), nvs[o8 + 2 * t], da); da = fmaf(hi_t<G16>(wd[t]), nvs[o8 + 2 * t + 1], da);
                 }
             }
             sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
@@ -794,7 +803,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
         for (int g = 0; g < NH; ++g) {                           // (operands rounded to bf16 as the matrix-pipe mixes round theirs)
             float pm = 0.f, dp = 0.f;
 #pragma unroll
-            for (int h = 0; h < NH; ++h) { pm = fmaf(wsh[g * NH + h], bf2f(f2bf(PN[h])), pm); dp = fmaf(wtsh[g * NH + h], bf2f(f2bf(dN[h])), dp); }
+            for (int h = 0; h < NH; ++h) { pm = fmaf(wsh[g * NH + h], rnd16<G16>(PN[h]), pm); dp = fmaf(wtsh[g * NH + h], rnd16<G16>(dN[h]), dp); }
             PmN[g] = pm; dPN[g] = dp;                            // dPN[h = g] = sum_g' W[g'][h] dP'_null[g']  (wtsh row h)
         }
         {   // dW_th share of the null key through the same tile and tiles: a "chunk" whose only key sits in slot 0 of key group 0
@@ -833,7 +842,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
         uint16_t* pmn = a.Pm + ((size_t)(nch - 1) * a.n + qi) * 32;
 #pragma unroll
         for (int g = 0; g < NH; ++g)
-            if (g4 == 0 && qok) *reinterpret_cast<uint4*>(pmn + ((size_t)b * NH + g) * hplane) = make_uint4(pack2_rne(PmN[g], 0.f), 0u, 0u, 0u);
+            if (g4 == 0 && qok) *reinterpret_cast<uint4*>(pmn + ((size_t)b * NH + g) * hplane) = make_uint4(pack2_t<G16>(PmN[g], 0.f), 0u, 0u, 0u);
     }
     // a query's keys are spread over the 4 lane groups
 #pragma unroll
@@ -861,6 +870,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     if (tid < NH * NH) a.part_th[(size_t)bid * NH * NH + tid] = ((thsh[0][tid] + thsh[1][tid]) + thsh[2][tid]) + thsh[3][tid];
 
     // ---- pass B: ds[h] = P[h] (dP[h] - delta[h]) -> dS;  dq^T[h] += K^T[h] ds^T[h]
+    float samax = 0.f;                                           // G16: largest magnitude handed to a saturating fp16 store (amdnuwa_f16_sat_count)
     f32x4 dQ[NH][DB];
 #pragma unroll
     for (int h = 0; h < NH; ++h)
@@ -883,7 +893,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
                 dpp(vbase, 2 * gp, d0);
                 dpp(vbase, 2 * gp + 1, d1);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bw[e][gp] = pack2_rne(d0[e], d1[e]);
+                for (int e = 0; e < 8; ++e) bw[e][gp] = pack2_t<G16>(d0[e], d1[e]);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) bmD[e] = __builtin_bit_cast(bf16x8, make_uint4(bw[e][0], bw[e][1], bw[e][2], bw[e][3]));
@@ -901,7 +911,8 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
                 probs(kbase, h, b0, b1, P);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ds[e] = P[e] * (D[e][rp] - delta[h]);
-                const uint4 pk = make_uint4(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]), pack2_rne(ds[4], ds[5]), pack2_rne(ds[6], ds[7]));
+                const uint4 pk = G16 ? make_uint4(pack2_f16_sat_n(ds[0], ds[1], samax), pack2_f16_sat_n(ds[2], ds[3], samax), pack2_f16_sat_n(ds[4], ds[5], samax), pack2_f16_sat_n(ds[6], ds[7], samax))
+                                     : make_uint4(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]), pack2_rne(ds[4], ds[5]), pack2_rne(ds[6], ds[7]));
                 if (st) *reinterpret_cast<uint4*>(a.dS + ((size_t)b * NH + h) * hplane + ((size_t)ch * a.n + qi) * 32 + g4 * 8) = pk;
                 const bf16x8 sf = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
@@ -913,9 +924,9 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     if (rank1) {                                                 // pass B part: ds_null -> dS, dq += ds_null k_null
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            const uint32_t dsb = pack2_rne(PN[h] * (dPN[h] - delta[h]), 0.f);
+            const uint32_t dsb = G16 ? pack2_f16_sat_n(PN[h] * (dPN[h] - delta[h]), 0.f, samax) : pack2_rne(PN[h] * (dPN[h] - delta[h]), 0.f);
             if (g4 == 0 && qok) *reinterpret_cast<uint4*>(a.dS + ((size_t)b * NH + h) * hplane + ((size_t)(nch - 1) * a.n + qi) * 32) = make_uint4(dsb, 0u, 0u, 0u);
-            const float dsr = lo_f(dsb);
+            const float dsr = lo_t<G16>(dsb);
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const int o4 = h * DH + db * 16 + g4 * 4;
@@ -930,13 +941,16 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 uint16_t* dst = a.dq + ((size_t)b * a.n + qi) * a.lddq + h * DH + db * 16 + g4 * 4;
-                *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_rne(dQ[h][db][0] * a.scale, dQ[h][db][1] * a.scale),
-                                                            pack2_rne(dQ[h][db][2] * a.scale, dQ[h][db][3] * a.scale));
+                *reinterpret_cast<uint2*>(dst) = G16 ?
+                    make_uint2(pack2_f16_sat_n(dQ[h][db][0] * a.scale, dQ[h][db][1] * a.scale, samax), pack2_f16_sat_n(dQ[h][db][2] * a.scale, dQ[h][db][3] * a.scale, samax)) :
+                    make_uint2(pack2_rne(dQ[h][db][0] * a.scale, dQ[h][db][1] * a.scale), pack2_rne(dQ[h][db][2] * a.scale, dQ[h][db][3] * a.scale));
             }
     }
+    if constexpr (G16) f16_sat_commit(samax);
 }
 
 // images of the backward: kv [B*T, ldkv] bf16 + the null key / value -> K6 / V6 ([key][d] tiles, keys 0..T-1 the context, key T = null) / vbits
+template <bool F16>
 __global__ __launch_bounds__(256) void xattn6_pack_bwd_kernel(const uint16_t* __restrict__ kv, int ldkv, const float* __restrict__ null_k,
                                                               const float* __restrict__ null_v, const uint8_t* __restrict__ mask,
                                                               char* __restrict__ K6, char* __restrict__ V6, uint32_t* __restrict__ vbits, int T, int nch) {
@@ -953,7 +967,7 @@ __global__ __launch_bounds__(256) void xattn6_pack_bwd_kernel(const uint16_t* __
         uint4 r = make_uint4(0, 0, 0, 0);
         if (j == T) {
             const float* src = (part ? null_v : null_k) + h * DH + gc * 8;
-            r = make_uint4(pack2_rne(src[0], src[1]), pack2_rne(src[2], src[3]), pack2_rne(src[4], src[5]), pack2_rne(src[6], src[7]));
+            r = make_uint4(pack2_t<F16>(src[0], src[1]), pack2_t<F16>(src[2], src[3]), pack2_t<F16>(src[4], src[5]), pack2_t<F16>(src[6], src[7]));
         } else if (j < T) r = *reinterpret_cast<const uint4*>(kv + ((size_t)b * T + j) * ldkv + part * NH * DH + h * DH + gc * 8);
         *reinterpret_cast<uint4*>((part ? V6 : K6) + cbase + h * TILE + row * 128 + pos * 16) = r;
     }
@@ -1005,7 +1019,8 @@ extern "C" int amdnuwa_xattn6_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
                                   int f16, hipStream_t stream) {
     int rc = check6(g);
     if (rc) return rc;
-    if (!q16 || !kv || !kv->K6 || !kv->V6 || !kv->vbits || !null_k || !null_v || !w_th || !o || ldq % 8 || ldo % 4) return AMDNUWA_ERR_ARG;
+    if (!q16 || !kv || !kv->K6 || !kv->V6 || !kv->vbits || !null_k || !null_v || !w_th || ldq % 8 || ldo % 4) return AMDNUWA_ERR_ARG;
+    if (!o && !(o_lo && o_lo_f16)) return AMDNUWA_ERR_ARG;        // o == NULL: the fp16 copy is the only output
     if (g->B <= 0 || g->n <= 0) return AMDNUWA_OK;
     X6Args a{};
     a.q = q16; a.ldq = ldq; a.K6 = (const char*)kv->K6; a.V6 = (const char*)kv->V6; a.vbits = kv->vbits;
@@ -1029,23 +1044,25 @@ extern "C" int amdnuwa_xattn6_fwd(const amdnuwa_xattn_geom* g, const uint16_t* q
 extern "C" size_t amdnuwa_xattn6_bwd_image_bytes(const amdnuwa_xattn_geom* g) {
     return (check6(g) || g->JP % 32 || g->JP < g->T + 1 || g->JP / 32 > 64) ? 0 : (size_t)g->B * (g->JP / 32) * KT;
 }
-extern "C" int amdnuwa_xattn6_pack_bwd(const amdnuwa_xattn_geom* g, const uint16_t* kv, int ldkv, const float* null_k, const float* null_v,
-                                       const uint8_t* context_mask, const amdnuwa_xattn6_kv* out, hipStream_t stream) {
+namespace {
+int x6_pack_bwd(const amdnuwa_xattn_geom* g, const uint16_t* kv, int ldkv, const float* null_k, const float* null_v, const uint8_t* context_mask,
+                const amdnuwa_xattn6_kv* out, bool f16, hipStream_t stream) {
     if (!amdnuwa_xattn6_bwd_image_bytes(g)) return g ? AMDNUWA_ERR_UNSUPPORTED : AMDNUWA_ERR_ARG;
     if (!kv || !null_k || !null_v || !out || !out->K6 || !out->V6 || !out->vbits || ldkv % 8 || ldkv < 2 * NH * DH) return AMDNUWA_ERR_ARG;
     if (g->B <= 0) return AMDNUWA_OK;
     const int nch = g->JP / 32;
-    hipLaunchKernelGGL(xattn6_pack_bwd_kernel, dim3(g->B * nch), dim3(256), 0, stream, kv, ldkv, null_k, null_v, context_mask, (char*)out->K6,
-                       (char*)out->V6, out->vbits, g->T, nch);
+    if (f16)
+        hipLaunchKernelGGL(xattn6_pack_bwd_kernel<true>, dim3(g->B * nch), dim3(256), 0, stream, kv, ldkv, null_k, null_v, context_mask, (char*)out->K6,
+                           (char*)out->V6, out->vbits, g->T, nch);
+    else
+        hipLaunchKernelGGL(xattn6_pack_bwd_kernel<false>, dim3(g->B * nch), dim3(256), 0, stream, kv, ldkv, null_k, null_v, context_mask, (char*)out->K6,
+                           (char*)out->V6, out->vbits, g->T, nch);
     LAUNCH_CHECK();
     return AMDNUWA_OK;
 }
-extern "C" size_t amdnuwa_xattn6_bwd_workspace_bytes(const amdnuwa_xattn_geom* g) {
-    return amdnuwa_xattn6_bwd_image_bytes(g) ? (size_t)g->B * ((g->n + 63) / 64) * NH * NH * sizeof(float) : 0;
-}
-extern "C" int amdnuwa_xattn6_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo, const amdnuwa_xattn6_kv* kv,
-                                  const float* null_k, const float* null_v, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm, uint16_t* dq, int lddq, float* part_th,
-                                  size_t part_bytes, hipStream_t stream) {
+int x6_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo, const amdnuwa_xattn6_kv* kv, const float* null_k,
+           const float* null_v, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm, uint16_t* dq, int lddq, float* part_th,
+           size_t part_bytes, bool g16, hipStream_t stream) {
     if (!amdnuwa_xattn6_bwd_image_bytes(g)) return g ? AMDNUWA_ERR_UNSUPPORTED : AMDNUWA_ERR_ARG;
     if (!q || !dO || !kv || !kv->K6 || !kv->V6 || !kv->vbits || !null_k || !null_v || !w_th || !stats || !dS || !Pm || !dq || ldq % 8 || lddo % 8 || lddq % 4)
         return AMDNUWA_ERR_ARG;
@@ -1056,10 +1073,43 @@ extern "C" int amdnuwa_xattn6_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q
     a.null_k = null_k; a.null_v = null_v; a.wth = w_th; a.stats = stats; a.dS = dS; a.Pm = Pm; a.dq = dq; a.lddq = lddq; a.part_th = part_th;
     a.B = g->B; a.n = g->n; a.nch = g->JP / 32; a.T = g->T; a.scale = g->scale;
     // LDS: the two-stage K + V ring, the null key / value rows, one 4-KiB turning tile per wave (the dW_th products)
-    (void)hipFuncSetAttribute((const void*)xattn6_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 4096 + 4 * 4096);
-    hipLaunchKernelGGL(xattn6_bwd_kernel, dim3(g->B * ((g->n + 63) / 64)), dim3(256), 2 * STAGE + 4096 + 4 * 4096, stream, a);
+    constexpr int LB = 2 * STAGE + 4096 + 4 * 4096;
+    const dim3 grid(g->B * ((g->n + 63) / 64));
+    if (g16) {
+        (void)hipFuncSetAttribute((const void*)xattn6_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LB);
+        hipLaunchKernelGGL(xattn6_bwd_kernel<true>, grid, dim3(256), LB, stream, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)xattn6_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LB);
+        hipLaunchKernelGGL(xattn6_bwd_kernel<false>, grid, dim3(256), LB, stream, a);
+    }
     LAUNCH_CHECK();
     return AMDNUWA_OK;
+}
+}  // namespace
+
+extern "C" int amdnuwa_xattn6_pack_bwd(const amdnuwa_xattn_geom* g, const uint16_t* kv, int ldkv, const float* null_k, const float* null_v,
+                                       const uint8_t* context_mask, const amdnuwa_xattn6_kv* out, hipStream_t stream) {
+    return x6_pack_bwd(g, kv, ldkv, null_k, null_v, context_mask, out, false, stream);
+}
+// ... from the FP16 copy of the key / value projection (null key / value rounded to fp16): the images of amdnuwa_xattn6_bwd_f16
+extern "C" int amdnuwa_xattn6_pack_bwd_f16(const amdnuwa_xattn_geom* g, const uint16_t* kv_f16, int ldkv, const float* null_k, const float* null_v,
+                                           const uint8_t* context_mask, const amdnuwa_xattn6_kv* out, hipStream_t stream) {
+    return x6_pack_bwd(g, kv_f16, ldkv, null_k, null_v, context_mask, out, true, stream);
+}
+extern "C" size_t amdnuwa_xattn6_bwd_workspace_bytes(const amdnuwa_xattn_geom* g) {
+    return amdnuwa_xattn6_bwd_image_bytes(g) ? (size_t)g->B * ((g->n + 63) / 64) * NH * NH * sizeof(float) : 0;
+}
+extern "C" int amdnuwa_xattn6_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, const uint16_t* dO, int lddo, const amdnuwa_xattn6_kv* kv,
+                                  const float* null_k, const float* null_v, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm, uint16_t* dq, int lddq, float* part_th,
+                                  size_t part_bytes, hipStream_t stream) {
+    return x6_bwd(g, q, ldq, dO, lddo, kv, null_k, null_v, w_th, stats, dS, Pm, dq, lddq, part_th, part_bytes, false, stream);
+}
+// fp16-gradient form (ABI 19): q = the fp16 copy the forward read, dO = fp16(S dO), images from amdnuwa_xattn6_pack_bwd_f16; dS / dq leave as
+// fp16(S value) (saturating, counted), Pm as fp16, the dW_th partials carry the factor S (the caller multiplies their column sums by 1 / S)
+extern "C" int amdnuwa_xattn6_bwd_f16(const amdnuwa_xattn_geom* g, const uint16_t* q_f16, int ldq, const uint16_t* dO_f16, int lddo, const amdnuwa_xattn6_kv* kv,
+                                      const float* null_k, const float* null_v, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm, uint16_t* dq,
+                                      int lddq, float* part_th, size_t part_bytes, hipStream_t stream) {
+    return x6_bwd(g, q_f16, ldq, dO_f16, lddo, kv, null_k, null_v, w_th, stats, dS, Pm, dq, lddq, part_th, part_bytes, true, stream);
 }
 
 #if X6_TIMING

@@ -112,7 +112,7 @@ def cores_f16():
 # the fp16 one its forward reads -- and runs its backward on fp16 MFMAs as well: gradients travel as fp16(S * value), S a power of two taken
 # once per backward pass from the residual-stream gradient (ops._grad_scale), weight gradients leave the split-K reduction multiplied by
 # 1 / S.  Classes: 'f' FeedForward, 's' Sparse3DNA, 'x' cross attention (env AMDNUWA_BWD_F16, '0' / '' = off).
-DEFAULT_BWD_F16 = 'f'
+DEFAULT_BWD_F16 = 'fsx'
 G16 = namedtuple('G16', ['t', 's2'])        # t: fp16 tensor holding S * value; s2: device tensor {S, 1 / S}
 
 
@@ -501,9 +501,9 @@ def gemm_nt_f16x2_ok(M, N, Kd, *, out_bf16):
     return bool(_lib.lib().amdnuwa_gemm_nt_f16x2_supported(C.byref(d)))
 
 
-def gemm_nt_f16x2(A16, B16, *, out_bf16=False, bias=None, copy_f16=False):
+def gemm_nt_f16x2(A16, B16, *, out_bf16=False, bias=None, copy_f16=False, out_f16=False):
     """two-MFMA product: A16 fp16 [M, K] x (B16 = (hi, lo) fp16 [N, K] pair)^T.  out_bf16=False -> fp32 [M, N] (+ bias);
-    out_bf16=True -> BF(bf16 copy, None, fp16 copy if copy_f16)"""
+    out_bf16=True -> BF(bf16 copy, None, fp16 copy if copy_f16); out_f16=True -> ONE fp16 [M, N] tensor (saturating)"""
     L = _lib.lib()
     M, Kd = A16.shape
     Bh, Bl = B16
@@ -514,7 +514,12 @@ def gemm_nt_f16x2(A16, B16, *, out_bf16=False, bias=None, copy_f16=False):
     d.alpha, d.beta, d.bias = 1.0, 0.0, _p(bias)
     d.M, d.N, d.K, d.batch, d.ab_f16 = M, N, Kd, 1, 1
     c16 = None
-    if out_bf16:
+    if out_f16:
+        assert not (out_bf16 or copy_f16)
+        out = torch.empty((M, N), dtype=torch.float16, device=dev)
+        d.C, d.ldc, d.c_is_bf16, d.c_f16 = _p(out), N, 1, 1
+        out_bf16 = True
+    elif out_bf16:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         d.C, d.ldc, d.c_is_bf16 = _p(out), N, 1
         if copy_f16:
@@ -532,6 +537,8 @@ def gemm_nt_f16x2(A16, B16, *, out_bf16=False, bias=None, copy_f16=False):
     check(L.amdnuwa_gemm_nt(C.byref(d), st), 'amdnuwa_gemm_nt(f16 x f16 hi+lo)')
     if _TIMER['on']:
         L.amdnuwa_timer_end(st)
+    if out_f16:
+        return out
     return BF(out, None, c16) if out_bf16 else out
 
 
@@ -1315,7 +1322,9 @@ def xattn6_fwd(g, q16, pk, null_k, null_v, wth, o_f16=False, lo=True):
     assert pk.f16 == f16 and q16.stride(1) == 1
     inner = g.heads * g.dim_head
     dev = q16.device
-    if o_f16:
+    if o_f16 == 'only':                # the fp16 copy alone (the block's backward runs on fp16 gradients: xattn6_bwd16)
+        o = BF(None, None, torch.empty((g.B * g.n, inner), dtype=torch.float16, device=dev))
+    elif o_f16:
         o = BF(torch.empty((g.B * g.n, inner), dtype=torch.bfloat16, device=dev), None,
                torch.empty((g.B * g.n, inner), dtype=torch.float16, device=dev))
     else:
@@ -1330,10 +1339,12 @@ def xattn6_fwd(g, q16, pk, null_k, null_v, wth, o_f16=False, lo=True):
 class PackedKV6B:
     """bf16 [key][d] images of the xattn6 backward (amdnuwa_xattn6_pack_bwd): key 0 = the null key, keys 1..T the context, JP / 32 chunks"""
 
-    def __init__(self, g, device):
+    def __init__(self, g, device, f16=False):
         self.nch = g.JP // 32
+        self.f16 = f16
         sh = (g.B, self.nch, g.heads, 32, g.dim_head)
-        self.K6, self.V6 = torch.empty(sh, dtype=torch.bfloat16, device=device), torch.empty(sh, dtype=torch.bfloat16, device=device)
+        dt = torch.float16 if f16 else torch.bfloat16
+        self.K6, self.V6 = torch.empty(sh, dtype=dt, device=device), torch.empty(sh, dtype=dt, device=device)
         self.vbits = torch.empty((g.B, self.nch), dtype=torch.int32, device=device)
         s = _lib.X6KV()
         s.K6, s.V6, s.vbits = _p(self.K6), _p(self.V6), _p(self.vbits)
@@ -1345,13 +1356,34 @@ def xattn6_bwd_ok(g):
         xattn_chunk_major_ok(g)
 
 
-def xattn6_pack_bwd(g, kv_bf16, null_k, null_v, mask_u8):
-    assert kv_bf16.dtype == torch.bfloat16 and kv_bf16.stride(1) == 1
-    pk = PackedKV6B(g, kv_bf16.device)
+def xattn6_pack_bwd(g, kv16, null_k, null_v, mask_u8):
+    """kv16: the bf16 copy of to_kv(context) -- or its fp16 copy: the images of the fp16-gradient form (xattn6_bwd16)"""
+    f16 = kv16.dtype == torch.float16
+    assert (f16 or kv16.dtype == torch.bfloat16) and kv16.stride(1) == 1
+    pk = PackedKV6B(g, kv16.device, f16=f16)
     pk.null_k, pk.null_v = null_k, null_v
-    check(_lib.lib().amdnuwa_xattn6_pack_bwd(C.byref(g), _p(kv_bf16), kv_bf16.stride(0), _p(null_k), _p(null_v), _p(mask_u8), C.byref(pk.struct),
-                                             _stream()), 'amdnuwa_xattn6_pack_bwd')
+    fn = _lib.lib().amdnuwa_xattn6_pack_bwd_f16 if f16 else _lib.lib().amdnuwa_xattn6_pack_bwd
+    check(fn(C.byref(g), _p(kv16), kv16.stride(0), _p(null_k), _p(null_v), _p(mask_u8), C.byref(pk.struct), _stream()), 'amdnuwa_xattn6_pack_bwd')
     return pk
+
+
+@_family('xattn', _x_work('bwd'))
+def xattn6_bwd16(g, q16, dO16, pk, wth, stats, s2):
+    """fp16-gradient form of xattn6_bwd: q16 fp16 [B*n, inner] (the forward's operand), dO16 = fp16(S dO), pk = fp16 images, s2 = device {S, 1 / S}.
+    Returns dq fp16 (= S dq), dS fp16 (= S dS) and Pm fp16 chunk-major, dw_th fp32 [h, h] (unscaled)"""
+    L = _lib.lib()
+    assert pk.f16 and q16.dtype == torch.float16 and dO16.dtype == torch.float16
+    inner = g.heads * g.dim_head
+    dev = q16.device
+    dq = torch.empty((g.B * g.n, inner), dtype=torch.float16, device=dev)
+    shape = (g.B, g.heads, g.JP // 32, g.n, 32)
+    dS, Pm = torch.empty(shape, dtype=torch.float16, device=dev), torch.empty(shape, dtype=torch.float16, device=dev)
+    nb = L.amdnuwa_xattn6_bwd_workspace_bytes(C.byref(g))
+    part = torch.empty((nb // (4 * g.heads * g.heads), g.heads * g.heads), dtype=torch.float32, device=dev)
+    check(L.amdnuwa_xattn6_bwd_f16(C.byref(g), _p(q16), q16.stride(0), _p(dO16), dO16.stride(0), C.byref(pk.struct), _p(pk.null_k), _p(pk.null_v), _p(wth),
+                                   _p(stats), _p(dS), _p(Pm), _p(dq), inner, _p(part), nb, _stream()), 'amdnuwa_xattn6_bwd_f16')
+    dwth = (colsum(part) * s2[1]).reshape(g.heads, g.heads)          # fixed-order reduction over the workgroups; the partials carry S
+    return dq, dS, Pm, dwth
 
 
 @_family('xattn', _x_work('bwd'))
@@ -1522,6 +1554,33 @@ def xattn2_bwd_rc(g, q, dO, pk, wth, stats):
                                   _p(stats), _p(dq.hi), inner, _p(part), nb, _p(nbd), sb, _p(dKp), _p(dVp), _stream()),
           'amdnuwa_xattn2_bwd_rc')
     return dq, dKp, dVp, colsum(part).reshape(g.heads, g.heads)
+
+
+@_family('xattn', _x_work('kv'))
+def xattn_kv_grads16(g, dS16, Pm16, q16, dO16, s2):
+    """fp16-gradient form of xattn_kv_grads on the chunk-major fp16 arrays of xattn6_bwd16: dKp = scale / S * (S dS)^T q, dVp = 1 / S * Pm^T (S dO)"""
+    dev = q16.device
+    Mx = xattn_permuted_extent(g)
+    dKp = torch.empty((g.B, g.heads, g.JP, g.dim_head), dtype=torch.float32, device=dev)
+    dVp = torch.empty_like(dKp)
+    for (A, Bm, out, alpha) in ((dS16, q16, dKp, g.scale), (Pm16, dO16, dVp, 1.0)):
+        d = _xattn_tn_desc(g, Mx, True)
+        d.A, d.B, d.ldb, d.ab_f16 = _p(A), _p(Bm), Bm.stride(0), 1
+        d.strideB, d.strideB_inner = g.n * Bm.stride(0), g.dim_head
+        d.C, d.alpha, d.alpha_dev = _p(out), float(alpha), s2.data_ptr() + 4
+        gemm_tn_batched(d, dev)
+    return dKp, dVp
+
+
+def xattn_bwd16_ok(g):
+    """do the fp16-gradient kernels of the cross attention take this geometry (xattn6 backward + the whole-M TN kernel on fp16 chunk-major arrays)?"""
+    if not xattn6_bwd_ok(g):
+        return False
+    d = _xattn_tn_desc(g, xattn_permuted_extent(g), True)
+    d.A, d.B, d.C, d.ab_f16 = ctypes_dummy(), ctypes_dummy(), ctypes_dummy(), 1
+    d.ldb = g.heads * g.dim_head
+    L = _lib.lib()
+    return bool(L.amdnuwa_gemm_tn_f16_supported(C.byref(d))) and bool(L.amdnuwa_gemm_tn_chunked_a_supported(C.byref(d)))
 
 
 @_family('xattn', _x_work('kv'))

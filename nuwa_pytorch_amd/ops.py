@@ -279,8 +279,20 @@ class XInner:
             out = dict(q=_cast(wq), qT=_cast_t(wq), kv=_cast(wkv), kvT=_cast_t(wkv), out=_cast(wo), outT=_cast_t(wo))
             if K.mixed() and f16_weights_ok(wq, wo):    # fp16 hi + lo pairs for the two-MFMA q and to_out products of 'bf16x3-fwd'
                 out['q_16'], out['out_16'] = K.f16_pair(wq), K.f16_pair(wo)
+                if K.bwd_f16('x'):                      # ... and fp16 transposes for the dgrad products of the fp16-gradient backward
+                    out['qT_16'] = wq.detach().t().contiguous().to(torch.float16)
+                    out['outT_16'] = wo.detach().t().contiguous().to(torch.float16)
             return out
         return cache.get('x', (wq, wkv, wo), build)
+
+    @staticmethod
+    def bwd16_ok(R, D, inner, g, meta, ws=None):
+        """the fp16-gradient backward applies (class 'x'): the two-MFMA q projection, the fp16 xattn6 cores and the two-MFMA to_out of the forward
+        apply, and the backward products fit their fp16 kernels (ws = to_q.weight, to_out.weight)"""
+        return K.bwd_f16('x') and XInner.f16x2_ok(R, D, inner, g, meta, ws) and K.proj_f16x2('o') and K.xattn6_on() and K.xattn6_supported(g) and \
+            K.gemm_nt_f16x2_ok(R, D, inner, out_bf16=False) and K.xattn_bwd16_ok(g) and not K.xattn2_bwd_rc_ok(g) and \
+            K.gemm_nt_f16ops_ok(R, inner, D, out_bf16=False, out_f16=True) and K.gemm_nt_f16ops_ok(R, D, inner, out_bf16=False, out_f16=True) and \
+            K.gemm_tn16_ok(R, D, inner) and K.gemm_tn16_ok(R, inner, D)
 
     @staticmethod
     def f16x2_ok(R, D, inner, g, meta, ws=None):
@@ -297,8 +309,19 @@ class XInner:
         g = meta['xgeom']
         ctx = h if meta.get('self_kv') else meta['ctx_bf']          # self-attention (text encoder): keys / values from the same rows
         rot = meta.get('rotary')
-        R, D = h.hi.shape
+        R, D, _ = K.bf_rows_cols(h)
         inner = g.heads * g.dim_head
+        if meta.get('bwd16') and 'qT_16' in W and ctx.lo is not None and nk.dtype == torch.float32:
+            # fp16-gradient backward: ONE (fp16) copy of h, of q and of the core's output; the backward's images come from the fp16 copy of k / v
+            q16 = K.gemm_nt_f16x2(h.f16, W['q_16'], out_f16=True)
+            kv = K.gemm_nt(ctx, W['kv'], out_bf16=True, out_f16=True)
+            nk2, nv2 = nk.detach().reshape(g.heads, g.dim_head).contiguous(), nv.detach().reshape(g.heads, g.dim_head).contiguous()
+            wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
+            pk = K.xattn6_pack_bwd(g, kv.f16, nk2, nv2, meta['mask_u8'])
+            o, stats = K.xattn6_fwd(g, q16, K.xattn6_pack(g, kv.f16, meta['mask_u8']), nk2, nv2, wth2, o_f16='only')
+            y = K.gemm_nt_f16x2(o.f16, W['out_16'])
+            return y, (K.BF(None, None, h.f16), K.hi_only(ctx), K.BF(None, None, q16), pk, stats, None, o)
+        assert h.hi is not None, 'a bf16 backward needs the bf16 copy of the LayerNorm output'
         x2 = 'q_16' in W and ctx.lo is not None and XInner.f16x2_ok(R, D, inner, g, meta)
         if not x2:
             h = _f16_to_pair(h)
@@ -353,6 +376,21 @@ class XInner:
         nk, nv, wth, wq, wkv, wo = p
         g = meta['xgeom']
         wth2 = wth.detach().reshape(g.heads, g.heads).contiguous()
+        if isinstance(dy, K.G16):
+            # fp16-gradient backward: dy = fp16(S dy); every large product on the fp16 MFMA against the fp16 copies the forward left
+            s2 = dy.s2
+            d_o = K.gemm_nt_f16ops(dy.t, W['outT_16'], out_f16=True)
+            dwo = torch.empty_like(wo)
+            K.gemm_tn16(dy.t, o.f16, dwo, s2)
+            dq, dS, Pm, dwth = K.xattn6_bwd16(g, q.f16, d_o, pk, wth2, P, s2)
+            dKp, dVp = K.xattn_kv_grads16(g, dS, Pm, q.f16, d_o, s2)
+            dkv, dnk, dnv = K.xattn_unpack(g, dKp, dVp, lo=False, permuted=True, null_last=True)       # (context-sized from here on: bf16 as before)
+            dh = K.G16(K.gemm_nt_f16ops(dq, W['qT_16'], out_f16=True), s2)
+            dwq, dwkv = torch.empty_like(wq), torch.empty_like(wkv)
+            K.gemm_tn16(dq, h.f16, dwq, s2)
+            K.gemm_tn(dkv, ctx, dwkv)
+            dctx = K.gemm_nt(dkv, W['kvT'])
+            return dh, dctx, [dnk.reshape(nk.shape), dnv.reshape(nv.shape), dwth.reshape(wth.shape), dwq, dwkv, dwo]
         d_o = K.gemm_nt(dy, W['outT'], out_bf16=True)
         dwo = torch.empty_like(wo)
         K.gemm_tn(dy, o, dwo)
@@ -664,6 +702,8 @@ def _block_bwd16(kind, R, D, p, meta):
         return FFInner.bwd16_ok(R, D, _ru(p[1].shape[1], 32), p[1].shape[1], (p[0], p[1]))
     if kind == 's3':
         return S3Inner.bwd16_ok(R, D, p[0].shape[0], meta['geom'], (p[0], p[1]), p[3], len(p) > 5)
+    if kind == 'xattn':
+        return XInner.bwd16_ok(R, D, p[3].shape[0], meta['xgeom'], meta, (p[3], p[5]))
     return False
 
 
@@ -725,7 +765,8 @@ class SandwichBlockFn(Function):
                                         (nk[0] == 's3' and S3Inner.f16_proj_ok(B * n, D, nk[1], nk[2], nk[3])) or
                                         (nk[0] == 'x' and XInner.f16x2_ok(B * n, D, nk[1], nk[2], nk[3], nk[4])))
             if nxt16 and ((nk[0] == 'ff' and FFInner.bwd16_ok(B * n, D, _ru(nk[1], 32), nk[1], nk[2])) or
-                          (nk[0] == 's3' and len(nk) > 5 and S3Inner.bwd16_ok(B * n, D, nk[1], nk[2], nk[3], nk[4], nk[5]))):
+                          (nk[0] == 's3' and len(nk) > 5 and S3Inner.bwd16_ok(B * n, D, nk[1], nk[2], nk[3], nk[4], nk[5])) or
+                          (nk[0] == 'x' and XInner.bwd16_ok(B * n, D, nk[1], nk[2], nk[3], nk[4]))):
                 nxt16 = 'only'                    # the next block keeps ONE (fp16) copy of its LayerNorm input: fp16-gradient backward
             xo, m2, r2, hn, mn, rn = K.ln_post_pre_fwd(y, r2_, post_w.detach(), post_b.detach(), nxt[0].detach(),
                                                        nxt[1].detach(), next_shift=nxt[2], next_f16=nxt16)

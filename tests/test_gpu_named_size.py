@@ -500,14 +500,15 @@ def test_fp16_gradient_backward_of_the_compliant_mode(A, O):
             assert wc <= 1.4e-2 and fc <= max(f1 * 1.5, 2e-3), res
         # round 6: the Sparse3DNA block too (class 's': q / k / v, the core's output and the LayerNorm output in front of the block as ONE fp16
         # copy each, amdnuwa_sparse3dna_bwd_f16): same forward bits, every gradient inside the bound and the block's own weight gradients no worse
-        s3w = 'layers.0.0.fn.fn.to_q.weight'
-        for cls in ('fs',):
+        # ... and the cross-attention block (class 'x': the LayerNorm output, q and the core's output as ONE fp16 copy each, amdnuwa_xattn6_bwd_f16,
+        # the dK / dV products on fp16 chunk-major arrays)
+        for cls, wname in (('fs', 'layers.0.0.fn.fn.to_q.weight'), ('fsx', 'layers.0.1.fn.to_q.weight')):
             y2, w2, _ = run(cls, 1.0)
             assert torch.equal(y0, y2), f'the fp16-gradient switch {cls!r} must not change the forward'
-            q2 = rel_err(dict(tr.named_parameters())[s3w].grad, Pr[s3w].grad)
+            q2 = rel_err(dict(tr.named_parameters())[wname].grad, Pr[wname].grad)
             run('f', 1.0)
-            q1 = rel_err(dict(tr.named_parameters())[s3w].grad, Pr[s3w].grad)
-            res.update({f'worst_f16_bwd[{cls}]': w2, f'to_q_weight_f16_bwd[{cls}]': q2, 'to_q_weight_bf16_bwd': q1})
+            q1 = rel_err(dict(tr.named_parameters())[wname].grad, Pr[wname].grad)
+            res.update({f'worst_f16_bwd[{cls}]': w2, f'to_q_weight_f16_bwd[{cls}]': q2, f'to_q_weight_bf16_bwd[{cls}]': q1})
             assert w2 <= 1.4e-2 and q2 <= max(q1 * 1.05, 2e-3), res
             for c in (1e-6, 1e3):
                 _, wc, _ = run(cls, c)
