@@ -528,8 +528,9 @@ int amdnuwa_xattn6_bwd(const amdnuwa_xattn_geom* g, const uint16_t* q, int ldq, 
                        const float* null_k, const float* null_v, const float* w_th, const float* stats, uint16_t* dS, uint16_t* Pm, uint16_t* dq, int lddq, float* part_th,
                        size_t part_bytes, amdnuwa_stream stream);
 /* ABI 19, the fp16-gradient form (block class 'x' of the 'bf16x3-fwd' mode): images from the FP16 copy of to_kv(context)
- * (amdnuwa_xattn6_pack_bwd_f16; the null key / value rounded to fp16), q = the fp16 copy the forward read, dO = fp16(S dO); dq and dS leave
- * as fp16(S value), saturating and counted by amdnuwa_f16_sat_count, Pm as fp16, and the part_th partials carry the factor S.  Every MFMA is
+ * (amdnuwa_xattn6_pack_bwd_f16; the null key / value rounded to fp16), q = the fp16 copy the forward read, dO = fp16(S dO); dq leaves as
+ * fp16(S dq), saturating and counted by amdnuwa_f16_sat_count, dS as fp16(S dS) and Pm as fp16 through the plain converter; the V image carries the
+ * factor 2^-6 (the kernel's dP' = dO . V then stays inside fp16 where dO does) and the part_th partials the factor S / 64.  Every MFMA is
  * the fp16 one.  The dK / dV products over dS / Pm then run amdnuwa_gemm_tn with ab_f16 + a_chunk32 and alpha_dev = 1 / S.
  * amdnuwa_xattn6_fwd accepts o == NULL together with o_lo_f16 (the fp16 copy is then the only output). */
 int amdnuwa_xattn6_pack_bwd_f16(const amdnuwa_xattn_geom* g, const uint16_t* kv_f16, int ldkv, const float* null_k, const float* null_v,

@@ -540,6 +540,13 @@ struct X6BArgs {
     float scale;
 };
 constexpr float MASK_BIAS_RAW = -400000.f;   // unscaled score of a masked key (x scale * log2 e = -72 000 in the log2 domain)
+// Range of the fp16-gradient form.  dO arrives as fp16(S dO) with S chosen from the residual-stream gradient at the top of the backward pass; by the
+// time it reaches a cross-attention block it has grown through LayerNorm backwards (measured on a 3-layer cfg-3 model: |S dO| up to 1.5e4), and
+// dP' = dO . V sums 64 such products: packed to fp16 for the head mix it left the format (inf -> NaN gradients).  The V image of this form
+// therefore carries the factor X6B_VS = 2^-6 (exact in fp16 but for values below 2^-8, which lose up to 6 trailing bits), so that everything
+// derived from dP' -- dP, delta, the dW_th products -- is smaller by that factor; pass B folds the inverse into the probabilities it multiplies ds
+// with (+6 on the exponent offset of exp2: free), the rank-one null-key term multiplies explicitly, and the caller multiplies dW_th by 2^6 / S.
+constexpr float X6B_VS = 0.015625f, X6B_VS_LOG2_INV = 6.f;
 // (G16, a template flag of everything below: the fp16-gradient form -- q / dO / the images hold fp16 values, dO = fp16(S dO), every MFMA the fp16
 //  one, Pm / dS / dq leave as fp16 -- dS and dq saturating and counted; amdnuwa_xattn6_bwd_f16)
 #define MFMAB(a, b, c) mfma16<G16>(a, b, c)
@@ -602,7 +609,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     if (tid < NH * NH) { const float v = a.wth[tid]; wsh[tid] = v; wtsh[(tid & 7) * 8 + (tid >> 3)] = v; }
     float* nks = reinterpret_cast<float*>(smem + 2 * STAGE);     // the null key / value, rounded to bf16 as an image row is: 2 x 2 KiB behind the ring
     float* nvs = nks + NH * DH;
-    for (int e = tid; e < NH * DH; e += 256) { nks[e] = rnd16<G16>(a.null_k[e]); nvs[e] = rnd16<G16>(a.null_v[e]); }
+    for (int e = tid; e < NH * DH; e += 256) { nks[e] = rnd16<G16>(a.null_k[e]); nvs[e] = rnd16<G16>(a.null_v[e]) * (G16 ? X6B_VS : 1.f); }
     const uint32_t wv = lane < nch ? a.vbits[(size_t)b * nch + lane] : 0u;
     // T % 32 == 0: the null key (position T) is alone in the last chunk -- that chunk is not a matrix iteration but a rank-one term
     const bool rank1 = (a.T & 31) == 0;
@@ -653,15 +660,15 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     }
     const size_t hplane = (size_t)nch * a.n * 32;                // elements between heads in dS / Pm
     // probabilities of head h for this lane's 8 slots of the chunk in `kbase`
-    auto probs = [&](const char* kbase, int h, const f32x4& b0, const f32x4& b1, float* P) {
+    auto probs = [&](const char* kbase, int h, const f32x4& b0, const f32x4& b1, float* P, float off) {
         const KF f = k_frags(kbase, h, ko0, ko1);
         f32x4 s0 = b0, s1 = b1;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) { s0 = MFMAB(f.v[0][ks], qf[h][ks], s0); s1 = MFMAB(f.v[1][ks], qf[h][ks], s1); }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            P[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c1, nb[h]));
-            P[4 + r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c1, nb[h]));
+            P[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c1, off));
+            P[4 + r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c1, off));
         }
     };
     // dP'^T[g] = V[g] dO[g]^T for this lane's 8 slots
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
         bias_raw(ch, b0, b1);
         float P[NH][8];
 #pragma unroll
-        for (int h = 0; h < NH; ++h) probs(kbase, h, b0, b1, P[h]);
+        for (int h = 0; h < NH; ++h) probs(kbase, h, b0, b1, P[h], nb[h]);
         const bool st = qok && 32 * ch + 4 * g4 <= a.T;          // (a lane group whose 8 keys are all padding writes nothing)
 #pragma unroll
         for (int Q = 0; Q < 2; ++Q) {
@@ -772,6 +779,9 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     }
     // pass B's first chunk is on its way while the statistics are reduced
     stage(0, 0);
+    float nbB[NH];                                               // exponent offsets of pass B's probabilities (G16: times 2^6, undoing the V image's factor in ds)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) nbB[h] = nb[h] + (G16 ? X6B_VS_LOG2_INV : 0.f);
     // ---- the null key as a rank-one term (T % 32 == 0), pass A part: P_null, dP'_null, their mixes, the shares of delta and dW_th, Pm
     float PN[NH], dPN[NH];
 #pragma unroll
@@ -908,11 +918,12 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
             for (int rp = 0; rp < 4; ++rp) {
                 const int h = 4 * Q + rp;
                 float P[8], ds[8];
-                probs(kbase, h, b0, b1, P);
+                probs(kbase, h, b0, b1, P, nbB[h]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ds[e] = P[e] * (D[e][rp] - delta[h]);
-                const uint4 pk = G16 ? make_uint4(pack2_f16_sat_n(ds[0], ds[1], samax), pack2_f16_sat_n(ds[2], ds[3], samax), pack2_f16_sat_n(ds[4], ds[5], samax), pack2_f16_sat_n(ds[6], ds[7], samax))
-                                     : make_uint4(pack2_rne(ds[0], ds[1]), pack2_rne(ds[2], ds[3]), pack2_rne(ds[4], ds[5]), pack2_rne(ds[6], ds[7]));
+                // (G16: |ds| <= |dP - delta| with dP a head mix of fp16 values that carry 2^-6: it stays inside the format wherever dP' did; the plain
+                //  converter -- the saturating, counted one costs 5 more instructions per pair, 160 per chunk; dq below IS saturating and counted)
+                const uint4 pk = make_uint4(pack2_t<G16>(ds[0], ds[1]), pack2_t<G16>(ds[2], ds[3]), pack2_t<G16>(ds[4], ds[5]), pack2_t<G16>(ds[6], ds[7]));
                 if (st) *reinterpret_cast<uint4*>(a.dS + ((size_t)b * NH + h) * hplane + ((size_t)ch * a.n + qi) * 32 + g4 * 8) = pk;
                 const bf16x8 sf = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
@@ -924,7 +935,7 @@ __global__ __launch_bounds__(256, 1) void xattn6_bwd_kernel(X6BArgs a) {
     if (rank1) {                                                 // pass B part: ds_null -> dS, dq += ds_null k_null
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            const uint32_t dsb = G16 ? pack2_f16_sat_n(PN[h] * (dPN[h] - delta[h]), 0.f, samax) : pack2_rne(PN[h] * (dPN[h] - delta[h]), 0.f);
+            const uint32_t dsb = G16 ? pack2_f16_sat_n(PN[h] * (dPN[h] - delta[h]) * (1.f / X6B_VS), 0.f, samax) : pack2_rne(PN[h] * (dPN[h] - delta[h]), 0.f);
             if (g4 == 0 && qok) *reinterpret_cast<uint4*>(a.dS + ((size_t)b * NH + h) * hplane + ((size_t)(nch - 1) * a.n + qi) * 32) = make_uint4(dsb, 0u, 0u, 0u);
             const float dsr = lo_t<G16>(dsb);
 #pragma unroll
@@ -969,6 +980,11 @@ __global__ __launch_bounds__(256) void xattn6_pack_bwd_kernel(const uint16_t* __
             const float* src = (part ? null_v : null_k) + h * DH + gc * 8;
             r = make_uint4(pack2_t<F16>(src[0], src[1]), pack2_t<F16>(src[2], src[3]), pack2_t<F16>(src[4], src[5]), pack2_t<F16>(src[6], src[7]));
         } else if (j < T) r = *reinterpret_cast<const uint4*>(kv + ((size_t)b * T + j) * ldkv + part * NH * DH + h * DH + gc * 8);
+        if (F16 && part) {     // fp16-gradient form: the V image carries the factor X6B_VS (see xattn6_bwd_kernel)
+            const f16x2_t k2 = {(_Float16)X6B_VS, (_Float16)X6B_VS};
+            r.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2_t, r.x) * k2); r.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2_t, r.y) * k2);
+            r.z = __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2_t, r.z) * k2); r.w = __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2_t, r.w) * k2);
+        }
         *reinterpret_cast<uint4*>((part ? V6 : K6) + cbase + h * TILE + row * 128 + pos * 16) = r;
     }
 }

@@ -1382,7 +1382,7 @@ def xattn6_bwd16(g, q16, dO16, pk, wth, stats, s2):
     part = torch.empty((nb // (4 * g.heads * g.heads), g.heads * g.heads), dtype=torch.float32, device=dev)
     check(L.amdnuwa_xattn6_bwd_f16(C.byref(g), _p(q16), q16.stride(0), _p(dO16), dO16.stride(0), C.byref(pk.struct), _p(pk.null_k), _p(pk.null_v), _p(wth),
                                    _p(stats), _p(dS), _p(Pm), _p(dq), inner, _p(part), nb, _stream()), 'amdnuwa_xattn6_bwd_f16')
-    dwth = (colsum(part) * s2[1]).reshape(g.heads, g.heads)          # fixed-order reduction over the workgroups; the partials carry S
+    dwth = (colsum(part) * (s2[1] * 64.0)).reshape(g.heads, g.heads)  # fixed-order reduction over the workgroups; the partials carry S / 64 (the V image's 2^-6)
     return dq, dS, Pm, dwth
 
 

@@ -684,13 +684,21 @@ def _as_f32(t):
     return t.hi.float() if isinstance(t, K.BF) else t
 
 
+GRAD_SCALE_LOG2 = float(os.environ.get('AMDNUWA_GRAD_SCALE_LOG2', '-4'))      # S * max|g| in [2^x, 2^(x+1))
+
+
 def _grad_scale(g2):
-    """device tensor {S, 1 / S} for the fp16 gradients of one backward pass: S = the power of two with S * max|g| in [8, 16), g = the
-    residual-stream gradient entering the first block of the pass (kernels.G16).  No host synchronisation."""
+    """device tensor {S, 1 / S} for the fp16 gradients of one backward pass: S = the power of two with S * max|g| in [2^-4, 2^-3), g = the
+    residual-stream gradient entering the first block of the pass (kernels.G16).  No host synchronisation.
+    Why that low (round 5 used [8, 16)): the gradients INSIDE the blocks are larger than the stream's -- a post-norm backward multiplies by
+    w / std(y), and the cross-attention block's y is small -- and they grow towards layer 0: on the random-init cfg-3 stack (24 layers)
+    |S g| of the cross-attention blocks' dy climbs from 1.2e3 at the top to beyond 65504 at layers 0 and 1 with [8, 16) (tools/grad_range.py,
+    profiles/r06l_grad_range.txt: saturation counter 36).  Seven bits lower the largest tensor peaks at 2^9 and the smallest (|S g| max 0.1)
+    still keeps 8 significant bits -- bf16's -- down to 2^-12 of its own maximum (fp16 is normal to 6.1e-5, subnormal to 6e-8)."""
     a = g2.detach().abs().amax().float()
     ok = torch.isfinite(a) & (a > 0)
     e = torch.floor(torch.log2(torch.where(ok, a, torch.ones_like(a))))
-    S = torch.where(ok, torch.exp2((3.0 - e).clamp(-60.0, 60.0)), torch.ones_like(a))
+    S = torch.where(ok, torch.exp2((GRAD_SCALE_LOG2 - e).clamp(-60.0, 60.0)), torch.ones_like(a))
     return torch.stack((S, 1.0 / S)).contiguous()
 
 

@@ -128,7 +128,8 @@ def test_bench_py_two_ranks_end_to_end(launcher):
     assert out['config']['global_batch'] == 4 and out['config']['parallelism'] == 'dp2'
     assert out['value'] > 0 and abs(out['value'] - 2 * out['per_gpu_value']) < 1e-6 * out['value']
     assert abs(out['value'] - 2 * 2 * 2560 * 2 / (out['ms_per_step'] * 2e-3)) < 1e-3 * out['value']
-    assert out['roofline']['launches'] > 0 and 0 < out['roofline']['frac'] < 1
+    assert out['roofline']['families']['gemm_nt']['launches'] > 0 and 0 < out['roofline']['frac'] < 1 and \
+        abs(out['roofline']['frac'] - out['step_mfma_frac']) < 1e-12      # the line's roofline IS the whole step
     assert out['precision_mode'] == 'bf16x3-fwd' and out['fast_mode']['dtype'] == 'bf16' and out['fast_mode']['value'] > 0
     assert 'single fp16 MFMA on' in out['dtype'] and out['fp16_forward_parts'] == {'cores': True, 'ff': True, 'qkv': True, 'two_mfma_products': 'oq'} and \
         '2 fp16 MFMAs (fp16 activation x fp16 hi+lo weight) on to_out x2, cross-attention q projection' in out['dtype']
