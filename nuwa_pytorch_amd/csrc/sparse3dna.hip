@@ -1660,7 +1660,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
     }
     {   // (nsp is a multiple of 4 floats and both tables start 16-byte aligned: 16-byte stores)
         const float4 neg4 = make_float4(NEG_MAX, NEG_MAX, NEG_MAX, NEG_MAX), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int e = t; e < nsp / 4; e += blockDim.x) { reinterpret_cast<float4*>(SP)[e] = neg4; reinterpret_cast<float4*>(DP)[e] = zero4; }
+        for (int e = t; e < nsp / 4 && !(a.dbg & 2048); e += blockDim.x) { reinterpret_cast<float4*>(SP)[e] = neg4; reinterpret_cast<float4*>(DP)[e] = zero4; }
     }
     rowm_planes(a, f, y, pslot, ptok);
     const RowM r = rowm_init(a, b, ry, pslot, ptok);
@@ -1675,7 +1675,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
     // recomputing key side: this kernel leaves (row max, 1 / row sum, delta) per (query, head) instead of the ds / P' workspace
     float* gst = a.stats ? a.stats + ((size_t)b * nq + (size_t)ry * W) * NH * 4 : nullptr;
     const int wvalid = a.ntok - 1 - ry * W;                                                 // queries of this row that exist
-    rowm_softmax(SP, J, gst, wvalid, BIAS ? 1.f : a.scale);                                 // P
+    if (!(a.dbg & 64)) rowm_softmax(SP, J, gst, wvalid, BIAS ? 1.f : a.scale);             // P   (more probe bits of key 17: 64 no softmax, 128 no item pass, 256 no ds pass, 512 no pack pass, 1024 no <bos> partials, 2048 no table init)
     __syncthreads();
     // ONE pass over the (query, slot) items, all 8 heads of an item in the thread's registers (tuning key 19 = 1 restores the three
     // separate passes it replaces):
@@ -1696,7 +1696,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
 #pragma unroll
             for (int k = 0; k < 32; ++k) acc[k] = 0.f;
 #pragma unroll 1
-            for (int item = t; item < W * J; item += blockDim.x) {
+            for (int item = t; item < W * J && !(a.dbg & 128); item += blockDim.x) {
                 const int wq = (int)(((float)item + 0.5f) * rJ), j = item - wq * J;
                 const int iq = 1 + ry * W + wq;
                 const int ib = item * NH + wq * S3M_PAD;
@@ -1840,7 +1840,8 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
         const int cc = t & 3, wh = t >> 2, h = wh % NH, w = wh / NH;
         const int i = 1 + ry * W + w;
         float ds_amax = 0.f;                                      // G16: S ds is clamped to the fp16 range HERE (every later use packs it to fp16) and counted
-        if (J <= 48) {                                            // the thread's <= 12 slots in registers (see rowm_softmax); same order of operations
+        if (a.dbg & 256) {
+        } else if (J <= 48) {                                            // the thread's <= 12 slots in registers (see rowm_softmax); same order of operations
             float pv[12], dv[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
@@ -1890,7 +1891,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
         // rows of every key that EXISTS, so it only ever asks for the entries kept here.
         const int ta0 = max(0, a.kf - 1 - f / a.df), tb0 = max(0, a.kh - 1 - y / a.dh);
         const float rkw = 1.f / (float)a.kw, rkh = 1.f / (float)a.kh;
-        for (int item = t; item < W * J; item += blockDim.x) {
+        for (int item = t; item < W * J && !(a.dbg & 512); item += blockDim.x) {
             const int wq = (int)(((float)item + 0.5f) * rJ), j = item - wq * J;
             const int iq = 1 + ry * W + wq;
             bool keep = false;                                                    // (slot 0, <bos>: its dk / dv come from this kernel's own partials, never from the workspace)
@@ -1939,27 +1940,60 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
         }
     }
     // <bos> partials of this row: dk0[e] = scale * sum_w ds[w][0][h] q[w][e],  dv0[e] = sum_w P'[w][0][g] dO[w][e]
-    for (int e = t; e < inner; e += blockDim.x) {
-        const int h = e / DH;
-        // all W rows of q and dO in flight at once, branch-free (rows past the sequence re-read the last valid one and add zero); the
-        // loop with an early exit issued one dependent 2-byte load pair per iteration: 16 L2 round trips at the tail of every workgroup
-        float qv[W], dv_[W];
+    // Round 6: 16-byte row pieces.  Thread (wave, eg) takes channels 8 eg .. 8 eg + 7 of query rows 2 wave and 2 wave + 1 (four 16-byte loads;
+    // the form before it had one thread per channel issue thirty-two 2-byte loads: 256 vector-memory instructions per workgroup at its tail,
+    // 163 us of the 1410-us kernel at dilation 2 in the phase probe, profiles/r06o_s3q_probe.txt), the eight waves' partial sums meet in the
+    // LDS region the dq sweep's K tiles have left (fixed order: waves ascending) and thread e writes channel e.
+    __syncthreads();                                                              // every wave is done with its K tile
+    if (!(a.dbg & 1024)) {
+        // records of 16 floats [8 waves][64 eg] = 32 KiB <= r1 (the ds table behind it is still being read); the four 16-byte pieces of a record
+        // sit rotated by eg / 4 so that the 16 lanes of a store phase (64-byte pitch) hit 16 different bank quads
+        float* part = reinterpret_cast<float*>(smem);
+        const int eg = t & 63, wv = t >> 6, h = eg >> 3;
+        float sk[8], sv[8];
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            const int i = 1 + ry * W + w;
-            const size_t ic = r.tok0 + (i < a.ntok ? i : a.ntok - 1);
-            qv[w] = ld16_t<G16>(a.q[ic * a.ld + e]);
-            dv_[w] = ld16_t<G16>(a.dO[ic * a.lddo + e]);
-        }
-        float sk = 0.f, sv = 0.f;
+        for (int k = 0; k < 8; ++k) { sk[k] = 0.f; sv[k] = 0.f; }
+        uint4 qv[2], dv4[2];
+        float cs[2], cp[2];
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            const bool in = 1 + ry * W + w < a.ntok;
-            sk += in ? DP[w * TS + h] * qv[w] : 0.f;
-            sv += in ? PM0[w * NH + h] * dv_[w] : 0.f;
+        for (int rr = 0; rr < 2; ++rr) {
+            const int w = 2 * wv + rr, i = 1 + ry * W + w;
+            const bool in = i < a.ntok;
+            const size_t ic = r.tok0 + (in ? i : a.ntok - 1);
+            qv[rr] = *reinterpret_cast<const uint4*>(a.q + ic * a.ld + 8 * eg);
+            dv4[rr] = *reinterpret_cast<const uint4*>(a.dO + ic * a.lddo + 8 * eg);
+            cs[rr] = in ? DP[w * TS + h] : 0.f;
+            cp[rr] = in ? PM0[w * NH + h] : 0.f;
         }
-        pk0[e] = a.scale * sk;
-        pv0[e] = sv;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const uint32_t qw[4] = {qv[rr].x, qv[rr].y, qv[rr].z, qv[rr].w}, dw[4] = {dv4[rr].x, dv4[rr].y, dv4[rr].z, dv4[rr].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sk[2 * k] = fmaf(cs[rr], lo_t<G16>(qw[k]), sk[2 * k]); sk[2 * k + 1] = fmaf(cs[rr], hi_t<G16>(qw[k]), sk[2 * k + 1]);
+                sv[2 * k] = fmaf(cp[rr], lo_t<G16>(dw[k]), sv[2 * k]); sv[2 * k + 1] = fmaf(cp[rr], hi_t<G16>(dw[k]), sv[2 * k + 1]);
+            }
+        }
+        float4* dst = reinterpret_cast<float4*>(part + (wv * 64 + eg) * 16);
+        const int rot = eg >> 2;
+        dst[rot & 3] = make_float4(sk[0], sk[1], sk[2], sk[3]); dst[(1 + rot) & 3] = make_float4(sk[4], sk[5], sk[6], sk[7]);
+        dst[(2 + rot) & 3] = make_float4(sv[0], sv[1], sv[2], sv[3]); dst[(3 + rot) & 3] = make_float4(sv[4], sv[5], sv[6], sv[7]);
+    }
+    __syncthreads();
+    if (!(a.dbg & 1024)) {
+        const float* part = reinterpret_cast<const float*>(smem);
+        for (int e = t; e < inner; e += blockDim.x) {
+            const int eg = e >> 3, cmp = e & 7, rot = eg >> 2;
+            const int ok_ = 4 * (((cmp >> 2) + rot) & 3) + (cmp & 3), ov_ = 4 * ((2 + (cmp >> 2) + rot) & 3) + (cmp & 3);
+            float sk = 0.f, sv = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) {
+                sk += part[(wv * 64 + eg) * 16 + ok_];
+                sv += part[(wv * 64 + eg) * 16 + ov_];
+            }
+            pk0[e] = a.scale * sk;
+            pv0[e] = sv;
+        }
     }
 }
 
