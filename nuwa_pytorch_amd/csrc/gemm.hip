@@ -470,8 +470,9 @@ __device__ __forceinline__ int b64_off(int row, int cc) { return row * 128 + ((c
 // with C2, the gate output computed on the fp32 accumulators as an fp16 copy (C2: FF2's operand) + a bf16 copy (C2lo: backward).
 // Epilogue of the 256-row ring tiles (gemm_nt_256_kernel and its persistent form): accumulators -> C (and the fused second outputs).
 // Lane (fr, fg) of wave (wm, wn): row fragments i = 0..7 are rows m0 + wm*128 + i*16 + fr; see the EPI notes at the kernel.
-template <int EPI, bool F16, int WNW>
-__device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane, long long oC) {
+template <int EPI, bool F16, int WNW, bool LT = false>     // LT (EPI 5 on the persistent ring): ltile = a wave-private 4-KiB LDS tile, u comes through coalesced loads
+__device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane, long long oC,
+                                               char* ltile = nullptr) {
     constexpr int BN = 64 * WNW;
     const int fr = lane & 15, fg = lane >> 4;
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
@@ -665,28 +666,80 @@ __device__ __forceinline__ void nt256_epilogue(const GemmArgs& p, const f32x4 (&
                     dp[2 * q + 1] = make_uint4(pack2_f16_sat_n(dgt[0], dgt[1], sat), pack2_f16_sat_n(dgt[2], dgt[3], sat), pack2_f16_sat_n(dgt[4], dgt[5], sat), pack2_f16_sat_n(dgt[6], dgt[7], sat));
                 }
             };
-            if (m0 + 256 <= p.M && n0 + BN <= p.N) {
-                // full tile: u of the NEXT row fragment in flight while this one is finished (see the bf16 form in EPI 1)
-                const bf16_t* ubase = p.Uin + ((long long)m0 + wm * 128 + fr) * p.ldu + 2 * nb;
+            if (LT && m0 + 256 <= p.M && n0 + BN <= p.N) {
+                // Full tile on the persistent ring (round 6): u arrives through COALESCED loads and a turn in LDS.  A lane owns row fr and the 64 bytes
+                // of u behind its 16 columns, so in the direct form below each 16-byte load instruction touches 64 different 64-byte segments.  Here
+                // instruction q of a fragment reads rows 4q .. 4q + 3 of the wave's [16 rows][256 B] block, 16 lanes per row (1 KiB contiguous per 4
+                // rows), the block is written to the wave's LDS tile as it is consumed and every lane reads its own four pieces back.  Piece p of row
+                // r sits at 16-byte slot p ^ g(r), g(r) = r ^ ((r & 4) << 1): the ds_write_b128 / ds_read_b128 lane groups of both directions then
+                // touch 16 different slots.  Two fragments are in flight behind the one being consumed, in three NAMED register sets (a modulo-
+                // indexed array of them was kept in scratch by the compiler).  tools/geglu_bwd_probe.py, b = 128: 1302 -> 1254 us.
+                const int lq = lane >> 4, lp = lane & 15;
+                const bf16_t* ucb = p.Uin + ((long long)m0 + wm * 128 + lq) * p.ldu + 2 * (n0 + wn * 64) + lp * 8;
                 bf16_t* dbase = p.C2 + ((long long)m0 + wm * 128 + fr) * p.ldc2 + 2 * nb;
-                uint4 un[4];
+                int wpos[4], rpos[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) un[q] = reinterpret_cast<const uint4*>(ubase)[q];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * q + lq;
+                    wpos[q] = r * 256 + ((lp ^ (r ^ ((r & 4) << 1))) << 4);
+                    rpos[q] = fr * 256 + (((4 * fg + q) ^ (fr ^ ((fr & 4) << 1))) << 4);
+                }
+                uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3, sc0, sc1, sc2, sc3;
+                auto uload = [&](int f, uint4& d0, uint4& d1, uint4& d2, uint4& d3) {
+                    d0 = *reinterpret_cast<const uint4*>(ucb + (long long)(f * 16) * p.ldu);
+                    d1 = *reinterpret_cast<const uint4*>(ucb + (long long)(f * 16 + 4) * p.ldu);
+                    d2 = *reinterpret_cast<const uint4*>(ucb + (long long)(f * 16 + 8) * p.ldu);
+                    d3 = *reinterpret_cast<const uint4*>(ucb + (long long)(f * 16 + 12) * p.ldu);
+                };
+                auto ustep = [&](int i, const f32x4 (&ai)[4], uint4& c0, uint4& c1, uint4& c2, uint4& c3, uint4& n0_, uint4& n1_, uint4& n2_, uint4& n3_) {
+                    if (i + 2 < 8) uload(i + 2, n0_, n1_, n2_, n3_);
+                    *reinterpret_cast<uint4*>(ltile + wpos[0]) = c0; *reinterpret_cast<uint4*>(ltile + wpos[1]) = c1;
+                    *reinterpret_cast<uint4*>(ltile + wpos[2]) = c2; *reinterpret_cast<uint4*>(ltile + wpos[3]) = c3;
+                    __builtin_amdgcn_wave_barrier();
                     uint4 uc[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) uc[q] = un[q];
-                    if (i + 1 < 8) {
+                    for (int q = 0; q < 4; ++q) uc[q] = *reinterpret_cast<const uint4*>(ltile + rpos[q]);
+                    __builtin_amdgcn_wave_barrier();
+                    float vv[16];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) un[q] = reinterpret_cast<const uint4*>(ubase + (long long)(i + 1) * 16 * p.ldu)[q];
-                    }
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vv[j * 4 + r] = ai[j][r] * p.alpha;
+                    geglu_bwd_store16(vv, uc, reinterpret_cast<uint4*>(dbase + (long long)i * 16 * p.ldc2));
+                };
+                uload(0, sa0, sa1, sa2, sa3); uload(1, sb0, sb1, sb2, sb3);
+                ustep(0, acc[0], sa0, sa1, sa2, sa3, sc0, sc1, sc2, sc3);
+                ustep(1, acc[1], sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+                ustep(2, acc[2], sc0, sc1, sc2, sc3, sb0, sb1, sb2, sb3);
+                ustep(3, acc[3], sa0, sa1, sa2, sa3, sc0, sc1, sc2, sc3);
+                ustep(4, acc[4], sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+                ustep(5, acc[5], sc0, sc1, sc2, sc3, sb0, sb1, sb2, sb3);
+                ustep(6, acc[6], sa0, sa1, sa2, sa3, sc0, sc1, sc2, sc3);
+                ustep(7, acc[7], sb0, sb1, sb2, sb3, sa0, sa1, sa2, sa3);
+            } else if (!LT && m0 + 256 <= p.M && n0 + BN <= p.N) {
+                // full tile, direct form (the one-tile ring): a queue of u row fragments that grows as the accumulator registers of finished
+                // fragments come free (three in flight at the start, four from fragment 1 on; one fragment ahead: 1302 us, this: 1273 us on the
+                // persistent ring before it took the coalesced form above).  sched_barriers keep the compiler from hoisting the loads into a spill.
+                const bf16_t* ubase = p.Uin + ((long long)m0 + wm * 128 + fr) * p.ldu + 2 * nb;
+                bf16_t* dbase = p.C2 + ((long long)m0 + wm * 128 + fr) * p.ldc2 + 2 * nb;
+                uint4 ub[8][4];
+                auto uload = [&](int f) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ub[f][q] = reinterpret_cast<const uint4*>(ubase + (long long)f * 16 * p.ldu)[q];
+                };
+                uload(0); uload(1); uload(2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i == 1) { uload(3); uload(4); }
+                    if (i >= 2 && i + 3 < 8) uload(i + 3);
+                    __builtin_amdgcn_sched_barrier(0);
                     float vv[16];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[i][j][r] * p.alpha;
-                    geglu_bwd_store16(vv, uc, reinterpret_cast<uint4*>(dbase + (long long)i * 16 * p.ldc2));
+                    geglu_bwd_store16(vv, ub[i], reinterpret_cast<uint4*>(dbase + (long long)i * 16 * p.ldc2));
                 }
             } else
 #pragma unroll
@@ -1169,7 +1222,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256p_kernel(GemmArgs p) {
             slot = (slot + 1) & (NS - 1);
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();                               // rows back in step: both run their epilogues together
-        nt256_epilogue<EPI, F16, 4>(p, acc, m0, n0, wm, wn, lane, oC);
+        nt256_epilogue<EPI, F16, 4, EPI == 5>(p, acc, m0, n0, wm, wn, lane, oC, smem + NS * STG + wave * 4096);   // (EPI 5: 8 x 4 KiB of u tiles behind the ring, see the launcher)
         if (!has_next) break;
         ns_prev = (m0 + 256 <= p.M && n0 + 256 <= p.N) ? ns_full : 0;
 #pragma unroll
@@ -3011,8 +3064,9 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
 #define EPI5 5
         if (nt_persistent(q.tiles_m * q.tiles_n, d->K, q.dbg)) {               // one workgroup per CU walks the tile list (gemm_nt_256p_kernel)
             dim3 gp(nt_persistent_grid(), 1);
+            const size_t l2p = l2 + (epi == 5 ? (size_t)8 * 4096 : 0);             // EPI 5: the waves' u tiles behind the ring (160 KiB in all)
 #define F16_TAIL , true
-            F16_LAUNCH(gemm_nt_256p_kernel, gp, b2, l2, );
+            F16_LAUNCH(gemm_nt_256p_kernel, gp, b2, l2p, );
 #undef F16_TAIL
         }
 #define F16_TAIL , 4, 4, 1, true

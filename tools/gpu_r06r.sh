@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 6, call r: fp16 GEGLU-backward epilogue with two row fragments of u in flight: tests, standalone time, the step
+mkdir -p gpurun_out; export PYTHONUNBUFFERED=1 TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_named_size.py -q -x -k "geglu or fp16_gradient or f16 or bit_reproducible" --tb=short 2>&1 | tail -n 8 > gpurun_out/r06r_test.txt; cat gpurun_out/r06r_test.txt
+python tools/gemm_skew_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-80 | tee gpurun_out/r06r_probe.txt
+BA="--steps 6 --warmup 2 --no-cpu-baseline --no-tokenizer --no-parity"
+for rnd in 1 2; do
+  timeout 600 python bench.py $BA 2>/dev/null | tail -n 1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print(round(d['ms_per_step'], 1), 'ms', round(d['value']), 'tok/s', {k: round(v['ms_per_step'], 1) for k, v in d['roofline']['families'].items()})" | tee -a gpurun_out/r06r_bench.txt
+done
