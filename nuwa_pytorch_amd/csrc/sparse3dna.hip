@@ -1626,6 +1626,8 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
 // fragment and V as the rows), dW_th partial, dP = W^T dP', ds = P (dP - sum P dP), dq = scale * ds . K (band apply over K);
 // ds and P' go to the fp32 workspace for the key-side kernel, the <bos> key / value partials to part_k0 / part_v0.
 // LDS: R1 = SP (P) until ds exists, then the 8 transposed K tiles | DP | RED [8][64] | PM0 [W][NH]
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+constexpr float S3Q_DPS = 0.015625f;      // factor on dP' (and everything derived from it up to ds) in the fp16-gradient form: see the item pass
 template <bool BIAS, bool G16 = false>     // G16: the fp16-gradient form (S3Args::gs2)
 __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      // (4 waves per SIMD = two workgroups per CU: <= 128 registers)
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W, inner = NH * DH;
@@ -1669,7 +1671,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
     //  apply sweep, bit 3 the dW_th partial; results are garbage)
     if (!(a.dbg & 1)) {
     mfma_band_scores_staged<G16>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, BIAS ? a.scale : 1.f, BIAS ? a.bias : nullptr, stile);   // scores (raw products unless a bias table is added: see rowm_softmax)
-    mfma_band_scores_staged<G16>(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, 1.f, nullptr, stile);         // dP'[g] = dO[g] . v_j[g]  (G16: times S, as everything derived from it below)
+    mfma_band_scores_staged<G16>(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, G16 ? S3Q_DPS : 1.f, nullptr, stile);   // dP'[g] = dO[g] . v_j[g]  (G16: times S * 2^-6, as everything derived from it up to ds)
     }
     __syncthreads();
     // recomputing key side: this kernel leaves (row max, 1 / row sum, delta) per (query, head) instead of the ds / P' workspace
@@ -1685,7 +1687,73 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
     // The separate dW_th pass (thread = one (g, h) pair walking all 736 items: 2 LDS reads + ~8 index instructions per FMA) was the
     // largest block of this kernel (probe: -224 us of 1838 with it skipped, tools/attn_probe.py); here it costs 64 FMAs per item on
     // values that are in registers anyway.  Absent queries hold dP' = 0 (their dO fragment is zero) and add nothing.
-    if (!a.sep_passes) {
+    if constexpr (G16) {
+        // Round 6, the item pass on the MATRIX pipe (fp16-gradient form only: there dP' carries the gradient scale S and sits in fp16's range; the
+        // band sweep above wrote it times 2^-6 -- 64 products of |S dO| <= 2^10 -- and ds below takes the factor back).  A wave takes 32 items
+        // (query, slot) at a time as the B operand of v_mfma_f32_16x16x16_f16: lane (n, kg) holds heads 4 (kg & 1) .. + 3 of item 16 (kg >> 1) + n,
+        // one ds_read_b128 of the table.  The A operand is the 8 x 8 mix matrix twice on the diagonal of a 16 x 16 block (rows / k 0..7: the
+        // first 16 items, 8..15: the second 16), as an fp16 hi + lo pair so that only dP' (and P in the pack pass) is rounded:
+        //     D[h | 8 + h][item] = sum_g W[g][h] dP'[g][item]      -- and lane (n, kg) of D is again (item, heads 4 (kg & 1) .. + 3): stored in place.
+        // dW_th[g][h] = sum over the items of dP'[g] P[h] contracts over the ITEMS: A = dP' of head (m & 7) for 4 items, B = P of head (n & 7)
+        // for the same 4 items (scalar table reads, their order rotated per lane group so that the 32 lanes of an LDS pass hit 32 banks); rows /
+        // columns 0..7 run on the first 16 items of the group and 8..15 on the second, the two diagonal blocks of the accumulator are the two
+        // partial sums.  Against the VALU pass it replaces: 192 FMAs and 48 LDS reads of W per item -> 5 MFMAs per 32 items.
+        const int lane = t & 63, wv = t >> 6, n16 = lane & 15, kg = lane >> 4, sset = n16 >> 3, kh = kg & 1;
+        const bool on = (n16 < 8) == (kg < 2);
+        f16x4_t awt_hi, awt_lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float wt = on ? wsh[(4 * kh + i) * NH + (n16 & 7)] : 0.f;          // A[r = h][k = g] = W[g][h]
+            const _Float16 h16 = (_Float16)wt;
+            awt_hi[i] = h16; awt_lo[i] = (_Float16)(wt - (float)h16);
+        }
+        const int nitems = W * J, ngrp = (nitems + 31) >> 5;
+        f32x4 CW = {0.f, 0.f, 0.f, 0.f};
+        float dp_amax = 0.f;
+        for (int G = wv; G < ngrp && !(a.dbg & 128); G += 8) {
+            {   // dW_th operands first: this group's dP' is overwritten below
+                const int ib0 = 32 * G + 16 * sset + 4 * kg;
+                float avf[4], bvf[4];
+#pragma unroll
+                for (int ts = 0; ts < 4; ++ts) {
+                    const int item = ib0 + ((ts + sset + 2 * kh) & 3);
+                    const bool ok = item < nitems;
+                    const int idx = s3m_item(ok ? item : 0, rJ) + (n16 & 7);
+                    avf[ts] = ok ? DP[idx] : 0.f;
+                    bvf[ts] = ok ? SP[idx] : 0.f;
+                }
+                const f16x4_t av = __builtin_bit_cast(f16x4_t, make_uint2(pack2_f16_sat(avf[0], avf[1]), pack2_f16_sat(avf[2], avf[3])));
+                const f16x4_t bv = __builtin_bit_cast(f16x4_t, make_uint2(pack2_f16(bvf[0], bvf[1]), pack2_f16(bvf[2], bvf[3])));
+                CW = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, CW, 0, 0, 0);
+            }
+            const int item = 32 * G + 16 * (kg >> 1) + n16;
+            const bool ok = item < nitems;
+            const int ib = s3m_item(ok ? item : 0, rJ) + 4 * kh;
+            const float4 d4 = *reinterpret_cast<const float4*>(DP + ib);
+            // (dP' x 2^-6 leaves for fp16 through the saturating, counted converter: every table entry passes here exactly once)
+            const f16x4_t df = __builtin_bit_cast(f16x4_t, make_uint2(pack2_f16_sat_n(d4.x, d4.y, dp_amax), pack2_f16_sat_n(d4.z, d4.w, dp_amax)));
+            f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+            rr = __builtin_amdgcn_mfma_f32_16x16x16f16(awt_hi, df, rr, 0, 0, 0);
+            rr = __builtin_amdgcn_mfma_f32_16x16x16f16(awt_lo, df, rr, 0, 0, 0);
+            if (ok) *reinterpret_cast<float4*>(DP + ib) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        }
+        f16_sat_commit(dp_amax);
+        // the wave's dW_th: diagonal block (g, h) of lane (h, kg < 2) + block (8 + g, 8 + h) of lane (8 + h, kg + 2) = lane + 40
+        float tw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tw[i] = CW[i] + __shfl(CW[i], (lane + 40) & 63, 64);
+        if (n16 < 8 && kg < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) RED[wv * 64 + (4 * kg + i) * NH + n16] = tw[i] * (1.f / S3Q_DPS);
+        }
+        __syncthreads();
+        if (t < NH * NH) {
+            float sum = 0.f;
+            for (int k = 0; k < 8; ++k) sum += RED[k * 64 + t];
+            pth[t] = sum;
+        }
+        __syncthreads();
+    } else if (!a.sep_passes) {
         // two sweeps over the items so that only 32 of the 64 dW_th partial sums are live at a time (with all 64 next to the mix
         // operands the compiler spills ~130 registers at the 128-register budget of two workgroups per CU):
         //   sweep 0: P' (-> global, PM0) and dW_th rows g = 0..3;   sweep 1: dW_th rows g = 4..7 and dP (in place of dP')
@@ -1859,7 +1927,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
                 if (j < J) {
                     const int idx = w * TS + j * NH + h;
                     float dsv = pv[k] * (dv[k] - d);
-                    if constexpr (G16) { ds_amax = fmaxf(ds_amax, fabsf(dsv)); dsv = f16_clamp(dsv); }
+                    if constexpr (G16) { dsv *= 1.f / S3Q_DPS; ds_amax = fmaxf(ds_amax, fabsf(dsv)); dsv = f16_clamp(dsv); }
                     DP[idx] = dsv;
                     if (i < a.ntok && !gst && !a.packed && !(a.dbg & 2)) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
                 }
@@ -1872,7 +1940,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
         for (int j = cc; j < J; j += 4) {
             const int idx = w * TS + j * NH + h;
             float dsv = SP[idx] * (DP[idx] - d);
-            if constexpr (G16) { ds_amax = fmaxf(ds_amax, fabsf(dsv)); dsv = f16_clamp(dsv); }
+            if constexpr (G16) { dsv *= 1.f / S3Q_DPS; ds_amax = fmaxf(ds_amax, fabsf(dsv)); dsv = f16_clamp(dsv); }
             DP[idx] = dsv;
             if (i < a.ntok && !gst && !a.packed) a.ds[(((size_t)b * nq + (i - 1)) * J + j) * NH + h] = dsv;
         }
@@ -1884,7 +1952,52 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
     // fp32 form wrote P' as two 16-byte stores in the item pass above and ds as twelve scattered 4-byte stores per thread in the ds pass: 1.98 GB
     // per call at b = 128, read back by the key side with two 4-byte loads per coefficient.  Same values as before: the key side rounded both to
     // bf16 (round to nearest even) for its MFMA operands anyway, so dK / dV do not change by a bit.  P' is mixed here (the item pass skips it).
-    if (a.packed) {
+    if constexpr (G16) {
+        // pack pass of the fp16-gradient form on the matrix pipe: P' = W P for 32 items per MFMA pair (same operand shape as the item pass above),
+        // lane (n, kg) ends with P'[4 (kg & 1) .. + 3] of its item next to the ds it reads from the table: four (fp16 S ds | fp16 P') words, ONE
+        // 16-byte store.  P' of the <bos> slot also goes to PM0.  Entries the key side never reads are not written (see the VALU form below).
+        const int lane = t & 63, wv = t >> 6, n16 = lane & 15, kg = lane >> 4, kh = kg & 1;
+        const bool on = (n16 < 8) == (kg < 2);
+        f16x4_t aw_hi, aw_lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ww = on ? wsh[(n16 & 7) * NH + 4 * kh + i] : 0.f;            // A[r = g][k = h] = W[g][h]
+            const _Float16 h16 = (_Float16)ww;
+            aw_hi[i] = h16; aw_lo[i] = (_Float16)(ww - (float)h16);
+        }
+        const int ta0 = max(0, a.kf - 1 - f / a.df), tb0 = max(0, a.kh - 1 - y / a.dh);
+        const float rkw = 1.f / (float)a.kw, rkh = 1.f / (float)a.kh;
+        const int nitems = W * J, ngrp = (nitems + 31) >> 5;
+        for (int G = wv; G < ngrp && !(a.dbg & 512); G += 8) {
+            const int item = 32 * G + 16 * (kg >> 1) + n16;
+            const bool ok = item < nitems;
+            const int itc = ok ? item : 0;
+            const int wq = (int)(((float)itc + 0.5f) * rJ), j = itc - wq * J;
+            const int iq = 1 + ry * W + wq;
+            bool keep = false;
+            if (j > 0) {
+                const int pl = (int)(((float)(j - 1) + 0.5f) * rkw), tc = j - 1 - pl * a.kw;
+                const int ta = (int)(((float)pl + 0.5f) * rkh), tb = pl - ta * a.kh;
+                keep = ta >= ta0 && tb >= tb0 && wq - (a.kw - 1 - tc) * a.dw >= 0;
+            }
+            const int ib = itc * NH + wq * S3M_PAD + 4 * kh;
+            const float4 p4 = *reinterpret_cast<const float4*>(SP + ib);
+            const float4 s4 = *reinterpret_cast<const float4*>(DP + ib);
+            const f16x4_t pf = __builtin_bit_cast(f16x4_t, ok ? make_uint2(pack2_f16(p4.x, p4.y), pack2_f16(p4.z, p4.w)) : make_uint2(0u, 0u));
+            f32x4 pm = {0.f, 0.f, 0.f, 0.f};
+            pm = __builtin_amdgcn_mfma_f32_16x16x16f16(aw_hi, pf, pm, 0, 0, 0);
+            pm = __builtin_amdgcn_mfma_f32_16x16x16f16(aw_lo, pf, pm, 0, 0, 0);
+            if (ok && j == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) PM0[wq * NH + 4 * kh + i] = iq < a.ntok ? pm[i] : 0.f;
+            }
+            if (ok && iq < a.ntok && keep && !(a.dbg & 2)) {
+                uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(a.pm) + (((size_t)b * nq + (iq - 1)) * J + j) * NH + 4 * kh);
+                *dst = make_uint4(pack2_f16(s4.x, pm[0]), pack2_f16(s4.y, pm[1]), pack2_f16(s4.z, pm[2]), pack2_f16(s4.w, pm[3]));
+            }
+        }
+        __syncthreads();                                                          // P is dead: its region now holds the K tiles
+    } else if (a.packed) {
         const float* wv = wsh;
         // entries the key side never reads are not written: slots of planes that lie before the grid for this row (ta < ta0 or tb < tb0, as in
         // rowm_planes: 78 % of the slots at dilation 4) and taps whose key column would be negative.  The key side walks the attending query

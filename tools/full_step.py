@@ -60,7 +60,8 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(f'[{A.get_precision()}] full NUWA step (text encoder + VAE tokenizer + decoder fwd/bwd{" + clip + AdamW" if opt else ""}), cfg 3, b={b}, {'fused' if ops.FUSE_LINEAR_CE_X3 is True else ('auto' if ops.FUSE_LINEAR_CE_X3 else 'unfused')} logits + CE: {dt * 1e3:.1f} ms/step, '
+    ce_form = 'fused' if ops.FUSE_LINEAR_CE_X3 is True else ('auto' if ops.FUSE_LINEAR_CE_X3 else 'unfused')
+    print(f'[{A.get_precision()}] full NUWA step (text encoder + VAE tokenizer + decoder fwd/bwd{" + clip + AdamW" if opt else ""}), cfg 3, b={b}, {ce_form} logits + CE: {dt * 1e3:.1f} ms/step, '
           f'{2560 * b / dt:.0f} video-tokens/s, loss {float(loss.detach()):.4f}, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB')
 
 
