@@ -551,8 +551,19 @@ def main():
                     par[mode] = {'error': f'{type(e).__name__}: {e}'}
             try:
                 with open(os.path.join(ROOT, 'profiles', 'parity_sweep.json')) as f:
-                    par['worst_of_8'] = json.load(f)
-            except (OSError, ValueError):
+                    sweep = json.load(f)
+                # the committed sweep (tools/parity_sweep.py on the round's evidence box): the 8 samples the 1e-3 bound is asserted on -- two
+                # random initialisations x 3 samples + the mild trained-like model x 2 -- in the shipped two-MFMA class set; the harsh
+                # trained-like model (recorded, not asserted: DESIGN.md section 2) beside it
+                x2 = ''.join(sorted(K._PROJ_F16X2)) if hasattr(K, '_PROJ_F16X2') else 'oq'
+                rows = [r for r in sweep if r.get('mode') == 'bf16x3-fwd' and ''.join(sorted(r.get('two_mfma') or '')) == x2]
+                harsh = [r for r in rows if 'tails x4' in r['model']]
+                eight = [r for r in rows if 'tails x4' not in r['model']]
+                par['worst_of_8'] = {'source': 'profiles/parity_sweep.json', 'samples': len(eight),
+                                     'logits_rel_max': max(r['rel_max'] for r in eight), 'logits_rel_l2': max(r['rel_l2'] for r in eight),
+                                     'worst_sample': max(eight, key=lambda r: r['rel_max'])['model'],
+                                     'harsh_trained_like_rel_max_not_asserted': max((r['rel_max'] for r in harsh), default=None)}
+            except (OSError, ValueError, KeyError):
                 par['worst_of_8'] = None
             try:
                 gr = layer_grad_parity(A, c)

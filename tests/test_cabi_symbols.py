@@ -91,7 +91,7 @@ def test_profiles_readme_lists_only_files_that_exist():
 
 def test_committed_pmc_traffic_belongs_to_the_current_gemm_kernels():
     """bench.py refuses a PMC traffic figure taken on other kernel sources (roofline.traffic = null).  The figure of the headline
-    configuration must therefore be re-taken (tools/gpu_final_r05.sh; copy gpurun_out/<TAG>_traffic.json over profiles/traffic.json)
+    configuration must therefore be re-taken (tools/gpu_final_r06.sh; copy gpurun_out/<TAG>_traffic.json over profiles/traffic.json)
     whenever csrc/gemm.hip changes: a stale file fails HERE, not silently in the round's final bench line."""
     import hashlib
     import json
