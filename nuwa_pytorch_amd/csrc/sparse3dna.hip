@@ -841,6 +841,7 @@ struct RowM {
     size_t tok0;                                // first token row of the sample
     int tsel[4];                                // tap index linking query c to key 4*g4 + r (the same in every plane), or -1
     const int *pslot, *ptok;                    // valid planes: first key slot j, token row of key 0
+    int vps, vpt;                               // ... and the same lists with plane p in LANE p of a register (read back with v_readlane: see mfma_band_scores_fast)
 };
 constexpr int S3M_NH = 8, S3M_DH = 64, S3M_W = 16;
 // Workgroup order inside a sample (a.ymajor; tuning key 3 bit 1 restores the frame-major order).  The ~64 workgroups an XCD runs
@@ -930,6 +931,8 @@ __device__ __forceinline__ RowM rowm_init(const S3Args& a, int b, int ry, const 
     r.iq = 1 + ry * S3M_W + r.c;
     r.qok = r.iq < a.ntok;
     r.pslot = pslot; r.ptok = ptok;
+    r.vps = r.lane < r.nplanes ? pslot[r.lane] : 0;
+    r.vpt = r.lane < r.nplanes ? ptok[r.lane] : 0;
     // Which tap (if any) links query c to each of the lane's 4 keys 4*g4 + r: the same for every plane, so all of the band
     // logic of the sweeps is decided here once.
 #pragma unroll
@@ -1131,6 +1134,158 @@ __device__ __forceinline__ void mfma_band_apply(const S3Args& a, const RowM& r, 
         const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pack2_t<F16>(pf[0], pf[1]), pack2_t<F16>(pf[2], pf[3]),
                                                                  pack2_t<F16>(pf[4], pf[5]), pack2_t<F16>(pf[6], pf[7])));
         __builtin_amdgcn_wave_barrier();                                          // LDS is in-order per wave: the tile is complete
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db] + 2048));
+            const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            O[db] = mfma16<F16>(__builtin_bit_cast(bf16x8, v8), pb, O[db]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- round 6: the two single-row sweeps with their address arithmetic taken out of the plane loop ----------------------------------------------
+// The ISA of mfma_band_scores_staged / mfma_band_apply spent, per plane and wave: an LDS read of the plane's slot / token (a wave-uniform value
+// fetched through a VGPR), four v_mul_lo_u32 + shifts + adds for the four table addresses, two v_mad_i64_i32 + v_lshl_add_u64 for the two row
+// addresses and an exec-masked branch around each load -- about half of the sweep's ~80 instructions, on a chip where a VALU instruction costs
+// ~4 cycles of its SIMD (profiles/r06w_geglu_pmc.txt).  Here: the plane lists sit in one register each (plane p in lane p, v_readlane with the
+// loop counter), the key rows are addressed as a wave-uniform 64-bit base + a 32-bit byte offset = (plane's first token) x (row bytes) [scalar]
+// + a per-lane constant, a plane whose 16 rows all exist (every plane but the last row of a sample) loads without a mask, and a table address
+// is ONE v_mad_u32_u24 (slot x 32 bytes or x 0, + the lane's base address).  Same loads, same MFMAs, same stores, same values.
+typedef __attribute__((address_space(3))) float lds_f32_t;
+__device__ __forceinline__ unsigned lds_byte_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ void lds_st32(unsigned addr, float v) { *reinterpret_cast<lds_f32_t*>((size_t)addr) = v; }
+__device__ __forceinline__ float lds_ld32(unsigned addr) { return *reinterpret_cast<const lds_f32_t*>((size_t)addr); }
+__device__ __forceinline__ uint4 ldg_u4(const char* sb, unsigned off) { return *reinterpret_cast<const uint4*>(sb + off); }
+
+template <bool F16>
+__device__ __forceinline__ void mfma_band_scores_fast(const S3Args& a, const RowM& r, const bf16_t* rows, int ldr, const bf16_t* frag, int ldf,
+                                                      int h, float* TAB, float mul, char* tile) {
+    constexpr int NH = S3M_NH, DH = S3M_DH;
+    const bf16_t* qrow = frag + (r.tok0 + r.iq) * ldf + h * DH + r.g4 * 8;
+    const bf16x8 qf0 = ldg8(qrow, r.qok), qf1 = ldg8(qrow + 32, r.qok);
+    const int gc = r.lane & 7, r8 = r.lane >> 3;
+    const char* sb = reinterpret_cast<const char*>(rows + r.tok0 * ldr + __builtin_amdgcn_readfirstlane(h) * DH);   // wave-uniform (h = the wave's index: said so, it stays in scalar registers)
+    const unsigned ldb = (unsigned)ldr * 2u;
+    const unsigned vb = (unsigned)gc * 16u, v0 = (unsigned)r8 * ldb + vb, v1 = v0 + 8u * ldb;
+    const unsigned tab0 = lds_byte_addr(TAB);
+    const int spb = r.c * r.TS + h;
+    unsigned wb4[4], wm4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool on = r.tsel[q] >= 0 && r.qok;
+        wb4[q] = tab0 + 4u * (unsigned)(on ? spb + r.tsel[q] * NH : r.c * r.TS + r.J * NH + r.g4);   // (off: the lane's own pad word of the table row)
+        wm4[q] = on ? 4u * NH : 0u;
+    }
+    const int w0 = vt_off(r8, gc), w1 = vt_off(r8 + 8, gc);
+    const int f0 = vt_off(r.c, r.g4), f1 = vt_off(r.c, 4 + r.g4);
+    constexpr int PF = S3M_PF;
+    static_assert(PF == 3, "the sweep below names its three register sets");
+    auto issue = [&](int sq, uint4& d0, uint4& d1) {
+        if (sq > r.nplanes) return;                                                          // (past the end: the register set is never consumed)
+        if (sq == 0) { d0 = ldg_u4(sb, vb); d1 = d0; return; }                               // sequence 0: every row is token 0 (<bos>)
+        const int base = __builtin_amdgcn_readlane(r.vpt, sq - 1);
+        const unsigned so = (unsigned)base * ldb;
+        if (base + 16 <= a.ntok) { d0 = ldg_u4(sb, so + v0); d1 = ldg_u4(sb, so + v1); }
+        else {
+            d0 = base + r8 < a.ntok ? ldg_u4(sb, so + v0) : make_uint4(0, 0, 0, 0);
+            d1 = base + r8 + 8 < a.ntok ? ldg_u4(sb, so + v1) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    uint4 sa0 = make_uint4(0, 0, 0, 0), sa1 = sa0, sb0 = sa0, sb1 = sa0, sc0 = sa0, sc1 = sa0;
+    issue(0, sa0, sa1); issue(1, sb0, sb1); issue(2, sc0, sc1);
+    auto step = [&](int sq, uint4& d0, uint4& d1) {
+        *reinterpret_cast<uint4*>(tile + w0) = d0;
+        *reinterpret_cast<uint4*>(tile + w1) = d1;
+        issue(sq + PF, d0, d1);
+        __builtin_amdgcn_wave_barrier();
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(tile + f0), k1 = *reinterpret_cast<const bf16x8*>(tile + f1);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        sc = mfma16<F16>(k0, qf0, sc);
+        sc = mfma16<F16>(k1, qf1, sc);
+        __builtin_amdgcn_wave_barrier();
+        if (sq == 0) {
+            if (r.g4 == 0 && r.qok) lds_st32(tab0 + 4u * (unsigned)spb, sc[0] * mul);
+        } else {
+            const unsigned jb = (unsigned)__builtin_amdgcn_readlane(r.vps, sq - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lds_st32(__umul24(jb, wm4[q]) + wb4[q], sc[q] * mul);
+        }
+    };
+    for (int sq = 0; sq <= r.nplanes; sq += 3) {
+        step(sq, sa0, sa1);
+        if (sq + 1 <= r.nplanes) step(sq + 1, sb0, sb1);
+        if (sq + 2 <= r.nplanes) step(sq + 2, sc0, sc1);
+    }
+}
+
+template <bool F16>
+__device__ __forceinline__ void mfma_band_apply_fast(const S3Args& a, const RowM& r, const bf16_t* rows, int ldr, int g, const float* TAB,
+                                                     char* tile, f32x4 (&O)[4]) {
+    constexpr int NH = S3M_NH, DH = S3M_DH;
+    const int spb = r.c * r.TS + g;
+    {   // <bos> slot
+        const float p0 = r.qok ? TAB[spb] : 0.f;
+        const bf16_t* vb = rows + r.tok0 * ldr + g * DH + 4 * r.g4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const uint2 u = *reinterpret_cast<const uint2*>(vb + db * 16);
+            O[db] = f32x4{p0 * lo_t<F16>(u.x), p0 * hi_t<F16>(u.x), p0 * lo_t<F16>(u.y), p0 * hi_t<F16>(u.y)};
+        }
+    }
+    const int gc = r.lane & 7, r8 = r.lane >> 3;
+    const char* sb = reinterpret_cast<const char*>(rows + r.tok0 * ldr + __builtin_amdgcn_readfirstlane(g) * DH);   // wave-uniform
+    const unsigned ldb = (unsigned)ldr * 2u;
+    const unsigned v0 = (unsigned)r8 * ldb + (unsigned)gc * 16u, v1 = v0 + 8u * ldb;
+    const unsigned tab0 = lds_byte_addr(TAB);
+    int woff[4], troff[4];
+    unsigned sidx4[4];
+    bool on[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) woff[i] = vt_off(r8 + 8 * i, gc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        on[q] = r.tsel[q] >= 0 && r.qok;
+        sidx4[q] = tab0 + 4u * (unsigned)(spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH);
+    }
+    {
+        const int r0 = 4 * r.g4 + (r.c >> 2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const int col = db * 16 + ((r.c & 3) << 2);
+            troff[db] = vt_off(r0, col >> 3) + ((col >> 2) & 1) * 8;
+        }
+    }
+    uint4 st[4];
+    auto fetch2 = [&](int pj, uint4& d0, uint4& d1) {                                       // the 16 rows of plane pj: this lane's two pieces
+        if (pj >= r.nplanes) { d0 = d1 = make_uint4(0, 0, 0, 0); return; }                   // (the odd plane of the last pair: its rows must be zeros)
+        const int base = __builtin_amdgcn_readlane(r.vpt, pj);
+        const unsigned so = (unsigned)base * ldb;
+        if (base + 16 <= a.ntok) { d0 = ldg_u4(sb, so + v0); d1 = ldg_u4(sb, so + v1); }
+        else {
+            d0 = base + r8 < a.ntok ? ldg_u4(sb, so + v0) : make_uint4(0, 0, 0, 0);
+            d1 = base + r8 + 8 < a.ntok ? ldg_u4(sb, so + v1) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    fetch2(0, st[0], st[1]); fetch2(1, st[2], st[3]);
+    for (int pi = 0; pi < r.nplanes; pi += 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + woff[i]) = st[i];
+        const unsigned jb0 = 4u * NH * (unsigned)__builtin_amdgcn_readlane(r.vps, pi);
+        const bool two = pi + 1 < r.nplanes;
+        const unsigned jb1 = two ? 4u * NH * (unsigned)__builtin_amdgcn_readlane(r.vps, pi + 1) : jb0;
+        if (pi + 2 < r.nplanes) { fetch2(pi + 2, st[0], st[1]); fetch2(pi + 3, st[2], st[3]); }   // the next chunk's rows are in flight below
+        float pf[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = lds_ld32(sidx4[j] + jb0), x1 = lds_ld32(sidx4[j] + jb1);
+            pf[j] = on[j] ? x0 : 0.f;
+            pf[4 + j] = (on[j] && two) ? x1 : 0.f;
+        }
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pack2_t<F16>(pf[0], pf[1]), pack2_t<F16>(pf[2], pf[3]),
+                                                                 pack2_t<F16>(pf[4], pf[5]), pack2_t<F16>(pf[6], pf[7])));
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db]));
@@ -1670,8 +1825,13 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
     // (a.dbg, tuning key 17: timing probes only -- bit 0 skips the two score sweeps, bit 1 the ds / P' workspace stores, bit 2 the dq
     //  apply sweep, bit 3 the dW_th partial; results are garbage)
     if (!(a.dbg & 1)) {
+    if constexpr (!BIAS) {
+    mfma_band_scores_fast<G16>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, 1.f, stile);                   // scores (raw products: see rowm_softmax)
+    mfma_band_scores_fast<G16>(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, G16 ? S3Q_DPS : 1.f, stile); // dP'[g] = dO[g] . v_j[g]  (G16: times S * 2^-6, as everything derived from it up to ds)
+    } else {
     mfma_band_scores_staged<G16>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, BIAS ? a.scale : 1.f, BIAS ? a.bias : nullptr, stile);   // scores (raw products unless a bias table is added: see rowm_softmax)
-    mfma_band_scores_staged<G16>(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, G16 ? S3Q_DPS : 1.f, nullptr, stile);   // dP'[g] = dO[g] . v_j[g]  (G16: times S * 2^-6, as everything derived from it up to ds)
+    mfma_band_scores_staged<G16>(a, r, a.v, a.ld, a.dO, a.lddo, r.wave, DP, G16 ? S3Q_DPS : 1.f, nullptr, stile);   // dP'[g] = dO[g] . v_j[g]
+    }
     }
     __syncthreads();
     // recomputing key side: this kernel leaves (row max, 1 / row sum, delta) per (query, head) instead of the ds / P' workspace
@@ -2040,7 +2200,7 @@ __global__ __launch_bounds__(512, 4) void s3_bwd_q_mfma_kernel(S3Args a) {      
     {
         const int h = r.wave;
         f32x4 O[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        if (!(a.dbg & 4)) mfma_band_apply<G16>(a, r, a.k, a.ld, h, DP, smem + r.wave * 4096, O);
+        if (!(a.dbg & 4)) mfma_band_apply_fast<G16>(a, r, a.k, a.ld, h, DP, smem + r.wave * 4096, O);
         if (r.qok) {
             bf16_t* orow = a.dq + (r.tok0 + r.iq) * a.ldd + h * DH + 4 * r.g4;
             float amax = 0.f;
