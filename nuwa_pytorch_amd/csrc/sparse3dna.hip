@@ -2335,7 +2335,52 @@ __global__ __launch_bounds__(512, 2) void s3_bwd_kv_mfma_kernel(S3Args a) {
     uint4 sq[4], sd[4];
     float cs[8], cp[8];                                                          // ds / P' coefficients of the 8 (plane, query) slots
     uint32_t cw[8];                                                              // ... or (PACKED) their (bf16 ds | bf16 P') words
+    // Round 6 (PACKED form): the plane lists in one register each (plane p in lane p, v_readlane with the loop counter), q / dO rows and
+    // workspace words addressed as a wave-uniform base + a 32-bit byte offset = a scalar term of the plane + a per-lane constant, planes
+    // whose 16 query rows all exist fetched without a mask (see mfma_band_scores_fast; the form before it spent a 64-bit multiply-add chain
+    // per row piece and per coefficient word: 16 of them per pair of planes and lane).
+    const int vps = lane < nplanes ? pslot[lane] : 0, vpt = lane < nplanes ? ptok[lane] : 0;
+    const int hu = __builtin_amdgcn_readfirstlane(h);
+    const char* sbq = reinterpret_cast<const char*>(a.q + tok0 * a.ld + hu * DH);
+    const char* sbd = reinterpret_cast<const char*>(a.dO + tok0 * a.lddo + hu * DH);
+    const char* sbw = reinterpret_cast<const char*>(reinterpret_cast<const uint32_t*>(a.pm) + (size_t)b * nq * J * NH + hu);
+    const unsigned ldqb = (unsigned)a.ld * 2u, lddb = (unsigned)a.lddo * 2u;
+    const unsigned vq0 = (unsigned)r8 * ldqb + (unsigned)gc * 16u, vq1 = vq0 + 8u * ldqb;
+    const unsigned vd0 = (unsigned)r8 * lddb + (unsigned)gc * 16u, vd1 = vd0 + 8u * lddb;
+    unsigned cj[4];                                                              // ((4 g4 + j) J + tap) words of 32 bytes: the lane's part of a coefficient's offset
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cj[j] = 32u * (unsigned)((4 * g4 + j) * J + (tsel[j] < 0 ? 0 : tsel[j]));
     auto fetch = [&](int pi) {
+        if constexpr (PACKED) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int pj = pi + kb;
+                if (pj >= nplanes) {                                              // (uniform: the odd plane of the last pair)
+                    sq[2 * kb] = sq[2 * kb + 1] = sd[2 * kb] = sd[2 * kb + 1] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cw[kb * 4 + j] = 0u;
+                    continue;
+                }
+                const int base = __builtin_amdgcn_readlane(vpt, pj < 64 ? pj : 63);
+                const unsigned soq = (unsigned)base * ldqb, sod = (unsigned)base * lddb;
+                const unsigned sw = 32u * (unsigned)((base - 1) * J + __builtin_amdgcn_readlane(vps, pj < 64 ? pj : 63));
+                const bool nof = (a.dbg & 32) != 0, nog = (a.dbg & 16) != 0;
+                if (base + 16 <= a.ntok && !nof && !nog) {
+                    sq[2 * kb] = ldg_u4(sbq, soq + vq0); sq[2 * kb + 1] = ldg_u4(sbq, soq + vq1);
+                    sd[2 * kb] = ldg_u4(sbd, sod + vd0); sd[2 * kb + 1] = ldg_u4(sbd, sod + vd1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cw[kb * 4 + j] = tsel[j] >= 0 ? *reinterpret_cast<const uint32_t*>(sbw + (sw + cj[j])) : 0u;
+                } else {
+                    const bool ok0 = base + r8 < a.ntok && !nof, ok1 = base + r8 + 8 < a.ntok && !nof;
+                    sq[2 * kb] = ok0 ? ldg_u4(sbq, soq + vq0) : make_uint4(0, 0, 0, 0); sq[2 * kb + 1] = ok1 ? ldg_u4(sbq, soq + vq1) : make_uint4(0, 0, 0, 0);
+                    sd[2 * kb] = ok0 ? ldg_u4(sbd, sod + vd0) : make_uint4(0, 0, 0, 0); sd[2 * kb + 1] = ok1 ? ldg_u4(sbd, sod + vd1) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        cw[kb * 4 + j] = (tsel[j] >= 0 && base + 4 * g4 + j < a.ntok && !nog) ? *reinterpret_cast<const uint32_t*>(sbw + (sw + cj[j])) : 0u;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pj = pi + (i >> 1);
