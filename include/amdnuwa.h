@@ -37,16 +37,16 @@ int amdnuwa_abi_version(void);                 /* bumps when any signature or do
                                                 *     ab_f16 on the whole-M TN kernel with alpha_dev in its direct epilogue, c_f16 on the two-MFMA NT product) */
 const char* amdnuwa_error_string(int code);
 /* runtime tuning knobs (A/B benchmarking only; 0 = the library's auto policy everywhere):
- *   key 0  NT GEMM variant: 1 direct-to-LDS BK 64, 2 direct-to-LDS BK 32, 3 / 4 256x256 tile with a 4- / 3-stage DMA ring,
- *          5 register-staged 128x128
+ *   key 0  NT GEMM variant: 2 direct-to-LDS BK 32 (128x128 tiles), 5 register-staged 128x128, 7 the 256x256 ring family for every size,
+ *          11 its K-step 64 form with staggered wave rows, 12 the four-wave long-K kernel for every K % 64 == 0
+ *          (1, 3, 4, 6, 8, 9, 10: A/B variants of rounds 2-4, removed in round 6 -- 1 runs as 2, 10 as 0, the others as 7)
  *   key 1  TN split-K workgroup slots        key 2  TN minimum token rows per split
  *   key 3  Sparse3DNA forward: 1 = keep the VALU (dot2) kernel        key 13 hi + lo NT GEMM: 1 = first-generation 128x128 kernel
  *   key 4  Sparse3DNA backward: 1 = VALU kernels, 2 = MFMA query side + VALU key side, 4 = MFMA query side + RECOMPUTING MFMA key side
  *          (no ds / P' workspace: 1.5x instead of 2.85x the algorithmic HBM bytes, 15-22 % slower; 0 = MFMA kernels with the workspace)
  *   key 5  cross-attention forward: 1 = generic (not unrolled) kernel
  *   key 6  TN GEMM variant: 1 register-staged, 2 direct-to-LDS 128x128, 3 256x256 ring
- *   key 7  NT probe: bit 0 skips the epilogue stores, bit 1 skips the main loop (tools/gemm_probe.py; results are garbage); with key 0 = 9
- *          also bit 2 MFMAs, bit 3 LDS fragment reads, bit 4 in-loop DMA pieces (tools/gemm_w4_parts.py)
+ *   key 7  NT probe: bit 0 skips the epilogue stores, bit 1 skips the main loop (tools/gemm_probe.py; results are garbage)
  *   key 8  TN 256x256 ring: 2 = staggered wave rows instead of the lock-step schedule
  *   key 9  3DNA MFMA forward probe: bits 0 / 1 / 2 skip the score / softmax+mix / apply phase (garbage results), bit 3 = fragment-shaped
  *          key loads in the score pass instead of the staged ones
@@ -64,12 +64,8 @@ const char* amdnuwa_error_string(int code);
  *   key 24 Sparse3DNA MFMA backward workspace: 0 = ONE array of (bf16 ds | bf16 P') words (round 5), 1 = the two fp32 arrays (same dK / dV bits)
  *   key 25 batched narrow TN (N <= 64, 128 < M <= 384: the cross attention's dK / dV): 1 = 128-row tiles instead of one workgroup per batch element,
  *          2 = always through the split-K reduction (no direct store of a one-split result)
- * (keys run 0..31; key 0 also takes 10 / 11 = the K-step 64 forms of the 256x256 ring (lock-step / staggered wave rows: full 128-byte
- *  DMA lines, two 64 KiB stages; `auto` uses 11 for 1024 <= K < 2048); key 14 < 0 with key 0 = 6 delays the second workgroup of a CU;
- *  key 7 bit 6 issues a tile's stores inside the main loop (probe))
- * (key 0 also takes 6 = 256x128 tile, two workgroups per CU, 7 = 256x256 ring with staggered wave rows, 8 = 7 + DMA issue inside the
- *  MFMA phase, 9 = 256x256 tile on FOUR waves of 128x128 (plain fp32 / bf16 outputs only, else 7; opt-in: DESIGN.md 5n);
- *  any non-zero key 0 disables the few-row weight-streaming path that M <= 32 normally takes) */
+ * (keys run 0..31; the K-step 64 form of the 256x256 ring stages full 128-byte DMA lines in two 64 KiB stages, `auto` uses it for
+ *  1024 <= K < 2048; any non-zero key 0 disables the few-row weight-streaming path that M <= 32 normally takes) */
 int amdnuwa_set_tuning(int key, int value);
 /* fp16 saturation monitor: number of threads (since the last reset) that handed a value beyond +-65504 to one of the library's saturating
  * COUNTED fp16 stores: the LayerNorm fp16 copies, the fp16-gradient epilogues (GEMM EPI 4 / 5, LayerNorm backward) and the fp16 copy of

@@ -1235,230 +1235,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_256p_kernel(GemmArgs p) {
     }
 }
 
-// Epilogue of the four-wave 256x256 tiles (2 x 2 waves of 128x128): acc[column half][row fragment][column fragment]; plain fp32 (EPI 0) or
-// bf16 (EPI 1) outputs
-template <int EPI>
-__device__ __forceinline__ void w4_epilogue(const GemmArgs& p, const f32x4 (&acc)[2][8][4], int m0, int n0, int wm, int wn, int lane, long long oC) {
-    const int fr = lane & 15, fg = lane >> 4;
-    const bool skip = (p.dbg & 1) != 0;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int ncol0 = n0 + (wn * 2 + c) * 64;
-        if constexpr (EPI == 0) {
-            const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0);
-            float biasf[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = ncol0 + j * 16 + fg * 4 + r;
-                    const bool in = p.bias != nullptr && n < p.N;
-                    const float bvv = (p.bias ? p.bias : reinterpret_cast<const float*>(g_zero_page))[in ? n : 0];
-                    biasf[j][r] = in ? bvv : 0.f;
-                }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
-                if (m >= p.M) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = ncol0 + j * 16 + fg * 4;
-                    if (n >= p.N) continue;
-                    if (skip && acc[c][i][j][0] != 12345.678f) continue;
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[c][i][j][r] * p.alpha + biasf[j][r];
-                    float* C = reinterpret_cast<float*>(p.C) + oC + m * p.ldc + n;
-                    if (vec_ok) *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
-                    else
-                        for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
-                }
-            }
-        } else {
-            // lane (fr, fg) owns row m = .. + fr and the 16 contiguous columns nb + [j * 4 + r] (permuted B rows, as the 8-wave kernel)
-            const bool vec8 = (p.N % 8 == 0) && (p.ldc % 8 == 0);
-            const int nb = ncol0 + fg * 16;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const long long m = (long long)m0 + wm * 128 + i * 16 + fr;
-                if (m >= p.M || nb >= p.N) continue;
-                if (skip && acc[c][i][0][0] != 12345.678f) continue;
-                float vv[16];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[j * 4 + r] = acc[c][i][j][r] * p.alpha;
-                bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + oC + m * p.ldc + nb;
-                if (vec8 && nb + 16 <= p.N) {
-                    reinterpret_cast<uint4*>(C)[0] = make_uint4(pack2_rne(vv[0], vv[1]), pack2_rne(vv[2], vv[3]), pack2_rne(vv[4], vv[5]), pack2_rne(vv[6], vv[7]));
-                    reinterpret_cast<uint4*>(C)[1] = make_uint4(pack2_rne(vv[8], vv[9]), pack2_rne(vv[10], vv[11]), pack2_rne(vv[12], vv[13]), pack2_rne(vv[14], vv[15]));
-                } else {
-                    for (int e = 0; e < 16 && nb + e < p.N; ++e) C[e] = f2bf(vv[e]);
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// NT, 256x256 tile, FOUR waves (2 x 2, 128x128 each), K-step 32, 4-stage LDS-DMA ring.
-// Why: every MFMA of the 8-wave layout above takes 0.375 KiB of fragments out of LDS (12 ds_read_b128 per 32 MFMAs for a 128x64
-// wave tile) -- 96 B/clk per CU at the matrix pipe's rate, which the LDS does not deliver next to the DMA writes: its main loop
-// measures 42-44 % of the MFMA peak with the stores skipped (tools/gemm_probe.py).  A 128x128 wave tile needs 16 reads per 64
-// MFMAs = 0.25 KiB per MFMA = 64 B/clk.  One wave per SIMD, so the overlap is inside the wave: fragments are reloaded from tile kt+1
-// as soon as their last MFMA of K-step kt has been issued (rolling, single-buffered: a register double buffer of 2 x 64 next to
-// 256 accumulators sent the allocator into spills), and the 8 DMA pieces per wave of tile kt+4 go out one after every 4 MFMAs of
-// the second half.  256 accumulator registers (AGPRs) + 64 fragment registers.
-// Accumulation order per output element = the 8-wave kernel's (k ascending in chunks of 32): bit-identical results.
-// ---------------------------------------------------------------------------------------------
-// PROBE: the instantiation tools/gemm_w4_parts.py runs (tuning key 7 bits 2-4 switch MFMAs / fragment reads / in-loop DMA off)
-template <int EPI, bool F16 = false, bool PROBE = false>
-__global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NS = 4;
-    constexpr int TB = 256 * 32 * 2;             // A tile: 16 KiB per stage (B likewise)
-    constexpr int STG = 2 * TB;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int lid = xcd_remap(blockIdx.x, nwg);
-    const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
-    const int m0 = tm * 256, n0 = tn * 256;
-    const long long bz = blockIdx.y;
-    const long long oA = boff(p, bz, p.sA, p.sA_in), oB = boff(p, bz, p.sB, p.sB_in), oC = boff(p, bz, p.sC, p.sC_in);
-    const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
-
-    // this wave's DMA pieces: pieces j * 4 + wave (j = 0..3) of the A and of the B tile; a piece = 16 rows x 32 k (1 KiB).  Source =
-    // a wave-uniform base (SGPR pair, advanced by 64 bytes per K-step with scalar adds) + a constant per-lane byte offset: one
-    // instruction per piece and no vector arithmetic inside the loop.  Rows past M / N are CLAMPED to the last row instead of read
-    // from a zero page: they only feed output rows / columns that are never stored.
-    const unsigned lds0 = (unsigned)(size_t)(lds_vptr_t)smem;
-    const char* baseA = reinterpret_cast<const char*>(p.A + oA + (long long)m0 * p.lda);
-    const char* baseB = reinterpret_cast<const char*>(p.B + oB + (long long)n0 * p.ldb);
-    unsigned offa[4], offb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (j * 4 + wave) * 16 + (lane >> 2);
-        const int ra = min(row, p.M - 1 - m0), rb = min(row, p.N - 1 - n0);
-        offa[j] = (unsigned)((ra * p.lda + ((lane & 3) ^ glds_swz<32>(row)) * 8) * 2);
-        offb[j] = (unsigned)((rb * p.ldb + ((lane & 3) ^ b256_swz<EPI>(row)) * 8) * 2);
-    }
-    auto issue_piece = [&](int q, int slot, int k0) {            // q = 0..3: A pieces, 4..7: B pieces
-        const char* sb = (q < 4 ? baseA : baseB) + (size_t)k0 * 2;
-        const unsigned long long sbu = (unsigned long long)sb;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sbu), hi = __builtin_amdgcn_readfirstlane((unsigned)(sbu >> 32));
-        const unsigned long long sbase = ((unsigned long long)hi << 32) | lo;
-        const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds0 + slot * STG + (q < 4 ? 0 : TB) + ((q & 3) * 4 + wave) * 1024);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(q < 4 ? offa[q & 3] : offb[q & 3]), "s"(sbase), "s"(lds_addr)
-                     : "memory", "m0");
-    };
-
-    f32x4 acc[2][8][4];                          // [column half][row fragment][column fragment]
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (p.dbg & 2) ? 0 : p.K / 32;
-    const int fr = lane & 15, fg = lane >> 4;
-    // Rolling single-buffered fragments: a K-step runs its 64 MFMAs as two column halves.  After the first half the B fragments of that
-    // half are dead and are reloaded from tile kt+1; during the second half each A fragment is reloaded right after its last MFMA; the
-    // second half's B fragments are reloaded at the end and have the whole next first half to arrive.
-    // The fragment reads are INLINE ASM with "v" operands and explicit, counted lgkmcnt waits: left to the compiler, the reads land in
-    // AGPRs (gfx950 LDS loads may target them), the 64 accumulator tuples get shuffled around them (60-200 v_accvgpr_mov per K-step)
-    // and every loop iteration starts with lgkmcnt(0) although the four youngest reads are not needed for another 32 MFMAs.
-    const bool nomfma = PROBE && (p.dbg & 4) != 0, nord = PROBE && (p.dbg & 8) != 0, nodma = PROBE && (p.dbg & 16) != 0;
-    bf16x8 af[8], bfr[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) af[i] = bfr[i] = bf16x8{};
-    constexpr int JB = EPI >= 1 ? 256 : 1024;                    // byte step between a lane's B fragments j, j + 1 (b256_row)
-    const unsigned la = lds0 + glds_off<32>(wm * 128 + fr, fg);
-    const unsigned lb = lds0 + TB + b256_off<EPI>(wn * 128 + b256_row<EPI>(0, fr), fg);
-#define W4_RD(DST, ADDR, OFF) do { if (!nord) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(DST) : "v"(ADDR), "n"(OFF)); } while (0)
-#define W4_READ_B_LO(ADDR) do { W4_RD(bfr[0], ADDR, 0); W4_RD(bfr[1], ADDR, JB); W4_RD(bfr[2], ADDR, 2 * JB); W4_RD(bfr[3], ADDR, 3 * JB); } while (0)
-#define W4_READ_B_HI(ADDR) do { W4_RD(bfr[4], ADDR, 4096); W4_RD(bfr[5], ADDR, 4096 + JB); W4_RD(bfr[6], ADDR, 4096 + 2 * JB); W4_RD(bfr[7], ADDR, 4096 + 3 * JB); } while (0)
-    // row i of the first half needs the first-half B fragments (the oldest reads) and A fragment i: 7 - i younger A reads and the four
-    // second-half B reads may still be in flight
-#define W4_WAIT_ROW(I, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(af[I]), "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]))
-#define W4_WAIT_ALL() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[4]), "+v"(bfr[5]), "+v"(bfr[6]), "+v"(bfr[7]) :: "memory")
-    for (int s_ = 0; s_ < NS; ++s_)
-        if (s_ < nk) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) issue_piece(q, s_, s_ * 32);
-        }
-    if (nk > 0) {
-        if (nk >= 4) VMCNT(24); else if (nk == 3) VMCNT(16); else if (nk == 2) VMCNT(8); else VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-        W4_READ_B_LO(lb);
-        W4_RD(af[0], la, 0); W4_RD(af[1], la, 1024); W4_RD(af[2], la, 2048); W4_RD(af[3], la, 3072);
-        W4_RD(af[4], la, 4096); W4_RD(af[5], la, 5120); W4_RD(af[6], la, 6144); W4_RD(af[7], la, 7168);
-        W4_READ_B_HI(lb);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#define W4_FROW(I, N)                                                                                         \
-    do {                                                                                                      \
-        W4_WAIT_ROW(I, N);                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-        if (!nomfma) { _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[0][I][j] = mfma16<F16>(bfr[j], af[I], acc[0][I][j]); } \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-    } while (0)
-#define W4_FIRST_HALF()                                                                                       \
-    do {                                                                                                      \
-        W4_FROW(0, 11); W4_FROW(1, 10); W4_FROW(2, 9); W4_FROW(3, 8); W4_FROW(4, 7); W4_FROW(5, 6); W4_FROW(6, 5); W4_FROW(7, 4); \
-    } while (0)
-#define W4_ROW(I, NEXT_, MORE_)                                                                               \
-    do {                                                                                                      \
-        if (!nomfma) { _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[1][I][j] = mfma16<F16>(bfr[4 + j], af[I], acc[1][I][j]); } \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-        if (NEXT_) W4_RD(af[I], a1, (I) * 1024);                                                              \
-        if (MORE_ && !nodma) issue_piece(I, kt % NS, (kt + NS) * 32);                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-    } while (0)
-    int kt = 0;
-    for (; kt + NS < nk; ++kt) {                 // steady state: tiles kt+1 .. kt+3 in flight, tile kt+4 goes out in this step
-        W4_FIRST_HALF();
-        // tile kt+1 landed (this wave's pieces; tiles kt+2, kt+3 may fly) and every wave's reads of tile kt are complete: its slot is free
-        VMCNT(16);
-        W4_WAIT_ALL();
-        __builtin_amdgcn_s_barrier();
-        const unsigned so = (unsigned)(((kt + 1) % NS) * STG), a1 = la + so, b1 = lb + so;
-        W4_READ_B_LO(b1);
-        __builtin_amdgcn_sched_barrier(0);
-        W4_ROW(0, true, true); W4_ROW(1, true, true); W4_ROW(2, true, true); W4_ROW(3, true, true);
-        W4_ROW(4, true, true); W4_ROW(5, true, true); W4_ROW(6, true, true); W4_ROW(7, true, true);
-        W4_READ_B_HI(b1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (; kt < nk; ++kt) {                      // the last NS steps: nothing left to issue
-        const bool next = kt + 1 < nk;
-        W4_FIRST_HALF();
-        const int rem = nk - 1 - kt;
-        if (rem >= 3) VMCNT(16); else if (rem == 2) VMCNT(8); else VMCNT(0);
-        W4_WAIT_ALL();
-        __builtin_amdgcn_s_barrier();
-        const unsigned so = (unsigned)(((kt + 1) % NS) * STG), a1 = la + so, b1 = lb + so;
-        if (next) W4_READ_B_LO(b1);
-        __builtin_amdgcn_sched_barrier(0);
-        W4_ROW(0, next, false); W4_ROW(1, next, false); W4_ROW(2, next, false); W4_ROW(3, next, false);
-        W4_ROW(4, next, false); W4_ROW(5, next, false); W4_ROW(6, next, false); W4_ROW(7, next, false);
-        if (next) W4_READ_B_HI(b1);
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#undef W4_RD
-#undef W4_READ_B_LO
-#undef W4_READ_B_HI
-#undef W4_WAIT_ROW
-#undef W4_FROW
-#undef W4_WAIT_ALL
-#undef W4_FIRST_HALF
-#undef W4_ROW
-
-    w4_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, oC);
-}
+// (round 6: gemm_nt_w4_kernel -- the four-wave K-step 32 predecessor of gemm_nt_w4k_kernel, reachable through tuning key 0 = 9 only -- and its
+//  epilogue were removed; docs/DESIGN_history_r1-r4.md section 5v describes it)
 
 // ---------------------------------------------------------------------------------------------
 // NT, 256x256 tile, bf16x3: every operand a bf16 hi + lo pair, three MFMAs per product (lo*hi + hi*lo + hi*hi, the small
@@ -3032,24 +2810,10 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
     } while (0)
         // (EPI5: the GEGLU-backward epilogue exists on the persistent ring and the plain ring only; elsewhere the name stands for EPI 4 and is never reached)
 #define EPI5 4
-        if (g_amdnuwa_tuning[0] == 6 && epi < 4) {  // probe: 256x128 tile, 3-stage ring, TWO workgroups per CU (one's epilogue under the other's main loop)
-            q.tiles_n = (d->N + 127) / 128;
-            q.skew = g_amdnuwa_tuning[14] < 0 ? g_amdnuwa_tuning[14] : 0;
-            const size_t l6 = (size_t)3 * (256 + 128) * 32 * 2;
-            dim3 g6(q.tiles_m * q.tiles_n, 1), b6(256);
-#define F16_TAIL , 3, 2, 0, true
-            F16_LAUNCH(gemm_nt_256_kernel, g6, b6, l6, false,);
-#undef F16_TAIL
-        }
         const size_t l64 = (size_t)2 * 2 * 256 * 64 * 2;
         dim3 g2(q.tiles_m * q.tiles_n, 1), b2(512);
         if (epi != 5 && (g_amdnuwa_tuning[0] == 11 || (g_amdnuwa_tuning[0] == 0 && d->K >= 1024 && d->K < 2048))) {     // K-step 64 form with staggered wave rows (FF2: -9 %)
 #define F16_TAIL , 1, 4, 4, true
-            F16_LAUNCH(gemm_nt_256_kernel, g2, b2, l64, false,);
-#undef F16_TAIL
-        }
-        if (epi != 5 && g_amdnuwa_tuning[0] == 10) { // K-step 64 form: full 128-byte lines through the DMA ring, two 64 KiB stages
-#define F16_TAIL , 1, 4, 3, true
             F16_LAUNCH(gemm_nt_256_kernel, g2, b2, l64, false,);
 #undef F16_TAIL
         }
@@ -3136,37 +2900,6 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         LAUNCH_CHECK();
         return AMDNUWA_OK;
     }
-    if (!x3 && (variant == 3 || variant == 4) && d->K % 32 == 0) {        // 256x256 tile, 4- / 3-stage DMA ring
-        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
-        dim3 g256(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b256(512);
-#define G256(SH, EP, NS_)                                                                                             \
-    do {                                                                                                              \
-        const size_t l256 = (size_t)NS_ * 2 * 256 * 32 * 2;                                                           \
-        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<SH, EP, NS_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l256); \
-        hipLaunchKernelGGL((gemm_nt_256_kernel<SH, EP, NS_, 4>), g256, b256, l256, stream, p);                            \
-    } while (0)
-        if (variant == 3) { if (sh) { if (ob) G256(true, 1, 4); else G256(true, 0, 4); } else { if (ob) G256(false, 1, 4); else G256(false, 0, 4); } }
-        else              { if (sh) { if (ob) G256(true, 1, 3); else G256(true, 0, 3); } else { if (ob) G256(false, 1, 3); else G256(false, 0, 3); } }
-#undef G256
-        LAUNCH_CHECK();
-        return AMDNUWA_OK;
-    }
-    if (!x3 && !sh && variant == 9 && d->K % 32 == 0 && !d->C2 && !d->Clo && !(ob && d->bias)) {    // 4 waves x 128x128 (probe)
-        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
-        dim3 g4(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b4(256);
-        const size_t l4 = (size_t)4 * 2 * 256 * 32 * 2;
-#define W4_LAUNCH(EP, PR)                                                                                            \
-    do {                                                                                                              \
-        (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<EP, false, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4); \
-        hipLaunchKernelGGL((gemm_nt_w4_kernel<EP, false, PR>), g4, b4, l4, stream, p);                                  \
-    } while (0)
-        const bool probe = (p.dbg & 28) != 0;
-        if (ob) { if (probe) W4_LAUNCH(1, true); else W4_LAUNCH(1, false); }
-        else    { if (probe) W4_LAUNCH(0, true); else W4_LAUNCH(0, false); }
-#undef W4_LAUNCH
-        LAUNCH_CHECK();
-        return AMDNUWA_OK;
-    }
     if (!x3 && !sh && variant == 12 && d->K % 64 == 0 && !d->C2 && !d->Clo && !(ob && d->bias)) {   // 4 waves x 128x128, K-step 64, 1.5-iteration prefetch
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         dim3 g4(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b4(256);
@@ -3181,8 +2914,8 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         LAUNCH_CHECK();
         return AMDNUWA_OK;
     }
-    if (variant == 12) variant = 7;
-    if (variant == 9) variant = 7;
+    if (variant == 12 || variant == 9 || variant == 8 || variant == 6 || variant == 3 || variant == 4) variant = 7;   // (3 / 4 / 6 / 8 / 9: probe variants of rounds 2-4, removed in round 6)
+    if (variant == 1) variant = 2;
     // K-step 64 form with staggered wave rows (two 64 KiB stages of full 128-byte row lines): measured ahead of the K-step 32 ring on the
     // K = 1376 / 1536 shapes only (FF2 -10 %, dgrad qkv -1.5 %; K = 512 shapes and K >= 2752 equal or slower: profiles/r04g_gemm_k64.txt), so `auto`
     // takes it for 1024 <= K < 2048; tuning key 0 = 11 forces it, 7 keeps the ring
@@ -3201,20 +2934,6 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         return AMDNUWA_OK;
     }
     if (variant == 11) variant = 7;
-    if (!x3 && variant == 8 && d->K % 32 == 0) {                           // staggered rows + DMA issue inside the MFMA phase
-        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
-        dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(512);
-#define GS2(SH, EP)                                                                                                   \
-    do {                                                                                                              \
-        const size_t l2 = (size_t)4 * 2 * 256 * 32 * 2;                                                               \
-        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<SH, EP, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
-        hipLaunchKernelGGL((gemm_nt_256_kernel<SH, EP, 4, 4, 2>), g2, b2, l2, stream, p);                              \
-    } while (0)
-        if (sh) { if (ob) GS2(true, 1); else GS2(true, 0); } else { if (ob) GS2(false, 1); else GS2(false, 0); }
-#undef GS2
-        LAUNCH_CHECK();
-        return AMDNUWA_OK;
-    }
     if (!x3 && variant == 7 && d->K % 32 == 0) {                           // 256x256 tile, 4-stage ring, staggered wave rows
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         if (d->C2) { p.C2 = (bf16_t*)d->C2; p.ldc2 = d->ldc2; p.Uin = (const bf16_t*)d->geglu_u; p.ldu = d->ld_u; }
@@ -3257,26 +2976,10 @@ extern "C" int amdnuwa_gemm_nt(const amdnuwa_gemm_desc* d, hipStream_t stream) {
         LAUNCH_CHECK();
         return AMDNUWA_OK;
     }
-    if (!x3 && variant == 6 && d->K % 32 == 0) {                           // 256x128 tile, 3-stage ring, two workgroups per CU
-        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 127) / 128;
-        dim3 g2(p.tiles_m * p.tiles_n, d->batch > 0 ? d->batch : 1), b2(256);
-#define G2(SH, EP)                                                                                                    \
-    do {                                                                                                              \
-        const size_t l2 = (size_t)3 * (256 + 128) * 32 * 2;                                                           \
-        (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<SH, EP, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
-        hipLaunchKernelGGL((gemm_nt_256_kernel<SH, EP, 3, 2>), g2, b2, l2, stream, p);                                 \
-    } while (0)
-        if (sh) { if (ob) G2(true, 1); else G2(true, 0); } else { if (ob) G2(false, 1); else G2(false, 0); }
-#undef G2
-        LAUNCH_CHECK();
-        return AMDNUWA_OK;
-    }
-    const int gbk = variant == 1 ? 64 : (variant == 2 ? 32 : 0);
-    if (!x3 && gbk && d->K % gbk == 0) {
-        const size_t gl = (size_t)2 * 2 * 128 * gbk * 2;
+    if (!x3 && variant == 2 && d->K % 32 == 0) {
+        const size_t gl = (size_t)2 * 2 * 128 * 32 * 2;
 #define GL_LAUNCH(BK__, SH, EP) hipLaunchKernelGGL((gemm_nt_glds_kernel<BK__, SH, EP>), grid, block, gl, stream, p)
-        if (gbk == 64) { if (sh) { if (ob) GL_LAUNCH(64, true, 1); else GL_LAUNCH(64, true, 0); } else { if (ob) GL_LAUNCH(64, false, 1); else GL_LAUNCH(64, false, 0); } }
-        else           { if (sh) { if (ob) GL_LAUNCH(32, true, 1); else GL_LAUNCH(32, true, 0); } else { if (ob) GL_LAUNCH(32, false, 1); else GL_LAUNCH(32, false, 0); } }
+        if (sh) { if (ob) GL_LAUNCH(32, true, 1); else GL_LAUNCH(32, true, 0); } else { if (ob) GL_LAUNCH(32, false, 1); else GL_LAUNCH(32, false, 0); }
 #undef GL_LAUNCH
         LAUNCH_CHECK();
         return AMDNUWA_OK;

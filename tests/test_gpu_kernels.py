@@ -705,29 +705,6 @@ def test_cross_attention_core(K, O, case, x3):
         report('xattn2_dnull_v' + tag, dnv2, nv.grad, 2 ** -6)
 
 
-@pytest.mark.parametrize('M,N,Kd,obf', [(2560, 512, 1536, True), (2560, 1536, 512, False), (1000, 6216, 96, False), (700, 1376, 512, True),
-                                        (513, 257 * 8, 32, True), (4096, 512, 2752, False)])
-def test_gemm_nt_four_wave_kernel_equals_the_ring(K, M, N, Kd, obf):
-    """tuning key 0 = 9 (256x256 tile on four waves of 128x128, rolling single-buffered fragments, rows past M / N clamped instead of
-    zero-filled) sums every output element in the order of the 8-wave ring: bit-identical results, ragged edges and short K included"""
-    from nuwa_pytorch_amd import _lib
-    L = _lib.lib()
-    torch.manual_seed(5)
-    A = K.BF((torch.randn(M, Kd, device=DEV) * 0.5).to(torch.bfloat16), None)
-    Bm = K.BF((torch.randn(N, Kd, device=DEV) * 0.5).to(torch.bfloat16), None)
-    outs = []
-    try:
-        for var in (7, 9):
-            L.amdnuwa_set_tuning(0, var)
-            o = K.gemm_nt(A, Bm, out_bf16=obf)
-            outs.append((o.hi if obf else o).float().clone())
-    finally:
-        L.amdnuwa_set_tuning(0, 0)
-    assert torch.equal(outs[0], outs[1])
-    ref = A.hi.float() @ Bm.hi.float().t()
-    report(f'gemm_nt_w4[{M}x{N}x{Kd}]', outs[1], ref, 2 ** -7 if obf else 1e-5)
-
-
 @pytest.mark.parametrize('M,N,Kd', [(2560, 512, 1536), (4096 + 77, 1536 + 24, 512), (300, 264, 64), (70000, 512, 2752), (2560 * 8, 2752, 1408),
                                     (2560 * 8, 512, 1376), (1000, 600, 96), (777, 512, 160)])       # (the last three: K % 64 == 32, the zeroed half iteration)
 def test_gemm_nt_long_k_kernel_equals_the_ring(K, M, N, Kd):

@@ -47,7 +47,7 @@ def main():
         A, Bm = mk(m, kk), mk(nn, kk)
         ref = None
         row = []
-        for var in (0, 5, 2, 4):      # 0 = auto, 5 = register-staged, 2 = glds BK32, 4 = 256x256 3-stage ring
+        for var in (0, 5, 2, 7):      # 0 = auto, 5 = register-staged, 2 = glds BK32, 7 = the 256x256 ring for every size
             L.amdnuwa_set_tuning(0, var)
             out = K.gemm_nt(A, Bm, out_bf16=obf, shift=(n, 16) if sh else None)
             o = out.hi.float() if obf else out

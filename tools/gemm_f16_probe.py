@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """The three fp16-operand forward GEMMs of 'bf16x3-fwd' at cfg-3 size (per-GPU batch b): default 256x256 ring (one workgroup per CU)
-against the 256x128 tile with two workgroups per CU (tuning key 0 = 6), and the epilogue / main-loop split (key 7)."""
+against the K-step 64 form with staggered wave rows (tuning key 0 = 11), and the epilogue / main-loop split (key 7); the 256x128 two-workgroup tile (key 0 = 6) and the lock-step K-step 64 form (10) it also compared were removed in round 6."""
 import os
 import sys
 
@@ -24,7 +24,7 @@ cases = [('qkv (bf16 + fp16 copies)', lambda: K.gemm_nt_f16ops(h16, wqkv, out_bf
 for name, fn, fl, by in cases:
     row = []
     ref = None
-    for var in (0, 10, 11, 0, 10, 11):
+    for var in (0, 11, 0, 11):
         L.amdnuwa_set_tuning(0, var)
         out = fn()
         cur = [t.float() for t in (((out.hi, out.f16) if hasattr(out, 'hi') else out) if isinstance(out, tuple) else (out,)) if t is not None]
@@ -34,7 +34,7 @@ for name, fn, fl, by in cases:
         for dbg in (0, 1):
             L.amdnuwa_set_tuning(7, dbg)
             t = bench(fn, 10)
-            row.append(f'{ {0: "K32 ring", 10: "K64 lock-step", 11: "K64 staggered"}[var]} {["full", "no-st"][dbg]} {t * 1e6:7.1f}' + ('' if same else ' MISMATCH'))
+            row.append(f'{ {0: "K32 ring", 11: "K64 staggered"}[var]} {["full", "no-st"][dbg]} {t * 1e6:7.1f}' + ('' if same else ' MISMATCH'))
         L.amdnuwa_set_tuning(7, 0)
     L.amdnuwa_set_tuning(0, 0)
     print(f'{name:40s} ' + ' | '.join(row))
