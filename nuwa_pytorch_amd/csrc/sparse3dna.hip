@@ -1446,6 +1446,7 @@ struct TileM {
     bool qok[ROWS];
     int tsel[4];
     const int *ktok, *kmeta;                     // key-row list: token row of key 0; meta = tap frame ta << 8 | (m + 64), y_key = y0 + m dh
+    int vkt, vkm;                                // the same list with entry e in LANE e of a register (nk <= 64: tile_band_scores_fast)
 };
 // tile t2 of a sample -> (frame, first row y0); the order keeps a residue class of y together (see s3m_row_order)
 template <int ROWS>
@@ -1486,6 +1487,8 @@ __device__ __forceinline__ TileM<ROWS> s3t_init(const S3Args& a, int b, int f, i
         r.qok[i] = i < nrows && r.iq[i] < a.ntok;
     }
     r.ktok = ktok; r.kmeta = kmeta;
+    r.vkt = r.lane < nk ? ktok[r.lane] : 0;
+    r.vkm = r.lane < nk ? kmeta[r.lane] : 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int d = r.c - (4 * r.g4 + q);
@@ -1685,6 +1688,185 @@ __device__ __forceinline__ void tile_band_apply(const S3Args& a, const TileM<ROW
     }
 }
 
+// ---- round 6: the tile sweeps with their address arithmetic out of the key-row loop (see mfma_band_scores_fast): key-row list by v_readlane
+// (nk <= 64), wave-uniform row base + 32-bit offsets, unmasked loads for key rows whose 16 tokens exist, one v_mad_u32_u24 per table address.
+// No bias table (the training kernels).  Same loads, MFMAs, stores and values as tile_band_scores / tile_band_apply.
+template <int ROWS, bool F16, int PF>
+__device__ __forceinline__ void tile_band_scores_fast(const S3Args& a, const TileM<ROWS>& r, const bf16_t* rows, int ldr, const bf16_t* frag,
+                                                      int ldf, int h, float* TAB, float mul, char* tile) {
+    constexpr int NH = S3M_NH, DH = S3M_DH;
+    bf16x8 qf0[ROWS], qf1[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const bf16_t* qrow = frag + (r.tok0 + (r.qok[i] ? r.iq[i] : 0)) * ldf + h * DH + r.g4 * 8;
+        qf0[i] = __builtin_bit_cast(bf16x8, ldg16_sel(qrow, r.qok[i]));
+        qf1[i] = __builtin_bit_cast(bf16x8, ldg16_sel(qrow + 32, r.qok[i]));
+    }
+    const int gc = r.lane & 7, r8 = r.lane >> 3;
+    const char* sb = reinterpret_cast<const char*>(rows + r.tok0 * ldr + __builtin_amdgcn_readfirstlane(h) * DH);   // wave-uniform
+    const unsigned ldb = (unsigned)ldr * 2u;
+    const unsigned vb = (unsigned)gc * 16u, v0 = (unsigned)r8 * ldb + vb, v1 = v0 + 8u * ldb;
+    const unsigned tab0 = lds_byte_addr(TAB);
+    const int spb = r.c * r.TS + h;
+    const int wpad = r.c * r.TS + r.J * NH + r.g4;                               // the lane's pad word of query c's table row
+    unsigned wb4[ROWS][4], wm4[ROWS][4];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool on = r.tsel[q] >= 0 && r.qok[i];
+            wb4[i][q] = tab0 + 4u * (unsigned)(i * r.WTS + (on ? spb + r.tsel[q] * NH : wpad));
+            wm4[i][q] = on ? 4u * NH : 0u;
+        }
+    const int w0 = vt_off(r8, gc), w1 = vt_off(r8 + 8, gc);
+    const int f0 = vt_off(r.c, r.g4), f1 = vt_off(r.c, 4 + r.g4);
+    auto issue = [&](int sq, uint4& d0, uint4& d1) {
+        if (sq > r.nk) return;                                                   // (past the end: the register set is never consumed)
+        if (sq == 0) { d0 = ldg_u4(sb, vb); d1 = d0; return; }                   // sequence 0: every row is token 0 (<bos>)
+        const int base = __builtin_amdgcn_readlane(r.vkt, sq - 1);
+        const unsigned so = (unsigned)base * ldb;
+        if (base + 16 <= a.ntok) { d0 = ldg_u4(sb, so + v0); d1 = ldg_u4(sb, so + v1); }
+        else {
+            d0 = base + r8 < a.ntok ? ldg_u4(sb, so + v0) : make_uint4(0, 0, 0, 0);
+            d1 = base + r8 + 8 < a.ntok ? ldg_u4(sb, so + v1) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto step = [&](int sq, uint4& d0, uint4& d1) {
+        *reinterpret_cast<uint4*>(tile + w0) = d0;
+        *reinterpret_cast<uint4*>(tile + w1) = d1;
+        issue(sq + PF, d0, d1);
+        __builtin_amdgcn_wave_barrier();
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(tile + f0), k1 = *reinterpret_cast<const bf16x8*>(tile + f1);
+        f32x4 sc[ROWS];
+        if (sq == 0) {
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                if (i >= r.nrows) continue;
+                sc[i] = mfma16<F16>(k1, qf1[i], mfma16<F16>(k0, qf0[i], f32x4{0.f, 0.f, 0.f, 0.f}));
+            }
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i)
+                if (i < r.nrows && r.g4 == 0 && r.qok[i]) lds_st32(tab0 + 4u * (unsigned)(i * r.WTS + spb), sc[i][0] * mul);
+        } else {
+            const int meta = __builtin_amdgcn_readlane(r.vkm, sq - 1), ta = meta >> 8, m = (meta & 255) - 64;
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                const int tb = m - i + a.kh - 1;
+                if (i >= r.nrows || tb < 0 || tb >= a.kh) continue;              // (wave-uniform)
+                sc[i] = mfma16<F16>(k1, qf1[i], mfma16<F16>(k0, qf0[i], f32x4{0.f, 0.f, 0.f, 0.f}));
+            }
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                const int tb = m - i + a.kh - 1;
+                if (i >= r.nrows || tb < 0 || tb >= a.kh) continue;
+                const unsigned jb = (unsigned)(1 + (ta * a.kh + tb) * a.kw);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lds_st32(__umul24(jb, wm4[i][q]) + wb4[i][q], sc[i][q] * mul);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    static_assert(PF == 3 || PF == 4, "named register sets");
+    uint4 sa0 = make_uint4(0, 0, 0, 0), sa1 = sa0, sb0 = sa0, sb1 = sa0, sc0 = sa0, sc1 = sa0, sd0 = sa0, sd1 = sa0;
+    issue(0, sa0, sa1); issue(1, sb0, sb1); issue(2, sc0, sc1);
+    if (PF == 4) issue(3, sd0, sd1);
+    for (int sq = 0; sq <= r.nk; sq += PF) {
+        step(sq, sa0, sa1);
+        if (sq + 1 <= r.nk) step(sq + 1, sb0, sb1);
+        if (sq + 2 <= r.nk) step(sq + 2, sc0, sc1);
+        if (PF == 4 && sq + 3 <= r.nk) step(sq + 3, sd0, sd1);
+    }
+}
+
+template <int ROWS, bool F16>
+__device__ __forceinline__ void tile_band_apply_fast(const S3Args& a, const TileM<ROWS>& r, const bf16_t* rows, int ldr, int g, const float* TAB,
+                                                     char* tile, f32x4 (&O)[ROWS][4]) {
+    constexpr int NH = S3M_NH, DH = S3M_DH;
+    const int spb = r.c * r.TS + g;
+    {   // <bos> slot
+        const bf16_t* vb = rows + r.tok0 * ldr + g * DH + 4 * r.g4;
+        uint2 u[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) u[db] = *reinterpret_cast<const uint2*>(vb + db * 16);
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const float p0 = r.qok[i] ? TAB[i * r.WTS + spb] : 0.f;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                O[i][db] = f32x4{p0 * lo_t<F16>(u[db].x), p0 * hi_t<F16>(u[db].x), p0 * lo_t<F16>(u[db].y), p0 * hi_t<F16>(u[db].y)};
+        }
+    }
+    const int gc = r.lane & 7, r8 = r.lane >> 3;
+    const char* sb = reinterpret_cast<const char*>(rows + r.tok0 * ldr + __builtin_amdgcn_readfirstlane(g) * DH);   // wave-uniform
+    const unsigned ldb = (unsigned)ldr * 2u;
+    const unsigned v0 = (unsigned)r8 * ldb + (unsigned)gc * 16u, v1 = v0 + 8u * ldb;
+    const unsigned tab0 = lds_byte_addr(TAB);
+    int woff[4], troff[4];
+    unsigned sidx4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) woff[i] = vt_off(r8 + 8 * i, gc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sidx4[q] = tab0 + 4u * (unsigned)(spb + (r.tsel[q] < 0 ? 0 : r.tsel[q]) * NH);
+    {
+        const int r0 = 4 * r.g4 + (r.c >> 2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const int col = db * 16 + ((r.c & 3) << 2);
+            troff[db] = vt_off(r0, col >> 3) + ((col >> 2) & 1) * 8;
+        }
+    }
+    uint4 st[4];
+    auto fetch2 = [&](int pj, uint4& d0, uint4& d1) {
+        if (pj >= r.nk) { d0 = d1 = make_uint4(0, 0, 0, 0); return; }           // (the odd entry of the last pair: its rows must be zeros)
+        const int base = __builtin_amdgcn_readlane(r.vkt, pj);
+        const unsigned so = (unsigned)base * ldb;
+        if (base + 16 <= a.ntok) { d0 = ldg_u4(sb, so + v0); d1 = ldg_u4(sb, so + v1); }
+        else {
+            d0 = base + r8 < a.ntok ? ldg_u4(sb, so + v0) : make_uint4(0, 0, 0, 0);
+            d1 = base + r8 + 8 < a.ntok ? ldg_u4(sb, so + v1) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    fetch2(0, st[0], st[1]); fetch2(1, st[2], st[3]);
+    for (int pi = 0; pi < r.nk; pi += 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + woff[i]) = st[i];
+        const int meta0 = __builtin_amdgcn_readlane(r.vkm, pi), meta1 = pi + 1 < r.nk ? __builtin_amdgcn_readlane(r.vkm, pi + 1) : -1;
+        if (pi + 2 < r.nk) { fetch2(pi + 2, st[0], st[1]); fetch2(pi + 3, st[2], st[3]); }
+        const int ta0 = meta0 >> 8, m0 = (meta0 & 255) - 64, ta1 = meta1 >> 8, m1 = (meta1 & 255) - 64;
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 A[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + troff[db] + 2048));
+            const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            A[db] = __builtin_bit_cast(bf16x8, v8);
+        }
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int tb0 = m0 - i + a.kh - 1, tb1 = m1 - i + a.kh - 1;
+            const bool u0 = i < r.nrows && tb0 >= 0 && tb0 < a.kh, u1 = i < r.nrows && meta1 >= 0 && tb1 >= 0 && tb1 < a.kh;
+            if (!(u0 || u1)) continue;                                            // (wave-uniform)
+            const unsigned rb = 4u * (unsigned)(i * r.WTS);
+            const unsigned jb0 = rb + 4u * NH * (unsigned)(1 + (ta0 * a.kh + (u0 ? tb0 : 0)) * a.kw);
+            const unsigned jb1 = u1 ? rb + 4u * NH * (unsigned)(1 + (ta1 * a.kh + tb1) * a.kw) : jb0;
+            float pf[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = r.tsel[j] >= 0 && r.qok[i];
+                const float x0 = lds_ld32(sidx4[j] + jb0), x1 = lds_ld32(sidx4[j] + jb1);
+                pf[j] = (on && u0) ? x0 : 0.f;
+                pf[4 + j] = (on && u1) ? x1 : 0.f;
+            }
+            const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pack2_t<F16>(pf[0], pf[1]), pack2_t<F16>(pf[2], pf[3]),
+                                                                     pack2_t<F16>(pf[4], pf[5]), pack2_t<F16>(pf[6], pf[7])));
+#pragma unroll
+            for (int db = 0; db < 4; ++db) O[i][db] = mfma16<F16>(A[db], pb, O[i][db]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int ROWS, bool F16, bool BIAS>      // BIAS: a.bias != NULL (the relative-position bias of cfg 5; compiled out of the training kernels otherwise)
 __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3Args a) {
     constexpr int NH = S3M_NH, DH = S3M_DH, W = S3M_W;
@@ -1724,7 +1906,10 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
     s3t_keylist<ROWS>(a, f, y0, ktok, kmeta, kcnt);
     const TileM<ROWS> r = s3t_init<ROWS>(a, b, f, y0, nrows, ktok, kmeta, kcnt[0]);
     if (!(a.dbg & 1))     // (a.dbg, tuning key 9: bits 0 / 1 / 2 skip the score / softmax + mix / apply phase -- timing probes, garbage results)
-        tile_band_scores<ROWS, F16, ROWS >= 4 ? 4 : S3M_PF>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, BIAS ? a.scale : 1.f, BIAS ? a.bias : nullptr, vt_base + r.wave * 4096);
+    {
+        if (!BIAS && r.nk <= 64) tile_band_scores_fast<ROWS, F16, ROWS >= 4 ? 4 : S3M_PF>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, 1.f, vt_base + r.wave * 4096);
+        else tile_band_scores<ROWS, F16, ROWS >= 4 ? 4 : S3M_PF>(a, r, a.k, a.ld, a.q, a.ld, r.wave, SP, BIAS ? a.scale : 1.f, BIAS ? a.bias : nullptr, vt_base + r.wave * 4096);
+    }
     __syncthreads();
     for (int i = 0; i < nrows && !(a.dbg & 2); ++i) rowm_softmax(SP + i * WTS, J, nullptr, 0, BIAS ? 1.f : a.scale);
     __syncthreads();
@@ -1753,7 +1938,10 @@ __global__ __launch_bounds__(512, ROWS >= 4 ? 1 : 2) void s3_fwd_tile_kernel(S3A
     {
         const int g = r.wave;
         f32x4 O[ROWS][4];
-        if (!(a.dbg & 4)) tile_band_apply<ROWS, F16>(a, r, a.v, a.ld, g, SP, vt_base + r.wave * 4096, O);
+        if (!(a.dbg & 4)) {
+            if (r.nk <= 64) tile_band_apply_fast<ROWS, F16>(a, r, a.v, a.ld, g, SP, vt_base + r.wave * 4096, O);
+            else tile_band_apply<ROWS, F16>(a, r, a.v, a.ld, g, SP, vt_base + r.wave * 4096, O);
+        }
         else {
 #pragma unroll
             for (int i = 0; i < ROWS; ++i)
