@@ -2023,6 +2023,141 @@ __global__ __launch_bounds__(256) void gemm_tn_wm_kernel(GemmArgs p, float* __re
     }
 }
 
+// The same kernel with its per-K-step instruction count cut (round 6).  The counters of the form above (profiles/r06z_bench_b128_pmc_all.txt) show
+// a kernel that is bound by instruction ISSUE, not by memory: 14 non-matrix vector instructions per MFMA (~235 per wave and K-step: 64-bit source
+// addresses per DMA piece, per-lane live / tail selects, fragment addresses recomputed per read), waves active 58 % and waiting 13 % of their cycles.
+// Here a DMA piece is ONE instruction: scalar base (advanced by a scalar add per K-step) + a per-lane 32-bit offset computed once; lanes of dead
+// columns are clamped onto the last live 16-byte piece of their row (same cache line as a live lane: no extra traffic, no exec games, and the
+// counted vmcnt stays exact); fragment addresses are six per-lane registers + immediates.  Host contract: whole K-steps only (rows of the split a
+// multiple of 32) and plane offsets below 4 GiB -- everything else takes gemm_tn_wm_kernel.  Same loads into the same LDS places, same fragment
+// reads, same MFMA order: bit-identical results.
+template <int MT, int MI, bool F16>     // MI: row fragments per wave, ceil(ceil(M / 16) / 4) -- 2 MT - 1 or 2 MT; NO branch around an MFMA (see below)
+__global__ __launch_bounds__(256) void gemm_tn_wmf_kernel(GemmArgs p, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NS = 4;
+    constexpr int STG = (MT + 1) * TN_TILE_BYTES;
+    constexpr int PER_STAGE = 2 * (MT + 1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N1 = p.M, N2 = p.N;
+    const long long bz = blockIdx.x;
+    const int z = blockIdx.y;
+    const long long mbeg = (long long)z * p.ksplit_len;
+    const long long mend = min((long long)p.K, mbeg + p.ksplit_len);
+    const int nk = (int)((mend - mbeg) / TK);
+    const unsigned rowA = p.a_chunk ? 64u : (unsigned)p.lda * 2u, rowB = (unsigned)p.ldb * 2u;           // bytes per token row
+    const char* baseA = reinterpret_cast<const char*>(p.A + boff(p, bz, p.sA, p.sA_in)) + mbeg * rowA;
+    const char* baseB = reinterpret_cast<const char*>(p.B + boff(p, bz, p.sB, p.sB_in)) + mbeg * rowB;
+    const unsigned lds0 = (unsigned)(size_t)(lds_vptr_t)smem;
+
+    unsigned offa[2][MT], offb[2];
+    {
+        const int cmaxA = (N1 - 1) & ~7, cmaxB = (N2 - 1) & ~7;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (j * 4 + wave) * 4 + (lane >> 4);
+            const int ps = lane & 15;
+            const int col = ((((ps >> 1) ^ tn_f(row)) << 1) | (ps & 1)) * 8;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int c = min(t * 128 + col, cmaxA);
+                offa[j][t] = p.a_chunk ? (unsigned)(c >> 5) * (unsigned)p.K * 64u + (unsigned)row * 64u + (unsigned)(c & 31) * 2u
+                                       : (unsigned)row * rowA + (unsigned)c * 2u;
+            }
+            offb[j] = (unsigned)row * rowB + (unsigned)min(col, cmaxB) * 2u;
+        }
+    }
+    auto piece = [&](unsigned voff, const char* sb, unsigned lds_addr) {
+        const unsigned long long sbu = (unsigned long long)sb;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sbu), hi = __builtin_amdgcn_readfirstlane((unsigned)(sbu >> 32));
+        const unsigned long long sbase = ((unsigned long long)hi << 32) | lo;
+        const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
+    };
+    auto issue = [&](int buf, int kt) {
+        const char* sa = baseA + (size_t)kt * (TK * rowA);
+        const char* sb = baseB + (size_t)kt * (TK * rowB);
+        const unsigned l = lds0 + buf * STG + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) piece(offa[j][t], sa, l + t * TN_TILE_BYTES + j * 4096);
+            piece(offb[j], sb, l + MT * TN_TILE_BYTES + j * 4096);
+        }
+    };
+
+    // fragment addresses (tn_frag): row 8 g + (t >> 2) (+ 4 for the second read: + 1024 bytes, same swizzle), 16-column group x -> (x ^ f) << 5
+    unsigned fa[2], fb[4];
+    {
+        const int t = lane & 15, g = lane >> 4;
+        const int row = 8 * g + (t >> 2), f = tn_f(row);
+        const unsigned rb = lds0 + (unsigned)row * 256u + (unsigned)((t & 3) << 3);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) fa[h] = rb + (unsigned)(((h * 4 + wave) ^ f) << 5);     // this wave's row fragments: f = 4 i + wave -> group (i & 1) * 4 + wave of tile i >> 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = rb + (unsigned)((j ^ f) << 5) + MT * TN_TILE_BYTES;
+    }
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    auto frag = [&](unsigned addr) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(size_t)addr);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(size_t)(addr + 1024u));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    // Every wave multiplies all MI of its fragments, also the (at most three) waves whose last one lies past M (their products are not stored): a
+    // wave-uniform branch around four MFMAs makes the compiler carry the accumulators through the loop in AGPRs and copy all of them to VGPRs and
+    // back in EVERY iteration (192 v_accvgpr moves per 24 MFMAs in gemm_tn_wm_kernel: the issue bound named above).
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nk) issue(st, st);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + NS - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (NS - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue((kt + NS - 1) & (NS - 1), kt + NS - 1);
+        const unsigned so = (unsigned)((kt & (NS - 1)) * STG);
+        bf16x8 bfr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = frag(fb[j] + so);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const bf16x8 af = frag(fa[i & 1] + so + (i >> 1) * TN_TILE_BYTES);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<F16>(bfr[j], af, acc[i][j]);
+        }
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+    const bool direct = p.nsplit == 0;                                       // (see gemm_tn_wm_kernel)
+    float* P = direct ? reinterpret_cast<float*>(p.C) + boff(p, bz, p.sC, p.sC_in) : partial + ((size_t)bz * gridDim.y + z) * (size_t)N1 * N2;
+    const int ldp = direct ? p.ldc : N2;
+    const float al = direct ? p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.f) : 1.f;
+    const bool v4 = (N2 & 3) == 0 && (ldp & 3) == 0 && (reinterpret_cast<size_t>(P) & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int n1 = (i * 4 + wave) * 16 + fr;
+        if (n1 >= N1) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n2 = j * 16 + fg * 4;
+            if (direct) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = al * acc[i][j][r];
+            }
+            if (v4 && n2 + 3 < N2) *reinterpret_cast<float4*>(P + (size_t)n1 * ldp + n2) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n2 + r < N2) P[(size_t)n1 * ldp + n2 + r] = acc[i][j][r];
+        }
+    }
+}
+
 // TN, 256x256 output tile, 8 waves (2 x 4, 128 x 64 each), 32 token rows per K-step, NS-stage DMA ring with
 // counted vmcnt + raw barrier (see gemm_nt_256_kernel).  Operand tiles are [32 rows][256 columns] (512-byte
 // rows, 32-byte XOR swizzle on the source column), fragments come from ds_read_b64_tr_b16.
@@ -3125,8 +3260,23 @@ extern "C" int amdnuwa_gemm_tn(const amdnuwa_gemm_desc* d, void* workspace, size
         (void)hipFuncSetAttribute((const void*)gemm_tn_wm_kernel<MT_, 4, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
         hipLaunchKernelGGL((gemm_tn_wm_kernel<MT_, 4, F_>), gw, block, l, stream, p, part);                               \
     } while (0)
+#define TNWMF(MT_, MI_, F_)                                                                                              \
+    do {                                                                                                                 \
+        const size_t l = (size_t)4 * (MT_ + 1) * TN_TILE_BYTES;                                                          \
+        (void)hipFuncSetAttribute((const void*)gemm_tn_wmf_kernel<MT_, MI_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
+        hipLaunchKernelGGL((gemm_tn_wmf_kernel<MT_, MI_, F_>), gw, block, l, stream, p, part);                            \
+    } while (0)
+        // the lean form: whole K-steps in every split, 32-bit piece offsets (tuning key 25 = 3 keeps the general kernel)
+        const bool lean = g_amdnuwa_tuning[25] != 3 && d->K % TK == 0 && (long long)((d->M + 31) / 32) * d->K * 64 < (1LL << 32) &&
+                          32LL * d->lda * 2 < (1LL << 31) && 32LL * d->ldb * 2 < (1LL << 31);
+        const int mi = ((d->M + 15) / 16 + 3) / 4;                                // row fragments per wave
+        if (lean) {
+            if (mt == 3) { if (mi == 5) { if (d->ab_f16) TNWMF(3, 5, true); else TNWMF(3, 5, false); } else { if (d->ab_f16) TNWMF(3, 6, true); else TNWMF(3, 6, false); } }
+            else         { if (mi == 3) { if (d->ab_f16) TNWMF(2, 3, true); else TNWMF(2, 3, false); } else { if (d->ab_f16) TNWMF(2, 4, true); else TNWMF(2, 4, false); } }
+        } else
         if (mt == 3) { if (d->ab_f16) TNWM(3, true); else TNWM(3, false); }
         else         { if (d->ab_f16) TNWM(2, true); else TNWM(2, false); }
+#undef TNWMF
 #undef TNWM
     } else
     if (tnv == 2) {
