@@ -15,6 +15,7 @@ perceptual / adversarial branch and says so once.
 """
 import copy
 import math
+import os
 import warnings
 
 import torch
@@ -426,7 +427,14 @@ class VQGanVAE(nn.Module):
             raise RuntimeError('VQGanVAE.get_video_indices runs through libamdnuwa and needs the video on an MI355X device')
         b, f, _, h, w = video.shape
         images = video.reshape(b * f, *video.shape[2:])
-        indices = self._hip_encode_indices(images)
+        # every stage works per image (conv, GroupNorm, attention, VQ lookup): chunks of the frame list give the same ids bit for bit and keep the
+        # tokenizer's fp32 feature maps (5 GiB per 1280 frames after the first conv) out of a step that already fills the card (tools/full_step.py,
+        # b = 128: 235 GiB).  AMDNUWA_TOKENIZER_CHUNK = frames per call (0 = all at once)
+        chunk = int(os.environ.get('AMDNUWA_TOKENIZER_CHUNK', '320'))
+        if chunk <= 0 or images.shape[0] <= chunk:
+            indices = self._hip_encode_indices(images)
+        else:
+            indices = torch.cat([self._hip_encode_indices(images[i:i + chunk]) for i in range(0, images.shape[0], chunk)], dim=0)
         return indices.reshape(b, f, *indices.shape[1:])
 
     def forward(self, img, return_loss=False, return_discr_loss=False, return_recons=False, apply_grad_penalty=False):

@@ -171,6 +171,20 @@ def test_cfg3_vae_tokenizer_matches_oracle():
     assert torch.equal(idx[sure], idx_ref[sure])
 
 
+def test_tokenizer_in_frame_chunks_gives_the_same_ids(monkeypatch):
+    """VQGanVAE.get_video_indices walks the frame list in chunks (AMDNUWA_TOKENIZER_CHUNK frames per call, default 320): every stage works per
+    image, so the ids must be the ids of one call over all frames, bit for bit -- also with a ragged last chunk"""
+    import nuwa_pytorch_amd as A
+    torch.manual_seed(3)
+    vae = A.VQGanVAE(dim=32, image_size=64, num_layers=2, vq_codebook_size=512, use_vgg_and_gan=False).eval().to(DEV)
+    video = torch.rand(3, 5, 3, 64, 64, device=DEV)
+    monkeypatch.setenv('AMDNUWA_TOKENIZER_CHUNK', '0')
+    whole = vae.get_video_indices(video)
+    for chunk in ('4', '15', '7'):
+        monkeypatch.setenv('AMDNUWA_TOKENIZER_CHUNK', chunk)
+        assert torch.equal(vae.get_video_indices(video), whole), chunk
+
+
 def test_g7_vae_decoder_on_hip(K):
     """VQGanVAE.decode (vq.py:437-441) through libamdnuwa: GLUResBlock, VQGanAttention, x2 bilinear upsample + conv stages,
     final 1x1 conv, against the reference's reconstruction in fixture g7 (decode of the quantised feature map)"""

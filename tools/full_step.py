@@ -21,7 +21,8 @@ import nuwa_pytorch_amd as A  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=16)
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--optimizer', action='store_true', help='add the fused clip(0.5) + AdamW step of the trainer (row f2)')
     args = ap.parse_args()
     dev = 'cuda'
@@ -53,16 +54,22 @@ def main():
         if opt is not None:
             opt.step(max_grad_norm=0.5)
         return loss
-    step()
+    for _ in range(args.warmup):       # (the caching allocator still maps new segments in the second step of a run at 235 GiB: one warm-up step left 663 ... 830 ms in the timed ones)
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    times = []
     for _ in range(args.steps):
+        t1 = time.perf_counter()
         loss = step()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t1) * 1e3)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     ce_form = 'fused' if ops.FUSE_LINEAR_CE_X3 is True else ('auto' if ops.FUSE_LINEAR_CE_X3 else 'unfused')
     print(f'[{A.get_precision()}] full NUWA step (text encoder + VAE tokenizer + decoder fwd/bwd{" + clip + AdamW" if opt else ""}), cfg 3, b={b}, {ce_form} logits + CE: {dt * 1e3:.1f} ms/step, '
-          f'{2560 * b / dt:.0f} video-tokens/s, loss {float(loss.detach()):.4f}, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB')
+          f'{2560 * b / dt:.0f} video-tokens/s, loss {float(loss.detach()):.4f}, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB, reserved '
+          f'{torch.cuda.max_memory_reserved() / 2 ** 30:.1f} GiB, allocator retries {torch.cuda.memory_stats().get("num_alloc_retries", 0)}, per step ' + ' / '.join(f'{t:.0f}' for t in times) + ' ms')
 
 
 if __name__ == '__main__':
