@@ -339,8 +339,10 @@ class FeedForward(nn.Module):
 # ---------------------------------------------------------------------------------------------------
 
 class Attention(nn.Module):
-    """np.py:290-379.  With `context` (the decoder's text cross-attention) the core runs on the MFMA
-    cross-attention kernels; the self-attention use (text encoder, row f1) is PyTorch-ROCm ops for now."""
+    """np.py:290-379.  With `context` (the decoder's text cross-attention) and as non-causal self-attention (the text encoder, row f1:
+    keys / values = the query rows, rotary on q, k and v) the core runs on the MFMA cross-attention kernels (xattn6; xattn2 / xattn for
+    the shapes it does not take).  Outside `_hip_ok` -- causal=True, more than 287 keys, more than 8 heads, dim_head not 32 / 64,
+    attention dropout > 0 in training -- the forward below runs on PyTorch-ROCm ops."""
 
     def __init__(self, *, dim, heads=8, dim_head=64, causal=False, dropout=0.):
         super().__init__()
