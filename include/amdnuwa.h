@@ -63,7 +63,8 @@ const char* amdnuwa_error_string(int code);
  *          1 = never (8-wave ring), 2 = for every K % 64 == 0        key 23 TN four-wave kernel (gemm_tn_w4k_kernel): 1 = keep the 8-wave ring
  *   key 24 Sparse3DNA MFMA backward workspace: 0 = ONE array of (bf16 ds | bf16 P') words (round 5), 1 = the two fp32 arrays (same dK / dV bits)
  *   key 25 batched narrow TN (N <= 64, 128 < M <= 384: the cross attention's dK / dV): 1 = 128-row tiles instead of one workgroup per batch element,
- *          2 = always through the split-K reduction (no direct store of a one-split result)
+ *          2 = always through the split-K reduction (no direct store of a one-split result), 3 = the general whole-M kernel also where the lean
+ *          form applies (whole 32-row K-steps per split, plane offsets below 4 GiB: gemm_tn_wmf_kernel, bit-identical results)
  * (keys run 0..31; the K-step 64 form of the 256x256 ring stages full 128-byte DMA lines in two 64 KiB stages, `auto` uses it for
  *  1024 <= K < 2048; any non-zero key 0 disables the few-row weight-streaming path that M <= 32 normally takes) */
 int amdnuwa_set_tuning(int key, int value);
