@@ -825,7 +825,8 @@ def test_cross_attention_bwd_recomputing_key_side(K, O, B, n, T):
     assert torch.equal(dKp, dKp2) and torch.equal(dVp, dVp2)
 
 
-@pytest.mark.parametrize('Bq,heads,n,T,dh', [(2, 8, 2560, 256, 64), (3, 4, 100, 200, 32), (1, 2, 71, 300, 64), (5, 8, 640, 129, 64)])
+@pytest.mark.parametrize('Bq,heads,n,T,dh', [(2, 8, 2560, 256, 64), (3, 4, 100, 200, 32), (1, 2, 71, 300, 64), (5, 8, 640, 129, 64),
+                                             (2, 8, 320, 360, 64), (2, 4, 96, 230, 32)])       # (the last two: six / four row fragments per wave of the lean form)
 def test_batched_tn_whole_m_kernel_equals_the_tiled_one(K, Bq, heads, n, T, dh):
     """gemm_tn_wm_kernel (one workgroup per (sample, head) owns all JP rows of dK / dV) sums every element in the order of the 128-row
     tiles of gemm_tn_glds_kernel (tuning key 25 = 1): bit-identical, ragged token counts and column counts included"""
@@ -846,6 +847,14 @@ def test_batched_tn_whole_m_kernel_equals_the_tiled_one(K, Bq, heads, n, T, dh):
     finally:
         L.amdnuwa_set_tuning(25, 0)
     for a, b in zip(got, ref):
+        assert torch.equal(a[:, :, :mx], b[:, :, :mx])
+    # round 6: whole 32-row K-steps take the lean form (gemm_tn_wmf_kernel); tuning key 25 = 3 keeps the general whole-M kernel
+    L.amdnuwa_set_tuning(25, 3)
+    try:
+        gen = K.xattn_kv_grads(g, dS, Pm, qp, dop)
+    finally:
+        L.amdnuwa_set_tuning(25, 0)
+    for a, b in zip(got, gen):
         assert torch.equal(a[:, :, :mx], b[:, :, :mx])
     # the same operands in planes of 32 columns (a_chunk32: how xattn2_bwd writes them for this kernel)
     assert K.xattn_chunk_major_ok(g)
