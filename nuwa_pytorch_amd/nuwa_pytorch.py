@@ -328,9 +328,14 @@ class FeedForward(nn.Module):
     def forward(self, x):
         B, n, D = x.shape
         if self._dropout_active() and x.is_cuda:
-            # ff_dropout > 0 in training (np.py:276): the GEGLU output passes through nn.Dropout -- torch ops, torch's RNG stream;
-            # every BASELINE config trains with dropout 0 and stays on the fused libamdnuwa node
-            return self.net(x)
+            # ff_dropout > 0 in training (np.py:276): the GEGLU output passes through nn.Dropout.  Both products, the gate and its backward stay on
+            # libamdnuwa (standalone node, bf16 backward; the mask comes from torch's RNG stream and is kept for the backward); the block is not
+            # part of the fused / chained stack (SandwichNorm._inner).  Inside a reversible stack the forward runs twice per step and there is no
+            # RNG replay here (Deterministic): those modules keep the torch-op forward.  Every BASELINE config trains with dropout 0.
+            if getattr(self, '_no_hip_dropout', False):
+                return self.net(x)
+            meta = dict(kind='ff', cache=self._cache, drop_p=float(self.net[2].p))
+            return ops.InnerFn.apply(x, None, meta, *self._params())
         return ops.InnerFn.apply(x, None, self._meta(B, n, x.device), *self._params())
 
 
@@ -889,6 +894,9 @@ class ReversibleTransformer(nn.Module):
         attn_route_map = {'mask': route_attn, 'rotary_pos_emb': route_attn}
         self.net = ReversibleSequence(self.layers, args_route={**context_route_map, **attn_route_map})
         self.norm = StableLayerNorm(dim)
+        for m in self.modules():                 # a reversible block's forward runs twice per step without RNG replay: no kept dropout mask here
+            if isinstance(m, FeedForward):
+                m._no_hip_dropout = True
 
     def forward_layers(self, x, **kwargs):
         return self.net(x, **kwargs)

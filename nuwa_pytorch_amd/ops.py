@@ -423,6 +423,16 @@ class XInner:
         return dh, dctx, [dnk.reshape(nk.shape), dnv.reshape(nv.shape), dwth.reshape(wth.shape), dwq, dwkv, dwo]
 
 
+def _ff_keep_mask(R, C, p, device):
+    """keep mask of nn.Dropout(p) over the GEGLU output [R, C] (torch's RNG stream; tests replace this function by a fixed mask)"""
+    return torch.rand((R, C), device=device) >= p
+
+
+def _ff_drop(t_f32, keep, p):
+    """nn.Dropout in training: kept entries times 1 / (1 - p) (one fp32 multiply, as torch does), the others exactly 0"""
+    return torch.where(keep, t_f32 * (1.0 / (1.0 - p)), torch.zeros((), dtype=t_f32.dtype, device=t_f32.device))
+
+
 class FFInner:
     """Linear -> GEGLU -> Linear (np.py:255-286).  params: net.0.w (2*FFI, D), net.3.w (D, FFI).
     The inner width is zero-padded to FP = roundup(FFI, 32) inside the bf16 copies."""
@@ -480,6 +490,8 @@ class FFInner:
     def fwd(h, p, meta):
         W = FFInner.weights(meta['cache'], p)
         R, D, _ = K.bf_rows_cols(h)
+        drop_p = float(meta.get('drop_p') or 0.0)
+        assert not (drop_p and meta.get('bwd16')), 'FeedForward dropout runs on the bf16 backward (the fp16 GEGLU-backward epilogue has no mask input)'
         if meta.get('shift') is None and 'w1_16' in W and FFInner.f16_ok(R, D, W['FP']):
             # 'bf16x3-fwd': both FeedForward products on single fp16 MFMAs (h arrives with an fp16 copy from the LayerNorm store);
             # u and the gate output also leave as bf16 copies for the bf16 backward
@@ -491,17 +503,28 @@ class FFInner:
                 return y, (K.BF(None, None, h16), K.BF(u, None), K.BF(None, None, gg16))
             assert h.hi is not None, 'a bf16 backward needs the bf16 copy of the LayerNorm output'
             u, gg16, ggb = K.gemm_nt_f16ops(h16, W['w1_16'], out_bf16=True, gate=True)
+            if drop_p:          # ff_dropout > 0 in training (np.py:276): nn.Dropout on the GEGLU output, between the two products
+                keep = _ff_keep_mask(R, W['FP'], drop_p, gg16.device)
+                gf = _ff_drop(gg16.float(), keep, drop_p)
+                gg16, ggb = gf.to(torch.float16), gf.to(torch.bfloat16)
+                return K.gemm_nt_f16ops(gg16, W['w2_16']), (K.BF(h.hi, None), K.BF(u, None), K.BF(ggb, None), keep)
             y = K.gemm_nt_f16ops(gg16, W['w2_16'])
             return y, (K.BF(h.hi, None), K.BF(u, None), K.BF(ggb, None))
         h = _f16_to_pair(h)
         gg = K.empty_bf((h.hi.shape[0], W['FP']), h.hi.device)
         u = K.gemm_nt(h, W['w1'], out_bf16=True, shift=meta.get('shift'), geglu_out=gg)   # u (interleaved layout) and a * gelu(gate)
+        if drop_p:
+            keep = _ff_keep_mask(R, W['FP'], drop_p, h.hi.device)
+            ggd = K.empty_bf((h.hi.shape[0], W['FP']), h.hi.device)
+            K.cast_pad(_ff_drop(_bf_val(gg), keep, drop_p).contiguous(), ggd)
+            return K.gemm_nt(ggd, W['w2'], out_bf16=_fast()), (*_sv(h, u, ggd), keep)
         y = K.gemm_nt(gg, W['w2'], out_bf16=_fast())
         return y, _sv(h, u, gg)
 
     @staticmethod
     def bwd(saved, dy, p, meta, need_dbias=False, dy_f32=None):
-        h, u, gg = saved
+        h, u, gg = saved[:3]
+        keep = saved[3] if len(saved) > 3 else None          # FeedForward dropout: the keep mask of the forward (gg is the DROPPED gate output)
         W = FFInner.weights(meta['cache'], p)
         w1, w2 = p
         FP, FFI = W['FP'], W['FFI']
@@ -516,7 +539,13 @@ class FFInner:
             K.gemm_tn16(du, h.f16, dw1p, s2)
             d = K.geglu_deinterleave(dw1p, FP, dim=0)
             return dh, None, [torch.cat((d[:FFI], d[FP:FP + FFI]), 0), dw2]
-        if FUSE_GEGLU_BWD:
+        if keep is not None:
+            assert not isinstance(dy, K.G16)
+            dgg = K.gemm_nt(dy, W['w2T'], out_bf16=True)
+            dgd = K.empty_bf(tuple(dgg.hi.shape), dgg.hi.device)
+            K.cast_pad(_ff_drop(_bf_val(dgg), keep, float(meta['drop_p'])).contiguous(), dgd)
+            du = K.geglu_bwd(u, dgd, FP, interleaved=True)
+        elif FUSE_GEGLU_BWD:
             du = K.gemm_nt_geglu_bwd(dy, W['w2T'], u, FP)      # dgg = dy W2 and the gate's backward in one pass
         else:
             du = K.geglu_bwd(u, K.gemm_nt(dy, W['w2T'], out_bf16=True), FP, interleaved=True)
@@ -707,7 +736,7 @@ def _block_bwd16(kind, R, D, p, meta):
     if not K.bwd_f16() or meta.get('shift_unfused'):
         return False
     if kind == 'ff':
-        return FFInner.bwd16_ok(R, D, _ru(p[1].shape[1], 32), p[1].shape[1], (p[0], p[1]))
+        return not meta.get('drop_p') and FFInner.bwd16_ok(R, D, _ru(p[1].shape[1], 32), p[1].shape[1], (p[0], p[1]))
     if kind == 's3':
         return S3Inner.bwd16_ok(R, D, p[0].shape[0], meta['geom'], (p[0], p[1]), p[3], len(p) > 5)
     if kind == 'xattn':

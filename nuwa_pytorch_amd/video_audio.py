@@ -479,6 +479,9 @@ class ReversibleDualModalityDecoder(nn.Module):
         self.net = DualModalityReversibleSequence(self.layers, self.layer_types)
         self.video_norm = StableLayerNorm(dim)
         self.audio_norm = StableLayerNorm(dim)
+        for m in self.modules():                 # (see ReversibleTransformer: no kept dropout mask where the forward is recomputed)
+            if isinstance(m, FeedForward):
+                m._no_hip_dropout = True
 
     def forward_layers(self, video, audio, *, context, audio_mask=None, video_mask=None, context_mask=None, **kwargs):
         return self.net(video, audio, context=context, audio_mask=audio_mask, video_mask=video_mask, context_mask=context_mask)

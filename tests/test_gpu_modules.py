@@ -105,6 +105,50 @@ def test_g3_feedforward_module(A, dim, mode, tol, gtol):
         A.set_precision('bf16')
 
 
+@pytest.mark.parametrize('mode,tol,gtol', MODES)
+@pytest.mark.parametrize('dim', [64, 512])       # (512: the fp16-operand forward of 'bf16x3-fwd' takes the product; 64: the generic ring)
+def test_feedforward_dropout_runs_on_the_library(A, monkeypatch, dim, mode, tol, gtol):
+    """FeedForward with ff_dropout > 0 in training (np.py:260-286: Linear -> GEGLU -> nn.Dropout -> Linear): both products, the gate and its backward
+    on libamdnuwa, the keep mask kept for the backward.  Checked against the same arithmetic in torch fp32 with the SAME mask (the mask itself comes
+    from torch's RNG stream in production; here ops._ff_keep_mask is replaced by a fixed one), forward and every gradient; in eval mode the module
+    must give the dropout-free result."""
+    from nuwa_pytorch_amd import ops
+    import torch.nn.functional as F
+    torch.manual_seed(11)
+    p = 0.25
+    m = A.FeedForward(dim=dim, dropout=p).to(DEV).train()
+    w1, w2 = m.net[0].weight, m.net[3].weight
+    FFI = w2.shape[1]
+    x = torch.randn(2, 48, dim, device=DEV, requires_grad=True)
+    dy = torch.randn(2, 48, dim, device=DEV)
+    keep_all = torch.rand(96, (FFI + 31) // 32 * 32, device=DEV) >= p
+    monkeypatch.setattr(ops, '_ff_keep_mask', lambda R, C, pp, device: keep_all[:R, :C].clone())
+    run_mode(A, mode)
+    try:
+        y = m(x)
+        y.backward(dy)
+        got = (y.detach().clone(), x.grad.clone(), w1.grad.clone(), w2.grad.clone())
+        for t in (x, w1, w2):
+            t.grad = None
+        u = x.reshape(96, dim) @ w1.t()
+        a, g = u.chunk(2, dim=-1)
+        gg = a * F.gelu(g)
+        gg = torch.where(keep_all[:, :FFI], gg * (1.0 / (1.0 - p)), torch.zeros((), device=DEV))
+        yr = (gg @ w2.t()).reshape(2, 48, dim)
+        yr.backward(dy)
+        report(f'ff_dropout[{dim},{mode}].y', got[0], yr.detach(), tol)
+        report(f'ff_dropout[{dim},{mode}].dx', got[1], x.grad, gtol)
+        report(f'ff_dropout[{dim},{mode}].dw1', got[2], w1.grad, gtol)
+        report(f'ff_dropout[{dim},{mode}].dw2', got[3], w2.grad, gtol)
+        assert float((got[0] - m.eval()(x).detach()).abs().max()) > 1e-3          # (the mask did something)
+        m.eval()
+        ye = m(x).detach()
+        yn = (torch.nn.functional.linear(a * F.gelu(g), w2)).reshape(2, 48, dim).detach()
+        report(f'ff_dropout[{dim},{mode}].eval', ye, yn, tol)
+    finally:
+        A.set_precision('bf16')
+
+
 def test_g4_sandwich_shift_and_stable_ln(A):
     R = load_raw('g4_norms_shift')
     sn = A.SandwichNorm(dim=32, fn=A.ShiftVideoTokens(torch.nn.Identity(), image_size=int(R['fmap'])))
