@@ -55,7 +55,9 @@ EXTRA_FLAGS = {'xattn2.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'], 'xattn6.hip':
 # (round 4's cure) / written freely (fails the stress: the experiment that separated the two cures); 'pin': the shipped flags + the pin.
 # The host pass ignores the feature flag.
 NOPK_FLAGS = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
-VARIANTS = {'': [], 'pk': ['-DS3_MIX_PIN=1'], 'pk_nofix': ['-DS3_MIX_PIN=0'], 'pin': ['-DS3_MIX_PIN=1'], 'x6t': ['-DX6_TIMING=1']}
+VARIANTS = {'': [], 'pk': ['-DS3_MIX_PIN=1'], 'pk_nofix': ['-DS3_MIX_PIN=0'], 'pin': ['-DS3_MIX_PIN=1'], 'x6t': ['-DX6_TIMING=1'],
+            # round 6, call zm: the backend's other scheduling strategies over the whole library (the hand-placed loops are pinned with sched_barrier and do not move)
+            'ilp': ['-mllvm', '-amdgpu-sched-strategy=max-ilp'], 'mclause': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause']}
 
 
 def lib_path(variant=''):
