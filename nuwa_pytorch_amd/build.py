@@ -14,7 +14,12 @@ LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libamdnuwa.so')
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'amdnuwa.h')
 SOURCES = ['api.hip', 'gemm.hip', 'elementwise.hip', 'sparse3dna.hip', 'xattn.hip', 'xattn2.hip', 'xattn6.hip', 'vae.hip', 'optim.hip', 'decode.hip', 'comm.hip']
-ARCH = 'gfx950'
+# One generic `gfx950` code object (loads whatever the device's XNACK mode).  Measured at the end of round 6 (profiles/r06zn_xnack_ab.txt): a code object built for
+# XNACK-off devices only (AMDNUWA_BUILD_ARCH=gfx950:xnack-) runs the step 0.5 % faster in an A/B/A/B of one call (457.0 -> 454.4 ms: the generic object must stay
+# safe under XNACK replay, e.g. a load's destination may not overlap its address registers) -- an opt-in for deployments that never enable demand paging; it
+# does not load on a device running with HSA_XNACK=1, and a library that also carried the xnack+ object is refused by this pool's job runner.
+# AMDNUWA_BUILD_ARCH: comma-separated --offload-arch list (A/B runs and that opt-in).
+ARCHS = os.environ.get('AMDNUWA_BUILD_ARCH', 'gfx950').split(',')
 # Flags of every device compile of the SHIPPED library: no packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).
 # Round 4 found the head-mix loop of the two-row Sparse3DNA forward tile returning wrong LOW halves out of a packed-FMA sequence once two
 # workgroups shared a CU.  Round 5 separated the two cures on the GPU (profiles/r05a_mix_variants.txt): packed ops ON + loops written freely
@@ -57,7 +62,8 @@ EXTRA_FLAGS = {'xattn2.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'], 'xattn6.hip':
 NOPK_FLAGS = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 VARIANTS = {'': [], 'pk': ['-DS3_MIX_PIN=1'], 'pk_nofix': ['-DS3_MIX_PIN=0'], 'pin': ['-DS3_MIX_PIN=1'], 'x6t': ['-DX6_TIMING=1'],
             # round 6, call zm: the backend's other scheduling strategies over the whole library (the hand-placed loops are pinned with sched_barrier and do not move)
-            'ilp': ['-mllvm', '-amdgpu-sched-strategy=max-ilp'], 'mclause': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause']}
+            'ilp': ['-mllvm', '-amdgpu-sched-strategy=max-ilp'], 'mclause': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause'],
+            'xoff': []}        # (with AMDNUWA_BUILD_ARCH=gfx950:xnack- : a code object for XNACK-off devices only, see ARCHS)
 
 
 def lib_path(variant=''):
@@ -77,7 +83,7 @@ def build(force=False, verbose=True, variant=''):
         obj = os.path.join(LIBDIR, s.replace('.hip', '.o'))
         objs.append(obj)
         if force or _stale(obj, [src] + common + [os.path.abspath(__file__)]):
-            jobs.append([_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC'] + EXTRA_FLAGS.get(s, []) + DEFAULT_FLAGS_FOR(variant) + vflags + ['-c', src, '-o', obj])
+            jobs.append([_hipcc()] + [f'--offload-arch={a}' for a in ARCHS] + ['-O3', '-std=c++17', '-fPIC'] + EXTRA_FLAGS.get(s, []) + DEFAULT_FLAGS_FOR(variant) + vflags + ['-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:
@@ -90,7 +96,7 @@ def build(force=False, verbose=True, variant=''):
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl'])
+        run([_hipcc()] + [f'--offload-arch={a}' for a in ARCHS] + ['-shared', '-fPIC', '-o', LIB] + objs + ['-ldl'])
     return LIB
 
 

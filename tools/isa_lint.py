@@ -58,7 +58,8 @@ def code_objects(lib, scratch):
     dst = os.path.join(scratch, os.path.basename(lib))
     shutil.copy(lib, dst)
     subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '--offloading', dst], capture_output=True, cwd=scratch, check=False)
-    return sorted(glob.glob(dst + '.*gfx950'))
+    # (also the code objects of a build with target features in its name, e.g. gfx950:xnack-: AMDNUWA_BUILD_ARCH)
+    return sorted(glob.glob(dst + '.*gfx950*'))
 
 
 def scan(lib):
